@@ -164,7 +164,7 @@ def exp_noise(seed: int, scenario: int, t: int, agent: int, head: int, n: int) -
 
 
 def noise_key(seed: int, scenario: int, t: int, agent: int, head: int) -> int:
-    k = (seed * 0x9E3779B97F4A7C15 + 0x1234567) & _MASK
+    k = (int(seed) * 0x9E3779B97F4A7C15 + 0x1234567) & _MASK
     for v in (scenario, t, agent, head):
-        k = int(splitmix64(np.array([(k ^ (v & _MASK)) & _MASK], dtype=np.uint64))[0])
+        k = int(splitmix64(np.array([(k ^ (int(v) & _MASK)) & _MASK], dtype=np.uint64))[0])
     return k

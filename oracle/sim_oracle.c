@@ -44,8 +44,8 @@ typedef struct {
   float length, width;
   /* Object state (what Python reads) */
   float px, py, heading, speed;
-  /* Box2D body */
-  float cx, cy, a, vx, vy, w, sleep_time;
+  /* Box2D body: sweep.c (centre of mass), sweep.a, velocities; xf.p is (px,py) above; lc = sweep.localCenter */
+  float cx, cy, a, vx, vy, w, sleep_time, lcx, lcy;
   int awake;
   /* FreeCar controls */
   float throttle, brake, steer;
@@ -57,6 +57,43 @@ typedef struct {
   Veh* v;
   float* segs;
 } Sim;
+
+/* b2PolygonShape::SetAsBox(hx,hy) + ComputeMass(density 20) + b2Body::ResetMassData: the body's local centre
+ * of mass.  Mathematically (0,0); in float32 the triangle-fan sum leaves a ~1e-8 residue that shifts the body
+ * origin by an ulp now and then, so it has to be carried.  third_party/box2d/src/collision/b2_polygon_shape.cpp:36-48,
+ * 357-431; src/dynamics/b2_body.cpp ResetMassData; FreeCar.cpp:34-40. */
+static void local_center(float width, float length, float* lcx, float* lcy) {
+  float hx = width / 2, hy = length / 2;
+  float vx[4] = {-hx, hx, hx, -hx}, vy[4] = {-hy, -hy, hy, hy};
+  float cx = 0.0f, cy = 0.0f, area = 0.0f;
+  float sx = vx[0], sy = vy[0];
+  const float k_inv3 = 1.0f / 3.0f;
+  for (int i = 0; i < 4; ++i) {
+    float e1x = vx[i] - sx, e1y = vy[i] - sy;
+    float e2x = (i + 1 < 4 ? vx[i + 1] : vx[0]) - sx, e2y = (i + 1 < 4 ? vy[i + 1] : vy[0]) - sy;
+    float D = e1x * e2y - e1y * e2x;
+    float ta = 0.5f * D;
+    area += ta;
+    float k = ta * k_inv3;
+    cx += k * (e1x + e2x);
+    cy += k * (e1y + e2y);
+  }
+  float mass = 20.f * area;
+  float inv_area = 1.0f / area;
+  cx *= inv_area; cy *= inv_area;
+  float mcx = cx + sx, mcy = cy + sy;           /* massData->center */
+  float lx = mass * mcx, ly = mass * mcy;       /* localCenter += massData.mass * massData.center */
+  float inv_mass = 1.0f / mass;
+  *lcx = lx * inv_mass; *lcy = ly * inv_mass;
+}
+
+/* b2Body::SetTransform(position, angle): sweep.c = b2Mul(xf, localCenter) */
+static void set_transform(Veh* v, float x, float y, float angle) {
+  float qs = sinf(angle), qc = cosf(angle);
+  v->px = x; v->py = y; v->a = angle;
+  v->cx = (qc * v->lcx - qs * v->lcy) + x;
+  v->cy = (qs * v->lcx + qc * v->lcy) + y;
+}
 
 static float dampen(float speed, float target, float damping, float dt) {
   float red = damping * dt;
@@ -120,6 +157,11 @@ static void island_solve(Veh* v, float h) {
     v->sleep_time = 0.0f;
   } else {
     v->sleep_time += h;
+  }
+  {                                             /* b2Body::SynchronizeTransform (b2_island.cpp copy-back) */
+    float qs = sinf(v->a), qc = cosf(v->a);
+    v->px = v->cx - (qc * v->lcx - qs * v->lcy);
+    v->py = v->cy - (qs * v->lcx + qc * v->lcy);
   }
   if (v->sleep_time >= B2_TIMETOSLEEP) {  /* single-body island, positionSolved is true without contacts */
     v->awake = 0; v->sleep_time = 0.0f; v->vx = v->vy = 0.0f; v->w = 0.0f;
@@ -231,8 +273,9 @@ void* orasim_create(int n, const float* length, const float* width, const float*
     Veh* v = &s->v[i];
     v->length = length[i]; v->width = width[i];
     v->px = x[i]; v->py = y[i]; v->heading = heading[i]; v->speed = speed[i];
-    v->a = (float)((double)v->heading - M_PI * 0.5f);   /* vehicle.cc:168 */
-    v->cx = v->px; v->cy = v->py;
+    local_center(v->width, v->length, &v->lcx, &v->lcy);
+    set_transform(v, 0.f, 0.f, (float)((double)v->heading - M_PI * 0.5f));   /* SetAngle, vehicle.cc:168 */
+    set_transform(v, x[i], y[i], v->a);                                      /* SetPosition, vehicle.cc:169 */
     float c = cosf(v->heading), sn = sinf(v->heading);
     v->vx = v->speed * c; v->vy = v->speed * sn;        /* BaseCar::SetSpeed: plain assignment + wake */
     v->w = 0.f; v->sleep_time = 0.f; v->awake = 1;
@@ -257,7 +300,7 @@ void orasim_set_action(void* h, int i, double accel, double steer) {
 
 void orasim_set_position(void* h, int i, float x, float y) {
   Veh* v = &((Sim*)h)->v[i];
-  v->px = x; v->py = y; v->cx = x; v->cy = y;   /* b2Body::SetTransform keeps the angle, does not wake */
+  set_transform(v, x, y, v->a);                 /* b2Body::SetTransform keeps the angle, does not wake */
 }
 
 void orasim_step(void* h, float dt) {
@@ -266,8 +309,7 @@ void orasim_step(void* h, float dt) {
   for (int i = 0; i < s->n; ++i) island_solve(&s->v[i], dt);
   for (int i = 0; i < s->n; ++i) {
     Veh* v = &s->v[i];
-    v->coll_veh = v->coll_edge = 0;
-    v->px = v->cx; v->py = v->cy;
+    v->coll_veh = v->coll_edge = 0;             /* position_ <- m_xf.p (already in px,py) */
     v->speed = sqrtf(v->vx * v->vx + v->vy * v->vy);
     v->heading = (float)((double)v->a + M_PI * 0.5f);
   }
@@ -289,7 +331,7 @@ void orasim_get_body(void* h, float* out) {
   Sim* s = (Sim*)h;
   for (int i = 0; i < s->n; ++i) {
     const Veh* v = &s->v[i];
-    out[6 * i + 0] = v->cx; out[6 * i + 1] = v->cy; out[6 * i + 2] = v->a;
+    out[6 * i + 0] = v->px; out[6 * i + 1] = v->py; out[6 * i + 2] = v->a;
     out[6 * i + 3] = v->vx; out[6 * i + 4] = v->vy; out[6 * i + 5] = v->w;
   }
 }

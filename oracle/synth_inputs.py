@@ -74,3 +74,31 @@ def to_motion_data(d):
     return {"agent": _Store({k: t[k] for k in ("agent_states", "agent_types", "goals", "actions", "rtgs",
                                                 "timesteps", "moving_agent_mask")}),
             "map": _Store({k: t[k] for k in ("road_points", "road_types")})}
+
+
+def synth_policy_buffers(scn, cfg, seed):
+    """Deterministic pseudo-history for Policy buffers: agents drift along their heading; one agent per 7
+    drives away fast so that it leaves the 60 m disc of its group later on."""
+    rs = np.random.RandomState(seed)
+    N, steps = scn.N, cfg.nocturne.steps
+    w = cfg.dataset.waymo
+    states = np.zeros((N, steps, 8))
+    t = np.arange(steps)[None, :]
+    sp = scn.speed.astype(np.float64)[:, None] * (1 + 3.0 * (np.arange(N) % 7 == 3))[:, None]
+    hd = scn.heading.astype(np.float64)[:, None] + 0.01 * t
+    states[..., 0] = scn.x[:, None] + np.cumsum(sp * np.cos(hd) * 0.1, axis=1)
+    states[..., 1] = scn.y[:, None] + np.cumsum(sp * np.sin(hd) * 0.1, axis=1)
+    states[..., 2] = sp * np.cos(hd)
+    states[..., 3] = sp * np.sin(hd)
+    states[..., 4] = hd
+    states[..., 5] = scn.length[:, None]
+    states[..., 6] = scn.width[:, None]
+    states[..., 7] = 1.0
+    states = states.astype(np.float32).astype(np.float64)
+    actions = np.stack([rs.uniform(-12, 12, (N, steps)), rs.uniform(-0.9, 0.9, (N, steps))], -1)
+    rtgs = np.stack([rs.uniform(-1, 11, (N, steps)), rs.uniform(-20, 100, (N, steps)),
+                     rs.uniform(-20, 100, (N, steps))], -1)
+    goals = np.repeat(scn.goals5()[:, None], steps, 1)
+    timesteps = np.repeat(np.arange(steps)[None, :, None], N, 0).astype(np.float64)
+    return dict(states=states, types=scn.types.copy(), actions=actions, rtgs=rtgs, goals=goals,
+                timesteps=timesteps)

@@ -1,0 +1,20 @@
+import os
+
+import numpy as np
+
+from conftest import GOLDEN
+from ctrlsim_amd import spec
+
+TINY = dict(dataset__waymo__max_num_agents=4, dataset__waymo__train_context_length=4,
+            dataset__waymo__max_num_road_polylines=6, dataset__waymo__max_num_road_pts_per_polyline=8)
+LOOP = dict(dataset__waymo__max_num_agents=6, dataset__waymo__train_context_length=8,
+            dataset__waymo__max_num_road_polylines=12, dataset__waymo__max_num_road_pts_per_polyline=10,
+            nocturne__steps=20)
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def cfg_of(kind):
+    return spec.make_cfg(**{"tiny": TINY, "loop": LOOP, "full": {}}[kind])

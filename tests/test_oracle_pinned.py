@@ -1,0 +1,217 @@
+"""CPU tests: the oracle (oracle/*.py, oracle/sim_oracle.c) is pinned against golden vectors that were
+produced by running the reference itself (oracle/gen_golden.py) — SURVEY.md §8c G1-G10."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden, cfg_of
+from ctrlsim_amd import spec, weights, scenarios
+import features_oracle as fo
+import model_oracle as mo
+import synth_inputs
+import sim_libs
+import rollout_oracle
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _build():
+    sim_libs.build_oracle()
+
+
+def test_weight_generator_matches_reference_parameter_count():
+    d = spec.Dims(cfg_of("full"))
+    assert weights.num_params(d) == 8285762            # SURVEY.md §8a M7 (probe of the reference modules)
+    w = weights.generate(d, 0)
+    w2 = weights.generate(d, 0)
+    assert all(np.array_equal(w[k], w2[k]) for k in w)
+    assert abs(float(w["encoder.embed_action.weight"].std()) - 0.02) < 1e-3
+
+
+def test_mask_closed_form_fraction():
+    g = golden("model_full")
+    cm = mo.causal_mask_closed_form(24, 32, 3)
+    assert abs(float(cm.float().mean()) - float(g["mask_visible_fraction"])) < 1e-12   # 49.5 %
+
+
+@pytest.mark.parametrize("kind", ["tiny", "full"])
+def test_model_oracle_matches_reference(kind):
+    cfg = cfg_of(kind)
+    d = spec.Dims(cfg)
+    tw = mo.as_torch_weights(weights.generate(d, 0))
+    g = golden(f"model_{kind}")
+    for seed in (1, 2):
+        _, t_fill, n_ag, n_pl = [int(v) for v in g[f"s{seed}_recipe"]]
+        inp = synth_inputs.random_context(d, seed, B=1, t_fill=t_fill, n_agents=n_ag, n_polys=n_pl)
+        with torch.no_grad():
+            out = mo.forward(tw, synth_inputs.to_torch(inp), d)
+        if kind == "tiny":
+            for k in ("action_preds", "rtg_preds", "state_preds"):
+                np.testing.assert_allclose(out[k].numpy(), g[f"s{seed}_{k}"], atol=2e-5, rtol=0)
+        else:
+            ti = t_fill - 1
+            np.testing.assert_allclose(out["action_preds"][0, :, ti].numpy(), g[f"s{seed}_action_logits"], atol=2e-5, rtol=0)
+            np.testing.assert_allclose(out["rtg_preds"][0, :, ti].numpy(), g[f"s{seed}_rtg_logits"], atol=2e-5, rtol=0)
+
+
+@pytest.mark.parametrize("tag,kind,n_ag,n_pl,extent", [("small", "loop", 10, 20, 45.0), ("full", "full", 30, 260, 70.0),
+                                                       ("wide", "full", 64, 512, 70.0)])
+def test_feature_oracle_matches_reference(tag, kind, n_ag, n_pl, extent):
+    cfg = cfg_of(kind)
+    d = spec.Dims(cfg)
+    w = cfg.dataset.waymo
+    g = golden("features")
+    scn = scenarios.make_scenario(11, 0, n_agents=n_ag, n_polylines=n_pl, n_points=d.NP, extent=extent)
+    b = synth_inputs.synth_policy_buffers(scn, cfg, seed=5)
+    buf = fo.PolicyBuffers(scn.N, cfg.nocturne.steps)
+    for k in ("states", "types", "actions", "rtgs", "goals", "timesteps"):
+        getattr(buf, k)[:] = b[k]
+    n_checked = 0
+    for t in (0, 3, d.T + 5):
+        groups, dead = fo.build_contexts(buf, w, t, list(scn.eval_order), scn.road_points.astype(np.float64), scn.road_types)
+        assert [gr["focal"] for gr in groups] == list(g[f"{tag}_t{t}_focals"])
+        for gi, gr in enumerate(groups):
+            pre = f"{tag}_t{t}_g{gi}_"
+            assert gr["ids"] == list(g[pre + "ids"])
+            assert gr["members"] == list(g[pre + "members"])
+            if pre + "agent_states" in g:
+                dt = gr["data"]
+                # bit-exact: same float64 op sequence as the reference's NumPy path
+                assert np.array_equal(dt["agent_states"][0], g[pre + "agent_states"])
+                assert np.array_equal(dt["goals"][0], g[pre + "goals"])
+                assert np.array_equal(dt["actions"][0], g[pre + "actions"])
+                assert np.array_equal(dt["rtgs"][0], g[pre + "rtgs"])
+                assert np.array_equal(dt["agent_types"][0], g[pre + "types"])
+                assert np.array_equal(dt["timesteps"][0], g[pre + "timesteps"])
+                assert np.array_equal(dt["road_types"][0], g[pre + "road_types"])
+                rp = dt["road_points"][0]
+                assert np.array_equal(rp if tag == "small" else rp[:, ::25], g[pre + "road_points"])
+                np.testing.assert_allclose(rp.sum(axis=(1, 2)), g[pre + "road_points_sum"], rtol=1e-12)
+                n_checked += 1
+    assert n_checked >= 3
+
+
+def test_discretisation_round_trips_and_placeholders():
+    w = cfg_of("full").dataset.waymo
+    tok = np.arange(1000)
+    assert np.array_equal(fo.discretize_actions(fo.undiscretize_actions(tok, w), w), tok)
+    bins = np.stack([np.arange(350)] * 3, -1)
+    assert np.array_equal(fo.discretize_rtgs(fo.normalize_rtgs(fo.undiscretize_rtgs(bins, w), w), w), bins)
+    assert fo.discretize_actions(np.zeros((1, 2)), w)[0] == spec.ZERO_ACTION_TOKEN        # half-to-even
+    assert tuple(fo.discretize_rtgs(fo.normalize_rtgs(np.zeros((1, 3)), w), w)[0]) == spec.ZERO_RTG_BINS
+
+
+def test_sampling_oracle_matches_reference():
+    cfg = cfg_of("full")
+    d = spec.Dims(cfg)
+    w = cfg.dataset.waymo
+    g = golden("sampling")
+    assert tuple(g["multinomial_agreement"]) == (32, 32)
+    n = g["rtg_logits"].shape[0]
+    for ti, tl in enumerate(g["tilts"]):
+        tilt = fo.tilt_logits(*tl, w)
+        for i in range(n):
+            noise = lambda head, m, i=i: weights.exp_noise(9, 0, 0, i, head, m)
+            bins = rollout_oracle.sample_rtg(torch.from_numpy(g["rtg_logits"][i]), tilt, d.R, d.C, noise)
+            assert bins == list(g[f"rtg_bins_tilt{ti}"][i])
+    for tag, temp, nuc in (("t1", 1.0, False), ("t15", 1.5, False), ("nuc", 1.0, True), ("nuc_t07", 0.7, True)):
+        for i in range(n):
+            noise = lambda head, m, i=i: weights.exp_noise(9, 0, 0, i, head, m)
+            tok = rollout_oracle.sample_action(torch.from_numpy(g["act_logits"][i]), temp, nuc, 0.8, noise)
+            assert tok == int(g[f"act_tok_{tag}"][i])
+
+
+def _run_scripted(sim_cls, g):
+    sim = sim_cls(g["L"], g["W"], g["x"], g["y"], g["h"], g["v"], g["segs"])
+    steps, n = g["acts"].shape[:2]
+    traj = np.zeros((steps + 1, n, 6), np.float32); cv = np.zeros((steps + 1, n), np.uint8); ce = cv.copy()
+    traj[0], cv[0], ce[0] = sim.state()
+    for t in range(steps):
+        for i in range(n):
+            sim.set_action(i, g["acts"][t, i, 0], g["acts"][t, i, 1])
+        sim.step(0.1)
+        traj[t + 1], cv[t + 1], ce[t + 1] = sim.state()
+    sim.close()
+    return traj, cv, ce
+
+
+def test_sim_oracle_bit_exact_vs_reference_physics_fixture():
+    g = golden("physics")
+    traj, cv, ce = _run_scripted(sim_libs.OracleSim, g)
+    assert np.array_equal(traj, g["traj"])                      # float32 bit-exact (contact-free)
+    assert np.array_equal(cv, g["coll_veh"]) and np.array_equal(ce, g["coll_edge"])
+    assert g["coll_edge"].sum() > 0
+    # brake-to-zero car is at rest, clamped car is at 50 m/s
+    assert g["traj"][-1, 0, 3] == 0.0 and abs(g["traj"][-1, 1, 3] - 50.0) < 1e-4
+
+
+@pytest.mark.skipif(not sim_libs.RefSim.available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_sim_oracle_bit_exact_vs_live_reference_physics():
+    g = golden("physics")
+    a = _run_scripted(sim_libs.RefSim, g)
+    b = _run_scripted(sim_libs.OracleSim, g)
+    assert np.array_equal(a[0], g["traj"])
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def test_collision_oracle_matches_reference_geometry():
+    g = golden("collision")
+    geo = sim_libs.oracle_geo()
+    for i in range(len(g["segs"])):
+        a = np.ascontiguousarray(g["boxes"][i, 0]); b = np.ascontiguousarray(g["boxes"][i, 1])
+        assert geo.orageo_poly_poly(a, 4, b, 4) == g["poly_poly"][i]
+        assert geo.orageo_poly_seg(a, 4, np.ascontiguousarray(g["segs"][i])) == g["poly_seg"][i]
+
+
+def test_collision_oracle_reference_kats():
+    """Known-answer cases held by the reference's own gtest files (values only):
+    nocturne/cpp/tests/src/geometry/polygon_test.cc:60-86, intersection_test.cc:52-76."""
+    geo = sim_libs.oracle_geo()
+    f = lambda pts: np.ascontiguousarray(np.array(pts, np.float32))
+    p1 = f([[1, 1], [3, 1], [2, 2]])
+    tri = lambda dx, dy: f([[1 + dx, 1 + dy], [3 + dx, 1 + dy], [2 + dx, 2 + dy]])
+    assert geo.orageo_poly_poly(p1, 3, tri(0.5, 0.5), 3) == 1
+    assert geo.orageo_poly_poly(p1, 3, tri(1.0, 1.0), 3) == 1          # touching corner counts
+    assert geo.orageo_poly_poly(p1, 3, tri(5.0, 0.0), 3) == 0
+    sq = f([[0, 0], [2, 0], [2, 2], [0, 2]])
+    assert geo.orageo_poly_seg(sq, 4, f([1, 1, 3, 3])) == 1
+    assert geo.orageo_poly_seg(sq, 4, f([3, 0, 3, 3])) == 0
+    assert geo.orageo_poly_seg(sq, 4, f([-1, 3, 3, -1])) == 1
+    assert geo.orageo_poly_seg(sq, 4, f([2, 3, 3, 2])) == 0
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_rollout_oracle_matches_reference_closed_loop(tag):
+    """G8: the unmodified reference AutoregressivePolicy + real FreeCar/Box2D, 20 steps, vs this repo's
+    restated loop + C sim: tokens, RTG bins, float32 states and collision flags all identical."""
+    cfg = cfg_of("loop")
+    d = spec.Dims(cfg)
+    g = golden("closed_loop")
+    rc = g[f"{tag}_recipe"]
+    scn = scenarios.make_scenario(int(rc[0]), int(rc[1]), n_agents=int(rc[2]), n_polylines=int(rc[3]),
+                                  n_points=d.NP, extent=float(rc[4]))
+    pol = cfg.eval.policy.copy()
+    pol.nucleus_sampling = bool(rc[9]); pol.action_temperature = float(rc[10])
+    ro = rollout_oracle.RolloutOracle(cfg, weights.generate(d, 0), policy_cfg=pol, tilt=tuple(rc[6:9]), seed=int(rc[5]))
+    r = ro.run(scn, 20, sim_libs.OracleSim, record_groups=True)
+    assert g[f"{tag}_coll"][..., 0].sum() == 0                  # fixture is contact-free by construction
+    assert np.array_equal(r["tokens"], g[f"{tag}_tokens"])
+    assert np.array_equal(r["n_groups"], g[f"{tag}_n_groups"])
+    np.testing.assert_allclose(fo.undiscretize_rtgs(r["rtg_bins"], cfg.dataset.waymo), g[f"{tag}_rtg_cont"], atol=1e-9)
+    np.testing.assert_allclose(r["states"], g[f"{tag}_states"], atol=1e-4, rtol=0)   # north-star tolerance
+    assert np.array_equal(r["states"], g[f"{tag}_states"])      # and in fact identical here
+    assert np.array_equal(r["coll"], g[f"{tag}_coll"])
+    tf = g[f"{tag}_groups_t_focal"]
+    assert [(x["t"], x["focal"]) for x in r["groups"]] == [tuple(v) for v in tf]
+    for x, ids, mem in zip(r["groups"], g[f"{tag}_groups_ids"], g[f"{tag}_groups_members"]):
+        assert x["ids"] == [int(v) for v in ids if v >= 0]
+        assert x["members"] == [int(v) for v in mem if v >= 0]
+    assert g[f"{tag}_margins"].min() > 1e-4                     # no sampling race was a near-tie
+
+
+def test_inverse_bicycle_matches_reference():
+    """G10: nocturne/bicycle_model.py:51-109 (log-replay actions)."""
+    from ctrlsim_amd.kinematics import bicycle_backward
+    g = golden("bicycle_backward")
+    a, s = bicycle_backward(g["nxt"], g["prev"], 0.1)
+    np.testing.assert_allclose(np.stack([a, s], 1), g["accel_steer"], rtol=0, atol=1e-12)
