@@ -1,0 +1,83 @@
+"""ctypes binding of libctrlsim_hip.so (the C ABI of include/ctrlsim.h).
+
+The product path has NO fallback: if the HIP library is missing or cannot be loaded this module raises — callers
+must build it first (`python ctrl-sim_amd/csrc/build.py`, done by `__graft_entry__.build()`).
+`import torch` happens before the CDLL so that the library binds to the HIP runtime torch already loaded
+(both carry soname libamdhip64.so.7).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the CDLL: shares the already-loaded HIP runtime)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libctrlsim_hip.so")
+
+
+class Dims(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("A", "T", "P", "NP", "D", "H", "F", "V", "R", "C", "NE", "ND", "MAXT")]
+
+
+class Ctx(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("st12", "exist", "goal5", "act_tok", "rtg_bin", "tstep", "slot_gid",
+                                           "road_pts", "road_types")]
+
+
+P, I, L, D, F = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_float
+U64 = C.c_uint64
+
+SIGNATURES = {
+    "ctrlsim_version": (C.c_char_p, []),
+    "ctrlsim_gemm_nt": (I, [P, I, P, I, P, P, I, P, I, I, I, I, I, P]),
+    "ctrlsim_layernorm256": (I, [P, I, P, I, P, P, P, I, I, I, P]),
+    "ctrlsim_attention": (I, [I, P, I, L, P, P, I, L, P, I, L, P, P, I, I, I, I, P]),
+    "ctrlsim_sim_init": (I, [I, I, I, P, P, P, P, P, P, P, I, P]),
+    "ctrlsim_sim_step": (I, [I, I, I, P, P, P, P, P, P, P, P, P, P, I, I, F, I, P]),
+    "ctrlsim_group_build": (I, [I, I, I, I, I, I, D, P, P, I, P, P, P, P, P, P, P, P, P]),
+    "ctrlsim_ctx_index": (I, [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "ctrlsim_build_context": (I, [I] * 11 + [P] * 12 + [C.POINTER(Ctx), P]),
+    "ctrlsim_model_create": (I, [C.POINTER(Dims), P, I, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(P)]),
+    "ctrlsim_model_destroy": (None, [P]),
+    "ctrlsim_forward_workspace_bytes": (L, [C.POINTER(Dims), I, I]),
+    "ctrlsim_dt_forward_pass1": (I, [P, I, I, C.POINTER(Ctx), P, P, P, P]),
+    "ctrlsim_dt_forward_pass2": (I, [P, I, I, I, I, I, C.POINTER(Ctx), P, P, P, P, P]),
+    "ctrlsim_sample_rtg": (I, [P, I, I, P, P, P, P, P, U64, P, I, P, I, I, I, P]),
+    "ctrlsim_sample_action": (I, [P, I, I, P, P, F, D, P, U64, P, I, P, P, I, I, I, I, P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the CDLL with argtypes set.  Raises if the HIP extension is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build the HIP extension first "
+                               "(python ctrl-sim_amd/csrc/build.py); there is no CPU fallback")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)      # AttributeError if an ABI symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(code, what=""):
+    if code != 0:
+        raise RuntimeError(f"ctrlsim call failed ({what}): status {code}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "ctrlsim kernels take contiguous tensors"
+    return t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream

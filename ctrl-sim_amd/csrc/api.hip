@@ -1,0 +1,95 @@
+// extern "C" exports of the C ABI declared in include/ctrlsim.h (thin wrappers over the kernel launchers).
+#include "common.h"
+#include "../../include/ctrlsim.h"
+
+int launch_gemm_nt(const float*, int, const float*, int, const float*, const float*, int, float*, int, int, int, int, int,
+                   hipStream_t);
+int launch_layernorm256(const float*, int, const float*, int, const float*, const float*, float*, int, int, int,
+                        hipStream_t);
+int launch_attention(int, const float*, int, long, const float*, const float*, int, long, float*, int, long, const int*,
+                     const unsigned char*, int, int, int, int, hipStream_t);
+int launch_sim_init(int, int, int, const float*, const float*, const float*, const unsigned char*, float*, float*,
+                    unsigned char*, int, hipStream_t);
+int launch_sim_step(int, int, int, const int*, const double*, const double*, const float*, const float*,
+                    const unsigned char*, float*, float*, unsigned char*, double*, int, int, float, int, hipStream_t);
+int launch_group_build(int, int, int, int, int, int, double, const float*, const int*, int, unsigned long long*, int*, int*,
+                       unsigned long long*, unsigned long long*, int*, int*, unsigned char*, hipStream_t);
+int launch_ctx_index(int, int, int, const int*, const int*, const unsigned long long*, const int*, const int*, int*, int*,
+                     int*, int*, int*, int*, int*, hipStream_t);
+struct CtxOut { float *st12, *exist, *goal5; int *act_tok, *rtg_bin, *tstep, *slot_gid; float *road_pts, *road_types; };
+int launch_build_context(int, int, int, int, int, int, int, int, int, int, int, const int*, const int*, const int*,
+                         const unsigned long long*, const float*, const int*, const int*, const double*, const float*,
+                         const float*, const float*, const int*, CtxOut, hipStream_t);
+int launch_sample_rtg(const float*, int, int, const int*, const int*, const unsigned char*, const double*, const float*,
+                      uint64_t, const int64_t*, int, int*, int, int, int, hipStream_t);
+int launch_sample_action(const float*, int, int, const int*, const int*, float, double, const float*, uint64_t,
+                         const int64_t*, int, int*, int*, int, int, int, int, hipStream_t);
+
+extern "C" {
+
+const char* ctrlsim_version(void) { return "ctrlsim-hip 0.1 (gfx950)"; }
+
+int ctrlsim_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
+                    int ldc, int M, int N, int K, int relu, hipStream_t st) {
+  return launch_gemm_nt(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, relu, st);
+}
+int ctrlsim_layernorm256(const float* X, int ldx, const float* Radd, int ldr, const float* gamma, const float* beta, float* Y,
+                         int ldy, int rows, int relu, hipStream_t st) {
+  return launch_layernorm256(X, ldx, Radd, ldr, gamma, beta, Y, ldy, rows, relu, st);
+}
+int ctrlsim_attention(int mode, const float* Q, int ldq, int64_t qbs, const float* K, const float* V, int ldkv, int64_t kbs,
+                      float* O, int ldo, int64_t obs, const int* q_pos, const uint8_t* key_pad, int B, int Lq, int Lk, int A,
+                      hipStream_t st) {
+  return launch_attention(mode, Q, ldq, (long)qbs, K, V, ldkv, (long)kbs, O, ldo, (long)obs, q_pos, key_pad, B, Lq, Lk, A, st);
+}
+int ctrlsim_sim_init(int S, int N, int E, const float* init_pose, const float* size, const float* edges, const uint8_t* exists,
+                     float* phys, float* hist_states, uint8_t* coll, int Tmax1, hipStream_t st) {
+  return launch_sim_init(S, N, E, init_pose, size, edges, exists, phys, hist_states, coll, Tmax1, st);
+}
+int ctrlsim_sim_step(int S, int N, int E, const int* act_tok, const double* act_f64, const double* disc6, const float* size,
+                     const float* edges, const uint8_t* exists, float* phys, float* hist_states, uint8_t* coll,
+                     double* applied, int t, int Tmax1, float dt, int mode, hipStream_t st) {
+  if (!disc6) return CTRLSIM_EINVAL;
+  return launch_sim_step(S, N, E, act_tok, act_f64, disc6, size, edges, exists, phys, hist_states, coll, applied, t, Tmax1, dt,
+                         mode, st);
+}
+int ctrlsim_group_build(int S, int N, int A, int T, int t, int Tmax1, double dist_thresh, const float* hist_states,
+                        const int* eval_order, int has_roads, uint64_t* persist, int* n_groups, int* grp_focal,
+                        uint64_t* grp_ids, uint64_t* grp_members, int* own_g, int* mem_g, uint8_t* tilted, hipStream_t st) {
+  return launch_group_build(S, N, A, T, t, Tmax1, dist_thresh, hist_states, eval_order, has_roads,
+                            (unsigned long long*)persist, n_groups, grp_focal, (unsigned long long*)grp_ids,
+                            (unsigned long long*)grp_members, own_g, mem_g, tilted, st);
+}
+int ctrlsim_ctx_index(int s0, int s1, int N, const int* n_groups, const int* grp_focal, const uint64_t* grp_ids,
+                      const int* own_g, const int* mem_g, int* ctx_scn, int* ctx_grp, int* own_ctx, int* own_slot,
+                      int* mem_ctx, int* mem_slot, int* ctx_base, hipStream_t st) {
+  return launch_ctx_index(s0, s1, N, n_groups, grp_focal, (const unsigned long long*)grp_ids, own_g, mem_g, ctx_scn, ctx_grp,
+                          own_ctx, own_slot, mem_ctx, mem_slot, ctx_base, st);
+}
+int ctrlsim_build_context(int B, int N, int A, int T, int t, int Tq, int Tmax1, int Tmax, int P_all, int P, int NP,
+                          const int* ctx_scn, const int* ctx_grp, const int* grp_focal, const uint64_t* grp_ids,
+                          const float* hist_states, const int* hist_tok, const int* hist_rtg, const double* goals,
+                          const float* types, const float* roads, const float* road_types, const int* zero4,
+                          const ctrlsim_ctx* out, hipStream_t st) {
+  if (!out || !zero4) return CTRLSIM_EINVAL;
+  CtxOut o{out->st12, out->exist, out->goal5, out->act_tok, out->rtg_bin, out->tstep, out->slot_gid, out->road_pts,
+           out->road_types};
+  return launch_build_context(B, N, A, T, t, Tq, Tmax1, Tmax, P_all, P, NP, ctx_scn, ctx_grp, grp_focal,
+                              (const unsigned long long*)grp_ids, hist_states, hist_tok, hist_rtg, goals, types, roads,
+                              road_types, zero4, o, st);
+}
+int ctrlsim_sample_rtg(const float* rtg_logits, int A, int R, const int* own_ctx, const int* own_slot, const uint8_t* tilted,
+                       const double* tilt3, const float* noise, uint64_t seed, const int64_t* scenario_id, int t,
+                       int* hist_rtg, int S, int N, int Tmax, hipStream_t st) {
+  if (!tilt3) return CTRLSIM_EINVAL;
+  return launch_sample_rtg(rtg_logits, A, R, own_ctx, own_slot, tilted, tilt3, noise, seed, scenario_id, t, hist_rtg, S, N,
+                           Tmax, st);
+}
+int ctrlsim_sample_action(const float* act_logits, int A, int V, const int* mem_ctx, const int* mem_slot, float temperature,
+                          double top_p, const float* noise, uint64_t seed, const int64_t* scenario_id, int t, int* hist_tok,
+                          int* act_now, int S, int N, int Tmax, int zero_token, hipStream_t st) {
+  return launch_sample_action(act_logits, A, V, mem_ctx, mem_slot, temperature, top_p, noise, seed, scenario_id, t, hist_tok,
+                              act_now, S, N, Tmax, zero_token, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,47 @@
+"""Build libctrlsim_hip.so (gfx950) in-tree with hipcc.  Usage: python build.py [--force]
+
+sim.hip and context.hip are compiled with -ffp-contract=off: their float32/float64 arithmetic must equal the
+reference's plain IEEE evaluation (no FMA contraction); the MFMA/GEMM files use the default contraction.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRCS = {"gemm": "", "attention": "", "sim": "-ffp-contract=off", "context": "-ffp-contract=off", "embed": "",
+        "map_encoder": "", "sample": "", "forward": "", "api": ""}
+OUT = os.path.join(HERE, "libctrlsim_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _newer(a, b):
+    return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force=False, verbose=False):
+    deps = [os.path.join(HERE, "common.h"), os.path.join(HERE, "..", "..", "include", "ctrlsim.h")]
+    objs = []
+    procs = []
+    for name, extra in SRCS.items():
+        src = os.path.join(HERE, name + ".hip")
+        obj = os.path.join(HERE, "build", name + ".o")
+        os.makedirs(os.path.dirname(obj), exist_ok=True)
+        objs.append(obj)
+        if force or _newer(src, obj) or any(_newer(d, obj) for d in deps):
+            cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj] + extra.split()
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((name, subprocess.Popen(cmd)))
+    for name, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {name}.hip")
+    if force or procs or not os.path.exists(OUT):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

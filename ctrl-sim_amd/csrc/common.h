@@ -1,0 +1,45 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the CtRL-Sim rollout path.
+// Wavefront = 64 lanes; fp32-input MFMA (v_mfma_f32_32x32x2_f32) is the matrix instruction used
+// throughout: token parity with the reference's fp32 path rules out bf16/fp8 operands.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CTRLSIM_OK 0
+#define CTRLSIM_EINVAL (-22)
+#define CTRLSIM_ELAUNCH (-5)
+
+#define HD 32            // head dim (hidden 256 / 8 heads)
+#define DM 256           // hidden dim
+#define NHEAD 8
+
+static inline int ctrlsim_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? CTRLSIM_OK : CTRLSIM_ELAUNCH;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// C/D fragment of mfma_f32_32x32x2f32: lane l, register r -> (row, col)
+__device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// splitmix64 finaliser: the counter-based generator shared with ctrlsim_amd/weights.py
+__device__ __host__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  uint64_t z = x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}

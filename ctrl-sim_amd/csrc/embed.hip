@@ -1,0 +1,125 @@
+// Token assembly for the decoder sequence and the scene-encoder's initial-state tokens (gfx950).
+//
+// Reference: modules/encoder.py:95-153.  Per (timestep tt, agent slot a) three tokens are produced in the order
+// (state, rtg, action), sequence index l = (tt*A + a)*3 + k, each  LN_embed( (content + embed_timestep[ts] +
+// embed_agent_id[a]) * existence ):
+//   state   content = embed_state_goal([embed_state(states||types), embed_goal(goal)])       (:103, :106)
+//   rtg     content = embed_rtg([E_goal[b0], E_veh[b1], E_road[b2]])                          (:116-125)
+//   action  content = embed_action[token]                                                     (:111)
+// Linear algebra that does not depend on the data is folded at weight-pack time (ctrlsim_amd/pack.py, float64):
+//   * embed_state.mlp.3 followed by the state half of embed_state_goal is ONE 256x256 matrix; the goal branch
+//     likewise; so the state content arrives here as  S2[b,tt,a] (GEMM over the hidden state features) + Gp[b,a].
+//   * embed_rtg applied to three embedding rows is the sum of three pre-multiplied 350x256 tables.
+// This kernel is the fused gather + add + mask + LayerNorm: one wavefront per (b, tt, a), 4 channels per lane, rows
+// written as 1 KiB contiguous stores.  The pre-LN masked state row of window index 0 is also written to the scene
+// encoder's source buffer as that agent's "initial state" token (encoder.py:108-109,137-139), with its padding flag.
+#include "common.h"
+
+__device__ __forceinline__ f32x4 ln256(f32x4 v, const f32x4 g, const f32x4 b) {
+  const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
+  const f32x4 d = v - mean;
+  const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / 256.f);
+  return d * (1.0f / sqrtf(var + 1e-5f)) * g + b;
+}
+
+struct EmbedTables {
+  const float* act;        // [V,256]      encoder.embed_action.weight
+  const float* rtg_g;      // [R,256]      E_goal @ W_rtg[:, 0:256]^T   (folded)
+  const float* rtg_v;      // [R,256]
+  const float* rtg_r;      // [R,256]
+  const float* rtg_bias;   // [256]
+  const float* tstep;      // [MAXT,256]   encoder.embed_timestep.weight
+  const float* agent;      // [A,256]      encoder.embed_agent_id.weight
+  const float* ln_g;       // [256]        encoder.embed_ln
+  const float* ln_b;
+};
+
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(
+    int rows, int Tq, int A, const float* __restrict__ S2,   // [B*Tq*A, 256] state content (without goal part)
+    const float* __restrict__ Gp,                            // [B*A, 256] goal part + fused biases
+    const float* __restrict__ exist, const int* __restrict__ act_tok, const int* __restrict__ rtg_bin,
+    const int* __restrict__ tstep, EmbedTables tb, float* __restrict__ X,   // [B, Tq*A*3, 256]
+    float* __restrict__ src, int M, int P,                                   // [B, M, 256] scene-encoder source
+    unsigned char* __restrict__ src_pad) {                                   // [B, M] 1 = ignore
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63, c4 = lane * 4;
+  const int a = row % A, bt = row / A, tt = bt % Tq, b = bt / Tq;
+  const float ex = exist[row];
+  const int ts = tstep[(size_t)b * Tq + tt];
+  const f32x4 g = *reinterpret_cast<const f32x4*>(tb.ln_g + c4);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(tb.ln_b + c4);
+  const f32x4 pos = *reinterpret_cast<const f32x4*>(tb.tstep + (size_t)ts * DM + c4) +
+                    *reinterpret_cast<const f32x4*>(tb.agent + (size_t)a * DM + c4);
+  float* xo = X + ((size_t)b * Tq * A + (size_t)tt * A + a) * 3 * DM + c4;
+  // state
+  f32x4 v = (*reinterpret_cast<const f32x4*>(S2 + (size_t)row * DM + c4) +
+             *reinterpret_cast<const f32x4*>(Gp + ((size_t)b * A + a) * DM + c4) + pos) * ex;
+  if (tt == 0) {
+    *reinterpret_cast<f32x4*>(src + ((size_t)b * M + P + a) * DM + c4) = v;
+    if (lane == 0) src_pad[(size_t)b * M + P + a] = ex != 0.f ? 0 : 1;
+  }
+  *reinterpret_cast<f32x4*>(xo) = ln256(v, g, be);
+  // rtg
+  const int* rb = rtg_bin + (size_t)row * 3;
+  v = (*reinterpret_cast<const f32x4*>(tb.rtg_g + (size_t)rb[0] * DM + c4) +
+       *reinterpret_cast<const f32x4*>(tb.rtg_v + (size_t)rb[1] * DM + c4) +
+       *reinterpret_cast<const f32x4*>(tb.rtg_r + (size_t)rb[2] * DM + c4) +
+       *reinterpret_cast<const f32x4*>(tb.rtg_bias + c4) + pos) * ex;
+  *reinterpret_cast<f32x4*>(xo + DM) = ln256(v, g, be);
+  // action
+  v = (*reinterpret_cast<const f32x4*>(tb.act + (size_t)act_tok[row] * DM + c4) + pos) * ex;
+  *reinterpret_cast<f32x4*>(xo + 2 * DM) = ln256(v, g, be);
+}
+
+// Pass 2: only the RTG tokens of the current timestep change (the sampled bins replace the placeholder); rebuild those
+// A rows per context into a compact [B*A, 256] buffer.  hist_rtg [S,N,Tmax,3] holds the bins sampled this step.
+__global__ __launch_bounds__(256) void assemble_rtg_rows_kernel(int rows, int A, int Tq, int ti, int t, int N, int Tmax,
+                                                                const int* __restrict__ ctx_scn,
+                                                                const int* __restrict__ slot_gid,
+                                                                const int* __restrict__ hist_rtg,
+                                                                const float* __restrict__ exist,
+                                                                const int* __restrict__ tstep, EmbedTables tb,
+                                                                int zr0, int zr1, int zr2, float* __restrict__ Xr) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);   // row = b*A + a
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63, c4 = lane * 4;
+  const int a = row % A, b = row / A;
+  const int gid = slot_gid[row];
+  int b0 = zr0, b1 = zr1, b2 = zr2;
+  if (gid >= 0) {
+    const int* rb = hist_rtg + (((size_t)ctx_scn[b] * N + gid) * Tmax + t) * 3;
+    b0 = rb[0]; b1 = rb[1]; b2 = rb[2];
+  }
+  const float ex = exist[((size_t)b * Tq + ti) * A + a];
+  const int ts = tstep[(size_t)b * Tq + ti];
+  const f32x4 g = *reinterpret_cast<const f32x4*>(tb.ln_g + c4);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(tb.ln_b + c4);
+  const f32x4 pos = *reinterpret_cast<const f32x4*>(tb.tstep + (size_t)ts * DM + c4) +
+                    *reinterpret_cast<const f32x4*>(tb.agent + (size_t)a * DM + c4);
+  const f32x4 v = (*reinterpret_cast<const f32x4*>(tb.rtg_g + (size_t)b0 * DM + c4) +
+                   *reinterpret_cast<const f32x4*>(tb.rtg_v + (size_t)b1 * DM + c4) +
+                   *reinterpret_cast<const f32x4*>(tb.rtg_r + (size_t)b2 * DM + c4) +
+                   *reinterpret_cast<const f32x4*>(tb.rtg_bias + c4) + pos) * ex;
+  *reinterpret_cast<f32x4*>(Xr + (size_t)row * DM + c4) = ln256(v, g, be);
+}
+
+int launch_assemble_tokens(int B, int Tq, int A, const float* S2, const float* Gp, const float* exist,
+                           const int* act_tok, const int* rtg_bin, const int* tstep, EmbedTables tb, float* X,
+                           float* src, int M, int P, unsigned char* src_pad, hipStream_t st) {
+  const int rows = B * Tq * A;
+  if (rows <= 0) return CTRLSIM_OK;
+  hipLaunchKernelGGL(assemble_tokens_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, rows, Tq, A, S2, Gp, exist, act_tok,
+                     rtg_bin, tstep, tb, X, src, M, P, src_pad);
+  return ctrlsim_launch_status();
+}
+
+int launch_assemble_rtg_rows(int B, int A, int Tq, int ti, int t, int N, int Tmax, const int* ctx_scn,
+                             const int* slot_gid, const int* hist_rtg, const float* exist, const int* tstep,
+                             EmbedTables tb, const int* zr, float* Xr, hipStream_t st) {
+  const int rows = B * A;
+  if (rows <= 0) return CTRLSIM_OK;
+  hipLaunchKernelGGL(assemble_rtg_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, rows, A, Tq, ti, t, N, Tmax, ctx_scn,
+                     slot_gid, hist_rtg, exist, tstep, tb, zr[0], zr[1], zr[2], Xr);
+  return ctrlsim_launch_status();
+}

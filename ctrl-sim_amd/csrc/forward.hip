@@ -1,0 +1,338 @@
+// Host-side orchestration of the CtRL-Sim forward for a batch of B agent-local contexts (gfx950).
+//
+// Replaces, for the rollout, `CtRLSim.forward` = Decoder(Encoder(data)) (models/ctrl_sim.py:41-45;
+// modules/encoder.py:50-178, modules/map_encoder.py:34-53, modules/decoder.py:39-79) as it is called twice per
+// focal group and step by AutoregressivePolicy.predict (policies/autoregressive_policy.py:189-210):
+//   pass 1  -> RTG logits of the current-timestep STATE tokens      (predict_rtg head,    decoder.py:74-77)
+//   pass 2  -> action logits of the current-timestep RTG tokens     (predict_action head, decoder.py:58-62)
+// Exact (in real arithmetic) savings over the reference's two dense passes:
+//   * only the first Tq = token_index+1 window steps are materialised (later tokens are invisible to the queries);
+//   * heads are evaluated for the A current-timestep tokens only, and the last decoder layer computes K/V for all
+//     tokens but attention/FFN only for those A queries;
+//   * pass 2 re-evaluates nothing but the A RTG tokens of the current timestep through the 4 layers against the
+//     cached per-layer K/V of pass 1 (the sampled RTG only changes tokens that are visible to the same agent's
+//     RTG/action tokens of that timestep: SURVEY.md §8a M6 corollary);
+//   * map encoder / embedding linear chains are folded at pack time (map_encoder.hip, embed.hip).
+// Everything is fp32; GEMMs and attention run on the f32-input MFMA.  No allocation, no synchronisation: the caller
+// provides the workspace (ctrlsim_forward_workspace_bytes) and a stream.
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+#include "../../include/ctrlsim.h"
+
+// launchers from the other translation units
+int launch_gemm_nt(const float*, int, const float*, int, const float*, const float*, int, float*, int, int, int, int, int,
+                   hipStream_t);
+int launch_layernorm256(const float*, int, const float*, int, const float*, const float*, float*, int, int, int,
+                        hipStream_t);
+int launch_in_mlp(const float*, int, int, const float*, const float*, const float*, const float*, float*, int, int,
+                  hipStream_t);
+int launch_row_copy(const float*, int, float*, int, const int*, int, int, int, hipStream_t);
+int launch_attention(int, const float*, int, long, const float*, const float*, int, long, float*, int, long, const int*,
+                     const unsigned char*, int, int, int, int, hipStream_t);
+struct EmbedTables { const float *act, *rtg_g, *rtg_v, *rtg_r, *rtg_bias, *tstep, *agent, *ln_g, *ln_b; };
+int launch_assemble_tokens(int, int, int, const float*, const float*, const float*, const int*, const int*, const int*,
+                           EmbedTables, float*, float*, int, int, unsigned char*, hipStream_t);
+int launch_assemble_rtg_rows(int, int, int, int, int, int, int, const int*, const int*, const int*, const float*,
+                             const int*, EmbedTables, const int*, float*, hipStream_t);
+struct MapPoolWeights { const float *W1, *b1, *ln_g, *ln_b, *U, *cb, *Mt, *mb; };
+int launch_map_pool(int, int, int, int, const float*, MapPoolWeights, float*, unsigned char*, hipStream_t);
+
+namespace {
+
+struct Lin { const float* w; const float* b; };
+struct LNp { const float* g; const float* b; };
+struct Mlp { Lin l0; LNp ln; Lin l3; };
+struct EncLayer { Lin qkv, out, lin1, lin2; LNp n1, n2; };
+struct DecLayer { Lin qkv, out, cq, ckv, cout, lin1, lin2; LNp n1, n2, n3; };
+
+}  // namespace
+
+struct ctrlsim_model {
+  ctrlsim_dims d;
+  // embeddings
+  Mlp embed_state, embed_goal;             // only l0 + ln used (l3 folded)
+  const float *fold_state_w, *fold_goal_w, *fold_goal_b;
+  EmbedTables tb;
+  // map encoder
+  MapPoolWeights mp;
+  Lin map_out;
+  LNp map_n1, map_n2;
+  Mlp map_feats, road_type, road_fuse;
+  std::vector<EncLayer> enc;
+  std::vector<DecLayer> dec;
+  Mlp head_action, head_rtg;
+  int zero_rtg[3];
+};
+
+#define CHK(x)            \
+  do {                    \
+    int _e = (x);         \
+    if (_e != 0) return _e; \
+  } while (0)
+
+extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_weights, int n, const char* const* names,
+                                    const int64_t* offsets, ctrlsim_model** out) {
+  if (!dims || !dev_weights || !names || !offsets || !out) return CTRLSIM_EINVAL;
+  if (dims->D != DM || dims->H != NHEAD || dims->A < 1 || dims->A > 64) return CTRLSIM_EINVAL;
+  std::unordered_map<std::string, const float*> tab;
+  for (int i = 0; i < n; ++i) tab[names[i]] = dev_weights + offsets[i];
+  bool ok = true;
+  auto P = [&](const std::string& k) -> const float* {
+    auto it = tab.find(k);
+    if (it == tab.end()) { ok = false; return nullptr; }
+    return it->second;
+  };
+  auto lin = [&](const std::string& k) { return Lin{P(k + ".weight"), P(k + ".bias")}; };
+  auto lnp = [&](const std::string& k) { return LNp{P(k + ".weight"), P(k + ".bias")}; };
+  auto mlp = [&](const std::string& k) { return Mlp{lin(k + ".mlp.0"), lnp(k + ".mlp.1"), lin(k + ".mlp.3")}; };
+  ctrlsim_model* m = new ctrlsim_model();
+  m->d = *dims;
+  m->embed_state = mlp("encoder.embed_state");
+  m->embed_goal = mlp("encoder.embed_goal");
+  m->fold_state_w = P("fold.embed_state.w");
+  m->fold_goal_w = P("fold.embed_goal.w");
+  m->fold_goal_b = P("fold.embed_goal.b");
+  m->tb = EmbedTables{P("encoder.embed_action.weight"), P("fold.rtg_table_goal"), P("fold.rtg_table_veh"),
+                      P("fold.rtg_table_road"), P("encoder.embed_rtg.bias"), P("encoder.embed_timestep.weight"),
+                      P("encoder.embed_agent_id.weight"), P("encoder.embed_ln.weight"), P("encoder.embed_ln.bias")};
+  const std::string me = "encoder.map_encoder.";
+  m->mp = MapPoolWeights{P(me + "road_pts_encoder.mlp.0.weight"), P(me + "road_pts_encoder.mlp.0.bias"),
+                         P(me + "road_pts_encoder.mlp.1.weight"), P(me + "road_pts_encoder.mlp.1.bias"),
+                         P("fold.map.U"), P("fold.map.cb"), P("fold.map.Mt"), P("fold.map.mb")};
+  m->map_out = lin(me + "road_pts_attn_layer.out_proj");
+  m->map_n1 = lnp(me + "norm1");
+  m->map_n2 = lnp(me + "norm2");
+  m->map_feats = mlp(me + "map_feats");
+  m->road_type = mlp(me + "road_type_encoder");
+  m->road_fuse = mlp(me + "road_road_type_encoder");
+  for (int i = 0; i < dims->NE; ++i) {
+    const std::string p = "encoder.transformer_encoder.layers." + std::to_string(i);
+    EncLayer L;
+    L.qkv = Lin{P(p + ".self_attn.in_proj_weight"), P(p + ".self_attn.in_proj_bias")};
+    L.out = lin(p + ".self_attn.out_proj");
+    L.lin1 = lin(p + ".linear1");
+    L.lin2 = lin(p + ".linear2");
+    L.n1 = lnp(p + ".norm1");
+    L.n2 = lnp(p + ".norm2");
+    m->enc.push_back(L);
+  }
+  for (int i = 0; i < dims->ND; ++i) {
+    const std::string p = "decoder.transformer_decoder.layers." + std::to_string(i);
+    DecLayer L;
+    L.qkv = Lin{P(p + ".self_attn.in_proj_weight"), P(p + ".self_attn.in_proj_bias")};
+    L.out = lin(p + ".self_attn.out_proj");
+    const float* cw = P(p + ".multihead_attn.in_proj_weight");
+    const float* cb = P(p + ".multihead_attn.in_proj_bias");
+    L.cq = Lin{cw, cb};
+    L.ckv = Lin{cw ? cw + DM * DM : nullptr, cb ? cb + DM : nullptr};
+    L.cout = lin(p + ".multihead_attn.out_proj");
+    L.lin1 = lin(p + ".linear1");
+    L.lin2 = lin(p + ".linear2");
+    L.n1 = lnp(p + ".norm1");
+    L.n2 = lnp(p + ".norm2");
+    L.n3 = lnp(p + ".norm3");
+    m->dec.push_back(L);
+  }
+  m->head_action = mlp("decoder.predict_action");
+  m->head_rtg = mlp("decoder.predict_rtg");
+  m->zero_rtg[0] = 0; m->zero_rtg[1] = 35; m->zero_rtg[2] = 35;
+  if (!ok) { delete m; return CTRLSIM_EINVAL; }
+  *out = m;
+  return CTRLSIM_OK;
+}
+
+extern "C" void ctrlsim_model_destroy(ctrlsim_model* m) { delete m; }
+
+// ------------------------------------------------------------------------------------------------ workspace
+namespace {
+struct Ws {
+  float *hS, *S2, *hG, *Gp, *X, *src, *attn_pre, *m1, *m2, *cat, *tfh, *eqkv, *eatt, *etmp, *effn;
+  float *memkv[8], *qkv[8];
+  float *att, *tmp, *qc, *ffn;
+  float *xc, *xc2, *tmpc, *attc, *qkvc, *qcc, *ffnc, *headh;
+  unsigned char* src_pad;
+  int *pos_state, *pos_rtg, *idx_state, *idx_rtg, *idx_poly;
+  size_t bytes;
+};
+
+Ws carve(const ctrlsim_dims& d, int B, int Tq, char* base) {
+  Ws w;
+  size_t off = 0;
+  auto take = [&](size_t nbytes) -> char* {
+    char* p = base ? base + off : nullptr;
+    off += (nbytes + 255) & ~size_t(255);
+    return p;
+  };
+  const size_t L = (size_t)Tq * d.A * 3, M = (size_t)d.P + d.A;
+  const size_t rL = B * L, rM = B * M, rA = (size_t)B * d.A, rS = (size_t)B * Tq * d.A, rP = (size_t)B * d.P;
+  auto F = [&](size_t rows, size_t cols) { return reinterpret_cast<float*>(take(rows * cols * sizeof(float))); };
+  w.hS = F(rS, DM); w.S2 = F(rS, DM); w.hG = F(rA, DM); w.Gp = F(rA, DM);
+  w.X = F(rL, DM); w.src = F(rM, DM);
+  w.attn_pre = F(rP, DM); w.m1 = F(rP, DM); w.m2 = F(rP, DM); w.cat = F(rP, 2 * DM); w.tfh = F(rP, DM);
+  w.eqkv = F(rM, 3 * DM); w.eatt = F(rM, DM); w.etmp = F(rM, DM); w.effn = F(rM, d.F);
+  for (int i = 0; i < d.ND; ++i) w.memkv[i] = F(rM, 2 * DM);
+  for (int i = 0; i < d.ND; ++i) w.qkv[i] = F(rL, 3 * DM);
+  w.att = F(rL, DM); w.tmp = F(rL, DM); w.qc = F(rL, DM); w.ffn = F(rL, d.F);
+  w.xc = F(rA, DM); w.xc2 = F(rA, DM); w.tmpc = F(rA, DM); w.attc = F(rA, DM); w.qkvc = F(rA, 3 * DM);
+  w.qcc = F(rA, DM); w.ffnc = F(rA, d.F); w.headh = F(rA, DM);
+  w.src_pad = reinterpret_cast<unsigned char*>(take(rM));
+  w.pos_state = reinterpret_cast<int*>(take(d.A * sizeof(int)));
+  w.pos_rtg = reinterpret_cast<int*>(take(d.A * sizeof(int)));
+  w.idx_state = reinterpret_cast<int*>(take(rA * sizeof(int)));
+  w.idx_rtg = reinterpret_cast<int*>(take(rA * sizeof(int)));
+  w.idx_poly = reinterpret_cast<int*>(take(rP * sizeof(int)));
+  w.bytes = off;
+  return w;
+}
+
+__global__ void fill_index_kernel(int B, int A, int L, int ti, int P, int M, int* pos_state, int* pos_rtg, int* idx_state,
+                                  int* idx_rtg, int* idx_poly) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * P) idx_poly[i] = (i / P) * M + (i % P);
+  if (i < A) { pos_state[i] = (ti * A + i) * 3; pos_rtg[i] = (ti * A + i) * 3 + 1; }
+  if (i < B * A) {
+    const int b = i / A, a = i - b * A;
+    idx_state[i] = b * L + (ti * A + a) * 3;
+    idx_rtg[i] = b * L + (ti * A + a) * 3 + 1;
+  }
+}
+
+int mlp_tail(const Mlp& m, const float* h_in, int rows, float* hid, float* out, int n_out, hipStream_t st) {
+  // Linear(256->256) -> LN -> ReLU -> Linear(256->n_out)
+  CHK(launch_gemm_nt(h_in, DM, m.l0.w, DM, m.l0.b, nullptr, 0, hid, DM, rows, DM, DM, 0, st));
+  CHK(launch_layernorm256(hid, DM, nullptr, 0, m.ln.g, m.ln.b, hid, DM, rows, 1, st));
+  CHK(launch_gemm_nt(hid, DM, m.l3.w, DM, m.l3.b, nullptr, 0, out, n_out, rows, n_out, DM, 0, st));
+  return 0;
+}
+
+// cross-attention + FFN sub-blocks shared by the full-row and compact-row paths (post-LN, residual fused in GEMM)
+int cross_and_ffn(const ctrlsim_model* m, const DecLayer& Ld, int layer, const Ws& w, float* x, float* tmp, float* att,
+                  float* qc, float* ffn, int rows, int B, int rows_per_b, hipStream_t st) {
+  const ctrlsim_dims& d = m->d;
+  const int M = d.P + d.A;
+  CHK(launch_gemm_nt(x, DM, Ld.cq.w, DM, Ld.cq.b, nullptr, 0, qc, DM, rows, DM, DM, 0, st));
+  CHK(launch_attention(0, qc, DM, (long)rows_per_b * DM, w.memkv[layer], w.memkv[layer] + DM, 2 * DM, (long)M * 2 * DM, att,
+                       DM, (long)rows_per_b * DM, nullptr, w.src_pad, B, rows_per_b, M, d.A, st));
+  CHK(launch_gemm_nt(att, DM, Ld.cout.w, DM, Ld.cout.b, x, DM, tmp, DM, rows, DM, DM, 0, st));
+  CHK(launch_layernorm256(tmp, DM, nullptr, 0, Ld.n2.g, Ld.n2.b, x, DM, rows, 0, st));
+  CHK(launch_gemm_nt(x, DM, Ld.lin1.w, DM, Ld.lin1.b, nullptr, 0, ffn, d.F, rows, d.F, DM, 1, st));
+  CHK(launch_gemm_nt(ffn, d.F, Ld.lin2.w, d.F, Ld.lin2.b, x, DM, tmp, DM, rows, DM, d.F, 0, st));
+  CHK(launch_layernorm256(tmp, DM, nullptr, 0, Ld.n3.g, Ld.n3.b, x, DM, rows, 0, st));
+  return 0;
+}
+}  // namespace
+
+extern "C" int64_t ctrlsim_forward_workspace_bytes(const ctrlsim_dims* d, int B, int Tq) {
+  if (!d || B < 1 || Tq < 1 || Tq > d->T) return CTRLSIM_EINVAL;
+  return (int64_t)carve(*d, B, Tq, nullptr).bytes;
+}
+
+// ------------------------------------------------------------------------------------------------ pass 1
+extern "C" int ctrlsim_dt_forward_pass1(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* c, void* workspace,
+                                        float* rtg_logits, float* dbg_seg_emb, hipStream_t st) {
+  if (!m || !c || !workspace || !rtg_logits || B < 1 || Tq < 1 || Tq > m->d.T) return CTRLSIM_EINVAL;
+  const ctrlsim_dims& d = m->d;
+  const Ws w = carve(d, B, Tq, static_cast<char*>(workspace));
+  const int A = d.A, P = d.P, M = P + A, L = Tq * A * 3, ti = Tq - 1;
+  const int rL = B * L, rM = B * M, rA = B * A, rS = B * Tq * A, rP = B * P;
+  hipLaunchKernelGGL(fill_index_kernel, dim3(((rA > rP ? rA : rP) + 255) / 256), dim3(256), 0, st, B, A, L, ti, P, M,
+                     w.pos_state, w.pos_rtg, w.idx_state, w.idx_rtg, w.idx_poly);
+  // ---- token embeddings (encoder.py:95-153)
+  CHK(launch_in_mlp(c->st12, 12, 12, m->embed_state.l0.w, m->embed_state.l0.b, m->embed_state.ln.g, m->embed_state.ln.b,
+                    w.hS, DM, rS, st));
+  CHK(launch_gemm_nt(w.hS, DM, m->fold_state_w, DM, nullptr, nullptr, 0, w.S2, DM, rS, DM, DM, 0, st));
+  CHK(launch_in_mlp(c->goal5, 5, 5, m->embed_goal.l0.w, m->embed_goal.l0.b, m->embed_goal.ln.g, m->embed_goal.ln.b, w.hG,
+                    DM, rA, st));
+  CHK(launch_gemm_nt(w.hG, DM, m->fold_goal_w, DM, m->fold_goal_b, nullptr, 0, w.Gp, DM, rA, DM, DM, 0, st));
+  CHK(launch_assemble_tokens(B, Tq, A, w.S2, w.Gp, c->exist, c->act_tok, c->rtg_bin, c->tstep, m->tb, w.X, w.src, M, P,
+                             w.src_pad, st));
+  // ---- map encoder (map_encoder.py:34-53): rows of `src` 0..P-1 per context
+  CHK(launch_map_pool(B, P, d.NP, M, c->road_pts, m->mp, w.attn_pre, w.src_pad, st));
+  CHK(launch_gemm_nt(w.attn_pre, DM, m->map_out.w, DM, m->map_out.b, nullptr, 0, w.m1, DM, rP, DM, DM, 0, st));
+  CHK(launch_layernorm256(w.m1, DM, nullptr, 0, m->map_n1.g, m->map_n1.b, w.m1, DM, rP, 0, st));            // emb
+  CHK(launch_gemm_nt(w.m1, DM, m->map_feats.l0.w, DM, m->map_feats.l0.b, nullptr, 0, w.m2, DM, rP, DM, DM, 0, st));
+  CHK(launch_layernorm256(w.m2, DM, nullptr, 0, m->map_feats.ln.g, m->map_feats.ln.b, w.m2, DM, rP, 1, st));
+  CHK(launch_gemm_nt(w.m2, DM, m->map_feats.l3.w, DM, m->map_feats.l3.b, w.m1, DM, w.attn_pre, DM, rP, DM, DM, 0, st));
+  CHK(launch_layernorm256(w.attn_pre, DM, nullptr, 0, m->map_n2.g, m->map_n2.b, w.cat, 2 * DM, rP, 0, st));  // cat[:, :256]
+  CHK(launch_in_mlp(c->road_types, 8, 8, m->road_type.l0.w, m->road_type.l0.b, m->road_type.ln.g, m->road_type.ln.b, w.tfh,
+                    DM, rP, st));
+  CHK(launch_gemm_nt(w.tfh, DM, m->road_type.l3.w, DM, m->road_type.l3.b, nullptr, 0, w.cat + DM, 2 * DM, rP, DM, DM, 0,
+                     st));                                                                                  // cat[:, 256:]
+  CHK(launch_gemm_nt(w.cat, 2 * DM, m->road_fuse.l0.w, 2 * DM, m->road_fuse.l0.b, nullptr, 0, w.m2, DM, rP, DM, 2 * DM, 0,
+                     st));
+  CHK(launch_layernorm256(w.m2, DM, nullptr, 0, m->road_fuse.ln.g, m->road_fuse.ln.b, w.m2, DM, rP, 1, st));
+  // final Linear -> compact [B*P,256], then scattered into the scene-encoder source rows [b, 0..P-1]
+  CHK(launch_gemm_nt(w.m2, DM, m->road_fuse.l3.w, DM, m->road_fuse.l3.b, nullptr, 0, w.m1, DM, rP, DM, DM, 0, st));
+  CHK(launch_row_copy(w.m1, DM, w.src, DM, w.idx_poly, rP, DM, 1, st));
+  if (dbg_seg_emb) {
+    hipError_t e = hipMemcpyAsync(dbg_seg_emb, w.m1, (size_t)rP * DM * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return CTRLSIM_ELAUNCH;
+  }
+  // ---- scene encoder (encoder.py:155-168): post-LN layers over [polylines || initial states] with key padding
+  for (int i = 0; i < d.NE; ++i) {
+    const EncLayer& Le = m->enc[i];
+    CHK(launch_gemm_nt(w.src, DM, Le.qkv.w, DM, Le.qkv.b, nullptr, 0, w.eqkv, 3 * DM, rM, 3 * DM, DM, 0, st));
+    CHK(launch_attention(0, w.eqkv, 3 * DM, (long)M * 3 * DM, w.eqkv + DM, w.eqkv + 2 * DM, 3 * DM, (long)M * 3 * DM, w.eatt,
+                         DM, (long)M * DM, nullptr, w.src_pad, B, M, M, A, st));
+    CHK(launch_gemm_nt(w.eatt, DM, Le.out.w, DM, Le.out.b, w.src, DM, w.etmp, DM, rM, DM, DM, 0, st));
+    CHK(launch_layernorm256(w.etmp, DM, nullptr, 0, Le.n1.g, Le.n1.b, w.src, DM, rM, 0, st));
+    CHK(launch_gemm_nt(w.src, DM, Le.lin1.w, DM, Le.lin1.b, nullptr, 0, w.effn, d.F, rM, d.F, DM, 1, st));
+    CHK(launch_gemm_nt(w.effn, d.F, Le.lin2.w, d.F, Le.lin2.b, w.src, DM, w.etmp, DM, rM, DM, d.F, 0, st));
+    CHK(launch_layernorm256(w.etmp, DM, nullptr, 0, Le.n2.g, Le.n2.b, w.src, DM, rM, 0, st));
+  }
+  // memory K/V of every decoder layer (cached for pass 2)
+  for (int i = 0; i < d.ND; ++i)
+    CHK(launch_gemm_nt(w.src, DM, m->dec[i].ckv.w, DM, m->dec[i].ckv.b, nullptr, 0, w.memkv[i], 2 * DM, rM, 2 * DM, DM, 0,
+                       st));
+  // ---- decoder (decoder.py:52): layers 0..ND-2 on all L tokens
+  for (int i = 0; i < d.ND; ++i) {
+    const DecLayer& Ld = m->dec[i];
+    CHK(launch_gemm_nt(w.X, DM, Ld.qkv.w, DM, Ld.qkv.b, nullptr, 0, w.qkv[i], 3 * DM, rL, 3 * DM, DM, 0, st));
+    if (i < d.ND - 1) {
+      CHK(launch_attention(1, w.qkv[i], 3 * DM, (long)L * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
+                           w.att, DM, (long)L * DM, nullptr, nullptr, B, L, L, A, st));
+      CHK(launch_gemm_nt(w.att, DM, Ld.out.w, DM, Ld.out.b, w.X, DM, w.tmp, DM, rL, DM, DM, 0, st));
+      CHK(launch_layernorm256(w.tmp, DM, nullptr, 0, Ld.n1.g, Ld.n1.b, w.X, DM, rL, 0, st));
+      CHK(cross_and_ffn(m, Ld, i, w, w.X, w.tmp, w.att, w.qc, w.ffn, rL, B, L, st));
+    } else {
+      // last layer: only the A state tokens of the current timestep are queried
+      CHK(launch_row_copy(w.X, DM, w.xc, DM, w.idx_state, rA, DM, 0, st));
+      CHK(launch_row_copy(w.qkv[i], 3 * DM, w.qkvc, 3 * DM, w.idx_state, rA, 3 * DM, 0, st));
+      CHK(launch_attention(1, w.qkvc, 3 * DM, (long)A * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
+                           w.attc, DM, (long)A * DM, w.pos_state, nullptr, B, A, L, A, st));
+      CHK(launch_gemm_nt(w.attc, DM, Ld.out.w, DM, Ld.out.b, w.xc, DM, w.tmpc, DM, rA, DM, DM, 0, st));
+      CHK(launch_layernorm256(w.tmpc, DM, nullptr, 0, Ld.n1.g, Ld.n1.b, w.xc, DM, rA, 0, st));
+      CHK(cross_and_ffn(m, Ld, i, w, w.xc, w.tmpc, w.attc, w.qcc, w.ffnc, rA, B, A, st));
+    }
+  }
+  // ---- predict_rtg head on the A state tokens (decoder.py:74-77)
+  CHK(mlp_tail(m->head_rtg, w.xc, rA, w.headh, rtg_logits, d.R * d.C, st));
+  return CTRLSIM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ pass 2
+extern "C" int ctrlsim_dt_forward_pass2(const ctrlsim_model* m, int B, int Tq, int t, int N, int Tmax,
+                                        const ctrlsim_ctx* c, const int* ctx_scn, const int* hist_rtg, void* workspace,
+                                        float* act_logits, hipStream_t st) {
+  if (!m || !c || !workspace || !act_logits || B < 1 || Tq < 1 || Tq > m->d.T) return CTRLSIM_EINVAL;
+  const ctrlsim_dims& d = m->d;
+  const Ws w = carve(d, B, Tq, static_cast<char*>(workspace));
+  const int A = d.A, L = Tq * A * 3, ti = Tq - 1, rA = B * A;
+  CHK(launch_assemble_rtg_rows(B, A, Tq, ti, t, N, Tmax, ctx_scn, c->slot_gid, hist_rtg, c->exist, c->tstep, m->tb,
+                               m->zero_rtg, w.xc2, st));
+  for (int i = 0; i < d.ND; ++i) {
+    const DecLayer& Ld = m->dec[i];
+    CHK(launch_gemm_nt(w.xc2, DM, Ld.qkv.w, DM, Ld.qkv.b, nullptr, 0, w.qkvc, 3 * DM, rA, 3 * DM, DM, 0, st));
+    CHK(launch_row_copy(w.qkvc, 3 * DM, w.qkv[i], 3 * DM, w.idx_rtg, rA, 3 * DM, 1, st));   // refresh the rtg rows' K/V
+    CHK(launch_attention(1, w.qkvc, 3 * DM, (long)A * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
+                         w.attc, DM, (long)A * DM, w.pos_rtg, nullptr, B, A, L, A, st));
+    CHK(launch_gemm_nt(w.attc, DM, Ld.out.w, DM, Ld.out.b, w.xc2, DM, w.tmpc, DM, rA, DM, DM, 0, st));
+    CHK(launch_layernorm256(w.tmpc, DM, nullptr, 0, Ld.n1.g, Ld.n1.b, w.xc2, DM, rA, 0, st));
+    CHK(cross_and_ffn(m, Ld, i, w, w.xc2, w.tmpc, w.attc, w.qcc, w.ffnc, rA, B, A, st));
+  }
+  CHK(mlp_tail(m->head_action, w.xc2, rA, w.headh, act_logits, d.V, st));
+  return CTRLSIM_OK;
+}

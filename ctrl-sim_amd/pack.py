@@ -1,0 +1,76 @@
+"""Weight packing for the HIP forward: the reference state_dict tensors plus the "fold.*" tensors.
+
+Folds (all in float64, rounded once to float32) are products of weights only — no data dependence — and leave
+the model function unchanged in exact arithmetic:
+
+  fold.embed_state.w   = W_sg[:, :D] @ W_state3            encoder.embed_state.mlp.3 then the state half of
+  fold.embed_goal.w    = W_sg[:, D:] @ W_goal3             encoder.embed_state_goal (modules/encoder.py:21-23,106)
+  fold.embed_goal.b    = W_sg[:, :D] b_state3 + W_sg[:, D:] b_goal3 + b_sg
+  fold.rtg_table_{goal,veh,road} = E_c @ W_rtg[:, cD:(c+1)D]^T   embed_rtg over three embedding rows (:116-125)
+  fold.map.U, fold.map.cb, fold.map.Mt, fold.map.mb         single-seed attention pooling of the map encoder
+                                                             (modules/map_encoder.py:44-46; see csrc/map_encoder.hip)
+Tensors are laid out back to back in ONE float32 buffer, each aligned to 256 bytes; `names`/`offsets` (in floats)
+are handed to ctrlsim_model_create.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .spec import Dims
+
+
+def fold(dims: Dims, w: dict) -> dict:
+    D, H = dims.D, dims.H
+    dh = D // H
+    f8 = lambda k: np.asarray(w[k], np.float64)
+    out = {}
+    Wsg, bsg = f8("encoder.embed_state_goal.weight"), f8("encoder.embed_state_goal.bias")
+    Ws3, bs3 = f8("encoder.embed_state.mlp.3.weight"), f8("encoder.embed_state.mlp.3.bias")
+    Wg3, bg3 = f8("encoder.embed_goal.mlp.3.weight"), f8("encoder.embed_goal.mlp.3.bias")
+    out["fold.embed_state.w"] = Wsg[:, :D] @ Ws3
+    out["fold.embed_goal.w"] = Wsg[:, D:] @ Wg3
+    out["fold.embed_goal.b"] = Wsg[:, :D] @ bs3 + Wsg[:, D:] @ bg3 + bsg
+    Wr = f8("encoder.embed_rtg.weight")
+    for c, nm in enumerate(("goal", "veh", "road")):
+        out[f"fold.rtg_table_{nm}"] = f8(f"encoder.embed_rtg_{nm}.weight") @ Wr[:, c * D:(c + 1) * D].T
+    pre = "encoder.map_encoder."
+    W2, b2 = f8(pre + "road_pts_encoder.mlp.3.weight"), f8(pre + "road_pts_encoder.mlp.3.bias")
+    Wi, bi = f8(pre + "road_pts_attn_layer.in_proj_weight"), f8(pre + "road_pts_attn_layer.in_proj_bias")
+    seed = f8(pre + "map_seeds").reshape(D)
+    q = Wi[:D] @ seed + bi[:D]
+    Wk, bk, Wv, bv = Wi[D:2 * D], bi[D:2 * D], Wi[2 * D:], bi[2 * D:]
+    U = np.zeros((D, H))
+    cb = np.zeros(H)
+    M = np.zeros((D, D))
+    mb = np.zeros(D)
+    sc = 1.0 / np.sqrt(dh)
+    for h in range(H):
+        sl = slice(h * dh, (h + 1) * dh)
+        U[:, h] = (W2.T @ (Wk[sl].T @ q[sl])) * sc
+        cb[h] = (q[sl] @ (Wk[sl] @ b2 + bk[sl])) * sc
+        M[sl, :] = Wv[sl] @ W2
+        mb[sl] = Wv[sl] @ b2 + bv[sl]
+    out["fold.map.U"] = U
+    out["fold.map.cb"] = cb
+    out["fold.map.Mt"] = M.T.copy()
+    out["fold.map.mb"] = mb
+    return {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in out.items()}
+
+
+def pack(dims: Dims, w: dict):
+    """-> (flat float32 ndarray, names list, offsets int64 ndarray in floats)."""
+    allw = dict(w)
+    allw.update(fold(dims, w))
+    names, offsets, chunks = [], [], []
+    off = 0
+    for k, v in allw.items():
+        v = np.ascontiguousarray(v, dtype=np.float32).reshape(-1)
+        pad = (-off) % 64
+        if pad:
+            chunks.append(np.zeros(pad, np.float32))
+            off += pad
+        names.append(k)
+        offsets.append(off)
+        chunks.append(v)
+        off += v.size
+    return np.concatenate(chunks), names, np.asarray(offsets, np.int64)

@@ -1,0 +1,134 @@
+/* ctrlsim.h — C ABI of the MI355X-native CtRL-Sim closed-loop rollout path (libctrlsim_hip.so).
+ *
+ * Conventions: every pointer is a DEVICE pointer owned by the caller (in this repo: torch tensors, data_ptr()),
+ * contiguous, little-endian; every function takes a hipStream_t, enqueues work on it and returns immediately
+ * (0 = OK, negative errno-style code otherwise: -22 invalid argument, -5 launch failure); nothing allocates,
+ * synchronises or throws.  No torch types appear here: the library links only against the HIP runtime.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the reference repository
+ * montrealrobotics/ctrl-sim @ 2024_10_08).  The pybind11 module `nocturne_cpp` (the .cc files under nocturne/pybind11/src) and the
+ * per-vehicle Python dict traffic of evaluators/policy_evaluator.py:99-159,514-542 are what a host binding calls today;
+ * INTEGRATION.md shows the ctypes stub a maintainer adds to call these instead.
+ *
+ * Layouts (S scenarios, N <= 64 vehicles each, A context slots, T context steps, Tq = token_index+1 <= T,
+ * P polylines x NP points per context, P_all polylines per scenario, Tmax rollout steps, Tmax1 = Tmax+1):
+ *   hist_states [S,N,Tmax1,8] f32   x, y, vx, vy, heading, length, width, existence   (policies/policy.py:68-79)
+ *   hist_tok    [S,N,Tmax]    i32   applied action token per step (default ZERO_ACTION_TOKEN = 524)
+ *   hist_rtg    [S,N,Tmax,3]  i32   sampled RTG bins per step (default (0,35,35))
+ *   coll        [S,N,Tmax1,2] u8    vehicle-vehicle / vehicle-road-edge collision flags
+ *   phys        [S,N,20]      f32   Box2D body + FreeCar control state (see csrc/sim.hip)
+ */
+#ifndef CTRLSIM_H
+#define CTRLSIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+typedef struct ctrlsim_dims {
+  int A, T, P, NP, D, H, F, V, R, C, NE, ND, MAXT;
+} ctrlsim_dims;
+
+/* Agent-local context tensors of B contexts (outputs of ctrlsim_build_context, inputs of the forward). */
+typedef struct ctrlsim_ctx {
+  float* st12;       /* [B,Tq,A,12] x,y,vx,vy,yaw,len,wid + 5 type one-hot (-1 on padded slots) */
+  float* exist;      /* [B,Tq,A]                                                                 */
+  float* goal5;      /* [B,A,5]                                                                  */
+  int* act_tok;      /* [B,Tq,A]                                                                 */
+  int* rtg_bin;      /* [B,Tq,A,3]                                                               */
+  int* tstep;        /* [B,Tq]                                                                   */
+  int* slot_gid;     /* [B,A] global vehicle index per slot, -1 = padding                        */
+  float* road_pts;   /* [B,P,NP,3] x,y,exist in the focal frame                                  */
+  float* road_types; /* [B,P,8] one-hot, -1 rows = padding                                       */
+} ctrlsim_ctx;
+
+typedef struct ctrlsim_model ctrlsim_model;
+
+/* ---- simulator step -------------------------------------------------------------------------------------------
+ * Replaces nocturne_cpp Simulation.step(dt) + the per-vehicle setters (nocturne/pybind11/src/simulation.cc:20-38,
+ * object.cc:52-54,89-92, vehicle.cc:20) i.e. Vehicle::set_acceleration/brake/set_steering/set_position,
+ * PhysicsSimulation::Step -> FreeCar::Step + b2World::Step, Vehicle::Step, Scenario::UpdateCollision
+ * (nocturne/cpp/src/vehicle.cc:25-135, physics/FreeCar.cpp:66-186, scenario.cc:266-328), AutoregressivePolicy.act
+ * (policies/autoregressive_policy.py:256-274) and the state read-back of update_vehicle_data_dict
+ * (evaluators/policy_evaluator.py:99-121).  Contact-free tier (no Box2D contact solver). */
+int ctrlsim_sim_init(int S, int N, int E, const float* init_pose /*[S,N,4] x,y,heading,speed*/,
+                     const float* size /*[S,N,2] length,width*/, const float* edges /*[S,E,4]*/,
+                     const uint8_t* exists /*[S,N]*/, float* phys, float* hist_states, uint8_t* coll, int Tmax1,
+                     hipStream_t stream);
+/* act_tok [S,N] (token id, or -1 = zero action) or act_f64 [S,N,2] (accel, steer); disc6 = {min_accel, max_accel,
+ * min_steer, max_steer, n_accel, n_steer}; applied (nullable) [S,N,2] f64 receives the continuous actions.
+ * mode 0 = FreeCar/Box2D (what eval_sim.py executes), 1 = Object::KinematicBicycleStep (object.cc:126-137). */
+int ctrlsim_sim_step(int S, int N, int E, const int* act_tok, const double* act_f64, const double* disc6,
+                     const float* size, const float* edges, const uint8_t* exists, float* phys, float* hist_states,
+                     uint8_t* coll, double* applied, int t, int Tmax1, float dt, int mode, hipStream_t stream);
+
+/* ---- focal grouping + context tensors ------------------------------------------------------------------------
+ * Replaces AutoregressivePolicy.get_data (policies/autoregressive_policy.py:51-165) with
+ * RLWaymoDataset.select_relevant_agents / normalize_scene (datasets/rl_waymo/dataset.py:278-319,390-428). */
+int ctrlsim_group_build(int S, int N, int A, int T, int t, int Tmax1, double dist_thresh, const float* hist_states,
+                        const int* eval_order /*[S,N] -1 padded*/, int has_roads, uint64_t* persist /*[S,N]*/,
+                        int* n_groups /*[S]*/, int* grp_focal /*[S,N]*/, uint64_t* grp_ids, uint64_t* grp_members,
+                        int* own_g /*[S,N]*/, int* mem_g /*[S,N]*/, uint8_t* tilted /*[S,N]*/, hipStream_t stream);
+int ctrlsim_ctx_index(int s0, int s1, int N, const int* n_groups, const int* grp_focal, const uint64_t* grp_ids,
+                      const int* own_g, const int* mem_g, int* ctx_scn, int* ctx_grp, int* own_ctx, int* own_slot,
+                      int* mem_ctx, int* mem_slot, int* ctx_base, hipStream_t stream);
+int ctrlsim_build_context(int B, int N, int A, int T, int t, int Tq, int Tmax1, int Tmax, int P_all, int P, int NP,
+                          const int* ctx_scn, const int* ctx_grp, const int* grp_focal, const uint64_t* grp_ids,
+                          const float* hist_states, const int* hist_tok, const int* hist_rtg,
+                          const double* goals /*[S,N,5]*/, const float* types /*[S,N,5]*/,
+                          const float* roads /*[S,P_all,NP,3]*/, const float* road_types /*[S,P_all,8]*/,
+                          const int* zero4 /*{zero action token, rtg bins x3}*/, const ctrlsim_ctx* out,
+                          hipStream_t stream);
+
+/* ---- model ----------------------------------------------------------------------------------------------------
+ * Replaces CtRLSim.load_from_checkpoint + CtRLSim.forward (models/ctrl_sim.py:19-45; modules/encoder.py,
+ * map_encoder.py, decoder.py) as used by AutoregressivePolicy.predict (autoregressive_policy.py:189-210).
+ * `names`/`offsets` describe the packed fp32 weight buffer (state_dict names + the "fold.*" tensors of
+ * ctrlsim_amd/pack.py). */
+int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_weights, int n, const char* const* names,
+                         const int64_t* offsets, ctrlsim_model** out);
+void ctrlsim_model_destroy(ctrlsim_model* m);
+int64_t ctrlsim_forward_workspace_bytes(const ctrlsim_dims* dims, int B, int Tq);
+/* pass 1: rtg_logits [B,A,R*C] of the current-timestep state tokens; caches per-layer K/V in `workspace`. */
+int ctrlsim_dt_forward_pass1(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* ctx, void* workspace,
+                             float* rtg_logits, float* dbg_seg_emb /*nullable [B,P,D]*/, hipStream_t stream);
+/* pass 2 (same workspace, after ctrlsim_sample_rtg wrote hist_rtg[...,t,:]): act_logits [B,A,V]. */
+int ctrlsim_dt_forward_pass2(const ctrlsim_model* m, int B, int Tq, int t, int N, int Tmax, const ctrlsim_ctx* ctx,
+                             const int* ctx_scn, const int* hist_rtg, void* workspace, float* act_logits,
+                             hipStream_t stream);
+
+/* ---- sampling -------------------------------------------------------------------------------------------------
+ * Replaces Policy.process_predicted_rtg (policies/policy.py:108-142) and the action-sampling block of
+ * AutoregressivePolicy.predict (autoregressive_policy.py:211-240): tilt, softmax, torch.multinomial as an
+ * exponential race with explicit (noise != NULL) or in-kernel counter-based Exp(1) noise. */
+int ctrlsim_sample_rtg(const float* rtg_logits, int A, int R, const int* own_ctx, const int* own_slot,
+                       const uint8_t* tilted, const double* tilt3, const float* noise /*[S*N,3,R] or NULL*/,
+                       uint64_t seed, const int64_t* scenario_id /*[S]*/, int t, int* hist_rtg, int S, int N, int Tmax,
+                       hipStream_t stream);
+int ctrlsim_sample_action(const float* act_logits, int A, int V, const int* mem_ctx, const int* mem_slot,
+                          float temperature, double top_p /*<=0: off*/, const float* noise /*[S*N,V] or NULL*/,
+                          uint64_t seed, const int64_t* scenario_id, int t, int* hist_tok, int* act_now /*[S,N]*/,
+                          int S, int N, int Tmax, int zero_token, hipStream_t stream);
+
+/* ---- building blocks (exported for parity tests and profiling) ------------------------------------------------ */
+int ctrlsim_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr,
+                    float* C, int ldc, int M, int N, int K, int relu, hipStream_t stream);
+int ctrlsim_layernorm256(const float* X, int ldx, const float* Radd, int ldr, const float* gamma, const float* beta,
+                         float* Y, int ldy, int rows, int relu, hipStream_t stream);
+/* mode 0: key padding (key_pad [B,Lk], 1 = ignore); mode 1: CtRL-Sim structured causal mask (utils/train_utils.py:81-129) */
+int ctrlsim_attention(int mode, const float* Q, int ldq, int64_t q_batch_stride, const float* K, const float* V,
+                      int ldkv, int64_t kv_batch_stride, float* O, int ldo, int64_t o_batch_stride, const int* q_pos,
+                      const uint8_t* key_pad, int B, int Lq, int Lk, int A, hipStream_t stream);
+
+const char* ctrlsim_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTRLSIM_H */

@@ -1,0 +1,106 @@
+"""GPU parity of the building-block kernels against plain PyTorch fp32 references (tolerances are fp32 rounding)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from ctrlsim_amd import _lib  # noqa: E402
+import model_oracle as mo  # noqa: E402
+from gpu_utils import DEV, gemm  # noqa: E402
+
+
+@pytest.mark.parametrize("M,N,K,relu,resid", [(128, 128, 256, False, False), (300, 1050, 256, False, False),
+                                              (1000, 768, 256, True, False), (777, 256, 1024, False, True),
+                                              (5000, 32, 256, False, False), (24, 1000, 256, False, False),
+                                              (4097, 512, 512, False, False)])
+def test_gemm_nt(M, N, K, relu, resid):
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    W = (torch.randn(N, K, generator=g) * 0.1).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    R = torch.randn(M, N, generator=g).to(DEV) if resid else None
+    out = gemm(A, W, b, R, relu)
+    ref = (A.double() @ W.double().T + b.double())
+    if resid:
+        ref = ref + R.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    err = (out.double() - ref).abs().max().item()
+    assert err < 5e-5 * math.sqrt(K / 256), err
+    # transpose-detecting: asymmetric W, identity-like A picks columns of W^T
+    A2 = torch.zeros(M, K, device=DEV); A2[torch.arange(M), torch.arange(M) % K] = 1.0
+    out2 = gemm(A2, W, None, None, False)
+    assert torch.equal(out2, W.T[torch.arange(M) % K])
+
+
+def test_layernorm_and_in_place():
+    g = torch.Generator().manual_seed(1)
+    X = torch.randn(1003, 256, generator=g).to(DEV) * 3 + 1
+    R = torch.randn(1003, 256, generator=g).to(DEV)
+    gam = torch.randn(256, generator=g).to(DEV); bet = torch.randn(256, generator=g).to(DEV)
+    Y = torch.empty_like(X)
+    p = _lib.ptr
+    for relu, radd in ((0, None), (1, R)):
+        _lib.check(_lib.lib().ctrlsim_layernorm256(p(X), 256, p(radd), 256, p(gam), p(bet), p(Y), 256, 1003, relu,
+                                                   _lib.stream_ptr()))
+        ref = torch.nn.functional.layer_norm(X + (radd if radd is not None else 0), (256,), gam, bet, 1e-5)
+        if relu:
+            ref = ref.relu()
+        assert (Y - ref).abs().max().item() < 2e-5
+    Z = X.clone()
+    _lib.check(_lib.lib().ctrlsim_layernorm256(p(Z), 256, None, 0, p(gam), p(bet), p(Z), 256, 1003, 0, _lib.stream_ptr()))
+    assert (Z - torch.nn.functional.layer_norm(X, (256,), gam, bet, 1e-5)).abs().max().item() < 2e-5
+
+
+def _attn_ref(q, k, v, vis):  # q [B,H,Lq,32] ... vis bool [B,1|H,Lq,Lk]
+    s = (q.double() @ k.double().transpose(-1, -2)) / math.sqrt(32)
+    s = s.masked_fill(~vis, float("-inf"))
+    return (torch.softmax(s, -1) @ v.double())
+
+
+@pytest.mark.parametrize("A,T", [(24, 32), (4, 4), (6, 8), (24, 7)])
+def test_attention_structured_causal_mask(A, T):
+    B, H = 2, 8
+    L = A * T * 3
+    g = torch.Generator().manual_seed(A * T)
+    qkv = torch.randn(B, L, 768, generator=g).to(DEV)
+    O = torch.zeros(B, L, 256, device=DEV)
+    p = _lib.ptr
+    _lib.check(_lib.lib().ctrlsim_attention(1, p(qkv), 768, L * 768, qkv.data_ptr() + 256 * 4, qkv.data_ptr() + 512 * 4, 768,
+                                            L * 768, p(O), 256, L * 256, None, None, B, L, L, A, _lib.stream_ptr()))
+    q, k, v = [qkv[..., i * 256:(i + 1) * 256].view(B, L, H, 32).transpose(1, 2) for i in range(3)]
+    vis = mo.causal_mask_closed_form(A, T, 3).to(DEV)[None, None]
+    ref = _attn_ref(q, k, v, vis).transpose(1, 2).reshape(B, L, 256)
+    assert (O.double() - ref).abs().max().item() < 2e-5
+    # gathered queries: the A rtg tokens of timestep ti, compact Q/O buffers
+    ti = T - 1
+    pos = torch.tensor([(ti * A + a) * 3 + 1 for a in range(A)], dtype=torch.int32, device=DEV)
+    qc = qkv[:, pos.long(), :].contiguous()
+    Oc = torch.zeros(B, A, 256, device=DEV)
+    _lib.check(_lib.lib().ctrlsim_attention(1, p(qc), 768, A * 768, qkv.data_ptr() + 256 * 4, qkv.data_ptr() + 512 * 4, 768,
+                                            L * 768, p(Oc), 256, A * 256, p(pos), None, B, A, L, A, _lib.stream_ptr()))
+    assert (Oc.double() - ref[:, pos.long()]).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("Lq,Lk", [(224, 224), (2304, 224), (10, 10), (24, 224), (130, 67)])
+def test_attention_key_padding(Lq, Lk):
+    B, H = 3, 8
+    g = torch.Generator().manual_seed(Lq + Lk)
+    Q = torch.randn(B, Lq, 256, generator=g).to(DEV)
+    KV = torch.randn(B, Lk, 512, generator=g).to(DEV)
+    pad = (torch.rand(B, Lk, generator=g) < 0.3)
+    pad[:, 0] = False
+    pad_d = pad.to(torch.uint8).to(DEV)
+    O = torch.zeros(B, Lq, 256, device=DEV)
+    p = _lib.ptr
+    _lib.check(_lib.lib().ctrlsim_attention(0, p(Q), 256, Lq * 256, p(KV), KV.data_ptr() + 256 * 4, 512, Lk * 512, p(O), 256,
+                                            Lq * 256, None, p(pad_d), B, Lq, Lk, 24, _lib.stream_ptr()))
+    q = Q.view(B, Lq, H, 32).transpose(1, 2)
+    k = KV[..., :256].reshape(B, Lk, H, 32).transpose(1, 2)
+    v = KV[..., 256:].reshape(B, Lk, H, 32).transpose(1, 2)
+    vis = (~pad).to(DEV)[:, None, None, :].expand(B, 1, Lq, Lk)
+    ref = _attn_ref(q, k, v, vis).transpose(1, 2).reshape(B, Lq, 256)
+    assert (O.double() - ref).abs().max().item() < 2e-5

@@ -1,0 +1,120 @@
+"""CPU tests of the host side: weight folding algebra, C-ABI library load + exported symbols, chunking, scenarios."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import ROOT
+from helpers import cfg_of
+from ctrlsim_amd import spec, weights, pack, scenarios
+import model_oracle as mo
+import synth_inputs
+
+
+def test_folds_are_exact_in_float64():
+    cfg = cfg_of("tiny")
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    tw = {k: torch.from_numpy(v).double() for k, v in w.items()}
+    f = {k: torch.from_numpy(v).double() for k, v in pack.fold(d, w).items()}
+    inp = synth_inputs.to_torch(synth_inputs.random_context(d, 3, B=2))
+    # ---- state/goal embedding fold
+    ag = inp["agent_states"]
+    B, A, T, _ = ag.shape
+    types = inp["agent_types"].unsqueeze(2).expand(B, A, T, -1)
+    states = torch.cat([ag[..., :-1], types], -1)
+    hs = F.relu(F.layer_norm(F.linear(states, tw["encoder.embed_state.mlp.0.weight"], tw["encoder.embed_state.mlp.0.bias"]),
+                             (d.D,), tw["encoder.embed_state.mlp.1.weight"], tw["encoder.embed_state.mlp.1.bias"], 1e-5))
+    hg = F.relu(F.layer_norm(F.linear(inp["goals"], tw["encoder.embed_goal.mlp.0.weight"], tw["encoder.embed_goal.mlp.0.bias"]),
+                             (d.D,), tw["encoder.embed_goal.mlp.1.weight"], tw["encoder.embed_goal.mlp.1.bias"], 1e-5))
+    s_ref = mo._mlp(states, tw, "encoder.embed_state")
+    g_ref = mo._mlp(inp["goals"], tw, "encoder.embed_goal").unsqueeze(2).expand(B, A, T, -1)
+    ref = mo._linear(torch.cat([s_ref, g_ref], -1), tw, "encoder.embed_state_goal")
+    mine = hs @ f["fold.embed_state.w"].T + (hg @ f["fold.embed_goal.w"].T + f["fold.embed_goal.b"]).unsqueeze(2)
+    assert (ref - mine).abs().max() < 1e-6          # folds are rounded to fp32 once
+    # ---- rtg tables
+    bins = inp["rtgs"].long()
+    cat = torch.cat([F.embedding(bins[..., 0], tw["encoder.embed_rtg_goal.weight"]),
+                     F.embedding(bins[..., 1], tw["encoder.embed_rtg_veh.weight"]),
+                     F.embedding(bins[..., 2], tw["encoder.embed_rtg_road.weight"])], -1)
+    ref = mo._linear(cat, tw, "encoder.embed_rtg")
+    mine = (f["fold.rtg_table_goal"][bins[..., 0]] + f["fold.rtg_table_veh"][bins[..., 1]] +
+            f["fold.rtg_table_road"][bins[..., 2]] + tw["encoder.embed_rtg.bias"])
+    assert (ref - mine).abs().max() < 1e-6
+    # ---- map pooling fold: attention output before out_proj
+    pre = "encoder.map_encoder."
+    rp = inp["road_points"]
+    Bp = rp.shape[0] * rp.shape[1]
+    feats = mo._mlp(rp, tw, pre + "road_pts_encoder").view(Bp, d.NP, -1)
+    exist = rp[..., -1].reshape(Bp, d.NP)
+    mask = (1.0 - exist).bool().clone()
+    mask[:, 0][mask.sum(-1) == d.NP] = False
+    Wi, bi = tw[pre + "road_pts_attn_layer.in_proj_weight"], tw[pre + "road_pts_attn_layer.in_proj_bias"]
+    D = d.D
+    q = F.linear(tw[pre + "map_seeds"].view(1, 1, D).expand(Bp, 1, D), Wi[:D], bi[:D])
+    k = F.linear(feats, Wi[D:2 * D], bi[D:2 * D]); v = F.linear(feats, Wi[2 * D:], bi[2 * D:])
+    dh = D // d.H
+    qh = q.view(Bp, 1, d.H, dh).transpose(1, 2); kh = k.view(Bp, d.NP, d.H, dh).transpose(1, 2)
+    vh = v.view(Bp, d.NP, d.H, dh).transpose(1, 2)
+    s = (qh @ kh.transpose(-1, -2)) / np.sqrt(dh)
+    s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(Bp, D)
+    h1 = F.relu(F.layer_norm(F.linear(rp, tw[pre + "road_pts_encoder.mlp.0.weight"], tw[pre + "road_pts_encoder.mlp.0.bias"]),
+                             (D,), tw[pre + "road_pts_encoder.mlp.1.weight"], tw[pre + "road_pts_encoder.mlp.1.bias"], 1e-5)).view(Bp, d.NP, D)
+    sc = h1 @ f["fold.map.U"] + f["fold.map.cb"]                       # [Bp, NP, H]
+    sc = sc.masked_fill(mask[:, :, None], float("-inf"))
+    a = torch.softmax(sc, 1)
+    pooled = torch.einsum("bph,bpc->bhc", a, h1)                        # [Bp, H, D]
+    M = f["fold.map.Mt"].T
+    mine = torch.stack([pooled[:, j // dh] @ M[j] for j in range(D)], 1) + f["fold.map.mb"]
+    assert (ref - mine).abs().max() < 1e-6
+
+
+def test_pack_alignment_and_names():
+    d = spec.Dims(cfg_of("tiny"))
+    flat, names, offs = pack.pack(d, weights.generate(d, 0))
+    assert all(o % 64 == 0 for o in offs) and len(set(names)) == len(names)
+    assert any(n.startswith("fold.") for n in names) and flat.dtype == np.float32
+
+
+def test_c_abi_library_loads_and_exports_every_declared_symbol():
+    from ctrlsim_amd import _lib
+    from ctrlsim_amd.csrc import build as _b  # noqa: F401  (importable build script)
+    l = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "ctrlsim.h")).read()
+    declared = set(re.findall(r"\b(ctrlsim_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"ctrlsim_dims", "ctrlsim_ctx", "ctrlsim_model"}
+    assert len(declared) >= 16
+    for sym in declared:
+        assert hasattr(l, sym), f"{sym} declared in include/ctrlsim.h but not exported"
+    assert set(_lib.SIGNATURES) == declared
+    assert l.ctrlsim_version().startswith(b"ctrlsim-hip")
+    # invalid-argument paths return errno-style codes without touching a GPU
+    assert l.ctrlsim_forward_workspace_bytes(None, 1, 1) == -22
+
+
+def test_workspace_query_without_gpu():
+    from ctrlsim_amd import _lib
+    from ctrlsim_amd.engine import _dims_struct
+    d = spec.Dims(cfg_of("full"))
+    cd = _dims_struct(d)
+    n1 = _lib.lib().ctrlsim_forward_workspace_bytes(ctypes.byref(cd), 1, 32)
+    n8 = _lib.lib().ctrlsim_forward_workspace_bytes(ctypes.byref(cd), 8, 32)
+    assert 40e6 < n1 < 80e6 and 7.5 * n1 < n8 < 8.5 * n1      # ~ 50 MB of activations + caches per context
+
+
+def test_synthetic_scenarios_are_deterministic_and_well_formed():
+    a = scenarios.make_scenario(3, 5, n_agents=16, n_polylines=40)
+    b = scenarios.make_scenario(3, 5, n_agents=16, n_polylines=40)
+    assert np.array_equal(a.x, b.x) and np.array_equal(a.road_points, b.road_points)
+    assert a.road_points.dtype == np.float32 and a.road_points.shape == (40, 100, 3)
+    assert (a.road_types.sum(1) == 1).all() and a.road_types[:, 3].sum() >= 10        # >= 25 % road edges
+    assert a.edge_segments.shape[1] == 4 and len(a.edge_segments) > 0
+    dx = a.x[:, None] - a.x[None, :]; dy = a.y[:, None] - a.y[None, :]
+    dist = np.sqrt(dx ** 2 + dy ** 2) + np.eye(16) * 1e9
+    assert dist.min() > 4.0
+    assert sorted(a.eval_order.tolist()) == list(range(16))
