@@ -136,10 +136,12 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(
 #pragma unroll
         for (int c = 0; c < 4; ++c) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c], qf[j][c], s, 0, 0, 0);
       }
-      // ---- mask
+      // ---- mask into a separate VGPR array (the MFMA accumulator itself is never edited in place: hipcc 7.2 was seen
+      //      to lose in-place element writes to an AGPR-resident accumulator across the masked/unmasked join)
+      float sc[16];
       if (MODE == MODE_KEYPAD) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] += padbias[sub * 32 + mfma_row(r, half)];
+        for (int r = 0; r < 16; ++r) sc[r] = s[r] + padbias[sub * 32 + mfma_row(r, half)];
       } else if (need_mask) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -149,13 +151,16 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(
           const int aj = rem / 3;
           const int kk = rem - aj * 3;
           const bool vis = (kj < Lk) && ((tj < tq) || (tj == tq && ((aj == aq && kk <= kq) || kk == 0)));
-          if (!vis) s[r] = NEG_INF;
+          sc[r] = vis ? s[r] : NEG_INF;
         }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = s[r];
       }
       // ---- online softmax (one query per lane column; partner lane^32 holds the other 16 keys)
-      float tmax = s[0];
+      float tmax = sc[0];
 #pragma unroll
-      for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+      for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sc[r]);
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
       const float m_new = fmaxf(m_run, tmax);
       const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
@@ -163,8 +168,8 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(
       float psum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s[r] = expf(s[r] - m_use);
-        psum += s[r];
+        sc[r] = expf(sc[r] - m_use);
+        psum += sc[r];
       }
       psum += __shfl_xor(psum, 32, 64);
       l_run = l_run * alpha + psum;
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float vf = vr_[mfma_row(r, half) * KP];
-        oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, s[r], oacc, 0, 0, 0);
+        oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, sc[r], oacc, 0, 0, 0);
       }
     }
     __syncthreads();
