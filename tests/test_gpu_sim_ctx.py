@@ -81,7 +81,8 @@ def test_collision_flags_on_random_boxes():
     exists = torch.ones(S, N, dtype=torch.uint8, device=DEV)
     phys = torch.zeros(S, N, 20, device=DEV); hist = torch.zeros(S, N, 2, 8, device=DEV)
     coll = torch.zeros(S, N, 2, 2, dtype=torch.uint8, device=DEV)
-    _lib.check(lib.ctrlsim_sim_init(S, N, E, p(dev(pose)), p(dev(size)), p(dev(segs)), p(exists), p(phys), p(hist), p(coll), 2, st))
+    tp, ts, tg = dev(pose), dev(size), dev(segs)        # keep the device tensors alive across the async launch
+    _lib.check(lib.ctrlsim_sim_init(S, N, E, p(tp), p(ts), p(tg), p(exists), p(phys), p(hist), p(coll), 2, st))
     torch.cuda.synchronize()
     got = coll.cpu().numpy()[:, :, 0]
     hits = 0
