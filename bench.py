@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""bench.py — closed-loop rollout throughput of the HIP path (agent-steps/s), one process per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One bench "step" = one complete closed-loop rollout (default 90 simulator steps) of this rank's batch of S synthetic
+Waymo-shaped scenarios (64 vehicles, 512 road polylines x 100 points, CtRL-Sim base model with random-init weights):
+policy inference (focal grouping, context build, two-pass transformer, sampling) + simulator step + collision flags +
+history update, everything resident in HBM (inputs are uploaded before the timed region).  Scenarios are independent,
+so ranks shard them with no data-path collective (weak scaling: S per GPU fixed); the only collective is one
+all-reduce of the metric accumulators after the rollouts.
+
+Printed by rank 0: ONE JSON line (metric, value = whole-job agent-steps/s, roofline of the dominant kernel measured
+with HIP events on the launch stream during the timed region, cpu_baseline = the CPU oracle timed on this box).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scenarios", type=int, default=32, help="scenarios per GPU per rollout")
+    ap.add_argument("--agents", type=int, default=64)
+    ap.add_argument("--polylines", type=int, default=512)
+    ap.add_argument("--rollout-steps", type=int, default=90)
+    ap.add_argument("--max-ctx", type=int, default=256, help="model batch (contexts per forward chunk)")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--tilt", type=float, nargs=3, default=(0.0, 0.0, 0.0))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    device = f"cuda:{local_rank}"
+    torch.cuda.set_device(device)
+
+    import ctrlsim_amd  # noqa: F401
+    from ctrlsim_amd import spec, weights, scenarios, metrics, _lib
+    from ctrlsim_amd.engine import RolloutEngine
+
+    cfg = spec.make_cfg(nocturne__steps=args.rollout_steps, nocturne__history_steps=1)
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    S, N, R = args.scenarios, args.agents, args.rollout_steps
+    # global scenario ids: interleaved over ranks (rank r takes r, r+W, ...) so results do not depend on W
+    ids = [rank + i * world for i in range(S)]
+    scns = scenarios.make_batch(args.seed, ids, n_agents=N, n_polylines=args.polylines)
+    eng = RolloutEngine(cfg, w, device, max_ctx=args.max_ctx, seed=args.seed, tilt=tuple(args.tilt))
+    eng.load_scenarios(scns, steps=R)
+    lib = _lib.lib()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.reset()
+        eng.run(R)
+    barrier()
+    lib.ctrlsim_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.reset()
+        eng.run(R)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ms = (C.c_double * 2)(); cnt = (C.c_int64 * 2)(); fl = (C.c_double * 2)()
+    _lib.check(lib.ctrlsim_prof_collect(ms, cnt, fl), "prof_collect")
+    lib.ctrlsim_prof_enable(0)
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+    elapsed = float(t_el.item())
+
+    # ---- metrics: one packed all-reduce (the only collective of the job)
+    res = eng.results()
+    acc = metrics.MetricAccumulators()
+    for i, scn in enumerate(scns):
+        st = res["states"][i].astype(np.float64)
+        T1 = st.shape[1]
+        tt = np.arange(T1)[None, :] * cfg.nocturne.dt
+        sp, hd = scn.speed.astype(np.float64)[:, None], scn.heading.astype(np.float64)[:, None]
+        gt = np.stack([scn.x[:, None] + sp * np.cos(hd) * tt, scn.y[:, None] + sp * np.sin(hd) * tt,
+                       np.broadcast_to(hd, (N, T1)), np.broadcast_to(sp, (N, T1)), np.ones((N, T1))], -1)
+        tok = res["tokens"][i]
+        accel = np.concatenate([(tok // d.NS) / (d.NA - 1) * 20.0 - 10.0, np.zeros((N, 1))], 1)
+        acc.add_scenario(st, res["coll"][i], accel, gt, scn.goal_pos.astype(np.float64),
+                         scn.goal_heading.astype(np.float64), scn.goal_speed.astype(np.float64), cfg)
+    vec = torch.from_numpy(acc.pack()).to(device)
+    if dist is not None:
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+    acc.unpack(vec.cpu().numpy())
+
+    if rank == 0:
+        agent_steps = S * N * R * args.steps * world
+        value = agent_steps / elapsed
+        ctx_per_rollout = int(res["n_groups"].sum())
+        dom = 0 if ms[0] >= ms[1] else 1
+        names = ("gemm_nt_f32_kernel (f32 MFMA 32x32x2, all Linear layers)",
+                 "attention_f32_kernel (f32 MFMA flash attention)")
+        roof = {"bound": "mfma", "kernel": names[dom], "achieved": fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else None,
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "traffic": None,
+                "avg_launch_ms": ms[dom] / max(cnt[dom], 1), "launches": int(cnt[dom]),
+                "time_share_of_step": ms[dom] * 1e-3 / elapsed,
+                "other": {"kernel": names[1 - dom], "achieved": fl[1 - dom] / (ms[1 - dom] * 1e-3) / 1e12 if ms[1 - dom] > 0 else None,
+                          "avg_launch_ms": ms[1 - dom] / max(cnt[1 - dom], 1), "launches": int(cnt[1 - dom]),
+                          "time_share_of_step": ms[1 - dom] * 1e-3 / elapsed}}
+        roof["frac"] = roof["achieved"] / roof["peak"] if roof["achieved"] else None
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(cfg, w, scns[0], args)
+        m, _ = acc.compute()
+        out = {
+            "metric": "agent-steps/sec (closed-loop rollout), 64 agents x 90 steps",
+            "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{S} synthetic Waymo-shaped scenarios per GPU x {N} agents x {R} steps, "
+                                   f"{args.polylines} road polylines x 100 points, CtRL-Sim base model (8.29M params, "
+                                   f"random init), context A=24/T=32/P=200 (BASELINE.json configs[2] shape; "
+                                   f"S per GPU reduced from 2048 so the default run finishes in minutes)",
+                       "scenarios_per_gpu": S, "agents": N, "rollout_steps": R, "polylines": args.polylines,
+                       "model_batch_contexts": args.max_ctx, "contexts_per_rollout_rank0": ctx_per_rollout,
+                       "mean_focal_groups_per_scenario_step": ctx_per_rollout / (S * R),
+                       "parallelism": f"scenario-sharded x{world}"},
+            "roofline": roof, "cpu_baseline": cpu,
+            "rollout_metrics": {k: (None if v != v else v) for k, v in m.items()},
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, w, scn, args):
+    """The CPU oracle (reference cost structure: two dense B=1 forwards per focal group and step, C physics) on the
+    host cores of this box, on a bounded sample of the same workload."""
+    import rollout_oracle
+    import sim_libs
+    sim_libs.build_oracle()
+    cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 64))
+    ro = rollout_oracle.RolloutOracle(cfg, w, seed=args.seed, threads=threads)
+    k = args.cpu_sample_steps
+    t0 = time.perf_counter()
+    o = ro.run(scn, k, sim_libs.OracleSim)
+    el = time.perf_counter() - t0
+    return {"value": scn.N * k / el, "unit": "agent-steps/s", "cores": threads, "kind": "port",
+            "sample": f"1 scenario x {scn.N} agents x {k} rollout steps ({int(o['n_groups'].sum())} focal-group steps, "
+                      f"{el:.1f} s); oracle/rollout_oracle.py + oracle/sim_oracle.c, torch {torch.__version__} CPU, "
+                      f"{threads} threads"}
+
+
+if __name__ == "__main__":
+    main()

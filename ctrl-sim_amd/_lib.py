@@ -30,6 +30,8 @@ U64 = C.c_uint64
 
 SIGNATURES = {
     "ctrlsim_version": (C.c_char_p, []),
+    "ctrlsim_prof_enable": (None, [I]),
+    "ctrlsim_prof_collect": (I, [P, P, P]),
     "ctrlsim_gemm_nt": (I, [P, I, P, I, P, P, I, P, I, I, I, I, I, P]),
     "ctrlsim_layernorm256": (I, [P, I, P, I, P, P, P, I, I, I, P]),
     "ctrlsim_attention": (I, [I, P, I, L, P, P, I, L, P, I, L, P, P, I, I, I, I, P]),

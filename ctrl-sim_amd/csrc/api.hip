@@ -25,7 +25,48 @@ int launch_sample_rtg(const float*, int, int, const int*, const int*, const unsi
 int launch_sample_action(const float*, int, int, const int*, const int*, float, double, const float*, uint64_t,
                          const int64_t*, int, int*, int*, int, int, int, int, hipStream_t);
 
+#include <vector>
+namespace {
+struct ProfRec { hipEvent_t a, b; int cls; double flops; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_recs;
+std::vector<hipEvent_t> g_pool;
+hipEvent_t g_pending[PROF_CLASSES];
+hipEvent_t take_event() {
+  if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+  hipEvent_t e; hipEventCreate(&e); return e;
+}
+}  // namespace
+void prof_before(int cls, hipStream_t st) {
+  if (!g_prof_on) return;
+  g_pending[cls] = take_event();
+  hipEventRecord(g_pending[cls], st);
+}
+void prof_after(int cls, double flops, hipStream_t st) {
+  if (!g_prof_on) return;
+  hipEvent_t b = take_event();
+  hipEventRecord(b, st);
+  g_recs.push_back(ProfRec{g_pending[cls], b, cls, flops});
+}
+
 extern "C" {
+
+// enable/disable event timing; enabling clears previous records
+void ctrlsim_prof_enable(int on) {
+  for (auto& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
+  g_recs.clear();
+  g_prof_on = on != 0;
+}
+// after the caller synchronised the stream(s): per class total milliseconds, launch count, algorithmic FLOPs
+int ctrlsim_prof_collect(double* ms, int64_t* count, double* flops) {
+  for (int c = 0; c < PROF_CLASSES; ++c) { ms[c] = 0; count[c] = 0; flops[c] = 0; }
+  for (auto& r : g_recs) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return CTRLSIM_ELAUNCH;
+    ms[r.cls] += t; count[r.cls] += 1; flops[r.cls] += r.flops;
+  }
+  return CTRLSIM_OK;
+}
 
 const char* ctrlsim_version(void) { return "ctrlsim-hip 0.1 (gfx950)"; }
 

@@ -209,6 +209,20 @@ int launch_attention(int mode, const float* Q, int ldq, long q_batch_stride, con
   if (Lk <= 0 || (ldq & 3) || (ldkv & 3)) return CTRLSIM_EINVAL;
   dim3 g((Lq + 127) / 128, NHEAD, B), blk(256);
   const float scale = 0.17677669529663687f;  // 1/sqrt(32)
+  // algorithmic FLOPs: (QK^T + PV) = 4*32 per visible (query, key) pair and head
+  double pairs;
+  if (mode == MODE_CAUSAL) {
+    const double A3 = 3.0 * A;
+    if (!q_pos) {   // all Lq = Lk tokens: per timestep block of A3 queries, keys of earlier steps + in-step pattern
+      const double T = (double)Lq / A3;
+      pairs = A3 * A3 * T * (T - 1) / 2.0 + T * A * (1.0 * (1 + A - 1) + (2 + A - 1) + (3 + A - 1));
+    } else {        // gathered current-timestep tokens: bounded by the keys up to and including their timestep
+      pairs = (double)Lq * (double)Lk;
+    }
+  } else {
+    pairs = (double)Lq * (double)Lk;
+  }
+  prof_before(PROF_ATTN, st);
   if (mode == MODE_CAUSAL) {
     hipLaunchKernelGGL((attention_f32_kernel<MODE_CAUSAL>), g, blk, 0, st, Q, ldq, q_batch_stride, K, V, ldkv,
                        kv_batch_stride, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale);
@@ -217,5 +231,6 @@ int launch_attention(int mode, const float* Q, int ldq, long q_batch_stride, con
     hipLaunchKernelGGL((attention_f32_kernel<MODE_KEYPAD>), g, blk, 0, st, Q, ldq, q_batch_stride, K, V, ldkv,
                        kv_batch_stride, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale);
   }
+  prof_after(PROF_ATTN, pairs * 128.0 * NHEAD * B, st);
   return ctrlsim_launch_status();
 }

@@ -43,3 +43,10 @@ __device__ __host__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
+
+// ---- optional per-launch HIP-event timing of the two MFMA kernel classes (bench.py's roofline numbers).
+// Disabled by default (zero overhead); when enabled every GEMM / attention launch is bracketed by two events on the
+// launch stream and tagged with its algorithmic FLOPs; nothing synchronises until ctrlsim_prof_collect().
+enum { PROF_GEMM = 0, PROF_ATTN = 1, PROF_CLASSES = 2 };
+void prof_before(int cls, hipStream_t st);
+void prof_after(int cls, double flops, hipStream_t st);

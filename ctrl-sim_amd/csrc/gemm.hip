@@ -208,6 +208,7 @@ int launch_gemm_nt(const float* A, int lda, const float* W, int ldw, const float
   const int m_tiles = (M + BM - 1) / BM, n_tiles = (N + BN - 1) / BN;
   const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
   dim3 g(grid), b(256);
+  prof_before(PROF_GEMM, st);
   if (R) {
     if (relu) return CTRLSIM_EINVAL;
     hipLaunchKernelGGL((gemm_nt_f32_kernel<false, true>), g, b, 0, st, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K,
@@ -219,6 +220,7 @@ int launch_gemm_nt(const float* A, int lda, const float* W, int ldw, const float
     hipLaunchKernelGGL((gemm_nt_f32_kernel<false, false>), g, b, 0, st, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N,
                        K, m_tiles, n_tiles);
   }
+  prof_after(PROF_GEMM, 2.0 * (double)M * (double)N * (double)K, st);
   return ctrlsim_launch_status();
 }
 

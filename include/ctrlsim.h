@@ -126,6 +126,12 @@ int ctrlsim_attention(int mode, const float* Q, int ldq, int64_t q_batch_stride,
                       int ldkv, int64_t kv_batch_stride, float* O, int ldo, int64_t o_batch_stride, const int* q_pos,
                       const uint8_t* key_pad, int B, int Lq, int Lk, int A, hipStream_t stream);
 
+/* ---- measurement hooks (bench.py): HIP-event timing of every GEMM (class 0) / attention (class 1) launch on its own
+ * launch stream.  enable(1) clears and starts recording; after the caller synchronised, collect() returns per class the
+ * summed milliseconds, the launch count and the algorithmic FLOPs (2*M*N*K; 128 per visible (query,key) pair and head). */
+void ctrlsim_prof_enable(int on);
+int ctrlsim_prof_collect(double* ms2, int64_t* count2, double* flops2);
+
 const char* ctrlsim_version(void);
 
 #ifdef __cplusplus
