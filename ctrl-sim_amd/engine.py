@@ -106,13 +106,13 @@ def ctx_from_reference_layout(d: Dims, data: dict, Tq: int, device):
 
 class RolloutEngine:
     def __init__(self, cfg, weights: dict, device="cuda:0", max_ctx=256, seed=0, tilt=(0.0, 0.0, 0.0),
-                 temperature=None, nucleus=None, top_p=None, kinematic=False):
+                 temperature=None, nucleus=None, top_p=None, kinematic=False, model=None):
         self.cfg = cfg
         self.w = cfg.dataset.waymo
         self.dims = Dims(cfg)
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
-        self.model = HipModel(cfg, weights, device)
+        self.model = model if model is not None else HipModel(cfg, weights, device)
         self.lib = self.model.lib
         pol = cfg.eval.policy
         self.temperature = float(pol.action_temperature if temperature is None else temperature)
@@ -216,7 +216,20 @@ class RolloutEngine:
         return [c for c in chunks if c[1] > c[0]]
 
     def step(self, t, noise_rtg=None, noise_act=None):
-        """noise_rtg [S,N,3,R] / noise_act [S,N,V] float32 tensors (explicit Exp(1) noise) or None (in-kernel)."""
+        """One closed-loop step: policy (grouping, contexts, two-pass model, sampling) then the simulator step.
+        noise_rtg [S,N,3,R] / noise_act [S,N,V] float32 tensors (explicit Exp(1) noise) or None (in-kernel)."""
+        self.policy_step(t, noise_rtg, noise_act)
+        self.sim_step(t)
+
+    def sim_step(self, t, act_f64=None):
+        lib, p, st = self.lib, _lib.ptr, _lib.stream_ptr()
+        _lib.check(lib.ctrlsim_sim_step(self.S, self.N, self.E, p(self.act_now) if act_f64 is None else None,
+                                        p(act_f64) if act_f64 is not None else None, self.disc6, p(self.size), p(self.edges),
+                                        p(self.exists), p(self.phys), p(self.hist_states), p(self.coll), None, t,
+                                        self.steps + 1, self.dt, self.kinematic, st), "sim_step")
+
+    def policy_step(self, t, noise_rtg=None, noise_act=None):
+        """AutoregressivePolicy.predict for every scenario: writes hist_rtg[..., t, :], hist_tok[..., t], act_now."""
         lib, p, st, d = self.lib, _lib.ptr, _lib.stream_ptr(), self.dims
         S, N, Tmax = self.S, self.N, self.steps
         _lib.check(lib.ctrlsim_group_build(S, N, d.A, d.T, t, Tmax + 1, float(self.w.agent_dist_threshold),
@@ -261,9 +274,6 @@ class RolloutEngine:
                                                  p(noise_act[sl]) if noise_act is not None else None, self.seed,
                                                  p(self.scenario_id[sl]), t, p(self.hist_tok[sl]), p(self.act_now[sl]),
                                                  ns, N, Tmax, ZERO_ACTION_TOKEN, st), "sample_action")
-        _lib.check(lib.ctrlsim_sim_step(S, N, self.E, p(self.act_now), None, self.disc6, p(self.size), p(self.edges),
-                                        p(self.exists), p(self.phys), p(self.hist_states), p(self.coll), None, t,
-                                        Tmax + 1, self.dt, self.kinematic, st), "sim_step")
 
     def run(self, steps=None, noise_fn=None):
         """Roll all loaded scenarios `steps` steps.  noise_fn(t) -> (noise_rtg, noise_act) or None."""

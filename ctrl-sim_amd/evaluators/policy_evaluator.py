@@ -1,0 +1,206 @@
+"""`PolicyEvaluator(cfg, policy).evaluate_policy() -> (metrics_dict, [str])` — the rollout driver of the plugin surface
+(reference: evaluators/policy_evaluator.py:27-595, evaluators/evaluator.py:24-193, utils/sim.py:83-141).
+
+The per-scenario loop is the reference's (update_vehicle_data_dict -> policy.update_state -> policy.predict ->
+policy.act / apply_gt_action -> sim.step -> update_running_statistics -> compute_metrics) with the same dict schema
+(policy_evaluator.py:70-96), so a `Policy` written against the reference runs here unchanged.  Differences, all forced
+by the environment: scenarios come from `cfg.eval.synthetic` (no Nocturne JSON / preprocessed pickles exist here) and
+"ground truth" is the constant-velocity extrapolation of the initial state; the simulator is
+`ctrlsim_amd.simulation.Simulation` (HIP kernels) instead of the pybind `nocturne_cpp` module."""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+import torch
+
+from .. import scenarios as _scn
+from ..kinematics import bicycle_backward, angle_sub
+from ..metrics import MetricAccumulators
+from ..simulation import Simulation, CollisionType
+
+
+class PolicyEvaluator:
+    def __init__(self, cfg, policy):
+        self.cfg = cfg
+        self.cfg_rl_waymo = cfg.dataset.waymo
+        self.steps = cfg.nocturne.steps
+        self.dt = cfg.nocturne.dt
+        self.history_steps = cfg.nocturne.history_steps
+        self.policy = policy
+        self.vehicles_to_evaluate = None
+        syn = cfg.eval.get("synthetic") or dict(num_scenarios=1, n_agents=8, n_polylines=40, seed=0, extent=60.0)
+        self.synthetic = dict(syn)
+        self.reset()
+
+    def reset(self):
+        seed = self.cfg.eval.seed
+        random.seed(seed)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        self.acc = MetricAccumulators()
+
+    # ---- policy_evaluator.py:70-96
+    def initialize_vehicle_data_dict(self, veh, goal_dict):
+        return {"gt_position": [], "gt_speed": [], "gt_heading": [], "gt_acceleration": [], "gt_nearest_dist": [],
+                "position": [], "velocity": [], "heading": [], "nearest_dist": [], "existence": [], "acceleration": [],
+                "steering": [], "reward": [], "dense_reward": [],
+                "goal_position": {"x": goal_dict["pos"][0], "y": goal_dict["pos"][1]},
+                "goal_heading": goal_dict["heading"], "goal_speed": goal_dict["speed"], "width": veh.getWidth(),
+                "length": veh.getLength(), "type": "vehicle", "timestep": [], "rtgs": [], "next_acceleration": 0.,
+                "next_steering": 0.}
+
+    # ---- utils/sim.py:83-141
+    def compute_reward(self, veh, goal, goal_dist_normalizer, d):
+        rew_cfg = self.cfg.nocturne.rew_cfg
+        pos = np.array([veh.position.x, veh.position.y])
+        prev = len(d["reward"]) > 0 and d["reward"][-1][0]
+        pos_t = float(True) if prev else float(np.linalg.norm(goal["pos"] - pos) < rew_cfg["position_target_tolerance"])
+        spd_t = float(np.abs(goal["speed"] - veh.speed) < rew_cfg["speed_target_tolerance"])
+        hd_t = float(np.abs(angle_sub(goal["heading"], veh.heading)) < rew_cfg["heading_target_tolerance"])
+        sc, rs = rew_cfg.get("shaped_goal_distance_scaling", 1.0), rew_cfg["reward_scaling"]
+        norm = goal_dist_normalizer if goal_dist_normalizer != 0.0 else 1.0
+        pos_r = sc / rs if prev else sc * (1 - np.linalg.norm(goal["pos"] - pos) / norm) / rs
+        spd_r = sc * (1 - np.abs(veh.speed - goal["speed"]) / 40.0) / rs
+        hd_r = sc * (1 - np.abs(angle_sub(veh.heading, goal["heading"])) / (2 * np.pi)) / rs
+        return [pos_t, hd_t, spd_t, pos_r, spd_r, hd_r, float(veh.collision_type_veh == CollisionType.VEHICLE_VEHICLE),
+                float(veh.collision_type_edge == CollisionType.VEHICLE_ROAD)]
+
+    # ---- policy_evaluator.py:99-159 (real_time_rewards=False branch)
+    def update_vehicle_data_dict(self, t, vehicles, vdd, goal_dict, goal_norm, gt_data_dict):
+        for veh in vehicles:
+            v = veh.getID()
+            gt = np.array(gt_data_dict[v]["traj"])
+            d = vdd[v]
+            d["gt_position"].append({"x": gt[t, 0], "y": gt[t, 1]})
+            d["gt_heading"].append(gt[t, 2])
+            d["gt_speed"].append(gt[t, 3])
+            d["gt_acceleration"].append((gt[t + 1, 3] - gt[t - 1, 3]) / (2 * self.dt) if 0 < t < self.steps - 1 else 0)
+            d["position"].append({"x": veh.getPosition().x, "y": veh.getPosition().y})
+            d["velocity"].append({"x": veh.velocity().x, "y": veh.velocity().y})
+            d["heading"].append(veh.getHeading())
+            d["timestep"].append(t)
+            ex = gt[t, 4]
+            if t > 0 and d["existence"][-1] == 0:
+                ex = 0
+            d["existence"].append(ex)
+            d["reward"].append(self.compute_reward(veh, goal_dict[v], goal_norm[v], d))
+        ids = list(vdd.keys())
+        pos = np.array([[vdd[v]["position"][t]["x"], vdd[v]["position"][t]["y"]] for v in ids])
+        gpos = np.array([[vdd[v]["gt_position"][t]["x"], vdd[v]["gt_position"][t]["y"]] for v in ids])
+        ex = np.array([vdd[v]["existence"][t] for v in ids], float)
+        from ..metrics import nearest_vehicle_distance
+        nd = nearest_vehicle_distance(pos[:, None], ex[:, None])[:, 0]
+        gnd = nearest_vehicle_distance(gpos[:, None], ex[:, None])[:, 0]
+        for i, v in enumerate(ids):
+            vdd[v]["nearest_dist"].append(nd[i])
+            vdd[v]["gt_nearest_dist"].append(gnd[i])
+        return vdd
+
+    # ---- evaluators/evaluator.py:160-193
+    def apply_gt_action(self, veh, t, gt_data_dict, vdd):
+        v = veh.getID()
+        traj = gt_data_dict[v]["traj"]
+        exists = traj[t][4] and traj[t + 1][4]
+        if t > 0 and vdd[v]["existence"][-1] == 0:
+            exists = 0
+        if not exists:
+            a, s = 0.0, 0.0
+            veh.setPosition(-1000000, -1000000)
+        else:
+            nxt = np.array([[traj[t + 1][0], traj[t + 1][1], traj[t + 1][2], traj[t + 1][3], traj[t + 1][-1]]])
+            prev = np.array([[veh.getPosition().x, veh.getPosition().y, veh.getHeading(), veh.getSpeed()]])
+            a, s = bicycle_backward(nxt, prev, self.dt)
+            a, s = float(a[0]), float(s[0])
+        if a > 0.0:
+            veh.acceleration = a
+        else:
+            veh.brake(np.abs(a))
+        veh.steering = s
+        return veh, [a, s]
+
+    def _ground_truth(self, scn):
+        """Constant-velocity extrapolation as the stand-in expert log: traj rows = x, y, heading, speed, exist, length."""
+        T1 = self.steps + 1
+        tt = np.arange(T1)[:, None] * self.dt
+        out = {}
+        for i in range(scn.N):
+            sp, hd = float(scn.speed[i]), float(scn.heading[i])
+            tr = np.zeros((T1, 6))
+            tr[:, 0] = scn.x[i] + sp * np.cos(hd) * tt[:, 0]
+            tr[:, 1] = scn.y[i] + sp * np.sin(hd) * tt[:, 0]
+            tr[:, 2], tr[:, 3], tr[:, 4], tr[:, 5] = hd, sp, 1.0, scn.length[i]
+            out[i] = {"traj": tr}
+        return out
+
+    def evaluate_policy(self):
+        self.reset()
+        syn = self.synthetic
+        d_model = self.policy.model.dims
+        for k in range(int(syn["num_scenarios"])):
+            scn = _scn.make_scenario(int(syn.get("seed", 0)), k, n_agents=int(syn["n_agents"]),
+                                     n_polylines=int(syn["n_polylines"]), n_points=d_model.NP,
+                                     extent=float(syn.get("extent", 100.0)))
+            self.policy.scenario_index = scn.index
+            gt_data_dict = self._ground_truth(scn)
+            sim = Simulation(scn, device=self.policy.model.device, steps=self.steps, dt=self.dt)
+            vehicles = sim.getScenario().vehicles()
+            for veh in vehicles:
+                veh.expert_control = False
+                veh.physics_simulated = True
+            moving = [veh.getID() for veh in vehicles]
+            thr = self.cfg.eval.multi_agent_eval_threshold
+            self.vehicles_to_evaluate = random.sample(moving, thr) if len(moving) > thr else moving
+            preproc_data = {"road_points": scn.road_points.astype(np.float64), "road_types": scn.road_types.copy()}
+            vdd, goal_dict, goal_norm = {}, {}, {}
+            for veh in vehicles:
+                v = veh.getID()
+                goal_dict[v] = {"pos": scn.goal_pos[v].astype(np.float64), "heading": float(scn.goal_heading[v]),
+                                "speed": float(scn.goal_speed[v])}
+                vdd[v] = self.initialize_vehicle_data_dict(veh, goal_dict[v])
+                goal_norm[v] = np.linalg.norm(np.array([veh.getPosition().x, veh.getPosition().y]) - goal_dict[v]["pos"])
+            self.policy.reset(vdd)
+            for t in range(self.steps):
+                vdd = self.update_vehicle_data_dict(t, vehicles, vdd, goal_dict, goal_norm, gt_data_dict)
+                self.policy.update_state(vdd, self.vehicles_to_evaluate, t)
+                vdd = self.policy.predict(vdd, gt_data_dict, preproc_data, None, self.vehicles_to_evaluate, t)
+                for veh in vehicles:
+                    v = veh.getID()
+                    if t >= self.history_steps - 1 and v in self.vehicles_to_evaluate:
+                        veh, act = self.policy.act(veh, t, vdd)
+                    else:
+                        veh, act = self.apply_gt_action(veh, t, gt_data_dict, vdd)
+                    vdd[v]["acceleration"].append(act[0])
+                    vdd[v]["steering"].append(act[1])
+                sim.step(self.dt)
+            vdd = self.update_vehicle_data_dict(self.steps, vehicles, vdd, goal_dict, goal_norm, gt_data_dict)
+            for veh in vehicles:
+                vdd[veh.getID()]["acceleration"].append(0)
+                vdd[veh.getID()]["steering"].append(0)
+            self.last_vehicle_data_dict = vdd
+            self.update_running_statistics(vdd, scn, gt_data_dict)
+        return self.compute_metrics()
+
+    # ---- policy_evaluator.py:162-248 on arrays
+    def update_running_statistics(self, vdd, scn, gt_data_dict):
+        ids = list(vdd.keys())
+        T1 = self.steps + 1
+        st = np.zeros((len(ids), T1, 8))
+        coll = np.zeros((len(ids), T1, 2))
+        accel = np.zeros((len(ids), T1))
+        gt = np.zeros((len(ids), T1, 5))
+        for i, v in enumerate(ids):
+            d = vdd[v]
+            st[i, :, 0] = [p["x"] for p in d["position"]]; st[i, :, 1] = [p["y"] for p in d["position"]]
+            st[i, :, 2] = [p["x"] for p in d["velocity"]]; st[i, :, 3] = [p["y"] for p in d["velocity"]]
+            st[i, :, 4] = d["heading"]; st[i, :, 7] = d["existence"]
+            r = np.array(d["reward"])
+            coll[i] = r[:, 6:8]
+            accel[i] = d["acceleration"]
+            tr = gt_data_dict[v]["traj"]
+            gt[i] = tr[:, [0, 1, 2, 3, 4]]
+        self.acc.add_scenario(st, coll, accel, gt, scn.goal_pos.astype(np.float64), scn.goal_heading.astype(np.float64),
+                              scn.goal_speed.astype(np.float64), self.cfg, eval_ids=[ids.index(v) for v in self.vehicles_to_evaluate])
+
+    def compute_metrics(self):
+        return self.acc.compute()

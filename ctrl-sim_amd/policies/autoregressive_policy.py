@@ -1,0 +1,129 @@
+"""`AutoregressivePolicy` — drop-in for the reference's policies/autoregressive_policy.py:9-274, backed by the HIP path.
+
+Same constructor, `predict(vehicle_data_dict, gt_data_dict, preproc_data, dset, vehicles_to_evaluate, t)` and
+`act(veh, t, vehicle_data_dict)` contracts: predict sets `next_acceleration` / `next_steering` / `next_rtg_*` and
+appends to the `rtgs` list of every vehicle; act drives a vehicle handle exposing getID / setPosition / .acceleration=
+/ brake() / .steering= (the pybind Vehicle surface, nocturne/pybind11/src/object.cc:33-99, vehicle.cc:19-21).
+
+What happens inside predict is not the reference's NumPy + per-group model calls: the host buffers of `Policy` are
+mirrored into a one-scenario device session and the whole of get_data / two-pass model / sampling runs as the kernel
+sequence of `ctrlsim_amd.engine.RolloutEngine.policy_step` (focal grouping, context build, forward pass 1, RTG race,
+forward pass 2, action race).  Sampling noise is the counter-based Exp(1) stream keyed by
+(cfg.eval.seed, scenario index, t, vehicle index, head) instead of torch's global generator.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .policy import Policy
+from .. import discretize as dz
+from ..scenarios import Scenario
+
+
+class AutoregressivePolicy(Policy):
+    def __init__(self, cfg, model_path, model, use_rtg, predict_rtgs, discretize_rtgs, real_time_rewards,
+                 privileged_return, max_return, min_return, key_dict, tilt_dict, name, action_temperature,
+                 nucleus_sampling, nucleus_threshold):
+        super().__init__(cfg, model_path, model, use_rtg, predict_rtgs, discretize_rtgs, real_time_rewards,
+                         privileged_return, max_return, min_return, key_dict, tilt_dict, name)
+        self.action_temperature = action_temperature
+        self.nucleus_sampling = nucleus_sampling
+        self.nucleus_threshold = nucleus_threshold
+        if tilt_dict["tilt"]:
+            self.goal_tilt = tilt_dict["goal_tilt"]
+            self.veh_veh_tilt = tilt_dict["veh_veh_tilt"]
+            self.veh_edge_tilt = tilt_dict["veh_edge_tilt"]
+        if not (use_rtg and predict_rtgs and discretize_rtgs) or real_time_rewards:
+            raise NotImplementedError("the HIP path implements the CtRL-Sim variant (cfgs/policy/ctrl_sim.yaml): "
+                                      "use_rtg, predict_rtgs, discretize_rtgs, no real_time_rewards")
+        self._session = None
+        self.scenario_index = 0
+
+    # ------------------------------------------------------------------ device session
+    def _open_session(self, vehicle_data_dict, preproc_data, gt_data_dict, vehicles_to_evaluate):
+        from ..engine import RolloutEngine
+        ids = list(vehicle_data_dict.keys())
+        n = len(ids)
+        f32 = lambda a: np.asarray(a, np.float32)
+        d0 = [vehicle_data_dict[v] for v in ids]
+        # processing order of the vehicles to evaluate: decreasing ground-truth length (autoregressive_policy.py:88-94)
+        lengths = [int(np.array(gt_data_dict[v]["traj"])[:, 4].sum()) for v in vehicles_to_evaluate]
+        order = list(np.array(vehicles_to_evaluate)[np.argsort(np.array(lengths))[::-1]])
+        eval_order = np.array([self.veh_id_to_idx[v] for v in order], np.int32)
+        rp = np.asarray(preproc_data["road_points"])
+        scn = Scenario(index=self.scenario_index, length=f32([d["length"] for d in d0]), width=f32([d["width"] for d in d0]),
+                       x=f32([d["position"][0]["x"] for d in d0]), y=f32([d["position"][0]["y"] for d in d0]),
+                       heading=f32([d["heading"][0] for d in d0]), speed=f32(np.zeros(n)),
+                       goal_pos=f32([[d["goal_position"]["x"], d["goal_position"]["y"]] for d in d0]),
+                       goal_heading=f32([d["goal_heading"] for d in d0]), goal_speed=f32([d["goal_speed"] for d in d0]),
+                       types=self.types.copy(), road_points=f32(rp), road_types=np.asarray(preproc_data["road_types"], np.float64),
+                       edge_segments=np.zeros((0, 4), np.float32), eval_order=eval_order)
+        tilt = (self.goal_tilt, self.veh_veh_tilt, self.veh_edge_tilt) if self.tilt_dict["tilt"] else (0.0, 0.0, 0.0)
+        eng = RolloutEngine(self.model.cfg, self.model.weights, self.model.device, max_ctx=max(16, n),
+                            seed=int(self.cfg.eval.seed), tilt=tilt, temperature=self.action_temperature,
+                            nucleus=self.nucleus_sampling, top_p=self.nucleus_threshold, model=self.model.hip)
+        eng.load_scenarios([scn], steps=self.steps)
+        self._session = eng
+        self._session_key = (tuple(ids), rp.shape)
+
+    def reset(self, vehicle_data_dict):
+        super().reset(vehicle_data_dict)
+        self._session = None
+
+    def get_data(self, gt_data_dict, preproc_data, dset, vehicles_to_evaluate, t):
+        raise NotImplementedError("context construction runs on the device (ctrlsim_build_context); see predict()")
+
+    def predict(self, vehicle_data_dict, gt_data_dict, preproc_data, dset, vehicles_to_evaluate, t):
+        import torch
+        w = self.cfg_rl_waymo
+        if self._session is None or t == 0:
+            self._open_session(vehicle_data_dict, preproc_data, gt_data_dict, vehicles_to_evaluate)
+        eng = self._session
+        dev = eng.device
+        n = self.states.shape[0]
+        # mirror the host buffers (rows <= t are meaningful; goals are constant in time)
+        hs = np.zeros((1, n, self.steps + 1, 8), np.float32)
+        hs[0, :, :self.steps] = self.states
+        eng.hist_states.copy_(torch.from_numpy(hs).to(dev))
+        eng.hist_tok.copy_(torch.from_numpy(dz.discretize_actions(self.actions, w).astype(np.int32)[None]).to(dev))
+        eng.hist_rtg.copy_(torch.from_numpy(dz.discretize_rtgs_from_raw(self.rtgs, w).astype(np.int32)[None]).to(dev))
+        eng.goals.copy_(torch.from_numpy(self.goals[:, 0][None]).to(dev))
+        eng.policy_step(t)
+        torch.cuda.synchronize(dev)
+        bins = eng.hist_rtg[0, :, t].cpu().numpy()
+        toks = eng.act_now[0].cpu().numpy()
+        own = eng.own_ctx[0].cpu().numpy()
+        cont_rtg = dz.undiscretize_rtgs(bins, w)
+        ids = list(vehicle_data_dict.keys())
+        for i, v in enumerate(ids):
+            d = vehicle_data_dict[v]
+            if own[i] >= 0:
+                d["next_rtg_goal"], d["next_rtg_veh"], d["next_rtg_road"] = cont_rtg[i]
+                d[self.key_dict["rtgs"]].append(np.array(cont_rtg[i]))
+            else:
+                d[self.key_dict["rtgs"]].append(np.array([0] * self.cfg_model.num_reward_components))
+        for v in vehicles_to_evaluate:
+            i = self.veh_id_to_idx[v]
+            if toks[i] >= 0:
+                a, s = dz.undiscretize_actions(np.array([toks[i]]), w)[0]
+            else:                                                    # dead_agent_veh_ids
+                a, s = 0.0, 0.0
+            vehicle_data_dict[v][self.key_dict["next_acceleration"]] = a
+            vehicle_data_dict[v][self.key_dict["next_steering"]] = s
+        return vehicle_data_dict
+
+    def act(self, veh, t, vehicle_data_dict):
+        veh_id = veh.getID()
+        veh_exists = vehicle_data_dict[veh_id]["existence"][-1]
+        if not veh_exists:
+            acceleration, steering = 0.0, 0.0
+            veh.setPosition(-1000000, -1000000)
+        else:
+            acceleration = vehicle_data_dict[veh_id][self.key_dict["next_acceleration"]]
+            steering = vehicle_data_dict[veh_id][self.key_dict["next_steering"]]
+        if acceleration > 0.0:
+            veh.acceleration = acceleration
+        else:
+            veh.brake(np.abs(acceleration))
+        veh.steering = steering
+        return veh, [acceleration, steering]
