@@ -24,24 +24,32 @@
 // token position used by the mask (pass-2 / last-layer evaluation of the current-timestep tokens only).
 #include "common.h"
 
+#ifndef KT
 #define KT 64
+#endif
+#ifndef ATT_WPS
+#define ATT_WPS 4
+#endif
 #define KP 36
 
 enum { MODE_KEYPAD = 0, MODE_CAUSAL = 1 };
 
 template <int MODE>
-__global__ __launch_bounds__(256) void attention_f32_kernel(
+__global__ __launch_bounds__(256, ATT_WPS) void attention_f32_kernel(
     const float* __restrict__ Q, int ldq, long q_batch_stride,   // Q[b*q_batch_stride + i*ldq + h*32 + d]
     const float* __restrict__ K, const float* __restrict__ V, int ldkv, long kv_batch_stride,
     float* __restrict__ O, int ldo, long o_batch_stride, const int* __restrict__ q_pos,
     const unsigned char* __restrict__ key_pad,                    // [B, Lk], 1 = ignore (MODE_KEYPAD)
-    int Lq, int Lk, int A, float scale) {
-  __shared__ __attribute__((aligned(16))) float Ks[KT * KP];
-  __shared__ __attribute__((aligned(16))) float Vs[KT * KP];
-  __shared__ float padbias[KT];
-  __shared__ float Ot[4][32 * 33];
+    int Lq, int Lk, int A, float scale_log2e) {
+  // one LDS arena: K/V staging during the key loop, re-used for the output transpose afterwards
+  // (two K/V buffers: the next tile is written while the current one is read, one barrier per tile)
+  __shared__ __attribute__((aligned(16))) float arena[2 * (2 * KT * KP + KT)];
+  __shared__ int blk_tmax[4];
+  constexpr int BUF = 2 * KT * KP + KT;
 
-  const int b = blockIdx.z, h = blockIdx.y, qb = blockIdx.x * 128;
+  // causal blocks are issued heaviest (latest queries) first so the tail of the launch is made of short blocks
+  const int qblk = (MODE == MODE_CAUSAL) ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;
+  const int b = blockIdx.z, h = blockIdx.y, qb = qblk * 128;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int A3 = 3 * A;
   const float NEG_INF = -__builtin_inff();
@@ -63,14 +71,13 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     qf[j] = *reinterpret_cast<const f32x4*>(qp + j * 8);
-    qf[j] *= scale;
+    qf[j] *= scale_log2e;                                   // scores live in the log2 domain: p = exp2(s - m)
   }
 
   // ---- key range
   int k_end = Lk;
   int tq_min_w = 0, tq_max_w = 0;
   if (MODE == MODE_CAUSAL) {
-    // wave-level and block-level timestep bounds of the queries
     int tmin = tq, tmax = tq;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -79,7 +86,6 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(
     }
     tq_min_w = tmin;
     tq_max_w = tmax;
-    __shared__ int blk_tmax[4];
     if (lane == 0) blk_tmax[wave] = tmax;
     __syncthreads();
     const int bt = max(max(blk_tmax[0], blk_tmax[1]), max(blk_tmax[2], blk_tmax[3]));
@@ -95,28 +101,53 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(
   const float* Vb = V + (size_t)b * kv_batch_stride + h * HD;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  for (int k0 = 0; k0 < k_end; k0 += KT) {
-    // stage 64 keys x 32 dims of K and V (512 float4 each; 2 per thread per operand)
+  // register prefetch of the next K/V tile (KT keys x 32 dims each: KT/32 float4 per thread and operand)
+  constexpr int LDI = KT / 32;
+  f32x4 pk[LDI], pv[LDI];
+  float ppad = 0.f;
+  auto gload = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < LDI; ++i) {
       const int idx = tid + 256 * i, r = idx >> 3, c = (idx & 7) * 4;
       const int kr = k0 + r;
-      f32x4 kv = zero4, vv = zero4;
+      pk[i] = zero4; pv[i] = zero4;
       if (kr < Lk) {
-        kv = *reinterpret_cast<const f32x4*>(Kb + (size_t)kr * ldkv + c);
-        vv = *reinterpret_cast<const f32x4*>(Vb + (size_t)kr * ldkv + c);
+        pk[i] = *reinterpret_cast<const f32x4*>(Kb + (size_t)kr * ldkv + c);
+        pv[i] = *reinterpret_cast<const f32x4*>(Vb + (size_t)kr * ldkv + c);
       }
-      *reinterpret_cast<f32x4*>(Ks + r * KP + c) = kv;
-      *reinterpret_cast<f32x4*>(Vs + r * KP + c) = vv;
     }
     if (MODE == MODE_KEYPAD && tid < KT) {
       const int kr = k0 + tid;
-      padbias[tid] = (kr < Lk && !key_pad[(size_t)b * Lk + kr]) ? 0.f : NEG_INF;
+      ppad = (kr < Lk && !key_pad[(size_t)b * Lk + kr]) ? 0.f : NEG_INF;
     }
-    __syncthreads();
+  };
+  auto sstore = [&](int buf) {
+    float* Kd = arena + buf * BUF;
+    float* Vd = Kd + KT * KP;
+#pragma unroll
+    for (int i = 0; i < LDI; ++i) {
+      const int idx = tid + 256 * i, r = idx >> 3, c = (idx & 7) * 4;
+      *reinterpret_cast<f32x4*>(Kd + r * KP + c) = pk[i];
+      *reinterpret_cast<f32x4*>(Vd + r * KP + c) = pv[i];
+    }
+    if (MODE == MODE_KEYPAD && tid < KT) Kd[2 * KT * KP + tid] = ppad;
+  };
+
+  if (k_end > 0) {
+    gload(0);
+    sstore(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = 0; k0 < k_end; k0 += KT, cur ^= 1) {
+    const bool more = k0 + KT < k_end;
+    if (more) gload(k0 + KT);                               // in flight while this tile is consumed
+    const float* Ks = arena + cur * BUF;
+    const float* Vs = Ks + KT * KP;
+    const float* padbias = Ks + 2 * KT * KP;
 
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
+    for (int sub = 0; sub < KT / 32; ++sub) {
       const int ks = k0 + sub * 32;  // first key of the sub-tile
       if (ks >= k_end) continue;
       bool need_mask = true;
@@ -164,18 +195,20 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
       const float m_new = fmaxf(m_run, tmax);
       const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-      const float alpha = expf(m_run - m_use);              // m_run = -inf -> 0
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);   // m_run = -inf -> 0
       float psum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        sc[r] = expf(sc[r] - m_use);
+        sc[r] = __builtin_amdgcn_exp2f(sc[r] - m_use);
         psum += sc[r];
       }
       psum += __shfl_xor(psum, 32, 64);
       l_run = l_run * alpha + psum;
       m_run = m_new;
+      if (!__all(alpha == 1.0f)) {                         // running max unchanged for the whole wave: no rescale
 #pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+        for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+      }
       // ---- O^T += V^T . P^T
       const float* vr_ = Vs + (sub * 32) * KP + l31;
 #pragma unroll
@@ -184,15 +217,15 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(
         oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, sc[r], oacc, 0, 0, 0);
       }
     }
+    if (more) sstore(cur ^ 1);                              // the other buffer was last read before the previous barrier
     __syncthreads();
   }
 
-  // ---- normalise, transpose through LDS, store rows
+  // ---- normalise, transpose through LDS (arena is free: every wave passed the loop's final barrier), store rows
   const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-  float* ot = Ot[wave];
+  float* ot = arena + wave * (32 * 33);
 #pragma unroll
   for (int r = 0; r < 16; ++r) ot[l31 * 33 + mfma_row(r, half)] = oacc[r] * inv;   // ot[q][d]
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave are visible to its own lanes
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -208,7 +241,7 @@ int launch_attention(int mode, const float* Q, int ldq, long q_batch_stride, con
   if (B <= 0 || Lq <= 0) return CTRLSIM_OK;
   if (Lk <= 0 || (ldq & 3) || (ldkv & 3)) return CTRLSIM_EINVAL;
   dim3 g((Lq + 127) / 128, NHEAD, B), blk(256);
-  const float scale = 0.17677669529663687f;  // 1/sqrt(32)
+  const float scale = 0.17677669529663687f * 1.4426950408889634f;  // log2(e)/sqrt(32)
   // algorithmic FLOPs: (QK^T + PV) = 4*32 per visible (query, key) pair and head
   double pairs;
   if (mode == MODE_CAUSAL) {

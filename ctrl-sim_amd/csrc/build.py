@@ -29,6 +29,7 @@ def build(force=False, verbose=False):
         objs.append(obj)
         if force or _newer(src, obj) or any(_newer(d, obj) for d in deps):
             cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj] + extra.split()
+            cmd += os.environ.get("CTRLSIM_EXTRA_DEFS", "").split()   # A/B tuning knobs, e.g. -DGEMM_TBK=16
             if verbose:
                 print(" ".join(cmd))
             procs.append((name, subprocess.Popen(cmd)))

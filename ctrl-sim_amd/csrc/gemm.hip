@@ -17,37 +17,50 @@
 
 #define BM 128
 #define BN 128
-#define BK 32
-#define BKP 36
 
-template <bool RELU, bool RESID>
-__global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restrict__ A, int lda,
+// TBK = K-slab width staged in LDS (16 or 32).  LDS = max(K-loop double buffer, epilogue staging of 64 rows):
+//   TBK=32: 73.7 KB -> 2 workgroups / CU;   TBK=16: 41 KB -> 3 workgroups / CU (VGPR-limited), twice the barriers.
+template <int TBK, bool RELU, bool RESID>
+__global__ __launch_bounds__(256, (TBK == 16 ? 3 : 2)) void gemm_nt_f32_kernel(const float* __restrict__ A, int lda,
                                                           const float* __restrict__ W, int ldw,
                                                           const float* __restrict__ bias,
                                                           const float* __restrict__ R, int ldr,
                                                           float* __restrict__ C, int ldc, int M, int N, int K,
                                                           int m_tiles, int n_tiles) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * BKP];
+  constexpr int BKP = TBK + 4;
+  constexpr int CP = BN + 4;
+  constexpr int LOOP_FLOATS = 2 * (BM + BN) * BKP;
+  constexpr int EPI_FLOATS = 64 * CP;
+  __shared__ __attribute__((aligned(16))) float lds[LOOP_FLOATS > EPI_FLOATS ? LOOP_FLOATS : EPI_FLOATS];
   float* As = lds;
   float* Ws = lds + 2 * BM * BKP;
-
-  // XCD-aware tile mapping
-  const int id = blockIdx.x;
-  const int xcd = id & 7, j = id >> 3;
-  const int mt = (j / n_tiles) * 8 + xcd, nt = j % n_tiles;
-  if (mt >= m_tiles) return;
-  const int bm = mt * BM, bn = nt * BN;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int l31 = lane & 31, half = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;
 
-  f32x4 ra[4], rw[4];
+  // Persistent workgroups: tile ids id = blockIdx.x, += gridDim.x (gridDim.x is a multiple of 8, so a workgroup stays
+  // on its XCD).  XCD-aware tile order: id -> (xcd = id & 7, j = id >> 3), M-tile = (j / n_tiles) * 8 + xcd,
+  // N-tile = j % n_tiles: all N-tiles of an M-tile are consecutive on ONE XCD, the activation slab is fetched into a
+  // single L2.  The first K-slab of the NEXT tile is loaded into registers before the epilogue of the current one.
+  const int total_ids = ((m_tiles + 7) / 8) * 8 * n_tiles;
+  int bm = 0, bn = 0;
+  auto tile_of = [&](int id, int& tbm, int& tbn) -> bool {
+    const int xcd = id & 7, j = id >> 3;
+    const int mt = (j / n_tiles) * 8 + xcd, nt = j % n_tiles;
+    tbm = mt * BM;
+    tbn = nt * BN;
+    return mt < m_tiles;
+  };
+
+  constexpr int F4_PER_ROW = TBK / 4;                 // float4 per tile row
+  constexpr int LD_ITERS = (BM * F4_PER_ROW) / 256;   // float4 per thread and operand
+  f32x4 ra[LD_ITERS], rw[LD_ITERS];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = tid + 256 * i, r = idx >> 3, c = (idx & 7) * 4;
+    for (int i = 0; i < LD_ITERS; ++i) {
+      const int idx = tid + 256 * i, r = idx / F4_PER_ROW, c = (idx % F4_PER_ROW) * 4;
       const int ga = bm + r, gw = bn + r;
       ra[i] = ga < M ? *reinterpret_cast<const f32x4*>(A + (size_t)ga * lda + k0 + c) : zero4;
       rw[i] = gw < N ? *reinterpret_cast<const f32x4*>(W + (size_t)gw * ldw + k0 + c) : zero4;
@@ -55,13 +68,19 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
   };
   auto sstore = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = tid + 256 * i, r = idx >> 3, c = (idx & 7) * 4;
+    for (int i = 0; i < LD_ITERS; ++i) {
+      const int idx = tid + 256 * i, r = idx / F4_PER_ROW, c = (idx % F4_PER_ROW) * 4;
       *reinterpret_cast<f32x4*>(As + buf * BM * BKP + r * BKP + c) = ra[i];
       *reinterpret_cast<f32x4*>(Ws + buf * BN * BKP + r * BKP + c) = rw[i];
     }
   };
 
+  const int nk = K / TBK;
+  int id = blockIdx.x;
+  while (id < total_ids && !tile_of(id, bm, bn)) id += gridDim.x;
+  if (id >= total_ids) return;
+  gload(0);
+  for (;;) {
   f32x16 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -70,17 +89,15 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const int nk = K / BK;
-  gload(0);
   sstore(0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) gload((kt + 1) * BK);
+    if (kt + 1 < nk) gload((kt + 1) * TBK);
     const float* as = As + cur * BM * BKP + (wr * 64 + l31) * BKP + half * 4;
     const float* ws = Ws + cur * BN * BKP + (wc * 64 + l31) * BKP + half * 4;
 #pragma unroll
-    for (int kc = 0; kc < BK / 8; ++kc) {
+    for (int kc = 0; kc < TBK / 8; ++kc) {
       const f32x4 a0 = *reinterpret_cast<const f32x4*>(as + kc * 8);
       const f32x4 a1 = *reinterpret_cast<const f32x4*>(as + 32 * BKP + kc * 8);
       const f32x4 b0 = *reinterpret_cast<const f32x4*>(ws + kc * 8);
@@ -97,25 +114,58 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     __syncthreads();
   }
 
-  // epilogue: lane holds col = l31, rows (r&3)+8*(r>>2)+4*half of each 32x32 tile
+  // epilogue: stage the tile through LDS in two 64-row halves (the K-loop buffers are free after its final barrier) so
+  // that bias / residual loads and the stores are 16-byte, 512-byte-per-row transactions instead of dword accesses.
+  // acc fragment: lane holds col = l31, rows (r&3)+8*(r>>2)+4*half of each 32x32 tile.
+  float* Cs = lds;   // [64][BN + 4]
+  const bool vec_ok = !(ldc & 3) && (!RESID || !(ldr & 3));
+  const int cbm = bm, cbn = bn;            // this tile's origin (bm/bn move on to the prefetched tile)
+  int nid = id + gridDim.x;
+  while (nid < total_ids && !tile_of(nid, bm, bn)) nid += gridDim.x;
+  const bool have_next = nid < total_ids;
+  if (have_next) gload(0);                 // next tile's first slab: in flight during the epilogue
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
+  for (int hrow = 0; hrow < 2; ++hrow) {
+    if (wr == hrow) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int col = bn + wc * 64 + b * 32 + l31;
-      if (col >= N) continue;
-      const float bv = bias ? bias[col] : 0.f;
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = bm + wr * 64 + a * 32 + mfma_row(r, half);
-        if (row < M) {
-          float v = acc[a][b][r] + bv;
-          if (RESID) v += R[(size_t)row * ldr + col];
-          if (RELU) v = fmaxf(v, 0.f);
-          C[(size_t)row * ldc + col] = v;
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            Cs[(a * 32 + mfma_row(r, half)) * CP + wc * 64 + b * 32 + l31] = acc[a][b][r];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 5, col = (idx & 31) * 4;
+      const int grow = cbm + hrow * 64 + row, gcol = cbn + col;
+      if (grow >= M || gcol >= N) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * CP + col);
+      if (vec_ok && gcol + 3 < N) {
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + gcol);
+        if (RESID) v += *reinterpret_cast<const f32x4*>(R + (size_t)grow * ldr + gcol);
+        if (RELU) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(C + (size_t)grow * ldc + gcol) = v;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (gcol + c < N) {
+            float x = v[c] + (bias ? bias[gcol + c] : 0.f);
+            if (RESID) x += R[(size_t)grow * ldr + gcol + c];
+            if (RELU) x = fmaxf(x, 0.f);
+            C[(size_t)grow * ldc + gcol + c] = x;
+          }
         }
       }
     }
+    __syncthreads();
+  }
+  if (!have_next) break;
+  id = nid;
   }
 }
 
@@ -200,24 +250,29 @@ __global__ void row_copy_kernel(const float* __restrict__ src, int lds_, float* 
     reinterpret_cast<f32x4*>(d)[c] = reinterpret_cast<const f32x4*>(s)[c];
 }
 
+#ifndef GEMM_TBK
+#define GEMM_TBK 16
+#endif
 // ------------------------------------------------------------------------------------------------ host launchers
 int launch_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr,
                    float* C, int ldc, int M, int N, int K, int relu, hipStream_t st) {
   if (M <= 0) return CTRLSIM_OK;
-  if (K % BK != 0 || (lda & 3) || (ldw & 3) || N <= 0) return CTRLSIM_EINVAL;
+  if (K % 32 != 0 || (lda & 3) || (ldw & 3) || N <= 0) return CTRLSIM_EINVAL;
   const int m_tiles = (M + BM - 1) / BM, n_tiles = (N + BN - 1) / BN;
-  const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
+  const int total = ((m_tiles + 7) / 8) * 8 * n_tiles;
+  const int resident = 256 * (GEMM_TBK == 16 ? 3 : 2);          // CUs x workgroups per CU (LDS / VGPR bound)
+  const int grid = total < resident ? total : resident;
   dim3 g(grid), b(256);
   prof_before(PROF_GEMM, st);
   if (R) {
     if (relu) return CTRLSIM_EINVAL;
-    hipLaunchKernelGGL((gemm_nt_f32_kernel<false, true>), g, b, 0, st, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K,
+    hipLaunchKernelGGL((gemm_nt_f32_kernel<GEMM_TBK, false, true>), g, b, 0, st, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K,
                        m_tiles, n_tiles);
   } else if (relu) {
-    hipLaunchKernelGGL((gemm_nt_f32_kernel<true, false>), g, b, 0, st, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K,
+    hipLaunchKernelGGL((gemm_nt_f32_kernel<GEMM_TBK, true, false>), g, b, 0, st, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K,
                        m_tiles, n_tiles);
   } else {
-    hipLaunchKernelGGL((gemm_nt_f32_kernel<false, false>), g, b, 0, st, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N,
+    hipLaunchKernelGGL((gemm_nt_f32_kernel<GEMM_TBK, false, false>), g, b, 0, st, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N,
                        K, m_tiles, n_tiles);
   }
   prof_after(PROF_GEMM, 2.0 * (double)M * (double)N * (double)K, st);
