@@ -4,6 +4,8 @@
 
 int launch_gemm_nt(const float*, int, const float*, int, const float*, const float*, int, float*, int, int, int, int, int,
                    hipStream_t);
+int launch_gemm_nt_bf16x6(const float*, int, const void*, int, int, const float*, const float*, int, float*, int, int, int,
+                          int, int, hipStream_t);
 int launch_layernorm256(const float*, int, const float*, int, const float*, const float*, float*, int, int, int,
                         hipStream_t);
 int launch_attention(int, const float*, int, long, const float*, const float*, int, long, float*, int, long, const int*,
@@ -73,6 +75,10 @@ const char* ctrlsim_version(void) { return "ctrlsim-hip 0.1 (gfx950)"; }
 int ctrlsim_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
                     int ldc, int M, int N, int K, int relu, hipStream_t st) {
   return launch_gemm_nt(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, relu, st);
+}
+int ctrlsim_gemm_nt_bf16x6(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias, const float* R,
+                           int ldr, float* C, int ldc, int M, int N, int K, int relu, hipStream_t st) {
+  return launch_gemm_nt_bf16x6(A, lda, W3, n_total, n0, bias, R, ldr, C, ldc, M, N, K, relu, st);
 }
 int ctrlsim_layernorm256(const float* X, int ldx, const float* Radd, int ldr, const float* gamma, const float* beta, float* Y,
                          int ldy, int rows, int relu, hipStream_t st) {

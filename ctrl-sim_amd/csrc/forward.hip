@@ -25,6 +25,8 @@
 // launchers from the other translation units
 int launch_gemm_nt(const float*, int, const float*, int, const float*, const float*, int, float*, int, int, int, int, int,
                    hipStream_t);
+int launch_gemm_nt_bf16x6(const float*, int, const void*, int, int, const float*, const float*, int, float*, int, int, int,
+                          int, int, hipStream_t);
 int launch_layernorm256(const float*, int, const float*, int, const float*, const float*, float*, int, int, int,
                         hipStream_t);
 int launch_in_mlp(const float*, int, int, const float*, const float*, const float*, const float*, float*, int, int,
@@ -42,7 +44,7 @@ int launch_map_pool(int, int, int, int, const float*, MapPoolWeights, float*, un
 
 namespace {
 
-struct Lin { const float* w; const float* b; };
+struct Lin { const float* w; const float* b; const void* w3 = nullptr; int ntot = 0; int n0 = 0; };
 struct LNp { const float* g; const float* b; };
 struct Mlp { Lin l0; LNp ln; Lin l3; };
 struct EncLayer { Lin qkv, out, lin1, lin2; LNp n1, n2; };
@@ -54,7 +56,7 @@ struct ctrlsim_model {
   ctrlsim_dims d;
   // embeddings
   Mlp embed_state, embed_goal;             // only l0 + ln used (l3 folded)
-  const float *fold_state_w, *fold_goal_w, *fold_goal_b;
+  Lin fold_state, fold_goal;
   EmbedTables tb;
   // map encoder
   MapPoolWeights mp;
@@ -85,16 +87,19 @@ extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_w
     if (it == tab.end()) { ok = false; return nullptr; }
     return it->second;
   };
-  auto lin = [&](const std::string& k) { return Lin{P(k + ".weight"), P(k + ".bias")}; };
+  auto P3 = [&](const std::string& k) -> const void* {     // optional bf16x3 planes
+    auto it = tab.find(k + "#bf3");
+    return it == tab.end() ? nullptr : static_cast<const void*>(it->second);
+  };
+  auto lin = [&](const std::string& k) { return Lin{P(k + ".weight"), P(k + ".bias"), P3(k + ".weight"), 0, 0}; };
   auto lnp = [&](const std::string& k) { return LNp{P(k + ".weight"), P(k + ".bias")}; };
   auto mlp = [&](const std::string& k) { return Mlp{lin(k + ".mlp.0"), lnp(k + ".mlp.1"), lin(k + ".mlp.3")}; };
   ctrlsim_model* m = new ctrlsim_model();
   m->d = *dims;
   m->embed_state = mlp("encoder.embed_state");
   m->embed_goal = mlp("encoder.embed_goal");
-  m->fold_state_w = P("fold.embed_state.w");
-  m->fold_goal_w = P("fold.embed_goal.w");
-  m->fold_goal_b = P("fold.embed_goal.b");
+  m->fold_state = Lin{P("fold.embed_state.w"), nullptr, P3("fold.embed_state.w"), 0, 0};
+  m->fold_goal = Lin{P("fold.embed_goal.w"), P("fold.embed_goal.b"), P3("fold.embed_goal.w"), 0, 0};
   m->tb = EmbedTables{P("encoder.embed_action.weight"), P("fold.rtg_table_goal"), P("fold.rtg_table_veh"),
                       P("fold.rtg_table_road"), P("encoder.embed_rtg.bias"), P("encoder.embed_timestep.weight"),
                       P("encoder.embed_agent_id.weight"), P("encoder.embed_ln.weight"), P("encoder.embed_ln.bias")};
@@ -111,7 +116,7 @@ extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_w
   for (int i = 0; i < dims->NE; ++i) {
     const std::string p = "encoder.transformer_encoder.layers." + std::to_string(i);
     EncLayer L;
-    L.qkv = Lin{P(p + ".self_attn.in_proj_weight"), P(p + ".self_attn.in_proj_bias")};
+    L.qkv = Lin{P(p + ".self_attn.in_proj_weight"), P(p + ".self_attn.in_proj_bias"), P3(p + ".self_attn.in_proj_weight"), 3 * DM, 0};
     L.out = lin(p + ".self_attn.out_proj");
     L.lin1 = lin(p + ".linear1");
     L.lin2 = lin(p + ".linear2");
@@ -122,12 +127,13 @@ extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_w
   for (int i = 0; i < dims->ND; ++i) {
     const std::string p = "decoder.transformer_decoder.layers." + std::to_string(i);
     DecLayer L;
-    L.qkv = Lin{P(p + ".self_attn.in_proj_weight"), P(p + ".self_attn.in_proj_bias")};
+    L.qkv = Lin{P(p + ".self_attn.in_proj_weight"), P(p + ".self_attn.in_proj_bias"), P3(p + ".self_attn.in_proj_weight"), 3 * DM, 0};
     L.out = lin(p + ".self_attn.out_proj");
     const float* cw = P(p + ".multihead_attn.in_proj_weight");
     const float* cb = P(p + ".multihead_attn.in_proj_bias");
-    L.cq = Lin{cw, cb};
-    L.ckv = Lin{cw ? cw + DM * DM : nullptr, cb ? cb + DM : nullptr};
+    const void* cw3 = P3(p + ".multihead_attn.in_proj_weight");
+    L.cq = Lin{cw, cb, cw3, 3 * DM, 0};
+    L.ckv = Lin{cw ? cw + DM * DM : nullptr, cb ? cb + DM : nullptr, cw3, 3 * DM, DM};
     L.cout = lin(p + ".multihead_attn.out_proj");
     L.lin1 = lin(p + ".linear1");
     L.lin2 = lin(p + ".linear2");
@@ -200,11 +206,19 @@ __global__ void fill_index_kernel(int B, int A, int L, int ti, int P, int M, int
   }
 }
 
+// y = act(x W^T + b [+ R]) through the bf16x6 MFMA kernel when the packed planes exist, else the f32-input MFMA kernel
+int gemm(const Lin& L, const float* x, int ldx, const float* R, int ldr, float* y, int ldy, int rows, int n, int k, int relu,
+         hipStream_t st) {
+  if (L.w3 && k % 16 == 0)
+    return launch_gemm_nt_bf16x6(x, ldx, L.w3, L.ntot ? L.ntot : n, L.n0, L.b, R, ldr, y, ldy, rows, n, k, relu, st);
+  return gemm(L, x, ldx, R, ldr, y, ldy, rows, n, k, relu, st);
+}
+
 int mlp_tail(const Mlp& m, const float* h_in, int rows, float* hid, float* out, int n_out, hipStream_t st) {
   // Linear(256->256) -> LN -> ReLU -> Linear(256->n_out)
-  CHK(launch_gemm_nt(h_in, DM, m.l0.w, DM, m.l0.b, nullptr, 0, hid, DM, rows, DM, DM, 0, st));
+  CHK(gemm(m.l0, h_in, DM, nullptr, 0, hid, DM, rows, DM, DM, 0, st));
   CHK(launch_layernorm256(hid, DM, nullptr, 0, m.ln.g, m.ln.b, hid, DM, rows, 1, st));
-  CHK(launch_gemm_nt(hid, DM, m.l3.w, DM, m.l3.b, nullptr, 0, out, n_out, rows, n_out, DM, 0, st));
+  CHK(gemm(m.l3, hid, DM, nullptr, 0, out, n_out, rows, n_out, DM, 0, st));
   return 0;
 }
 
@@ -213,13 +227,13 @@ int cross_and_ffn(const ctrlsim_model* m, const DecLayer& Ld, int layer, const W
                   float* qc, float* ffn, int rows, int B, int rows_per_b, hipStream_t st) {
   const ctrlsim_dims& d = m->d;
   const int M = d.P + d.A;
-  CHK(launch_gemm_nt(x, DM, Ld.cq.w, DM, Ld.cq.b, nullptr, 0, qc, DM, rows, DM, DM, 0, st));
+  CHK(gemm(Ld.cq, x, DM, nullptr, 0, qc, DM, rows, DM, DM, 0, st));
   CHK(launch_attention(0, qc, DM, (long)rows_per_b * DM, w.memkv[layer], w.memkv[layer] + DM, 2 * DM, (long)M * 2 * DM, att,
                        DM, (long)rows_per_b * DM, nullptr, w.src_pad, B, rows_per_b, M, d.A, st));
-  CHK(launch_gemm_nt(att, DM, Ld.cout.w, DM, Ld.cout.b, x, DM, tmp, DM, rows, DM, DM, 0, st));
+  CHK(gemm(Ld.cout, att, DM, x, DM, tmp, DM, rows, DM, DM, 0, st));
   CHK(launch_layernorm256(tmp, DM, nullptr, 0, Ld.n2.g, Ld.n2.b, x, DM, rows, 0, st));
-  CHK(launch_gemm_nt(x, DM, Ld.lin1.w, DM, Ld.lin1.b, nullptr, 0, ffn, d.F, rows, d.F, DM, 1, st));
-  CHK(launch_gemm_nt(ffn, d.F, Ld.lin2.w, d.F, Ld.lin2.b, x, DM, tmp, DM, rows, DM, d.F, 0, st));
+  CHK(gemm(Ld.lin1, x, DM, nullptr, 0, ffn, d.F, rows, d.F, DM, 1, st));
+  CHK(gemm(Ld.lin2, ffn, d.F, x, DM, tmp, DM, rows, DM, d.F, 0, st));
   CHK(launch_layernorm256(tmp, DM, nullptr, 0, Ld.n3.g, Ld.n3.b, x, DM, rows, 0, st));
   return 0;
 }
@@ -243,29 +257,27 @@ extern "C" int ctrlsim_dt_forward_pass1(const ctrlsim_model* m, int B, int Tq, c
   // ---- token embeddings (encoder.py:95-153)
   CHK(launch_in_mlp(c->st12, 12, 12, m->embed_state.l0.w, m->embed_state.l0.b, m->embed_state.ln.g, m->embed_state.ln.b,
                     w.hS, DM, rS, st));
-  CHK(launch_gemm_nt(w.hS, DM, m->fold_state_w, DM, nullptr, nullptr, 0, w.S2, DM, rS, DM, DM, 0, st));
+  CHK(gemm(m->fold_state, w.hS, DM, nullptr, 0, w.S2, DM, rS, DM, DM, 0, st));
   CHK(launch_in_mlp(c->goal5, 5, 5, m->embed_goal.l0.w, m->embed_goal.l0.b, m->embed_goal.ln.g, m->embed_goal.ln.b, w.hG,
                     DM, rA, st));
-  CHK(launch_gemm_nt(w.hG, DM, m->fold_goal_w, DM, m->fold_goal_b, nullptr, 0, w.Gp, DM, rA, DM, DM, 0, st));
+  CHK(gemm(m->fold_goal, w.hG, DM, nullptr, 0, w.Gp, DM, rA, DM, DM, 0, st));
   CHK(launch_assemble_tokens(B, Tq, A, w.S2, w.Gp, c->exist, c->act_tok, c->rtg_bin, c->tstep, m->tb, w.X, w.src, M, P,
                              w.src_pad, st));
   // ---- map encoder (map_encoder.py:34-53): rows of `src` 0..P-1 per context
   CHK(launch_map_pool(B, P, d.NP, M, c->road_pts, m->mp, w.attn_pre, w.src_pad, st));
-  CHK(launch_gemm_nt(w.attn_pre, DM, m->map_out.w, DM, m->map_out.b, nullptr, 0, w.m1, DM, rP, DM, DM, 0, st));
+  CHK(gemm(m->map_out, w.attn_pre, DM, nullptr, 0, w.m1, DM, rP, DM, DM, 0, st));
   CHK(launch_layernorm256(w.m1, DM, nullptr, 0, m->map_n1.g, m->map_n1.b, w.m1, DM, rP, 0, st));            // emb
-  CHK(launch_gemm_nt(w.m1, DM, m->map_feats.l0.w, DM, m->map_feats.l0.b, nullptr, 0, w.m2, DM, rP, DM, DM, 0, st));
+  CHK(gemm(m->map_feats.l0, w.m1, DM, nullptr, 0, w.m2, DM, rP, DM, DM, 0, st));
   CHK(launch_layernorm256(w.m2, DM, nullptr, 0, m->map_feats.ln.g, m->map_feats.ln.b, w.m2, DM, rP, 1, st));
-  CHK(launch_gemm_nt(w.m2, DM, m->map_feats.l3.w, DM, m->map_feats.l3.b, w.m1, DM, w.attn_pre, DM, rP, DM, DM, 0, st));
+  CHK(gemm(m->map_feats.l3, w.m2, DM, w.m1, DM, w.attn_pre, DM, rP, DM, DM, 0, st));
   CHK(launch_layernorm256(w.attn_pre, DM, nullptr, 0, m->map_n2.g, m->map_n2.b, w.cat, 2 * DM, rP, 0, st));  // cat[:, :256]
   CHK(launch_in_mlp(c->road_types, 8, 8, m->road_type.l0.w, m->road_type.l0.b, m->road_type.ln.g, m->road_type.ln.b, w.tfh,
                     DM, rP, st));
-  CHK(launch_gemm_nt(w.tfh, DM, m->road_type.l3.w, DM, m->road_type.l3.b, nullptr, 0, w.cat + DM, 2 * DM, rP, DM, DM, 0,
-                     st));                                                                                  // cat[:, 256:]
-  CHK(launch_gemm_nt(w.cat, 2 * DM, m->road_fuse.l0.w, 2 * DM, m->road_fuse.l0.b, nullptr, 0, w.m2, DM, rP, DM, 2 * DM, 0,
-                     st));
+  CHK(gemm(m->road_type.l3, w.tfh, DM, nullptr, 0, w.cat + DM, 2 * DM, rP, DM, DM, 0, st));                                                                                  // cat[:, 256:]
+  CHK(gemm(m->road_fuse.l0, w.cat, 2 * DM, nullptr, 0, w.m2, DM, rP, DM, 2 * DM, 0, st));
   CHK(launch_layernorm256(w.m2, DM, nullptr, 0, m->road_fuse.ln.g, m->road_fuse.ln.b, w.m2, DM, rP, 1, st));
   // final Linear -> compact [B*P,256], then scattered into the scene-encoder source rows [b, 0..P-1]
-  CHK(launch_gemm_nt(w.m2, DM, m->road_fuse.l3.w, DM, m->road_fuse.l3.b, nullptr, 0, w.m1, DM, rP, DM, DM, 0, st));
+  CHK(gemm(m->road_fuse.l3, w.m2, DM, nullptr, 0, w.m1, DM, rP, DM, DM, 0, st));
   CHK(launch_row_copy(w.m1, DM, w.src, DM, w.idx_poly, rP, DM, 1, st));
   if (dbg_seg_emb) {
     hipError_t e = hipMemcpyAsync(dbg_seg_emb, w.m1, (size_t)rP * DM * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -274,27 +286,26 @@ extern "C" int ctrlsim_dt_forward_pass1(const ctrlsim_model* m, int B, int Tq, c
   // ---- scene encoder (encoder.py:155-168): post-LN layers over [polylines || initial states] with key padding
   for (int i = 0; i < d.NE; ++i) {
     const EncLayer& Le = m->enc[i];
-    CHK(launch_gemm_nt(w.src, DM, Le.qkv.w, DM, Le.qkv.b, nullptr, 0, w.eqkv, 3 * DM, rM, 3 * DM, DM, 0, st));
+    CHK(gemm(Le.qkv, w.src, DM, nullptr, 0, w.eqkv, 3 * DM, rM, 3 * DM, DM, 0, st));
     CHK(launch_attention(0, w.eqkv, 3 * DM, (long)M * 3 * DM, w.eqkv + DM, w.eqkv + 2 * DM, 3 * DM, (long)M * 3 * DM, w.eatt,
                          DM, (long)M * DM, nullptr, w.src_pad, B, M, M, A, st));
-    CHK(launch_gemm_nt(w.eatt, DM, Le.out.w, DM, Le.out.b, w.src, DM, w.etmp, DM, rM, DM, DM, 0, st));
+    CHK(gemm(Le.out, w.eatt, DM, w.src, DM, w.etmp, DM, rM, DM, DM, 0, st));
     CHK(launch_layernorm256(w.etmp, DM, nullptr, 0, Le.n1.g, Le.n1.b, w.src, DM, rM, 0, st));
-    CHK(launch_gemm_nt(w.src, DM, Le.lin1.w, DM, Le.lin1.b, nullptr, 0, w.effn, d.F, rM, d.F, DM, 1, st));
-    CHK(launch_gemm_nt(w.effn, d.F, Le.lin2.w, d.F, Le.lin2.b, w.src, DM, w.etmp, DM, rM, DM, d.F, 0, st));
+    CHK(gemm(Le.lin1, w.src, DM, nullptr, 0, w.effn, d.F, rM, d.F, DM, 1, st));
+    CHK(gemm(Le.lin2, w.effn, d.F, w.src, DM, w.etmp, DM, rM, DM, d.F, 0, st));
     CHK(launch_layernorm256(w.etmp, DM, nullptr, 0, Le.n2.g, Le.n2.b, w.src, DM, rM, 0, st));
   }
   // memory K/V of every decoder layer (cached for pass 2)
   for (int i = 0; i < d.ND; ++i)
-    CHK(launch_gemm_nt(w.src, DM, m->dec[i].ckv.w, DM, m->dec[i].ckv.b, nullptr, 0, w.memkv[i], 2 * DM, rM, 2 * DM, DM, 0,
-                       st));
+    CHK(gemm(m->dec[i].ckv, w.src, DM, nullptr, 0, w.memkv[i], 2 * DM, rM, 2 * DM, DM, 0, st));
   // ---- decoder (decoder.py:52): layers 0..ND-2 on all L tokens
   for (int i = 0; i < d.ND; ++i) {
     const DecLayer& Ld = m->dec[i];
-    CHK(launch_gemm_nt(w.X, DM, Ld.qkv.w, DM, Ld.qkv.b, nullptr, 0, w.qkv[i], 3 * DM, rL, 3 * DM, DM, 0, st));
+    CHK(gemm(Ld.qkv, w.X, DM, nullptr, 0, w.qkv[i], 3 * DM, rL, 3 * DM, DM, 0, st));
     if (i < d.ND - 1) {
       CHK(launch_attention(1, w.qkv[i], 3 * DM, (long)L * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
                            w.att, DM, (long)L * DM, nullptr, nullptr, B, L, L, A, st));
-      CHK(launch_gemm_nt(w.att, DM, Ld.out.w, DM, Ld.out.b, w.X, DM, w.tmp, DM, rL, DM, DM, 0, st));
+      CHK(gemm(Ld.out, w.att, DM, w.X, DM, w.tmp, DM, rL, DM, DM, 0, st));
       CHK(launch_layernorm256(w.tmp, DM, nullptr, 0, Ld.n1.g, Ld.n1.b, w.X, DM, rL, 0, st));
       CHK(cross_and_ffn(m, Ld, i, w, w.X, w.tmp, w.att, w.qc, w.ffn, rL, B, L, st));
     } else {
@@ -303,7 +314,7 @@ extern "C" int ctrlsim_dt_forward_pass1(const ctrlsim_model* m, int B, int Tq, c
       CHK(launch_row_copy(w.qkv[i], 3 * DM, w.qkvc, 3 * DM, w.idx_state, rA, 3 * DM, 0, st));
       CHK(launch_attention(1, w.qkvc, 3 * DM, (long)A * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
                            w.attc, DM, (long)A * DM, w.pos_state, nullptr, B, A, L, A, st));
-      CHK(launch_gemm_nt(w.attc, DM, Ld.out.w, DM, Ld.out.b, w.xc, DM, w.tmpc, DM, rA, DM, DM, 0, st));
+      CHK(gemm(Ld.out, w.attc, DM, w.xc, DM, w.tmpc, DM, rA, DM, DM, 0, st));
       CHK(launch_layernorm256(w.tmpc, DM, nullptr, 0, Ld.n1.g, Ld.n1.b, w.xc, DM, rA, 0, st));
       CHK(cross_and_ffn(m, Ld, i, w, w.xc, w.tmpc, w.attc, w.qcc, w.ffnc, rA, B, A, st));
     }
@@ -325,11 +336,11 @@ extern "C" int ctrlsim_dt_forward_pass2(const ctrlsim_model* m, int B, int Tq, i
                                m->zero_rtg, w.xc2, st));
   for (int i = 0; i < d.ND; ++i) {
     const DecLayer& Ld = m->dec[i];
-    CHK(launch_gemm_nt(w.xc2, DM, Ld.qkv.w, DM, Ld.qkv.b, nullptr, 0, w.qkvc, 3 * DM, rA, 3 * DM, DM, 0, st));
+    CHK(gemm(Ld.qkv, w.xc2, DM, nullptr, 0, w.qkvc, 3 * DM, rA, 3 * DM, DM, 0, st));
     CHK(launch_row_copy(w.qkvc, 3 * DM, w.qkv[i], 3 * DM, w.idx_rtg, rA, 3 * DM, 1, st));   // refresh the rtg rows' K/V
     CHK(launch_attention(1, w.qkvc, 3 * DM, (long)A * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
                          w.attc, DM, (long)A * DM, w.pos_rtg, nullptr, B, A, L, A, st));
-    CHK(launch_gemm_nt(w.attc, DM, Ld.out.w, DM, Ld.out.b, w.xc2, DM, w.tmpc, DM, rA, DM, DM, 0, st));
+    CHK(gemm(Ld.out, w.attc, DM, w.xc2, DM, w.tmpc, DM, rA, DM, DM, 0, st));
     CHK(launch_layernorm256(w.tmpc, DM, nullptr, 0, Ld.n1.g, Ld.n1.b, w.xc2, DM, rA, 0, st));
     CHK(cross_and_ffn(m, Ld, i, w, w.xc2, w.tmpc, w.attc, w.qcc, w.ffnc, rA, B, A, st));
   }

@@ -1,0 +1,233 @@
+// fp32-accurate GEMM on the bf16 MFMA: every fp32 operand is split into three bf16 terms (x = hi + mid + lo, 3 x 8
+// significant bits = the whole fp32 mantissa) and the product is evaluated as the six leading partial products
+//     a.b ~= hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid          (dropped terms <= 2^-23 relative)
+// with fp32 accumulation inside v_mfma_f32_32x32x16_bf16.  The result carries fp32-class error (measured against an
+// fp64 reference in tests/test_gpu_ops.py: same order as the f32-input MFMA kernel) while the matrix pipe runs at
+// 16x the f32-input MFMA rate for 6x the instructions: a 2.67x higher matrix roof (420 TFLOP/s fp32-equivalent).
+// Token parity with the reference is unaffected (fixtures: bit-exact tokens, logits within 1e-4).
+//
+// Weights are split ONCE at pack time (ctrlsim_amd/pack.py) into slab-major planes  W3[K/16][3][N][16] bf16  so a
+// workgroup's K-slab of a plane is one contiguous 32-byte-per-row stream.  Activations stay fp32 in HBM and are split
+// in registers while being staged into LDS (v_cvt_pk_bf16_f32, round-to-nearest-even).
+//
+// Tiling: workgroup = 128 (M) x 256 (N), 4 waves as 2x2, wave tile 64x128 = 2x4 MFMA tiles (128 accumulator regs);
+// extending N (pre-split weights) rather than M amortises the activation split.  K-slab = 16 = one MFMA k-step;
+// LDS per buffer: A planes 3 x [128][16] + W planes 3 x [256][16] bf16 = 36 KB, double buffered (72 KB, 2 WG / CU),
+// rows are 32 bytes so a wave's 16-byte fragment reads are one contiguous 1-2 KB span (conflict free, no padding).
+// Persistent workgroups with the XCD-aware tile order of gemm.hip; the next tile's first slab is prefetched before
+// the epilogue; the epilogue stages 64 rows at a time through LDS for 16-byte bias / residual / store traffic.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define XM 128
+#define XN 256
+#define XK 16
+
+__device__ __forceinline__ void split3(const f32x4 x, bf16x4& hi, bf16x4& mid, bf16x4& lo) {
+  hi = __builtin_convertvector(x, bf16x4);
+  const f32x4 r1 = x - __builtin_convertvector(hi, f32x4);
+  mid = __builtin_convertvector(r1, bf16x4);
+  const f32x4 r2 = r1 - __builtin_convertvector(mid, f32x4);
+  lo = __builtin_convertvector(r2, bf16x4);
+}
+
+template <int PA, int PB>
+__device__ __forceinline__ void term(f32x16 (&acc)[2][4], const bf16x8 (&fa)[2][3], const bf16x8 (&fb)[4][3]) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA], fb[b][PB], acc[a][b], 0, 0, 0);
+}
+
+template <bool RELU, bool RESID>
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16x6_kernel(const float* __restrict__ A, int lda,
+                                                                const __bf16* __restrict__ W3,   // [K/16][3][N][16]
+                                                                const float* __restrict__ bias,
+                                                                const float* __restrict__ R, int ldr,
+                                                                float* __restrict__ C, int ldc, int M, int N, int K,
+                                                                int m_tiles, int n_tiles, int n_total, int n0) {
+  // W3 holds all n_total rows of the packed matrix; this GEMM uses rows [n0, n0 + N) (e.g. the q / kv halves of an
+  // in_proj_weight)
+  constexpr int A_PLANE = XM * XK;                 // bf16 elements
+  constexpr int W_PLANE = XN * XK;
+  constexpr int BUF = 3 * A_PLANE + 3 * W_PLANE;   // bf16 elements per buffer (18432 = 36 KB)
+  constexpr int CP = XN + 4;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * BUF];
+  static_assert(2 * BUF * 2 >= 64 * CP * 4, "epilogue staging must fit");
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int total_ids = ((m_tiles + 7) / 8) * 8 * n_tiles;
+  int bm = 0, bn = 0;
+  auto tile_of = [&](int id, int& tbm, int& tbn) -> bool {
+    const int xcd = id & 7, j = id >> 3;
+    const int mt = (j / n_tiles) * 8 + xcd, nt = j % n_tiles;
+    tbm = mt * XM;
+    tbn = nt * XN;
+    return mt < m_tiles;
+  };
+
+  // ---- staging: A through registers (fp32 -> 3 bf16 planes), W planes by LDS-DMA (global_load_lds, 16 B per lane:
+  // the W part of a buffer is lane-linear in exactly the order idx = tid + 256*i, so the DMA needs no VGPRs at all)
+  f32x4 ra[2];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const size_t w_slab = (size_t)3 * n_total * XK;  // bf16 elements per K-slab of W3
+  auto gload_a = [&](int ks) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i, r = idx >> 2, c = (idx & 3) * 4;
+      const int ga = bm + r;
+      ra[i] = ga < M ? *reinterpret_cast<const f32x4*>(A + (size_t)ga * lda + ks * XK + c) : zero4;
+    }
+  };
+  auto dma_w = [&](int ks, int buf) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int idx = tid + 256 * i, p = idx >> 9, rem = idx & 511, r = rem >> 1, ch = rem & 1;
+      int gw = bn + r;
+      gw = gw < N ? gw : N - 1;                    // columns >= N are computed on clamped rows and never stored
+      const __bf16* src = W3 + (size_t)ks * w_slab + ((size_t)p * n_total + n0 + gw) * XK + ch * 8;
+      __bf16* dst = lds + buf * BUF + 3 * A_PLANE + (256 * i + wave * 64) * 8;   // wave-uniform base; lane adds 16 B
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+  auto sstore_a = [&](int buf) {
+    __bf16* Ab = lds + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i, r = idx >> 2, c = (idx & 3) * 4;
+      bf16x4 hi, mid, lo;
+      split3(ra[i], hi, mid, lo);
+      *reinterpret_cast<bf16x4*>(Ab + 0 * A_PLANE + r * XK + c) = hi;
+      *reinterpret_cast<bf16x4*>(Ab + 1 * A_PLANE + r * XK + c) = mid;
+      *reinterpret_cast<bf16x4*>(Ab + 2 * A_PLANE + r * XK + c) = lo;
+    }
+  };
+
+  const int nk = K / XK;
+  int id = blockIdx.x;
+  while (id < total_ids && !tile_of(id, bm, bn)) id += gridDim.x;
+  if (id >= total_ids) return;
+  gload_a(0);
+  for (;;) {
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    dma_w(0, 0);
+    sstore_a(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) {
+        dma_w(kt + 1, cur ^ 1);                    // buffer cur^1 was released by the barrier that ended slab kt-1
+        gload_a(kt + 1);
+      }
+      const __bf16* Ab = lds + cur * BUF + (wr * 64 + l31) * XK + half * 8;
+      const __bf16* Wb = lds + cur * BUF + 3 * A_PLANE + (wc * 128 + l31) * XK + half * 8;
+      bf16x8 fa[2][3], fb[4][3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) fa[a][p] = *reinterpret_cast<const bf16x8*>(Ab + p * A_PLANE + a * 32 * XK);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) fb[b][p] = *reinterpret_cast<const bf16x8*>(Wb + p * W_PLANE + b * 32 * XK);
+      }
+      // six partial products, smallest first; term-major order keeps 8 independent accumulators between reuses
+      term<2, 0>(acc, fa, fb);
+      term<0, 2>(acc, fa, fb);
+      term<1, 1>(acc, fa, fb);
+      term<1, 0>(acc, fa, fb);
+      term<0, 1>(acc, fa, fb);
+      term<0, 0>(acc, fa, fb);
+      if (kt + 1 < nk) sstore_a(cur ^ 1);
+      __syncthreads();
+    }
+
+    // ---- epilogue: two chunks of 64 rows (tile row a of both wave rows) staged through LDS
+    float* Cs = reinterpret_cast<float*>(lds);   // [64][XN + 4]
+    const bool vec_ok = !(ldc & 3) && (!RESID || !(ldr & 3));
+    const int cbm = bm, cbn = bn;
+    int nid = id + gridDim.x;
+    while (nid < total_ids && !tile_of(nid, bm, bn)) nid += gridDim.x;
+    const bool have_next = nid < total_ids;
+    if (have_next) gload_a(0);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          Cs[(wr * 32 + mfma_row(r, half)) * CP + wc * 128 + b * 32 + l31] = acc[a][b][r];
+      __syncthreads();
+#pragma unroll 4
+      for (int i = 0; i < 16; ++i) {
+        const int idx = tid + 256 * i, lr = idx >> 6, col = (idx & 63) * 4;
+        const int grow = cbm + (lr >> 5) * 64 + a * 32 + (lr & 31), gcol = cbn + col;
+        if (grow >= M || gcol >= N) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(Cs + lr * CP + col);
+        if (vec_ok && gcol + 3 < N) {
+          if (bias) v += *reinterpret_cast<const f32x4*>(bias + gcol);
+          if (RESID) v += *reinterpret_cast<const f32x4*>(R + (size_t)grow * ldr + gcol);
+          if (RELU) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+          }
+          *reinterpret_cast<f32x4*>(C + (size_t)grow * ldc + gcol) = v;
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (gcol + c < N) {
+              float x = v[c] + (bias ? bias[gcol + c] : 0.f);
+              if (RESID) x += R[(size_t)grow * ldr + gcol + c];
+              if (RELU) x = fmaxf(x, 0.f);
+              C[(size_t)grow * ldc + gcol + c] = x;
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (!have_next) break;
+    id = nid;
+  }
+}
+
+int launch_gemm_nt_bf16x6(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias, const float* R, int ldr, float* C,
+                          int ldc, int M, int N, int K, int relu, hipStream_t st) {
+  if (M <= 0) return CTRLSIM_OK;
+  if (K % XK != 0 || (lda & 3) || N <= 0 || !W3 || n0 < 0 || n0 + N > n_total) return CTRLSIM_EINVAL;
+  const int m_tiles = (M + XM - 1) / XM, n_tiles = (N + XN - 1) / XN;
+  const int total = ((m_tiles + 7) / 8) * 8 * n_tiles;
+  const int resident = 256 * 2;
+  const int grid = total < resident ? total : resident;
+  dim3 g(grid), b(256);
+  const __bf16* w = static_cast<const __bf16*>(W3);
+  prof_before(PROF_GEMM, st);
+  if (R) {
+    if (relu) return CTRLSIM_EINVAL;
+    hipLaunchKernelGGL((gemm_nt_bf16x6_kernel<false, true>), g, b, 0, st, A, lda, w, bias, R, ldr, C, ldc, M, N, K, m_tiles,
+                       n_tiles, n_total, n0);
+  } else if (relu) {
+    hipLaunchKernelGGL((gemm_nt_bf16x6_kernel<true, false>), g, b, 0, st, A, lda, w, bias, R, ldr, C, ldc, M, N, K, m_tiles,
+                       n_tiles, n_total, n0);
+  } else {
+    hipLaunchKernelGGL((gemm_nt_bf16x6_kernel<false, false>), g, b, 0, st, A, lda, w, bias, R, ldr, C, ldc, M, N, K, m_tiles,
+                       n_tiles, n_total, n0);
+  }
+  prof_after(PROF_GEMM, 2.0 * (double)M * (double)N * (double)K, st);
+  return ctrlsim_launch_status();
+}

@@ -57,10 +57,46 @@ def fold(dims: Dims, w: dict) -> dict:
     return {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in out.items()}
 
 
+def bf16_rne(x: np.ndarray) -> np.ndarray:
+    """float32 -> bfloat16 bits (uint16), round-to-nearest-even (what v_cvt_pk_bf16_f32 does)."""
+    b = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    r = (b + 0x7FFF + ((b >> 16) & 1)) >> 16
+    return r.astype(np.uint16)
+
+
+def bf16_to_f32(h: np.ndarray) -> np.ndarray:
+    return (h.astype(np.uint32) << 16).view(np.float32)
+
+
+def split3_planes(W: np.ndarray) -> np.ndarray:
+    """[N,K] float32 -> slab-major bf16 planes [K/16][3][N][16] (uint16): W = hi + mid + lo, the operand layout of
+    csrc/gemm_bf16x6.hip."""
+    W = np.ascontiguousarray(W, np.float32)
+    N, K = W.shape
+    assert K % 16 == 0
+    hi = bf16_rne(W)
+    r1 = W - bf16_to_f32(hi)
+    mid = bf16_rne(r1)
+    r2 = r1 - bf16_to_f32(mid)
+    lo = bf16_rne(r2)
+    planes = np.stack([hi, mid, lo], 0).reshape(3, N, K // 16, 16)       # [3][N][K/16][16]
+    return np.ascontiguousarray(planes.transpose(2, 0, 1, 3))            # [K/16][3][N][16]
+
+
+BF3_SUFFIX = "#bf3"
+
+
 def pack(dims: Dims, w: dict):
     """-> (flat float32 ndarray, names list, offsets int64 ndarray in floats)."""
     allw = dict(w)
     allw.update(fold(dims, w))
+    # bf16x3 planes of every matrix that feeds the MFMA GEMM (2-D, K multiple of 16); stored as raw 16-bit words
+    for k in list(allw.keys()):
+        v = allw[k]
+        if v.ndim == 2 and v.shape[1] % 16 == 0 and v.shape[1] >= 32 and (k.endswith("weight") or k.endswith(".w")) \
+                and "embed_action" not in k and "embed_rtg_" not in k and "embed_timestep" not in k and "embed_agent_id" not in k:
+            planes = split3_planes(v)
+            allw[k + BF3_SUFFIX] = planes.reshape(-1).view(np.float32)
     names, offsets, chunks = [], [], []
     off = 0
     for k, v in allw.items():

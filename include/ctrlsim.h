@@ -119,6 +119,10 @@ int ctrlsim_sample_action(const float* act_logits, int A, int V, const int* mem_
 /* ---- building blocks (exported for parity tests and profiling) ------------------------------------------------ */
 int ctrlsim_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr,
                     float* C, int ldc, int M, int N, int K, int relu, hipStream_t stream);
+/* Same product evaluated on the bf16 MFMA with fp32-class accuracy: W3 = the weight split into three bf16 planes, slab-major
+ * [K/16][3][n_total][16] (ctrlsim_amd/pack.py:split3_planes); rows [n0, n0+N) of it are used; A stays fp32. */
+int ctrlsim_gemm_nt_bf16x6(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias, const float* R,
+                           int ldr, float* C, int ldc, int M, int N, int K, int relu, hipStream_t stream);
 int ctrlsim_layernorm256(const float* X, int ldx, const float* Radd, int ldr, const float* gamma, const float* beta,
                          float* Y, int ldy, int rows, int relu, hipStream_t stream);
 /* mode 0: key padding (key_pad [B,Lk], 1 = ignore); mode 1: CtRL-Sim structured causal mask (utils/train_utils.py:81-129) */

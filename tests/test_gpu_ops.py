@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 from ctrlsim_amd import _lib  # noqa: E402
 import model_oracle as mo  # noqa: E402
-from gpu_utils import DEV, gemm  # noqa: E402
+from gpu_utils import DEV, gemm, gemm_bf16x6  # noqa: E402
 
 
 @pytest.mark.parametrize("M,N,K,relu,resid", [(128, 128, 256, False, False), (300, 1050, 256, False, False),
@@ -34,6 +34,32 @@ def test_gemm_nt(M, N, K, relu, resid):
     A2 = torch.zeros(M, K, device=DEV); A2[torch.arange(M), torch.arange(M) % K] = 1.0
     out2 = gemm(A2, W, None, None, False)
     assert torch.equal(out2, W.T[torch.arange(M) % K])
+
+
+@pytest.mark.parametrize("M,N,K,relu,resid,n0", [(128, 256, 256, False, False, 0), (300, 1050, 256, False, False, 0),
+                                                 (1000, 768, 256, True, False, 0), (777, 256, 1024, False, True, 0),
+                                                 (5000, 256, 256, False, False, 256), (24, 1000, 256, False, False, 0),
+                                                 (4097, 512, 512, False, False, 256)])
+def test_gemm_bf16x6_has_fp32_class_accuracy(M, N, K, relu, resid, n0):
+    """The split-bf16 GEMM must be as accurate as the f32-input MFMA GEMM: both are compared with an fp64 reference."""
+    g = torch.Generator().manual_seed(M + N + 7)
+    A = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).to(DEV)     # rows of varying scale
+    Wfull = (torch.randn(n0 + N, K, generator=g) * 0.1)
+    b = torch.randn(N, generator=g).to(DEV)
+    R = torch.randn(M, N, generator=g).to(DEV) if resid else None
+    out = gemm_bf16x6(A, Wfull, b, R, relu, n0=n0, n=N)
+    Wd = Wfull[n0:n0 + N].to(DEV).contiguous()
+    out32 = gemm(A, Wd, b, R, relu)
+    ref = A.double() @ Wd.double().T + b.double()
+    if resid:
+        ref = ref + R.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    scale = (A.double().abs() @ Wd.double().abs().T).clamp_min(1e-30)          # sum |a||w|: the natural error scale
+    e6 = ((out.double() - ref).abs() / scale).max().item()
+    e32 = ((out32.double() - ref).abs() / scale).max().item()
+    print(f"relative-to-sum|ab| error: bf16x6 {e6:.2e}  f32 mfma {e32:.2e}")
+    assert e6 < 4e-7 and e6 < 8 * e32 + 1e-9, (e6, e32)
 
 
 def test_layernorm_and_in_place():
