@@ -51,7 +51,16 @@ void prof_after(int cls, double flops, hipStream_t st) {
   g_recs.push_back(ProfRec{g_pending[cls], b, cls, flops});
 }
 
+static int g_options[OPT_COUNT] = {1, 1};
+int ctrlsim_option(int key) { return (key >= 0 && key < OPT_COUNT) ? g_options[key] : 0; }
+
 extern "C" {
+
+int ctrlsim_set_option(int key, int value) {
+  if (key < 0 || key >= OPT_COUNT) return CTRLSIM_EINVAL;
+  g_options[key] = value;
+  return CTRLSIM_OK;
+}
 
 // enable/disable event timing; enabling clears previous records
 void ctrlsim_prof_enable(int on) {

@@ -235,11 +235,17 @@ __global__ __launch_bounds__(256, ATT_WPS) void attention_f32_kernel(
   }
 }
 
+int launch_attention_bf16x6(int, const float*, int, long, const float*, const float*, int, long, float*, int, long, const int*,
+                            const unsigned char*, int, int, int, int, hipStream_t);
+
 int launch_attention(int mode, const float* Q, int ldq, long q_batch_stride, const float* K, const float* V, int ldkv,
                      long kv_batch_stride, float* O, int ldo, long o_batch_stride, const int* q_pos,
                      const unsigned char* key_pad, int B, int Lq, int Lk, int A, hipStream_t st) {
   if (B <= 0 || Lq <= 0) return CTRLSIM_OK;
   if (Lk <= 0 || (ldq & 3) || (ldkv & 3)) return CTRLSIM_EINVAL;
+  if (ctrlsim_option(OPT_ATTN_IMPL) == 1)
+    return launch_attention_bf16x6(mode, Q, ldq, q_batch_stride, K, V, ldkv, kv_batch_stride, O, ldo, o_batch_stride, q_pos,
+                                   key_pad, B, Lq, Lk, A, st);
   dim3 g((Lq + 127) / 128, NHEAD, B), blk(256);
   const float scale = 0.17677669529663687f * 1.4426950408889634f;  // log2(e)/sqrt(32)
   // algorithmic FLOPs: (QK^T + PV) = 4*32 per visible (query, key) pair and head

@@ -1,0 +1,318 @@
+// Streaming attention with fp32-class accuracy on the bf16 MFMA (gfx950): the split-operand variant of attention.hip.
+//
+// Same contract, modes, masks and work split as attention.hip (read its header first).  Difference: every fp32 operand
+// of the two matrix products is split into three bf16 terms (x = hi + mid + lo) and each product is evaluated as its
+// six leading partial products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (see gemm_bf16x6.hip for the error
+// argument: dropped terms <= 2^-23 relative).  Per 32-key sub-tile a wave issues 24 bf16 MFMAs (768 matrix-pipe
+// cycles) instead of 32 f32-input MFMAs (2048 cycles).
+//
+//   S^T = K.Q^T   A = K rows  (bf16 planes in LDS [3][64 keys][32 d], row stride 40 -> conflict-free ds_read_b128),
+//                 B = the wave's Q fragment, pre-scaled by log2(e)/sqrt(32) in fp32, split once, held in registers.
+//   softmax       unchanged (fp32, lane-local: one query per lane column).
+//   O^T += V^T.P^T A = V^T (bf16 planes stored TRANSPOSED in LDS [3][32 d][64 keys], row stride 68 -> conflict-free
+//                 ds_read_b64), B = P^T: the exponentiated scores of the lane are split in registers and packed in
+//                 accumulator-register order.  The MFMA k-slot <-> key map is free as long as both operands agree:
+//                 slot j of lane-half h  <->  key 16*kk + (j&3) + 8*(j>>2) + 4*h, which is exactly the C-fragment row
+//                 map of the S^T tile, so P never moves between lanes.
+// Two accumulator chains (even / odd k-step) per product keep dependent MFMAs apart.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define KT6 64
+#define KS6 40     // K plane row stride (bf16)
+#define VS6 68     // V^T plane row stride (bf16)
+
+enum { MODE6_KEYPAD = 0, MODE6_CAUSAL = 1 };
+
+__device__ __forceinline__ void split3v(const f32x4 x, bf16x4& hi, bf16x4& mid, bf16x4& lo) {
+  hi = __builtin_convertvector(x, bf16x4);
+  const f32x4 r1 = x - __builtin_convertvector(hi, f32x4);
+  mid = __builtin_convertvector(r1, bf16x4);
+  const f32x4 r2 = r1 - __builtin_convertvector(mid, f32x4);
+  lo = __builtin_convertvector(r2, bf16x4);
+}
+
+__device__ __forceinline__ bf16x8 cat8(const bf16x4 a, const bf16x4 b) {
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void attention_bf16x6_kernel(
+    const float* __restrict__ Q, int ldq, long q_batch_stride, const float* __restrict__ K,
+    const float* __restrict__ V, int ldkv, long kv_batch_stride, float* __restrict__ O, int ldo, long o_batch_stride,
+    const int* __restrict__ q_pos, const unsigned char* __restrict__ key_pad, int Lq, int Lk, int A, float scale_log2e) {
+  constexpr int K_PLANE = KT6 * KS6;             // bf16 elements
+  constexpr int V_PLANE = HD * VS6;
+  constexpr int BUF = 3 * K_PLANE + 3 * V_PLANE + 2 * KT6;   // + KT6 floats of key-padding bias
+  __shared__ __attribute__((aligned(16))) __bf16 arena[2 * BUF];
+  __shared__ int blk_tmax[4];
+  static_assert(2 * BUF * 2 >= 4 * 32 * 33 * 4, "output transpose must fit");
+
+  const int qblk = (MODE == MODE6_CAUSAL) ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;
+  const int b = blockIdx.z, h = blockIdx.y, qb = qblk * 128;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int A3 = 3 * A;
+  const float NEG_INF = -__builtin_inff();
+
+  // ---- this lane's query: fragment of Q^T (B operand), k-step ks covers d = 16*ks + 8*half .. +7
+  const int qi = qb + wave * 32 + l31;
+  const bool qvalid = qi < Lq;
+  const int qrow = qvalid ? qi : (Lq - 1);
+  const int pos = q_pos ? q_pos[qrow] : qrow;
+  int tq = 0, aq = 0, kq = 0;
+  if (MODE == MODE6_CAUSAL) {
+    tq = pos / A3;
+    const int rem = pos - tq * A3;
+    aq = rem / 3;
+    kq = rem - aq * 3;
+  }
+  bf16x8 qf[2][3];
+  {
+    const float* qp = Q + (size_t)b * q_batch_stride + (size_t)qrow * ldq + h * HD + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f32x4 x0 = *reinterpret_cast<const f32x4*>(qp + ks * 16);
+      f32x4 x1 = *reinterpret_cast<const f32x4*>(qp + ks * 16 + 4);
+      x0 *= scale_log2e;
+      x1 *= scale_log2e;
+      bf16x4 h0, m0, l0, h1, m1, l1;
+      split3v(x0, h0, m0, l0);
+      split3v(x1, h1, m1, l1);
+      qf[ks][0] = cat8(h0, h1);
+      qf[ks][1] = cat8(m0, m1);
+      qf[ks][2] = cat8(l0, l1);
+    }
+  }
+
+  // ---- key range
+  int k_end = Lk;
+  int tq_min_w = 0, tq_max_w = 0;
+  if (MODE == MODE6_CAUSAL) {
+    int tmin = tq, tmax = tq;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      tmin = min(tmin, __shfl_xor(tmin, o, 64));
+      tmax = max(tmax, __shfl_xor(tmax, o, 64));
+    }
+    tq_min_w = tmin;
+    tq_max_w = tmax;
+    if (lane == 0) blk_tmax[wave] = tmax;
+    __syncthreads();
+    const int bt = max(max(blk_tmax[0], blk_tmax[1]), max(blk_tmax[2], blk_tmax[3]));
+    k_end = min(Lk, (bt + 1) * A3);
+  }
+
+  f32x16 oa, ob;                                   // O^T accumulators of the even / odd k-step chains
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { oa[r] = 0.f; ob[r] = 0.f; }
+  float m_run = NEG_INF, l_run = 0.f;
+
+  const float* Kb = K + (size_t)b * kv_batch_stride + h * HD;
+  const float* Vb = V + (size_t)b * kv_batch_stride + h * HD;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  f32x4 pk[2], pv[2];
+  float ppad = 0.f;
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i, r = idx >> 3, c = (idx & 7) * 4;
+      const int kr = k0 + r;
+      pk[i] = zero4; pv[i] = zero4;
+      if (kr < Lk) {
+        pk[i] = *reinterpret_cast<const f32x4*>(Kb + (size_t)kr * ldkv + c);
+        pv[i] = *reinterpret_cast<const f32x4*>(Vb + (size_t)kr * ldkv + c);
+      }
+    }
+    if (MODE == MODE6_KEYPAD && tid < KT6) {
+      const int kr = k0 + tid;
+      ppad = (kr < Lk && !key_pad[(size_t)b * Lk + kr]) ? 0.f : NEG_INF;
+    }
+  };
+  auto sstore = [&](int buf) {
+    __bf16* Kd = arena + buf * BUF;
+    __bf16* Vd = Kd + 3 * K_PLANE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i, r = idx >> 3, c = (idx & 7) * 4;
+      bf16x4 hi, mid, lo;
+      split3v(pk[i], hi, mid, lo);
+      *reinterpret_cast<bf16x4*>(Kd + 0 * K_PLANE + r * KS6 + c) = hi;
+      *reinterpret_cast<bf16x4*>(Kd + 1 * K_PLANE + r * KS6 + c) = mid;
+      *reinterpret_cast<bf16x4*>(Kd + 2 * K_PLANE + r * KS6 + c) = lo;
+      split3v(pv[i], hi, mid, lo);                 // V is stored transposed: Vd[plane][d][key]
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        Vd[0 * V_PLANE + (c + e) * VS6 + r] = hi[e];
+        Vd[1 * V_PLANE + (c + e) * VS6 + r] = mid[e];
+        Vd[2 * V_PLANE + (c + e) * VS6 + r] = lo[e];
+      }
+    }
+    if (MODE == MODE6_KEYPAD && tid < KT6) reinterpret_cast<float*>(Vd + 3 * V_PLANE)[tid] = ppad;
+  };
+
+  if (k_end > 0) {
+    gload(0);
+    sstore(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = 0; k0 < k_end; k0 += KT6, cur ^= 1) {
+    const bool more = k0 + KT6 < k_end;
+    if (more) gload(k0 + KT6);
+    const __bf16* Ks = arena + cur * BUF;
+    const __bf16* Vs = Ks + 3 * K_PLANE;
+    const float* padbias = reinterpret_cast<const float*>(Vs + 3 * V_PLANE);
+
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int ks0 = k0 + sub * 32;
+      if (ks0 >= k_end) continue;
+      bool need_mask = true;
+      if (MODE == MODE6_CAUSAL) {
+        const int t_lo = ks0 / A3, t_hi = min(ks0 + 31, Lk - 1) / A3;
+        if (t_lo > tq_max_w) continue;
+        need_mask = !(t_hi < tq_min_w && ks0 + 31 < Lk);
+      }
+      // ---- S^T = K . Q^T : two chains (d 0-15, d 16-31), six partial products each
+      f32x16 s0, s1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+      {
+        const __bf16* kr_ = Ks + (sub * 32 + l31) * KS6 + half * 8;
+        bf16x8 k0f[3], k1f[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          k0f[p] = *reinterpret_cast<const bf16x8*>(kr_ + p * K_PLANE);
+          k1f[p] = *reinterpret_cast<const bf16x8*>(kr_ + p * K_PLANE + 16);
+        }
+#define QK(PA, PB)                                                                        \
+  s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0f[PA], qf[0][PB], s0, 0, 0, 0);           \
+  s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1f[PA], qf[1][PB], s1, 0, 0, 0);
+        QK(2, 0) QK(0, 2) QK(1, 1) QK(1, 0) QK(0, 1) QK(0, 0)
+#undef QK
+      }
+      float sc[16];
+      if (MODE == MODE6_KEYPAD) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = (s0[r] + s1[r]) + padbias[sub * 32 + mfma_row(r, half)];
+      } else if (need_mask) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kj = ks0 + mfma_row(r, half);
+          const int tj = kj / A3;
+          const int rem = kj - tj * A3;
+          const int aj = rem / 3;
+          const int kk = rem - aj * 3;
+          const bool vis = (kj < Lk) && ((tj < tq) || (tj == tq && ((aj == aq && kk <= kq) || kk == 0)));
+          sc[r] = vis ? (s0[r] + s1[r]) : NEG_INF;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = s0[r] + s1[r];
+      }
+      // ---- online softmax
+      float tmax = sc[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sc[r]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m_run, tmax);
+      const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sc[r] = __builtin_amdgcn_exp2f(sc[r] - m_use);
+        psum += sc[r];
+      }
+      psum += __shfl_xor(psum, 32, 64);
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+      if (!__all(alpha == 1.0f)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { oa[r] *= alpha; ob[r] *= alpha; }
+      }
+      // ---- P^T fragments: k-step kk uses accumulator registers 8*kk .. 8*kk+7 (slot j <-> register 8*kk + j)
+      bf16x8 pf[2][3];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const f32x4 x0 = {sc[8 * kk + 0], sc[8 * kk + 1], sc[8 * kk + 2], sc[8 * kk + 3]};
+        const f32x4 x1 = {sc[8 * kk + 4], sc[8 * kk + 5], sc[8 * kk + 6], sc[8 * kk + 7]};
+        bf16x4 h0, m0, l0, h1, m1, l1;
+        split3v(x0, h0, m0, l0);
+        split3v(x1, h1, m1, l1);
+        pf[kk][0] = cat8(h0, h1);
+        pf[kk][1] = cat8(m0, m1);
+        pf[kk][2] = cat8(l0, l1);
+      }
+      // ---- O^T += V^T . P^T : A = V^T rows d = l31, slots 0-3 <-> keys 16kk+4half+0..3, slots 4-7 <-> +8
+      {
+        const __bf16* vr_ = Vs + l31 * VS6 + sub * 32 + half * 4;
+        bf16x8 v0f[3], v1f[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const bf16x4 a0 = *reinterpret_cast<const bf16x4*>(vr_ + p * V_PLANE);
+          const bf16x4 a1 = *reinterpret_cast<const bf16x4*>(vr_ + p * V_PLANE + 8);
+          const bf16x4 b0 = *reinterpret_cast<const bf16x4*>(vr_ + p * V_PLANE + 16);
+          const bf16x4 b1 = *reinterpret_cast<const bf16x4*>(vr_ + p * V_PLANE + 24);
+          v0f[p] = cat8(a0, a1);
+          v1f[p] = cat8(b0, b1);
+        }
+#define PV(PA, PB)                                                                        \
+  oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0f[PA], pf[0][PB], oa, 0, 0, 0);           \
+  ob = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1f[PA], pf[1][PB], ob, 0, 0, 0);
+        PV(2, 0) PV(0, 2) PV(1, 1) PV(1, 0) PV(0, 1) PV(0, 0)
+#undef PV
+      }
+    }
+    if (more) sstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- normalise, transpose through LDS, store rows
+  const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+  float* ot = reinterpret_cast<float*>(arena) + wave * (32 * 33);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ot[l31 * 33 + mfma_row(r, half)] = (oa[r] + ob[r]) * inv;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int q = i * 2 + half;
+    const int gq = qb + wave * 32 + q;
+    if (gq < Lq) O[(size_t)b * o_batch_stride + (size_t)gq * ldo + h * HD + l31] = ot[q * 33 + l31];
+  }
+}
+
+int launch_attention_bf16x6(int mode, const float* Q, int ldq, long q_batch_stride, const float* K, const float* V,
+                            int ldkv, long kv_batch_stride, float* O, int ldo, long o_batch_stride, const int* q_pos,
+                            const unsigned char* key_pad, int B, int Lq, int Lk, int A, hipStream_t st) {
+  if (B <= 0 || Lq <= 0) return CTRLSIM_OK;
+  if (Lk <= 0 || (ldq & 3) || (ldkv & 3)) return CTRLSIM_EINVAL;
+  dim3 g((Lq + 127) / 128, NHEAD, B), blk(256);
+  const float scale = 0.17677669529663687f * 1.4426950408889634f;  // log2(e)/sqrt(32)
+  double pairs;
+  if (mode == MODE6_CAUSAL) {
+    const double A3 = 3.0 * A;
+    if (!q_pos) {
+      const double T = (double)Lq / A3;
+      pairs = A3 * A3 * T * (T - 1) / 2.0 + T * A * (3.0 * A + 3.0);
+    } else {
+      pairs = (double)Lq * (double)Lk;
+    }
+  } else {
+    pairs = (double)Lq * (double)Lk;
+  }
+  prof_before(PROF_ATTN, st);
+  if (mode == MODE6_CAUSAL) {
+    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL>), g, blk, 0, st, Q, ldq, q_batch_stride, K, V, ldkv,
+                       kv_batch_stride, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale);
+  } else {
+    if (!key_pad) return CTRLSIM_EINVAL;
+    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD>), g, blk, 0, st, Q, ldq, q_batch_stride, K, V, ldkv,
+                       kv_batch_stride, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale);
+  }
+  prof_after(PROF_ATTN, pairs * 128.0 * NHEAD * B, st);
+  return ctrlsim_launch_status();
+}

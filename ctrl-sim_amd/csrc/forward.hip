@@ -209,7 +209,7 @@ __global__ void fill_index_kernel(int B, int A, int L, int ti, int P, int M, int
 // y = act(x W^T + b [+ R]) through the bf16x6 MFMA kernel when the packed planes exist, else the f32-input MFMA kernel
 int gemm(const Lin& L, const float* x, int ldx, const float* R, int ldr, float* y, int ldy, int rows, int n, int k, int relu,
          hipStream_t st) {
-  if (L.w3 && k % 16 == 0)
+  if (L.w3 && k % 16 == 0 && ctrlsim_option(OPT_GEMM_IMPL) == 1)
     return launch_gemm_nt_bf16x6(x, ldx, L.w3, L.ntot ? L.ntot : n, L.n0, L.b, R, ldr, y, ldy, rows, n, k, relu, st);
   return gemm(L, x, ldx, R, ldr, y, ldy, rows, n, k, relu, st);
 }

@@ -69,8 +69,8 @@ def bf16_to_f32(h: np.ndarray) -> np.ndarray:
 
 
 def split3_planes(W: np.ndarray) -> np.ndarray:
-    """[N,K] float32 -> slab-major bf16 planes [K/16][3][N][16] (uint16): W = hi + mid + lo, the operand layout of
-    csrc/gemm_bf16x6.hip."""
+    """[N,K] float32 -> slab-major bf16 planes [K/16][3][2][N][8] (uint16): W = hi + mid + lo, each 16-wide k-step stored
+    as two 8-wide half planes — the operand layout of csrc/gemm_bf16x6.hip."""
     W = np.ascontiguousarray(W, np.float32)
     N, K = W.shape
     assert K % 16 == 0
@@ -79,8 +79,8 @@ def split3_planes(W: np.ndarray) -> np.ndarray:
     mid = bf16_rne(r1)
     r2 = r1 - bf16_to_f32(mid)
     lo = bf16_rne(r2)
-    planes = np.stack([hi, mid, lo], 0).reshape(3, N, K // 16, 16)       # [3][N][K/16][16]
-    return np.ascontiguousarray(planes.transpose(2, 0, 1, 3))            # [K/16][3][N][16]
+    planes = np.stack([hi, mid, lo], 0).reshape(3, N, K // 16, 2, 8)     # [3][N][K/16][2][8]
+    return np.ascontiguousarray(planes.transpose(2, 0, 3, 1, 4))         # [K/16][3][2][N][8]
 
 
 BF3_SUFFIX = "#bf3"

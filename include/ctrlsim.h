@@ -136,6 +136,10 @@ int ctrlsim_attention(int mode, const float* Q, int ldq, int64_t q_batch_stride,
 void ctrlsim_prof_enable(int on);
 int ctrlsim_prof_collect(double* ms2, int64_t* count2, double* flops2);
 
+/* Runtime options: key 0 = attention path, key 1 = GEMM path of the forward; value 0 = f32-input MFMA
+ * (v_mfma_f32_32x32x2_f32), 1 = split-bf16 "bf16x6" MFMA with fp32-class accuracy (default). */
+int ctrlsim_set_option(int key, int value);
+
 const char* ctrlsim_version(void);
 
 #ifdef __cplusplus

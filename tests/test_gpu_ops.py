@@ -87,8 +87,15 @@ def _attn_ref(q, k, v, vis):  # q [B,H,Lq,32] ... vis bool [B,1|H,Lq,Lk]
     return (torch.softmax(s, -1) @ v.double())
 
 
+@pytest.fixture(params=[0, 1], ids=["f32mfma", "bf16x6"])
+def attn_impl(request):
+    _lib.lib().ctrlsim_set_option(0, request.param)
+    yield request.param
+    _lib.lib().ctrlsim_set_option(0, 1)
+
+
 @pytest.mark.parametrize("A,T", [(24, 32), (4, 4), (6, 8), (24, 7)])
-def test_attention_structured_causal_mask(A, T):
+def test_attention_structured_causal_mask(A, T, attn_impl):
     B, H = 2, 8
     L = A * T * 3
     g = torch.Generator().manual_seed(A * T)
@@ -112,7 +119,7 @@ def test_attention_structured_causal_mask(A, T):
 
 
 @pytest.mark.parametrize("Lq,Lk", [(224, 224), (2304, 224), (10, 10), (24, 224), (130, 67)])
-def test_attention_key_padding(Lq, Lk):
+def test_attention_key_padding(Lq, Lk, attn_impl):
     B, H = 3, 8
     g = torch.Generator().manual_seed(Lq + Lk)
     Q = torch.randn(B, Lq, 256, generator=g).to(DEV)
