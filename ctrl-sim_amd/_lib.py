@@ -41,12 +41,13 @@ SIGNATURES = {
     "ctrlsim_sim_step": (I, [I, I, I, P, P, P, P, P, P, P, P, P, P, I, I, F, I, P]),
     "ctrlsim_group_build": (I, [I, I, I, I, I, I, D, P, P, I, P, P, P, P, P, P, P, P, P]),
     "ctrlsim_ctx_index": (I, [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),
-    "ctrlsim_build_context": (I, [I] * 11 + [P] * 12 + [C.POINTER(Ctx), P]),
+    "ctrlsim_build_context": (I, [I] * 12 + [P] * 12 + [C.POINTER(Ctx), P]),
     "ctrlsim_model_create": (I, [C.POINTER(Dims), P, I, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(P)]),
     "ctrlsim_model_destroy": (None, [P]),
     "ctrlsim_forward_workspace_bytes": (L, [C.POINTER(Dims), I, I]),
     "ctrlsim_dt_forward_pass1": (I, [P, I, I, C.POINTER(Ctx), P, P, P, P]),
-    "ctrlsim_dt_forward_pass2": (I, [P, I, I, I, I, I, C.POINTER(Ctx), P, P, P, P, P]),
+    "ctrlsim_dt_forward_pass2": (I, [P, I, I, I, I, I, C.POINTER(Ctx), P, P, P, P, I, P]),
+    "ctrlsim_dt_forward_pass1_cached": (I, [P, I, I, C.POINTER(Ctx), P, P, P]),
     "ctrlsim_sample_rtg": (I, [P, I, I, P, P, P, P, P, U64, P, I, P, I, I, I, P]),
     "ctrlsim_sample_action": (I, [P, I, I, P, P, F, D, P, U64, P, I, P, P, I, I, I, I, P]),
 }

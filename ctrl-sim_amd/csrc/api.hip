@@ -19,7 +19,7 @@ int launch_group_build(int, int, int, int, int, int, double, const float*, const
 int launch_ctx_index(int, int, int, const int*, const int*, const unsigned long long*, const int*, const int*, int*, int*,
                      int*, int*, int*, int*, int*, hipStream_t);
 struct CtxOut { float *st12, *exist, *goal5; int *act_tok, *rtg_bin, *tstep, *slot_gid; float *road_pts, *road_types; };
-int launch_build_context(int, int, int, int, int, int, int, int, int, int, int, const int*, const int*, const int*,
+int launch_build_context(int, int, int, int, int, int, int, int, int, int, int, int, const int*, const int*, const int*,
                          const unsigned long long*, const float*, const int*, const int*, const double*, const float*,
                          const float*, const float*, const int*, CtxOut, hipStream_t);
 int launch_sample_rtg(const float*, int, int, const int*, const int*, const unsigned char*, const double*, const float*,
@@ -122,7 +122,7 @@ int ctrlsim_ctx_index(int s0, int s1, int N, const int* n_groups, const int* grp
   return launch_ctx_index(s0, s1, N, n_groups, grp_focal, (const unsigned long long*)grp_ids, own_g, mem_g, ctx_scn, ctx_grp,
                           own_ctx, own_slot, mem_ctx, mem_slot, ctx_base, st);
 }
-int ctrlsim_build_context(int B, int N, int A, int T, int t, int Tq, int Tmax1, int Tmax, int P_all, int P, int NP,
+int ctrlsim_build_context(int B, int N, int A, int T, int t, int Tq, int tt_first, int Tmax1, int Tmax, int P_all, int P, int NP,
                           const int* ctx_scn, const int* ctx_grp, const int* grp_focal, const uint64_t* grp_ids,
                           const float* hist_states, const int* hist_tok, const int* hist_rtg, const double* goals,
                           const float* types, const float* roads, const float* road_types, const int* zero4,
@@ -130,7 +130,7 @@ int ctrlsim_build_context(int B, int N, int A, int T, int t, int Tq, int Tmax1, 
   if (!out || !zero4) return CTRLSIM_EINVAL;
   CtxOut o{out->st12, out->exist, out->goal5, out->act_tok, out->rtg_bin, out->tstep, out->slot_gid, out->road_pts,
            out->road_types};
-  return launch_build_context(B, N, A, T, t, Tq, Tmax1, Tmax, P_all, P, NP, ctx_scn, ctx_grp, grp_focal,
+  return launch_build_context(B, N, A, T, t, Tq, tt_first, Tmax1, Tmax, P_all, P, NP, ctx_scn, ctx_grp, grp_focal,
                               (const unsigned long long*)grp_ids, hist_states, hist_tok, hist_rtg, goals, types, roads,
                               road_types, zero4, o, st);
 }

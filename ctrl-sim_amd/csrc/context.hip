@@ -177,8 +177,10 @@ struct CtxOut {
 };
 
 // One block per context.  Agent part: threads over (tt, slot).  Road part: two sweeps over P_all x NP points.
+// Window rows [tt_first, Tq) are emitted (Tn = Tq - tt_first rows per context): the cached incremental forward only needs
+// the last one or two timesteps; tt_first = 0 gives the whole window.
 __global__ __launch_bounds__(256) void build_context_kernel(
-    int N, int A, int T, int t, int Tq, int Tmax1, int Tmax, int P_all, int P, int NP,
+    int N, int A, int T, int t, int Tq, int tt_first, int Tmax1, int Tmax, int P_all, int P, int NP,
     const int* __restrict__ ctx_scn, const int* __restrict__ ctx_grp, const int* __restrict__ grp_focal,
     const unsigned long long* __restrict__ grp_ids, const float* __restrict__ hist_states,
     const int* __restrict__ hist_tok, const int* __restrict__ hist_rtg, const double* __restrict__ goals,  // [S,N,5] f64
@@ -212,8 +214,9 @@ __global__ __launch_bounds__(256) void build_context_kernel(
   const double tx = (double)f0[0], ty = (double)f0[1];
 
   // ---- agents
-  for (int k = tid; k < Tq * A; k += blockDim.x) {
-    const int tt = k / A, slot = k - tt * A;
+  const int Tn = Tq - tt_first;
+  for (int k = tid; k < Tn * A; k += blockDim.x) {
+    const int to = k / A, slot = k - to * A, tt = tt_first + to;
     double raw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float ty5[5] = {-1.f, -1.f, -1.f, -1.f, -1.f};
     // padded slots: zero action -> placeholder token, zero (un-normalised) rtg rows -> bins (0,0,0) (dataset.py:284-288)
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(256) void build_context_kernel(
       }
     }
     const double px = raw[0] - tx, py = raw[1] - ty;
-    float* so = o.st12 + (((size_t)b * Tq + tt) * A + slot) * 12;
+    float* so = o.st12 + (((size_t)b * Tn + to) * A + slot) * 12;
     so[0] = (float)(cr * px + (-sr) * py);
     so[1] = (float)(sr * px + cr * py);
     so[2] = (float)(cr * raw[2] + (-sr) * raw[3]);
@@ -244,15 +247,15 @@ __global__ __launch_bounds__(256) void build_context_kernel(
     so[6] = (float)raw[6];
 #pragma unroll
     for (int c = 0; c < 5; ++c) so[7 + c] = ty5[c];
-    o.exist[((size_t)b * Tq + tt) * A + slot] = (float)raw[7];
-    o.act_tok[((size_t)b * Tq + tt) * A + slot] = tok;
-    int* rbo = o.rtg_bin + (((size_t)b * Tq + tt) * A + slot) * 3;
+    o.exist[((size_t)b * Tn + to) * A + slot] = (float)raw[7];
+    o.act_tok[((size_t)b * Tn + to) * A + slot] = tok;
+    int* rbo = o.rtg_bin + (((size_t)b * Tn + to) * A + slot) * 3;
     rbo[0] = r0; rbo[1] = r1; rbo[2] = r2;
   }
   // timesteps: self.timesteps[0, window] — rows not yet written are 0 (policy.py:53,79)
-  for (int tt = tid; tt < Tq; tt += blockDim.x) {
-    const int abs_t = w0 + tt;
-    o.tstep[(size_t)b * Tq + tt] = abs_t <= t ? abs_t : 0;
+  for (int to = tid; to < Tn; to += blockDim.x) {
+    const int abs_t = w0 + tt_first + to;
+    o.tstep[(size_t)b * Tn + to] = abs_t <= t ? abs_t : 0;
   }
   // goals (goal row at window index 0; constant in time): dataset.py:408-415
   for (int slot = tid; slot < A; slot += blockDim.x) {
@@ -347,15 +350,15 @@ int launch_ctx_index(int s0, int s1, int N, const int* n_groups, const int* grp_
   return ctrlsim_launch_status();
 }
 
-int launch_build_context(int B, int N, int A, int T, int t, int Tq, int Tmax1, int Tmax, int P_all, int P, int NP,
+int launch_build_context(int B, int N, int A, int T, int t, int Tq, int tt_first, int Tmax1, int Tmax, int P_all, int P, int NP,
                          const int* ctx_scn, const int* ctx_grp, const int* grp_focal,
                          const unsigned long long* grp_ids, const float* hist_states, const int* hist_tok,
                          const int* hist_rtg, const double* goals, const float* types, const float* roads,
                          const float* rtypes, const int* zero4, CtxOut o, hipStream_t st) {
   if (B <= 0) return CTRLSIM_OK;
-  if (N > 64 || A > 64 || Tq < 1) return CTRLSIM_EINVAL;
+  if (N > 64 || A > 64 || Tq < 1 || tt_first < 0 || tt_first >= Tq) return CTRLSIM_EINVAL;
   const size_t shm = (size_t)P_all * sizeof(double) + (size_t)(P > 0 ? P : 1) * sizeof(int);
-  hipLaunchKernelGGL(build_context_kernel, dim3(B), dim3(256), shm, st, N, A, T, t, Tq, Tmax1, Tmax, P_all, P, NP, ctx_scn,
+  hipLaunchKernelGGL(build_context_kernel, dim3(B), dim3(256), shm, st, N, A, T, t, Tq, tt_first, Tmax1, Tmax, P_all, P, NP, ctx_scn,
                      ctx_grp, grp_focal, grp_ids, hist_states, hist_tok, hist_rtg, goals, types, roads, rtypes, zero4[0],
                      zero4[1], zero4[2], zero4[3], o);
   return ctrlsim_launch_status();

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void assemble_tokens_kernel(
 
 // Pass 2: only the RTG tokens of the current timestep change (the sampled bins replace the placeholder); rebuild those
 // A rows per context into a compact [B*A, 256] buffer.  hist_rtg [S,N,Tmax,3] holds the bins sampled this step.
-__global__ __launch_bounds__(256) void assemble_rtg_rows_kernel(int rows, int A, int Tq, int ti, int t, int N, int Tmax,
+__global__ __launch_bounds__(256) void assemble_rtg_rows_kernel(int rows, int A, int Tq, int ti, int t, int N, int Tmax,   // Tq/ti: rows per context / row of the current step IN THE CONTEXT TENSORS
                                                                 const int* __restrict__ ctx_scn,
                                                                 const int* __restrict__ slot_gid,
                                                                 const int* __restrict__ hist_rtg,
@@ -102,6 +102,55 @@ __global__ __launch_bounds__(256) void assemble_rtg_rows_kernel(int rows, int A,
                    *reinterpret_cast<const f32x4*>(tb.rtg_r + (size_t)b2 * DM + c4) +
                    *reinterpret_cast<const f32x4*>(tb.rtg_bias + c4) + pos) * ex;
   *reinterpret_cast<f32x4*>(Xr + (size_t)row * DM + c4) = ln256(v, g, be);
+}
+
+// Cached incremental forward: build only the token rows listed in pos_new[Rn] (the previous step's action tokens, whose
+// ids changed from the placeholder to the applied action, and the 3A tokens of the current timestep) into a compact
+// [B*Rn, 256] buffer.  Context tensors hold the window rows [tt_first, tt_first + Tn).
+__global__ __launch_bounds__(256) void assemble_rows_kernel(int rows, int Rn, int A, int tt_first, int Tn,
+                                                            const int* __restrict__ pos_new,
+                                                            const float* __restrict__ S2,    // [B*Tn*A, 256]
+                                                            const float* __restrict__ Gp,    // [B*A, 256]
+                                                            const float* __restrict__ exist, const int* __restrict__ act_tok,
+                                                            const int* __restrict__ rtg_bin, const int* __restrict__ tstep,
+                                                            EmbedTables tb, float* __restrict__ Xn) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63, c4 = lane * 4;
+  const int b = row / Rn, j = row - b * Rn;
+  const int pos = pos_new[j];
+  const int tt = pos / (3 * A), rem = pos - tt * 3 * A, a = rem / 3, k = rem - a * 3;
+  const int to = tt - tt_first;
+  const size_t cr = ((size_t)b * Tn + to) * A + a;          // row in the context tensors
+  const float ex = exist[cr];
+  const int ts = tstep[(size_t)b * Tn + to];
+  const f32x4 g = *reinterpret_cast<const f32x4*>(tb.ln_g + c4);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(tb.ln_b + c4);
+  const f32x4 posemb = *reinterpret_cast<const f32x4*>(tb.tstep + (size_t)ts * DM + c4) +
+                       *reinterpret_cast<const f32x4*>(tb.agent + (size_t)a * DM + c4);
+  f32x4 v;
+  if (k == 0) {
+    v = *reinterpret_cast<const f32x4*>(S2 + cr * DM + c4) + *reinterpret_cast<const f32x4*>(Gp + ((size_t)b * A + a) * DM + c4);
+  } else if (k == 1) {
+    const int* rb = rtg_bin + cr * 3;
+    v = *reinterpret_cast<const f32x4*>(tb.rtg_g + (size_t)rb[0] * DM + c4) +
+        *reinterpret_cast<const f32x4*>(tb.rtg_v + (size_t)rb[1] * DM + c4) +
+        *reinterpret_cast<const f32x4*>(tb.rtg_r + (size_t)rb[2] * DM + c4) + *reinterpret_cast<const f32x4*>(tb.rtg_bias + c4);
+  } else {
+    v = *reinterpret_cast<const f32x4*>(tb.act + (size_t)act_tok[cr] * DM + c4);
+  }
+  v = (v + posemb) * ex;
+  *reinterpret_cast<f32x4*>(Xn + (size_t)row * DM + c4) = ln256(v, g, be);
+}
+
+int launch_assemble_rows(int B, int Rn, int A, int tt_first, int Tn, const int* pos_new, const float* S2, const float* Gp,
+                         const float* exist, const int* act_tok, const int* rtg_bin, const int* tstep, EmbedTables tb,
+                         float* Xn, hipStream_t st) {
+  const int rows = B * Rn;
+  if (rows <= 0) return CTRLSIM_OK;
+  hipLaunchKernelGGL(assemble_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, rows, Rn, A, tt_first, Tn, pos_new, S2, Gp,
+                     exist, act_tok, rtg_bin, tstep, tb, Xn);
+  return ctrlsim_launch_status();
 }
 
 int launch_assemble_tokens(int B, int Tq, int A, const float* S2, const float* Gp, const float* exist,

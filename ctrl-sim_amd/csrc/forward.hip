@@ -37,6 +37,8 @@ int launch_attention(int, const float*, int, long, const float*, const float*, i
 struct EmbedTables { const float *act, *rtg_g, *rtg_v, *rtg_r, *rtg_bias, *tstep, *agent, *ln_g, *ln_b; };
 int launch_assemble_tokens(int, int, int, const float*, const float*, const float*, const int*, const int*, const int*,
                            EmbedTables, float*, float*, int, int, unsigned char*, hipStream_t);
+int launch_assemble_rows(int, int, int, int, int, const int*, const float*, const float*, const float*, const int*, const int*,
+                         const int*, EmbedTables, float*, hipStream_t);
 int launch_assemble_rtg_rows(int, int, int, int, int, int, int, const int*, const int*, const int*, const float*,
                              const int*, EmbedTables, const int*, float*, hipStream_t);
 struct MapPoolWeights { const float *W1, *b1, *ln_g, *ln_b, *U, *cb, *Mt, *mb; };
@@ -161,6 +163,9 @@ struct Ws {
   float *xc, *xc2, *tmpc, *attc, *qkvc, *qcc, *ffnc, *headh;
   unsigned char* src_pad;
   int *pos_state, *pos_rtg, *idx_state, *idx_rtg, *idx_poly;
+  // cached incremental path: up to 4A new rows per context
+  float *xn, *tmpn, *attn_n, *qkvn, *qcn, *ffnn;
+  int *pos_new, *idx_new, *idx_state_in_new;
   size_t bytes;
 };
 
@@ -190,6 +195,11 @@ Ws carve(const ctrlsim_dims& d, int B, int Tq, char* base) {
   w.idx_state = reinterpret_cast<int*>(take(rA * sizeof(int)));
   w.idx_rtg = reinterpret_cast<int*>(take(rA * sizeof(int)));
   w.idx_poly = reinterpret_cast<int*>(take(rP * sizeof(int)));
+  const size_t rN = rA * 4;
+  w.xn = F(rN, DM); w.tmpn = F(rN, DM); w.attn_n = F(rN, DM); w.qkvn = F(rN, 3 * DM); w.qcn = F(rN, DM); w.ffnn = F(rN, d.F);
+  w.pos_new = reinterpret_cast<int*>(take(4 * d.A * sizeof(int)));
+  w.idx_new = reinterpret_cast<int*>(take(rN * sizeof(int)));
+  w.idx_state_in_new = reinterpret_cast<int*>(take(rA * sizeof(int)));
   w.bytes = off;
   return w;
 }
@@ -212,6 +222,23 @@ int gemm(const Lin& L, const float* x, int ldx, const float* R, int ldr, float* 
   if (L.w3 && k % 16 == 0 && ctrlsim_option(OPT_GEMM_IMPL) == 1)
     return launch_gemm_nt_bf16x6(x, ldx, L.w3, L.ntot ? L.ntot : n, L.n0, L.b, R, ldr, y, ldy, rows, n, k, relu, st);
   return gemm(L, x, ldx, R, ldr, y, ldy, rows, n, k, relu, st);
+}
+
+// index lists of the cached path: new rows of step t are the A action tokens of t-1 (t > 0) and the 3A tokens of t;
+// cache rows live at b * Lf + position with Lf = T * 3A
+__global__ void fill_index_cached_kernel(int B, int A, int Lf, int t, int Rn, int* pos_new, int* idx_new,
+                                         int* idx_state_in_new, int* pos_rtg, int* idx_rtg) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int A3 = 3 * A, off = t > 0 ? A : 0;
+  auto pos_of = [&](int j) { return (t > 0 && j < A) ? (t - 1) * A3 + 3 * j + 2 : t * A3 + (j - off); };
+  if (i < Rn) pos_new[i] = pos_of(i);
+  if (i < A) pos_rtg[i] = t * A3 + 3 * i + 1;
+  if (i < B * Rn) idx_new[i] = (i / Rn) * Lf + pos_of(i % Rn);
+  if (i < B * A) {
+    const int b = i / A, a = i - b * A;
+    idx_state_in_new[i] = b * Rn + off + 3 * a;
+    idx_rtg[i] = b * Lf + t * A3 + 3 * a + 1;
+  }
 }
 
 int mlp_tail(const Mlp& m, const float* h_in, int rows, float* hid, float* out, int n_out, hipStream_t st) {
@@ -237,32 +264,10 @@ int cross_and_ffn(const ctrlsim_model* m, const DecLayer& Ld, int layer, const W
   CHK(launch_layernorm256(tmp, DM, nullptr, 0, Ld.n3.g, Ld.n3.b, x, DM, rows, 0, st));
   return 0;
 }
-}  // namespace
-
-extern "C" int64_t ctrlsim_forward_workspace_bytes(const ctrlsim_dims* d, int B, int Tq) {
-  if (!d || B < 1 || Tq < 1 || Tq > d->T) return CTRLSIM_EINVAL;
-  return (int64_t)carve(*d, B, Tq, nullptr).bytes;
-}
-
-// ------------------------------------------------------------------------------------------------ pass 1
-extern "C" int ctrlsim_dt_forward_pass1(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* c, void* workspace,
-                                        float* rtg_logits, float* dbg_seg_emb, hipStream_t st) {
-  if (!m || !c || !workspace || !rtg_logits || B < 1 || Tq < 1 || Tq > m->d.T) return CTRLSIM_EINVAL;
+// map encoder + scene encoder + per-layer memory K/V (everything that only depends on the frame of the context)
+int scene_side(const ctrlsim_model* m, const Ws& w, const ctrlsim_ctx* c, int B, float* dbg_seg_emb, hipStream_t st) {
   const ctrlsim_dims& d = m->d;
-  const Ws w = carve(d, B, Tq, static_cast<char*>(workspace));
-  const int A = d.A, P = d.P, M = P + A, L = Tq * A * 3, ti = Tq - 1;
-  const int rL = B * L, rM = B * M, rA = B * A, rS = B * Tq * A, rP = B * P;
-  hipLaunchKernelGGL(fill_index_kernel, dim3(((rA > rP ? rA : rP) + 255) / 256), dim3(256), 0, st, B, A, L, ti, P, M,
-                     w.pos_state, w.pos_rtg, w.idx_state, w.idx_rtg, w.idx_poly);
-  // ---- token embeddings (encoder.py:95-153)
-  CHK(launch_in_mlp(c->st12, 12, 12, m->embed_state.l0.w, m->embed_state.l0.b, m->embed_state.ln.g, m->embed_state.ln.b,
-                    w.hS, DM, rS, st));
-  CHK(gemm(m->fold_state, w.hS, DM, nullptr, 0, w.S2, DM, rS, DM, DM, 0, st));
-  CHK(launch_in_mlp(c->goal5, 5, 5, m->embed_goal.l0.w, m->embed_goal.l0.b, m->embed_goal.ln.g, m->embed_goal.ln.b, w.hG,
-                    DM, rA, st));
-  CHK(gemm(m->fold_goal, w.hG, DM, nullptr, 0, w.Gp, DM, rA, DM, DM, 0, st));
-  CHK(launch_assemble_tokens(B, Tq, A, w.S2, w.Gp, c->exist, c->act_tok, c->rtg_bin, c->tstep, m->tb, w.X, w.src, M, P,
-                             w.src_pad, st));
+  const int A = d.A, P = d.P, M = P + A, rM = B * M, rP = B * P;
   // ---- map encoder (map_encoder.py:34-53): rows of `src` 0..P-1 per context
   CHK(launch_map_pool(B, P, d.NP, M, c->road_pts, m->mp, w.attn_pre, w.src_pad, st));
   CHK(gemm(m->map_out, w.attn_pre, DM, nullptr, 0, w.m1, DM, rP, DM, DM, 0, st));
@@ -298,6 +303,36 @@ extern "C" int ctrlsim_dt_forward_pass1(const ctrlsim_model* m, int B, int Tq, c
   // memory K/V of every decoder layer (cached for pass 2)
   for (int i = 0; i < d.ND; ++i)
     CHK(gemm(m->dec[i].ckv, w.src, DM, nullptr, 0, w.memkv[i], 2 * DM, rM, 2 * DM, DM, 0, st));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t ctrlsim_forward_workspace_bytes(const ctrlsim_dims* d, int B, int Tq) {
+  if (!d || B < 1 || Tq < 1 || Tq > d->T) return CTRLSIM_EINVAL;
+  return (int64_t)carve(*d, B, Tq, nullptr).bytes;
+}
+
+// ------------------------------------------------------------------------------------------------ pass 1
+extern "C" int ctrlsim_dt_forward_pass1(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* c, void* workspace,
+                                        float* rtg_logits, float* dbg_seg_emb, hipStream_t st) {
+  if (!m || !c || !workspace || !rtg_logits || B < 1 || Tq < 1 || Tq > m->d.T) return CTRLSIM_EINVAL;
+  const ctrlsim_dims& d = m->d;
+  const Ws w = carve(d, B, Tq, static_cast<char*>(workspace));
+  const int A = d.A, P = d.P, M = P + A, L = Tq * A * 3, ti = Tq - 1;
+  const int rL = B * L, rM = B * M, rA = B * A, rS = B * Tq * A, rP = B * P;
+  hipLaunchKernelGGL(fill_index_kernel, dim3(((rA > rP ? rA : rP) + 255) / 256), dim3(256), 0, st, B, A, L, ti, P, M,
+                     w.pos_state, w.pos_rtg, w.idx_state, w.idx_rtg, w.idx_poly);
+  // ---- token embeddings (encoder.py:95-153)
+  CHK(launch_in_mlp(c->st12, 12, 12, m->embed_state.l0.w, m->embed_state.l0.b, m->embed_state.ln.g, m->embed_state.ln.b,
+                    w.hS, DM, rS, st));
+  CHK(gemm(m->fold_state, w.hS, DM, nullptr, 0, w.S2, DM, rS, DM, DM, 0, st));
+  CHK(launch_in_mlp(c->goal5, 5, 5, m->embed_goal.l0.w, m->embed_goal.l0.b, m->embed_goal.ln.g, m->embed_goal.ln.b, w.hG,
+                    DM, rA, st));
+  CHK(gemm(m->fold_goal, w.hG, DM, nullptr, 0, w.Gp, DM, rA, DM, DM, 0, st));
+  CHK(launch_assemble_tokens(B, Tq, A, w.S2, w.Gp, c->exist, c->act_tok, c->rtg_bin, c->tstep, m->tb, w.X, w.src, M, P,
+                             w.src_pad, st));
+  CHK(scene_side(m, w, c, B, dbg_seg_emb, st));
   // ---- decoder (decoder.py:52): layers 0..ND-2 on all L tokens
   for (int i = 0; i < d.ND; ++i) {
     const DecLayer& Ld = m->dec[i];
@@ -327,23 +362,77 @@ extern "C" int ctrlsim_dt_forward_pass1(const ctrlsim_model* m, int B, int Tq, c
 // ------------------------------------------------------------------------------------------------ pass 2
 extern "C" int ctrlsim_dt_forward_pass2(const ctrlsim_model* m, int B, int Tq, int t, int N, int Tmax,
                                         const ctrlsim_ctx* c, const int* ctx_scn, const int* hist_rtg, void* workspace,
-                                        float* act_logits, hipStream_t st) {
+                                        float* act_logits, int cached, hipStream_t st) {
   if (!m || !c || !workspace || !act_logits || B < 1 || Tq < 1 || Tq > m->d.T) return CTRLSIM_EINVAL;
   const ctrlsim_dims& d = m->d;
-  const Ws w = carve(d, B, Tq, static_cast<char*>(workspace));
-  const int A = d.A, L = Tq * A * 3, ti = Tq - 1, rA = B * A;
-  CHK(launch_assemble_rtg_rows(B, A, Tq, ti, t, N, Tmax, ctx_scn, c->slot_gid, hist_rtg, c->exist, c->tstep, m->tb,
+  // cached mode: the workspace is carved for the full window (K/V cache rows at b * T*3A + position) and the context
+  // tensors hold only the last Tn = min(Tq, 2) window rows
+  const Ws w = carve(d, B, cached ? d.T : Tq, static_cast<char*>(workspace));
+  const int A = d.A, L = (cached ? d.T : Tq) * A * 3, rA = B * A;
+  const int ctx_rows = cached ? (Tq < 2 ? Tq : 2) : Tq, ti = ctx_rows - 1;
+  CHK(launch_assemble_rtg_rows(B, A, ctx_rows, ti, t, N, Tmax, ctx_scn, c->slot_gid, hist_rtg, c->exist, c->tstep, m->tb,
                                m->zero_rtg, w.xc2, st));
   for (int i = 0; i < d.ND; ++i) {
     const DecLayer& Ld = m->dec[i];
     CHK(gemm(Ld.qkv, w.xc2, DM, nullptr, 0, w.qkvc, 3 * DM, rA, 3 * DM, DM, 0, st));
     CHK(launch_row_copy(w.qkvc, 3 * DM, w.qkv[i], 3 * DM, w.idx_rtg, rA, 3 * DM, 1, st));   // refresh the rtg rows' K/V
     CHK(launch_attention(1, w.qkvc, 3 * DM, (long)A * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
-                         w.attc, DM, (long)A * DM, w.pos_rtg, nullptr, B, A, L, A, st));
+                         w.attc, DM, (long)A * DM, w.pos_rtg, nullptr, B, A, Tq * A * 3, A, st));   // keys: steps <= current
     CHK(gemm(Ld.out, w.attc, DM, w.xc2, DM, w.tmpc, DM, rA, DM, DM, 0, st));
     CHK(launch_layernorm256(w.tmpc, DM, nullptr, 0, Ld.n1.g, Ld.n1.b, w.xc2, DM, rA, 0, st));
     CHK(cross_and_ffn(m, Ld, i, w, w.xc2, w.tmpc, w.attc, w.qcc, w.ffnc, rA, B, A, st));
   }
   CHK(mlp_tail(m->head_action, w.xc2, rA, w.headh, act_logits, d.V, st));
+  return CTRLSIM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ pass 1, cached
+// While t < T the window starts at step 0, so the frame of a context (focal pose at window index 0), its membership
+// and its map never change: the scene side is computed once (t == 0) and the decoder K/V of every layer are cached at
+// fixed rows (b * T*3A + position).  Step t only evaluates the rows whose inputs changed — the A action tokens of step
+// t-1 (placeholder -> applied action) and the 3A tokens of step t — against the cache: 4A rows instead of 3A*(t+1).
+// No other hidden state changes: an action token is visible only to later timesteps and to itself (mask closed form).
+// ctx holds the window rows [max(t-1,0), t]; the workspace must be the one used at t-1 (sized with Tq = T).
+extern "C" int ctrlsim_dt_forward_pass1_cached(const ctrlsim_model* m, int B, int t, const ctrlsim_ctx* c, void* workspace,
+                                               float* rtg_logits, hipStream_t st) {
+  if (!m || !c || !workspace || !rtg_logits || B < 1 || t < 0 || t >= m->d.T) return CTRLSIM_EINVAL;
+  const ctrlsim_dims& d = m->d;
+  const Ws w = carve(d, B, d.T, static_cast<char*>(workspace));
+  const int A = d.A, P = d.P, M = P + A, Lf = d.T * A * 3;
+  const int Rn = t > 0 ? 4 * A : 3 * A, tt_first = t > 0 ? t - 1 : 0, Tn = t + 1 - tt_first;
+  const int rA = B * A, rN = B * Rn, rS = B * Tn * A;
+  hipLaunchKernelGGL(fill_index_cached_kernel, dim3((rN + 255) / 256), dim3(256), 0, st, B, A, Lf, t, Rn, w.pos_new, w.idx_new,
+                     w.idx_state_in_new, w.pos_rtg, w.idx_rtg);
+  CHK(launch_in_mlp(c->st12, 12, 12, m->embed_state.l0.w, m->embed_state.l0.b, m->embed_state.ln.g, m->embed_state.ln.b,
+                    w.hS, DM, rS, st));
+  CHK(gemm(m->fold_state, w.hS, DM, nullptr, 0, w.S2, DM, rS, DM, DM, 0, st));
+  if (t == 0) {
+    CHK(launch_in_mlp(c->goal5, 5, 5, m->embed_goal.l0.w, m->embed_goal.l0.b, m->embed_goal.ln.g, m->embed_goal.ln.b, w.hG,
+                      DM, rA, st));
+    CHK(gemm(m->fold_goal, w.hG, DM, nullptr, 0, w.Gp, DM, rA, DM, DM, 0, st));
+    hipLaunchKernelGGL(fill_index_kernel, dim3(((rA > B * P ? rA : B * P) + 255) / 256), dim3(256), 0, st, B, A, 3 * A, 0, P, M,
+                       w.pos_state, w.pos_rtg, w.idx_state, w.idx_rtg, w.idx_poly);
+    // token order of assemble_tokens at Tq = 1 is (a, k) = pos_new order; it also writes the initial-state rows of `src`
+    CHK(launch_assemble_tokens(B, 1, A, w.S2, w.Gp, c->exist, c->act_tok, c->rtg_bin, c->tstep, m->tb, w.xn, w.src, M, P,
+                               w.src_pad, st));
+    CHK(scene_side(m, w, c, B, nullptr, st));
+    hipLaunchKernelGGL(fill_index_cached_kernel, dim3((rN + 255) / 256), dim3(256), 0, st, B, A, Lf, t, Rn, w.pos_new,
+                       w.idx_new, w.idx_state_in_new, w.pos_rtg, w.idx_rtg);   // pos_rtg / idx_rtg for the cache layout
+  } else {
+    CHK(launch_assemble_rows(B, Rn, A, tt_first, Tn, w.pos_new, w.S2, w.Gp, c->exist, c->act_tok, c->rtg_bin, c->tstep, m->tb,
+                             w.xn, st));
+  }
+  for (int i = 0; i < d.ND; ++i) {
+    const DecLayer& Ld = m->dec[i];
+    CHK(gemm(Ld.qkv, w.xn, DM, nullptr, 0, w.qkvn, 3 * DM, rN, 3 * DM, DM, 0, st));
+    CHK(launch_row_copy(w.qkvn, 3 * DM, w.qkv[i], 3 * DM, w.idx_new, rN, 3 * DM, 1, st));       // K/V (and Q) into the cache
+    CHK(launch_attention(1, w.qkvn, 3 * DM, (long)Rn * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)Lf * 3 * DM,
+                         w.attn_n, DM, (long)Rn * DM, w.pos_new, nullptr, B, Rn, (t + 1) * A * 3, A, st));   // rows beyond are not loaded
+    CHK(gemm(Ld.out, w.attn_n, DM, w.xn, DM, w.tmpn, DM, rN, DM, DM, 0, st));
+    CHK(launch_layernorm256(w.tmpn, DM, nullptr, 0, Ld.n1.g, Ld.n1.b, w.xn, DM, rN, 0, st));
+    CHK(cross_and_ffn(m, Ld, i, w, w.xn, w.tmpn, w.attn_n, w.qcn, w.ffnn, rN, B, Rn, st));
+  }
+  CHK(launch_row_copy(w.xn, DM, w.xc, DM, w.idx_state_in_new, rA, DM, 0, st));
+  CHK(mlp_tail(m->head_rtg, w.xc, rA, w.headh, rtg_logits, d.R * d.C, st));
   return CTRLSIM_OK;
 }

@@ -106,7 +106,7 @@ def ctx_from_reference_layout(d: Dims, data: dict, Tq: int, device):
 
 class RolloutEngine:
     def __init__(self, cfg, weights: dict, device="cuda:0", max_ctx=256, seed=0, tilt=(0.0, 0.0, 0.0),
-                 temperature=None, nucleus=None, top_p=None, kinematic=False, model=None):
+                 temperature=None, nucleus=None, top_p=None, kinematic=False, model=None, use_cache=True):
         self.cfg = cfg
         self.w = cfg.dataset.waymo
         self.dims = Dims(cfg)
@@ -122,6 +122,7 @@ class RolloutEngine:
         self.tilt = (C.c_double * 3)(*[float(x) for x in tilt])
         self.kinematic = int(bool(kinematic))
         self.max_ctx = int(max_ctx)
+        self.use_cache = bool(use_cache)
         self.dt = float(cfg.nocturne.dt)
         w = self.w
         self.disc6 = (C.c_double * 6)(w.min_accel, w.max_accel, w.min_steer, w.max_steer, w.accel_discretization,
@@ -221,28 +222,95 @@ class RolloutEngine:
         self.policy_step(t, noise_rtg, noise_act)
         self.sim_step(t)
 
-    def sim_step(self, t, act_f64=None):
+    def sim_step(self, t, act_f64=None, s0=0, s1=None):
+        """Simulator step of scenarios [s0, s1) (default: all)."""
         lib, p, st = self.lib, _lib.ptr, _lib.stream_ptr()
-        _lib.check(lib.ctrlsim_sim_step(self.S, self.N, self.E, p(self.act_now) if act_f64 is None else None,
-                                        p(act_f64) if act_f64 is not None else None, self.disc6, p(self.size), p(self.edges),
-                                        p(self.exists), p(self.phys), p(self.hist_states), p(self.coll), None, t,
-                                        self.steps + 1, self.dt, self.kinematic, st), "sim_step")
+        s1 = self.S if s1 is None else s1
+        sl = slice(s0, s1)
+        _lib.check(lib.ctrlsim_sim_step(s1 - s0, self.N, self.E, p(self.act_now[sl]) if act_f64 is None else None,
+                                        p(act_f64[sl]) if act_f64 is not None else None, self.disc6, p(self.size[sl]),
+                                        p(self.edges[sl]), p(self.exists[sl]), p(self.phys[sl]), p(self.hist_states[sl]),
+                                        p(self.coll[sl]), None, t, self.steps + 1, self.dt, self.kinematic, st), "sim_step")
+
+    def _group_build(self, t, s0=0, s1=None):
+        lib, p, st, d = self.lib, _lib.ptr, _lib.stream_ptr(), self.dims
+        s1 = self.S if s1 is None else s1
+        sl = slice(s0, s1)
+        _lib.check(lib.ctrlsim_group_build(s1 - s0, self.N, d.A, d.T, t, self.steps + 1, float(self.w.agent_dist_threshold),
+                                           p(self.hist_states[sl]), p(self.eval_order[sl]), 1 if self.P_all > 0 else 0,
+                                           p(self.persist[sl]), p(self.n_groups[sl]), p(self.grp_focal[sl]),
+                                           p(self.grp_ids[sl]), p(self.grp_members[sl]), p(self.own_g[sl]), p(self.mem_g[sl]),
+                                           p(self.tilted[sl]), st), "group_build")
+
+    # ------------------------------------------------------------------ cached phase (t < T), chunk-major
+    def _chunk_step_cached(self, s0, s1, B, t, ws):
+        """Policy + simulator step of one chunk of scenarios with the decoder K/V cache of that chunk (`ws`)."""
+        lib, p, st, d = self.lib, _lib.ptr, _lib.stream_ptr(), self.dims
+        N, Tmax, ns, sl = self.N, self.steps, s1 - s0, slice(s0, s1)
+        Tq, tt_first = t + 1, max(t - 1, 0)
+        _lib.check(lib.ctrlsim_ctx_index(s0, s1, N, p(self.n_groups), p(self.grp_focal), p(self.grp_ids), p(self.own_g),
+                                         p(self.mem_g), p(self.ctx_scn), p(self.ctx_grp), p(self.own_ctx), p(self.own_slot),
+                                         p(self.mem_ctx), p(self.mem_slot), p(self.ctx_base), st), "ctx_index")
+        _lib.check(lib.ctrlsim_build_context(B, N, d.A, d.T, t, Tq, tt_first, Tmax + 1, Tmax, self.P_all, d.P, d.NP,
+                                             p(self.ctx_scn), p(self.ctx_grp), p(self.grp_focal), p(self.grp_ids),
+                                             p(self.hist_states), p(self.hist_tok), p(self.hist_rtg), p(self.goals),
+                                             p(self.types), p(self.roads), p(self.rtypes), self._zero4,
+                                             C.byref(self.ctx.struct), st), "build_context")
+        _lib.check(lib.ctrlsim_dt_forward_pass1_cached(self.model.handle, B, t, C.byref(self.ctx.struct), p(ws),
+                                                       p(self.rtg_logits), st), "pass1_cached")
+        _lib.check(lib.ctrlsim_sample_rtg(p(self.rtg_logits), d.A, d.R, p(self.own_ctx[sl]), p(self.own_slot[sl]),
+                                          p(self.tilted[sl]), self.tilt, None, self.seed, p(self.scenario_id[sl]), t,
+                                          p(self.hist_rtg[sl]), ns, N, Tmax, st), "sample_rtg")
+        _lib.check(lib.ctrlsim_dt_forward_pass2(self.model.handle, B, Tq, t, N, Tmax, C.byref(self.ctx.struct), p(self.ctx_scn),
+                                                p(self.hist_rtg), p(ws), p(self.act_logits), 1, st), "pass2_cached")
+        _lib.check(lib.ctrlsim_sample_action(p(self.act_logits), d.A, d.V, p(self.mem_ctx[sl]), p(self.mem_slot[sl]),
+                                             self.temperature, self.top_p, None, self.seed, p(self.scenario_id[sl]), t,
+                                             p(self.hist_tok[sl]), p(self.act_now[sl]), ns, N, Tmax, ZERO_ACTION_TOKEN, st),
+                   "sample_action")
+        self.sim_step(t, s0=s0, s1=s1)
+
+    def _run_cached_phase(self, n_steps):
+        """Steps 0 .. n_steps-1 (n_steps <= T) chunk by chunk: while t < T the window starts at step 0, so a context's
+        frame, membership and map are constant and its decoder K/V can be cached across steps (csrc/forward.hip).
+        A chunk whose context set does change (a vehicle stops existing) falls back to the full recompute."""
+        self._group_build(0)
+        self.n_groups_host.copy_(self.n_groups, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        counts = self.n_groups_host.numpy().copy()
+        self.groups_per_step[0] = counts
+        for (s0, s1, B) in self._chunks(counts):
+            sl = slice(s0, s1)
+            cached_ok = B > 0
+            ref_focal, ref_ids = self.grp_focal[sl].clone(), self.grp_ids[sl].clone()
+            for t in range(n_steps):
+                if t > 0:
+                    self._group_build(t, s0, s1)
+                    self.n_groups_host[sl].copy_(self.n_groups[sl], non_blocking=True)
+                    same = torch.equal(self.grp_focal[sl], ref_focal) and torch.equal(self.grp_ids[sl], ref_ids)   # syncs
+                    cnt = self.n_groups_host.numpy()[sl]
+                    self.groups_per_step[t, sl] = cnt
+                    cached_ok = cached_ok and same and np.array_equal(cnt, counts[sl])
+                if cached_ok:
+                    self._chunk_step_cached(s0, s1, B, t, self.ws)
+                else:
+                    self._policy_chunks(t, self.n_groups_host.numpy(), s0, s1)
+                    self.sim_step(t, s0=s0, s1=s1)
 
     def policy_step(self, t, noise_rtg=None, noise_act=None):
         """AutoregressivePolicy.predict for every scenario: writes hist_rtg[..., t, :], hist_tok[..., t], act_now."""
-        lib, p, st, d = self.lib, _lib.ptr, _lib.stream_ptr(), self.dims
-        S, N, Tmax = self.S, self.N, self.steps
-        _lib.check(lib.ctrlsim_group_build(S, N, d.A, d.T, t, Tmax + 1, float(self.w.agent_dist_threshold),
-                                           p(self.hist_states), p(self.eval_order), 1 if self.P_all > 0 else 0,
-                                           p(self.persist), p(self.n_groups), p(self.grp_focal), p(self.grp_ids),
-                                           p(self.grp_members), p(self.own_g), p(self.mem_g), p(self.tilted), st),
-                   "group_build")
+        self._group_build(t)
         self.n_groups_host.copy_(self.n_groups, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         counts = self.n_groups_host.numpy()
         self.groups_per_step[t] = counts
+        self._policy_chunks(t, counts, 0, self.S, noise_rtg, noise_act)
+
+    def _policy_chunks(self, t, counts, lo, hi, noise_rtg=None, noise_act=None):
+        """Full-recompute policy for scenarios [lo, hi), chunked to the model batch."""
+        lib, p, st, d = self.lib, _lib.ptr, _lib.stream_ptr(), self.dims
+        S, N, Tmax = self.S, self.N, self.steps
         Tq = min(t, d.T - 1) + 1
-        for (s0, s1, B) in self._chunks(counts):
+        for (s0, s1, B) in [(lo + a, lo + b, c) for (a, b, c) in self._chunks(counts[lo:hi])]:
             ns = s1 - s0
             sl = slice(s0, s1)
             if B > 0:
@@ -250,7 +318,7 @@ class RolloutEngine:
                                                  p(self.own_g), p(self.mem_g), p(self.ctx_scn), p(self.ctx_grp),
                                                  p(self.own_ctx), p(self.own_slot), p(self.mem_ctx), p(self.mem_slot),
                                                  p(self.ctx_base), st), "ctx_index")
-                _lib.check(lib.ctrlsim_build_context(B, N, d.A, d.T, t, Tq, Tmax + 1, Tmax, self.P_all, d.P, d.NP,
+                _lib.check(lib.ctrlsim_build_context(B, N, d.A, d.T, t, Tq, 0, Tmax + 1, Tmax, self.P_all, d.P, d.NP,
                                                      p(self.ctx_scn), p(self.ctx_grp), p(self.grp_focal), p(self.grp_ids),
                                                      p(self.hist_states), p(self.hist_tok), p(self.hist_rtg),
                                                      p(self.goals), p(self.types), p(self.roads), p(self.rtypes),
@@ -268,7 +336,7 @@ class RolloutEngine:
             if B > 0:
                 _lib.check(lib.ctrlsim_dt_forward_pass2(self.model.handle, B, Tq, t, N, Tmax, C.byref(self.ctx.struct),
                                                         p(self.ctx_scn), p(self.hist_rtg), p(self.ws),
-                                                        p(self.act_logits), st), "pass2")
+                                                        p(self.act_logits), 0, st), "pass2")
             _lib.check(lib.ctrlsim_sample_action(p(self.act_logits), d.A, d.V, p(self.mem_ctx[sl]), p(self.mem_slot[sl]),
                                                  self.temperature, self.top_p,
                                                  p(noise_act[sl]) if noise_act is not None else None, self.seed,
@@ -278,7 +346,11 @@ class RolloutEngine:
     def run(self, steps=None, noise_fn=None):
         """Roll all loaded scenarios `steps` steps.  noise_fn(t) -> (noise_rtg, noise_act) or None."""
         steps = self.steps if steps is None else steps
-        for t in range(steps):
+        start = 0
+        if self.use_cache and noise_fn is None and steps > 0:
+            start = min(self.dims.T, steps)
+            self._run_cached_phase(start)
+        for t in range(start, steps):
             if noise_fn is not None:
                 nr, na = noise_fn(t)
                 self.step(t, nr, na)

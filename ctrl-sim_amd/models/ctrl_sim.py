@@ -80,6 +80,6 @@ class CtRLSim:
         lib, st = _lib.lib(), _lib.stream_ptr()
         _lib.check(lib.ctrlsim_dt_forward_pass1(self.hip.handle, B, Tq, C.byref(cb.struct), ws.data_ptr(), rtg.data_ptr(), None, st))
         _lib.check(lib.ctrlsim_dt_forward_pass2(self.hip.handle, B, Tq, 0, d.A, 1, C.byref(cb.struct), scn.data_ptr(),
-                                                hist.data_ptr(), ws.data_ptr(), act.data_ptr(), st))
+                                                hist.data_ptr(), ws.data_ptr(), act.data_ptr(), 0, st))
         torch.cuda.synchronize()
         return {"rtg_preds": rtg, "action_preds": act}

@@ -78,7 +78,8 @@ int ctrlsim_group_build(int S, int N, int A, int T, int t, int Tmax1, double dis
 int ctrlsim_ctx_index(int s0, int s1, int N, const int* n_groups, const int* grp_focal, const uint64_t* grp_ids,
                       const int* own_g, const int* mem_g, int* ctx_scn, int* ctx_grp, int* own_ctx, int* own_slot,
                       int* mem_ctx, int* mem_slot, int* ctx_base, hipStream_t stream);
-int ctrlsim_build_context(int B, int N, int A, int T, int t, int Tq, int Tmax1, int Tmax, int P_all, int P, int NP,
+int ctrlsim_build_context(int B, int N, int A, int T, int t, int Tq, int tt_first /*emit window rows [tt_first,Tq)*/,
+                          int Tmax1, int Tmax, int P_all, int P, int NP,
                           const int* ctx_scn, const int* ctx_grp, const int* grp_focal, const uint64_t* grp_ids,
                           const float* hist_states, const int* hist_tok, const int* hist_rtg,
                           const double* goals /*[S,N,5]*/, const float* types /*[S,N,5]*/,
@@ -98,10 +99,17 @@ int64_t ctrlsim_forward_workspace_bytes(const ctrlsim_dims* dims, int B, int Tq)
 /* pass 1: rtg_logits [B,A,R*C] of the current-timestep state tokens; caches per-layer K/V in `workspace`. */
 int ctrlsim_dt_forward_pass1(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* ctx, void* workspace,
                              float* rtg_logits, float* dbg_seg_emb /*nullable [B,P,D]*/, hipStream_t stream);
-/* pass 2 (same workspace, after ctrlsim_sample_rtg wrote hist_rtg[...,t,:]): act_logits [B,A,V]. */
+/* pass 2 (same workspace, after ctrlsim_sample_rtg wrote hist_rtg[...,t,:]): act_logits [B,A,V].
+ * cached = 1 pairs with ctrlsim_dt_forward_pass1_cached (workspace sized with Tq = T, ctx = last min(Tq,2) window rows). */
 int ctrlsim_dt_forward_pass2(const ctrlsim_model* m, int B, int Tq, int t, int N, int Tmax, const ctrlsim_ctx* ctx,
-                             const int* ctx_scn, const int* hist_rtg, void* workspace, float* act_logits,
+                             const int* ctx_scn, const int* hist_rtg, void* workspace, float* act_logits, int cached,
                              hipStream_t stream);
+/* pass 1 while the window still starts at step 0 (t < T) for a FIXED set of contexts: the scene side is evaluated at
+ * t == 0 only and decoder K/V are cached per layer in `workspace` (ctrlsim_forward_workspace_bytes(dims, B, T), the same
+ * buffer at every step); step t re-evaluates the 4A rows whose inputs changed.  ctx holds the window rows
+ * [max(t-1,0), t] (ctrlsim_build_context with tt_first = max(t-1,0)). */
+int ctrlsim_dt_forward_pass1_cached(const ctrlsim_model* m, int B, int t, const ctrlsim_ctx* ctx, void* workspace,
+                                    float* rtg_logits, hipStream_t stream);
 
 /* ---- sampling -------------------------------------------------------------------------------------------------
  * Replaces Policy.process_predicted_rtg (policies/policy.py:108-142) and the action-sampling block of

@@ -34,7 +34,7 @@ def _run_both_passes(model, d, inp, Tq, new_bins):
     hist_rtg[:, :, t] = torch.from_numpy(new_bins.astype(np.int32)).to(DEV)
     ctx_scn = torch.arange(B, dtype=torch.int32, device=DEV)
     _lib.check(lib.ctrlsim_dt_forward_pass2(model.handle, B, Tq, t, d.A, Tmax, C.byref(cb.struct), ctx_scn.data_ptr(),
-                                            hist_rtg.data_ptr(), ws.data_ptr(), act.data_ptr(), st), "pass2")
+                                            hist_rtg.data_ptr(), ws.data_ptr(), act.data_ptr(), 0, st), "pass2")
     torch.cuda.synchronize()
     return rtg.cpu().numpy(), act.cpu().numpy(), seg.cpu().numpy()
 

@@ -152,7 +152,7 @@ def test_grouping_and_context_tensors_match_oracle(tag, kind, n_ag, n_pl, extent
         Tq = d.T
         cb = eng.ctx
         zero4 = (C.c_int * 4)(524, 0, 35, 35)
-        _lib.check(lib.ctrlsim_build_context(G, N, d.A, d.T, t, Tq, Tmax + 1, Tmax, n_pl, d.P, d.NP,
+        _lib.check(lib.ctrlsim_build_context(G, N, d.A, d.T, t, Tq, 0, Tmax + 1, Tmax, n_pl, d.P, d.NP,
                                              p(eng.ctx_scn), p(eng.ctx_grp), p(eng.grp_focal), p(eng.grp_ids),
                                              p(eng.hist_states), p(eng.hist_tok), p(eng.hist_rtg), p(eng.goals), p(eng.types),
                                              p(eng.roads), p(eng.rtypes), zero4, C.byref(cb.struct), st))
@@ -269,3 +269,22 @@ def test_rollout_matches_oracle_on_fresh_scenarios_full_dims():
         assert np.array_equal(r["tokens"][s][:, :6], o["tokens"])
         np.testing.assert_allclose(r["states"][s], o["states"], atol=1e-4, rtol=0)
         assert np.array_equal(r["coll"][s], o["coll"])
+
+
+@pytest.mark.parametrize("kind,n_ag,n_pl,steps", [("loop", 10, 20, 14), ("full", 12, 40, 5)])
+def test_kv_cached_phase_equals_full_recompute(kind, n_ag, n_pl, steps):
+    """While t < T the engine evaluates only the 4A changed token rows against cached K/V (chunk-major); the result
+    must equal the full per-step recompute: same tokens, same trajectories."""
+    cfg = cfg_of(kind)
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    scns = [scenarios.make_scenario(31, i, n_agents=n_ag, n_polylines=n_pl, n_points=d.NP, extent=45.0) for i in range(3)]
+    out = {}
+    for cache in (True, False):
+        eng = RolloutEngine(cfg, w, DEV, max_ctx=12, seed=9, use_cache=cache)   # small max_ctx: several chunks
+        eng.load_scenarios(scns, steps=steps)
+        out[cache] = eng.run(steps).results()
+    assert np.array_equal(out[True]["n_groups"], out[False]["n_groups"])
+    assert np.array_equal(out[True]["tokens"], out[False]["tokens"])
+    assert np.array_equal(out[True]["rtg_bins"], out[False]["rtg_bins"])
+    np.testing.assert_allclose(out[True]["states"], out[False]["states"], atol=1e-4, rtol=0)
