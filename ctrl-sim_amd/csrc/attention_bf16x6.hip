@@ -6,11 +6,12 @@
 // argument: dropped terms <= 2^-23 relative).  Per 32-key sub-tile a wave issues 24 bf16 MFMAs (768 matrix-pipe
 // cycles) instead of 32 f32-input MFMAs (2048 cycles).
 //
-//   S^T = K.Q^T   A = K rows  (bf16 planes in LDS [3][64 keys][32 d], row stride 40 -> conflict-free ds_read_b128),
+//   S^T = K.Q^T   A = K rows  (bf16 planes in LDS [3][k-step 2][half 2][64 keys][8]: a wave's ds_read_b128 of a fragment is
+//                 two contiguous 512-byte spans, conflict-free without padding),
 //                 B = the wave's Q fragment, pre-scaled by log2(e)/sqrt(32) in fp32, split once, held in registers.
 //   softmax       unchanged (fp32, lane-local: one query per lane column).
-//   O^T += V^T.P^T A = V^T (bf16 planes stored TRANSPOSED in LDS [3][32 d][64 keys], row stride 68 -> conflict-free
-//                 ds_read_b64), B = P^T: the exponentiated scores of the lane are split in registers and packed in
+//   O^T += V^T.P^T A = V^T (bf16 planes stored TRANSPOSED in LDS as key quads [3][16 quads][32 d][4 keys]: a wave's
+//                 ds_read_b64 of a fragment half is one contiguous 256-byte span), B = P^T: the exponentiated scores of the lane are split in registers and packed in
 //                 accumulator-register order.  The MFMA k-slot <-> key map is free as long as both operands agree:
 //                 slot j of lane-half h  <->  key 16*kk + (j&3) + 8*(j>>2) + 4*h, which is exactly the C-fragment row
 //                 map of the S^T tile, so P never moves between lanes.
@@ -21,30 +22,51 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 #define KT6 64
-#define KS6 40     // K plane row stride (bf16)
-#define VS6 68     // V^T plane row stride (bf16)
 
 enum { MODE6_KEYPAD = 0, MODE6_CAUSAL = 1 };
 
-__device__ __forceinline__ void split3v(const f32x4 x, bf16x4& hi, bf16x4& mid, bf16x4& lo) {
-  hi = __builtin_convertvector(x, bf16x4);
-  const f32x4 r1 = x - __builtin_convertvector(hi, f32x4);
-  mid = __builtin_convertvector(r1, bf16x4);
-  const f32x4 r2 = r1 - __builtin_convertvector(mid, f32x4);
-  lo = __builtin_convertvector(r2, bf16x4);
-}
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
+// Two fp32 values -> three packed bf16 pairs (low half = a, high half = b), round-to-nearest-even at every level:
+// hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid).  One v_cvt_pk_bf16_f32 converts AND packs a pair (hipcc's
+// own lowering of a vector convert emits one instruction per element plus shift/or packing); 11 VALU ops per pair.
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = cvt_pk_bf16(a, b);
+  const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xFFFF0000u);
+  mid = cvt_pk_bf16(ra, rb);
+  const float sa = ra - __uint_as_float(mid << 16), sb = rb - __uint_as_float(mid & 0xFFFF0000u);
+  lo = cvt_pk_bf16(sa, sb);
+}
+// eight consecutive fp32 values -> three bf16x8 fragments
+__device__ __forceinline__ void split3_frag(const float* x, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+  u32x4 h, m, l;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned a, b, c;
+    split3_pair(x[2 * i], x[2 * i + 1], a, b, c);
+    h[i] = a; m[i] = b; l[i] = c;
+  }
+  hi = __builtin_bit_cast(bf16x8, h);
+  mid = __builtin_bit_cast(bf16x8, m);
+  lo = __builtin_bit_cast(bf16x8, l);
+}
 __device__ __forceinline__ bf16x8 cat8(const bf16x4 a, const bf16x4 b) {
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void attention_bf16x6_kernel(
+__global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
     const float* __restrict__ Q, int ldq, long q_batch_stride, const float* __restrict__ K,
     const float* __restrict__ V, int ldkv, long kv_batch_stride, float* __restrict__ O, int ldo, long o_batch_stride,
     const int* __restrict__ q_pos, const unsigned char* __restrict__ key_pad, int Lq, int Lk, int A, float scale_log2e) {
-  constexpr int K_PLANE = KT6 * KS6;             // bf16 elements
-  constexpr int V_PLANE = HD * VS6;
+  constexpr int K_PLANE = KT6 * HD;              // bf16 elements: [ks 2][half 2][64 keys][8]
+  constexpr int V_PLANE = HD * KT6;              // [16 quads][32 d][4 keys]
   constexpr int BUF = 3 * K_PLANE + 3 * V_PLANE + 2 * KT6;   // + KT6 floats of key-padding bias
   __shared__ __attribute__((aligned(16))) __bf16 arena[2 * BUF];
   __shared__ int blk_tmax[4];
@@ -77,12 +99,8 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x6_kernel(
       f32x4 x1 = *reinterpret_cast<const f32x4*>(qp + ks * 16 + 4);
       x0 *= scale_log2e;
       x1 *= scale_log2e;
-      bf16x4 h0, m0, l0, h1, m1, l1;
-      split3v(x0, h0, m0, l0);
-      split3v(x1, h1, m1, l1);
-      qf[ks][0] = cat8(h0, h1);
-      qf[ks][1] = cat8(m0, m1);
-      qf[ks][2] = cat8(l0, l1);
+      const float xs[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+      split3_frag(xs, qf[ks][0], qf[ks][1], qf[ks][2]);
     }
   }
 
@@ -113,6 +131,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x6_kernel(
   const float* Vb = V + (size_t)b * kv_batch_stride + h * HD;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
+  // staging registers: K rows (idx -> row, 4 consecutive d), V row PAIRS (thread -> keys 2rp, 2rp+1, 4 consecutive d)
   f32x4 pk[2], pv[2];
   float ppad = 0.f;
   auto gload = [&](int k0) {
@@ -120,11 +139,9 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x6_kernel(
     for (int i = 0; i < 2; ++i) {
       const int idx = tid + 256 * i, r = idx >> 3, c = (idx & 7) * 4;
       const int kr = k0 + r;
-      pk[i] = zero4; pv[i] = zero4;
-      if (kr < Lk) {
-        pk[i] = *reinterpret_cast<const f32x4*>(Kb + (size_t)kr * ldkv + c);
-        pv[i] = *reinterpret_cast<const f32x4*>(Vb + (size_t)kr * ldkv + c);
-      }
+      pk[i] = kr < Lk ? *reinterpret_cast<const f32x4*>(Kb + (size_t)kr * ldkv + c) : zero4;
+      const int vr = k0 + 2 * (tid >> 3) + i;
+      pv[i] = vr < Lk ? *reinterpret_cast<const f32x4*>(Vb + (size_t)vr * ldkv + (tid & 7) * 4) : zero4;
     }
     if (MODE == MODE6_KEYPAD && tid < KT6) {
       const int kr = k0 + tid;
@@ -137,17 +154,25 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x6_kernel(
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int idx = tid + 256 * i, r = idx >> 3, c = (idx & 7) * 4;
-      bf16x4 hi, mid, lo;
-      split3v(pk[i], hi, mid, lo);
-      *reinterpret_cast<bf16x4*>(Kd + 0 * K_PLANE + r * KS6 + c) = hi;
-      *reinterpret_cast<bf16x4*>(Kd + 1 * K_PLANE + r * KS6 + c) = mid;
-      *reinterpret_cast<bf16x4*>(Kd + 2 * K_PLANE + r * KS6 + c) = lo;
-      split3v(pv[i], hi, mid, lo);                 // V is stored transposed: Vd[plane][d][key]
+      unsigned h0, m0, l0, h1, m1, l1;
+      split3_pair(pk[i][0], pk[i][1], h0, m0, l0);                // pairs along d: the fragment order
+      split3_pair(pk[i][2], pk[i][3], h1, m1, l1);
+      const u32x2 h = {h0, h1}, m = {m0, m1}, l = {l0, l1};
+      const int ko = ((c >> 3) * KT6 + r) * 8 + (c & 7);          // (ks*2 + half) = c >> 3
+      *reinterpret_cast<u32x2*>(Kd + 0 * K_PLANE + ko) = h;
+      *reinterpret_cast<u32x2*>(Kd + 1 * K_PLANE + ko) = m;
+      *reinterpret_cast<u32x2*>(Kd + 2 * K_PLANE + ko) = l;
+    }
+    {  // V^T: pairs along the key axis (keys 2rp, 2rp+1 of one d) -> one 32-bit store per (plane, d)
+      const int rp = tid >> 3, c = (tid & 7) * 4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        Vd[0 * V_PLANE + (c + e) * VS6 + r] = hi[e];
-        Vd[1 * V_PLANE + (c + e) * VS6 + r] = mid[e];
-        Vd[2 * V_PLANE + (c + e) * VS6 + r] = lo[e];
+        unsigned h, m, l;
+        split3_pair(pv[0][e], pv[1][e], h, m, l);
+        const int vo = ((rp >> 1) * HD + (c + e)) * 4 + (rp & 1) * 2;   // [quad][d][key & 3]
+        *reinterpret_cast<unsigned*>(Vd + 0 * V_PLANE + vo) = h;
+        *reinterpret_cast<unsigned*>(Vd + 1 * V_PLANE + vo) = m;
+        *reinterpret_cast<unsigned*>(Vd + 2 * V_PLANE + vo) = l;
       }
     }
     if (MODE == MODE6_KEYPAD && tid < KT6) reinterpret_cast<float*>(Vd + 3 * V_PLANE)[tid] = ppad;
@@ -181,12 +206,12 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x6_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
       {
-        const __bf16* kr_ = Ks + (sub * 32 + l31) * KS6 + half * 8;
+        const __bf16* kr_ = Ks + (half * KT6 + sub * 32 + l31) * 8;
         bf16x8 k0f[3], k1f[3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-          k0f[p] = *reinterpret_cast<const bf16x8*>(kr_ + p * K_PLANE);
-          k1f[p] = *reinterpret_cast<const bf16x8*>(kr_ + p * K_PLANE + 16);
+          k0f[p] = *reinterpret_cast<const bf16x8*>(kr_ + p * K_PLANE);                  // k-step 0 (d 0-15)
+          k1f[p] = *reinterpret_cast<const bf16x8*>(kr_ + p * K_PLANE + 2 * KT6 * 8);    // k-step 1 (d 16-31)
         }
 #define QK(PA, PB)                                                                        \
   s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0f[PA], qf[0][PB], s0, 0, 0, 0);           \
@@ -238,25 +263,19 @@ __global__ __launch_bounds__(256, 2) void attention_bf16x6_kernel(
       bf16x8 pf[2][3];
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        const f32x4 x0 = {sc[8 * kk + 0], sc[8 * kk + 1], sc[8 * kk + 2], sc[8 * kk + 3]};
-        const f32x4 x1 = {sc[8 * kk + 4], sc[8 * kk + 5], sc[8 * kk + 6], sc[8 * kk + 7]};
-        bf16x4 h0, m0, l0, h1, m1, l1;
-        split3v(x0, h0, m0, l0);
-        split3v(x1, h1, m1, l1);
-        pf[kk][0] = cat8(h0, h1);
-        pf[kk][1] = cat8(m0, m1);
-        pf[kk][2] = cat8(l0, l1);
+        split3_frag(sc + 8 * kk, pf[kk][0], pf[kk][1], pf[kk][2]);
       }
       // ---- O^T += V^T . P^T : A = V^T rows d = l31, slots 0-3 <-> keys 16kk+4half+0..3, slots 4-7 <-> +8
       {
-        const __bf16* vr_ = Vs + l31 * VS6 + sub * 32 + half * 4;
+        // quad of subtile-local keys [4q', 4q'+3] is quad index sub*8 + q'; lane half h needs q' = 4kk + h and 4kk + 2 + h
+        const __bf16* vr_ = Vs + ((sub * 8 + half) * HD + l31) * 4;
         bf16x8 v0f[3], v1f[3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
           const bf16x4 a0 = *reinterpret_cast<const bf16x4*>(vr_ + p * V_PLANE);
-          const bf16x4 a1 = *reinterpret_cast<const bf16x4*>(vr_ + p * V_PLANE + 8);
-          const bf16x4 b0 = *reinterpret_cast<const bf16x4*>(vr_ + p * V_PLANE + 16);
-          const bf16x4 b1 = *reinterpret_cast<const bf16x4*>(vr_ + p * V_PLANE + 24);
+          const bf16x4 a1 = *reinterpret_cast<const bf16x4*>(vr_ + p * V_PLANE + 2 * HD * 4);
+          const bf16x4 b0 = *reinterpret_cast<const bf16x4*>(vr_ + p * V_PLANE + 4 * HD * 4);
+          const bf16x4 b1 = *reinterpret_cast<const bf16x4*>(vr_ + p * V_PLANE + 6 * HD * 4);
           v0f[p] = cat8(a0, a1);
           v1f[p] = cat8(b0, b1);
         }

@@ -30,12 +30,25 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define XN 256
 #define XK 16
 
-__device__ __forceinline__ void split3(const f32x4 x, bf16x4& hi, bf16x4& mid, bf16x4& lo) {
-  hi = __builtin_convertvector(x, bf16x4);
-  const f32x4 r1 = x - __builtin_convertvector(hi, f32x4);
-  mid = __builtin_convertvector(r1, bf16x4);
-  const f32x4 r2 = r1 - __builtin_convertvector(mid, f32x4);
-  lo = __builtin_convertvector(r2, bf16x4);
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// one v_cvt_pk_bf16_f32 converts AND packs two values (RNE); 11 VALU ops per pair for the three planes
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = cvt_pk_bf16(a, b);
+  const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xFFFF0000u);
+  mid = cvt_pk_bf16(ra, rb);
+  const float sa = ra - __uint_as_float(mid << 16), sb = rb - __uint_as_float(mid & 0xFFFF0000u);
+  lo = cvt_pk_bf16(sa, sb);
+}
+__device__ __forceinline__ void split3(const f32x4 x, u32x2& hi, u32x2& mid, u32x2& lo) {
+  unsigned h0, m0, l0, h1, m1, l1;
+  split3_pair(x[0], x[1], h0, m0, l0);
+  split3_pair(x[2], x[3], h1, m1, l1);
+  hi = u32x2{h0, h1}; mid = u32x2{m0, m1}; lo = u32x2{l0, l1};
 }
 
 template <int PA, int PB>
@@ -110,12 +123,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x6_kernel(const float* __r
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int idx = tid + 512 * i, r = idx >> 3, c = (idx & 7) * 4;
-      bf16x4 hi, mid, lo;
+      u32x2 hi, mid, lo;
       split3(ra[i], hi, mid, lo);
       __bf16* Ab = lds + buf * BUF + (c >> 4) * KSBUF + ((c >> 3) & 1) * (A_PLANE / 2) + r * 8 + (c & 7);
-      *reinterpret_cast<bf16x4*>(Ab + 0 * A_PLANE) = hi;
-      *reinterpret_cast<bf16x4*>(Ab + 1 * A_PLANE) = mid;
-      *reinterpret_cast<bf16x4*>(Ab + 2 * A_PLANE) = lo;
+      *reinterpret_cast<u32x2*>(Ab + 0 * A_PLANE) = hi;
+      *reinterpret_cast<u32x2*>(Ab + 1 * A_PLANE) = mid;
+      *reinterpret_cast<u32x2*>(Ab + 2 * A_PLANE) = lo;
     }
   };
 
