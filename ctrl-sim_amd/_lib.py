@@ -34,8 +34,10 @@ SIGNATURES = {
     "ctrlsim_prof_enable": (None, [I]),
     "ctrlsim_prof_collect": (I, [P, P, P]),
     "ctrlsim_gemm_nt": (I, [P, I, P, I, P, P, I, P, I, I, I, I, I, P]),
-    "ctrlsim_gemm_nt_bf16x6": (I, [P, I, P, I, I, P, P, I, P, I, I, I, I, I, P]),
+    "ctrlsim_gemm_nt_bf16x6": (I, [P, I, P, I, I, P, P, I, P, I, I, I, I, I, P, P, P]),
     "ctrlsim_layernorm256": (I, [P, I, P, I, P, P, P, I, I, I, P]),
+    "ctrlsim_kv_split": (I, [P, P, I, L, P, I, I, I, P, P]),
+    "ctrlsim_attention_presplit": (I, [I, P, I, L, P, I, P, I, L, P, P, I, I, I, I, P]),
     "ctrlsim_attention": (I, [I, P, I, L, P, P, I, L, P, I, L, P, P, I, I, I, I, P]),
     "ctrlsim_sim_init": (I, [I, I, I, P, P, P, P, P, P, P, I, P]),
     "ctrlsim_sim_step": (I, [I, I, I, P, P, P, P, P, P, P, P, P, P, I, I, F, I, P]),

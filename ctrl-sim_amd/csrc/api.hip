@@ -5,11 +5,15 @@
 int launch_gemm_nt(const float*, int, const float*, int, const float*, const float*, int, float*, int, int, int, int, int,
                    hipStream_t);
 int launch_gemm_nt_bf16x6(const float*, int, const void*, int, int, const float*, const float*, int, float*, int, int, int,
-                          int, int, hipStream_t);
+                          int, int, const float*, const float*, hipStream_t);
 int launch_layernorm256(const float*, int, const float*, int, const float*, const float*, float*, int, int, int,
                         hipStream_t);
 int launch_attention(int, const float*, int, long, const float*, const float*, int, long, float*, int, long, const int*,
                      const unsigned char*, int, int, int, int, hipStream_t);
+int launch_kv_split(const float*, const float*, int, long, int, int, int, void*, hipStream_t);
+int launch_kv_split_rows(const float*, const float*, int, long, const int*, int, int, int, void*, hipStream_t);
+int launch_attention_bf16x6_pre(int, const float*, int, long, const void*, int, float*, int, long, const int*,
+                                const unsigned char*, int, int, int, int, hipStream_t);
 int launch_sim_init(int, int, int, const float*, const float*, const float*, const unsigned char*, float*, float*,
                     unsigned char*, int, hipStream_t);
 int launch_sim_step(int, int, int, const int*, const double*, const double*, const float*, const float*,
@@ -51,7 +55,7 @@ void prof_after(int cls, double flops, hipStream_t st) {
   g_recs.push_back(ProfRec{g_pending[cls], b, cls, flops});
 }
 
-static int g_options[OPT_COUNT] = {1, 1};
+static int g_options[OPT_COUNT] = {1, 1, 0};
 int ctrlsim_option(int key) { return (key >= 0 && key < OPT_COUNT) ? g_options[key] : 0; }
 
 extern "C" {
@@ -86,12 +90,23 @@ int ctrlsim_gemm_nt(const float* A, int lda, const float* W, int ldw, const floa
   return launch_gemm_nt(A, lda, W, ldw, bias, R, ldr, C, ldc, M, N, K, relu, st);
 }
 int ctrlsim_gemm_nt_bf16x6(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias, const float* R,
-                           int ldr, float* C, int ldc, int M, int N, int K, int relu, hipStream_t st) {
-  return launch_gemm_nt_bf16x6(A, lda, W3, n_total, n0, bias, R, ldr, C, ldc, M, N, K, relu, st);
+                           int ldr, float* C, int ldc, int M, int N, int K, int relu, const float* ln_gamma,
+                           const float* ln_beta, hipStream_t st) {
+  return launch_gemm_nt_bf16x6(A, lda, W3, n_total, n0, bias, R, ldr, C, ldc, M, N, K, relu, ln_gamma, ln_beta, st);
 }
 int ctrlsim_layernorm256(const float* X, int ldx, const float* Radd, int ldr, const float* gamma, const float* beta, float* Y,
                          int ldy, int rows, int relu, hipStream_t st) {
   return launch_layernorm256(X, ldx, Radd, ldr, gamma, beta, Y, ldy, rows, relu, st);
+}
+int ctrlsim_kv_split(const float* K, const float* V, int ldkv, int64_t kbs, const int* pos, int B, int rows, int nkt, void* img,
+                     hipStream_t st) {
+  if (pos) return launch_kv_split_rows(K, V, ldkv, (long)kbs, pos, B, rows, nkt, img, st);
+  return launch_kv_split(K, V, ldkv, (long)kbs, B, rows, nkt, img, st);
+}
+int ctrlsim_attention_presplit(int mode, const float* Q, int ldq, int64_t qbs, const void* img, int nkt, float* O, int ldo,
+                               int64_t obs, const int* q_pos, const uint8_t* key_pad, int B, int Lq, int Lk, int A,
+                               hipStream_t st) {
+  return launch_attention_bf16x6_pre(mode, Q, ldq, (long)qbs, img, nkt, O, ldo, (long)obs, q_pos, key_pad, B, Lq, Lk, A, st);
 }
 int ctrlsim_attention(int mode, const float* Q, int ldq, int64_t qbs, const float* K, const float* V, int ldkv, int64_t kbs,
                       float* O, int ldo, int64_t obs, const int* q_pos, const uint8_t* key_pad, int B, int Lq, int Lk, int A,

@@ -22,6 +22,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 #define KT6 64
+#define KV_IMG (2 * 3 * KT6 * HD)   // bf16 elements of one (context, head, 64-key tile) image: K planes then V^T planes (24 KB)
 
 enum { MODE6_KEYPAD = 0, MODE6_CAUSAL = 1 };
 
@@ -60,7 +61,20 @@ __device__ __forceinline__ bf16x8 cat8(const bf16x4 a, const bf16x4 b) {
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int MODE>
+#ifdef ATT_TIMING   // scratch/att_timing.hip: per-segment s_memtime accounting of one wave's main loop
+__device__ unsigned long long g_att_t[8];
+#define TSTAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); tacc[i] += _t - tlast; tlast = _t; }
+#define TCOUNT(i) { tacc[i] += 1; }
+#else
+#define TSTAMP(i)
+#define TCOUNT(i)
+#endif
+
+// PRE = true: K / V arrive already split, as per-(context, head, 64-key tile) images of exactly the LDS stage layout
+// (kv_split_kernel below; K = the image base, V / ldkv unused, kv_batch_stride = tiles per context): staging is six
+// 16-byte LDS-DMA pieces per thread and tile — no registers, no VALU, no ds_write.
+template <int MODE, bool PRE>
 __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
     const float* __restrict__ Q, int ldq, long q_batch_stride, const float* __restrict__ K,
     const float* __restrict__ V, int ldkv, long kv_batch_stride, float* __restrict__ O, int ldo, long o_batch_stride,
@@ -134,14 +148,29 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
   // staging registers: K rows (idx -> row, 4 consecutive d), V row PAIRS (thread -> keys 2rp, 2rp+1, 4 consecutive d)
   f32x4 pk[2], pv[2];
   float ppad = 0.f;
-  auto gload = [&](int k0) {
+  const __bf16* img = PRE ? reinterpret_cast<const __bf16*>(K) + ((size_t)b * NHEAD + h) * (size_t)kv_batch_stride * KV_IMG : nullptr;
+  auto gload = [&](int k0, int buf) {
+    if (PRE) {
+      const __bf16* src = img + (size_t)(k0 / KT6) * KV_IMG + tid * 8;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        __bf16* dst = arena + buf * BUF + (wave * 64 + 256 * i) * 8;          // wave-uniform LDS base (+ 16 B per lane)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 256 * 8 * i),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int idx = tid + 256 * i, r = idx >> 3, c = (idx & 7) * 4;
       const int kr = k0 + r;
+#ifndef ABL_NO_GLOAD
       pk[i] = kr < Lk ? *reinterpret_cast<const f32x4*>(Kb + (size_t)kr * ldkv + c) : zero4;
       const int vr = k0 + 2 * (tid >> 3) + i;
       pv[i] = vr < Lk ? *reinterpret_cast<const f32x4*>(Vb + (size_t)vr * ldkv + (tid & 7) * 4) : zero4;
+#else
+      pk[i] = zero4 + (float)kr; pv[i] = zero4 + (float)(kr + i);
+#endif
+    }
     }
     if (MODE == MODE6_KEYPAD && tid < KT6) {
       const int kr = k0 + tid;
@@ -151,12 +180,17 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
   auto sstore = [&](int buf) {
     __bf16* Kd = arena + buf * BUF;
     __bf16* Vd = Kd + 3 * K_PLANE;
+    if (!PRE) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int idx = tid + 256 * i, r = idx >> 3, c = (idx & 7) * 4;
       unsigned h0, m0, l0, h1, m1, l1;
+#ifndef ABL_NO_STAGE_SPLIT
       split3_pair(pk[i][0], pk[i][1], h0, m0, l0);                // pairs along d: the fragment order
       split3_pair(pk[i][2], pk[i][3], h1, m1, l1);
+#else
+      h0 = __float_as_uint(pk[i][0]); m0 = __float_as_uint(pk[i][1]); l0 = h0; h1 = __float_as_uint(pk[i][2]); m1 = __float_as_uint(pk[i][3]); l1 = h1;
+#endif
       const u32x2 h = {h0, h1}, m = {m0, m1}, l = {l0, l1};
       const int ko = ((c >> 3) * KT6 + r) * 8 + (c & 7);          // (ks*2 + half) = c >> 3
       *reinterpret_cast<u32x2*>(Kd + 0 * K_PLANE + ko) = h;
@@ -168,25 +202,35 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         unsigned h, m, l;
+#ifndef ABL_NO_STAGE_SPLIT
         split3_pair(pv[0][e], pv[1][e], h, m, l);
+#else
+        h = __float_as_uint(pv[0][e]); m = __float_as_uint(pv[1][e]); l = h;
+#endif
         const int vo = ((rp >> 1) * HD + (c + e)) * 4 + (rp & 1) * 2;   // [quad][d][key & 3]
         *reinterpret_cast<unsigned*>(Vd + 0 * V_PLANE + vo) = h;
         *reinterpret_cast<unsigned*>(Vd + 1 * V_PLANE + vo) = m;
         *reinterpret_cast<unsigned*>(Vd + 2 * V_PLANE + vo) = l;
       }
     }
+    }
     if (MODE == MODE6_KEYPAD && tid < KT6) reinterpret_cast<float*>(Vd + 3 * V_PLANE)[tid] = ppad;
   };
 
   if (k_end > 0) {
-    gload(0);
+    gload(0, 0);
     sstore(0);
   }
   __syncthreads();
+#ifdef ATT_TIMING
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#endif
   int cur = 0;
   for (int k0 = 0; k0 < k_end; k0 += KT6, cur ^= 1) {
     const bool more = k0 + KT6 < k_end;
-    if (more) gload(k0 + KT6);
+    if (more) gload(k0 + KT6, cur ^ 1);
+    TSTAMP(0) TCOUNT(7)
     const __bf16* Ks = arena + cur * BUF;
     const __bf16* Vs = Ks + 3 * K_PLANE;
     const float* padbias = reinterpret_cast<const float*>(Vs + 3 * V_PLANE);
@@ -213,11 +257,19 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
           k0f[p] = *reinterpret_cast<const bf16x8*>(kr_ + p * K_PLANE);                  // k-step 0 (d 0-15)
           k1f[p] = *reinterpret_cast<const bf16x8*>(kr_ + p * K_PLANE + 2 * KT6 * 8);    // k-step 1 (d 16-31)
         }
+#ifndef ABL_NO_MFMA
 #define QK(PA, PB)                                                                        \
   s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0f[PA], qf[0][PB], s0, 0, 0, 0);           \
   s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1f[PA], qf[1][PB], s1, 0, 0, 0);
         QK(2, 0) QK(0, 2) QK(1, 1) QK(1, 0) QK(0, 1) QK(0, 0)
 #undef QK
+        TSTAMP(1) TCOUNT(6)
+#else
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { asm volatile("" ::"v"(k0f[p]), "v"(k1f[p])); }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = __builtin_bit_cast(float, (unsigned)(k0f[0][r & 7]) << 16); s1[r] = 0.01f * r; }
+#endif
       }
       float sc[16];
       if (MODE == MODE6_KEYPAD) {
@@ -249,7 +301,11 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
       float psum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+#ifndef ABL_NO_EXP
         sc[r] = __builtin_amdgcn_exp2f(sc[r] - m_use);
+#else
+        sc[r] = sc[r] - m_use;
+#endif
         psum += sc[r];
       }
       psum += __shfl_xor(psum, 32, 64);
@@ -259,11 +315,18 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) { oa[r] *= alpha; ob[r] *= alpha; }
       }
+      TSTAMP(2)
       // ---- P^T fragments: k-step kk uses accumulator registers 8*kk .. 8*kk+7 (slot j <-> register 8*kk + j)
       bf16x8 pf[2][3];
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
+#ifndef ABL_NO_PSPLIT
         split3_frag(sc + 8 * kk, pf[kk][0], pf[kk][1], pf[kk][2]);
+#else
+        { u32x4 u = {__float_as_uint(sc[8 * kk]), __float_as_uint(sc[8 * kk + 1]), __float_as_uint(sc[8 * kk + 2]), __float_as_uint(sc[8 * kk + 3])};
+          u32x4 w = {__float_as_uint(sc[8 * kk + 4]), __float_as_uint(sc[8 * kk + 5]), __float_as_uint(sc[8 * kk + 6]), __float_as_uint(sc[8 * kk + 7])};
+          pf[kk][0] = __builtin_bit_cast(bf16x8, u); pf[kk][1] = __builtin_bit_cast(bf16x8, w); pf[kk][2] = pf[kk][0]; }
+#endif
       }
       // ---- O^T += V^T . P^T : A = V^T rows d = l31, slots 0-3 <-> keys 16kk+4half+0..3, slots 4-7 <-> +8
       {
@@ -279,16 +342,30 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
           v0f[p] = cat8(a0, a1);
           v1f[p] = cat8(b0, b1);
         }
+#ifndef ABL_NO_MFMA
 #define PV(PA, PB)                                                                        \
   oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0f[PA], pf[0][PB], oa, 0, 0, 0);           \
   ob = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1f[PA], pf[1][PB], ob, 0, 0, 0);
         PV(2, 0) PV(0, 2) PV(1, 1) PV(1, 0) PV(0, 1) PV(0, 0)
 #undef PV
+        TSTAMP(3)
+#else
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { asm volatile("" ::"v"(v0f[p]), "v"(v1f[p]), "v"(pf[0][p]), "v"(pf[1][p])); }
+#endif
       }
     }
     if (more) sstore(cur ^ 1);
+    TSTAMP(4)
     __syncthreads();
+    TSTAMP(5)
   }
+#ifdef ATT_TIMING
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_att_t[i], tacc[i]);
+  }
+#endif
 
   // ---- normalise, transpose through LDS, store rows
   const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
@@ -304,34 +381,158 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
   }
 }
 
+// ---- K / V rows -> split images (the layout the PRE kernel stages by DMA) -------------------------------------------
+// image of (context b, head h, tile kt) at img + ((b*NHEAD + h)*nkt + kt) * KV_IMG:
+//   K part  [plane 3][d>>3 4][key 64][d&7 8]          V^T part  [plane 3][key>>2 16][d 32][key&3 4]
+// Full mode: one block per (tile, head, context) builds the 24 KB image in LDS and writes it out in 16-byte pieces;
+// keys >= Lk are zero (P = 0 times a garbage V would be NaN).
+__global__ __launch_bounds__(256) void kv_split_kernel(const float* __restrict__ K, const float* __restrict__ V, int ldkv,
+                                                       long kv_batch_stride, int Lk, int nkt, __bf16* __restrict__ img) {
+  constexpr int K_PLANE = KT6 * HD, V_PLANE = HD * KT6;
+  __shared__ __attribute__((aligned(16))) __bf16 im[KV_IMG];
+  const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, k0 = kt * KT6;
+  const float* Kb = K + (size_t)b * kv_batch_stride + h * HD;
+  const float* Vb = V + (size_t)b * kv_batch_stride + h * HD;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 pk[2], pv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + 256 * i, r = idx >> 3, c = (idx & 7) * 4;
+    const int kr = k0 + r;
+    pk[i] = kr < Lk ? *reinterpret_cast<const f32x4*>(Kb + (size_t)kr * ldkv + c) : zero4;
+    const int vr = k0 + 2 * (tid >> 3) + i;
+    pv[i] = vr < Lk ? *reinterpret_cast<const f32x4*>(Vb + (size_t)vr * ldkv + (tid & 7) * 4) : zero4;
+  }
+  __bf16* Kd = im;
+  __bf16* Vd = im + 3 * K_PLANE;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + 256 * i, r = idx >> 3, c = (idx & 7) * 4;
+    unsigned h0, m0, l0, h1, m1, l1;
+    split3_pair(pk[i][0], pk[i][1], h0, m0, l0);
+    split3_pair(pk[i][2], pk[i][3], h1, m1, l1);
+    const int ko = ((c >> 3) * KT6 + r) * 8 + (c & 7);
+    *reinterpret_cast<u32x2*>(Kd + 0 * K_PLANE + ko) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(Kd + 1 * K_PLANE + ko) = u32x2{m0, m1};
+    *reinterpret_cast<u32x2*>(Kd + 2 * K_PLANE + ko) = u32x2{l0, l1};
+  }
+  {
+    const int rp = tid >> 3, c = (tid & 7) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned hh, mm, ll;
+      split3_pair(pv[0][e], pv[1][e], hh, mm, ll);
+      const int vo = ((rp >> 1) * HD + (c + e)) * 4 + (rp & 1) * 2;
+      *reinterpret_cast<unsigned*>(Vd + 0 * V_PLANE + vo) = hh;
+      *reinterpret_cast<unsigned*>(Vd + 1 * V_PLANE + vo) = mm;
+      *reinterpret_cast<unsigned*>(Vd + 2 * V_PLANE + vo) = ll;
+    }
+  }
+  __syncthreads();
+  u32x4* dst = reinterpret_cast<u32x4*>(img + (((size_t)b * NHEAD + h) * nkt + kt) * KV_IMG);
+  const u32x4* srcv = reinterpret_cast<const u32x4*>(im);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dst[tid + 256 * i] = srcv[tid + 256 * i];
+}
+
+// Rows mode (KV cache updates): row r of context b (K + b*kv_batch_stride + r*ldkv) goes to key position pos[r] of
+// the context's images; one thread per (context, row, 4 consecutive dims).
+__global__ __launch_bounds__(256) void kv_split_rows_kernel(const float* __restrict__ K, const float* __restrict__ V,
+                                                            int ldkv, long kv_batch_stride, const int* __restrict__ pos,
+                                                            int B, int R, int nkt, __bf16* __restrict__ img) {
+  constexpr int K_PLANE = KT6 * HD, V_PLANE = HD * KT6;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long)B * R * 64) return;
+  const int g = (int)(gid & 63), r = (int)((gid >> 6) % R), b = (int)((gid >> 6) / R);
+  const int col = g * 4, h = col >> 5, d = col & 31;
+  const int p = pos[r], kt = p >> 6, key = p & 63;
+  const f32x4 kx = *reinterpret_cast<const f32x4*>(K + (size_t)b * kv_batch_stride + (size_t)r * ldkv + col);
+  const f32x4 vx = *reinterpret_cast<const f32x4*>(V + (size_t)b * kv_batch_stride + (size_t)r * ldkv + col);
+  __bf16* Kd = img + (((size_t)b * NHEAD + h) * nkt + kt) * KV_IMG;
+  __bf16* Vd = Kd + 3 * K_PLANE;
+  unsigned h0, m0, l0, h1, m1, l1;
+  split3_pair(kx[0], kx[1], h0, m0, l0);
+  split3_pair(kx[2], kx[3], h1, m1, l1);
+  const int ko = ((d >> 3) * KT6 + key) * 8 + (d & 7);
+  *reinterpret_cast<u32x2*>(Kd + 0 * K_PLANE + ko) = u32x2{h0, h1};
+  *reinterpret_cast<u32x2*>(Kd + 1 * K_PLANE + ko) = u32x2{m0, m1};
+  *reinterpret_cast<u32x2*>(Kd + 2 * K_PLANE + ko) = u32x2{l0, l1};
+  unsigned short* Vs = reinterpret_cast<unsigned short*>(Vd);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    unsigned hh, mm, ll;
+    split3_pair(vx[e], 0.f, hh, mm, ll);
+    const int vo = ((key >> 2) * HD + (d + e)) * 4 + (key & 3);
+    Vs[0 * V_PLANE + vo] = (unsigned short)hh;
+    Vs[1 * V_PLANE + vo] = (unsigned short)mm;
+    Vs[2 * V_PLANE + vo] = (unsigned short)ll;
+  }
+}
+
+int launch_kv_split(const float* K, const float* V, int ldkv, long kv_batch_stride, int B, int Lk, int nkt, void* img,
+                    hipStream_t st) {
+  if (B <= 0 || Lk <= 0) return CTRLSIM_OK;
+  if (!K || !V || !img || (ldkv & 3) || nkt * KT6 < Lk) return CTRLSIM_EINVAL;
+  hipLaunchKernelGGL(kv_split_kernel, dim3(nkt, NHEAD, B), dim3(256), 0, st, K, V, ldkv, kv_batch_stride, Lk, nkt,
+                     static_cast<__bf16*>(img));
+  return ctrlsim_launch_status();
+}
+int launch_kv_split_rows(const float* K, const float* V, int ldkv, long kv_batch_stride, const int* pos, int B, int R,
+                         int nkt, void* img, hipStream_t st) {
+  if (B <= 0 || R <= 0) return CTRLSIM_OK;
+  if (!K || !V || !img || !pos || (ldkv & 3)) return CTRLSIM_EINVAL;
+  const long total = (long)B * R * 64;
+  hipLaunchKernelGGL(kv_split_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, K, V, ldkv,
+                     kv_batch_stride, pos, B, R, nkt, static_cast<__bf16*>(img));
+  return ctrlsim_launch_status();
+}
+
+static double attn_pairs(int mode, const int* q_pos, int Lq, int Lk, int A) {
+  if (mode == MODE6_CAUSAL && !q_pos) {
+    const double A3 = 3.0 * A, T = (double)Lq / A3;
+    return A3 * A3 * T * (T - 1) / 2.0 + T * A * (3.0 * A + 3.0);
+  }
+  return (double)Lq * (double)Lk;
+}
+
 int launch_attention_bf16x6(int mode, const float* Q, int ldq, long q_batch_stride, const float* K, const float* V,
                             int ldkv, long kv_batch_stride, float* O, int ldo, long o_batch_stride, const int* q_pos,
                             const unsigned char* key_pad, int B, int Lq, int Lk, int A, hipStream_t st) {
   if (B <= 0 || Lq <= 0) return CTRLSIM_OK;
   if (Lk <= 0 || (ldq & 3) || (ldkv & 3)) return CTRLSIM_EINVAL;
+  if (mode != MODE6_CAUSAL && !key_pad) return CTRLSIM_EINVAL;
   dim3 g((Lq + 127) / 128, NHEAD, B), blk(256);
   const float scale = 0.17677669529663687f * 1.4426950408889634f;  // log2(e)/sqrt(32)
-  double pairs;
-  if (mode == MODE6_CAUSAL) {
-    const double A3 = 3.0 * A;
-    if (!q_pos) {
-      const double T = (double)Lq / A3;
-      pairs = A3 * A3 * T * (T - 1) / 2.0 + T * A * (3.0 * A + 3.0);
-    } else {
-      pairs = (double)Lq * (double)Lk;
-    }
-  } else {
-    pairs = (double)Lq * (double)Lk;
-  }
   prof_before(PROF_ATTN, st);
   if (mode == MODE6_CAUSAL) {
-    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL>), g, blk, 0, st, Q, ldq, q_batch_stride, K, V, ldkv,
+    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, false>), g, blk, 0, st, Q, ldq, q_batch_stride, K, V, ldkv,
                        kv_batch_stride, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale);
   } else {
-    if (!key_pad) return CTRLSIM_EINVAL;
-    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD>), g, blk, 0, st, Q, ldq, q_batch_stride, K, V, ldkv,
+    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, false>), g, blk, 0, st, Q, ldq, q_batch_stride, K, V, ldkv,
                        kv_batch_stride, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale);
   }
-  prof_after(PROF_ATTN, pairs * 128.0 * NHEAD * B, st);
+  prof_after(PROF_ATTN, attn_pairs(mode, q_pos, Lq, Lk, A) * 128.0 * NHEAD * B, st);
+  return ctrlsim_launch_status();
+}
+
+// K / V from split images (launch_kv_split*): img holds nkt tiles per (context, head)
+int launch_attention_bf16x6_pre(int mode, const float* Q, int ldq, long q_batch_stride, const void* img, int nkt, float* O,
+                                int ldo, long o_batch_stride, const int* q_pos, const unsigned char* key_pad, int B, int Lq,
+                                int Lk, int A, hipStream_t st) {
+  if (B <= 0 || Lq <= 0) return CTRLSIM_OK;
+  if (Lk <= 0 || (ldq & 3) || !img || nkt * KT6 < Lk) return CTRLSIM_EINVAL;
+  if (mode != MODE6_CAUSAL && !key_pad) return CTRLSIM_EINVAL;
+  dim3 g((Lq + 127) / 128, NHEAD, B), blk(256);
+  const float scale = 0.17677669529663687f * 1.4426950408889634f;
+  const float* imgf = static_cast<const float*>(img);
+  prof_before(PROF_ATTN, st);
+  if (mode == MODE6_CAUSAL) {
+    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, true>), g, blk, 0, st, Q, ldq, q_batch_stride, imgf, nullptr, 0,
+                       (long)nkt, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale);
+  } else {
+    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, true>), g, blk, 0, st, Q, ldq, q_batch_stride, imgf, nullptr, 0,
+                       (long)nkt, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale);
+  }
+  prof_after(PROF_ATTN, attn_pairs(mode, q_pos, Lq, Lk, A) * 128.0 * NHEAD * B, st);
   return ctrlsim_launch_status();
 }

@@ -26,9 +26,13 @@
 int launch_gemm_nt(const float*, int, const float*, int, const float*, const float*, int, float*, int, int, int, int, int,
                    hipStream_t);
 int launch_gemm_nt_bf16x6(const float*, int, const void*, int, int, const float*, const float*, int, float*, int, int, int,
-                          int, int, hipStream_t);
+                          int, int, const float*, const float*, hipStream_t);
 int launch_layernorm256(const float*, int, const float*, int, const float*, const float*, float*, int, int, int,
                         hipStream_t);
+int launch_kv_split(const float*, const float*, int, long, int, int, int, void*, hipStream_t);
+int launch_kv_split_rows(const float*, const float*, int, long, const int*, int, int, int, void*, hipStream_t);
+int launch_attention_bf16x6_pre(int, const float*, int, long, const void*, int, float*, int, long, const int*,
+                                const unsigned char*, int, int, int, int, hipStream_t);
 int launch_in_mlp(const float*, int, int, const float*, const float*, const float*, const float*, float*, int, int,
                   hipStream_t);
 int launch_row_copy(const float*, int, float*, int, const int*, int, int, int, hipStream_t);
@@ -166,6 +170,11 @@ struct Ws {
   // cached incremental path: up to 4A new rows per context
   float *xn, *tmpn, *attn_n, *qkvn, *qcn, *ffnn;
   int *pos_new, *idx_new, *idx_state_in_new;
+  // split-bf16 K/V images (attention_bf16x6.hip: kv_split_kernel): decoder self-attention per layer, memory K/V per
+  // layer, scene encoder (reused by its layers); nkt = 64-key tiles per context
+  void *img_dec[8], *img_mem[8], *img_enc;
+  int nkt_dec, nkt_mem;
+  size_t img_dec_bytes;
   size_t bytes;
 };
 
@@ -200,6 +209,13 @@ Ws carve(const ctrlsim_dims& d, int B, int Tq, char* base) {
   w.pos_new = reinterpret_cast<int*>(take(4 * d.A * sizeof(int)));
   w.idx_new = reinterpret_cast<int*>(take(rN * sizeof(int)));
   w.idx_state_in_new = reinterpret_cast<int*>(take(rA * sizeof(int)));
+  w.nkt_dec = (int)((L + 63) / 64);
+  w.nkt_mem = (int)((M + 63) / 64);
+  const size_t tile_bytes = 2 * 3 * 64 * HD * 2;   // 24 KB per (context, head, tile)
+  w.img_dec_bytes = (size_t)B * NHEAD * w.nkt_dec * tile_bytes;
+  for (int i = 0; i < d.ND; ++i) w.img_dec[i] = take(w.img_dec_bytes);
+  for (int i = 0; i < d.ND; ++i) w.img_mem[i] = take((size_t)B * NHEAD * w.nkt_mem * tile_bytes);
+  w.img_enc = take((size_t)B * NHEAD * w.nkt_mem * tile_bytes);
   w.bytes = off;
   return w;
 }
@@ -219,9 +235,37 @@ __global__ void fill_index_kernel(int B, int A, int L, int ti, int P, int M, int
 // y = act(x W^T + b [+ R]) through the bf16x6 MFMA kernel when the packed planes exist, else the f32-input MFMA kernel
 int gemm(const Lin& L, const float* x, int ldx, const float* R, int ldr, float* y, int ldy, int rows, int n, int k, int relu,
          hipStream_t st) {
-  if (L.w3 && k % 16 == 0 && ctrlsim_option(OPT_GEMM_IMPL) == 1)
-    return launch_gemm_nt_bf16x6(x, ldx, L.w3, L.ntot ? L.ntot : n, L.n0, L.b, R, ldr, y, ldy, rows, n, k, relu, st);
-  return gemm(L, x, ldx, R, ldr, y, ldy, rows, n, k, relu, st);
+  if (L.w3 && k % 32 == 0 && ctrlsim_option(OPT_GEMM_IMPL) == 1)
+    return launch_gemm_nt_bf16x6(x, ldx, L.w3, L.ntot ? L.ntot : n, L.n0, L.b, R, ldr, y, ldy, rows, n, k, relu, nullptr,
+                                 nullptr, st);
+  return launch_gemm_nt(x, ldx, L.w, k, L.b, R, ldr, y, ldy, rows, n, k, relu, st);
+}
+
+// y = [relu] LayerNorm(x W^T + b [+ R]) for the 256-wide blocks: one kernel on the bf16x6 path (LN in the GEMM epilogue;
+// y may alias R), GEMM into `tmp` + layernorm256 on the f32-input path
+int gemm_ln(const Lin& L, const LNp& n, const float* x, int ldx, const float* R, int ldr, float* y, int ldy, float* tmp,
+            int rows, int k, int relu, hipStream_t st) {
+  if (L.w3 && k % 32 == 0 && ctrlsim_option(OPT_GEMM_IMPL) == 1)
+    return launch_gemm_nt_bf16x6(x, ldx, L.w3, L.ntot ? L.ntot : DM, L.n0, L.b, R, ldr, y, ldy, rows, DM, k, relu, n.g, n.b, st);
+  CHK(launch_gemm_nt(x, ldx, L.w, k, L.b, R, ldr, tmp, DM, rows, DM, k, 0, st));
+  return launch_layernorm256(tmp, DM, nullptr, 0, n.g, n.b, y, ldy, rows, relu, st);
+}
+
+// Attention over K/V given both as fp32 rows and (when the split-bf16 path is selected) as pre-split images
+inline bool presplit() { return ctrlsim_option(OPT_ATTN_IMPL) == 1; }
+int attention_kv(int mode, const float* Q, int ldq, long qbs, const float* K, const float* V, int ldkv, long kbs,
+                 const void* img, int nkt, float* O, int ldo, long obs, const int* q_pos, const unsigned char* key_pad, int B,
+                 int Lq, int Lk, int A, hipStream_t st) {
+  if (presplit())
+    return launch_attention_bf16x6_pre(mode, Q, ldq, qbs, img, nkt, O, ldo, obs, q_pos, key_pad, B, Lq, Lk, A, st);
+  return launch_attention(mode, Q, ldq, qbs, K, V, ldkv, kbs, O, ldo, obs, q_pos, key_pad, B, Lq, Lk, A, st);
+}
+int kv_split(const float* K, const float* V, int ldkv, long kbs, int B, int Lk, int nkt, void* img, hipStream_t st) {
+  return presplit() ? launch_kv_split(K, V, ldkv, kbs, B, Lk, nkt, img, st) : 0;
+}
+int kv_split_rows(const float* K, const float* V, int ldkv, long kbs, const int* pos, int B, int R, int nkt, void* img,
+                  hipStream_t st) {
+  return presplit() ? launch_kv_split_rows(K, V, ldkv, kbs, pos, B, R, nkt, img, st) : 0;
 }
 
 // index lists of the cached path: new rows of step t are the A action tokens of t-1 (t > 0) and the 3A tokens of t;
@@ -243,8 +287,7 @@ __global__ void fill_index_cached_kernel(int B, int A, int Lf, int t, int Rn, in
 
 int mlp_tail(const Mlp& m, const float* h_in, int rows, float* hid, float* out, int n_out, hipStream_t st) {
   // Linear(256->256) -> LN -> ReLU -> Linear(256->n_out)
-  CHK(gemm(m.l0, h_in, DM, nullptr, 0, hid, DM, rows, DM, DM, 0, st));
-  CHK(launch_layernorm256(hid, DM, nullptr, 0, m.ln.g, m.ln.b, hid, DM, rows, 1, st));
+  CHK(gemm_ln(m.l0, m.ln, h_in, DM, nullptr, 0, hid, DM, hid, rows, DM, 1, st));
   CHK(gemm(m.l3, hid, DM, nullptr, 0, out, n_out, rows, n_out, DM, 0, st));
   return 0;
 }
@@ -255,13 +298,11 @@ int cross_and_ffn(const ctrlsim_model* m, const DecLayer& Ld, int layer, const W
   const ctrlsim_dims& d = m->d;
   const int M = d.P + d.A;
   CHK(gemm(Ld.cq, x, DM, nullptr, 0, qc, DM, rows, DM, DM, 0, st));
-  CHK(launch_attention(0, qc, DM, (long)rows_per_b * DM, w.memkv[layer], w.memkv[layer] + DM, 2 * DM, (long)M * 2 * DM, att,
-                       DM, (long)rows_per_b * DM, nullptr, w.src_pad, B, rows_per_b, M, d.A, st));
-  CHK(gemm(Ld.cout, att, DM, x, DM, tmp, DM, rows, DM, DM, 0, st));
-  CHK(launch_layernorm256(tmp, DM, nullptr, 0, Ld.n2.g, Ld.n2.b, x, DM, rows, 0, st));
+  CHK(attention_kv(0, qc, DM, (long)rows_per_b * DM, w.memkv[layer], w.memkv[layer] + DM, 2 * DM, (long)M * 2 * DM,
+                   w.img_mem[layer], w.nkt_mem, att, DM, (long)rows_per_b * DM, nullptr, w.src_pad, B, rows_per_b, M, d.A, st));
+  CHK(gemm_ln(Ld.cout, Ld.n2, att, DM, x, DM, x, DM, tmp, rows, DM, 0, st));
   CHK(gemm(Ld.lin1, x, DM, nullptr, 0, ffn, d.F, rows, d.F, DM, 1, st));
-  CHK(gemm(Ld.lin2, ffn, d.F, x, DM, tmp, DM, rows, DM, d.F, 0, st));
-  CHK(launch_layernorm256(tmp, DM, nullptr, 0, Ld.n3.g, Ld.n3.b, x, DM, rows, 0, st));
+  CHK(gemm_ln(Ld.lin2, Ld.n3, ffn, d.F, x, DM, x, DM, tmp, rows, d.F, 0, st));
   return 0;
 }
 // map encoder + scene encoder + per-layer memory K/V (everything that only depends on the frame of the context)
@@ -270,17 +311,13 @@ int scene_side(const ctrlsim_model* m, const Ws& w, const ctrlsim_ctx* c, int B,
   const int A = d.A, P = d.P, M = P + A, rM = B * M, rP = B * P;
   // ---- map encoder (map_encoder.py:34-53): rows of `src` 0..P-1 per context
   CHK(launch_map_pool(B, P, d.NP, M, c->road_pts, m->mp, w.attn_pre, w.src_pad, st));
-  CHK(gemm(m->map_out, w.attn_pre, DM, nullptr, 0, w.m1, DM, rP, DM, DM, 0, st));
-  CHK(launch_layernorm256(w.m1, DM, nullptr, 0, m->map_n1.g, m->map_n1.b, w.m1, DM, rP, 0, st));            // emb
-  CHK(gemm(m->map_feats.l0, w.m1, DM, nullptr, 0, w.m2, DM, rP, DM, DM, 0, st));
-  CHK(launch_layernorm256(w.m2, DM, nullptr, 0, m->map_feats.ln.g, m->map_feats.ln.b, w.m2, DM, rP, 1, st));
-  CHK(gemm(m->map_feats.l3, w.m2, DM, w.m1, DM, w.attn_pre, DM, rP, DM, DM, 0, st));
-  CHK(launch_layernorm256(w.attn_pre, DM, nullptr, 0, m->map_n2.g, m->map_n2.b, w.cat, 2 * DM, rP, 0, st));  // cat[:, :256]
+  CHK(gemm_ln(m->map_out, m->map_n1, w.attn_pre, DM, nullptr, 0, w.m1, DM, w.m1, rP, DM, 0, st));            // emb
+  CHK(gemm_ln(m->map_feats.l0, m->map_feats.ln, w.m1, DM, nullptr, 0, w.m2, DM, w.m2, rP, DM, 1, st));
+  CHK(gemm_ln(m->map_feats.l3, m->map_n2, w.m2, DM, w.m1, DM, w.cat, 2 * DM, w.attn_pre, rP, DM, 0, st));   // cat[:, :256]
   CHK(launch_in_mlp(c->road_types, 8, 8, m->road_type.l0.w, m->road_type.l0.b, m->road_type.ln.g, m->road_type.ln.b, w.tfh,
                     DM, rP, st));
   CHK(gemm(m->road_type.l3, w.tfh, DM, nullptr, 0, w.cat + DM, 2 * DM, rP, DM, DM, 0, st));                                                                                  // cat[:, 256:]
-  CHK(gemm(m->road_fuse.l0, w.cat, 2 * DM, nullptr, 0, w.m2, DM, rP, DM, 2 * DM, 0, st));
-  CHK(launch_layernorm256(w.m2, DM, nullptr, 0, m->road_fuse.ln.g, m->road_fuse.ln.b, w.m2, DM, rP, 1, st));
+  CHK(gemm_ln(m->road_fuse.l0, m->road_fuse.ln, w.cat, 2 * DM, nullptr, 0, w.m2, DM, w.m2, rP, 2 * DM, 1, st));
   // final Linear -> compact [B*P,256], then scattered into the scene-encoder source rows [b, 0..P-1]
   CHK(gemm(m->road_fuse.l3, w.m2, DM, nullptr, 0, w.m1, DM, rP, DM, DM, 0, st));
   CHK(launch_row_copy(w.m1, DM, w.src, DM, w.idx_poly, rP, DM, 1, st));
@@ -292,17 +329,18 @@ int scene_side(const ctrlsim_model* m, const Ws& w, const ctrlsim_ctx* c, int B,
   for (int i = 0; i < d.NE; ++i) {
     const EncLayer& Le = m->enc[i];
     CHK(gemm(Le.qkv, w.src, DM, nullptr, 0, w.eqkv, 3 * DM, rM, 3 * DM, DM, 0, st));
-    CHK(launch_attention(0, w.eqkv, 3 * DM, (long)M * 3 * DM, w.eqkv + DM, w.eqkv + 2 * DM, 3 * DM, (long)M * 3 * DM, w.eatt,
-                         DM, (long)M * DM, nullptr, w.src_pad, B, M, M, A, st));
-    CHK(gemm(Le.out, w.eatt, DM, w.src, DM, w.etmp, DM, rM, DM, DM, 0, st));
-    CHK(launch_layernorm256(w.etmp, DM, nullptr, 0, Le.n1.g, Le.n1.b, w.src, DM, rM, 0, st));
+    CHK(kv_split(w.eqkv + DM, w.eqkv + 2 * DM, 3 * DM, (long)M * 3 * DM, B, M, w.nkt_mem, w.img_enc, st));
+    CHK(attention_kv(0, w.eqkv, 3 * DM, (long)M * 3 * DM, w.eqkv + DM, w.eqkv + 2 * DM, 3 * DM, (long)M * 3 * DM, w.img_enc,
+                     w.nkt_mem, w.eatt, DM, (long)M * DM, nullptr, w.src_pad, B, M, M, A, st));
+    CHK(gemm_ln(Le.out, Le.n1, w.eatt, DM, w.src, DM, w.src, DM, w.etmp, rM, DM, 0, st));
     CHK(gemm(Le.lin1, w.src, DM, nullptr, 0, w.effn, d.F, rM, d.F, DM, 1, st));
-    CHK(gemm(Le.lin2, w.effn, d.F, w.src, DM, w.etmp, DM, rM, DM, d.F, 0, st));
-    CHK(launch_layernorm256(w.etmp, DM, nullptr, 0, Le.n2.g, Le.n2.b, w.src, DM, rM, 0, st));
+    CHK(gemm_ln(Le.lin2, Le.n2, w.effn, d.F, w.src, DM, w.src, DM, w.etmp, rM, d.F, 0, st));
   }
   // memory K/V of every decoder layer (cached for pass 2)
-  for (int i = 0; i < d.ND; ++i)
+  for (int i = 0; i < d.ND; ++i) {
     CHK(gemm(m->dec[i].ckv, w.src, DM, nullptr, 0, w.memkv[i], 2 * DM, rM, 2 * DM, DM, 0, st));
+    CHK(kv_split(w.memkv[i], w.memkv[i] + DM, 2 * DM, (long)M * 2 * DM, B, M, w.nkt_mem, w.img_mem[i], st));
+  }
   return 0;
 }
 
@@ -337,20 +375,19 @@ extern "C" int ctrlsim_dt_forward_pass1(const ctrlsim_model* m, int B, int Tq, c
   for (int i = 0; i < d.ND; ++i) {
     const DecLayer& Ld = m->dec[i];
     CHK(gemm(Ld.qkv, w.X, DM, nullptr, 0, w.qkv[i], 3 * DM, rL, 3 * DM, DM, 0, st));
+    CHK(kv_split(w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM, B, L, w.nkt_dec, w.img_dec[i], st));
     if (i < d.ND - 1) {
-      CHK(launch_attention(1, w.qkv[i], 3 * DM, (long)L * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
-                           w.att, DM, (long)L * DM, nullptr, nullptr, B, L, L, A, st));
-      CHK(gemm(Ld.out, w.att, DM, w.X, DM, w.tmp, DM, rL, DM, DM, 0, st));
-      CHK(launch_layernorm256(w.tmp, DM, nullptr, 0, Ld.n1.g, Ld.n1.b, w.X, DM, rL, 0, st));
+      CHK(attention_kv(1, w.qkv[i], 3 * DM, (long)L * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
+                       w.img_dec[i], w.nkt_dec, w.att, DM, (long)L * DM, nullptr, nullptr, B, L, L, A, st));
+      CHK(gemm_ln(Ld.out, Ld.n1, w.att, DM, w.X, DM, w.X, DM, w.tmp, rL, DM, 0, st));
       CHK(cross_and_ffn(m, Ld, i, w, w.X, w.tmp, w.att, w.qc, w.ffn, rL, B, L, st));
     } else {
       // last layer: only the A state tokens of the current timestep are queried
       CHK(launch_row_copy(w.X, DM, w.xc, DM, w.idx_state, rA, DM, 0, st));
       CHK(launch_row_copy(w.qkv[i], 3 * DM, w.qkvc, 3 * DM, w.idx_state, rA, 3 * DM, 0, st));
-      CHK(launch_attention(1, w.qkvc, 3 * DM, (long)A * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
-                           w.attc, DM, (long)A * DM, w.pos_state, nullptr, B, A, L, A, st));
-      CHK(gemm(Ld.out, w.attc, DM, w.xc, DM, w.tmpc, DM, rA, DM, DM, 0, st));
-      CHK(launch_layernorm256(w.tmpc, DM, nullptr, 0, Ld.n1.g, Ld.n1.b, w.xc, DM, rA, 0, st));
+      CHK(attention_kv(1, w.qkvc, 3 * DM, (long)A * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
+                       w.img_dec[i], w.nkt_dec, w.attc, DM, (long)A * DM, w.pos_state, nullptr, B, A, L, A, st));
+      CHK(gemm_ln(Ld.out, Ld.n1, w.attc, DM, w.xc, DM, w.xc, DM, w.tmpc, rA, DM, 0, st));
       CHK(cross_and_ffn(m, Ld, i, w, w.xc, w.tmpc, w.attc, w.qcc, w.ffnc, rA, B, A, st));
     }
   }
@@ -376,10 +413,10 @@ extern "C" int ctrlsim_dt_forward_pass2(const ctrlsim_model* m, int B, int Tq, i
     const DecLayer& Ld = m->dec[i];
     CHK(gemm(Ld.qkv, w.xc2, DM, nullptr, 0, w.qkvc, 3 * DM, rA, 3 * DM, DM, 0, st));
     CHK(launch_row_copy(w.qkvc, 3 * DM, w.qkv[i], 3 * DM, w.idx_rtg, rA, 3 * DM, 1, st));   // refresh the rtg rows' K/V
-    CHK(launch_attention(1, w.qkvc, 3 * DM, (long)A * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
-                         w.attc, DM, (long)A * DM, w.pos_rtg, nullptr, B, A, Tq * A * 3, A, st));   // keys: steps <= current
-    CHK(gemm(Ld.out, w.attc, DM, w.xc2, DM, w.tmpc, DM, rA, DM, DM, 0, st));
-    CHK(launch_layernorm256(w.tmpc, DM, nullptr, 0, Ld.n1.g, Ld.n1.b, w.xc2, DM, rA, 0, st));
+    CHK(kv_split_rows(w.qkvc + DM, w.qkvc + 2 * DM, 3 * DM, (long)A * 3 * DM, w.pos_rtg, B, A, w.nkt_dec, w.img_dec[i], st));
+    CHK(attention_kv(1, w.qkvc, 3 * DM, (long)A * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
+                     w.img_dec[i], w.nkt_dec, w.attc, DM, (long)A * DM, w.pos_rtg, nullptr, B, A, Tq * A * 3, A, st));   // keys: steps <= current
+    CHK(gemm_ln(Ld.out, Ld.n1, w.attc, DM, w.xc2, DM, w.xc2, DM, w.tmpc, rA, DM, 0, st));
     CHK(cross_and_ffn(m, Ld, i, w, w.xc2, w.tmpc, w.attc, w.qcc, w.ffnc, rA, B, A, st));
   }
   CHK(mlp_tail(m->head_action, w.xc2, rA, w.headh, act_logits, d.V, st));
@@ -426,10 +463,13 @@ extern "C" int ctrlsim_dt_forward_pass1_cached(const ctrlsim_model* m, int B, in
     const DecLayer& Ld = m->dec[i];
     CHK(gemm(Ld.qkv, w.xn, DM, nullptr, 0, w.qkvn, 3 * DM, rN, 3 * DM, DM, 0, st));
     CHK(launch_row_copy(w.qkvn, 3 * DM, w.qkv[i], 3 * DM, w.idx_new, rN, 3 * DM, 1, st));       // K/V (and Q) into the cache
-    CHK(launch_attention(1, w.qkvn, 3 * DM, (long)Rn * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)Lf * 3 * DM,
-                         w.attn_n, DM, (long)Rn * DM, w.pos_new, nullptr, B, Rn, (t + 1) * A * 3, A, st));   // rows beyond are not loaded
-    CHK(gemm(Ld.out, w.attn_n, DM, w.xn, DM, w.tmpn, DM, rN, DM, DM, 0, st));
-    CHK(launch_layernorm256(w.tmpn, DM, nullptr, 0, Ld.n1.g, Ld.n1.b, w.xn, DM, rN, 0, st));
+    if (t == 0 && presplit()) {   // image tiles are read whole: stale bits beyond the written rows must at least be finite
+      if (hipMemsetAsync(w.img_dec[i], 0, w.img_dec_bytes, st) != hipSuccess) return CTRLSIM_ELAUNCH;
+    }
+    CHK(kv_split_rows(w.qkvn + DM, w.qkvn + 2 * DM, 3 * DM, (long)Rn * 3 * DM, w.pos_new, B, Rn, w.nkt_dec, w.img_dec[i], st));
+    CHK(attention_kv(1, w.qkvn, 3 * DM, (long)Rn * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)Lf * 3 * DM,
+                     w.img_dec[i], w.nkt_dec, w.attn_n, DM, (long)Rn * DM, w.pos_new, nullptr, B, Rn, (t + 1) * A * 3, A, st));
+    CHK(gemm_ln(Ld.out, Ld.n1, w.attn_n, DM, w.xn, DM, w.xn, DM, w.tmpn, rN, DM, 0, st));
     CHK(cross_and_ffn(m, Ld, i, w, w.xn, w.tmpn, w.attn_n, w.qcn, w.ffnn, rN, B, Rn, st));
   }
   CHK(launch_row_copy(w.xn, DM, w.xc, DM, w.idx_state_in_new, rA, DM, 0, st));

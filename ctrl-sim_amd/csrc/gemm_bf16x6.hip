@@ -3,21 +3,24 @@
 //     a.b ~= hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid          (dropped terms <= 2^-23 relative)
 // with fp32 accumulation inside v_mfma_f32_32x32x16_bf16.  The result carries fp32-class error (measured against an
 // fp64 reference in tests/test_gpu_ops.py: same order as the f32-input MFMA kernel) while the matrix pipe runs at
-// 16x the f32-input MFMA rate for 6x the instructions: a 2.67x higher matrix roof (420 TFLOP/s fp32-equivalent).
+// 16x the f32-input MFMA rate for 6x the instructions: a 2.67x higher matrix roof (417 TFLOP/s fp32-equivalent).
 // Token parity with the reference is unaffected (fixtures: bit-exact tokens, logits within 1e-4).
 //
 // Weights are split ONCE at pack time (ctrlsim_amd/pack.py) into slab-major planes  W3[K/16][3][2][N][8] bf16  (the
 // two 8-element halves of a 16-wide k-step are separate sub-planes) so a workgroup's K-slab of a sub-plane is one
 // contiguous 16-byte-per-row stream and the LDS image [plane][half][row][8] makes every fragment read of a wave two
-// contiguous 512-byte spans (no bank conflicts; rows adjacent in a 32-byte layout were 2-way conflicting).  Activations stay fp32 in HBM and are split
-// in registers while being staged into LDS (v_cvt_pk_bf16_f32, round-to-nearest-even).
+// contiguous 512-byte spans (no bank conflicts).  Activations stay fp32 in HBM and are split in registers while being
+// staged into LDS (v_cvt_pk_bf16_f32, round-to-nearest-even).
 //
-// Tiling: workgroup = 128 (M) x 256 (N), 4 waves as 2x2, wave tile 64x128 = 2x4 MFMA tiles (128 accumulator regs);
-// extending N (pre-split weights) rather than M amortises the activation split.  K-slab = 16 = one MFMA k-step;
-// LDS per buffer: A planes 3 x [128][16] + W planes 3 x [256][16] bf16 = 36 KB, double buffered (72 KB, 2 WG / CU),
-// rows are 32 bytes so a wave's 16-byte fragment reads are one contiguous 1-2 KB span (conflict free, no padding).
-// Persistent workgroups with the XCD-aware tile order of gemm.hip; the next tile's first slab is prefetched before
-// the epilogue; the epilogue stages 64 rows at a time through LDS for 16-byte bias / residual / store traffic.
+// Tiling: 256 threads = 4 waves, wave tile 64x64 (2x2 MFMA tiles, 64 accumulator registers), arranged
+//   2x2 -> workgroup tile 128 x 128, 48 KB of LDS, THREE workgroups per CU     (plain Linear)
+//   1x4 -> workgroup tile  64 x 256, 60 KB of LDS, two workgroups per CU       (Linear + LayerNorm: whole rows)
+// One LDS stage = one 16-wide k-step, double buffered, one barrier per k-step.  Several independent workgroups per CU
+// are what overlaps the phases: measured on the previous one-workgroup-per-CU version (8 waves in barrier lock-step)
+// the k-loop, its operand staging and the epilogue simply added up (0.19 + 0.18 + 0.17 ms on the FFN-1 shape).
+// Persistent workgroups with the XCD-aware tile order of gemm.hip; the next tile's first A slab is prefetched before
+// the epilogue; the epilogue stages half the tile's rows at a time through LDS for 16-byte bias / residual / store
+// traffic and, for LN, normalises whole rows there (one wave per row).
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -26,8 +29,6 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-#define XM 128
-#define XN 256
 #define XK 16
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -60,28 +61,28 @@ __device__ __forceinline__ void term(f32x16 (&acc)[2][2], const bf16x8 (&fa)[2][
       acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA], fb[b][PB], acc[a][b], 0, 0, 0);
 }
 
-// 512 threads = 8 waves as 2 (M) x 4 (N), wave tile 64 x 64 (2x2 MFMA tiles); one LDS stage = 32 k (two 16-wide k-steps),
-// two stages (144 KB, one workgroup per CU, two waves per SIMD), one barrier per 32 k.
-template <bool RELU, bool RESID>
-__global__ __launch_bounds__(512, 2) void gemm_nt_bf16x6_kernel(const float* __restrict__ A, int lda,
-                                                                const __bf16* __restrict__ W3,   // [K/16][3][2][N][8]
-                                                                const float* __restrict__ bias,
-                                                                const float* __restrict__ R, int ldr,
-                                                                float* __restrict__ C, int ldc, int M, int N, int K,
-                                                                int m_tiles, int n_tiles, int n_total, int n0) {
+template <int WR, int WC, bool RELU, bool RESID, bool LN>
+__global__ __launch_bounds__(256, (WR == 2 && WC == 2) ? 3 : 2) void gemm_nt_bf16x6_kernel(
+    const float* __restrict__ A, int lda, const __bf16* __restrict__ W3,   // [K/16][3][2][n_total][8]
+    const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ R, int ldr, float* __restrict__ C, int ldc, int M, int N, int K, int m_tiles, int n_tiles,
+    int n_total, int n0) {
   // W3 holds all n_total rows of the packed matrix; this GEMM uses rows [n0, n0 + N) (e.g. the q / kv halves of an
   // in_proj_weight)
+  constexpr int XM = 64 * WR, XN = 64 * WC;
   constexpr int A_PLANE = XM * XK;                 // bf16 elements of one plane of one k-step
   constexpr int W_PLANE = XN * XK;
-  constexpr int KSBUF = 3 * A_PLANE + 3 * W_PLANE; // one k-step (18432 bf16 = 36 KB)
-  constexpr int BUF = 2 * KSBUF;                   // one stage = two k-steps (72 KB)
-  constexpr int CP = XN + 4;
-  extern __shared__ __attribute__((aligned(16))) __bf16 lds[];   // 2 * BUF bf16 = 144 KB
-  static_assert(2 * BUF * 2 >= 64 * CP * 4, "epilogue staging must fit");
+  constexpr int STAGE = 3 * A_PLANE + 3 * W_PLANE; // one k-step: 24 KB (2x2) / 30 KB (1x4)
+  constexpr int CP = XN + 4, CR = 32 * WR;         // epilogue chunk: CR rows x XN columns of fp32
+  constexpr int NA = XM / 64;                      // f32x4 loads of A per thread and stage
+  constexpr int NW = 6 * XN / 256;                 // 16-byte DMA chunks of W per thread and stage
+  static_assert(!LN || (WR == 1 && WC == 4), "LayerNorm epilogue needs whole 256-wide rows");
+  static_assert(2 * STAGE * 2 >= CR * CP * 4, "epilogue staging must fit");
+  extern __shared__ __attribute__((aligned(16))) __bf16 lds[];   // 2 * STAGE bf16
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int l31 = lane & 31, half = lane >> 5;
-  const int wr = wave >> 2, wc = wave & 3;
+  const int wr = wave / WC, wc = wave % WC;
 
   const int total_ids = ((m_tiles + 7) / 8) * 8 * n_tiles;
   int bm = 0, bn = 0;
@@ -94,45 +95,52 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x6_kernel(const float* __r
   };
 
   // ---- staging: A through registers (fp32 -> 3 bf16 planes), W planes by LDS-DMA (global_load_lds, 16 B per lane:
-  // the W part of a stage is lane-linear in exactly the order idx = tid + 512*i, so the DMA needs no VGPRs at all)
-  f32x4 ra[2];
+  // the W part of a stage is lane-linear in exactly the order idx = tid + 256*i, so the DMA needs no VGPRs at all)
+  f32x4 ra[NA];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const size_t w_slab = (size_t)3 * n_total * XK;  // bf16 elements per 16-wide K-slab of W3
   auto gload_a = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 512 * i, r = idx >> 3, c = (idx & 7) * 4;
+    for (int i = 0; i < NA; ++i) {
+      const int idx = tid + 256 * i, r = idx >> 2, c = (idx & 3) * 4;
       const int ga = bm + r;
-      ra[i] = ga < M ? *reinterpret_cast<const f32x4*>(A + (size_t)ga * lda + kt * 32 + c) : zero4;
+#ifndef ABL_NO_ALOAD
+      ra[i] = ga < M ? *reinterpret_cast<const f32x4*>(A + (size_t)ga * lda + kt * XK + c) : zero4;
+#else
+      ra[i] = zero4 + (float)(ga + kt);
+#endif
     }
   };
   auto dma_w = [&](int kt, int buf) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int idx = tid + 512 * i, ks = idx / 1536, rem = idx - ks * 1536, pc = rem >> 8, r = rem & 255;
+    for (int i = 0; i < NW; ++i) {
+      const int idx = tid + 256 * i, pc = idx / XN, r = idx % XN;
       int gw = bn + r;
       gw = gw < N ? gw : N - 1;                    // columns >= N are computed on clamped rows and never stored
-      const __bf16* src = W3 + (size_t)(2 * kt + ks) * w_slab + ((size_t)pc * n_total + n0 + gw) * 8;
-      const int idx0 = wave * 64 + 512 * i, ks0 = idx0 / 1536, rem0 = idx0 - ks0 * 1536;   // wave-uniform LDS base
-      __bf16* dst = lds + buf * BUF + ks0 * KSBUF + 3 * A_PLANE + rem0 * 8;
+      const __bf16* src = W3 + (size_t)kt * w_slab + ((size_t)pc * n_total + n0 + gw) * 8;
+      __bf16* dst = lds + buf * STAGE + 3 * A_PLANE + (wave * 64 + 256 * i) * 8;   // wave-uniform LDS base
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
   };
   auto sstore_a = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 512 * i, r = idx >> 3, c = (idx & 7) * 4;
+    for (int i = 0; i < NA; ++i) {
+      const int idx = tid + 256 * i, r = idx >> 2, c = (idx & 3) * 4;
       u32x2 hi, mid, lo;
+#ifndef ABL_NO_SPLIT
       split3(ra[i], hi, mid, lo);
-      __bf16* Ab = lds + buf * BUF + (c >> 4) * KSBUF + ((c >> 3) & 1) * (A_PLANE / 2) + r * 8 + (c & 7);
+#else
+      hi = u32x2{__float_as_uint(ra[i][0]), __float_as_uint(ra[i][1])}; mid = u32x2{__float_as_uint(ra[i][2]), __float_as_uint(ra[i][3])}; lo = hi;
+#endif
+      __bf16* Ab = lds + buf * STAGE + (c >> 3) * (A_PLANE / 2) + r * 8 + (c & 7);
       *reinterpret_cast<u32x2*>(Ab + 0 * A_PLANE) = hi;
       *reinterpret_cast<u32x2*>(Ab + 1 * A_PLANE) = mid;
       *reinterpret_cast<u32x2*>(Ab + 2 * A_PLANE) = lo;
     }
   };
 
-  const int nk = K / 32;
+  const int nk = K / XK;
   int id = blockIdx.x;
   while (id < total_ids && !tile_of(id, bm, bn)) id += gridDim.x;
   if (id >= total_ids) return;
@@ -153,15 +161,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x6_kernel(const float* __r
       const int cur = kt & 1;
       if (kt + 1 < nk) {
 #ifndef ABL_NO_DMA
-        dma_w(kt + 1, cur ^ 1);
-#endif                    // stage cur^1 was released by the barrier that ended kt-1
+        dma_w(kt + 1, cur ^ 1);                    // stage cur^1 was released by the barrier that ended kt-1
+#endif
         gload_a(kt + 1);
       }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const __bf16* Ab = lds + cur * BUF + ks * KSBUF + half * (A_PLANE / 2) + (wr * 64 + l31) * 8;
-        const __bf16* Wb = lds + cur * BUF + ks * KSBUF + 3 * A_PLANE + half * (W_PLANE / 2) + (wc * 64 + l31) * 8;
+      {
+        const __bf16* Ab = lds + cur * STAGE + half * (A_PLANE / 2) + (wr * 64 + l31) * 8;
+        const __bf16* Wb = lds + cur * STAGE + 3 * A_PLANE + half * (W_PLANE / 2) + (wc * 64 + l31) * 8;
         bf16x8 fa[2][3], fb[2][3];
+#ifndef ABL_NO_FRAG
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
@@ -169,6 +177,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x6_kernel(const float* __r
 #pragma unroll
           for (int b = 0; b < 2; ++b) fb[b][p] = *reinterpret_cast<const bf16x8*>(Wb + p * W_PLANE + b * 32 * 8);
         }
+#else
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+          for (int a = 0; a < 2; ++a) { fa[a][p] = bf16x8{}; fb[a][p] = bf16x8{}; asm volatile("" : "+v"(fa[a][p]), "+v"(fb[a][p])); }
+        }
+#endif
         // six partial products, smallest first; term-major order keeps 4 independent accumulators between reuses
 #ifndef ABL_NO_MFMA
         term<2, 0>(acc, fa, fb);
@@ -186,14 +201,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x6_kernel(const float* __r
       __syncthreads();
     }
 
-    // ---- epilogue: two chunks of 64 rows (tile row a of both wave rows) staged through LDS
-    float* Cs = reinterpret_cast<float*>(lds);   // [64][XN + 4]
+    // ---- epilogue: two chunks of CR rows (MFMA tile row a of every wave row) staged through LDS
+    float* Cs = reinterpret_cast<float*>(lds);   // [CR][XN + 4]
     const bool vec_ok = !(ldc & 3) && (!RESID || !(ldr & 3));
     const int cbm = bm, cbn = bn;
     int nid = id + gridDim.x;
     while (nid < total_ids && !tile_of(nid, bm, bn)) nid += gridDim.x;
     const bool have_next = nid < total_ids;
     if (have_next) gload_a(0);
+#ifdef ABL_NO_EPI
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) asm volatile("" ::"v"(acc[a][b]));
+    if (tid == 0 && M < 0) C[0] = Cs[0];
+#else
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
 #pragma unroll
@@ -202,10 +224,29 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x6_kernel(const float* __r
         for (int r = 0; r < 16; ++r)
           Cs[(wr * 32 + mfma_row(r, half)) * CP + wc * 64 + b * 32 + l31] = acc[a][b][r];
       __syncthreads();
+      constexpr int LPR = XN / 4;                  // lanes per row (f32x4 each): 32 (2x2) or 64 = one wave (1x4)
 #pragma unroll 4
-      for (int i = 0; i < 8; ++i) {
-        const int idx = tid + 512 * i, lr = idx >> 6, col = (idx & 63) * 4;
+      for (int i = 0; i < CR * LPR / 256; ++i) {
+        const int idx = tid + 256 * i, lr = idx / LPR, col = (idx % LPR) * 4;
         const int grow = cbm + (lr >> 5) * 64 + a * 32 + (lr & 31), gcol = cbn + col;
+        if (LN) {
+          // one wave = one full 256-wide row (lane -> 4 consecutive columns); rows beyond M are skipped wave-uniformly
+          if (grow >= M) continue;
+          f32x4 v = *reinterpret_cast<const f32x4*>(Cs + lr * CP + col);
+          if (bias) v += *reinterpret_cast<const f32x4*>(bias + gcol);
+          if (RESID) v += *reinterpret_cast<const f32x4*>(R + (size_t)grow * ldr + gcol);
+          const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
+          const f32x4 dv = v - mean;
+          const float var = wave_sum(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2] + dv[3] * dv[3]) * (1.f / 256.f);
+          f32x4 y = dv * (1.0f / sqrtf(var + 1e-5f)) * *reinterpret_cast<const f32x4*>(gamma + gcol) +
+                    *reinterpret_cast<const f32x4*>(beta + gcol);
+          if (RELU) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) y[c] = fmaxf(y[c], 0.f);
+          }
+          *reinterpret_cast<f32x4*>(C + (size_t)grow * ldc + gcol) = y;
+          continue;
+        }
         if (grow >= M || gcol >= N) continue;
         f32x4 v = *reinterpret_cast<const f32x4*>(Cs + lr * CP + col);
         if (vec_ok && gcol + 3 < N) {
@@ -230,41 +271,57 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16x6_kernel(const float* __r
       }
       __syncthreads();
     }
+#endif
     if (!have_next) break;
     id = nid;
   }
 }
 
-int launch_gemm_nt_bf16x6(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias, const float* R, int ldr, float* C,
-                          int ldc, int M, int N, int K, int relu, hipStream_t st) {
+int launch_gemm_nt_bf16x6(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias,
+                          const float* R, int ldr, float* C, int ldc, int M, int N, int K, int relu,
+                          const float* ln_gamma, const float* ln_beta, hipStream_t st) {
   if (M <= 0) return CTRLSIM_OK;
-  if (K % 32 != 0 || (lda & 3) || N <= 0 || !W3 || n0 < 0 || n0 + N > n_total) return CTRLSIM_EINVAL;
+  if (K % XK != 0 || (lda & 3) || N <= 0 || !W3 || n0 < 0 || n0 + N > n_total) return CTRLSIM_EINVAL;
+  const bool ln = ln_gamma != nullptr;
+  if (ln && (N != 256 || (ldc & 3) || (R && (ldr & 3)))) return CTRLSIM_EINVAL;
+  if (!ln && R && relu) return CTRLSIM_EINVAL;
+  const int tile_opt = ctrlsim_option(OPT_GEMM6_TILE);          // 0 = auto, 1 = 128x128, 2 = 64x256 (A/B knob)
+  const bool wide = ln || tile_opt == 2 || (tile_opt == 0 && false);
+  const int XM = wide ? 64 : 128, XN = wide ? 256 : 128;
   const int m_tiles = (M + XM - 1) / XM, n_tiles = (N + XN - 1) / XN;
   const int total = ((m_tiles + 7) / 8) * 8 * n_tiles;
-  const int resident = 256;                        // one 512-thread workgroup per CU (144 KB of LDS)
+  const int resident = 256 * (wide ? 2 : 3);
   const int grid = total < resident ? total : resident;
-  dim3 g(grid), b(512);
+  dim3 g(grid), b(256);
   const __bf16* w = static_cast<const __bf16*>(W3);
-  const size_t shm = (size_t)2 * 2 * (3 * XM * XK + 3 * XN * XK) * sizeof(__bf16);   // 147456 B
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16x6_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16x6_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16x6_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    attr_set = true;
-  }
+  const size_t shm = (size_t)2 * 3 * (XM + XN) * XK * sizeof(__bf16);   // 48 KB / 60 KB
+#define GEMM6_LAUNCH(WR_, WC_, RELU_, RESID_, LN_)                                                                    \
+  do {                                                                                                                \
+    static bool attr = false;                                                                                         \
+    if (!attr) {                                                                                                      \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16x6_kernel<WR_, WC_, RELU_, RESID_, LN_>),        \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                                      \
+      attr = true;                                                                                                    \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((gemm_nt_bf16x6_kernel<WR_, WC_, RELU_, RESID_, LN_>), g, b, shm, st, A, lda, w, bias,         \
+                       ln_gamma, ln_beta, R, ldr, C, ldc, M, N, K, m_tiles, n_tiles, n_total, n0);                    \
+  } while (0)
   prof_before(PROF_GEMM, st);
-  if (R) {
-    if (relu) return CTRLSIM_EINVAL;
-    hipLaunchKernelGGL((gemm_nt_bf16x6_kernel<false, true>), g, b, shm, st, A, lda, w, bias, R, ldr, C, ldc, M, N, K, m_tiles,
-                       n_tiles, n_total, n0);
-  } else if (relu) {
-    hipLaunchKernelGGL((gemm_nt_bf16x6_kernel<true, false>), g, b, shm, st, A, lda, w, bias, R, ldr, C, ldc, M, N, K, m_tiles,
-                       n_tiles, n_total, n0);
+  if (ln) {
+    if (R && relu) GEMM6_LAUNCH(1, 4, true, true, true);
+    else if (R) GEMM6_LAUNCH(1, 4, false, true, true);
+    else if (relu) GEMM6_LAUNCH(1, 4, true, false, true);
+    else GEMM6_LAUNCH(1, 4, false, false, true);
+  } else if (wide) {
+    if (R) GEMM6_LAUNCH(1, 4, false, true, false);
+    else if (relu) GEMM6_LAUNCH(1, 4, true, false, false);
+    else GEMM6_LAUNCH(1, 4, false, false, false);
   } else {
-    hipLaunchKernelGGL((gemm_nt_bf16x6_kernel<false, false>), g, b, shm, st, A, lda, w, bias, R, ldr, C, ldc, M, N, K, m_tiles,
-                       n_tiles, n_total, n0);
+    if (R) GEMM6_LAUNCH(2, 2, false, true, false);
+    else if (relu) GEMM6_LAUNCH(2, 2, true, false, false);
+    else GEMM6_LAUNCH(2, 2, false, false, false);
   }
+#undef GEMM6_LAUNCH
   prof_after(PROF_GEMM, 2.0 * (double)M * (double)N * (double)K, st);
   return ctrlsim_launch_status();
 }

@@ -128,15 +128,29 @@ int ctrlsim_sample_action(const float* act_logits, int A, int V, const int* mem_
 int ctrlsim_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr,
                     float* C, int ldc, int M, int N, int K, int relu, hipStream_t stream);
 /* Same product evaluated on the bf16 MFMA with fp32-class accuracy: W3 = the weight split into three bf16 planes, slab-major
- * [K/16][3][n_total][16] (ctrlsim_amd/pack.py:split3_planes); rows [n0, n0+N) of it are used; A stays fp32. */
+ * [K/16][3][2][n_total][8] (ctrlsim_amd/pack.py:split3_planes); rows [n0, n0+N) of it are used; A stays fp32.
+ * ln_gamma/ln_beta non-NULL (N must be 256): C = [relu] LayerNorm(A W^T + bias [+ R]) * gamma + beta, eps 1e-5 — the
+ * post-LN residual blocks of nn.TransformerEncoder/DecoderLayer and the Linear-LayerNorm-ReLU halves of MLPLayer
+ * (modules/layers.py) as one kernel; C may alias R. */
 int ctrlsim_gemm_nt_bf16x6(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias, const float* R,
-                           int ldr, float* C, int ldc, int M, int N, int K, int relu, hipStream_t stream);
+                           int ldr, float* C, int ldc, int M, int N, int K, int relu, const float* ln_gamma,
+                           const float* ln_beta, hipStream_t stream);
 int ctrlsim_layernorm256(const float* X, int ldx, const float* Radd, int ldr, const float* gamma, const float* beta,
                          float* Y, int ldy, int rows, int relu, hipStream_t stream);
 /* mode 0: key padding (key_pad [B,Lk], 1 = ignore); mode 1: CtRL-Sim structured causal mask (utils/train_utils.py:81-129) */
 int ctrlsim_attention(int mode, const float* Q, int ldq, int64_t q_batch_stride, const float* K, const float* V,
                       int ldkv, int64_t kv_batch_stride, float* O, int ldo, int64_t o_batch_stride, const int* q_pos,
                       const uint8_t* key_pad, int B, int Lq, int Lk, int A, hipStream_t stream);
+/* Split-bf16 K/V images for the bf16x6 attention (csrc/attention_bf16x6.hip): per (context, head, 64-key tile) 24 KB =
+ * K planes [3][d>>3][key][d&7] then V^T planes [3][key>>2][d][key&3], bf16; img holds B * 8 * nkt tiles.
+ * pos == NULL: rows [0, rows) of every context are split, keys beyond are zero-filled (rows <= 64 * nkt);
+ * pos != NULL: row r of context b is written at key position pos[r] (KV-cache update; other keys untouched). */
+int ctrlsim_kv_split(const float* K, const float* V, int ldkv, int64_t kv_batch_stride, const int* pos, int B, int rows,
+                     int nkt, void* img, hipStream_t stream);
+/* ctrlsim_attention with K/V taken from such images (staged by LDS-DMA, no in-kernel split); same modes and masks. */
+int ctrlsim_attention_presplit(int mode, const float* Q, int ldq, int64_t q_batch_stride, const void* img, int nkt, float* O,
+                               int ldo, int64_t o_batch_stride, const int* q_pos, const uint8_t* key_pad, int B, int Lq,
+                               int Lk, int A, hipStream_t stream);
 
 /* ---- measurement hooks (bench.py): HIP-event timing of every GEMM (class 0) / attention (class 1) launch on its own
  * launch stream.  enable(1) clears and starts recording; after the caller synchronised, collect() returns per class the

@@ -79,3 +79,22 @@ def test_forward_matches_reference_golden_logits():
         rtg, act, _ = _run_both_passes(model, d, inp, t_fill, bins)
         np.testing.assert_allclose(rtg[0], g[f"s{seed}_rtg_logits"], atol=TOL, rtol=0)
         np.testing.assert_allclose(act[0], g[f"s{seed}_action_logits"], atol=TOL, rtol=0)
+
+
+def test_forward_f32_mfma_kernels_selectable():
+    """ctrlsim_set_option(0/1, 0) routes every Linear / attention through the f32-input MFMA kernels (separate LayerNorm
+    kernel); the logits must agree with the default split-bf16 path to well inside the tolerance."""
+    cfg = cfg_of("loop")
+    d = spec.Dims(cfg)
+    model = HipModel(cfg, weights.generate(d, 0), DEV)
+    inp = synth_inputs.random_context(d, 5, B=2, t_fill=d.T, n_agents=d.A - 1, n_polys=d.P - 1)
+    bins = np.random.RandomState(5).randint(0, d.R, (2, d.A, 3))
+    lib = _lib.lib()
+    a = _run_both_passes(model, d, inp, d.T, bins)
+    try:
+        lib.ctrlsim_set_option(0, 0); lib.ctrlsim_set_option(1, 0)
+        b = _run_both_passes(model, d, inp, d.T, bins)
+    finally:
+        lib.ctrlsim_set_option(0, 1); lib.ctrlsim_set_option(1, 1)
+    for x, y in zip(a, b):
+        np.testing.assert_allclose(x, y, atol=TOL, rtol=0)

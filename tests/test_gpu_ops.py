@@ -62,6 +62,28 @@ def test_gemm_bf16x6_has_fp32_class_accuracy(M, N, K, relu, resid, n0):
     assert e6 < 4e-7 and e6 < 8 * e32 + 1e-9, (e6, e32)
 
 
+@pytest.mark.parametrize("M,K,relu,resid,ldc", [(1003, 256, False, True, 256), (130, 1024, False, True, 256),
+                                                 (517, 512, True, False, 512), (24, 256, True, False, 256)])
+def test_gemm_bf16x6_fused_layernorm(M, K, relu, resid, ldc):
+    """LayerNorm in the GEMM epilogue (in place over the residual when there is one) against torch in float64."""
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    W = torch.randn(256, K, generator=g) * 0.1
+    b = torch.randn(256, generator=g).to(DEV)
+    gam = torch.randn(256, generator=g).to(DEV); bet = torch.randn(256, generator=g).to(DEV)
+    buf = torch.randn(M, ldc, generator=g).to(DEV)
+    R = buf if resid else None
+    before = buf.clone()
+    out = gemm_bf16x6(A, W, b, R, relu, ln=(gam, bet), out=buf)
+    pre = A.double() @ W.to(DEV).double().T + b.double() + (before[:, :256].double() if resid else 0)
+    ref = torch.nn.functional.layer_norm(pre, (256,), gam.double(), bet.double(), 1e-5)
+    if relu:
+        ref = ref.clamp_min(0)
+    assert (out[:, :256].double() - ref).abs().max().item() < 2e-5
+    if ldc > 256:
+        assert torch.equal(out[:, 256:], before[:, 256:])     # columns beyond N untouched
+
+
 def test_layernorm_and_in_place():
     g = torch.Generator().manual_seed(1)
     X = torch.randn(1003, 256, generator=g).to(DEV) * 3 + 1
@@ -137,3 +159,51 @@ def test_attention_key_padding(Lq, Lk, attn_impl):
     vis = (~pad).to(DEV)[:, None, None, :].expand(B, 1, Lq, Lk)
     ref = _attn_ref(q, k, v, vis).transpose(1, 2).reshape(B, Lq, 256)
     assert (O.double() - ref).abs().max().item() < 2e-5
+
+
+def _kv_images(K_ptr, V_ptr, ldkv, kbs, B, rows, nkt, pos=None, img=None):
+    img = torch.full((B * 8 * nkt * 12288,), 0x7FC0, dtype=torch.int16, device=DEV) if img is None else img   # NaN-filled
+    _lib.check(_lib.lib().ctrlsim_kv_split(K_ptr, V_ptr, ldkv, kbs, _lib.ptr(pos), B, rows, nkt, _lib.ptr(img),
+                                           _lib.stream_ptr()), "kv_split")
+    return img
+
+
+@pytest.mark.parametrize("A,T", [(24, 32), (6, 8), (24, 7)])
+def test_attention_presplit_images_match_in_kernel_split(A, T):
+    """K/V split once into bf16 images + DMA staging must give bit-identical output to the in-kernel split, for the
+    full build, for a row-scatter (KV-cache) build, and in both mask modes."""
+    B = 2
+    L = A * T * 3
+    nkt = (L + 63) // 64
+    g = torch.Generator().manual_seed(A + T)
+    qkv = torch.randn(B, L, 768, generator=g).to(DEV)
+    p = _lib.ptr
+    lib, st = _lib.lib(), _lib.stream_ptr()
+    Kp, Vp = qkv.data_ptr() + 1024, qkv.data_ptr() + 2048
+    O0 = torch.zeros(B, L, 256, device=DEV); O1 = torch.zeros_like(O0); O2 = torch.zeros_like(O0)
+    _lib.check(lib.ctrlsim_attention(1, p(qkv), 768, L * 768, Kp, Vp, 768, L * 768, p(O0), 256, L * 256, None, None, B, L, L, A, st))
+    img = _kv_images(Kp, Vp, 768, L * 768, B, L, nkt)
+    _lib.check(lib.ctrlsim_attention_presplit(1, p(qkv), 768, L * 768, p(img), nkt, p(O1), 256, L * 256, None, None, B, L, L, A, st))
+    assert torch.equal(O0, O1)
+    # scatter build: zeroed images, rows written in a shuffled order through the position list
+    perm = torch.randperm(L, generator=g)
+    rows = qkv[:, perm, :].contiguous()
+    img2 = torch.zeros_like(img)
+    pos = perm.to(torch.int32).to(DEV)
+    _kv_images(rows.data_ptr() + 1024, rows.data_ptr() + 2048, 768, L * 768, B, L, nkt, pos=pos, img=img2)
+    _lib.check(lib.ctrlsim_attention_presplit(1, p(qkv), 768, L * 768, p(img2), nkt, p(O2), 256, L * 256, None, None, B, L, L, A, st))
+    assert torch.equal(O0, O2)
+    # key-padding mode over a ragged memory length
+    Lk = 224 if L > 224 else L - 3
+    nk2 = (Lk + 63) // 64
+    KV = torch.randn(B, Lk, 512, generator=g).to(DEV)
+    pad = (torch.rand(B, Lk, generator=g) < 0.3); pad[:, 0] = False
+    pad_d = pad.to(torch.uint8).to(DEV)
+    Q = qkv[..., :256].contiguous()
+    Oa = torch.zeros(B, L, 256, device=DEV); Ob = torch.zeros_like(Oa)
+    _lib.check(lib.ctrlsim_attention(0, p(Q), 256, L * 256, p(KV), KV.data_ptr() + 1024, 512, Lk * 512, p(Oa), 256, L * 256, None,
+                                     p(pad_d), B, L, Lk, A, st))
+    img3 = _kv_images(p(KV), KV.data_ptr() + 1024, 512, Lk * 512, B, Lk, nk2)
+    _lib.check(lib.ctrlsim_attention_presplit(0, p(Q), 256, L * 256, p(img3), nk2, p(Ob), 256, L * 256, None, p(pad_d), B, L, Lk,
+                                              A, st))
+    assert torch.equal(Oa, Ob) and torch.isfinite(Ob).all()
