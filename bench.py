@@ -98,8 +98,9 @@ def main():
         eng.run(R)
     barrier()
     elapsed = time.perf_counter() - t0
-    ms = (C.c_double * 2)(); cnt = (C.c_int64 * 2)(); fl = (C.c_double * 2)()
+    ms = (C.c_double * 2)(); cnt = (C.c_int64 * 2)(); fl = (C.c_double * 2)(); by = (C.c_double * 2)()
     _lib.check(lib.ctrlsim_prof_collect(ms, cnt, fl), "prof_collect")
+    _lib.check(lib.ctrlsim_prof_bytes(by), "prof_bytes")
     lib.ctrlsim_prof_enable(0)
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if dist is not None:
@@ -133,17 +134,30 @@ def main():
         names = ("gemm_nt_bf16x6_kernel (every nn.Linear; split-bf16 MFMA 32x32x16, 6 partial products per fp32 product)",
                  "attention_bf16x6_kernel (all multi-head attention; split-bf16 MFMA flash attention, structured mask)")
 
+        # HBM bytes per launch from the PMC counters: collected offline on this same command (separate --pmc passes,
+        # tools/pmc_traffic.sh) and committed with its calibration under profiles/; None if the summary is absent
+        pmc = {}
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+        keys = ("gemm_nt_bf16x6_kernel", "attention_bf16x6_kernel")
+
         def cls(i):
             a = fl[i] / (ms[i] * 1e-3) / 1e12 if ms[i] > 0 else None
+            n = max(cnt[i], 1)
             return {"kernel": names[i], "achieved": a, "peak": PEAK_FP32_EQUIV_TFLOPS, "unit": "TFLOP/s",
-                    "frac": a / PEAK_FP32_EQUIV_TFLOPS if a else None, "avg_launch_ms": ms[i] / max(cnt[i], 1),
+                    "frac": a / PEAK_FP32_EQUIV_TFLOPS if a else None, "avg_launch_ms": ms[i] / n,
                     "launches": int(cnt[i]), "time_share_of_step": ms[i] * 1e-3 / elapsed,
-                    "mfma_executed_tflops": 6.0 * a if a else None, "mfma_peak_tflops": PEAK_BF16_MFMA_TFLOPS}
-        roof = {"bound": "mfma", **cls(dom), "traffic": None,
+                    "mfma_executed_tflops": 6.0 * a if a else None, "mfma_peak_tflops": PEAK_BF16_MFMA_TFLOPS,
+                    "algorithmic_flops_per_launch": fl[i] / n, "algorithmic_hbm_bytes_per_launch": by[i] / n,
+                    "traffic": pmc.get(keys[i], {}).get("hbm_bytes_per_launch"),
+                    "hbm_rate_at_algorithmic_bytes_TBps": by[i] / (ms[i] * 1e-3) / 1e12 if ms[i] > 0 else None}
+        roof = {"bound": "mfma", **cls(dom),
                 "note": "achieved = algorithmic fp32 FLOPs (2MNK per Linear; 128 per visible (q,k) pair and head) / summed "
                         "HIP-event time of the class; peak = dense bf16 MFMA peak / 6 because each fp32 product costs six "
                         "bf16 MFMA products (bf16x6 split, fp32-class accuracy); the f32-input MFMA path (157.3 TF peak) is "
-                        "selectable with ctrlsim_set_option",
+                        "selectable with ctrlsim_set_option; traffic = HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, PMC, "
+                        "profiles/r01_pmc_traffic.json: measured on this command, averaged over the class's launches)",
                 "other": cls(1 - dom)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

@@ -33,6 +33,7 @@ SIGNATURES = {
     "ctrlsim_set_option": (I, [I, I]),
     "ctrlsim_prof_enable": (None, [I]),
     "ctrlsim_prof_collect": (I, [P, P, P]),
+    "ctrlsim_prof_bytes": (I, [P]),
     "ctrlsim_gemm_nt": (I, [P, I, P, I, P, P, I, P, I, I, I, I, I, P]),
     "ctrlsim_gemm_nt_bf16x6": (I, [P, I, P, I, I, P, P, I, P, I, I, I, I, I, P, P, P]),
     "ctrlsim_layernorm256": (I, [P, I, P, I, P, P, P, I, I, I, P]),

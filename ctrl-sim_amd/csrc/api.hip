@@ -33,7 +33,7 @@ int launch_sample_action(const float*, int, int, const int*, const int*, float, 
 
 #include <vector>
 namespace {
-struct ProfRec { hipEvent_t a, b; int cls; double flops; };
+struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_recs;
 std::vector<hipEvent_t> g_pool;
@@ -48,11 +48,11 @@ void prof_before(int cls, hipStream_t st) {
   g_pending[cls] = take_event();
   hipEventRecord(g_pending[cls], st);
 }
-void prof_after(int cls, double flops, hipStream_t st) {
+void prof_after(int cls, double flops, hipStream_t st, double bytes) {
   if (!g_prof_on) return;
   hipEvent_t b = take_event();
   hipEventRecord(b, st);
-  g_recs.push_back(ProfRec{g_pending[cls], b, cls, flops});
+  g_recs.push_back(ProfRec{g_pending[cls], b, cls, flops, bytes});
 }
 
 static int g_options[OPT_COUNT] = {1, 1, 0};
@@ -80,6 +80,13 @@ int ctrlsim_prof_collect(double* ms, int64_t* count, double* flops) {
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return CTRLSIM_ELAUNCH;
     ms[r.cls] += t; count[r.cls] += 1; flops[r.cls] += r.flops;
   }
+  return CTRLSIM_OK;
+}
+
+// algorithmic HBM bytes of the recorded launches per class (same records as ctrlsim_prof_collect)
+int ctrlsim_prof_bytes(double* bytes) {
+  for (int c = 0; c < PROF_CLASSES; ++c) bytes[c] = 0;
+  for (auto& r : g_recs) bytes[r.cls] += r.bytes;
   return CTRLSIM_OK;
 }
 

@@ -270,6 +270,6 @@ int launch_attention(int mode, const float* Q, int ldq, long q_batch_stride, con
     hipLaunchKernelGGL((attention_f32_kernel<MODE_KEYPAD>), g, blk, 0, st, Q, ldq, q_batch_stride, K, V, ldkv,
                        kv_batch_stride, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale);
   }
-  prof_after(PROF_ATTN, pairs * 128.0 * NHEAD * B, st);
+  prof_after(PROF_ATTN, pairs * 128.0 * NHEAD * B, st, (double)B * (8.0 * DM * Lq + 8.0 * DM * Lk));
   return ctrlsim_launch_status();
 }

@@ -15,7 +15,8 @@
 //                 accumulator-register order.  The MFMA k-slot <-> key map is free as long as both operands agree:
 //                 slot j of lane-half h  <->  key 16*kk + (j&3) + 8*(j>>2) + 4*h, which is exactly the C-fragment row
 //                 map of the S^T tile, so P never moves between lanes.
-// Two accumulator chains (even / odd k-step) per product keep dependent MFMAs apart.
+// One accumulator chain per product: with three waves per SIMD the matrix pipe stays fed across the dependent MFMAs
+// (measured: 1829 vs 1966 TFLOP/s register-only), and the merge adds / second rescale / 32 registers go away.
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -86,8 +87,15 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
   __shared__ int blk_tmax[4];
   static_assert(2 * BUF * 2 >= 4 * 32 * 33 * 4, "output transpose must fit");
 
-  const int qblk = (MODE == MODE6_CAUSAL) ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;
-  const int b = blockIdx.z, h = blockIdx.y, qb = qblk * 128;
+  // XCD-aware work map: workgroups are dealt round-robin to the 8 XCDs (linear id % 8) and each XCD has its own L2, so all
+  // query blocks of one (context, head) — which re-read the same K/V tiles — are given to ONE XCD: head = linear id % 8.
+  // (With the natural x-fastest order the 18 query blocks of a head were spread over all 8 L2s: measured 2.8x the
+  // algorithmic HBM-side fetch traffic.)  Causal: longest query blocks first.
+  const int lin = blockIdx.x + gridDim.x * (blockIdx.y + NHEAD * blockIdx.z);
+  const int h = lin & (NHEAD - 1), j = lin >> 3;
+  const int qx = j % gridDim.x, b = j / gridDim.x;
+  const int qblk = (MODE == MODE6_CAUSAL) ? (gridDim.x - 1 - qx) : qx;
+  const int qb = qblk * 128;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int A3 = 3 * A;
   const float NEG_INF = -__builtin_inff();
@@ -128,17 +136,19 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
       tmin = min(tmin, __shfl_xor(tmin, o, 64));
       tmax = max(tmax, __shfl_xor(tmax, o, 64));
     }
-    tq_min_w = tmin;
-    tq_max_w = tmax;
+    tq_min_w = __builtin_amdgcn_readfirstlane(tmin);       // wave-uniform: keep them (and the branches on them) scalar
+    tq_max_w = __builtin_amdgcn_readfirstlane(tmax);
     if (lane == 0) blk_tmax[wave] = tmax;
     __syncthreads();
     const int bt = max(max(blk_tmax[0], blk_tmax[1]), max(blk_tmax[2], blk_tmax[3]));
-    k_end = min(Lk, (bt + 1) * A3);
+    k_end = __builtin_amdgcn_readfirstlane(min(Lk, (bt + 1) * A3));
   }
 
-  f32x16 oa, ob;                                   // O^T accumulators of the even / odd k-step chains
+  f32x16 oa;                                       // O^T accumulator
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { oa[r] = 0.f; ob[r] = 0.f; }
+  for (int r = 0; r < 16; ++r) oa[r] = 0.f;
+  int tk_t = 0, tk_r = 0;                          // (timestep, offset in it) of the next sub-tile's first key
+  const int t_last = (MODE == MODE6_CAUSAL) ? (Lk - 1) / A3 : 0;
   float m_run = NEG_INF, l_run = 0.f;
 
   const float* Kb = K + (size_t)b * kv_batch_stride + h * HD;
@@ -238,17 +248,21 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       const int ks0 = k0 + sub * 32;
+      // timestep of the first / last key of this sub-tile (tracked incrementally: no divisions in the loop)
+      const int t_lo = tk_t, t_hi = min(tk_t + (tk_r + 31 >= A3 ? (tk_r + 31 - A3 >= A3 ? (tk_r + 31) / A3 : 1) : 0), t_last);
+      const int ks_t0 = ks0 - tk_r;                 // position of the first key of timestep t_lo
+      tk_r += 32;
+      while (tk_r >= A3) { tk_r -= A3; ++tk_t; }
       if (ks0 >= k_end) continue;
       bool need_mask = true;
       if (MODE == MODE6_CAUSAL) {
-        const int t_lo = ks0 / A3, t_hi = min(ks0 + 31, Lk - 1) / A3;
         if (t_lo > tq_max_w) continue;
         need_mask = !(t_hi < tq_min_w && ks0 + 31 < Lk);
       }
-      // ---- S^T = K . Q^T : two chains (d 0-15, d 16-31), six partial products each
-      f32x16 s0, s1;
+      // ---- S^T = K . Q^T : one accumulator chain, k-steps d 0-15 and d 16-31, six partial products each
+      f32x16 s0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+      for (int r = 0; r < 16; ++r) s0[r] = 0.f;
       {
         const __bf16* kr_ = Ks + (half * KT6 + sub * 32 + l31) * 8;
         bf16x8 k0f[3], k1f[3];
@@ -260,7 +274,7 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
 #ifndef ABL_NO_MFMA
 #define QK(PA, PB)                                                                        \
   s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0f[PA], qf[0][PB], s0, 0, 0, 0);           \
-  s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1f[PA], qf[1][PB], s1, 0, 0, 0);
+  s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1f[PA], qf[1][PB], s0, 0, 0, 0);
         QK(2, 0) QK(0, 2) QK(1, 1) QK(1, 0) QK(0, 1) QK(0, 0)
 #undef QK
         TSTAMP(1) TCOUNT(6)
@@ -268,27 +282,32 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
 #pragma unroll
         for (int p = 0; p < 3; ++p) { asm volatile("" ::"v"(k0f[p]), "v"(k1f[p])); }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s0[r] = __builtin_bit_cast(float, (unsigned)(k0f[0][r & 7]) << 16); s1[r] = 0.01f * r; }
+        for (int r = 0; r < 16; ++r) { s0[r] = __builtin_bit_cast(float, (unsigned)(k0f[0][r & 7]) << 16) + 0.01f * r; }
 #endif
       }
       float sc[16];
       if (MODE == MODE6_KEYPAD) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = (s0[r] + s1[r]) + padbias[sub * 32 + mfma_row(r, half)];
+        for (int r = 0; r < 16; ++r) sc[r] = s0[r] + padbias[sub * 32 + mfma_row(r, half)];
       } else if (need_mask) {
+        // visibility of the 32 keys of this sub-tile for this lane's query as a bit mask (bit i <-> key ks0 + i):
+        //   keys of earlier timesteps: all; of the query's timestep: every state token (offset % 3 == 0) and the query's
+        //   own agent's tokens up to the query itself; later timesteps and keys >= Lk: none.
+        asm volatile("" ::: "memory");   // keep this a real (scalar) branch: hipcc otherwise speculates the mask math for every sub-tile
+        auto ones = [](int n) -> unsigned { return n >= 32 ? 0xFFFFFFFFu : (n <= 0 ? 0u : ((1u << n) - 1u)); };
+        const int same0 = tq * A3 - ks0;                                   // first key of the query's timestep
+        const unsigned before = ones(same0);
+        const unsigned same = ones(min(same0 + A3, Lk - ks0)) & ~before;
+        int off3 = (ks_t0 - ks0) % 3;                                      // ks_t0 <= ks0: first state token at or after ks0
+        off3 = off3 < 0 ? off3 + 3 : off3;
+        const unsigned every3 = (unsigned)(0x249249249249ull << off3);
+        const unsigned own = ones(pos - ks0 + 1) & ~ones(pos - kq - ks0);
+        const unsigned vis = (before | ((every3 | own) & same)) >> (4 * half);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int kj = ks0 + mfma_row(r, half);
-          const int tj = kj / A3;
-          const int rem = kj - tj * A3;
-          const int aj = rem / 3;
-          const int kk = rem - aj * 3;
-          const bool vis = (kj < Lk) && ((tj < tq) || (tj == tq && ((aj == aq && kk <= kq) || kk == 0)));
-          sc[r] = vis ? (s0[r] + s1[r]) : NEG_INF;
-        }
+        for (int r = 0; r < 16; ++r) sc[r] = (vis & (1u << ((r & 3) + 8 * (r >> 2)))) ? s0[r] : NEG_INF;
       } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = s0[r] + s1[r];
+        for (int r = 0; r < 16; ++r) sc[r] = s0[r];
       }
       // ---- online softmax
       float tmax = sc[0];
@@ -313,7 +332,7 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
       m_run = m_new;
       if (!__all(alpha == 1.0f)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { oa[r] *= alpha; ob[r] *= alpha; }
+        for (int r = 0; r < 16; ++r) oa[r] *= alpha;
       }
       TSTAMP(2)
       // ---- P^T fragments: k-step kk uses accumulator registers 8*kk .. 8*kk+7 (slot j <-> register 8*kk + j)
@@ -345,7 +364,7 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
 #ifndef ABL_NO_MFMA
 #define PV(PA, PB)                                                                        \
   oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0f[PA], pf[0][PB], oa, 0, 0, 0);           \
-  ob = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1f[PA], pf[1][PB], ob, 0, 0, 0);
+  oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1f[PA], pf[1][PB], oa, 0, 0, 0);
         PV(2, 0) PV(0, 2) PV(1, 1) PV(1, 0) PV(0, 1) PV(0, 0)
 #undef PV
         TSTAMP(3)
@@ -371,7 +390,7 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
   const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
   float* ot = reinterpret_cast<float*>(arena) + wave * (32 * 33);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) ot[l31 * 33 + mfma_row(r, half)] = (oa[r] + ob[r]) * inv;
+  for (int r = 0; r < 16; ++r) ot[l31 * 33 + mfma_row(r, half)] = oa[r] * inv;
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -469,6 +488,30 @@ __global__ __launch_bounds__(256) void kv_split_rows_kernel(const float* __restr
   }
 }
 
+// Zero the keys >= Lk of the last tile of every (context, head): producers that write images row by row (the fused QKV
+// GEMM epilogue) leave that tail untouched, and the attention kernel stages whole tiles.
+__global__ __launch_bounds__(256) void kv_zero_tail_kernel(int Lk, int nkt, __bf16* __restrict__ img) {
+  constexpr int K_PLANE = KT6 * HD, V_PLANE = HD * KT6;
+  const int k0 = Lk - (nkt - 1) * KT6;                       // first invalid key of the last tile (multiple of 4)
+  __bf16* base = img + ((size_t)blockIdx.x * nkt + (nkt - 1)) * KV_IMG;
+  const int nk = KT6 - k0;
+  for (int i = threadIdx.x; i < 12 * nk * 4; i += 256) {     // K: 12 (plane, d>>3) runs of nk keys x 8 bf16 = nk*4 dwords
+    const int run = i / (nk * 4), off = i - run * (nk * 4);
+    reinterpret_cast<unsigned*>(base + run * KT6 * 8 + k0 * 8)[off] = 0u;
+  }
+  const int q0 = k0 >> 2, nq = 16 - q0;
+  for (int i = threadIdx.x; i < 3 * nq * 64; i += 256) {     // V^T: 3 planes, quads >= q0, 32 d x 4 keys = 64 dwords each
+    const int pl = i / (nq * 64), off = i - pl * (nq * 64);
+    reinterpret_cast<unsigned*>(base + 3 * K_PLANE + pl * V_PLANE + q0 * HD * 4)[off] = 0u;
+  }
+}
+int launch_kv_zero_tail(int B, int Lk, int nkt, void* img, hipStream_t st) {
+  if (B <= 0 || Lk % KT6 == 0) return CTRLSIM_OK;
+  if (!img || (Lk & 3) || nkt != (Lk + KT6 - 1) / KT6) return CTRLSIM_EINVAL;
+  hipLaunchKernelGGL(kv_zero_tail_kernel, dim3(B * NHEAD), dim3(256), 0, st, Lk, nkt, static_cast<__bf16*>(img));
+  return ctrlsim_launch_status();
+}
+
 int launch_kv_split(const float* K, const float* V, int ldkv, long kv_batch_stride, int B, int Lk, int nkt, void* img,
                     hipStream_t st) {
   if (B <= 0 || Lk <= 0) return CTRLSIM_OK;
@@ -511,7 +554,8 @@ int launch_attention_bf16x6(int mode, const float* Q, int ldq, long q_batch_stri
     hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, false>), g, blk, 0, st, Q, ldq, q_batch_stride, K, V, ldkv,
                        kv_batch_stride, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale);
   }
-  prof_after(PROF_ATTN, attn_pairs(mode, q_pos, Lq, Lk, A) * 128.0 * NHEAD * B, st);
+  prof_after(PROF_ATTN, attn_pairs(mode, q_pos, Lq, Lk, A) * 128.0 * NHEAD * B, st,
+             (double)B * (8.0 * DM * Lq + 8.0 * DM * Lk));
   return ctrlsim_launch_status();
 }
 
@@ -533,6 +577,7 @@ int launch_attention_bf16x6_pre(int mode, const float* Q, int ldq, long q_batch_
     hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, true>), g, blk, 0, st, Q, ldq, q_batch_stride, imgf, nullptr, 0,
                        (long)nkt, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale);
   }
-  prof_after(PROF_ATTN, attn_pairs(mode, q_pos, Lq, Lk, A) * 128.0 * NHEAD * B, st);
+  prof_after(PROF_ATTN, attn_pairs(mode, q_pos, Lq, Lk, A) * 128.0 * NHEAD * B, st,
+             (double)B * (8.0 * DM * Lq + 12.0 * DM * Lk));
   return ctrlsim_launch_status();
 }

@@ -49,7 +49,7 @@ __device__ __host__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 // launch stream and tagged with its algorithmic FLOPs; nothing synchronises until ctrlsim_prof_collect().
 enum { PROF_GEMM = 0, PROF_ATTN = 1, PROF_CLASSES = 2 };
 void prof_before(int cls, hipStream_t st);
-void prof_after(int cls, double flops, hipStream_t st);
+void prof_after(int cls, double flops, hipStream_t st, double bytes = 0.0);   // bytes = compulsory (algorithmic) HBM traffic
 
 // ---- runtime options (ctrlsim_set_option): which MFMA path the matrix kernels take
 enum { OPT_ATTN_IMPL = 0, OPT_GEMM_IMPL = 1,   // 0 = f32-input MFMA, 1 = split-bf16 (bf16x6) MFMA

@@ -29,6 +29,9 @@ int launch_gemm_nt_bf16x6(const float*, int, const void*, int, int, const float*
                           int, int, const float*, const float*, hipStream_t);
 int launch_layernorm256(const float*, int, const float*, int, const float*, const float*, float*, int, int, int,
                         hipStream_t);
+int launch_gemm_nt_bf16x6_kv(const float*, int, const void*, int, int, const float*, const float*, int, float*, int, int, int,
+                             int, int, const float*, const float*, void*, int, int, int, hipStream_t);
+int launch_kv_zero_tail(int, int, int, void*, hipStream_t);
 int launch_kv_split(const float*, const float*, int, long, int, int, int, void*, hipStream_t);
 int launch_kv_split_rows(const float*, const float*, int, long, const int*, int, int, int, void*, hipStream_t);
 int launch_attention_bf16x6_pre(int, const float*, int, long, const void*, int, float*, int, long, const int*,
@@ -263,6 +266,20 @@ int attention_kv(int mode, const float* Q, int ldq, long qbs, const float* K, co
 int kv_split(const float* K, const float* V, int ldkv, long kbs, int B, int Lk, int nkt, void* img, hipStream_t st) {
   return presplit() ? launch_kv_split(K, V, ldkv, kbs, B, Lk, nkt, img, st) : 0;
 }
+// Linear whose last 512 output columns are attention keys / values of B contexts x Lk rows: y[:, :kcol0] as fp32 rows,
+// K / V as split images straight from the GEMM epilogue when both bf16x6 kernels are selected (the fp32 K / V columns
+// of y are then NOT written); otherwise GEMM + kv_split.
+int gemm_kv(const Lin& L, const float* x, int ldx, float* y, int ldy, int B, int Lk, int n, int k, int kcol0, void* img, int nkt,
+            hipStream_t st) {
+  const int rows = B * Lk;
+  if (presplit() && L.w3 && k % 16 == 0 && ctrlsim_option(OPT_GEMM_IMPL) == 1 && !(Lk & 3) && Lk >= 32) {
+    CHK(launch_kv_zero_tail(B, Lk, nkt, img, st));
+    return launch_gemm_nt_bf16x6_kv(x, ldx, L.w3, L.ntot ? L.ntot : n, L.n0, L.b, nullptr, 0, y, ldy, rows, n, k, 0, nullptr,
+                                    nullptr, img, Lk, nkt, kcol0, st);
+  }
+  CHK(gemm(L, x, ldx, nullptr, 0, y, ldy, rows, n, k, 0, st));
+  return kv_split(y + kcol0, y + kcol0 + DM, ldy, (long)Lk * ldy, B, Lk, nkt, img, st);
+}
 int kv_split_rows(const float* K, const float* V, int ldkv, long kbs, const int* pos, int B, int R, int nkt, void* img,
                   hipStream_t st) {
   return presplit() ? launch_kv_split_rows(K, V, ldkv, kbs, pos, B, R, nkt, img, st) : 0;
@@ -328,8 +345,7 @@ int scene_side(const ctrlsim_model* m, const Ws& w, const ctrlsim_ctx* c, int B,
   // ---- scene encoder (encoder.py:155-168): post-LN layers over [polylines || initial states] with key padding
   for (int i = 0; i < d.NE; ++i) {
     const EncLayer& Le = m->enc[i];
-    CHK(gemm(Le.qkv, w.src, DM, nullptr, 0, w.eqkv, 3 * DM, rM, 3 * DM, DM, 0, st));
-    CHK(kv_split(w.eqkv + DM, w.eqkv + 2 * DM, 3 * DM, (long)M * 3 * DM, B, M, w.nkt_mem, w.img_enc, st));
+    CHK(gemm_kv(Le.qkv, w.src, DM, w.eqkv, 3 * DM, B, M, 3 * DM, DM, DM, w.img_enc, w.nkt_mem, st));
     CHK(attention_kv(0, w.eqkv, 3 * DM, (long)M * 3 * DM, w.eqkv + DM, w.eqkv + 2 * DM, 3 * DM, (long)M * 3 * DM, w.img_enc,
                      w.nkt_mem, w.eatt, DM, (long)M * DM, nullptr, w.src_pad, B, M, M, A, st));
     CHK(gemm_ln(Le.out, Le.n1, w.eatt, DM, w.src, DM, w.src, DM, w.etmp, rM, DM, 0, st));
@@ -338,8 +354,7 @@ int scene_side(const ctrlsim_model* m, const Ws& w, const ctrlsim_ctx* c, int B,
   }
   // memory K/V of every decoder layer (cached for pass 2)
   for (int i = 0; i < d.ND; ++i) {
-    CHK(gemm(m->dec[i].ckv, w.src, DM, nullptr, 0, w.memkv[i], 2 * DM, rM, 2 * DM, DM, 0, st));
-    CHK(kv_split(w.memkv[i], w.memkv[i] + DM, 2 * DM, (long)M * 2 * DM, B, M, w.nkt_mem, w.img_mem[i], st));
+    CHK(gemm_kv(m->dec[i].ckv, w.src, DM, w.memkv[i], 2 * DM, B, M, 2 * DM, DM, 0, w.img_mem[i], w.nkt_mem, st));
   }
   return 0;
 }
@@ -374,8 +389,7 @@ extern "C" int ctrlsim_dt_forward_pass1(const ctrlsim_model* m, int B, int Tq, c
   // ---- decoder (decoder.py:52): layers 0..ND-2 on all L tokens
   for (int i = 0; i < d.ND; ++i) {
     const DecLayer& Ld = m->dec[i];
-    CHK(gemm(Ld.qkv, w.X, DM, nullptr, 0, w.qkv[i], 3 * DM, rL, 3 * DM, DM, 0, st));
-    CHK(kv_split(w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM, B, L, w.nkt_dec, w.img_dec[i], st));
+    CHK(gemm_kv(Ld.qkv, w.X, DM, w.qkv[i], 3 * DM, B, L, 3 * DM, DM, DM, w.img_dec[i], w.nkt_dec, st));
     if (i < d.ND - 1) {
       CHK(attention_kv(1, w.qkv[i], 3 * DM, (long)L * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
                        w.img_dec[i], w.nkt_dec, w.att, DM, (long)L * DM, nullptr, nullptr, B, L, L, A, st));

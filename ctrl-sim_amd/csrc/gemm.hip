@@ -275,7 +275,8 @@ int launch_gemm_nt(const float* A, int lda, const float* W, int ldw, const float
     hipLaunchKernelGGL((gemm_nt_f32_kernel<GEMM_TBK, false, false>), g, b, 0, st, A, lda, W, ldw, bias, R, ldr, C, ldc, M, N,
                        K, m_tiles, n_tiles);
   }
-  prof_after(PROF_GEMM, 2.0 * (double)M * (double)N * (double)K, st);
+  prof_after(PROF_GEMM, 2.0 * (double)M * (double)N * (double)K, st,
+             4.0 * ((double)M * K + (double)M * N * (R ? 2.0 : 1.0) + (double)N * K));
   return ctrlsim_launch_status();
 }
 

@@ -52,31 +52,38 @@ __device__ __forceinline__ void split3(const f32x4 x, u32x2& hi, u32x2& mid, u32
   hi = u32x2{h0, h1}; mid = u32x2{m0, m1}; lo = u32x2{l0, l1};
 }
 
-template <int PA, int PB>
-__device__ __forceinline__ void term(f32x16 (&acc)[2][2], const bf16x8 (&fa)[2][3], const bf16x8 (&fb)[2][3]) {
+template <int PA, int PB, int MR>
+__device__ __forceinline__ void term(f32x16 (&acc)[MR][2], const bf16x8 (&fa)[MR][3], const bf16x8 (&fb)[2][3]) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < MR; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
       acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA], fb[b][PB], acc[a][b], 0, 0, 0);
 }
 
-template <int WR, int WC, bool RELU, bool RESID, bool LN>
-__global__ __launch_bounds__(256, (WR == 2 && WC == 2) ? 3 : 2) void gemm_nt_bf16x6_kernel(
+// KVIMG = true (2x2 tiles, plain Linear): output columns >= kv.k_col0 are attention keys (256 columns) and values (the
+// next 256) and are written NOT as fp32 rows but directly as the split-bf16 K / V^T tile images the attention kernel
+// stages by DMA (attention_bf16x6.hip: layout at kv_split_kernel) — the K/V split costs no extra pass over HBM.
+struct KvImg { __bf16* img; int L; int nkt; int k_col0; };   // L = rows (keys) per context
+
+template <int WR, int WC, int MR, bool RELU, bool RESID, bool LN, bool KVIMG = false>
+__global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? 3 : 2)) void gemm_nt_bf16x6_kernel(
     const float* __restrict__ A, int lda, const __bf16* __restrict__ W3,   // [K/16][3][2][n_total][8]
     const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ R, int ldr, float* __restrict__ C, int ldc, int M, int N, int K, int m_tiles, int n_tiles,
-    int n_total, int n0) {
+    int n_total, int n0, KvImg kv) {
   // W3 holds all n_total rows of the packed matrix; this GEMM uses rows [n0, n0 + N) (e.g. the q / kv halves of an
   // in_proj_weight)
-  constexpr int XM = 64 * WR, XN = 64 * WC;
+  constexpr int WMR = 32 * MR;                     // rows of a wave tile (MR x 2 MFMA tiles of 32 x 32)
+  constexpr int XM = WMR * WR, XN = 64 * WC;
   constexpr int A_PLANE = XM * XK;                 // bf16 elements of one plane of one k-step
   constexpr int W_PLANE = XN * XK;
   constexpr int STAGE = 3 * A_PLANE + 3 * W_PLANE; // one k-step: 24 KB (2x2) / 30 KB (1x4)
   constexpr int CP = XN + 4, CR = 32 * WR;         // epilogue chunk: CR rows x XN columns of fp32
-  constexpr int NA = XM / 64;                      // f32x4 loads of A per thread and stage
+  constexpr int NA = (XM + 63) / 64;               // f32x4 loads of A per thread and stage
   constexpr int NW = 6 * XN / 256;                 // 16-byte DMA chunks of W per thread and stage
   static_assert(!LN || (WR == 1 && WC == 4), "LayerNorm epilogue needs whole 256-wide rows");
+  static_assert(XM % 64 == 0, "A staging assumes whole 64-row groups");
   static_assert(2 * STAGE * 2 >= CR * CP * 4, "epilogue staging must fit");
   extern __shared__ __attribute__((aligned(16))) __bf16 lds[];   // 2 * STAGE bf16
 
@@ -146,9 +153,9 @@ __global__ __launch_bounds__(256, (WR == 2 && WC == 2) ? 3 : 2) void gemm_nt_bf1
   if (id >= total_ids) return;
   gload_a(0);
   for (;;) {
-    f32x16 acc[2][2];
+    f32x16 acc[MR][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MR; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -166,14 +173,14 @@ __global__ __launch_bounds__(256, (WR == 2 && WC == 2) ? 3 : 2) void gemm_nt_bf1
         gload_a(kt + 1);
       }
       {
-        const __bf16* Ab = lds + cur * STAGE + half * (A_PLANE / 2) + (wr * 64 + l31) * 8;
+        const __bf16* Ab = lds + cur * STAGE + half * (A_PLANE / 2) + (wr * WMR + l31) * 8;
         const __bf16* Wb = lds + cur * STAGE + 3 * A_PLANE + half * (W_PLANE / 2) + (wc * 64 + l31) * 8;
-        bf16x8 fa[2][3], fb[2][3];
+        bf16x8 fa[MR][3], fb[2][3];
 #ifndef ABL_NO_FRAG
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
-          for (int a = 0; a < 2; ++a) fa[a][p] = *reinterpret_cast<const bf16x8*>(Ab + p * A_PLANE + a * 32 * 8);
+          for (int a = 0; a < MR; ++a) fa[a][p] = *reinterpret_cast<const bf16x8*>(Ab + p * A_PLANE + a * 32 * 8);
 #pragma unroll
           for (int b = 0; b < 2; ++b) fb[b][p] = *reinterpret_cast<const bf16x8*>(Wb + p * W_PLANE + b * 32 * 8);
         }
@@ -181,23 +188,28 @@ __global__ __launch_bounds__(256, (WR == 2 && WC == 2) ? 3 : 2) void gemm_nt_bf1
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
-          for (int a = 0; a < 2; ++a) { fa[a][p] = bf16x8{}; fb[a][p] = bf16x8{}; asm volatile("" : "+v"(fa[a][p]), "+v"(fb[a][p])); }
+          for (int a = 0; a < 2; ++a) { fa[a % MR][p] = bf16x8{}; fb[a][p] = bf16x8{}; asm volatile("" : "+v"(fa[a % MR][p]), "+v"(fb[a][p])); }
         }
 #endif
         // six partial products, smallest first; term-major order keeps 4 independent accumulators between reuses
 #ifndef ABL_NO_MFMA
-        term<2, 0>(acc, fa, fb);
-        term<0, 2>(acc, fa, fb);
-        term<1, 1>(acc, fa, fb);
-        term<1, 0>(acc, fa, fb);
-        term<0, 1>(acc, fa, fb);
-        term<0, 0>(acc, fa, fb);
+        term<2, 0, MR>(acc, fa, fb);
+        term<0, 2, MR>(acc, fa, fb);
+        term<1, 1, MR>(acc, fa, fb);
+#ifdef GEMM6_EARLY_STORE
+        if (kt + 1 < nk) sstore_a(cur ^ 1);        // the A slab issued at the top of this k-step: split + LDS write between MFMAs
+#endif
+        term<1, 0, MR>(acc, fa, fb);
+        term<0, 1, MR>(acc, fa, fb);
+        term<0, 0, MR>(acc, fa, fb);
 #else
 #pragma unroll
-        for (int p = 0; p < 3; ++p) { asm volatile("" ::"v"(fa[0][p]), "v"(fa[1][p]), "v"(fb[0][p]), "v"(fb[1][p])); }
+        for (int p = 0; p < 3; ++p) { asm volatile("" ::"v"(fa[0][p]), "v"(fa[MR - 1][p]), "v"(fb[0][p]), "v"(fb[1][p])); }
 #endif
       }
+#ifndef GEMM6_EARLY_STORE
       if (kt + 1 < nk) sstore_a(cur ^ 1);
+#endif
       __syncthreads();
     }
 
@@ -211,24 +223,81 @@ __global__ __launch_bounds__(256, (WR == 2 && WC == 2) ? 3 : 2) void gemm_nt_bf1
     if (have_next) gload_a(0);
 #ifdef ABL_NO_EPI
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MR; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) asm volatile("" ::"v"(acc[a][b]));
     if (tid == 0 && M < 0) C[0] = Cs[0];
 #else
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+    for (int a = 0; a < MR; ++a) {
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           Cs[(wr * 32 + mfma_row(r, half)) * CP + wc * 64 + b * 32 + l31] = acc[a][b][r];
       __syncthreads();
+      if (KVIMG && cbn >= kv.k_col0) {
+        // ---- this tile is 4 heads of K or of V: emit the images.  Chunk rows lr = s*32 + j <-> global row
+        // cbm + s*64 + a*32 + j (two 32-row segments); key position = row % L, context = row / L.
+        constexpr int KIMG = 2 * 3 * 64 * HD, KPL = 64 * HD;      // image / plane sizes in bf16 elements
+        const int rel = cbn - kv.k_col0;
+        const bool isV = rel >= DM;
+        const int head0 = (rel & (DM - 1)) >> 5;
+        if (!isV) {
+          const int lr = tid & 63;
+          const int grow = cbm + (lr >> 5) * WMR + a * 32 + (lr & 31);
+          if (grow < M) {
+            const int b = grow / kv.L, pos = grow - b * kv.L, kt = pos >> 6, key = pos & 63;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int c = (tid >> 6) + 4 * i, hh = c >> 2, dg = c & 3;     // 8 dims [8c, 8c+8) of the tile's 128 columns
+              f32x4 x0 = *reinterpret_cast<const f32x4*>(Cs + lr * CP + c * 8);
+              f32x4 x1 = *reinterpret_cast<const f32x4*>(Cs + lr * CP + c * 8 + 4);
+              if (bias) {
+                x0 += *reinterpret_cast<const f32x4*>(bias + cbn + c * 8);
+                x1 += *reinterpret_cast<const f32x4*>(bias + cbn + c * 8 + 4);
+              }
+              u32x4 ph, pm, pl;
+              unsigned h_, m_, l_;
+              split3_pair(x0[0], x0[1], h_, m_, l_); ph[0] = h_; pm[0] = m_; pl[0] = l_;
+              split3_pair(x0[2], x0[3], h_, m_, l_); ph[1] = h_; pm[1] = m_; pl[1] = l_;
+              split3_pair(x1[0], x1[1], h_, m_, l_); ph[2] = h_; pm[2] = m_; pl[2] = l_;
+              split3_pair(x1[2], x1[3], h_, m_, l_); ph[3] = h_; pm[3] = m_; pl[3] = l_;
+              __bf16* dst = kv.img + (((size_t)b * NHEAD + head0 + hh) * kv.nkt + kt) * KIMG + (dg * 64 + key) * 8;
+              *reinterpret_cast<u32x4*>(dst + 0 * KPL) = ph;
+              *reinterpret_cast<u32x4*>(dst + 1 * KPL) = pm;
+              *reinterpret_cast<u32x4*>(dst + 2 * KPL) = pl;
+            }
+          }
+        } else {
+          const int col = tid & 127, hh = col >> 5, d = col & 31;
+          const float bv = bias ? bias[cbn + col] : 0.f;
+#pragma unroll
+          for (int i = 0; i < CR / 8; ++i) {
+            const int lr0 = ((tid >> 7) + 2 * i) * 4;                      // a key quad: 4 consecutive rows of one segment
+            const int grow0 = cbm + (lr0 >> 5) * WMR + a * 32 + (lr0 & 31);
+            if (grow0 < M) {                                               // L % 4 == 0: quads never straddle contexts
+              const int b = grow0 / kv.L, pos = grow0 - b * kv.L, kt = pos >> 6, q = (pos & 63) >> 2;
+              const float x0 = Cs[(lr0 + 0) * CP + col] + bv, x1 = Cs[(lr0 + 1) * CP + col] + bv;
+              const float x2 = Cs[(lr0 + 2) * CP + col] + bv, x3 = Cs[(lr0 + 3) * CP + col] + bv;
+              unsigned h0, m0, l0, h1, m1, l1;
+              split3_pair(x0, x1, h0, m0, l0);
+              split3_pair(x2, x3, h1, m1, l1);
+              __bf16* dst = kv.img + (((size_t)b * NHEAD + head0 + hh) * kv.nkt + kt) * KIMG + 3 * KPL + (q * HD + d) * 4;
+              *reinterpret_cast<u32x2*>(dst + 0 * KPL) = u32x2{h0, h1};
+              *reinterpret_cast<u32x2*>(dst + 1 * KPL) = u32x2{m0, m1};
+              *reinterpret_cast<u32x2*>(dst + 2 * KPL) = u32x2{l0, l1};
+            }
+          }
+        }
+        __syncthreads();
+        continue;
+      }
       constexpr int LPR = XN / 4;                  // lanes per row (f32x4 each): 32 (2x2) or 64 = one wave (1x4)
 #pragma unroll 4
       for (int i = 0; i < CR * LPR / 256; ++i) {
         const int idx = tid + 256 * i, lr = idx / LPR, col = (idx % LPR) * 4;
-        const int grow = cbm + (lr >> 5) * 64 + a * 32 + (lr & 31), gcol = cbn + col;
+        const int grow = cbm + (lr >> 5) * WMR + a * 32 + (lr & 31), gcol = cbn + col;
         if (LN) {
           // one wave = one full 256-wide row (lane -> 4 consecutive columns); rows beyond M are skipped wave-uniformly
           if (grow >= M) continue;
@@ -277,51 +346,82 @@ __global__ __launch_bounds__(256, (WR == 2 && WC == 2) ? 3 : 2) void gemm_nt_bf1
   }
 }
 
+int launch_gemm_nt_bf16x6_kv(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias,
+                             const float* R, int ldr, float* C, int ldc, int M, int N, int K, int relu,
+                             const float* ln_gamma, const float* ln_beta, void* kv_img, int kv_L, int kv_nkt, int kv_col0,
+                             hipStream_t st);
 int launch_gemm_nt_bf16x6(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias,
                           const float* R, int ldr, float* C, int ldc, int M, int N, int K, int relu,
                           const float* ln_gamma, const float* ln_beta, hipStream_t st) {
+  return launch_gemm_nt_bf16x6_kv(A, lda, W3, n_total, n0, bias, R, ldr, C, ldc, M, N, K, relu, ln_gamma, ln_beta, nullptr, 0, 0,
+                                  0, st);
+}
+// kv_img != NULL: columns [kv_col0, kv_col0 + 512) are keys / values of 8 heads x 32 and go to the split images of
+// kv_nkt 64-key tiles per context of kv_L rows (kv_L % 4 == 0, kv_L >= 32, kv_col0 % 128 == 0, M % kv_L == 0)
+int launch_gemm_nt_bf16x6_kv(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias,
+                             const float* R, int ldr, float* C, int ldc, int M, int N, int K, int relu,
+                             const float* ln_gamma, const float* ln_beta, void* kv_img, int kv_L, int kv_nkt, int kv_col0,
+                             hipStream_t st) {
   if (M <= 0) return CTRLSIM_OK;
+  if (kv_img && (ln_gamma || R || relu || (kv_L & 3) || kv_L < 32 || (kv_col0 & 127) || N != kv_col0 + 2 * DM || M % kv_L ||
+                 kv_nkt * 64 < kv_L))
+    return CTRLSIM_EINVAL;
+  const KvImg kv{static_cast<__bf16*>(kv_img), kv_L, kv_nkt, kv_col0};
   if (K % XK != 0 || (lda & 3) || N <= 0 || !W3 || n0 < 0 || n0 + N > n_total) return CTRLSIM_EINVAL;
   const bool ln = ln_gamma != nullptr;
   if (ln && (N != 256 || (ldc & 3) || (R && (ldr & 3)))) return CTRLSIM_EINVAL;
   if (!ln && R && relu) return CTRLSIM_EINVAL;
   const int tile_opt = ctrlsim_option(OPT_GEMM6_TILE);          // 0 = auto, 1 = 128x128, 2 = 64x256 (A/B knob)
-  const bool wide = ln || tile_opt == 2 || (tile_opt == 0 && false);
-  const int XM = wide ? 64 : 128, XN = wide ? 256 : 128;
+  const bool wide = !kv_img && (ln || tile_opt == 2);
+  const bool small = !wide && tile_opt == 3;                     // 64x128 tiles (wave tile 32x64), 4 workgroups per CU
+  const int XM = (wide || small) ? 64 : 128, XN = wide ? 256 : 128;
   const int m_tiles = (M + XM - 1) / XM, n_tiles = (N + XN - 1) / XN;
   const int total = ((m_tiles + 7) / 8) * 8 * n_tiles;
-  const int resident = 256 * (wide ? 2 : 3);
+  const int resident = 256 * (wide ? 2 : (small ? 4 : 3));
   const int grid = total < resident ? total : resident;
   dim3 g(grid), b(256);
   const __bf16* w = static_cast<const __bf16*>(W3);
   const size_t shm = (size_t)2 * 3 * (XM + XN) * XK * sizeof(__bf16);   // 48 KB / 60 KB
-#define GEMM6_LAUNCH(WR_, WC_, RELU_, RESID_, LN_)                                                                    \
+#define GEMM6_LAUNCH(WR_, WC_, RELU_, RESID_, LN_, KV_) GEMM6_LAUNCH_(WR_, WC_, 2, RELU_, RESID_, LN_, KV_)
+#define GEMM6_LAUNCH_(WR_, WC_, MR_, RELU_, RESID_, LN_, KV_)                                                               \
   do {                                                                                                                \
     static bool attr = false;                                                                                         \
     if (!attr) {                                                                                                      \
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16x6_kernel<WR_, WC_, RELU_, RESID_, LN_>),        \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16x6_kernel<WR_, WC_, MR_, RELU_, RESID_, LN_, KV_>),   \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                                      \
       attr = true;                                                                                                    \
     }                                                                                                                 \
-    hipLaunchKernelGGL((gemm_nt_bf16x6_kernel<WR_, WC_, RELU_, RESID_, LN_>), g, b, shm, st, A, lda, w, bias,         \
-                       ln_gamma, ln_beta, R, ldr, C, ldc, M, N, K, m_tiles, n_tiles, n_total, n0);                    \
+    hipLaunchKernelGGL((gemm_nt_bf16x6_kernel<WR_, WC_, MR_, RELU_, RESID_, LN_, KV_>), g, b, shm, st, A, lda, w, bias,    \
+                       ln_gamma, ln_beta, R, ldr, C, ldc, M, N, K, m_tiles, n_tiles, n_total, n0, kv);                \
   } while (0)
   prof_before(PROF_GEMM, st);
-  if (ln) {
-    if (R && relu) GEMM6_LAUNCH(1, 4, true, true, true);
-    else if (R) GEMM6_LAUNCH(1, 4, false, true, true);
-    else if (relu) GEMM6_LAUNCH(1, 4, true, false, true);
-    else GEMM6_LAUNCH(1, 4, false, false, true);
+  if (kv_img) {
+    if (small) GEMM6_LAUNCH_(2, 2, 1, false, false, false, true);
+    else GEMM6_LAUNCH(2, 2, false, false, false, true);
+  } else if (small) {
+    if (R) GEMM6_LAUNCH_(2, 2, 1, false, true, false, false);
+    else if (relu) GEMM6_LAUNCH_(2, 2, 1, true, false, false, false);
+    else GEMM6_LAUNCH_(2, 2, 1, false, false, false, false);
+  } else if (ln) {
+    if (R && relu) GEMM6_LAUNCH(1, 4, true, true, true, false);
+    else if (R) GEMM6_LAUNCH(1, 4, false, true, true, false);
+    else if (relu) GEMM6_LAUNCH(1, 4, true, false, true, false);
+    else GEMM6_LAUNCH(1, 4, false, false, true, false);
   } else if (wide) {
-    if (R) GEMM6_LAUNCH(1, 4, false, true, false);
-    else if (relu) GEMM6_LAUNCH(1, 4, true, false, false);
-    else GEMM6_LAUNCH(1, 4, false, false, false);
+    if (R) GEMM6_LAUNCH(1, 4, false, true, false, false);
+    else if (relu) GEMM6_LAUNCH(1, 4, true, false, false, false);
+    else GEMM6_LAUNCH(1, 4, false, false, false, false);
   } else {
-    if (R) GEMM6_LAUNCH(2, 2, false, true, false);
-    else if (relu) GEMM6_LAUNCH(2, 2, true, false, false);
-    else GEMM6_LAUNCH(2, 2, false, false, false);
+    if (R) GEMM6_LAUNCH(2, 2, false, true, false, false);
+    else if (relu) GEMM6_LAUNCH(2, 2, true, false, false, false);
+    else GEMM6_LAUNCH(2, 2, false, false, false, false);
   }
 #undef GEMM6_LAUNCH
-  prof_after(PROF_GEMM, 2.0 * (double)M * (double)N * (double)K, st);
+#undef GEMM6_LAUNCH_
+  {
+    const double MN = (double)M * N, kvN = kv_img ? 2.0 * DM : 0.0;
+    const double out_bytes = 4.0 * (double)M * (N - kvN) + 6.0 * (double)M * kvN;       // K / V columns leave as 3 bf16 planes
+    prof_after(PROF_GEMM, 2.0 * MN * (double)K, st, 4.0 * (double)M * K + out_bytes + (R ? 4.0 * MN : 0.0) + 6.0 * (double)N * K);
+  }
   return ctrlsim_launch_status();
 }

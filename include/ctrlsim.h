@@ -157,6 +157,7 @@ int ctrlsim_attention_presplit(int mode, const float* Q, int ldq, int64_t q_batc
  * summed milliseconds, the launch count and the algorithmic FLOPs (2*M*N*K; 128 per visible (query,key) pair and head). */
 void ctrlsim_prof_enable(int on);
 int ctrlsim_prof_collect(double* ms2, int64_t* count2, double* flops2);
+int ctrlsim_prof_bytes(double* bytes2);   /* compulsory HBM bytes (operands read once + results written once) of the same launches */
 
 /* Runtime options: key 0 = attention path, key 1 = GEMM path of the forward; value 0 = f32-input MFMA
  * (v_mfma_f32_32x32x2_f32), 1 = split-bf16 "bf16x6" MFMA with fp32-class accuracy (default). */
