@@ -45,13 +45,29 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned& hi, unsi
   const float sa = ra - __uint_as_float(mid << 16), sb = rb - __uint_as_float(mid & 0xFFFF0000u);
   lo = cvt_pk_bf16(sa, sb);
 }
+// same split with the residual arithmetic on the packed-f32 VALU (v_pk_add_f32: both values of the pair per instruction)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3_pair_pk(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = cvt_pk_bf16(a, b);
+  const f32x2 x = {a, b};
+  const f32x2 h = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xFFFF0000u)};
+  const f32x2 r = x - h;
+  mid = cvt_pk_bf16(r[0], r[1]);
+  const f32x2 m = {__uint_as_float(mid << 16), __uint_as_float(mid & 0xFFFF0000u)};
+  const f32x2 t = r - m;
+  lo = cvt_pk_bf16(t[0], t[1]);
+}
 // eight consecutive fp32 values -> three bf16x8 fragments
 __device__ __forceinline__ void split3_frag(const float* x, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
   u32x4 h, m, l;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     unsigned a, b, c;
+#ifdef ATT_PK_SPLIT
+    split3_pair_pk(x[2 * i], x[2 * i + 1], a, b, c);
+#else
     split3_pair(x[2 * i], x[2 * i + 1], a, b, c);
+#endif
     h[i] = a; m[i] = b; l[i] = c;
   }
   hi = __builtin_bit_cast(bf16x8, h);
@@ -260,9 +276,12 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
         need_mask = !(t_hi < tq_min_w && ks0 + 31 < Lk);
       }
       // ---- S^T = K . Q^T : one accumulator chain, k-steps d 0-15 and d 16-31, six partial products each
+      // the accumulator starts at -m_base (the running maximum, 0 before the first visible key): the MFMA chain then
+      // delivers S - m directly and the per-element subtraction is needed only in the (rare) sub-tiles that raise the maximum
+      const float m_base = (m_run == NEG_INF) ? 0.f : m_run;
       f32x16 s0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s0[r] = 0.f;
+      for (int r = 0; r < 16; ++r) s0[r] = -m_base;
       {
         const __bf16* kr_ = Ks + (half * KT6 + sub * 32 + l31) * 8;
         bf16x8 k0f[3], k1f[3];
@@ -309,28 +328,40 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = s0[r];
       }
-      // ---- online softmax
+      // ---- online softmax (scores are relative to m_base)
       float tmax = sc[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sc[r]);
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float m_new = fmaxf(m_run, tmax);
-      const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-      float psum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-#ifndef ABL_NO_EXP
-        sc[r] = __builtin_amdgcn_exp2f(sc[r] - m_use);
-#else
-        sc[r] = sc[r] - m_use;
-#endif
-        psum += sc[r];
+      {  // the other 16 keys of this query live in lane ^ 32: one v_permlane32_swap instead of an LDS bpermute round trip
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        tmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
       }
-      psum += __shfl_xor(psum, 32, 64);
-      l_run = l_run * alpha + psum;
-      m_run = m_new;
-      if (!__all(alpha == 1.0f)) {
+      const float m_rel_old = m_run - m_base;                       // 0, or -inf before the first visible key
+      const float m_rel_new = fmaxf(m_rel_old, tmax);
+      const float shift = (m_rel_new == NEG_INF) ? 0.f : m_rel_new;
+      float psum = 0.f;
+      if (__all(shift == 0.f)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#ifndef ABL_NO_EXP
+          sc[r] = __builtin_amdgcn_exp2f(sc[r]);
+#endif
+          psum += sc[r];
+        }
+        l_run += psum;
+      } else {
+        const float alpha = __builtin_amdgcn_exp2f(m_rel_old - shift);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#ifndef ABL_NO_EXP
+          sc[r] = __builtin_amdgcn_exp2f(sc[r] - shift);
+#else
+          sc[r] = sc[r] - shift;
+#endif
+          psum += sc[r];
+        }
+        l_run = l_run * alpha + psum;                                // per-lane partial (own 16 keys); halves are added at the end
+        m_run = (m_rel_new == NEG_INF) ? NEG_INF : m_base + shift;
 #pragma unroll
         for (int r = 0; r < 16; ++r) oa[r] *= alpha;
       }
@@ -387,6 +418,10 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
 #endif
 
   // ---- normalise, transpose through LDS, store rows
+  {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+    l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
   const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
   float* ot = reinterpret_cast<float*>(arena) + wave * (32 * 33);
 #pragma unroll

@@ -21,15 +21,30 @@ static inline int ctrlsim_launch_status() {
   return e == hipSuccess ? CTRLSIM_OK : CTRLSIM_ELAUNCH;
 }
 
+// Wave-wide (64-lane) reductions on the DPP cross-lane path: four row-local steps (quad_perm xor 1 / xor 2,
+// row_half_mirror, row_mirror: every lane then holds its 16-lane row total) and one combine of the four row totals
+// through v_readlane.  hipcc lowers __shfl_xor to ds_bpermute_b32 — an LDS round trip per step, 6 dependent ones per
+// reduction — which made the LayerNorm epilogue of the GEMM as long as its k-loop.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_f32(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_f32<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141>(v);   // row_half_mirror
+  v += dpp_f32<0x140>(v);   // row_mirror
+  return (lane_f32(v, 0) + lane_f32(v, 16)) + (lane_f32(v, 32) + lane_f32(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_f32<0xB1>(v));
+  v = fmaxf(v, dpp_f32<0x4E>(v));
+  v = fmaxf(v, dpp_f32<0x141>(v));
+  v = fmaxf(v, dpp_f32<0x140>(v));
+  return fmaxf(fmaxf(lane_f32(v, 0), lane_f32(v, 16)), fmaxf(lane_f32(v, 32), lane_f32(v, 48)));
 }
 
 // C/D fragment of mfma_f32_32x32x2f32: lane l, register r -> (row, col)
