@@ -14,6 +14,8 @@ int launch_kv_split(const float*, const float*, int, long, int, int, int, void*,
 int launch_kv_split_rows(const float*, const float*, int, long, const int*, int, int, int, void*, hipStream_t);
 int launch_attention_bf16x6_pre(int, const float*, int, long, const void*, int, float*, int, long, const int*,
                                 const unsigned char*, int, int, int, int, hipStream_t);
+int launch_ffn_fused_bf16x6(const float*, int, const void*, const float*, const void*, const float*, const float*, const float*,
+                            float*, int, int, int, hipStream_t);
 int launch_sim_init(int, int, int, const float*, const float*, const float*, const unsigned char*, float*, float*,
                     unsigned char*, int, hipStream_t);
 int launch_sim_step(int, int, int, const int*, const double*, const double*, const float*, const float*,
@@ -55,7 +57,7 @@ void prof_after(int cls, double flops, hipStream_t st, double bytes) {
   g_recs.push_back(ProfRec{g_pending[cls], b, cls, flops, bytes});
 }
 
-static int g_options[OPT_COUNT] = {1, 1, 0};
+static int g_options[OPT_COUNT] = {1, 1, 0, 1};
 int ctrlsim_option(int key) { return (key >= 0 && key < OPT_COUNT) ? g_options[key] : 0; }
 
 extern "C" {
@@ -100,6 +102,10 @@ int ctrlsim_gemm_nt_bf16x6(const float* A, int lda, const void* W3, int n_total,
                            int ldr, float* C, int ldc, int M, int N, int K, int relu, const float* ln_gamma,
                            const float* ln_beta, hipStream_t st) {
   return launch_gemm_nt_bf16x6(A, lda, W3, n_total, n0, bias, R, ldr, C, ldc, M, N, K, relu, ln_gamma, ln_beta, st);
+}
+int ctrlsim_ffn_fused(const float* X, int ldx, const void* W1p, const float* b1, const void* W2p, const float* b2,
+                      const float* gamma, const float* beta, float* Y, int ldy, int M, int F, hipStream_t st) {
+  return launch_ffn_fused_bf16x6(X, ldx, W1p, b1, W2p, b2, gamma, beta, Y, ldy, M, F, st);
 }
 int ctrlsim_layernorm256(const float* X, int ldx, const float* Radd, int ldr, const float* gamma, const float* beta, float* Y,
                          int ldy, int rows, int relu, hipStream_t st) {

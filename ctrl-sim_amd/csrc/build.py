@@ -8,7 +8,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = {"gemm": "", "gemm_bf16x6": "", "attention": "", "attention_bf16x6": "", "sim": "-ffp-contract=off", "context": "-ffp-contract=off", "embed": "",
+SRCS = {"gemm": "", "gemm_bf16x6": "", "ffn_fused": "", "attention": "", "attention_bf16x6": "", "sim": "-ffp-contract=off", "context": "-ffp-contract=off", "embed": "",
         "map_encoder": "", "sample": "", "forward": "", "api": ""}
 OUT = os.path.join(HERE, "libctrlsim_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

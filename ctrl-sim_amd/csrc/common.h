@@ -69,5 +69,6 @@ void prof_after(int cls, double flops, hipStream_t st, double bytes = 0.0);   //
 // ---- runtime options (ctrlsim_set_option): which MFMA path the matrix kernels take
 enum { OPT_ATTN_IMPL = 0, OPT_GEMM_IMPL = 1,   // 0 = f32-input MFMA, 1 = split-bf16 (bf16x6) MFMA
        OPT_GEMM6_TILE = 2,                       // bf16x6 GEMM tile: 0 = auto, 1 = 128x128, 2 = 64x256 (tuning knob)
-       OPT_COUNT = 3 };
+       OPT_FFN_FUSED = 3,                        // 1 = linear1-ReLU-linear2-residual-LayerNorm as one kernel (ffn_fused.hip)
+       OPT_COUNT = 4 };
 int ctrlsim_option(int key);

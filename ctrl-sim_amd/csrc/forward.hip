@@ -32,6 +32,8 @@ int launch_layernorm256(const float*, int, const float*, int, const float*, cons
 int launch_gemm_nt_bf16x6_kv(const float*, int, const void*, int, int, const float*, const float*, int, float*, int, int, int,
                              int, int, const float*, const float*, void*, int, int, int, hipStream_t);
 int launch_kv_zero_tail(int, int, int, void*, hipStream_t);
+int launch_ffn_fused_bf16x6(const float*, int, const void*, const float*, const void*, const float*, const float*, const float*,
+                            float*, int, int, int, hipStream_t);
 int launch_kv_split(const float*, const float*, int, long, int, int, int, void*, hipStream_t);
 int launch_kv_split_rows(const float*, const float*, int, long, const int*, int, int, int, void*, hipStream_t);
 int launch_attention_bf16x6_pre(int, const float*, int, long, const void*, int, float*, int, long, const int*,
@@ -56,8 +58,8 @@ namespace {
 struct Lin { const float* w; const float* b; const void* w3 = nullptr; int ntot = 0; int n0 = 0; };
 struct LNp { const float* g; const float* b; };
 struct Mlp { Lin l0; LNp ln; Lin l3; };
-struct EncLayer { Lin qkv, out, lin1, lin2; LNp n1, n2; };
-struct DecLayer { Lin qkv, out, cq, ckv, cout, lin1, lin2; LNp n1, n2, n3; };
+struct EncLayer { Lin qkv, out, lin1, lin2; LNp n1, n2; const void *w1p = nullptr, *w2p = nullptr; };
+struct DecLayer { Lin qkv, out, cq, ckv, cout, lin1, lin2; LNp n1, n2, n3; const void *w1p = nullptr, *w2p = nullptr; };
 
 }  // namespace
 
@@ -100,6 +102,10 @@ extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_w
     auto it = tab.find(k + "#bf3");
     return it == tab.end() ? nullptr : static_cast<const void*>(it->second);
   };
+  auto PX = [&](const std::string& k) -> const void* {     // optional extra operand images
+    auto it = tab.find(k);
+    return it == tab.end() ? nullptr : static_cast<const void*>(it->second);
+  };
   auto lin = [&](const std::string& k) { return Lin{P(k + ".weight"), P(k + ".bias"), P3(k + ".weight"), 0, 0}; };
   auto lnp = [&](const std::string& k) { return LNp{P(k + ".weight"), P(k + ".bias")}; };
   auto mlp = [&](const std::string& k) { return Mlp{lin(k + ".mlp.0"), lnp(k + ".mlp.1"), lin(k + ".mlp.3")}; };
@@ -131,6 +137,8 @@ extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_w
     L.lin2 = lin(p + ".linear2");
     L.n1 = lnp(p + ".norm1");
     L.n2 = lnp(p + ".norm2");
+    L.w1p = PX(p + ".ffn#w1p");
+    L.w2p = PX(p + ".ffn#w2p");
     m->enc.push_back(L);
   }
   for (int i = 0; i < dims->ND; ++i) {
@@ -149,6 +157,8 @@ extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_w
     L.n1 = lnp(p + ".norm1");
     L.n2 = lnp(p + ".norm2");
     L.n3 = lnp(p + ".norm3");
+    L.w1p = PX(p + ".ffn#w1p");
+    L.w2p = PX(p + ".ffn#w2p");
     m->dec.push_back(L);
   }
   m->head_action = mlp("decoder.predict_action");
@@ -254,6 +264,15 @@ int gemm_ln(const Lin& L, const LNp& n, const float* x, int ldx, const float* R,
   return launch_layernorm256(tmp, DM, nullptr, 0, n.g, n.b, y, ldy, rows, relu, st);
 }
 
+// x <- LayerNorm(x + linear2(relu(linear1(x)))): one fused kernel (hidden tile in registers) or Linear + Linear/LN
+int ffn_block(const Lin& l1, const Lin& l2, const LNp& n, const void* w1p, const void* w2p, float* x, float* hidden, float* tmp,
+              int rows, int F, hipStream_t st) {
+  if (w1p && w2p && !(F & 31) && ctrlsim_option(OPT_FFN_FUSED) == 1 && ctrlsim_option(OPT_GEMM_IMPL) == 1)
+    return launch_ffn_fused_bf16x6(x, DM, w1p, l1.b, w2p, l2.b, n.g, n.b, x, DM, rows, F, st);
+  CHK(gemm(l1, x, DM, nullptr, 0, hidden, F, rows, F, DM, 1, st));
+  return gemm_ln(l2, n, hidden, F, x, DM, x, DM, tmp, rows, F, 0, st);
+}
+
 // Attention over K/V given both as fp32 rows and (when the split-bf16 path is selected) as pre-split images
 inline bool presplit() { return ctrlsim_option(OPT_ATTN_IMPL) == 1; }
 int attention_kv(int mode, const float* Q, int ldq, long qbs, const float* K, const float* V, int ldkv, long kbs,
@@ -318,8 +337,7 @@ int cross_and_ffn(const ctrlsim_model* m, const DecLayer& Ld, int layer, const W
   CHK(attention_kv(0, qc, DM, (long)rows_per_b * DM, w.memkv[layer], w.memkv[layer] + DM, 2 * DM, (long)M * 2 * DM,
                    w.img_mem[layer], w.nkt_mem, att, DM, (long)rows_per_b * DM, nullptr, w.src_pad, B, rows_per_b, M, d.A, st));
   CHK(gemm_ln(Ld.cout, Ld.n2, att, DM, x, DM, x, DM, tmp, rows, DM, 0, st));
-  CHK(gemm(Ld.lin1, x, DM, nullptr, 0, ffn, d.F, rows, d.F, DM, 1, st));
-  CHK(gemm_ln(Ld.lin2, Ld.n3, ffn, d.F, x, DM, x, DM, tmp, rows, d.F, 0, st));
+  CHK(ffn_block(Ld.lin1, Ld.lin2, Ld.n3, Ld.w1p, Ld.w2p, x, ffn, tmp, rows, d.F, st));
   return 0;
 }
 // map encoder + scene encoder + per-layer memory K/V (everything that only depends on the frame of the context)
@@ -349,8 +367,7 @@ int scene_side(const ctrlsim_model* m, const Ws& w, const ctrlsim_ctx* c, int B,
     CHK(attention_kv(0, w.eqkv, 3 * DM, (long)M * 3 * DM, w.eqkv + DM, w.eqkv + 2 * DM, 3 * DM, (long)M * 3 * DM, w.img_enc,
                      w.nkt_mem, w.eatt, DM, (long)M * DM, nullptr, w.src_pad, B, M, M, A, st));
     CHK(gemm_ln(Le.out, Le.n1, w.eatt, DM, w.src, DM, w.src, DM, w.etmp, rM, DM, 0, st));
-    CHK(gemm(Le.lin1, w.src, DM, nullptr, 0, w.effn, d.F, rM, d.F, DM, 1, st));
-    CHK(gemm_ln(Le.lin2, Le.n2, w.effn, d.F, w.src, DM, w.src, DM, w.etmp, rM, d.F, 0, st));
+    CHK(ffn_block(Le.lin1, Le.lin2, Le.n2, Le.w1p, Le.w2p, w.src, w.effn, w.etmp, rM, d.F, st));
   }
   // memory K/V of every decoder layer (cached for pass 2)
   for (int i = 0; i < d.ND; ++i) {

@@ -86,6 +86,37 @@ def split3_planes(W: np.ndarray) -> np.ndarray:
 BF3_SUFFIX = "#bf3"
 
 
+def _planes3(W: np.ndarray):
+    W = np.ascontiguousarray(W, np.float32)
+    hi = bf16_rne(W)
+    r1 = W - bf16_to_f32(hi)
+    mid = bf16_rne(r1)
+    lo = bf16_rne(r1 - bf16_to_f32(mid))
+    return np.stack([hi, mid, lo], 0)                                     # [3][rows][cols] uint16
+
+
+def ffn_planes(W1: np.ndarray, W2: np.ndarray):
+    """Operand images of the fused FFN kernel (csrc/ffn_fused.hip), one 48 KB block per 32 hidden units hb:
+      W1p[hb][p 3][ks K/16][half 2][row 32][8]   = plane_p(W1)[32 hb + row, 16 ks + 8 half + e]
+      W2p[hb][p 3][kk 2][half 2][o D][8]         = plane_p(W2)[o, 32 hb + 16 kk + (j & 3) + 8 (j >> 2) + 4 half]
+    (the k-slot order of W2p is the accumulator-register order of the hidden tile, so the ReLU output feeds the second
+    product straight from registers).  W1 [F,K], W2 [D,F] float32 -> two uint16 arrays."""
+    F, K = W1.shape
+    D = W2.shape[0]
+    assert W2.shape[1] == F and F % 32 == 0 and K % 16 == 0
+    p1 = _planes3(W1).reshape(3, F // 32, 32, K // 16, 2, 8)              # [p][hb][row][ks][half][e]
+    w1p = np.ascontiguousarray(p1.transpose(1, 0, 3, 4, 2, 5))            # [hb][p][ks][half][row][e]
+    j = np.arange(8)
+    idx = np.empty((2, 2, 8), np.int64)                                   # [kk][half][j] -> hidden offset in the block
+    for kk in range(2):
+        for half in range(2):
+            idx[kk, half] = 16 * kk + (j & 3) + 8 * (j >> 2) + 4 * half
+    p2 = _planes3(W2).reshape(3, D, F // 32, 32)                          # [p][o][hb][hid]
+    p2 = p2[:, :, :, idx]                                                 # [p][o][hb][kk][half][j]
+    w2p = np.ascontiguousarray(p2.transpose(2, 0, 3, 4, 1, 5))            # [hb][p][kk][half][o][j]
+    return w1p, w2p
+
+
 def pack(dims: Dims, w: dict):
     """-> (flat float32 ndarray, names list, offsets int64 ndarray in floats)."""
     allw = dict(w)
@@ -97,6 +128,13 @@ def pack(dims: Dims, w: dict):
                 and "embed_action" not in k and "embed_rtg_" not in k and "embed_timestep" not in k and "embed_agent_id" not in k:
             planes = split3_planes(v)
             allw[k + BF3_SUFFIX] = planes.reshape(-1).view(np.float32)
+    # fused-FFN operand images of every transformer layer (post-LN block: linear1 -> ReLU -> linear2 -> +x -> LayerNorm)
+    for k in list(w.keys()):
+        if k.endswith(".linear1.weight"):
+            pre = k[:-len(".linear1.weight")]
+            w1p, w2p = ffn_planes(np.asarray(w[k], np.float32), np.asarray(w[pre + ".linear2.weight"], np.float32))
+            allw[pre + ".ffn#w1p"] = w1p.reshape(-1).view(np.float32)
+            allw[pre + ".ffn#w2p"] = w2p.reshape(-1).view(np.float32)
     names, offsets, chunks = [], [], []
     off = 0
     for k, v in allw.items():

@@ -135,6 +135,11 @@ int ctrlsim_gemm_nt(const float* A, int lda, const float* W, int ldw, const floa
 int ctrlsim_gemm_nt_bf16x6(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias, const float* R,
                            int ldr, float* C, int ldc, int M, int N, int K, int relu, const float* ln_gamma,
                            const float* ln_beta, hipStream_t stream);
+/* Post-LN feed-forward block of nn.TransformerEncoderLayer / DecoderLayer as one kernel:
+ * Y = LayerNorm(X + W2 relu(W1 X + b1) + b2) * gamma + beta, rows of 256, F hidden units (multiple of 32); W1p / W2p are the
+ * operand images of ctrlsim_amd/pack.py:ffn_planes; Y may alias X.  The hidden activation never touches memory. */
+int ctrlsim_ffn_fused(const float* X, int ldx, const void* W1p, const float* b1, const void* W2p, const float* b2,
+                      const float* gamma, const float* beta, float* Y, int ldy, int M, int F, hipStream_t stream);
 int ctrlsim_layernorm256(const float* X, int ldx, const float* Radd, int ldr, const float* gamma, const float* beta,
                          float* Y, int ldy, int rows, int relu, hipStream_t stream);
 /* mode 0: key padding (key_pad [B,Lk], 1 = ignore); mode 1: CtRL-Sim structured causal mask (utils/train_utils.py:81-129) */

@@ -207,3 +207,35 @@ def test_attention_presplit_images_match_in_kernel_split(A, T):
     _lib.check(lib.ctrlsim_attention_presplit(0, p(Q), 256, L * 256, p(img3), nk2, p(Ob), 256, L * 256, None, p(pad_d), B, L, Lk,
                                               A, st))
     assert torch.equal(Oa, Ob) and torch.isfinite(Ob).all()
+
+
+@pytest.mark.parametrize("M,F", [(128, 1024), (1000, 1024), (37, 64), (4133, 512)])
+def test_ffn_fused_block(M, F):
+    """linear1 -> ReLU -> linear2 -> + x -> LayerNorm as one kernel (hidden tile in registers) vs torch in float64,
+    out of place and in place."""
+    from ctrlsim_amd.pack import ffn_planes
+    g = torch.Generator().manual_seed(M + F)
+    X = (torch.randn(M, 256, generator=g) * torch.exp(0.5 * torch.randn(M, 1, generator=g))).to(DEV)
+    W1 = torch.randn(F, 256, generator=g) * 0.08
+    W2 = torch.randn(256, F, generator=g) * 0.05
+    b1 = torch.randn(F, generator=g).to(DEV) * 0.3
+    b2 = torch.randn(256, generator=g).to(DEV) * 0.3
+    gam = torch.randn(256, generator=g).to(DEV); bet = torch.randn(256, generator=g).to(DEV)
+    w1p, w2p = ffn_planes(W1.numpy(), W2.numpy())
+    w1d = torch.from_numpy(w1p.view(np.int16).copy()).to(DEV)
+    w2d = torch.from_numpy(w2p.view(np.int16).copy()).to(DEV)
+    Y = torch.empty_like(X)
+    p = _lib.ptr
+    _lib.check(_lib.lib().ctrlsim_ffn_fused(p(X), 256, p(w1d), p(b1), p(w2d), p(b2), p(gam), p(bet), p(Y), 256, M, F,
+                                            _lib.stream_ptr()), "ffn_fused")
+    Xd = X.double()
+    h = torch.relu(Xd @ W1.to(DEV).double().T + b1.double())
+    pre = Xd + h @ W2.to(DEV).double().T + b2.double()
+    ref = torch.nn.functional.layer_norm(pre, (256,), gam.double(), bet.double(), 1e-5)
+    err = (Y.double() - ref).abs().max().item()
+    print("fused ffn max abs err", err)
+    assert err < 3e-5
+    Z = X.clone()
+    _lib.check(_lib.lib().ctrlsim_ffn_fused(p(Z), 256, p(w1d), p(b1), p(w2d), p(b2), p(gam), p(bet), p(Z), 256, M, F,
+                                            _lib.stream_ptr()), "ffn_fused in place")
+    assert torch.equal(Z, Y)
