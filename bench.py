@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--tilt", type=float, nargs=3, default=(0.0, 0.0, 0.0))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-steps", type=int, default=2)
+    ap.add_argument("--cpu-sample-steps", type=int, default=6)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
