@@ -131,7 +131,8 @@ def main():
         value = agent_steps / elapsed
         ctx_per_rollout = int(res["n_groups"].sum())
         dom = 0 if ms[0] >= ms[1] else 1
-        names = ("gemm_nt_bf16x6_kernel (every nn.Linear; split-bf16 MFMA 32x32x16, 6 partial products per fp32 product)",
+        names = ("gemm_nt_bf16x6_kernel + ffn_fused_bf16x6_kernel (every nn.Linear incl. fused LayerNorm / K-V image epilogues and the fused "
+                 "feed-forward block; split-bf16 MFMA 32x32x16, 6 partial products per fp32 product)",
                  "attention_bf16x6_kernel (all multi-head attention; split-bf16 MFMA flash attention, structured mask)")
 
         # HBM bytes per launch from the PMC counters: collected offline on this same command (separate --pmc passes,

@@ -18,7 +18,7 @@ def main():
             if r["Counter_Name"] != ctr:
                 continue
             k = r["Kernel_Name"]
-            k = k.split("(")[0].replace("void ", "")
+            k = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
             tot[k] += float(r["Counter_Value"]); n[k] += 1
         for k in tot:
             res[k][ctr + "_raw_sum"] = tot[k]
