@@ -54,6 +54,9 @@ __device__ __forceinline__ void ffn_split3_frag(const float* x, bf16x8& hi, bf16
 
 constexpr int FF_BLK = 3 * 16 * 2 * 32 * 8;        // bf16 elements of one weight block (W1: [3][16][2][32][8]; W2: [3][2][2][256][8])
 constexpr int FF_RING = 3;
+#ifndef FFN_PF
+#define FFN_PF 2                                   // LDS fragment prefetch distance in k-steps (2 or 3; four register buffers)
+#endif
 constexpr int FF_CP = DM + 4;                      // row pitch (floats) of the epilogue staging
 
 // six partial products, smallest first
@@ -164,6 +167,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
         };
         ld1(0, wf[0]);
         ld1(1, wf[1]);
+        if (FFN_PF == 3) ld1(2, wf[2]);
 #ifdef FFN_TWO_CHAINS
 #pragma unroll
         for (int ks = 0; ks < 16; ks += 2) {           // even k-steps accumulate into hacc, odd ones into hacc1
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
 #else
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-          if (ks + 2 < 16) ld1(ks + 2, wf[(ks + 2) & 3]);
+          if (ks + FFN_PF < 16) ld1(ks + FFN_PF, wf[(ks + FFN_PF) & 3]);
           FFN_TERMS(hacc, wf[ks & 3], xT[ks])
         }
 #endif
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
 #endif
       {
         const __bf16* w2 = ring + slot * FF_BLK + (half * 256 + l31) * 8;   // [p][kk][half][o][8]
-        bf16x8 wf[3][3];
+        bf16x8 wf[4][3];
         auto ld2 = [&](int i, bf16x8 (&f)[3]) {        // step i = (out block ob = i >> 1, k-step kk = i & 1)
 #pragma unroll
           for (int p = 0; p < 3; ++p)
@@ -206,10 +210,11 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
         };
         ld2(0, wf[0]);
         ld2(1, wf[1]);
+        if (FFN_PF == 3) ld2(2, wf[2]);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          if (i + 2 < 16) ld2(i + 2, wf[(i + 2) % 3]);
-          FFN_TERMS(yacc[i >> 1], wf[i % 3], hf[i & 1])
+          if (i + FFN_PF < 16) ld2(i + FFN_PF, wf[(i + FFN_PF) & 3]);
+          FFN_TERMS(yacc[i >> 1], wf[i & 3], hf[i & 1])
         }
       }
       phase_barrier(2 * hb + 3 < nblk);
