@@ -37,7 +37,6 @@ SIGNATURES = {
     "ctrlsim_gemm_nt": (I, [P, I, P, I, P, P, I, P, I, I, I, I, I, P]),
     "ctrlsim_gemm_nt_bf16x6": (I, [P, I, P, I, I, P, P, I, P, I, I, I, I, I, P, P, P]),
     "ctrlsim_ffn_fused": (I, [P, I, P, P, P, P, P, P, P, I, I, I, P]),
-    "ctrlsim_linear_ln_rs": (I, [P, I, P, P, P, I, P, P, P, I, I, P]),
     "ctrlsim_layernorm256": (I, [P, I, P, I, P, P, P, I, I, I, P]),
     "ctrlsim_kv_split": (I, [P, P, I, L, P, I, I, I, P, P]),
     "ctrlsim_attention_presplit": (I, [I, P, I, L, P, I, P, I, L, P, P, I, I, I, I, P]),

@@ -14,8 +14,6 @@ int launch_kv_split(const float*, const float*, int, long, int, int, int, void*,
 int launch_kv_split_rows(const float*, const float*, int, long, const int*, int, int, int, void*, hipStream_t);
 int launch_attention_bf16x6_pre(int, const float*, int, long, const void*, int, float*, int, long, const int*,
                                 const unsigned char*, int, int, int, int, hipStream_t);
-int launch_linear_ln_rs(const float*, int, const void*, const float*, const float*, int, const float*, const float*, float*, int, int,
-                        hipStream_t);
 int launch_ffn_fused_bf16x6(const float*, int, const void*, const float*, const void*, const float*, const float*, const float*,
                             float*, int, int, int, hipStream_t);
 int launch_sim_init(int, int, int, const float*, const float*, const float*, const unsigned char*, float*, float*,
@@ -108,10 +106,6 @@ int ctrlsim_gemm_nt_bf16x6(const float* A, int lda, const void* W3, int n_total,
 int ctrlsim_ffn_fused(const float* X, int ldx, const void* W1p, const float* b1, const void* W2p, const float* b2,
                       const float* gamma, const float* beta, float* Y, int ldy, int M, int F, hipStream_t st) {
   return launch_ffn_fused_bf16x6(X, ldx, W1p, b1, W2p, b2, gamma, beta, Y, ldy, M, F, st);
-}
-int ctrlsim_linear_ln_rs(const float* X, int ldx, const void* Wp, const float* bias, const float* R, int ldr, const float* gamma,
-                         const float* beta, float* Y, int ldy, int M, hipStream_t st) {
-  return launch_linear_ln_rs(X, ldx, Wp, bias, R, ldr, gamma, beta, Y, ldy, M, st);
 }
 int ctrlsim_layernorm256(const float* X, int ldx, const float* Radd, int ldr, const float* gamma, const float* beta, float* Y,
                          int ldy, int rows, int relu, hipStream_t st) {

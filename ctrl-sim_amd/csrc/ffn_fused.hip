@@ -20,6 +20,7 @@
 // 13 KB per row for Linear / Linear+LN kernels with the hidden tensor in HBM.  Weights (3 MB of planes per block) come
 // from L2.
 #include "common.h"
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -68,22 +69,9 @@ constexpr int FF_CP = DM + 4;                      // row pitch (floats) of the 
   ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[1], ACC, 0, 0, 0);       \
   ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[0], ACC, 0, 0, 0);
 
-// the same six terms of two independent products, interleaved: consecutive MFMAs never share an accumulator (one wave per
-// SIMD: a single dependent chain runs the matrix pipe at 73 % — tools/microbench/mfma_peak.hip)
-#define FFN_TERMS2(ACC0, A0, B0, ACC1, A1, B1)                                   \
-  ACC0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[2], B0[0], ACC0, 0, 0, 0);   \
-  ACC1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[2], B1[0], ACC1, 0, 0, 0);   \
-  ACC0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[0], B0[2], ACC0, 0, 0, 0);   \
-  ACC1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[0], B1[2], ACC1, 0, 0, 0);   \
-  ACC0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[1], B0[1], ACC0, 0, 0, 0);   \
-  ACC1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[1], B1[1], ACC1, 0, 0, 0);   \
-  ACC0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[1], B0[0], ACC0, 0, 0, 0);   \
-  ACC1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[1], B1[0], ACC1, 0, 0, 0);   \
-  ACC0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[0], B0[1], ACC0, 0, 0, 0);   \
-  ACC1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[0], B1[1], ACC1, 0, 0, 0);   \
-  ACC0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[0], B0[0], ACC0, 0, 0, 0);   \
-  ACC1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[0], B1[0], ACC1, 0, 0, 0);
-
+// (Two independent accumulator chains per product were tried — a single dependent chain runs the matrix pipe at ~73 % with
+// one wave per SIMD — but at this register pressure hipcc answers with v_accvgpr_mov shuffles / spills and the result is
+// slower: profiles/r01_c_pmc_pipes.md.)
 __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
     const float* __restrict__ X, int ldx, const __bf16* __restrict__ W1p, const float* __restrict__ b1,
     const __bf16* __restrict__ W2p, const float* __restrict__ b2, const float* __restrict__ gamma,
@@ -103,10 +91,20 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 256 * 8),
                                        (__attribute__((address_space(3))) void*)(dst + j * 256 * 8), 16, 0, 0);
   };
+  // one 1 KB piece (per wave) of block i: issued between the MFMAs of a phase instead of as a burst of 12 at its start —
+  // a piece costs the wave ~60-80 issue cycles, which then overlap the matrix pipe instead of idling it (ablation: the
+  // burst cost 18 % of the kernel)
+  auto dma_piece = [&](const __bf16* src, __bf16* dst, int j) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 256 * 8),
+                                     (__attribute__((address_space(3))) void*)(dst + j * 256 * 8), 16, 0, 0);
+  };
   const int nblk = 2 * nhb;
   // end of a phase: the block issued in the PREVIOUS phase must have landed (it is read next phase); the 12 pieces issued
   // in this phase may stay in flight (vmcnt counts in order).  LDS reads of this wave are complete (lgkmcnt(0)).
   auto phase_barrier = [&](bool issued_this_phase) {
+#ifdef ABL_NO_BARRIER
+    return;
+#endif
     if (issued_this_phase) __builtin_amdgcn_s_waitcnt(0x0070 | 12);   // vmcnt(12) expcnt(7) lgkmcnt(0)  [gfx9: vmcnt = bits 3:0 + 15:14]
     else __builtin_amdgcn_s_waitcnt(0x0070);                          // nothing newer in flight: vmcnt(0)
     __builtin_amdgcn_s_barrier();
@@ -139,15 +137,12 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
     int slot = 0;                                                     // ring slot of the block the current phase reads
     for (int hb = 0; hb < nhb; ++hb) {
       // ---------------- phase 2 hb: H^T = W1_blk . X^T (+ b1), block 2 hb in slot (2 hb) % 3
-#ifndef ABL_NO_DMA
-      if (2 * hb + 2 < nblk) dma_block(2 * hb + 2, slot == 0 ? 2 : slot - 1);   // two blocks ahead = the slot read last phase
-#endif
+      // the block two ahead goes to the slot read last phase.  Past the end of the stream the last block is fetched again
+      // (into a slot nobody reads any more; drained before the epilogue): the phases stay branch-free.
+      const int hb_next = hb + 1 < nhb ? hb + 1 : nhb - 1;
+      const __bf16* dsrc_a = W1p + (size_t)hb_next * FF_BLK + tid * 8;
+      __bf16* ddst_a = ring + (slot == 0 ? 2 : slot - 1) * FF_BLK + wave * 64 * 8;
       f32x16 hacc;
-#ifdef FFN_TWO_CHAINS
-      f32x16 hacc1;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) hacc1[r] = 0.f;
-#endif
       {
         const float* bp = b1s + hb * 32 + 4 * half;                    // register r <-> hidden (r & 3) + 8 (r >> 2) + 4 half
 #pragma unroll
@@ -163,26 +158,23 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
         bf16x8 wf[4][3];
         auto ld1 = [&](int ks, bf16x8 (&f)[3]) {
 #pragma unroll
+#ifndef ABL_NO_FRAG
           for (int p = 0; p < 3; ++p) f[p] = *reinterpret_cast<const bf16x8*>(w1 + ((p * 16 + ks) * 2) * 32 * 8);
+#else
+          for (int p = 0; p < 3; ++p) { f[p] = xT[ks][p]; asm volatile("" : "+v"(f[p])); }
+#endif
         };
         ld1(0, wf[0]);
         ld1(1, wf[1]);
         if (FFN_PF == 3) ld1(2, wf[2]);
-#ifdef FFN_TWO_CHAINS
-#pragma unroll
-        for (int ks = 0; ks < 16; ks += 2) {           // even k-steps accumulate into hacc, odd ones into hacc1
-          if (ks + 2 < 16) { ld1(ks + 2, wf[(ks + 2) & 3]); ld1(ks + 3, wf[(ks + 3) & 3]); }
-          FFN_TERMS2(hacc, wf[ks & 3], xT[ks], hacc1, wf[(ks + 1) & 3], xT[ks + 1])
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hacc[r] += hacc1[r];
-#else
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
           if (ks + FFN_PF < 16) ld1(ks + FFN_PF, wf[(ks + FFN_PF) & 3]);
+#ifndef ABL_NO_DMA
+          if (ks < 12) dma_piece(dsrc_a, ddst_a, ks);
+#endif
           FFN_TERMS(hacc, wf[ks & 3], xT[ks])
         }
-#endif
       }
       // ReLU + split: k-step kk of the second product uses accumulator registers 8 kk .. 8 kk + 7
       bf16x8 hf[2][3];
@@ -190,23 +182,36 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
         float hv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) hv[r] = fmaxf(hacc[r], 0.f);
+#ifndef ABL_NO_SPLIT
         ffn_split3_frag(hv, hf[0][0], hf[0][1], hf[0][2]);
         ffn_split3_frag(hv + 8, hf[1][0], hf[1][1], hf[1][2]);
+#else
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            u32x4 u = {__float_as_uint(hv[8 * kk + p]), __float_as_uint(hv[8 * kk + p + 1]), __float_as_uint(hv[8 * kk + p + 2]), __float_as_uint(hv[8 * kk + p + 3])};
+            hf[kk][p] = __builtin_bit_cast(bf16x8, u);
+          }
+#endif
       }
-      phase_barrier(2 * hb + 2 < nblk);                               // block 2 hb + 1 has landed; everyone is done with this slot
+      phase_barrier(true);                               // block 2 hb + 1 has landed; everyone is done with this slot
       slot = slot == FF_RING - 1 ? 0 : slot + 1;
 
       // ---------------- phase 2 hb + 1: Y^T += W2_blk . H^T, block 2 hb + 1 in slot (2 hb + 1) % 3
-#ifndef ABL_NO_DMA
-      if (2 * hb + 3 < nblk) dma_block(2 * hb + 3, slot == 0 ? 2 : slot - 1);
-#endif
+      const __bf16* dsrc_b = W2p + (size_t)hb_next * FF_BLK + tid * 8;
+      __bf16* ddst_b = ring + (slot == 0 ? 2 : slot - 1) * FF_BLK + wave * 64 * 8;
       {
         const __bf16* w2 = ring + slot * FF_BLK + (half * 256 + l31) * 8;   // [p][kk][half][o][8]
         bf16x8 wf[4][3];
         auto ld2 = [&](int i, bf16x8 (&f)[3]) {        // step i = (out block ob = i >> 1, k-step kk = i & 1)
 #pragma unroll
           for (int p = 0; p < 3; ++p)
+#ifndef ABL_NO_FRAG
             f[p] = *reinterpret_cast<const bf16x8*>(w2 + (((p * 2 + (i & 1)) * 2) * 256 + (i >> 1) * 32) * 8);
+#else
+          { f[p] = hf[i & 1][p]; asm volatile("" : "+v"(f[p])); }
+#endif
         };
         ld2(0, wf[0]);
         ld2(1, wf[1]);
@@ -214,10 +219,13 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           if (i + FFN_PF < 16) ld2(i + FFN_PF, wf[(i + FFN_PF) & 3]);
+#ifndef ABL_NO_DMA
+          if (i < 12) dma_piece(dsrc_b, ddst_b, i);
+#endif
           FFN_TERMS(yacc[i >> 1], wf[i & 3], hf[i & 1])
         }
       }
-      phase_barrier(2 * hb + 3 < nblk);
+      phase_barrier(true);
       slot = slot == FF_RING - 1 ? 0 : slot + 1;
     }
     __syncthreads();                                                  // drain everything before the ring is reused as staging
@@ -253,97 +261,6 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
   }
 }
 
-
-// Register-stationary Linear(256 -> 256) + residual + LayerNorm (the attention output projections of the post-LN blocks):
-//     y = LayerNorm( r + W . x + b ) * gamma + beta
-// Same machinery as the first product above: X^T fragments of the wave's 32 rows stay in registers, the eight 32-row
-// blocks of W (ffn_planes' W1 block format) stream through the LDS ring, all eight output tiles accumulate in registers,
-// and the epilogue is the row-major LayerNorm pass.  x is split once per row (the tiled GEMM re-splits it per N-tile).
-__global__ __launch_bounds__(256, 1) void linear_ln_rs_kernel(
-    const float* __restrict__ X, int ldx, const __bf16* __restrict__ Wp, const float* __restrict__ bias,
-    const float* __restrict__ R, int ldr, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float* __restrict__ Y, int ldy, int M) {
-  extern __shared__ __attribute__((aligned(16))) __bf16 ring[];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
-  const int n_rb = (M + 127) / 128;
-  auto dma_block = [&](int i, int to_slot) {
-    const __bf16* src = Wp + (size_t)i * FF_BLK + tid * 8;
-    __bf16* dst = ring + to_slot * FF_BLK + wave * 64 * 8;
-#pragma unroll
-    for (int j = 0; j < 12; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 256 * 8),
-                                       (__attribute__((address_space(3))) void*)(dst + j * 256 * 8), 16, 0, 0);
-  };
-  for (int rb = blockIdx.x; rb < n_rb; rb += gridDim.x) {
-    const int row = rb * 128 + wave * 32 + l31;
-    const int rowc = row < M ? row : M - 1;
-    dma_block(0, 0);
-    dma_block(1, 1);
-    bf16x8 xT[16][3];
-    {
-      const float* xp = X + (size_t)rowc * ldx + half * 8;
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(xp + ks * 16);
-        const f32x4 x1 = *reinterpret_cast<const f32x4*>(xp + ks * 16 + 4);
-        const float xs[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-        ffn_split3_frag(xs, xT[ks][0], xT[ks][1], xT[ks][2]);
-      }
-    }
-    f32x16 yacc[8];
-    __syncthreads();
-#pragma unroll
-    for (int ob = 0; ob < 8; ++ob) {
-      if (ob + 2 < 8) dma_block(ob + 2, (ob + 2) % FF_RING);          // = the slot read in the previous phase
-#pragma unroll
-      for (int r = 0; r < 16; ++r) yacc[ob][r] = 0.f;
-      const __bf16* w1 = ring + (ob % FF_RING) * FF_BLK + (half * 32 + l31) * 8;
-      bf16x8 wf[3][3];
-      auto ld1 = [&](int ks, bf16x8 (&f)[3]) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) f[p] = *reinterpret_cast<const bf16x8*>(w1 + ((p * 16 + ks) * 2) * 32 * 8);
-      };
-      ld1(0, wf[0]);
-      ld1(1, wf[1]);
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        if (ks + 2 < 16) ld1(ks + 2, wf[(ks + 2) % 3]);
-        FFN_TERMS(yacc[ob], wf[ks % 3], xT[ks])
-      }
-      if (ob + 2 < 8) __builtin_amdgcn_s_waitcnt(0x0070 | 12); else __builtin_amdgcn_s_waitcnt(0x0070);
-      __builtin_amdgcn_s_barrier();
-    }
-    __syncthreads();
-    float* Cs = reinterpret_cast<float*>(ring) + wave * 32 * FF_CP;
-#pragma unroll
-    for (int ob = 0; ob < 8; ++ob)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) Cs[l31 * FF_CP + ob * 32 + mfma_row(r, half)] = yacc[ob][r];
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    {
-      const int col = lane * 4;
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + col);
-      const f32x4 gg = *reinterpret_cast<const f32x4*>(gamma + col);
-      const f32x4 be = *reinterpret_cast<const f32x4*>(beta + col);
-#pragma unroll 4
-      for (int rr = 0; rr < 32; ++rr) {
-        const int grow = rb * 128 + wave * 32 + rr;
-        if (grow >= M) break;
-        f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * FF_CP + col);
-        v += bb;
-        v += *reinterpret_cast<const f32x4*>(R + (size_t)grow * ldr + col);
-        const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
-        const f32x4 dv = v - mean;
-        const float var = wave_sum(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2] + dv[3] * dv[3]) * (1.f / 256.f);
-        const f32x4 y = dv * (1.0f / sqrtf(var + 1e-5f)) * gg + be;
-        *reinterpret_cast<f32x4*>(Y + (size_t)grow * ldy + col) = y;
-      }
-    }
-    __syncthreads();
-  }
-}
-
 }  // namespace
 
 // y = LayerNorm(x + W2 relu(W1 x + b1) + b2) * gamma + beta for rows of 256; W1p / W2p = pack.py:ffn_planes images of
@@ -366,25 +283,5 @@ int launch_ffn_fused_bf16x6(const float* X, int ldx, const void* W1p, const floa
   hipLaunchKernelGGL(ffn_fused_bf16x6_kernel, dim3(grid), dim3(256), shm, st, X, ldx, static_cast<const __bf16*>(W1p), b1,
                      static_cast<const __bf16*>(W2p), b2, gamma, beta, Y, ldy, M, F / 32);
   prof_after(PROF_GEMM, 4.0 * (double)M * DM * (double)F, st, 12.0 * (double)M * DM + 12.0 * (double)DM * F);
-  return ctrlsim_launch_status();
-}
-
-// y = LayerNorm(r + W x + b) * gamma + beta, W [256, 256] given as pack.py:rows_planes blocks; y may alias r (not x)
-int launch_linear_ln_rs(const float* X, int ldx, const void* Wp, const float* bias, const float* R, int ldr,
-                        const float* gamma, const float* beta, float* Y, int ldy, int M, hipStream_t st) {
-  if (M <= 0) return CTRLSIM_OK;
-  if (!X || !Wp || !bias || !R || !gamma || !beta || !Y || (ldx & 3) || (ldy & 3) || (ldr & 3)) return CTRLSIM_EINVAL;
-  const int n_rb = (M + 127) / 128;
-  const int grid = n_rb < 256 ? n_rb : 256;
-  const size_t shm = (size_t)FF_RING * FF_BLK * sizeof(__bf16);
-  static bool attr = false;
-  if (!attr) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_ln_rs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    attr = true;
-  }
-  prof_before(PROF_GEMM, st);
-  hipLaunchKernelGGL(linear_ln_rs_kernel, dim3(grid), dim3(256), shm, st, X, ldx, static_cast<const __bf16*>(Wp), bias, R, ldr,
-                     gamma, beta, Y, ldy, M);
-  prof_after(PROF_GEMM, 2.0 * (double)M * DM * DM, st, 12.0 * (double)M * DM + 6.0 * DM * DM);
   return ctrlsim_launch_status();
 }

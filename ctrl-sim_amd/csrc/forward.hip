@@ -32,8 +32,6 @@ int launch_layernorm256(const float*, int, const float*, int, const float*, cons
 int launch_gemm_nt_bf16x6_kv(const float*, int, const void*, int, int, const float*, const float*, int, float*, int, int, int,
                              int, int, const float*, const float*, void*, int, int, int, hipStream_t);
 int launch_kv_zero_tail(int, int, int, void*, hipStream_t);
-int launch_linear_ln_rs(const float*, int, const void*, const float*, const float*, int, const float*, const float*, float*, int, int,
-                        hipStream_t);
 int launch_ffn_fused_bf16x6(const float*, int, const void*, const float*, const void*, const float*, const float*, const float*,
                             float*, int, int, int, hipStream_t);
 int launch_kv_split(const float*, const float*, int, long, int, int, int, void*, hipStream_t);
@@ -57,7 +55,7 @@ int launch_map_pool(int, int, int, int, const float*, MapPoolWeights, float*, un
 
 namespace {
 
-struct Lin { const float* w; const float* b; const void* w3 = nullptr; int ntot = 0; int n0 = 0; const void* wrs = nullptr; };
+struct Lin { const float* w; const float* b; const void* w3 = nullptr; int ntot = 0; int n0 = 0; };
 struct LNp { const float* g; const float* b; };
 struct Mlp { Lin l0; LNp ln; Lin l3; };
 struct EncLayer { Lin qkv, out, lin1, lin2; LNp n1, n2; const void *w1p = nullptr, *w2p = nullptr; };
@@ -108,7 +106,7 @@ extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_w
     auto it = tab.find(k);
     return it == tab.end() ? nullptr : static_cast<const void*>(it->second);
   };
-  auto lin = [&](const std::string& k) { return Lin{P(k + ".weight"), P(k + ".bias"), P3(k + ".weight"), 0, 0, PX(k + ".weight#rs")}; };
+  auto lin = [&](const std::string& k) { return Lin{P(k + ".weight"), P(k + ".bias"), P3(k + ".weight"), 0, 0}; };
   auto lnp = [&](const std::string& k) { return LNp{P(k + ".weight"), P(k + ".bias")}; };
   auto mlp = [&](const std::string& k) { return Mlp{lin(k + ".mlp.0"), lnp(k + ".mlp.1"), lin(k + ".mlp.3")}; };
   ctrlsim_model* m = new ctrlsim_model();
@@ -260,10 +258,6 @@ int gemm(const Lin& L, const float* x, int ldx, const float* R, int ldr, float* 
 // y may alias R), GEMM into `tmp` + layernorm256 on the f32-input path
 int gemm_ln(const Lin& L, const LNp& n, const float* x, int ldx, const float* R, int ldr, float* y, int ldy, float* tmp,
             int rows, int k, int relu, hipStream_t st) {
-  // register-stationary variant: measured SLOWER than the tiled LN GEMM at K = 256 (60 vs 89 TFLOP/s: only 768 MFMAs per
-  // row block to amortise the X split, ring prologue and LayerNorm pass) -> opt-in (option value 2) for experiments only
-  if (L.wrs && k == DM && R && !relu && x != y && ctrlsim_option(OPT_FFN_FUSED) == 2 && ctrlsim_option(OPT_GEMM_IMPL) == 1)
-    return launch_linear_ln_rs(x, ldx, L.wrs, L.b, R, ldr, n.g, n.b, y, ldy, rows, st);
   if (L.w3 && k % 32 == 0 && ctrlsim_option(OPT_GEMM_IMPL) == 1)
     return launch_gemm_nt_bf16x6(x, ldx, L.w3, L.ntot ? L.ntot : DM, L.n0, L.b, R, ldr, y, ldy, rows, DM, k, relu, n.g, n.b, st);
   CHK(launch_gemm_nt(x, ldx, L.w, k, L.b, R, ldr, tmp, DM, rows, DM, k, 0, st));

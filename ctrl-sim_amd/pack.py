@@ -95,15 +95,6 @@ def _planes3(W: np.ndarray):
     return np.stack([hi, mid, lo], 0)                                     # [3][rows][cols] uint16
 
 
-def rows_planes(W: np.ndarray) -> np.ndarray:
-    """[N,K] float32 -> [N/32][p 3][ks K/16][half 2][row 32][8] uint16: 32-row operand blocks of the register-stationary
-    kernels (csrc/ffn_fused.hip)."""
-    N, K = W.shape
-    assert N % 32 == 0 and K % 16 == 0
-    p1 = _planes3(W).reshape(3, N // 32, 32, K // 16, 2, 8)
-    return np.ascontiguousarray(p1.transpose(1, 0, 3, 4, 2, 5))
-
-
 def ffn_planes(W1: np.ndarray, W2: np.ndarray):
     """Operand images of the fused FFN kernel (csrc/ffn_fused.hip), one 48 KB block per 32 hidden units hb:
       W1p[hb][p 3][ks K/16][half 2][row 32][8]   = plane_p(W1)[32 hb + row, 16 ks + 8 half + e]
@@ -144,8 +135,6 @@ def pack(dims: Dims, w: dict):
             w1p, w2p = ffn_planes(np.asarray(w[k], np.float32), np.asarray(w[pre + ".linear2.weight"], np.float32))
             allw[pre + ".ffn#w1p"] = w1p.reshape(-1).view(np.float32)
             allw[pre + ".ffn#w2p"] = w2p.reshape(-1).view(np.float32)
-        if k.endswith("out_proj.weight") and tuple(np.shape(w[k])) == (256, 256):
-            allw[k + "#rs"] = rows_planes(np.asarray(w[k], np.float32)).reshape(-1).view(np.float32)
     names, offsets, chunks = [], [], []
     off = 0
     for k, v in allw.items():

@@ -140,10 +140,6 @@ int ctrlsim_gemm_nt_bf16x6(const float* A, int lda, const void* W3, int n_total,
  * operand images of ctrlsim_amd/pack.py:ffn_planes; Y may alias X.  The hidden activation never touches memory. */
 int ctrlsim_ffn_fused(const float* X, int ldx, const void* W1p, const float* b1, const void* W2p, const float* b2,
                       const float* gamma, const float* beta, float* Y, int ldy, int M, int F, hipStream_t stream);
-/* Y = LayerNorm(R + W X + b) * gamma + beta for a 256 x 256 W given as pack.py:rows_planes blocks (the attention output
- * projections of the post-LN blocks), register-stationary variant; Y may alias R. */
-int ctrlsim_linear_ln_rs(const float* X, int ldx, const void* Wp, const float* bias, const float* R, int ldr,
-                         const float* gamma, const float* beta, float* Y, int ldy, int M, hipStream_t stream);
 int ctrlsim_layernorm256(const float* X, int ldx, const float* Radd, int ldr, const float* gamma, const float* beta,
                          float* Y, int ldy, int rows, int relu, hipStream_t stream);
 /* mode 0: key padding (key_pad [B,Lk], 1 = ignore); mode 1: CtRL-Sim structured causal mask (utils/train_utils.py:81-129) */

@@ -239,23 +239,3 @@ def test_ffn_fused_block(M, F):
     _lib.check(_lib.lib().ctrlsim_ffn_fused(p(Z), 256, p(w1d), p(b1), p(w2d), p(b2), p(gam), p(bet), p(Z), 256, M, F,
                                             _lib.stream_ptr()), "ffn_fused in place")
     assert torch.equal(Z, Y)
-
-
-@pytest.mark.parametrize("M", [128, 1000, 37, 4133])
-def test_linear_ln_register_stationary(M):
-    """Linear(256->256) + residual + LayerNorm with X^T held in registers vs torch in float64 (in place over the residual)."""
-    from ctrlsim_amd.pack import rows_planes
-    g = torch.Generator().manual_seed(M)
-    X = torch.randn(M, 256, generator=g).to(DEV)
-    R = torch.randn(M, 256, generator=g).to(DEV)
-    W = torch.randn(256, 256, generator=g) * 0.1
-    b = torch.randn(256, generator=g).to(DEV)
-    gam = torch.randn(256, generator=g).to(DEV); bet = torch.randn(256, generator=g).to(DEV)
-    wp = torch.from_numpy(rows_planes(W.numpy()).view(np.int16).copy()).to(DEV)
-    ref = torch.nn.functional.layer_norm(R.double() + X.double() @ W.to(DEV).double().T + b.double(), (256,), gam.double(),
-                                         bet.double(), 1e-5)
-    Y = R.clone()
-    p = _lib.ptr
-    _lib.check(_lib.lib().ctrlsim_linear_ln_rs(p(X), 256, p(wp), p(b), p(Y), 256, p(gam), p(bet), p(Y), 256, M,
-                                               _lib.stream_ptr()), "linear_ln_rs")
-    assert (Y.double() - ref).abs().max().item() < 2e-5

@@ -4,7 +4,7 @@ import collections
 import csv
 import json
 
-GEMM_KEYS = ("gemm_nt_bf16x6", "ffn_fused_bf16x6", "linear_ln_rs")
+GEMM_KEYS = ("gemm_nt_bf16x6", "ffn_fused_bf16x6")
 ATTN_KEYS = ("attention_bf16x6",)
 
 

@@ -27,12 +27,3 @@ def two():
     lib.ctrlsim_gemm_nt_bf16x6(p(X),256,p(pl1),F,0,p(b1),None,0,p(H),F,M,F,256,1,None,None,st)
     lib.ctrlsim_gemm_nt_bf16x6(p(H),F,p(pl2),256,0,p(b2),p(X),256,p(Y),256,M,256,F,0,p(g),p(g),st)
 ms=timeit(two); print(f'ffn two kernels M={M}: {ms:.3f} ms  {4*M*256*F/ms/1e9:.1f} TF-eq')
-from ctrlsim_amd.pack import rows_planes
-Wo=torch.randn(256,256)*0.05
-wp=torch.from_numpy(rows_planes(Wo.numpy()).view(np.int16).copy()).to(DEV)
-plo=torch.from_numpy(split3_planes(Wo.numpy()).view(np.int16).copy()).to(DEV)
-Rr=torch.randn(M,256,device=DEV)
-f=lambda: lib.ctrlsim_linear_ln_rs(p(X),256,p(wp),p(b2),p(Rr),256,p(g),p(g),p(Y),256,M,st)
-ms=timeit(f); print(f'ffn-like linear+LN rs M={M}: {ms:.3f} ms  {2*M*256*256/ms/1e9:.1f} TF-eq')
-f=lambda: lib.ctrlsim_gemm_nt_bf16x6(p(X),256,p(plo),256,0,p(b2),p(Rr),256,p(Y),256,M,256,256,0,p(g),p(g),st)
-ms=timeit(f); print(f'ffn-like linear+LN tiled M={M}: {ms:.3f} ms  {2*M*256*256/ms/1e9:.1f} TF-eq')
