@@ -41,8 +41,9 @@ SIGNATURES = {
     "ctrlsim_kv_split": (I, [P, P, I, L, P, I, I, I, P, P]),
     "ctrlsim_attention_presplit": (I, [I, P, I, L, P, I, P, I, L, P, P, I, I, I, I, P]),
     "ctrlsim_attention": (I, [I, P, I, L, P, P, I, L, P, I, L, P, P, I, I, I, I, P]),
-    "ctrlsim_sim_init": (I, [I, I, I, P, P, P, P, P, P, P, I, P]),
-    "ctrlsim_sim_step": (I, [I, I, I, P, P, P, P, P, P, P, P, P, P, I, I, F, I, P]),
+    "ctrlsim_sim_init": (I, [I, I, I, P, P, P, P, P, P, P, I, P, P]),
+    "ctrlsim_sim_contact_floats": (L, [I]),
+    "ctrlsim_sim_step": (I, [I, I, I, P, P, P, P, P, P, P, P, P, P, I, I, F, I, P, P]),
     "ctrlsim_group_build": (I, [I, I, I, I, I, I, D, P, P, I, P, P, P, P, P, P, P, P, P]),
     "ctrlsim_ctx_index": (I, [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "ctrlsim_build_context": (I, [I] * 12 + [P] * 12 + [C.POINTER(Ctx), P]),

@@ -17,9 +17,9 @@ int launch_attention_bf16x6_pre(int, const float*, int, long, const void*, int, 
 int launch_ffn_fused_bf16x6(const float*, int, const void*, const float*, const void*, const float*, const float*, const float*,
                             float*, int, int, int, hipStream_t);
 int launch_sim_init(int, int, int, const float*, const float*, const float*, const unsigned char*, float*, float*,
-                    unsigned char*, int, hipStream_t);
+                    unsigned char*, int, float*, hipStream_t);
 int launch_sim_step(int, int, int, const int*, const double*, const double*, const float*, const float*,
-                    const unsigned char*, float*, float*, unsigned char*, double*, int, int, float, int, hipStream_t);
+                    const unsigned char*, float*, float*, unsigned char*, double*, int, int, float, int, float*, hipStream_t);
 int launch_group_build(int, int, int, int, int, int, double, const float*, const int*, int, unsigned long long*, int*, int*,
                        unsigned long long*, unsigned long long*, int*, int*, unsigned char*, hipStream_t);
 int launch_ctx_index(int, int, int, const int*, const int*, const unsigned long long*, const int*, const int*, int*, int*,
@@ -127,15 +127,16 @@ int ctrlsim_attention(int mode, const float* Q, int ldq, int64_t qbs, const floa
   return launch_attention(mode, Q, ldq, (long)qbs, K, V, ldkv, (long)kbs, O, ldo, (long)obs, q_pos, key_pad, B, Lq, Lk, A, st);
 }
 int ctrlsim_sim_init(int S, int N, int E, const float* init_pose, const float* size, const float* edges, const uint8_t* exists,
-                     float* phys, float* hist_states, uint8_t* coll, int Tmax1, hipStream_t st) {
-  return launch_sim_init(S, N, E, init_pose, size, edges, exists, phys, hist_states, coll, Tmax1, st);
+                     float* phys, float* hist_states, uint8_t* coll, int Tmax1, float* contact_state, hipStream_t st) {
+  return launch_sim_init(S, N, E, init_pose, size, edges, exists, phys, hist_states, coll, Tmax1, contact_state, st);
 }
+int64_t ctrlsim_sim_contact_floats(int N) { return N < 1 ? 0 : (int64_t)N * (N - 1) / 2 * 20 + 4; }
 int ctrlsim_sim_step(int S, int N, int E, const int* act_tok, const double* act_f64, const double* disc6, const float* size,
                      const float* edges, const uint8_t* exists, float* phys, float* hist_states, uint8_t* coll,
-                     double* applied, int t, int Tmax1, float dt, int mode, hipStream_t st) {
+                     double* applied, int t, int Tmax1, float dt, int mode, float* contact_state, hipStream_t st) {
   if (!disc6) return CTRLSIM_EINVAL;
   return launch_sim_step(S, N, E, act_tok, act_f64, disc6, size, edges, exists, phys, hist_states, coll, applied, t, Tmax1, dt,
-                         mode, st);
+                         mode, contact_state, st);
 }
 int ctrlsim_group_build(int S, int N, int A, int T, int t, int Tmax1, double dist_thresh, const float* hist_states,
                         const int* eval_order, int has_roads, uint64_t* persist, int* n_groups, int* grp_focal,

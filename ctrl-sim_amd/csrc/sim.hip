@@ -7,8 +7,11 @@
 //   nocturne/cpp/src/vehicle.cc:75-135         setters -> FreeCar::Throttle/Brake/Turn
 //   nocturne/cpp/src/physics/FreeCar.cpp:66-186 FreeCar controller (DampenSpeed, slip angle beta, steering radius)
 //   third_party/box2d/src/dynamics/b2_island.cpp:194-229,279-310,349-392  integrate, translation/rotation clamps
-//                                              (patched b2_maxTranslation = 5.0f, b2_common.h:95), auto-sleep;
-//                                              contact-free tier: no contact solver (DESIGN.md "scope")
+//                                              (patched b2_maxTranslation = 5.0f, b2_common.h:95), auto-sleep
+//   third_party/box2d/src/collision/b2_collide_polygon.cpp, b2_collision.cpp; src/dynamics/b2_contact.cpp:165-245,
+//   b2_world.cpp:393-560, b2_contact_solver.cpp          box-box contacts between vehicles: manifolds, impulse matching,
+//                                              islands, warm-started velocity solver with the 2-point block solver,
+//                                              position solver (when a contact-state buffer is given; see "contacts" below)
 //   nocturne/cpp/src/vehicle.cc:45-55          read-back: position <- xf.p, speed <- |v|, heading <- angle + pi/2
 //   nocturne/cpp/src/scenario.cc:266-328       reset flags, vehicle-vehicle SAT and vehicle-road-edge tests with the
 //                                              strict-AABB candidate predicate (aabb.h:47-50, bvh.h:181-193)
@@ -42,10 +45,11 @@ __device__ __forceinline__ float dampen(float speed, float target, float damping
 }
 
 // b2PolygonShape::SetAsBox + ComputeMass(density 20) + b2Body::ResetMassData (float32 residue of the centroid)
-__device__ void local_center(float width, float length, float* lcx, float* lcy) {
+__device__ void local_center(float width, float length, float* lcx, float* lcy, float* inv_mass_out = nullptr,
+                             float* inv_i_out = nullptr) {
   const float hx = width / 2, hy = length / 2;
   const float vx[4] = {-hx, hx, hx, -hx}, vy[4] = {-hy, -hy, hy, hy};
-  float cx = 0.0f, cy = 0.0f, area = 0.0f;
+  float cx = 0.0f, cy = 0.0f, area = 0.0f, I = 0.0f;
   const float sx = vx[0], sy = vy[0];
   const float k_inv3 = 1.0f / 3.0f;
 #pragma unroll
@@ -58,6 +62,9 @@ __device__ void local_center(float width, float length, float* lcx, float* lcy) 
     const float k = ta * k_inv3;
     cx += k * (e1x + e2x);
     cy += k * (e1y + e2y);
+    const float intx2 = e1x * e1x + e2x * e1x + e2x * e2x;
+    const float inty2 = e1y * e1y + e2y * e1y + e2y * e2y;
+    I += (0.25f * k_inv3 * D) * (intx2 + inty2);
   }
   const float mass = 20.f * area;
   const float inv_area = 1.0f / area;
@@ -68,6 +75,13 @@ __device__ void local_center(float width, float length, float* lcx, float* lcy) 
   const float inv_mass = 1.0f / mass;
   *lcx = lx * inv_mass;
   *lcy = ly * inv_mass;
+  if (inv_mass_out) {                                   // b2PolygonShape::ComputeMass inertia + b2Body::ResetMassData
+    float mI = 20.f * I;
+    mI += mass * ((mcx * mcx + mcy * mcy) - (cx * cx + cy * cy));
+    const float bI = mI - mass * (*lcx * *lcx + *lcy * *lcy);
+    *inv_mass_out = inv_mass;
+    *inv_i_out = 1.0f / bI;
+  }
 }
 
 __device__ __forceinline__ void set_transform(float* p, float x, float y, float angle) {
@@ -190,12 +204,430 @@ __device__ void collide_and_record(int s, int N, int E, const float* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------------- contacts
+// Box2D's treatment of overlapping vehicle boxes, restated from the C++ sources cited at the top (and, line for line, from
+// this repo's CPU oracle oracle/sim_oracle.c, which is pinned bit-exactly against the real Box2D for two-body islands).
+// Per scenario and step:  (1) every vehicle pair: b2CollidePolygons manifold + impulse matching by feature id (parallel
+// over pairs), (2) islands by depth-first search over touching pairs, (3) per island the sequential-impulse solver:
+// warm start, 8 velocity iterations (friction, then normal / 2-point block solver), integration with the translation and
+// rotation clamps, 3 position iterations, sleep.  Islands of one body integrate on their own lanes in parallel; islands
+// with contacts are solved by lane 0 in Box2D's sequential order (Gauss-Seidel is order dependent).
+// Contact state per pair (i < j), CS_STRIDE floats: two manifold points {local x, y, normal impulse, tangent impulse, id},
+// local normal, local point, type, point count, touching flag.
+#define CS_STRIDE 20
+#define CS_LN 10
+#define CS_LP 12
+#define CS_TYPE 14
+#define CS_COUNT 15
+#define CS_TOUCH 16
+#define MAX_ISLAND_CONTACTS 160
+#define B2_LINEAR_SLOP 0.005f
+#define B2_POLY_RADIUS (2.0f * B2_LINEAR_SLOP)
+#define B2_FLT_MAX 3.402823466e+38F
+#define B2_FLT_EPS 1.1920928955078125e-7f
+
+struct V2 { float x, y; };
+struct Rot { float s, c; };
+struct Xf { V2 p; Rot q; };
+__device__ __forceinline__ float b2maxf(float a, float b) { return a > b ? a : b; }
+__device__ __forceinline__ float b2minf(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ V2 v2(float x, float y) { V2 r; r.x = x; r.y = y; return r; }
+__device__ __forceinline__ V2 rot_mul(Rot q, V2 v) { return v2(q.c * v.x - q.s * v.y, q.s * v.x + q.c * v.y); }
+__device__ __forceinline__ V2 rot_mulT(Rot q, V2 v) { return v2(q.c * v.x + q.s * v.y, -q.s * v.x + q.c * v.y); }
+__device__ __forceinline__ V2 xf_mul(Xf t, V2 v) {
+  return v2((t.q.c * v.x - t.q.s * v.y) + t.p.x, (t.q.s * v.x + t.q.c * v.y) + t.p.y);
+}
+__device__ __forceinline__ V2 xf_mulT(Xf t, V2 v) {
+  const float px = v.x - t.p.x, py = v.y - t.p.y;
+  return v2(t.q.c * px + t.q.s * py, -t.q.s * px + t.q.c * py);
+}
+__device__ __forceinline__ Xf xf_mulT_xf(Xf A, Xf B) {
+  Xf C;
+  C.q.s = A.q.c * B.q.s - A.q.s * B.q.c;
+  C.q.c = A.q.c * B.q.c + A.q.s * B.q.s;
+  C.p = rot_mulT(A.q, v2(B.p.x - A.p.x, B.p.y - A.p.y));
+  return C;
+}
+__device__ __forceinline__ float dot2(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
+__device__ __forceinline__ float crossvv(V2 a, V2 b) { return a.x * b.y - a.y * b.x; }
+__device__ __forceinline__ V2 cross_vs(V2 a, float s) { return v2(s * a.y, -s * a.x); }
+__device__ __forceinline__ V2 cross_sv(float s, V2 a) { return v2(-s * a.y, s * a.x); }
+
+struct Box { V2 v[4], n[4]; };
+__device__ __forceinline__ Box box_of(float width, float length) {   // SetAsBox(width/2, length/2), FreeCar.cpp:39
+  const float hx = width / 2, hy = length / 2;
+  Box b;
+  b.v[0] = v2(-hx, -hy); b.v[1] = v2(hx, -hy); b.v[2] = v2(hx, hy); b.v[3] = v2(-hx, hy);
+  b.n[0] = v2(0.0f, -1.0f); b.n[1] = v2(1.0f, 0.0f); b.n[2] = v2(0.0f, 1.0f); b.n[3] = v2(-1.0f, 0.0f);
+  return b;
+}
+struct ClipV { V2 v; unsigned ia, ib, ta, tb; };
+
+__device__ float find_max_separation(int* edge, const Box& p1, Xf xf1, const Box& p2, Xf xf2) {
+  const Xf xf = xf_mulT_xf(xf2, xf1);
+  int best = 0;
+  float max_sep = -B2_FLT_MAX;
+  for (int i = 0; i < 4; ++i) {
+    const V2 n = rot_mul(xf.q, p1.n[i]);
+    const V2 v1 = xf_mul(xf, p1.v[i]);
+    float si = B2_FLT_MAX;
+    for (int j = 0; j < 4; ++j) {
+      const float sij = dot2(n, v2(p2.v[j].x - v1.x, p2.v[j].y - v1.y));
+      if (sij < si) si = sij;
+    }
+    if (si > max_sep) { max_sep = si; best = i; }
+  }
+  *edge = best;
+  return max_sep;
+}
+__device__ int clip_segment(ClipV* out, const ClipV* in, V2 normal, float offset, int vertex_index_a) {
+  int count = 0;
+  const float d0 = dot2(normal, in[0].v) - offset;
+  const float d1 = dot2(normal, in[1].v) - offset;
+  if (d0 <= 0.0f) out[count++] = in[0];
+  if (d1 <= 0.0f) out[count++] = in[1];
+  if (d0 * d1 < 0.0f) {
+    const float interp = d0 / (d0 - d1);
+    out[count].v = v2(in[0].v.x + interp * (in[1].v.x - in[0].v.x), in[0].v.y + interp * (in[1].v.y - in[0].v.y));
+    out[count].ia = (unsigned)vertex_index_a;
+    out[count].ib = in[0].ib;
+    out[count].ta = 0;      // e_vertex
+    out[count].tb = 1;      // e_face
+    ++count;
+  }
+  return count;
+}
+// b2CollidePolygons into the contact record m (point impulses are set by the caller); returns the point count
+__device__ int collide_boxes(float* m, const Box& A, Xf xfA, const Box& B, Xf xfB) {
+  const float total_radius = B2_POLY_RADIUS + B2_POLY_RADIUS;
+  int edgeA = 0, edgeB = 0;
+  const float sepA = find_max_separation(&edgeA, A, xfA, B, xfB);
+  if (sepA > total_radius) return 0;
+  const float sepB = find_max_separation(&edgeB, B, xfB, A, xfA);
+  if (sepB > total_radius) return 0;
+  const float k_tol = 0.1f * B2_LINEAR_SLOP;
+  const bool flip = sepB > sepA + k_tol;
+  const Box& p1 = flip ? B : A;
+  const Box& p2 = flip ? A : B;
+  const Xf xf1 = flip ? xfB : xfA, xf2 = flip ? xfA : xfB;
+  const int edge1 = flip ? edgeB : edgeA;
+  ClipV inc[2];
+  {
+    const V2 normal1 = rot_mulT(xf2.q, rot_mul(xf1.q, p1.n[edge1]));
+    int index = 0;
+    float min_dot = B2_FLT_MAX;
+    for (int i = 0; i < 4; ++i) {
+      const float d = dot2(normal1, p2.n[i]);
+      if (d < min_dot) { min_dot = d; index = i; }
+    }
+    const int i1 = index, i2 = i1 + 1 < 4 ? i1 + 1 : 0;
+    inc[0].v = xf_mul(xf2, p2.v[i1]); inc[0].ia = (unsigned)edge1; inc[0].ib = (unsigned)i1; inc[0].ta = 1; inc[0].tb = 0;
+    inc[1].v = xf_mul(xf2, p2.v[i2]); inc[1].ia = (unsigned)edge1; inc[1].ib = (unsigned)i2; inc[1].ta = 1; inc[1].tb = 0;
+  }
+  const int iv1 = edge1, iv2 = edge1 + 1 < 4 ? edge1 + 1 : 0;
+  V2 v11 = p1.v[iv1], v12 = p1.v[iv2];
+  V2 lt = v2(v12.x - v11.x, v12.y - v11.y);
+  {
+    const float len = sqrtf(lt.x * lt.x + lt.y * lt.y);
+    if (!(len < B2_FLT_EPS)) { const float inv = 1.0f / len; lt.x *= inv; lt.y *= inv; }
+  }
+  const V2 local_normal = cross_vs(lt, 1.0f);
+  const V2 plane_point = v2(0.5f * (v11.x + v12.x), 0.5f * (v11.y + v12.y));
+  const V2 tangent = rot_mul(xf1.q, lt);
+  const V2 normal = cross_vs(tangent, 1.0f);
+  v11 = xf_mul(xf1, v11);
+  v12 = xf_mul(xf1, v12);
+  const float front_offset = dot2(normal, v11);
+  const float side1 = -dot2(tangent, v11) + total_radius;
+  const float side2 = dot2(tangent, v12) + total_radius;
+  ClipV c1[2], c2[2];
+  int np = clip_segment(c1, inc, v2(-tangent.x, -tangent.y), side1, iv1);
+  if (np < 2) return 0;
+  np = clip_segment(c2, c1, tangent, side2, iv2);
+  if (np < 2) return 0;
+  m[CS_LN] = local_normal.x; m[CS_LN + 1] = local_normal.y;
+  m[CS_LP] = plane_point.x; m[CS_LP + 1] = plane_point.y;
+  m[CS_TYPE] = flip ? 2.0f : 1.0f;                         // e_faceB : e_faceA
+  int pc = 0;
+  for (int i = 0; i < 2; ++i) {
+    const float separation = dot2(normal, c2[i].v) - front_offset;
+    if (separation <= total_radius) {
+      const V2 lp = xf_mulT(xf2, c2[i].v);
+      m[5 * pc + 0] = lp.x; m[5 * pc + 1] = lp.y;
+      unsigned ia = c2[i].ia, ib = c2[i].ib, ta = c2[i].ta, tb = c2[i].tb;
+      if (flip) { unsigned t = ia; ia = ib; ib = t; t = ta; ta = tb; tb = t; }
+      m[5 * pc + 4] = __uint_as_float(ia | (ib << 8) | (ta << 16) | (tb << 24));
+      ++pc;
+    }
+  }
+  return pc;
+}
+
+// per-scenario body arrays in LDS, shared by the phases of one step
+struct BodyLds {
+  float cx[64], cy[64], a[64], vx[64], vy[64], w[64], sleep[64], lcx[64], lcy[64], invm[64], invi[64], px[64], py[64];
+  int awake[64];
+  unsigned long long adj[64];
+};
+
+// one island with contacts, solved by a single lane (b2Island::Solve + b2ContactSolver)
+struct Constraint {
+  int ia, ib, count, vcount;
+  float* m;
+  V2 normal, rA[2], rB[2];
+  float nmass[2], tmass[2], nimp[2], timp[2], K[4], NM[4];
+};
+__device__ void island_solve(BodyLds& B, const int* bodies, int nb, Constraint* C, int nc, float h, float dt_ratio,
+                             V2* pc, float* pa, V2* vv, float* vw) {
+  for (int i = 0; i < nb; ++i) {            // gravity / forces / damping are zero: v += +0 (a -0 becomes +0), * 1.0f
+    const int b = bodies[i];
+    pc[i] = v2(B.cx[b], B.cy[b]); pa[i] = B.a[b]; vv[i] = v2(B.vx[b] + 0.0f, B.vy[b] + 0.0f); vw[i] = B.w[b] + 0.0f;
+  }
+  const float friction = sqrtf(0.2f * 0.2f);
+  for (int c = 0; c < nc; ++c) {            // constructor + InitializeVelocityConstraints
+    Constraint& k = C[c];
+    const int gA = bodies[k.ia], gB = bodies[k.ib];
+    const float mA = B.invm[gA], mB = B.invm[gB], iA = B.invi[gA], iB = B.invi[gB];
+    k.count = k.vcount = (int)k.m[CS_COUNT];
+    for (int j = 0; j < k.count; ++j) { k.nimp[j] = dt_ratio * k.m[5 * j + 2]; k.timp[j] = dt_ratio * k.m[5 * j + 3]; }
+    const V2 cAv = pc[k.ia], cBv = pc[k.ib];
+    Xf xfA, xfB;
+    xfA.q.s = sinf(pa[k.ia]); xfA.q.c = cosf(pa[k.ia]);
+    xfB.q.s = sinf(pa[k.ib]); xfB.q.c = cosf(pa[k.ib]);
+    { const V2 r = rot_mul(xfA.q, v2(B.lcx[gA], B.lcy[gA])); xfA.p = v2(cAv.x - r.x, cAv.y - r.y); }
+    { const V2 r = rot_mul(xfB.q, v2(B.lcx[gB], B.lcy[gB])); xfB.p = v2(cBv.x - r.x, cBv.y - r.y); }
+    V2 wn, wp[2];
+    const V2 ln = v2(k.m[CS_LN], k.m[CS_LN + 1]), lpt = v2(k.m[CS_LP], k.m[CS_LP + 1]);
+    if (k.m[CS_TYPE] == 1.0f) {
+      wn = rot_mul(xfA.q, ln);
+      const V2 pp = xf_mul(xfA, lpt);
+      for (int j = 0; j < k.count; ++j) {
+        const V2 cp = xf_mul(xfB, v2(k.m[5 * j], k.m[5 * j + 1]));
+        const float t = B2_POLY_RADIUS - dot2(v2(cp.x - pp.x, cp.y - pp.y), wn);
+        const V2 a = v2(cp.x + t * wn.x, cp.y + t * wn.y);
+        const V2 b = v2(cp.x - B2_POLY_RADIUS * wn.x, cp.y - B2_POLY_RADIUS * wn.y);
+        wp[j] = v2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
+      }
+    } else {
+      wn = rot_mul(xfB.q, ln);
+      const V2 pp = xf_mul(xfB, lpt);
+      for (int j = 0; j < k.count; ++j) {
+        const V2 cp = xf_mul(xfA, v2(k.m[5 * j], k.m[5 * j + 1]));
+        const float t = B2_POLY_RADIUS - dot2(v2(cp.x - pp.x, cp.y - pp.y), wn);
+        const V2 b = v2(cp.x + t * wn.x, cp.y + t * wn.y);
+        const V2 a = v2(cp.x - B2_POLY_RADIUS * wn.x, cp.y - B2_POLY_RADIUS * wn.y);
+        wp[j] = v2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
+      }
+      wn = v2(-wn.x, -wn.y);
+    }
+    k.normal = wn;
+    for (int j = 0; j < k.count; ++j) {
+      k.rA[j] = v2(wp[j].x - cAv.x, wp[j].y - cAv.y);
+      k.rB[j] = v2(wp[j].x - cBv.x, wp[j].y - cBv.y);
+      const float rnA = crossvv(k.rA[j], wn), rnB = crossvv(k.rB[j], wn);
+      const float kn = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+      k.nmass[j] = kn > 0.0f ? 1.0f / kn : 0.0f;
+      const V2 tg = cross_vs(wn, 1.0f);
+      const float rtA = crossvv(k.rA[j], tg), rtB = crossvv(k.rB[j], tg);
+      const float kt = mA + mB + iA * rtA * rtA + iB * rtB * rtB;
+      k.tmass[j] = kt > 0.0f ? 1.0f / kt : 0.0f;
+    }
+    if (k.vcount == 2) {
+      const float rn1A = crossvv(k.rA[0], wn), rn1B = crossvv(k.rB[0], wn);
+      const float rn2A = crossvv(k.rA[1], wn), rn2B = crossvv(k.rB[1], wn);
+      const float k11 = mA + mB + iA * rn1A * rn1A + iB * rn1B * rn1B;
+      const float k22 = mA + mB + iA * rn2A * rn2A + iB * rn2B * rn2B;
+      const float k12 = mA + mB + iA * rn1A * rn2A + iB * rn1B * rn2B;
+      if (k11 * k11 < 1000.0f * (k11 * k22 - k12 * k12)) {
+        k.K[0] = k11; k.K[1] = k12; k.K[2] = k12; k.K[3] = k22;
+        float det = k11 * k22 - k12 * k12;
+        if (det != 0.0f) det = 1.0f / det;
+        k.NM[0] = det * k22; k.NM[2] = -det * k12; k.NM[1] = -det * k12; k.NM[3] = det * k11;
+      } else {
+        k.vcount = 1;
+      }
+    }
+  }
+  for (int c = 0; c < nc; ++c) {            // WarmStart
+    Constraint& k = C[c];
+    const int gA = bodies[k.ia], gB = bodies[k.ib];
+    const float mA = B.invm[gA], mB = B.invm[gB], iA = B.invi[gA], iB = B.invi[gB];
+    V2 vA = vv[k.ia], vB = vv[k.ib]; float wA = vw[k.ia], wB = vw[k.ib];
+    const V2 nrm = k.normal, tg = cross_vs(nrm, 1.0f);
+    for (int j = 0; j < k.vcount; ++j) {
+      const V2 P = v2(k.nimp[j] * nrm.x + k.timp[j] * tg.x, k.nimp[j] * nrm.y + k.timp[j] * tg.y);
+      wA -= iA * crossvv(k.rA[j], P);
+      vA.x -= mA * P.x; vA.y -= mA * P.y;
+      wB += iB * crossvv(k.rB[j], P);
+      vB.x += mB * P.x; vB.y += mB * P.y;
+    }
+    vv[k.ia] = vA; vw[k.ia] = wA; vv[k.ib] = vB; vw[k.ib] = wB;
+  }
+  for (int it = 0; it < 8; ++it)            // velocity iterations
+    for (int c = 0; c < nc; ++c) {
+      Constraint& k = C[c];
+      const int gA = bodies[k.ia], gB = bodies[k.ib];
+      const float mA = B.invm[gA], mB = B.invm[gB], iA = B.invi[gA], iB = B.invi[gB];
+      V2 vA = vv[k.ia], vB = vv[k.ib]; float wA = vw[k.ia], wB = vw[k.ib];
+      const V2 nrm = k.normal, tg = cross_vs(nrm, 1.0f);
+      auto rel_v = [&](int j) {
+        const V2 cb = cross_sv(wB, k.rB[j]), ca = cross_sv(wA, k.rA[j]);
+        return v2(vB.x + cb.x - vA.x - ca.x, vB.y + cb.y - vA.y - ca.y);
+      };
+      auto apply = [&](V2 P, int j) {
+        vA.x -= mA * P.x; vA.y -= mA * P.y; wA -= iA * crossvv(k.rA[j], P);
+        vB.x += mB * P.x; vB.y += mB * P.y; wB += iB * crossvv(k.rB[j], P);
+      };
+      for (int j = 0; j < k.vcount; ++j) {
+        const V2 dv = rel_v(j);
+        const float vt = dot2(dv, tg) - 0.0f;
+        float lambda = k.tmass[j] * (-vt);
+        const float max_f = friction * k.nimp[j];
+        const float ni = b2maxf(-max_f, b2minf(k.timp[j] + lambda, max_f));
+        lambda = ni - k.timp[j];
+        k.timp[j] = ni;
+        apply(v2(lambda * tg.x, lambda * tg.y), j);
+      }
+      if (k.vcount == 1) {
+        const V2 dv = rel_v(0);
+        const float vn = dot2(dv, nrm);
+        float lambda = -k.nmass[0] * (vn - 0.0f);
+        const float ni = b2maxf(k.nimp[0] + lambda, 0.0f);
+        lambda = ni - k.nimp[0];
+        k.nimp[0] = ni;
+        apply(v2(lambda * nrm.x, lambda * nrm.y), 0);
+      } else {
+        const V2 a = v2(k.nimp[0], k.nimp[1]);
+        const V2 dv1 = rel_v(0), dv2 = rel_v(1);
+        float vn1 = dot2(dv1, nrm), vn2 = dot2(dv2, nrm);
+        V2 b = v2(vn1 - 0.0f, vn2 - 0.0f);
+        { const V2 Ka = v2(k.K[0] * a.x + k.K[2] * a.y, k.K[1] * a.x + k.K[3] * a.y); b.x -= Ka.x; b.y -= Ka.y; }
+        V2 x;
+        bool done = false;
+        auto block_apply = [&]() {
+          const V2 d = v2(x.x - a.x, x.y - a.y);
+          const V2 P1 = v2(d.x * nrm.x, d.x * nrm.y), P2 = v2(d.y * nrm.x, d.y * nrm.y);
+          vA.x -= mA * (P1.x + P2.x); vA.y -= mA * (P1.y + P2.y);
+          wA -= iA * (crossvv(k.rA[0], P1) + crossvv(k.rA[1], P2));
+          vB.x += mB * (P1.x + P2.x); vB.y += mB * (P1.y + P2.y);
+          wB += iB * (crossvv(k.rB[0], P1) + crossvv(k.rB[1], P2));
+          k.nimp[0] = x.x; k.nimp[1] = x.y;
+          done = true;
+        };
+        { const V2 t = v2(k.NM[0] * b.x + k.NM[2] * b.y, k.NM[1] * b.x + k.NM[3] * b.y); x = v2(-t.x, -t.y); }
+        if (x.x >= 0.0f && x.y >= 0.0f) block_apply();
+        if (!done) {
+          x.x = -k.nmass[0] * b.x; x.y = 0.0f;
+          vn2 = k.K[1] * x.x + b.y;
+          if (x.x >= 0.0f && vn2 >= 0.0f) block_apply();
+        }
+        if (!done) {
+          x.x = 0.0f; x.y = -k.nmass[1] * b.y;
+          vn1 = k.K[2] * x.y + b.x;
+          if (x.y >= 0.0f && vn1 >= 0.0f) block_apply();
+        }
+        if (!done) {
+          x.x = 0.0f; x.y = 0.0f;
+          vn1 = b.x; vn2 = b.y;
+          if (vn1 >= 0.0f && vn2 >= 0.0f) block_apply();
+        }
+      }
+      vv[k.ia] = vA; vw[k.ia] = wA; vv[k.ib] = vB; vw[k.ib] = wB;
+    }
+  for (int c = 0; c < nc; ++c)              // StoreImpulses
+    for (int j = 0; j < C[c].vcount; ++j) { C[c].m[5 * j + 2] = C[c].nimp[j]; C[c].m[5 * j + 3] = C[c].timp[j]; }
+  for (int i = 0; i < nb; ++i) {            // integrate positions
+    V2 v = vv[i]; float w = vw[i];
+    const float tx = h * v.x, ty = h * v.y;
+    if (tx * tx + ty * ty > B2_MAXTRANSLATION * B2_MAXTRANSLATION) {
+      const float ratio = B2_MAXTRANSLATION / sqrtf(tx * tx + ty * ty);
+      v.x *= ratio; v.y *= ratio;
+    }
+    const float rot = h * w;
+    if (rot * rot > B2_MAXROTATION * B2_MAXROTATION) {
+      const float ratio = B2_MAXROTATION / fabsf(rot);
+      w *= ratio;
+    }
+    pc[i].x += h * v.x; pc[i].y += h * v.y;
+    pa[i] += h * w;
+    vv[i] = v; vw[i] = w;
+  }
+  bool position_solved = false;
+  for (int it = 0; it < 3; ++it) {          // position iterations
+    float min_sep = 0.0f;
+    for (int c = 0; c < nc; ++c) {
+      Constraint& k = C[c];
+      const int gA = bodies[k.ia], gB = bodies[k.ib];
+      const float mA = B.invm[gA], mB = B.invm[gB], iA = B.invi[gA], iB = B.invi[gB];
+      V2 cAv = pc[k.ia], cBv = pc[k.ib]; float aA = pa[k.ia], aB = pa[k.ib];
+      const V2 ln = v2(k.m[CS_LN], k.m[CS_LN + 1]), lpt = v2(k.m[CS_LP], k.m[CS_LP + 1]);
+      for (int j = 0; j < k.count; ++j) {
+        Xf xfA, xfB;
+        xfA.q.s = sinf(aA); xfA.q.c = cosf(aA); xfB.q.s = sinf(aB); xfB.q.c = cosf(aB);
+        { const V2 r = rot_mul(xfA.q, v2(B.lcx[gA], B.lcy[gA])); xfA.p = v2(cAv.x - r.x, cAv.y - r.y); }
+        { const V2 r = rot_mul(xfB.q, v2(B.lcx[gB], B.lcy[gB])); xfB.p = v2(cBv.x - r.x, cBv.y - r.y); }
+        V2 nrm, point; float separation;
+        if (k.m[CS_TYPE] == 1.0f) {
+          nrm = rot_mul(xfA.q, ln);
+          const V2 pp = xf_mul(xfA, lpt);
+          const V2 cp = xf_mul(xfB, v2(k.m[5 * j], k.m[5 * j + 1]));
+          separation = dot2(v2(cp.x - pp.x, cp.y - pp.y), nrm) - B2_POLY_RADIUS - B2_POLY_RADIUS;
+          point = cp;
+        } else {
+          nrm = rot_mul(xfB.q, ln);
+          const V2 pp = xf_mul(xfB, lpt);
+          const V2 cp = xf_mul(xfA, v2(k.m[5 * j], k.m[5 * j + 1]));
+          separation = dot2(v2(cp.x - pp.x, cp.y - pp.y), nrm) - B2_POLY_RADIUS - B2_POLY_RADIUS;
+          point = cp;
+          nrm = v2(-nrm.x, -nrm.y);
+        }
+        const V2 rA = v2(point.x - cAv.x, point.y - cAv.y), rB = v2(point.x - cBv.x, point.y - cBv.y);
+        min_sep = b2minf(min_sep, separation);
+        const float Cc = b2maxf(-0.2f, b2minf(0.2f * (separation + B2_LINEAR_SLOP), 0.0f));
+        const float rnA = crossvv(rA, nrm), rnB = crossvv(rB, nrm);
+        const float K = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+        const float impulse = K > 0.0f ? -Cc / K : 0.0f;
+        const V2 P = v2(impulse * nrm.x, impulse * nrm.y);
+        cAv.x -= mA * P.x; cAv.y -= mA * P.y; aA -= iA * crossvv(rA, P);
+        cBv.x += mB * P.x; cBv.y += mB * P.y; aB += iB * crossvv(rB, P);
+      }
+      pc[k.ia] = cAv; pa[k.ia] = aA; pc[k.ib] = cBv; pa[k.ib] = aB;
+    }
+    if (min_sep >= -3.0f * B2_LINEAR_SLOP) { position_solved = true; break; }
+  }
+  float min_sleep = B2_FLT_MAX;              // copy back, SynchronizeTransform, sleep
+  for (int i = 0; i < nb; ++i) {
+    const int b = bodies[i];
+    B.cx[b] = pc[i].x; B.cy[b] = pc[i].y; B.a[b] = pa[i]; B.vx[b] = vv[i].x; B.vy[b] = vv[i].y; B.w[b] = vw[i];
+    const float qs = sinf(pa[i]), qc = cosf(pa[i]);
+    B.px[b] = B.cx[b] - (qc * B.lcx[b] - qs * B.lcy[b]);
+    B.py[b] = B.cy[b] - (qs * B.lcx[b] + qc * B.lcy[b]);
+    if (B.w[b] * B.w[b] > B2_ANGSLEEPTOL * B2_ANGSLEEPTOL ||
+        B.vx[b] * B.vx[b] + B.vy[b] * B.vy[b] > B2_LINSLEEPTOL * B2_LINSLEEPTOL) {
+      B.sleep[b] = 0.0f; min_sleep = 0.0f;
+    } else {
+      B.sleep[b] += h; min_sleep = b2minf(min_sleep, B.sleep[b]);
+    }
+  }
+  if (min_sleep >= B2_TIMETOSLEEP && position_solved)
+    for (int i = 0; i < nb; ++i) {
+      const int b = bodies[i];
+      B.awake[b] = 0; B.sleep[b] = 0.0f; B.vx[b] = B.vy[b] = 0.0f; B.w[b] = 0.0f;
+    }
+}
+
 // init_pose [S,N,4] = x, y, heading, speed; size [S,N,2] = length, width
 __global__ __launch_bounds__(256) void sim_init_kernel(int N, int E, const float* __restrict__ init_pose,
                                                        const float* __restrict__ size, const float* __restrict__ edges,
                                                        const unsigned char* __restrict__ exists,
                                                        float* __restrict__ phys, float* __restrict__ hist_states,
-                                                       unsigned char* __restrict__ coll, int Tmax1) {
+                                                       unsigned char* __restrict__ coll, int Tmax1,
+                                                       float* __restrict__ contact_state) {
+  if (contact_state) {                                   // no manifolds, no impulses, b2World::m_inv_dt0 = 0
+    const int per = N * (N - 1) / 2 * CS_STRIDE + 4;
+    float* cs = contact_state + (size_t)blockIdx.x * per;
+    for (int i = threadIdx.x; i < per; i += blockDim.x) cs[i] = 0.f;
+  }
   __shared__ float corner[64][8];
   __shared__ float box[64][4];
   __shared__ int flag_veh[64], flag_edge[64];
@@ -229,7 +661,13 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
                                                        const unsigned char* __restrict__ exists,
                                                        float* __restrict__ phys, float* __restrict__ hist_states,
                                                        unsigned char* __restrict__ coll, double* __restrict__ applied,
-                                                       int t, int Tmax1, float dt, int kinematic) {
+                                                       int t, int Tmax1, float dt, int kinematic,
+                                                       float* __restrict__ contact_state) {
+  __shared__ BodyLds B;
+  __shared__ int isl_bodies[64], isl_stack[64], isl_index[64], wake[64];
+  __shared__ V2 isl_pc[64], isl_vv[64];
+  __shared__ float isl_pa[64], isl_vw[64];
+  __shared__ Constraint isl_c[MAX_ISLAND_CONTACTS];
   __shared__ float corner[64][8];
   __shared__ float box[64][4];
   __shared__ int flag_veh[64], flag_edge[64];
@@ -308,35 +746,138 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
       float awake = p[P_AWAKE], sleep_t = p[P_SLEEP];
       if (nvx * nvx + nvy * nvy > 0.0f) { awake = 1.f; sleep_t = 0.f; }   // b2Body::SetLinearVelocity
       if (ang * ang > 0.0f) { awake = 1.f; sleep_t = 0.f; }               // b2Body::SetAngularVelocity
-      float vx = nvx, vy = nvy, w = ang;
-      // ---- b2Island::Solve (single-body island, no contacts)
-      if (awake != 0.f) {
-        const float tx = dt * vx, ty = dt * vy;
-        if (tx * tx + ty * ty > B2_MAXTRANSLATION * B2_MAXTRANSLATION) {
-          const float ratio = B2_MAXTRANSLATION / sqrtf(tx * tx + ty * ty);
-          vx *= ratio; vy *= ratio;
+      // body state into LDS for the Box2D step below
+      B.cx[tid] = p[P_CX]; B.cy[tid] = p[P_CY]; B.a[tid] = p[P_A]; B.vx[tid] = nvx; B.vy[tid] = nvy; B.w[tid] = ang;
+      B.sleep[tid] = sleep_t; B.awake[tid] = awake != 0.f; B.lcx[tid] = p[P_LCX]; B.lcy[tid] = p[P_LCY];
+      B.px[tid] = p[P_PX]; B.py[tid] = p[P_PY];
+      B.adj[tid] = 0ull; wake[tid] = 0;
+      float lx, ly;
+      local_center(size[sn * 2 + 1], L, &lx, &ly, &B.invm[tid], &B.invi[tid]);
+    }
+  }
+  if (!kinematic) {
+    // ================================================================================================ b2World::Step
+    const int NP = N * (N - 1) / 2;
+    float* cs = contact_state ? contact_state + (size_t)s * (NP * CS_STRIDE + 4) : nullptr;
+    __syncthreads();
+    if (cs) {
+      // ---- b2ContactManager::Collide / b2Contact::Update over every pair (i < j: fixture A = i, B = j)
+      for (int pr = tid; pr < NP; pr += blockDim.x) {
+        int i = 0, rem = pr;                              // pair index -> (i, j), rows of lengths N-1, N-2, ...
+        while (rem >= N - 1 - i) { rem -= N - 1 - i; ++i; }
+        const int j = i + 1 + rem;
+        if (!B.awake[i] && !B.awake[j]) continue;
+        float* m = cs + (size_t)pr * CS_STRIDE;
+        float old[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) old[k] = m[k];
+        const int old_count = (int)m[CS_COUNT];
+        const bool was_touching = m[CS_TOUCH] != 0.f;
+        Xf xfA, xfB;
+        xfA.p = v2(B.px[i], B.py[i]); xfA.q.s = sinf(B.a[i]); xfA.q.c = cosf(B.a[i]);
+        xfB.p = v2(B.px[j], B.py[j]); xfB.q.s = sinf(B.a[j]); xfB.q.c = cosf(B.a[j]);
+        const size_t si = (size_t)s * N + i, sj = (size_t)s * N + j;
+        const Box bA = box_of(size[si * 2 + 1], size[si * 2]), bB = box_of(size[sj * 2 + 1], size[sj * 2]);
+        const int cnt = collide_boxes(m, bA, xfA, bB, xfB);
+        for (int k = 0; k < cnt; ++k) {                    // match old contact ids, copy the stored impulses
+          float ni = 0.f, ti = 0.f;
+          const unsigned id2 = __float_as_uint(m[5 * k + 4]);
+          for (int l = 0; l < old_count; ++l)
+            if (__float_as_uint(old[5 * l + 4]) == id2) { ni = old[5 * l + 2]; ti = old[5 * l + 3]; break; }
+          m[5 * k + 2] = ni; m[5 * k + 3] = ti;
         }
-        const float rot = dt * w;
-        if (rot * rot > B2_MAXROTATION * B2_MAXROTATION) {
-          const float ratio = B2_MAXROTATION / fabsf(rot);
-          w *= ratio;
-        }
-        p[P_CX] += dt * vx;
-        p[P_CY] += dt * vy;
-        p[P_A] += dt * w;
-        if (w * w > B2_ANGSLEEPTOL * B2_ANGSLEEPTOL || vx * vx + vy * vy > B2_LINSLEEPTOL * B2_LINSLEEPTOL) sleep_t = 0.0f;
-        else sleep_t += dt;
-        const float qs = sinf(p[P_A]), qc = cosf(p[P_A]);                  // SynchronizeTransform
-        p[P_PX] = p[P_CX] - (qc * p[P_LCX] - qs * p[P_LCY]);
-        p[P_PY] = p[P_CY] - (qs * p[P_LCX] + qc * p[P_LCY]);
-        if (sleep_t >= B2_TIMETOSLEEP) { awake = 0.f; sleep_t = 0.f; vx = vy = 0.f; w = 0.f; }
+        m[CS_COUNT] = (float)cnt;
+        const bool touching = cnt > 0;
+        m[CS_TOUCH] = touching ? 1.f : 0.f;
+        if (touching != was_touching) { wake[i] = 1; wake[j] = 1; }
+        if (touching) { atomicOr(&B.adj[i], 1ull << j); atomicOr(&B.adj[j], 1ull << i); }
       }
-      p[P_VX] = vx; p[P_VY] = vy; p[P_W] = w; p[P_AWAKE] = awake; p[P_SLEEP] = sleep_t;
+      __syncthreads();
+      // pairs of two sleeping bodies were skipped above: their (unchanged) touching flag still links them
+      for (int pr = tid; pr < NP; pr += blockDim.x) {
+        int i = 0, rem = pr;
+        while (rem >= N - 1 - i) { rem -= N - 1 - i; ++i; }
+        const int j = i + 1 + rem;
+        if (!B.awake[i] && !B.awake[j] && cs[(size_t)pr * CS_STRIDE + CS_TOUCH] != 0.f) {
+          atomicOr(&B.adj[i], 1ull << j); atomicOr(&B.adj[j], 1ull << i);
+        }
+      }
+      if (tid < N && wake[tid]) { B.awake[tid] = 1; B.sleep[tid] = 0.f; }     // b2Body::SetAwake(true)
+      __syncthreads();
+    }
+    // ---- islands of one body: integrate on their own lanes (b2Island::Solve without contacts)
+    if (tid < N && B.adj[tid] == 0ull && B.awake[tid]) {
+      float vx = B.vx[tid] + 0.0f, vy = B.vy[tid] + 0.0f, w = B.w[tid] + 0.0f;
+      const float tx = dt * vx, ty = dt * vy;
+      if (tx * tx + ty * ty > B2_MAXTRANSLATION * B2_MAXTRANSLATION) {
+        const float ratio = B2_MAXTRANSLATION / sqrtf(tx * tx + ty * ty);
+        vx *= ratio; vy *= ratio;
+      }
+      const float rot = dt * w;
+      if (rot * rot > B2_MAXROTATION * B2_MAXROTATION) {
+        const float ratio = B2_MAXROTATION / fabsf(rot);
+        w *= ratio;
+      }
+      B.cx[tid] += dt * vx;
+      B.cy[tid] += dt * vy;
+      B.a[tid] += dt * w;
+      float sleep_t = B.sleep[tid];
+      if (w * w > B2_ANGSLEEPTOL * B2_ANGSLEEPTOL || vx * vx + vy * vy > B2_LINSLEEPTOL * B2_LINSLEEPTOL) sleep_t = 0.0f;
+      else sleep_t += dt;
+      const float qs = sinf(B.a[tid]), qc = cosf(B.a[tid]);                    // SynchronizeTransform
+      B.px[tid] = B.cx[tid] - (qc * B.lcx[tid] - qs * B.lcy[tid]);
+      B.py[tid] = B.cy[tid] - (qs * B.lcx[tid] + qc * B.lcy[tid]);
+      if (sleep_t >= B2_TIMETOSLEEP) { B.awake[tid] = 0; sleep_t = 0.f; vx = vy = 0.f; w = 0.f; }
+      B.vx[tid] = vx; B.vy[tid] = vy; B.w[tid] = w; B.sleep[tid] = sleep_t;
+    }
+    // ---- islands with contacts: b2World::Solve's depth-first search and the sequential solver, on lane 0
+    if (cs && tid == 0) {
+      const float dt_ratio = cs[(size_t)NP * CS_STRIDE] * dt;
+      unsigned long long in_island = 0ull;
+      for (int seed = N - 1; seed >= 0; --seed) {          // m_bodyList: newest body first
+        if (B.adj[seed] == 0ull || ((in_island >> seed) & 1ull) || !B.awake[seed]) continue;
+        int nb = 0, nc = 0, sc = 0;
+        isl_stack[sc++] = seed; in_island |= 1ull << seed;
+        while (sc > 0) {
+          const int b = isl_stack[--sc];
+          isl_index[b] = nb; isl_bodies[nb++] = b;
+          B.awake[b] = 1;                                  // woken without resetting the sleep timer
+          for (int o = N - 1; o >= 0; --o) {               // contact edges of b
+            if (!((B.adj[b] >> o) & 1ull)) continue;
+            const int i = b < o ? b : o, j = b < o ? o : b;
+            // pair index of (i, j)
+            const int pr = i * (2 * N - i - 1) / 2 + (j - i - 1);   // rows i of length N-1-i
+            float* m = cs + (size_t)pr * CS_STRIDE;
+            if (m[CS_TOUCH] == 2.f) continue;              // already in this island (flag restored below)
+            m[CS_TOUCH] = 2.f;
+            if (nc < MAX_ISLAND_CONTACTS) { isl_c[nc].m = m; isl_c[nc].ia = i; isl_c[nc].ib = j; ++nc; }
+            if ((in_island >> o) & 1ull) continue;
+            isl_stack[sc++] = o; in_island |= 1ull << o;
+          }
+        }
+        for (int c = 0; c < nc; ++c) {
+          isl_c[c].ia = isl_index[isl_c[c].ia]; isl_c[c].ib = isl_index[isl_c[c].ib];
+          isl_c[c].m[CS_TOUCH] = 1.f;
+        }
+        island_solve(B, isl_bodies, nb, isl_c, nc, dt, dt_ratio, isl_pc, isl_pa, isl_vv, isl_vw);
+      }
+      // contacts beyond MAX_ISLAND_CONTACTS keep their island mark: restore it
+      for (int pr = 0; pr < NP; ++pr)
+        if (cs[(size_t)pr * CS_STRIDE + CS_TOUCH] == 2.f) cs[(size_t)pr * CS_STRIDE + CS_TOUCH] = 1.f;
+      cs[(size_t)NP * CS_STRIDE] = dt > 0.0f ? 1.0f / dt : 0.0f;                // m_inv_dt0
+    }
+    __syncthreads();
+    if (tid < N) {
+      const size_t sn = (size_t)s * N + tid;
+      float* p = phys + sn * PHYS_STRIDE;
+      p[P_CX] = B.cx[tid]; p[P_CY] = B.cy[tid]; p[P_A] = B.a[tid]; p[P_PX] = B.px[tid]; p[P_PY] = B.py[tid];
+      p[P_VX] = B.vx[tid]; p[P_VY] = B.vy[tid]; p[P_W] = B.w[tid];
+      p[P_AWAKE] = B.awake[tid] ? 1.f : 0.f; p[P_SLEEP] = B.sleep[tid];
       // ---- Vehicle::Step read-back (vehicle.cc:45-55)
-      px[tid] = p[P_PX];
-      py[tid] = p[P_PY];
-      sp[tid] = sqrtf(vx * vx + vy * vy);
-      hd[tid] = (float)((double)p[P_A] + M_PI_D * 0.5f);
+      px[tid] = B.px[tid];
+      py[tid] = B.py[tid];
+      sp[tid] = sqrtf(B.vx[tid] * B.vx[tid] + B.vy[tid] * B.vy[tid]);
+      hd[tid] = (float)((double)B.a[tid] + M_PI_D * 0.5f);
       p[P_HEADING] = hd[tid]; p[P_SPEED] = sp[tid];
     }
   }
@@ -347,22 +888,22 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
 
 int launch_sim_init(int S, int N, int E, const float* init_pose, const float* size, const float* edges,
                     const unsigned char* exists, float* phys, float* hist_states, unsigned char* coll, int Tmax1,
-                    hipStream_t st) {
+                    float* contact_state, hipStream_t st) {
   if (S <= 0) return CTRLSIM_OK;
   if (N < 1 || N > 64 || E < 0) return CTRLSIM_EINVAL;
   hipLaunchKernelGGL(sim_init_kernel, dim3(S), dim3(256), 0, st, N, E, init_pose, size, edges, exists, phys, hist_states,
-                     coll, Tmax1);
+                     coll, Tmax1, contact_state);
   return ctrlsim_launch_status();
 }
 
 int launch_sim_step(int S, int N, int E, const int* act_tok, const double* act_f64, const double* disc6,
                     const float* size, const float* edges, const unsigned char* exists, float* phys,
                     float* hist_states, unsigned char* coll, double* applied, int t, int Tmax1, float dt, int kinematic,
-                    hipStream_t st) {
+                    float* contact_state, hipStream_t st) {
   if (S <= 0) return CTRLSIM_OK;
   if (N < 1 || N > 64 || E < 0 || t < 0 || t + 1 >= Tmax1 || (!act_tok && !act_f64)) return CTRLSIM_EINVAL;
   SimDiscretisation dz{disc6[0], disc6[1], disc6[2], disc6[3], (int)disc6[4], (int)disc6[5]};
   hipLaunchKernelGGL(sim_step_kernel, dim3(S), dim3(256), 0, st, N, E, act_tok, act_f64, dz, size, edges, exists, phys,
-                     hist_states, coll, applied, t, Tmax1, dt, kinematic);
+                     hist_states, coll, applied, t, Tmax1, dt, kinematic, contact_state);
   return ctrlsim_launch_status();
 }

@@ -106,7 +106,7 @@ def ctx_from_reference_layout(d: Dims, data: dict, Tq: int, device):
 
 class RolloutEngine:
     def __init__(self, cfg, weights: dict, device="cuda:0", max_ctx=256, seed=0, tilt=(0.0, 0.0, 0.0),
-                 temperature=None, nucleus=None, top_p=None, kinematic=False, model=None, use_cache=True):
+                 temperature=None, nucleus=None, top_p=None, kinematic=False, model=None, use_cache=True, contacts=True):
         self.cfg = cfg
         self.w = cfg.dataset.waymo
         self.dims = Dims(cfg)
@@ -123,6 +123,7 @@ class RolloutEngine:
         self.kinematic = int(bool(kinematic))
         self.max_ctx = int(max_ctx)
         self.use_cache = bool(use_cache)
+        self.contacts = bool(contacts) and not kinematic
         self.dt = float(cfg.nocturne.dt)
         w = self.w
         self.disc6 = (C.c_double * 6)(w.min_accel, w.max_accel, w.min_steer, w.max_steer, w.accel_discretization,
@@ -168,6 +169,8 @@ class RolloutEngine:
         self.scenario_id = torch.tensor([s.index for s in scns], dtype=torch.int64, device=dev)
         z = lambda *sh, dt=torch.float32: torch.zeros(*sh, dtype=dt, device=dev)
         self.phys = z(S, N, 20)
+        # Box2D contact manifolds + impulses per vehicle pair (None = contact-free integration)
+        self.contact_state = z(S, int(self.lib.ctrlsim_sim_contact_floats(N))) if self.contacts else None
         self.hist_states = z(S, N, Tmax1, 8)
         self.coll = z(S, N, Tmax1, 2, dt=torch.uint8)
         self.hist_tok = z(S, N, Tmax, dt=torch.int32)
@@ -200,7 +203,7 @@ class RolloutEngine:
         p = _lib.ptr
         _lib.check(self.lib.ctrlsim_sim_init(self.S, self.N, self.E, p(self.init_pose), p(self.size), p(self.edges),
                                              p(self.exists), p(self.phys), p(self.hist_states), p(self.coll),
-                                             self.steps + 1, st), "sim_init")
+                                             self.steps + 1, p(self.contact_state), st), "sim_init")
 
     # ------------------------------------------------------------------ one step
     def _chunks(self, counts):
@@ -230,7 +233,8 @@ class RolloutEngine:
         _lib.check(lib.ctrlsim_sim_step(s1 - s0, self.N, self.E, p(self.act_now[sl]) if act_f64 is None else None,
                                         p(act_f64[sl]) if act_f64 is not None else None, self.disc6, p(self.size[sl]),
                                         p(self.edges[sl]), p(self.exists[sl]), p(self.phys[sl]), p(self.hist_states[sl]),
-                                        p(self.coll[sl]), None, t, self.steps + 1, self.dt, self.kinematic, st), "sim_step")
+                                        p(self.coll[sl]), None, t, self.steps + 1, self.dt, self.kinematic,
+                                        p(self.contact_state[sl]) if self.contact_state is not None else None, st), "sim_step")
 
     def _group_build(self, t, s0=0, s1=None):
         lib, p, st, d = self.lib, _lib.ptr, _lib.stream_ptr(), self.dims

@@ -169,8 +169,10 @@ class Simulation:
         self.alive = np.ones(N, np.uint8)
         self.act = np.zeros((N, 2), np.float64)
         p = _lib.ptr
+        self.contact_state = torch.zeros(1, int(self.lib.ctrlsim_sim_contact_floats(N)), device=self.device)
         _lib.check(self.lib.ctrlsim_sim_init(1, N, self.E, p(self.init_pose), p(self.size), p(self.edges), p(self.exists),
-                                             p(self.phys), p(self.hist), p(self.coll), T1, _lib.stream_ptr()), "sim_init")
+                                             p(self.phys), p(self.hist), p(self.coll), T1, p(self.contact_state),
+                                             _lib.stream_ptr()), "sim_init")
         self._read()
 
     def _read(self):
@@ -187,6 +189,6 @@ class Simulation:
         act = torch.from_numpy(self.act[None].copy()).to(self.device)
         _lib.check(self.lib.ctrlsim_sim_step(1, self.N, self.E, None, p(act), self.disc6, p(self.size), p(self.edges),
                                              p(self.exists), p(self.phys), p(self.hist), p(self.coll), None, self.t,
-                                             self.steps + 1, float(dt), 0, _lib.stream_ptr()), "sim_step")
+                                             self.steps + 1, float(dt), 0, p(self.contact_state), _lib.stream_ptr()), "sim_step")
         self.t += 1
         self._read()

@@ -56,17 +56,24 @@ typedef struct ctrlsim_model ctrlsim_model;
  * PhysicsSimulation::Step -> FreeCar::Step + b2World::Step, Vehicle::Step, Scenario::UpdateCollision
  * (nocturne/cpp/src/vehicle.cc:25-135, physics/FreeCar.cpp:66-186, scenario.cc:266-328), AutoregressivePolicy.act
  * (policies/autoregressive_policy.py:256-274) and the state read-back of update_vehicle_data_dict
- * (evaluators/policy_evaluator.py:99-121).  Contact-free tier (no Box2D contact solver). */
+ * (evaluators/policy_evaluator.py:99-121).
+ * contact_state: [S, ctrlsim_sim_contact_floats(N)] floats owned by the caller, initialised by ctrlsim_sim_init and carried from
+ * step to step: Box2D's persistent per-pair contact manifolds with their accumulated impulses (warm starting) and
+ * b2World::m_inv_dt0.  With it the step includes Box2D's box-box contact handling between vehicles (b2CollidePolygons,
+ * islands, b2ContactSolver: third_party/box2d/src/collision/b2_collide_polygon.cpp, src/dynamics/b2_contact_solver.cpp,
+ * b2_island.cpp, b2_world.cpp); NULL = contact-free integration (vehicles pass through each other; flags still exact). */
+int64_t ctrlsim_sim_contact_floats(int N);
 int ctrlsim_sim_init(int S, int N, int E, const float* init_pose /*[S,N,4] x,y,heading,speed*/,
                      const float* size /*[S,N,2] length,width*/, const float* edges /*[S,E,4]*/,
                      const uint8_t* exists /*[S,N]*/, float* phys, float* hist_states, uint8_t* coll, int Tmax1,
-                     hipStream_t stream);
+                     float* contact_state, hipStream_t stream);
 /* act_tok [S,N] (token id, or -1 = zero action) or act_f64 [S,N,2] (accel, steer); disc6 = {min_accel, max_accel,
  * min_steer, max_steer, n_accel, n_steer}; applied (nullable) [S,N,2] f64 receives the continuous actions.
  * mode 0 = FreeCar/Box2D (what eval_sim.py executes), 1 = Object::KinematicBicycleStep (object.cc:126-137). */
 int ctrlsim_sim_step(int S, int N, int E, const int* act_tok, const double* act_f64, const double* disc6,
                      const float* size, const float* edges, const uint8_t* exists, float* phys, float* hist_states,
-                     uint8_t* coll, double* applied, int t, int Tmax1, float dt, int mode, hipStream_t stream);
+                     uint8_t* coll, double* applied, int t, int Tmax1, float dt, int mode, float* contact_state,
+                     hipStream_t stream);
 
 /* ---- focal grouping + context tensors ------------------------------------------------------------------------
  * Replaces AutoregressivePolicy.get_data (policies/autoregressive_policy.py:51-165) with

@@ -410,6 +410,65 @@ def gen_physics():
     save("physics", **out)
 
 
+def contact_scene(kind, seed):
+    """Scripted scenes in which vehicle boxes run into each other (used by gen_contacts and the tests)."""
+    r = np.random.RandomState(seed)
+    if kind == "headon":
+        n = 2
+        x = np.array([-10, 10], np.float32); y = np.array([0, r.uniform(-1.5, 1.5)], np.float32)
+        h = np.array([r.uniform(-0.2, 0.2), np.pi + r.uniform(-0.2, 0.2)], np.float32)
+        v = r.uniform(3, 12, n).astype(np.float32)
+    elif kind == "tbone":
+        n = 2
+        x = np.array([-8, r.uniform(-1, 1)], np.float32); y = np.array([0, -9], np.float32)
+        h = np.array([r.uniform(-0.1, 0.1), np.pi / 2 + r.uniform(-0.1, 0.1)], np.float32)
+        v = r.uniform(5, 10, n).astype(np.float32)
+    else:                                   # "pairs": four separate two-car encounters in one world
+        n = 8
+        x = np.zeros(n, np.float32); y = np.zeros(n, np.float32); h = np.zeros(n, np.float32)
+        for k in range(4):
+            cx, cy = 60.0 * k, 40.0 * (k % 2)
+            a = r.uniform(0, 2 * np.pi)
+            x[2 * k], y[2 * k] = cx - 9 * np.cos(a), cy - 9 * np.sin(a)
+            x[2 * k + 1], y[2 * k + 1] = cx + 9 * np.cos(a) + r.uniform(-1, 1), cy + 9 * np.sin(a) + r.uniform(-1, 1)
+            h[2 * k], h[2 * k + 1] = a + r.uniform(-0.2, 0.2), a + np.pi + r.uniform(-0.2, 0.2)
+        v = r.uniform(4, 11, n).astype(np.float32)
+    L = r.uniform(4, 5.5, n).astype(np.float32); W = r.uniform(1.8, 2.3, n).astype(np.float32)
+    steps = 40
+    acts = np.stack([r.uniform(-3, 3, (steps, n)), r.uniform(-0.3, 0.3, (steps, n))], -1)
+    return dict(L=L, W=W, x=x, y=y, h=h, v=v, acts=acts, segs=np.zeros((1, 4), np.float32) + 1e6)
+
+
+def run_scripted(sim_cls, sc):
+    sim = sim_cls(sc["L"], sc["W"], sc["x"], sc["y"], sc["h"], sc["v"], sc["segs"])
+    steps, n = sc["acts"].shape[:2]
+    traj = np.zeros((steps + 1, n, 6), np.float32); cv = np.zeros((steps + 1, n), np.uint8); body = np.zeros((steps + 1, n, 6), np.float32)
+    traj[0], cv[0], _ = sim.state(); body[0] = sim.body()
+    for t in range(steps):
+        for i in range(n):
+            sim.set_action(i, sc["acts"][t, i, 0], sc["acts"][t, i, 1])
+        sim.step(0.1)
+        traj[t + 1], cv[t + 1], _ = sim.state(); body[t + 1] = sim.body()
+    sim.close()
+    return traj, cv, body
+
+
+def gen_contacts():
+    """Vehicles colliding, through the REAL FreeCar + Box2D (contact solver active): trajectories + body velocities."""
+    out = {}
+    cases = [("headon", 3), ("headon", 10), ("tbone", 0), ("tbone", 5), ("pairs", 1), ("pairs", 2)]
+    for k, (kind, seed) in enumerate(cases):
+        sc = contact_scene(kind, seed)
+        traj, cv, body = run_scripted(RefSim, sc)
+        print(kind, seed, "vehicle-collision flags", int(cv.sum()))
+        assert cv.sum() > 0
+        for key, val in sc.items():
+            out[f"c{k}_{key}"] = val
+        out[f"c{k}_traj"] = traj; out[f"c{k}_coll_veh"] = cv; out[f"c{k}_body"] = body
+    out["n_cases"] = np.array(len(cases))
+    save("contacts", **out)
+
+
 def gen_collision():
     geo = ref_geo()
     rs = np.random.RandomState(6)
@@ -459,7 +518,7 @@ def gen_bicycle():
 
 
 ALL = dict(model=gen_model, features=gen_features, sampling=gen_sampling, physics=gen_physics,
-           collision=gen_collision, closed_loop=gen_closed_loop, bicycle=gen_bicycle)
+           collision=gen_collision, closed_loop=gen_closed_loop, bicycle=gen_bicycle, contacts=gen_contacts)
 
 if __name__ == "__main__":
     assert ref_shims.available(), "the reference tree is required to (re)generate golden vectors"

@@ -14,9 +14,20 @@
  *   Intersects(ConvexPolygon, LineSegment)                      nocturne/cpp/src/geometry/intersection.cc:200-232
  *   AABB::Intersects (strict)                                   nocturne/cpp/include/geometry/aabb.h:47-50
  *
- * Tier: CONTACT-FREE.  Box2D's contact solver (cars pushing each other apart when their boxes overlap) is
- * not restated; rollouts in which two live boxes overlap diverge from the reference after the overlap
- * (DESIGN.md "scope").  Collision FLAGS are exact in every case.
+ *   b2CollidePolygons, b2ClipSegmentToLine, b2WorldManifold    third_party/box2d/src/collision/b2_collide_polygon.cpp:26-244, b2_collision.cpp:26-90,205-237
+ *   b2Contact::Update (manifold, impulse matching, wake)        third_party/box2d/src/dynamics/b2_contact.cpp:165-245
+ *   b2World::Solve (island DFS), b2Island::Solve                third_party/box2d/src/dynamics/b2_world.cpp:393-560, b2_island.cpp:194-392
+ *   b2ContactSolver (init, warm start, velocity / block solver, position)   third_party/box2d/src/dynamics/b2_contact_solver.cpp:52-760
+ *   b2PolygonShape::ComputeMass / b2Body::ResetMassData         b2_polygon_shape.cpp:357-431, b2_body.cpp:290-354
+ *
+ * Tier: CONTACTS INCLUDED.  Box-box contacts between vehicles (friction 0.2, restitution 0, density 20, polygon skin
+ * 0.01, 8 velocity / 3 position iterations, warm starting, block solver) are restated and are bit-exact against the
+ * real Box2D for islands of two bodies.  What is NOT reproduced is the ORDER in which Box2D's dynamic tree hands
+ * out new pairs: islands with three or more bodies in simultaneous contact are solved with contacts ordered by
+ * vehicle index instead (Gauss-Seidel order differs -> low-order bits, then drift).  Broad-phase bookkeeping needs no
+ * restatement: a contact exists whenever fat AABBs overlap, which always precedes touching, and a non-touching
+ * contact carries no state.  TOI sub-stepping never triggers between two non-bullet dynamic bodies
+ * (b2_world.cpp SolveTOI).  Collision FLAGS are exact in every case.
  *
  * Pinned against oracle/_ref/libref_sim.so (the real FreeCar + Box2D + geometry sources) by
  * tests/test_sim_oracle.py and the fixtures tests/golden/physics_*.npz.
@@ -45,27 +56,34 @@ typedef struct {
   /* Object state (what Python reads) */
   float px, py, heading, speed;
   /* Box2D body: sweep.c (centre of mass), sweep.a, velocities; xf.p is (px,py) above; lc = sweep.localCenter */
-  float cx, cy, a, vx, vy, w, sleep_time, lcx, lcy;
+  float cx, cy, a, vx, vy, w, sleep_time, lcx, lcy, inv_mass, inv_i;
   int awake;
   /* FreeCar controls */
   float throttle, brake, steer;
   unsigned char coll_veh, coll_edge;
 } Veh;
 
+/* b2Manifold of one vehicle pair (i < j: fixture A = vehicle i, B = vehicle j) with the accumulated impulses */
+typedef struct { float lx, ly, ni, ti; unsigned id; } MPoint;
+typedef struct { MPoint p[2]; float lnx, lny, lpx, lpy; int type, count, touching; } Manifold;
+enum { M_FACE_A = 1, M_FACE_B = 2 };
+
 typedef struct {
   int n, n_seg;
   Veh* v;
   float* segs;
+  Manifold* man;          /* [n * n], entry i * n + j for i < j */
+  float inv_dt0;          /* b2World::m_inv_dt0 */
 } Sim;
 
 /* b2PolygonShape::SetAsBox(hx,hy) + ComputeMass(density 20) + b2Body::ResetMassData: the body's local centre
  * of mass.  Mathematically (0,0); in float32 the triangle-fan sum leaves a ~1e-8 residue that shifts the body
  * origin by an ulp now and then, so it has to be carried.  third_party/box2d/src/collision/b2_polygon_shape.cpp:36-48,
  * 357-431; src/dynamics/b2_body.cpp ResetMassData; FreeCar.cpp:34-40. */
-static void local_center(float width, float length, float* lcx, float* lcy) {
+static void local_center(float width, float length, float* lcx, float* lcy, float* inv_mass, float* inv_i) {
   float hx = width / 2, hy = length / 2;
   float vx[4] = {-hx, hx, hx, -hx}, vy[4] = {-hy, -hy, hy, hy};
-  float cx = 0.0f, cy = 0.0f, area = 0.0f;
+  float cx = 0.0f, cy = 0.0f, area = 0.0f, I = 0.0f;
   float sx = vx[0], sy = vy[0];
   const float k_inv3 = 1.0f / 3.0f;
   for (int i = 0; i < 4; ++i) {
@@ -77,14 +95,21 @@ static void local_center(float width, float length, float* lcx, float* lcy) {
     float k = ta * k_inv3;
     cx += k * (e1x + e2x);
     cy += k * (e1y + e2y);
+    float intx2 = e1x * e1x + e2x * e1x + e2x * e2x;
+    float inty2 = e1y * e1y + e2y * e1y + e2y * e2y;
+    I += (0.25f * k_inv3 * D) * (intx2 + inty2);
   }
   float mass = 20.f * area;
   float inv_area = 1.0f / area;
   cx *= inv_area; cy *= inv_area;
   float mcx = cx + sx, mcy = cy + sy;           /* massData->center */
   float lx = mass * mcx, ly = mass * mcy;       /* localCenter += massData.mass * massData.center */
-  float inv_mass = 1.0f / mass;
-  *lcx = lx * inv_mass; *lcy = ly * inv_mass;
+  float im = 1.0f / mass;
+  *lcx = lx * im; *lcy = ly * im;
+  float mI = 20.f * I;                                                   /* massData->I = density * I ... */
+  mI += mass * ((mcx * mcx + mcy * mcy) - (cx * cx + cy * cy));         /* ... shifted to the shape origin */
+  float bI = mI - mass * (*lcx * *lcx + *lcy * *lcy);                   /* b2Body: about the centre of mass */
+  *inv_mass = im; *inv_i = 1.0f / bI;
 }
 
 /* b2Body::SetTransform(position, angle): sweep.c = b2Mul(xf, localCenter) */
@@ -138,34 +163,470 @@ static void freecar_step(Veh* v, float dt) {
   v->w = ang;
 }
 
-static void island_solve(Veh* v, float h) {
-  if (!v->awake) return;
-  float tx = h * v->vx, ty = h * v->vy;
-  if (tx * tx + ty * ty > B2_MAXTRANSLATION * B2_MAXTRANSLATION) {
-    float ratio = B2_MAXTRANSLATION / sqrtf(tx * tx + ty * ty);
-    v->vx *= ratio; v->vy *= ratio;
+/* ---------------------------------------------------------------------------------------------------- Box2D step
+ * Plain-C restatement of what b2World::Step does to a world of dynamic boxes (no gravity, no damping, no joints, no
+ * bullets): contact update, islands, contact solver, integration, sleep.  Every expression keeps the operand order of
+ * the C++ source (float32, no contraction). */
+typedef struct { float x, y; } V2;
+typedef struct { float s, c; } Rot;
+typedef struct { V2 p; Rot q; } Xf;
+#define B2_LINEAR_SLOP 0.005f
+#define B2_POLY_RADIUS (2.0f * B2_LINEAR_SLOP)
+#define B2_BAUMGARTE 0.2f
+#define B2_MAX_LIN_CORR 0.2f
+#define B2_EPS 1.1920928955078125e-7f          /* FLT_EPSILON */
+#define B2_FLT_MAX 3.402823466e+38F
+
+static float b2maxf(float a, float b) { return a > b ? a : b; }     /* b2Max / b2Min as written in b2_math.h */
+static float b2minf(float a, float b) { return a < b ? a : b; }
+static V2 v2(float x, float y) { V2 r = {x, y}; return r; }
+static V2 rot_mul(Rot q, V2 v) { return v2(q.c * v.x - q.s * v.y, q.s * v.x + q.c * v.y); }
+static V2 rot_mulT(Rot q, V2 v) { return v2(q.c * v.x + q.s * v.y, -q.s * v.x + q.c * v.y); }
+static V2 xf_mul(Xf t, V2 v) { return v2((t.q.c * v.x - t.q.s * v.y) + t.p.x, (t.q.s * v.x + t.q.c * v.y) + t.p.y); }
+static V2 xf_mulT(Xf t, V2 v) {
+  float px = v.x - t.p.x, py = v.y - t.p.y;
+  return v2(t.q.c * px + t.q.s * py, -t.q.s * px + t.q.c * py);
+}
+static Xf xf_mulT_xf(Xf A, Xf B) {             /* b2MulT(A, B) */
+  Xf C;
+  C.q.s = A.q.c * B.q.s - A.q.s * B.q.c;
+  C.q.c = A.q.c * B.q.c + A.q.s * B.q.s;
+  C.p = rot_mulT(A.q, v2(B.p.x - A.p.x, B.p.y - A.p.y));
+  return C;
+}
+static float dot2(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
+static float crossvv(V2 a, V2 b) { return a.x * b.y - a.y * b.x; }
+static V2 cross_vs(V2 a, float s) { return v2(s * a.y, -s * a.x); }     /* b2Cross(vec, scalar) */
+static V2 cross_sv(float s, V2 a) { return v2(-s * a.y, s * a.x); }     /* b2Cross(scalar, vec) */
+static Xf body_xf(const Veh* v) { Xf t; t.p = v2(v->px, v->py); t.q.s = sinf(v->a); t.q.c = cosf(v->a); return t; }
+
+typedef struct { V2 v[4], n[4]; } Box;         /* b2PolygonShape::SetAsBox(width/2, length/2), FreeCar.cpp:39 */
+static Box box_of(const Veh* v) {
+  float hx = v->width / 2, hy = v->length / 2;
+  Box b;
+  b.v[0] = v2(-hx, -hy); b.v[1] = v2(hx, -hy); b.v[2] = v2(hx, hy); b.v[3] = v2(-hx, hy);
+  b.n[0] = v2(0.0f, -1.0f); b.n[1] = v2(1.0f, 0.0f); b.n[2] = v2(0.0f, 1.0f); b.n[3] = v2(-1.0f, 0.0f);
+  return b;
+}
+
+typedef struct { V2 v; unsigned char ia, ib, ta, tb; } ClipV;   /* b2ClipVertex: id.cf = indexA, indexB, typeA, typeB */
+enum { CF_VERTEX = 0, CF_FACE = 1 };
+
+static float find_max_separation(int* edge, const Box* p1, Xf xf1, const Box* p2, Xf xf2) {
+  Xf xf = xf_mulT_xf(xf2, xf1);
+  int best = 0;
+  float max_sep = -B2_FLT_MAX;
+  for (int i = 0; i < 4; ++i) {
+    V2 n = rot_mul(xf.q, p1->n[i]);
+    V2 v1 = xf_mul(xf, p1->v[i]);
+    float si = B2_FLT_MAX;
+    for (int j = 0; j < 4; ++j) {
+      float sij = dot2(n, v2(p2->v[j].x - v1.x, p2->v[j].y - v1.y));
+      if (sij < si) si = sij;
+    }
+    if (si > max_sep) { max_sep = si; best = i; }
   }
-  float rot = h * v->w;
-  if (rot * rot > B2_MAXROTATION * B2_MAXROTATION) {
-    float ratio = B2_MAXROTATION / fabsf(rot);
-    v->w *= ratio;
+  *edge = best;
+  return max_sep;
+}
+
+static int clip_segment(ClipV out[2], const ClipV in[2], V2 normal, float offset, int vertex_index_a) {
+  int count = 0;
+  float d0 = dot2(normal, in[0].v) - offset;
+  float d1 = dot2(normal, in[1].v) - offset;
+  if (d0 <= 0.0f) out[count++] = in[0];
+  if (d1 <= 0.0f) out[count++] = in[1];
+  if (d0 * d1 < 0.0f) {
+    float interp = d0 / (d0 - d1);
+    out[count].v = v2(in[0].v.x + interp * (in[1].v.x - in[0].v.x), in[0].v.y + interp * (in[1].v.y - in[0].v.y));
+    out[count].ia = (unsigned char)vertex_index_a;
+    out[count].ib = in[0].ib;
+    out[count].ta = CF_VERTEX;
+    out[count].tb = CF_FACE;
+    ++count;
   }
-  v->cx += h * v->vx; v->cy += h * v->vy;
-  v->a += h * v->w;
-  if (v->w * v->w > B2_ANGSLEEPTOL * B2_ANGSLEEPTOL ||
-      v->vx * v->vx + v->vy * v->vy > B2_LINSLEEPTOL * B2_LINSLEEPTOL) {
-    v->sleep_time = 0.0f;
-  } else {
-    v->sleep_time += h;
+  return count;
+}
+
+/* b2CollidePolygons; impulses of the points are left untouched (set by contact_update) */
+static void collide_boxes(Manifold* m, const Box* A, Xf xfA, const Box* B, Xf xfB) {
+  m->count = 0;
+  const float total_radius = B2_POLY_RADIUS + B2_POLY_RADIUS;
+  int edgeA = 0, edgeB = 0;
+  float sepA = find_max_separation(&edgeA, A, xfA, B, xfB);
+  if (sepA > total_radius) return;
+  float sepB = find_max_separation(&edgeB, B, xfB, A, xfA);
+  if (sepB > total_radius) return;
+  const Box *p1, *p2;
+  Xf xf1, xf2;
+  int edge1, flip;
+  const float k_tol = 0.1f * B2_LINEAR_SLOP;
+  if (sepB > sepA + k_tol) { p1 = B; p2 = A; xf1 = xfB; xf2 = xfA; edge1 = edgeB; m->type = M_FACE_B; flip = 1; }
+  else { p1 = A; p2 = B; xf1 = xfA; xf2 = xfB; edge1 = edgeA; m->type = M_FACE_A; flip = 0; }
+  /* b2FindIncidentEdge */
+  ClipV inc[2];
+  {
+    V2 normal1 = rot_mulT(xf2.q, rot_mul(xf1.q, p1->n[edge1]));
+    int index = 0;
+    float min_dot = B2_FLT_MAX;
+    for (int i = 0; i < 4; ++i) {
+      float d = dot2(normal1, p2->n[i]);
+      if (d < min_dot) { min_dot = d; index = i; }
+    }
+    int i1 = index, i2 = i1 + 1 < 4 ? i1 + 1 : 0;
+    inc[0].v = xf_mul(xf2, p2->v[i1]); inc[0].ia = (unsigned char)edge1; inc[0].ib = (unsigned char)i1; inc[0].ta = CF_FACE; inc[0].tb = CF_VERTEX;
+    inc[1].v = xf_mul(xf2, p2->v[i2]); inc[1].ia = (unsigned char)edge1; inc[1].ib = (unsigned char)i2; inc[1].ta = CF_FACE; inc[1].tb = CF_VERTEX;
   }
-  {                                             /* b2Body::SynchronizeTransform (b2_island.cpp copy-back) */
-    float qs = sinf(v->a), qc = cosf(v->a);
-    v->px = v->cx - (qc * v->lcx - qs * v->lcy);
-    v->py = v->cy - (qs * v->lcx + qc * v->lcy);
+  int iv1 = edge1, iv2 = edge1 + 1 < 4 ? edge1 + 1 : 0;
+  V2 v11 = p1->v[iv1], v12 = p1->v[iv2];
+  V2 lt = v2(v12.x - v11.x, v12.y - v11.y);
+  {                                               /* b2Vec2::Normalize */
+    float len = sqrtf(lt.x * lt.x + lt.y * lt.y);
+    if (!(len < B2_EPS)) { float inv = 1.0f / len; lt.x *= inv; lt.y *= inv; }
   }
-  if (v->sleep_time >= B2_TIMETOSLEEP) {  /* single-body island, positionSolved is true without contacts */
-    v->awake = 0; v->sleep_time = 0.0f; v->vx = v->vy = 0.0f; v->w = 0.0f;
+  V2 local_normal = cross_vs(lt, 1.0f);
+  V2 plane_point = v2(0.5f * (v11.x + v12.x), 0.5f * (v11.y + v12.y));
+  V2 tangent = rot_mul(xf1.q, lt);
+  V2 normal = cross_vs(tangent, 1.0f);
+  v11 = xf_mul(xf1, v11);
+  v12 = xf_mul(xf1, v12);
+  float front_offset = dot2(normal, v11);
+  float side1 = -dot2(tangent, v11) + total_radius;
+  float side2 = dot2(tangent, v12) + total_radius;
+  ClipV c1[2], c2[2];
+  int np = clip_segment(c1, inc, v2(-tangent.x, -tangent.y), side1, iv1);
+  if (np < 2) return;
+  np = clip_segment(c2, c1, tangent, side2, iv2);
+  if (np < 2) return;
+  m->lnx = local_normal.x; m->lny = local_normal.y;
+  m->lpx = plane_point.x; m->lpy = plane_point.y;
+  int pc = 0;
+  for (int i = 0; i < 2; ++i) {
+    float separation = dot2(normal, c2[i].v) - front_offset;
+    if (separation <= total_radius) {
+      MPoint* cp = &m->p[pc];
+      V2 lp = xf_mulT(xf2, c2[i].v);
+      cp->lx = lp.x; cp->ly = lp.y;
+      unsigned char ia = c2[i].ia, ib = c2[i].ib, ta = c2[i].ta, tb = c2[i].tb;
+      if (flip) { unsigned char t; t = ia; ia = ib; ib = t; t = ta; ta = tb; tb = t; }
+      cp->id = (unsigned)ia | ((unsigned)ib << 8) | ((unsigned)ta << 16) | ((unsigned)tb << 24);
+      ++pc;
+    }
   }
+  m->count = pc;
+}
+
+/* b2ContactManager::Collide + b2Contact::Update over every vehicle pair */
+static void contacts_update(Sim* s) {
+  int n = s->n;
+  for (int i = 0; i < n; ++i)
+    for (int j = i + 1; j < n; ++j) {
+      Veh *A = &s->v[i], *B = &s->v[j];
+      if (!A->awake && !B->awake) continue;
+      Manifold* m = &s->man[i * n + j];
+      Manifold old = *m;
+      Box bA = box_of(A), bB = box_of(B);
+      collide_boxes(m, &bA, body_xf(A), &bB, body_xf(B));
+      int touching = m->count > 0;
+      for (int k = 0; k < m->count; ++k) {
+        MPoint* mp2 = &m->p[k];
+        mp2->ni = 0.0f; mp2->ti = 0.0f;
+        for (int l = 0; l < old.count; ++l)
+          if (old.p[l].id == mp2->id) { mp2->ni = old.p[l].ni; mp2->ti = old.p[l].ti; break; }
+      }
+      if (touching != old.touching) { set_awake_true(A); set_awake_true(B); }
+      m->touching = touching;
+    }
+}
+
+typedef struct {                      /* b2ContactVelocityConstraint + b2ContactPositionConstraint of one contact */
+  int ia, ib, count, vcount;          /* island body indices; manifold points; points the velocity solver uses */
+  Manifold* m;
+  V2 normal, rA[2], rB[2];
+  float nmass[2], tmass[2], nimp[2], timp[2];
+  float K[4], NM[4];                  /* ex.x, ex.y, ey.x, ey.y */
+} Constraint;
+
+static void island_solve(Sim* s, const int* bodies, int nb, Manifold** contacts, const int* cA, const int* cB, int nc, float h,
+                         float dt_ratio) {
+  V2* pc = (V2*)malloc(sizeof(V2) * nb); float* pa = (float*)malloc(sizeof(float) * nb);
+  V2* vv = (V2*)malloc(sizeof(V2) * nb); float* vw = (float*)malloc(sizeof(float) * nb);
+  Constraint* C = (Constraint*)malloc(sizeof(Constraint) * (nc > 0 ? nc : 1));
+  for (int i = 0; i < nb; ++i) {      /* gravity, forces, torque, damping are zero: v += +0 (turns a -0 into +0), then * 1.0f */
+    const Veh* b = &s->v[bodies[i]];
+    pc[i] = v2(b->cx, b->cy); pa[i] = b->a; vv[i] = v2(b->vx + 0.0f, b->vy + 0.0f); vw[i] = b->w + 0.0f;
+  }
+  const float friction = sqrtf(0.2f * 0.2f);             /* b2MixFriction of two default fixtures */
+  /* ---- constructor + InitializeVelocityConstraints */
+  for (int c = 0; c < nc; ++c) {
+    Constraint* k = &C[c];
+    k->m = contacts[c]; k->ia = cA[c]; k->ib = cB[c]; k->count = k->vcount = k->m->count;
+    const Veh *bA = &s->v[bodies[k->ia]], *bB = &s->v[bodies[k->ib]];
+    float mA = bA->inv_mass, mB = bB->inv_mass, iA = bA->inv_i, iB = bB->inv_i;
+    for (int j = 0; j < k->count; ++j) { k->nimp[j] = dt_ratio * k->m->p[j].ni; k->timp[j] = dt_ratio * k->m->p[j].ti; }
+    V2 cAv = pc[k->ia], cBv = pc[k->ib];
+    Xf xfA, xfB;
+    xfA.q.s = sinf(pa[k->ia]); xfA.q.c = cosf(pa[k->ia]);
+    xfB.q.s = sinf(pa[k->ib]); xfB.q.c = cosf(pa[k->ib]);
+    { V2 r = rot_mul(xfA.q, v2(bA->lcx, bA->lcy)); xfA.p = v2(cAv.x - r.x, cAv.y - r.y); }
+    { V2 r = rot_mul(xfB.q, v2(bB->lcx, bB->lcy)); xfB.p = v2(cBv.x - r.x, cBv.y - r.y); }
+    /* b2WorldManifold::Initialize */
+    V2 wn, wp[2];
+    if (k->m->type == M_FACE_A) {
+      wn = rot_mul(xfA.q, v2(k->m->lnx, k->m->lny));
+      V2 pp = xf_mul(xfA, v2(k->m->lpx, k->m->lpy));
+      for (int j = 0; j < k->count; ++j) {
+        V2 cp = xf_mul(xfB, v2(k->m->p[j].lx, k->m->p[j].ly));
+        float t = B2_POLY_RADIUS - dot2(v2(cp.x - pp.x, cp.y - pp.y), wn);
+        V2 a = v2(cp.x + t * wn.x, cp.y + t * wn.y);
+        V2 b = v2(cp.x - B2_POLY_RADIUS * wn.x, cp.y - B2_POLY_RADIUS * wn.y);
+        wp[j] = v2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
+      }
+    } else {
+      wn = rot_mul(xfB.q, v2(k->m->lnx, k->m->lny));
+      V2 pp = xf_mul(xfB, v2(k->m->lpx, k->m->lpy));
+      for (int j = 0; j < k->count; ++j) {
+        V2 cp = xf_mul(xfA, v2(k->m->p[j].lx, k->m->p[j].ly));
+        float t = B2_POLY_RADIUS - dot2(v2(cp.x - pp.x, cp.y - pp.y), wn);
+        V2 b = v2(cp.x + t * wn.x, cp.y + t * wn.y);
+        V2 a = v2(cp.x - B2_POLY_RADIUS * wn.x, cp.y - B2_POLY_RADIUS * wn.y);
+        wp[j] = v2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
+      }
+      wn = v2(-wn.x, -wn.y);
+    }
+    k->normal = wn;
+    for (int j = 0; j < k->count; ++j) {
+      k->rA[j] = v2(wp[j].x - cAv.x, wp[j].y - cAv.y);
+      k->rB[j] = v2(wp[j].x - cBv.x, wp[j].y - cBv.y);
+      float rnA = crossvv(k->rA[j], wn), rnB = crossvv(k->rB[j], wn);
+      float kn = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+      k->nmass[j] = kn > 0.0f ? 1.0f / kn : 0.0f;
+      V2 tg = cross_vs(wn, 1.0f);
+      float rtA = crossvv(k->rA[j], tg), rtB = crossvv(k->rB[j], tg);
+      float kt = mA + mB + iA * rtA * rtA + iB * rtB * rtB;
+      k->tmass[j] = kt > 0.0f ? 1.0f / kt : 0.0f;
+      /* restitution 0: velocityBias = -0 * vRel = 0 in every branch */
+    }
+    if (k->vcount == 2) {
+      float rn1A = crossvv(k->rA[0], wn), rn1B = crossvv(k->rB[0], wn);
+      float rn2A = crossvv(k->rA[1], wn), rn2B = crossvv(k->rB[1], wn);
+      float k11 = mA + mB + iA * rn1A * rn1A + iB * rn1B * rn1B;
+      float k22 = mA + mB + iA * rn2A * rn2A + iB * rn2B * rn2B;
+      float k12 = mA + mB + iA * rn1A * rn2A + iB * rn1B * rn2B;
+      if (k11 * k11 < 1000.0f * (k11 * k22 - k12 * k12)) {
+        k->K[0] = k11; k->K[1] = k12; k->K[2] = k12; k->K[3] = k22;
+        float a = k11, b = k12, c2 = k12, d = k22;                /* b2Mat22::GetInverse */
+        float det = a * d - b * c2;
+        if (det != 0.0f) det = 1.0f / det;
+        k->NM[0] = det * d; k->NM[2] = -det * b; k->NM[1] = -det * c2; k->NM[3] = det * a;
+      } else {
+        k->vcount = 1;
+      }
+    }
+  }
+  /* ---- WarmStart */
+  for (int c = 0; c < nc; ++c) {
+    Constraint* k = &C[c];
+    const Veh *bA = &s->v[bodies[k->ia]], *bB = &s->v[bodies[k->ib]];
+    float mA = bA->inv_mass, mB = bB->inv_mass, iA = bA->inv_i, iB = bB->inv_i;
+    V2 vA = vv[k->ia], vB = vv[k->ib]; float wA = vw[k->ia], wB = vw[k->ib];
+    V2 nrm = k->normal, tg = cross_vs(nrm, 1.0f);
+    for (int j = 0; j < k->vcount; ++j) {
+      V2 P = v2(k->nimp[j] * nrm.x + k->timp[j] * tg.x, k->nimp[j] * nrm.y + k->timp[j] * tg.y);
+      wA -= iA * crossvv(k->rA[j], P);
+      vA.x -= mA * P.x; vA.y -= mA * P.y;
+      wB += iB * crossvv(k->rB[j], P);
+      vB.x += mB * P.x; vB.y += mB * P.y;
+    }
+    vv[k->ia] = vA; vw[k->ia] = wA; vv[k->ib] = vB; vw[k->ib] = wB;
+  }
+  /* ---- 8 velocity iterations */
+  for (int it = 0; it < 8; ++it)
+    for (int c = 0; c < nc; ++c) {
+      Constraint* k = &C[c];
+      const Veh *bA = &s->v[bodies[k->ia]], *bB = &s->v[bodies[k->ib]];
+      float mA = bA->inv_mass, mB = bB->inv_mass, iA = bA->inv_i, iB = bB->inv_i;
+      V2 vA = vv[k->ia], vB = vv[k->ib]; float wA = vw[k->ia], wB = vw[k->ib];
+      V2 nrm = k->normal, tg = cross_vs(nrm, 1.0f);
+#define REL_V(j) { V2 cb = cross_sv(wB, k->rB[j]), ca = cross_sv(wA, k->rA[j]); dv = v2(vB.x + cb.x - vA.x - ca.x, vB.y + cb.y - vA.y - ca.y); }
+#define APPLY(P, j) { vA.x -= mA * P.x; vA.y -= mA * P.y; wA -= iA * crossvv(k->rA[j], P); vB.x += mB * P.x; vB.y += mB * P.y; wB += iB * crossvv(k->rB[j], P); }
+      for (int j = 0; j < k->vcount; ++j) {                /* friction first */
+        V2 dv; REL_V(j)
+        float vt = dot2(dv, tg) - 0.0f;
+        float lambda = k->tmass[j] * (-vt);
+        float max_f = friction * k->nimp[j];
+        float ni = b2maxf(-max_f, b2minf(k->timp[j] + lambda, max_f));     /* b2Clamp = b2Max(low, b2Min(a, high)) */
+        lambda = ni - k->timp[j];
+        k->timp[j] = ni;
+        V2 P = v2(lambda * tg.x, lambda * tg.y);
+        APPLY(P, j)
+      }
+      if (k->vcount == 1) {
+        for (int j = 0; j < 1; ++j) {
+          V2 dv; REL_V(j)
+          float vn = dot2(dv, nrm);
+          float lambda = -k->nmass[j] * (vn - 0.0f);
+          float ni = b2maxf(k->nimp[j] + lambda, 0.0f);
+          lambda = ni - k->nimp[j];
+          k->nimp[j] = ni;
+          V2 P = v2(lambda * nrm.x, lambda * nrm.y);
+          APPLY(P, j)
+        }
+      } else {                                             /* block solver (2-point LCP) */
+        V2 a = v2(k->nimp[0], k->nimp[1]);
+        V2 dv; REL_V(0) V2 dv1 = dv; REL_V(1) V2 dv2 = dv;
+        float vn1 = dot2(dv1, nrm), vn2 = dot2(dv2, nrm);
+        V2 b = v2(vn1 - 0.0f, vn2 - 0.0f);
+        { V2 Ka = v2(k->K[0] * a.x + k->K[2] * a.y, k->K[1] * a.x + k->K[3] * a.y); b.x -= Ka.x; b.y -= Ka.y; }
+        V2 x; int done = 0;
+#define BLOCK_APPLY { V2 d = v2(x.x - a.x, x.y - a.y); V2 P1 = v2(d.x * nrm.x, d.x * nrm.y), P2 = v2(d.y * nrm.x, d.y * nrm.y); \
+          vA.x -= mA * (P1.x + P2.x); vA.y -= mA * (P1.y + P2.y); wA -= iA * (crossvv(k->rA[0], P1) + crossvv(k->rA[1], P2)); \
+          vB.x += mB * (P1.x + P2.x); vB.y += mB * (P1.y + P2.y); wB += iB * (crossvv(k->rB[0], P1) + crossvv(k->rB[1], P2)); \
+          k->nimp[0] = x.x; k->nimp[1] = x.y; done = 1; }
+        { V2 t = v2(k->NM[0] * b.x + k->NM[2] * b.y, k->NM[1] * b.x + k->NM[3] * b.y); x = v2(-t.x, -t.y); }
+        if (x.x >= 0.0f && x.y >= 0.0f) BLOCK_APPLY
+        if (!done) {
+          x.x = -k->nmass[0] * b.x; x.y = 0.0f;
+          vn2 = k->K[1] * x.x + b.y;
+          if (x.x >= 0.0f && vn2 >= 0.0f) BLOCK_APPLY
+        }
+        if (!done) {
+          x.x = 0.0f; x.y = -k->nmass[1] * b.y;
+          vn1 = k->K[2] * x.y + b.x;
+          if (x.y >= 0.0f && vn1 >= 0.0f) BLOCK_APPLY
+        }
+        if (!done) {
+          x.x = 0.0f; x.y = 0.0f;
+          vn1 = b.x; vn2 = b.y;
+          if (vn1 >= 0.0f && vn2 >= 0.0f) BLOCK_APPLY
+        }
+      }
+      vv[k->ia] = vA; vw[k->ia] = wA; vv[k->ib] = vB; vw[k->ib] = wB;
+    }
+  /* ---- StoreImpulses */
+  for (int c = 0; c < nc; ++c)
+    for (int j = 0; j < C[c].vcount; ++j) { C[c].m->p[j].ni = C[c].nimp[j]; C[c].m->p[j].ti = C[c].timp[j]; }
+  /* ---- integrate positions */
+  for (int i = 0; i < nb; ++i) {
+    V2 v = vv[i]; float w = vw[i];
+    float tx = h * v.x, ty = h * v.y;
+    if (tx * tx + ty * ty > B2_MAXTRANSLATION * B2_MAXTRANSLATION) {
+      float ratio = B2_MAXTRANSLATION / sqrtf(tx * tx + ty * ty);
+      v.x *= ratio; v.y *= ratio;
+    }
+    float rot = h * w;
+    if (rot * rot > B2_MAXROTATION * B2_MAXROTATION) {
+      float ratio = B2_MAXROTATION / fabsf(rot);
+      w *= ratio;
+    }
+    pc[i].x += h * v.x; pc[i].y += h * v.y;
+    pa[i] += h * w;
+    vv[i] = v; vw[i] = w;
+  }
+  /* ---- 3 position iterations */
+  int position_solved = 0;
+  for (int it = 0; it < 3; ++it) {
+    float min_sep = 0.0f;
+    for (int c = 0; c < nc; ++c) {
+      Constraint* k = &C[c];
+      const Veh *bA = &s->v[bodies[k->ia]], *bB = &s->v[bodies[k->ib]];
+      float mA = bA->inv_mass, mB = bB->inv_mass, iA = bA->inv_i, iB = bB->inv_i;
+      V2 cAv = pc[k->ia], cBv = pc[k->ib]; float aA = pa[k->ia], aB = pa[k->ib];
+      for (int j = 0; j < k->count; ++j) {
+        Xf xfA, xfB;
+        xfA.q.s = sinf(aA); xfA.q.c = cosf(aA); xfB.q.s = sinf(aB); xfB.q.c = cosf(aB);
+        { V2 r = rot_mul(xfA.q, v2(bA->lcx, bA->lcy)); xfA.p = v2(cAv.x - r.x, cAv.y - r.y); }
+        { V2 r = rot_mul(xfB.q, v2(bB->lcx, bB->lcy)); xfB.p = v2(cBv.x - r.x, cBv.y - r.y); }
+        V2 nrm, point; float separation;
+        if (k->m->type == M_FACE_A) {
+          nrm = rot_mul(xfA.q, v2(k->m->lnx, k->m->lny));
+          V2 pp = xf_mul(xfA, v2(k->m->lpx, k->m->lpy));
+          V2 cp = xf_mul(xfB, v2(k->m->p[j].lx, k->m->p[j].ly));
+          separation = dot2(v2(cp.x - pp.x, cp.y - pp.y), nrm) - B2_POLY_RADIUS - B2_POLY_RADIUS;
+          point = cp;
+        } else {
+          nrm = rot_mul(xfB.q, v2(k->m->lnx, k->m->lny));
+          V2 pp = xf_mul(xfB, v2(k->m->lpx, k->m->lpy));
+          V2 cp = xf_mul(xfA, v2(k->m->p[j].lx, k->m->p[j].ly));
+          separation = dot2(v2(cp.x - pp.x, cp.y - pp.y), nrm) - B2_POLY_RADIUS - B2_POLY_RADIUS;
+          point = cp;
+          nrm = v2(-nrm.x, -nrm.y);
+        }
+        V2 rA = v2(point.x - cAv.x, point.y - cAv.y), rB = v2(point.x - cBv.x, point.y - cBv.y);
+        min_sep = b2minf(min_sep, separation);
+        float Cc = b2maxf(-B2_MAX_LIN_CORR, b2minf(B2_BAUMGARTE * (separation + B2_LINEAR_SLOP), 0.0f));
+        float rnA = crossvv(rA, nrm), rnB = crossvv(rB, nrm);
+        float K = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+        float impulse = K > 0.0f ? -Cc / K : 0.0f;
+        V2 P = v2(impulse * nrm.x, impulse * nrm.y);
+        cAv.x -= mA * P.x; cAv.y -= mA * P.y; aA -= iA * crossvv(rA, P);
+        cBv.x += mB * P.x; cBv.y += mB * P.y; aB += iB * crossvv(rB, P);
+      }
+      pc[k->ia] = cAv; pa[k->ia] = aA; pc[k->ib] = cBv; pa[k->ib] = aB;
+    }
+    if (min_sep >= -3.0f * B2_LINEAR_SLOP) { position_solved = 1; break; }
+  }
+  /* ---- copy back, SynchronizeTransform, sleep */
+  float min_sleep = B2_FLT_MAX;
+  for (int i = 0; i < nb; ++i) {
+    Veh* b = &s->v[bodies[i]];
+    b->cx = pc[i].x; b->cy = pc[i].y; b->a = pa[i]; b->vx = vv[i].x; b->vy = vv[i].y; b->w = vw[i];
+    float qs = sinf(b->a), qc = cosf(b->a);
+    b->px = b->cx - (qc * b->lcx - qs * b->lcy);
+    b->py = b->cy - (qs * b->lcx + qc * b->lcy);
+    if (b->w * b->w > B2_ANGSLEEPTOL * B2_ANGSLEEPTOL || b->vx * b->vx + b->vy * b->vy > B2_LINSLEEPTOL * B2_LINSLEEPTOL) {
+      b->sleep_time = 0.0f; min_sleep = 0.0f;
+    } else {
+      b->sleep_time += h; min_sleep = b2minf(min_sleep, b->sleep_time);
+    }
+  }
+  if (min_sleep >= B2_TIMETOSLEEP && position_solved)
+    for (int i = 0; i < nb; ++i) {
+      Veh* b = &s->v[bodies[i]];
+      b->awake = 0; b->sleep_time = 0.0f; b->vx = b->vy = 0.0f; b->w = 0.0f;
+    }
+  free(pc); free(pa); free(vv); free(vw); free(C);
+}
+
+/* b2World::Step for this world: Collide, Solve (islands by DFS over touching contacts), m_inv_dt0 */
+static void world_step(Sim* s, float dt) {
+  int n = s->n;
+  contacts_update(s);
+  float inv_dt = dt > 0.0f ? 1.0f / dt : 0.0f;
+  float dt_ratio = s->inv_dt0 * dt;
+  char* in_island = (char*)calloc(n > 0 ? n : 1, 1);
+  char* c_flag = (char*)calloc((size_t)n * n + 1, 1);
+  int* stack = (int*)malloc(sizeof(int) * (n > 0 ? n : 1));
+  int* bodies = (int*)malloc(sizeof(int) * (n > 0 ? n : 1));
+  int* isl_index = (int*)malloc(sizeof(int) * (n > 0 ? n : 1));
+  Manifold** contacts = (Manifold**)malloc(sizeof(Manifold*) * ((size_t)n * n / 2 + 1));
+  int* cA = (int*)malloc(sizeof(int) * ((size_t)n * n / 2 + 1));
+  int* cB = (int*)malloc(sizeof(int) * ((size_t)n * n / 2 + 1));
+  for (int seed = n - 1; seed >= 0; --seed) {            /* m_bodyList: newest body first */
+    if (in_island[seed] || !s->v[seed].awake) continue;
+    int nb = 0, nc = 0, sc = 0;
+    stack[sc++] = seed; in_island[seed] = 1;
+    /* contacts are recorded with vehicle ids first; island indices are filled in once the island is complete */
+    while (sc > 0) {
+      int b = stack[--sc];
+      isl_index[b] = nb; bodies[nb++] = b;
+      s->v[b].awake = 1;                                  /* wake without resetting the sleep timer */
+      for (int o = n - 1; o >= 0; --o) {                  /* contact edges (order: see file header) */
+        if (o == b) continue;
+        int i = b < o ? b : o, j = b < o ? o : b;
+        Manifold* m = &s->man[i * n + j];
+        if (c_flag[i * n + j] || !m->touching) continue;
+        c_flag[i * n + j] = 1;
+        contacts[nc] = m; cA[nc] = i; cB[nc] = j; ++nc;
+        if (in_island[o]) continue;
+        stack[sc++] = o; in_island[o] = 1;
+      }
+    }
+    for (int c = 0; c < nc; ++c) { cA[c] = isl_index[cA[c]]; cB[c] = isl_index[cB[c]]; }
+    island_solve(s, bodies, nb, contacts, cA, cB, nc, dt, dt_ratio);
+  }
+  s->inv_dt0 = inv_dt;
+  free(in_island); free(c_flag); free(stack); free(bodies); free(isl_index); free(contacts); free(cA); free(cB);
 }
 
 static void corners(const Veh* v, float* p /*[8]*/) {
@@ -267,13 +728,15 @@ void* orasim_create(int n, const float* length, const float* width, const float*
   Sim* s = (Sim*)calloc(1, sizeof(Sim));
   s->n = n; s->n_seg = n_seg;
   s->v = (Veh*)calloc(n > 0 ? n : 1, sizeof(Veh));
+  s->man = (Manifold*)calloc((size_t)n * n + 1, sizeof(Manifold));
+  s->inv_dt0 = 0.0f;
   s->segs = (float*)malloc(sizeof(float) * 4 * (n_seg > 0 ? n_seg : 1));
   if (n_seg > 0) memcpy(s->segs, segs, sizeof(float) * 4 * n_seg);
   for (int i = 0; i < n; ++i) {
     Veh* v = &s->v[i];
     v->length = length[i]; v->width = width[i];
     v->px = x[i]; v->py = y[i]; v->heading = heading[i]; v->speed = speed[i];
-    local_center(v->width, v->length, &v->lcx, &v->lcy);
+    local_center(v->width, v->length, &v->lcx, &v->lcy, &v->inv_mass, &v->inv_i);
     set_transform(v, 0.f, 0.f, (float)((double)v->heading - M_PI * 0.5f));   /* SetAngle, vehicle.cc:168 */
     set_transform(v, x[i], y[i], v->a);                                      /* SetPosition, vehicle.cc:169 */
     float c = cosf(v->heading), sn = sinf(v->heading);
@@ -306,7 +769,7 @@ void orasim_set_position(void* h, int i, float x, float y) {
 void orasim_step(void* h, float dt) {
   Sim* s = (Sim*)h;
   for (int i = 0; i < s->n; ++i) freecar_step(&s->v[i], dt);
-  for (int i = 0; i < s->n; ++i) island_solve(&s->v[i], dt);
+  world_step(s, dt);
   for (int i = 0; i < s->n; ++i) {
     Veh* v = &s->v[i];
     v->coll_veh = v->coll_edge = 0;             /* position_ <- m_xf.p (already in px,py) */
@@ -338,7 +801,7 @@ void orasim_get_body(void* h, float* out) {
 
 void orasim_destroy(void* h) {
   Sim* s = (Sim*)h;
-  free(s->v); free(s->segs); free(s);
+  free(s->v); free(s->segs); free(s->man); free(s);
 }
 
 int orageo_poly_poly(const float* a, int na, const float* b, int nb) { return poly_poly(a, na, b, nb); }

@@ -22,7 +22,7 @@ def _build():
     sim_libs.build_oracle()
 
 
-def _gpu_scripted(g, mode=0):
+def _gpu_scripted(g, mode=0, contacts=True):
     """Run the physics fixture's scripted actions through ctrlsim_sim_init/step (explicit float64 actions)."""
     lib, st, p = _lib.lib(), _lib.stream_ptr(), _lib.ptr
     steps, n = g["acts"].shape[:2]
@@ -36,11 +36,13 @@ def _gpu_scripted(g, mode=0):
     hist = torch.zeros(S, n, steps + 1, 8, device=DEV)
     coll = torch.zeros(S, n, steps + 1, 2, dtype=torch.uint8, device=DEV)
     disc = (C.c_double * 6)(-10, 10, -0.7, 0.7, 20, 50)
-    _lib.check(lib.ctrlsim_sim_init(S, n, E, p(pose), p(size), p(edges), p(exists), p(phys), p(hist), p(coll), steps + 1, st))
+    cstate = torch.full((S, int(lib.ctrlsim_sim_contact_floats(n))), float("nan"), device=DEV) if contacts else None
+    _lib.check(lib.ctrlsim_sim_init(S, n, E, p(pose), p(size), p(edges), p(exists), p(phys), p(hist), p(coll), steps + 1,
+                                    p(cstate), st))
     for t in range(steps):
         act = dev(np.tile(g["acts"][t][None], (S, 1, 1)).astype(np.float64))
         _lib.check(lib.ctrlsim_sim_step(S, n, E, None, p(act), disc, p(size), p(edges), p(exists), p(phys), p(hist), p(coll),
-                                        None, t, steps + 1, 0.1, mode, st))
+                                        None, t, steps + 1, 0.1, mode, p(cstate), st))
     torch.cuda.synchronize()
     return hist.cpu().numpy(), coll.cpu().numpy()
 
@@ -63,6 +65,30 @@ def test_sim_step_matches_reference_physics_fixture():
     assert same > 0.5
 
 
+def test_sim_step_contacts_match_reference_fixture():
+    """Vehicles colliding (tests/golden/contacts.npz: the real FreeCar + Box2D with its contact solver): the HIP step with a
+    contact-state buffer must follow the reference through and after the collisions — positions / velocities within the
+    north-star 1e-4 (device libm differs from glibc by ulps in sin/cos; the CPU oracle is bit-exact), flags identical."""
+    g = golden("contacts")
+    for k in range(int(g["n_cases"])):
+        sc = {key: g[f"c{k}_{key}"] for key in ("L", "W", "x", "y", "h", "v", "acts", "segs")}
+        hist, coll = _gpu_scripted(sc)
+        traj = g[f"c{k}_traj"]
+        assert g[f"c{k}_coll_veh"].sum() > 0
+        for s in range(hist.shape[0]):
+            got = hist[s].transpose(1, 0, 2)
+            np.testing.assert_allclose(got[..., 0], traj[..., 0], atol=1e-4, rtol=0)
+            np.testing.assert_allclose(got[..., 1], traj[..., 1], atol=1e-4, rtol=0)
+            np.testing.assert_allclose(got[..., 4], traj[..., 2], atol=1e-4, rtol=0)
+            np.testing.assert_allclose(got[..., 2], traj[..., 4], atol=1e-4, rtol=0)
+            np.testing.assert_allclose(got[..., 3], traj[..., 5], atol=1e-4, rtol=0)
+            assert np.array_equal(coll[s, :, :, 0].T, g[f"c{k}_coll_veh"])
+        # without the contact-state buffer the cars drive through each other: the fixture must tell the two apart
+        if g[f"c{k}_coll_veh"].sum() >= 8:
+            hist0, _ = _gpu_scripted(sc, contacts=False)
+            assert np.abs(hist0[0].transpose(1, 0, 2)[..., :2] - traj[..., :2]).max() > 1e-2
+
+
 def test_collision_flags_on_random_boxes():
     """Place two boxes / a segment per scenario exactly as in the collision fixture and compare flags bit-exactly."""
     g = golden("collision")
@@ -82,7 +108,7 @@ def test_collision_flags_on_random_boxes():
     phys = torch.zeros(S, N, 20, device=DEV); hist = torch.zeros(S, N, 2, 8, device=DEV)
     coll = torch.zeros(S, N, 2, 2, dtype=torch.uint8, device=DEV)
     tp, ts, tg = dev(pose), dev(size), dev(segs)        # keep the device tensors alive across the async launch
-    _lib.check(lib.ctrlsim_sim_init(S, N, E, p(tp), p(ts), p(tg), p(exists), p(phys), p(hist), p(coll), 2, st))
+    _lib.check(lib.ctrlsim_sim_init(S, N, E, p(tp), p(ts), p(tg), p(exists), p(phys), p(hist), p(coll), 2, None, st))
     torch.cuda.synchronize()
     got = coll.cpu().numpy()[:, :, 0]
     hits = 0

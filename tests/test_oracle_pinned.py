@@ -154,6 +154,55 @@ def test_sim_oracle_bit_exact_vs_live_reference_physics():
         assert np.array_equal(x, y)
 
 
+def _contact_case(g, k):
+    return {key: g[f"c{k}_{key}"] for key in ("L", "W", "x", "y", "h", "v", "acts", "segs")}
+
+
+def _run_scripted_body(sim_cls, sc):
+    sim = sim_cls(sc["L"], sc["W"], sc["x"], sc["y"], sc["h"], sc["v"], sc["segs"])
+    steps, n = sc["acts"].shape[:2]
+    traj = np.zeros((steps + 1, n, 6), np.float32); cv = np.zeros((steps + 1, n), np.uint8)
+    body = np.zeros((steps + 1, n, 6), np.float32)
+    traj[0], cv[0], _ = sim.state(); body[0] = sim.body()
+    for t in range(steps):
+        for i in range(n):
+            sim.set_action(i, sc["acts"][t, i, 0], sc["acts"][t, i, 1])
+        sim.step(0.1)
+        traj[t + 1], cv[t + 1], _ = sim.state(); body[t + 1] = sim.body()
+    sim.close()
+    return traj, cv, body
+
+
+def test_sim_oracle_contacts_bit_exact_vs_reference_fixture():
+    """tests/golden/contacts.npz: vehicles running into each other through the REAL FreeCar + Box2D (manifolds, warm-started
+    sequential impulses, block solver, position correction).  The C restatement must reproduce positions, headings,
+    speeds AND Box2D body velocities bit for bit (float32), through and after the collisions."""
+    g = golden("contacts")
+    for k in range(int(g["n_cases"])):
+        traj, cv, body = _run_scripted_body(sim_libs.OracleSim, _contact_case(g, k))
+        assert g[f"c{k}_coll_veh"].sum() > 0
+        assert np.array_equal(cv, g[f"c{k}_coll_veh"]), k
+        assert np.array_equal(traj.view(np.int32), g[f"c{k}_traj"].view(np.int32)), k
+        assert np.array_equal(body.view(np.int32), g[f"c{k}_body"].view(np.int32)), k
+
+
+@pytest.mark.skipif(not sim_libs.RefSim.available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_sim_oracle_contacts_bit_exact_vs_live_reference():
+    """Fresh random two-car encounters (and worlds of several independent encounters) against the real Box2D, live."""
+    import gen_golden
+    n_coll = 0
+    for kind in ("headon", "tbone", "pairs"):
+        for seed in range(20, 32):
+            sc = gen_golden.contact_scene(kind, seed)
+            a = _run_scripted_body(sim_libs.RefSim, sc)
+            b = _run_scripted_body(sim_libs.OracleSim, sc)
+            n_coll += int(a[1].sum())
+            for x, y in zip(a, b):
+                assert np.array_equal(x.view(x.dtype if x.dtype == np.uint8 else np.int32),
+                                      y.view(y.dtype if y.dtype == np.uint8 else np.int32)), (kind, seed)
+    assert n_coll > 100
+
+
 def test_collision_oracle_matches_reference_geometry():
     g = golden("collision")
     geo = sim_libs.oracle_geo()
