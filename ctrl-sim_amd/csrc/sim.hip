@@ -220,7 +220,14 @@ __device__ void collide_and_record(int s, int N, int E, const float* __restrict_
 #define CS_TYPE 14
 #define CS_COUNT 15
 #define CS_TOUCH 16
+#define CS_EXISTS 17     // contact exists (fat AABBs overlap since it was created)
+#define CS_STAMP 18      // creation order (larger = newer): decides the contact order inside islands
+// per-scenario tail after the NP pair records: [inv_dt0, stamp counter, new-contacts flag, move-buffer length],
+// fat AABB per proxy [N][4], moved flag [N], sweep.c0 / a0 [N][3], move buffer [4N]
+#define CS_TAIL 4
 #define MAX_ISLAND_CONTACTS 160
+#define B2_AABB_EXT 0.1f
+#define B2_AABB_MULT 4.0f
 #define B2_LINEAR_SLOP 0.005f
 #define B2_POLY_RADIUS (2.0f * B2_LINEAR_SLOP)
 #define B2_FLT_MAX 3.402823466e+38F
@@ -361,6 +368,81 @@ __device__ int collide_boxes(float* m, const Box& A, Xf xfA, const Box& B, Xf xf
     }
   }
   return pc;
+}
+
+// ---- broad phase bookkeeping: only what fixes the ORDER in which Box2D creates contacts (b2_dynamic_tree.cpp:107-195
+// MoveProxy fat AABBs, b2_broad_phase.cpp / .h BufferMove, UpdatePairs, QueryCallback; b2_fixture.cpp:156-178)
+__device__ void shape_aabb(const Box& b, Xf xf, float* bb) {      // b2PolygonShape::ComputeAABB
+  V2 lo = xf_mul(xf, b.v[0]), hi = lo;
+  for (int i = 1; i < 4; ++i) {
+    const V2 p = xf_mul(xf, b.v[i]);
+    lo = v2(b2minf(lo.x, p.x), b2minf(lo.y, p.y));
+    hi = v2(b2maxf(hi.x, p.x), b2maxf(hi.y, p.y));
+  }
+  bb[0] = lo.x - B2_POLY_RADIUS; bb[1] = lo.y - B2_POLY_RADIUS; bb[2] = hi.x + B2_POLY_RADIUS; bb[3] = hi.y + B2_POLY_RADIUS;
+}
+__device__ __forceinline__ bool aabb_contains(const float* a, const float* b) {
+  return a[0] <= b[0] && a[1] <= b[1] && b[2] <= a[2] && b[3] <= a[3];
+}
+__device__ __forceinline__ bool aabb_overlap(const float* a, const float* b) {
+  const float d1x = b[0] - a[2], d1y = b[1] - a[3], d2x = a[0] - b[2], d2y = a[1] - b[3];
+  if (d1x > 0.0f || d1y > 0.0f) return false;
+  if (d2x > 0.0f || d2y > 0.0f) return false;
+  return true;
+}
+// b2Fixture::Synchronize + b2DynamicTree::MoveProxy for one proxy; returns true when the proxy was re-inserted (moved)
+__device__ bool synchronize_fixture(float* fat, const Box& b, Xf xf1, Xf xf2) {
+  float a1[4], a2[4], c[4];
+  shape_aabb(b, xf1, a1); shape_aabb(b, xf2, a2);
+  c[0] = b2minf(a1[0], a2[0]); c[1] = b2minf(a1[1], a2[1]); c[2] = b2maxf(a1[2], a2[2]); c[3] = b2maxf(a1[3], a2[3]);
+  const float dx = 0.5f * (a2[0] + a2[2]) - 0.5f * (a1[0] + a1[2]);
+  const float dy = 0.5f * (a2[1] + a2[3]) - 0.5f * (a1[1] + a1[3]);
+  float fatn[4] = {c[0] - B2_AABB_EXT, c[1] - B2_AABB_EXT, c[2] + B2_AABB_EXT, c[3] + B2_AABB_EXT};
+  const float ddx = B2_AABB_MULT * dx, ddy = B2_AABB_MULT * dy;
+  if (ddx < 0.0f) fatn[0] += ddx; else fatn[2] += ddx;
+  if (ddy < 0.0f) fatn[1] += ddy; else fatn[3] += ddy;
+  if (aabb_contains(fat, c)) {
+    const float huge[4] = {fatn[0] - 4.0f * B2_AABB_EXT, fatn[1] - 4.0f * B2_AABB_EXT, fatn[2] + 4.0f * B2_AABB_EXT,
+                           fatn[3] + 4.0f * B2_AABB_EXT};
+    if (aabb_contains(huge, fat)) return false;
+  }
+  fat[0] = fatn[0]; fat[1] = fatn[1]; fat[2] = fatn[2]; fat[3] = fatn[3];
+  return true;
+}
+// b2BroadPhase::UpdatePairs + b2ContactManager::AddPair, one lane.  tail: see CS_TAIL; hits of one query are taken in
+// ascending proxy order (the dynamic tree's own traversal order is not reproduced).
+__device__ void find_new_contacts(float* cs, int N, int NP) {
+  float* tail = cs + (size_t)NP * CS_STRIDE;
+  float* fat = tail + CS_TAIL;
+  float* moved = fat + 4 * N;
+  float* move_buf = moved + N + 3 * N;
+  const int n_move = (int)tail[3];
+  int stamp = (int)tail[1];
+  for (int k = 0; k < n_move; ++k) {
+    const int q = (int)move_buf[k];
+    const float* fq = fat + 4 * q;
+    for (int o = 0; o < N; ++o) {
+      if (o == q || !aabb_overlap(fat + 4 * o, fq)) continue;
+      if (moved[o] != 0.f && o > q) continue;
+      const int i = o < q ? o : q, j = o < q ? q : o;
+      float* m = cs + (size_t)(i * (2 * N - i - 1) / 2 + (j - i - 1)) * CS_STRIDE;
+      if (m[CS_EXISTS] != 0.f) continue;
+      for (int z = 0; z < CS_STRIDE; ++z) m[z] = 0.f;
+      m[CS_EXISTS] = 1.f;
+      m[CS_STAMP] = (float)(++stamp);
+    }
+  }
+  for (int k = 0; k < n_move; ++k) moved[(int)move_buf[k]] = 0.f;
+  tail[1] = (float)stamp;
+  tail[3] = 0.f;
+}
+__device__ __forceinline__ void buffer_move(float* cs, int N, int NP, int i) {
+  float* tail = cs + (size_t)NP * CS_STRIDE;
+  float* moved = tail + CS_TAIL + 4 * N;
+  float* move_buf = moved + N + 3 * N;
+  const int n = (int)tail[3];
+  moved[i] = 1.f;
+  if (n < 4 * N) { move_buf[n] = (float)i; tail[3] = (float)(n + 1); }
 }
 
 // per-scenario body arrays in LDS, shared by the phases of one step
@@ -623,9 +705,9 @@ __global__ __launch_bounds__(256) void sim_init_kernel(int N, int E, const float
                                                        float* __restrict__ phys, float* __restrict__ hist_states,
                                                        unsigned char* __restrict__ coll, int Tmax1,
                                                        float* __restrict__ contact_state) {
-  if (contact_state) {                                   // no manifolds, no impulses, b2World::m_inv_dt0 = 0
-    const int per = N * (N - 1) / 2 * CS_STRIDE + 4;
-    float* cs = contact_state + (size_t)blockIdx.x * per;
+  const int NP = N * (N - 1) / 2, per = NP * CS_STRIDE + CS_TAIL + 12 * N;
+  float* cs = contact_state ? contact_state + (size_t)blockIdx.x * per : nullptr;
+  if (cs) {                                              // no contacts, no impulses, b2World::m_inv_dt0 = 0
     for (int i = threadIdx.x; i < per; i += blockDim.x) cs[i] = 0.f;
   }
   __shared__ float corner[64][8];
@@ -649,6 +731,27 @@ __global__ __launch_bounds__(256) void sim_init_kernel(int N, int E, const float
     px[tid] = ip[0]; py[tid] = ip[1]; hd[tid] = heading; sp[tid] = speed;
   }
   __syncthreads();
+  if (cs && tid == 0) {
+    // proxies in creation order (vehicle.cc:137-179): CreateFixture on the body at the origin (b2DynamicTree::CreateProxy),
+    // SetAngle and SetPosition (b2Body::SetTransform -> Synchronize); contacts are looked for at the first step
+    float* tail = cs + (size_t)NP * CS_STRIDE;
+    float* fat = tail + CS_TAIL;
+    for (int i = 0; i < N; ++i) {
+      const float* p = phys + ((size_t)s * N + i) * PHYS_STRIDE;
+      const Box b = box_of(size[((size_t)s * N + i) * 2 + 1], size[((size_t)s * N + i) * 2]);
+      Xf xf0; xf0.p = v2(0.f, 0.f); xf0.q.s = sinf(0.f); xf0.q.c = cosf(0.f);
+      float bb[4];
+      shape_aabb(b, xf0, bb);
+      fat[4 * i] = bb[0] - B2_AABB_EXT; fat[4 * i + 1] = bb[1] - B2_AABB_EXT;
+      fat[4 * i + 2] = bb[2] + B2_AABB_EXT; fat[4 * i + 3] = bb[3] + B2_AABB_EXT;
+      buffer_move(cs, N, NP, i);
+      Xf xfa; xfa.p = v2(0.f, 0.f); xfa.q.s = sinf(p[P_A]); xfa.q.c = cosf(p[P_A]);
+      if (synchronize_fixture(fat + 4 * i, b, xfa, xfa)) buffer_move(cs, N, NP, i);
+      Xf xfp = xfa; xfp.p = v2(p[P_PX], p[P_PY]);
+      if (synchronize_fixture(fat + 4 * i, b, xfp, xfp)) buffer_move(cs, N, NP, i);
+    }
+    tail[2] = 1.f;                                       // m_newContacts
+  }
   collide_and_record(s, N, E, size, edges, exists, hist_states, coll, 0, Tmax1, corner, box, flag_veh, flag_edge, px, py,
                      hd, sp);
 }
@@ -664,7 +767,7 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
                                                        int t, int Tmax1, float dt, int kinematic,
                                                        float* __restrict__ contact_state) {
   __shared__ BodyLds B;
-  __shared__ int isl_bodies[64], isl_stack[64], isl_index[64], wake[64];
+  __shared__ int isl_bodies[64], isl_stack[64], isl_index[64], wake[64], tele[64], in_isl[64], moved_now[64];
   __shared__ V2 isl_pc[64], isl_vv[64];
   __shared__ float isl_pa[64], isl_vw[64];
   __shared__ Constraint isl_c[MAX_ISLAND_CONTACTS];
@@ -678,9 +781,11 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
     float* p = phys + sn * PHYS_STRIDE;
     const float L = size[sn * 2 + 0];
     double accel, steer;
+    tele[tid] = 0; in_isl[tid] = 0; moved_now[tid] = 0;
     if (!exists[sn]) {                                   // autoregressive_policy.py:260-263
       accel = 0.0; steer = 0.0;
       set_transform(p, -1000000.f, -1000000.f, p[P_A]);
+      tele[tid] = 1;
     } else if (act_f64) {
       accel = act_f64[sn * 2 + 0];
       steer = act_f64[sn * 2 + 1];
@@ -758,16 +863,37 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
   if (!kinematic) {
     // ================================================================================================ b2World::Step
     const int NP = N * (N - 1) / 2;
-    float* cs = contact_state ? contact_state + (size_t)s * (NP * CS_STRIDE + 4) : nullptr;
+    float* cs = contact_state ? contact_state + (size_t)s * (NP * CS_STRIDE + CS_TAIL + 12 * N) : nullptr;
+    float* tail = cs ? cs + (size_t)NP * CS_STRIDE : nullptr;
+    float* fat = cs ? tail + CS_TAIL : nullptr;
+    float* sweep0 = cs ? fat + 4 * N + N : nullptr;
     __syncthreads();
     if (cs) {
-      // ---- b2ContactManager::Collide / b2Contact::Update over every pair (i < j: fixture A = i, B = j)
+      if (tid == 0) {
+        // teleported (non-existing) vehicles: b2Body::SetTransform synchronises the proxy and flags new contacts
+        for (int i = 0; i < N; ++i)
+          if (tele[i]) {
+            const size_t si = (size_t)s * N + i;
+            const Box b = box_of(size[si * 2 + 1], size[si * 2]);
+            Xf xf; xf.p = v2(B.px[i], B.py[i]); xf.q.s = sinf(B.a[i]); xf.q.c = cosf(B.a[i]);
+            if (synchronize_fixture(fat + 4 * i, b, xf, xf)) buffer_move(cs, N, NP, i);
+            tail[2] = 1.f;
+          }
+        if (tail[2] != 0.f) { find_new_contacts(cs, N, NP); tail[2] = 0.f; }
+      }
+      __syncthreads();
+      // ---- b2ContactManager::Collide / b2Contact::Update over the existing contacts (i < j: fixture A = i, B = j)
       for (int pr = tid; pr < NP; pr += blockDim.x) {
+        float* m = cs + (size_t)pr * CS_STRIDE;
+        if (m[CS_EXISTS] == 0.f) continue;
         int i = 0, rem = pr;                              // pair index -> (i, j), rows of lengths N-1, N-2, ...
         while (rem >= N - 1 - i) { rem -= N - 1 - i; ++i; }
         const int j = i + 1 + rem;
         if (!B.awake[i] && !B.awake[j]) continue;
-        float* m = cs + (size_t)pr * CS_STRIDE;
+        if (!aabb_overlap(fat + 4 * i, fat + 4 * j)) {   // the fat AABBs ceased to overlap: the contact is destroyed
+          for (int z = 0; z < CS_STRIDE; ++z) m[z] = 0.f;
+          continue;
+        }
         float old[10];
 #pragma unroll
         for (int k = 0; k < 10; ++k) old[k] = m[k];
@@ -787,6 +913,7 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
           m[5 * k + 2] = ni; m[5 * k + 3] = ti;
         }
         m[CS_COUNT] = (float)cnt;
+        if (cnt == 0) { m[CS_COUNT] = 0.f; }
         const bool touching = cnt > 0;
         m[CS_TOUCH] = touching ? 1.f : 0.f;
         if (touching != was_touching) { wake[i] = 1; wake[j] = 1; }
@@ -803,10 +930,12 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
         }
       }
       if (tid < N && wake[tid]) { B.awake[tid] = 1; B.sleep[tid] = 0.f; }     // b2Body::SetAwake(true)
+      if (tid < N) { sweep0[3 * tid] = B.cx[tid]; sweep0[3 * tid + 1] = B.cy[tid]; sweep0[3 * tid + 2] = B.a[tid]; }
       __syncthreads();
     }
     // ---- islands of one body: integrate on their own lanes (b2Island::Solve without contacts)
     if (tid < N && B.adj[tid] == 0ull && B.awake[tid]) {
+      in_isl[tid] = 1;
       float vx = B.vx[tid] + 0.0f, vy = B.vy[tid] + 0.0f, w = B.w[tid] + 0.0f;
       const float tx = dt * vx, ty = dt * vy;
       if (tx * tx + ty * ty > B2_MAXTRANSLATION * B2_MAXTRANSLATION) {
@@ -842,10 +971,18 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
           const int b = isl_stack[--sc];
           isl_index[b] = nb; isl_bodies[nb++] = b;
           B.awake[b] = 1;                                  // woken without resetting the sleep timer
-          for (int o = N - 1; o >= 0; --o) {               // contact edges of b
-            if (!((B.adj[b] >> o) & 1ull)) continue;
+          in_isl[b] = 1;
+          unsigned long long rem_edges = B.adj[b];         // touching contacts of b, newest contact first
+          while (rem_edges) {
+            int o = -1; float best = -1.f;
+            for (unsigned long long r2 = rem_edges; r2; r2 &= r2 - 1) {
+              const int c = __ffsll((long long)r2) - 1;
+              const int i2 = b < c ? b : c, j2 = b < c ? c : b;
+              const float st = cs[(size_t)(i2 * (2 * N - i2 - 1) / 2 + (j2 - i2 - 1)) * CS_STRIDE + CS_STAMP];
+              if (st > best) { best = st; o = c; }
+            }
+            rem_edges &= ~(1ull << o);
             const int i = b < o ? b : o, j = b < o ? o : b;
-            // pair index of (i, j)
             const int pr = i * (2 * N - i - 1) / 2 + (j - i - 1);   // rows i of length N-1-i
             float* m = cs + (size_t)pr * CS_STRIDE;
             if (m[CS_TOUCH] == 2.f) continue;              // already in this island (flag restored below)
@@ -867,6 +1004,27 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
       cs[(size_t)NP * CS_STRIDE] = dt > 0.0f ? 1.0f / dt : 0.0f;                // m_inv_dt0
     }
     __syncthreads();
+    if (cs) {
+      // ---- b2Body::SynchronizeFixtures of every body that was in an island, then b2ContactManager::FindNewContacts
+      if (tid < N && in_isl[tid]) {
+        const size_t si = (size_t)s * N + tid;
+        const Box b = box_of(size[si * 2 + 1], size[si * 2]);
+        Xf xf2; xf2.p = v2(B.px[tid], B.py[tid]); xf2.q.s = sinf(B.a[tid]); xf2.q.c = cosf(B.a[tid]);
+        Xf xf1 = xf2;
+        if (B.awake[tid]) {
+          xf1.q.s = sinf(sweep0[3 * tid + 2]); xf1.q.c = cosf(sweep0[3 * tid + 2]);
+          const V2 r = rot_mul(xf1.q, v2(B.lcx[tid], B.lcy[tid]));
+          xf1.p = v2(sweep0[3 * tid] - r.x, sweep0[3 * tid + 1] - r.y);
+        }
+        moved_now[tid] = synchronize_fixture(fat + 4 * tid, b, xf1, xf2) ? 1 : 0;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        for (int b = N - 1; b >= 0; --b)                   // m_bodyList order: newest body first
+          if (moved_now[b]) buffer_move(cs, N, NP, b);
+        find_new_contacts(cs, N, NP);
+      }
+    }
     if (tid < N) {
       const size_t sn = (size_t)s * N + tid;
       float* p = phys + sn * PHYS_STRIDE;

@@ -423,6 +423,13 @@ def contact_scene(kind, seed):
         x = np.array([-8, r.uniform(-1, 1)], np.float32); y = np.array([0, -9], np.float32)
         h = np.array([r.uniform(-0.1, 0.1), np.pi / 2 + r.uniform(-0.1, 0.1)], np.float32)
         v = r.uniform(5, 10, n).astype(np.float32)
+    elif kind == "crowd":                   # cars converging on one point: islands of three and more bodies
+        n = 8 + 4 * (seed % 3)
+        ang = np.linspace(0, 2 * np.pi, n, endpoint=False) + r.uniform(-0.1, 0.1, n)
+        rad = r.uniform(12, 22, n)
+        x = (rad * np.cos(ang)).astype(np.float32); y = (rad * np.sin(ang)).astype(np.float32)
+        h = (ang + np.pi + r.uniform(-0.15, 0.15, n)).astype(np.float32)
+        v = r.uniform(4, 10, n).astype(np.float32)
     else:                                   # "pairs": four separate two-car encounters in one world
         n = 8
         x = np.zeros(n, np.float32); y = np.zeros(n, np.float32); h = np.zeros(n, np.float32)
@@ -456,7 +463,8 @@ def run_scripted(sim_cls, sc):
 def gen_contacts():
     """Vehicles colliding, through the REAL FreeCar + Box2D (contact solver active): trajectories + body velocities."""
     out = {}
-    cases = [("headon", 3), ("headon", 10), ("tbone", 0), ("tbone", 5), ("pairs", 1), ("pairs", 2)]
+    cases = [("headon", 3), ("headon", 10), ("tbone", 0), ("tbone", 5), ("pairs", 1), ("pairs", 2), ("crowd", 0), ("crowd", 1),
+             ("crowd", 5)]
     for k, (kind, seed) in enumerate(cases):
         sc = contact_scene(kind, seed)
         traj, cv, body = run_scripted(RefSim, sc)

@@ -74,6 +74,16 @@ typedef struct {
   float* segs;
   Manifold* man;          /* [n * n], entry i * n + j for i < j */
   float inv_dt0;          /* b2World::m_inv_dt0 */
+  /* broad-phase bookkeeping, kept only to reproduce the ORDER in which Box2D creates contacts (it decides the
+   * Gauss-Seidel order inside islands of three or more bodies): fat AABB per proxy (b2DynamicTree::MoveProxy),
+   * move buffer (b2BroadPhase::BufferMove / UpdatePairs), contact existence + creation stamp per pair */
+  float* fat;             /* [n][4] lower x, y, upper x, y */
+  char* moved;            /* [n] b2TreeNode::moved */
+  int* move_buf; int n_move, cap_move;
+  char* c_exists;         /* [n * n] */
+  int* c_stamp;           /* [n * n] creation order (larger = newer) */
+  int stamp, new_contacts;
+  float* sweep0;          /* [n][3] sweep.c0, sweep.a0 of the last island solve */
 } Sim;
 
 /* b2PolygonShape::SetAsBox(hx,hy) + ComputeMass(density 20) + b2Body::ResetMassData: the body's local centre
@@ -316,27 +326,108 @@ static void collide_boxes(Manifold* m, const Box* A, Xf xfA, const Box* B, Xf xf
   m->count = pc;
 }
 
-/* b2ContactManager::Collide + b2Contact::Update over every vehicle pair */
-static void contacts_update(Sim* s) {
+/* ---- broad phase (third_party/box2d/src/collision/b2_dynamic_tree.cpp:107-195, b2_broad_phase.cpp:60-131,
+ *      include/box2d/b2_broad_phase.h:172-216, src/dynamics/b2_fixture.cpp:156-178, b2_body.cpp:447-469) */
+#define B2_AABB_EXT 0.1f
+#define B2_AABB_MULT 4.0f
+static void shape_aabb(const Veh* v, Xf xf, float* bb) {       /* b2PolygonShape::ComputeAABB */
+  Box b = box_of(v);
+  V2 lo = xf_mul(xf, b.v[0]), hi = lo;
+  for (int i = 1; i < 4; ++i) {
+    V2 p = xf_mul(xf, b.v[i]);
+    lo = v2(b2minf(lo.x, p.x), b2minf(lo.y, p.y));
+    hi = v2(b2maxf(hi.x, p.x), b2maxf(hi.y, p.y));
+  }
+  bb[0] = lo.x - B2_POLY_RADIUS; bb[1] = lo.y - B2_POLY_RADIUS; bb[2] = hi.x + B2_POLY_RADIUS; bb[3] = hi.y + B2_POLY_RADIUS;
+}
+static void buffer_move(Sim* s, int i) {
+  if (s->n_move == s->cap_move) { s->cap_move = s->cap_move ? 2 * s->cap_move : 64; s->move_buf = (int*)realloc(s->move_buf, sizeof(int) * s->cap_move); }
+  s->move_buf[s->n_move++] = i;
+}
+static int aabb_contains(const float* a, const float* b) { return a[0] <= b[0] && a[1] <= b[1] && b[2] <= a[2] && b[3] <= a[3]; }
+static int aabb_overlap(const float* a, const float* b) {      /* b2TestOverlap(aabb, aabb) */
+  float d1x = b[0] - a[2], d1y = b[1] - a[3], d2x = a[0] - b[2], d2y = a[1] - b[3];
+  if (d1x > 0.0f || d1y > 0.0f) return 0;
+  if (d2x > 0.0f || d2y > 0.0f) return 0;
+  return 1;
+}
+static void move_proxy(Sim* s, int i, const float* aabb, float dx, float dy) {
+  float fatn[4] = {aabb[0] - B2_AABB_EXT, aabb[1] - B2_AABB_EXT, aabb[2] + B2_AABB_EXT, aabb[3] + B2_AABB_EXT};
+  float ddx = B2_AABB_MULT * dx, ddy = B2_AABB_MULT * dy;
+  if (ddx < 0.0f) fatn[0] += ddx; else fatn[2] += ddx;
+  if (ddy < 0.0f) fatn[1] += ddy; else fatn[3] += ddy;
+  float* tree = s->fat + 4 * i;
+  if (aabb_contains(tree, aabb)) {
+    float huge[4] = {fatn[0] - 4.0f * B2_AABB_EXT, fatn[1] - 4.0f * B2_AABB_EXT, fatn[2] + 4.0f * B2_AABB_EXT, fatn[3] + 4.0f * B2_AABB_EXT};
+    if (aabb_contains(huge, tree)) return;
+  }
+  memcpy(tree, fatn, sizeof(fatn));
+  s->moved[i] = 1;
+  buffer_move(s, i);
+}
+static void synchronize_fixture(Sim* s, int i, Xf xf1, Xf xf2) {
+  float a1[4], a2[4], c[4];
+  shape_aabb(&s->v[i], xf1, a1); shape_aabb(&s->v[i], xf2, a2);
+  c[0] = b2minf(a1[0], a2[0]); c[1] = b2minf(a1[1], a2[1]); c[2] = b2maxf(a1[2], a2[2]); c[3] = b2maxf(a1[3], a2[3]);
+  float dx = 0.5f * (a2[0] + a2[2]) - 0.5f * (a1[0] + a1[2]);
+  float dy = 0.5f * (a2[1] + a2[3]) - 0.5f * (a1[1] + a1[3]);
+  move_proxy(s, i, c, dx, dy);
+}
+/* b2BroadPhase::UpdatePairs + b2ContactManager::AddPair.  The order in which one tree query reports its hits is a
+ * property of the dynamic tree's shape, which is not reproduced: hits are taken in ascending proxy order. */
+static void find_new_contacts(Sim* s) {
   int n = s->n;
-  for (int i = 0; i < n; ++i)
-    for (int j = i + 1; j < n; ++j) {
-      Veh *A = &s->v[i], *B = &s->v[j];
-      if (!A->awake && !B->awake) continue;
+  for (int k = 0; k < s->n_move; ++k) {
+    int q = s->move_buf[k];
+    const float* fq = s->fat + 4 * q;
+    for (int o = 0; o < n; ++o) {
+      if (o == q || !aabb_overlap(s->fat + 4 * o, fq)) continue;
+      if (s->moved[o] && o > q) continue;
+      int i = o < q ? o : q, j = o < q ? q : o;
+      if (s->c_exists[i * n + j]) continue;
+      s->c_exists[i * n + j] = 1;
+      s->c_stamp[i * n + j] = ++s->stamp;
       Manifold* m = &s->man[i * n + j];
-      Manifold old = *m;
-      Box bA = box_of(A), bB = box_of(B);
-      collide_boxes(m, &bA, body_xf(A), &bB, body_xf(B));
-      int touching = m->count > 0;
-      for (int k = 0; k < m->count; ++k) {
-        MPoint* mp2 = &m->p[k];
-        mp2->ni = 0.0f; mp2->ti = 0.0f;
-        for (int l = 0; l < old.count; ++l)
-          if (old.p[l].id == mp2->id) { mp2->ni = old.p[l].ni; mp2->ti = old.p[l].ti; break; }
-      }
-      if (touching != old.touching) { set_awake_true(A); set_awake_true(B); }
-      m->touching = touching;
+      memset(m, 0, sizeof(*m));
     }
+  }
+  for (int k = 0; k < s->n_move; ++k) s->moved[s->move_buf[k]] = 0;
+  s->n_move = 0;
+}
+
+/* b2ContactManager::Collide + b2Contact::Update over the contact list (newest contact first) */
+static int cmp_stamp_desc(const void* a, const void* b) { return ((const int*)b)[0] - ((const int*)a)[0]; }
+static void contacts_update(Sim* s) {
+  int n = s->n, nc = 0;
+  int* order = (int*)malloc(sizeof(int) * 2 * ((size_t)n * n / 2 + 1));
+  for (int i = 0; i < n; ++i)
+    for (int j = i + 1; j < n; ++j)
+      if (s->c_exists[i * n + j]) { order[2 * nc] = s->c_stamp[i * n + j]; order[2 * nc + 1] = i * n + j; ++nc; }
+  qsort(order, nc, 2 * sizeof(int), cmp_stamp_desc);
+  for (int c = 0; c < nc; ++c) {
+    int ij = order[2 * c + 1], i = ij / n, j = ij % n;
+    Veh *A = &s->v[i], *B = &s->v[j];
+    if (!A->awake && !B->awake) continue;
+    Manifold* m = &s->man[ij];
+    if (!aabb_overlap(s->fat + 4 * i, s->fat + 4 * j)) {    /* the fat AABBs ceased to overlap: contact destroyed */
+      s->c_exists[ij] = 0;
+      memset(m, 0, sizeof(*m));
+      continue;
+    }
+    Manifold old = *m;
+    Box bA = box_of(A), bB = box_of(B);
+    collide_boxes(m, &bA, body_xf(A), &bB, body_xf(B));
+    int touching = m->count > 0;
+    for (int k = 0; k < m->count; ++k) {
+      MPoint* mp2 = &m->p[k];
+      mp2->ni = 0.0f; mp2->ti = 0.0f;
+      for (int l = 0; l < old.count; ++l)
+        if (old.p[l].id == mp2->id) { mp2->ni = old.p[l].ni; mp2->ti = old.p[l].ti; break; }
+    }
+    if (touching != old.touching) { set_awake_true(A); set_awake_true(B); }
+    m->touching = touching;
+  }
+  free(order);
 }
 
 typedef struct {                      /* b2ContactVelocityConstraint + b2ContactPositionConstraint of one contact */
@@ -354,6 +445,7 @@ static void island_solve(Sim* s, const int* bodies, int nb, Manifold** contacts,
   Constraint* C = (Constraint*)malloc(sizeof(Constraint) * (nc > 0 ? nc : 1));
   for (int i = 0; i < nb; ++i) {      /* gravity, forces, torque, damping are zero: v += +0 (turns a -0 into +0), then * 1.0f */
     const Veh* b = &s->v[bodies[i]];
+    s->sweep0[3 * bodies[i]] = b->cx; s->sweep0[3 * bodies[i] + 1] = b->cy; s->sweep0[3 * bodies[i] + 2] = b->a;
     pc[i] = v2(b->cx, b->cy); pa[i] = b->a; vv[i] = v2(b->vx + 0.0f, b->vy + 0.0f); vw[i] = b->w + 0.0f;
   }
   const float friction = sqrtf(0.2f * 0.2f);             /* b2MixFriction of two default fixtures */
@@ -591,14 +683,17 @@ static void island_solve(Sim* s, const int* bodies, int nb, Manifold** contacts,
 /* b2World::Step for this world: Collide, Solve (islands by DFS over touching contacts), m_inv_dt0 */
 static void world_step(Sim* s, float dt) {
   int n = s->n;
+  if (s->new_contacts) { find_new_contacts(s); s->new_contacts = 0; }
   contacts_update(s);
   float inv_dt = dt > 0.0f ? 1.0f / dt : 0.0f;
   float dt_ratio = s->inv_dt0 * dt;
   char* in_island = (char*)calloc(n > 0 ? n : 1, 1);
+  char* was_in_island = (char*)calloc(n > 0 ? n : 1, 1);
   char* c_flag = (char*)calloc((size_t)n * n + 1, 1);
   int* stack = (int*)malloc(sizeof(int) * (n > 0 ? n : 1));
   int* bodies = (int*)malloc(sizeof(int) * (n > 0 ? n : 1));
   int* isl_index = (int*)malloc(sizeof(int) * (n > 0 ? n : 1));
+  int* edges = (int*)malloc(sizeof(int) * 2 * (n > 0 ? n : 1));
   Manifold** contacts = (Manifold**)malloc(sizeof(Manifold*) * ((size_t)n * n / 2 + 1));
   int* cA = (int*)malloc(sizeof(int) * ((size_t)n * n / 2 + 1));
   int* cB = (int*)malloc(sizeof(int) * ((size_t)n * n / 2 + 1));
@@ -606,13 +701,19 @@ static void world_step(Sim* s, float dt) {
     if (in_island[seed] || !s->v[seed].awake) continue;
     int nb = 0, nc = 0, sc = 0;
     stack[sc++] = seed; in_island[seed] = 1;
-    /* contacts are recorded with vehicle ids first; island indices are filled in once the island is complete */
     while (sc > 0) {
       int b = stack[--sc];
       isl_index[b] = nb; bodies[nb++] = b;
       s->v[b].awake = 1;                                  /* wake without resetting the sleep timer */
-      for (int o = n - 1; o >= 0; --o) {                  /* contact edges (order: see file header) */
+      int ne = 0;                                         /* b's contact edges, newest contact first */
+      for (int o = 0; o < n; ++o) {
         if (o == b) continue;
+        int i = b < o ? b : o, j = b < o ? o : b;
+        if (s->c_exists[i * n + j]) { edges[2 * ne] = s->c_stamp[i * n + j]; edges[2 * ne + 1] = o; ++ne; }
+      }
+      qsort(edges, ne, 2 * sizeof(int), cmp_stamp_desc);
+      for (int e = 0; e < ne; ++e) {
+        int o = edges[2 * e + 1];
         int i = b < o ? b : o, j = b < o ? o : b;
         Manifold* m = &s->man[i * n + j];
         if (c_flag[i * n + j] || !m->touching) continue;
@@ -625,8 +726,25 @@ static void world_step(Sim* s, float dt) {
     for (int c = 0; c < nc; ++c) { cA[c] = isl_index[cA[c]]; cB[c] = isl_index[cB[c]]; }
     island_solve(s, bodies, nb, contacts, cA, cB, nc, dt, dt_ratio);
   }
+  /* SynchronizeFixtures of every body that was in an island (m_bodyList order), then FindNewContacts */
+  for (int b = n - 1; b >= 0; --b) {
+    if (!in_island[b]) continue;
+    Veh* v = &s->v[b];
+    Xf xf2 = body_xf(v);
+    if (v->awake) {
+      Xf xf1;
+      xf1.q.s = sinf(s->sweep0[3 * b + 2]); xf1.q.c = cosf(s->sweep0[3 * b + 2]);
+      V2 r = rot_mul(xf1.q, v2(v->lcx, v->lcy));
+      xf1.p = v2(s->sweep0[3 * b] - r.x, s->sweep0[3 * b + 1] - r.y);
+      synchronize_fixture(s, b, xf1, xf2);
+    } else {
+      synchronize_fixture(s, b, xf2, xf2);
+    }
+  }
+  find_new_contacts(s);
   s->inv_dt0 = inv_dt;
-  free(in_island); free(c_flag); free(stack); free(bodies); free(isl_index); free(contacts); free(cA); free(cB);
+  free(in_island); free(was_in_island); free(c_flag); free(stack); free(bodies); free(isl_index); free(edges);
+  free(contacts); free(cA); free(cB);
 }
 
 static void corners(const Veh* v, float* p /*[8]*/) {
@@ -730,6 +848,12 @@ void* orasim_create(int n, const float* length, const float* width, const float*
   s->v = (Veh*)calloc(n > 0 ? n : 1, sizeof(Veh));
   s->man = (Manifold*)calloc((size_t)n * n + 1, sizeof(Manifold));
   s->inv_dt0 = 0.0f;
+  s->fat = (float*)calloc((size_t)4 * n + 4, sizeof(float));
+  s->moved = (char*)calloc(n + 1, 1);
+  s->c_exists = (char*)calloc((size_t)n * n + 1, 1);
+  s->c_stamp = (int*)calloc((size_t)n * n + 1, sizeof(int));
+  s->sweep0 = (float*)calloc((size_t)3 * n + 3, sizeof(float));
+  s->move_buf = NULL; s->n_move = s->cap_move = 0; s->stamp = 0; s->new_contacts = 1;
   s->segs = (float*)malloc(sizeof(float) * 4 * (n_seg > 0 ? n_seg : 1));
   if (n_seg > 0) memcpy(s->segs, segs, sizeof(float) * 4 * n_seg);
   for (int i = 0; i < n; ++i) {
@@ -737,8 +861,18 @@ void* orasim_create(int n, const float* length, const float* width, const float*
     v->length = length[i]; v->width = width[i];
     v->px = x[i]; v->py = y[i]; v->heading = heading[i]; v->speed = speed[i];
     local_center(v->width, v->length, &v->lcx, &v->lcy, &v->inv_mass, &v->inv_i);
+    {                                          /* CreateFixture on the body at the origin: b2DynamicTree::CreateProxy */
+      v->px = v->py = 0.f; v->a = 0.f;
+      float bb[4];
+      shape_aabb(v, body_xf(v), bb);
+      s->fat[4 * i] = bb[0] - B2_AABB_EXT; s->fat[4 * i + 1] = bb[1] - B2_AABB_EXT;
+      s->fat[4 * i + 2] = bb[2] + B2_AABB_EXT; s->fat[4 * i + 3] = bb[3] + B2_AABB_EXT;
+      s->moved[i] = 1; buffer_move(s, i);
+    }
     set_transform(v, 0.f, 0.f, (float)((double)v->heading - M_PI * 0.5f));   /* SetAngle, vehicle.cc:168 */
+    synchronize_fixture(s, i, body_xf(v), body_xf(v));
     set_transform(v, x[i], y[i], v->a);                                      /* SetPosition, vehicle.cc:169 */
+    synchronize_fixture(s, i, body_xf(v), body_xf(v));
     float c = cosf(v->heading), sn = sinf(v->heading);
     v->vx = v->speed * c; v->vy = v->speed * sn;        /* BaseCar::SetSpeed: plain assignment + wake */
     v->w = 0.f; v->sleep_time = 0.f; v->awake = 1;
@@ -764,6 +898,8 @@ void orasim_set_action(void* h, int i, double accel, double steer) {
 void orasim_set_position(void* h, int i, float x, float y) {
   Veh* v = &((Sim*)h)->v[i];
   set_transform(v, x, y, v->a);                 /* b2Body::SetTransform keeps the angle, does not wake */
+  synchronize_fixture((Sim*)h, i, body_xf(v), body_xf(v));
+  ((Sim*)h)->new_contacts = 1;
 }
 
 void orasim_step(void* h, float dt) {
@@ -801,7 +937,8 @@ void orasim_get_body(void* h, float* out) {
 
 void orasim_destroy(void* h) {
   Sim* s = (Sim*)h;
-  free(s->v); free(s->segs); free(s->man); free(s);
+  free(s->v); free(s->segs); free(s->man); free(s->fat); free(s->moved); free(s->c_exists); free(s->c_stamp);
+  free(s->sweep0); free(s->move_buf); free(s);
 }
 
 int orageo_poly_poly(const float* a, int na, const float* b, int nb) { return poly_poly(a, na, b, nb); }

@@ -188,19 +188,30 @@ def test_sim_oracle_contacts_bit_exact_vs_reference_fixture():
 
 @pytest.mark.skipif(not sim_libs.RefSim.available(), reason="oracle/_ref not built (needs /root/reference)")
 def test_sim_oracle_contacts_bit_exact_vs_live_reference():
-    """Fresh random two-car encounters (and worlds of several independent encounters) against the real Box2D, live."""
+    """Fresh random encounters against the real Box2D, live.  Two-car collisions (alone or several per world) must be
+    bit-exact.  Pile-ups of 8-16 cars are bit-exact as long as Box2D does not create two contacts of one island in the same
+    step (their relative order then comes from the dynamic tree's traversal, which is not restated): most are."""
     import gen_golden
     n_coll = 0
+    same = lambda x, y: np.array_equal(x.view(x.dtype if x.dtype == np.uint8 else np.int32),
+                                       y.view(y.dtype if y.dtype == np.uint8 else np.int32))
     for kind in ("headon", "tbone", "pairs"):
         for seed in range(20, 32):
             sc = gen_golden.contact_scene(kind, seed)
             a = _run_scripted_body(sim_libs.RefSim, sc)
             b = _run_scripted_body(sim_libs.OracleSim, sc)
             n_coll += int(a[1].sum())
-            for x, y in zip(a, b):
-                assert np.array_equal(x.view(x.dtype if x.dtype == np.uint8 else np.int32),
-                                      y.view(y.dtype if y.dtype == np.uint8 else np.int32)), (kind, seed)
+            assert all(same(x, y) for x, y in zip(a, b)), (kind, seed)
     assert n_coll > 100
+    exact = 0
+    for seed in range(20, 32):
+        sc = gen_golden.contact_scene("crowd", seed)
+        a = _run_scripted_body(sim_libs.RefSim, sc)
+        b = _run_scripted_body(sim_libs.OracleSim, sc)
+        assert a[1].sum() > 20
+        exact += all(same(x, y) for x, y in zip(a, b))
+    print("bit-exact pile-up scenes:", exact, "of 12")
+    assert exact >= 8
 
 
 def test_collision_oracle_matches_reference_geometry():
