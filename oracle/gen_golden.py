@@ -224,14 +224,15 @@ def gen_closed_loop():
     w = weights.generate(d, 0)
     out = {}
     for tag, n_ag, n_pl, tilt, nucleus, temp in (("a", 8, 20, (0, 0, 0), False, 1.0),
-                                                  ("b", 10, 9, (5.0, -10.0, 20.0), True, 1.5)):
-        # tier-1 parity is contact-free: take the first scenario index whose reference rollout never
-        # overlaps two car boxes (Box2D's contact solver is not restated; DESIGN.md "scope")
-        for idx in range({"a": 0, "b": 100}[tag], 1000):
-            scn = scenarios.make_scenario(7, idx, n_agents=n_ag, n_polylines=n_pl, n_points=d.NP, extent=40.0)
+                                                  ("b", 10, 9, (5.0, -10.0, 20.0), True, 1.5),
+                                                  ("c", 10, 12, (0.0, -10.0, 0.0), False, 1.0)):
+        # "a", "b": the first scenario index whose reference rollout never overlaps two car boxes (contact-free);
+        # "c": the first one in which vehicles DO collide (Box2D's contact solver in the loop), vehicle-vehicle tilt -10
+        for idx in range({"a": 0, "b": 100, "c": 200}[tag], 1000):
+            scn = scenarios.make_scenario(7, idx, n_agents=n_ag, n_polylines=n_pl, n_points=d.NP, extent={"c": 22.0}.get(tag, 40.0))
             r = ref_closed_loop(cfg, w, scn, 20, seed=3, tilt=tilt, nucleus=nucleus, temperature=temp)
             print(tag, idx, "veh-veh flags", r["coll"][..., 0].sum())
-            if r["coll"][..., 0].sum() == 0:
+            if (r["coll"][..., 0].sum() == 0) if tag != "c" else (r["coll"][..., 0].sum() >= 12):
                 break
         print(tag, "groups/step", r["n_groups"], "min race margin", r["margins"].min(),
               "collisions", r["coll"].sum(0).sum(0))
@@ -241,7 +242,7 @@ def gen_closed_loop():
         out[f"{tag}_groups_t_focal"] = np.array([(t, f) for t, f, _, _ in g])
         out[f"{tag}_groups_ids"] = np.array([ids + [-1] * (d.A - len(ids)) for _, _, ids, _ in g])
         out[f"{tag}_groups_members"] = np.array([m + [-1] * (n_ag - len(m)) for _, _, _, m in g])
-        out[f"{tag}_recipe"] = np.array([7, idx, n_ag, n_pl, 40.0, 3, *tilt, int(nucleus), temp])
+        out[f"{tag}_recipe"] = np.array([7, idx, n_ag, n_pl, {"c": 22.0}.get(tag, 40.0), 3, *tilt, int(nucleus), temp])
     save("closed_loop", **out)
 
 

@@ -259,10 +259,11 @@ def test_sampling_matches_reference_fixture_and_in_kernel_noise():
     assert (hist.cpu().numpy()[0, ::2, 1] == 524).all() and (now.cpu().numpy()[0, ::2] == -1).all()
 
 
-@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_closed_loop_rollout_matches_reference_fixture(tag):
     """G8 on the GPU: tokens / RTG bins bit-exact, float32 states within 1e-4 of the unmodified reference policy
-    driven by the real FreeCar+Box2D (tests/golden/closed_loop.npz), in-kernel noise."""
+    driven by the real FreeCar+Box2D (tests/golden/closed_loop.npz), in-kernel noise.  In "c" vehicles collide: the
+    Box2D contact solver runs inside the closed loop."""
     cfg = cfg_of("loop")
     d = spec.Dims(cfg)
     g = golden("closed_loop")
