@@ -70,6 +70,9 @@ def main():
     from ctrlsim_amd import spec, weights, scenarios, metrics, _lib
     from ctrlsim_amd.engine import RolloutEngine
 
+    for kv in filter(None, os.environ.get("CTRLSIM_OPTIONS", "").split(",")):   # "<option>=<value>,...": kernel A/B runs only
+        k, v = kv.split("=")
+        _lib.lib().ctrlsim_set_option(int(k), int(v))
     cfg = spec.make_cfg(nocturne__steps=args.rollout_steps, nocturne__history_steps=1)
     d = spec.Dims(cfg)
     w = weights.generate(d, 0)
