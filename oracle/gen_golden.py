@@ -431,6 +431,11 @@ def contact_scene(kind, seed):
         x = (rad * np.cos(ang)).astype(np.float32); y = (rad * np.sin(ang)).astype(np.float32)
         h = (ang + np.pi + r.uniform(-0.15, 0.15, n)).astype(np.float32)
         v = r.uniform(4, 10, n).astype(np.float32)
+    elif kind == "dense":                   # random placement in a small lot: boxes overlap from the start, large islands
+        n = 32 + 16 * (seed % 2)
+        x = r.uniform(-25, 25, n).astype(np.float32); y = r.uniform(-25, 25, n).astype(np.float32)
+        h = r.uniform(-np.pi, np.pi, n).astype(np.float32)
+        v = r.uniform(2, 10, n).astype(np.float32)
     else:                                   # "pairs": four separate two-car encounters in one world
         n = 8
         x = np.zeros(n, np.float32); y = np.zeros(n, np.float32); h = np.zeros(n, np.float32)
@@ -465,7 +470,7 @@ def gen_contacts():
     """Vehicles colliding, through the REAL FreeCar + Box2D (contact solver active): trajectories + body velocities."""
     out = {}
     cases = [("headon", 3), ("headon", 10), ("tbone", 0), ("tbone", 5), ("pairs", 1), ("pairs", 2), ("crowd", 0), ("crowd", 1),
-             ("crowd", 5)]
+             ("crowd", 5), ("dense", 0), ("dense", 1)]
     for k, (kind, seed) in enumerate(cases):
         sc = contact_scene(kind, seed)
         traj, cv, body = run_scripted(RefSim, sc)

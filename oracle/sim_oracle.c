@@ -68,6 +68,7 @@ typedef struct { float lx, ly, ni, ti; unsigned id; } MPoint;
 typedef struct { MPoint p[2]; float lnx, lny, lpx, lpy; int type, count, touching; } Manifold;
 enum { M_FACE_A = 1, M_FACE_B = 2 };
 
+struct TNode { float bb[4]; int parent, c1, c2, height; };   /* b2TreeNode; `parent` doubles as `next` in the free list */
 typedef struct {
   int n, n_seg;
   Veh* v;
@@ -84,6 +85,10 @@ typedef struct {
   int* c_stamp;           /* [n * n] creation order (larger = newer) */
   int stamp, new_contacts;
   float* sweep0;          /* [n][3] sweep.c0, sweep.a0 of the last island solve */
+  /* b2DynamicTree: its shape decides the order in which one query reports its hits, hence the order in which contacts that
+   * begin in the same step are created.  Leaf of vehicle i = node leaf_of[i] (its box is fat[i]) */
+  struct TNode* tn; int t_root, t_free, t_cap;
+  int* leaf_of; int* veh_of;
 } Sim;
 
 /* b2PolygonShape::SetAsBox(hx,hy) + ComputeMass(density 20) + b2Body::ResetMassData: the body's local centre
@@ -351,6 +356,142 @@ static int aabb_overlap(const float* a, const float* b) {      /* b2TestOverlap(
   if (d2x > 0.0f || d2y > 0.0f) return 0;
   return 1;
 }
+/* ---- b2DynamicTree (third_party/box2d/src/collision/b2_dynamic_tree.cpp:57-105 node pool, :198-332 InsertLeaf,
+ *      :334-393 RemoveLeaf, :397-534 Balance; include/box2d/b2_dynamic_tree.h:187-220 Query, b2_collision.h AABB helpers) */
+#define T_NULL (-1)
+static void bb_combine(float* o, const float* a, const float* b) {
+  o[0] = b2minf(a[0], b[0]); o[1] = b2minf(a[1], b[1]); o[2] = b2maxf(a[2], b[2]); o[3] = b2maxf(a[3], b[3]);
+}
+static float bb_perimeter(const float* a) { float wx = a[2] - a[0], wy = a[3] - a[1]; return 2.0f * (wx + wy); }
+static int t_alloc(Sim* s) {
+  if (s->t_free == T_NULL) {                       /* pool exhausted: new nodes continue the id sequence */
+    int old = s->t_cap;
+    s->t_cap = old ? 2 * old : 16;
+    s->tn = (struct TNode*)realloc(s->tn, sizeof(struct TNode) * s->t_cap);
+    s->veh_of = (int*)realloc(s->veh_of, sizeof(int) * s->t_cap);
+    for (int i = old; i < s->t_cap; ++i) { s->tn[i].parent = i + 1 < s->t_cap ? i + 1 : T_NULL; s->tn[i].height = -1; s->veh_of[i] = -1; }
+    s->t_free = old;
+  }
+  int id = s->t_free;
+  s->t_free = s->tn[id].parent;
+  s->tn[id].parent = s->tn[id].c1 = s->tn[id].c2 = T_NULL; s->tn[id].height = 0; s->veh_of[id] = -1;
+  return id;
+}
+static void t_free_node(Sim* s, int id) { s->tn[id].parent = s->t_free; s->tn[id].height = -1; s->t_free = id; }
+static int t_is_leaf(const Sim* s, int id) { return s->tn[id].c1 == T_NULL; }
+static int t_balance(Sim* s, int iA) {
+  struct TNode* N = s->tn;
+  if (t_is_leaf(s, iA) || N[iA].height < 2) return iA;
+  int iB = N[iA].c1, iC = N[iA].c2;
+  int balance = N[iC].height - N[iB].height;
+  if (balance > 1) {                               /* rotate C up */
+    int iF = N[iC].c1, iG = N[iC].c2;
+    N[iC].c1 = iA; N[iC].parent = N[iA].parent; N[iA].parent = iC;
+    if (N[iC].parent != T_NULL) { if (N[N[iC].parent].c1 == iA) N[N[iC].parent].c1 = iC; else N[N[iC].parent].c2 = iC; }
+    else s->t_root = iC;
+    if (N[iF].height > N[iG].height) {
+      N[iC].c2 = iF; N[iA].c2 = iG; N[iG].parent = iA;
+      bb_combine(N[iA].bb, N[iB].bb, N[iG].bb); bb_combine(N[iC].bb, N[iA].bb, N[iF].bb);
+      N[iA].height = 1 + (N[iB].height > N[iG].height ? N[iB].height : N[iG].height);
+      N[iC].height = 1 + (N[iA].height > N[iF].height ? N[iA].height : N[iF].height);
+    } else {
+      N[iC].c2 = iG; N[iA].c2 = iF; N[iF].parent = iA;
+      bb_combine(N[iA].bb, N[iB].bb, N[iF].bb); bb_combine(N[iC].bb, N[iA].bb, N[iG].bb);
+      N[iA].height = 1 + (N[iB].height > N[iF].height ? N[iB].height : N[iF].height);
+      N[iC].height = 1 + (N[iA].height > N[iG].height ? N[iA].height : N[iG].height);
+    }
+    return iC;
+  }
+  if (balance < -1) {                              /* rotate B up */
+    int iD = N[iB].c1, iE = N[iB].c2;
+    N[iB].c1 = iA; N[iB].parent = N[iA].parent; N[iA].parent = iB;
+    if (N[iB].parent != T_NULL) { if (N[N[iB].parent].c1 == iA) N[N[iB].parent].c1 = iB; else N[N[iB].parent].c2 = iB; }
+    else s->t_root = iB;
+    if (N[iD].height > N[iE].height) {
+      N[iB].c2 = iD; N[iA].c1 = iE; N[iE].parent = iA;
+      bb_combine(N[iA].bb, N[iC].bb, N[iE].bb); bb_combine(N[iB].bb, N[iA].bb, N[iD].bb);
+      N[iA].height = 1 + (N[iC].height > N[iE].height ? N[iC].height : N[iE].height);
+      N[iB].height = 1 + (N[iA].height > N[iD].height ? N[iA].height : N[iD].height);
+    } else {
+      N[iB].c2 = iE; N[iA].c1 = iD; N[iD].parent = iA;
+      bb_combine(N[iA].bb, N[iC].bb, N[iD].bb); bb_combine(N[iB].bb, N[iA].bb, N[iE].bb);
+      N[iA].height = 1 + (N[iC].height > N[iD].height ? N[iC].height : N[iD].height);
+      N[iB].height = 1 + (N[iA].height > N[iE].height ? N[iA].height : N[iE].height);
+    }
+    return iB;
+  }
+  return iA;
+}
+static void t_insert_leaf(Sim* s, int leaf) {
+  if (s->t_root == T_NULL) { s->t_root = leaf; s->tn[leaf].parent = T_NULL; return; }
+  float lb[4]; memcpy(lb, s->tn[leaf].bb, sizeof(lb));
+  int index = s->t_root;
+  while (!t_is_leaf(s, index)) {                   /* surface-area heuristic descent */
+    int c1 = s->tn[index].c1, c2 = s->tn[index].c2;
+    float area = bb_perimeter(s->tn[index].bb);
+    float comb[4]; bb_combine(comb, s->tn[index].bb, lb);
+    float combined_area = bb_perimeter(comb);
+    float cost = 2.0f * combined_area;
+    float inheritance = 2.0f * (combined_area - area);
+    float cost1, cost2, t[4];
+    bb_combine(t, lb, s->tn[c1].bb);
+    if (t_is_leaf(s, c1)) cost1 = bb_perimeter(t) + inheritance;
+    else { float old_area = bb_perimeter(s->tn[c1].bb), new_area = bb_perimeter(t); cost1 = (new_area - old_area) + inheritance; }
+    bb_combine(t, lb, s->tn[c2].bb);
+    if (t_is_leaf(s, c2)) cost2 = bb_perimeter(t) + inheritance;
+    else { float old_area = bb_perimeter(s->tn[c2].bb), new_area = bb_perimeter(t); cost2 = new_area - old_area + inheritance; }
+    if (cost < cost1 && cost < cost2) break;
+    index = cost1 < cost2 ? c1 : c2;
+  }
+  int sibling = index;
+  int old_parent = s->tn[sibling].parent;
+  int new_parent = t_alloc(s);
+  struct TNode* N = s->tn;                          /* (t_alloc may have moved the pool) */
+  N[new_parent].parent = old_parent;
+  bb_combine(N[new_parent].bb, lb, N[sibling].bb);
+  N[new_parent].height = N[sibling].height + 1;
+  if (old_parent != T_NULL) { if (N[old_parent].c1 == sibling) N[old_parent].c1 = new_parent; else N[old_parent].c2 = new_parent; }
+  else s->t_root = new_parent;
+  N[new_parent].c1 = sibling; N[new_parent].c2 = leaf;
+  N[sibling].parent = new_parent; N[leaf].parent = new_parent;
+  index = N[leaf].parent;
+  while (index != T_NULL) {                        /* walk up: rebalance, refit */
+    index = t_balance(s, index);
+    int c1 = N[index].c1, c2 = N[index].c2;
+    N[index].height = 1 + (N[c1].height > N[c2].height ? N[c1].height : N[c2].height);
+    bb_combine(N[index].bb, N[c1].bb, N[c2].bb);
+    index = N[index].parent;
+  }
+}
+static void t_remove_leaf(Sim* s, int leaf) {
+  struct TNode* N = s->tn;
+  if (leaf == s->t_root) { s->t_root = T_NULL; return; }
+  int parent = N[leaf].parent, grand = N[parent].parent;
+  int sibling = N[parent].c1 == leaf ? N[parent].c2 : N[parent].c1;
+  if (grand != T_NULL) {
+    if (N[grand].c1 == parent) N[grand].c1 = sibling; else N[grand].c2 = sibling;
+    N[sibling].parent = grand;
+    t_free_node(s, parent);
+    int index = grand;
+    while (index != T_NULL) {
+      index = t_balance(s, index);
+      int c1 = N[index].c1, c2 = N[index].c2;
+      bb_combine(N[index].bb, N[c1].bb, N[c2].bb);
+      N[index].height = 1 + (N[c1].height > N[c2].height ? N[c1].height : N[c2].height);
+      index = N[index].parent;
+    }
+  } else {
+    s->t_root = sibling; N[sibling].parent = T_NULL;
+    t_free_node(s, parent);
+  }
+}
+static void t_create_proxy(Sim* s, int veh) {      /* fat[veh] already holds the fattened box */
+  int id = t_alloc(s);
+  memcpy(s->tn[id].bb, s->fat + 4 * veh, 4 * sizeof(float));
+  s->veh_of[id] = veh; s->leaf_of[veh] = id;
+  t_insert_leaf(s, id);
+}
+
 static void move_proxy(Sim* s, int i, const float* aabb, float dx, float dy) {
   float fatn[4] = {aabb[0] - B2_AABB_EXT, aabb[1] - B2_AABB_EXT, aabb[2] + B2_AABB_EXT, aabb[3] + B2_AABB_EXT};
   float ddx = B2_AABB_MULT * dx, ddy = B2_AABB_MULT * dy;
@@ -361,7 +502,10 @@ static void move_proxy(Sim* s, int i, const float* aabb, float dx, float dy) {
     float huge[4] = {fatn[0] - 4.0f * B2_AABB_EXT, fatn[1] - 4.0f * B2_AABB_EXT, fatn[2] + 4.0f * B2_AABB_EXT, fatn[3] + 4.0f * B2_AABB_EXT};
     if (aabb_contains(huge, tree)) return;
   }
+  t_remove_leaf(s, s->leaf_of[i]);
   memcpy(tree, fatn, sizeof(fatn));
+  memcpy(s->tn[s->leaf_of[i]].bb, fatn, sizeof(fatn));
+  t_insert_leaf(s, s->leaf_of[i]);
   s->moved[i] = 1;
   buffer_move(s, i);
 }
@@ -373,15 +517,24 @@ static void synchronize_fixture(Sim* s, int i, Xf xf1, Xf xf2) {
   float dy = 0.5f * (a2[1] + a2[3]) - 0.5f * (a1[1] + a1[3]);
   move_proxy(s, i, c, dx, dy);
 }
-/* b2BroadPhase::UpdatePairs + b2ContactManager::AddPair.  The order in which one tree query reports its hits is a
- * property of the dynamic tree's shape, which is not reproduced: hits are taken in ascending proxy order. */
+/* b2BroadPhase::UpdatePairs + QueryCallback + b2ContactManager::AddPair: one tree query per buffered proxy; a query
+ * reports its hits in the tree's stack order (child2 before child1).  Leaf ids grow with vehicle index (each vehicle takes
+ * a fresh leaf, parents recycle among themselves), so "proxyId > queryProxyId" is "o > q". */
 static void find_new_contacts(Sim* s) {
   int n = s->n;
+  int stack[256];
   for (int k = 0; k < s->n_move; ++k) {
     int q = s->move_buf[k];
     const float* fq = s->fat + 4 * q;
-    for (int o = 0; o < n; ++o) {
-      if (o == q || !aabb_overlap(s->fat + 4 * o, fq)) continue;
+    int sc = 0;
+    stack[sc++] = s->t_root;
+    while (sc > 0) {
+      int id = stack[--sc];
+      if (id == T_NULL) continue;
+      if (!aabb_overlap(s->tn[id].bb, fq)) continue;
+      if (!t_is_leaf(s, id)) { stack[sc++] = s->tn[id].c1; stack[sc++] = s->tn[id].c2; continue; }
+      int o = s->veh_of[id];
+      if (o == q) continue;
       if (s->moved[o] && o > q) continue;
       int i = o < q ? o : q, j = o < q ? q : o;
       if (s->c_exists[i * n + j]) continue;
@@ -853,6 +1006,8 @@ void* orasim_create(int n, const float* length, const float* width, const float*
   s->c_exists = (char*)calloc((size_t)n * n + 1, 1);
   s->c_stamp = (int*)calloc((size_t)n * n + 1, sizeof(int));
   s->sweep0 = (float*)calloc((size_t)3 * n + 3, sizeof(float));
+  s->tn = NULL; s->veh_of = NULL; s->t_cap = 0; s->t_root = T_NULL; s->t_free = T_NULL;
+  s->leaf_of = (int*)calloc(n + 1, sizeof(int));
   s->move_buf = NULL; s->n_move = s->cap_move = 0; s->stamp = 0; s->new_contacts = 1;
   s->segs = (float*)malloc(sizeof(float) * 4 * (n_seg > 0 ? n_seg : 1));
   if (n_seg > 0) memcpy(s->segs, segs, sizeof(float) * 4 * n_seg);
@@ -867,6 +1022,7 @@ void* orasim_create(int n, const float* length, const float* width, const float*
       shape_aabb(v, body_xf(v), bb);
       s->fat[4 * i] = bb[0] - B2_AABB_EXT; s->fat[4 * i + 1] = bb[1] - B2_AABB_EXT;
       s->fat[4 * i + 2] = bb[2] + B2_AABB_EXT; s->fat[4 * i + 3] = bb[3] + B2_AABB_EXT;
+      t_create_proxy(s, i);
       s->moved[i] = 1; buffer_move(s, i);
     }
     set_transform(v, 0.f, 0.f, (float)((double)v->heading - M_PI * 0.5f));   /* SetAngle, vehicle.cc:168 */
@@ -938,7 +1094,7 @@ void orasim_get_body(void* h, float* out) {
 void orasim_destroy(void* h) {
   Sim* s = (Sim*)h;
   free(s->v); free(s->segs); free(s->man); free(s->fat); free(s->moved); free(s->c_exists); free(s->c_stamp);
-  free(s->sweep0); free(s->move_buf); free(s);
+  free(s->sweep0); free(s->move_buf); free(s->tn); free(s->veh_of); free(s->leaf_of); free(s);
 }
 
 int orageo_poly_poly(const float* a, int na, const float* b, int nb) { return poly_poly(a, na, b, nb); }

@@ -188,9 +188,9 @@ def test_sim_oracle_contacts_bit_exact_vs_reference_fixture():
 
 @pytest.mark.skipif(not sim_libs.RefSim.available(), reason="oracle/_ref not built (needs /root/reference)")
 def test_sim_oracle_contacts_bit_exact_vs_live_reference():
-    """Fresh random encounters against the real Box2D, live.  Two-car collisions (alone or several per world) must be
-    bit-exact.  Pile-ups of 8-16 cars are bit-exact as long as Box2D does not create two contacts of one island in the same
-    step (their relative order then comes from the dynamic tree's traversal, which is not restated): most are."""
+    """Fresh random encounters against the real Box2D, live: two-car collisions (alone or several per world), pile-ups of
+    8-16 cars and lots of 32-48 cars that overlap from the start — all bit-exact (the order in which contacts of one step
+    are created comes from the restated b2DynamicTree)."""
     import gen_golden
     n_coll = 0
     same = lambda x, y: np.array_equal(x.view(x.dtype if x.dtype == np.uint8 else np.int32),
@@ -203,15 +203,13 @@ def test_sim_oracle_contacts_bit_exact_vs_live_reference():
             n_coll += int(a[1].sum())
             assert all(same(x, y) for x, y in zip(a, b)), (kind, seed)
     assert n_coll > 100
-    exact = 0
-    for seed in range(20, 32):
-        sc = gen_golden.contact_scene("crowd", seed)
-        a = _run_scripted_body(sim_libs.RefSim, sc)
-        b = _run_scripted_body(sim_libs.OracleSim, sc)
-        assert a[1].sum() > 20
-        exact += all(same(x, y) for x, y in zip(a, b))
-    print("bit-exact pile-up scenes:", exact, "of 12")
-    assert exact >= 8
+    for kind, seeds in (("crowd", range(20, 32)), ("dense", range(20, 26))):
+        for seed in seeds:
+            sc = gen_golden.contact_scene(kind, seed)
+            a = _run_scripted_body(sim_libs.RefSim, sc)
+            b = _run_scripted_body(sim_libs.OracleSim, sc)
+            assert a[1].sum() > 20
+            assert all(same(x, y) for x, y in zip(a, b)), (kind, seed)
 
 
 def test_collision_oracle_matches_reference_geometry():
