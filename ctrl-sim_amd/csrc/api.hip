@@ -130,7 +130,7 @@ int ctrlsim_sim_init(int S, int N, int E, const float* init_pose, const float* s
                      float* phys, float* hist_states, uint8_t* coll, int Tmax1, float* contact_state, hipStream_t st) {
   return launch_sim_init(S, N, E, init_pose, size, edges, exists, phys, hist_states, coll, Tmax1, contact_state, st);
 }
-int64_t ctrlsim_sim_contact_floats(int N) { return N < 1 ? 0 : (int64_t)N * (N - 1) / 2 * 20 + 4 + 12 * (int64_t)N; }
+int64_t ctrlsim_sim_contact_floats(int N) { return N < 1 ? 0 : (int64_t)N * (N - 1) / 2 * 20 + 6 + 28 * (int64_t)N; }
 int ctrlsim_sim_step(int S, int N, int E, const int* act_tok, const double* act_f64, const double* disc6, const float* size,
                      const float* edges, const uint8_t* exists, float* phys, float* hist_states, uint8_t* coll,
                      double* applied, int t, int Tmax1, float dt, int mode, float* contact_state, hipStream_t st) {

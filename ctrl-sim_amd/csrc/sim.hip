@@ -223,8 +223,10 @@ __device__ void collide_and_record(int s, int N, int E, const float* __restrict_
 #define CS_EXISTS 17     // contact exists (fat AABBs overlap since it was created)
 #define CS_STAMP 18      // creation order (larger = newer): decides the contact order inside islands
 // per-scenario tail after the NP pair records: [inv_dt0, stamp counter, new-contacts flag, move-buffer length],
-// fat AABB per proxy [N][4], moved flag [N], sweep.c0 / a0 [N][3], move buffer [4N]
-#define CS_TAIL 4
+// fat AABB per proxy [N][4], moved flag [N], sweep.c0 / a0 [N][3], move buffer [4N], b2DynamicTree nodes [2N][8]
+#define CS_TAIL 6        // m_inv_dt0, contact stamp, m_newContacts, move count, tree root, tree free-list head
+#define TN_STRIDE 8      // tree node: box lower x, y, upper x, y, parent (= next in the free list), child1, child2, height
+#define CS_PER(N) ((N) * ((N) - 1) / 2 * CS_STRIDE + CS_TAIL + 12 * (N) + 2 * (N) * TN_STRIDE)
 #define MAX_ISLAND_CONTACTS 160
 #define B2_AABB_EXT 0.1f
 #define B2_AABB_MULT 4.0f
@@ -370,7 +372,7 @@ __device__ int collide_boxes(float* m, const Box& A, Xf xfA, const Box& B, Xf xf
   return pc;
 }
 
-// ---- broad phase bookkeeping: only what fixes the ORDER in which Box2D creates contacts (b2_dynamic_tree.cpp:107-195
+// ---- broad phase: what fixes the ORDER in which Box2D creates contacts (b2_dynamic_tree.cpp:107-195
 // MoveProxy fat AABBs, b2_broad_phase.cpp / .h BufferMove, UpdatePairs, QueryCallback; b2_fixture.cpp:156-178)
 __device__ void shape_aabb(const Box& b, Xf xf, float* bb) {      // b2PolygonShape::ComputeAABB
   V2 lo = xf_mul(xf, b.v[0]), hi = lo;
@@ -409,20 +411,170 @@ __device__ bool synchronize_fixture(float* fat, const Box& b, Xf xf1, Xf xf2) {
   fat[0] = fatn[0]; fat[1] = fatn[1]; fat[2] = fatn[2]; fat[3] = fatn[3];
   return true;
 }
-// b2BroadPhase::UpdatePairs + b2ContactManager::AddPair, one lane.  tail: see CS_TAIL; hits of one query are taken in
-// ascending proxy order (the dynamic tree's own traversal order is not reproduced).
-__device__ void find_new_contacts(float* cs, int N, int NP) {
+// ---- b2DynamicTree (b2_dynamic_tree.cpp:57-105 pool, :198-332 InsertLeaf, :334-393 RemoveLeaf, :397-534 Balance;
+// b2_dynamic_tree.h:187-220 Query).  Its shape fixes the order in which one query reports its hits, i.e. the order in which
+// contacts that begin in the same step are created.  One lane works on it.  Every vehicle takes a fresh leaf at creation and
+// internal nodes recycle among themselves, so leaf(vehicle i) = i ? 2 i - 1 : 0 and ids compare like vehicle indices.
+struct Tree {
+  float* n;        // nodes [2N][TN_STRIDE]
+  float* rf;       // rf[0] = root, rf[1] = free-list head
+  __device__ float* bb(int i) const { return n + i * TN_STRIDE; }
+  __device__ int parent(int i) const { return (int)n[i * TN_STRIDE + 4]; }
+  __device__ int c1(int i) const { return (int)n[i * TN_STRIDE + 5]; }
+  __device__ int c2(int i) const { return (int)n[i * TN_STRIDE + 6]; }
+  __device__ int height(int i) const { return (int)n[i * TN_STRIDE + 7]; }
+  __device__ void set_parent(int i, int v) { n[i * TN_STRIDE + 4] = (float)v; }
+  __device__ void set_c1(int i, int v) { n[i * TN_STRIDE + 5] = (float)v; }
+  __device__ void set_c2(int i, int v) { n[i * TN_STRIDE + 6] = (float)v; }
+  __device__ void set_height(int i, int v) { n[i * TN_STRIDE + 7] = (float)v; }
+  __device__ bool leaf(int i) const { return c1(i) < 0; }
+  __device__ int root() const { return (int)rf[0]; }
+  __device__ void set_root(int v) { rf[0] = (float)v; }
+};
+__device__ __forceinline__ int tree_leaf_of(int veh) { return veh ? 2 * veh - 1 : 0; }
+__device__ __forceinline__ int tree_veh_of(int leaf) { return leaf ? (leaf + 1) >> 1 : 0; }
+__device__ __forceinline__ void bb_combine(float* o, const float* a, const float* b) {
+  const float x0 = b2minf(a[0], b[0]), y0 = b2minf(a[1], b[1]), x1 = b2maxf(a[2], b[2]), y1 = b2maxf(a[3], b[3]);
+  o[0] = x0; o[1] = y0; o[2] = x1; o[3] = y1;
+}
+__device__ __forceinline__ float bb_perimeter(const float* a) {
+  const float wx = a[2] - a[0], wy = a[3] - a[1];
+  return 2.0f * (wx + wy);
+}
+__device__ void tree_reset(Tree T, int N) {            // empty tree, free list 0 -> 1 -> ... (b2DynamicTree ctor / pool growth)
+  for (int i = 0; i < 2 * N; ++i) { T.set_parent(i, i + 1 < 2 * N ? i + 1 : -1); T.set_c1(i, -1); T.set_c2(i, -1); T.set_height(i, -1); }
+  T.rf[0] = -1.f; T.rf[1] = 0.f;
+}
+__device__ int tree_alloc(Tree T) {
+  const int id = (int)T.rf[1];
+  T.rf[1] = (float)T.parent(id);
+  T.set_parent(id, -1); T.set_c1(id, -1); T.set_c2(id, -1); T.set_height(id, 0);
+  return id;
+}
+__device__ void tree_free(Tree T, int id) { T.set_parent(id, (int)T.rf[1]); T.set_height(id, -1); T.rf[1] = (float)id; }
+__device__ int tree_balance(Tree T, int iA) {
+  if (T.leaf(iA) || T.height(iA) < 2) return iA;
+  const int iB = T.c1(iA), iC = T.c2(iA);
+  const int balance = T.height(iC) - T.height(iB);
+  auto hmax = [&](int a, int b) { const int ha = T.height(a), hb = T.height(b); return 1 + (ha > hb ? ha : hb); };
+  if (balance > 1) {                                   // rotate C up
+    const int iF = T.c1(iC), iG = T.c2(iC);
+    T.set_c1(iC, iA); T.set_parent(iC, T.parent(iA)); T.set_parent(iA, iC);
+    const int pc = T.parent(iC);
+    if (pc >= 0) { if (T.c1(pc) == iA) T.set_c1(pc, iC); else T.set_c2(pc, iC); } else T.set_root(iC);
+    const bool f_up = T.height(iF) > T.height(iG);
+    const int up = f_up ? iF : iG, down = f_up ? iG : iF;
+    T.set_c2(iC, up); T.set_c2(iA, down); T.set_parent(down, iA);
+    bb_combine(T.bb(iA), T.bb(iB), T.bb(down)); bb_combine(T.bb(iC), T.bb(iA), T.bb(up));
+    T.set_height(iA, hmax(iB, down)); T.set_height(iC, hmax(iA, up));
+    return iC;
+  }
+  if (balance < -1) {                                  // rotate B up
+    const int iD = T.c1(iB), iE = T.c2(iB);
+    T.set_c1(iB, iA); T.set_parent(iB, T.parent(iA)); T.set_parent(iA, iB);
+    const int pb = T.parent(iB);
+    if (pb >= 0) { if (T.c1(pb) == iA) T.set_c1(pb, iB); else T.set_c2(pb, iB); } else T.set_root(iB);
+    const bool d_up = T.height(iD) > T.height(iE);
+    const int up = d_up ? iD : iE, down = d_up ? iE : iD;
+    T.set_c2(iB, up); T.set_c1(iA, down); T.set_parent(down, iA);
+    bb_combine(T.bb(iA), T.bb(iC), T.bb(down)); bb_combine(T.bb(iB), T.bb(iA), T.bb(up));
+    T.set_height(iA, hmax(iC, down)); T.set_height(iB, hmax(iA, up));
+    return iB;
+  }
+  return iA;
+}
+__device__ void tree_refit_up(Tree T, int index) {       // walk to the root: rebalance, refit heights and boxes
+  while (index >= 0) {
+    index = tree_balance(T, index);
+    const int a = T.c1(index), b = T.c2(index);
+    const int ha = T.height(a), hb = T.height(b);
+    T.set_height(index, 1 + (ha > hb ? ha : hb));
+    bb_combine(T.bb(index), T.bb(a), T.bb(b));
+    index = T.parent(index);
+  }
+}
+__device__ void tree_insert_leaf(Tree T, int leaf) {
+  if (T.root() < 0) { T.set_root(leaf); T.set_parent(leaf, -1); return; }
+  float lb[4] = {T.bb(leaf)[0], T.bb(leaf)[1], T.bb(leaf)[2], T.bb(leaf)[3]};
+  int index = T.root();
+  while (!T.leaf(index)) {                             // surface-area heuristic descent
+    const int a = T.c1(index), b = T.c2(index);
+    const float area = bb_perimeter(T.bb(index));
+    float comb[4]; bb_combine(comb, T.bb(index), lb);
+    const float combined = bb_perimeter(comb);
+    const float cost = 2.0f * combined;
+    const float inherit = 2.0f * (combined - area);
+    float t[4], cost1, cost2;
+    bb_combine(t, lb, T.bb(a));
+    if (T.leaf(a)) cost1 = bb_perimeter(t) + inherit;
+    else { const float old_area = bb_perimeter(T.bb(a)), new_area = bb_perimeter(t); cost1 = (new_area - old_area) + inherit; }
+    bb_combine(t, lb, T.bb(b));
+    if (T.leaf(b)) cost2 = bb_perimeter(t) + inherit;
+    else { const float old_area = bb_perimeter(T.bb(b)), new_area = bb_perimeter(t); cost2 = new_area - old_area + inherit; }
+    if (cost < cost1 && cost < cost2) break;
+    index = cost1 < cost2 ? a : b;
+  }
+  const int sibling = index, old_parent = T.parent(sibling);
+  const int np = tree_alloc(T);
+  T.set_parent(np, old_parent);
+  bb_combine(T.bb(np), lb, T.bb(sibling));
+  T.set_height(np, T.height(sibling) + 1);
+  if (old_parent >= 0) { if (T.c1(old_parent) == sibling) T.set_c1(old_parent, np); else T.set_c2(old_parent, np); }
+  else T.set_root(np);
+  T.set_c1(np, sibling); T.set_c2(np, leaf);
+  T.set_parent(sibling, np); T.set_parent(leaf, np);
+  tree_refit_up(T, np);
+}
+__device__ void tree_remove_leaf(Tree T, int leaf) {
+  if (leaf == T.root()) { T.set_root(-1); return; }
+  const int parent = T.parent(leaf), grand = T.parent(parent);
+  const int sibling = T.c1(parent) == leaf ? T.c2(parent) : T.c1(parent);
+  if (grand >= 0) {
+    if (T.c1(grand) == parent) T.set_c1(grand, sibling); else T.set_c2(grand, sibling);
+    T.set_parent(sibling, grand);
+    tree_free(T, parent);
+    tree_refit_up(T, grand);
+  } else {
+    T.set_root(sibling); T.set_parent(sibling, -1);
+    tree_free(T, parent);
+  }
+}
+// b2DynamicTree::CreateProxy / the re-insertion half of MoveProxy for vehicle i whose fattened box is fat[4 i ..]
+__device__ void tree_create_proxy(Tree T, const float* fat, int i) {
+  const int id = tree_alloc(T);                        // == tree_leaf_of(i) by construction
+  float* b = T.bb(id);
+  b[0] = fat[4 * i]; b[1] = fat[4 * i + 1]; b[2] = fat[4 * i + 2]; b[3] = fat[4 * i + 3];
+  tree_insert_leaf(T, id);
+}
+__device__ void tree_move_proxy(Tree T, const float* fat, int i) {
+  const int id = tree_leaf_of(i);
+  tree_remove_leaf(T, id);
+  float* b = T.bb(id);
+  b[0] = fat[4 * i]; b[1] = fat[4 * i + 1]; b[2] = fat[4 * i + 2]; b[3] = fat[4 * i + 3];
+  tree_insert_leaf(T, id);
+}
+
+// b2BroadPhase::UpdatePairs + QueryCallback + b2ContactManager::AddPair, one lane.  tail: see CS_TAIL; one tree query per
+// buffered proxy, hits in the tree's stack order (child2 before child1).
+__device__ void find_new_contacts(float* cs, int N, int NP, Tree T) {
   float* tail = cs + (size_t)NP * CS_STRIDE;
   float* fat = tail + CS_TAIL;
   float* moved = fat + 4 * N;
   float* move_buf = moved + N + 3 * N;
   const int n_move = (int)tail[3];
   int stamp = (int)tail[1];
+  int stack[64];                                       // depth of a balanced tree of <= 64 leaves stays far below this
   for (int k = 0; k < n_move; ++k) {
     const int q = (int)move_buf[k];
     const float* fq = fat + 4 * q;
-    for (int o = 0; o < N; ++o) {
-      if (o == q || !aabb_overlap(fat + 4 * o, fq)) continue;
+    int sc = 0;
+    stack[sc++] = T.root();
+    while (sc > 0) {
+      const int id = stack[--sc];
+      if (id < 0 || !aabb_overlap(T.bb(id), fq)) continue;
+      if (!T.leaf(id)) { if (sc + 2 <= 64) { stack[sc++] = T.c1(id); stack[sc++] = T.c2(id); } continue; }
+      const int o = tree_veh_of(id);
+      if (o == q) continue;
       if (moved[o] != 0.f && o > q) continue;
       const int i = o < q ? o : q, j = o < q ? q : o;
       float* m = cs + (size_t)(i * (2 * N - i - 1) / 2 + (j - i - 1)) * CS_STRIDE;
@@ -705,7 +857,7 @@ __global__ __launch_bounds__(256) void sim_init_kernel(int N, int E, const float
                                                        float* __restrict__ phys, float* __restrict__ hist_states,
                                                        unsigned char* __restrict__ coll, int Tmax1,
                                                        float* __restrict__ contact_state) {
-  const int NP = N * (N - 1) / 2, per = NP * CS_STRIDE + CS_TAIL + 12 * N;
+  const int NP = N * (N - 1) / 2, per = CS_PER(N);
   float* cs = contact_state ? contact_state + (size_t)blockIdx.x * per : nullptr;
   if (cs) {                                              // no contacts, no impulses, b2World::m_inv_dt0 = 0
     for (int i = threadIdx.x; i < per; i += blockDim.x) cs[i] = 0.f;
@@ -736,6 +888,8 @@ __global__ __launch_bounds__(256) void sim_init_kernel(int N, int E, const float
     // SetAngle and SetPosition (b2Body::SetTransform -> Synchronize); contacts are looked for at the first step
     float* tail = cs + (size_t)NP * CS_STRIDE;
     float* fat = tail + CS_TAIL;
+    Tree T{fat + 12 * N, tail + 4};
+    tree_reset(T, N);
     for (int i = 0; i < N; ++i) {
       const float* p = phys + ((size_t)s * N + i) * PHYS_STRIDE;
       const Box b = box_of(size[((size_t)s * N + i) * 2 + 1], size[((size_t)s * N + i) * 2]);
@@ -744,11 +898,12 @@ __global__ __launch_bounds__(256) void sim_init_kernel(int N, int E, const float
       shape_aabb(b, xf0, bb);
       fat[4 * i] = bb[0] - B2_AABB_EXT; fat[4 * i + 1] = bb[1] - B2_AABB_EXT;
       fat[4 * i + 2] = bb[2] + B2_AABB_EXT; fat[4 * i + 3] = bb[3] + B2_AABB_EXT;
+      tree_create_proxy(T, fat, i);
       buffer_move(cs, N, NP, i);
       Xf xfa; xfa.p = v2(0.f, 0.f); xfa.q.s = sinf(p[P_A]); xfa.q.c = cosf(p[P_A]);
-      if (synchronize_fixture(fat + 4 * i, b, xfa, xfa)) buffer_move(cs, N, NP, i);
+      if (synchronize_fixture(fat + 4 * i, b, xfa, xfa)) { tree_move_proxy(T, fat, i); buffer_move(cs, N, NP, i); }
       Xf xfp = xfa; xfp.p = v2(p[P_PX], p[P_PY]);
-      if (synchronize_fixture(fat + 4 * i, b, xfp, xfp)) buffer_move(cs, N, NP, i);
+      if (synchronize_fixture(fat + 4 * i, b, xfp, xfp)) { tree_move_proxy(T, fat, i); buffer_move(cs, N, NP, i); }
     }
     tail[2] = 1.f;                                       // m_newContacts
   }
@@ -863,10 +1018,17 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
   if (!kinematic) {
     // ================================================================================================ b2World::Step
     const int NP = N * (N - 1) / 2;
-    float* cs = contact_state ? contact_state + (size_t)s * (NP * CS_STRIDE + CS_TAIL + 12 * N) : nullptr;
+    float* cs = contact_state ? contact_state + (size_t)s * CS_PER(N) : nullptr;
     float* tail = cs ? cs + (size_t)NP * CS_STRIDE : nullptr;
     float* fat = cs ? tail + CS_TAIL : nullptr;
     float* sweep0 = cs ? fat + 4 * N + N : nullptr;
+    // the dynamic tree of this world works from LDS (one lane walks it; written back at the end of the step)
+    __shared__ float tree_lds[2 * 64 * TN_STRIDE + 2];
+    Tree T{tree_lds, tree_lds + 2 * 64 * TN_STRIDE};
+    if (cs) {
+      for (int i = tid; i < 2 * N * TN_STRIDE; i += blockDim.x) tree_lds[i] = fat[12 * N + i];
+      if (tid < 2) T.rf[tid] = tail[4 + tid];
+    }
     __syncthreads();
     if (cs) {
       if (tid == 0) {
@@ -876,10 +1038,10 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
             const size_t si = (size_t)s * N + i;
             const Box b = box_of(size[si * 2 + 1], size[si * 2]);
             Xf xf; xf.p = v2(B.px[i], B.py[i]); xf.q.s = sinf(B.a[i]); xf.q.c = cosf(B.a[i]);
-            if (synchronize_fixture(fat + 4 * i, b, xf, xf)) buffer_move(cs, N, NP, i);
+            if (synchronize_fixture(fat + 4 * i, b, xf, xf)) { tree_move_proxy(T, fat, i); buffer_move(cs, N, NP, i); }
             tail[2] = 1.f;
           }
-        if (tail[2] != 0.f) { find_new_contacts(cs, N, NP); tail[2] = 0.f; }
+        if (tail[2] != 0.f) { find_new_contacts(cs, N, NP, T); tail[2] = 0.f; }
       }
       __syncthreads();
       // ---- b2ContactManager::Collide / b2Contact::Update over the existing contacts (i < j: fixture A = i, B = j)
@@ -1021,9 +1183,12 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
       __syncthreads();
       if (tid == 0) {
         for (int b = N - 1; b >= 0; --b)                   // m_bodyList order: newest body first
-          if (moved_now[b]) buffer_move(cs, N, NP, b);
-        find_new_contacts(cs, N, NP);
+          if (moved_now[b]) { tree_move_proxy(T, fat, b); buffer_move(cs, N, NP, b); }
+        find_new_contacts(cs, N, NP, T);
       }
+      __syncthreads();
+      for (int i = tid; i < 2 * N * TN_STRIDE; i += blockDim.x) fat[12 * N + i] = tree_lds[i];
+      if (tid < 2) tail[4 + tid] = T.rf[tid];
     }
     if (tid < N) {
       const size_t sn = (size_t)s * N + tid;

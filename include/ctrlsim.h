@@ -58,8 +58,8 @@ typedef struct ctrlsim_model ctrlsim_model;
  * (policies/autoregressive_policy.py:256-274) and the state read-back of update_vehicle_data_dict
  * (evaluators/policy_evaluator.py:99-121).
  * contact_state: [S, ctrlsim_sim_contact_floats(N)] floats owned by the caller, initialised by ctrlsim_sim_init and carried from
- * step to step: Box2D's persistent per-pair contact manifolds with their accumulated impulses (warm starting) and
- * b2World::m_inv_dt0.  With it the step includes Box2D's box-box contact handling between vehicles (b2CollidePolygons,
+ * step to step: Box2D's persistent per-pair contact manifolds with their accumulated impulses (warm starting),
+ * b2World::m_inv_dt0 and the broad phase (fat AABBs, move buffer, b2DynamicTree nodes).  With it the step includes Box2D's box-box contact handling between vehicles (b2CollidePolygons,
  * islands, b2ContactSolver: third_party/box2d/src/collision/b2_collide_polygon.cpp, src/dynamics/b2_contact_solver.cpp,
  * b2_island.cpp, b2_world.cpp); NULL = contact-free integration (vehicles pass through each other; flags still exact). */
 int64_t ctrlsim_sim_contact_floats(int N);

@@ -22,11 +22,10 @@
  *
  * Tier: CONTACTS INCLUDED.  Box-box contacts between vehicles (friction 0.2, restitution 0, density 20, polygon skin
  * 0.01, 8 velocity / 3 position iterations, warm starting, block solver) are restated and are bit-exact against the
- * real Box2D for islands of two bodies.  What is NOT reproduced is the ORDER in which Box2D's dynamic tree hands
- * out new pairs: islands with three or more bodies in simultaneous contact are solved with contacts ordered by
- * vehicle index instead (Gauss-Seidel order differs -> low-order bits, then drift).  Broad-phase bookkeeping needs no
- * restatement: a contact exists whenever fat AABBs overlap, which always precedes touching, and a non-touching
- * contact carries no state.  TOI sub-stepping never triggers between two non-bullet dynamic bodies
+ * real Box2D: two-body islands, pile-ups, and lots of up to 64 cars that overlap from the start (live check in
+ * tests/test_oracle_pinned.py).  Gauss-Seidel is order dependent, so the broad phase is restated as well, down to
+ * b2DynamicTree (its shape fixes the order in which contacts that begin in the same step are created).
+ * TOI sub-stepping never triggers between two non-bullet dynamic bodies
  * (b2_world.cpp SolveTOI).  Collision FLAGS are exact in every case.
  *
  * Pinned against oracle/_ref/libref_sim.so (the real FreeCar + Box2D + geometry sources) by
