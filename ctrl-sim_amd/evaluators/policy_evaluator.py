@@ -5,7 +5,7 @@ The per-scenario loop is the reference's (update_vehicle_data_dict -> policy.upd
 policy.act / apply_gt_action -> sim.step -> update_running_statistics -> compute_metrics) with the same dict schema
 (policy_evaluator.py:70-96), so a `Policy` written against the reference runs here unchanged.  Differences, all forced
 by the environment: scenarios come from `cfg.eval.synthetic` (no Nocturne JSON / preprocessed pickles exist here) and
-"ground truth" is the constant-velocity extrapolation of the initial state; the simulator is
+"ground truth" is a stand-in log (constant-acceleration arcs from the initial state, scenarios.standin_log); the simulator is
 `ctrlsim_amd.simulation.Simulation` (HIP kernels) instead of the pybind `nocturne_cpp` module."""
 from __future__ import annotations
 
@@ -120,18 +120,8 @@ class PolicyEvaluator:
         return veh, [a, s]
 
     def _ground_truth(self, scn):
-        """Constant-velocity extrapolation as the stand-in expert log: traj rows = x, y, heading, speed, exist, length."""
-        T1 = self.steps + 1
-        tt = np.arange(T1)[:, None] * self.dt
-        out = {}
-        for i in range(scn.N):
-            sp, hd = float(scn.speed[i]), float(scn.heading[i])
-            tr = np.zeros((T1, 6))
-            tr[:, 0] = scn.x[i] + sp * np.cos(hd) * tt[:, 0]
-            tr[:, 1] = scn.y[i] + sp * np.sin(hd) * tt[:, 0]
-            tr[:, 2], tr[:, 3], tr[:, 4], tr[:, 5] = hd, sp, 1.0, scn.length[i]
-            out[i] = {"traj": tr}
-        return out
+        """The stand-in expert log (scenarios.standin_log): traj rows = x, y, heading, speed, exist, length."""
+        return _scn.standin_log(scn, self.steps, self.dt)
 
     def evaluate_policy(self):
         self.reset()

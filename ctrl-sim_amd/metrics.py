@@ -81,7 +81,7 @@ class MetricAccumulators:
     def add_scenario(self, states, coll, applied_accel, gt_states, goal_pos, goal_heading, goal_speed, cfg,
                      eval_ids=None):
         """One finished rollout.  states [N,T1,8], coll [N,T1,2], applied_accel [N,T1] (last entry 0), gt_states
-        [N,T1,5] = x, y, heading, speed, exist (synthetic scenes: constant-velocity extrapolation)."""
+        [N,T1,5] = x, y, heading, speed, exist (synthetic scenes: scenarios.standin_log)."""
         w = cfg.dataset.waymo
         dt, hist_steps = cfg.nocturne.dt, cfg.nocturne.history_steps
         N, T1 = states.shape[:2]

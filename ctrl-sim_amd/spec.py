@@ -91,13 +91,21 @@ EVAL = dict(
     partitions=1, partition=0, visualize=False, verbose=False,
 )
 
+# cfgs/eval_planner_adversary/base.yaml with cfgs/policy/ctrl_sim_{planner,adversary}.yaml mounted at .planner / .adversary
+EVAL_PLANNER_ADVERSARY = dict(
+    history_steps=10, verbose=True, seed=0, visualize=False, num_files_to_evaluate=1000,
+    planner=dict(POLICY, goal_tilt=10, veh_veh_tilt=10, veh_edge_tilt=10),
+    adversary=dict(POLICY, goal_tilt=0, veh_veh_tilt=-10, veh_edge_tilt=0),
+)
+
 
 def make_cfg(**overrides):
     """Build the attribute-style cfg. `overrides` are dotted keys with '__' separators,
     e.g. make_cfg(dataset__waymo__max_num_agents=4, nocturne__steps=20)."""
     cfg = _wrap(dict(
         dataset=dict(waymo=dict(WAYMO)), model=dict(MODEL), nocturne=copy.deepcopy(NOCTURNE),
-        eval=dict(EVAL, policy=dict(POLICY)), dataset_root="", nocturne_waymo_val_folder="",
+        eval=dict(EVAL, policy=dict(POLICY)), eval_planner_adversary=copy.deepcopy(EVAL_PLANNER_ADVERSARY),
+        dataset_root="", nocturne_waymo_val_folder="",
     ))
     for k, v in overrides.items():
         node = cfg

@@ -531,8 +531,146 @@ def gen_bicycle():
     save("bicycle_backward", nxt=nxt, prev=prev, accel_steer=res)
 
 
+# --------------------------------------------------------------------------------------------- planner vs adversary
+PLANNER_TILT = (10.0, 10.0, 10.0)       # cfgs/policy/ctrl_sim_planner.yaml:5-7
+ADVERSARY_TILT = (0.0, -10.0, 0.0)      # cfgs/policy/ctrl_sim_adversary.yaml:6-8
+
+
+def pick_ego_adversary(scn):
+    """Synthetic stand-in of the CAT dictionary (planner_adversary_evaluator.py:431-456): ego = vehicle 0, adversary = the
+    vehicle nearest to it at t = 0."""
+    d = np.hypot(scn.x - scn.x[0], scn.y - scn.y[0])
+    d[0] = np.inf
+    return 0, int(np.argmin(d))
+
+
+def ref_planner_adversary(cfg, w, scn, steps, seed, history_steps):
+    """evaluate_planner_adversary's inner loop (planner_adversary_evaluator.py:497-546) around two UNMODIFIED reference
+    policies: the planner drives the ego, the adversary drives one other vehicle, everybody else (and both of them before
+    history_steps - 1) replays the log through the reference's inverse bicycle model (evaluators/evaluator.py:160-193)."""
+    ref_shims.install()
+    from policies.autoregressive_policy import AutoregressivePolicy
+    import importlib.util
+    sp = importlib.util.spec_from_file_location("ref_bicycle_model", ref_shims.REF + "/nocturne/bicycle_model.py")
+    bmod = importlib.util.module_from_spec(sp)
+    import matplotlib
+    matplotlib.use("Agg")
+    sp.loader.exec_module(bmod)
+
+    model = ref_shims.build_reference_model(cfg, w)
+    dset = ref_shims.build_reference_dataset(cfg)
+
+    def make(role, tilt):
+        key_dict = {"next_acceleration": f"next_{role}_acceleration", "next_steering": f"next_{role}_steering",
+                    "rtgs": f"{role}_rtgs"}
+        tilt_dict = {"tilt": True, "goal_tilt": tilt[0], "veh_veh_tilt": tilt[1], "veh_edge_tilt": tilt[2]}
+        return AutoregressivePolicy(cfg=cfg, model_path="", model=model, use_rtg=True, predict_rtgs=True,
+                                    discretize_rtgs=True, real_time_rewards=False, privileged_return=False,
+                                    max_return=False, min_return=False, key_dict=key_dict, tilt_dict=tilt_dict,
+                                    name="ctrl_sim", action_temperature=1.0, nucleus_sampling=False, nucleus_threshold=0.8)
+    planner, adversary = make("planner", PLANNER_TILT), make("adversary", ADVERSARY_TILT)
+    N = scn.N
+    ego, adv = pick_ego_adversary(scn)
+    sim = RefSim(scn.length, scn.width, scn.x, scn.y, scn.heading, scn.speed, scn.edge_segments)
+    vehs = [_FakeVeh(sim, i) for i in range(N)]
+    gt = scenarios.standin_log(scn, steps)
+    vdd = {}
+    for i in range(N):
+        vdd[i] = {"position": [], "velocity": [], "heading": [], "existence": [], "acceleration": [], "steering": [],
+                  "timestep": [], "planner_rtgs": [], "next_planner_acceleration": 0., "next_planner_steering": 0.,
+                  "adversary_rtgs": [], "next_adversary_acceleration": 0., "next_adversary_steering": 0.,
+                  "goal_position": {"x": scn.goal_pos[i, 0], "y": scn.goal_pos[i, 1]},
+                  "goal_heading": scn.goal_heading[i], "goal_speed": scn.goal_speed[i],
+                  "width": scn.width[i], "length": scn.length[i], "type": "vehicle"}
+    preproc = {"road_points": scn.road_points.astype(np.float64), "road_types": scn.road_types.copy()}
+    patches = {"planner": _NoisePatch(seed, scn.index), "adversary": _NoisePatch(seed, scn.index)}
+    orig = torch.multinomial
+    states = np.zeros((N, steps + 1, 8))
+    coll = np.zeros((N, steps + 1, 2), np.uint8)
+    applied = np.zeros((N, steps, 2))
+    rtg_cont = np.zeros((2, N, steps, 3))
+    cur = {}
+
+    def update(t):
+        st, cv, ce = sim.state()
+        cur["st"] = st
+        for i in range(N):
+            vdd[i]["position"].append({"x": st[i, 0], "y": st[i, 1]})
+            vdd[i]["velocity"].append({"x": st[i, 4], "y": st[i, 5]})
+            vdd[i]["heading"].append(st[i, 2])
+            vdd[i]["timestep"].append(t)
+            vdd[i]["existence"].append(1.0)
+            states[i, t] = [st[i, 0], st[i, 1], st[i, 4], st[i, 5], st[i, 2], scn.length[i], scn.width[i], 1.0]
+        coll[:, t, 0], coll[:, t, 1] = cv, ce
+
+    def apply_gt_action(i, t):
+        tr = gt[i]["traj"]
+        st = cur["st"]
+        bm = bmod.BicycleModel(x=tr[t + 1][0], y=tr[t + 1][1], theta=tr[t + 1][2], vel=tr[t + 1][3], L=tr[t + 1][-1], dt=0.1)
+        a, s, _, _ = bm.backward(prev_pos=np.array([st[i, 0], st[i, 1]]), prev_theta=st[i, 2], prev_vel=st[i, 3])
+        v = vehs[i]
+        if a > 0.0:
+            v.acceleration = a
+        else:
+            v.brake(np.abs(a))
+        v.steering = s
+        return [a, s]
+
+    try:
+        planner.reset(vdd)
+        adversary.reset(vdd)
+        for t in range(steps):
+            update(t)
+            planner.update_state(vdd, [ego], t)
+            adversary.update_state(vdd, [adv], t)
+            for role, pol, who in (("planner", planner, ego), ("adversary", adversary, adv)):
+                patches[role].t = t
+                torch.multinomial = patches[role]
+                vdd = pol.predict(vdd, gt, preproc, dset, [who], t)
+                torch.multinomial = orig
+            for i in range(N):
+                if t >= history_steps - 1 and i == ego:
+                    _, act = planner.act(vehs[i], t, vdd)
+                elif t >= history_steps - 1 and i == adv:
+                    _, act = adversary.act(vehs[i], t, vdd)
+                else:
+                    act = apply_gt_action(i, t)
+                vdd[i]["acceleration"].append(act[0])
+                vdd[i]["steering"].append(act[1])
+                applied[i, t] = act
+                rtg_cont[0, i, t] = vdd[i]["planner_rtgs"][-1]
+                rtg_cont[1, i, t] = vdd[i]["adversary_rtgs"][-1]
+            sim.step(0.1)
+        update(steps)
+    finally:
+        torch.multinomial = orig
+        sim.close()
+    tokens = dset.discretize_actions(applied.copy())
+    return dict(states=states, coll=coll, actions=applied, tokens=tokens, rtg_cont=rtg_cont, ego_adv=np.array([ego, adv]),
+                margins=np.array(patches["planner"].log + patches["adversary"].log))
+
+
+def gen_planner_adversary():
+    cfg = spec.make_cfg(**LOOP)
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    out = {}
+    for tag, idx0, n_ag, n_pl, extent, hist in (("a", 0, 8, 12, 25.0, 3), ("b", 1, 10, 9, 30.0, 1)):
+        for idx in range(idx0, 50):     # first scene whose sampling races are all clear of ties ("b": and with a collision)
+            scn = scenarios.make_scenario(9, idx, n_agents=n_ag, n_polylines=n_pl, n_points=d.NP, extent=extent)
+            r = ref_planner_adversary(cfg, w, scn, 20, seed=3, history_steps=hist)
+            if r["margins"].min() > 2e-4 and (tag == "a" or r["coll"][..., 0].sum() > 0):
+                break
+        print(tag, "ego/adv", r["ego_adv"], "veh-veh flags", r["coll"][..., 0].sum(), "min race margin", r["margins"].min())
+        for k, v in r.items():
+            out[f"{tag}_{k}"] = v
+        out[f"{tag}_recipe"] = np.array([9, idx, n_ag, n_pl, extent, 3, hist])
+    save("planner_adversary", **out)
+
+
 ALL = dict(model=gen_model, features=gen_features, sampling=gen_sampling, physics=gen_physics,
-           collision=gen_collision, closed_loop=gen_closed_loop, bicycle=gen_bicycle, contacts=gen_contacts)
+           collision=gen_collision, closed_loop=gen_closed_loop, bicycle=gen_bicycle, contacts=gen_contacts,
+           planner_adversary=gen_planner_adversary)
 
 if __name__ == "__main__":
     assert ref_shims.available(), "the reference tree is required to (re)generate golden vectors"

@@ -82,17 +82,50 @@ class RolloutOracle:
             return mo.forward(self.tw, {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in data.items()},
                               self.dims)
 
+    def policy_step(self, buf, scn, t, eval_list, tilt, explicit_noise=None, groups_log=None):
+        """One AutoregressivePolicy.predict (autoregressive_policy.py:168-253) on the policy's own buffers `buf` for the
+        vehicles `eval_list`: -> (processed {veh: rtg bins}, tokens {veh: id}, next_act {veh: (a, s)}, dead, n_groups)."""
+        w, dims = self.w, self.dims
+        T = w.train_context_length
+        tilt_on = fo.tilt_logits(*tilt, w)
+        tilt_off = fo.tilt_logits(0, 0, 0, w)
+        groups, dead = fo.build_contexts(buf, w, t, list(eval_list), scn.road_points.astype(np.float64), scn.road_types)
+        ti = t if t < T else T - 1                                    # token_index (t or -1)
+        processed, tokens, next_act = {}, {}, {}
+        for g in groups:
+            data = g["data"]
+            noise_for = lambda agent: (lambda head, n: explicit_noise(t, agent, head, n) if explicit_noise
+                                       else self._noise(self.seed, scn.index, t, agent, head, n))
+            preds = self.forward(data)                                # pass 1
+            rtg_logits = preds["rtg_preds"][0]
+            for v in fo_persisted(buf, g):                            # context vehicles, ascending global index
+                s = g["slot"][v]
+                if v not in processed:
+                    tl = tilt_on if v in g["members"] else tilt_off
+                    processed[v] = sample_rtg(rtg_logits[s, ti], tl, dims.R, dims.C, noise_for(v))
+                data["rtgs"][0, s, ti] = processed[v]
+            preds = self.forward(data)                                # pass 2
+            act_logits = preds["action_preds"][0]
+            for v in g["members"]:
+                tok = sample_action(act_logits[g["slot"][v], ti], self.temperature, self.nucleus, self.top_p,
+                                    noise_for(v))
+                tokens[v] = tok
+                next_act[v] = fo.undiscretize_actions(np.array([[tok]]), w)[0, 0]
+            if groups_log is not None:
+                groups_log.append(dict(t=t, focal=g["focal"], ids=list(g["ids"]), members=list(g["members"])))
+        for v in dead:
+            next_act[v] = np.zeros(2)
+        return processed, tokens, next_act, dead, len(groups)
+
     def run(self, scn, steps, sim_cls, explicit_noise=None, record_groups=False, dt=0.1):
         """Roll one scenario.  Returns dict(tokens[N,steps], rtg_bins[N,steps,3], states[N,steps+1,8] f32-valued,
         coll[N,steps+1,2], actions[N,steps,2], n_groups[steps])."""
-        w, dims = self.w, self.dims
-        N, T = scn.N, w.train_context_length
+        w = self.w
+        N = scn.N
         sim = sim_cls(scn.length, scn.width, scn.x, scn.y, scn.heading, scn.speed, scn.edge_segments)
         buf = fo.PolicyBuffers(N, steps)
         buf.types[:] = scn.types
         goals5 = scn.goals5()
-        tilt_on = fo.tilt_logits(*self.tilt, w)
-        tilt_off = fo.tilt_logits(0, 0, 0, w)
         states = np.zeros((N, steps + 1, 8))
         coll = np.zeros((N, steps + 1, 2), np.uint8)
         tokens = -np.ones((N, steps), np.int64)
@@ -100,7 +133,7 @@ class RolloutOracle:
         applied = np.zeros((N, steps, 2))
         rtg_list = np.zeros((N, steps, 3))
         n_groups = np.zeros(steps, np.int64)
-        groups_log = []
+        groups_log = [] if record_groups else None
         exist = np.ones(N)
 
         def read_state(t):
@@ -119,39 +152,17 @@ class RolloutOracle:
                 buf.actions[:, t - 1] = applied[:, t - 1]             # policy.py:85-92
                 buf.rtgs[:, t - 1] = rtg_list[:, t - 1]
             buf.goals[:, t] = goals5
-            groups, dead = fo.build_contexts(buf, w, t, list(scn.eval_order), scn.road_points.astype(np.float64),
-                                             scn.road_types)
-            n_groups[t] = len(groups)
-            ti = t if t < T else T - 1                                # token_index (t or -1)
-            processed = {}
+            processed, toks, acts, dead, n_groups[t] = self.policy_step(buf, scn, t, scn.eval_order, self.tilt,
+                                                                        explicit_noise, groups_log)
             next_act = np.zeros((N, 2))
-            for g in groups:
-                data = g["data"]
-                noise_for = lambda agent: (lambda head, n: explicit_noise(t, agent, head, n) if explicit_noise
-                                           else self._noise(self.seed, scn.index, t, agent, head, n))
-                preds = self.forward(data)                            # pass 1
-                rtg_logits = preds["rtg_preds"][0]
-                for v in fo_persisted(buf, g):                        # context vehicles, ascending global index
-                    s = g["slot"][v]
-                    if v not in processed:
-                        tl = tilt_on if v in g["members"] else tilt_off
-                        processed[v] = sample_rtg(rtg_logits[s, ti], tl, dims.R, dims.C, noise_for(v))
-                    data["rtgs"][0, s, ti] = processed[v]
-                preds = self.forward(data)                            # pass 2
-                act_logits = preds["action_preds"][0]
-                for v in g["members"]:
-                    tok = sample_action(act_logits[g["slot"][v], ti], self.temperature, self.nucleus, self.top_p,
-                                        noise_for(v))
-                    tokens[v, t] = tok
-                    next_act[v] = fo.undiscretize_actions(np.array([[tok]]), w)[0, 0]
-                if record_groups:
-                    groups_log.append(dict(t=t, focal=g["focal"], ids=list(g["ids"]), members=list(g["members"])))
+            for v, tok in toks.items():
+                tokens[v, t] = tok
+            for v, a in acts.items():
+                next_act[v] = a
             for v in range(N):                                        # autoregressive_policy.py:242-247
                 if v in processed:
                     rtg_bins[v, t] = processed[v]
                     rtg_list[v, t] = fo.undiscretize_rtgs(np.array([[processed[v]]]), w)[0, 0]
-            for v in dead:
-                next_act[v] = 0.0
             for v in range(N):                                        # act(): autoregressive_policy.py:256-274
                 if not exist[v]:
                     sim.set_position(v, -1000000, -1000000)
@@ -167,6 +178,64 @@ class RolloutOracle:
         if record_groups:
             out["groups"] = groups_log
         return out
+
+    def run_planner_adversary(self, scn, steps, sim_cls, ego, adv, gt, history_steps, planner_tilt, adversary_tilt, dt=0.1):
+        """evaluate_planner_adversary's loop (evaluators/planner_adversary_evaluator.py:497-546): two policies with their own
+        buffers and tilts, the planner drives `ego`, the adversary drives `adv`, every other vehicle (and both of them before
+        history_steps - 1) replays the log `gt` through the inverse bicycle model (evaluators/evaluator.py:160-193,
+        nocturne/bicycle_model.py:51-109).  -> dict(states, coll, actions, rtg_cont[2,N,steps,3])."""
+        from ctrlsim_amd.kinematics import bicycle_backward
+        w = self.w
+        N = scn.N
+        sim = sim_cls(scn.length, scn.width, scn.x, scn.y, scn.heading, scn.speed, scn.edge_segments)
+        roles = ((ego, planner_tilt), (adv, adversary_tilt))
+        bufs = [fo.PolicyBuffers(N, steps) for _ in roles]
+        for b in bufs:
+            b.types[:] = scn.types
+        goals5 = scn.goals5()
+        states = np.zeros((N, steps + 1, 8))
+        coll = np.zeros((N, steps + 1, 2), np.uint8)
+        applied = np.zeros((N, steps, 2))
+        rtg_cont = np.zeros((2, N, steps, 3))
+
+        def read_state(t):
+            st, cv, ce = sim.state()
+            row = np.stack([st[:, 0], st[:, 1], st[:, 4], st[:, 5], st[:, 2], scn.length, scn.width,
+                            np.ones(N, np.float32)], 1).astype(np.float64)
+            states[:, t] = row
+            coll[:, t, 0], coll[:, t, 1] = cv, ce
+            return row, st
+
+        for t in range(steps):
+            row, st = read_state(t)
+            chosen = {}
+            for r, ((who, tilt), buf) in enumerate(zip(roles, bufs)):
+                buf.states[:, t] = row
+                buf.timesteps[:, t, 0] = t
+                if t > 0:
+                    buf.actions[:, t - 1] = applied[:, t - 1]
+                    buf.rtgs[:, t - 1] = rtg_cont[r, :, t - 1]
+                buf.goals[:, t] = goals5
+            for r, ((who, tilt), buf) in enumerate(zip(roles, bufs)):
+                processed, _, acts, _, _ = self.policy_step(buf, scn, t, [who], tilt)
+                for v, bins in processed.items():
+                    rtg_cont[r, v, t] = fo.undiscretize_rtgs(np.array([[bins]]), w)[0, 0]
+                chosen[who] = acts.get(who, np.zeros(2))
+            for v in range(N):
+                if t >= history_steps - 1 and v in chosen:
+                    a, s = chosen[v]
+                else:                                                 # apply_gt_action
+                    tr = gt[v]["traj"]
+                    nxt = np.array([[tr[t + 1][0], tr[t + 1][1], tr[t + 1][2], tr[t + 1][3], tr[t + 1][-1]]])
+                    prev = np.array([[st[v, 0], st[v, 1], st[v, 2], st[v, 3]]], np.float64)
+                    aa, ss = bicycle_backward(nxt, prev, dt)
+                    a, s = float(aa[0]), float(ss[0])
+                sim.set_action(v, a, s)
+                applied[v, t] = (a, s)
+            sim.step(dt)
+        read_state(steps)
+        sim.close()
+        return dict(states=states, coll=coll, actions=applied, rtg_cont=rtg_cont)
 
 
 def fo_persisted(buf, g):

@@ -271,6 +271,33 @@ def test_rollout_oracle_matches_reference_closed_loop(tag):
     assert g[f"{tag}_margins"].min() > 1e-4                     # no sampling race was a near-tie
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_rollout_oracle_matches_reference_planner_vs_adversary(tag):
+    """Planner-vs-adversary driver (evaluators/planner_adversary_evaluator.py:497-546): two unmodified reference policies
+    with the planner / adversary tilts of cfgs/policy/ctrl_sim_{planner,adversary}.yaml, one vehicle each, everybody else
+    (and both before history_steps - 1) log-replayed through the reference's inverse bicycle model, real FreeCar/Box2D
+    underneath ("b" has the two colliding) — vs the restated loop + C sim: applied actions, RTGs, states, flags identical."""
+    import gen_golden
+    cfg = cfg_of("loop")
+    d = spec.Dims(cfg)
+    g = golden("planner_adversary")
+    rc = g[f"{tag}_recipe"]
+    scn = scenarios.make_scenario(int(rc[0]), int(rc[1]), n_agents=int(rc[2]), n_polylines=int(rc[3]), n_points=d.NP,
+                                  extent=float(rc[4]))
+    ego, adv = gen_golden.pick_ego_adversary(scn)
+    assert [ego, adv] == list(g[f"{tag}_ego_adv"])
+    ro = rollout_oracle.RolloutOracle(cfg, weights.generate(d, 0), seed=int(rc[5]))
+    r = ro.run_planner_adversary(scn, 20, sim_libs.OracleSim, ego, adv, scenarios.standin_log(scn, 20),
+                                 int(rc[6]), gen_golden.PLANNER_TILT, gen_golden.ADVERSARY_TILT)
+    if tag == "b":
+        assert g[f"{tag}_coll"][..., 0].sum() > 0
+    np.testing.assert_allclose(r["actions"], g[f"{tag}_actions"], atol=1e-12, rtol=0)
+    np.testing.assert_allclose(r["rtg_cont"], g[f"{tag}_rtg_cont"], atol=1e-9, rtol=0)
+    assert np.array_equal(r["states"], g[f"{tag}_states"])
+    assert np.array_equal(r["coll"], g[f"{tag}_coll"])
+    assert g[f"{tag}_margins"].min() > 1e-4
+
+
 def test_inverse_bicycle_matches_reference():
     """G10: nocturne/bicycle_model.py:51-109 (log-replay actions)."""
     from ctrlsim_amd.kinematics import bicycle_backward
