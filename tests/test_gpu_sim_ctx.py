@@ -296,6 +296,32 @@ def test_rollout_matches_oracle_on_fresh_scenarios_full_dims():
         assert np.array_equal(r["coll"][s], o["coll"])
 
 
+@pytest.mark.parametrize("n_ag,n_pl,extent,steps", [(1, 3, 30.0, 12),      # a single vehicle: one context with one agent
+                                                     (5, 6, 600.0, 10),     # everybody > 60 m apart: five contexts of one
+                                                     (14, 2, 16.0, 10),     # more vehicles than the 6 context slots of the
+                                                                            # small model, packed: agents dropped from
+                                                                            # contexts, pile-up contacts from step 0
+                                                     (9, 30, 40.0, 10)])    # more polylines than the model's map slots
+def test_rollout_edge_cases_match_oracle(n_ag, n_pl, extent, steps):
+    """Ragged / extreme scenes through the whole closed loop (small model, window T = 8 so the sliding-window phase is
+    reached) vs the CPU oracle: same focal groups, tokens, RTG bins, collision flags; states within 1e-4."""
+    cfg = cfg_of("loop")
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    scn = scenarios.make_scenario(41, n_ag, n_agents=n_ag, n_polylines=n_pl, n_points=d.NP, extent=extent)
+    eng = RolloutEngine(cfg, w, DEV, max_ctx=32, seed=2, tilt=(0.0, -10.0, 5.0))
+    eng.load_scenarios([scn], steps=steps)
+    r = eng.run(steps).results()
+    o = rollout_oracle.RolloutOracle(cfg, w, seed=2, tilt=(0.0, -10.0, 5.0)).run(scn, steps, sim_libs.OracleSim)
+    assert np.array_equal(r["n_groups"][:, 0], o["n_groups"])
+    assert np.array_equal(r["tokens"][0][:, :steps], o["tokens"])
+    assert np.array_equal(r["rtg_bins"][0][:, :steps], o["rtg_bins"])
+    np.testing.assert_allclose(r["states"][0], o["states"], atol=1e-4, rtol=0)
+    assert np.array_equal(r["coll"][0], o["coll"])
+    if extent < 20:
+        assert o["coll"][..., 0].sum() > 0
+
+
 @pytest.mark.parametrize("kind,n_ag,n_pl,steps", [("loop", 10, 20, 14), ("full", 12, 40, 5)])
 def test_kv_cached_phase_equals_full_recompute(kind, n_ag, n_pl, steps):
     """While t < T the engine evaluates only the 4A changed token rows against cached K/V (chunk-major); the result
