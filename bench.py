@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--max-ctx", type=int, default=512, help="model batch (contexts per forward chunk)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--tilt", type=float, nargs=3, default=(0.0, 0.0, 0.0))
+    ap.add_argument("--tilt-sweep", action="store_true",
+                    help="BASELINE configs[4]: scenario i runs with goal = veh = road tilt TILT_SWEEP[i %% 8] (one batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-steps", type=int, default=6)
     args = ap.parse_args()
@@ -80,7 +82,11 @@ def main():
     # global scenario ids: interleaved over ranks (rank r takes r, r+W, ...) so results do not depend on W
     ids = [rank + i * world for i in range(S)]
     scns = scenarios.make_batch(args.seed, ids, n_agents=N, n_polylines=args.polylines)
-    eng = RolloutEngine(cfg, w, device, max_ctx=args.max_ctx, seed=args.seed, tilt=tuple(args.tilt))
+    tilt = tuple(args.tilt)
+    if args.tilt_sweep:                                       # the sweep values of config 5
+        sweep = np.array([-20.0, -10.0, -5.0, 0.0, 5.0, 10.0, 20.0, 30.0])
+        tilt = np.repeat(sweep[np.array(ids) % 8][:, None], 3, axis=1)
+    eng = RolloutEngine(cfg, w, device, max_ctx=args.max_ctx, seed=args.seed, tilt=tilt)
     eng.load_scenarios(scns, steps=R)
     lib = _lib.lib()
 
@@ -179,6 +185,7 @@ def main():
                        "scenarios_per_gpu": S, "agents": N, "rollout_steps": R, "polylines": args.polylines,
                        "model_batch_contexts": args.max_ctx, "contexts_per_rollout_rank0": ctx_per_rollout,
                        "mean_focal_groups_per_scenario_step": ctx_per_rollout / (S * R),
+                       "tilt": "sweep of 8 values, one per scenario (configs[4])" if args.tilt_sweep else list(args.tilt),
                        "parallelism": f"scenario-sharded x{world}"},
             "roofline": roof, "cpu_baseline": cpu,
             "rollout_metrics": {k: (None if v != v else v) for k, v in m.items()},

@@ -53,7 +53,7 @@ SIGNATURES = {
     "ctrlsim_dt_forward_pass1": (I, [P, I, I, C.POINTER(Ctx), P, P, P, P]),
     "ctrlsim_dt_forward_pass2": (I, [P, I, I, I, I, I, C.POINTER(Ctx), P, P, P, P, I, P]),
     "ctrlsim_dt_forward_pass1_cached": (I, [P, I, I, C.POINTER(Ctx), P, P, P]),
-    "ctrlsim_sample_rtg": (I, [P, I, I, P, P, P, P, P, U64, P, I, P, I, I, I, P]),
+    "ctrlsim_sample_rtg": (I, [P, I, I, P, P, P, P, P, P, U64, P, I, P, I, I, I, P]),
     "ctrlsim_sample_action": (I, [P, I, I, P, P, F, D, P, U64, P, I, P, P, I, I, I, I, P]),
 }
 

@@ -28,7 +28,7 @@ struct CtxOut { float *st12, *exist, *goal5; int *act_tok, *rtg_bin, *tstep, *sl
 int launch_build_context(int, int, int, int, int, int, int, int, int, int, int, int, const int*, const int*, const int*,
                          const unsigned long long*, const float*, const int*, const int*, const double*, const float*,
                          const float*, const float*, const int*, CtxOut, hipStream_t);
-int launch_sample_rtg(const float*, int, int, const int*, const int*, const unsigned char*, const double*, const float*,
+int launch_sample_rtg(const float*, int, int, const int*, const int*, const unsigned char*, const double*, const double*, const float*,
                       uint64_t, const int64_t*, int, int*, int, int, int, hipStream_t);
 int launch_sample_action(const float*, int, int, const int*, const int*, float, double, const float*, uint64_t,
                          const int64_t*, int, int*, int*, int, int, int, int, hipStream_t);
@@ -164,10 +164,10 @@ int ctrlsim_build_context(int B, int N, int A, int T, int t, int Tq, int tt_firs
                               road_types, zero4, o, st);
 }
 int ctrlsim_sample_rtg(const float* rtg_logits, int A, int R, const int* own_ctx, const int* own_slot, const uint8_t* tilted,
-                       const double* tilt3, const float* noise, uint64_t seed, const int64_t* scenario_id, int t,
-                       int* hist_rtg, int S, int N, int Tmax, hipStream_t st) {
+                       const double* tilt3, const double* tilt_scn, const float* noise, uint64_t seed, const int64_t* scenario_id,
+                       int t, int* hist_rtg, int S, int N, int Tmax, hipStream_t st) {
   if (!tilt3) return CTRLSIM_EINVAL;
-  return launch_sample_rtg(rtg_logits, A, R, own_ctx, own_slot, tilted, tilt3, noise, seed, scenario_id, t, hist_rtg, S, N,
+  return launch_sample_rtg(rtg_logits, A, R, own_ctx, own_slot, tilted, tilt3, tilt_scn, noise, seed, scenario_id, t, hist_rtg, S, N,
                            Tmax, st);
 }
 int ctrlsim_sample_action(const float* act_logits, int A, int V, const int* mem_ctx, const int* mem_slot, float temperature,

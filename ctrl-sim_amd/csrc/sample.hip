@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void sample_rtg_kernel(const float* __restrict
                                                          const int* __restrict__ own_slot,
                                                          const unsigned char* __restrict__ tilted, double tilt_goal,
                                                          double tilt_veh, double tilt_road,
+                                                         const double* __restrict__ tilt_scn,  // [S,3] or null (uniform)
                                                          const float* __restrict__ noise,      // [S*N, 3, R] or null
                                                          uint64_t seed, const int64_t* __restrict__ scenario_id, int t,
                                                          int* __restrict__ hist_rtg, int N, int Tmax, int SN) {
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(256) void sample_rtg_kernel(const float* __restrict
   const int s = sv / N, v = sv - s * N;
   const float* lg = rtg_logits + ((size_t)ctx * A + own_slot[sv]) * (size_t)(R * 3);
   const bool tl = tilted[sv] != 0;
+  if (tilt_scn) { tilt_goal = tilt_scn[3 * s]; tilt_veh = tilt_scn[3 * s + 1]; tilt_road = tilt_scn[3 * s + 2]; }
   const double tilts[3] = {tl ? tilt_goal : 0.0, tl ? tilt_veh : 0.0, tl ? tilt_road : 0.0};
   const double step = 1.0 / (double)(R - 1);        // np.linspace(0, 1, R)[i] = i * step  (endpoint exact)
 #pragma unroll
@@ -139,13 +141,13 @@ __global__ __launch_bounds__(256) void sample_action_kernel(const float* __restr
 }
 
 int launch_sample_rtg(const float* rtg_logits, int A, int R, const int* own_ctx, const int* own_slot,
-                      const unsigned char* tilted, const double* tilt3, const float* noise, uint64_t seed,
+                      const unsigned char* tilted, const double* tilt3, const double* tilt_scn, const float* noise, uint64_t seed,
                       const int64_t* scenario_id, int t, int* hist_rtg, int S, int N, int Tmax, hipStream_t st) {
   const int SN = S * N;
   if (SN <= 0) return CTRLSIM_OK;
   if (t < 0 || t >= Tmax) return CTRLSIM_EINVAL;
   hipLaunchKernelGGL(sample_rtg_kernel, dim3((SN + 3) / 4), dim3(256), 0, st, rtg_logits, A, R, own_ctx, own_slot, tilted,
-                     tilt3[0], tilt3[1], tilt3[2], noise, seed, scenario_id, t, hist_rtg, N, Tmax, SN);
+                     tilt3[0], tilt3[1], tilt3[2], tilt_scn, noise, seed, scenario_id, t, hist_rtg, N, Tmax, SN);
   return ctrlsim_launch_status();
 }
 

@@ -119,7 +119,11 @@ class RolloutEngine:
         nuc = bool(pol.nucleus_sampling if nucleus is None else nucleus)
         self.top_p = float(pol.nucleus_threshold if top_p is None else top_p) if nuc else 0.0
         self.seed = int(seed)
-        self.tilt = (C.c_double * 3)(*[float(x) for x in tilt])
+        # tilt = (goal, veh_veh, veh_edge) for every scenario, or an [S,3] array: one triple per scenario (tilt sweep)
+        tilt = np.asarray(tilt, np.float64)
+        self._tilt_per_scenario = tilt if tilt.ndim == 2 else None
+        self.tilt_scn = None
+        self.tilt = (C.c_double * 3)(*([0.0, 0.0, 0.0] if tilt.ndim == 2 else [float(x) for x in tilt]))
         self.kinematic = int(bool(kinematic))
         self.max_ctx = int(max_ctx)
         self.use_cache = bool(use_cache)
@@ -167,6 +171,9 @@ class RolloutEngine:
             eo[i, :len(s.eval_order)] = s.eval_order
         self.eval_order = torch.from_numpy(eo).to(dev)
         self.scenario_id = torch.tensor([s.index for s in scns], dtype=torch.int64, device=dev)
+        if self._tilt_per_scenario is not None:
+            assert self._tilt_per_scenario.shape == (S, 3), "per-scenario tilt must be [S,3]"
+            self.tilt_scn = torch.from_numpy(np.ascontiguousarray(self._tilt_per_scenario)).to(dev)
         z = lambda *sh, dt=torch.float32: torch.zeros(*sh, dtype=dt, device=dev)
         self.phys = z(S, N, 20)
         # Box2D contact manifolds + impulses per vehicle pair (None = contact-free integration)
@@ -263,8 +270,9 @@ class RolloutEngine:
         _lib.check(lib.ctrlsim_dt_forward_pass1_cached(self.model.handle, B, t, C.byref(self.ctx.struct), p(ws),
                                                        p(self.rtg_logits), st), "pass1_cached")
         _lib.check(lib.ctrlsim_sample_rtg(p(self.rtg_logits), d.A, d.R, p(self.own_ctx[sl]), p(self.own_slot[sl]),
-                                          p(self.tilted[sl]), self.tilt, None, self.seed, p(self.scenario_id[sl]), t,
-                                          p(self.hist_rtg[sl]), ns, N, Tmax, st), "sample_rtg")
+                                          p(self.tilted[sl]), self.tilt,
+                                          p(self.tilt_scn[sl]) if self.tilt_scn is not None else None, None, self.seed,
+                                          p(self.scenario_id[sl]), t, p(self.hist_rtg[sl]), ns, N, Tmax, st), "sample_rtg")
         _lib.check(lib.ctrlsim_dt_forward_pass2(self.model.handle, B, Tq, t, N, Tmax, C.byref(self.ctx.struct), p(self.ctx_scn),
                                                 p(self.hist_rtg), p(ws), p(self.act_logits), 1, st), "pass2_cached")
         _lib.check(lib.ctrlsim_sample_action(p(self.act_logits), d.A, d.V, p(self.mem_ctx[sl]), p(self.mem_slot[sl]),
@@ -334,6 +342,7 @@ class RolloutEngine:
                 self.mem_ctx[sl].fill_(-1)
             _lib.check(lib.ctrlsim_sample_rtg(p(self.rtg_logits), d.A, d.R, p(self.own_ctx[sl]), p(self.own_slot[sl]),
                                               p(self.tilted[sl]), self.tilt,
+                                              p(self.tilt_scn[sl]) if self.tilt_scn is not None else None,
                                               p(noise_rtg[sl]) if noise_rtg is not None else None, self.seed,
                                               p(self.scenario_id[sl]), t, p(self.hist_rtg[sl]), ns, N, Tmax, st),
                        "sample_rtg")

@@ -121,11 +121,13 @@ int ctrlsim_dt_forward_pass1_cached(const ctrlsim_model* m, int B, int t, const 
 /* ---- sampling -------------------------------------------------------------------------------------------------
  * Replaces Policy.process_predicted_rtg (policies/policy.py:108-142) and the action-sampling block of
  * AutoregressivePolicy.predict (autoregressive_policy.py:211-240): tilt, softmax, torch.multinomial as an
- * exponential race with explicit (noise != NULL) or in-kernel counter-based Exp(1) noise. */
+ * exponential race with explicit (noise != NULL) or in-kernel counter-based Exp(1) noise.
+ * tilt3 = (goal, veh_veh, veh_edge) tilts of the policy (host pointer; tilt_dict of policies/policy.py:20-25) applied to
+ * every scenario, unless tilt_scn (device, [S,3]) gives one triple per scenario — a reward-tilt sweep in one batch. */
 int ctrlsim_sample_rtg(const float* rtg_logits, int A, int R, const int* own_ctx, const int* own_slot,
-                       const uint8_t* tilted, const double* tilt3, const float* noise /*[S*N,3,R] or NULL*/,
-                       uint64_t seed, const int64_t* scenario_id /*[S]*/, int t, int* hist_rtg, int S, int N, int Tmax,
-                       hipStream_t stream);
+                       const uint8_t* tilted, const double* tilt3, const double* tilt_scn /*[S,3] or NULL*/,
+                       const float* noise /*[S*N,3,R] or NULL*/, uint64_t seed, const int64_t* scenario_id /*[S]*/, int t,
+                       int* hist_rtg, int S, int N, int Tmax, hipStream_t stream);
 int ctrlsim_sample_action(const float* act_logits, int A, int V, const int* mem_ctx, const int* mem_slot,
                           float temperature, double top_p /*<=0: off*/, const float* noise /*[S*N,V] or NULL*/,
                           uint64_t seed, const int64_t* scenario_id, int t, int* hist_tok, int* act_now /*[S,N]*/,

@@ -222,7 +222,7 @@ def test_sampling_matches_reference_fixture_and_in_kernel_noise():
     for ti, tl in enumerate(g["tilts"]):
         hist = torch.zeros(S, N, Tmax, 3, dtype=torch.int32, device=DEV)
         tilt = (C.c_double * 3)(*tl)
-        _lib.check(lib.ctrlsim_sample_rtg(p(rtg_logits), A, d.R, p(ctx0), p(slot), p(tilted), tilt, p(noise_r), 0, p(sid), t,
+        _lib.check(lib.ctrlsim_sample_rtg(p(rtg_logits), A, d.R, p(ctx0), p(slot), p(tilted), tilt, None, p(noise_r), 0, p(sid), t,
                                           p(hist), S, N, Tmax, st))
         torch.cuda.synchronize()
         assert np.array_equal(hist.cpu().numpy()[0, :, t], g[f"rtg_bins_tilt{ti}"])
@@ -241,7 +241,7 @@ def test_sampling_matches_reference_fixture_and_in_kernel_noise():
     _lib.check(lib.ctrlsim_sample_action(p(act_logits), A, d.V, p(ctx0), p(slot), 1.0, 0.0, None, 9, p(sid), 0, p(hist), p(now),
                                          S, N, Tmax, 524, st))
     hr = torch.zeros(S, N, Tmax, 3, dtype=torch.int32, device=DEV)
-    _lib.check(lib.ctrlsim_sample_rtg(p(rtg_logits), A, d.R, p(ctx0), p(slot), p(tilted), (C.c_double * 3)(0, 0, 0), None, 9,
+    _lib.check(lib.ctrlsim_sample_rtg(p(rtg_logits), A, d.R, p(ctx0), p(slot), p(tilted), (C.c_double * 3)(0, 0, 0), None, None, 9,
                                       p(sid), 0, p(hr), S, N, Tmax, st))
     torch.cuda.synchronize()
     assert np.array_equal(hist.cpu().numpy()[0, :, 0], g["act_tok_t1"])
@@ -320,6 +320,27 @@ def test_rollout_edge_cases_match_oracle(n_ag, n_pl, extent, steps):
     assert np.array_equal(r["coll"][0], o["coll"])
     if extent < 20:
         assert o["coll"][..., 0].sum() > 0
+
+
+def test_tilt_sweep_in_one_batch_equals_one_engine_per_tilt():
+    """BASELINE configs[4] (reward-tilt sweep): per-scenario tilt triples in ONE batch give each scenario exactly the rollout
+    it has in a batch of its own with that tilt as the policy-wide tilt_dict."""
+    cfg = cfg_of("loop")
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    tilts = np.array([[-20.0, -20.0, -20.0], [0.0, 0.0, 0.0], [10.0, -10.0, 30.0], [5.0, 5.0, 5.0]])
+    scns = [scenarios.make_scenario(51, i % 2, n_agents=9, n_polylines=10, n_points=d.NP, extent=35.0) for i in range(4)]
+    eng = RolloutEngine(cfg, w, DEV, max_ctx=32, seed=4, tilt=tilts)
+    eng.load_scenarios(scns, steps=12)
+    r = eng.run(12).results()
+    for i in range(4):
+        e1 = RolloutEngine(cfg, w, DEV, max_ctx=32, seed=4, tilt=tuple(tilts[i]))
+        e1.load_scenarios([scns[i]], steps=12)
+        r1 = e1.run(12).results()
+        assert np.array_equal(r["tokens"][i], r1["tokens"][0]) and np.array_equal(r["rtg_bins"][i], r1["rtg_bins"][0])
+        assert np.array_equal(r["states"][i], r1["states"][0]) and np.array_equal(r["coll"][i], r1["coll"][0])
+    # the tilt matters: same scene (0 and 2 share scenario index 0), different tilts -> different RTGs
+    assert not np.array_equal(r["rtg_bins"][0], r["rtg_bins"][2])
 
 
 @pytest.mark.parametrize("kind,n_ag,n_pl,steps", [("loop", 10, 20, 14), ("full", 12, 40, 5)])
