@@ -123,30 +123,57 @@ class PolicyEvaluator:
         """The stand-in expert log (scenarios.standin_log): traj rows = x, y, heading, speed, exist, length."""
         return _scn.standin_log(scn, self.steps, self.dt)
 
-    def evaluate_policy(self):
-        self.reset()
-        syn = self.synthetic
+    def _scenes(self, syn):
+        """-> (scenario, ground-truth dict keyed by vehicle index, indices of the vehicles that move): Nocturne JSON files
+        when cfg.eval.scenario_files lists any (ctrlsim_amd.ingest: the reference's load_scenario + get_ground_truth_states +
+        get_moving_vehicles + preprocessed road arrays), synthetic scenes otherwise."""
         d_model = self.policy.model.dims
+        files = self.cfg.eval.get("scenario_files")
+        if files:
+            from .. import ingest
+            for k, path in enumerate(files):
+                scn, info = ingest.load_nocturne_json(path, index=k, max_pts=d_model.NP, steps=self.steps)
+                gt = {i: info["gt_data_dict"][int(vid)] for i, vid in enumerate(info["ids"])}
+                yield scn, gt, [i for i in range(scn.N) if info["moving"][i]]
+            return
         for k in range(int(syn["num_scenarios"])):
             scn = _scn.make_scenario(int(syn.get("seed", 0)), k, n_agents=int(syn["n_agents"]),
                                      n_polylines=int(syn["n_polylines"]), n_points=d_model.NP,
                                      extent=float(syn.get("extent", 100.0)))
+            yield scn, self._ground_truth(scn), list(range(scn.N))
+
+    # ---- evaluators/evaluator.py:60-76
+    def initialize_goal_dict(self, scn, v, gt_traj):
+        pos, heading, speed = scn.goal_pos[v].astype(np.float64), float(scn.goal_heading[v]), float(scn.goal_speed[v])
+        gone = np.where(gt_traj[:, 4] == 0)[0]
+        if len(gone) > 0:                                              # leaves the log: the goal is where it was last seen
+            i = gone[0] - 1
+            if np.linalg.norm(gt_traj[i, :2] - pos) > 0.0:
+                pos, heading, speed = gt_traj[i, :2], gt_traj[i, 2], gt_traj[i, 3]
+        return {"pos": pos, "heading": heading, "speed": speed}
+
+    def evaluate_policy(self):
+        self.reset()
+        n_done = 0
+        for scn, gt_data_dict, moving in self._scenes(self.synthetic):
+            if n_done == self.cfg.eval.num_files_to_evaluate // self.cfg.eval.partitions:
+                break
             self.policy.scenario_index = scn.index
-            gt_data_dict = self._ground_truth(scn)
             sim = Simulation(scn, device=self.policy.model.device, steps=self.steps, dt=self.dt)
             vehicles = sim.getScenario().vehicles()
             for veh in vehicles:
                 veh.expert_control = False
                 veh.physics_simulated = True
-            moving = [veh.getID() for veh in vehicles]
             thr = self.cfg.eval.multi_agent_eval_threshold
             self.vehicles_to_evaluate = random.sample(moving, thr) if len(moving) > thr else moving
+            if not self.vehicles_to_evaluate:
+                continue
+            n_done += 1
             preproc_data = {"road_points": scn.road_points.astype(np.float64), "road_types": scn.road_types.copy()}
             vdd, goal_dict, goal_norm = {}, {}, {}
             for veh in vehicles:
                 v = veh.getID()
-                goal_dict[v] = {"pos": scn.goal_pos[v].astype(np.float64), "heading": float(scn.goal_heading[v]),
-                                "speed": float(scn.goal_speed[v])}
+                goal_dict[v] = self.initialize_goal_dict(scn, v, np.array(gt_data_dict[v]["traj"]))
                 vdd[v] = self.initialize_vehicle_data_dict(veh, goal_dict[v])
                 goal_norm[v] = np.linalg.norm(np.array([veh.getPosition().x, veh.getPosition().y]) - goal_dict[v]["pos"])
             self.policy.reset(vdd)

@@ -668,9 +668,33 @@ def gen_planner_adversary():
     save("planner_adversary", **out)
 
 
+# --------------------------------------------------------------------------------------------- ingest (road chunking)
+def ingest_road_data(seed=12):
+    """A road list in the get_road_data layout that exercises every branch of RLWaymoDataset.get_roads."""
+    rs = np.random.RandomState(seed)
+
+    def line(n, kind):
+        xy = np.cumsum(rs.normal(0, 1, (n, 2)), 0) + rs.uniform(-50, 50, 2)
+        return {"geometry": [{"x": float(np.float32(a)), "y": float(np.float32(b))} for a, b in xy], "type": kind}
+    return [line(250, "lane"), line(100, "road_edge"), line(3, "crosswalk"),
+            {"geometry": {"x": 4.5, "y": -7.25}, "type": "stop_sign"}, line(1, "speed_bump"), line(101, "road_line"),
+            line(37, "road_edge"), line(200, "lane")]
+
+
+def gen_ingest():
+    import json
+    cfg = spec.make_cfg()
+    dset = ref_shims.build_reference_dataset(cfg)
+    road_data = ingest_road_data()
+    pts, types, edges = dset.get_roads({"roads": road_data})
+    print("chunks", pts.shape, "edge polylines", [e.shape for e in edges])
+    save("ingest", road_json=np.frombuffer(json.dumps(road_data).encode(), np.uint8), road_points=pts, road_types=types,
+         n_edges=np.array(len(edges)), **{f"edge{i}": e for i, e in enumerate(edges)})
+
+
 ALL = dict(model=gen_model, features=gen_features, sampling=gen_sampling, physics=gen_physics,
            collision=gen_collision, closed_loop=gen_closed_loop, bicycle=gen_bicycle, contacts=gen_contacts,
-           planner_adversary=gen_planner_adversary)
+           planner_adversary=gen_planner_adversary, ingest=gen_ingest)
 
 if __name__ == "__main__":
     assert ref_shims.available(), "the reference tree is required to (re)generate golden vectors"

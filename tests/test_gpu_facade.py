@@ -126,3 +126,43 @@ def test_planner_vs_adversary_matches_reference_fixture(tag):
     for role, r in (("planner", 0), ("adversary", 1)):
         rt = np.array([[vdd[v][f"{role}_rtgs"][t] for t in range(steps)] for v in range(n)])
         np.testing.assert_allclose(rt, g[f"{tag}_rtg_cont"][r], atol=1e-9, rtol=0)
+
+
+def test_policy_evaluator_on_nocturne_json_files(tmp_path):
+    """cfg.eval.scenario_files: scenes come from Nocturne-format JSON (ctrlsim_amd.ingest) instead of the synthetic generator —
+    a pedestrian that is skipped, a stop sign, a vehicle that leaves the log mid-way (it is teleported away and its goal becomes
+    the last logged state), a parked vehicle that is not evaluated; history steps are log-replayed."""
+    import json
+    from ctrlsim_amd import ingest
+    cfg = cfg_of("loop")
+    cfg.nocturne.history_steps = 3
+    d = spec.Dims(cfg)
+    scn = scenarios.make_scenario(13, 0, n_agents=7, n_polylines=9, n_points=d.NP, extent=40.0)
+    log = scenarios.standin_log(scn, cfg.nocturne.steps)
+    log[2]["traj"][9:, 4] = 0
+    js = ingest.scenario_to_nocturne_json(scn, log)
+    js["objects"].insert(1, dict(js["objects"][0], type="pedestrian"))
+    js["roads"].append({"geometry": [{"x": 3.0, "y": 4.0}], "type": "stop_sign"})
+    parked = js["objects"][-1]
+    parked["position"] = [dict(parked["position"][0]) for _ in parked["position"]]
+    parked["velocity"] = [{"x": 0.0, "y": 0.0} for _ in parked["velocity"]]
+    parked["goalPosition"] = dict(parked["position"][0])
+    path = tmp_path / "tfrecord-00000-of-00150_1.json"
+    path.write_text(json.dumps(js))
+    cfg.eval["scenario_files"] = [str(path)]
+    model, policy = _make(cfg)
+    ev = PolicyEvaluator(cfg, policy)
+    m, lines = ev.evaluate_policy()
+    assert all(np.isfinite(v) for v in m.values()) and len(lines) == 9
+    vdd = ev.last_vehicle_data_dict
+    assert len(vdd) == 7 and sorted(ev.vehicles_to_evaluate) == [0, 1, 2, 3, 4, 5]     # the parked one (index 6) is replayed
+    ex = np.array(vdd[2]["existence"])
+    assert ex[:9].all() and not ex[9:].any() and vdd[2]["position"][-1]["x"] < -1e5   # left the log: teleported away
+    np.testing.assert_allclose([vdd[2]["goal_position"]["x"], vdd[2]["goal_position"]["y"]],
+                               np.float32(log[2]["traj"][8, :2]), rtol=1e-6)
+    # history steps replay the log through the inverse bicycle model: after two replayed steps every car is near its log
+    for v in range(6):
+        p, g = vdd[v]["position"][2], log[v]["traj"][2]
+        assert np.hypot(p["x"] - g[0], p["y"] - g[1]) < 0.5
+    p = vdd[6]["position"][-1]
+    assert np.hypot(p["x"] - scn.x[6], p["y"] - scn.y[6]) < 0.5                      # the parked car stays put
