@@ -59,13 +59,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # debugging aid only: several ranks on ONE GPU with gloo collectives, to exercise the multi-rank flow on a 1-GPU box
+    shared_gpu = os.environ.get("CTRLSIM_BENCH_DEBUG_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank %= torch.cuda.device_count()
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     device = f"cuda:{local_rank}"
+    coll_device = "cpu" if shared_gpu else device
     torch.cuda.set_device(device)
 
     import ctrlsim_amd  # noqa: F401
@@ -111,7 +119,7 @@ def main():
     _lib.check(lib.ctrlsim_prof_collect(ms, cnt, fl), "prof_collect")
     _lib.check(lib.ctrlsim_prof_bytes(by), "prof_bytes")
     lib.ctrlsim_prof_enable(0)
-    t_el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
     if dist is not None:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
     elapsed = float(t_el.item())
@@ -130,7 +138,7 @@ def main():
         accel = np.concatenate([(tok // d.NS) / (d.NA - 1) * 20.0 - 10.0, np.zeros((N, 1))], 1)
         acc.add_scenario(st, res["coll"][i], accel, gt, scn.goal_pos.astype(np.float64),
                          scn.goal_heading.astype(np.float64), scn.goal_speed.astype(np.float64), cfg)
-    vec = torch.from_numpy(acc.pack()).to(device)
+    vec = torch.from_numpy(acc.pack()).to(coll_device)
     if dist is not None:
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
     acc.unpack(vec.cpu().numpy())
