@@ -135,16 +135,17 @@ class _NoisePatch:
         return torch.argmax(ratio).reshape(1)
 
 
-def ref_closed_loop(cfg, w, scn, steps, seed, tilt=(0, 0, 0), nucleus=False, temperature=1.0):
-    """evaluate_policy's inner loop (policy_evaluator.py:514-557) around the UNMODIFIED reference policy."""
+def ref_closed_loop(cfg, w, scn, steps, seed, tilt=(0, 0, 0), nucleus=False, temperature=1.0, rtgs=True):
+    """evaluate_policy's inner loop (policy_evaluator.py:514-557) around the UNMODIFIED reference policy.
+    rtgs=False: the IL / Trajeglish policies (cfgs/policy/{il,trajeglish}.yaml: use_rtg = predict_rtgs = False)."""
     ref_shims.install()
     from policies.autoregressive_policy import AutoregressivePolicy
 
-    model = ref_shims.build_reference_model(cfg, w)
+    model = ref_shims.build_reference_model(cfg, variant_weights(cfg, w))
     dset = ref_shims.build_reference_dataset(cfg)
     key_dict = {"next_acceleration": "next_acceleration", "next_steering": "next_steering", "rtgs": "rtgs"}
     tilt_dict = {"tilt": True, "goal_tilt": tilt[0], "veh_veh_tilt": tilt[1], "veh_edge_tilt": tilt[2]}
-    pol = AutoregressivePolicy(cfg=cfg, model_path="", model=model, use_rtg=True, predict_rtgs=True,
+    pol = AutoregressivePolicy(cfg=cfg, model_path="", model=model, use_rtg=rtgs, predict_rtgs=rtgs,
                                discretize_rtgs=True, real_time_rewards=False, privileged_return=False,
                                max_return=False, min_return=False, key_dict=key_dict, tilt_dict=tilt_dict,
                                name="ctrl_sim", action_temperature=temperature, nucleus_sampling=nucleus,
@@ -207,7 +208,8 @@ def ref_closed_loop(cfg, w, scn, steps, seed, tilt=(0, 0, 0), nucleus=False, tem
                 vdd[i]["acceleration"].append(act[0])
                 vdd[i]["steering"].append(act[1])
                 applied[i, t] = act
-                rtg_cont[i, t] = vdd[i]["rtgs"][-1]
+                if rtgs:
+                    rtg_cont[i, t] = vdd[i]["rtgs"][-1]
             tokens[:, t] = dset.discretize_actions(applied[:, t:t + 1].copy())[:, 0]
             sim.step(0.1)
         update(steps)
@@ -692,9 +694,63 @@ def gen_ingest():
          n_edges=np.array(len(edges)), **{f"edge{i}": e for i, e in enumerate(edges)})
 
 
+# --------------------------------------------------------------------------------------------- IL / Trajeglish variants
+def variant_weights(cfg, w):
+    """The reference IL / Trajeglish modules have no predict_rtg / predict_future_states heads (cfgs/model/{il,trajeglish}.yaml)."""
+    if not (cfg.model.get("il", False) or cfg.model.get("trajeglish", False)):
+        return w
+    return {k: v for k, v in w.items() if not k.startswith(("decoder.predict_rtg", "decoder.predict_future_states"))}
+
+
+def variant_cfg(name, **over):
+    return spec.make_cfg(**{f"model__{name}": True, "model__predict_rtg": False, "model__predict_future_states": False}, **over)
+
+
+def gen_variants():
+    """cfgs/model/il.yaml and trajeglish.yaml through the UNMODIFIED reference modules / policy: masks, logits, closed loop."""
+    ref_shims.install()
+    from utils.train_utils import get_causal_mask
+    out = {}
+    for name, K in (("il", 2), ("trajeglish", 1)):
+        # masks (small, full array) and the closed form at the real size
+        cfg_t = variant_cfg(name, **TINY)
+        out[f"{name}_mask_tiny"] = (get_causal_mask(cfg_t, 4, K) == 0).numpy()
+        # logits: tiny config in full, loop config at the last filled step
+        for tag, over in (("tiny", TINY), ("loop", LOOP)):
+            cfg = variant_cfg(name, **over)
+            d = spec.Dims(cfg)
+            w = weights.generate(d, 0)
+            ref = ref_shims.build_reference_model(cfg, variant_weights(cfg, w))
+            cm = model_oracle.causal_mask_closed_form(d.A, d.T, K)
+            assert bool(((ref.decoder.causal_mask == 0) == cm).all()), "closed-form mask != get_causal_mask"
+            for seed, t_fill in ((1, d.T), (2, max(1, d.T // 2))):
+                inp = synth_inputs.random_context(d, seed, B=1, t_fill=t_fill, n_agents=d.A - 1, n_polys=d.P - 1)
+                r = ref(synth_inputs.to_motion_data(inp), eval=True)
+                assert set(r.keys()) == {"action_preds"}
+                ap = r["action_preds"].detach().numpy()
+                out[f"{name}_{tag}_s{seed}_action"] = ap if tag == "tiny" else ap[0, :, t_fill - 1]
+                out[f"{name}_{tag}_s{seed}_recipe"] = np.array([seed, t_fill, d.A - 1, d.P - 1])
+        # closed loop, 14 steps (window T = 8 slides from step 8 on)
+        cfg = variant_cfg(name, **LOOP)
+        d = spec.Dims(cfg)
+        w = weights.generate(d, 0)
+        for idx in range(60):
+            scn = scenarios.make_scenario(17, idx, n_agents=9, n_polylines=15, n_points=d.NP, extent=40.0)
+            r = ref_closed_loop(cfg, w, scn, 14, seed=6, rtgs=False)
+            if r["margins"].min() > 2e-4:
+                break
+        print(name, "scene", idx, "groups/step", r["n_groups"], "min race margin", r["margins"].min(), "veh-veh flags",
+              r["coll"][..., 0].sum())
+        for k in ("tokens", "states", "coll", "actions", "n_groups", "margins"):
+            out[f"{name}_loop_{k}"] = r[k]
+        out[f"{name}_loop_recipe"] = np.array([17, idx, 9, 15, 40.0, 6])
+    save("variants", **out)
+
+
 ALL = dict(model=gen_model, features=gen_features, sampling=gen_sampling, physics=gen_physics,
            collision=gen_collision, closed_loop=gen_closed_loop, bicycle=gen_bicycle, contacts=gen_contacts,
-           planner_adversary=gen_planner_adversary, ingest=gen_ingest)
+           planner_adversary=gen_planner_adversary, ingest=gen_ingest,
+           variants=gen_variants)
 
 if __name__ == "__main__":
     assert ref_shims.available(), "the reference tree is required to (re)generate golden vectors"

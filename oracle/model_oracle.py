@@ -35,7 +35,8 @@ def as_torch_weights(w):
 
 
 def causal_mask_closed_form(A: int, T: int, K: int = 3) -> torch.Tensor:
-    """Boolean [L,L], True = visible.  CtRL-Sim variant (state_index 0, no attend_own_return_action)."""
+    """Boolean [L,L], True = visible (state_index 0, no attend_own_return_action); K = token types per agent-step:
+    3 CtRL-Sim, 2 IL, 1 Trajeglish (utils/train_utils.py:83-113 with num_types = K)."""
     L = A * T * K
     i = torch.arange(L)
     t = i // (A * K)
@@ -134,7 +135,13 @@ def embed_tokens(w, data, dims):
     s_emb, a_emb, r_emb = s_emb * ex, a_emb * ex, r_emb * ex
     init_emb = s_emb[:, 0]                                            # [B,A,D]
     init_exist = exist[:, 0, :, 0].bool()
-    stacked = torch.stack([s_emb, r_emb, a_emb], dim=3).reshape(B, T * A * 3, -1)
+    variant = getattr(dims, "VARIANT", 0)
+    if variant == 1:                                                  # il: (state, action)           encoder.py:143-146
+        stacked = torch.stack([s_emb, a_emb], dim=3).reshape(B, T * A * 2, -1)
+    elif variant == 2:                                                # trajeglish: action tokens only  encoder.py:141-142
+        stacked = a_emb.reshape(B, T * A, -1)
+    else:
+        stacked = torch.stack([s_emb, r_emb, a_emb], dim=3).reshape(B, T * A * 3, -1)
     stacked = _ln(stacked, w, "encoder.embed_ln")
     return stacked, init_emb, init_exist
 
@@ -168,13 +175,19 @@ def forward(w, data, dims, return_hidden=False):
     for i in range(dims.NE):
         mem = _enc_layer(mem, w, f"encoder.transformer_encoder.layers.{i}", H, pad)
     B, A, T = data["agent_states"].shape[:3]
-    key = (A, T)
+    variant = getattr(dims, "VARIANT", 0)
+    K = {0: 3, 1: 2, 2: 1}[variant]                                   # decoder.py:29-35
+    key = (A, T, K)
     if key not in _MASK_CACHE:
-        _MASK_CACHE[key] = causal_mask_closed_form(A, T, 3)
+        _MASK_CACHE[key] = causal_mask_closed_form(A, T, K)
     tgt_mask = _MASK_CACHE[key]
     x = stacked
     for i in range(dims.ND):
         x = _dec_layer(x, mem, w, f"decoder.transformer_decoder.layers.{i}", H, tgt_mask, pad)
+    if variant:                                                       # decoder.py:58-64: actions from token type 0, no other head
+        out = x.view(B, T * A, K, -1)
+        act = _mlp(out[:, :, 0], w, "decoder.predict_action").view(B, T, A, -1).permute(0, 2, 1, 3)
+        return {"action_preds": act}
     out = x.view(B, T * A, 3, -1)
     act = _mlp(out[:, :, 1], w, "decoder.predict_action").view(B, T, A, -1).permute(0, 2, 1, 3)
     rtg = _mlp(out[:, :, 0], w, "decoder.predict_rtg").view(B, T, A, -1).permute(0, 2, 1, 3)

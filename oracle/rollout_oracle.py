@@ -96,14 +96,15 @@ class RolloutOracle:
             data = g["data"]
             noise_for = lambda agent: (lambda head, n: explicit_noise(t, agent, head, n) if explicit_noise
                                        else self._noise(self.seed, scn.index, t, agent, head, n))
-            preds = self.forward(data)                                # pass 1
-            rtg_logits = preds["rtg_preds"][0]
-            for v in fo_persisted(buf, g):                            # context vehicles, ascending global index
-                s = g["slot"][v]
-                if v not in processed:
-                    tl = tilt_on if v in g["members"] else tilt_off
-                    processed[v] = sample_rtg(rtg_logits[s, ti], tl, dims.R, dims.C, noise_for(v))
-                data["rtgs"][0, s, ti] = processed[v]
+            if not getattr(dims, "VARIANT", 0):                       # IL / Trajeglish: predict_rtgs False, one forward
+                preds = self.forward(data)                            # pass 1
+                rtg_logits = preds["rtg_preds"][0]
+                for v in fo_persisted(buf, g):                        # context vehicles, ascending global index
+                    s = g["slot"][v]
+                    if v not in processed:
+                        tl = tilt_on if v in g["members"] else tilt_off
+                        processed[v] = sample_rtg(rtg_logits[s, ti], tl, dims.R, dims.C, noise_for(v))
+                    data["rtgs"][0, s, ti] = processed[v]
             preds = self.forward(data)                                # pass 2
             act_logits = preds["action_preds"][0]
             for v in g["members"]:
