@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "libctrlsim_hip.so")
 
 
 class Dims(C.Structure):
-    _fields_ = [(k, C.c_int) for k in ("A", "T", "P", "NP", "D", "H", "F", "V", "R", "C", "NE", "ND", "MAXT")]
+    _fields_ = [(k, C.c_int) for k in ("A", "T", "P", "NP", "D", "H", "F", "V", "R", "C", "NE", "ND", "MAXT", "variant")]
 
 
 class Ctx(C.Structure):
@@ -51,6 +51,7 @@ SIGNATURES = {
     "ctrlsim_model_destroy": (None, [P]),
     "ctrlsim_forward_workspace_bytes": (L, [C.POINTER(Dims), I, I]),
     "ctrlsim_dt_forward_pass1": (I, [P, I, I, C.POINTER(Ctx), P, P, P, P]),
+    "ctrlsim_dt_forward_actions": (I, [P, I, I, C.POINTER(Ctx), P, P, P]),
     "ctrlsim_dt_forward_pass2": (I, [P, I, I, I, I, I, C.POINTER(Ctx), P, P, P, P, I, P]),
     "ctrlsim_dt_forward_pass1_cached": (I, [P, I, I, C.POINTER(Ctx), P, P, P]),
     "ctrlsim_sample_rtg": (I, [P, I, I, P, P, P, P, P, P, U64, P, I, P, I, I, I, P]),

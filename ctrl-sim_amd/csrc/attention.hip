@@ -246,6 +246,7 @@ int launch_attention(int mode, const float* Q, int ldq, long q_batch_stride, con
   if (ctrlsim_option(OPT_ATTN_IMPL) == 1)
     return launch_attention_bf16x6(mode, Q, ldq, q_batch_stride, K, V, ldkv, kv_batch_stride, O, ldo, o_batch_stride, q_pos,
                                    key_pad, B, Lq, Lk, A, st);
+  if (mode < 0 || mode > MODE_CAUSAL) return CTRLSIM_EINVAL;       // the IL / Trajeglish masks (modes 2, 3) exist in the bf16x6 kernel only
   dim3 g((Lq + 127) / 128, NHEAD, B), blk(256);
   const float scale = 0.17677669529663687f * 1.4426950408889634f;  // log2(e)/sqrt(32)
   // algorithmic FLOPs: (QK^T + PV) = 4*32 per visible (query, key) pair and head

@@ -95,7 +95,8 @@ template <int MODE, bool PRE>
 __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
     const float* __restrict__ Q, int ldq, long q_batch_stride, const float* __restrict__ K,
     const float* __restrict__ V, int ldkv, long kv_batch_stride, float* __restrict__ O, int ldo, long o_batch_stride,
-    const int* __restrict__ q_pos, const unsigned char* __restrict__ key_pad, int Lq, int Lk, int A, float scale_log2e) {
+    const int* __restrict__ q_pos, const unsigned char* __restrict__ key_pad, int Lq, int Lk, int A, float scale_log2e,
+    int variant) {
   constexpr int K_PLANE = KT6 * HD;              // bf16 elements: [ks 2][half 2][64 keys][8]
   constexpr int V_PLANE = HD * KT6;              // [16 quads][32 d][4 keys]
   constexpr int BUF = 3 * K_PLANE + 3 * V_PLANE + 2 * KT6;   // + KT6 floats of key-padding bias
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
       bool need_mask = true;
       if (MODE == MODE6_CAUSAL) {
         if (t_lo > tq_max_w) continue;
-        need_mask = !(t_hi < tq_min_w && ks0 + 31 < Lk);
+        need_mask = !(t_hi < tq_min_w && ks0 + 31 < Lk) || variant != 0;   // IL / Trajeglish: dead key types everywhere
       }
       // ---- S^T = K . Q^T : one accumulator chain, k-steps d 0-15 and d 16-31, six partial products each
       // the accumulator starts at -m_base (the running maximum, 0 before the first visible key): the MFMA chain then
@@ -321,7 +322,17 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
         off3 = off3 < 0 ? off3 + 3 : off3;
         const unsigned every3 = (unsigned)(0x249249249249ull << off3);
         const unsigned own = ones(pos - ks0 + 1) & ~ones(pos - kq - ks0);
-        const unsigned vis = (before | ((every3 | own) & same)) >> (4 * half);
+        unsigned vis_all = before | ((every3 | own) & same);
+        if (variant) {
+          // the 3-slot token layout is kept for the baselines of cfgs/model/{il,trajeglish}.yaml; the token types they do not
+          // have are dead as keys.  IL (state, action): rtg keys invisible.  Trajeglish (action only): action keys of earlier
+          // steps and of the WHOLE current step (get_causal_mask with one token type: every same-step token is "the state").
+          int o2 = off3 + 2;
+          o2 = o2 >= 3 ? o2 - 3 : o2;
+          const unsigned actions = (unsigned)(0x249249249249ull << o2);
+          vis_all = (variant == 1) ? (vis_all & (every3 | actions)) : ((before | same) & actions);
+        }
+        const unsigned vis = vis_all >> (4 * half);
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = (vis & (1u << ((r & 3) + 8 * (r >> 2)))) ? s0[r] : NEG_INF;
       } else {
@@ -578,16 +589,18 @@ int launch_attention_bf16x6(int mode, const float* Q, int ldq, long q_batch_stri
                             const unsigned char* key_pad, int B, int Lq, int Lk, int A, hipStream_t st) {
   if (B <= 0 || Lq <= 0) return CTRLSIM_OK;
   if (Lk <= 0 || (ldq & 3) || (ldkv & 3)) return CTRLSIM_EINVAL;
-  if (mode != MODE6_CAUSAL && !key_pad) return CTRLSIM_EINVAL;
+  if (mode < 0 || mode > 3 || (mode == MODE6_KEYPAD && !key_pad)) return CTRLSIM_EINVAL;
+  const int variant = mode >= MODE6_CAUSAL ? mode - MODE6_CAUSAL : 0;   // mode 1 CtRL-Sim mask, 2 IL, 3 Trajeglish
+  mode = mode >= MODE6_CAUSAL ? MODE6_CAUSAL : MODE6_KEYPAD;
   dim3 g((Lq + 127) / 128, NHEAD, B), blk(256);
   const float scale = 0.17677669529663687f * 1.4426950408889634f;  // log2(e)/sqrt(32)
   prof_before(PROF_ATTN, st);
   if (mode == MODE6_CAUSAL) {
     hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, false>), g, blk, 0, st, Q, ldq, q_batch_stride, K, V, ldkv,
-                       kv_batch_stride, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale);
+                       kv_batch_stride, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale, variant);
   } else {
     hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, false>), g, blk, 0, st, Q, ldq, q_batch_stride, K, V, ldkv,
-                       kv_batch_stride, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale);
+                       kv_batch_stride, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale, 0);
   }
   prof_after(PROF_ATTN, attn_pairs(mode, q_pos, Lq, Lk, A) * 128.0 * NHEAD * B, st,
              (double)B * (8.0 * DM * Lq + 8.0 * DM * Lk));
@@ -600,17 +613,19 @@ int launch_attention_bf16x6_pre(int mode, const float* Q, int ldq, long q_batch_
                                 int Lk, int A, hipStream_t st) {
   if (B <= 0 || Lq <= 0) return CTRLSIM_OK;
   if (Lk <= 0 || (ldq & 3) || !img || nkt * KT6 < Lk) return CTRLSIM_EINVAL;
-  if (mode != MODE6_CAUSAL && !key_pad) return CTRLSIM_EINVAL;
+  if (mode < 0 || mode > 3 || (mode == MODE6_KEYPAD && !key_pad)) return CTRLSIM_EINVAL;
+  const int variant = mode >= MODE6_CAUSAL ? mode - MODE6_CAUSAL : 0;
+  mode = mode >= MODE6_CAUSAL ? MODE6_CAUSAL : MODE6_KEYPAD;
   dim3 g((Lq + 127) / 128, NHEAD, B), blk(256);
   const float scale = 0.17677669529663687f * 1.4426950408889634f;
   const float* imgf = static_cast<const float*>(img);
   prof_before(PROF_ATTN, st);
   if (mode == MODE6_CAUSAL) {
     hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, true>), g, blk, 0, st, Q, ldq, q_batch_stride, imgf, nullptr, 0,
-                       (long)nkt, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale);
+                       (long)nkt, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale, variant);
   } else {
     hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, true>), g, blk, 0, st, Q, ldq, q_batch_stride, imgf, nullptr, 0,
-                       (long)nkt, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale);
+                       (long)nkt, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale, 0);
   }
   prof_after(PROF_ATTN, attn_pairs(mode, q_pos, Lq, Lk, A) * 128.0 * NHEAD * B, st,
              (double)B * (8.0 * DM * Lq + 12.0 * DM * Lk));

@@ -89,7 +89,8 @@ struct ctrlsim_model {
 extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_weights, int n, const char* const* names,
                                     const int64_t* offsets, ctrlsim_model** out) {
   if (!dims || !dev_weights || !names || !offsets || !out) return CTRLSIM_EINVAL;
-  if (dims->D != DM || dims->H != NHEAD || dims->A < 1 || dims->A > 64) return CTRLSIM_EINVAL;
+  if (dims->D != DM || dims->H != NHEAD || dims->A < 1 || dims->A > 64 || dims->variant < 0 || dims->variant > 2)
+    return CTRLSIM_EINVAL;
   std::unordered_map<std::string, const float*> tab;
   for (int i = 0; i < n; ++i) tab[names[i]] = dev_weights + offsets[i];
   bool ok = true;
@@ -162,7 +163,7 @@ extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_w
     m->dec.push_back(L);
   }
   m->head_action = mlp("decoder.predict_action");
-  m->head_rtg = mlp("decoder.predict_rtg");
+  if (dims->variant == 0) m->head_rtg = mlp("decoder.predict_rtg");      // the IL / Trajeglish models have no such head
   m->zero_rtg[0] = 0; m->zero_rtg[1] = 35; m->zero_rtg[2] = 35;
   if (!ok) { delete m; return CTRLSIM_EINVAL; }
   *out = m;
@@ -233,14 +234,15 @@ Ws carve(const ctrlsim_dims& d, int B, int Tq, char* base) {
   return w;
 }
 
-__global__ void fill_index_kernel(int B, int A, int L, int ti, int P, int M, int* pos_state, int* pos_rtg, int* idx_state,
-                                  int* idx_rtg, int* idx_poly) {
+// qoff: token type whose rows feed the first pass's head (0 = state tokens; 2 = action tokens, Trajeglish)
+__global__ void fill_index_kernel(int B, int A, int L, int ti, int P, int M, int qoff, int* pos_state, int* pos_rtg,
+                                  int* idx_state, int* idx_rtg, int* idx_poly) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B * P) idx_poly[i] = (i / P) * M + (i % P);
-  if (i < A) { pos_state[i] = (ti * A + i) * 3; pos_rtg[i] = (ti * A + i) * 3 + 1; }
+  if (i < A) { pos_state[i] = (ti * A + i) * 3 + qoff; pos_rtg[i] = (ti * A + i) * 3 + 1; }
   if (i < B * A) {
     const int b = i / A, a = i - b * A;
-    idx_state[i] = b * L + (ti * A + a) * 3;
+    idx_state[i] = b * L + (ti * A + a) * 3 + qoff;
     idx_rtg[i] = b * L + (ti * A + a) * 3 + 1;
   }
 }
@@ -384,14 +386,19 @@ extern "C" int64_t ctrlsim_forward_workspace_bytes(const ctrlsim_dims* d, int B,
 }
 
 // ------------------------------------------------------------------------------------------------ pass 1
-extern "C" int ctrlsim_dt_forward_pass1(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* c, void* workspace,
-                                        float* rtg_logits, float* dbg_seg_emb, hipStream_t st) {
-  if (!m || !c || !workspace || !rtg_logits || B < 1 || Tq < 1 || Tq > m->d.T) return CTRLSIM_EINVAL;
+namespace {
+// The full forward over the first Tq window steps; logits of the head that the first pass of the variant needs:
+// CtRL-Sim: predict_rtg on the A state tokens of the current step; IL: predict_action on the same rows; Trajeglish:
+// predict_action on the A action tokens (decoder.py:55-77).
+int forward_full(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* c, void* workspace, float* logits,
+                 float* dbg_seg_emb, hipStream_t st) {
   const ctrlsim_dims& d = m->d;
+  const int variant = d.variant, amode = 1 + variant, qoff = variant == 2 ? 2 : 0;
+  if (variant && !presplit()) return CTRLSIM_EINVAL;       // the IL / Trajeglish masks live in the split-bf16 attention only
   const Ws w = carve(d, B, Tq, static_cast<char*>(workspace));
   const int A = d.A, P = d.P, M = P + A, L = Tq * A * 3, ti = Tq - 1;
   const int rL = B * L, rM = B * M, rA = B * A, rS = B * Tq * A, rP = B * P;
-  hipLaunchKernelGGL(fill_index_kernel, dim3(((rA > rP ? rA : rP) + 255) / 256), dim3(256), 0, st, B, A, L, ti, P, M,
+  hipLaunchKernelGGL(fill_index_kernel, dim3(((rA > rP ? rA : rP) + 255) / 256), dim3(256), 0, st, B, A, L, ti, P, M, qoff,
                      w.pos_state, w.pos_rtg, w.idx_state, w.idx_rtg, w.idx_poly);
   // ---- token embeddings (encoder.py:95-153)
   CHK(launch_in_mlp(c->st12, 12, 12, m->embed_state.l0.w, m->embed_state.l0.b, m->embed_state.ln.g, m->embed_state.ln.b,
@@ -408,30 +415,42 @@ extern "C" int ctrlsim_dt_forward_pass1(const ctrlsim_model* m, int B, int Tq, c
     const DecLayer& Ld = m->dec[i];
     CHK(gemm_kv(Ld.qkv, w.X, DM, w.qkv[i], 3 * DM, B, L, 3 * DM, DM, DM, w.img_dec[i], w.nkt_dec, st));
     if (i < d.ND - 1) {
-      CHK(attention_kv(1, w.qkv[i], 3 * DM, (long)L * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
+      CHK(attention_kv(amode, w.qkv[i], 3 * DM, (long)L * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
                        w.img_dec[i], w.nkt_dec, w.att, DM, (long)L * DM, nullptr, nullptr, B, L, L, A, st));
       CHK(gemm_ln(Ld.out, Ld.n1, w.att, DM, w.X, DM, w.X, DM, w.tmp, rL, DM, 0, st));
       CHK(cross_and_ffn(m, Ld, i, w, w.X, w.tmp, w.att, w.qc, w.ffn, rL, B, L, st));
     } else {
-      // last layer: only the A state tokens of the current timestep are queried
+      // last layer: only the A queried tokens of the current timestep (state tokens; Trajeglish: action tokens)
       CHK(launch_row_copy(w.X, DM, w.xc, DM, w.idx_state, rA, DM, 0, st));
       CHK(launch_row_copy(w.qkv[i], 3 * DM, w.qkvc, 3 * DM, w.idx_state, rA, 3 * DM, 0, st));
-      CHK(attention_kv(1, w.qkvc, 3 * DM, (long)A * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
+      CHK(attention_kv(amode, w.qkvc, 3 * DM, (long)A * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
                        w.img_dec[i], w.nkt_dec, w.attc, DM, (long)A * DM, w.pos_state, nullptr, B, A, L, A, st));
       CHK(gemm_ln(Ld.out, Ld.n1, w.attc, DM, w.xc, DM, w.xc, DM, w.tmpc, rA, DM, 0, st));
       CHK(cross_and_ffn(m, Ld, i, w, w.xc, w.tmpc, w.attc, w.qcc, w.ffnc, rA, B, A, st));
     }
   }
-  // ---- predict_rtg head on the A state tokens (decoder.py:74-77)
-  CHK(mlp_tail(m->head_rtg, w.xc, rA, w.headh, rtg_logits, d.R * d.C, st));
-  return CTRLSIM_OK;
+  // ---- predict_rtg head on the A state tokens (decoder.py:74-77) / predict_action for the baselines (decoder.py:58-64)
+  if (variant) return mlp_tail(m->head_action, w.xc, rA, w.headh, logits, d.V, st);
+  return mlp_tail(m->head_rtg, w.xc, rA, w.headh, logits, d.R * d.C, st);
+}
+}  // namespace
+
+extern "C" int ctrlsim_dt_forward_pass1(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* c, void* workspace,
+                                        float* rtg_logits, float* dbg_seg_emb, hipStream_t st) {
+  if (!m || !c || !workspace || !rtg_logits || B < 1 || Tq < 1 || Tq > m->d.T || m->d.variant != 0) return CTRLSIM_EINVAL;
+  return forward_full(m, B, Tq, c, workspace, rtg_logits, dbg_seg_emb, st);
+}
+extern "C" int ctrlsim_dt_forward_actions(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* c, void* workspace,
+                                          float* act_logits, hipStream_t st) {
+  if (!m || !c || !workspace || !act_logits || B < 1 || Tq < 1 || Tq > m->d.T || m->d.variant == 0) return CTRLSIM_EINVAL;
+  return forward_full(m, B, Tq, c, workspace, act_logits, nullptr, st);
 }
 
 // ------------------------------------------------------------------------------------------------ pass 2
 extern "C" int ctrlsim_dt_forward_pass2(const ctrlsim_model* m, int B, int Tq, int t, int N, int Tmax,
                                         const ctrlsim_ctx* c, const int* ctx_scn, const int* hist_rtg, void* workspace,
                                         float* act_logits, int cached, hipStream_t st) {
-  if (!m || !c || !workspace || !act_logits || B < 1 || Tq < 1 || Tq > m->d.T) return CTRLSIM_EINVAL;
+  if (!m || !c || !workspace || !act_logits || B < 1 || Tq < 1 || Tq > m->d.T || m->d.variant != 0) return CTRLSIM_EINVAL;
   const ctrlsim_dims& d = m->d;
   // cached mode: the workspace is carved for the full window (K/V cache rows at b * T*3A + position) and the context
   // tensors hold only the last Tn = min(Tq, 2) window rows
@@ -463,7 +482,7 @@ extern "C" int ctrlsim_dt_forward_pass2(const ctrlsim_model* m, int B, int Tq, i
 // ctx holds the window rows [max(t-1,0), t]; the workspace must be the one used at t-1 (sized with Tq = T).
 extern "C" int ctrlsim_dt_forward_pass1_cached(const ctrlsim_model* m, int B, int t, const ctrlsim_ctx* c, void* workspace,
                                                float* rtg_logits, hipStream_t st) {
-  if (!m || !c || !workspace || !rtg_logits || B < 1 || t < 0 || t >= m->d.T) return CTRLSIM_EINVAL;
+  if (!m || !c || !workspace || !rtg_logits || B < 1 || t < 0 || t >= m->d.T || m->d.variant != 0) return CTRLSIM_EINVAL;
   const ctrlsim_dims& d = m->d;
   const Ws w = carve(d, B, d.T, static_cast<char*>(workspace));
   const int A = d.A, P = d.P, M = P + A, Lf = d.T * A * 3;
@@ -478,7 +497,7 @@ extern "C" int ctrlsim_dt_forward_pass1_cached(const ctrlsim_model* m, int B, in
     CHK(launch_in_mlp(c->goal5, 5, 5, m->embed_goal.l0.w, m->embed_goal.l0.b, m->embed_goal.ln.g, m->embed_goal.ln.b, w.hG,
                       DM, rA, st));
     CHK(gemm(m->fold_goal, w.hG, DM, nullptr, 0, w.Gp, DM, rA, DM, DM, 0, st));
-    hipLaunchKernelGGL(fill_index_kernel, dim3(((rA > B * P ? rA : B * P) + 255) / 256), dim3(256), 0, st, B, A, 3 * A, 0, P, M,
+    hipLaunchKernelGGL(fill_index_kernel, dim3(((rA > B * P ? rA : B * P) + 255) / 256), dim3(256), 0, st, B, A, 3 * A, 0, P, M, 0,
                        w.pos_state, w.pos_rtg, w.idx_state, w.idx_rtg, w.idx_poly);
     // token order of assemble_tokens at Tq = 1 is (a, k) = pos_new order; it also writes the initial-state rows of `src`
     CHK(launch_assemble_tokens(B, 1, A, w.S2, w.Gp, c->exist, c->act_tok, c->rtg_bin, c->tstep, m->tb, w.xn, w.src, M, P,

@@ -29,7 +29,7 @@ from .spec import Dims, ZERO_ACTION_TOKEN, ZERO_RTG_BINS
 
 def _dims_struct(d: Dims):
     return _lib.Dims(A=d.A, T=d.T, P=d.P, NP=d.NP, D=d.D, H=d.H, F=d.F, V=d.V, R=d.R, C=d.C, NE=d.NE, ND=d.ND,
-                     MAXT=d.MAXT)
+                     MAXT=d.MAXT, variant=d.VARIANT)
 
 
 class HipModel:
@@ -126,7 +126,7 @@ class RolloutEngine:
         self.tilt = (C.c_double * 3)(*([0.0, 0.0, 0.0] if tilt.ndim == 2 else [float(x) for x in tilt]))
         self.kinematic = int(bool(kinematic))
         self.max_ctx = int(max_ctx)
-        self.use_cache = bool(use_cache)
+        self.use_cache = bool(use_cache) and not self.dims.VARIANT    # the K/V-cached phase is built for the CtRL-Sim tokens
         self.contacts = bool(contacts) and not kinematic
         self.dt = float(cfg.nocturne.dt)
         w = self.w
@@ -335,18 +335,23 @@ class RolloutEngine:
                                                      p(self.hist_states), p(self.hist_tok), p(self.hist_rtg),
                                                      p(self.goals), p(self.types), p(self.roads), p(self.rtypes),
                                                      self._zero4, C.byref(self.ctx.struct), st), "build_context")
-                _lib.check(lib.ctrlsim_dt_forward_pass1(self.model.handle, B, Tq, C.byref(self.ctx.struct), p(self.ws),
-                                                        p(self.rtg_logits), None, st), "pass1")
+                if d.VARIANT:                                # IL / Trajeglish: no RTG tokens, one forward (predict_rtgs False)
+                    _lib.check(lib.ctrlsim_dt_forward_actions(self.model.handle, B, Tq, C.byref(self.ctx.struct), p(self.ws),
+                                                              p(self.act_logits), st), "forward_actions")
+                else:
+                    _lib.check(lib.ctrlsim_dt_forward_pass1(self.model.handle, B, Tq, C.byref(self.ctx.struct), p(self.ws),
+                                                            p(self.rtg_logits), None, st), "pass1")
             else:
                 self.own_ctx[sl].fill_(-1)
                 self.mem_ctx[sl].fill_(-1)
-            _lib.check(lib.ctrlsim_sample_rtg(p(self.rtg_logits), d.A, d.R, p(self.own_ctx[sl]), p(self.own_slot[sl]),
-                                              p(self.tilted[sl]), self.tilt,
-                                              p(self.tilt_scn[sl]) if self.tilt_scn is not None else None,
-                                              p(noise_rtg[sl]) if noise_rtg is not None else None, self.seed,
-                                              p(self.scenario_id[sl]), t, p(self.hist_rtg[sl]), ns, N, Tmax, st),
-                       "sample_rtg")
-            if B > 0:
+            if not d.VARIANT:
+                _lib.check(lib.ctrlsim_sample_rtg(p(self.rtg_logits), d.A, d.R, p(self.own_ctx[sl]), p(self.own_slot[sl]),
+                                                  p(self.tilted[sl]), self.tilt,
+                                                  p(self.tilt_scn[sl]) if self.tilt_scn is not None else None,
+                                                  p(noise_rtg[sl]) if noise_rtg is not None else None, self.seed,
+                                                  p(self.scenario_id[sl]), t, p(self.hist_rtg[sl]), ns, N, Tmax, st),
+                           "sample_rtg")
+            if B > 0 and not d.VARIANT:
                 _lib.check(lib.ctrlsim_dt_forward_pass2(self.model.handle, B, Tq, t, N, Tmax, C.byref(self.ctx.struct),
                                                         p(self.ctx_scn), p(self.hist_rtg), p(self.ws),
                                                         p(self.act_logits), 0, st), "pass2")

@@ -33,9 +33,13 @@ class AutoregressivePolicy(Policy):
             self.goal_tilt = tilt_dict["goal_tilt"]
             self.veh_veh_tilt = tilt_dict["veh_veh_tilt"]
             self.veh_edge_tilt = tilt_dict["veh_edge_tilt"]
-        if not (use_rtg and predict_rtgs and discretize_rtgs) or real_time_rewards:
-            raise NotImplementedError("the HIP path implements the CtRL-Sim variant (cfgs/policy/ctrl_sim.yaml): "
-                                      "use_rtg, predict_rtgs, discretize_rtgs, no real_time_rewards")
+        variant = model.dims.VARIANT
+        if variant == 0 and (not (use_rtg and predict_rtgs and discretize_rtgs) or real_time_rewards):
+            raise NotImplementedError("the CtRL-Sim model runs as in cfgs/policy/ctrl_sim.yaml: use_rtg, predict_rtgs, "
+                                      "discretize_rtgs, no real_time_rewards")
+        if variant != 0 and (use_rtg or predict_rtgs or real_time_rewards):
+            raise NotImplementedError("the IL / Trajeglish models have no RTG tokens (cfgs/policy/{il,trajeglish}.yaml: "
+                                      "use_rtg = predict_rtgs = False)")
         self._session = None
         self.scenario_index = 0
 
@@ -95,7 +99,7 @@ class AutoregressivePolicy(Policy):
         own = eng.own_ctx[0].cpu().numpy()
         cont_rtg = dz.undiscretize_rtgs(bins, w)
         ids = list(vehicle_data_dict.keys())
-        for i, v in enumerate(ids):
+        for i, v in enumerate(ids if self.predict_rtgs else []):       # autoregressive_policy.py:242-247
             d = vehicle_data_dict[v]
             if own[i] >= 0:
                 d["next_rtg_goal"], d["next_rtg_veh"], d["next_rtg_road"] = cont_rtg[i]

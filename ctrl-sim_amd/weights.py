@@ -106,8 +106,9 @@ def param_table(dims: Dims):
         ln(f"{p}.norm2")
         ln(f"{p}.norm3")
     mlp("decoder.predict_action", D, D, dims.V)
-    mlp("decoder.predict_rtg", D, D, dims.R * dims.C)
-    mlp("decoder.predict_future_states", D, D, dims.FUT)
+    if not getattr(dims, "VARIANT", 0):       # the IL / Trajeglish models have neither head (cfgs/model/{il,trajeglish}.yaml)
+        mlp("decoder.predict_rtg", D, D, dims.R * dims.C)
+        mlp("decoder.predict_future_states", D, D, dims.FUT)
     return t
 
 

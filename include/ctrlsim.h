@@ -33,6 +33,8 @@ typedef struct ihipStream_t* hipStream_t;
 
 typedef struct ctrlsim_dims {
   int A, T, P, NP, D, H, F, V, R, C, NE, ND, MAXT;
+  int variant; /* 0 CtRL-Sim (state, rtg, action tokens; cfgs/model/ctrl_sim.yaml), 1 IL (state, action; il.yaml),
+                  2 Trajeglish (action tokens only; trajeglish.yaml) — modules/encoder.py:141-152, decoder.py:29-64 */
 } ctrlsim_dims;
 
 /* Agent-local context tensors of B contexts (outputs of ctrlsim_build_context, inputs of the forward). */
@@ -106,6 +108,12 @@ int64_t ctrlsim_forward_workspace_bytes(const ctrlsim_dims* dims, int B, int Tq)
 /* pass 1: rtg_logits [B,A,R*C] of the current-timestep state tokens; caches per-layer K/V in `workspace`. */
 int ctrlsim_dt_forward_pass1(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* ctx, void* workspace,
                              float* rtg_logits, float* dbg_seg_emb /*nullable [B,P,D]*/, hipStream_t stream);
+/* The baselines of cfgs/model/{il,trajeglish}.yaml (dims.variant 1 / 2) have no RTG tokens and one forward per step
+ * (policies with predict_rtgs = False, autoregressive_policy.py:189,208-240): action logits [B,A,V] of the current step from
+ * the state tokens (IL) / action tokens (Trajeglish), decoder.py:58-64.  ctrlsim_dt_forward_pass1 / _pass2 / _cached refuse
+ * these models and this call refuses the CtRL-Sim model. */
+int ctrlsim_dt_forward_actions(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* ctx, void* workspace,
+                               float* act_logits, hipStream_t stream);
 /* pass 2 (same workspace, after ctrlsim_sample_rtg wrote hist_rtg[...,t,:]): act_logits [B,A,V].
  * cached = 1 pairs with ctrlsim_dt_forward_pass1_cached (workspace sized with Tq = T, ctx = last min(Tq,2) window rows). */
 int ctrlsim_dt_forward_pass2(const ctrlsim_model* m, int B, int Tq, int t, int N, int Tmax, const ctrlsim_ctx* ctx,

@@ -16,5 +16,9 @@ def golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 
 
-def cfg_of(kind):
-    return spec.make_cfg(**{"tiny": TINY, "loop": LOOP, "full": {}}[kind])
+def cfg_of(kind, variant=None):
+    """variant "il" / "trajeglish": cfgs/model/{il,trajeglish}.yaml on top of the size preset."""
+    over = dict({"tiny": TINY, "loop": LOOP, "full": {}}[kind])
+    if variant:
+        over.update({f"model__{variant}": True, "model__predict_rtg": False, "model__predict_future_states": False})
+    return spec.make_cfg(**over)

@@ -166,3 +166,35 @@ def test_policy_evaluator_on_nocturne_json_files(tmp_path):
         assert np.hypot(p["x"] - g[0], p["y"] - g[1]) < 0.5
     p = vdd[6]["position"][-1]
     assert np.hypot(p["x"] - scn.x[6], p["y"] - scn.y[6]) < 0.5                      # the parked car stays put
+
+
+@pytest.mark.parametrize("name", ["il", "trajeglish"])
+def test_baseline_policies_through_the_plugin_surface(name):
+    """eval_sim.py flow with cfgs/policy/{il,trajeglish}.yaml (use_rtg = predict_rtgs = False) and the matching model config:
+    same rollout as the batched engine; a CtRL-Sim-style policy on these models is refused."""
+    cfg = cfg_of("loop", variant=name)
+    cfg.nocturne.history_steps = 1
+    cfg.eval.seed = 6
+    cfg.eval["synthetic"] = dict(num_scenarios=1, n_agents=9, n_polylines=15, seed=17, extent=40.0)
+    model = CtRLSim(cfg, seed=0, device="cuda:0")
+    kw = dict(cfg=cfg, model_path="", model=model, discretize_rtgs=True, real_time_rewards=False, privileged_return=False,
+              max_return=False, min_return=False,
+              key_dict={"next_acceleration": "next_acceleration", "next_steering": "next_steering", "rtgs": "rtgs"},
+              tilt_dict={"tilt": False, "goal_tilt": None, "veh_veh_tilt": None, "veh_edge_tilt": None}, name=name,
+              action_temperature=1.0, nucleus_sampling=False, nucleus_threshold=0.8)
+    with pytest.raises(NotImplementedError):
+        AutoregressivePolicy(use_rtg=True, predict_rtgs=True, **kw)
+    policy = AutoregressivePolicy(use_rtg=False, predict_rtgs=False, **kw)
+    cfg.eval.multi_agent_eval_threshold = 100            # evaluate all nine vehicles, like the engine run below
+    ev = PolicyEvaluator(cfg, policy)
+    m, _ = ev.evaluate_policy()
+    assert all(np.isfinite(v) for v in m.values())
+    vdd = ev.last_vehicle_data_dict
+    d = spec.Dims(cfg)
+    scn = scenarios.make_scenario(17, 0, n_agents=9, n_polylines=15, n_points=d.NP, extent=40.0)
+    eng = RolloutEngine(cfg, model.weights, "cuda:0", max_ctx=32, seed=6)
+    eng.load_scenarios([scn], steps=20)
+    r = eng.run(20).results()
+    acts = np.array([[vdd[v]["acceleration"][t], vdd[v]["steering"][t]] for v in range(9) for t in range(20)]).reshape(9, 20, 2)
+    assert np.array_equal(dz.discretize_actions(acts, cfg.dataset.waymo).astype(np.int64), r["tokens"][0])
+    assert vdd[0]["rtgs"] == []                           # nothing is appended without predict_rtgs

@@ -140,6 +140,38 @@ def test_attention_structured_causal_mask(A, T, attn_impl):
     assert (Oc.double() - ref[:, pos.long()]).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("mode", [2, 3], ids=["il", "trajeglish"])
+@pytest.mark.parametrize("A,T", [(24, 32), (6, 8), (24, 7)])
+def test_attention_mask_variants_of_the_baselines(A, T, mode):
+    """Modes 2 / 3 of the structured mask: the IL (state, action) and Trajeglish (action only) models keep the 3-slot token layout
+    and the token types they lack are dead as keys.  Restricted to the live tokens the visibility must be get_causal_mask with
+    2 / 1 token types (oracle closed form, pinned against the reference in tests/golden/variants.npz)."""
+    B, H = 2, 8
+    L = A * T * 3
+    g = torch.Generator().manual_seed(A * T + mode)
+    qkv = torch.randn(B, L, 768, generator=g).to(DEV)
+    O = torch.zeros(B, L, 256, device=DEV)
+    p = _lib.ptr
+    _lib.check(_lib.lib().ctrlsim_attention(mode, p(qkv), 768, L * 768, qkv.data_ptr() + 256 * 4, qkv.data_ptr() + 512 * 4, 768,
+                                            L * 768, p(O), 256, L * 256, None, None, B, L, L, A, _lib.stream_ptr()))
+    live = [0, 2] if mode == 2 else [2]                              # token types the model has, in slot order
+    K = len(live)
+    idx = torch.tensor([(ta * 3 + k) for ta in range(T * A) for k in live], device=DEV)
+    q, k, v = [qkv[..., i * 256:(i + 1) * 256].view(B, L, H, 32).transpose(1, 2) for i in range(3)]
+    vis = mo.causal_mask_closed_form(A, T, K).to(DEV)[None, None]
+    ref = _attn_ref(q[:, :, idx], k[:, :, idx], v[:, :, idx], vis).transpose(1, 2).reshape(B, len(idx), 256)
+    assert (O[:, idx].double() - ref).abs().max().item() < 2e-5
+    assert torch.isfinite(O).all()                                    # the dead rows hold finite values too
+    # gathered queries (the last layer's compact rows): state tokens (IL) / action tokens (Trajeglish) of the last step
+    ti, off = T - 1, (0 if mode == 2 else 2)
+    pos = torch.tensor([(ti * A + a) * 3 + off for a in range(A)], dtype=torch.int32, device=DEV)
+    qc = qkv[:, pos.long(), :].contiguous()
+    Oc = torch.zeros(B, A, 256, device=DEV)
+    _lib.check(_lib.lib().ctrlsim_attention(mode, p(qc), 768, A * 768, qkv.data_ptr() + 256 * 4, qkv.data_ptr() + 512 * 4, 768,
+                                            L * 768, p(Oc), 256, A * 256, p(pos), None, B, A, L, A, _lib.stream_ptr()))
+    assert (Oc.double() - O[:, pos.long()].double()).abs().max().item() < 2e-5
+
+
 @pytest.mark.parametrize("Lq,Lk", [(224, 224), (2304, 224), (10, 10), (24, 224), (130, 67)])
 def test_attention_key_padding(Lq, Lk, attn_impl):
     B, H = 3, 8

@@ -396,3 +396,40 @@ def test_full_size_rollout_is_invariant_to_batching_and_cache():
                 assert np.array_equal(a["states"], b["states"]), tag
             else:
                 np.testing.assert_allclose(a["states"], b["states"], atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["il", "trajeglish"])
+def test_baseline_variants_match_reference_fixture(name):
+    """cfgs/model/{il,trajeglish}.yaml on the HIP path (3-slot token layout with dead key types, one forward per step):
+    action logits vs the reference modules' (tests/golden/variants.npz), then the closed loop vs the unmodified reference policy
+    + real FreeCar/Box2D — tokens bit-exact, states within 1e-4, flags identical (the scene has collisions)."""
+    from ctrlsim_amd.engine import HipModel, ctx_from_reference_layout
+    g = golden("variants")
+    cfg = cfg_of("loop", variant=name)
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    model = HipModel(cfg, w, DEV)
+    lib, p, st = _lib.lib(), _lib.ptr, _lib.stream_ptr()
+    ws = torch.empty(model.workspace_bytes(1, d.T), dtype=torch.uint8, device=DEV)
+    for seed in (1, 2):
+        _, t_fill, n_ag, n_pl = [int(v) for v in g[f"{name}_loop_s{seed}_recipe"]]
+        inp = synth_inputs.random_context(d, seed, B=1, t_fill=t_fill, n_agents=n_ag, n_polys=n_pl)
+        cb = ctx_from_reference_layout(d, inp, t_fill, DEV)
+        logits = torch.empty(1, d.A, d.V, device=DEV)
+        _lib.check(lib.ctrlsim_dt_forward_actions(model.handle, 1, t_fill, C.byref(cb.struct), p(ws), p(logits), st), "actions")
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(logits[0].cpu().numpy(), g[f"{name}_loop_s{seed}_action"], atol=1e-4, rtol=0)
+        # the CtRL-Sim entry points refuse this model
+        assert lib.ctrlsim_dt_forward_pass1(model.handle, 1, t_fill, C.byref(cb.struct), p(ws), p(logits), None, st) != 0
+    rc = g[f"{name}_loop_recipe"]
+    scn = scenarios.make_scenario(int(rc[0]), int(rc[1]), n_agents=int(rc[2]), n_polylines=int(rc[3]), n_points=d.NP,
+                                  extent=float(rc[4]))
+    eng = RolloutEngine(cfg, w, DEV, max_ctx=32, seed=int(rc[5]), model=model)
+    eng.load_scenarios([scn, scn], steps=14)
+    r = eng.run(14).results()
+    for s in range(2):
+        assert np.array_equal(r["n_groups"][:, s], g[f"{name}_loop_n_groups"])
+        assert np.array_equal(r["tokens"][s][:, :14], g[f"{name}_loop_tokens"])
+        np.testing.assert_allclose(r["states"][s], g[f"{name}_loop_states"], atol=1e-4, rtol=0)
+        assert np.array_equal(r["coll"][s], g[f"{name}_loop_coll"])
+    assert g[f"{name}_loop_coll"][..., 0].sum() > 0

@@ -303,11 +303,10 @@ def test_variant_oracles_match_reference(name, K):
     """cfgs/model/{il,trajeglish}.yaml: token stacks of 2 / 1 types, their causal masks, action logits from token type 0, and
     the single-forward policy — model oracle vs the reference modules' logits, rollout oracle vs the unmodified reference policy
     (tests/golden/variants.npz)."""
-    import gen_golden
     g = golden("variants")
     assert np.array_equal(mo.causal_mask_closed_form(4, 4, K).numpy(), g[f"{name}_mask_tiny"])
     for tag in ("tiny", "loop"):
-        cfg = gen_golden.variant_cfg(name, **(gen_golden.TINY if tag == "tiny" else gen_golden.LOOP))
+        cfg = cfg_of(tag, variant=name)
         d = spec.Dims(cfg)
         assert d.VARIANT == {"il": 1, "trajeglish": 2}[name]
         tw = mo.as_torch_weights(weights.generate(d, 0))
@@ -319,7 +318,7 @@ def test_variant_oracles_match_reference(name, K):
             got = out["action_preds"].numpy() if tag == "tiny" else out["action_preds"][0, :, t_fill - 1].numpy()
             np.testing.assert_allclose(got, g[f"{name}_{tag}_s{seed}_action"], atol=2e-5, rtol=0)
     rc = g[f"{name}_loop_recipe"]
-    cfg = gen_golden.variant_cfg(name, **gen_golden.LOOP)
+    cfg = cfg_of("loop", variant=name)
     d = spec.Dims(cfg)
     scn = scenarios.make_scenario(int(rc[0]), int(rc[1]), n_agents=int(rc[2]), n_polylines=int(rc[3]), n_points=d.NP,
                                   extent=float(rc[4]))
