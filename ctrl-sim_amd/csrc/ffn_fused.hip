@@ -73,9 +73,9 @@ constexpr int FF_CP = DM + 4;                      // row pitch (floats) of the 
 // one wave per SIMD — but at this register pressure hipcc answers with v_accvgpr_mov shuffles / spills and the result is
 // slower: profiles/r01_c_pmc_pipes.md.)
 __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
-    const float* __restrict__ X, int ldx, const __bf16* __restrict__ W1p, const float* __restrict__ b1,
+    const float* X, int ldx, const __bf16* __restrict__ W1p, const float* __restrict__ b1,   // X may alias Y: no restrict
     const __bf16* __restrict__ W2p, const float* __restrict__ b2, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float* __restrict__ Y, int ldy, int M, int nhb) {
+    const float* __restrict__ beta, float* Y, int ldy, int M, int nhb) {
   extern __shared__ __attribute__((aligned(16))) __bf16 ring[];      // FF_RING blocks of 48 KB, then b1 (F floats)
   float* b1s = reinterpret_cast<float*>(ring + FF_RING * FF_BLK);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;

@@ -24,8 +24,8 @@ template <int TBK, bool RELU, bool RESID>
 __global__ __launch_bounds__(256, (TBK == 16 ? 3 : 2)) void gemm_nt_f32_kernel(const float* __restrict__ A, int lda,
                                                           const float* __restrict__ W, int ldw,
                                                           const float* __restrict__ bias,
-                                                          const float* __restrict__ R, int ldr,
-                                                          float* __restrict__ C, int ldc, int M, int N, int K,
+                                                          const float* R, int ldr,   // C may alias R: no restrict
+                                                          float* C, int ldc, int M, int N, int K,
                                                           int m_tiles, int n_tiles) {
   constexpr int BKP = TBK + 4;
   constexpr int CP = BN + 4;
@@ -172,10 +172,10 @@ __global__ __launch_bounds__(256, (TBK == 16 ? 3 : 2)) void gemm_nt_f32_kernel(c
 // y = LayerNorm(x [+ r]) * gamma + beta [ReLU], rows of 256; one wave per row (4 channels per lane).
 // torch.nn.LayerNorm semantics: biased variance, eps inside the sqrt (eps = 1e-5 everywhere in the model).
 template <bool RELU>
-__global__ __launch_bounds__(256) void layernorm256_kernel(const float* __restrict__ X, int ldx,
-                                                           const float* __restrict__ Radd, int ldr,
+__global__ __launch_bounds__(256) void layernorm256_kernel(const float* X, int ldx,    // Y may alias X / Radd: no restrict
+                                                           const float* Radd, int ldr,
                                                            const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* __restrict__ Y,
+                                                           const float* __restrict__ beta, float* Y,
                                                            int ldy, int rows) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;

@@ -70,7 +70,7 @@ template <int WR, int WC, int MR, bool RELU, bool RESID, bool LN, bool KVIMG = f
 __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? 3 : 2)) void gemm_nt_bf16x6_kernel(
     const float* __restrict__ A, int lda, const __bf16* __restrict__ W3,   // [K/16][3][2][n_total][8]
     const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ R, int ldr, float* __restrict__ C, int ldc, int M, int N, int K, int m_tiles, int n_tiles,
+    const float* R, int ldr, float* C, int ldc, int M, int N, int K, int m_tiles, int n_tiles,   // C may alias R: no restrict
     int n_total, int n0, KvImg kv) {
   // W3 holds all n_total rows of the packed matrix; this GEMM uses rows [n0, n0 + N) (e.g. the q / kv halves of an
   // in_proj_weight)
