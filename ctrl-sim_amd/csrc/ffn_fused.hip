@@ -273,12 +273,11 @@ int launch_ffn_fused_bf16x6(const float* X, int ldx, const void* W1p, const floa
   const int n_rb = (M + 127) / 128;
   const int grid = n_rb < 256 ? n_rb : 256;                           // one persistent workgroup per CU
   const size_t shm = (size_t)FF_RING * FF_BLK * sizeof(__bf16) + (size_t)F * sizeof(float);   // 147456 B + b1
-  static bool attr = false;
-  if (!attr) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_bf16x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)shm);
-    attr = true;
-  }
+  // once per process (thread-safe static initialisation), sized for the largest F this launcher accepts
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_bf16x6_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)(FF_RING * FF_BLK * sizeof(__bf16) + 4096 * sizeof(float))) == hipSuccess;
+  if (!attr_ok) return CTRLSIM_EINVAL;
   prof_before(PROF_GEMM, st);
   hipLaunchKernelGGL(ffn_fused_bf16x6_kernel, dim3(grid), dim3(256), shm, st, X, ldx, static_cast<const __bf16*>(W1p), b1,
                      static_cast<const __bf16*>(W2p), b2, gamma, beta, Y, ldy, M, F / 32);

@@ -385,12 +385,10 @@ int launch_gemm_nt_bf16x6_kv(const float* A, int lda, const void* W3, int n_tota
 #define GEMM6_LAUNCH(WR_, WC_, RELU_, RESID_, LN_, KV_) GEMM6_LAUNCH_(WR_, WC_, 2, RELU_, RESID_, LN_, KV_)
 #define GEMM6_LAUNCH_(WR_, WC_, MR_, RELU_, RESID_, LN_, KV_)                                                               \
   do {                                                                                                                \
-    static bool attr = false;                                                                                         \
-    if (!attr) {                                                                                                      \
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16x6_kernel<WR_, WC_, MR_, RELU_, RESID_, LN_, KV_>),   \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                                      \
-      attr = true;                                                                                                    \
-    }                                                                                                                 \
+    static const bool attr_ok =      /* once per instantiation, thread-safe static initialisation */                  \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16x6_kernel<WR_, WC_, MR_, RELU_, RESID_, LN_, KV_>), \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess;                      \
+    if (!attr_ok) return CTRLSIM_EINVAL;                                                                              \
     hipLaunchKernelGGL((gemm_nt_bf16x6_kernel<WR_, WC_, MR_, RELU_, RESID_, LN_, KV_>), g, b, shm, st, A, lda, w, bias,    \
                        ln_gamma, ln_beta, R, ldr, C, ldc, M, N, K, m_tiles, n_tiles, n_total, n0, kv);                \
   } while (0)

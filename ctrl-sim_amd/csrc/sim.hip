@@ -227,7 +227,7 @@ __device__ void collide_and_record(int s, int N, int E, const float* __restrict_
 #define CS_TAIL 6        // m_inv_dt0, contact stamp, m_newContacts, move count, tree root, tree free-list head
 #define TN_STRIDE 8      // tree node: box lower x, y, upper x, y, parent (= next in the free list), child1, child2, height
 #define CS_PER(N) ((N) * ((N) - 1) / 2 * CS_STRIDE + CS_TAIL + 12 * (N) + 2 * (N) * TN_STRIDE)
-#define MAX_ISLAND_CONTACTS 160
+#define MAX_ISLAND_CONTACTS 192   // >= 3 N - 6 = 186 at N = 64: the touching graph of disjoint convex boxes is planar
 #define B2_AABB_EXT 0.1f
 #define B2_AABB_MULT 4.0f
 #define B2_LINEAR_SLOP 0.005f
