@@ -95,7 +95,11 @@ def main():
         sweep = np.array([-20.0, -10.0, -5.0, 0.0, 5.0, 10.0, 20.0, 30.0])
         tilt = np.repeat(sweep[np.array(ids) % 8][:, None], 3, axis=1)
     eng = RolloutEngine(cfg, w, device, max_ctx=args.max_ctx, seed=args.seed, tilt=tilt)
-    eng.load_scenarios(scns, steps=R)
+    torch.cuda.synchronize()
+    t_up = time.perf_counter()
+    eng.load_scenarios(scns, steps=R)                         # host -> HBM: the only PCIe traffic of a rollout (untimed)
+    torch.cuda.synchronize()
+    upload_ms = (time.perf_counter() - t_up) * 1e3
     lib = _lib.lib()
 
     def barrier():
@@ -193,6 +197,7 @@ def main():
                        "scenarios_per_gpu": S, "agents": N, "rollout_steps": R, "polylines": args.polylines,
                        "model_batch_contexts": args.max_ctx, "contexts_per_rollout_rank0": ctx_per_rollout,
                        "mean_focal_groups_per_scenario_step": ctx_per_rollout / (S * R),
+                       "scenario_upload_ms_untimed": upload_ms,
                        "tilt": "sweep of 8 values, one per scenario (configs[4])" if args.tilt_sweep else list(args.tilt),
                        "parallelism": f"scenario-sharded x{world}"},
             "roofline": roof, "cpu_baseline": cpu,
