@@ -433,3 +433,22 @@ def test_baseline_variants_match_reference_fixture(name):
         np.testing.assert_allclose(r["states"][s], g[f"{name}_loop_states"], atol=1e-4, rtol=0)
         assert np.array_equal(r["coll"][s], g[f"{name}_loop_coll"])
     assert g[f"{name}_loop_coll"][..., 0].sum() > 0
+
+
+def test_kinematic_integrator_mode_matches_oracle():
+    """mode 1 of ctrlsim_sim_step = Object::KinematicBicycleStep (object.cc:126-137; not what eval_sim.py runs — optional,
+    SURVEY 8a S6): scripted actions vs the oracle's restatement, which holds the reference's own known answers
+    (tests/test_oracle_pinned.py)."""
+    import ctypes as C2
+    g = golden("physics")
+    hist, _ = _gpu_scripted(g, mode=1, contacts=False)
+    lib = C2.CDLL(sim_libs.ORA_SO)
+    lib.orasim_kinematic_step.argtypes = [C2.POINTER(C2.c_float), C2.c_float, C2.c_float, C2.c_float, C2.c_float]
+    steps, n = g["acts"].shape[:2]
+    for i in range(n):
+        st = (C2.c_float * 4)(g["x"][i], g["y"][i], g["h"][i], g["v"][i])
+        for t in range(steps):
+            lib.orasim_kinematic_step(st, float(g["L"][i]), float(np.float32(g["acts"][t, i, 0])), float(np.float32(g["acts"][t, i, 1])), 0.1)
+            got = hist[0, i, t + 1]
+            np.testing.assert_allclose([got[0], got[1], got[4]], [st[0], st[1], st[2]], atol=1e-4, rtol=0)
+            np.testing.assert_allclose(np.hypot(got[2], got[3]), abs(st[3]), atol=1e-4, rtol=0)

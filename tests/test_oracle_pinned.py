@@ -333,3 +333,48 @@ def test_inverse_bicycle_matches_reference():
     g = golden("bicycle_backward")
     a, s = bicycle_backward(g["nxt"], g["prev"], 0.1)
     np.testing.assert_allclose(np.stack([a, s], 1), g["accel_steer"], rtol=0, atol=1e-12)
+
+
+def _kin(state, length, accel, steer, dt, steps=1):
+    """Object::KinematicBicycleStep through the oracle (optional integrator mode S6)."""
+    import ctypes as C
+    lib = C.CDLL(sim_libs.ORA_SO)
+    lib.orasim_kinematic_step.argtypes = [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_float]
+    st = (C.c_float * 4)(*state)
+    for _ in range(steps):
+        lib.orasim_kinematic_step(st, length, accel, steer, dt)
+    return np.array(st[:], np.float32)
+
+
+def test_kinematic_step_known_answers_of_the_reference():
+    """The known-answer tests the reference holds for Object::KinematicBicycleStep (nocturne/cpp/tests/src/object_test.cc:35-191;
+    values transcribed as data), on the oracle's restatement of object.cc:126-137: uniform motion, constant acceleration
+    forward and backward, one steering step against the closed form of the test file.  (SpeedCliptTest needs a finite
+    max_speed, which the evaluated path never sets: object.h:189.)"""
+    q, t, n = np.float32(np.pi / 4), 10.0, 100
+    dt = np.float32(t / n)
+    # UniformLinearMotionTest: (1,1), heading pi/4, speed 10, 100 steps of 0.1
+    st = _kin([1, 1, q, 10], 2.0, 0.0, 0.0, dt, n)
+    v = np.float32(10) * np.array([np.cos(q), np.sin(q)], np.float32)
+    np.testing.assert_allclose(st[:2], 1 + v * np.float32(t), atol=1e-4)
+    assert st[2] == q and st[3] == np.float32(10)
+    # ConstantAccelerationMotionTest, forward: speed 0, a = 2
+    st = _kin([1, 1, q, 0], 2.0, 2.0, 0.0, dt, n)
+    tgt = 1 + np.float32(2) * np.array([np.cos(q), np.sin(q)], np.float32) * np.float32(t * t * 0.5)
+    np.testing.assert_allclose(st[:2], tgt, atol=1e-4)
+    assert st[2] == q and abs(st[3] - 20.0) < 1e-4
+    # backward: speed 10, a = -2
+    st = _kin([1, 1, q, 10], 2.0, -2.0, 0.0, dt, n)
+    tgt = 1 + v * np.float32(t) - np.float32(2) * np.array([np.cos(q), np.sin(q)], np.float32) * np.float32(t * t * 0.5)
+    np.testing.assert_allclose(st[:2], tgt, atol=1e-4)
+    assert st[2] == q and abs(st[3] - (-10.0)) < 1e-4
+    # SteeringMotionTest: speed 2, steering 10 degrees, one step of 0.1 vs KinematicBicycleModel() of the test file
+    f = np.float32
+    delta = f(f(10.0) / 180.0 * np.pi)
+    beta = f(np.arctan(f(np.tan(delta)) * f(0.5)))
+    dx, dy = f(2) * f(np.cos(q + beta)), f(2) * f(np.sin(q + beta))
+    dth = f(2) * f(np.tan(delta)) * f(np.cos(beta)) / f(2)
+    st = _kin([1, 1, q, 2], 2.0, 0.0, float(delta), 0.1)
+    np.testing.assert_allclose(st[:2], [f(1) + dx * f(0.1), f(1) + dy * f(0.1)], rtol=4e-7)      # EXPECT_FLOAT_EQ = 4 ulp
+    np.testing.assert_allclose(st[2], q + dth * f(0.1), rtol=4e-7)
+    assert st[3] == f(2)
