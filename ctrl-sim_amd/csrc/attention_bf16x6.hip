@@ -321,7 +321,9 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
         int off3 = (ks_t0 - ks0) % 3;                                      // ks_t0 <= ks0: first state token at or after ks0
         off3 = off3 < 0 ? off3 + 3 : off3;
         const unsigned every3 = (unsigned)(0x249249249249ull << off3);
-        const unsigned own = ones(pos - ks0 + 1) & ~ones(pos - kq - ks0);
+        // variant 3 (Decision Transformer, token order rtg, state, action — kept in the slots state, rtg, action): a state
+        // token also sees its own agent's rtg token, one position AFTER it
+        const unsigned own = ones(pos - ks0 + 1 + ((variant == 3 && kq == 0) ? 1 : 0)) & ~ones(pos - kq - ks0);
         unsigned vis_all = before | ((every3 | own) & same);
         if (variant) {
           // the 3-slot token layout is kept for the baselines of cfgs/model/{il,trajeglish}.yaml; the token types they do not
@@ -330,7 +332,8 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
           int o2 = off3 + 2;
           o2 = o2 >= 3 ? o2 - 3 : o2;
           const unsigned actions = (unsigned)(0x249249249249ull << o2);
-          vis_all = (variant == 1) ? (vis_all & (every3 | actions)) : ((before | same) & actions);
+          if (variant == 1) vis_all &= every3 | actions;
+          else if (variant == 2) vis_all = (before | same) & actions;
         }
         const unsigned vis = vis_all >> (4 * half);
 #pragma unroll
@@ -589,8 +592,8 @@ int launch_attention_bf16x6(int mode, const float* Q, int ldq, long q_batch_stri
                             const unsigned char* key_pad, int B, int Lq, int Lk, int A, hipStream_t st) {
   if (B <= 0 || Lq <= 0) return CTRLSIM_OK;
   if (Lk <= 0 || (ldq & 3) || (ldkv & 3)) return CTRLSIM_EINVAL;
-  if (mode < 0 || mode > 3 || (mode == MODE6_KEYPAD && !key_pad)) return CTRLSIM_EINVAL;
-  const int variant = mode >= MODE6_CAUSAL ? mode - MODE6_CAUSAL : 0;   // mode 1 CtRL-Sim mask, 2 IL, 3 Trajeglish
+  if (mode < 0 || mode > 4 || (mode == MODE6_KEYPAD && !key_pad)) return CTRLSIM_EINVAL;
+  const int variant = mode >= MODE6_CAUSAL ? mode - MODE6_CAUSAL : 0;   // mode 1 CtRL-Sim mask, 2 IL, 3 Trajeglish, 4 DT
   mode = mode >= MODE6_CAUSAL ? MODE6_CAUSAL : MODE6_KEYPAD;
   dim3 g((Lq + 127) / 128, NHEAD, B), blk(256);
   const float scale = 0.17677669529663687f * 1.4426950408889634f;  // log2(e)/sqrt(32)
@@ -613,7 +616,7 @@ int launch_attention_bf16x6_pre(int mode, const float* Q, int ldq, long q_batch_
                                 int Lk, int A, hipStream_t st) {
   if (B <= 0 || Lq <= 0) return CTRLSIM_OK;
   if (Lk <= 0 || (ldq & 3) || !img || nkt * KT6 < Lk) return CTRLSIM_EINVAL;
-  if (mode < 0 || mode > 3 || (mode == MODE6_KEYPAD && !key_pad)) return CTRLSIM_EINVAL;
+  if (mode < 0 || mode > 4 || (mode == MODE6_KEYPAD && !key_pad)) return CTRLSIM_EINVAL;
   const int variant = mode >= MODE6_CAUSAL ? mode - MODE6_CAUSAL : 0;
   mode = mode >= MODE6_CAUSAL ? MODE6_CAUSAL : MODE6_KEYPAD;
   dim3 g((Lq + 127) / 128, NHEAD, B), blk(256);

@@ -32,6 +32,8 @@ struct EmbedTables {
   const float* agent;      // [A,256]      encoder.embed_agent_id.weight
   const float* ln_g;       // [256]        encoder.embed_ln
   const float* ln_b;
+  int rtg_linear;          // Decision Transformer: the RTGs are continuous (float bits in rtg_bin) and rtg_g/v/r are single
+                           // rows: embed_rtg(cat_c Linear_c(r_c)) = r_0 g + r_1 v + r_2 r + rtg_bias (pack.py fold)
 };
 
 __global__ __launch_bounds__(256) void assemble_tokens_kernel(
@@ -62,10 +64,17 @@ __global__ __launch_bounds__(256) void assemble_tokens_kernel(
   *reinterpret_cast<f32x4*>(xo) = ln256(v, g, be);
   // rtg
   const int* rb = rtg_bin + (size_t)row * 3;
-  v = (*reinterpret_cast<const f32x4*>(tb.rtg_g + (size_t)rb[0] * DM + c4) +
-       *reinterpret_cast<const f32x4*>(tb.rtg_v + (size_t)rb[1] * DM + c4) +
-       *reinterpret_cast<const f32x4*>(tb.rtg_r + (size_t)rb[2] * DM + c4) +
-       *reinterpret_cast<const f32x4*>(tb.rtg_bias + c4) + pos) * ex;
+  if (tb.rtg_linear) {
+    v = (*reinterpret_cast<const f32x4*>(tb.rtg_g + c4) * __int_as_float(rb[0]) +
+         *reinterpret_cast<const f32x4*>(tb.rtg_v + c4) * __int_as_float(rb[1]) +
+         *reinterpret_cast<const f32x4*>(tb.rtg_r + c4) * __int_as_float(rb[2]) +
+         *reinterpret_cast<const f32x4*>(tb.rtg_bias + c4) + pos) * ex;
+  } else {
+    v = (*reinterpret_cast<const f32x4*>(tb.rtg_g + (size_t)rb[0] * DM + c4) +
+         *reinterpret_cast<const f32x4*>(tb.rtg_v + (size_t)rb[1] * DM + c4) +
+         *reinterpret_cast<const f32x4*>(tb.rtg_r + (size_t)rb[2] * DM + c4) +
+         *reinterpret_cast<const f32x4*>(tb.rtg_bias + c4) + pos) * ex;
+  }
   *reinterpret_cast<f32x4*>(xo + DM) = ln256(v, g, be);
   // action
   v = (*reinterpret_cast<const f32x4*>(tb.act + (size_t)act_tok[row] * DM + c4) + pos) * ex;

@@ -43,7 +43,7 @@ int launch_in_mlp(const float*, int, int, const float*, const float*, const floa
 int launch_row_copy(const float*, int, float*, int, const int*, int, int, int, hipStream_t);
 int launch_attention(int, const float*, int, long, const float*, const float*, int, long, float*, int, long, const int*,
                      const unsigned char*, int, int, int, int, hipStream_t);
-struct EmbedTables { const float *act, *rtg_g, *rtg_v, *rtg_r, *rtg_bias, *tstep, *agent, *ln_g, *ln_b; };
+struct EmbedTables { const float *act, *rtg_g, *rtg_v, *rtg_r, *rtg_bias, *tstep, *agent, *ln_g, *ln_b; int rtg_linear; };
 int launch_assemble_tokens(int, int, int, const float*, const float*, const float*, const int*, const int*, const int*,
                            EmbedTables, float*, float*, int, int, unsigned char*, hipStream_t);
 int launch_assemble_rows(int, int, int, int, int, const int*, const float*, const float*, const float*, const int*, const int*,
@@ -89,7 +89,7 @@ struct ctrlsim_model {
 extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_weights, int n, const char* const* names,
                                     const int64_t* offsets, ctrlsim_model** out) {
   if (!dims || !dev_weights || !names || !offsets || !out) return CTRLSIM_EINVAL;
-  if (dims->D != DM || dims->H != NHEAD || dims->A < 1 || dims->A > 64 || dims->variant < 0 || dims->variant > 2)
+  if (dims->D != DM || dims->H != NHEAD || dims->A < 1 || dims->A > 64 || dims->variant < 0 || dims->variant > 3)
     return CTRLSIM_EINVAL;
   std::unordered_map<std::string, const float*> tab;
   for (int i = 0; i < n; ++i) tab[names[i]] = dev_weights + offsets[i];
@@ -117,8 +117,9 @@ extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_w
   m->fold_state = Lin{P("fold.embed_state.w"), nullptr, P3("fold.embed_state.w"), 0, 0};
   m->fold_goal = Lin{P("fold.embed_goal.w"), P("fold.embed_goal.b"), P3("fold.embed_goal.w"), 0, 0};
   m->tb = EmbedTables{P("encoder.embed_action.weight"), P("fold.rtg_table_goal"), P("fold.rtg_table_veh"),
-                      P("fold.rtg_table_road"), P("encoder.embed_rtg.bias"), P("encoder.embed_timestep.weight"),
-                      P("encoder.embed_agent_id.weight"), P("encoder.embed_ln.weight"), P("encoder.embed_ln.bias")};
+                      P("fold.rtg_table_road"), P("fold.rtg_bias"), P("encoder.embed_timestep.weight"),
+                      P("encoder.embed_agent_id.weight"), P("encoder.embed_ln.weight"), P("encoder.embed_ln.bias"),
+                      dims->variant == 3 ? 1 : 0};
   const std::string me = "encoder.map_encoder.";
   m->mp = MapPoolWeights{P(me + "road_pts_encoder.mlp.0.weight"), P(me + "road_pts_encoder.mlp.0.bias"),
                          P(me + "road_pts_encoder.mlp.1.weight"), P(me + "road_pts_encoder.mlp.1.bias"),

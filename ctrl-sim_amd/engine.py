@@ -96,7 +96,10 @@ def ctx_from_reference_layout(d: Dims, data: dict, Tq: int, device):
     cb.exist.view(-1)[:B * Tq * d.A] = flat(st[..., 7].transpose(0, 2, 1)[:, :Tq], np.float32)
     cb.goal5.copy_(torch.from_numpy(np.asarray(data["goals"], np.float64).astype(np.float32)).to(device))
     cb.act_tok.view(-1)[:B * Tq * d.A] = flat(np.asarray(data["actions"]).transpose(0, 2, 1)[:, :Tq], np.int32)
-    cb.rtg_bin.view(-1)[:B * Tq * d.A * 3] = flat(np.asarray(data["rtgs"]).transpose(0, 2, 1, 3)[:, :Tq], np.int32)
+    rt = np.asarray(data["rtgs"]).transpose(0, 2, 1, 3)[:, :Tq]
+    if d.VARIANT == 3:                                   # decision transformer: continuous RTGs travel as float bits
+        rt = np.ascontiguousarray(rt, np.float32).view(np.int32)
+    cb.rtg_bin.view(-1)[:B * Tq * d.A * 3] = flat(rt, np.int32)
     cb.tstep.view(-1)[:B * Tq] = flat(np.asarray(data["timesteps"])[:, 0, :Tq, 0], np.int32)
     cb.slot_gid.fill_(-1)
     cb.road_pts.copy_(torch.from_numpy(np.asarray(data["road_points"], np.float64).astype(np.float32)).to(device))

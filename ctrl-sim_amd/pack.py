@@ -31,8 +31,17 @@ def fold(dims: Dims, w: dict) -> dict:
     out["fold.embed_goal.w"] = Wsg[:, D:] @ Wg3
     out["fold.embed_goal.b"] = Wsg[:, :D] @ bs3 + Wsg[:, D:] @ bg3 + bsg
     Wr = f8("encoder.embed_rtg.weight")
+    rtg_bias = f8("encoder.embed_rtg.bias").copy()
     for c, nm in enumerate(("goal", "veh", "road")):
-        out[f"fold.rtg_table_{nm}"] = f8(f"encoder.embed_rtg_{nm}.weight") @ Wr[:, c * D:(c + 1) * D].T
+        if getattr(dims, "VARIANT", 0) == 3:
+            # decision transformer: embed_rtg(cat_c(w_c r_c + b_c)) = sum_c r_c (W_c w_c) + (sum_c W_c b_c + bias): one row per
+            # component instead of a table, the constants folded into the bias
+            Wc = Wr[:, c * D:(c + 1) * D]
+            out[f"fold.rtg_table_{nm}"] = (Wc @ f8(f"encoder.embed_rtg_{nm}.weight")[:, 0])[None, :]
+            rtg_bias += Wc @ f8(f"encoder.embed_rtg_{nm}.bias")
+        else:
+            out[f"fold.rtg_table_{nm}"] = f8(f"encoder.embed_rtg_{nm}.weight") @ Wr[:, c * D:(c + 1) * D].T
+    out["fold.rtg_bias"] = rtg_bias
     pre = "encoder.map_encoder."
     W2, b2 = f8(pre + "road_pts_encoder.mlp.3.weight"), f8(pre + "road_pts_encoder.mlp.3.bias")
     Wi, bi = f8(pre + "road_pts_attn_layer.in_proj_weight"), f8(pre + "road_pts_attn_layer.in_proj_bias")
@@ -125,7 +134,7 @@ def pack(dims: Dims, w: dict):
     for k in list(allw.keys()):
         v = allw[k]
         if v.ndim == 2 and v.shape[1] % 16 == 0 and v.shape[1] >= 32 and (k.endswith("weight") or k.endswith(".w")) \
-                and "embed_action" not in k and "embed_rtg_" not in k and "embed_timestep" not in k and "embed_agent_id" not in k:
+                and "embed_action" not in k and "embed_rtg_" not in k and "rtg_table" not in k and "embed_timestep" not in k and "embed_agent_id" not in k:
             planes = split3_planes(v)
             allw[k + BF3_SUFFIX] = planes.reshape(-1).view(np.float32)
     # fused-FFN operand images of every transformer layer (post-LN block: linear1 -> ReLU -> linear2 -> +x -> LayerNorm)

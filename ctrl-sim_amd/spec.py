@@ -124,11 +124,11 @@ class Dims:
         self.A = int(w.max_num_agents)            # agents per context
         self.T = int(w.train_context_length)      # context steps
         self.K = 3                                # token types: state, rtg, action
-        # model variant (cfgs/model/{ctrl_sim,il,trajeglish}.yaml): IL drops the rtg tokens, Trajeglish keeps only the
+        # model variant (cfgs/model/{ctrl_sim,il,trajeglish,dt}.yaml): IL drops the rtg tokens, Trajeglish keeps only the
         # action tokens; on the device both keep the 3-slot token layout with the dropped types dead as attention keys
-        self.VARIANT = 1 if bool(m.get("il", False)) else (2 if bool(m.get("trajeglish", False)) else 0)
-        if bool(m.get("decision_transformer", False)):
-            raise NotImplementedError("decision_transformer (real-time continuous RTG) is not built")
+        # 3 = Decision Transformer (cfgs/model/dt.yaml): continuous RTG embeddings, token order (rtg, state, action)
+        self.VARIANT = 1 if bool(m.get("il", False)) else (2 if bool(m.get("trajeglish", False)) else
+                                                            (3 if bool(m.get("decision_transformer", False)) else 0))
         self.L = self.A * self.T * self.K         # decoder tokens
         self.P = int(w.max_num_road_polylines)
         self.NP = int(w.max_num_road_pts_per_polyline)

@@ -83,7 +83,10 @@ def param_table(dims: Dims):
     linear("encoder.embed_state_goal", 2 * D, D)
     t.append(("encoder.embed_action.weight", (dims.V, D), "normal", 0.02))
     for c in ("goal", "veh", "road"):
-        t.append((f"encoder.embed_rtg_{c}.weight", (dims.R, D), "normal", 0.02))
+        if getattr(dims, "VARIANT", 0) == 3:      # decision transformer: nn.Linear(1, D) per component (encoder.py:27-30)
+            linear(f"encoder.embed_rtg_{c}", 1, D)
+        else:
+            t.append((f"encoder.embed_rtg_{c}.weight", (dims.R, D), "normal", 0.02))
     linear("encoder.embed_rtg", D * dims.C, D)
     t.append(("encoder.embed_timestep.weight", (dims.MAXT, D), "normal", 0.02))
     t.append(("encoder.embed_agent_id.weight", (dims.A, D), "normal", 0.02))

@@ -34,7 +34,9 @@ typedef struct ihipStream_t* hipStream_t;
 typedef struct ctrlsim_dims {
   int A, T, P, NP, D, H, F, V, R, C, NE, ND, MAXT;
   int variant; /* 0 CtRL-Sim (state, rtg, action tokens; cfgs/model/ctrl_sim.yaml), 1 IL (state, action; il.yaml),
-                  2 Trajeglish (action tokens only; trajeglish.yaml) — modules/encoder.py:141-152, decoder.py:29-64 */
+                  2 Trajeglish (action tokens only; trajeglish.yaml), 3 Decision Transformer (continuous RTGs: ctx.rtg_bin
+                  holds float bits; token order rtg, state, action; dt.yaml) — modules/encoder.py:27-34,116-152,
+                  decoder.py:29-64 */
 } ctrlsim_dims;
 
 /* Agent-local context tensors of B contexts (outputs of ctrlsim_build_context, inputs of the forward). */
@@ -108,9 +110,9 @@ int64_t ctrlsim_forward_workspace_bytes(const ctrlsim_dims* dims, int B, int Tq)
 /* pass 1: rtg_logits [B,A,R*C] of the current-timestep state tokens; caches per-layer K/V in `workspace`. */
 int ctrlsim_dt_forward_pass1(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* ctx, void* workspace,
                              float* rtg_logits, float* dbg_seg_emb /*nullable [B,P,D]*/, hipStream_t stream);
-/* The baselines of cfgs/model/{il,trajeglish}.yaml (dims.variant 1 / 2) have no RTG tokens and one forward per step
+/* The baselines of cfgs/model/{il,trajeglish,dt}.yaml (dims.variant 1 / 2 / 3) have no RTG head and one forward per step
  * (policies with predict_rtgs = False, autoregressive_policy.py:189,208-240): action logits [B,A,V] of the current step from
- * the state tokens (IL) / action tokens (Trajeglish), decoder.py:58-64.  ctrlsim_dt_forward_pass1 / _pass2 / _cached refuse
+ * the state tokens (IL, DT) / action tokens (Trajeglish), decoder.py:55-64.  ctrlsim_dt_forward_pass1 / _pass2 / _cached refuse
  * these models and this call refuses the CtRL-Sim model. */
 int ctrlsim_dt_forward_actions(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* ctx, void* workspace,
                                float* act_logits, hipStream_t stream);

@@ -711,25 +711,30 @@ def gen_variants():
     ref_shims.install()
     from utils.train_utils import get_causal_mask
     out = {}
-    for name, K in (("il", 2), ("trajeglish", 1)):
+    for name, K in (("il", 2), ("trajeglish", 1), ("decision_transformer", 3)):
         # masks (small, full array) and the closed form at the real size
         cfg_t = variant_cfg(name, **TINY)
         out[f"{name}_mask_tiny"] = (get_causal_mask(cfg_t, 4, K) == 0).numpy()
+        sidx = 1 if name == "decision_transformer" else 0
         # logits: tiny config in full, loop config at the last filled step
         for tag, over in (("tiny", TINY), ("loop", LOOP)):
             cfg = variant_cfg(name, **over)
             d = spec.Dims(cfg)
             w = weights.generate(d, 0)
             ref = ref_shims.build_reference_model(cfg, variant_weights(cfg, w))
-            cm = model_oracle.causal_mask_closed_form(d.A, d.T, K)
+            cm = model_oracle.causal_mask_closed_form(d.A, d.T, K, sidx)
             assert bool(((ref.decoder.causal_mask == 0) == cm).all()), "closed-form mask != get_causal_mask"
             for seed, t_fill in ((1, d.T), (2, max(1, d.T // 2))):
                 inp = synth_inputs.random_context(d, seed, B=1, t_fill=t_fill, n_agents=d.A - 1, n_polys=d.P - 1)
+                if name == "decision_transformer":                    # continuous, normalised RTGs (autoregressive_policy.py:73-78)
+                    inp["rtgs"] = synth_inputs.dt_rtgs(inp["rtgs"], seed)
                 r = ref(synth_inputs.to_motion_data(inp), eval=True)
                 assert set(r.keys()) == {"action_preds"}
                 ap = r["action_preds"].detach().numpy()
                 out[f"{name}_{tag}_s{seed}_action"] = ap if tag == "tiny" else ap[0, :, t_fill - 1]
                 out[f"{name}_{tag}_s{seed}_recipe"] = np.array([seed, t_fill, d.A - 1, d.P - 1])
+        if name == "decision_transformer":
+            continue                                                  # its policy needs real-time rewards: see gen_dt_loop
         # closed loop, 14 steps (window T = 8 slides from step 8 on)
         cfg = variant_cfg(name, **LOOP)
         d = spec.Dims(cfg)

@@ -34,9 +34,10 @@ def as_torch_weights(w):
     return {k: (torch.from_numpy(v) if not torch.is_tensor(v) else v) for k, v in w.items()}
 
 
-def causal_mask_closed_form(A: int, T: int, K: int = 3) -> torch.Tensor:
+def causal_mask_closed_form(A: int, T: int, K: int = 3, state_index: int = 0) -> torch.Tensor:
     """Boolean [L,L], True = visible (state_index 0, no attend_own_return_action); K = token types per agent-step:
-    3 CtRL-Sim, 2 IL, 1 Trajeglish (utils/train_utils.py:83-113 with num_types = K)."""
+    3 CtRL-Sim, 2 IL, 1 Trajeglish (utils/train_utils.py:83-113 with num_types = K); state_index 1 = Decision Transformer
+    (token order rtg, state, action)."""
     L = A * T * K
     i = torch.arange(L)
     t = i // (A * K)
@@ -45,7 +46,7 @@ def causal_mask_closed_form(A: int, T: int, K: int = 3) -> torch.Tensor:
     ti, tj = t[:, None], t[None, :]
     ai, aj = a[:, None], a[None, :]
     ki, kj = k[:, None], k[None, :]
-    return (tj < ti) | ((tj == ti) & (((aj == ai) & (kj <= ki)) | (kj == 0)))
+    return (tj < ti) | ((tj == ti) & (((aj == ai) & (kj <= ki)) | (kj == state_index)))
 
 
 def _linear(x, w, name):
@@ -116,7 +117,7 @@ def embed_tokens(w, data, dims):
     goals = data["goals"].unsqueeze(2).expand(B, A, T, -1).transpose(1, 2)[..., :dims.GOAL]
     states = torch.cat([ag[..., :-1].transpose(1, 2), types], -1).float()   # [B,T,A,12]
     actions = data["actions"].transpose(1, 2).long()                  # [B,T,A]
-    rtgs = data["rtgs"].transpose(1, 2).long()                        # [B,T,A,3]
+    rtgs = data["rtgs"].transpose(1, 2).long()                        # [B,T,A,3] (bins; continuous values for the DT variant)
     ts = data["timesteps"].transpose(1, 2).reshape(B, T, A).long()
     ids = torch.arange(A).view(1, 1, A).expand(B, T, A)
 
@@ -126,10 +127,15 @@ def embed_tokens(w, data, dims):
     g_emb = _mlp(goals.float(), w, "encoder.embed_goal")
     s_emb = _linear(torch.cat([s_emb, g_emb], -1), w, "encoder.embed_state_goal") + ts_emb + id_emb
     a_emb = F.embedding(actions, w["encoder.embed_action.weight"]) + ts_emb + id_emb
-    r_emb = torch.cat([
-        F.embedding(rtgs[..., 0], w["encoder.embed_rtg_goal.weight"]),
-        F.embedding(rtgs[..., 1], w["encoder.embed_rtg_veh.weight"]),
-        F.embedding(rtgs[..., 2], w["encoder.embed_rtg_road.weight"])], -1)
+    if getattr(dims, "VARIANT", 0) == 3:                              # decision transformer: nn.Linear(1, D) on continuous RTGs
+        rc = data["rtgs"].transpose(1, 2).float()                     # encoder.py:119-123
+        r_emb = torch.cat([_linear(rc[..., c:c + 1], w, f"encoder.embed_rtg_{nm}")
+                           for c, nm in enumerate(("goal", "veh", "road"))], -1)
+    else:
+        r_emb = torch.cat([
+            F.embedding(rtgs[..., 0], w["encoder.embed_rtg_goal.weight"]),
+            F.embedding(rtgs[..., 1], w["encoder.embed_rtg_veh.weight"]),
+            F.embedding(rtgs[..., 2], w["encoder.embed_rtg_road.weight"])], -1)
     r_emb = _linear(r_emb, w, "encoder.embed_rtg") + ts_emb + id_emb
     ex = exist.float()
     s_emb, a_emb, r_emb = s_emb * ex, a_emb * ex, r_emb * ex
@@ -140,6 +146,8 @@ def embed_tokens(w, data, dims):
         stacked = torch.stack([s_emb, a_emb], dim=3).reshape(B, T * A * 2, -1)
     elif variant == 2:                                                # trajeglish: action tokens only  encoder.py:141-142
         stacked = a_emb.reshape(B, T * A, -1)
+    elif variant == 3:                                                # decision transformer: (rtg, state, action)  encoder.py:137-140
+        stacked = torch.stack([r_emb, s_emb, a_emb], dim=3).reshape(B, T * A * 3, -1)
     else:
         stacked = torch.stack([s_emb, r_emb, a_emb], dim=3).reshape(B, T * A * 3, -1)
     stacked = _ln(stacked, w, "encoder.embed_ln")
@@ -176,17 +184,17 @@ def forward(w, data, dims, return_hidden=False):
         mem = _enc_layer(mem, w, f"encoder.transformer_encoder.layers.{i}", H, pad)
     B, A, T = data["agent_states"].shape[:3]
     variant = getattr(dims, "VARIANT", 0)
-    K = {0: 3, 1: 2, 2: 1}[variant]                                   # decoder.py:29-35
-    key = (A, T, K)
+    K = {0: 3, 1: 2, 2: 1, 3: 3}[variant]                             # decoder.py:29-35
+    key = (A, T, K, variant == 3)
     if key not in _MASK_CACHE:
-        _MASK_CACHE[key] = causal_mask_closed_form(A, T, K)
+        _MASK_CACHE[key] = causal_mask_closed_form(A, T, K, 1 if variant == 3 else 0)
     tgt_mask = _MASK_CACHE[key]
     x = stacked
     for i in range(dims.ND):
         x = _dec_layer(x, mem, w, f"decoder.transformer_decoder.layers.{i}", H, tgt_mask, pad)
-    if variant:                                                       # decoder.py:58-64: actions from token type 0, no other head
-        out = x.view(B, T * A, K, -1)
-        act = _mlp(out[:, :, 0], w, "decoder.predict_action").view(B, T, A, -1).permute(0, 2, 1, 3)
+    if variant:                                                       # decoder.py:55-64: one head; DT reads token 1 (its state
+        out = x.view(B, T * A, K, -1)                                 # token), IL / Trajeglish token 0
+        act = _mlp(out[:, :, 1 if variant == 3 else 0], w, "decoder.predict_action").view(B, T, A, -1).permute(0, 2, 1, 3)
         return {"action_preds": act}
     out = x.view(B, T * A, 3, -1)
     act = _mlp(out[:, :, 1], w, "decoder.predict_action").view(B, T, A, -1).permute(0, 2, 1, 3)

@@ -102,3 +102,8 @@ def synth_policy_buffers(scn, cfg, seed):
     timesteps = np.repeat(np.arange(steps)[None, :, None], N, 0).astype(np.float64)
     return dict(states=states, types=scn.types.copy(), actions=actions, rtgs=rtgs, goals=goals,
                 timesteps=timesteps)
+
+
+def dt_rtgs(rtg_bins, seed):
+    """Continuous RTGs in [0, 1] (the Decision-Transformer variant) of the shape of the synthetic bins."""
+    return np.random.RandomState(1000 + seed).uniform(0.0, 1.0, np.shape(rtg_bins))

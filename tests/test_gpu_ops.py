@@ -172,6 +172,27 @@ def test_attention_mask_variants_of_the_baselines(A, T, mode):
     assert (Oc.double() - O[:, pos.long()].double()).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("A,T", [(24, 32), (6, 8), (24, 7), (5, 13)])
+def test_attention_mask_of_the_decision_transformer(A, T):
+    """Mode 4: get_causal_mask with state_index 1 for the token order (rtg, state, action), evaluated on tokens stored in the
+    slots (state, rtg, action) — i.e. the reference's mask with rows and columns permuted accordingly."""
+    B, H = 2, 8
+    L = A * T * 3
+    g = torch.Generator().manual_seed(A * T + 4)
+    qkv = torch.randn(B, L, 768, generator=g).to(DEV)
+    O = torch.zeros(B, L, 256, device=DEV)
+    p = _lib.ptr
+    _lib.check(_lib.lib().ctrlsim_attention(4, p(qkv), 768, L * 768, qkv.data_ptr() + 256 * 4, qkv.data_ptr() + 512 * 4, 768,
+                                            L * 768, p(O), 256, L * 256, None, None, B, L, L, A, _lib.stream_ptr()))
+    # position of slot (state, rtg, action) token in the reference's (rtg, state, action) sequence
+    perm = torch.tensor([(i // 3) * 3 + (1, 0, 2)[i % 3] for i in range(L)], device=DEV)
+    vis_ref = mo.causal_mask_closed_form(A, T, 3, 1).to(DEV)
+    vis = vis_ref[perm][:, perm][None, None]
+    q, k, v = [qkv[..., i * 256:(i + 1) * 256].view(B, L, H, 32).transpose(1, 2) for i in range(3)]
+    ref = _attn_ref(q, k, v, vis).transpose(1, 2).reshape(B, L, 256)
+    assert (O.double() - ref).abs().max().item() < 2e-5
+
+
 @pytest.mark.parametrize("Lq,Lk", [(224, 224), (2304, 224), (10, 10), (24, 224), (130, 67)])
 def test_attention_key_padding(Lq, Lk, attn_impl):
     B, H = 3, 8

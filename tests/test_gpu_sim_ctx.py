@@ -452,3 +452,25 @@ def test_kinematic_integrator_mode_matches_oracle():
             got = hist[0, i, t + 1]
             np.testing.assert_allclose([got[0], got[1], got[4]], [st[0], st[1], st[2]], atol=1e-4, rtol=0)
             np.testing.assert_allclose(np.hypot(got[2], got[3]), abs(st[3]), atol=1e-4, rtol=0)
+
+
+def test_decision_transformer_logits_match_reference_fixture():
+    """cfgs/model/dt.yaml at the model level: continuous RTG embeddings (float bits in ctx.rtg_bin, Linear(1, D) folded into one
+    row per component), mask mode 4, action head on the state tokens — vs the reference modules' logits."""
+    from ctrlsim_amd.engine import HipModel, ctx_from_reference_layout
+    g = golden("variants")
+    cfg = cfg_of("loop", variant="decision_transformer")
+    d = spec.Dims(cfg)
+    assert d.VARIANT == 3
+    model = HipModel(cfg, weights.generate(d, 0), DEV)
+    lib, p, st = _lib.lib(), _lib.ptr, _lib.stream_ptr()
+    ws = torch.empty(model.workspace_bytes(1, d.T), dtype=torch.uint8, device=DEV)
+    for seed in (1, 2):
+        _, t_fill, n_ag, n_pl = [int(v) for v in g[f"decision_transformer_loop_s{seed}_recipe"]]
+        inp = synth_inputs.random_context(d, seed, B=1, t_fill=t_fill, n_agents=n_ag, n_polys=n_pl)
+        inp["rtgs"] = synth_inputs.dt_rtgs(inp["rtgs"], seed)
+        cb = ctx_from_reference_layout(d, inp, t_fill, DEV)
+        logits = torch.empty(1, d.A, d.V, device=DEV)
+        _lib.check(lib.ctrlsim_dt_forward_actions(model.handle, 1, t_fill, C.byref(cb.struct), p(ws), p(logits), st), "actions")
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(logits[0].cpu().numpy(), g[f"decision_transformer_loop_s{seed}_action"], atol=1e-4, rtol=0)

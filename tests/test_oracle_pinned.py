@@ -298,25 +298,30 @@ def test_rollout_oracle_matches_reference_planner_vs_adversary(tag):
     assert g[f"{tag}_margins"].min() > 1e-4
 
 
-@pytest.mark.parametrize("name,K", [("il", 2), ("trajeglish", 1)])
+@pytest.mark.parametrize("name,K", [("il", 2), ("trajeglish", 1), ("decision_transformer", 3)])
 def test_variant_oracles_match_reference(name, K):
     """cfgs/model/{il,trajeglish}.yaml: token stacks of 2 / 1 types, their causal masks, action logits from token type 0, and
     the single-forward policy — model oracle vs the reference modules' logits, rollout oracle vs the unmodified reference policy
     (tests/golden/variants.npz)."""
     g = golden("variants")
-    assert np.array_equal(mo.causal_mask_closed_form(4, 4, K).numpy(), g[f"{name}_mask_tiny"])
+    dt = name == "decision_transformer"
+    assert np.array_equal(mo.causal_mask_closed_form(4, 4, K, 1 if dt else 0).numpy(), g[f"{name}_mask_tiny"])
     for tag in ("tiny", "loop"):
         cfg = cfg_of(tag, variant=name)
         d = spec.Dims(cfg)
-        assert d.VARIANT == {"il": 1, "trajeglish": 2}[name]
+        assert d.VARIANT == {"il": 1, "trajeglish": 2, "decision_transformer": 3}[name]
         tw = mo.as_torch_weights(weights.generate(d, 0))
         for seed in (1, 2):
             _, t_fill, n_ag, n_pl = [int(v) for v in g[f"{name}_{tag}_s{seed}_recipe"]]
             inp = synth_inputs.random_context(d, seed, B=1, t_fill=t_fill, n_agents=n_ag, n_polys=n_pl)
+            if dt:
+                inp["rtgs"] = synth_inputs.dt_rtgs(inp["rtgs"], seed)
             with torch.no_grad():
                 out = mo.forward(tw, synth_inputs.to_torch(inp), d)
             got = out["action_preds"].numpy() if tag == "tiny" else out["action_preds"][0, :, t_fill - 1].numpy()
             np.testing.assert_allclose(got, g[f"{name}_{tag}_s{seed}_action"], atol=2e-5, rtol=0)
+    if dt:
+        return                                            # its closed loop needs real-time rewards (separate fixture)
     rc = g[f"{name}_loop_recipe"]
     cfg = cfg_of("loop", variant=name)
     d = spec.Dims(cfg)
