@@ -135,8 +135,13 @@ class RolloutEngine:
         w = self.w
         self.disc6 = (C.c_double * 6)(w.min_accel, w.max_accel, w.min_steer, w.max_steer, w.accel_discretization,
                                       w.steer_discretization)
-        self.zero4 = torch.tensor([ZERO_ACTION_TOKEN, *ZERO_RTG_BINS], dtype=torch.int32)  # host copy for ctypes
-        self._zero4 = (C.c_int * 4)(ZERO_ACTION_TOKEN, *ZERO_RTG_BINS)
+        # "not yet written" rows: zero action, zero RTG -> bins (0, 35, 35); the Decision-Transformer variant carries continuous,
+        # normalised RTGs as float bits: zero -> (0, 0.1, 0.1) (autoregressive_policy.py:73-78)
+        self.zero_rtg = ZERO_RTG_BINS
+        if self.dims.VARIANT == 3:
+            from .rewards import normalize_rtgs
+            self.zero_rtg = tuple(int(v) for v in normalize_rtgs(np.zeros(3), self.w).astype(np.float32).view(np.int32))
+        self._zero4 = (C.c_int * 4)(ZERO_ACTION_TOKEN, *self.zero_rtg)
         self.ctx = CtxBuffers(self.dims, self.max_ctx, self.device)
         self.ws = torch.empty(self.model.workspace_bytes(self.max_ctx, self.dims.T), dtype=torch.uint8, device=self.device)
         d = self.dims
@@ -207,7 +212,7 @@ class RolloutEngine:
         self.hist_states.zero_()
         self.coll.zero_()
         self.hist_tok.fill_(ZERO_ACTION_TOKEN)
-        self.hist_rtg.copy_(torch.tensor(ZERO_RTG_BINS, dtype=torch.int32, device=self.device).expand_as(self.hist_rtg))
+        self.hist_rtg.copy_(torch.tensor(self.zero_rtg, dtype=torch.int32, device=self.device).expand_as(self.hist_rtg))
         self.persist.zero_()
         self.applied.zero_()
         p = _lib.ptr
@@ -367,6 +372,9 @@ class RolloutEngine:
     def run(self, steps=None, noise_fn=None):
         """Roll all loaded scenarios `steps` steps.  noise_fn(t) -> (noise_rtg, noise_act) or None."""
         steps = self.steps if steps is None else steps
+        if self.dims.VARIANT == 3:
+            raise NotImplementedError("the Decision-Transformer policy conditions on real-time rewards computed by the rollout "
+                                      "driver: run it through PolicyEvaluator (hist_rtg is fed per step), not RolloutEngine.run")
         start = 0
         if self.use_cache and noise_fn is None and steps > 0:
             start = min(self.dims.T, steps)

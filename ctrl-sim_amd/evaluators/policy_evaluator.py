@@ -84,7 +84,21 @@ class PolicyEvaluator:
             if t > 0 and d["existence"][-1] == 0:
                 ex = 0
             d["existence"].append(ex)
+            if self.policy.real_time_rewards:                      # policy_evaluator.py:122-147: the RTG the policy is fed
+                key = self.policy.key_dict["rtgs"]
+                if t == 0:
+                    if not (self.policy.max_return or self.policy.min_return):
+                        raise NotImplementedError("initial RTGs from the preprocessed dataset (preproc_data['rtgs']) need logged "
+                                                  "rewards; use max_return / min_return as cfgs/policy/dt.yaml does")
+                    rtg = np.array([10.0, 90.0, 90.0])             # the maximum achievable return
+                    if self.policy.min_return and not self.policy.max_return and v in self.vehicles_to_evaluate:
+                        rtg = np.array([0.0, -10.0, -10.0])        # evaluated vehicles: the minimum possible return
+                    d[key].append(rtg)
+                else:
+                    d[key].append(d[key][-1] - d["dense_reward"][-1])
             d["reward"].append(self.compute_reward(veh, goal_dict[v], goal_norm[v], d))
+        if self.policy.real_time_rewards:
+            return self.compute_dense_reward(t, vdd)
         ids = list(vdd.keys())
         pos = np.array([[vdd[v]["position"][t]["x"], vdd[v]["position"][t]["y"]] for v in ids])
         gpos = np.array([[vdd[v]["gt_position"][t]["x"], vdd[v]["gt_position"][t]["y"]] for v in ids])
@@ -96,6 +110,35 @@ class PolicyEvaluator:
             vdd[v]["nearest_dist"].append(nd[i])
             vdd[v]["gt_nearest_dist"].append(gnd[i])
         return vdd
+
+    # ---- evaluators/evaluator.py:106-140
+    def compute_dense_reward(self, t, vdd):
+        from ..rewards import dense_reward, nearest_vehicle_distance_raw
+        ids = list(vdd.keys())
+        xy = np.array([[vdd[v]["position"][t]["x"], vdd[v]["position"][t]["y"]] for v in ids])
+        gxy = np.array([[vdd[v]["gt_position"][t]["x"], vdd[v]["gt_position"][t]["y"]] for v in ids])
+        ex = np.array([vdd[v]["existence"][t] for v in ids], float)
+        step0 = np.array([vdd[v]["reward"][0] for v in ids], float)   # the reference indexes its reward stack at step 0 (:137)
+        dense, nearest = dense_reward(xy, ex, step0, self.road_edge_polylines, self.cfg_rl_waymo)
+        gt_nearest = nearest_vehicle_distance_raw(gxy, ex) * ex
+        scale = self.cfg_rl_waymo.max_veh_veh_distance                 # as written there (:126-127): metres times 15
+        for i, v in enumerate(ids):
+            vdd[v]["nearest_dist"].append(nearest[i] * scale)
+            vdd[v]["gt_nearest_dist"].append(gt_nearest[i] * scale)
+            vdd[v]["dense_reward"].append(dense[i])
+        return vdd
+
+    @staticmethod
+    def extract_road_edge_polylines(scn):
+        """evaluators/evaluator.py:143-157 on the scenario arrays: the road_edge polylines as point lists."""
+        polys = getattr(scn, "road_edge_polylines", None)
+        if polys is not None:
+            return polys
+        out = []
+        for pl, ty in zip(scn.road_points, scn.road_types):
+            if int(np.argmax(ty)) == 3:
+                out.append(np.asarray(pl[:int(pl[:, 2].sum()), :2], np.float64))
+        return out
 
     # ---- evaluators/evaluator.py:160-193
     def apply_gt_action(self, veh, t, gt_data_dict, vdd):
@@ -169,6 +212,7 @@ class PolicyEvaluator:
             if not self.vehicles_to_evaluate:
                 continue
             n_done += 1
+            self.road_edge_polylines = self.extract_road_edge_polylines(scn)
             preproc_data = {"road_points": scn.road_points.astype(np.float64), "road_types": scn.road_types.copy()}
             vdd, goal_dict, goal_norm = {}, {}, {}
             for veh in vehicles:

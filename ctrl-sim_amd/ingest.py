@@ -148,6 +148,7 @@ def load_nocturne_json(src, index=0, max_pts=100, start_time=0, allow_non_vehicl
                    speed=col("speed"), goal_pos=col("goal").reshape(N, 2), goal_heading=col("goal_heading"),
                    goal_speed=col("goal_speed"), types=types, road_points=road_points.astype(f32), road_types=road_types,
                    edge_segments=edge_segments, eval_order=eval_order)
+    scn.road_edge_polylines = edge_polys                     # unchunked, for the real-time road-edge distance reward
     info = dict(ids=np.array(ids, np.int64), moving=np.array(moving, bool), gt_data_dict=gt, road_data=road_data,
                 road_edge_polylines=edge_polys, name=data.get("name", ""))
     return scn, info

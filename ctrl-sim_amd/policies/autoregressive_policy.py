@@ -37,9 +37,12 @@ class AutoregressivePolicy(Policy):
         if variant == 0 and (not (use_rtg and predict_rtgs and discretize_rtgs) or real_time_rewards):
             raise NotImplementedError("the CtRL-Sim model runs as in cfgs/policy/ctrl_sim.yaml: use_rtg, predict_rtgs, "
                                       "discretize_rtgs, no real_time_rewards")
-        if variant != 0 and (use_rtg or predict_rtgs or real_time_rewards):
+        if variant in (1, 2) and (use_rtg or predict_rtgs or real_time_rewards):
             raise NotImplementedError("the IL / Trajeglish models have no RTG tokens (cfgs/policy/{il,trajeglish}.yaml: "
                                       "use_rtg = predict_rtgs = False)")
+        if variant == 3 and not (use_rtg and real_time_rewards and not predict_rtgs and not discretize_rtgs):
+            raise NotImplementedError("the Decision-Transformer model runs as in cfgs/policy/dt.yaml: use_rtg, real_time_rewards, "
+                                      "continuous (not discretised, not predicted) RTGs")
         self._session = None
         self.scenario_index = 0
 
@@ -90,7 +93,12 @@ class AutoregressivePolicy(Policy):
         hs[0, :, :self.steps] = self.states
         eng.hist_states.copy_(torch.from_numpy(hs).to(dev))
         eng.hist_tok.copy_(torch.from_numpy(dz.discretize_actions(self.actions, w).astype(np.int32)[None]).to(dev))
-        eng.hist_rtg.copy_(torch.from_numpy(dz.discretize_rtgs_from_raw(self.rtgs, w).astype(np.int32)[None]).to(dev))
+        if self.model.dims.VARIANT == 3:                 # continuous RTGs, clip-normalised (get_data:73-78), as float bits
+            from ..rewards import normalize_rtgs
+            rt = np.ascontiguousarray(normalize_rtgs(self.rtgs, w), np.float32).view(np.int32)
+            eng.hist_rtg.copy_(torch.from_numpy(rt[None]).to(dev))
+        else:
+            eng.hist_rtg.copy_(torch.from_numpy(dz.discretize_rtgs_from_raw(self.rtgs, w).astype(np.int32)[None]).to(dev))
         eng.goals.copy_(torch.from_numpy(self.goals[:, 0][None]).to(dev))
         eng.policy_step(t)
         torch.cuda.synchronize(dev)

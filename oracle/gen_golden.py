@@ -752,10 +752,154 @@ def gen_variants():
     save("variants", **out)
 
 
+# --------------------------------------------------------------------------------------------- real-time (dense) rewards
+def ref_dense_reward(dset, w, xy, exist, rewards, polys):
+    """evaluators/evaluator.py:106-140, line by line, on the reference's dataset methods.  rewards [N, steps so far, 8].
+    -> (dense_reward rows [N,3] as appended there, nearest_dist metric values [N], signed-edge reward [N,1])."""
+    processed = rewards * exist[:, None, None]
+    ag = xy[:, None, :].copy()
+    edge = dset.compute_dist_to_nearest_road_edge_rewards(ag, polys) * exist[:, None]
+    ag = np.concatenate([xy, exist[:, None]], 1)[:, None, :].copy()
+    veh_raw = dset.compute_dist_to_nearest_vehicle_rewards(ag, normalize=False) * exist[:, None]
+    nearest = veh_raw[:, 0] * w.max_veh_veh_distance
+    veh = np.clip(veh_raw, 0.0, w.max_veh_veh_distance) / w.max_veh_veh_distance
+    allr = dset.compute_rewards(ag, processed, edge, veh)
+    allr = np.concatenate([allr[:, :, :1], allr[:, :, 3:]], -1)
+    return allr[:, 0], nearest, edge
+
+
+def gen_dense_reward():
+    """The reference's own reward functions, called exactly as Evaluator.compute_dense_reward calls them
+    (evaluators/evaluator.py:106-140), on random scenes: positions, existence, reward rows of several steps, road-edge polylines."""
+    cfg = spec.make_cfg()
+    dset = ref_shims.build_reference_dataset(cfg)
+    w = cfg.dataset.waymo
+    out = {}
+    for case in range(4):
+        rs = np.random.RandomState(40 + case)
+        N, T = (1, 2) if case == 3 else (9, 3 + case)
+        xy = rs.uniform(-30, 30, (N, 2))
+        exist = (rs.uniform(size=N) > 0.25).astype(float)
+        if case == 2:
+            exist[:] = 0
+            exist[0] = 1                                              # a single existing vehicle: nearest distance undefined
+        rewards = rs.uniform(0, 1, (N, T, 8))
+        rewards[..., [0, 1, 2, 6, 7]] = (rewards[..., [0, 1, 2, 6, 7]] > 0.6).astype(float)
+        polys = []
+        for k in range(3):
+            n = [12, 2, 30][k]
+            ang = np.sort(rs.uniform(0, 2 * np.pi, n))
+            rad = rs.uniform(15, 25, n)
+            p = np.stack([rad * np.cos(ang), rad * np.sin(ang)], 1) + rs.uniform(-10, 10, 2)
+            if k == 2:
+                p = np.concatenate([p, p[:1] + 0.1])                  # closed ring (cyclic branch)
+            polys.append(p)
+        allr, nearest, edge = ref_dense_reward(dset, w, xy, exist, rewards, polys)
+        out[f"c{case}_xy"], out[f"c{case}_exist"], out[f"c{case}_rewards"] = xy, exist, rewards
+        out[f"c{case}_npoly"] = np.array(len(polys))
+        for k, p in enumerate(polys):
+            out[f"c{case}_poly{k}"] = p
+        out[f"c{case}_dense"] = allr
+        out[f"c{case}_nearest_metric"] = nearest
+        out[f"c{case}_edge_signed"] = edge[:, 0]
+    save("dense_reward", **out)
+
+
+def ref_closed_loop_dt(cfg, w, scn, steps, seed):
+    """The Decision-Transformer policy of cfgs/policy/dt.yaml (real_time_rewards, max_return, continuous RTGs) in the loop of
+    policy_evaluator.py:514-557 with its RTG bookkeeping (:122-153): the UNMODIFIED reference policy and model, the reference's
+    own reward functions, the real FreeCar/Box2D; the per-vehicle compute_reward rows (utils/sim.py:83-141) are restated (only
+    their goal / collision flags enter)."""
+    ref_shims.install()
+    from policies.autoregressive_policy import AutoregressivePolicy
+    model = ref_shims.build_reference_model(cfg, w)
+    dset = ref_shims.build_reference_dataset(cfg)
+    wcfg = cfg.dataset.waymo
+    pol = AutoregressivePolicy(cfg=cfg, model_path="", model=model, use_rtg=True, predict_rtgs=False, discretize_rtgs=False,
+                               real_time_rewards=True, privileged_return=False, max_return=True, min_return=False,
+                               key_dict={"next_acceleration": "next_acceleration", "next_steering": "next_steering", "rtgs": "rtgs"},
+                               tilt_dict={"tilt": False, "goal_tilt": None, "veh_veh_tilt": None, "veh_edge_tilt": None},
+                               name="dt", action_temperature=1.0, nucleus_sampling=False, nucleus_threshold=0.8)
+    N = scn.N
+    sim = RefSim(scn.length, scn.width, scn.x, scn.y, scn.heading, scn.speed, scn.edge_segments)
+    vehs = [_FakeVeh(sim, i) for i in range(N)]
+    polys = [np.asarray(pl[:int(pl[:, 2].sum()), :2], np.float64) for pl, ty in zip(scn.road_points, scn.road_types)
+             if int(np.argmax(ty)) == 3]
+    vdd = {i: {"position": [], "velocity": [], "heading": [], "existence": [], "acceleration": [], "steering": [], "timestep": [],
+               "rtgs": [], "reward": [], "dense_reward": [], "next_acceleration": 0., "next_steering": 0.,
+               "goal_position": {"x": scn.goal_pos[i, 0], "y": scn.goal_pos[i, 1]}, "goal_heading": scn.goal_heading[i],
+               "goal_speed": scn.goal_speed[i], "width": scn.width[i], "length": scn.length[i], "type": "vehicle"} for i in range(N)}
+    gt = {i: {"traj": np.ones((91, 6))} for i in range(N)}
+    preproc = {"road_points": scn.road_points.astype(np.float64), "road_types": scn.road_types.copy()}
+    to_eval = list(range(N))
+    patch = _NoisePatch(seed, scn.index)
+    orig = torch.multinomial
+    torch.multinomial = patch
+    states = np.zeros((N, steps + 1, 8)); coll = np.zeros((N, steps + 1, 2), np.uint8)
+    applied = np.zeros((N, steps, 2)); rtg_raw = np.zeros((N, steps, 3)); dense_log = np.zeros((N, steps, 3))
+
+    def update(t):
+        st, cv, ce = sim.state()
+        for i in range(N):
+            d = vdd[i]
+            d["position"].append({"x": st[i, 0], "y": st[i, 1]}); d["velocity"].append({"x": st[i, 4], "y": st[i, 5]})
+            d["heading"].append(st[i, 2]); d["timestep"].append(t); d["existence"].append(1.0)
+            states[i, t] = [st[i, 0], st[i, 1], st[i, 4], st[i, 5], st[i, 2], scn.length[i], scn.width[i], 1.0]
+            if t == 0:                                                   # policy_evaluator.py:123-144 with max_return
+                d["rtgs"].append(np.array([10.0, 90.0, 90.0]))
+            else:
+                d["rtgs"].append(d["rtgs"][-1] - d["dense_reward"][-1])
+            reached = float(True) if (d["reward"] and d["reward"][-1][0]) else \
+                float(np.linalg.norm(scn.goal_pos[i].astype(np.float64) - st[i, :2]) < 1.0)
+            d["reward"].append([reached, 0.0, 0.0, 0.0, 0.0, 0.0, float(cv[i]), float(ce[i])])
+        coll[:, t, 0], coll[:, t, 1] = cv, ce
+        xy = np.array([[vdd[i]["position"][t]["x"], vdd[i]["position"][t]["y"]] for i in range(N)], np.float64)
+        rew = np.array([vdd[i]["reward"] for i in range(N)], np.float64)
+        dense, _, _ = ref_dense_reward(dset, wcfg, xy, np.ones(N), rew, polys)
+        for i in range(N):
+            vdd[i]["dense_reward"].append(dense[i])
+
+    try:
+        pol.reset(vdd)
+        for t in range(steps):
+            patch.t = t
+            update(t)
+            pol.update_state(vdd, to_eval, t)
+            vdd = pol.predict(vdd, gt, preproc, dset, to_eval, t)
+            for i in range(N):
+                _, act = pol.act(vehs[i], t, vdd)
+                vdd[i]["acceleration"].append(act[0]); vdd[i]["steering"].append(act[1])
+                applied[i, t] = act
+                rtg_raw[i, t] = vdd[i]["rtgs"][t]; dense_log[i, t] = vdd[i]["dense_reward"][t]
+            sim.step(0.1)
+        update(steps)
+    finally:
+        torch.multinomial = orig
+        sim.close()
+    return dict(tokens=dset.discretize_actions(applied.copy()), states=states, coll=coll, actions=applied, rtgs=rtg_raw,
+                dense=dense_log, margins=np.array(patch.log))
+
+
+def gen_dt_loop():
+    cfg = variant_cfg("decision_transformer", **LOOP)
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    for idx in range(60):
+        scn = scenarios.make_scenario(19, idx, n_agents=9, n_polylines=15, n_points=d.NP, extent=40.0)
+        r = ref_closed_loop_dt(cfg, w, scn, 14, seed=8)
+        if r["margins"].min() > 2e-4:
+            break
+    print("dt scene", idx, "min race margin", r["margins"].min(), "veh-veh flags", r["coll"][..., 0].sum(), "rtg[0] range",
+          r["rtgs"][..., 0].min(), r["rtgs"][..., 0].max(), "rtg[1] range", r["rtgs"][..., 1].min(), r["rtgs"][..., 1].max())
+    out = {f"loop_{k}": v for k, v in r.items()}
+    out["loop_recipe"] = np.array([19, idx, 9, 15, 40.0, 8])
+    save("dt_loop", **out)
+
+
 ALL = dict(model=gen_model, features=gen_features, sampling=gen_sampling, physics=gen_physics,
            collision=gen_collision, closed_loop=gen_closed_loop, bicycle=gen_bicycle, contacts=gen_contacts,
            planner_adversary=gen_planner_adversary, ingest=gen_ingest,
-           variants=gen_variants)
+           variants=gen_variants, dense_reward=gen_dense_reward, dt_loop=gen_dt_loop)
 
 if __name__ == "__main__":
     assert ref_shims.available(), "the reference tree is required to (re)generate golden vectors"

@@ -89,7 +89,8 @@ class RolloutOracle:
         T = w.train_context_length
         tilt_on = fo.tilt_logits(*tilt, w)
         tilt_off = fo.tilt_logits(0, 0, 0, w)
-        groups, dead = fo.build_contexts(buf, w, t, list(eval_list), scn.road_points.astype(np.float64), scn.road_types)
+        groups, dead = fo.build_contexts(buf, w, t, list(eval_list), scn.road_points.astype(np.float64), scn.road_types,
+                                         continuous_rtgs=getattr(dims, "VARIANT", 0) == 3)
         ti = t if t < T else T - 1                                    # token_index (t or -1)
         processed, tokens, next_act = {}, {}, {}
         for g in groups:
@@ -136,6 +137,12 @@ class RolloutOracle:
         n_groups = np.zeros(steps, np.int64)
         groups_log = [] if record_groups else None
         exist = np.ones(N)
+        dt_policy = getattr(self.dims, "VARIANT", 0) == 3
+        if dt_policy:
+            from ctrlsim_amd.rewards import dense_reward
+            edge_polys = [np.asarray(pl[:int(pl[:, 2].sum()), :2], np.float64)
+                          for pl, ty in zip(scn.road_points, scn.road_types) if int(np.argmax(ty)) == 3]
+            reached_latch = np.zeros(N, bool)
 
         def read_state(t):
             st, cv, ce = sim.state()
@@ -152,6 +159,20 @@ class RolloutOracle:
             if t > 0:
                 buf.actions[:, t - 1] = applied[:, t - 1]             # policy.py:85-92
                 buf.rtgs[:, t - 1] = rtg_list[:, t - 1]
+            if dt_policy:
+                # cfgs/policy/dt.yaml: real_time_rewards + max_return.  policy_evaluator.py:122-153: RTG_0 = (10, 90, 90),
+                # RTG_t = RTG_{t-1} - dense_reward_{t-1}; evaluator.py:106-140 for the dense reward (the reference reads the
+                # goal / collision flags of STEP 0 there); policy.py:94-96 writes the current RTG before predict
+                reached = np.where(reached_latch, 1.0, (np.linalg.norm(scn.goal_pos.astype(np.float64) - row[:, :2], axis=1) < 1.0))
+                reached_latch = reached.astype(bool)
+                rew_t = np.zeros((N, 8)); rew_t[:, 0] = reached; rew_t[:, 6] = coll[:, t, 0]; rew_t[:, 7] = coll[:, t, 1]
+                if t == 0:
+                    rew0 = rew_t
+                    rtg_list[:, 0] = (10.0, 90.0, 90.0)
+                else:
+                    rtg_list[:, t] = rtg_list[:, t - 1] - dense_prev
+                dense_prev, _ = dense_reward(row[:, :2], exist, rew0, edge_polys, w)
+                buf.rtgs[:, t] = rtg_list[:, t]
             buf.goals[:, t] = goals5
             processed, toks, acts, dead, n_groups[t] = self.policy_step(buf, scn, t, scn.eval_order, self.tilt,
                                                                         explicit_noise, groups_log)
@@ -175,7 +196,8 @@ class RolloutOracle:
             sim.step(dt)
         read_state(steps)
         sim.close()
-        out = dict(tokens=tokens, rtg_bins=rtg_bins, states=states, coll=coll, actions=applied, n_groups=n_groups)
+        out = dict(tokens=tokens, rtg_bins=rtg_bins, states=states, coll=coll, actions=applied, n_groups=n_groups,
+                   rtgs=rtg_list)
         if record_groups:
             out["groups"] = groups_log
         return out

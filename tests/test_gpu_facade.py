@@ -198,3 +198,35 @@ def test_baseline_policies_through_the_plugin_surface(name):
     acts = np.array([[vdd[v]["acceleration"][t], vdd[v]["steering"][t]] for v in range(9) for t in range(20)]).reshape(9, 20, 2)
     assert np.array_equal(dz.discretize_actions(acts, cfg.dataset.waymo).astype(np.int64), r["tokens"][0])
     assert vdd[0]["rtgs"] == []                           # nothing is appended without predict_rtgs
+
+
+def test_decision_transformer_policy_matches_reference_fixture():
+    """cfgs/policy/dt.yaml through the plugin surface: PolicyEvaluator keeps the real-time RTG ledger (max_return start, minus
+    the dense reward of every step: road-edge signed distance, nearest-vehicle distance), the policy feeds it to the HIP model
+    as continuous RTGs — vs tests/golden/dt_loop.npz (unmodified reference policy + the reference's reward functions + real
+    FreeCar/Box2D): sampled actions identical, RTG ledger and states within 1e-4."""
+    g = golden("dt_loop")
+    rc = g["loop_recipe"]
+    cfg = cfg_of("loop", variant="decision_transformer")
+    cfg.nocturne.history_steps = 1
+    cfg.eval.seed = int(rc[5])
+    cfg.eval.multi_agent_eval_threshold = 100
+    cfg.eval["synthetic"] = dict(num_scenarios=int(rc[1]) + 1, n_agents=int(rc[2]), n_polylines=int(rc[3]), seed=int(rc[0]),
+                                 extent=float(rc[4]))
+    model = CtRLSim(cfg, seed=0, device="cuda:0")
+    policy = AutoregressivePolicy(cfg=cfg, model_path="", model=model, use_rtg=True, predict_rtgs=False, discretize_rtgs=False,
+                                  real_time_rewards=True, privileged_return=False, max_return=True, min_return=False,
+                                  key_dict={"next_acceleration": "next_acceleration", "next_steering": "next_steering", "rtgs": "rtgs"},
+                                  tilt_dict={"tilt": False, "goal_tilt": None, "veh_veh_tilt": None, "veh_edge_tilt": None},
+                                  name="dt", action_temperature=1.0, nucleus_sampling=False, nucleus_threshold=0.8)
+    ev = PolicyEvaluator(cfg, policy)
+    m, _ = ev.evaluate_policy()
+    assert all(np.isfinite(v) for v in m.values())
+    vdd = ev.last_vehicle_data_dict
+    n, steps = int(rc[2]), 14
+    acts = np.array([[vdd[v]["acceleration"][t], vdd[v]["steering"][t]] for v in range(n) for t in range(steps)]).reshape(n, steps, 2)
+    assert np.array_equal(dz.discretize_actions(acts, cfg.dataset.waymo).astype(np.int64), g["loop_tokens"])
+    rt = np.array([[vdd[v]["rtgs"][t] for t in range(steps)] for v in range(n)])
+    np.testing.assert_allclose(rt, g["loop_rtgs"], atol=1e-4, rtol=0)
+    xs = np.array([[vdd[v]["position"][t]["x"] for t in range(steps + 1)] for v in range(n)])
+    np.testing.assert_allclose(xs, g["loop_states"][:, :, 0], atol=1e-4, rtol=0)

@@ -383,3 +383,35 @@ def test_kinematic_step_known_answers_of_the_reference():
     np.testing.assert_allclose(st[:2], [f(1) + dx * f(0.1), f(1) + dy * f(0.1)], rtol=4e-7)      # EXPECT_FLOAT_EQ = 4 ulp
     np.testing.assert_allclose(st[2], q + dth * f(0.1), rtol=4e-7)
     assert st[3] == f(2)
+
+
+def test_dense_reward_matches_reference_functions():
+    """Real-time rewards (ctrlsim_amd/rewards.py: the road-edge signed distance, the nearest-vehicle distance and the reward
+    combination of Evaluator.compute_dense_reward) vs the reference's own functions called as the evaluator calls them
+    (tests/golden/dense_reward.npz): a single vehicle, an all-but-one-missing scene, cyclic and two-point polylines."""
+    from ctrlsim_amd import rewards
+    g = golden("dense_reward")
+    w = spec.make_cfg().dataset.waymo
+    for c in range(4):
+        polys = [g[f"c{c}_poly{k}"] for k in range(int(g[f"c{c}_npoly"]))]
+        dense, nearest = rewards.dense_reward(g[f"c{c}_xy"], g[f"c{c}_exist"], g[f"c{c}_rewards"][:, 0], polys, w)
+        np.testing.assert_allclose(dense, g[f"c{c}_dense"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(nearest * w.max_veh_veh_distance, g[f"c{c}_nearest_metric"], rtol=0, atol=1e-12)
+        sd = -rewards.signed_distance_to_road_edges(g[f"c{c}_xy"], polys) / w.dist_to_road_edge_scaling_factor * g[f"c{c}_exist"]
+        np.testing.assert_allclose(sd, g[f"c{c}_edge_signed"], rtol=0, atol=1e-12)
+
+
+def test_rollout_oracle_matches_reference_decision_transformer_loop():
+    """cfgs/policy/dt.yaml (real_time_rewards, max_return, continuous RTGs) in closed loop: the unmodified reference policy and
+    model + the reference's reward functions + real FreeCar/Box2D (tests/golden/dt_loop.npz) vs the restated loop."""
+    g = golden("dt_loop")
+    rc = g["loop_recipe"]
+    cfg = cfg_of("loop", variant="decision_transformer")
+    d = spec.Dims(cfg)
+    scn = scenarios.make_scenario(int(rc[0]), int(rc[1]), n_agents=int(rc[2]), n_polylines=int(rc[3]), n_points=d.NP,
+                                  extent=float(rc[4]))
+    r = rollout_oracle.RolloutOracle(cfg, weights.generate(d, 0), seed=int(rc[5])).run(scn, 14, sim_libs.OracleSim)
+    assert np.array_equal(r["tokens"], g["loop_tokens"])
+    np.testing.assert_allclose(r["rtgs"], g["loop_rtgs"], rtol=0, atol=1e-9)
+    assert np.array_equal(r["states"], g["loop_states"]) and np.array_equal(r["coll"], g["loop_coll"])
+    assert g["loop_rtgs"][:, -1, 1].max() < 90.0               # the vehicle-distance RTG is being spent
