@@ -1,4 +1,4 @@
-"""Parity sweep outside the test suite: N random scenes through the HIP engine and the CPU oracle, counts scenes with any\ndifferent sampled token / RTG bin.  usage (GPU box): python tools/flip_rate.py [n_scenes]   (about 11 s of oracle time per scene)"""
+"""Parity sweep outside the test suite: N random scenes through the HIP engine and the CPU oracle, counts scenes with any\ndifferent sampled token / RTG bin.  usage (GPU box): python tools/flip_rate.py [n_scenes] [loop|full]   (about 11 s of oracle time per scene)"""
 import sys, time
 sys.path.insert(0, "tests"); sys.path.insert(0, "."); sys.path.insert(0, "oracle")
 import numpy as np
@@ -6,9 +6,11 @@ from helpers import cfg_of
 import rollout_oracle, sim_libs
 from ctrlsim_amd import spec, scenarios, weights
 from ctrlsim_amd.engine import RolloutEngine
-cfg = cfg_of("loop"); d = spec.Dims(cfg); w = weights.generate(d, 0)
-n_scn, steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40, 12
-scns = [scenarios.make_scenario(77, i, n_agents=10, n_polylines=14, n_points=d.NP, extent=38.0) for i in range(n_scn)]
+kind = sys.argv[2] if len(sys.argv) > 2 else "loop"           # "full" = the real model size (slow oracle: use few scenes)
+cfg = cfg_of(kind); d = spec.Dims(cfg); w = weights.generate(d, 0)
+n_scn, steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40, (12 if kind == "loop" else 8)
+scns = [scenarios.make_scenario(77, i, n_agents=10, n_polylines=14 if kind == "loop" else 230, n_points=d.NP, extent=38.0)
+        for i in range(n_scn)]
 eng = RolloutEngine(cfg, w, "cuda:0", max_ctx=256, seed=11, tilt=(5.0, -10.0, 10.0))
 eng.load_scenarios(scns, steps=steps)
 r = eng.run(steps).results()
