@@ -31,6 +31,7 @@ U64 = C.c_uint64
 SIGNATURES = {
     "ctrlsim_version": (C.c_char_p, []),
     "ctrlsim_set_option": (I, [I, I]),
+    "ctrlsim_split_scheme": (I, []),
     "ctrlsim_prof_enable": (None, [I]),
     "ctrlsim_prof_collect": (I, [P, P, P]),
     "ctrlsim_prof_bytes": (I, [P]),

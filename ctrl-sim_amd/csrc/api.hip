@@ -1,5 +1,5 @@
 // extern "C" exports of the C ABI declared in include/ctrlsim.h (thin wrappers over the kernel launchers).
-#include "common.h"
+#include "split.h"
 #include "../../include/ctrlsim.h"
 
 int launch_gemm_nt(const float*, int, const float*, int, const float*, const float*, int, float*, int, int, int, int, int,
@@ -58,6 +58,7 @@ void prof_after(int cls, double flops, hipStream_t st, double bytes) {
 }
 
 static int g_options[OPT_COUNT] = {1, 1, 0, 1};
+extern "C" int ctrlsim_split_scheme() { return CTRLSIM_F16X3; }
 int ctrlsim_option(int key) { return (key >= 0 && key < OPT_COUNT) ? g_options[key] : 0; }
 
 extern "C" {

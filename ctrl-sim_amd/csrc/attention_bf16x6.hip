@@ -17,64 +17,16 @@
 //                 map of the S^T tile, so P never moves between lanes.
 // One accumulator chain per product: with three waves per SIMD the matrix pipe stays fed across the dependent MFMAs
 // (measured: 1829 vs 1966 TFLOP/s register-only), and the merge adds / second rescale / 32 registers go away.
-#include "common.h"
+#include "split.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 #define KT6 64
-#define KV_IMG (2 * 3 * KT6 * HD)   // bf16 elements of one (context, head, 64-key tile) image: K planes then V^T planes (24 KB)
+#define KV_IMG (2 * NPL * KT6 * HD)   // 16-bit elements of one (context, head, 64-key tile) image: K planes then V^T planes (8 KB per plane pair)
+#define KV_PIECES (2 * NPL)          // 16-byte-per-thread LDS-DMA pieces of an image
 
 enum { MODE6_KEYPAD = 0, MODE6_CAUSAL = 1 };
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-
-// Two fp32 values -> three packed bf16 pairs (low half = a, high half = b), round-to-nearest-even at every level:
-// hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid).  One v_cvt_pk_bf16_f32 converts AND packs a pair (hipcc's
-// own lowering of a vector convert emits one instruction per element plus shift/or packing); 11 VALU ops per pair.
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ void split3_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
-  hi = cvt_pk_bf16(a, b);
-  const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xFFFF0000u);
-  mid = cvt_pk_bf16(ra, rb);
-  const float sa = ra - __uint_as_float(mid << 16), sb = rb - __uint_as_float(mid & 0xFFFF0000u);
-  lo = cvt_pk_bf16(sa, sb);
-}
-// same split with the residual arithmetic on the packed-f32 VALU (v_pk_add_f32: both values of the pair per instruction)
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split3_pair_pk(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
-  hi = cvt_pk_bf16(a, b);
-  const f32x2 x = {a, b};
-  const f32x2 h = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xFFFF0000u)};
-  const f32x2 r = x - h;
-  mid = cvt_pk_bf16(r[0], r[1]);
-  const f32x2 m = {__uint_as_float(mid << 16), __uint_as_float(mid & 0xFFFF0000u)};
-  const f32x2 t = r - m;
-  lo = cvt_pk_bf16(t[0], t[1]);
-}
-// eight consecutive fp32 values -> three bf16x8 fragments
-__device__ __forceinline__ void split3_frag(const float* x, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
-  u32x4 h, m, l;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    unsigned a, b, c;
-#ifdef ATT_PK_SPLIT
-    split3_pair_pk(x[2 * i], x[2 * i + 1], a, b, c);
-#else
-    split3_pair(x[2 * i], x[2 * i + 1], a, b, c);
-#endif
-    h[i] = a; m[i] = b; l[i] = c;
-  }
-  hi = __builtin_bit_cast(bf16x8, h);
-  mid = __builtin_bit_cast(bf16x8, m);
-  lo = __builtin_bit_cast(bf16x8, l);
-}
-__device__ __forceinline__ bf16x8 cat8(const bf16x4 a, const bf16x4 b) {
+__device__ __forceinline__ opx8 cat8(const opx4 a, const opx4 b) {
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
@@ -99,8 +51,8 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
     int variant) {
   constexpr int K_PLANE = KT6 * HD;              // bf16 elements: [ks 2][half 2][64 keys][8]
   constexpr int V_PLANE = HD * KT6;              // [16 quads][32 d][4 keys]
-  constexpr int BUF = 3 * K_PLANE + 3 * V_PLANE + 2 * KT6;   // + KT6 floats of key-padding bias
-  __shared__ __attribute__((aligned(16))) __bf16 arena[2 * BUF];
+  constexpr int BUF = NPL * (K_PLANE + V_PLANE) + 2 * KT6;   // + KT6 floats of key-padding bias
+  __shared__ __attribute__((aligned(16))) op_t arena[2 * BUF];
   __shared__ int blk_tmax[4];
   static_assert(2 * BUF * 2 >= 4 * 32 * 33 * 4, "output transpose must fit");
 
@@ -129,7 +81,7 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
     aq = rem / 3;
     kq = rem - aq * 3;
   }
-  bf16x8 qf[2][3];
+  opx8 qf[2][NPL];
   {
     const float* qp = Q + (size_t)b * q_batch_stride + (size_t)qrow * ldq + h * HD + half * 8;
 #pragma unroll
@@ -139,7 +91,7 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
       x0 *= scale_log2e;
       x1 *= scale_log2e;
       const float xs[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-      split3_frag(xs, qf[ks][0], qf[ks][1], qf[ks][2]);
+      split_frag(xs, qf[ks]);
     }
   }
 
@@ -175,13 +127,13 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
   // staging registers: K rows (idx -> row, 4 consecutive d), V row PAIRS (thread -> keys 2rp, 2rp+1, 4 consecutive d)
   f32x4 pk[2], pv[2];
   float ppad = 0.f;
-  const __bf16* img = PRE ? reinterpret_cast<const __bf16*>(K) + ((size_t)b * NHEAD + h) * (size_t)kv_batch_stride * KV_IMG : nullptr;
+  const op_t* img = PRE ? reinterpret_cast<const op_t*>(K) + ((size_t)b * NHEAD + h) * (size_t)kv_batch_stride * KV_IMG : nullptr;
   auto gload = [&](int k0, int buf) {
     if (PRE) {
-      const __bf16* src = img + (size_t)(k0 / KT6) * KV_IMG + tid * 8;
+      const op_t* src = img + (size_t)(k0 / KT6) * KV_IMG + tid * 8;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        __bf16* dst = arena + buf * BUF + (wave * 64 + 256 * i) * 8;          // wave-uniform LDS base (+ 16 B per lane)
+      for (int i = 0; i < KV_PIECES; ++i) {
+        op_t* dst = arena + buf * BUF + (wave * 64 + 256 * i) * 8;          // wave-uniform LDS base (+ 16 B per lane)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 256 * 8 * i),
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
       }
@@ -205,43 +157,31 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
     }
   };
   auto sstore = [&](int buf) {
-    __bf16* Kd = arena + buf * BUF;
-    __bf16* Vd = Kd + 3 * K_PLANE;
+    op_t* Kd = arena + buf * BUF;
+    op_t* Vd = Kd + NPL * K_PLANE;
     if (!PRE) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int idx = tid + 256 * i, r = idx >> 3, c = (idx & 7) * 4;
-      unsigned h0, m0, l0, h1, m1, l1;
-#ifndef ABL_NO_STAGE_SPLIT
-      split3_pair(pk[i][0], pk[i][1], h0, m0, l0);                // pairs along d: the fragment order
-      split3_pair(pk[i][2], pk[i][3], h1, m1, l1);
-#else
-      h0 = __float_as_uint(pk[i][0]); m0 = __float_as_uint(pk[i][1]); l0 = h0; h1 = __float_as_uint(pk[i][2]); m1 = __float_as_uint(pk[i][3]); l1 = h1;
-#endif
-      const u32x2 h = {h0, h1}, m = {m0, m1}, l = {l0, l1};
+      u32x2 kp[NPL];
+      split_quad(pk[i], kp);                                      // pairs along d: the fragment order
       const int ko = ((c >> 3) * KT6 + r) * 8 + (c & 7);          // (ks*2 + half) = c >> 3
-      *reinterpret_cast<u32x2*>(Kd + 0 * K_PLANE + ko) = h;
-      *reinterpret_cast<u32x2*>(Kd + 1 * K_PLANE + ko) = m;
-      *reinterpret_cast<u32x2*>(Kd + 2 * K_PLANE + ko) = l;
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x2*>(Kd + q * K_PLANE + ko) = kp[q];
     }
     {  // V^T: pairs along the key axis (keys 2rp, 2rp+1 of one d) -> one 32-bit store per (plane, d)
       const int rp = tid >> 3, c = (tid & 7) * 4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        unsigned h, m, l;
-#ifndef ABL_NO_STAGE_SPLIT
-        split3_pair(pv[0][e], pv[1][e], h, m, l);
-#else
-        h = __float_as_uint(pv[0][e]); m = __float_as_uint(pv[1][e]); l = h;
-#endif
+        unsigned vp[NPL];
+        split_pair(pv[0][e], pv[1][e], vp);
         const int vo = ((rp >> 1) * HD + (c + e)) * 4 + (rp & 1) * 2;   // [quad][d][key & 3]
-        *reinterpret_cast<unsigned*>(Vd + 0 * V_PLANE + vo) = h;
-        *reinterpret_cast<unsigned*>(Vd + 1 * V_PLANE + vo) = m;
-        *reinterpret_cast<unsigned*>(Vd + 2 * V_PLANE + vo) = l;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) *reinterpret_cast<unsigned*>(Vd + q * V_PLANE + vo) = vp[q];
       }
     }
     }
-    if (MODE == MODE6_KEYPAD && tid < KT6) reinterpret_cast<float*>(Vd + 3 * V_PLANE)[tid] = ppad;
+    if (MODE == MODE6_KEYPAD && tid < KT6) reinterpret_cast<float*>(Vd + NPL * V_PLANE)[tid] = ppad;
   };
 
   if (k_end > 0) {
@@ -258,9 +198,9 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
     const bool more = k0 + KT6 < k_end;
     if (more) gload(k0 + KT6, cur ^ 1);
     TSTAMP(0) TCOUNT(7)
-    const __bf16* Ks = arena + cur * BUF;
-    const __bf16* Vs = Ks + 3 * K_PLANE;
-    const float* padbias = reinterpret_cast<const float*>(Vs + 3 * V_PLANE);
+    const op_t* Ks = arena + cur * BUF;
+    const op_t* Vs = Ks + NPL * K_PLANE;
+    const float* padbias = reinterpret_cast<const float*>(Vs + NPL * V_PLANE);
 
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
@@ -284,23 +224,23 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) s0[r] = -m_base;
       {
-        const __bf16* kr_ = Ks + (half * KT6 + sub * 32 + l31) * 8;
-        bf16x8 k0f[3], k1f[3];
+        const op_t* kr_ = Ks + (half * KT6 + sub * 32 + l31) * 8;
+        opx8 k0f[NPL], k1f[NPL];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          k0f[p] = *reinterpret_cast<const bf16x8*>(kr_ + p * K_PLANE);                  // k-step 0 (d 0-15)
-          k1f[p] = *reinterpret_cast<const bf16x8*>(kr_ + p * K_PLANE + 2 * KT6 * 8);    // k-step 1 (d 16-31)
+        for (int p = 0; p < NPL; ++p) {
+          k0f[p] = *reinterpret_cast<const opx8*>(kr_ + p * K_PLANE);                  // k-step 0 (d 0-15)
+          k1f[p] = *reinterpret_cast<const opx8*>(kr_ + p * K_PLANE + 2 * KT6 * 8);    // k-step 1 (d 16-31)
         }
 #ifndef ABL_NO_MFMA
-#define QK(PA, PB)                                                                        \
-  s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0f[PA], qf[0][PB], s0, 0, 0, 0);           \
-  s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1f[PA], qf[1][PB], s0, 0, 0, 0);
-        QK(2, 0) QK(0, 2) QK(1, 1) QK(1, 0) QK(0, 1) QK(0, 0)
+#define QK(PA, PB)                       \
+  s0 = MFMA_OP(k0f[PA], qf[0][PB], s0);  \
+  s0 = MFMA_OP(k1f[PA], qf[1][PB], s0);
+        PROD_LIST(QK)
 #undef QK
         TSTAMP(1) TCOUNT(6)
 #else
 #pragma unroll
-        for (int p = 0; p < 3; ++p) { asm volatile("" ::"v"(k0f[p]), "v"(k1f[p])); }
+        for (int p = 0; p < NPL; ++p) { asm volatile("" ::"v"(k0f[p]), "v"(k1f[p])); }
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s0[r] = __builtin_bit_cast(float, (unsigned)(k0f[0][r & 7]) << 16) + 0.01f * r; }
 #endif
@@ -381,41 +321,41 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
       }
       TSTAMP(2)
       // ---- P^T fragments: k-step kk uses accumulator registers 8*kk .. 8*kk+7 (slot j <-> register 8*kk + j)
-      bf16x8 pf[2][3];
+      opx8 pf[2][NPL];
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
 #ifndef ABL_NO_PSPLIT
-        split3_frag(sc + 8 * kk, pf[kk][0], pf[kk][1], pf[kk][2]);
+        split_frag(sc + 8 * kk, pf[kk]);
 #else
         { u32x4 u = {__float_as_uint(sc[8 * kk]), __float_as_uint(sc[8 * kk + 1]), __float_as_uint(sc[8 * kk + 2]), __float_as_uint(sc[8 * kk + 3])};
           u32x4 w = {__float_as_uint(sc[8 * kk + 4]), __float_as_uint(sc[8 * kk + 5]), __float_as_uint(sc[8 * kk + 6]), __float_as_uint(sc[8 * kk + 7])};
-          pf[kk][0] = __builtin_bit_cast(bf16x8, u); pf[kk][1] = __builtin_bit_cast(bf16x8, w); pf[kk][2] = pf[kk][0]; }
+          pf[kk][0] = __builtin_bit_cast(opx8, u); pf[kk][1] = __builtin_bit_cast(opx8, w); pf[kk][NPL - 1] = pf[kk][0]; }
 #endif
       }
       // ---- O^T += V^T . P^T : A = V^T rows d = l31, slots 0-3 <-> keys 16kk+4half+0..3, slots 4-7 <-> +8
       {
         // quad of subtile-local keys [4q', 4q'+3] is quad index sub*8 + q'; lane half h needs q' = 4kk + h and 4kk + 2 + h
-        const __bf16* vr_ = Vs + ((sub * 8 + half) * HD + l31) * 4;
-        bf16x8 v0f[3], v1f[3];
+        const op_t* vr_ = Vs + ((sub * 8 + half) * HD + l31) * 4;
+        opx8 v0f[NPL], v1f[NPL];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          const bf16x4 a0 = *reinterpret_cast<const bf16x4*>(vr_ + p * V_PLANE);
-          const bf16x4 a1 = *reinterpret_cast<const bf16x4*>(vr_ + p * V_PLANE + 2 * HD * 4);
-          const bf16x4 b0 = *reinterpret_cast<const bf16x4*>(vr_ + p * V_PLANE + 4 * HD * 4);
-          const bf16x4 b1 = *reinterpret_cast<const bf16x4*>(vr_ + p * V_PLANE + 6 * HD * 4);
+        for (int p = 0; p < NPL; ++p) {
+          const opx4 a0 = *reinterpret_cast<const opx4*>(vr_ + p * V_PLANE);
+          const opx4 a1 = *reinterpret_cast<const opx4*>(vr_ + p * V_PLANE + 2 * HD * 4);
+          const opx4 b0 = *reinterpret_cast<const opx4*>(vr_ + p * V_PLANE + 4 * HD * 4);
+          const opx4 b1 = *reinterpret_cast<const opx4*>(vr_ + p * V_PLANE + 6 * HD * 4);
           v0f[p] = cat8(a0, a1);
           v1f[p] = cat8(b0, b1);
         }
 #ifndef ABL_NO_MFMA
-#define PV(PA, PB)                                                                        \
-  oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0f[PA], pf[0][PB], oa, 0, 0, 0);           \
-  oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1f[PA], pf[1][PB], oa, 0, 0, 0);
-        PV(2, 0) PV(0, 2) PV(1, 1) PV(1, 0) PV(0, 1) PV(0, 0)
+#define PV(PA, PB)                       \
+  oa = MFMA_OP(v0f[PA], pf[0][PB], oa);  \
+  oa = MFMA_OP(v1f[PA], pf[1][PB], oa);
+        PROD_LIST(PV)
 #undef PV
         TSTAMP(3)
 #else
 #pragma unroll
-        for (int p = 0; p < 3; ++p) { asm volatile("" ::"v"(v0f[p]), "v"(v1f[p]), "v"(pf[0][p]), "v"(pf[1][p])); }
+        for (int p = 0; p < NPL; ++p) { asm volatile("" ::"v"(v0f[p]), "v"(v1f[p]), "v"(pf[0][p]), "v"(pf[1][p])); }
 #endif
       }
     }
@@ -455,9 +395,9 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
 // Full mode: one block per (tile, head, context) builds the 24 KB image in LDS and writes it out in 16-byte pieces;
 // keys >= Lk are zero (P = 0 times a garbage V would be NaN).
 __global__ __launch_bounds__(256) void kv_split_kernel(const float* __restrict__ K, const float* __restrict__ V, int ldkv,
-                                                       long kv_batch_stride, int Lk, int nkt, __bf16* __restrict__ img) {
+                                                       long kv_batch_stride, int Lk, int nkt, op_t* __restrict__ img) {
   constexpr int K_PLANE = KT6 * HD, V_PLANE = HD * KT6;
-  __shared__ __attribute__((aligned(16))) __bf16 im[KV_IMG];
+  __shared__ __attribute__((aligned(16))) op_t im[KV_IMG];
   const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, k0 = kt * KT6;
   const float* Kb = K + (size_t)b * kv_batch_stride + h * HD;
   const float* Vb = V + (size_t)b * kv_batch_stride + h * HD;
@@ -471,43 +411,40 @@ __global__ __launch_bounds__(256) void kv_split_kernel(const float* __restrict__
     const int vr = k0 + 2 * (tid >> 3) + i;
     pv[i] = vr < Lk ? *reinterpret_cast<const f32x4*>(Vb + (size_t)vr * ldkv + (tid & 7) * 4) : zero4;
   }
-  __bf16* Kd = im;
-  __bf16* Vd = im + 3 * K_PLANE;
+  op_t* Kd = im;
+  op_t* Vd = im + NPL * K_PLANE;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int idx = tid + 256 * i, r = idx >> 3, c = (idx & 7) * 4;
-    unsigned h0, m0, l0, h1, m1, l1;
-    split3_pair(pk[i][0], pk[i][1], h0, m0, l0);
-    split3_pair(pk[i][2], pk[i][3], h1, m1, l1);
+    u32x2 kp[NPL];
+    split_quad(pk[i], kp);
     const int ko = ((c >> 3) * KT6 + r) * 8 + (c & 7);
-    *reinterpret_cast<u32x2*>(Kd + 0 * K_PLANE + ko) = u32x2{h0, h1};
-    *reinterpret_cast<u32x2*>(Kd + 1 * K_PLANE + ko) = u32x2{m0, m1};
-    *reinterpret_cast<u32x2*>(Kd + 2 * K_PLANE + ko) = u32x2{l0, l1};
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x2*>(Kd + q * K_PLANE + ko) = kp[q];
   }
   {
     const int rp = tid >> 3, c = (tid & 7) * 4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      unsigned hh, mm, ll;
-      split3_pair(pv[0][e], pv[1][e], hh, mm, ll);
+      unsigned vp[NPL];
+      split_pair(pv[0][e], pv[1][e], vp);
       const int vo = ((rp >> 1) * HD + (c + e)) * 4 + (rp & 1) * 2;
-      *reinterpret_cast<unsigned*>(Vd + 0 * V_PLANE + vo) = hh;
-      *reinterpret_cast<unsigned*>(Vd + 1 * V_PLANE + vo) = mm;
-      *reinterpret_cast<unsigned*>(Vd + 2 * V_PLANE + vo) = ll;
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) *reinterpret_cast<unsigned*>(Vd + q * V_PLANE + vo) = vp[q];
     }
   }
   __syncthreads();
   u32x4* dst = reinterpret_cast<u32x4*>(img + (((size_t)b * NHEAD + h) * nkt + kt) * KV_IMG);
   const u32x4* srcv = reinterpret_cast<const u32x4*>(im);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) dst[tid + 256 * i] = srcv[tid + 256 * i];
+  for (int i = 0; i < KV_PIECES; ++i) dst[tid + 256 * i] = srcv[tid + 256 * i];
 }
 
 // Rows mode (KV cache updates): row r of context b (K + b*kv_batch_stride + r*ldkv) goes to key position pos[r] of
 // the context's images; one thread per (context, row, 4 consecutive dims).
 __global__ __launch_bounds__(256) void kv_split_rows_kernel(const float* __restrict__ K, const float* __restrict__ V,
                                                             int ldkv, long kv_batch_stride, const int* __restrict__ pos,
-                                                            int B, int R, int nkt, __bf16* __restrict__ img) {
+                                                            int B, int R, int nkt, op_t* __restrict__ img) {
   constexpr int K_PLANE = KT6 * HD, V_PLANE = HD * KT6;
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (long)B * R * 64) return;
@@ -516,48 +453,45 @@ __global__ __launch_bounds__(256) void kv_split_rows_kernel(const float* __restr
   const int p = pos[r], kt = p >> 6, key = p & 63;
   const f32x4 kx = *reinterpret_cast<const f32x4*>(K + (size_t)b * kv_batch_stride + (size_t)r * ldkv + col);
   const f32x4 vx = *reinterpret_cast<const f32x4*>(V + (size_t)b * kv_batch_stride + (size_t)r * ldkv + col);
-  __bf16* Kd = img + (((size_t)b * NHEAD + h) * nkt + kt) * KV_IMG;
-  __bf16* Vd = Kd + 3 * K_PLANE;
-  unsigned h0, m0, l0, h1, m1, l1;
-  split3_pair(kx[0], kx[1], h0, m0, l0);
-  split3_pair(kx[2], kx[3], h1, m1, l1);
+  op_t* Kd = img + (((size_t)b * NHEAD + h) * nkt + kt) * KV_IMG;
+  op_t* Vd = Kd + NPL * K_PLANE;
+  u32x2 kp[NPL];
+  split_quad(kx, kp);
   const int ko = ((d >> 3) * KT6 + key) * 8 + (d & 7);
-  *reinterpret_cast<u32x2*>(Kd + 0 * K_PLANE + ko) = u32x2{h0, h1};
-  *reinterpret_cast<u32x2*>(Kd + 1 * K_PLANE + ko) = u32x2{m0, m1};
-  *reinterpret_cast<u32x2*>(Kd + 2 * K_PLANE + ko) = u32x2{l0, l1};
+#pragma unroll
+  for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x2*>(Kd + q * K_PLANE + ko) = kp[q];
   unsigned short* Vs = reinterpret_cast<unsigned short*>(Vd);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    unsigned hh, mm, ll;
-    split3_pair(vx[e], 0.f, hh, mm, ll);
+    unsigned vp[NPL];
+    split_pair(vx[e], 0.f, vp);
     const int vo = ((key >> 2) * HD + (d + e)) * 4 + (key & 3);
-    Vs[0 * V_PLANE + vo] = (unsigned short)hh;
-    Vs[1 * V_PLANE + vo] = (unsigned short)mm;
-    Vs[2 * V_PLANE + vo] = (unsigned short)ll;
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) Vs[q * V_PLANE + vo] = (unsigned short)vp[q];
   }
 }
 
 // Zero the keys >= Lk of the last tile of every (context, head): producers that write images row by row (the fused QKV
 // GEMM epilogue) leave that tail untouched, and the attention kernel stages whole tiles.
-__global__ __launch_bounds__(256) void kv_zero_tail_kernel(int Lk, int nkt, __bf16* __restrict__ img) {
+__global__ __launch_bounds__(256) void kv_zero_tail_kernel(int Lk, int nkt, op_t* __restrict__ img) {
   constexpr int K_PLANE = KT6 * HD, V_PLANE = HD * KT6;
   const int k0 = Lk - (nkt - 1) * KT6;                       // first invalid key of the last tile (multiple of 4)
-  __bf16* base = img + ((size_t)blockIdx.x * nkt + (nkt - 1)) * KV_IMG;
+  op_t* base = img + ((size_t)blockIdx.x * nkt + (nkt - 1)) * KV_IMG;
   const int nk = KT6 - k0;
-  for (int i = threadIdx.x; i < 12 * nk * 4; i += 256) {     // K: 12 (plane, d>>3) runs of nk keys x 8 bf16 = nk*4 dwords
+  for (int i = threadIdx.x; i < 4 * NPL * nk * 4; i += 256) {     // K: 4 NPL (plane, d>>3) runs of nk keys x 8 elements = nk*4 dwords
     const int run = i / (nk * 4), off = i - run * (nk * 4);
     reinterpret_cast<unsigned*>(base + run * KT6 * 8 + k0 * 8)[off] = 0u;
   }
   const int q0 = k0 >> 2, nq = 16 - q0;
-  for (int i = threadIdx.x; i < 3 * nq * 64; i += 256) {     // V^T: 3 planes, quads >= q0, 32 d x 4 keys = 64 dwords each
+  for (int i = threadIdx.x; i < NPL * nq * 64; i += 256) {     // V^T: NPL planes, quads >= q0, 32 d x 4 keys = 64 dwords each
     const int pl = i / (nq * 64), off = i - pl * (nq * 64);
-    reinterpret_cast<unsigned*>(base + 3 * K_PLANE + pl * V_PLANE + q0 * HD * 4)[off] = 0u;
+    reinterpret_cast<unsigned*>(base + NPL * K_PLANE + pl * V_PLANE + q0 * HD * 4)[off] = 0u;
   }
 }
 int launch_kv_zero_tail(int B, int Lk, int nkt, void* img, hipStream_t st) {
   if (B <= 0 || Lk % KT6 == 0) return CTRLSIM_OK;
   if (!img || (Lk & 3) || nkt != (Lk + KT6 - 1) / KT6) return CTRLSIM_EINVAL;
-  hipLaunchKernelGGL(kv_zero_tail_kernel, dim3(B * NHEAD), dim3(256), 0, st, Lk, nkt, static_cast<__bf16*>(img));
+  hipLaunchKernelGGL(kv_zero_tail_kernel, dim3(B * NHEAD), dim3(256), 0, st, Lk, nkt, static_cast<op_t*>(img));
   return ctrlsim_launch_status();
 }
 
@@ -566,7 +500,7 @@ int launch_kv_split(const float* K, const float* V, int ldkv, long kv_batch_stri
   if (B <= 0 || Lk <= 0) return CTRLSIM_OK;
   if (!K || !V || !img || (ldkv & 3) || nkt * KT6 < Lk) return CTRLSIM_EINVAL;
   hipLaunchKernelGGL(kv_split_kernel, dim3(nkt, NHEAD, B), dim3(256), 0, st, K, V, ldkv, kv_batch_stride, Lk, nkt,
-                     static_cast<__bf16*>(img));
+                     static_cast<op_t*>(img));
   return ctrlsim_launch_status();
 }
 int launch_kv_split_rows(const float* K, const float* V, int ldkv, long kv_batch_stride, const int* pos, int B, int R,
@@ -575,7 +509,7 @@ int launch_kv_split_rows(const float* K, const float* V, int ldkv, long kv_batch
   if (!K || !V || !img || !pos || (ldkv & 3)) return CTRLSIM_EINVAL;
   const long total = (long)B * R * 64;
   hipLaunchKernelGGL(kv_split_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, K, V, ldkv,
-                     kv_batch_stride, pos, B, R, nkt, static_cast<__bf16*>(img));
+                     kv_batch_stride, pos, B, R, nkt, static_cast<op_t*>(img));
   return ctrlsim_launch_status();
 }
 

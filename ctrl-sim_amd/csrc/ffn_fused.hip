@@ -19,82 +19,50 @@
 // HBM traffic: x read twice (operand + residual, the second an L2 hit) and y written once = 2-3 KB per row, against
 // 13 KB per row for Linear / Linear+LN kernels with the hidden tensor in HBM.  Weights (3 MB of planes per block) come
 // from L2.
-#include "common.h"
+#include "split.h"
 #include <type_traits>
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-__device__ __forceinline__ unsigned ffn_cvt_pk_bf16(float a, float b) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ void ffn_split3_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
-  hi = ffn_cvt_pk_bf16(a, b);
-  const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xFFFF0000u);
-  mid = ffn_cvt_pk_bf16(ra, rb);
-  const float sa = ra - __uint_as_float(mid << 16), sb = rb - __uint_as_float(mid & 0xFFFF0000u);
-  lo = ffn_cvt_pk_bf16(sa, sb);
-}
-// eight fp32 values -> three bf16x8 fragments
-__device__ __forceinline__ void ffn_split3_frag(const float* x, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
-  u32x4 h, m, l;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    unsigned a, b, c;
-    ffn_split3_pair(x[2 * i], x[2 * i + 1], a, b, c);
-    h[i] = a; m[i] = b; l[i] = c;
-  }
-  hi = __builtin_bit_cast(bf16x8, h);
-  mid = __builtin_bit_cast(bf16x8, m);
-  lo = __builtin_bit_cast(bf16x8, l);
-}
-
-constexpr int FF_BLK = 3 * 16 * 2 * 32 * 8;        // bf16 elements of one weight block (W1: [3][16][2][32][8]; W2: [3][2][2][256][8])
+constexpr int FF_BLK = NPL * 16 * 2 * 32 * 8;      // 16-bit elements of one weight block (W1: [NPL][16][2][32][8]; W2: [NPL][2][2][256][8])
+constexpr int FF_PIECES = FF_BLK / (256 * 8);      // 16-byte-per-thread LDS-DMA pieces of a block (8 / 12)
 constexpr int FF_RING = 3;
 #ifndef FFN_PF
 #define FFN_PF 2                                   // LDS fragment prefetch distance in k-steps (2 or 3; four register buffers)
 #endif
 constexpr int FF_CP = DM + 4;                      // row pitch (floats) of the epilogue staging
+// LDS: the ring, re-used by the epilogue as 4 x 32 rows of FF_CP floats — whichever is larger — then b1 (F floats)
+constexpr size_t FF_RING_BYTES = (size_t)FF_RING * FF_BLK * sizeof(op_t) > (size_t)4 * 32 * FF_CP * 4
+                                     ? (size_t)FF_RING * FF_BLK * sizeof(op_t) : (size_t)4 * 32 * FF_CP * 4;
 
-// six partial products, smallest first
-#define FFN_TERMS(ACC, A, B)                                                     \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], B[0], ACC, 0, 0, 0);       \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[2], ACC, 0, 0, 0);       \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[1], ACC, 0, 0, 0);       \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[0], ACC, 0, 0, 0);       \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[1], ACC, 0, 0, 0);       \
-  ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[0], ACC, 0, 0, 0);
+#define FFN_TERMS(ACC, A, B) SPLIT_TERMS(ACC, A, B)
 
 // (Two independent accumulator chains per product were tried — a single dependent chain runs the matrix pipe at ~73 % with
 // one wave per SIMD — but at this register pressure hipcc answers with v_accvgpr_mov shuffles / spills and the result is
 // slower: profiles/r01_c_pmc_pipes.md.)
 __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
-    const float* X, int ldx, const __bf16* __restrict__ W1p, const float* __restrict__ b1,   // X may alias Y: no restrict
-    const __bf16* __restrict__ W2p, const float* __restrict__ b2, const float* __restrict__ gamma,
+    const float* X, int ldx, const op_t* __restrict__ W1p, const float* __restrict__ b1,   // X may alias Y: no restrict
+    const op_t* __restrict__ W2p, const float* __restrict__ b2, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* Y, int ldy, int M, int nhb) {
-  extern __shared__ __attribute__((aligned(16))) __bf16 ring[];      // FF_RING blocks of 48 KB, then b1 (F floats)
-  float* b1s = reinterpret_cast<float*>(ring + FF_RING * FF_BLK);
+  extern __shared__ __attribute__((aligned(16))) op_t ring[];      // FF_RING blocks of 48 KB, then b1 (F floats)
+  float* b1s = reinterpret_cast<float*>(reinterpret_cast<char*>(ring) + FF_RING_BYTES);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int n_rb = (M + 127) / 128;
   for (int i = tid; i < nhb * 32; i += 256) b1s[i] = b1[i];          // global loads inside a phase would queue behind its DMA
 
   // block i of the weight stream: W1 of hidden block i/2 (even i) or W2 of it (odd i); lives in ring slot i % 3
   auto dma_block = [&](int i, int to_slot) {
-    const __bf16* src = ((i & 1) ? W2p : W1p) + (size_t)(i >> 1) * FF_BLK + tid * 8;
-    __bf16* dst = ring + to_slot * FF_BLK + wave * 64 * 8;            // wave-uniform LDS base (+ 16 B per lane)
+    const op_t* src = ((i & 1) ? W2p : W1p) + (size_t)(i >> 1) * FF_BLK + tid * 8;
+    op_t* dst = ring + to_slot * FF_BLK + wave * 64 * 8;            // wave-uniform LDS base (+ 16 B per lane)
 #pragma unroll
-    for (int j = 0; j < 12; ++j)
+    for (int j = 0; j < FF_PIECES; ++j)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 256 * 8),
                                        (__attribute__((address_space(3))) void*)(dst + j * 256 * 8), 16, 0, 0);
   };
   // one 1 KB piece (per wave) of block i: issued between the MFMAs of a phase instead of as a burst of 12 at its start —
   // a piece costs the wave ~60-80 issue cycles, which then overlap the matrix pipe instead of idling it (ablation: the
   // burst cost 18 % of the kernel)
-  auto dma_piece = [&](const __bf16* src, __bf16* dst, int j) {
+  auto dma_piece = [&](const op_t* src, op_t* dst, int j) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 256 * 8),
                                      (__attribute__((address_space(3))) void*)(dst + j * 256 * 8), 16, 0, 0);
   };
@@ -105,7 +73,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
 #ifdef ABL_NO_BARRIER
     return;
 #endif
-    if (issued_this_phase) __builtin_amdgcn_s_waitcnt(0x0070 | 12);   // vmcnt(12) expcnt(7) lgkmcnt(0)  [gfx9: vmcnt = bits 3:0 + 15:14]
+    if (issued_this_phase) __builtin_amdgcn_s_waitcnt(0x0070 | FF_PIECES);   // vmcnt(pieces) expcnt(7) lgkmcnt(0)  [gfx9: vmcnt = bits 3:0 + 15:14]
     else __builtin_amdgcn_s_waitcnt(0x0070);                          // nothing newer in flight: vmcnt(0)
     __builtin_amdgcn_s_barrier();
   };
@@ -116,7 +84,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
     const int rowc = row < M ? row : M - 1;                           // rows beyond M are computed on a clamped row, never stored
     dma_block(0, 0);
     dma_block(1, 1);
-    bf16x8 xT[16][3];
+    opx8 xT[16][NPL];
     {
       const float* xp = X + (size_t)rowc * ldx + half * 8;
 #pragma unroll
@@ -124,7 +92,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
         const f32x4 x0 = *reinterpret_cast<const f32x4*>(xp + ks * 16);
         const f32x4 x1 = *reinterpret_cast<const f32x4*>(xp + ks * 16 + 4);
         const float xs[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-        ffn_split3_frag(xs, xT[ks][0], xT[ks][1], xT[ks][2]);
+        split_frag(xs, xT[ks]);
       }
     }
     f32x16 yacc[8];
@@ -140,28 +108,28 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
       // the block two ahead goes to the slot read last phase.  Past the end of the stream the last block is fetched again
       // (into a slot nobody reads any more; drained before the epilogue): the phases stay branch-free.
       const int hb_next = hb + 1 < nhb ? hb + 1 : nhb - 1;
-      const __bf16* dsrc_a = W1p + (size_t)hb_next * FF_BLK + tid * 8;
-      __bf16* ddst_a = ring + (slot == 0 ? 2 : slot - 1) * FF_BLK + wave * 64 * 8;
+      const op_t* dsrc_a = W1p + (size_t)hb_next * FF_BLK + tid * 8;
+      op_t* ddst_a = ring + (slot == 0 ? 2 : slot - 1) * FF_BLK + wave * 64 * 8;
       f32x16 hacc;
       {
         const float* bp = b1s + hb * 32 + 4 * half;                    // register r <-> hidden (r & 3) + 8 (r >> 2) + 4 half
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + 8 * g);
-          hacc[4 * g + 0] = bv[0]; hacc[4 * g + 1] = bv[1]; hacc[4 * g + 2] = bv[2]; hacc[4 * g + 3] = bv[3];
+          hacc[4 * g + 0] = bv[0] * WSCALE; hacc[4 * g + 1] = bv[1] * WSCALE; hacc[4 * g + 2] = bv[2] * WSCALE; hacc[4 * g + 3] = bv[3] * WSCALE;   // the W1 planes carry WSCALE
         }
       }
       {
         // fragments are fetched two k-steps ahead of the MFMAs that consume them (one wave per SIMD: nothing else hides
         // the LDS latency; hipcc does not hoist the reads by itself)
-        const __bf16* w1 = ring + slot * FF_BLK + (half * 32 + l31) * 8;   // [p][ks][half][row][8]
-        bf16x8 wf[4][3];
-        auto ld1 = [&](int ks, bf16x8 (&f)[3]) {
+        const op_t* w1 = ring + slot * FF_BLK + (half * 32 + l31) * 8;   // [p][ks][half][row][8]
+        opx8 wf[4][NPL];
+        auto ld1 = [&](int ks, opx8 (&f)[NPL]) {
 #pragma unroll
 #ifndef ABL_NO_FRAG
-          for (int p = 0; p < 3; ++p) f[p] = *reinterpret_cast<const bf16x8*>(w1 + ((p * 16 + ks) * 2) * 32 * 8);
+          for (int p = 0; p < NPL; ++p) f[p] = *reinterpret_cast<const opx8*>(w1 + ((p * 16 + ks) * 2) * 32 * 8);
 #else
-          for (int p = 0; p < 3; ++p) { f[p] = xT[ks][p]; asm volatile("" : "+v"(f[p])); }
+          for (int p = 0; p < NPL; ++p) { f[p] = xT[ks][p]; asm volatile("" : "+v"(f[p])); }
 #endif
         };
         ld1(0, wf[0]);
@@ -171,27 +139,27 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
         for (int ks = 0; ks < 16; ++ks) {
           if (ks + FFN_PF < 16) ld1(ks + FFN_PF, wf[(ks + FFN_PF) & 3]);
 #ifndef ABL_NO_DMA
-          if (ks < 12) dma_piece(dsrc_a, ddst_a, ks);
+          if (ks < FF_PIECES) dma_piece(dsrc_a, ddst_a, ks);
 #endif
           FFN_TERMS(hacc, wf[ks & 3], xT[ks])
         }
       }
       // ReLU + split: k-step kk of the second product uses accumulator registers 8 kk .. 8 kk + 7
-      bf16x8 hf[2][3];
+      opx8 hf[2][NPL];
       {
         float hv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hv[r] = fmaxf(hacc[r], 0.f);
+        for (int r = 0; r < 16; ++r) hv[r] = fmaxf(hacc[r] * WSCALE_INV, 0.f);
 #ifndef ABL_NO_SPLIT
-        ffn_split3_frag(hv, hf[0][0], hf[0][1], hf[0][2]);
-        ffn_split3_frag(hv + 8, hf[1][0], hf[1][1], hf[1][2]);
+        split_frag(hv, hf[0]);
+        split_frag(hv + 8, hf[1]);
 #else
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) {
+          for (int p = 0; p < NPL; ++p) {
             u32x4 u = {__float_as_uint(hv[8 * kk + p]), __float_as_uint(hv[8 * kk + p + 1]), __float_as_uint(hv[8 * kk + p + 2]), __float_as_uint(hv[8 * kk + p + 3])};
-            hf[kk][p] = __builtin_bit_cast(bf16x8, u);
+            hf[kk][p] = __builtin_bit_cast(opx8, u);
           }
 #endif
       }
@@ -199,16 +167,16 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
       slot = slot == FF_RING - 1 ? 0 : slot + 1;
 
       // ---------------- phase 2 hb + 1: Y^T += W2_blk . H^T, block 2 hb + 1 in slot (2 hb + 1) % 3
-      const __bf16* dsrc_b = W2p + (size_t)hb_next * FF_BLK + tid * 8;
-      __bf16* ddst_b = ring + (slot == 0 ? 2 : slot - 1) * FF_BLK + wave * 64 * 8;
+      const op_t* dsrc_b = W2p + (size_t)hb_next * FF_BLK + tid * 8;
+      op_t* ddst_b = ring + (slot == 0 ? 2 : slot - 1) * FF_BLK + wave * 64 * 8;
       {
-        const __bf16* w2 = ring + slot * FF_BLK + (half * 256 + l31) * 8;   // [p][kk][half][o][8]
-        bf16x8 wf[4][3];
-        auto ld2 = [&](int i, bf16x8 (&f)[3]) {        // step i = (out block ob = i >> 1, k-step kk = i & 1)
+        const op_t* w2 = ring + slot * FF_BLK + (half * 256 + l31) * 8;   // [p][kk][half][o][8]
+        opx8 wf[4][NPL];
+        auto ld2 = [&](int i, opx8 (&f)[NPL]) {        // step i = (out block ob = i >> 1, k-step kk = i & 1)
 #pragma unroll
-          for (int p = 0; p < 3; ++p)
+          for (int p = 0; p < NPL; ++p)
 #ifndef ABL_NO_FRAG
-            f[p] = *reinterpret_cast<const bf16x8*>(w2 + (((p * 2 + (i & 1)) * 2) * 256 + (i >> 1) * 32) * 8);
+            f[p] = *reinterpret_cast<const opx8*>(w2 + (((p * 2 + (i & 1)) * 2) * 256 + (i >> 1) * 32) * 8);
 #else
           { f[p] = hf[i & 1][p]; asm volatile("" : "+v"(f[p])); }
 #endif
@@ -220,7 +188,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
         for (int i = 0; i < 16; ++i) {
           if (i + FFN_PF < 16) ld2(i + FFN_PF, wf[(i + FFN_PF) & 3]);
 #ifndef ABL_NO_DMA
-          if (i < 12) dma_piece(dsrc_b, ddst_b, i);
+          if (i < FF_PIECES) dma_piece(dsrc_b, ddst_b, i);
 #endif
           FFN_TERMS(yacc[i >> 1], wf[i & 3], hf[i & 1])
         }
@@ -235,7 +203,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
 #pragma unroll
     for (int ob = 0; ob < 8; ++ob)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) Cs[l31 * FF_CP + ob * 32 + mfma_row(r, half)] = yacc[ob][r];
+      for (int r = 0; r < 16; ++r) Cs[l31 * FF_CP + ob * 32 + mfma_row(r, half)] = yacc[ob][r] * WSCALE_INV;
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);                               // lgkmcnt(0): this wave's LDS writes are complete
     {
@@ -272,15 +240,15 @@ int launch_ffn_fused_bf16x6(const float* X, int ldx, const void* W1p, const floa
     return CTRLSIM_EINVAL;
   const int n_rb = (M + 127) / 128;
   const int grid = n_rb < 256 ? n_rb : 256;                           // one persistent workgroup per CU
-  const size_t shm = (size_t)FF_RING * FF_BLK * sizeof(__bf16) + (size_t)F * sizeof(float);   // 147456 B + b1
+  const size_t shm = FF_RING_BYTES + (size_t)F * sizeof(float);
   // once per process (thread-safe static initialisation), sized for the largest F this launcher accepts
   static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_bf16x6_kernel),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  (int)(FF_RING * FF_BLK * sizeof(__bf16) + 4096 * sizeof(float))) == hipSuccess;
+                                                  (int)(FF_RING_BYTES + 4096 * sizeof(float))) == hipSuccess;
   if (!attr_ok) return CTRLSIM_EINVAL;
   prof_before(PROF_GEMM, st);
-  hipLaunchKernelGGL(ffn_fused_bf16x6_kernel, dim3(grid), dim3(256), shm, st, X, ldx, static_cast<const __bf16*>(W1p), b1,
-                     static_cast<const __bf16*>(W2p), b2, gamma, beta, Y, ldy, M, F / 32);
+  hipLaunchKernelGGL(ffn_fused_bf16x6_kernel, dim3(grid), dim3(256), shm, st, X, ldx, static_cast<const op_t*>(W1p), b1,
+                     static_cast<const op_t*>(W2p), b2, gamma, beta, Y, ldy, M, F / 32);
   prof_after(PROF_GEMM, 4.0 * (double)M * DM * (double)F, st, 12.0 * (double)M * DM + 12.0 * (double)DM * F);
   return ctrlsim_launch_status();
 }

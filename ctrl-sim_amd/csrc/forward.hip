@@ -19,7 +19,7 @@
 #include <unordered_map>
 #include <vector>
 
-#include "common.h"
+#include "split.h"
 #include "../../include/ctrlsim.h"
 
 // launchers from the other translation units
@@ -226,7 +226,7 @@ Ws carve(const ctrlsim_dims& d, int B, int Tq, char* base) {
   w.idx_state_in_new = reinterpret_cast<int*>(take(rA * sizeof(int)));
   w.nkt_dec = (int)((L + 63) / 64);
   w.nkt_mem = (int)((M + 63) / 64);
-  const size_t tile_bytes = 2 * 3 * 64 * HD * 2;   // 24 KB per (context, head, tile)
+  const size_t tile_bytes = (size_t)2 * NPL * 64 * HD * 2;   // 8 KB per plane pair of a (context, head, tile) image
   w.img_dec_bytes = (size_t)B * NHEAD * w.nkt_dec * tile_bytes;
   for (int i = 0; i < d.ND; ++i) w.img_dec[i] = take(w.img_dec_bytes);
   for (int i = 0; i < d.ND; ++i) w.img_mem[i] = take((size_t)B * NHEAD * w.nkt_mem * tile_bytes);

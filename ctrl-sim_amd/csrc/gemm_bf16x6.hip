@@ -21,54 +21,28 @@
 // Persistent workgroups with the XCD-aware tile order of gemm.hip; the next tile's first A slab is prefetched before
 // the epilogue; the epilogue stages half the tile's rows at a time through LDS for 16-byte bias / residual / store
 // traffic and, for LN, normalises whole rows there (one wave per row).
-#include "common.h"
+#include "split.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define XK 16
 
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-// one v_cvt_pk_bf16_f32 converts AND packs two values (RNE); 11 VALU ops per pair for the three planes
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ void split3_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
-  hi = cvt_pk_bf16(a, b);
-  const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xFFFF0000u);
-  mid = cvt_pk_bf16(ra, rb);
-  const float sa = ra - __uint_as_float(mid << 16), sb = rb - __uint_as_float(mid & 0xFFFF0000u);
-  lo = cvt_pk_bf16(sa, sb);
-}
-__device__ __forceinline__ void split3(const f32x4 x, u32x2& hi, u32x2& mid, u32x2& lo) {
-  unsigned h0, m0, l0, h1, m1, l1;
-  split3_pair(x[0], x[1], h0, m0, l0);
-  split3_pair(x[2], x[3], h1, m1, l1);
-  hi = u32x2{h0, h1}; mid = u32x2{m0, m1}; lo = u32x2{l0, l1};
-}
-
 template <int PA, int PB, int MR>
-__device__ __forceinline__ void term(f32x16 (&acc)[MR][2], const bf16x8 (&fa)[MR][3], const bf16x8 (&fb)[2][3]) {
+__device__ __forceinline__ void term(f32x16 (&acc)[MR][2], const opx8 (&fa)[MR][NPL], const opx8 (&fb)[2][NPL]) {
 #pragma unroll
   for (int a = 0; a < MR; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA], fb[b][PB], acc[a][b], 0, 0, 0);
+    for (int b = 0; b < 2; ++b) acc[a][b] = MFMA_OP(fa[a][PA], fb[b][PB], acc[a][b]);
 }
 
 // KVIMG = true (2x2 tiles, plain Linear): output columns >= kv.k_col0 are attention keys (256 columns) and values (the
 // next 256) and are written NOT as fp32 rows but directly as the split-bf16 K / V^T tile images the attention kernel
 // stages by DMA (attention_bf16x6.hip: layout at kv_split_kernel) — the K/V split costs no extra pass over HBM.
-struct KvImg { __bf16* img; int L; int nkt; int k_col0; };   // L = rows (keys) per context
+struct KvImg { op_t* img; int L; int nkt; int k_col0; };   // L = rows (keys) per context
 
 template <int WR, int WC, int MR, bool RELU, bool RESID, bool LN, bool KVIMG = false>
 __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? 3 : 2)) void gemm_nt_bf16x6_kernel(
-    const float* __restrict__ A, int lda, const __bf16* __restrict__ W3,   // [K/16][3][2][n_total][8]
+    const float* __restrict__ A, int lda, const op_t* __restrict__ W3,   // [K/16][NPL][2][n_total][8]
     const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* R, int ldr, float* C, int ldc, int M, int N, int K, int m_tiles, int n_tiles,   // C may alias R: no restrict
     int n_total, int n0, KvImg kv) {
@@ -76,16 +50,15 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? 3 : 2)) 
   // in_proj_weight)
   constexpr int WMR = 32 * MR;                     // rows of a wave tile (MR x 2 MFMA tiles of 32 x 32)
   constexpr int XM = WMR * WR, XN = 64 * WC;
-  constexpr int A_PLANE = XM * XK;                 // bf16 elements of one plane of one k-step
+  constexpr int A_PLANE = XM * XK;                 // 16-bit elements of one plane of one k-step
   constexpr int W_PLANE = XN * XK;
-  constexpr int STAGE = 3 * A_PLANE + 3 * W_PLANE; // one k-step: 24 KB (2x2) / 30 KB (1x4)
+  constexpr int STAGE = NPL * (A_PLANE + W_PLANE); // one k-step: 8 / 10 KB per plane (2x2 / 1x4)
   constexpr int CP = XN + 4, CR = 32 * WR;         // epilogue chunk: CR rows x XN columns of fp32
   constexpr int NA = (XM + 63) / 64;               // f32x4 loads of A per thread and stage
-  constexpr int NW = 6 * XN / 256;                 // 16-byte DMA chunks of W per thread and stage
+  constexpr int NW = 2 * NPL * XN / 256;           // 16-byte DMA chunks of W per thread and stage
   static_assert(!LN || (WR == 1 && WC == 4), "LayerNorm epilogue needs whole 256-wide rows");
   static_assert(XM % 64 == 0, "A staging assumes whole 64-row groups");
-  static_assert(2 * STAGE * 2 >= CR * CP * 4, "epilogue staging must fit");
-  extern __shared__ __attribute__((aligned(16))) __bf16 lds[];   // 2 * STAGE bf16
+  extern __shared__ __attribute__((aligned(16))) op_t lds[];   // max(2 * STAGE elements, the epilogue chunk): see the launcher
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int l31 = lane & 31, half = lane >> 5;
@@ -105,7 +78,7 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? 3 : 2)) 
   // the W part of a stage is lane-linear in exactly the order idx = tid + 256*i, so the DMA needs no VGPRs at all)
   f32x4 ra[NA];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  const size_t w_slab = (size_t)3 * n_total * XK;  // bf16 elements per 16-wide K-slab of W3
+  const size_t w_slab = (size_t)NPL * n_total * XK;  // elements per 16-wide K-slab of W3
   auto gload_a = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -124,8 +97,8 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? 3 : 2)) 
       const int idx = tid + 256 * i, pc = idx / XN, r = idx % XN;
       int gw = bn + r;
       gw = gw < N ? gw : N - 1;                    // columns >= N are computed on clamped rows and never stored
-      const __bf16* src = W3 + (size_t)kt * w_slab + ((size_t)pc * n_total + n0 + gw) * 8;
-      __bf16* dst = lds + buf * STAGE + 3 * A_PLANE + (wave * 64 + 256 * i) * 8;   // wave-uniform LDS base
+      const op_t* src = W3 + (size_t)kt * w_slab + ((size_t)pc * n_total + n0 + gw) * 8;
+      op_t* dst = lds + buf * STAGE + NPL * A_PLANE + (wave * 64 + 256 * i) * 8;   // wave-uniform LDS base
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
@@ -134,16 +107,16 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? 3 : 2)) 
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int idx = tid + 256 * i, r = idx >> 2, c = (idx & 3) * 4;
-      u32x2 hi, mid, lo;
+      u32x2 pl[NPL];
 #ifndef ABL_NO_SPLIT
-      split3(ra[i], hi, mid, lo);
+      split_quad(ra[i], pl);
 #else
-      hi = u32x2{__float_as_uint(ra[i][0]), __float_as_uint(ra[i][1])}; mid = u32x2{__float_as_uint(ra[i][2]), __float_as_uint(ra[i][3])}; lo = hi;
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) pl[q] = u32x2{__float_as_uint(ra[i][0]), __float_as_uint(ra[i][1 + (q & 1)])};
 #endif
-      __bf16* Ab = lds + buf * STAGE + (c >> 3) * (A_PLANE / 2) + r * 8 + (c & 7);
-      *reinterpret_cast<u32x2*>(Ab + 0 * A_PLANE) = hi;
-      *reinterpret_cast<u32x2*>(Ab + 1 * A_PLANE) = mid;
-      *reinterpret_cast<u32x2*>(Ab + 2 * A_PLANE) = lo;
+      op_t* Ab = lds + buf * STAGE + (c >> 3) * (A_PLANE / 2) + r * 8 + (c & 7);
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x2*>(Ab + q * A_PLANE) = pl[q];
     }
   };
 
@@ -173,43 +146,44 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? 3 : 2)) 
         gload_a(kt + 1);
       }
       {
-        const __bf16* Ab = lds + cur * STAGE + half * (A_PLANE / 2) + (wr * WMR + l31) * 8;
-        const __bf16* Wb = lds + cur * STAGE + 3 * A_PLANE + half * (W_PLANE / 2) + (wc * 64 + l31) * 8;
-        bf16x8 fa[MR][3], fb[2][3];
+        const op_t* Ab = lds + cur * STAGE + half * (A_PLANE / 2) + (wr * WMR + l31) * 8;
+        const op_t* Wb = lds + cur * STAGE + NPL * A_PLANE + half * (W_PLANE / 2) + (wc * 64 + l31) * 8;
+        opx8 fa[MR][NPL], fb[2][NPL];
 #ifndef ABL_NO_FRAG
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NPL; ++p) {
 #pragma unroll
-          for (int a = 0; a < MR; ++a) fa[a][p] = *reinterpret_cast<const bf16x8*>(Ab + p * A_PLANE + a * 32 * 8);
+          for (int a = 0; a < MR; ++a) fa[a][p] = *reinterpret_cast<const opx8*>(Ab + p * A_PLANE + a * 32 * 8);
 #pragma unroll
-          for (int b = 0; b < 2; ++b) fb[b][p] = *reinterpret_cast<const bf16x8*>(Wb + p * W_PLANE + b * 32 * 8);
+          for (int b = 0; b < 2; ++b) fb[b][p] = *reinterpret_cast<const opx8*>(Wb + p * W_PLANE + b * 32 * 8);
         }
 #else
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NPL; ++p) {
 #pragma unroll
-          for (int a = 0; a < 2; ++a) { fa[a % MR][p] = bf16x8{}; fb[a][p] = bf16x8{}; asm volatile("" : "+v"(fa[a % MR][p]), "+v"(fb[a][p])); }
+          for (int a = 0; a < 2; ++a) { fa[a % MR][p] = opx8{}; fb[a][p] = opx8{}; asm volatile("" : "+v"(fa[a % MR][p]), "+v"(fb[a][p])); }
         }
 #endif
-        // six partial products, smallest first; term-major order keeps 4 independent accumulators between reuses
+        // the partial products, smallest first; term-major order keeps 4 independent accumulators between reuses
 #ifndef ABL_NO_MFMA
-        term<2, 0, MR>(acc, fa, fb);
-        term<0, 2, MR>(acc, fa, fb);
-        term<1, 1, MR>(acc, fa, fb);
-#ifdef GEMM6_EARLY_STORE
-        if (kt + 1 < nk) sstore_a(cur ^ 1);        // the A slab issued at the top of this k-step: split + LDS write between MFMAs
-#endif
+#if CTRLSIM_F16X3
         term<1, 0, MR>(acc, fa, fb);
         term<0, 1, MR>(acc, fa, fb);
         term<0, 0, MR>(acc, fa, fb);
 #else
+        term<2, 0, MR>(acc, fa, fb);
+        term<0, 2, MR>(acc, fa, fb);
+        term<1, 1, MR>(acc, fa, fb);
+        term<1, 0, MR>(acc, fa, fb);
+        term<0, 1, MR>(acc, fa, fb);
+        term<0, 0, MR>(acc, fa, fb);
+#endif
+#else
 #pragma unroll
-        for (int p = 0; p < 3; ++p) { asm volatile("" ::"v"(fa[0][p]), "v"(fa[MR - 1][p]), "v"(fb[0][p]), "v"(fb[1][p])); }
+        for (int p = 0; p < NPL; ++p) { asm volatile("" ::"v"(fa[0][p]), "v"(fa[MR - 1][p]), "v"(fb[0][p]), "v"(fb[1][p])); }
 #endif
       }
-#ifndef GEMM6_EARLY_STORE
       if (kt + 1 < nk) sstore_a(cur ^ 1);
-#endif
       __syncthreads();
     }
 
@@ -234,12 +208,12 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? 3 : 2)) 
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          Cs[(wr * 32 + mfma_row(r, half)) * CP + wc * 64 + b * 32 + l31] = acc[a][b][r];
+          Cs[(wr * 32 + mfma_row(r, half)) * CP + wc * 64 + b * 32 + l31] = acc[a][b][r] * WSCALE_INV;
       __syncthreads();
       if (KVIMG && cbn >= kv.k_col0) {
         // ---- this tile is 4 heads of K or of V: emit the images.  Chunk rows lr = s*32 + j <-> global row
         // cbm + s*64 + a*32 + j (two 32-row segments); key position = row % L, context = row / L.
-        constexpr int KIMG = 2 * 3 * 64 * HD, KPL = 64 * HD;      // image / plane sizes in bf16 elements
+        constexpr int KIMG = 2 * NPL * 64 * HD, KPL = 64 * HD;    // image / plane sizes in 16-bit elements
         const int rel = cbn - kv.k_col0;
         const bool isV = rel >= DM;
         const int head0 = (rel & (DM - 1)) >> 5;
@@ -257,16 +231,12 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? 3 : 2)) 
                 x0 += *reinterpret_cast<const f32x4*>(bias + cbn + c * 8);
                 x1 += *reinterpret_cast<const f32x4*>(bias + cbn + c * 8 + 4);
               }
-              u32x4 ph, pm, pl;
-              unsigned h_, m_, l_;
-              split3_pair(x0[0], x0[1], h_, m_, l_); ph[0] = h_; pm[0] = m_; pl[0] = l_;
-              split3_pair(x0[2], x0[3], h_, m_, l_); ph[1] = h_; pm[1] = m_; pl[1] = l_;
-              split3_pair(x1[0], x1[1], h_, m_, l_); ph[2] = h_; pm[2] = m_; pl[2] = l_;
-              split3_pair(x1[2], x1[3], h_, m_, l_); ph[3] = h_; pm[3] = m_; pl[3] = l_;
-              __bf16* dst = kv.img + (((size_t)b * NHEAD + head0 + hh) * kv.nkt + kt) * KIMG + (dg * 64 + key) * 8;
-              *reinterpret_cast<u32x4*>(dst + 0 * KPL) = ph;
-              *reinterpret_cast<u32x4*>(dst + 1 * KPL) = pm;
-              *reinterpret_cast<u32x4*>(dst + 2 * KPL) = pl;
+              u32x2 pa[NPL], pb[NPL];
+              split_quad(x0, pa);
+              split_quad(x1, pb);
+              op_t* dst = kv.img + (((size_t)b * NHEAD + head0 + hh) * kv.nkt + kt) * KIMG + (dg * 64 + key) * 8;
+#pragma unroll
+              for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x4*>(dst + q * KPL) = u32x4{pa[q][0], pa[q][1], pb[q][0], pb[q][1]};
             }
           }
         } else {
@@ -280,13 +250,11 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? 3 : 2)) 
               const int b = grow0 / kv.L, pos = grow0 - b * kv.L, kt = pos >> 6, q = (pos & 63) >> 2;
               const float x0 = Cs[(lr0 + 0) * CP + col] + bv, x1 = Cs[(lr0 + 1) * CP + col] + bv;
               const float x2 = Cs[(lr0 + 2) * CP + col] + bv, x3 = Cs[(lr0 + 3) * CP + col] + bv;
-              unsigned h0, m0, l0, h1, m1, l1;
-              split3_pair(x0, x1, h0, m0, l0);
-              split3_pair(x2, x3, h1, m1, l1);
-              __bf16* dst = kv.img + (((size_t)b * NHEAD + head0 + hh) * kv.nkt + kt) * KIMG + 3 * KPL + (q * HD + d) * 4;
-              *reinterpret_cast<u32x2*>(dst + 0 * KPL) = u32x2{h0, h1};
-              *reinterpret_cast<u32x2*>(dst + 1 * KPL) = u32x2{m0, m1};
-              *reinterpret_cast<u32x2*>(dst + 2 * KPL) = u32x2{l0, l1};
+              u32x2 pv[NPL];
+              split_quad(f32x4{x0, x1, x2, x3}, pv);
+              op_t* dst = kv.img + (((size_t)b * NHEAD + head0 + hh) * kv.nkt + kt) * KIMG + NPL * KPL + (q * HD + d) * 4;
+#pragma unroll
+              for (int qq = 0; qq < NPL; ++qq) *reinterpret_cast<u32x2*>(dst + qq * KPL) = pv[qq];
             }
           }
         }
@@ -366,7 +334,7 @@ int launch_gemm_nt_bf16x6_kv(const float* A, int lda, const void* W3, int n_tota
   if (kv_img && (ln_gamma || R || relu || (kv_L & 3) || kv_L < 32 || (kv_col0 & 127) || N != kv_col0 + 2 * DM || M % kv_L ||
                  kv_nkt * 64 < kv_L))
     return CTRLSIM_EINVAL;
-  const KvImg kv{static_cast<__bf16*>(kv_img), kv_L, kv_nkt, kv_col0};
+  const KvImg kv{static_cast<op_t*>(kv_img), kv_L, kv_nkt, kv_col0};
   if (K % XK != 0 || (lda & 3) || N <= 0 || !W3 || n0 < 0 || n0 + N > n_total) return CTRLSIM_EINVAL;
   const bool ln = ln_gamma != nullptr;
   if (ln && (N != 256 || (ldc & 3) || (R && (ldr & 3)))) return CTRLSIM_EINVAL;
@@ -380,8 +348,11 @@ int launch_gemm_nt_bf16x6_kv(const float* A, int lda, const void* W3, int n_tota
   const int resident = 256 * (wide ? 2 : (small ? 4 : 3));
   const int grid = total < resident ? total : resident;
   dim3 g(grid), b(256);
-  const __bf16* w = static_cast<const __bf16*>(W3);
-  const size_t shm = (size_t)2 * 3 * (XM + XN) * XK * sizeof(__bf16);   // 48 KB / 60 KB
+  const op_t* w = static_cast<const op_t*>(W3);
+  // two k-step stages of NPL planes each, or the epilogue's fp32 chunk (32 rows per wave row x XN + 4 columns), whichever is larger
+  const size_t shm_k = (size_t)2 * NPL * (XM + XN) * XK * sizeof(op_t);
+  const size_t shm_e = (size_t)(wide ? 32 : 64) * (XN + 4) * sizeof(float);
+  const size_t shm = shm_k > shm_e ? shm_k : shm_e;
 #define GEMM6_LAUNCH(WR_, WC_, RELU_, RESID_, LN_, KV_) GEMM6_LAUNCH_(WR_, WC_, 2, RELU_, RESID_, LN_, KV_)
 #define GEMM6_LAUNCH_(WR_, WC_, MR_, RELU_, RESID_, LN_, KV_)                                                               \
   do {                                                                                                                \

@@ -77,31 +77,40 @@ def bf16_to_f32(h: np.ndarray) -> np.ndarray:
     return (h.astype(np.uint32) << 16).view(np.float32)
 
 
-def split3_planes(W: np.ndarray) -> np.ndarray:
-    """[N,K] float32 -> slab-major bf16 planes [K/16][3][2][N][8] (uint16): W = hi + mid + lo, each 16-wide k-step stored
-    as two 8-wide half planes — the operand layout of csrc/gemm_bf16x6.hip."""
-    W = np.ascontiguousarray(W, np.float32)
-    N, K = W.shape
-    assert K % 16 == 0
-    hi = bf16_rne(W)
-    r1 = W - bf16_to_f32(hi)
-    mid = bf16_rne(r1)
-    r2 = r1 - bf16_to_f32(mid)
-    lo = bf16_rne(r2)
-    planes = np.stack([hi, mid, lo], 0).reshape(3, N, K // 16, 2, 8)     # [3][N][K/16][2][8]
-    return np.ascontiguousarray(planes.transpose(2, 0, 3, 1, 4))         # [K/16][3][2][N][8]
-
-
-BF3_SUFFIX = "#bf3"
+def split_scheme():
+    """(planes, weight scale) of the operand split compiled into the library (csrc/split.h): (2, 256.0) = two fp16 planes, three
+    products; (3, 1.0) = three bf16 planes, six products."""
+    from . import _lib
+    return (2, 256.0) if int(_lib.lib().ctrlsim_split_scheme()) == 1 else (3, 1.0)
 
 
 def _planes3(W: np.ndarray):
-    W = np.ascontiguousarray(W, np.float32)
+    """[rows, cols] float32 -> the operand planes [NPL][rows][cols] as 16-bit words: W * scale = sum of the planes."""
+    npl, scale = split_scheme()
+    W = np.ascontiguousarray(W, np.float32) * np.float32(scale)
+    if npl == 2:
+        hi = W.astype(np.float16)                                        # round-to-nearest-even, like v_cvt_pk_f16_f32
+        lo = (W - hi.astype(np.float32)).astype(np.float16)
+        return np.stack([hi.view(np.uint16), lo.view(np.uint16)], 0)
     hi = bf16_rne(W)
     r1 = W - bf16_to_f32(hi)
     mid = bf16_rne(r1)
     lo = bf16_rne(r1 - bf16_to_f32(mid))
-    return np.stack([hi, mid, lo], 0)                                     # [3][rows][cols] uint16
+    return np.stack([hi, mid, lo], 0)                                     # [NPL][rows][cols] uint16
+
+
+def split3_planes(W: np.ndarray) -> np.ndarray:
+    """[N,K] float32 -> slab-major operand planes [K/16][NPL][2][N][8] (uint16), each 16-wide k-step stored as two 8-wide half
+    planes — the operand layout of csrc/gemm_bf16x6.hip."""
+    W = np.ascontiguousarray(W, np.float32)
+    N, K = W.shape
+    assert K % 16 == 0
+    pl = _planes3(W)
+    planes = pl.reshape(pl.shape[0], N, K // 16, 2, 8)                    # [NPL][N][K/16][2][8]
+    return np.ascontiguousarray(planes.transpose(2, 0, 3, 1, 4))         # [K/16][NPL][2][N][8]
+
+
+BF3_SUFFIX = "#bf3"
 
 
 def ffn_planes(W1: np.ndarray, W2: np.ndarray):
@@ -113,14 +122,16 @@ def ffn_planes(W1: np.ndarray, W2: np.ndarray):
     F, K = W1.shape
     D = W2.shape[0]
     assert W2.shape[1] == F and F % 32 == 0 and K % 16 == 0
-    p1 = _planes3(W1).reshape(3, F // 32, 32, K // 16, 2, 8)              # [p][hb][row][ks][half][e]
+    pl1 = _planes3(W1)
+    p1 = pl1.reshape(pl1.shape[0], F // 32, 32, K // 16, 2, 8)            # [p][hb][row][ks][half][e]
     w1p = np.ascontiguousarray(p1.transpose(1, 0, 3, 4, 2, 5))            # [hb][p][ks][half][row][e]
     j = np.arange(8)
     idx = np.empty((2, 2, 8), np.int64)                                   # [kk][half][j] -> hidden offset in the block
     for kk in range(2):
         for half in range(2):
             idx[kk, half] = 16 * kk + (j & 3) + 8 * (j >> 2) + 4 * half
-    p2 = _planes3(W2).reshape(3, D, F // 32, 32)                          # [p][o][hb][hid]
+    pl2 = _planes3(W2)
+    p2 = pl2.reshape(pl2.shape[0], D, F // 32, 32)                        # [p][o][hb][hid]
     p2 = p2[:, :, :, idx]                                                 # [p][o][hb][kk][half][j]
     w2p = np.ascontiguousarray(p2.transpose(2, 0, 3, 4, 1, 5))            # [hb][p][kk][half][o][j]
     return w1p, w2p

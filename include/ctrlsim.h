@@ -186,6 +186,9 @@ int ctrlsim_prof_bytes(double* bytes2);   /* compulsory HBM bytes (operands read
 /* Runtime options: key 0 = attention path, key 1 = GEMM path of the forward; value 0 = f32-input MFMA
  * (v_mfma_f32_32x32x2_f32), 1 = split-bf16 "bf16x6" MFMA with fp32-class accuracy (default). */
 int ctrlsim_set_option(int key, int value);
+/* Operand split compiled into the library (csrc/split.h): 1 = two fp16 planes / three products (weights pre-scaled by 2^8), 0 = three
+ * bf16 planes / six products.  ctrlsim_amd/pack.py packs weight planes and sizes the K/V images accordingly. */
+int ctrlsim_split_scheme(void);
 
 const char* ctrlsim_version(void);
 
