@@ -31,10 +31,10 @@ import numpy as np
 import torch
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
-PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (AMD's 5 PF figure includes 2:1 sparsity)
-# Both matrix kernels evaluate every fp32 product as SIX bf16 partial products (x = hi + mid + lo splits, fp32-class
-# accuracy): the roof of the ALGORITHMIC (fp32-equivalent) FLOP rate is the dense bf16 peak / 6.
-PEAK_FP32_EQUIV_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+PEAK_16BIT_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA (AMD's 5 PF figure includes 2:1 sparsity)
+# Both matrix kernels evaluate every fp32 product as NPROD 16-bit partial products with fp32-class accuracy (csrc/split.h: three
+# fp16 products of two-plane splits, or six bf16 products of three-plane splits): the roof of the ALGORITHMIC (fp32-equivalent)
+# FLOP rate is the dense 16-bit MFMA peak / NPROD.
 
 
 def main():
@@ -152,9 +152,12 @@ def main():
         value = agent_steps / elapsed
         ctx_per_rollout = int(res["n_groups"].sum())
         dom = 0 if ms[0] >= ms[1] else 1
+        f16 = int(lib.ctrlsim_split_scheme()) == 1
+        nprod, scheme = (3, "two fp16 planes, 3") if f16 else (6, "three bf16 planes, 6")
+        PEAK_FP32_EQUIV_TFLOPS = PEAK_16BIT_MFMA_TFLOPS / nprod
         names = ("gemm_nt_bf16x6_kernel + ffn_fused_bf16x6_kernel (every nn.Linear incl. fused LayerNorm / K-V image epilogues and the fused "
-                 "feed-forward block; split-bf16 MFMA 32x32x16, 6 partial products per fp32 product)",
-                 "attention_bf16x6_kernel (all multi-head attention; split-bf16 MFMA flash attention, structured mask)")
+                 f"feed-forward block; split-operand MFMA 32x32x16: {scheme} partial products per fp32 product)",
+                 "attention_bf16x6_kernel (all multi-head attention; split-operand MFMA flash attention, structured mask)")
 
         # HBM bytes per launch from the PMC counters: collected offline on this same command (separate --pmc passes,
         # tools/pmc_traffic.sh) and committed with its calibration under profiles/; None if the summary is absent
@@ -170,14 +173,14 @@ def main():
             return {"kernel": names[i], "achieved": a, "peak": PEAK_FP32_EQUIV_TFLOPS, "unit": "TFLOP/s",
                     "frac": a / PEAK_FP32_EQUIV_TFLOPS if a else None, "avg_launch_ms": ms[i] / n,
                     "launches": int(cnt[i]), "time_share_of_step": ms[i] * 1e-3 / elapsed,
-                    "mfma_executed_tflops": 6.0 * a if a else None, "mfma_peak_tflops": PEAK_BF16_MFMA_TFLOPS,
+                    "mfma_executed_tflops": nprod * a if a else None, "mfma_peak_tflops": PEAK_16BIT_MFMA_TFLOPS,
                     "algorithmic_flops_per_launch": fl[i] / n, "algorithmic_hbm_bytes_per_launch": by[i] / n,
                     "traffic": pmc.get(keys[i], {}).get("hbm_bytes_per_launch"),
                     "hbm_rate_at_algorithmic_bytes_TBps": by[i] / (ms[i] * 1e-3) / 1e12 if ms[i] > 0 else None}
         roof = {"bound": "mfma", **cls(dom),
                 "note": "achieved = algorithmic fp32 FLOPs (2MNK per Linear; 128 per visible (q,k) pair and head) / summed "
-                        "HIP-event time of the class; peak = dense bf16 MFMA peak / 6 because each fp32 product costs six "
-                        "bf16 MFMA products (bf16x6 split, fp32-class accuracy); the f32-input MFMA path (157.3 TF peak) is "
+                        f"HIP-event time of the class; peak = dense 16-bit MFMA peak / {nprod} because each fp32 product costs {nprod} "
+                        f"MFMA products ({scheme} products, fp32-class accuracy: csrc/split.h); the f32-input MFMA path (157.3 TF peak) is "
                         "selectable with ctrlsim_set_option; traffic = HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, PMC, "
                         "profiles/r01_pmc_traffic.json: measured on this command, averaged over the class's launches)",
                 "other": cls(1 - dom)}

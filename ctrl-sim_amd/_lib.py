@@ -32,6 +32,7 @@ SIGNATURES = {
     "ctrlsim_version": (C.c_char_p, []),
     "ctrlsim_set_option": (I, [I, I]),
     "ctrlsim_split_scheme": (I, []),
+    "ctrlsim_nonfinite_count": (I, [I]),
     "ctrlsim_prof_enable": (None, [I]),
     "ctrlsim_prof_collect": (I, [P, P, P]),
     "ctrlsim_prof_bytes": (I, [P]),

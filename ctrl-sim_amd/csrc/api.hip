@@ -58,7 +58,9 @@ void prof_after(int cls, double flops, hipStream_t st, double bytes) {
 }
 
 static int g_options[OPT_COUNT] = {1, 1, 0, 1};
+int nonfinite_count(int reset);
 extern "C" int ctrlsim_split_scheme() { return CTRLSIM_F16X3; }
+extern "C" int ctrlsim_nonfinite_count(int reset) { return nonfinite_count(reset); }
 int ctrlsim_option(int key) { return (key >= 0 && key < OPT_COUNT) ? g_options[key] : 0; }
 
 extern "C" {

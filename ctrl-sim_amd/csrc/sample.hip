@@ -34,6 +34,10 @@ struct ArgBest {
   int i;
 };
 
+// Races that no finite score won (NaN logits: e.g. an activation beyond the fp16 range of the split operands, csrc/split.h):
+// counted here, the token falls back to a valid id, and ctrlsim_nonfinite_count lets the host fail loudly.
+__device__ int g_nonfinite = 0;
+
 __device__ __forceinline__ ArgBest wave_argmax(double s, int i) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -76,7 +80,8 @@ __global__ __launch_bounds__(256) void sample_rtg_kernel(const float* __restrict
       const double sc = ((double)lg[i * 3 + c] + tilts[c] * lin) - log((double)q);
       if (sc > best) { best = sc; bi = i; }
     }
-    const ArgBest r = wave_argmax(best, bi);
+    ArgBest r = wave_argmax(best, bi);
+    if (r.i >= R) { r.i = 0; if (lane == 0) atomicAdd(&g_nonfinite, 1); }
     if (lane == 0) hist_rtg[((size_t)sv * Tmax + t) * 3 + c] = r.i;
   }
 }
@@ -136,7 +141,8 @@ __global__ __launch_bounds__(256) void sample_action_kernel(const float* __restr
     const double sc = (double)(lg[i] / temperature) - log((double)q);
     if (sc > best) { best = sc; bi = i; }
   }
-  const ArgBest r = wave_argmax(best, bi);
+  ArgBest r = wave_argmax(best, bi);
+  if (r.i >= V) { r.i = zero_token; if (lane == 0) atomicAdd(&g_nonfinite, 1); }
   if (lane == 0) { hist_tok[(size_t)sv * Tmax + t] = r.i; act_now[sv] = r.i; }
 }
 
@@ -162,4 +168,15 @@ int launch_sample_action(const float* act_logits, int A, int V, const int* mem_c
   hipLaunchKernelGGL(sample_action_kernel, dim3((SN + 3) / 4), dim3(256), shm, st, act_logits, A, V, mem_ctx, mem_slot,
                      temperature, top_p, noise, seed, scenario_id, t, hist_tok, act_now, N, Tmax, SN, zero_token);
   return ctrlsim_launch_status();
+}
+
+// number of sampling races without a finite score since the last reset (synchronises the device)
+int nonfinite_count(int reset) {
+  int n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_nonfinite), sizeof(int)) != hipSuccess) return CTRLSIM_ELAUNCH;
+  if (reset) {
+    const int z = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_nonfinite), &z, sizeof(int)) != hipSuccess) return CTRLSIM_ELAUNCH;
+  }
+  return n;
 }

@@ -209,6 +209,7 @@ class RolloutEngine:
 
     def reset(self):
         st = _lib.stream_ptr()
+        self.lib.ctrlsim_nonfinite_count(1)
         self.hist_states.zero_()
         self.coll.zero_()
         self.hist_tok.fill_(ZERO_ACTION_TOKEN)
@@ -389,6 +390,10 @@ class RolloutEngine:
 
     def results(self):
         torch.cuda.synchronize(self.device)
+        bad = int(self.lib.ctrlsim_nonfinite_count(1))
+        if bad:
+            raise FloatingPointError(f"{bad} sampling races had no finite logit (NaN in the forward pass: an activation beyond "
+                                     "the fp16 range of the split operands, csrc/split.h, or bad weights)")
         return dict(tokens=self.hist_tok.cpu().numpy(), rtg_bins=self.hist_rtg.cpu().numpy(),
                     states=self.hist_states.cpu().numpy(), coll=self.coll.cpu().numpy(),
                     n_groups=self.groups_per_step.copy())

@@ -189,6 +189,10 @@ int ctrlsim_set_option(int key, int value);
 /* Operand split compiled into the library (csrc/split.h): 1 = two fp16 planes / three products (weights pre-scaled by 2^8), 0 = three
  * bf16 planes / six products.  ctrlsim_amd/pack.py packs weight planes and sizes the K/V images accordingly. */
 int ctrlsim_split_scheme(void);
+/* Sampling races (ctrlsim_sample_rtg / _action) that no finite score won since the last reset — NaN logits, e.g. from an
+ * activation beyond the fp16 range of the split operands.  Such a token falls back to a valid id; callers check this count
+ * (>= 0; synchronises the device) and fail.  reset != 0 clears it. */
+int ctrlsim_nonfinite_count(int reset);
 
 const char* ctrlsim_version(void);
 

@@ -474,3 +474,25 @@ def test_decision_transformer_logits_match_reference_fixture():
         _lib.check(lib.ctrlsim_dt_forward_actions(model.handle, 1, t_fill, C.byref(cb.struct), p(ws), p(logits), st), "actions")
         torch.cuda.synchronize()
         np.testing.assert_allclose(logits[0].cpu().numpy(), g[f"decision_transformer_loop_s{seed}_action"], atol=1e-4, rtol=0)
+
+
+def test_nonfinite_logits_are_counted_and_fail_loudly():
+    """NaN logits (what an activation beyond the fp16 range of the split operands would produce) never become an out-of-range
+    token: the race falls back to a valid id, ctrlsim_nonfinite_count reports it and RolloutEngine.results() raises."""
+    lib, p, st = _lib.lib(), _lib.ptr, _lib.stream_ptr()
+    S, N, A, V, R, Tmax = 1, 4, 4, 1000, 350, 3
+    lib.ctrlsim_nonfinite_count(1)
+    act = torch.zeros(1, A, V, device=DEV); act[0, 1] = float("nan")
+    rtg = torch.zeros(1, A, R * 3, device=DEV); rtg[0, 2] = float("nan")
+    ctx0 = torch.zeros(S * N, dtype=torch.int32, device=DEV); slot = torch.arange(N, dtype=torch.int32, device=DEV)
+    tilted = torch.zeros(S * N, dtype=torch.uint8, device=DEV); sid = torch.zeros(S, dtype=torch.int64, device=DEV)
+    hist = torch.full((S, N, Tmax), -7, dtype=torch.int32, device=DEV); now = torch.zeros(S, N, dtype=torch.int32, device=DEV)
+    hr = torch.full((S, N, Tmax, 3), -7, dtype=torch.int32, device=DEV)
+    _lib.check(lib.ctrlsim_sample_action(p(act), A, V, p(ctx0), p(slot), 1.0, 0.0, None, 1, p(sid), 0, p(hist), p(now), S, N, Tmax,
+                                         524, st))
+    _lib.check(lib.ctrlsim_sample_rtg(p(rtg), A, R, p(ctx0), p(slot), p(tilted), (C.c_double * 3)(0, 0, 0), None, None, 1, p(sid), 0,
+                                      p(hr), S, N, Tmax, st))
+    torch.cuda.synchronize()
+    assert lib.ctrlsim_nonfinite_count(0) == 1 + 3                     # one action race, three RTG components
+    assert hist[0, 1, 0].item() == 524 and (hr[0, 2, 0] == 0).all()
+    assert 0 <= hist[0, 0, 0].item() < V and lib.ctrlsim_nonfinite_count(1) == 4 and lib.ctrlsim_nonfinite_count(0) == 0

@@ -3,6 +3,7 @@ committed summaries profiles/r01_b_kernel_stats.md and profiles/r01_pmc_traffic.
 import collections
 import csv
 import json
+import re
 
 GEMM_KEYS = ("gemm_nt_bf16x6", "ffn_fused_bf16x6")
 ATTN_KEYS = ("attention_bf16x6",)
@@ -10,6 +11,15 @@ ATTN_KEYS = ("attention_bf16x6",)
 
 def short(n):
     n = n.replace("void ", "").replace("(anonymous namespace)::", "")
+    if n.startswith("_Z"):                      # rocprofv3 leaves names with _Float16 parameters mangled: recover name<template args>
+        m = re.match(r"_Z+N?(?:12_GLOBAL__N_1)?(\d+)", n)
+        if m:
+            k = int(m.group(1)); start = m.end(); name = n[start:start + k]; rest = n[start + k:]
+            t = re.match(r"I((?:L[ib]\d+E)+)E", rest)
+            if t:
+                vals = re.findall(r"L([ib])(\d+)E", t.group(1))
+                name += "<" + ", ".join(v if ty == "i" else ("true" if v == "1" else "false") for ty, v in vals) + ">"
+            return name
     return n.split("(")[0]
 
 
@@ -47,8 +57,8 @@ def main():
               f"| Linear class: gemm_nt_bf16x6_kernel (all variants) + ffn_fused_bf16x6_kernel | {gt / gc / 1e6:.4f} ms | {r['avg_launch_ms']:.4f} ms | {gc} / {r['launches']} | {100 * gt / tot:.1f} % |",
               f"| attention_bf16x6_kernel (causal + key-padding) | {at / ac / 1e6:.4f} ms | {o['avg_launch_ms']:.4f} ms | {ac} / {o['launches']} | {100 * at / tot:.1f} % |",
               "",
-              f"Roofline line of that run: Linear class {r['achieved']:.1f} TFLOP/s fp32-equivalent = {r['frac']:.3f} of the 416.7 TFLOP/s bf16x6 roof",
-              f"({r['mfma_executed_tflops']:.0f} TFLOP/s of bf16 MFMA issued), {100 * r['time_share_of_step']:.1f} % of the step; attention class {o['achieved']:.1f} TFLOP/s",
+              f"Roofline line of that run: Linear class {r['achieved']:.1f} TFLOP/s fp32-equivalent = {r['frac']:.3f} of the {r['peak']:.1f} TFLOP/s split-operand roof",
+              f"({r['mfma_executed_tflops']:.0f} TFLOP/s of 16-bit MFMA issued), {100 * r['time_share_of_step']:.1f} % of the step; attention class {o['achieved']:.1f} TFLOP/s",
               f"fp32-equivalent = {o['frac']:.3f}, {100 * o['time_share_of_step']:.1f} % of the step.", "",
               "The HIP-event interval brackets each launch on the launch stream, so it includes a few microseconds of dispatch gap; the two",
               "averages agree to within that gap."]
