@@ -1,10 +1,10 @@
-// Streaming attention with fp32-class accuracy on the bf16 MFMA (gfx950): the split-operand variant of attention.hip.
+// Streaming attention with fp32-class accuracy on the 16-bit MFMA (gfx950): the split-operand variant of attention.hip.
 //
 // Same contract, modes, masks and work split as attention.hip (read its header first).  Difference: every fp32 operand
-// of the two matrix products is split into three bf16 terms (x = hi + mid + lo) and each product is evaluated as its
-// six leading partial products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (see gemm_bf16x6.hip for the error
-// argument: dropped terms <= 2^-23 relative).  Per 32-key sub-tile a wave issues 24 bf16 MFMAs (768 matrix-pipe
-// cycles) instead of 32 f32-input MFMAs (2048 cycles).
+// of the two matrix products is split into NPL 16-bit planes and each product is evaluated as its leading partial products
+// with fp32 accumulation (csrc/split.h: two fp16 planes / three products by default, three bf16 planes / six products as the
+// alternative; "plane 3" / "bf16" below read NPL / the plane type).  Per 32-key sub-tile a wave issues 12 (24) 16-bit MFMAs
+// = 384 (768) matrix-pipe cycles instead of 32 f32-input MFMAs (2048 cycles).
 //
 //   S^T = K.Q^T   A = K rows  (bf16 planes in LDS [3][k-step 2][half 2][64 keys][8]: a wave's ds_read_b128 of a fragment is
 //                 two contiguous 512-byte spans, conflict-free without padding),

@@ -2,8 +2,8 @@
 //
 //     y = LayerNorm( x + W2 . relu(W1 . x + b1) + b2 ) * gamma + beta          x, y: [M, 256] fp32 (y may alias x)
 //
-// as ONE kernel with fp32-class accuracy on the bf16 MFMA (operand split x = hi + mid + lo, six partial products per
-// fp32 product: see gemm_bf16x6.hip).  The [M, F] hidden activation never exists in memory:
+// as ONE kernel with fp32-class accuracy on the 16-bit MFMA (operand split into NPL planes, csrc/split.h: two fp16 planes and
+// three partial products per fp32 product by default; register / block sizes below are quoted for three bf16 planes).  The [M, F] hidden activation never exists in memory:
 //
 //   * one wave owns 32 rows of x for the whole block.  Their transposed, split fragments X^T (the MFMA B operand of the
 //     first product: 16 k-steps x 3 planes = 192 registers) and the output accumulators Y^T [256 x 32] (128 registers)

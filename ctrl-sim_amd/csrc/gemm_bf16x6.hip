@@ -1,20 +1,19 @@
-// fp32-accurate GEMM on the bf16 MFMA: every fp32 operand is split into three bf16 terms (x = hi + mid + lo, 3 x 8
-// significant bits = the whole fp32 mantissa) and the product is evaluated as the six leading partial products
-//     a.b ~= hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid          (dropped terms <= 2^-23 relative)
-// with fp32 accumulation inside v_mfma_f32_32x32x16_bf16.  The result carries fp32-class error (measured against an
-// fp64 reference in tests/test_gpu_ops.py: same order as the f32-input MFMA kernel) while the matrix pipe runs at
-// 16x the f32-input MFMA rate for 6x the instructions: a 2.67x higher matrix roof (417 TFLOP/s fp32-equivalent).
-// Token parity with the reference is unaffected (fixtures: bit-exact tokens, logits within 1e-4).
+// fp32-accurate GEMM on the 16-bit MFMA: every fp32 operand is split into NPL 16-bit planes whose sum is the value and the
+// product is evaluated as its leading partial products with fp32 accumulation inside the MFMA (csrc/split.h: two fp16 planes
+// and three products by default — roof 833 TFLOP/s fp32-equivalent; three bf16 planes and six products — 417 — as the
+// range-safe alternative; file and kernel names keep the historical "bf16x6").  The result carries fp32-class error (measured
+// against an fp64 reference in tests/test_gpu_ops.py: same order as the f32-input MFMA kernel); token parity with the reference
+// is unaffected (fixtures: bit-exact tokens, logits within 1e-4).
 //
-// Weights are split ONCE at pack time (ctrlsim_amd/pack.py) into slab-major planes  W3[K/16][3][2][N][8] bf16  (the
-// two 8-element halves of a 16-wide k-step are separate sub-planes) so a workgroup's K-slab of a sub-plane is one
-// contiguous 16-byte-per-row stream and the LDS image [plane][half][row][8] makes every fragment read of a wave two
-// contiguous 512-byte spans (no bank conflicts).  Activations stay fp32 in HBM and are split in registers while being
-// staged into LDS (v_cvt_pk_bf16_f32, round-to-nearest-even).
+// Weights are split ONCE at pack time (ctrlsim_amd/pack.py, pre-scaled by WSCALE) into slab-major planes
+// W3[K/16][NPL][2][N][8]  (the two 8-element halves of a 16-wide k-step are separate sub-planes) so a workgroup's K-slab of a
+// sub-plane is one contiguous 16-byte-per-row stream and the LDS image [plane][half][row][8] makes every fragment read of a wave
+// two contiguous 512-byte spans (no bank conflicts).  Activations stay fp32 in HBM and are split in registers while being
+// staged into LDS (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32, round-to-nearest-even); the epilogue multiplies by 1 / WSCALE.
 //
 // Tiling: 256 threads = 4 waves, wave tile 64x64 (2x2 MFMA tiles, 64 accumulator registers), arranged
-//   2x2 -> workgroup tile 128 x 128, 48 KB of LDS, THREE workgroups per CU     (plain Linear)
-//   1x4 -> workgroup tile  64 x 256, 60 KB of LDS, two workgroups per CU       (Linear + LayerNorm: whole rows)
+//   2x2 -> workgroup tile 128 x 128, 34 KB of LDS (48 with three planes), THREE workgroups per CU   (plain Linear)
+//   1x4 -> workgroup tile  64 x 256, 40 KB of LDS (60), three workgroups per CU                     (Linear + LayerNorm: whole rows)
 // One LDS stage = one 16-wide k-step, double buffered, one barrier per k-step.  Several independent workgroups per CU
 // are what overlaps the phases: measured on the previous one-workgroup-per-CU version (8 waves in barrier lock-step)
 // the k-loop, its operand staging and the epilogue simply added up (0.19 + 0.18 + 0.17 ms on the FFN-1 shape).
@@ -41,7 +40,13 @@ __device__ __forceinline__ void term(f32x16 (&acc)[MR][2], const opx8 (&fa)[MR][
 struct KvImg { op_t* img; int L; int nkt; int k_col0; };   // L = rows (keys) per context
 
 template <int WR, int WC, int MR, bool RELU, bool RESID, bool LN, bool KVIMG = false>
-__global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? 3 : 2)) void gemm_nt_bf16x6_kernel(
+#ifndef GEMM_OCC_22
+#define GEMM_OCC_22 3
+#endif
+#ifndef GEMM_OCC_14
+#define GEMM_OCC_14 3        // 1x4 (LayerNorm) tiles: 40 KB of LDS with two planes -> three workgroups per CU (+24 % on out_proj+LN)
+#endif
+__global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC_22 : GEMM_OCC_14)) void gemm_nt_bf16x6_kernel(
     const float* __restrict__ A, int lda, const op_t* __restrict__ W3,   // [K/16][NPL][2][n_total][8]
     const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* R, int ldr, float* C, int ldc, int M, int N, int K, int m_tiles, int n_tiles,   // C may alias R: no restrict
@@ -345,7 +350,7 @@ int launch_gemm_nt_bf16x6_kv(const float* A, int lda, const void* W3, int n_tota
   const int XM = (wide || small) ? 64 : 128, XN = wide ? 256 : 128;
   const int m_tiles = (M + XM - 1) / XM, n_tiles = (N + XN - 1) / XN;
   const int total = ((m_tiles + 7) / 8) * 8 * n_tiles;
-  const int resident = 256 * (wide ? 2 : (small ? 4 : 3));
+  const int resident = 256 * (wide ? GEMM_OCC_14 : (small ? 4 : GEMM_OCC_22));
   const int grid = total < resident ? total : resident;
   dim3 g(grid), b(256);
   const op_t* w = static_cast<const op_t*>(W3);
