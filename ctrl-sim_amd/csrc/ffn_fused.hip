@@ -28,8 +28,8 @@ constexpr int FF_BLK = NPL * 16 * 2 * 32 * 8;      // 16-bit elements of one wei
 constexpr int FF_PIECES = FF_BLK / (256 * 8);      // 16-byte-per-thread LDS-DMA pieces of a block (8 / 12)
 constexpr int FF_RING = 3;
 #ifndef FFN_PF
-#define FFN_PF 2                                   // LDS fragment prefetch distance in k-steps (2 or 3; four register buffers)
-#endif
+#define FFN_PF (NPL == 2 ? 3 : 2)                   // LDS fragment prefetch distance in k-steps (four register buffers); 3 needs the
+#endif                                             // registers the two-plane scheme frees (+1.5 %), with three planes it spilled
 constexpr int FF_CP = DM + 4;                      // row pitch (floats) of the epilogue staging
 // LDS: the ring, re-used by the epilogue as 4 x 32 rows of FF_CP floats — whichever is larger — then b1 (F floats)
 constexpr size_t FF_RING_BYTES = (size_t)FF_RING * FF_BLK * sizeof(op_t) > (size_t)4 * 32 * FF_CP * 4

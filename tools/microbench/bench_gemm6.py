@@ -16,7 +16,7 @@ def timeit(fn, n=10):
     b.record(); torch.cuda.synchronize(); return a.elapsed_time(b)/n
 L=2304; M=B*L
 g=torch.randn(256,device=DEV)
-for tile in (0,):
+for tile in ((0, 1, 2) if len(sys.argv) > 2 else (0,)):
   lib.ctrlsim_set_option(2,tile)
   print('tile option',tile)
   for (N,K,relu,res,ln,name) in [(768,256,0,0,0,'qkv'),(256,256,0,1,0,'out+res'),(256,256,0,1,1,'out+res+LN'),(1024,256,1,0,0,'ffn1'),(256,1024,0,1,0,'ffn2+res'),(256,1024,0,1,1,'ffn2+res+LN')]:
