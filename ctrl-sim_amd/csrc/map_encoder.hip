@@ -29,24 +29,28 @@ struct MapPoolWeights {
   const float* mb;      // [256]
 };
 
-__global__ __launch_bounds__(256) void map_pool_kernel(int NP, int P, int M, const float* __restrict__ road_pts,
+// G polylines per workgroup (2 when a polyline has <= 128 points): the thread-per-point phase then uses 200 of the 256 lanes
+// instead of 100 — that phase is 60 % of the kernel's instructions.
+__global__ __launch_bounds__(256) void map_pool_kernel(int NP, int P, int M, int G, int total, const float* __restrict__ road_pts,
                                                        MapPoolWeights w, float* __restrict__ attn_pre,
                                                        unsigned char* __restrict__ src_pad) {
   __shared__ float pts[MAXNP][3];
   __shared__ float stat[MAXNP][2];
   __shared__ float sc[MAXNP][8];
-  __shared__ float pooled[8][DM];
-  __shared__ int any_exist;
-  const int bp = blockIdx.x, tid = threadIdx.x;
-  const float* src = road_pts + (size_t)bp * NP * 3;
-  if (tid == 0) any_exist = 0;
+  __shared__ float pooled[2][8][DM];
+  __shared__ int any_exist[2];
+  const int bp0 = blockIdx.x * G, tid = threadIdx.x;
+  const int g_here = min(G, total - bp0);                              // polylines of this block
+  const int n_pts = g_here * NP;
+  const float* src = road_pts + (size_t)bp0 * NP * 3;
+  if (tid < 2) any_exist[tid] = 0;
   __syncthreads();
-  for (int i = tid; i < NP * 3; i += blockDim.x) pts[i / 3][i % 3] = src[i];
+  for (int i = tid; i < n_pts * 3; i += blockDim.x) pts[i / 3][i % 3] = src[i];
   __syncthreads();
   // ---- phase 1: per point LN statistics and head scores
-  if (tid < NP) {
+  if (tid < n_pts) {
     const float x = pts[tid][0], y = pts[tid][1], e = pts[tid][2];
-    if (e != 0.f) any_exist = 1;
+    if (e != 0.f) any_exist[tid >= NP] = 1;
     float sum = 0.f;
     for (int c = 0; c < DM; ++c) sum += fmaf(w.W1[c * 3 + 2], e, fmaf(w.W1[c * 3 + 1], y, fmaf(w.W1[c * 3], x, w.b1[c])));
     const float mean = sum * (1.f / 256.f);
@@ -71,52 +75,57 @@ __global__ __launch_bounds__(256) void map_pool_kernel(int NP, int P, int M, con
     for (int h = 0; h < 8; ++h) sc[tid][h] = s8[h];
   }
   __syncthreads();
-  // ---- softmax over points, per head (key padding: non-existing points; all padded -> point 0 visible)
-  if (tid < 8) {
-    const bool none = any_exist == 0;
+  // ---- softmax over the points of a polyline, per head (key padding: non-existing points; all padded -> point 0 visible)
+  if (tid < 8 * g_here) {
+    const int g = tid >> 3, hd = tid & 7, p0 = g * NP;
+    const bool none = any_exist[g] == 0;
     float mx = -__builtin_inff();
     for (int p = 0; p < NP; ++p) {
-      const bool vis = pts[p][2] != 0.f || (none && p == 0);
-      if (vis) mx = fmaxf(mx, sc[p][tid]);
+      const bool vis = pts[p0 + p][2] != 0.f || (none && p == 0);
+      if (vis) mx = fmaxf(mx, sc[p0 + p][hd]);
     }
     float z = 0.f;
     for (int p = 0; p < NP; ++p) {
-      const bool vis = pts[p][2] != 0.f || (none && p == 0);
-      const float ev = vis ? expf(sc[p][tid] - mx) : 0.f;
-      sc[p][tid] = ev;
+      const bool vis = pts[p0 + p][2] != 0.f || (none && p == 0);
+      const float ev = vis ? expf(sc[p0 + p][hd] - mx) : 0.f;
+      sc[p0 + p][hd] = ev;
       z += ev;
     }
     const float inv = 1.0f / z;
-    for (int p = 0; p < NP; ++p) sc[p][tid] *= inv;
+    for (int p = 0; p < NP; ++p) sc[p0 + p][hd] *= inv;
   }
   __syncthreads();
-  // ---- phase 2: thread = channel; pooled[h][c] = sum_pt a[pt,h] * h1[pt,c]
+  // ---- phase 2: thread = channel; pooled[g][h][c] = sum_pt a[pt,h] * h1[pt,c]
   {
     const int c = tid;
-    const float w0 = w.W1[c * 3], w1 = w.W1[c * 3 + 1], w2 = w.W1[c * 3 + 2], bb = w.b1[c], g = w.ln_g[c], be = w.ln_b[c];
-    float acc[8];
+    const float w0 = w.W1[c * 3], w1 = w.W1[c * 3 + 1], w2 = w.W1[c * 3 + 2], bb = w.b1[c], gm = w.ln_g[c], be = w.ln_b[c];
+    for (int g = 0; g < g_here; ++g) {
+      float acc[8];
 #pragma unroll
-    for (int h = 0; h < 8; ++h) acc[h] = 0.f;
-    for (int p = 0; p < NP; ++p) {
-      const float yv = fmaf(w2, pts[p][2], fmaf(w1, pts[p][1], fmaf(w0, pts[p][0], bb)));
-      const float hv = fmaxf(fmaf((yv - stat[p][0]) * stat[p][1], g, be), 0.f);
+      for (int h = 0; h < 8; ++h) acc[h] = 0.f;
+      for (int p = g * NP; p < (g + 1) * NP; ++p) {
+        const float yv = fmaf(w2, pts[p][2], fmaf(w1, pts[p][1], fmaf(w0, pts[p][0], bb)));
+        const float hv = fmaxf(fmaf((yv - stat[p][0]) * stat[p][1], gm, be), 0.f);
 #pragma unroll
-      for (int h = 0; h < 8; ++h) acc[h] = fmaf(sc[p][h], hv, acc[h]);
+        for (int h = 0; h < 8; ++h) acc[h] = fmaf(sc[p][h], hv, acc[h]);
+      }
+#pragma unroll
+      for (int h = 0; h < 8; ++h) pooled[g][h][c] = acc[h];
     }
-#pragma unroll
-    for (int h = 0; h < 8; ++h) pooled[h][c] = acc[h];
   }
   __syncthreads();
   // ---- phase 3: thread = output channel j of head j>>5
   {
     const int j = tid, h = j >> 5;
-    float o = w.mb[j];
-    for (int c = 0; c < DM; ++c) o = fmaf(pooled[h][c], w.Mt[c * DM + j], o);
-    attn_pre[(size_t)bp * DM + j] = o;
+    for (int g = 0; g < g_here; ++g) {
+      float o = w.mb[j];
+      for (int c = 0; c < DM; ++c) o = fmaf(pooled[g][h][c], w.Mt[c * DM + j], o);
+      attn_pre[(size_t)(bp0 + g) * DM + j] = o;
+    }
   }
-  if (tid == 0) {
-    const int b = bp / P, p = bp - b * P;
-    src_pad[(size_t)b * M + p] = any_exist ? 0 : 1;
+  if (tid < g_here) {
+    const int bp = bp0 + tid, b = bp / P, p = bp - b * P;
+    src_pad[(size_t)b * M + p] = any_exist[tid] ? 0 : 1;
   }
 }
 
@@ -124,6 +133,8 @@ int launch_map_pool(int B, int P, int NP, int M, const float* road_pts, MapPoolW
                     unsigned char* src_pad, hipStream_t st) {
   if (B * P <= 0) return CTRLSIM_OK;
   if (NP < 1 || NP > MAXNP) return CTRLSIM_EINVAL;
-  hipLaunchKernelGGL(map_pool_kernel, dim3(B * P), dim3(256), 0, st, NP, P, M, road_pts, w, attn_pre, src_pad);
+  const int G = NP <= 128 ? 2 : 1, total = B * P;
+  hipLaunchKernelGGL(map_pool_kernel, dim3((total + G - 1) / G), dim3(256), 0, st, NP, P, M, G, total, road_pts, w, attn_pre,
+                     src_pad);
   return ctrlsim_launch_status();
 }
