@@ -14,17 +14,24 @@
 // Tiling: 256 threads = 4 waves, wave tile 64x64 (2x2 MFMA tiles, 64 accumulator registers), arranged
 //   2x2 -> workgroup tile 128 x 128, 34 KB of LDS (48 with three planes), THREE workgroups per CU   (plain Linear)
 //   1x4 -> workgroup tile  64 x 256, 40 KB of LDS (60), three workgroups per CU                     (Linear + LayerNorm: whole rows)
-// One LDS stage = one 16-wide k-step, double buffered, one barrier per k-step.  Several independent workgroups per CU
+// One LDS stage = one 16-wide k-step, one barrier per k-step; the 2x2 tiles keep THREE stages (W planes arrive by LDS-DMA two
+// k-steps ahead), the 1x4 tiles two; the fp32 A rows are prefetched two k-steps ahead into alternating register sets by
+// inline-asm loads with counted vmcnt waits (hipcc's own wait insertion drains everything: see gload_a / wait_a;
+// tools/check_prefetch_regs.py checks the generated ISA).  Several independent workgroups per CU
 // are what overlaps the phases: measured on the previous one-workgroup-per-CU version (8 waves in barrier lock-step)
 // the k-loop, its operand staging and the epilogue simply added up (0.19 + 0.18 + 0.17 ms on the FFN-1 shape).
 // Persistent workgroups with the XCD-aware tile order of gemm.hip; the next tile's first A slab is prefetched before
 // the epilogue; the epilogue stages half the tile's rows at a time through LDS for 16-byte bias / residual / store
 // traffic and, for LN, normalises whole rows there (one wave per row).
 #include "split.h"
+#include <type_traits>
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define XK 16
+// LDS stages of the k-loop: three for the 2x2 tiles of the two-plane scheme (16 KB per stage, 3 workgroups per CU = 144 KB);
+// two where a third would cost a resident workgroup (1x4 tiles: 20 KB per stage; three planes: 24 KB)
+#define GEMM_RING(WR_, WC_) ((NPL == 2 && (WR_) == 2 && (WC_) == 2) ? 3 : 2)
 
 template <int PA, int PB, int MR>
 __device__ __forceinline__ void term(f32x16 (&acc)[MR][2], const opx8 (&fa)[MR][NPL], const opx8 (&fb)[2][NPL]) {
@@ -61,9 +68,10 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
   constexpr int CP = XN + 4, CR = 32 * WR;         // epilogue chunk: CR rows x XN columns of fp32
   constexpr int NA = (XM + 63) / 64;               // f32x4 loads of A per thread and stage
   constexpr int NW = 2 * NPL * XN / 256;           // 16-byte DMA chunks of W per thread and stage
+  constexpr int RING = GEMM_RING(WR, WC);          // LDS stages: the W DMA runs RING - 1 k-steps ahead
   static_assert(!LN || (WR == 1 && WC == 4), "LayerNorm epilogue needs whole 256-wide rows");
   static_assert(XM % 64 == 0, "A staging assumes whole 64-row groups");
-  extern __shared__ __attribute__((aligned(16))) op_t lds[];   // max(2 * STAGE elements, the epilogue chunk): see the launcher
+  extern __shared__ __attribute__((aligned(16))) op_t lds[];   // max(RING * STAGE elements, the epilogue chunk): see the launcher
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int l31 = lane & 31, half = lane >> 5;
@@ -81,18 +89,27 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
 
   // ---- staging: A through registers (fp32 -> 3 bf16 planes), W planes by LDS-DMA (global_load_lds, 16 B per lane:
   // the W part of a stage is lane-linear in exactly the order idx = tid + 256*i, so the DMA needs no VGPRs at all)
-  f32x4 ra[NA];
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // A is prefetched TWO k-steps ahead into alternating register sets (the fp32 rows come from HBM: one k-step of MFMAs does
+  // not cover that latency), W RING - 1 k-steps ahead.  All loads are unconditional (rows / columns past the edge are clamped:
+  // they are computed and never stored) so that the in-order vmcnt arithmetic of the k-loop is exact.
+  f32x4 ra[2][NA];
   const size_t w_slab = (size_t)NPL * n_total * XK;  // elements per 16-wide K-slab of W3
-  auto gload_a = [&](int kt) {
+  auto gload_a = [&](int kt, auto SET) {
+    constexpr int set = decltype(SET)::value;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int idx = tid + 256 * i, r = idx >> 2, c = (idx & 3) * 4;
-      const int ga = bm + r;
+      int ga = bm + r;
+      ga = ga < M ? ga : M - 1;
 #ifndef ABL_NO_ALOAD
-      ra[i] = ga < M ? *reinterpret_cast<const f32x4*>(A + (size_t)ga * lda + kt * XK + c) : zero4;
+      // inline asm: hipcc's own s_waitcnt insertion answers a register load that is consumed two k-steps later with vmcnt(0)
+      // (draining the prefetches behind it); loads it does not see are waited for by the counted wait_a() below instead
+      const float* src = A + (size_t)ga * lda + kt * XK + c;
+      f32x4 t;                                     // (a local: clang rejects captured arrays as asm operands in a generic lambda)
+      asm volatile("global_load_dwordx4 %0, %1, off ; A-PREFETCH" : "=v"(t) : "v"(src) : "memory");
+      ra[set][i] = t;
 #else
-      ra[i] = zero4 + (float)(ga + kt);
+      ra[set][i] = f32x4{0.f, 0.f, 0.f, 0.f} + (float)(ga + kt);
 #endif
     }
   };
@@ -108,28 +125,56 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
   };
-  auto sstore_a = [&](int buf) {
+  // the register set becomes valid once at most NEWER younger VMEM operations are in flight (in-order return); the "+v" ties keep
+  // every use of the set behind the wait
+  auto wait_a = [&](auto SET, auto NEWER) {
+    constexpr int set = decltype(SET)::value, newer = decltype(NEWER)::value;
+    static_assert(newer < 64, "vmcnt is a 6-bit counter");
+#ifndef ABL_NO_ALOAD
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      f32x4 t = ra[set][i];
+      if (i == 0) asm volatile("s_waitcnt vmcnt(%1) ; A-WAIT" : "+v"(t) : "n"(newer) : "memory");
+      else asm volatile("" : "+v"(t));
+      ra[set][i] = t;
+    }
+#endif
+  };
+  auto sstore_a = [&](auto SET, int buf) {
+    constexpr int set = decltype(SET)::value;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int idx = tid + 256 * i, r = idx >> 2, c = (idx & 3) * 4;
       u32x2 pl[NPL];
 #ifndef ABL_NO_SPLIT
-      split_quad(ra[i], pl);
+      split_quad(ra[set][i], pl);
 #else
 #pragma unroll
-      for (int q = 0; q < NPL; ++q) pl[q] = u32x2{__float_as_uint(ra[i][0]), __float_as_uint(ra[i][1 + (q & 1)])};
+      for (int q = 0; q < NPL; ++q) pl[q] = u32x2{__float_as_uint(ra[set][i][0]), __float_as_uint(ra[set][i][1 + (q & 1)])};
 #endif
       op_t* Ab = lds + buf * STAGE + (c >> 3) * (A_PLANE / 2) + r * 8 + (c & 7);
 #pragma unroll
       for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x2*>(Ab + q * A_PLANE) = pl[q];
     }
   };
+  // end of a k-step: this wave's LDS writes are complete (lgkmcnt(0)), every VMEM operation except the newest `keep` ones has
+  // returned (vmcnt counts in order; gfx9 encoding: vmcnt = bits 3:0 and 15:14, expcnt(7) = no wait), then the barrier
+  auto step_barrier = [&](bool newer_in_flight) {
+    constexpr int keep = (RING == 3 ? NW : 0) + NA;
+    asm volatile("" ::: "memory");
+    if (newer_in_flight) __builtin_amdgcn_s_waitcnt(0x0070 | (keep & 15) | ((keep >> 4) << 14));
+    else __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  using set0 = std::integral_constant<int, 0>;
+  using set1 = std::integral_constant<int, 1>;
 
   const int nk = K / XK;
   int id = blockIdx.x;
   while (id < total_ids && !tile_of(id, bm, bn)) id += gridDim.x;
   if (id >= total_ids) return;
-  gload_a(0);
+  gload_a(0, set0{});
   for (;;) {
     f32x16 acc[MR][2];
 #pragma unroll
@@ -139,17 +184,20 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    dma_w(0, 0);
-    sstore_a(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
-      if (kt + 1 < nk) {
+    // one k-step on stage `cur`; SET = register set that receives A of step kt + 2 (it held step kt, staged one step ago)
+    auto kstep = [&](int kt, int cur, auto SET) {
+      constexpr int set = decltype(SET)::value;
+      using other = std::integral_constant<int, set ^ 1>;
+      const int nxt = cur + 1 == RING ? 0 : cur + 1;
+      // the prefetches are issued UNCONDITIONALLY (past the end of K they re-fetch the last slab into a released stage / a dead
+      // register set): a conditional issue makes the number of operations in flight path dependent, and both hipcc's own
+      // vmcnt for the register set and the counted wait below would have to assume the worst (vmcnt(0): no prefetch at all)
+      const int kpre = kt + 2 < nk ? kt + 2 : nk - 1;
 #ifndef ABL_NO_DMA
-        dma_w(kt + 1, cur ^ 1);                    // stage cur^1 was released by the barrier that ended kt-1
+      if (RING == 3) dma_w(kpre, nxt + 1 == RING ? 0 : nxt + 1);     // stage of step kt - 1: released by its barrier
+      else dma_w(kt + 1 < nk ? kt + 1 : nk - 1, nxt);
 #endif
-        gload_a(kt + 1);
-      }
+      gload_a(kpre, SET);
       {
         const op_t* Ab = lds + cur * STAGE + half * (A_PLANE / 2) + (wr * WMR + l31) * 8;
         const op_t* Wb = lds + cur * STAGE + NPL * A_PLANE + half * (W_PLANE / 2) + (wc * 64 + l31) * 8;
@@ -188,8 +236,30 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
         for (int p = 0; p < NPL; ++p) { asm volatile("" ::"v"(fa[0][p]), "v"(fa[MR - 1][p]), "v"(fb[0][p]), "v"(fb[1][p])); }
 #endif
       }
-      if (kt + 1 < nk) sstore_a(cur ^ 1);
-      __syncthreads();
+      wait_a(other{}, std::integral_constant<int, NW + NA>{});   // younger: this step's two prefetches
+      sstore_a(other{}, nxt);                      // A of step kt + 1 (loaded during step kt - 1)
+      // W of step kt + 1 must have landed: with three stages it was issued BEFORE the A rows just consumed (in-order return);
+      // with two it is the oldest operation of this step.  Only this step's prefetches may stay in flight — none after the
+      // last step: the epilogue reuses the stages.
+      step_barrier(kt + 1 < nk);
+    };
+
+    dma_w(0, 0);
+    if (RING == 3) dma_w(nk > 1 ? 1 : 0, 1);
+    gload_a(nk > 1 ? 1 : 0, set1{});
+    wait_a(set0{}, std::integral_constant<int, (RING - 1) * NW + NA>{});
+    sstore_a(set0{}, 0);
+    step_barrier(true);
+    {
+      int cur = 0;
+      for (int kt = 0; kt < nk; kt += 2) {
+        kstep(kt, cur, set0{});
+        cur = cur + 1 == RING ? 0 : cur + 1;
+        if (kt + 1 < nk) {
+          kstep(kt + 1, cur, set1{});
+          cur = cur + 1 == RING ? 0 : cur + 1;
+        }
+      }
     }
 
     // ---- epilogue: two chunks of CR rows (MFMA tile row a of every wave row) staged through LDS
@@ -199,7 +269,7 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
     int nid = id + gridDim.x;
     while (nid < total_ids && !tile_of(nid, bm, bn)) nid += gridDim.x;
     const bool have_next = nid < total_ids;
-    if (have_next) gload_a(0);
+    if (have_next) gload_a(0, set0{});
 #ifdef ABL_NO_EPI
 #pragma unroll
     for (int a = 0; a < MR; ++a)
@@ -354,8 +424,8 @@ int launch_gemm_nt_bf16x6_kv(const float* A, int lda, const void* W3, int n_tota
   const int grid = total < resident ? total : resident;
   dim3 g(grid), b(256);
   const op_t* w = static_cast<const op_t*>(W3);
-  // two k-step stages of NPL planes each, or the epilogue's fp32 chunk (32 rows per wave row x XN + 4 columns), whichever is larger
-  const size_t shm_k = (size_t)2 * NPL * (XM + XN) * XK * sizeof(op_t);
+  // the k-step stages (NPL planes each), or the epilogue's fp32 chunk (32 rows per wave row x XN + 4 columns), whichever is larger
+  const size_t shm_k = (size_t)(wide ? GEMM_RING(1, 4) : GEMM_RING(2, 2)) * NPL * (XM + XN) * XK * sizeof(op_t);
   const size_t shm_e = (size_t)(wide ? 32 : 64) * (XN + 4) * sizeof(float);
   const size_t shm = shm_k > shm_e ? shm_k : shm_e;
 #define GEMM6_LAUNCH(WR_, WC_, RELU_, RESID_, LN_, KV_) GEMM6_LAUNCH_(WR_, WC_, 2, RELU_, RESID_, LN_, KV_)
