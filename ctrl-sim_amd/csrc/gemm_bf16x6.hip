@@ -12,7 +12,7 @@
 // staged into LDS (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32, round-to-nearest-even); the epilogue multiplies by 1 / WSCALE.
 //
 // Tiling: 256 threads = 4 waves, wave tile 64x64 (2x2 MFMA tiles, 64 accumulator registers), arranged
-//   2x2 -> workgroup tile 128 x 128, 34 KB of LDS (48 with three planes), THREE workgroups per CU   (plain Linear)
+//   2x2 -> workgroup tile 128 x 128, 48 KB of LDS (three 16 KB stages; two 24 KB stages with three planes), THREE workgroups per CU
 //   1x4 -> workgroup tile  64 x 256, 40 KB of LDS (60), three workgroups per CU                     (Linear + LayerNorm: whole rows)
 // One LDS stage = one 16-wide k-step, one barrier per k-step; the 2x2 tiles keep THREE stages (W planes arrive by LDS-DMA two
 // k-steps ahead), the 1x4 tiles two; the fp32 A rows are prefetched two k-steps ahead into alternating register sets by
