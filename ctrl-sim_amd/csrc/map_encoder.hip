@@ -11,6 +11,8 @@
 //   attn[h*32+j]= (Wv_h W2)[j,:] . pooled[h] + (Wv_h b2 + bv_h)[j]
 // where h1 = ReLU(LN(W1 (x,y,e) + b1)).  The reference's two 20 000-row GEMMs per context (point MLP layer 2: 2.6 GFLOP,
 // K/V projection: 5.2 GFLOP) become ~0.3 GFLOP of VALU work; results are equal in exact arithmetic.
+// The first layer and its LayerNorm are evaluated in closed form too: centred, gain-scaled weights Wc and the 4x4 Gram matrix G
+// of the centred weights give  LN(.)_c = Wc[c].(x,y,e,1) * rsqrt((x,y,e,1)^T G (x,y,e,1) + eps) + beta_c  with one pass over c.
 // One workgroup per polyline: phase 1 thread-per-point (LN statistics + 8 scores, weights are wave-uniform scalar
 // loads), phase 2 thread-per-channel (softmax-weighted pooling), phase 3 thread-per-output (256x256 folded matrix,
 // stored transposed so the wave reads it coalesced from L2).
@@ -19,9 +21,8 @@
 #define MAXNP 256
 
 struct MapPoolWeights {
-  const float* W1;      // [256,3]
-  const float* b1;      // [256]
-  const float* ln_g;    // [256]
+  const float* Wc;      // [256,4]  g_c * (W1[c,:] - column mean, b1[c] - mean(b1)): LN(W1 p + b1)_c = Wc[c] . (x,y,e,1) * rstd + ln_b[c]
+  const float* G;       // [10]     upper triangle of sum_c wt_c wt_c^T / 256 (wt = Wc without the gain): var = (x,y,e,1)^T G (x,y,e,1)
   const float* ln_b;    // [256]
   const float* U;       // [256,8]
   const float* cb;      // [8]
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(256) void map_pool_kernel(int NP, int P, int M, int
                                                        MapPoolWeights w, float* __restrict__ attn_pre,
                                                        unsigned char* __restrict__ src_pad) {
   __shared__ float pts[MAXNP][3];
-  __shared__ float stat[MAXNP][2];
+  __shared__ float stat[MAXNP];
   __shared__ float sc[MAXNP][8];
   __shared__ float pooled[2][8][DM];
   __shared__ int any_exist[2];
@@ -51,26 +52,21 @@ __global__ __launch_bounds__(256) void map_pool_kernel(int NP, int P, int M, int
   if (tid < n_pts) {
     const float x = pts[tid][0], y = pts[tid][1], e = pts[tid][2];
     if (e != 0.f) any_exist[tid >= NP] = 1;
-    float sum = 0.f;
-    for (int c = 0; c < DM; ++c) sum += fmaf(w.W1[c * 3 + 2], e, fmaf(w.W1[c * 3 + 1], y, fmaf(w.W1[c * 3], x, w.b1[c])));
-    const float mean = sum * (1.f / 256.f);
-    float var = 0.f;
-    for (int c = 0; c < DM; ++c) {
-      const float d = fmaf(w.W1[c * 3 + 2], e, fmaf(w.W1[c * 3 + 1], y, fmaf(w.W1[c * 3], x, w.b1[c]))) - mean;
-      var = fmaf(d, d, var);
-    }
-    const float rstd = 1.0f / sqrtf(var * (1.f / 256.f) + 1e-5f);
+    // LayerNorm statistics in closed form (the layer is affine in the point: pack.py); the mean drops out of the centred weights
+    const float* G = w.G;
+    const float var = x * (G[0] * x + 2.f * (G[1] * y + G[2] * e + G[3])) + y * (G[4] * y + 2.f * (G[5] * e + G[6])) +
+                      e * (G[7] * e + 2.f * G[8]) + G[9];
+    const float rstd = 1.0f / sqrtf(fmaxf(var, 0.f) + 1e-5f);
     float s8[8];
 #pragma unroll
     for (int h = 0; h < 8; ++h) s8[h] = w.cb[h];
     for (int c = 0; c < DM; ++c) {
-      const float yv = fmaf(w.W1[c * 3 + 2], e, fmaf(w.W1[c * 3 + 1], y, fmaf(w.W1[c * 3], x, w.b1[c])));
-      const float hv = fmaxf(fmaf((yv - mean) * rstd, w.ln_g[c], w.ln_b[c]), 0.f);
+      const float d = fmaf(w.Wc[c * 4 + 2], e, fmaf(w.Wc[c * 4 + 1], y, fmaf(w.Wc[c * 4], x, w.Wc[c * 4 + 3])));
+      const float hv = fmaxf(fmaf(d, rstd, w.ln_b[c]), 0.f);
 #pragma unroll
       for (int h = 0; h < 8; ++h) s8[h] = fmaf(hv, w.U[c * 8 + h], s8[h]);
     }
-    stat[tid][0] = mean;
-    stat[tid][1] = rstd;
+    stat[tid] = rstd;
 #pragma unroll
     for (int h = 0; h < 8; ++h) sc[tid][h] = s8[h];
   }
@@ -98,14 +94,14 @@ __global__ __launch_bounds__(256) void map_pool_kernel(int NP, int P, int M, int
   // ---- phase 2: thread = channel; pooled[g][h][c] = sum_pt a[pt,h] * h1[pt,c]
   {
     const int c = tid;
-    const float w0 = w.W1[c * 3], w1 = w.W1[c * 3 + 1], w2 = w.W1[c * 3 + 2], bb = w.b1[c], gm = w.ln_g[c], be = w.ln_b[c];
+    const float w0 = w.Wc[c * 4], w1 = w.Wc[c * 4 + 1], w2 = w.Wc[c * 4 + 2], bb = w.Wc[c * 4 + 3], be = w.ln_b[c];
     for (int g = 0; g < g_here; ++g) {
       float acc[8];
 #pragma unroll
       for (int h = 0; h < 8; ++h) acc[h] = 0.f;
       for (int p = g * NP; p < (g + 1) * NP; ++p) {
-        const float yv = fmaf(w2, pts[p][2], fmaf(w1, pts[p][1], fmaf(w0, pts[p][0], bb)));
-        const float hv = fmaxf(fmaf((yv - stat[p][0]) * stat[p][1], gm, be), 0.f);
+        const float d = fmaf(w2, pts[p][2], fmaf(w1, pts[p][1], fmaf(w0, pts[p][0], bb)));
+        const float hv = fmaxf(fmaf(d, stat[p], be), 0.f);
 #pragma unroll
         for (int h = 0; h < 8; ++h) acc[h] = fmaf(sc[p][h], hv, acc[h]);
       }

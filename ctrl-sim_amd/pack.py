@@ -8,6 +8,7 @@ the model function unchanged in exact arithmetic:
   fold.embed_goal.b    = W_sg[:, :D] b_state3 + W_sg[:, D:] b_goal3 + b_sg
   fold.rtg_table_{goal,veh,road} = E_c @ W_rtg[:, cD:(c+1)D]^T   embed_rtg over three embedding rows (:116-125)
   fold.map.U, fold.map.cb, fold.map.Mt, fold.map.mb         single-seed attention pooling of the map encoder
+  fold.map.Wc, fold.map.G                                   first point-MLP layer + its LayerNorm in closed form
                                                              (modules/map_encoder.py:44-46; see csrc/map_encoder.hip)
 Tensors are laid out back to back in ONE float32 buffer, each aligned to 256 bytes; `names`/`offsets` (in floats)
 are handed to ctrlsim_model_create.
@@ -59,6 +60,15 @@ def fold(dims: Dims, w: dict) -> dict:
         cb[h] = (q[sl] @ (Wk[sl] @ b2 + bk[sl])) * sc
         M[sl, :] = Wv[sl] @ W2
         mb[sl] = Wv[sl] @ b2 + bv[sl]
+    # first point-MLP layer + LayerNorm in closed form: y_c - mean_c(y) = wt_c . (x, y, e, 1) with the column-centred weights
+    # wt_c, so  var = (x, y, e, 1)^T G (x, y, e, 1)  (G = sum_c wt_c wt_c^T / D: 10 numbers) and
+    # LN(y)_c = (g_c wt_c) . (x, y, e, 1) * rstd + beta_c — the kernel evaluates the layer once per point instead of three times
+    W1, b1 = f8(pre + "road_pts_encoder.mlp.0.weight"), f8(pre + "road_pts_encoder.mlp.0.bias")
+    g1 = f8(pre + "road_pts_encoder.mlp.1.weight")
+    Wt = np.concatenate([W1 - W1.mean(0, keepdims=True), (b1 - b1.mean())[:, None]], axis=1)      # [D, 4]
+    G = Wt.T @ Wt / D
+    out["fold.map.Wc"] = Wt * g1[:, None]
+    out["fold.map.G"] = G[np.triu_indices(4)]                            # 00 01 02 03 11 12 13 22 23 33
     out["fold.map.U"] = U
     out["fold.map.cb"] = cb
     out["fold.map.Mt"] = M.T.copy()

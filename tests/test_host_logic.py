@@ -65,6 +65,13 @@ def test_folds_are_exact_in_float64():
     ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(Bp, D)
     h1 = F.relu(F.layer_norm(F.linear(rp, tw[pre + "road_pts_encoder.mlp.0.weight"], tw[pre + "road_pts_encoder.mlp.0.bias"]),
                              (D,), tw[pre + "road_pts_encoder.mlp.1.weight"], tw[pre + "road_pts_encoder.mlp.1.bias"], 1e-5)).view(Bp, d.NP, D)
+    # closed form of the first layer + LayerNorm (fold.map.Wc / fold.map.G)
+    v4 = torch.cat([rp.reshape(Bp, d.NP, 3), torch.ones(Bp, d.NP, 1, dtype=rp.dtype)], -1)
+    G = torch.zeros(4, 4, dtype=rp.dtype); iu = np.triu_indices(4)
+    G[iu[0], iu[1]] = f["fold.map.G"].to(rp.dtype); G = G + G.T - torch.diag(torch.diag(G))
+    var = torch.einsum("bpi,ij,bpj->bp", v4, G, v4)
+    h1_fold = F.relu(v4 @ f["fold.map.Wc"].to(rp.dtype).T * torch.rsqrt(var + 1e-5)[..., None] + tw[pre + "road_pts_encoder.mlp.1.bias"])
+    assert (h1_fold - h1).abs().max() < 2e-6 * max(1.0, h1.abs().max().item())
     sc = h1 @ f["fold.map.U"] + f["fold.map.cb"]                       # [Bp, NP, H]
     sc = sc.masked_fill(mask[:, :, None], float("-inf"))
     a = torch.softmax(sc, 1)
