@@ -19,6 +19,10 @@
 // (measured: 1829 vs 1966 TFLOP/s register-only), and the merge adds / second rescale / 32 registers go away.
 #include "split.h"
 
+#ifndef ATT_TAU
+#define ATT_TAU 8.0f
+#endif
+
 
 #define KT6 64
 #define KV_IMG (2 * NPL * KT6 * HD)   // 16-bit elements of one (context, head, 64-key tile) image: K planes then V^T planes (8 KB per plane pair)
@@ -294,7 +298,12 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
       const float m_rel_new = fmaxf(m_rel_old, tmax);
       const float shift = (m_rel_new == NEG_INF) ? 0.f : m_rel_new;
       float psum = 0.f;
-      if (__all(shift == 0.f)) {
+      // lazy rescale: the base is moved only when a score exceeds it by more than ATT_TAU (log2 units) — until then the
+      // probabilities simply range up to 2^ATT_TAU (exact in the split: fp16 reaches 65504) and the accumulators keep their
+      // scale; softmax does not depend on the base.  Moving it at every new maximum sent ~60 % of the sub-tiles of a
+      // 32-query wave through the rescale path (one of 32 queries sees a new maximum almost every time).
+      const bool lazy_ok = (m_run == NEG_INF) ? (tmax == NEG_INF) : (tmax <= ATT_TAU);
+      if (__all(lazy_ok)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
 #ifndef ABL_NO_EXP

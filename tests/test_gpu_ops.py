@@ -147,6 +147,36 @@ def test_attention_structured_causal_mask(A, T, attn_impl):
     assert (Oc.double() - ref[:, pos.long()]).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("kind", ["sharp", "rising", "falling"])
+def test_attention_sharp_logits_exercise_lazy_and_full_rescale(kind, attn_impl):
+    """The split-operand kernel moves its softmax base only when a score exceeds it by more than 8 (log2 units) and lets the
+    probabilities range up to 2^8 until then.  Sharp logits (std 6), keys whose scores rise steadily (a new maximum in every tile,
+    by less and by more than the threshold) and keys whose scores fall (tiny probabilities after a large first one) against
+    float64."""
+    B, H, A, T = 2, 8, 24, 16
+    L = A * T * 3
+    g = torch.Generator().manual_seed(len(kind))
+    qkv = torch.randn(B, L, 768, generator=g)
+    if kind == "sharp":
+        qkv[..., :256] *= 6.0
+    else:
+        # one shared direction u: q = c u + noise, k_j = ramp_j u + noise  ->  score_j ~ c * ramp_j * |u|^2 / sqrt(32)
+        u = torch.randn(H, 32, generator=g); u = u / u.norm(dim=-1, keepdim=True)
+        ramp = torch.linspace(0.0, 40.0, L) * (1.0 if kind == "rising" else -1.0)
+        qkv[..., :256] = 0.3 * qkv[..., :256] + (math.sqrt(32) * u).reshape(1, 1, 256)
+        qkv[..., 256:512] = 0.3 * qkv[..., 256:512] + (ramp[:, None, None] * u[None]).reshape(1, L, 256)
+    qkv = qkv.to(DEV)
+    O = torch.zeros(B, L, 256, device=DEV)
+    p = _lib.ptr
+    _lib.check(_lib.lib().ctrlsim_attention(1, p(qkv), 768, L * 768, qkv.data_ptr() + 256 * 4, qkv.data_ptr() + 512 * 4, 768,
+                                            L * 768, p(O), 256, L * 256, None, None, B, L, L, A, _lib.stream_ptr()))
+    q, k, v = [qkv[..., i * 256:(i + 1) * 256].view(B, L, H, 32).transpose(1, 2) for i in range(3)]
+    vis = mo.causal_mask_closed_form(A, T, 3).to(DEV)[None, None]
+    ref = _attn_ref(q, k, v, vis).transpose(1, 2).reshape(B, L, 256)
+    assert torch.isfinite(O).all()
+    assert (O.double() - ref).abs().max().item() < 3e-5
+
+
 @pytest.mark.parametrize("mode", [2, 3], ids=["il", "trajeglish"])
 @pytest.mark.parametrize("A,T", [(24, 32), (6, 8), (24, 7)])
 def test_attention_mask_variants_of_the_baselines(A, T, mode):

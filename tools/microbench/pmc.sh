@@ -20,7 +20,7 @@ for r in csv.DictReader(open(f)):
     agg[k][r['Counter_Name']]+=float(r['Counter_Value'])
     cnt[(k,r['Counter_Name'])]+=1
 for k,d in agg.items():
-    if 'gemm_nt_bf16x6' in k or 'attention_bf16x6' in k:
+    if "gemm_nt_bf16x6" in k or "attention_bf16x6" in k or "ffn_fused" in k:
         print(k, {c: f"{v/cnt[(k,c)]:.4g}" for c,v in d.items()})
 PY
 done
