@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scenarios", type=int, default=64, help="scenarios per GPU per rollout")
+    ap.add_argument("--scenarios", type=int, default=256, help="scenarios per GPU per rollout")
     ap.add_argument("--agents", type=int, default=64)
     ap.add_argument("--polylines", type=int, default=512)
     ap.add_argument("--rollout-steps", type=int, default=90)

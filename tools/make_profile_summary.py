@@ -29,7 +29,7 @@ def main():
     b = json.load(open("gpurun_out/bench_r01.json"))
     lines = ["# r01_b — rocprofv3 --kernel-trace --stats of the default `python bench.py` (1x MI355X)", "",
              "Command: `rocprofv3 --kernel-trace --stats -d gpurun_out/prof_r01 -o r01 --output-format csv -- python bench.py`",
-             "(64 scenarios x 64 vehicles x 90 steps x 512 polylines, model batch 512 contexts, warmup 1 + timed 1 rollout; the",
+             f"({b['config']['scenarios_per_gpu']} scenarios x 64 vehicles x 90 steps x 512 polylines, model batch 512 contexts, warmup 1 + timed 1 rollout; the",
              "kernel table therefore covers TWO rollouts).  Un-profiled run of the same command, same box:", "",
              f"`value` = **{b['value']:.0f} agent-steps/s**, {b['ms_per_step']:.0f} ms per 90-step rollout, cpu_baseline "
              f"{b['cpu_baseline']['value']:.1f} agent-steps/s on {b['cpu_baseline']['cores']} threads "
