@@ -19,8 +19,8 @@
 // (measured: 1829 vs 1966 TFLOP/s register-only), and the merge adds / second rescale / 32 registers go away.
 #include "split.h"
 
-#ifndef ATT_TAU
-#define ATT_TAU 8.0f
+#ifndef ATT_PMAX
+#define ATT_PMAX 32768.0f     // row-sum bound of the speculative softmax path: every probability then fits the fp16 plane
 #endif
 
 
@@ -287,33 +287,45 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
         for (int r = 0; r < 16; ++r) sc[r] = s0[r];
       }
       // ---- online softmax (scores are relative to m_base)
-      float tmax = sc[0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sc[r]);
-      {  // the other 16 keys of this query live in lane ^ 32: one v_permlane32_swap instead of an LDS bpermute round trip
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
-        tmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-      }
-      const float m_rel_old = m_run - m_base;                       // 0, or -inf before the first visible key
-      const float m_rel_new = fmaxf(m_rel_old, tmax);
-      const float shift = (m_rel_new == NEG_INF) ? 0.f : m_rel_new;
+      // Speculative fast path: exponentiate against the CURRENT base and look at the row sums only.  The base has to move when
+      // a probability would leave the fp16 range of the split's leading plane; probabilities are non-negative, so
+      // psum < 2^15 bounds every one of them (and catches inf / NaN) without computing the maximum.  Softmax does not depend
+      // on the base, the accumulators simply keep their scale.  The general path below (exact maximum, rescale) runs while
+      // a query has no base yet and in the sub-tiles that fail the test — rare: moving the base at every new maximum sent
+      // ~60 % of the sub-tiles of a 32-query wave through it (one of 32 queries sees a new maximum almost every time).
       float psum = 0.f;
-      // lazy rescale: the base is moved only when a score exceeds it by more than ATT_TAU (log2 units) — until then the
-      // probabilities simply range up to 2^ATT_TAU (exact in the split: fp16 reaches 65504) and the accumulators keep their
-      // scale; softmax does not depend on the base.  Moving it at every new maximum sent ~60 % of the sub-tiles of a
-      // 32-query wave through the rescale path (one of 32 queries sees a new maximum almost every time).
-      const bool lazy_ok = (m_run == NEG_INF) ? (tmax == NEG_INF) : (tmax <= ATT_TAU);
-      if (__all(lazy_ok)) {
+      bool general = __any(m_run == NEG_INF);
+      if (!general) {
+        float pe[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
 #ifndef ABL_NO_EXP
-          sc[r] = __builtin_amdgcn_exp2f(sc[r]);
+          pe[r] = __builtin_amdgcn_exp2f(sc[r]);
+#else
+          pe[r] = sc[r];
 #endif
-          psum += sc[r];
+          psum += pe[r];
         }
-        l_run += psum;
-      } else {
+        general = __any(!(psum < ATT_PMAX));
+        if (!general) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc[r] = pe[r];
+          l_run += psum;
+        }
+      }
+      if (general) {
+        float tmax = sc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sc[r]);
+        {  // the other 16 keys of this query live in lane ^ 32: one v_permlane32_swap instead of an LDS bpermute round trip
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+          tmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        const float m_rel_old = m_run - m_base;                       // 0, or -inf before the first visible key
+        const float m_rel_new = fmaxf(m_rel_old, tmax);
+        const float shift = (m_rel_new == NEG_INF) ? 0.f : m_rel_new;
         const float alpha = __builtin_amdgcn_exp2f(m_rel_old - shift);
+        psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
 #ifndef ABL_NO_EXP

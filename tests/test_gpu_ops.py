@@ -149,10 +149,10 @@ def test_attention_structured_causal_mask(A, T, attn_impl):
 
 @pytest.mark.parametrize("kind", ["sharp", "rising", "falling"])
 def test_attention_sharp_logits_exercise_lazy_and_full_rescale(kind, attn_impl):
-    """The split-operand kernel moves its softmax base only when a score exceeds it by more than 8 (log2 units) and lets the
-    probabilities range up to 2^8 until then.  Sharp logits (std 6), keys whose scores rise steadily (a new maximum in every tile,
-    by less and by more than the threshold) and keys whose scores fall (tiny probabilities after a large first one) against
-    float64."""
+    """The split-operand kernel exponentiates against its current softmax base and moves the base only when a row sum reaches
+    2^15 (a probability would leave the fp16 range of the split's leading plane).  Sharp logits (std 6), keys whose scores rise
+    steadily (new maxima in every tile until the bound trips, again and again) and keys whose scores fall (tiny probabilities
+    after a large first one) against float64."""
     B, H, A, T = 2, 8, 24, 16
     L = A * T * 3
     g = torch.Generator().manual_seed(len(kind))
