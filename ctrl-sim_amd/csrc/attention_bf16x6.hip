@@ -9,7 +9,9 @@
 //   S^T = K.Q^T   A = K rows  (bf16 planes in LDS [3][k-step 2][half 2][64 keys][8]: a wave's ds_read_b128 of a fragment is
 //                 two contiguous 512-byte spans, conflict-free without padding),
 //                 B = the wave's Q fragment, pre-scaled by log2(e)/sqrt(32) in fp32, split once, held in registers.
-//   softmax       unchanged (fp32, lane-local: one query per lane column).
+//   softmax       fp32, lane-local (one query per lane column); the score MFMA chain starts from -base, so scores arrive
+//                 relative to the base, and the common path exponentiates against the CURRENT base and only tests the row
+//                 sums against ATT_PMAX (see the main loop); the exact-maximum / rescale path runs where that test fails.
 //   O^T += V^T.P^T A = V^T (bf16 planes stored TRANSPOSED in LDS as key quads [3][16 quads][32 d][4 keys]: a wave's
 //                 ds_read_b64 of a fragment half is one contiguous 256-byte span), B = P^T: the exponentiated scores of the lane are split in registers and packed in
 //                 accumulator-register order.  The MFMA k-slot <-> key map is free as long as both operands agree:
