@@ -148,7 +148,7 @@ def test_attention_structured_causal_mask(A, T, attn_impl):
 
 
 @pytest.mark.parametrize("kind", ["sharp", "rising", "falling"])
-def test_attention_sharp_logits_exercise_lazy_and_full_rescale(kind, attn_impl):
+def test_attention_sharp_logits_exercise_speculative_and_rescale_paths(kind, attn_impl):
     """The split-operand kernel exponentiates against its current softmax base and moves the base only when a row sum reaches
     2^15 (a probability would leave the fp16 range of the split's leading plane).  Sharp logits (std 6), keys whose scores rise
     steadily (new maxima in every tile until the bound trips, again and again) and keys whose scores fall (tiny probabilities
