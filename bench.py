@@ -5,15 +5,19 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-One bench "step" = one complete closed-loop rollout (default 90 simulator steps) of this rank's batch of S synthetic
-Waymo-shaped scenarios (64 vehicles, 512 road polylines x 100 points, CtRL-Sim base model with random-init weights):
-policy inference (focal grouping, context build, two-pass transformer, sampling) + simulator step + collision flags +
-history update, everything resident in HBM (inputs are uploaded before the timed region).  Scenarios are independent,
-so ranks shard them with no data-path collective (weak scaling: S per GPU fixed); the only collective is one
-all-reduce of the metric accumulators after the rollouts.
+Workload = BASELINE.json configs[2]: S = 2048 synthetic Waymo-shaped scenarios PER GPU (64 vehicles, 512 road polylines x
+100 points, 90 simulator steps, CtRL-Sim base model with random-init weights), all resident in HBM before the timed
+region (uploaded once, untimed).  One bench "step" = one complete 90-step closed-loop rollout of ONE SLICE of that
+resident batch: policy inference (focal grouping, context build, two-pass transformer, sampling) + simulator step +
+collision flags + history update.  The K timed steps roll out K consecutive slices that cover the 2048 scenarios
+EXACTLY ONCE (slice sizes floor/ceil(S/K)), so value = S x 64 x 90 x n_gpus / (time of the K steps) is the
+configs[2] figure itself; the W warm-up steps roll out slices of the same size from the same batch.  Scenarios are
+independent, so ranks shard them with no data-path collective (weak scaling: S per GPU fixed); the only collective is
+one all-reduce of the metric accumulators after the rollouts.
 
-Printed by rank 0: ONE JSON line (metric, value = whole-job agent-steps/s, roofline of the dominant kernel measured
-with HIP events on the launch stream during the timed region, cpu_baseline = the CPU oracle timed on this box).
+Printed by rank 0: ONE JSON line (metric, value = whole-job agent-steps/s, roofline of the dominant kernel class
+measured with HIP events on the launch stream during the timed region, satellite kernels against the HBM roof,
+cpu_baseline = the CPU oracle timed on this box's host cores on a bounded sample).
 """
 import argparse
 import ctypes as C
@@ -32,27 +36,31 @@ import torch
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 PEAK_16BIT_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA (AMD's 5 PF figure includes 2:1 sparsity)
+PEAK_HBM_TBPS = 8.0               # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s measured streaming copy)
 # Both matrix kernels evaluate every fp32 product as NPROD 16-bit partial products with fp32-class accuracy (csrc/split.h: three
 # fp16 products of two-plane splits, or six bf16 products of three-plane splits): the roof of the ALGORITHMIC (fp32-equivalent)
 # FLOP rate is the dense 16-bit MFMA peak / NPROD.
+CLASS_KEYS = ("gemm", "attention", "build_context", "assemble_tokens", "sim_step", "map_pool")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8, help="timed steps = slices that cover the resident batch exactly once")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scenarios", type=int, default=256, help="scenarios per GPU per rollout")
+    ap.add_argument("--scenarios", type=int, default=2048, help="scenarios resident per GPU (BASELINE configs[2]: 2048)")
     ap.add_argument("--agents", type=int, default=64)
     ap.add_argument("--polylines", type=int, default=512)
     ap.add_argument("--rollout-steps", type=int, default=90)
     ap.add_argument("--max-ctx", type=int, default=512, help="model batch (contexts per forward chunk)")
+    ap.add_argument("--lanes", type=int, default=2, help="scenario sets in flight per GPU (engine.py)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--tilt", type=float, nargs=3, default=(0.0, 0.0, 0.0))
     ap.add_argument("--tilt-sweep", action="store_true",
                     help="BASELINE configs[4]: scenario i runs with goal = veh = road tilt TILT_SWEEP[i %% 8] (one batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-steps", type=int, default=6)
+    ap.add_argument("--cpu-sample-scenarios", type=int, default=4)
+    ap.add_argument("--cpu-sample-steps", type=int, default=2)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -86,21 +94,26 @@ def main():
     cfg = spec.make_cfg(nocturne__steps=args.rollout_steps, nocturne__history_steps=1)
     d = spec.Dims(cfg)
     w = weights.generate(d, 0)
-    S, N, R = args.scenarios, args.agents, args.rollout_steps
+    S, N, R, K = args.scenarios, args.agents, args.rollout_steps, args.steps
+    if K < 1 or K > S:
+        raise SystemExit("--steps must be in [1, --scenarios]: the timed steps are slices of the resident batch")
     # global scenario ids: interleaved over ranks (rank r takes r, r+W, ...) so results do not depend on W
     ids = [rank + i * world for i in range(S)]
+    t_gen = time.perf_counter()
     scns = scenarios.make_batch(args.seed, ids, n_agents=N, n_polylines=args.polylines)
+    gen_s = time.perf_counter() - t_gen
     tilt = tuple(args.tilt)
     if args.tilt_sweep:                                       # the sweep values of config 5
         sweep = np.array([-20.0, -10.0, -5.0, 0.0, 5.0, 10.0, 20.0, 30.0])
         tilt = np.repeat(sweep[np.array(ids) % 8][:, None], 3, axis=1)
-    eng = RolloutEngine(cfg, w, device, max_ctx=args.max_ctx, seed=args.seed, tilt=tilt)
+    eng = RolloutEngine(cfg, w, device, max_ctx=args.max_ctx, seed=args.seed, tilt=tilt, lanes=args.lanes)
     torch.cuda.synchronize()
     t_up = time.perf_counter()
     eng.load_scenarios(scns, steps=R)                         # host -> HBM: the only PCIe traffic of a rollout (untimed)
     torch.cuda.synchronize()
     upload_ms = (time.perf_counter() - t_up) * 1e3
     lib = _lib.lib()
+    cuts = [S * i // K for i in range(K + 1)]                 # K slices, sizes floor / ceil (S / K), sum = S
 
     def barrier():
         torch.cuda.synchronize()
@@ -108,18 +121,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        eng.reset()
-        eng.run(R)
+    def bench_step(i):                                        # one 90-step closed-loop rollout of slice i
+        a, b = cuts[i % K], cuts[i % K + 1]
+        eng.reset(a, b)
+        eng.run(R, s0=a, s1=b)
+
+    for i in range(args.warmup):
+        bench_step(i)
     barrier()
     lib.ctrlsim_prof_enable(1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.reset()
-        eng.run(R)
+    for i in range(K):
+        bench_step(i)
     barrier()
     elapsed = time.perf_counter() - t0
-    ms = (C.c_double * 2)(); cnt = (C.c_int64 * 2)(); fl = (C.c_double * 2)(); by = (C.c_double * 2)()
+    ncls = int(lib.ctrlsim_prof_classes())
+    ms = (C.c_double * ncls)(); cnt = (C.c_int64 * ncls)(); fl = (C.c_double * ncls)(); by = (C.c_double * ncls)()
     _lib.check(lib.ctrlsim_prof_collect(ms, cnt, fl), "prof_collect")
     _lib.check(lib.ctrlsim_prof_bytes(by), "prof_bytes")
     lib.ctrlsim_prof_enable(0)
@@ -131,10 +148,10 @@ def main():
     # ---- metrics: one packed all-reduce (the only collective of the job)
     res = eng.results()
     acc = metrics.MetricAccumulators()
+    tt = np.arange(R + 1)[None, :] * cfg.nocturne.dt
     for i, scn in enumerate(scns):
         st = res["states"][i].astype(np.float64)
         T1 = st.shape[1]
-        tt = np.arange(T1)[None, :] * cfg.nocturne.dt
         sp, hd = scn.speed.astype(np.float64)[:, None], scn.heading.astype(np.float64)[:, None]
         gt = np.stack([scn.x[:, None] + sp * np.cos(hd) * tt, scn.y[:, None] + sp * np.sin(hd) * tt,
                        np.broadcast_to(hd, (N, T1)), np.broadcast_to(sp, (N, T1)), np.ones((N, T1))], -1)
@@ -148,7 +165,7 @@ def main():
     acc.unpack(vec.cpu().numpy())
 
     if rank == 0:
-        agent_steps = S * N * R * args.steps * world
+        agent_steps = S * N * R * world
         value = agent_steps / elapsed
         ctx_per_rollout = int(res["n_groups"].sum())
         dom = 0 if ms[0] >= ms[1] else 1
@@ -159,12 +176,14 @@ def main():
                  f"feed-forward block; split-operand MFMA 32x32x16: {scheme} partial products per fp32 product)",
                  "attention_bf16x6_kernel (all multi-head attention; split-operand MFMA flash attention, structured mask)")
 
-        # HBM bytes per launch from the PMC counters: collected offline on this same command (separate --pmc passes,
-        # tools/pmc_traffic.sh) and committed with its calibration under profiles/; None if the summary is absent
-        pmc = {}
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))
+        # HBM bytes per launch from the PMC counters: rocprofv3 cannot run inside this process, so they come from separate
+        # --pmc passes over this same command (tools/pmc_traffic.sh), committed with their calibration under profiles/
+        pmc, pmc_src = {}, None
+        for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            pmc_path = os.path.join(ROOT, "profiles", cand)
+            if os.path.exists(pmc_path):
+                pmc, pmc_src = json.load(open(pmc_path)), "profiles/" + cand
+                break
         keys = ("gemm_nt_bf16x6_kernel", "attention_bf16x6_kernel")
 
         def cls(i):
@@ -175,32 +194,51 @@ def main():
                     "launches": int(cnt[i]), "time_share_of_step": ms[i] * 1e-3 / elapsed,
                     "mfma_executed_tflops": nprod * a if a else None, "mfma_peak_tflops": PEAK_16BIT_MFMA_TFLOPS,
                     "algorithmic_flops_per_launch": fl[i] / n, "algorithmic_hbm_bytes_per_launch": by[i] / n,
-                    "traffic": pmc.get(keys[i], {}).get("hbm_bytes_per_launch"),
+                    "traffic": pmc.get(keys[i], {}).get("hbm_bytes_per_launch"), "traffic_source": pmc_src,
                     "hbm_rate_at_algorithmic_bytes_TBps": by[i] / (ms[i] * 1e-3) / 1e12 if ms[i] > 0 else None}
+
+        def sat(i):                                           # satellite kernels: algorithmic bytes / event time vs the HBM roof
+            if cnt[i] == 0 or ms[i] <= 0:
+                return None
+            rate = by[i] / (ms[i] * 1e-3) / 1e12
+            return {"achieved": rate, "peak": PEAK_HBM_TBPS, "unit": "TB/s", "frac": rate / PEAK_HBM_TBPS,
+                    "avg_launch_ms": ms[i] / cnt[i], "launches": int(cnt[i]), "time_share_of_step": ms[i] * 1e-3 / elapsed,
+                    "algorithmic_hbm_bytes_per_launch": by[i] / cnt[i]}
         roof = {"bound": "mfma", **cls(dom),
                 "note": "achieved = algorithmic fp32 FLOPs (2MNK per Linear; 128 per visible (q,k) pair and head) / summed "
                         f"HIP-event time of the class; peak = dense 16-bit MFMA peak / {nprod} because each fp32 product costs {nprod} "
                         f"MFMA products ({scheme} products, fp32-class accuracy: csrc/split.h); the f32-input MFMA path (157.3 TF peak) is "
-                        "selectable with ctrlsim_set_option; traffic = HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, PMC, "
-                        "profiles/r01_pmc_traffic.json: measured on this command, averaged over the class's launches)",
-                "other": cls(1 - dom)}
+                        "selectable with ctrlsim_set_option; traffic = HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, PMC, separate "
+                        "rocprofv3 --pmc passes over this command, committed under profiles/)",
+                "other": cls(1 - dom),
+                "satellite": {CLASS_KEYS[i]: sat(i) for i in range(2, ncls)},
+                "satellite_note": "HBM-side kernels (SURVEY 8d): algorithmic bytes (DESIGN.md 4) / HIP-event time vs the 8 TB/s HBM "
+                                  "peak; sim_step is latency-bound (one workgroup per scenario) and runs on a side stream "
+                                  "concurrently with the other lane's matrix kernels"}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(cfg, w, scns[0], args)
+            cpu = cpu_baseline(cfg, w, scns, args)
         m, _ = acc.compute()
+        sizes = sorted({cuts[i + 1] - cuts[i] for i in range(K)})
         out = {
             "metric": "agent-steps/sec (closed-loop rollout), 64 agents x 90 steps",
-            "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{S} synthetic Waymo-shaped scenarios per GPU x {N} agents x {R} steps, "
+            "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": f"f32 via {'f16x3' if f16 else 'bf16x6'} split operands ({scheme} 16-bit MFMA products per fp32 product, fp32 accumulate)",
+            "data": "synthetic",
+            "config": {"workload": f"{S} synthetic Waymo-shaped scenarios resident per GPU x {N} agents x {R} steps, "
                                    f"{args.polylines} road polylines x 100 points, CtRL-Sim base model (8.29M params, "
-                                   f"random init), context A=24/T=32/P=200 (BASELINE.json configs[2] shape; "
-                                   f"S per GPU reduced from 2048 so the default run finishes in minutes)",
-                       "scenarios_per_gpu": S, "agents": N, "rollout_steps": R, "polylines": args.polylines,
-                       "model_batch_contexts": args.max_ctx, "contexts_per_rollout_rank0": ctx_per_rollout,
+                                   f"random init), context A=24/T=32/P=200"
+                                   + (" = BASELINE.json configs[2]" if (S, N, R, args.polylines) == (2048, 64, 90, 512) else
+                                      " = BASELINE.json configs[1]" if (S, N, R, args.polylines) == (256, 32, 90, 200) else "")
+                                   + f"; one bench step = the {R}-step closed-loop rollout of one slice of {'/'.join(map(str, sizes))} "
+                                     f"scenarios, the {K} timed steps cover the {S} scenarios exactly once",
+                       "scenarios_per_gpu": S, "scenarios_per_step": sizes, "agents": N, "rollout_steps": R,
+                       "polylines": args.polylines, "model_batch_contexts": args.max_ctx, "lanes": args.lanes,
+                       "contexts_per_rollout_rank0": ctx_per_rollout,
                        "mean_focal_groups_per_scenario_step": ctx_per_rollout / (S * R),
-                       "scenario_upload_ms_untimed": upload_ms,
+                       "scenario_upload_ms_untimed": upload_ms, "scenario_generation_s_untimed": gen_s,
                        "tilt": "sweep of 8 values, one per scenario (configs[4])" if args.tilt_sweep else list(args.tilt),
                        "parallelism": f"scenario-sharded x{world}"},
             "roofline": roof, "cpu_baseline": cpu,
@@ -211,21 +249,36 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(cfg, w, scn, args):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, w, scns, args):
     """The CPU oracle (reference cost structure: two dense B=1 forwards per focal group and step, C physics) on the
-    host cores of this box, on a bounded sample of the same workload."""
+    host cores of this box, on a bounded sample of the same workload: the first steps of several scenarios (the
+    reference's cost per step does not depend on t: it always runs the dense T=32 forward)."""
     import rollout_oracle
     import sim_libs
     sim_libs.build_oracle()
     cores = os.cpu_count() or 1
     threads = max(1, min(cores, 64))
     ro = rollout_oracle.RolloutOracle(cfg, w, seed=args.seed, threads=threads)
-    k = args.cpu_sample_steps
+    k, ns = args.cpu_sample_steps, min(args.cpu_sample_scenarios, len(scns))
+    groups = 0
     t0 = time.perf_counter()
-    o = ro.run(scn, k, sim_libs.OracleSim)
+    for scn in scns[:ns]:
+        o = ro.run(scn, k, sim_libs.OracleSim)
+        groups += int(o["n_groups"].sum())
     el = time.perf_counter() - t0
-    return {"value": scn.N * k / el, "unit": "agent-steps/s", "cores": threads, "kind": "port",
-            "sample": f"1 scenario x {scn.N} agents x {k} rollout steps ({int(o['n_groups'].sum())} focal-group steps, "
+    return {"value": ns * scns[0].N * k / el, "unit": "agent-steps/s", "cores": threads, "kind": "port",
+            "cpu_model": cpu_model(), "host_logical_cpus": cores,
+            "sample": f"{ns} scenarios x {scns[0].N} agents x {k} rollout steps ({groups} focal-group steps, "
                       f"{el:.1f} s); oracle/rollout_oracle.py + oracle/sim_oracle.c, torch {torch.__version__} CPU, "
                       f"{threads} threads"}
 

@@ -33,6 +33,7 @@ SIGNATURES = {
     "ctrlsim_set_option": (I, [I, I]),
     "ctrlsim_split_scheme": (I, []),
     "ctrlsim_nonfinite_count": (I, [I]),
+    "ctrlsim_prof_classes": (I, []),
     "ctrlsim_prof_enable": (None, [I]),
     "ctrlsim_prof_collect": (I, [P, P, P]),
     "ctrlsim_prof_bytes": (I, [P]),
@@ -47,6 +48,7 @@ SIGNATURES = {
     "ctrlsim_sim_contact_floats": (L, [I]),
     "ctrlsim_sim_step": (I, [I, I, I, P, P, P, P, P, P, P, P, P, P, I, I, F, I, P, P]),
     "ctrlsim_group_build": (I, [I, I, I, I, I, I, D, P, P, I, P, P, P, P, P, P, P, P, P]),
+    "ctrlsim_groups_changed": (I, [I, I, P, P, P, P, P, P, P, P]),
     "ctrlsim_ctx_index": (I, [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "ctrlsim_build_context": (I, [I] * 12 + [P] * 12 + [C.POINTER(Ctx), P]),
     "ctrlsim_model_create": (I, [C.POINTER(Dims), P, I, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(P)]),

@@ -24,6 +24,8 @@ int launch_group_build(int, int, int, int, int, int, double, const float*, const
                        unsigned long long*, unsigned long long*, int*, int*, unsigned char*, hipStream_t);
 int launch_ctx_index(int, int, int, const int*, const int*, const unsigned long long*, const int*, const int*, int*, int*,
                      int*, int*, int*, int*, int*, hipStream_t);
+int launch_groups_changed(int, int, const int*, const int*, const unsigned long long*, const int*, const int*,
+                          const unsigned long long*, int*, hipStream_t);
 struct CtxOut { float *st12, *exist, *goal5; int *act_tok, *rtg_bin, *tstep, *slot_gid; float *road_pts, *road_types; };
 int launch_build_context(int, int, int, int, int, int, int, int, int, int, int, int, const int*, const int*, const int*,
                          const unsigned long long*, const float*, const int*, const int*, const double*, const float*,
@@ -71,6 +73,7 @@ int ctrlsim_set_option(int key, int value) {
   return CTRLSIM_OK;
 }
 
+int ctrlsim_prof_classes(void) { return PROF_CLASSES; }
 // enable/disable event timing; enabling clears previous records
 void ctrlsim_prof_enable(int on) {
   for (auto& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
@@ -153,6 +156,11 @@ int ctrlsim_ctx_index(int s0, int s1, int N, const int* n_groups, const int* grp
                       int* mem_ctx, int* mem_slot, int* ctx_base, hipStream_t st) {
   return launch_ctx_index(s0, s1, N, n_groups, grp_focal, (const unsigned long long*)grp_ids, own_g, mem_g, ctx_scn, ctx_grp,
                           own_ctx, own_slot, mem_ctx, mem_slot, ctx_base, st);
+}
+int ctrlsim_groups_changed(int S, int N, const int* n_groups, const int* grp_focal, const uint64_t* grp_ids, const int* ref_n,
+                           const int* ref_focal, const uint64_t* ref_ids, int* flag, hipStream_t st) {
+  return launch_groups_changed(S, N, n_groups, grp_focal, (const unsigned long long*)grp_ids, ref_n, ref_focal,
+                               (const unsigned long long*)ref_ids, flag, st);
 }
 int ctrlsim_build_context(int B, int N, int A, int T, int t, int Tq, int tt_first, int Tmax1, int Tmax, int P_all, int P, int NP,
                           const int* ctx_scn, const int* ctx_grp, const int* grp_focal, const uint64_t* grp_ids,

@@ -588,6 +588,6 @@ int launch_attention_bf16x6_pre(int mode, const float* Q, int ldq, long q_batch_
                        (long)nkt, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale, 0);
   }
   prof_after(PROF_ATTN, attn_pairs(mode, q_pos, Lq, Lk, A) * 128.0 * NHEAD * B, st,
-             (double)B * (8.0 * DM * Lq + 12.0 * DM * Lk));
+             (double)B * (8.0 * DM * Lq + 4.0 * NPL * DM * Lk));   // Q in + O out (fp32), K and V images (NPL 16-bit planes each)
   return ctrlsim_launch_status();
 }

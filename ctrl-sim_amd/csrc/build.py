@@ -19,7 +19,7 @@ def _newer(a, b):
 
 
 def build(force=False, verbose=False):
-    deps = [os.path.join(HERE, "common.h"), os.path.join(HERE, "..", "..", "include", "ctrlsim.h")]
+    deps = [os.path.join(HERE, "common.h"), os.path.join(HERE, "split.h"), os.path.join(HERE, "..", "..", "include", "ctrlsim.h")]
     objs = []
     procs = []
     for name, extra in SRCS.items():

@@ -59,10 +59,12 @@ __device__ __host__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   return z ^ (z >> 31);
 }
 
-// ---- optional per-launch HIP-event timing of the two MFMA kernel classes (bench.py's roofline numbers).
+// ---- optional per-launch HIP-event timing of the two MFMA kernel classes and four satellite kernels (bench.py's roofline numbers).
 // Disabled by default (zero overhead); when enabled every GEMM / attention launch is bracketed by two events on the
 // launch stream and tagged with its algorithmic FLOPs; nothing synchronises until ctrlsim_prof_collect().
-enum { PROF_GEMM = 0, PROF_ATTN = 1, PROF_CLASSES = 2 };
+enum { PROF_GEMM = 0, PROF_ATTN = 1,                         // the two MFMA kernel classes
+       PROF_CTX = 2, PROF_EMBED = 3, PROF_SIM = 4, PROF_MAP = 5,   // HBM / latency satellites: build_context, assemble_tokens, sim_step, map_pool
+       PROF_CLASSES = 6 };
 void prof_before(int cls, hipStream_t st);
 void prof_after(int cls, double flops, hipStream_t st, double bytes = 0.0);   // bytes = compulsory (algorithmic) HBM traffic
 

@@ -129,6 +129,25 @@ __global__ __launch_bounds__(64) void group_build_kernel(int N, int A, int T, in
   if (lane == 0) n_groups[s] = g;
 }
 
+// Did the focal groups of scenarios [0, S) change against a snapshot (ref_*)?  flag[0] |= 1 if any scenario's group count, a
+// focal vehicle or a context membership mask differs.  The K/V-cached phase (engine.py) keeps a chunk on the incremental
+// forward only while its context set is the one the cache was built for; the flag travels to the host with the group
+// counts in one small asynchronous copy instead of a blocking comparison.
+__global__ __launch_bounds__(256) void groups_changed_kernel(int S, int N, const int* __restrict__ n_groups,
+                                                             const int* __restrict__ grp_focal,
+                                                             const unsigned long long* __restrict__ grp_ids,
+                                                             const int* __restrict__ ref_n, const int* __restrict__ ref_focal,
+                                                             const unsigned long long* __restrict__ ref_ids,
+                                                             int* __restrict__ flag) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= S * N) return;
+  const int s = k / N, g = k - s * N;
+  const int n = n_groups[s];
+  bool diff = (g == 0 && n != ref_n[s]);
+  if (g < n && (grp_focal[k] != ref_focal[k] || grp_ids[k] != ref_ids[k])) diff = true;
+  if (diff) atomicOr(flag, 1);
+}
+
 // Flat context list for scenarios [s0, s1): ctx_base by exclusive scan (one block), then per-vehicle owner/member
 // context ids and slots.  ctx index is local to the chunk (0-based at s0).
 __global__ __launch_bounds__(256) void ctx_index_kernel(int s0, int s1, int N, const int* __restrict__ n_groups,
@@ -358,8 +377,22 @@ int launch_build_context(int B, int N, int A, int T, int t, int Tq, int tt_first
   if (B <= 0) return CTRLSIM_OK;
   if (N > 64 || A > 64 || Tq < 1 || tt_first < 0 || tt_first >= Tq) return CTRLSIM_EINVAL;
   const size_t shm = (size_t)P_all * sizeof(double) + (size_t)(P > 0 ? P : 1) * sizeof(int);
+  prof_before(PROF_CTX, st);
   hipLaunchKernelGGL(build_context_kernel, dim3(B), dim3(256), shm, st, N, A, T, t, Tq, tt_first, Tmax1, Tmax, P_all, P, NP, ctx_scn,
                      ctx_grp, grp_focal, grp_ids, hist_states, hist_tok, hist_rtg, goals, types, roads, rtypes, zero4[0],
                      zero4[1], zero4[2], zero4[3], o);
+  // per context: the scenario's road points in once (P_all x NP x 12 B; the selection sweep re-reads them from cache), the P
+  // selected polylines + types out, the window rows of A agents in (8 floats + token + 3 bins) and out (12 floats + 5 ints)
+  prof_after(PROF_CTX, 0.0, st, (double)B * (12.0 * P_all * NP + 12.0 * P * NP + 32.0 * P +
+                                             (double)(Tq - tt_first) * A * (48.0 + 68.0)));
+  return ctrlsim_launch_status();
+}
+
+int launch_groups_changed(int S, int N, const int* n_groups, const int* grp_focal, const unsigned long long* grp_ids,
+                          const int* ref_n, const int* ref_focal, const unsigned long long* ref_ids, int* flag, hipStream_t st) {
+  if (S <= 0) return CTRLSIM_OK;
+  if (!n_groups || !grp_focal || !grp_ids || !ref_n || !ref_focal || !ref_ids || !flag || N < 1 || N > 64) return CTRLSIM_EINVAL;
+  hipLaunchKernelGGL(groups_changed_kernel, dim3((S * N + 255) / 256), dim3(256), 0, st, S, N, n_groups, grp_focal, grp_ids,
+                     ref_n, ref_focal, ref_ids, flag);
   return ctrlsim_launch_status();
 }

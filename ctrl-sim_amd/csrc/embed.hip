@@ -167,8 +167,12 @@ int launch_assemble_tokens(int B, int Tq, int A, const float* S2, const float* G
                            float* src, int M, int P, unsigned char* src_pad, hipStream_t st) {
   const int rows = B * Tq * A;
   if (rows <= 0) return CTRLSIM_OK;
+  prof_before(PROF_EMBED, st);
   hipLaunchKernelGGL(assemble_tokens_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, rows, Tq, A, S2, Gp, exist, act_tok,
                      rtg_bin, tstep, tb, X, src, M, P, src_pad);
+  // per (context, step, agent): the state row in (1 KB), three token rows out (3 KB), 24 B of ids / existence; embedding
+  // tables stay cache-resident
+  prof_after(PROF_EMBED, 0.0, st, (double)rows * (4.0 * DM * 4.0 + 24.0));
   return ctrlsim_launch_status();
 }
 

@@ -464,8 +464,9 @@ int launch_gemm_nt_bf16x6_kv(const float* A, int lda, const void* W3, int n_tota
 #undef GEMM6_LAUNCH_
   {
     const double MN = (double)M * N, kvN = kv_img ? 2.0 * DM : 0.0;
-    const double out_bytes = 4.0 * (double)M * (N - kvN) + 6.0 * (double)M * kvN;       // K / V columns leave as 3 bf16 planes
-    prof_after(PROF_GEMM, 2.0 * MN * (double)K, st, 4.0 * (double)M * K + out_bytes + (R ? 4.0 * MN : 0.0) + 6.0 * (double)N * K);
+    const double out_bytes = 4.0 * (double)M * (N - kvN) + 2.0 * NPL * (double)M * kvN;   // K / V columns leave as NPL 16-bit planes
+    prof_after(PROF_GEMM, 2.0 * MN * (double)K, st,
+               4.0 * (double)M * K + out_bytes + (R ? 4.0 * MN : 0.0) + 2.0 * NPL * (double)N * K);   // weights: NPL 16-bit planes
   }
   return ctrlsim_launch_status();
 }

@@ -130,7 +130,10 @@ int launch_map_pool(int B, int P, int NP, int M, const float* road_pts, MapPoolW
   if (B * P <= 0) return CTRLSIM_OK;
   if (NP < 1 || NP > MAXNP) return CTRLSIM_EINVAL;
   const int G = NP <= 128 ? 2 : 1, total = B * P;
+  prof_before(PROF_MAP, st);
   hipLaunchKernelGGL(map_pool_kernel, dim3((total + G - 1) / G), dim3(256), 0, st, NP, P, M, G, total, road_pts, w, attn_pre,
                      src_pad);
+  // per polyline: NP points x 12 B in, one 256-float row + a padding byte out; ~1.5 MFLOP of folded point MLP + seed attention
+  prof_after(PROF_MAP, 1.5e6 * (double)total, st, (double)total * (12.0 * NP + 4.0 * DM + 1.0));
   return ctrlsim_launch_status();
 }

@@ -1226,7 +1226,12 @@ int launch_sim_step(int S, int N, int E, const int* act_tok, const double* act_f
   if (S <= 0) return CTRLSIM_OK;
   if (N < 1 || N > 64 || E < 0 || t < 0 || t + 1 >= Tmax1 || (!act_tok && !act_f64)) return CTRLSIM_EINVAL;
   SimDiscretisation dz{disc6[0], disc6[1], disc6[2], disc6[3], (int)disc6[4], (int)disc6[5]};
+  prof_before(PROF_SIM, st);
   hipLaunchKernelGGL(sim_step_kernel, dim3(S), dim3(256), 0, st, N, E, act_tok, act_f64, dz, size, edges, exists, phys,
                      hist_states, coll, applied, t, Tmax1, dt, kinematic, contact_state);
+  // per scenario: body + control state in and out (20 floats), one history row + flags out, the road-edge segments in,
+  // and (contacts) the persistent Box2D state in and out (20 floats per vehicle pair + broad phase)
+  prof_after(PROF_SIM, 0.0, st, (double)S * (N * (2.0 * 80 + 32 + 2 + 4) + 16.0 * E +
+                                             (contact_state ? 8.0 * (N * (N - 1) / 2 * 20 + 6 + 28 * N) : 0.0)));
   return ctrlsim_launch_status();
 }

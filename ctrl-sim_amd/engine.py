@@ -3,8 +3,17 @@
 This is the MI355X-native replacement of the reference's per-scenario Python loop
 (evaluators/policy_evaluator.py:514-557: update dict -> Policy.update_state -> AutoregressivePolicy.predict ->
 act -> Simulation.step).  All per-step state lives on the device ([S, N, ...] arrays, see include/ctrlsim.h); the host
-only sequences kernel launches through the C ABI and reads ONE small array per step (groups per scenario, needed to
-size the model batch).  torch is used for device memory and streams only.
+only sequences kernel launches through the C ABI and reads ONE small array per lane and step (groups per scenario, needed
+to size the model batch).  torch is used for device memory, streams and events only.
+
+Scenarios in flight are sharded over LANES (the intra-GPU "one scenario set per stream" sharding of the north star):
+a lane = a contiguous scenario range with its own model workspace, context tensors and side HIP stream.  The matrix
+kernels of all lanes run back to back on ONE main stream (they each fill the chip; keeping them in order keeps their
+per-launch timing clean), while a lane's simulator step, the focal grouping of its next step and the small
+device -> host copy of the group counts run on the lane's side stream, concurrently with the other lane's forward
+pass.  The host waits for a lane's counts only after it has queued the other lane's whole step, so the GPU never
+idles on that round trip: with two lanes the per-step host synchronisation, the single-lane-per-scenario solver of
+`sim_step` and the grouping kernels disappear from the critical path.
 
 Per step t:
   1. ctrlsim_group_build       focal groups of every scenario (one wavefront per scenario)
@@ -107,9 +116,31 @@ def ctx_from_reference_layout(d: Dims, data: dict, Tq: int, device):
     return cb
 
 
+class _Lane:
+    """A scenario set in flight: model workspace (K/V cache included), context tensors, logits, chunk index lists, a side
+    stream for its simulator step / grouping / count read-back, and the two events that order it against the main stream."""
+
+    def __init__(self, eng, idx, own_stream):
+        d, dev, B = eng.dims, eng.device, eng.max_ctx
+        self.idx = idx
+        self.ctx = CtxBuffers(d, B, dev)
+        self.ws = torch.empty(eng.model.workspace_bytes(B, d.T), dtype=torch.uint8, device=dev)
+        self.rtg_logits = torch.empty(B, d.A, d.R * d.C, device=dev)
+        self.act_logits = torch.empty(B, d.A, d.V, device=dev)
+        self.ctx_scn = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.ctx_grp = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.host_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.host_counts = None                                  # pinned [S] int32, sized by load_scenarios
+        self.side = torch.cuda.Stream(device=dev) if own_stream else None
+        self.ev_fwd, self.ev_ready = torch.cuda.Event(), torch.cuda.Event()
+        self.pending = (0, 0, False)                             # scenario range (+ compare flag) of the read-back in flight
+
+
 class RolloutEngine:
     def __init__(self, cfg, weights: dict, device="cuda:0", max_ctx=256, seed=0, tilt=(0.0, 0.0, 0.0),
-                 temperature=None, nucleus=None, top_p=None, kinematic=False, model=None, use_cache=True, contacts=True):
+                 temperature=None, nucleus=None, top_p=None, kinematic=False, model=None, use_cache=True, contacts=True,
+                 lanes=1):
         self.cfg = cfg
         self.w = cfg.dataset.waymo
         self.dims = Dims(cfg)
@@ -142,11 +173,12 @@ class RolloutEngine:
             from .rewards import normalize_rtgs
             self.zero_rtg = tuple(int(v) for v in normalize_rtgs(np.zeros(3), self.w).astype(np.float32).view(np.int32))
         self._zero4 = (C.c_int * 4)(ZERO_ACTION_TOKEN, *self.zero_rtg)
-        self.ctx = CtxBuffers(self.dims, self.max_ctx, self.device)
-        self.ws = torch.empty(self.model.workspace_bytes(self.max_ctx, self.dims.T), dtype=torch.uint8, device=self.device)
-        d = self.dims
-        self.rtg_logits = torch.empty(self.max_ctx, d.A, d.R * d.C, device=self.device)
-        self.act_logits = torch.empty(self.max_ctx, d.A, d.V, device=self.device)
+        self.n_lanes = max(1, int(lanes))
+        self.lanes = [_Lane(self, i, self.n_lanes > 1) for i in range(self.n_lanes)]
+        L0 = self.lanes[0]                   # the synchronous single-stream entry points (policy_step / step) use lane 0
+        self.ctx, self.ws, self.rtg_logits, self.act_logits = L0.ctx, L0.ws, L0.rtg_logits, L0.act_logits
+        self.ctx_scn, self.ctx_grp = L0.ctx_scn, L0.ctx_grp
+        self._main = torch.cuda.current_stream(self.device)
         self.S = 0
 
     # ------------------------------------------------------------------ scenario upload / reset
@@ -195,55 +227,64 @@ class RolloutEngine:
         self.persist = z(S, N, dt=torch.int64)
         self.n_groups = z(S, dt=torch.int32)
         self.n_groups_host = torch.zeros(S, dtype=torch.int32).pin_memory()
+        for L in self.lanes:
+            L.host_counts = torch.zeros(S, dtype=torch.int32).pin_memory()
         self.grp_focal = z(S, N, dt=torch.int32)
         self.grp_ids = z(S, N, dt=torch.int64)
         self.grp_members = z(S, N, dt=torch.int64)
+        # snapshot of the focal groups a chunk's K/V cache was built for (ctrlsim_groups_changed)
+        self.ref_n, self.ref_focal, self.ref_ids = z(S, dt=torch.int32), z(S, N, dt=torch.int32), z(S, N, dt=torch.int64)
         self.own_g, self.mem_g = z(S, N, dt=torch.int32), z(S, N, dt=torch.int32)
         self.tilted = z(S, N, dt=torch.uint8)
         self.own_ctx, self.own_slot = z(S, N, dt=torch.int32), z(S, N, dt=torch.int32)
         self.mem_ctx, self.mem_slot = z(S, N, dt=torch.int32), z(S, N, dt=torch.int32)
         self.ctx_base = z(S, dt=torch.int32)
-        self.ctx_scn, self.ctx_grp = z(self.max_ctx, dt=torch.int32), z(self.max_ctx, dt=torch.int32)
+        self._zero_rtg_row = torch.tensor(self.zero_rtg, dtype=torch.int32, device=dev)
         self.groups_per_step = np.zeros((self.steps, S), np.int32)
+        self.lib.ctrlsim_nonfinite_count(1)
         self.reset()
 
-    def reset(self):
+    def reset(self, s0=0, s1=None):
+        """Back to step 0 for scenarios [s0, s1) (default: all)."""
         st = _lib.stream_ptr()
-        self.lib.ctrlsim_nonfinite_count(1)
-        self.hist_states.zero_()
-        self.coll.zero_()
-        self.hist_tok.fill_(ZERO_ACTION_TOKEN)
-        self.hist_rtg.copy_(torch.tensor(self.zero_rtg, dtype=torch.int32, device=self.device).expand_as(self.hist_rtg))
-        self.persist.zero_()
-        self.applied.zero_()
+        s1 = self.S if s1 is None else s1
+        sl = slice(s0, s1)
+        self.hist_states[sl].zero_()
+        self.coll[sl].zero_()
+        self.hist_tok[sl].fill_(ZERO_ACTION_TOKEN)
+        self.hist_rtg[sl].copy_(self._zero_rtg_row.expand_as(self.hist_rtg[sl]))
+        self.persist[sl].zero_()
+        self.applied[sl].zero_()
         p = _lib.ptr
-        _lib.check(self.lib.ctrlsim_sim_init(self.S, self.N, self.E, p(self.init_pose), p(self.size), p(self.edges),
-                                             p(self.exists), p(self.phys), p(self.hist_states), p(self.coll),
-                                             self.steps + 1, p(self.contact_state), st), "sim_init")
+        _lib.check(self.lib.ctrlsim_sim_init(s1 - s0, self.N, self.E, p(self.init_pose[sl]), p(self.size[sl]), p(self.edges[sl]),
+                                             p(self.exists[sl]), p(self.phys[sl]), p(self.hist_states[sl]), p(self.coll[sl]),
+                                             self.steps + 1, p(self.contact_state[sl]) if self.contact_state is not None else None,
+                                             st), "sim_init")
 
-    # ------------------------------------------------------------------ one step
-    def _chunks(self, counts):
+    # ------------------------------------------------------------------ chunk plan
+    def _chunks(self, counts, base=0):
+        """Cut scenarios base .. base+len(counts) into model batches of <= max_ctx contexts, of balanced size (a short last
+        batch costs a whole set of launches).  -> [(s0, s1, n_contexts)]."""
+        counts = [int(c) for c in counts]
+        total, big = sum(counts), max(counts, default=0)
+        if big > self.max_ctx:
+            raise RuntimeError(f"a scenario has {big} focal groups > max_ctx={self.max_ctx}")
+        n = max(1, -(-total // self.max_ctx))
+        cap = min(self.max_ctx, -(-total // n) + big)
         chunks, s0, acc = [], 0, 0
         for s, c in enumerate(counts):
-            c = int(c)
-            if c > self.max_ctx:
-                raise RuntimeError(f"scenario {s} has {c} focal groups > max_ctx={self.max_ctx}")
-            if acc + c > self.max_ctx or s - s0 >= 4095:
-                chunks.append((s0, s, acc))
+            if acc + c > cap or s - s0 >= 4095:
+                chunks.append((base + s0, base + s, acc))
                 s0, acc = s, 0
             acc += c
-        chunks.append((s0, len(counts), acc))
+        chunks.append((base + s0, base + len(counts), acc))
         return [c for c in chunks if c[1] > c[0]]
 
-    def step(self, t, noise_rtg=None, noise_act=None):
-        """One closed-loop step: policy (grouping, contexts, two-pass model, sampling) then the simulator step.
-        noise_rtg [S,N,3,R] / noise_act [S,N,V] float32 tensors (explicit Exp(1) noise) or None (in-kernel)."""
-        self.policy_step(t, noise_rtg, noise_act)
-        self.sim_step(t)
-
-    def sim_step(self, t, act_f64=None, s0=0, s1=None):
+    # ------------------------------------------------------------------ kernels of one step, on explicit streams
+    def sim_step(self, t, act_f64=None, s0=0, s1=None, stream=None):
         """Simulator step of scenarios [s0, s1) (default: all)."""
-        lib, p, st = self.lib, _lib.ptr, _lib.stream_ptr()
+        lib, p = self.lib, _lib.ptr
+        st = _lib.stream_ptr() if stream is None else stream
         s1 = self.S if s1 is None else s1
         sl = slice(s0, s1)
         _lib.check(lib.ctrlsim_sim_step(s1 - s0, self.N, self.E, p(self.act_now[sl]) if act_f64 is None else None,
@@ -252,8 +293,9 @@ class RolloutEngine:
                                         p(self.coll[sl]), None, t, self.steps + 1, self.dt, self.kinematic,
                                         p(self.contact_state[sl]) if self.contact_state is not None else None, st), "sim_step")
 
-    def _group_build(self, t, s0=0, s1=None):
-        lib, p, st, d = self.lib, _lib.ptr, _lib.stream_ptr(), self.dims
+    def _group_build(self, t, s0=0, s1=None, stream=None):
+        lib, p, d = self.lib, _lib.ptr, self.dims
+        st = _lib.stream_ptr() if stream is None else stream
         s1 = self.S if s1 is None else s1
         sl = slice(s0, s1)
         _lib.check(lib.ctrlsim_group_build(s1 - s0, self.N, d.A, d.T, t, self.steps + 1, float(self.w.agent_dist_threshold),
@@ -262,131 +304,218 @@ class RolloutEngine:
                                            p(self.grp_ids[sl]), p(self.grp_members[sl]), p(self.own_g[sl]), p(self.mem_g[sl]),
                                            p(self.tilted[sl]), st), "group_build")
 
-    # ------------------------------------------------------------------ cached phase (t < T), chunk-major
-    def _chunk_step_cached(self, s0, s1, B, t, ws):
-        """Policy + simulator step of one chunk of scenarios with the decoder K/V cache of that chunk (`ws`)."""
-        lib, p, st, d = self.lib, _lib.ptr, _lib.stream_ptr(), self.dims
+    def _side(self, L):
+        return L.side if L.side is not None else self._main
+
+    def _enqueue_groups(self, L, t, s0, s1, compare=False):
+        """Side stream of lane L: focal groups of step t for scenarios [s0, s1), (compare) the changed-vs-snapshot flag, the
+        asynchronous read-back of the group counts (+ flag), then L.ev_ready."""
+        side = self._side(L)
+        sl = slice(s0, s1)
+        self._group_build(t, s0, s1, side.cuda_stream)
+        with torch.cuda.stream(side):
+            if compare:
+                L.flag.zero_()
+                p = _lib.ptr
+                _lib.check(self.lib.ctrlsim_groups_changed(s1 - s0, self.N, p(self.n_groups[sl]), p(self.grp_focal[sl]),
+                                                           p(self.grp_ids[sl]), p(self.ref_n[sl]), p(self.ref_focal[sl]),
+                                                           p(self.ref_ids[sl]), p(L.flag), side.cuda_stream), "groups_changed")
+                L.host_flag.copy_(L.flag, non_blocking=True)
+            L.host_counts[:s1 - s0].copy_(self.n_groups[sl], non_blocking=True)
+            L.ev_ready.record(side)
+        L.pending = (s0, s1, compare)
+
+    def _await_groups(self, L):
+        """Host side of _enqueue_groups: wait for the lane's read-back -> (counts [s1-s0] copy, changed)."""
+        s0, s1, compare = L.pending
+        L.ev_ready.synchronize()
+        return L.host_counts.numpy()[:s1 - s0].copy(), bool(compare and int(L.host_flag[0]) != 0)
+
+    def _snapshot_groups(self, L, s0, s1):
+        side, sl = self._side(L), slice(s0, s1)
+        with torch.cuda.stream(side):
+            self.ref_n[sl].copy_(self.n_groups[sl])
+            self.ref_focal[sl].copy_(self.grp_focal[sl])
+            self.ref_ids[sl].copy_(self.grp_ids[sl])
+
+    def _enqueue_sim(self, L, t, s0, s1):
+        """Simulator step of [s0, s1) on the lane's side stream, behind the sampled actions of the main stream."""
+        side = self._side(L)
+        if L.side is not None:
+            L.ev_fwd.record(self._main)
+            side.wait_event(L.ev_fwd)
+        self.sim_step(t, s0=s0, s1=s1, stream=side.cuda_stream)
+
+    def _main_waits(self, L):
+        if L.side is not None:
+            self._main.wait_event(L.ev_ready)
+
+    # ------------------------------------------------------------------ cached phase (t < T): one chunk, one step
+    def _chunk_step_cached(self, L, s0, s1, B, t):
+        """Policy step of one chunk of scenarios against the decoder K/V cache of that chunk (the lane's workspace)."""
+        lib, p, st, d = self.lib, _lib.ptr, self._main.cuda_stream, self.dims
         N, Tmax, ns, sl = self.N, self.steps, s1 - s0, slice(s0, s1)
         Tq, tt_first = t + 1, max(t - 1, 0)
         _lib.check(lib.ctrlsim_ctx_index(s0, s1, N, p(self.n_groups), p(self.grp_focal), p(self.grp_ids), p(self.own_g),
-                                         p(self.mem_g), p(self.ctx_scn), p(self.ctx_grp), p(self.own_ctx), p(self.own_slot),
+                                         p(self.mem_g), p(L.ctx_scn), p(L.ctx_grp), p(self.own_ctx), p(self.own_slot),
                                          p(self.mem_ctx), p(self.mem_slot), p(self.ctx_base), st), "ctx_index")
         _lib.check(lib.ctrlsim_build_context(B, N, d.A, d.T, t, Tq, tt_first, Tmax + 1, Tmax, self.P_all, d.P, d.NP,
-                                             p(self.ctx_scn), p(self.ctx_grp), p(self.grp_focal), p(self.grp_ids),
+                                             p(L.ctx_scn), p(L.ctx_grp), p(self.grp_focal), p(self.grp_ids),
                                              p(self.hist_states), p(self.hist_tok), p(self.hist_rtg), p(self.goals),
                                              p(self.types), p(self.roads), p(self.rtypes), self._zero4,
-                                             C.byref(self.ctx.struct), st), "build_context")
-        _lib.check(lib.ctrlsim_dt_forward_pass1_cached(self.model.handle, B, t, C.byref(self.ctx.struct), p(ws),
-                                                       p(self.rtg_logits), st), "pass1_cached")
-        _lib.check(lib.ctrlsim_sample_rtg(p(self.rtg_logits), d.A, d.R, p(self.own_ctx[sl]), p(self.own_slot[sl]),
+                                             C.byref(L.ctx.struct), st), "build_context")
+        _lib.check(lib.ctrlsim_dt_forward_pass1_cached(self.model.handle, B, t, C.byref(L.ctx.struct), p(L.ws),
+                                                       p(L.rtg_logits), st), "pass1_cached")
+        _lib.check(lib.ctrlsim_sample_rtg(p(L.rtg_logits), d.A, d.R, p(self.own_ctx[sl]), p(self.own_slot[sl]),
                                           p(self.tilted[sl]), self.tilt,
                                           p(self.tilt_scn[sl]) if self.tilt_scn is not None else None, None, self.seed,
                                           p(self.scenario_id[sl]), t, p(self.hist_rtg[sl]), ns, N, Tmax, st), "sample_rtg")
-        _lib.check(lib.ctrlsim_dt_forward_pass2(self.model.handle, B, Tq, t, N, Tmax, C.byref(self.ctx.struct), p(self.ctx_scn),
-                                                p(self.hist_rtg), p(ws), p(self.act_logits), 1, st), "pass2_cached")
-        _lib.check(lib.ctrlsim_sample_action(p(self.act_logits), d.A, d.V, p(self.mem_ctx[sl]), p(self.mem_slot[sl]),
+        _lib.check(lib.ctrlsim_dt_forward_pass2(self.model.handle, B, Tq, t, N, Tmax, C.byref(L.ctx.struct), p(L.ctx_scn),
+                                                p(self.hist_rtg), p(L.ws), p(L.act_logits), 1, st), "pass2_cached")
+        _lib.check(lib.ctrlsim_sample_action(p(L.act_logits), d.A, d.V, p(self.mem_ctx[sl]), p(self.mem_slot[sl]),
                                              self.temperature, self.top_p, None, self.seed, p(self.scenario_id[sl]), t,
                                              p(self.hist_tok[sl]), p(self.act_now[sl]), ns, N, Tmax, ZERO_ACTION_TOKEN, st),
                    "sample_action")
-        self.sim_step(t, s0=s0, s1=s1)
 
-    def _run_cached_phase(self, n_steps):
-        """Steps 0 .. n_steps-1 (n_steps <= T) chunk by chunk: while t < T the window starts at step 0, so a context's
-        frame, membership and map are constant and its decoder K/V can be cached across steps (csrc/forward.hip).
-        A chunk whose context set does change (a vehicle stops existing) falls back to the full recompute."""
-        self._group_build(0)
-        self.n_groups_host.copy_(self.n_groups, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-        counts = self.n_groups_host.numpy().copy()
-        self.groups_per_step[0] = counts
-        for (s0, s1, B) in self._chunks(counts):
-            sl = slice(s0, s1)
-            cached_ok = B > 0
-            ref_focal, ref_ids = self.grp_focal[sl].clone(), self.grp_ids[sl].clone()
-            for t in range(n_steps):
-                if t > 0:
-                    self._group_build(t, s0, s1)
-                    self.n_groups_host[sl].copy_(self.n_groups[sl], non_blocking=True)
-                    same = torch.equal(self.grp_focal[sl], ref_focal) and torch.equal(self.grp_ids[sl], ref_ids)   # syncs
-                    cnt = self.n_groups_host.numpy()[sl]
-                    self.groups_per_step[t, sl] = cnt
-                    cached_ok = cached_ok and same and np.array_equal(cnt, counts[sl])
-                if cached_ok:
-                    self._chunk_step_cached(s0, s1, B, t, self.ws)
-                else:
-                    self._policy_chunks(t, self.n_groups_host.numpy(), s0, s1)
-                    self.sim_step(t, s0=s0, s1=s1)
-
-    def policy_step(self, t, noise_rtg=None, noise_act=None):
-        """AutoregressivePolicy.predict for every scenario: writes hist_rtg[..., t, :], hist_tok[..., t], act_now."""
-        self._group_build(t)
-        self.n_groups_host.copy_(self.n_groups, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-        counts = self.n_groups_host.numpy()
-        self.groups_per_step[t] = counts
-        self._policy_chunks(t, counts, 0, self.S, noise_rtg, noise_act)
-
-    def _policy_chunks(self, t, counts, lo, hi, noise_rtg=None, noise_act=None):
-        """Full-recompute policy for scenarios [lo, hi), chunked to the model batch."""
-        lib, p, st, d = self.lib, _lib.ptr, _lib.stream_ptr(), self.dims
-        S, N, Tmax = self.S, self.N, self.steps
+    def _policy_chunks(self, L, t, counts, lo, hi, noise_rtg=None, noise_act=None):
+        """Full-recompute policy for scenarios [lo, hi) (counts = their group counts), chunked to the model batch, on the main
+        stream with lane L's buffers."""
+        lib, p, st, d = self.lib, _lib.ptr, self._main.cuda_stream, self.dims
+        N, Tmax = self.N, self.steps
         Tq = min(t, d.T - 1) + 1
-        for (s0, s1, B) in [(lo + a, lo + b, c) for (a, b, c) in self._chunks(counts[lo:hi])]:
+        for (s0, s1, B) in self._chunks(counts, lo):
             ns = s1 - s0
             sl = slice(s0, s1)
             if B > 0:
                 _lib.check(lib.ctrlsim_ctx_index(s0, s1, N, p(self.n_groups), p(self.grp_focal), p(self.grp_ids),
-                                                 p(self.own_g), p(self.mem_g), p(self.ctx_scn), p(self.ctx_grp),
+                                                 p(self.own_g), p(self.mem_g), p(L.ctx_scn), p(L.ctx_grp),
                                                  p(self.own_ctx), p(self.own_slot), p(self.mem_ctx), p(self.mem_slot),
                                                  p(self.ctx_base), st), "ctx_index")
                 _lib.check(lib.ctrlsim_build_context(B, N, d.A, d.T, t, Tq, 0, Tmax + 1, Tmax, self.P_all, d.P, d.NP,
-                                                     p(self.ctx_scn), p(self.ctx_grp), p(self.grp_focal), p(self.grp_ids),
+                                                     p(L.ctx_scn), p(L.ctx_grp), p(self.grp_focal), p(self.grp_ids),
                                                      p(self.hist_states), p(self.hist_tok), p(self.hist_rtg),
                                                      p(self.goals), p(self.types), p(self.roads), p(self.rtypes),
-                                                     self._zero4, C.byref(self.ctx.struct), st), "build_context")
+                                                     self._zero4, C.byref(L.ctx.struct), st), "build_context")
                 if d.VARIANT:                                # IL / Trajeglish: no RTG tokens, one forward (predict_rtgs False)
-                    _lib.check(lib.ctrlsim_dt_forward_actions(self.model.handle, B, Tq, C.byref(self.ctx.struct), p(self.ws),
-                                                              p(self.act_logits), st), "forward_actions")
+                    _lib.check(lib.ctrlsim_dt_forward_actions(self.model.handle, B, Tq, C.byref(L.ctx.struct), p(L.ws),
+                                                              p(L.act_logits), st), "forward_actions")
                 else:
-                    _lib.check(lib.ctrlsim_dt_forward_pass1(self.model.handle, B, Tq, C.byref(self.ctx.struct), p(self.ws),
-                                                            p(self.rtg_logits), None, st), "pass1")
+                    _lib.check(lib.ctrlsim_dt_forward_pass1(self.model.handle, B, Tq, C.byref(L.ctx.struct), p(L.ws),
+                                                            p(L.rtg_logits), None, st), "pass1")
             else:
-                self.own_ctx[sl].fill_(-1)
-                self.mem_ctx[sl].fill_(-1)
+                with torch.cuda.stream(self._main):
+                    self.own_ctx[sl].fill_(-1)
+                    self.mem_ctx[sl].fill_(-1)
             if not d.VARIANT:
-                _lib.check(lib.ctrlsim_sample_rtg(p(self.rtg_logits), d.A, d.R, p(self.own_ctx[sl]), p(self.own_slot[sl]),
+                _lib.check(lib.ctrlsim_sample_rtg(p(L.rtg_logits), d.A, d.R, p(self.own_ctx[sl]), p(self.own_slot[sl]),
                                                   p(self.tilted[sl]), self.tilt,
                                                   p(self.tilt_scn[sl]) if self.tilt_scn is not None else None,
                                                   p(noise_rtg[sl]) if noise_rtg is not None else None, self.seed,
                                                   p(self.scenario_id[sl]), t, p(self.hist_rtg[sl]), ns, N, Tmax, st),
                            "sample_rtg")
             if B > 0 and not d.VARIANT:
-                _lib.check(lib.ctrlsim_dt_forward_pass2(self.model.handle, B, Tq, t, N, Tmax, C.byref(self.ctx.struct),
-                                                        p(self.ctx_scn), p(self.hist_rtg), p(self.ws),
-                                                        p(self.act_logits), 0, st), "pass2")
-            _lib.check(lib.ctrlsim_sample_action(p(self.act_logits), d.A, d.V, p(self.mem_ctx[sl]), p(self.mem_slot[sl]),
+                _lib.check(lib.ctrlsim_dt_forward_pass2(self.model.handle, B, Tq, t, N, Tmax, C.byref(L.ctx.struct),
+                                                        p(L.ctx_scn), p(self.hist_rtg), p(L.ws),
+                                                        p(L.act_logits), 0, st), "pass2")
+            _lib.check(lib.ctrlsim_sample_action(p(L.act_logits), d.A, d.V, p(self.mem_ctx[sl]), p(self.mem_slot[sl]),
                                                  self.temperature, self.top_p,
                                                  p(noise_act[sl]) if noise_act is not None else None, self.seed,
                                                  p(self.scenario_id[sl]), t, p(self.hist_tok[sl]), p(self.act_now[sl]),
                                                  ns, N, Tmax, ZERO_ACTION_TOKEN, st), "sample_action")
 
-    def run(self, steps=None, noise_fn=None):
-        """Roll all loaded scenarios `steps` steps.  noise_fn(t) -> (noise_rtg, noise_act) or None."""
+    # ------------------------------------------------------------------ a lane's rollout as a generator
+    def _lane_gen(self, L, lo, hi, steps):
+        """Closed-loop rollout of scenarios [lo, hi) on lane L.  Yields wherever the host needs the lane's group counts
+        back: the scheduler (run) then queues another lane's step before this one blocks on its read-back."""
+        T = self.dims.T
+        t0 = 0
+        if self.use_cache and steps > 0:
+            # steps 0 .. nT-1 chunk by chunk: while t < T the window starts at step 0, so a context's frame, membership and map
+            # are constant and its decoder K/V can be cached across steps (csrc/forward.hip).  A chunk whose context set does
+            # change (a vehicle stops existing) falls back to the full recompute.
+            nT = min(T, steps)
+            self._enqueue_groups(L, 0, lo, hi)
+            yield
+            counts, _ = self._await_groups(L)
+            self.groups_per_step[0, lo:hi] = counts
+            for (s0, s1, B) in self._chunks(counts, lo):
+                cached_ok = B > 0
+                cnt = counts[s0 - lo:s1 - lo]
+                if nT > 1:
+                    self._snapshot_groups(L, s0, s1)
+                for t in range(nT):
+                    if t > 0:
+                        yield
+                        cnt, changed = self._await_groups(L)
+                        self.groups_per_step[t, s0:s1] = cnt
+                        cached_ok = cached_ok and not changed
+                    self._main_waits(L)
+                    if cached_ok:
+                        self._chunk_step_cached(L, s0, s1, B, t)
+                    else:
+                        self._policy_chunks(L, t, cnt, s0, s1)
+                    self._enqueue_sim(L, t, s0, s1)
+                    if t + 1 < nT:
+                        self._enqueue_groups(L, t + 1, s0, s1, compare=True)
+            t0 = nT
+        for t in range(t0, steps):
+            self._enqueue_groups(L, t, lo, hi)
+            yield
+            counts, _ = self._await_groups(L)
+            self.groups_per_step[t, lo:hi] = counts
+            self._main_waits(L)
+            self._policy_chunks(L, t, counts, lo, hi)
+            self._enqueue_sim(L, t, lo, hi)
+
+    def run(self, steps=None, noise_fn=None, s0=0, s1=None):
+        """Roll scenarios [s0, s1) (default: all loaded) `steps` steps from their current state (reset() first for a fresh
+        rollout).  noise_fn(t) -> (noise_rtg, noise_act): explicit sampling noise, synchronous single-lane path."""
         steps = self.steps if steps is None else steps
+        s1 = self.S if s1 is None else s1
         if self.dims.VARIANT == 3:
             raise NotImplementedError("the Decision-Transformer policy conditions on real-time rewards computed by the rollout "
                                       "driver: run it through PolicyEvaluator (hist_rtg is fed per step), not RolloutEngine.run")
-        start = 0
-        if self.use_cache and noise_fn is None and steps > 0:
-            start = min(self.dims.T, steps)
-            self._run_cached_phase(start)
-        for t in range(start, steps):
-            if noise_fn is not None:
+        if noise_fn is not None:
+            assert s0 == 0 and s1 == self.S
+            for t in range(steps):
                 nr, na = noise_fn(t)
                 self.step(t, nr, na)
-            else:
-                self.step(t)
+            return self
+        main = self._main = torch.cuda.current_stream(self.device)
+        n = min(self.n_lanes, max(1, s1 - s0))
+        cuts = [s0 + (s1 - s0) * i // n for i in range(n + 1)]
+        gens = []
+        for L, lo, hi in zip(self.lanes, cuts[:-1], cuts[1:]):
+            if L.side is not None:
+                L.side.wait_stream(main)
+            gens.append(self._lane_gen(L, lo, hi, steps))
+        while gens:                                   # round robin: each lane runs to its next read-back point
+            for g in list(gens):
+                try:
+                    next(g)
+                except StopIteration:
+                    gens.remove(g)
+        for L in self.lanes[:n]:
+            if L.side is not None:
+                main.wait_stream(L.side)
         return self
+
+    # ------------------------------------------------------------------ synchronous single-stream steps (plugin surface)
+    def step(self, t, noise_rtg=None, noise_act=None):
+        """One closed-loop step: policy (grouping, contexts, two-pass model, sampling) then the simulator step.
+        noise_rtg [S,N,3,R] / noise_act [S,N,V] float32 tensors (explicit Exp(1) noise) or None (in-kernel)."""
+        self.policy_step(t, noise_rtg, noise_act)
+        self.sim_step(t)
+
+    def policy_step(self, t, noise_rtg=None, noise_act=None):
+        """AutoregressivePolicy.predict for every scenario: writes hist_rtg[..., t, :], hist_tok[..., t], act_now."""
+        self._main = torch.cuda.current_stream(self.device)
+        self._group_build(t)
+        self.n_groups_host.copy_(self.n_groups, non_blocking=True)
+        self._main.synchronize()
+        counts = self.n_groups_host.numpy()
+        self.groups_per_step[t] = counts
+        self._policy_chunks(self.lanes[0], t, counts, 0, self.S, noise_rtg, noise_act)
 
     def results(self):
         torch.cuda.synchronize(self.device)

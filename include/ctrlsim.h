@@ -86,6 +86,11 @@ int ctrlsim_group_build(int S, int N, int A, int T, int t, int Tmax1, double dis
                         const int* eval_order /*[S,N] -1 padded*/, int has_roads, uint64_t* persist /*[S,N]*/,
                         int* n_groups /*[S]*/, int* grp_focal /*[S,N]*/, uint64_t* grp_ids, uint64_t* grp_members,
                         int* own_g /*[S,N]*/, int* mem_g /*[S,N]*/, uint8_t* tilted /*[S,N]*/, hipStream_t stream);
+/* flag[0] |= 1 if the focal groups of scenarios [0,S) (count, focal vehicle or membership mask of any group) differ from the
+ * snapshot ref_*: the device-side form of "did get_data build the same contexts as last step" that gates the K/V-cached
+ * phase; the caller zeroes flag and copies it to the host together with n_groups (one asynchronous copy per step). */
+int ctrlsim_groups_changed(int S, int N, const int* n_groups, const int* grp_focal, const uint64_t* grp_ids, const int* ref_n,
+                           const int* ref_focal, const uint64_t* ref_ids, int* flag, hipStream_t stream);
 int ctrlsim_ctx_index(int s0, int s1, int N, const int* n_groups, const int* grp_focal, const uint64_t* grp_ids,
                       const int* own_g, const int* mem_g, int* ctx_scn, int* ctx_grp, int* own_ctx, int* own_slot,
                       int* mem_ctx, int* mem_slot, int* ctx_base, hipStream_t stream);
@@ -176,12 +181,16 @@ int ctrlsim_attention_presplit(int mode, const float* Q, int ldq, int64_t q_batc
                                int ldo, int64_t o_batch_stride, const int* q_pos, const uint8_t* key_pad, int B, int Lq,
                                int Lk, int A, hipStream_t stream);
 
-/* ---- measurement hooks (bench.py): HIP-event timing of every GEMM (class 0) / attention (class 1) launch on its own
- * launch stream.  enable(1) clears and starts recording; after the caller synchronised, collect() returns per class the
- * summed milliseconds, the launch count and the algorithmic FLOPs (2*M*N*K; 128 per visible (query,key) pair and head). */
+/* ---- measurement hooks (bench.py): HIP-event timing of every launch of ctrlsim_prof_classes() kernel classes on its own
+ * launch stream — 0 GEMM (all Linear layers incl. the fused feed-forward block), 1 attention, 2 build_context, 3 assemble_tokens,
+ * 4 sim_step, 5 map_pool.  enable(1) clears and starts recording; after the caller synchronised, collect() returns per class
+ * the summed milliseconds, the launch count and the algorithmic FLOPs (2*M*N*K; 128 per visible (query,key) pair and head);
+ * bytes() the compulsory HBM bytes (operands read once + results written once) of the same launches.  Arrays hold
+ * ctrlsim_prof_classes() entries.  Process-global and single-threaded like the options below: one host thread per GPU. */
+int ctrlsim_prof_classes(void);
 void ctrlsim_prof_enable(int on);
-int ctrlsim_prof_collect(double* ms2, int64_t* count2, double* flops2);
-int ctrlsim_prof_bytes(double* bytes2);   /* compulsory HBM bytes (operands read once + results written once) of the same launches */
+int ctrlsim_prof_collect(double* ms, int64_t* count, double* flops);
+int ctrlsim_prof_bytes(double* bytes);
 
 /* Runtime options: key 0 = attention path, key 1 = GEMM path of the forward; value 0 = f32-input MFMA
  * (v_mfma_f32_32x32x2_f32), 1 = split-bf16 "bf16x6" MFMA with fp32-class accuracy (default). */

@@ -248,6 +248,34 @@ def gen_closed_loop():
     save("closed_loop", **out)
 
 
+def gen_closed_loop_full():
+    """The unmodified reference policy + real FreeCar/Box2D at the FULL model dims (A=24, T=32, P=200, 100 points) through
+    the sliding-window phase: 12 vehicles x 40 steps over 230 polylines (P_all > P: nearest-polyline selection every
+    step).  Steps 32..39 re-origin the frame at the focal agent's pose of window index 0 = t-31
+    (autoregressive_policy.py:55-70, dataset.py:390-394).  Second case: 30 vehicles (> 24 context slots: several focal
+    groups per step) x 36 steps."""
+    out = {}
+    for tag, n_ag, n_pl, steps, extent, tilt in (("a", 12, 230, 40, 40.0, (0.0, 0.0, 0.0)),
+                                                  ("b", 30, 210, 36, 45.0, (5.0, -10.0, 10.0))):
+        cfg = spec.make_cfg(nocturne__steps=steps)
+        d = spec.Dims(cfg)
+        w = weights.generate(d, 0)
+        scn = scenarios.make_scenario(11, {"a": 0, "b": 1}[tag], n_agents=n_ag, n_polylines=n_pl, n_points=d.NP, extent=extent)
+        import time
+        t0 = time.time()
+        r = ref_closed_loop(cfg, w, scn, steps, seed=5, tilt=tilt)
+        print(tag, f"{time.time() - t0:.0f} s; groups/step", r["n_groups"], "min race margin", r["margins"].min(),
+              "collisions", r["coll"].sum(0).sum(0))
+        for k in ("tokens", "rtg_cont", "states", "coll", "actions", "n_groups", "margins"):
+            out[f"{tag}_{k}"] = r[k]
+        g = r["groups"]
+        out[f"{tag}_groups_t_focal"] = np.array([(t, f) for t, f, _, _ in g])
+        out[f"{tag}_groups_ids"] = np.array([ids + [-1] * (d.A - len(ids)) for _, _, ids, _ in g])
+        out[f"{tag}_groups_members"] = np.array([m + [-1] * (n_ag - len(m)) for _, _, _, m in g])
+        out[f"{tag}_recipe"] = np.array([11, {"a": 0, "b": 1}[tag], n_ag, n_pl, extent, 5, *tilt, steps])
+    save("closed_loop_full", **out)
+
+
 # --------------------------------------------------------------------------------------------- G4 features
 def gen_features():
     """Reference get_data() on hand-built policy buffers: exercises select_relevant_agents (first call and
@@ -897,7 +925,7 @@ def gen_dt_loop():
 
 
 ALL = dict(model=gen_model, features=gen_features, sampling=gen_sampling, physics=gen_physics,
-           collision=gen_collision, closed_loop=gen_closed_loop, bicycle=gen_bicycle, contacts=gen_contacts,
+           collision=gen_collision, closed_loop=gen_closed_loop, closed_loop_full=gen_closed_loop_full, bicycle=gen_bicycle, contacts=gen_contacts,
            planner_adversary=gen_planner_adversary, ingest=gen_ingest,
            variants=gen_variants, dense_reward=gen_dense_reward, dt_loop=gen_dt_loop)
 

@@ -20,3 +20,20 @@ def pytest_sessionstart(session):
     if not os.path.exists(so) and os.path.exists("/opt/rocm/bin/hipcc"):
         import __graft_entry__
         __graft_entry__.build()
+
+
+def pytest_collection_modifyitems(config, items):
+    """gpu-marked tests are skipped (not failed) where no HIP device is visible, so a plain `pytest tests` is green on a
+    CPU box; on the GPU box `-m gpu` runs them."""
+    try:
+        import torch
+        have = torch.cuda.is_available()
+    except Exception:
+        have = False
+    if have:
+        return
+    import pytest
+    skip = pytest.mark.skip(reason="needs a HIP device (run with -m gpu on an MI355X box)")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)

@@ -277,6 +277,89 @@ def test_closed_loop_rollout_matches_reference_fixture(tag):
         assert np.array_equal(r["coll"][s], g[f"{tag}_coll"])
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_closed_loop_full_dims_through_sliding_window_matches_reference_fixture(tag):
+    """The unmodified reference policy + real FreeCar/Box2D at the FULL model dims (A=24, T=32, P=200) for 40 / 36 steps
+    (tests/golden/closed_loop_full.npz, oracle/gen_golden.py::gen_closed_loop_full): the last steps run in the
+    sliding-window phase where the frame re-origins at the focal pose of window index 0 = t-31 every step
+    (autoregressive_policy.py:55-70, dataset.py:390-394) — >90 % of the bench's run time.  Tokens / RTG bins / groups /
+    collision flags bit-exact, float32 states within 1e-4.  Run with and without the KV-cached phase."""
+    cfg = spec.make_cfg()
+    d = spec.Dims(cfg)
+    g = golden("closed_loop_full")
+    rc = g[f"{tag}_recipe"]
+    steps = int(rc[9])
+    cfg = spec.make_cfg(nocturne__steps=steps)
+    scn = scenarios.make_scenario(int(rc[0]), int(rc[1]), n_agents=int(rc[2]), n_polylines=int(rc[3]), n_points=d.NP,
+                                  extent=float(rc[4]))
+    assert steps > d.T + 2
+    model = None
+    for cache in (True, False):
+        eng = RolloutEngine(cfg, weights.generate(d, 0), DEV, max_ctx=16, seed=int(rc[5]), tilt=tuple(rc[6:9]), use_cache=cache,
+                            model=model)
+        model = eng.model
+        eng.load_scenarios([scn, scn], steps=steps)
+        r = eng.run(steps).results()
+        for s in range(2):
+            assert np.array_equal(r["n_groups"][:, s], g[f"{tag}_n_groups"])
+            bad = np.argwhere(r["tokens"][s] != g[f"{tag}_tokens"])
+            assert len(bad) == 0, (cache, bad[:5])
+            np.testing.assert_allclose(fo.undiscretize_rtgs(r["rtg_bins"][s], cfg.dataset.waymo), g[f"{tag}_rtg_cont"], atol=1e-9)
+            np.testing.assert_allclose(r["states"][s], g[f"{tag}_states"], atol=1e-4, rtol=0)
+            assert np.array_equal(r["coll"][s], g[f"{tag}_coll"])
+
+
+def test_tilt_sweep_in_one_batch_matches_oracle_per_tilt():
+    """BASELINE configs[4] against the CPU oracle (not against the HIP path itself): scenario i of one batch runs with its own
+    tilt triple (`tilt_scn`); the oracle runs each scenario alone with that triple as the policy's tilt_dict
+    (policies/policy.py:108-142, dataset.py:371-387)."""
+    cfg = cfg_of("loop")
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    sweep = np.array([-20.0, -10.0, -5.0, 0.0, 5.0, 10.0, 20.0, 30.0])
+    tilts = np.repeat(sweep[:, None], 3, axis=1)
+    scns = [scenarios.make_scenario(53, i, n_agents=9, n_polylines=14, n_points=d.NP, extent=32.0) for i in range(8)]
+    eng = RolloutEngine(cfg, w, DEV, max_ctx=48, seed=6, tilt=tilts)
+    eng.load_scenarios(scns, steps=12)
+    r = eng.run(12).results()
+    for i, scn in enumerate(scns):
+        o = rollout_oracle.RolloutOracle(cfg, w, seed=6, tilt=tuple(tilts[i])).run(scn, 12, sim_libs.OracleSim)
+        assert np.array_equal(r["n_groups"][:, i], o["n_groups"]), i
+        assert np.array_equal(r["tokens"][i][:, :12], o["tokens"]), i
+        assert np.array_equal(r["rtg_bins"][i][:, :12], o["rtg_bins"]), i
+        np.testing.assert_allclose(r["states"][i], o["states"], atol=1e-4, rtol=0)
+        assert np.array_equal(r["coll"][i], o["coll"]), i
+
+
+def test_config1_shape_rollout_properties():
+    """BASELINE configs[1] shape (32 vehicles x 200 polylines x 90 steps, full model; beyond the CPU oracle): the first 3 steps
+    of one scenario are checked against the oracle; over the 90 steps a scenario's rollout is independent of its batch
+    neighbours, of the chunking and of the scenario order; P_all = P = 200 means no polyline is ever dropped."""
+    cfg = spec.make_cfg(nocturne__steps=90, nocturne__history_steps=1)
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    scns = [scenarios.make_scenario(0, i, n_agents=32, n_polylines=200) for i in range(4)]
+    runs, model = {}, None
+    for tag, order, max_ctx in (("ref", [0, 1, 2, 3], 64), ("rechunk", [3, 1, 0, 2], 20)):
+        eng = RolloutEngine(cfg, w, DEV, max_ctx=max_ctx, seed=0, model=model)
+        model = eng.model
+        eng.load_scenarios([scns[i] for i in order], steps=90)
+        r = eng.run(90).results()
+        runs[tag] = {i: {k: (r[k][pos] if k != "n_groups" else r[k][:, pos]) for k in ("tokens", "rtg_bins", "states", "coll", "n_groups")}
+                     for pos, i in enumerate(order)}
+    for i in range(4):
+        a, b = runs["ref"][i], runs["rechunk"][i]
+        assert np.isfinite(a["states"]).all() and a["tokens"].min() >= 0 and a["tokens"].max() < d.V
+        assert a["n_groups"].min() >= 2
+        for k in ("n_groups", "tokens", "rtg_bins", "coll", "states"):
+            assert np.array_equal(a[k], b[k]), (i, k)
+    o = rollout_oracle.RolloutOracle(cfg, w, seed=0).run(scns[0], 3, sim_libs.OracleSim)
+    a = runs["ref"][0]
+    assert np.array_equal(a["n_groups"][:3], o["n_groups"])
+    assert np.array_equal(a["tokens"][:, :3], o["tokens"])
+    np.testing.assert_allclose(a["states"][:, :4], o["states"], atol=1e-4, rtol=0)
+
+
 def test_rollout_matches_oracle_on_fresh_scenarios_full_dims():
     """Full-size model (A=24, T=32, P=200), N=12 vehicles, 260 polylines (exercises nearest-200 selection), 6 steps,
     two scenarios in one batch vs the CPU oracle run per scenario."""
