@@ -39,6 +39,7 @@ SIGNATURES = {
     "ctrlsim_prof_bytes": (I, [P]),
     "ctrlsim_gemm_nt": (I, [P, I, P, I, P, P, I, P, I, I, I, I, I, P]),
     "ctrlsim_gemm_nt_bf16x6": (I, [P, I, P, I, I, P, P, I, P, I, I, I, I, I, P, P, P]),
+    "ctrlsim_gemm_nt_kv": (I, [P, I, P, I, I, P, P, I, I, I, I, P, I, I, I, P]),
     "ctrlsim_ffn_fused": (I, [P, I, P, P, P, P, P, P, P, I, I, I, P]),
     "ctrlsim_layernorm256": (I, [P, I, P, I, P, P, P, I, I, I, P]),
     "ctrlsim_kv_split": (I, [P, P, I, L, P, I, I, I, P, P]),
@@ -49,11 +50,20 @@ SIGNATURES = {
     "ctrlsim_sim_step": (I, [I, I, I, P, P, P, P, P, P, P, P, P, P, I, I, F, I, P, P]),
     "ctrlsim_group_build": (I, [I, I, I, I, I, I, D, P, P, I, P, P, P, P, P, P, P, P, P]),
     "ctrlsim_groups_changed": (I, [I, I, P, P, P, P, P, P, P, P]),
+    "ctrlsim_group_size_hist": (I, [I, I, P, P, I, P, P, P]),
+    "ctrlsim_ctx_index_classes": (I, [I, I, I, I, P, P, P, P, I, P, P, P, P, P, P, P, P, P, P]),
     "ctrlsim_ctx_index": (I, [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "ctrlsim_build_context": (I, [I] * 12 + [P] * 12 + [C.POINTER(Ctx), P]),
     "ctrlsim_model_create": (I, [C.POINTER(Dims), P, I, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(P)]),
     "ctrlsim_model_destroy": (None, [P]),
     "ctrlsim_forward_workspace_bytes": (L, [C.POINTER(Dims), I, I]),
+    "ctrlsim_forward_workspace_bytes_a": (L, [C.POINTER(Dims), I, I, I]),
+    "ctrlsim_dt_forward_pass1_a": (I, [P, I, I, I, C.POINTER(Ctx), P, P, P, P]),
+    "ctrlsim_dt_forward_pass2_a": (I, [P, I, I, I, I, I, I, C.POINTER(Ctx), P, P, P, P, I, P]),
+    "ctrlsim_dt_forward_pass1_cached_a": (I, [P, I, I, I, C.POINTER(Ctx), P, P, P]),
+    "ctrlsim_attention_compact": (I, [P, I, L, P, I, P, I, L, P, I, I, I, I, I, I, I, P]),
+    "ctrlsim_sample_rtg_rows": (I, [P, P, I, P, P, P, P, P, P, U64, P, I, P, I, I, I, P]),
+    "ctrlsim_sample_action_rows": (I, [P, P, I, P, P, F, D, P, U64, P, I, P, P, I, I, I, I, P]),
     "ctrlsim_dt_forward_pass1": (I, [P, I, I, C.POINTER(Ctx), P, P, P, P]),
     "ctrlsim_dt_forward_actions": (I, [P, I, I, C.POINTER(Ctx), P, P, P]),
     "ctrlsim_dt_forward_pass2": (I, [P, I, I, I, I, I, C.POINTER(Ctx), P, P, P, P, I, P]),

@@ -6,6 +6,8 @@ int launch_gemm_nt(const float*, int, const float*, int, const float*, const flo
                    hipStream_t);
 int launch_gemm_nt_bf16x6(const float*, int, const void*, int, int, const float*, const float*, int, float*, int, int, int,
                           int, int, const float*, const float*, hipStream_t);
+int launch_gemm_nt_bf16x6_kv(const float*, int, const void*, int, int, const float*, const float*, int, float*, int, int, int,
+                             int, int, const float*, const float*, void*, int, int, int, int, int, hipStream_t);
 int launch_layernorm256(const float*, int, const float*, int, const float*, const float*, float*, int, int, int,
                         hipStream_t);
 int launch_attention(int, const float*, int, long, const float*, const float*, int, long, float*, int, long, const int*,
@@ -13,7 +15,7 @@ int launch_attention(int, const float*, int, long, const float*, const float*, i
 int launch_kv_split(const float*, const float*, int, long, int, int, int, void*, hipStream_t);
 int launch_kv_split_rows(const float*, const float*, int, long, const int*, int, int, int, void*, hipStream_t);
 int launch_attention_bf16x6_pre(int, const float*, int, long, const void*, int, float*, int, long, const int*,
-                                const unsigned char*, int, int, int, int, hipStream_t);
+                                const unsigned char*, int, int, int, int, int, int, int, hipStream_t);
 int launch_ffn_fused_bf16x6(const float*, int, const void*, const float*, const void*, const float*, const float*, const float*,
                             float*, int, int, int, hipStream_t);
 int launch_sim_init(int, int, int, const float*, const float*, const float*, const unsigned char*, float*, float*,
@@ -30,9 +32,12 @@ struct CtxOut { float *st12, *exist, *goal5; int *act_tok, *rtg_bin, *tstep, *sl
 int launch_build_context(int, int, int, int, int, int, int, int, int, int, int, int, const int*, const int*, const int*,
                          const unsigned long long*, const float*, const int*, const int*, const double*, const float*,
                          const float*, const float*, const int*, CtxOut, hipStream_t);
-int launch_sample_rtg(const float*, int, int, const int*, const int*, const unsigned char*, const double*, const double*, const float*,
-                      uint64_t, const int64_t*, int, int*, int, int, int, hipStream_t);
-int launch_sample_action(const float*, int, int, const int*, const int*, float, double, const float*, uint64_t,
+int launch_sample_rtg(const float*, int, int, const int*, const int*, const int*, const unsigned char*, const double*, const double*,
+                      const float*, uint64_t, const int64_t*, int, int*, int, int, int, hipStream_t);
+int launch_group_size_hist(int, int, const int*, const unsigned long long*, int, const int*, int*, hipStream_t);
+int launch_ctx_index_classes(int, int, int, int, const int*, const unsigned long long*, const int*, const int*, int, const int*, int*,
+                             int*, int*, int*, int*, int*, int*, int*, hipStream_t);
+int launch_sample_action(const float*, int, int, const int*, const int*, const int*, float, double, const float*, uint64_t,
                          const int64_t*, int, int*, int*, int, int, int, int, hipStream_t);
 
 #include <vector>
@@ -109,6 +114,11 @@ int ctrlsim_gemm_nt_bf16x6(const float* A, int lda, const void* W3, int n_total,
                            const float* ln_beta, hipStream_t st) {
   return launch_gemm_nt_bf16x6(A, lda, W3, n_total, n0, bias, R, ldr, C, ldc, M, N, K, relu, ln_gamma, ln_beta, st);
 }
+int ctrlsim_gemm_nt_kv(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias, float* C, int ldc,
+                       int M, int N, int K, void* kv_img, int kv_L, int kv_nkt, int kv_col0, hipStream_t st) {
+  return launch_gemm_nt_bf16x6_kv(A, lda, W3, n_total, n0, bias, nullptr, 0, C, ldc, M, N, K, 0, nullptr, nullptr, kv_img, kv_L,
+                                  kv_nkt, kv_col0, 0, 0, st);
+}
 int ctrlsim_ffn_fused(const float* X, int ldx, const void* W1p, const float* b1, const void* W2p, const float* b2,
                       const float* gamma, const float* beta, float* Y, int ldy, int M, int F, hipStream_t st) {
   return launch_ffn_fused_bf16x6(X, ldx, W1p, b1, W2p, b2, gamma, beta, Y, ldy, M, F, st);
@@ -125,7 +135,14 @@ int ctrlsim_kv_split(const float* K, const float* V, int ldkv, int64_t kbs, cons
 int ctrlsim_attention_presplit(int mode, const float* Q, int ldq, int64_t qbs, const void* img, int nkt, float* O, int ldo,
                                int64_t obs, const int* q_pos, const uint8_t* key_pad, int B, int Lq, int Lk, int A,
                                hipStream_t st) {
-  return launch_attention_bf16x6_pre(mode, Q, ldq, (long)qbs, img, nkt, O, ldo, (long)obs, q_pos, key_pad, B, Lq, Lk, A, st);
+  return launch_attention_bf16x6_pre(mode, Q, ldq, (long)qbs, img, nkt, O, ldo, (long)obs, q_pos, key_pad, B, Lq, Lk, A, 0, 1, Lk,
+                                     st);
+}
+int ctrlsim_attention_compact(const float* Q, int ldq, int64_t qbs, const void* img, int nkt, float* O, int ldo, int64_t obs,
+                              const int* q_pos, int B, int Lq, int Lk, int A, int rep_keys, int rep_mult, int rep_pos0,
+                              hipStream_t st) {
+  return launch_attention_bf16x6_pre(1, Q, ldq, (long)qbs, img, nkt, O, ldo, (long)obs, q_pos, nullptr, B, Lq, Lk, A, rep_keys,
+                                     rep_mult, rep_pos0, st);
 }
 int ctrlsim_attention(int mode, const float* Q, int ldq, int64_t qbs, const float* K, const float* V, int ldkv, int64_t kbs,
                       float* O, int ldo, int64_t obs, const int* q_pos, const uint8_t* key_pad, int B, int Lq, int Lk, int A,
@@ -178,13 +195,37 @@ int ctrlsim_sample_rtg(const float* rtg_logits, int A, int R, const int* own_ctx
                        const double* tilt3, const double* tilt_scn, const float* noise, uint64_t seed, const int64_t* scenario_id,
                        int t, int* hist_rtg, int S, int N, int Tmax, hipStream_t st) {
   if (!tilt3) return CTRLSIM_EINVAL;
-  return launch_sample_rtg(rtg_logits, A, R, own_ctx, own_slot, tilted, tilt3, tilt_scn, noise, seed, scenario_id, t, hist_rtg, S, N,
-                           Tmax, st);
+  return launch_sample_rtg(rtg_logits, A, R, own_ctx, own_slot, nullptr, tilted, tilt3, tilt_scn, noise, seed, scenario_id, t, hist_rtg,
+                           S, N, Tmax, st);
+}
+int ctrlsim_sample_rtg_rows(const float* rtg_logits, const int* ctx_row0, int R, const int* own_ctx, const int* own_slot,
+                            const uint8_t* tilted, const double* tilt3, const double* tilt_scn, const float* noise, uint64_t seed,
+                            const int64_t* scenario_id, int t, int* hist_rtg, int S, int N, int Tmax, hipStream_t st) {
+  if (!tilt3 || !ctx_row0) return CTRLSIM_EINVAL;
+  return launch_sample_rtg(rtg_logits, 0, R, own_ctx, own_slot, ctx_row0, tilted, tilt3, tilt_scn, noise, seed, scenario_id, t,
+                           hist_rtg, S, N, Tmax, st);
+}
+int ctrlsim_sample_action_rows(const float* act_logits, const int* ctx_row0, int V, const int* mem_ctx, const int* mem_slot,
+                               float temperature, double top_p, const float* noise, uint64_t seed, const int64_t* scenario_id,
+                               int t, int* hist_tok, int* act_now, int S, int N, int Tmax, int zero_token, hipStream_t st) {
+  if (!ctx_row0) return CTRLSIM_EINVAL;
+  return launch_sample_action(act_logits, 0, V, mem_ctx, mem_slot, ctx_row0, temperature, top_p, noise, seed, scenario_id, t,
+                              hist_tok, act_now, S, N, Tmax, zero_token, st);
+}
+int ctrlsim_group_size_hist(int S, int N, const int* n_groups, const uint64_t* grp_ids, int nb, const int* sizes, int* hist,
+                            hipStream_t st) {
+  return launch_group_size_hist(S, N, n_groups, (const unsigned long long*)grp_ids, nb, sizes, hist, st);
+}
+int ctrlsim_ctx_index_classes(int s0, int s1, int N, int A, const int* n_groups, const uint64_t* grp_ids, const int* own_g,
+                              const int* mem_g, int nb, const int* sizes, int* ctx_scn, int* ctx_grp, int* ctx_row0,
+                              int* ctx_of_group, int* own_ctx, int* own_slot, int* mem_ctx, int* mem_slot, hipStream_t st) {
+  return launch_ctx_index_classes(s0, s1, N, A, n_groups, (const unsigned long long*)grp_ids, own_g, mem_g, nb, sizes, ctx_scn,
+                                  ctx_grp, ctx_row0, ctx_of_group, own_ctx, own_slot, mem_ctx, mem_slot, st);
 }
 int ctrlsim_sample_action(const float* act_logits, int A, int V, const int* mem_ctx, const int* mem_slot, float temperature,
                           double top_p, const float* noise, uint64_t seed, const int64_t* scenario_id, int t, int* hist_tok,
                           int* act_now, int S, int N, int Tmax, int zero_token, hipStream_t st) {
-  return launch_sample_action(act_logits, A, V, mem_ctx, mem_slot, temperature, top_p, noise, seed, scenario_id, t, hist_tok,
+  return launch_sample_action(act_logits, A, V, mem_ctx, mem_slot, nullptr, temperature, top_p, noise, seed, scenario_id, t, hist_tok,
                               act_now, S, N, Tmax, zero_token, st);
 }
 

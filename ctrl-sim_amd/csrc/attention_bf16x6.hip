@@ -20,6 +20,7 @@
 // One accumulator chain per product: with three waves per SIMD the matrix pipe stays fed across the dependent MFMAs
 // (measured: 1829 vs 1966 TFLOP/s register-only), and the merge adds / second rescale / 32 registers go away.
 #include "split.h"
+#include <type_traits>
 
 #ifndef ATT_PMAX
 #define ATT_PMAX 32768.0f     // row-sum bound of the speculative softmax path: every probability then fits the fp16 plane
@@ -54,7 +55,18 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
     const float* __restrict__ Q, int ldq, long q_batch_stride, const float* __restrict__ K,
     const float* __restrict__ V, int ldkv, long kv_batch_stride, float* __restrict__ O, int ldo, long o_batch_stride,
     const int* __restrict__ q_pos, const unsigned char* __restrict__ key_pad, int Lq, int Lk, int A, float scale_log2e,
-    int variant) {
+    int variant, int rep_keys, float log2m, int rep_pos0) {
+  // rep_keys > 0 (causal, PRE): COMPACT contexts.  Token rows of agent slots that never exist in the window are all equal
+  // (every embedding is multiplied by the existence flag before embed_ln, modules/encoder.py:127-133, and the decoder has
+  // no key padding on its targets), and by induction over the layers so are their hidden states at equal (timestep, token
+  // type): the 24 - n padded slots of a context are therefore evaluated ONCE, as a "representative" slot whose tokens stand
+  // for m = 2^log2m identical ones.  Sequence order of such a context: Lk "regular" tokens, (timestep, slot < A, type) as
+  // always (positions < rep_pos0 = the regular length of the FULL window; Lk of them are attended), then rep_keys = 3 Tq
+  // representative tokens (timestep, type) at positions rep_pos0 + 3 t + k, whose K/V tiles start at tile ceil(rep_pos0 / 64).
+  // A representative key (t, k) is visible to a query of timestep tq iff t < tq or (t == tq and k == 0), each time with
+  // multiplicity m (+log2m on the score: softmax over m equal keys); to the representative's own queries (positions
+  // >= rep_pos0) also its own tokens 1..kq of step tq, once.  Representative queries see regular keys like a query without own
+  // tokens (earlier steps, and the state tokens of their step).
   constexpr int K_PLANE = KT6 * HD;              // bf16 elements: [ks 2][half 2][64 keys][8]
   constexpr int V_PLANE = HD * KT6;              // [16 quads][32 d][4 keys]
   constexpr int BUF = NPL * (K_PLANE + V_PLANE) + 2 * KT6;   // + KT6 floats of key-padding bias
@@ -81,11 +93,18 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
   const int qrow = qvalid ? qi : (Lq - 1);
   const int pos = q_pos ? q_pos[qrow] : qrow;
   int tq = 0, aq = 0, kq = 0;
+  bool rep_q = false;                               // this lane's query is a representative token
   if (MODE == MODE6_CAUSAL) {
-    tq = pos / A3;
-    const int rem = pos - tq * A3;
-    aq = rem / 3;
-    kq = rem - aq * 3;
+    rep_q = rep_keys > 0 && pos >= rep_pos0;
+    if (rep_q) {
+      tq = (pos - rep_pos0) / 3;
+      kq = (pos - rep_pos0) - tq * 3;
+    } else {
+      tq = pos / A3;
+      const int rem = pos - tq * A3;
+      aq = rem / 3;
+      kq = rem - aq * 3;
+    }
   }
   opx8 qf[2][NPL];
   {
@@ -102,7 +121,7 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
   }
 
   // ---- key range
-  int k_end = Lk;
+  int k_end = Lk, rep_need = 0;                    // regular keys [0, k_end) and representative keys [0, rep_need) matter
   int tq_min_w = 0, tq_max_w = 0;
   if (MODE == MODE6_CAUSAL) {
     int tmin = tq, tmax = tq;
@@ -117,6 +136,7 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
     __syncthreads();
     const int bt = max(max(blk_tmax[0], blk_tmax[1]), max(blk_tmax[2], blk_tmax[3]));
     k_end = __builtin_amdgcn_readfirstlane(min(Lk, (bt + 1) * A3));
+    rep_need = __builtin_amdgcn_readfirstlane(min(rep_keys, (bt + 1) * 3));
   }
 
   f32x16 oa;                                       // O^T accumulator
@@ -140,8 +160,18 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
 #pragma unroll
       for (int i = 0; i < KV_PIECES; ++i) {
         op_t* dst = arena + buf * BUF + (wave * 64 + 256 * i) * 8;          // wave-uniform LDS base (+ 16 B per lane)
+#ifdef ATT_DMA_BUILTIN
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 256 * 8 * i),
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+#else
+        // Issued as inline asm on purpose: hipcc answers the builtin with `s_waitcnt vmcnt(0)` in front of the NEXT ds_read
+        // of any LDS address (it cannot tell the two stage buffers apart), i.e. every wave sat out the whole L2 / HBM
+        // latency of the tile it had just requested before touching the tile it already had.  The compiler does not see
+        // this load; the wave waits for its own pieces explicitly right before the end-of-tile barrier (dma_wait).
+        const unsigned lds_addr = (unsigned)(size_t)((__attribute__((address_space(3))) op_t*)dst);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off ; KV-DMA"
+                     :: "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(src + 256 * 8 * i) : "memory");
+#endif
       }
     } else {
 #pragma unroll
@@ -190,38 +220,28 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
     if (MODE == MODE6_KEYPAD && tid < KT6) reinterpret_cast<float*>(Vd + NPL * V_PLANE)[tid] = ppad;
   };
 
-  if (k_end > 0) {
-    gload(0, 0);
+  // ---- tile schedule: the regular tiles [0, n_reg) that hold keys < k_end, then the representative tiles (compact contexts)
+  const int n_reg = (k_end + KT6 - 1) / KT6, n_rep = (rep_need + KT6 - 1) / KT6, n_it = n_reg + n_rep;
+  const int nkt_reg = (rep_pos0 + KT6 - 1) / KT6;
+  auto tile_k0 = [&](int it) { return (it < n_reg ? it : nkt_reg + (it - n_reg)) * KT6; };
+  if (n_it > 0) {
+    gload(tile_k0(0), 0);
     sstore(0);
   }
+#ifndef ATT_DMA_BUILTIN
+  if (PRE) asm volatile("s_waitcnt vmcnt(0) ; KV-DMA landed" ::: "memory");
+#endif
   __syncthreads();
 #ifdef ATT_TIMING
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = __builtin_amdgcn_s_memtime();
 #endif
-  int cur = 0;
-  for (int k0 = 0; k0 < k_end; k0 += KT6, cur ^= 1) {
-    const bool more = k0 + KT6 < k_end;
-    if (more) gload(k0 + KT6, cur ^ 1);
-    TSTAMP(0) TCOUNT(7)
-    const op_t* Ks = arena + cur * BUF;
-    const op_t* Vs = Ks + NPL * K_PLANE;
-    const float* padbias = reinterpret_cast<const float*>(Vs + NPL * V_PLANE);
 
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      const int ks0 = k0 + sub * 32;
-      // timestep of the first / last key of this sub-tile (tracked incrementally: no divisions in the loop)
-      const int t_lo = tk_t, t_hi = min(tk_t + (tk_r + 31 >= A3 ? (tk_r + 31 - A3 >= A3 ? (tk_r + 31) / A3 : 1) : 0), t_last);
-      const int ks_t0 = ks0 - tk_r;                 // position of the first key of timestep t_lo
-      tk_r += 32;
-      while (tk_r >= A3) { tk_r -= A3; ++tk_t; }
-      if (ks0 >= k_end) continue;
-      bool need_mask = true;
-      if (MODE == MODE6_CAUSAL) {
-        if (t_lo > tq_max_w) continue;
-        need_mask = !(t_hi < tq_min_w && ks0 + 31 < Lk) || variant != 0;   // IL / Trajeglish: dead key types everywhere
-      }
+  // ---- one 32-key sub-tile: scores, mask, online softmax, P.V.  MASK 0 = none (all 32 keys visible), 1 = key padding
+  // (padbias), 2 = visibility word vis_all (bit i <-> key i of the sub-tile), 3 = vis_all + multiplicity bias on bias_all
+  auto sub_tile = [&](const op_t* Ks, const op_t* Vs, const float* padbias, int sub, auto MASK_, unsigned vis_all,
+                      unsigned bias_all) {
+    constexpr int MASK = decltype(MASK_)::value;
       // ---- S^T = K . Q^T : one accumulator chain, k-steps d 0-15 and d 16-31, six partial products each
       // the accumulator starts at -m_base (the running maximum, 0 before the first visible key): the MFMA chain then
       // delivers S - m directly and the per-element subtraction is needed only in the (rare) sub-tiles that raise the maximum
@@ -252,38 +272,19 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
 #endif
       }
       float sc[16];
-      if (MODE == MODE6_KEYPAD) {
+      if (MASK == 1) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = s0[r] + padbias[sub * 32 + mfma_row(r, half)];
-      } else if (need_mask) {
-        // visibility of the 32 keys of this sub-tile for this lane's query as a bit mask (bit i <-> key ks0 + i):
-        //   keys of earlier timesteps: all; of the query's timestep: every state token (offset % 3 == 0) and the query's
-        //   own agent's tokens up to the query itself; later timesteps and keys >= Lk: none.
-        asm volatile("" ::: "memory");   // keep this a real (scalar) branch: hipcc otherwise speculates the mask math for every sub-tile
-        auto ones = [](int n) -> unsigned { return n >= 32 ? 0xFFFFFFFFu : (n <= 0 ? 0u : ((1u << n) - 1u)); };
-        const int same0 = tq * A3 - ks0;                                   // first key of the query's timestep
-        const unsigned before = ones(same0);
-        const unsigned same = ones(min(same0 + A3, Lk - ks0)) & ~before;
-        int off3 = (ks_t0 - ks0) % 3;                                      // ks_t0 <= ks0: first state token at or after ks0
-        off3 = off3 < 0 ? off3 + 3 : off3;
-        const unsigned every3 = (unsigned)(0x249249249249ull << off3);
-        // variant 3 (Decision Transformer, token order rtg, state, action — kept in the slots state, rtg, action): a state
-        // token also sees its own agent's rtg token, one position AFTER it
-        const unsigned own = ones(pos - ks0 + 1 + ((variant == 3 && kq == 0) ? 1 : 0)) & ~ones(pos - kq - ks0);
-        unsigned vis_all = before | ((every3 | own) & same);
-        if (variant) {
-          // the 3-slot token layout is kept for the baselines of cfgs/model/{il,trajeglish}.yaml; the token types they do not
-          // have are dead as keys.  IL (state, action): rtg keys invisible.  Trajeglish (action only): action keys of earlier
-          // steps and of the WHOLE current step (get_causal_mask with one token type: every same-step token is "the state").
-          int o2 = off3 + 2;
-          o2 = o2 >= 3 ? o2 - 3 : o2;
-          const unsigned actions = (unsigned)(0x249249249249ull << o2);
-          if (variant == 1) vis_all &= every3 | actions;
-          else if (variant == 2) vis_all = (before | same) & actions;
-        }
+      } else if (MASK >= 2) {
         const unsigned vis = vis_all >> (4 * half);
+        const unsigned bia = bias_all >> (4 * half);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = (vis & (1u << ((r & 3) + 8 * (r >> 2)))) ? s0[r] : NEG_INF;
+        for (int r = 0; r < 16; ++r) {
+          const unsigned bit = 1u << ((r & 3) + 8 * (r >> 2));
+          float x = s0[r];
+          if (MASK == 3) x += (bia & bit) ? log2m : 0.f;
+          sc[r] = (vis & bit) ? x : NEG_INF;
+        }
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = s0[r];
@@ -381,9 +382,90 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
         for (int p = 0; p < NPL; ++p) { asm volatile("" ::"v"(v0f[p]), "v"(v1f[p]), "v"(pf[0][p]), "v"(pf[1][p])); }
 #endif
       }
+  };
+  typedef std::integral_constant<int, 0> M_NONE;
+  typedef std::integral_constant<int, 1> M_PAD;
+  typedef std::integral_constant<int, 2> M_VIS;
+  typedef std::integral_constant<int, 3> M_BIAS;
+
+  int cur = 0;
+  for (int it = 0; it < n_it; ++it, cur ^= 1) {
+    const bool more = it + 1 < n_it;
+    if (more) gload(tile_k0(it + 1), cur ^ 1);
+    TSTAMP(0) TCOUNT(7)
+    const op_t* Ks = arena + cur * BUF;
+    const op_t* Vs = Ks + NPL * K_PLANE;
+    const float* padbias = reinterpret_cast<const float*>(Vs + NPL * V_PLANE);
+
+    if (it < n_reg) {
+      const int k0 = it * KT6;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        const int ks0 = k0 + sub * 32;
+        // timestep of the first / last key of this sub-tile (tracked incrementally: no divisions in the loop)
+        const int t_lo = tk_t, t_hi = min(tk_t + (tk_r + 31 >= A3 ? (tk_r + 31 - A3 >= A3 ? (tk_r + 31) / A3 : 1) : 0), t_last);
+        const int ks_t0 = ks0 - tk_r;                 // position of the first key of timestep t_lo
+        tk_r += 32;
+        while (tk_r >= A3) { tk_r -= A3; ++tk_t; }
+        if (ks0 >= k_end) continue;
+        if (MODE == MODE6_KEYPAD) {
+          sub_tile(Ks, Vs, padbias, sub, M_PAD{}, 0u, 0u);
+          continue;
+        }
+        if (t_lo > tq_max_w) continue;
+        const bool need_mask = !(t_hi < tq_min_w && ks0 + 31 < Lk) || variant != 0;   // IL / Trajeglish: dead key types everywhere
+        if (!need_mask) {
+          sub_tile(Ks, Vs, padbias, sub, M_NONE{}, 0u, 0u);
+          continue;
+        }
+        // visibility of the 32 keys of this sub-tile for this lane's query as a bit mask (bit i <-> key ks0 + i):
+        //   keys of earlier timesteps: all; of the query's timestep: every state token (offset % 3 == 0) and the query's
+        //   own agent's tokens up to the query itself; later timesteps and keys >= Lk: none.
+        asm volatile("" ::: "memory");   // keep this a real (scalar) branch: hipcc otherwise speculates the mask math for every sub-tile
+        auto ones = [](int n) -> unsigned { return n >= 32 ? 0xFFFFFFFFu : (n <= 0 ? 0u : ((1u << n) - 1u)); };
+        const int same0 = tq * A3 - ks0;                                   // first key of the query's timestep
+        const unsigned before = ones(same0);
+        const unsigned same = ones(min(same0 + A3, Lk - ks0)) & ~before;
+        int off3 = (ks_t0 - ks0) % 3;                                      // ks_t0 <= ks0: first state token at or after ks0
+        off3 = off3 < 0 ? off3 + 3 : off3;
+        const unsigned every3 = (unsigned)(0x249249249249ull << off3);
+        // variant 3 (Decision Transformer, token order rtg, state, action — kept in the slots state, rtg, action): a state
+        // token also sees its own agent's rtg token, one position AFTER it
+        const unsigned own = rep_q ? 0u
+                                   : (ones(pos - ks0 + 1 + ((variant == 3 && kq == 0) ? 1 : 0)) & ~ones(pos - kq - ks0));
+        unsigned vis_all = before | ((every3 | own) & same);
+        if (variant) {
+          // the 3-slot token layout is kept for the baselines of cfgs/model/{il,trajeglish}.yaml; the token types they do not
+          // have are dead as keys.  IL (state, action): rtg keys invisible.  Trajeglish (action only): action keys of earlier
+          // steps and of the WHOLE current step (get_causal_mask with one token type: every same-step token is "the state").
+          int o2 = off3 + 2;
+          o2 = o2 >= 3 ? o2 - 3 : o2;
+          const unsigned actions = (unsigned)(0x249249249249ull << o2);
+          if (variant == 1) vis_all &= every3 | actions;
+          else if (variant == 2) vis_all = (before | same) & actions;
+        }
+        sub_tile(Ks, Vs, padbias, sub, M_VIS{}, vis_all, 0u);
+      }
+    } else if (MODE == MODE6_CAUSAL) {
+      // representative keys j = 3 t + k of this tile: visible while j <= 3 tq (earlier steps, and the state token of the
+      // query's step), m-fold; the representative's own queries also see their tokens 1..kq of step tq, once
+      const int r0 = (it - n_reg) * KT6;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        const int j0 = r0 + sub * 32;
+        if (j0 >= rep_need || j0 > 3 * tq_max_w + 2) continue;
+        auto ones = [](int n) -> unsigned { return n >= 32 ? 0xFFFFFFFFu : (n <= 0 ? 0u : ((1u << n) - 1u)); };
+        const int bias_end = 3 * tq + 1 - j0;
+        const unsigned bias_all = ones(min(bias_end, rep_keys - j0));
+        const unsigned vis_all = ones(min(bias_end + (rep_q ? kq : 0), rep_keys - j0));
+        sub_tile(Ks, Vs, padbias, sub, M_BIAS{}, vis_all, bias_all);
+      }
     }
     if (more) sstore(cur ^ 1);
     TSTAMP(4)
+#ifndef ATT_DMA_BUILTIN
+    if (PRE) asm volatile("s_waitcnt vmcnt(0) ; KV-DMA landed" ::: "memory");
+#endif
     __syncthreads();
     TSTAMP(5)
   }
@@ -494,12 +576,11 @@ __global__ __launch_bounds__(256) void kv_split_rows_kernel(const float* __restr
   }
 }
 
-// Zero the keys >= Lk of the last tile of every (context, head): producers that write images row by row (the fused QKV
-// GEMM epilogue) leave that tail untouched, and the attention kernel stages whole tiles.
-__global__ __launch_bounds__(256) void kv_zero_tail_kernel(int Lk, int nkt, op_t* __restrict__ img) {
+// Zero the keys >= k0 of tile `tile` of every (context, head): producers that write images row by row (the fused QKV GEMM
+// epilogue) leave the tail of the last tile of a key region untouched, and the attention kernel stages whole tiles.
+__global__ __launch_bounds__(256) void kv_zero_tail_kernel(int k0, int tile, int nkt, op_t* __restrict__ img) {
   constexpr int K_PLANE = KT6 * HD, V_PLANE = HD * KT6;
-  const int k0 = Lk - (nkt - 1) * KT6;                       // first invalid key of the last tile (multiple of 4)
-  op_t* base = img + ((size_t)blockIdx.x * nkt + (nkt - 1)) * KV_IMG;
+  op_t* base = img + ((size_t)blockIdx.x * nkt + tile) * KV_IMG;   // k0 = first invalid key of the tile (multiple of 4)
   const int nk = KT6 - k0;
   for (int i = threadIdx.x; i < 4 * NPL * nk * 4; i += 256) {     // K: 4 NPL (plane, d>>3) runs of nk keys x 8 elements = nk*4 dwords
     const int run = i / (nk * 4), off = i - run * (nk * 4);
@@ -511,10 +592,12 @@ __global__ __launch_bounds__(256) void kv_zero_tail_kernel(int Lk, int nkt, op_t
     reinterpret_cast<unsigned*>(base + NPL * K_PLANE + pl * V_PLANE + q0 * HD * 4)[off] = 0u;
   }
 }
-int launch_kv_zero_tail(int B, int Lk, int nkt, void* img, hipStream_t st) {
-  if (B <= 0 || Lk % KT6 == 0) return CTRLSIM_OK;
-  if (!img || (Lk & 3) || nkt != (Lk + KT6 - 1) / KT6) return CTRLSIM_EINVAL;
-  hipLaunchKernelGGL(kv_zero_tail_kernel, dim3(B * NHEAD), dim3(256), 0, st, Lk, nkt, static_cast<op_t*>(img));
+// keys [key0 + n, end of that tile) of every (context, head): the region of n keys starting at key0 (a multiple of 64)
+int launch_kv_zero_tail(int B, int key0, int n, int nkt, void* img, hipStream_t st) {
+  if (B <= 0 || n % KT6 == 0) return CTRLSIM_OK;
+  const int tile = (key0 + n) / KT6;
+  if (!img || (n & 3) || (key0 & 63) || tile >= nkt) return CTRLSIM_EINVAL;
+  hipLaunchKernelGGL(kv_zero_tail_kernel, dim3(B * NHEAD), dim3(256), 0, st, n % KT6, tile, nkt, static_cast<op_t*>(img));
   return ctrlsim_launch_status();
 }
 
@@ -536,12 +619,15 @@ int launch_kv_split_rows(const float* K, const float* V, int ldkv, long kv_batch
   return ctrlsim_launch_status();
 }
 
-static double attn_pairs(int mode, const int* q_pos, int Lq, int Lk, int A) {
+static double attn_pairs(int mode, const int* q_pos, int Lq, int Lk, int A, int rep_keys = 0) {
   if (mode == MODE6_CAUSAL && !q_pos) {
-    const double A3 = 3.0 * A, T = (double)Lq / A3;
-    return A3 * A3 * T * (T - 1) / 2.0 + T * A * (3.0 * A + 3.0);
+    const double A3 = 3.0 * A, T = (double)Lk / A3;
+    double pairs = A3 * A3 * T * (T - 1) / 2.0 + T * A * (3.0 * A + 3.0);
+    if (rep_keys > 0)   // regular queries x representative keys (3t + 1 each), representative queries x (regular + own) keys
+      pairs += A3 * (3.0 * T * (T - 1) / 2.0 + T) + 3.0 * A3 * T * (T - 1) / 2.0 + 3.0 * A * T + 9.0 * T * (T - 1) / 2.0 + 6.0 * T;
+    return pairs;
   }
-  return (double)Lq * (double)Lk;
+  return (double)Lq * (double)(Lk + rep_keys);
 }
 
 int launch_attention_bf16x6(int mode, const float* Q, int ldq, long q_batch_stride, const float* K, const float* V,
@@ -557,37 +643,45 @@ int launch_attention_bf16x6(int mode, const float* Q, int ldq, long q_batch_stri
   prof_before(PROF_ATTN, st);
   if (mode == MODE6_CAUSAL) {
     hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, false>), g, blk, 0, st, Q, ldq, q_batch_stride, K, V, ldkv,
-                       kv_batch_stride, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale, variant);
+                       kv_batch_stride, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale, variant, 0, 0.f, 0);
   } else {
     hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, false>), g, blk, 0, st, Q, ldq, q_batch_stride, K, V, ldkv,
-                       kv_batch_stride, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale, 0);
+                       kv_batch_stride, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale, 0, 0, 0.f, 0);
   }
   prof_after(PROF_ATTN, attn_pairs(mode, q_pos, Lq, Lk, A) * 128.0 * NHEAD * B, st,
              (double)B * (8.0 * DM * Lq + 8.0 * DM * Lk));
   return ctrlsim_launch_status();
 }
 
-// K / V from split images (launch_kv_split*): img holds nkt tiles per (context, head)
+// K / V from split images (launch_kv_split*): img holds nkt tiles per (context, head).
+// rep_keys > 0 (causal mask of the CtRL-Sim model only): compact contexts — Lk regular keys in tiles [0, ceil(Lk / 64)), and
+// rep_keys representative keys of multiplicity rep_mult in the tiles from ceil(rep_pos0 / 64) on (see the kernel header);
+// rep_pos0 >= Lk is the regular length of the full window (the K/V cache layout); query positions (row index, or q_pos)
+// >= rep_pos0 address the representative's own tokens.
 int launch_attention_bf16x6_pre(int mode, const float* Q, int ldq, long q_batch_stride, const void* img, int nkt, float* O,
                                 int ldo, long o_batch_stride, const int* q_pos, const unsigned char* key_pad, int B, int Lq,
-                                int Lk, int A, hipStream_t st) {
+                                int Lk, int A, int rep_keys, int rep_mult, int rep_pos0, hipStream_t st) {
   if (B <= 0 || Lq <= 0) return CTRLSIM_OK;
-  if (Lk <= 0 || (ldq & 3) || !img || nkt * KT6 < Lk) return CTRLSIM_EINVAL;
+  if (Lk <= 0 || (ldq & 3) || !img || rep_keys < 0) return CTRLSIM_EINVAL;
+  if (rep_keys == 0) rep_pos0 = Lk;
+  if (rep_pos0 < Lk || nkt < (rep_pos0 + KT6 - 1) / KT6 + (rep_keys + KT6 - 1) / KT6) return CTRLSIM_EINVAL;
   if (mode < 0 || mode > 4 || (mode == MODE6_KEYPAD && !key_pad)) return CTRLSIM_EINVAL;
+  if (rep_keys > 0 && (mode != MODE6_CAUSAL || rep_mult < 1 || Lk % (3 * A) || rep_pos0 % (3 * A))) return CTRLSIM_EINVAL;
   const int variant = mode >= MODE6_CAUSAL ? mode - MODE6_CAUSAL : 0;
   mode = mode >= MODE6_CAUSAL ? MODE6_CAUSAL : MODE6_KEYPAD;
   dim3 g((Lq + 127) / 128, NHEAD, B), blk(256);
   const float scale = 0.17677669529663687f * 1.4426950408889634f;
   const float* imgf = static_cast<const float*>(img);
+  const float log2m = rep_keys > 0 ? log2f((float)rep_mult) : 0.f;
   prof_before(PROF_ATTN, st);
   if (mode == MODE6_CAUSAL) {
     hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, true>), g, blk, 0, st, Q, ldq, q_batch_stride, imgf, nullptr, 0,
-                       (long)nkt, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale, variant);
+                       (long)nkt, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale, variant, rep_keys, log2m, rep_pos0);
   } else {
     hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, true>), g, blk, 0, st, Q, ldq, q_batch_stride, imgf, nullptr, 0,
-                       (long)nkt, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale, 0);
+                       (long)nkt, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale, 0, 0, 0.f, 0);
   }
-  prof_after(PROF_ATTN, attn_pairs(mode, q_pos, Lq, Lk, A) * 128.0 * NHEAD * B, st,
-             (double)B * (8.0 * DM * Lq + 4.0 * NPL * DM * Lk));   // Q in + O out (fp32), K and V images (NPL 16-bit planes each)
+  prof_after(PROF_ATTN, attn_pairs(mode, q_pos, Lq, Lk, A, rep_keys) * 128.0 * NHEAD * B, st,
+             (double)B * (8.0 * DM * Lq + 4.0 * NPL * DM * (Lk + rep_keys)));   // Q in + O out (fp32), K and V images (NPL 16-bit planes each)
   return ctrlsim_launch_status();
 }

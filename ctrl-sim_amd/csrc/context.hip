@@ -182,6 +182,71 @@ __global__ __launch_bounds__(256) void ctx_index_kernel(int s0, int s1, int N, c
   }
 }
 
+// Compact contexts (forward.hip: Shape): a context with n vehicles is evaluated with the smallest slot count of `sizes`
+// (ascending, nb <= 8, last = A) that is >= n + 1 — or A itself.  hist[s, k] = focal groups of scenario s that fall into
+// size class k: what the host needs (with n_groups) to cut a step into model batches.
+__device__ __forceinline__ int size_class(int n, const int* sizes, int nb) {
+  int k = 0;
+  while (k < nb - 1 && sizes[k] < n + 1) ++k;
+  return k;
+}
+struct SizeClasses { int nb; int sizes[8]; };
+__global__ __launch_bounds__(256) void group_size_hist_kernel(int S, int N, const int* __restrict__ n_groups,
+                                                              const unsigned long long* __restrict__ grp_ids, SizeClasses sc,
+                                                              int* __restrict__ hist) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  int h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int g = 0; g < n_groups[s]; ++g) ++h[size_class(__popcll(grp_ids[(size_t)s * N + g]), sc.sizes, sc.nb)];
+  for (int k = 0; k < sc.nb; ++k) hist[(size_t)s * sc.nb + k] = h[k];
+}
+
+// ctx_index with the contexts of scenarios [s0, s1) SORTED by size class (stable in (scenario, group) order inside a class):
+// class k occupies contexts [start_k, start_k + count_k).  ctx_row0[c] = first logits row of context c when every class
+// writes (slots - 1, or A for the last class) rows per context, classes in order.  One block.
+__global__ __launch_bounds__(256) void ctx_index_classes_kernel(int s0, int s1, int N, int A, const int* __restrict__ n_groups,
+                                                                const unsigned long long* __restrict__ grp_ids,
+                                                                const int* __restrict__ own_g, const int* __restrict__ mem_g,
+                                                                SizeClasses sc, int* __restrict__ ctx_scn,
+                                                                int* __restrict__ ctx_grp, int* __restrict__ ctx_row0,
+                                                                int* __restrict__ ctx_of_group,   // [S, N] scratch
+                                                                int* __restrict__ own_ctx, int* __restrict__ own_slot,
+                                                                int* __restrict__ mem_ctx, int* __restrict__ mem_slot) {
+  __shared__ int start[9], row0[9], fill[8];
+  const int ns = s1 - s0;
+  if (threadIdx.x == 0) {
+    int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < ns; ++i)
+      for (int g = 0; g < n_groups[s0 + i]; ++g) ++cnt[size_class(__popcll(grp_ids[(size_t)(s0 + i) * N + g]), sc.sizes, sc.nb)];
+    int acc = 0, racc = 0;
+    for (int k = 0; k < sc.nb; ++k) {
+      start[k] = acc; row0[k] = racc; fill[k] = 0;
+      acc += cnt[k];
+      racc += cnt[k] * (sc.sizes[k] < A ? sc.sizes[k] - 1 : A);
+    }
+    for (int i = 0; i < ns; ++i)
+      for (int g = 0; g < n_groups[s0 + i]; ++g) {
+        const int k = size_class(__popcll(grp_ids[(size_t)(s0 + i) * N + g]), sc.sizes, sc.nb);
+        const int c = start[k] + fill[k];
+        ctx_scn[c] = s0 + i; ctx_grp[c] = g;
+        ctx_row0[c] = row0[k] + fill[k] * (sc.sizes[k] < A ? sc.sizes[k] - 1 : A);
+        ctx_of_group[(size_t)(s0 + i) * N + g] = c;
+        ++fill[k];
+      }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < ns * N; k += blockDim.x) {
+    const int i = k / N, v = k - i * N;
+    const size_t sv = (size_t)(s0 + i) * N + v;
+    const int og = own_g[sv], mg = mem_g[sv];
+    const unsigned long long below = (v == 0) ? 0ull : (~0ull >> (64 - v));
+    own_ctx[sv] = og < 0 ? -1 : ctx_of_group[(size_t)(s0 + i) * N + og];
+    own_slot[sv] = og < 0 ? -1 : __popcll(grp_ids[(size_t)(s0 + i) * N + og] & below);
+    mem_ctx[sv] = mg < 0 ? -1 : ctx_of_group[(size_t)(s0 + i) * N + mg];
+    mem_slot[sv] = mg < 0 ? -1 : __popcll(grp_ids[(size_t)(s0 + i) * N + mg] & below);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ context tensors
 struct CtxOut {
   float* st12;            // [B, Tq, A, 12]  x,y,vx,vy,yaw,len,wid + 5 type one-hot (-1 padded slots)
@@ -394,5 +459,29 @@ int launch_groups_changed(int S, int N, const int* n_groups, const int* grp_foca
   if (!n_groups || !grp_focal || !grp_ids || !ref_n || !ref_focal || !ref_ids || !flag || N < 1 || N > 64) return CTRLSIM_EINVAL;
   hipLaunchKernelGGL(groups_changed_kernel, dim3((S * N + 255) / 256), dim3(256), 0, st, S, N, n_groups, grp_focal, grp_ids,
                      ref_n, ref_focal, ref_ids, flag);
+  return ctrlsim_launch_status();
+}
+
+int launch_group_size_hist(int S, int N, const int* n_groups, const unsigned long long* grp_ids, int nb, const int* sizes,
+                           int* hist, hipStream_t st) {
+  if (S <= 0) return CTRLSIM_OK;
+  if (!n_groups || !grp_ids || !sizes || !hist || nb < 1 || nb > 8) return CTRLSIM_EINVAL;
+  SizeClasses sc;
+  sc.nb = nb;
+  for (int k = 0; k < 8; ++k) sc.sizes[k] = k < nb ? sizes[k] : 0;
+  hipLaunchKernelGGL(group_size_hist_kernel, dim3((S + 255) / 256), dim3(256), 0, st, S, N, n_groups, grp_ids, sc, hist);
+  return ctrlsim_launch_status();
+}
+int launch_ctx_index_classes(int s0, int s1, int N, int A, const int* n_groups, const unsigned long long* grp_ids,
+                             const int* own_g, const int* mem_g, int nb, const int* sizes, int* ctx_scn, int* ctx_grp,
+                             int* ctx_row0, int* ctx_of_group, int* own_ctx, int* own_slot, int* mem_ctx, int* mem_slot,
+                             hipStream_t st) {
+  if (s1 <= s0) return CTRLSIM_OK;
+  if (nb < 1 || nb > 8 || !sizes || sizes[nb - 1] != A) return CTRLSIM_EINVAL;
+  SizeClasses sc;
+  sc.nb = nb;
+  for (int k = 0; k < 8; ++k) sc.sizes[k] = k < nb ? sizes[k] : 0;
+  hipLaunchKernelGGL(ctx_index_classes_kernel, dim3(1), dim3(256), 0, st, s0, s1, N, A, n_groups, grp_ids, own_g, mem_g, sc,
+                     ctx_scn, ctx_grp, ctx_row0, ctx_of_group, own_ctx, own_slot, mem_ctx, mem_slot);
   return ctrlsim_launch_status();
 }

@@ -36,8 +36,12 @@ struct EmbedTables {
                            // rows: embed_rtg(cat_c Linear_c(r_c)) = r_0 g + r_1 v + r_2 r + rtg_bias (pack.py fold)
 };
 
+// Compact contexts (forward.hip): the context tensors hold A slots per step, of which the first Areg are "regular" and — when
+// Areg < A — the last one is the representative of the padded slots; a context's L token rows are the regular ones,
+// (tt*Areg + a)*3 + k, followed from row Lreg on by the representative's, Lreg + 3*tt + k.  Areg == A: the plain layout.
 __global__ __launch_bounds__(256) void assemble_tokens_kernel(
-    int rows, int Tq, int A, const float* __restrict__ S2,   // [B*Tq*A, 256] state content (without goal part)
+    int rows, int Tq, int A, int Areg, int L, int Lreg,
+    const float* __restrict__ S2,   // [B*Tq*A, 256] state content (without goal part)
     const float* __restrict__ Gp,                            // [B*A, 256] goal part + fused biases
     const float* __restrict__ exist, const int* __restrict__ act_tok, const int* __restrict__ rtg_bin,
     const int* __restrict__ tstep, EmbedTables tb, float* __restrict__ X,   // [B, Tq*A*3, 256]
@@ -53,7 +57,7 @@ __global__ __launch_bounds__(256) void assemble_tokens_kernel(
   const f32x4 be = *reinterpret_cast<const f32x4*>(tb.ln_b + c4);
   const f32x4 pos = *reinterpret_cast<const f32x4*>(tb.tstep + (size_t)ts * DM + c4) +
                     *reinterpret_cast<const f32x4*>(tb.agent + (size_t)a * DM + c4);
-  float* xo = X + ((size_t)b * Tq * A + (size_t)tt * A + a) * 3 * DM + c4;
+  float* xo = X + ((size_t)b * L + (a < Areg ? ((size_t)tt * Areg + a) * 3 : (size_t)Lreg + 3 * tt)) * DM + c4;
   // state
   f32x4 v = (*reinterpret_cast<const f32x4*>(S2 + (size_t)row * DM + c4) +
              *reinterpret_cast<const f32x4*>(Gp + ((size_t)b * A + a) * DM + c4) + pos) * ex;
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(256) void assemble_tokens_kernel(
 
 // Pass 2: only the RTG tokens of the current timestep change (the sampled bins replace the placeholder); rebuild those
 // A rows per context into a compact [B*A, 256] buffer.  hist_rtg [S,N,Tmax,3] holds the bins sampled this step.
-__global__ __launch_bounds__(256) void assemble_rtg_rows_kernel(int rows, int A, int Tq, int ti, int t, int N, int Tmax,   // Tq/ti: rows per context / row of the current step IN THE CONTEXT TENSORS
+__global__ __launch_bounds__(256) void assemble_rtg_rows_kernel(int rows, int Ar, int A, int Tq, int ti, int t, int N, int Tmax,   // Ar rows (regular slots) per context of A slots; Tq/ti: rows per context / row of the current step IN THE CONTEXT TENSORS
                                                                 const int* __restrict__ ctx_scn,
                                                                 const int* __restrict__ slot_gid,
                                                                 const int* __restrict__ hist_rtg,
@@ -93,8 +97,8 @@ __global__ __launch_bounds__(256) void assemble_rtg_rows_kernel(int rows, int A,
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);   // row = b*A + a
   if (row >= rows) return;
   const int lane = threadIdx.x & 63, c4 = lane * 4;
-  const int a = row % A, b = row / A;
-  const int gid = slot_gid[row];
+  const int a = row % Ar, b = row / Ar;
+  const int gid = slot_gid[(size_t)b * A + a];
   int b0 = zr0, b1 = zr1, b2 = zr2;
   if (gid >= 0) {
     const int* rb = hist_rtg + (((size_t)ctx_scn[b] * N + gid) * Tmax + t) * 3;
@@ -113,9 +117,10 @@ __global__ __launch_bounds__(256) void assemble_rtg_rows_kernel(int rows, int A,
   *reinterpret_cast<f32x4*>(Xr + (size_t)row * DM + c4) = ln256(v, g, be);
 }
 
-// Cached incremental forward: build only the token rows listed in pos_new[Rn] (the previous step's action tokens, whose
-// ids changed from the placeholder to the applied action, and the 3A tokens of the current timestep) into a compact
-// [B*Rn, 256] buffer.  Context tensors hold the window rows [tt_first, tt_first + Tn).
+// Cached incremental forward: build only the Rn token rows listed in pos_new (the previous step's action tokens, whose
+// ids changed from the placeholder to the applied action, and the 3A tokens of the current timestep; each entry names a
+// (window row, slot, token type) of the context tensors) into a compact [B*Rn, 256] buffer.  Context tensors hold the
+// window rows [tt_first, tt_first + Tn).
 __global__ __launch_bounds__(256) void assemble_rows_kernel(int rows, int Rn, int A, int tt_first, int Tn,
                                                             const int* __restrict__ pos_new,
                                                             const float* __restrict__ S2,    // [B*Tn*A, 256]
@@ -127,9 +132,8 @@ __global__ __launch_bounds__(256) void assemble_rows_kernel(int rows, int Rn, in
   if (row >= rows) return;
   const int lane = threadIdx.x & 63, c4 = lane * 4;
   const int b = row / Rn, j = row - b * Rn;
-  const int pos = pos_new[j];
-  const int tt = pos / (3 * A), rem = pos - tt * 3 * A, a = rem / 3, k = rem - a * 3;
-  const int to = tt - tt_first;
+  const int code = pos_new[j];                    // (to * A + a) * 3 + k in the context tensors' own (A slots per step) layout
+  const int to = code / (3 * A), rem = code - to * 3 * A, a = rem / 3, k = rem - a * 3;
   const size_t cr = ((size_t)b * Tn + to) * A + a;          // row in the context tensors
   const float ex = exist[cr];
   const int ts = tstep[(size_t)b * Tn + to];
@@ -162,13 +166,15 @@ int launch_assemble_rows(int B, int Rn, int A, int tt_first, int Tn, const int* 
   return ctrlsim_launch_status();
 }
 
-int launch_assemble_tokens(int B, int Tq, int A, const float* S2, const float* Gp, const float* exist,
+int launch_assemble_tokens(int B, int Tq, int A, int Areg, const float* S2, const float* Gp, const float* exist,
                            const int* act_tok, const int* rtg_bin, const int* tstep, EmbedTables tb, float* X,
                            float* src, int M, int P, unsigned char* src_pad, hipStream_t st) {
   const int rows = B * Tq * A;
   if (rows <= 0) return CTRLSIM_OK;
+  if (Areg < 1 || Areg > A || A - Areg > 1) return CTRLSIM_EINVAL;
+  const int Lreg = Tq * Areg * 3, L = Lreg + (A - Areg) * 3 * Tq;
   prof_before(PROF_EMBED, st);
-  hipLaunchKernelGGL(assemble_tokens_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, rows, Tq, A, S2, Gp, exist, act_tok,
+  hipLaunchKernelGGL(assemble_tokens_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, rows, Tq, A, Areg, L, Lreg, S2, Gp, exist, act_tok,
                      rtg_bin, tstep, tb, X, src, M, P, src_pad);
   // per (context, step, agent): the state row in (1 KB), three token rows out (3 KB), 24 B of ids / existence; embedding
   // tables stay cache-resident
@@ -176,12 +182,12 @@ int launch_assemble_tokens(int B, int Tq, int A, const float* S2, const float* G
   return ctrlsim_launch_status();
 }
 
-int launch_assemble_rtg_rows(int B, int A, int Tq, int ti, int t, int N, int Tmax, const int* ctx_scn,
+int launch_assemble_rtg_rows(int B, int Ar, int A, int Tq, int ti, int t, int N, int Tmax, const int* ctx_scn,
                              const int* slot_gid, const int* hist_rtg, const float* exist, const int* tstep,
                              EmbedTables tb, const int* zr, float* Xr, hipStream_t st) {
-  const int rows = B * A;
+  const int rows = B * Ar;
   if (rows <= 0) return CTRLSIM_OK;
-  hipLaunchKernelGGL(assemble_rtg_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, rows, A, Tq, ti, t, N, Tmax, ctx_scn,
+  hipLaunchKernelGGL(assemble_rtg_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, rows, Ar, A, Tq, ti, t, N, Tmax, ctx_scn,
                      slot_gid, hist_rtg, exist, tstep, tb, zr[0], zr[1], zr[2], Xr);
   return ctrlsim_launch_status();
 }

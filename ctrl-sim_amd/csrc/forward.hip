@@ -30,25 +30,25 @@ int launch_gemm_nt_bf16x6(const float*, int, const void*, int, int, const float*
 int launch_layernorm256(const float*, int, const float*, int, const float*, const float*, float*, int, int, int,
                         hipStream_t);
 int launch_gemm_nt_bf16x6_kv(const float*, int, const void*, int, int, const float*, const float*, int, float*, int, int, int,
-                             int, int, const float*, const float*, void*, int, int, int, hipStream_t);
-int launch_kv_zero_tail(int, int, int, void*, hipStream_t);
+                             int, int, const float*, const float*, void*, int, int, int, int, int, hipStream_t);
+int launch_kv_zero_tail(int, int, int, int, void*, hipStream_t);
 int launch_ffn_fused_bf16x6(const float*, int, const void*, const float*, const void*, const float*, const float*, const float*,
                             float*, int, int, int, hipStream_t);
 int launch_kv_split(const float*, const float*, int, long, int, int, int, void*, hipStream_t);
 int launch_kv_split_rows(const float*, const float*, int, long, const int*, int, int, int, void*, hipStream_t);
 int launch_attention_bf16x6_pre(int, const float*, int, long, const void*, int, float*, int, long, const int*,
-                                const unsigned char*, int, int, int, int, hipStream_t);
+                                const unsigned char*, int, int, int, int, int, int, int, hipStream_t);
 int launch_in_mlp(const float*, int, int, const float*, const float*, const float*, const float*, float*, int, int,
                   hipStream_t);
 int launch_row_copy(const float*, int, float*, int, const int*, int, int, int, hipStream_t);
 int launch_attention(int, const float*, int, long, const float*, const float*, int, long, float*, int, long, const int*,
                      const unsigned char*, int, int, int, int, hipStream_t);
 struct EmbedTables { const float *act, *rtg_g, *rtg_v, *rtg_r, *rtg_bias, *tstep, *agent, *ln_g, *ln_b; int rtg_linear; };
-int launch_assemble_tokens(int, int, int, const float*, const float*, const float*, const int*, const int*, const int*,
+int launch_assemble_tokens(int, int, int, int, const float*, const float*, const float*, const int*, const int*, const int*,
                            EmbedTables, float*, float*, int, int, unsigned char*, hipStream_t);
 int launch_assemble_rows(int, int, int, int, int, const int*, const float*, const float*, const float*, const int*, const int*,
                          const int*, EmbedTables, float*, hipStream_t);
-int launch_assemble_rtg_rows(int, int, int, int, int, int, int, const int*, const int*, const int*, const float*,
+int launch_assemble_rtg_rows(int, int, int, int, int, int, int, int, const int*, const int*, const int*, const float*,
                              const int*, EmbedTables, const int*, float*, hipStream_t);
 struct MapPoolWeights { const float *Wc, *G, *ln_b, *U, *cb, *Mt, *mb; };
 int launch_map_pool(int, int, int, int, const float*, MapPoolWeights, float*, unsigned char*, hipStream_t);
@@ -174,16 +174,37 @@ extern "C" void ctrlsim_model_destroy(ctrlsim_model* m) { delete m; }
 
 // ------------------------------------------------------------------------------------------------ workspace
 namespace {
+// Shape of a uniform batch of contexts.  Token rows of agent slots that do not exist anywhere in the window are all equal
+// (every embedding is multiplied by the existence flag before embed_ln, modules/encoder.py:127-133) and stay equal through the
+// decoder (no key padding on the targets; the structured mask treats all of them alike), so a context with n < A vehicles
+// can be evaluated with Actx >= n + 1 slots: Areg = Actx - 1 regular slots, and ONE representative slot standing for the
+// mult = A - Areg padded slots of the reference's 24-slot layout (attention_bf16x6.hip: multiplicity of its keys).  A context's
+// L token rows: regular (tt, a < Areg, k) at (tt*Areg + a)*3 + k, representative (tt, k) at Lreg + 3*tt + k; its keys sit in
+// the tiles from key rep_k0 = 64*ceil(Lreg/64) on.  Actx == A: the plain layout (rep = 0).  Exact in real arithmetic; the engine
+// sorts the contexts of a step into a few such shapes (engine.py).
+struct Shape {
+  int A, Areg, rep, mult;
+  int rows(int Tq) const { return Tq * 3 * (Areg + rep); }
+  int lreg(int Tq) const { return Tq * 3 * Areg; }
+  int rep_k0(int Tq) const { return (lreg(Tq) + 63) / 64 * 64; }
+  int nkt(int Tq) const { return (lreg(Tq) + 63) / 64 + rep * ((3 * Tq + 63) / 64); }
+};
+Shape shape_of(const ctrlsim_dims& d, int Actx) {
+  Shape s;
+  s.A = Actx; s.rep = Actx < d.A ? 1 : 0; s.Areg = Actx - s.rep; s.mult = d.A - s.Areg;
+  return s;
+}
+
 struct Ws {
   float *hS, *S2, *hG, *Gp, *X, *src, *attn_pre, *m1, *m2, *cat, *tfh, *eqkv, *eatt, *etmp, *effn;
   float *memkv[8], *qkv[8];
   float *att, *tmp, *qc, *ffn;
   float *xc, *xc2, *tmpc, *attc, *qkvc, *qcc, *ffnc, *headh;
   unsigned char* src_pad;
-  int *pos_state, *pos_rtg, *idx_state, *idx_rtg, *idx_poly;
+  int *pos_state, *pos_rtg, *idx_state, *idx_rtg, *idx_poly, *key_all;
   // cached incremental path: up to 4A new rows per context
   float *xn, *tmpn, *attn_n, *qkvn, *qcn, *ffnn;
-  int *pos_new, *idx_new, *idx_state_in_new;
+  int *pos_new, *key_new, *src_new, *idx_new, *idx_state_in_new;
   // split-bf16 K/V images (attention_bf16x6.hip: kv_split_kernel): decoder self-attention per layer, memory K/V per
   // layer, scene encoder (reused by its layers); nkt = 64-key tiles per context
   void *img_dec[8], *img_mem[8], *img_enc;
@@ -192,7 +213,7 @@ struct Ws {
   size_t bytes;
 };
 
-Ws carve(const ctrlsim_dims& d, int B, int Tq, char* base) {
+Ws carve(const ctrlsim_dims& d, const Shape& sh, int B, int Tq, char* base) {
   Ws w;
   size_t off = 0;
   auto take = [&](size_t nbytes) -> char* {
@@ -200,8 +221,8 @@ Ws carve(const ctrlsim_dims& d, int B, int Tq, char* base) {
     off += (nbytes + 255) & ~size_t(255);
     return p;
   };
-  const size_t L = (size_t)Tq * d.A * 3, M = (size_t)d.P + d.A;
-  const size_t rL = B * L, rM = B * M, rA = (size_t)B * d.A, rS = (size_t)B * Tq * d.A, rP = (size_t)B * d.P;
+  const size_t L = (size_t)sh.rows(Tq), M = (size_t)d.P + sh.A;
+  const size_t rL = B * L, rM = B * M, rA = (size_t)B * sh.A, rS = (size_t)B * Tq * sh.A, rP = (size_t)B * d.P;
   auto F = [&](size_t rows, size_t cols) { return reinterpret_cast<float*>(take(rows * cols * sizeof(float))); };
   w.hS = F(rS, DM); w.S2 = F(rS, DM); w.hG = F(rA, DM); w.Gp = F(rA, DM);
   w.X = F(rL, DM); w.src = F(rM, DM);
@@ -213,17 +234,20 @@ Ws carve(const ctrlsim_dims& d, int B, int Tq, char* base) {
   w.xc = F(rA, DM); w.xc2 = F(rA, DM); w.tmpc = F(rA, DM); w.attc = F(rA, DM); w.qkvc = F(rA, 3 * DM);
   w.qcc = F(rA, DM); w.ffnc = F(rA, d.F); w.headh = F(rA, DM);
   w.src_pad = reinterpret_cast<unsigned char*>(take(rM));
-  w.pos_state = reinterpret_cast<int*>(take(d.A * sizeof(int)));
-  w.pos_rtg = reinterpret_cast<int*>(take(d.A * sizeof(int)));
+  w.pos_state = reinterpret_cast<int*>(take(sh.A * sizeof(int)));
+  w.pos_rtg = reinterpret_cast<int*>(take(sh.A * sizeof(int)));
   w.idx_state = reinterpret_cast<int*>(take(rA * sizeof(int)));
   w.idx_rtg = reinterpret_cast<int*>(take(rA * sizeof(int)));
   w.idx_poly = reinterpret_cast<int*>(take(rP * sizeof(int)));
+  w.key_all = reinterpret_cast<int*>(take(L * sizeof(int)));
   const size_t rN = rA * 4;
   w.xn = F(rN, DM); w.tmpn = F(rN, DM); w.attn_n = F(rN, DM); w.qkvn = F(rN, 3 * DM); w.qcn = F(rN, DM); w.ffnn = F(rN, d.F);
-  w.pos_new = reinterpret_cast<int*>(take(4 * d.A * sizeof(int)));
+  w.pos_new = reinterpret_cast<int*>(take(4 * sh.A * sizeof(int)));
+  w.key_new = reinterpret_cast<int*>(take(4 * sh.A * sizeof(int)));
+  w.src_new = reinterpret_cast<int*>(take(4 * sh.A * sizeof(int)));
   w.idx_new = reinterpret_cast<int*>(take(rN * sizeof(int)));
   w.idx_state_in_new = reinterpret_cast<int*>(take(rA * sizeof(int)));
-  w.nkt_dec = (int)((L + 63) / 64);
+  w.nkt_dec = sh.nkt(Tq);
   w.nkt_mem = (int)((M + 63) / 64);
   const size_t tile_bytes = (size_t)2 * NPL * 64 * HD * 2;   // 8 KB per plane pair of a (context, head, tile) image
   w.img_dec_bytes = (size_t)B * NHEAD * w.nkt_dec * tile_bytes;
@@ -234,17 +258,20 @@ Ws carve(const ctrlsim_dims& d, int B, int Tq, char* base) {
   return w;
 }
 
-// qoff: token type whose rows feed the first pass's head (0 = state tokens; 2 = action tokens, Trajeglish)
-__global__ void fill_index_kernel(int B, int A, int L, int ti, int P, int M, int qoff, int* pos_state, int* pos_rtg,
-                                  int* idx_state, int* idx_rtg, int* idx_poly) {
+// qoff: token type whose rows feed the first pass's head (0 = state tokens; 2 = action tokens, Trajeglish).  Index lists of the
+// Areg current-step query rows per context (positions in the context's row order; regular rows: position == key), the
+// polyline rows of the scene-encoder source, and key_all: row -> key position in the K/V images (Tq window steps).
+__global__ void fill_index_kernel(int B, int Areg, int L, int Lreg, int rep_k0, int ti, int P, int M, int qoff, int* pos_state,
+                                  int* pos_rtg, int* idx_state, int* idx_rtg, int* idx_poly, int* key_all) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B * P) idx_poly[i] = (i / P) * M + (i % P);
-  if (i < A) { pos_state[i] = (ti * A + i) * 3 + qoff; pos_rtg[i] = (ti * A + i) * 3 + 1; }
-  if (i < B * A) {
-    const int b = i / A, a = i - b * A;
-    idx_state[i] = b * L + (ti * A + a) * 3 + qoff;
-    idx_rtg[i] = b * L + (ti * A + a) * 3 + 1;
+  if (i < Areg) { pos_state[i] = (ti * Areg + i) * 3 + qoff; pos_rtg[i] = (ti * Areg + i) * 3 + 1; }
+  if (i < B * Areg) {
+    const int b = i / Areg, a = i - b * Areg;
+    idx_state[i] = b * L + (ti * Areg + a) * 3 + qoff;
+    idx_rtg[i] = b * L + (ti * Areg + a) * 3 + 1;
   }
+  if (i < L) key_all[i] = i < Lreg ? i : rep_k0 + (i - Lreg);
 }
 
 // y = act(x W^T + b [+ R]) through the bf16x6 MFMA kernel when the packed planes exist, else the f32-input MFMA kernel
@@ -275,51 +302,82 @@ int ffn_block(const Lin& l1, const Lin& l2, const LNp& n, const void* w1p, const
   return gemm_ln(l2, n, hidden, F, x, DM, x, DM, tmp, rows, F, 0, st);
 }
 
-// Attention over K/V given both as fp32 rows and (when the split-bf16 path is selected) as pre-split images
+// Attention over K/V given both as fp32 rows and (when the split-bf16 path is selected) as pre-split images.
+// Rep: the representative-token region of a compact context (split-operand path only; rep_keys == 0: none).
+struct Rep { int keys = 0, mult = 1, pos0 = 0; };
 inline bool presplit() { return ctrlsim_option(OPT_ATTN_IMPL) == 1; }
 int attention_kv(int mode, const float* Q, int ldq, long qbs, const float* K, const float* V, int ldkv, long kbs,
                  const void* img, int nkt, float* O, int ldo, long obs, const int* q_pos, const unsigned char* key_pad, int B,
-                 int Lq, int Lk, int A, hipStream_t st) {
+                 int Lq, int Lk, int A, hipStream_t st, Rep rep = Rep()) {
   if (presplit())
-    return launch_attention_bf16x6_pre(mode, Q, ldq, qbs, img, nkt, O, ldo, obs, q_pos, key_pad, B, Lq, Lk, A, st);
+    return launch_attention_bf16x6_pre(mode, Q, ldq, qbs, img, nkt, O, ldo, obs, q_pos, key_pad, B, Lq, Lk, A, rep.keys, rep.mult,
+                                       rep.pos0, st);
+  if (rep.keys) return CTRLSIM_EINVAL;
   return launch_attention(mode, Q, ldq, qbs, K, V, ldkv, kbs, O, ldo, obs, q_pos, key_pad, B, Lq, Lk, A, st);
 }
 int kv_split(const float* K, const float* V, int ldkv, long kbs, int B, int Lk, int nkt, void* img, hipStream_t st) {
   return presplit() ? launch_kv_split(K, V, ldkv, kbs, B, Lk, nkt, img, st) : 0;
 }
-// Linear whose last 512 output columns are attention keys / values of B contexts x Lk rows: y[:, :kcol0] as fp32 rows,
-// K / V as split images straight from the GEMM epilogue when both bf16x6 kernels are selected (the fp32 K / V columns
-// of y are then NOT written); otherwise GEMM + kv_split.
-int gemm_kv(const Lin& L, const float* x, int ldx, float* y, int ldy, int B, int Lk, int n, int k, int kcol0, void* img, int nkt,
-            hipStream_t st) {
-  const int rows = B * Lk;
-  if (presplit() && L.w3 && k % 16 == 0 && ctrlsim_option(OPT_GEMM_IMPL) == 1 && !(Lk & 3) && Lk >= 32) {
-    CHK(launch_kv_zero_tail(B, Lk, nkt, img, st));
-    return launch_gemm_nt_bf16x6_kv(x, ldx, L.w3, L.ntot ? L.ntot : n, L.n0, L.b, nullptr, 0, y, ldy, rows, n, k, 0, nullptr,
-                                    nullptr, img, Lk, nkt, kcol0, st);
-  }
-  CHK(gemm(L, x, ldx, nullptr, 0, y, ldy, rows, n, k, 0, st));
-  return kv_split(y + kcol0, y + kcol0 + DM, ldy, (long)Lk * ldy, B, Lk, nkt, img, st);
-}
 int kv_split_rows(const float* K, const float* V, int ldkv, long kbs, const int* pos, int B, int R, int nkt, void* img,
                   hipStream_t st) {
   return presplit() ? launch_kv_split_rows(K, V, ldkv, kbs, pos, B, R, nkt, img, st) : 0;
 }
+// Linear whose last 512 output columns are attention keys / values of B contexts x Lk rows: y[:, :kcol0] as fp32 rows,
+// K / V as split images straight from the GEMM epilogue when both bf16x6 kernels are selected (the fp32 K / V columns
+// of y are then NOT written); otherwise GEMM + kv_split.  Rows >= Lreg of a context go to the keys from rep_k0 on
+// (compact contexts; Lreg == Lk: plain layout); key_all = the row -> key list of the fallback.
+int gemm_kv(const Lin& L, const float* x, int ldx, float* y, int ldy, int B, int Lk, int n, int k, int kcol0, void* img, int nkt,
+            hipStream_t st, int Lreg = 0, int rep_k0 = 0, const int* key_all = nullptr, size_t img_bytes = 0) {
+  const int rows = B * Lk;
+  if (Lreg <= 0 || Lreg >= Lk) { Lreg = Lk; rep_k0 = 0; }
+  if (presplit() && L.w3 && k % 16 == 0 && ctrlsim_option(OPT_GEMM_IMPL) == 1 && !(Lk & 3) && !(Lreg & 3) && Lk >= 32) {
+    CHK(launch_kv_zero_tail(B, 0, Lreg, nkt, img, st));
+    if (Lreg < Lk) CHK(launch_kv_zero_tail(B, rep_k0, Lk - Lreg, nkt, img, st));
+    return launch_gemm_nt_bf16x6_kv(x, ldx, L.w3, L.ntot ? L.ntot : n, L.n0, L.b, nullptr, 0, y, ldy, rows, n, k, 0, nullptr,
+                                    nullptr, img, Lk, nkt, kcol0, Lreg, rep_k0, st);
+  }
+  CHK(gemm(L, x, ldx, nullptr, 0, y, ldy, rows, n, k, 0, st));
+  if (Lreg == Lk) return kv_split(y + kcol0, y + kcol0 + DM, ldy, (long)Lk * ldy, B, Lk, nkt, img, st);
+  if (!presplit()) return CTRLSIM_EINVAL;
+  if (hipMemsetAsync(img, 0, img_bytes, st) != hipSuccess) return CTRLSIM_ELAUNCH;
+  return kv_split_rows(y + kcol0, y + kcol0 + DM, ldy, (long)Lk * ldy, key_all, B, Lk, nkt, img, st);
+}
 
-// index lists of the cached path: new rows of step t are the A action tokens of t-1 (t > 0) and the 3A tokens of t;
-// cache rows live at b * Lf + position with Lf = T * 3A
-__global__ void fill_index_cached_kernel(int B, int A, int Lf, int t, int Rn, int* pos_new, int* idx_new,
-                                         int* idx_state_in_new, int* pos_rtg, int* idx_rtg) {
+// index lists of the cached path: the new rows of step t are the action tokens of step t-1 (t > 0) and the three tokens of step
+// t, of the Areg regular slots and then of the representative; cache rows live at b * Lf + position with Lf = rows of the
+// full window.  pos_new = position in the row order (= the query position the mask uses), key_new = key in the K/V images,
+// src_new = ((tt - tt_first) * Actx + slot) * 3 + k in the context tensors.
+__global__ void fill_index_cached_kernel(int B, int Actx, int Areg, int Lf, int Lreg_f, int rep_k0, int t, int Rn, int* pos_new,
+                                         int* key_new, int* src_new, int* idx_new, int* idx_state_in_new, int* pos_rtg,
+                                         int* idx_rtg) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int A3 = 3 * A, off = t > 0 ? A : 0;
-  auto pos_of = [&](int j) { return (t > 0 && j < A) ? (t - 1) * A3 + 3 * j + 2 : t * A3 + (j - off); };
-  if (i < Rn) pos_new[i] = pos_of(i);
-  if (i < A) pos_rtg[i] = t * A3 + 3 * i + 1;
-  if (i < B * Rn) idx_new[i] = (i / Rn) * Lf + pos_of(i % Rn);
-  if (i < B * A) {
-    const int b = i / A, a = i - b * A;
+  const int off = t > 0 ? Actx : 0;
+  // entry j -> (window step tt, slot a, token k)
+  auto decode = [&](int j, int& tt, int& a, int& k) {
+    if (t > 0 && j < Actx) { tt = t - 1; a = j; k = 2; return; }
+    const int r = j - off;
+    tt = t;
+    if (r < 3 * Areg) { a = r / 3; k = r - 3 * a; } else { a = Areg; k = r - 3 * Areg; }
+  };
+  auto pos_of = [&](int tt, int a, int k) { return a < Areg ? (tt * Areg + a) * 3 + k : Lreg_f + 3 * tt + k; };
+  if (i < Rn) {
+    int tt, a, k;
+    decode(i, tt, a, k);
+    const int p = pos_of(tt, a, k);
+    pos_new[i] = p;
+    key_new[i] = a < Areg ? p : rep_k0 + 3 * tt + k;
+    src_new[i] = ((tt - (t > 0 ? t - 1 : 0)) * Actx + a) * 3 + k;
+  }
+  if (i < Areg) pos_rtg[i] = (t * Areg + i) * 3 + 1;
+  if (i < B * Rn) {
+    int tt, a, k;
+    decode(i % Rn, tt, a, k);
+    idx_new[i] = (i / Rn) * Lf + pos_of(tt, a, k);
+  }
+  if (i < B * Areg) {
+    const int b = i / Areg, a = i - b * Areg;
     idx_state_in_new[i] = b * Rn + off + 3 * a;
-    idx_rtg[i] = b * Lf + t * A3 + 3 * a + 1;
+    idx_rtg[i] = b * Lf + (t * Areg + a) * 3 + 1;
   }
 }
 
@@ -331,21 +389,22 @@ int mlp_tail(const Mlp& m, const float* h_in, int rows, float* hid, float* out, 
 }
 
 // cross-attention + FFN sub-blocks shared by the full-row and compact-row paths (post-LN, residual fused in GEMM)
-int cross_and_ffn(const ctrlsim_model* m, const DecLayer& Ld, int layer, const Ws& w, float* x, float* tmp, float* att,
-                  float* qc, float* ffn, int rows, int B, int rows_per_b, hipStream_t st) {
+int cross_and_ffn(const ctrlsim_model* m, const Shape& sh, const DecLayer& Ld, int layer, const Ws& w, float* x, float* tmp,
+                  float* att, float* qc, float* ffn, int rows, int B, int rows_per_b, hipStream_t st) {
   const ctrlsim_dims& d = m->d;
-  const int M = d.P + d.A;
+  const int M = d.P + sh.A;
   CHK(gemm(Ld.cq, x, DM, nullptr, 0, qc, DM, rows, DM, DM, 0, st));
   CHK(attention_kv(0, qc, DM, (long)rows_per_b * DM, w.memkv[layer], w.memkv[layer] + DM, 2 * DM, (long)M * 2 * DM,
-                   w.img_mem[layer], w.nkt_mem, att, DM, (long)rows_per_b * DM, nullptr, w.src_pad, B, rows_per_b, M, d.A, st));
+                   w.img_mem[layer], w.nkt_mem, att, DM, (long)rows_per_b * DM, nullptr, w.src_pad, B, rows_per_b, M, sh.A, st));
   CHK(gemm_ln(Ld.cout, Ld.n2, att, DM, x, DM, x, DM, tmp, rows, DM, 0, st));
   CHK(ffn_block(Ld.lin1, Ld.lin2, Ld.n3, Ld.w1p, Ld.w2p, x, ffn, tmp, rows, d.F, st));
   return 0;
 }
 // map encoder + scene encoder + per-layer memory K/V (everything that only depends on the frame of the context)
-int scene_side(const ctrlsim_model* m, const Ws& w, const ctrlsim_ctx* c, int B, float* dbg_seg_emb, hipStream_t st) {
+int scene_side(const ctrlsim_model* m, const Shape& sh, const Ws& w, const ctrlsim_ctx* c, int B, float* dbg_seg_emb,
+               hipStream_t st) {
   const ctrlsim_dims& d = m->d;
-  const int A = d.A, P = d.P, M = P + A, rM = B * M, rP = B * P;
+  const int A = sh.A, P = d.P, M = P + A, rM = B * M, rP = B * P;
   // ---- map encoder (map_encoder.py:34-53): rows of `src` 0..P-1 per context
   CHK(launch_map_pool(B, P, d.NP, M, c->road_pts, m->mp, w.attn_pre, w.src_pad, st));
   CHK(gemm_ln(m->map_out, m->map_n1, w.attn_pre, DM, nullptr, 0, w.m1, DM, w.m1, rP, DM, 0, st));            // emb
@@ -378,28 +437,38 @@ int scene_side(const ctrlsim_model* m, const Ws& w, const ctrlsim_ctx* c, int B,
   return 0;
 }
 
+bool actx_ok(const ctrlsim_dims& d, int Actx) { return Actx >= 2 && Actx <= d.A && (Actx == d.A || (d.variant == 0 && presplit())); }
+
 }  // namespace
 
+extern "C" int64_t ctrlsim_forward_workspace_bytes_a(const ctrlsim_dims* d, int B, int Tq, int Actx) {
+  if (!d || B < 1 || Tq < 1 || Tq > d->T || Actx < 2 || Actx > d->A) return CTRLSIM_EINVAL;
+  return (int64_t)carve(*d, shape_of(*d, Actx), B, Tq, nullptr).bytes;
+}
 extern "C" int64_t ctrlsim_forward_workspace_bytes(const ctrlsim_dims* d, int B, int Tq) {
-  if (!d || B < 1 || Tq < 1 || Tq > d->T) return CTRLSIM_EINVAL;
-  return (int64_t)carve(*d, B, Tq, nullptr).bytes;
+  return d ? ctrlsim_forward_workspace_bytes_a(d, B, Tq, d->A) : CTRLSIM_EINVAL;
 }
 
 // ------------------------------------------------------------------------------------------------ pass 1
 namespace {
-// The full forward over the first Tq window steps; logits of the head that the first pass of the variant needs:
-// CtRL-Sim: predict_rtg on the A state tokens of the current step; IL: predict_action on the same rows; Trajeglish:
-// predict_action on the A action tokens (decoder.py:55-77).
-int forward_full(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* c, void* workspace, float* logits,
+// The full forward over the first Tq window steps; logits of the head that the first pass of the variant needs, for the Areg
+// regular slots of every context ([B*Areg, .] rows):
+// CtRL-Sim: predict_rtg on the state tokens of the current step; IL: predict_action on the same rows; Trajeglish:
+// predict_action on the action tokens (decoder.py:55-77).
+int forward_full(const ctrlsim_model* m, int B, int Tq, int Actx, const ctrlsim_ctx* c, void* workspace, float* logits,
                  float* dbg_seg_emb, hipStream_t st) {
   const ctrlsim_dims& d = m->d;
   const int variant = d.variant, amode = 1 + variant, qoff = variant == 2 ? 2 : 0;
   if (variant && !presplit()) return CTRLSIM_EINVAL;       // the IL / Trajeglish masks live in the split-bf16 attention only
-  const Ws w = carve(d, B, Tq, static_cast<char*>(workspace));
-  const int A = d.A, P = d.P, M = P + A, L = Tq * A * 3, ti = Tq - 1;
-  const int rL = B * L, rM = B * M, rA = B * A, rS = B * Tq * A, rP = B * P;
-  hipLaunchKernelGGL(fill_index_kernel, dim3(((rA > rP ? rA : rP) + 255) / 256), dim3(256), 0, st, B, A, L, ti, P, M, qoff,
-                     w.pos_state, w.pos_rtg, w.idx_state, w.idx_rtg, w.idx_poly);
+  if (!actx_ok(d, Actx)) return CTRLSIM_EINVAL;
+  const Shape sh = shape_of(d, Actx);
+  const Ws w = carve(d, sh, B, Tq, static_cast<char*>(workspace));
+  const int A = sh.A, Ar = sh.Areg, P = d.P, M = P + A, L = sh.rows(Tq), Lreg = sh.lreg(Tq), ti = Tq - 1;
+  const int rL = B * L, rA = B * A, rQ = B * Ar, rS = B * Tq * A, rP = B * P;
+  const Rep rep{sh.rep * 3 * Tq, sh.mult, Lreg};
+  const int nidx = max(max(rA, rP), L);
+  hipLaunchKernelGGL(fill_index_kernel, dim3((nidx + 255) / 256), dim3(256), 0, st, B, Ar, L, Lreg, sh.rep_k0(Tq), ti, P, M, qoff,
+                     w.pos_state, w.pos_rtg, w.idx_state, w.idx_rtg, w.idx_poly, w.key_all);
   // ---- token embeddings (encoder.py:95-153)
   CHK(launch_in_mlp(c->st12, 12, 12, m->embed_state.l0.w, m->embed_state.l0.b, m->embed_state.ln.g, m->embed_state.ln.b,
                     w.hS, DM, rS, st));
@@ -407,89 +476,110 @@ int forward_full(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* c, vo
   CHK(launch_in_mlp(c->goal5, 5, 5, m->embed_goal.l0.w, m->embed_goal.l0.b, m->embed_goal.ln.g, m->embed_goal.ln.b, w.hG,
                     DM, rA, st));
   CHK(gemm(m->fold_goal, w.hG, DM, nullptr, 0, w.Gp, DM, rA, DM, DM, 0, st));
-  CHK(launch_assemble_tokens(B, Tq, A, w.S2, w.Gp, c->exist, c->act_tok, c->rtg_bin, c->tstep, m->tb, w.X, w.src, M, P,
+  CHK(launch_assemble_tokens(B, Tq, A, Ar, w.S2, w.Gp, c->exist, c->act_tok, c->rtg_bin, c->tstep, m->tb, w.X, w.src, M, P,
                              w.src_pad, st));
-  CHK(scene_side(m, w, c, B, dbg_seg_emb, st));
+  CHK(scene_side(m, sh, w, c, B, dbg_seg_emb, st));
   // ---- decoder (decoder.py:52): layers 0..ND-2 on all L tokens
   for (int i = 0; i < d.ND; ++i) {
     const DecLayer& Ld = m->dec[i];
-    CHK(gemm_kv(Ld.qkv, w.X, DM, w.qkv[i], 3 * DM, B, L, 3 * DM, DM, DM, w.img_dec[i], w.nkt_dec, st));
+    CHK(gemm_kv(Ld.qkv, w.X, DM, w.qkv[i], 3 * DM, B, L, 3 * DM, DM, DM, w.img_dec[i], w.nkt_dec, st, Lreg, sh.rep_k0(Tq),
+                w.key_all, w.img_dec_bytes));
     if (i < d.ND - 1) {
       CHK(attention_kv(amode, w.qkv[i], 3 * DM, (long)L * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
-                       w.img_dec[i], w.nkt_dec, w.att, DM, (long)L * DM, nullptr, nullptr, B, L, L, A, st));
+                       w.img_dec[i], w.nkt_dec, w.att, DM, (long)L * DM, nullptr, nullptr, B, L, Lreg, Ar, st, rep));
       CHK(gemm_ln(Ld.out, Ld.n1, w.att, DM, w.X, DM, w.X, DM, w.tmp, rL, DM, 0, st));
-      CHK(cross_and_ffn(m, Ld, i, w, w.X, w.tmp, w.att, w.qc, w.ffn, rL, B, L, st));
+      CHK(cross_and_ffn(m, sh, Ld, i, w, w.X, w.tmp, w.att, w.qc, w.ffn, rL, B, L, st));
     } else {
-      // last layer: only the A queried tokens of the current timestep (state tokens; Trajeglish: action tokens)
-      CHK(launch_row_copy(w.X, DM, w.xc, DM, w.idx_state, rA, DM, 0, st));
-      CHK(launch_row_copy(w.qkv[i], 3 * DM, w.qkvc, 3 * DM, w.idx_state, rA, 3 * DM, 0, st));
-      CHK(attention_kv(amode, w.qkvc, 3 * DM, (long)A * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
-                       w.img_dec[i], w.nkt_dec, w.attc, DM, (long)A * DM, w.pos_state, nullptr, B, A, L, A, st));
-      CHK(gemm_ln(Ld.out, Ld.n1, w.attc, DM, w.xc, DM, w.xc, DM, w.tmpc, rA, DM, 0, st));
-      CHK(cross_and_ffn(m, Ld, i, w, w.xc, w.tmpc, w.attc, w.qcc, w.ffnc, rA, B, A, st));
+      // last layer: only the queried tokens of the current timestep (state tokens; Trajeglish: action tokens) of the regular slots
+      CHK(launch_row_copy(w.X, DM, w.xc, DM, w.idx_state, rQ, DM, 0, st));
+      CHK(launch_row_copy(w.qkv[i], 3 * DM, w.qkvc, 3 * DM, w.idx_state, rQ, 3 * DM, 0, st));
+      CHK(attention_kv(amode, w.qkvc, 3 * DM, (long)Ar * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
+                       w.img_dec[i], w.nkt_dec, w.attc, DM, (long)Ar * DM, w.pos_state, nullptr, B, Ar, Lreg, Ar, st, rep));
+      CHK(gemm_ln(Ld.out, Ld.n1, w.attc, DM, w.xc, DM, w.xc, DM, w.tmpc, rQ, DM, 0, st));
+      CHK(cross_and_ffn(m, sh, Ld, i, w, w.xc, w.tmpc, w.attc, w.qcc, w.ffnc, rQ, B, Ar, st));
     }
   }
-  // ---- predict_rtg head on the A state tokens (decoder.py:74-77) / predict_action for the baselines (decoder.py:58-64)
-  if (variant) return mlp_tail(m->head_action, w.xc, rA, w.headh, logits, d.V, st);
-  return mlp_tail(m->head_rtg, w.xc, rA, w.headh, logits, d.R * d.C, st);
+  // ---- predict_rtg head on the state tokens (decoder.py:74-77) / predict_action for the baselines (decoder.py:58-64)
+  if (variant) return mlp_tail(m->head_action, w.xc, rQ, w.headh, logits, d.V, st);
+  return mlp_tail(m->head_rtg, w.xc, rQ, w.headh, logits, d.R * d.C, st);
 }
 }  // namespace
 
+extern "C" int ctrlsim_dt_forward_pass1_a(const ctrlsim_model* m, int B, int Tq, int Actx, const ctrlsim_ctx* c, void* workspace,
+                                          float* rtg_logits, float* dbg_seg_emb, hipStream_t st) {
+  if (!m || !c || !workspace || !rtg_logits || B < 1 || Tq < 1 || Tq > m->d.T || m->d.variant != 0) return CTRLSIM_EINVAL;
+  return forward_full(m, B, Tq, Actx, c, workspace, rtg_logits, dbg_seg_emb, st);
+}
 extern "C" int ctrlsim_dt_forward_pass1(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* c, void* workspace,
                                         float* rtg_logits, float* dbg_seg_emb, hipStream_t st) {
-  if (!m || !c || !workspace || !rtg_logits || B < 1 || Tq < 1 || Tq > m->d.T || m->d.variant != 0) return CTRLSIM_EINVAL;
-  return forward_full(m, B, Tq, c, workspace, rtg_logits, dbg_seg_emb, st);
+  return m ? ctrlsim_dt_forward_pass1_a(m, B, Tq, m->d.A, c, workspace, rtg_logits, dbg_seg_emb, st) : CTRLSIM_EINVAL;
 }
 extern "C" int ctrlsim_dt_forward_actions(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* c, void* workspace,
                                           float* act_logits, hipStream_t st) {
   if (!m || !c || !workspace || !act_logits || B < 1 || Tq < 1 || Tq > m->d.T || m->d.variant == 0) return CTRLSIM_EINVAL;
-  return forward_full(m, B, Tq, c, workspace, act_logits, nullptr, st);
+  return forward_full(m, B, Tq, m->d.A, c, workspace, act_logits, nullptr, st);
 }
 
 // ------------------------------------------------------------------------------------------------ pass 2
-extern "C" int ctrlsim_dt_forward_pass2(const ctrlsim_model* m, int B, int Tq, int t, int N, int Tmax,
-                                        const ctrlsim_ctx* c, const int* ctx_scn, const int* hist_rtg, void* workspace,
-                                        float* act_logits, int cached, hipStream_t st) {
+extern "C" int ctrlsim_dt_forward_pass2_a(const ctrlsim_model* m, int B, int Tq, int Actx, int t, int N, int Tmax,
+                                          const ctrlsim_ctx* c, const int* ctx_scn, const int* hist_rtg, void* workspace,
+                                          float* act_logits, int cached, hipStream_t st) {
   if (!m || !c || !workspace || !act_logits || B < 1 || Tq < 1 || Tq > m->d.T || m->d.variant != 0) return CTRLSIM_EINVAL;
   const ctrlsim_dims& d = m->d;
-  // cached mode: the workspace is carved for the full window (K/V cache rows at b * T*3A + position) and the context
+  if (!actx_ok(d, Actx)) return CTRLSIM_EINVAL;
+  const Shape sh = shape_of(d, Actx);
+  // cached mode: the workspace is carved for the full window (K/V cache rows at b * rows(T) + position) and the context
   // tensors hold only the last Tn = min(Tq, 2) window rows
-  const Ws w = carve(d, B, cached ? d.T : Tq, static_cast<char*>(workspace));
-  const int A = d.A, L = (cached ? d.T : Tq) * A * 3, rA = B * A;
+  const int Tw = cached ? d.T : Tq;
+  const Ws w = carve(d, sh, B, Tw, static_cast<char*>(workspace));
+  const int Ar = sh.Areg, L = sh.rows(Tw), rQ = B * Ar;
   const int ctx_rows = cached ? (Tq < 2 ? Tq : 2) : Tq, ti = ctx_rows - 1;
-  CHK(launch_assemble_rtg_rows(B, A, ctx_rows, ti, t, N, Tmax, ctx_scn, c->slot_gid, hist_rtg, c->exist, c->tstep, m->tb,
+  const Rep rep{sh.rep * 3 * Tq, sh.mult, sh.lreg(Tw)};
+  CHK(launch_assemble_rtg_rows(B, Ar, sh.A, ctx_rows, ti, t, N, Tmax, ctx_scn, c->slot_gid, hist_rtg, c->exist, c->tstep, m->tb,
                                m->zero_rtg, w.xc2, st));
   for (int i = 0; i < d.ND; ++i) {
     const DecLayer& Ld = m->dec[i];
-    CHK(gemm(Ld.qkv, w.xc2, DM, nullptr, 0, w.qkvc, 3 * DM, rA, 3 * DM, DM, 0, st));
-    CHK(launch_row_copy(w.qkvc, 3 * DM, w.qkv[i], 3 * DM, w.idx_rtg, rA, 3 * DM, 1, st));   // refresh the rtg rows' K/V
-    CHK(kv_split_rows(w.qkvc + DM, w.qkvc + 2 * DM, 3 * DM, (long)A * 3 * DM, w.pos_rtg, B, A, w.nkt_dec, w.img_dec[i], st));
-    CHK(attention_kv(1, w.qkvc, 3 * DM, (long)A * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
-                     w.img_dec[i], w.nkt_dec, w.attc, DM, (long)A * DM, w.pos_rtg, nullptr, B, A, Tq * A * 3, A, st));   // keys: steps <= current
-    CHK(gemm_ln(Ld.out, Ld.n1, w.attc, DM, w.xc2, DM, w.xc2, DM, w.tmpc, rA, DM, 0, st));
-    CHK(cross_and_ffn(m, Ld, i, w, w.xc2, w.tmpc, w.attc, w.qcc, w.ffnc, rA, B, A, st));
+    CHK(gemm(Ld.qkv, w.xc2, DM, nullptr, 0, w.qkvc, 3 * DM, rQ, 3 * DM, DM, 0, st));
+    CHK(launch_row_copy(w.qkvc, 3 * DM, w.qkv[i], 3 * DM, w.idx_rtg, rQ, 3 * DM, 1, st));   // refresh the rtg rows' K/V
+    CHK(kv_split_rows(w.qkvc + DM, w.qkvc + 2 * DM, 3 * DM, (long)Ar * 3 * DM, w.pos_rtg, B, Ar, w.nkt_dec, w.img_dec[i], st));
+    CHK(attention_kv(1, w.qkvc, 3 * DM, (long)Ar * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
+                     w.img_dec[i], w.nkt_dec, w.attc, DM, (long)Ar * DM, w.pos_rtg, nullptr, B, Ar, Tq * Ar * 3, Ar, st, rep));   // keys: steps <= current
+    CHK(gemm_ln(Ld.out, Ld.n1, w.attc, DM, w.xc2, DM, w.xc2, DM, w.tmpc, rQ, DM, 0, st));
+    CHK(cross_and_ffn(m, sh, Ld, i, w, w.xc2, w.tmpc, w.attc, w.qcc, w.ffnc, rQ, B, Ar, st));
   }
-  CHK(mlp_tail(m->head_action, w.xc2, rA, w.headh, act_logits, d.V, st));
+  CHK(mlp_tail(m->head_action, w.xc2, rQ, w.headh, act_logits, d.V, st));
   return CTRLSIM_OK;
+}
+extern "C" int ctrlsim_dt_forward_pass2(const ctrlsim_model* m, int B, int Tq, int t, int N, int Tmax,
+                                        const ctrlsim_ctx* c, const int* ctx_scn, const int* hist_rtg, void* workspace,
+                                        float* act_logits, int cached, hipStream_t st) {
+  return m ? ctrlsim_dt_forward_pass2_a(m, B, Tq, m->d.A, t, N, Tmax, c, ctx_scn, hist_rtg, workspace, act_logits, cached, st)
+           : CTRLSIM_EINVAL;
 }
 
 // ------------------------------------------------------------------------------------------------ pass 1, cached
 // While t < T the window starts at step 0, so the frame of a context (focal pose at window index 0), its membership
 // and its map never change: the scene side is computed once (t == 0) and the decoder K/V of every layer are cached at
-// fixed rows (b * T*3A + position).  Step t only evaluates the rows whose inputs changed — the A action tokens of step
-// t-1 (placeholder -> applied action) and the 3A tokens of step t — against the cache: 4A rows instead of 3A*(t+1).
-// No other hidden state changes: an action token is visible only to later timesteps and to itself (mask closed form).
+// fixed rows (b * rows(T) + position).  Step t only evaluates the rows whose inputs changed — the action tokens of step
+// t-1 (placeholder -> applied action) and the three tokens of step t of every slot — against the cache: 4A rows instead of
+// 3A*(t+1).  No other hidden state changes: an action token is visible only to later timesteps and to itself (mask closed form).
 // ctx holds the window rows [max(t-1,0), t]; the workspace must be the one used at t-1 (sized with Tq = T).
-extern "C" int ctrlsim_dt_forward_pass1_cached(const ctrlsim_model* m, int B, int t, const ctrlsim_ctx* c, void* workspace,
-                                               float* rtg_logits, hipStream_t st) {
+extern "C" int ctrlsim_dt_forward_pass1_cached_a(const ctrlsim_model* m, int B, int t, int Actx, const ctrlsim_ctx* c,
+                                                 void* workspace, float* rtg_logits, hipStream_t st) {
   if (!m || !c || !workspace || !rtg_logits || B < 1 || t < 0 || t >= m->d.T || m->d.variant != 0) return CTRLSIM_EINVAL;
   const ctrlsim_dims& d = m->d;
-  const Ws w = carve(d, B, d.T, static_cast<char*>(workspace));
-  const int A = d.A, P = d.P, M = P + A, Lf = d.T * A * 3;
-  const int Rn = t > 0 ? 4 * A : 3 * A, tt_first = t > 0 ? t - 1 : 0, Tn = t + 1 - tt_first;
-  const int rA = B * A, rN = B * Rn, rS = B * Tn * A;
-  hipLaunchKernelGGL(fill_index_cached_kernel, dim3((rN + 255) / 256), dim3(256), 0, st, B, A, Lf, t, Rn, w.pos_new, w.idx_new,
-                     w.idx_state_in_new, w.pos_rtg, w.idx_rtg);
+  if (!actx_ok(d, Actx)) return CTRLSIM_EINVAL;
+  const Shape sh = shape_of(d, Actx);
+  const Ws w = carve(d, sh, B, d.T, static_cast<char*>(workspace));
+  const int A = sh.A, Ar = sh.Areg, P = d.P, M = P + A, Lf = sh.rows(d.T), Lreg_f = sh.lreg(d.T);
+  const int Rn = (t > 0 ? 4 : 3) * A, tt_first = t > 0 ? t - 1 : 0, Tn = t + 1 - tt_first;
+  const int rA = B * A, rQ = B * Ar, rN = B * Rn, rS = B * Tn * A;
+  const Rep rep{sh.rep * 3 * (t + 1), sh.mult, Lreg_f};
+  auto fill_cached = [&]() {
+    hipLaunchKernelGGL(fill_index_cached_kernel, dim3((rN + 255) / 256), dim3(256), 0, st, B, A, Ar, Lf, Lreg_f, sh.rep_k0(d.T), t,
+                       Rn, w.pos_new, w.key_new, w.src_new, w.idx_new, w.idx_state_in_new, w.pos_rtg, w.idx_rtg);
+  };
+  fill_cached();
   CHK(launch_in_mlp(c->st12, 12, 12, m->embed_state.l0.w, m->embed_state.l0.b, m->embed_state.ln.g, m->embed_state.ln.b,
                     w.hS, DM, rS, st));
   CHK(gemm(m->fold_state, w.hS, DM, nullptr, 0, w.S2, DM, rS, DM, DM, 0, st));
@@ -497,16 +587,17 @@ extern "C" int ctrlsim_dt_forward_pass1_cached(const ctrlsim_model* m, int B, in
     CHK(launch_in_mlp(c->goal5, 5, 5, m->embed_goal.l0.w, m->embed_goal.l0.b, m->embed_goal.ln.g, m->embed_goal.ln.b, w.hG,
                       DM, rA, st));
     CHK(gemm(m->fold_goal, w.hG, DM, nullptr, 0, w.Gp, DM, rA, DM, DM, 0, st));
-    hipLaunchKernelGGL(fill_index_kernel, dim3(((rA > B * P ? rA : B * P) + 255) / 256), dim3(256), 0, st, B, A, 3 * A, 0, P, M, 0,
-                       w.pos_state, w.pos_rtg, w.idx_state, w.idx_rtg, w.idx_poly);
-    // token order of assemble_tokens at Tq = 1 is (a, k) = pos_new order; it also writes the initial-state rows of `src`
-    CHK(launch_assemble_tokens(B, 1, A, w.S2, w.Gp, c->exist, c->act_tok, c->rtg_bin, c->tstep, m->tb, w.xn, w.src, M, P,
+    const int nidx = max(max(rA, B * P), 3 * A);
+    hipLaunchKernelGGL(fill_index_kernel, dim3((nidx + 255) / 256), dim3(256), 0, st, B, Ar, 3 * A, 3 * Ar, 0, 0, P, M, 0,
+                       w.pos_state, w.pos_rtg, w.idx_state, w.idx_rtg, w.idx_poly, w.key_all);
+    // token order of assemble_tokens at Tq = 1 is the pos_new order (regular (a, k), then the representative); it also writes
+    // the initial-state rows of `src`
+    CHK(launch_assemble_tokens(B, 1, A, Ar, w.S2, w.Gp, c->exist, c->act_tok, c->rtg_bin, c->tstep, m->tb, w.xn, w.src, M, P,
                                w.src_pad, st));
-    CHK(scene_side(m, w, c, B, nullptr, st));
-    hipLaunchKernelGGL(fill_index_cached_kernel, dim3((rN + 255) / 256), dim3(256), 0, st, B, A, Lf, t, Rn, w.pos_new,
-                       w.idx_new, w.idx_state_in_new, w.pos_rtg, w.idx_rtg);   // pos_rtg / idx_rtg for the cache layout
+    CHK(scene_side(m, sh, w, c, B, nullptr, st));
+    fill_cached();                                 // pos_rtg / idx_rtg for the cache layout
   } else {
-    CHK(launch_assemble_rows(B, Rn, A, tt_first, Tn, w.pos_new, w.S2, w.Gp, c->exist, c->act_tok, c->rtg_bin, c->tstep, m->tb,
+    CHK(launch_assemble_rows(B, Rn, A, tt_first, Tn, w.src_new, w.S2, w.Gp, c->exist, c->act_tok, c->rtg_bin, c->tstep, m->tb,
                              w.xn, st));
   }
   for (int i = 0; i < d.ND; ++i) {
@@ -516,13 +607,17 @@ extern "C" int ctrlsim_dt_forward_pass1_cached(const ctrlsim_model* m, int B, in
     if (t == 0 && presplit()) {   // image tiles are read whole: stale bits beyond the written rows must at least be finite
       if (hipMemsetAsync(w.img_dec[i], 0, w.img_dec_bytes, st) != hipSuccess) return CTRLSIM_ELAUNCH;
     }
-    CHK(kv_split_rows(w.qkvn + DM, w.qkvn + 2 * DM, 3 * DM, (long)Rn * 3 * DM, w.pos_new, B, Rn, w.nkt_dec, w.img_dec[i], st));
+    CHK(kv_split_rows(w.qkvn + DM, w.qkvn + 2 * DM, 3 * DM, (long)Rn * 3 * DM, w.key_new, B, Rn, w.nkt_dec, w.img_dec[i], st));
     CHK(attention_kv(1, w.qkvn, 3 * DM, (long)Rn * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)Lf * 3 * DM,
-                     w.img_dec[i], w.nkt_dec, w.attn_n, DM, (long)Rn * DM, w.pos_new, nullptr, B, Rn, (t + 1) * A * 3, A, st));
+                     w.img_dec[i], w.nkt_dec, w.attn_n, DM, (long)Rn * DM, w.pos_new, nullptr, B, Rn, (t + 1) * Ar * 3, Ar, st, rep));
     CHK(gemm_ln(Ld.out, Ld.n1, w.attn_n, DM, w.xn, DM, w.xn, DM, w.tmpn, rN, DM, 0, st));
-    CHK(cross_and_ffn(m, Ld, i, w, w.xn, w.tmpn, w.attn_n, w.qcn, w.ffnn, rN, B, Rn, st));
+    CHK(cross_and_ffn(m, sh, Ld, i, w, w.xn, w.tmpn, w.attn_n, w.qcn, w.ffnn, rN, B, Rn, st));
   }
-  CHK(launch_row_copy(w.xn, DM, w.xc, DM, w.idx_state_in_new, rA, DM, 0, st));
-  CHK(mlp_tail(m->head_rtg, w.xc, rA, w.headh, rtg_logits, d.R * d.C, st));
+  CHK(launch_row_copy(w.xn, DM, w.xc, DM, w.idx_state_in_new, rQ, DM, 0, st));
+  CHK(mlp_tail(m->head_rtg, w.xc, rQ, w.headh, rtg_logits, d.R * d.C, st));
   return CTRLSIM_OK;
+}
+extern "C" int ctrlsim_dt_forward_pass1_cached(const ctrlsim_model* m, int B, int t, const ctrlsim_ctx* c, void* workspace,
+                                               float* rtg_logits, hipStream_t st) {
+  return m ? ctrlsim_dt_forward_pass1_cached_a(m, B, t, m->d.A, c, workspace, rtg_logits, st) : CTRLSIM_EINVAL;
 }

@@ -44,7 +44,8 @@ __device__ __forceinline__ void term(f32x16 (&acc)[MR][2], const opx8 (&fa)[MR][
 // KVIMG = true (2x2 tiles, plain Linear): output columns >= kv.k_col0 are attention keys (256 columns) and values (the
 // next 256) and are written NOT as fp32 rows but directly as the split-bf16 K / V^T tile images the attention kernel
 // stages by DMA (attention_bf16x6.hip: layout at kv_split_kernel) — the K/V split costs no extra pass over HBM.
-struct KvImg { op_t* img; int L; int nkt; int k_col0; };   // L = rows (keys) per context
+struct KvImg { op_t* img; int L; int nkt; int k_col0; int Lreg; int rep_k0; };   // L = rows per context; rows >= Lreg (the
+// representative tokens of a compact context, attention_bf16x6.hip) are keys rep_k0 + (row - Lreg), the others key = row
 
 template <int WR, int WC, int MR, bool RELU, bool RESID, bool LN, bool KVIMG = false>
 #ifndef GEMM_OCC_22
@@ -296,7 +297,8 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
           const int lr = tid & 63;
           const int grow = cbm + (lr >> 5) * WMR + a * 32 + (lr & 31);
           if (grow < M) {
-            const int b = grow / kv.L, pos = grow - b * kv.L, kt = pos >> 6, key = pos & 63;
+            const int b = grow / kv.L, row = grow - b * kv.L, pos = row < kv.Lreg ? row : kv.rep_k0 + (row - kv.Lreg);
+            const int kt = pos >> 6, key = pos & 63;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const int c = (tid >> 6) + 4 * i, hh = c >> 2, dg = c & 3;     // 8 dims [8c, 8c+8) of the tile's 128 columns
@@ -321,8 +323,9 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
           for (int i = 0; i < CR / 8; ++i) {
             const int lr0 = ((tid >> 7) + 2 * i) * 4;                      // a key quad: 4 consecutive rows of one segment
             const int grow0 = cbm + (lr0 >> 5) * WMR + a * 32 + (lr0 & 31);
-            if (grow0 < M) {                                               // L % 4 == 0: quads never straddle contexts
-              const int b = grow0 / kv.L, pos = grow0 - b * kv.L, kt = pos >> 6, q = (pos & 63) >> 2;
+            if (grow0 < M) {                                               // L % 4 == Lreg % 4 == 0: quads never straddle contexts / regions
+              const int b = grow0 / kv.L, row = grow0 - b * kv.L, pos = row < kv.Lreg ? row : kv.rep_k0 + (row - kv.Lreg);
+              const int kt = pos >> 6, q = (pos & 63) >> 2;
               const float x0 = Cs[(lr0 + 0) * CP + col] + bv, x1 = Cs[(lr0 + 1) * CP + col] + bv;
               const float x2 = Cs[(lr0 + 2) * CP + col] + bv, x3 = Cs[(lr0 + 3) * CP + col] + bv;
               u32x2 pv[NPL];
@@ -392,24 +395,27 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
 int launch_gemm_nt_bf16x6_kv(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias,
                              const float* R, int ldr, float* C, int ldc, int M, int N, int K, int relu,
                              const float* ln_gamma, const float* ln_beta, void* kv_img, int kv_L, int kv_nkt, int kv_col0,
-                             hipStream_t st);
+                             int kv_Lreg, int kv_rep_k0, hipStream_t st);
 int launch_gemm_nt_bf16x6(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias,
                           const float* R, int ldr, float* C, int ldc, int M, int N, int K, int relu,
                           const float* ln_gamma, const float* ln_beta, hipStream_t st) {
   return launch_gemm_nt_bf16x6_kv(A, lda, W3, n_total, n0, bias, R, ldr, C, ldc, M, N, K, relu, ln_gamma, ln_beta, nullptr, 0, 0,
-                                  0, st);
+                                  0, 0, 0, st);
 }
 // kv_img != NULL: columns [kv_col0, kv_col0 + 512) are keys / values of 8 heads x 32 and go to the split images of
-// kv_nkt 64-key tiles per context of kv_L rows (kv_L % 4 == 0, kv_L >= 32, kv_col0 % 128 == 0, M % kv_L == 0)
+// kv_nkt 64-key tiles per context of kv_L rows (kv_L % 4 == 0, kv_L >= 32, kv_col0 % 128 == 0, M % kv_L == 0); rows >= kv_Lreg of a
+// context (kv_Lreg % 4 == 0; kv_Lreg = kv_L: none) are written from key kv_rep_k0 (a multiple of 64) on
 int launch_gemm_nt_bf16x6_kv(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias,
                              const float* R, int ldr, float* C, int ldc, int M, int N, int K, int relu,
                              const float* ln_gamma, const float* ln_beta, void* kv_img, int kv_L, int kv_nkt, int kv_col0,
-                             hipStream_t st) {
+                             int kv_Lreg, int kv_rep_k0, hipStream_t st) {
   if (M <= 0) return CTRLSIM_OK;
+  if (kv_img && kv_Lreg <= 0) { kv_Lreg = kv_L; kv_rep_k0 = 0; }
   if (kv_img && (ln_gamma || R || relu || (kv_L & 3) || kv_L < 32 || (kv_col0 & 127) || N != kv_col0 + 2 * DM || M % kv_L ||
-                 kv_nkt * 64 < kv_L))
+                 (kv_Lreg & 3) || kv_Lreg > kv_L || (kv_rep_k0 & 63) || (kv_Lreg < kv_L && kv_rep_k0 < kv_Lreg) ||
+                 kv_nkt * 64 < (kv_Lreg < kv_L ? kv_rep_k0 + (kv_L - kv_Lreg) : kv_L)))
     return CTRLSIM_EINVAL;
-  const KvImg kv{static_cast<op_t*>(kv_img), kv_L, kv_nkt, kv_col0};
+  const KvImg kv{static_cast<op_t*>(kv_img), kv_L, kv_nkt, kv_col0, kv_Lreg, kv_rep_k0};
   if (K % XK != 0 || (lda & 3) || N <= 0 || !W3 || n0 < 0 || n0 + N > n_total) return CTRLSIM_EINVAL;
   const bool ln = ln_gamma != nullptr;
   if (ln && (N != 256 || (ldc & 3) || (R && (ldr & 3)))) return CTRLSIM_EINVAL;

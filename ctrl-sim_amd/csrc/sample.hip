@@ -48,10 +48,12 @@ __device__ __forceinline__ ArgBest wave_argmax(double s, int i) {
   return {s, i};
 }
 
-// rtg_logits [Bctx, A, R*3]; own_ctx/own_slot/tilted [S*N]; hist_rtg [S,N,Tmax,3]
+// rtg_logits [Bctx, A, R*3] — or, with ctx_row0 (compact contexts of different slot counts), logits rows, context c's slot s at
+// row ctx_row0[c] + s; own_ctx/own_slot/tilted [S*N]; hist_rtg [S,N,Tmax,3]
 __global__ __launch_bounds__(256) void sample_rtg_kernel(const float* __restrict__ rtg_logits, int A, int R,
                                                          const int* __restrict__ own_ctx,
                                                          const int* __restrict__ own_slot,
+                                                         const int* __restrict__ ctx_row0,
                                                          const unsigned char* __restrict__ tilted, double tilt_goal,
                                                          double tilt_veh, double tilt_road,
                                                          const double* __restrict__ tilt_scn,  // [S,3] or null (uniform)
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(256) void sample_rtg_kernel(const float* __restrict
   if (ctx < 0) return;                              // vehicle is in no context this step: row keeps the (0,35,35) default
   const int lane = threadIdx.x & 63;
   const int s = sv / N, v = sv - s * N;
-  const float* lg = rtg_logits + ((size_t)ctx * A + own_slot[sv]) * (size_t)(R * 3);
+  const float* lg = rtg_logits + ((ctx_row0 ? (size_t)ctx_row0[ctx] : (size_t)ctx * A) + own_slot[sv]) * (size_t)(R * 3);
   const bool tl = tilted[sv] != 0;
   if (tilt_scn) { tilt_goal = tilt_scn[3 * s]; tilt_veh = tilt_scn[3 * s + 1]; tilt_road = tilt_scn[3 * s + 2]; }
   const double tilts[3] = {tl ? tilt_goal : 0.0, tl ? tilt_veh : 0.0, tl ? tilt_road : 0.0};
@@ -89,7 +91,8 @@ __global__ __launch_bounds__(256) void sample_rtg_kernel(const float* __restrict
 // act_logits [Bctx, A, V]; mem_ctx/mem_slot [S*N] (-1: not evaluated this step -> zero action)
 __global__ __launch_bounds__(256) void sample_action_kernel(const float* __restrict__ act_logits, int A, int V,
                                                             const int* __restrict__ mem_ctx,
-                                                            const int* __restrict__ mem_slot, float temperature,
+                                                            const int* __restrict__ mem_slot,
+                                                            const int* __restrict__ ctx_row0, float temperature,
                                                             double top_p, const float* __restrict__ noise,  // [S*N, V] or null
                                                             uint64_t seed, const int64_t* __restrict__ scenario_id,
                                                             int t, int* __restrict__ hist_tok, int* __restrict__ act_now,
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(256) void sample_action_kernel(const float* __restr
     return;
   }
   const int s = sv / N, v = sv - s * N;
-  const float* lg = act_logits + ((size_t)ctx * A + mem_slot[sv]) * (size_t)V;
+  const float* lg = act_logits + ((ctx_row0 ? (size_t)ctx_row0[ctx] : (size_t)ctx * A) + mem_slot[sv]) * (size_t)V;
   const uint64_t key = noise ? 0 : noise_key(seed, (uint64_t)scenario_id[s], (uint64_t)t, (uint64_t)v, 3ull);
   double* p = pbuf + (size_t)w * V;
   const bool nucleus = top_p > 0.0;
@@ -146,18 +149,18 @@ __global__ __launch_bounds__(256) void sample_action_kernel(const float* __restr
   if (lane == 0) { hist_tok[(size_t)sv * Tmax + t] = r.i; act_now[sv] = r.i; }
 }
 
-int launch_sample_rtg(const float* rtg_logits, int A, int R, const int* own_ctx, const int* own_slot,
+int launch_sample_rtg(const float* rtg_logits, int A, int R, const int* own_ctx, const int* own_slot, const int* ctx_row0,
                       const unsigned char* tilted, const double* tilt3, const double* tilt_scn, const float* noise, uint64_t seed,
                       const int64_t* scenario_id, int t, int* hist_rtg, int S, int N, int Tmax, hipStream_t st) {
   const int SN = S * N;
   if (SN <= 0) return CTRLSIM_OK;
   if (t < 0 || t >= Tmax) return CTRLSIM_EINVAL;
-  hipLaunchKernelGGL(sample_rtg_kernel, dim3((SN + 3) / 4), dim3(256), 0, st, rtg_logits, A, R, own_ctx, own_slot, tilted,
+  hipLaunchKernelGGL(sample_rtg_kernel, dim3((SN + 3) / 4), dim3(256), 0, st, rtg_logits, A, R, own_ctx, own_slot, ctx_row0, tilted,
                      tilt3[0], tilt3[1], tilt3[2], tilt_scn, noise, seed, scenario_id, t, hist_rtg, N, Tmax, SN);
   return ctrlsim_launch_status();
 }
 
-int launch_sample_action(const float* act_logits, int A, int V, const int* mem_ctx, const int* mem_slot,
+int launch_sample_action(const float* act_logits, int A, int V, const int* mem_ctx, const int* mem_slot, const int* ctx_row0,
                          float temperature, double top_p, const float* noise, uint64_t seed,
                          const int64_t* scenario_id, int t, int* hist_tok, int* act_now, int S, int N, int Tmax,
                          int zero_token, hipStream_t st) {
@@ -165,7 +168,7 @@ int launch_sample_action(const float* act_logits, int A, int V, const int* mem_c
   if (SN <= 0) return CTRLSIM_OK;
   if (t < 0 || t >= Tmax || temperature <= 0.f) return CTRLSIM_EINVAL;
   const size_t shm = top_p > 0.0 ? (size_t)4 * V * sizeof(double) : 0;
-  hipLaunchKernelGGL(sample_action_kernel, dim3((SN + 3) / 4), dim3(256), shm, st, act_logits, A, V, mem_ctx, mem_slot,
+  hipLaunchKernelGGL(sample_action_kernel, dim3((SN + 3) / 4), dim3(256), shm, st, act_logits, A, V, mem_ctx, mem_slot, ctx_row0,
                      temperature, top_p, noise, seed, scenario_id, t, hist_tok, act_now, N, Tmax, SN, zero_token);
   return ctrlsim_launch_status();
 }

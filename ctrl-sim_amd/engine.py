@@ -59,8 +59,8 @@ class HipModel:
                                                  self._offsets, C.byref(h)), "model_create")
         self.handle = h
 
-    def workspace_bytes(self, B, Tq):
-        n = self.lib.ctrlsim_forward_workspace_bytes(C.byref(self.cdims), B, Tq)
+    def workspace_bytes(self, B, Tq, A=None):
+        n = self.lib.ctrlsim_forward_workspace_bytes_a(C.byref(self.cdims), B, Tq, self.dims.A if A is None else A)
         if n < 0:
             raise RuntimeError(f"workspace query failed: {n}")
         return int(n)
@@ -88,27 +88,45 @@ class CtxBuffers:
         self.slot_gid = z(Bmax, d.A, dt=torch.int32)
         self.road_pts = z(Bmax, d.P, d.NP, 3)
         self.road_types = z(Bmax, d.P, 8)
-        self.struct = _lib.Ctx(*(getattr(self, k).data_ptr() for k in ("st12", "exist", "goal5", "act_tok", "rtg_bin",
-                                                                       "tstep", "slot_gid", "road_pts", "road_types")))
+        self.struct = _lib.Ctx(*(getattr(self, k).data_ptr() for k in self.FIELDS))
+        self._d = d
+
+    FIELDS = ("st12", "exist", "goal5", "act_tok", "rtg_bin", "tstep", "slot_gid", "road_pts", "road_types")
+
+    def class_structs(self, classes, Tn):
+        """One ctrlsim_ctx per size class: the buffers are shared, class k's B_k contexts of A_k slots x Tn window rows start
+        where the previous classes' end.  classes = [(B_k, A_k)]."""
+        d = self._d
+        per_ctx = lambda A: dict(st12=Tn * A * 12, exist=Tn * A, goal5=A * 5, act_tok=Tn * A, rtg_bin=Tn * A * 3, tstep=Tn,
+                                 slot_gid=A, road_pts=d.P * d.NP * 3, road_types=d.P * 8)
+        off = {k: 0 for k in self.FIELDS}
+        out = []
+        for B, A in classes:
+            out.append(_lib.Ctx(*(getattr(self, k).data_ptr() + 4 * off[k] for k in self.FIELDS)))
+            n = per_ctx(A)
+            for k in self.FIELDS:
+                off[k] += B * n[k]
+        return out
 
 
 def ctx_from_reference_layout(d: Dims, data: dict, Tq: int, device):
     """Reference-layout model inputs (agent_states [B,A,T,8], ... as in modules/encoder.py:52-63) -> CtxBuffers with
-    the first Tq window steps.  Used by the model-level parity tests."""
-    B = data["agent_states"].shape[0]
+    the first Tq window steps.  The arrays may hold fewer slots than d.A (a compact context: the leading A' slots of the
+    reference layout, the last one a padded slot).  Used by the model-level parity tests."""
+    B, A = data["agent_states"].shape[:2]
     cb = CtxBuffers(d, B, device)
     st = np.asarray(data["agent_states"], np.float64)
-    types = np.broadcast_to(np.asarray(data["agent_types"], np.float64)[:, :, None, :], (B, d.A, d.T, 5))
+    types = np.broadcast_to(np.asarray(data["agent_types"], np.float64)[:, :, None, :], (B, A, d.T, 5))
     st12 = np.concatenate([st[..., :7], types], -1).transpose(0, 2, 1, 3)[:, :Tq]
     flat = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt)).to(device).reshape(-1)
-    cb.st12.view(-1)[:B * Tq * d.A * 12] = flat(st12, np.float32)
-    cb.exist.view(-1)[:B * Tq * d.A] = flat(st[..., 7].transpose(0, 2, 1)[:, :Tq], np.float32)
-    cb.goal5.copy_(torch.from_numpy(np.asarray(data["goals"], np.float64).astype(np.float32)).to(device))
-    cb.act_tok.view(-1)[:B * Tq * d.A] = flat(np.asarray(data["actions"]).transpose(0, 2, 1)[:, :Tq], np.int32)
+    cb.st12.view(-1)[:B * Tq * A * 12] = flat(st12, np.float32)
+    cb.exist.view(-1)[:B * Tq * A] = flat(st[..., 7].transpose(0, 2, 1)[:, :Tq], np.float32)
+    cb.goal5.view(-1)[:B * A * 5] = flat(np.asarray(data["goals"], np.float64), np.float32)
+    cb.act_tok.view(-1)[:B * Tq * A] = flat(np.asarray(data["actions"]).transpose(0, 2, 1)[:, :Tq], np.int32)
     rt = np.asarray(data["rtgs"]).transpose(0, 2, 1, 3)[:, :Tq]
     if d.VARIANT == 3:                                   # decision transformer: continuous RTGs travel as float bits
         rt = np.ascontiguousarray(rt, np.float32).view(np.int32)
-    cb.rtg_bin.view(-1)[:B * Tq * d.A * 3] = flat(rt, np.int32)
+    cb.rtg_bin.view(-1)[:B * Tq * A * 3] = flat(rt, np.int32)
     cb.tstep.view(-1)[:B * Tq] = flat(np.asarray(data["timesteps"])[:, 0, :Tq, 0], np.int32)
     cb.slot_gid.fill_(-1)
     cb.road_pts.copy_(torch.from_numpy(np.asarray(data["road_points"], np.float64).astype(np.float32)).to(device))
@@ -121,17 +139,20 @@ class _Lane:
     stream for its simulator step / grouping / count read-back, and the two events that order it against the main stream."""
 
     def __init__(self, eng, idx, own_stream):
-        d, dev, B = eng.dims, eng.device, eng.max_ctx
+        d, dev = eng.dims, eng.device
+        B = eng.ctx_cap                                           # contexts per model batch (compact ones are cheap: see _chunks)
         self.idx = idx
         self.ctx = CtxBuffers(d, B, dev)
-        self.ws = torch.empty(eng.model.workspace_bytes(B, d.T), dtype=torch.uint8, device=dev)
+        self.ws = torch.empty(eng.model.workspace_bytes(eng.max_ctx, d.T) + eng._ws_fixed + (1 << 20), dtype=torch.uint8,
+                              device=dev)             # max_ctx plain contexts always fit, whatever the class mix
         self.rtg_logits = torch.empty(B, d.A, d.R * d.C, device=dev)
         self.act_logits = torch.empty(B, d.A, d.V, device=dev)
         self.ctx_scn = torch.zeros(B, dtype=torch.int32, device=dev)
         self.ctx_grp = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.ctx_row0 = torch.zeros(B, dtype=torch.int32, device=dev)
         self.flag = torch.zeros(1, dtype=torch.int32, device=dev)
         self.host_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
-        self.host_counts = None                                  # pinned [S] int32, sized by load_scenarios
+        self.host_hist = None                                    # pinned [S, classes] int32, sized by load_scenarios
         self.side = torch.cuda.Stream(device=dev) if own_stream else None
         self.ev_fwd, self.ev_ready = torch.cuda.Event(), torch.cuda.Event()
         self.pending = (0, 0, False)                             # scenario range (+ compare flag) of the read-back in flight
@@ -140,7 +161,7 @@ class _Lane:
 class RolloutEngine:
     def __init__(self, cfg, weights: dict, device="cuda:0", max_ctx=256, seed=0, tilt=(0.0, 0.0, 0.0),
                  temperature=None, nucleus=None, top_p=None, kinematic=False, model=None, use_cache=True, contacts=True,
-                 lanes=1):
+                 lanes=1, compact=True):
         self.cfg = cfg
         self.w = cfg.dataset.waymo
         self.dims = Dims(cfg)
@@ -173,11 +194,22 @@ class RolloutEngine:
             from .rewards import normalize_rtgs
             self.zero_rtg = tuple(int(v) for v in normalize_rtgs(np.zeros(3), self.w).astype(np.float32).view(np.int32))
         self._zero4 = (C.c_int * 4)(ZERO_ACTION_TOKEN, *self.zero_rtg)
+        # size classes of compact contexts (include/ctrlsim.h: ctrlsim_group_size_hist): slot counts 4, 8, ... and A.  A context
+        # with n vehicles runs with the first size >= n + 1; the CtRL-Sim model only (the baselines keep the plain layout).
+        A = self.dims.A
+        self.sizes = tuple(sorted({a for a in range(4, A, 4)} | {A})) if (compact and not self.dims.VARIANT) else (A,)
+        self._sizes_c = (C.c_int * len(self.sizes))(*self.sizes)
+        self.ctx_cap = self.max_ctx * (4 if len(self.sizes) > 1 else 1)
+        # workspace bytes per context of each class (the carve is linear in B up to alignment), + a fixed allowance per class
+        wb = self.model.workspace_bytes
+        self._bpc = [(wb(257, self.dims.T, a) - wb(1, self.dims.T, a)) / 256.0 for a in self.sizes]
+        self._ws_fixed = sum(wb(1, self.dims.T, a) for a in self.sizes)
         self.n_lanes = max(1, int(lanes))
         self.lanes = [_Lane(self, i, self.n_lanes > 1) for i in range(self.n_lanes)]
         L0 = self.lanes[0]                   # the synchronous single-stream entry points (policy_step / step) use lane 0
         self.ctx, self.ws, self.rtg_logits, self.act_logits = L0.ctx, L0.ws, L0.rtg_logits, L0.act_logits
         self.ctx_scn, self.ctx_grp = L0.ctx_scn, L0.ctx_grp
+        self._ws_cap = L0.ws.numel()
         self._main = torch.cuda.current_stream(self.device)
         self.S = 0
 
@@ -226,9 +258,11 @@ class RolloutEngine:
         self.applied = z(S, N, Tmax, 2, dt=torch.float64)
         self.persist = z(S, N, dt=torch.int64)
         self.n_groups = z(S, dt=torch.int32)
-        self.n_groups_host = torch.zeros(S, dtype=torch.int32).pin_memory()
+        nb = len(self.sizes)
+        self.size_hist = z(S, nb, dt=torch.int32)
+        self.ctx_of_group = z(S, N, dt=torch.int32)
         for L in self.lanes:
-            L.host_counts = torch.zeros(S, dtype=torch.int32).pin_memory()
+            L.host_hist = torch.zeros(S, nb, dtype=torch.int32).pin_memory()
         self.grp_focal = z(S, N, dt=torch.int32)
         self.grp_ids = z(S, N, dt=torch.int64)
         self.grp_members = z(S, N, dt=torch.int64)
@@ -262,23 +296,48 @@ class RolloutEngine:
                                              st), "sim_init")
 
     # ------------------------------------------------------------------ chunk plan
-    def _chunks(self, counts, base=0):
-        """Cut scenarios base .. base+len(counts) into model batches of <= max_ctx contexts, of balanced size (a short last
-        batch costs a whole set of launches).  -> [(s0, s1, n_contexts)]."""
-        counts = [int(c) for c in counts]
-        total, big = sum(counts), max(counts, default=0)
-        if big > self.max_ctx:
-            raise RuntimeError(f"a scenario has {big} focal groups > max_ctx={self.max_ctx}")
-        n = max(1, -(-total // self.max_ctx))
-        cap = min(self.max_ctx, -(-total // n) + big)
-        chunks, s0, acc = [], 0, 0
-        for s, c in enumerate(counts):
-            if acc + c > cap or s - s0 >= 4095:
-                chunks.append((base + s0, base + s, acc))
-                s0, acc = s, 0
-            acc += c
-        chunks.append((base + s0, base + len(counts), acc))
-        return [c for c in chunks if c[1] > c[0]]
+    def _chunks(self, hist, base=0):
+        """Cut scenarios base .. base+len(hist) into model batches.  hist [n, classes] = focal groups per scenario and size
+        class.  A batch must fit the lane's workspace (compact contexts are cheaper: bytes per context by class) and its
+        context buffers (ctx_cap contexts); batches are balanced (a short last batch costs a whole set of launches).
+        -> [(s0, s1, counts_per_class)]."""
+        hist = np.asarray(hist, np.int64).reshape(-1, len(self.sizes))
+        cost = hist @ np.asarray(self._bpc)                       # workspace bytes per scenario
+        nctx = hist.sum(1)
+        cap_b = self._ws_cap - self._ws_fixed - (1 << 20)
+        cap_c = self.ctx_cap
+        if len(hist) and (cost.max() > cap_b or nctx.max() > cap_c):
+            raise RuntimeError(f"a scenario has {int(nctx.max())} focal groups: more than one model batch (max_ctx={self.max_ctx})")
+        n = max(1, int(np.ceil(max(cost.sum() / cap_b, nctx.sum() / cap_c))))
+        lim_b = min(cap_b, cost.sum() / n + (cost.max() if len(cost) else 0))
+        lim_c = min(cap_c, nctx.sum() / n + (nctx.max() if len(nctx) else 0))
+        chunks, s0, acc_b, acc_c = [], 0, 0.0, 0
+        for s in range(len(hist)):
+            if acc_b + cost[s] > lim_b or acc_c + nctx[s] > lim_c or s - s0 >= 4095:
+                chunks.append((base + s0, base + s, hist[s0:s].sum(0)))
+                s0, acc_b, acc_c = s, 0.0, 0
+            acc_b += cost[s]
+            acc_c += nctx[s]
+        chunks.append((base + s0, base + len(hist), hist[s0:].sum(0)))
+        return [(a, b, [int(x) for x in c]) for (a, b, c) in chunks if b > a]
+
+    def _class_plan(self, counts, Tw, Tn):
+        """Per non-empty size class of a model batch: (B_k, A_k, first context, first logits row, workspace offset, ctx struct).
+        Tw = window steps the workspace is carved for, Tn = window rows held by the context tensors."""
+        d = self.dims
+        plan, c0, r0, w0 = [], 0, 0, 0
+        structs = None
+        classes = [(B, A) for B, A in zip(counts, self.sizes)]
+        for k, (B, A) in enumerate(classes):
+            if B > 0:
+                if structs is None:
+                    structs = self._plan_lane.ctx.class_structs(classes, Tn)
+                plan.append((B, A, c0, r0, w0, structs[k]))
+                w0 += (self.model.workspace_bytes(B, Tw, A) + 255) // 256 * 256
+            c0 += B
+            r0 += B * (A - 1 if A < d.A else A)
+        assert w0 <= self._ws_cap, "model batch exceeds the lane workspace"
+        return plan
 
     # ------------------------------------------------------------------ kernels of one step, on explicit streams
     def sim_step(self, t, act_f64=None, s0=0, s1=None, stream=None):
@@ -309,7 +368,7 @@ class RolloutEngine:
 
     def _enqueue_groups(self, L, t, s0, s1, compare=False):
         """Side stream of lane L: focal groups of step t for scenarios [s0, s1), (compare) the changed-vs-snapshot flag, the
-        asynchronous read-back of the group counts (+ flag), then L.ev_ready."""
+        asynchronous read-back of the group counts per size class (+ flag), then L.ev_ready."""
         side = self._side(L)
         sl = slice(s0, s1)
         self._group_build(t, s0, s1, side.cuda_stream)
@@ -321,15 +380,19 @@ class RolloutEngine:
                                                            p(self.grp_ids[sl]), p(self.ref_n[sl]), p(self.ref_focal[sl]),
                                                            p(self.ref_ids[sl]), p(L.flag), side.cuda_stream), "groups_changed")
                 L.host_flag.copy_(L.flag, non_blocking=True)
-            L.host_counts[:s1 - s0].copy_(self.n_groups[sl], non_blocking=True)
+            _lib.check(self.lib.ctrlsim_group_size_hist(s1 - s0, self.N, _lib.ptr(self.n_groups[sl]), _lib.ptr(self.grp_ids[sl]),
+                                                        len(self.sizes), self._sizes_c, _lib.ptr(self.size_hist[sl]),
+                                                        side.cuda_stream), "group_size_hist")
+            L.host_hist[:s1 - s0].copy_(self.size_hist[sl], non_blocking=True)
             L.ev_ready.record(side)
         L.pending = (s0, s1, compare)
 
     def _await_groups(self, L):
-        """Host side of _enqueue_groups: wait for the lane's read-back -> (counts [s1-s0] copy, changed)."""
+        """Host side of _enqueue_groups: wait for the lane's read-back -> (groups per scenario and size class [s1-s0, classes]
+        (copy), changed)."""
         s0, s1, compare = L.pending
         L.ev_ready.synchronize()
-        return L.host_counts.numpy()[:s1 - s0].copy(), bool(compare and int(L.host_flag[0]) != 0)
+        return L.host_hist.numpy()[:s1 - s0].copy(), bool(compare and int(L.host_flag[0]) != 0)
 
     def _snapshot_groups(self, L, s0, s1):
         side, sl = self._side(L), slice(s0, s1)
@@ -350,78 +413,87 @@ class RolloutEngine:
         if L.side is not None:
             self._main.wait_event(L.ev_ready)
 
-    # ------------------------------------------------------------------ cached phase (t < T): one chunk, one step
-    def _chunk_step_cached(self, L, s0, s1, B, t):
-        """Policy step of one chunk of scenarios against the decoder K/V cache of that chunk (the lane's workspace)."""
-        lib, p, st, d = self.lib, _lib.ptr, self._main.cuda_stream, self.dims
-        N, Tmax, ns, sl = self.N, self.steps, s1 - s0, slice(s0, s1)
-        Tq, tt_first = t + 1, max(t - 1, 0)
-        _lib.check(lib.ctrlsim_ctx_index(s0, s1, N, p(self.n_groups), p(self.grp_focal), p(self.grp_ids), p(self.own_g),
-                                         p(self.mem_g), p(L.ctx_scn), p(L.ctx_grp), p(self.own_ctx), p(self.own_slot),
-                                         p(self.mem_ctx), p(self.mem_slot), p(self.ctx_base), st), "ctx_index")
-        _lib.check(lib.ctrlsim_build_context(B, N, d.A, d.T, t, Tq, tt_first, Tmax + 1, Tmax, self.P_all, d.P, d.NP,
-                                             p(L.ctx_scn), p(L.ctx_grp), p(self.grp_focal), p(self.grp_ids),
-                                             p(self.hist_states), p(self.hist_tok), p(self.hist_rtg), p(self.goals),
-                                             p(self.types), p(self.roads), p(self.rtypes), self._zero4,
-                                             C.byref(L.ctx.struct), st), "build_context")
-        _lib.check(lib.ctrlsim_dt_forward_pass1_cached(self.model.handle, B, t, C.byref(L.ctx.struct), p(L.ws),
-                                                       p(L.rtg_logits), st), "pass1_cached")
-        _lib.check(lib.ctrlsim_sample_rtg(p(L.rtg_logits), d.A, d.R, p(self.own_ctx[sl]), p(self.own_slot[sl]),
-                                          p(self.tilted[sl]), self.tilt,
-                                          p(self.tilt_scn[sl]) if self.tilt_scn is not None else None, None, self.seed,
-                                          p(self.scenario_id[sl]), t, p(self.hist_rtg[sl]), ns, N, Tmax, st), "sample_rtg")
-        _lib.check(lib.ctrlsim_dt_forward_pass2(self.model.handle, B, Tq, t, N, Tmax, C.byref(L.ctx.struct), p(L.ctx_scn),
-                                                p(self.hist_rtg), p(L.ws), p(L.act_logits), 1, st), "pass2_cached")
-        _lib.check(lib.ctrlsim_sample_action(p(L.act_logits), d.A, d.V, p(self.mem_ctx[sl]), p(self.mem_slot[sl]),
-                                             self.temperature, self.top_p, None, self.seed, p(self.scenario_id[sl]), t,
-                                             p(self.hist_tok[sl]), p(self.act_now[sl]), ns, N, Tmax, ZERO_ACTION_TOKEN, st),
-                   "sample_action")
+    # ------------------------------------------------------------------ policy of one model batch
+    def _ctx_index(self, L, s0, s1, st):
+        lib, p = self.lib, _lib.ptr
+        _lib.check(lib.ctrlsim_ctx_index_classes(s0, s1, self.N, self.dims.A, p(self.n_groups), p(self.grp_ids), p(self.own_g),
+                                                 p(self.mem_g), len(self.sizes), self._sizes_c, p(L.ctx_scn), p(L.ctx_grp),
+                                                 p(L.ctx_row0), p(self.ctx_of_group), p(self.own_ctx), p(self.own_slot),
+                                                 p(self.mem_ctx), p(self.mem_slot), st), "ctx_index_classes")
 
-    def _policy_chunks(self, L, t, counts, lo, hi, noise_rtg=None, noise_act=None):
-        """Full-recompute policy for scenarios [lo, hi) (counts = their group counts), chunked to the model batch, on the main
-        stream with lane L's buffers."""
+    def _build_contexts(self, L, plan, t, Tq, tt_first, st):
+        lib, p, d = self.lib, _lib.ptr, self.dims
+        Tmax = self.steps
+        for (B, A, c0, r0, w0, cs) in plan:
+            _lib.check(lib.ctrlsim_build_context(B, self.N, A, d.T, t, Tq, tt_first, Tmax + 1, Tmax, self.P_all, d.P, d.NP,
+                                                 p(L.ctx_scn[c0:]), p(L.ctx_grp[c0:]), p(self.grp_focal), p(self.grp_ids),
+                                                 p(self.hist_states), p(self.hist_tok), p(self.hist_rtg), p(self.goals),
+                                                 p(self.types), p(self.roads), p(self.rtypes), self._zero4, C.byref(cs), st),
+                       "build_context")
+
+    def _sample_rtg(self, L, t, s0, s1, st, noise_rtg=None):
+        lib, p, d, sl = self.lib, _lib.ptr, self.dims, slice(s0, s1)
+        _lib.check(lib.ctrlsim_sample_rtg_rows(p(L.rtg_logits), p(L.ctx_row0), d.R, p(self.own_ctx[sl]), p(self.own_slot[sl]),
+                                               p(self.tilted[sl]), self.tilt,
+                                               p(self.tilt_scn[sl]) if self.tilt_scn is not None else None,
+                                               p(noise_rtg[sl]) if noise_rtg is not None else None, self.seed,
+                                               p(self.scenario_id[sl]), t, p(self.hist_rtg[sl]), s1 - s0, self.N, self.steps, st),
+                   "sample_rtg")
+
+    def _sample_action(self, L, t, s0, s1, st, noise_act=None):
+        lib, p, d, sl = self.lib, _lib.ptr, self.dims, slice(s0, s1)
+        _lib.check(lib.ctrlsim_sample_action_rows(p(L.act_logits), p(L.ctx_row0), d.V, p(self.mem_ctx[sl]), p(self.mem_slot[sl]),
+                                                  self.temperature, self.top_p,
+                                                  p(noise_act[sl]) if noise_act is not None else None, self.seed,
+                                                  p(self.scenario_id[sl]), t, p(self.hist_tok[sl]), p(self.act_now[sl]),
+                                                  s1 - s0, self.N, self.steps, ZERO_ACTION_TOKEN, st), "sample_action")
+
+    def _chunk_step_cached(self, L, s0, s1, counts, t):
+        """Cached phase (t < T): policy step of one model batch against the decoder K/V cache it keeps in the lane's workspace."""
+        lib, p, st, d = self.lib, _lib.ptr, self._main.cuda_stream, self.dims
+        N, Tmax = self.N, self.steps
+        Tq, tt_first = t + 1, max(t - 1, 0)
+        self._plan_lane = L
+        plan = self._class_plan(counts, d.T, Tq - tt_first)
+        RC, V = d.R * d.C * 4, d.V * 4
+        self._ctx_index(L, s0, s1, st)
+        self._build_contexts(L, plan, t, Tq, tt_first, st)
+        for (B, A, c0, r0, w0, cs) in plan:
+            _lib.check(lib.ctrlsim_dt_forward_pass1_cached_a(self.model.handle, B, t, A, C.byref(cs), L.ws.data_ptr() + w0,
+                                                             L.rtg_logits.data_ptr() + r0 * RC, st), "pass1_cached")
+        self._sample_rtg(L, t, s0, s1, st)
+        for (B, A, c0, r0, w0, cs) in plan:
+            _lib.check(lib.ctrlsim_dt_forward_pass2_a(self.model.handle, B, Tq, A, t, N, Tmax, C.byref(cs), p(L.ctx_scn[c0:]),
+                                                      p(self.hist_rtg), L.ws.data_ptr() + w0, L.act_logits.data_ptr() + r0 * V, 1,
+                                                      st), "pass2_cached")
+        self._sample_action(L, t, s0, s1, st)
+
+    def _policy_chunks(self, L, t, hist, lo, hi, noise_rtg=None, noise_act=None):
+        """Full-recompute policy for scenarios [lo, hi) (hist = their group counts per size class), cut into model batches, on
+        the main stream with lane L's buffers."""
         lib, p, st, d = self.lib, _lib.ptr, self._main.cuda_stream, self.dims
         N, Tmax = self.N, self.steps
         Tq = min(t, d.T - 1) + 1
-        for (s0, s1, B) in self._chunks(counts, lo):
-            ns = s1 - s0
-            sl = slice(s0, s1)
-            if B > 0:
-                _lib.check(lib.ctrlsim_ctx_index(s0, s1, N, p(self.n_groups), p(self.grp_focal), p(self.grp_ids),
-                                                 p(self.own_g), p(self.mem_g), p(L.ctx_scn), p(L.ctx_grp),
-                                                 p(self.own_ctx), p(self.own_slot), p(self.mem_ctx), p(self.mem_slot),
-                                                 p(self.ctx_base), st), "ctx_index")
-                _lib.check(lib.ctrlsim_build_context(B, N, d.A, d.T, t, Tq, 0, Tmax + 1, Tmax, self.P_all, d.P, d.NP,
-                                                     p(L.ctx_scn), p(L.ctx_grp), p(self.grp_focal), p(self.grp_ids),
-                                                     p(self.hist_states), p(self.hist_tok), p(self.hist_rtg),
-                                                     p(self.goals), p(self.types), p(self.roads), p(self.rtypes),
-                                                     self._zero4, C.byref(L.ctx.struct), st), "build_context")
+        RC, V = d.R * d.C * 4, d.V * 4
+        self._plan_lane = L
+        for (s0, s1, counts) in self._chunks(hist, lo):
+            plan = self._class_plan(counts, Tq, Tq)
+            self._ctx_index(L, s0, s1, st)
+            self._build_contexts(L, plan, t, Tq, 0, st)
+            for (B, A, c0, r0, w0, cs) in plan:
                 if d.VARIANT:                                # IL / Trajeglish: no RTG tokens, one forward (predict_rtgs False)
-                    _lib.check(lib.ctrlsim_dt_forward_actions(self.model.handle, B, Tq, C.byref(L.ctx.struct), p(L.ws),
-                                                              p(L.act_logits), st), "forward_actions")
+                    _lib.check(lib.ctrlsim_dt_forward_actions(self.model.handle, B, Tq, C.byref(cs), L.ws.data_ptr() + w0,
+                                                              L.act_logits.data_ptr() + r0 * V, st), "forward_actions")
                 else:
-                    _lib.check(lib.ctrlsim_dt_forward_pass1(self.model.handle, B, Tq, C.byref(L.ctx.struct), p(L.ws),
-                                                            p(L.rtg_logits), None, st), "pass1")
-            else:
-                with torch.cuda.stream(self._main):
-                    self.own_ctx[sl].fill_(-1)
-                    self.mem_ctx[sl].fill_(-1)
+                    _lib.check(lib.ctrlsim_dt_forward_pass1_a(self.model.handle, B, Tq, A, C.byref(cs), L.ws.data_ptr() + w0,
+                                                              L.rtg_logits.data_ptr() + r0 * RC, None, st), "pass1")
             if not d.VARIANT:
-                _lib.check(lib.ctrlsim_sample_rtg(p(L.rtg_logits), d.A, d.R, p(self.own_ctx[sl]), p(self.own_slot[sl]),
-                                                  p(self.tilted[sl]), self.tilt,
-                                                  p(self.tilt_scn[sl]) if self.tilt_scn is not None else None,
-                                                  p(noise_rtg[sl]) if noise_rtg is not None else None, self.seed,
-                                                  p(self.scenario_id[sl]), t, p(self.hist_rtg[sl]), ns, N, Tmax, st),
-                           "sample_rtg")
-            if B > 0 and not d.VARIANT:
-                _lib.check(lib.ctrlsim_dt_forward_pass2(self.model.handle, B, Tq, t, N, Tmax, C.byref(L.ctx.struct),
-                                                        p(L.ctx_scn), p(self.hist_rtg), p(L.ws),
-                                                        p(L.act_logits), 0, st), "pass2")
-            _lib.check(lib.ctrlsim_sample_action(p(L.act_logits), d.A, d.V, p(self.mem_ctx[sl]), p(self.mem_slot[sl]),
-                                                 self.temperature, self.top_p,
-                                                 p(noise_act[sl]) if noise_act is not None else None, self.seed,
-                                                 p(self.scenario_id[sl]), t, p(self.hist_tok[sl]), p(self.act_now[sl]),
-                                                 ns, N, Tmax, ZERO_ACTION_TOKEN, st), "sample_action")
+                self._sample_rtg(L, t, s0, s1, st, noise_rtg)
+                for (B, A, c0, r0, w0, cs) in plan:
+                    _lib.check(lib.ctrlsim_dt_forward_pass2_a(self.model.handle, B, Tq, A, t, N, Tmax, C.byref(cs),
+                                                              p(L.ctx_scn[c0:]), p(self.hist_rtg), L.ws.data_ptr() + w0,
+                                                              L.act_logits.data_ptr() + r0 * V, 0, st), "pass2")
+            self._sample_action(L, t, s0, s1, st, noise_act)
 
     # ------------------------------------------------------------------ a lane's rollout as a generator
     def _lane_gen(self, L, lo, hi, steps):
@@ -436,24 +508,24 @@ class RolloutEngine:
             nT = min(T, steps)
             self._enqueue_groups(L, 0, lo, hi)
             yield
-            counts, _ = self._await_groups(L)
-            self.groups_per_step[0, lo:hi] = counts
-            for (s0, s1, B) in self._chunks(counts, lo):
-                cached_ok = B > 0
-                cnt = counts[s0 - lo:s1 - lo]
+            hist, _ = self._await_groups(L)
+            self.groups_per_step[0, lo:hi] = hist.sum(1)
+            for (s0, s1, counts) in self._chunks(hist, lo):
+                cached_ok = sum(counts) > 0
+                h = hist[s0 - lo:s1 - lo]
                 if nT > 1:
                     self._snapshot_groups(L, s0, s1)
                 for t in range(nT):
                     if t > 0:
                         yield
-                        cnt, changed = self._await_groups(L)
-                        self.groups_per_step[t, s0:s1] = cnt
+                        h, changed = self._await_groups(L)
+                        self.groups_per_step[t, s0:s1] = h.sum(1)
                         cached_ok = cached_ok and not changed
                     self._main_waits(L)
                     if cached_ok:
-                        self._chunk_step_cached(L, s0, s1, B, t)
+                        self._chunk_step_cached(L, s0, s1, counts, t)
                     else:
-                        self._policy_chunks(L, t, cnt, s0, s1)
+                        self._policy_chunks(L, t, h, s0, s1)
                     self._enqueue_sim(L, t, s0, s1)
                     if t + 1 < nT:
                         self._enqueue_groups(L, t + 1, s0, s1, compare=True)
@@ -461,10 +533,10 @@ class RolloutEngine:
         for t in range(t0, steps):
             self._enqueue_groups(L, t, lo, hi)
             yield
-            counts, _ = self._await_groups(L)
-            self.groups_per_step[t, lo:hi] = counts
+            hist, _ = self._await_groups(L)
+            self.groups_per_step[t, lo:hi] = hist.sum(1)
             self._main_waits(L)
-            self._policy_chunks(L, t, counts, lo, hi)
+            self._policy_chunks(L, t, hist, lo, hi)
             self._enqueue_sim(L, t, lo, hi)
 
     def run(self, steps=None, noise_fn=None, s0=0, s1=None):
@@ -510,12 +582,15 @@ class RolloutEngine:
     def policy_step(self, t, noise_rtg=None, noise_act=None):
         """AutoregressivePolicy.predict for every scenario: writes hist_rtg[..., t, :], hist_tok[..., t], act_now."""
         self._main = torch.cuda.current_stream(self.device)
-        self._group_build(t)
-        self.n_groups_host.copy_(self.n_groups, non_blocking=True)
-        self._main.synchronize()
-        counts = self.n_groups_host.numpy()
-        self.groups_per_step[t] = counts
-        self._policy_chunks(self.lanes[0], t, counts, 0, self.S, noise_rtg, noise_act)
+        L = self.lanes[0]
+        side, L.side = L.side, None                   # everything on the caller's stream
+        try:
+            self._enqueue_groups(L, t, 0, self.S)
+            hist, _ = self._await_groups(L)
+        finally:
+            L.side = side
+        self.groups_per_step[t] = hist.sum(1)
+        self._policy_chunks(L, t, hist, 0, self.S, noise_rtg, noise_act)
 
     def results(self):
         torch.cuda.synchronize(self.device)

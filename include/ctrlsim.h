@@ -91,6 +91,21 @@ int ctrlsim_group_build(int S, int N, int A, int T, int t, int Tmax1, double dis
  * phase; the caller zeroes flag and copies it to the host together with n_groups (one asynchronous copy per step). */
 int ctrlsim_groups_changed(int S, int N, const int* n_groups, const int* grp_focal, const uint64_t* grp_ids, const int* ref_n,
                            const int* ref_focal, const uint64_t* ref_ids, int* flag, hipStream_t stream);
+/* Compact contexts.  Token rows of agent slots that exist nowhere in the window are identical (modules/encoder.py:127-133 multiplies
+ * every embedding by the existence flag before embed_ln; the decoder puts no key padding on its targets) and remain identical
+ * through all layers, so a context with n vehicles may be evaluated with any slot count Actx >= n + 1: Actx - 1 regular slots and
+ * ONE representative slot standing for the dims.A - (Actx - 1) padded slots of the reference layout (its keys carry that
+ * multiplicity in the attention: ctrlsim_attention_compact).  Exact in real arithmetic.  `sizes` = the ascending slot counts a
+ * caller uses (nb <= 8, last = dims.A; a context takes the first size >= n + 1, or dims.A).
+ * ctrlsim_group_size_hist: hist[s, k] = focal groups of scenario s in size class k (with n_groups: what the host needs to cut a
+ * step into model batches).  ctrlsim_ctx_index_classes: ctrlsim_ctx_index with the contexts SORTED by size class (class k =
+ * contexts [sum_{j<k} count_j, ...)); ctx_row0[c] = first logits row of context c when class k emits (sizes[k] - 1, or dims.A
+ * for the last class) rows per context; ctx_of_group: [S, N] scratch. */
+int ctrlsim_group_size_hist(int S, int N, const int* n_groups, const uint64_t* grp_ids, int nb, const int* sizes /*host*/,
+                            int* hist /*[S,nb]*/, hipStream_t stream);
+int ctrlsim_ctx_index_classes(int s0, int s1, int N, int A, const int* n_groups, const uint64_t* grp_ids, const int* own_g,
+                              const int* mem_g, int nb, const int* sizes /*host*/, int* ctx_scn, int* ctx_grp, int* ctx_row0,
+                              int* ctx_of_group, int* own_ctx, int* own_slot, int* mem_ctx, int* mem_slot, hipStream_t stream);
 int ctrlsim_ctx_index(int s0, int s1, int N, const int* n_groups, const int* grp_focal, const uint64_t* grp_ids,
                       const int* own_g, const int* mem_g, int* ctx_scn, int* ctx_grp, int* own_ctx, int* own_slot,
                       int* mem_ctx, int* mem_slot, int* ctx_base, hipStream_t stream);
@@ -112,6 +127,17 @@ int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_weights, int
                          const int64_t* offsets, ctrlsim_model** out);
 void ctrlsim_model_destroy(ctrlsim_model* m);
 int64_t ctrlsim_forward_workspace_bytes(const ctrlsim_dims* dims, int B, int Tq);
+/* The *_a forms take a uniform batch of COMPACT contexts of Actx slots (context tensors [B,Tq,Actx,.]; Actx == dims.A: the plain
+ * layout, what the forms without _a call): Actx - 1 regular slots + the representative (see ctrlsim_group_size_hist); logits
+ * come back for the regular slots only, [B*(Actx-1), .] rows (Actx == dims.A: [B*A, .]). */
+int64_t ctrlsim_forward_workspace_bytes_a(const ctrlsim_dims* dims, int B, int Tq, int Actx);
+int ctrlsim_dt_forward_pass1_a(const ctrlsim_model* m, int B, int Tq, int Actx, const ctrlsim_ctx* ctx, void* workspace,
+                               float* rtg_logits, float* dbg_seg_emb, hipStream_t stream);
+int ctrlsim_dt_forward_pass2_a(const ctrlsim_model* m, int B, int Tq, int Actx, int t, int N, int Tmax, const ctrlsim_ctx* ctx,
+                               const int* ctx_scn, const int* hist_rtg, void* workspace, float* act_logits, int cached,
+                               hipStream_t stream);
+int ctrlsim_dt_forward_pass1_cached_a(const ctrlsim_model* m, int B, int t, int Actx, const ctrlsim_ctx* ctx, void* workspace,
+                                      float* rtg_logits, hipStream_t stream);
 /* pass 1: rtg_logits [B,A,R*C] of the current-timestep state tokens; caches per-layer K/V in `workspace`. */
 int ctrlsim_dt_forward_pass1(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* ctx, void* workspace,
                              float* rtg_logits, float* dbg_seg_emb /*nullable [B,P,D]*/, hipStream_t stream);
@@ -143,6 +169,14 @@ int ctrlsim_sample_rtg(const float* rtg_logits, int A, int R, const int* own_ctx
                        const uint8_t* tilted, const double* tilt3, const double* tilt_scn /*[S,3] or NULL*/,
                        const float* noise /*[S*N,3,R] or NULL*/, uint64_t seed, const int64_t* scenario_id /*[S]*/, int t,
                        int* hist_rtg, int S, int N, int Tmax, hipStream_t stream);
+/* The same with logits rows addressed through ctx_row0 (context c, slot s -> row ctx_row0[c] + s): batches of compact contexts
+ * of different slot counts (ctrlsim_ctx_index_classes). */
+int ctrlsim_sample_rtg_rows(const float* rtg_logits, const int* ctx_row0, int R, const int* own_ctx, const int* own_slot,
+                            const uint8_t* tilted, const double* tilt3, const double* tilt_scn, const float* noise, uint64_t seed,
+                            const int64_t* scenario_id, int t, int* hist_rtg, int S, int N, int Tmax, hipStream_t stream);
+int ctrlsim_sample_action_rows(const float* act_logits, const int* ctx_row0, int V, const int* mem_ctx, const int* mem_slot,
+                               float temperature, double top_p, const float* noise, uint64_t seed, const int64_t* scenario_id,
+                               int t, int* hist_tok, int* act_now, int S, int N, int Tmax, int zero_token, hipStream_t stream);
 int ctrlsim_sample_action(const float* act_logits, int A, int V, const int* mem_ctx, const int* mem_slot,
                           float temperature, double top_p /*<=0: off*/, const float* noise /*[S*N,V] or NULL*/,
                           uint64_t seed, const int64_t* scenario_id, int t, int* hist_tok, int* act_now /*[S,N]*/,
@@ -159,6 +193,13 @@ int ctrlsim_gemm_nt(const float* A, int lda, const float* W, int ldw, const floa
 int ctrlsim_gemm_nt_bf16x6(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias, const float* R,
                            int ldr, float* C, int ldc, int M, int N, int K, int relu, const float* ln_gamma,
                            const float* ln_beta, hipStream_t stream);
+/* The same Linear whose last 512 output columns [kv_col0, kv_col0 + 512) are the keys / values of 8 heads x 32 of contexts of
+ * kv_L rows each: those columns leave the epilogue directly as the split K / V tile images of ctrlsim_kv_split (kv_nkt 64-key
+ * tiles per context and head; the tail of the last tile must be zeroed by the caller), columns [0, kv_col0) as fp32 rows of C.
+ * The in_proj of nn.MultiheadAttention (modules/decoder.py:16-20, encoder.py:42-46) fused with the attention kernel's operand
+ * preparation. */
+int ctrlsim_gemm_nt_kv(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias, float* C, int ldc,
+                       int M, int N, int K, void* kv_img, int kv_L, int kv_nkt, int kv_col0, hipStream_t stream);
 /* Post-LN feed-forward block of nn.TransformerEncoderLayer / DecoderLayer as one kernel:
  * Y = LayerNorm(X + W2 relu(W1 X + b1) + b2) * gamma + beta, rows of 256, F hidden units (multiple of 32); W1p / W2p are the
  * operand images of ctrlsim_amd/pack.py:ffn_planes; Y may alias X.  The hidden activation never touches memory. */
@@ -180,6 +221,16 @@ int ctrlsim_kv_split(const float* K, const float* V, int ldkv, int64_t kv_batch_
 int ctrlsim_attention_presplit(int mode, const float* Q, int ldq, int64_t q_batch_stride, const void* img, int nkt, float* O,
                                int ldo, int64_t o_batch_stride, const int* q_pos, const uint8_t* key_pad, int B, int Lq,
                                int Lk, int A, hipStream_t stream);
+
+/* Causal (CtRL-Sim mask) attention over the K/V images of COMPACT contexts: Lk regular keys (slots < A) in the tiles
+ * [0, ceil(Lk/64)), rep_keys representative keys (3 per window step, multiplicity rep_mult) in the tiles from ceil(rep_pos0/64)
+ * on; rep_pos0 >= Lk = the regular length of the full window (K/V-cache layout).  Query positions (row index or q_pos) >=
+ * rep_pos0 are the representative's own tokens.  A representative key (t, k) is visible to a query of step tq iff t < tq or
+ * (t == tq and k == 0), rep_mult-fold (log2(rep_mult) is added to its score); the representative's own queries also see their
+ * tokens 1..kq of step tq, once.  rep_keys = 0: ctrlsim_attention_presplit mode 1. */
+int ctrlsim_attention_compact(const float* Q, int ldq, int64_t q_batch_stride, const void* img, int nkt, float* O, int ldo,
+                              int64_t o_batch_stride, const int* q_pos, int B, int Lq, int Lk, int A, int rep_keys, int rep_mult,
+                              int rep_pos0, hipStream_t stream);
 
 /* ---- measurement hooks (bench.py): HIP-event timing of every launch of ctrlsim_prof_classes() kernel classes on its own
  * launch stream — 0 GEMM (all Linear layers incl. the fused feed-forward block), 1 attention, 2 build_context, 3 assemble_tokens,

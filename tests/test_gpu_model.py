@@ -98,3 +98,50 @@ def test_forward_f32_mfma_kernels_selectable():
         lib.ctrlsim_set_option(0, 1); lib.ctrlsim_set_option(1, 1)
     for x, y in zip(a, b):
         np.testing.assert_allclose(x, y, atol=TOL, rtol=0)
+
+
+def _run_compact(model, d, inp, Tq, new_bins, Actx):
+    """The same two passes on COMPACT contexts of Actx slots: the leading Actx slots of the reference layout, the last of them
+    a padded slot that stands for all d.A - (Actx - 1) padded ones.  -> logits of the Actx - 1 regular slots."""
+    B = inp["agent_states"].shape[0]
+    sub = {k: (v[:, :Actx] if k in ("agent_states", "agent_types", "goals", "actions", "rtgs", "timesteps", "moving_agent_mask")
+               else v) for k, v in inp.items()}
+    cb = ctx_from_reference_layout(d, sub, Tq, DEV)
+    Ar = Actx - 1 if Actx < d.A else d.A
+    gid = torch.arange(Actx, dtype=torch.int32, device=DEV).expand(B, Actx).contiguous()
+    cb.slot_gid.view(-1)[:B * Actx] = gid.reshape(-1)
+    ws = torch.empty(model.workspace_bytes(B, Tq, Actx), dtype=torch.uint8, device=DEV)
+    rtg = torch.empty(B, Ar, d.R * d.C, device=DEV)
+    act = torch.empty(B, Ar, d.V, device=DEV)
+    lib, st = _lib.lib(), _lib.stream_ptr()
+    _lib.check(lib.ctrlsim_dt_forward_pass1_a(model.handle, B, Tq, Actx, C.byref(cb.struct), ws.data_ptr(), rtg.data_ptr(),
+                                              None, st), "pass1_a")
+    Tmax, t = 90, 40
+    hist_rtg = torch.zeros(B, d.A, Tmax, 3, dtype=torch.int32, device=DEV)
+    hist_rtg[:, :, t] = torch.from_numpy(new_bins.astype(np.int32)).to(DEV)
+    ctx_scn = torch.arange(B, dtype=torch.int32, device=DEV)
+    _lib.check(lib.ctrlsim_dt_forward_pass2_a(model.handle, B, Tq, Actx, t, d.A, Tmax, C.byref(cb.struct), ctx_scn.data_ptr(),
+                                              hist_rtg.data_ptr(), ws.data_ptr(), act.data_ptr(), 0, st), "pass2_a")
+    torch.cuda.synchronize()
+    return rtg.cpu().numpy(), act.cpu().numpy()
+
+
+@pytest.mark.parametrize("kind,n_agents,Actx,Tqs", [("loop", 3, 4, (8, 3, 1)), ("loop", 2, 4, (8,)), ("full", 7, 8, (32, 5)),
+                                                     ("full", 10, 12, (32,)), ("full", 3, 4, (32, 1)), ("full", 19, 20, (32,))])
+def test_compact_contexts_equal_plain_contexts(kind, n_agents, Actx, Tqs):
+    """Padded agent slots are evaluated once, as one representative slot whose keys carry the multiplicity of the padded slots
+    it stands for (forward.hip: Shape; attention_bf16x6.hip).  Logits of the live slots must equal the plain 24-slot (6-slot)
+    evaluation of the same context — which the other tests pin to the reference — to fp32 round-off."""
+    cfg = cfg_of(kind)
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    model = HipModel(cfg, w, DEV)
+    for seed, Tq in zip((21, 22, 23), Tqs):
+        inp = synth_inputs.random_context(d, seed, B=2, t_fill=Tq, n_agents=n_agents, n_polys=d.P - 1)
+        new_bins = np.random.RandomState(seed).randint(0, d.R, (2, d.A, 3))
+        rtg, act, _ = _run_both_passes(model, d, inp, Tq, new_bins)
+        rtg_c, act_c = _run_compact(model, d, inp, Tq, new_bins, Actx)
+        Ar = Actx - 1
+        np.testing.assert_allclose(rtg_c[:, :n_agents], rtg[:, :n_agents], atol=2e-5, rtol=0)
+        np.testing.assert_allclose(act_c[:, :n_agents], act[:, :n_agents], atol=2e-5, rtol=0)
+        assert np.isfinite(rtg_c).all() and rtg_c.shape[1] == Ar
