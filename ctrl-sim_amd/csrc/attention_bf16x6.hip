@@ -50,12 +50,32 @@ __device__ unsigned long long g_att_t[8];
 // PRE = true: K / V arrive already split, as per-(context, head, 64-key tile) images of exactly the LDS stage layout
 // (kv_split_kernel below; K = the image base, V / ldkv unused, kv_batch_stride = tiles per context): staging is six
 // 16-byte LDS-DMA pieces per thread and tile — no registers, no VALU, no ds_write.
+// One launch serves up to 8 CLASSES of contexts (uniform shape inside a class; the engine sorts the compact contexts of a model
+// batch by slot count): the 1-D grid is the concatenation of the classes' (query block, head, context) grids and a workgroup
+// reads its class's shape from the table.  Offsets are in elements of the common Q / O / image / key_pad buffers.
+struct AttnClass {
+  long q_off, o_off, img_off, pad_off;     // class's first Q row / O row / image tile / key_pad byte
+  long q_bs, o_bs, kv_bs;                  // batch strides (kv_bs: tiles per (context, head) with images, else fp32 row stride)
+  const int* q_pos;
+  int Lq, Lk, A, rep_keys, rep_pos0, qblocks, wg0;
+  float log2m;
+};
+struct AttnBatch { int n; AttnClass c[8]; };
+
 template <int MODE, bool PRE>
 __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
-    const float* __restrict__ Q, int ldq, long q_batch_stride, const float* __restrict__ K,
-    const float* __restrict__ V, int ldkv, long kv_batch_stride, float* __restrict__ O, int ldo, long o_batch_stride,
-    const int* __restrict__ q_pos, const unsigned char* __restrict__ key_pad, int Lq, int Lk, int A, float scale_log2e,
-    int variant, int rep_keys, float log2m, int rep_pos0) {
+    const float* __restrict__ Qb_, int ldq, const float* __restrict__ K, const float* __restrict__ V, int ldkv,
+    float* __restrict__ Ob_, int ldo, const unsigned char* __restrict__ key_pad_, float scale_log2e, int variant, AttnBatch ab) {
+  int ci = 0;
+  while (ci + 1 < ab.n && (int)blockIdx.x >= ab.c[ci + 1].wg0) ++ci;
+  const AttnClass& cd = ab.c[ci];
+  const int Lq = cd.Lq, Lk = cd.Lk, A = cd.A, rep_keys = cd.rep_keys, rep_pos0 = cd.rep_pos0, nqb = cd.qblocks;
+  const float log2m = cd.log2m;
+  const long q_batch_stride = cd.q_bs, o_batch_stride = cd.o_bs, kv_batch_stride = cd.kv_bs;
+  const int* __restrict__ q_pos = cd.q_pos;
+  const float* __restrict__ Q = Qb_ + cd.q_off;
+  float* __restrict__ O = Ob_ + cd.o_off;
+  const unsigned char* __restrict__ key_pad = key_pad_ ? key_pad_ + cd.pad_off : nullptr;
   // rep_keys > 0 (causal, PRE): COMPACT contexts.  Token rows of agent slots that never exist in the window are all equal
   // (every embedding is multiplied by the existence flag before embed_ln, modules/encoder.py:127-133, and the decoder has
   // no key padding on its targets), and by induction over the layers so are their hidden states at equal (timestep, token
@@ -78,10 +98,10 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
   // query blocks of one (context, head) — which re-read the same K/V tiles — are given to ONE XCD: head = linear id % 8.
   // (With the natural x-fastest order the 18 query blocks of a head were spread over all 8 L2s: measured 2.8x the
   // algorithmic HBM-side fetch traffic.)  Causal: longest query blocks first.
-  const int lin = blockIdx.x + gridDim.x * (blockIdx.y + NHEAD * blockIdx.z);
+  const int lin = (int)blockIdx.x - cd.wg0;
   const int h = lin & (NHEAD - 1), j = lin >> 3;
-  const int qx = j % gridDim.x, b = j / gridDim.x;
-  const int qblk = (MODE == MODE6_CAUSAL) ? (gridDim.x - 1 - qx) : qx;
+  const int qx = j % nqb, b = j / nqb;
+  const int qblk = (MODE == MODE6_CAUSAL) ? (nqb - 1 - qx) : qx;
   const int qb = qblk * 128;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int A3 = 3 * A;
@@ -153,7 +173,7 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
   // staging registers: K rows (idx -> row, 4 consecutive d), V row PAIRS (thread -> keys 2rp, 2rp+1, 4 consecutive d)
   f32x4 pk[2], pv[2];
   float ppad = 0.f;
-  const op_t* img = PRE ? reinterpret_cast<const op_t*>(K) + ((size_t)b * NHEAD + h) * (size_t)kv_batch_stride * KV_IMG : nullptr;
+  const op_t* img = PRE ? reinterpret_cast<const op_t*>(K) + (cd.img_off + ((size_t)b * NHEAD + h) * (size_t)kv_batch_stride) * KV_IMG : nullptr;
   auto gload = [&](int k0, int buf) {
     if (PRE) {
       const op_t* src = img + (size_t)(k0 / KT6) * KV_IMG + tid * 8;
@@ -237,11 +257,38 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
   unsigned long long tlast = __builtin_amdgcn_s_memtime();
 #endif
 
-  // ---- one 32-key sub-tile: scores, mask, online softmax, P.V.  MASK 0 = none (all 32 keys visible), 1 = key padding
-  // (padbias), 2 = visibility word vis_all (bit i <-> key i of the sub-tile), 3 = vis_all + multiplicity bias on bias_all
-  auto sub_tile = [&](const op_t* Ks, const op_t* Vs, const float* padbias, int sub, auto MASK_, unsigned vis_all,
-                      unsigned bias_all) {
-    constexpr int MASK = decltype(MASK_)::value;
+  int cur = 0;
+  for (int it = 0; it < n_it; ++it, cur ^= 1) {
+    const bool more = it + 1 < n_it;
+    if (more) gload(tile_k0(it + 1), cur ^ 1);
+    const bool rep_tile = it >= n_reg;               // wave-uniform: a tile of representative keys (compact contexts)
+    const int k0 = it * KT6;
+    TSTAMP(0) TCOUNT(7)
+    const op_t* Ks = arena + cur * BUF;
+    const op_t* Vs = Ks + NPL * K_PLANE;
+    const float* padbias = reinterpret_cast<const float*>(Vs + NPL * V_PLANE);
+
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int ks0 = k0 + sub * 32;
+      int t_lo = 0, t_hi = 0, ks_t0 = 0;
+      bool need_mask = true;
+      const int j0 = (it - n_reg) * KT6 + sub * 32;   // first representative key of this sub-tile (rep_tile)
+      if (!rep_tile) {
+        // timestep of the first / last key of this sub-tile (tracked incrementally: no divisions in the loop)
+        t_lo = tk_t;
+        t_hi = min(tk_t + (tk_r + 31 >= A3 ? (tk_r + 31 - A3 >= A3 ? (tk_r + 31) / A3 : 1) : 0), t_last);
+        ks_t0 = ks0 - tk_r;                           // position of the first key of timestep t_lo
+        tk_r += 32;
+        while (tk_r >= A3) { tk_r -= A3; ++tk_t; }
+        if (ks0 >= k_end) continue;
+        if (MODE == MODE6_CAUSAL) {
+          if (t_lo > tq_max_w) continue;
+          need_mask = !(t_hi < tq_min_w && ks0 + 31 < Lk) || variant != 0;   // IL / Trajeglish: dead key types everywhere
+        }
+      } else if (j0 >= rep_need || j0 > 3 * tq_max_w + 2) {
+        continue;
+      }
       // ---- S^T = K . Q^T : one accumulator chain, k-steps d 0-15 and d 16-31, six partial products each
       // the accumulator starts at -m_base (the running maximum, 0 before the first visible key): the MFMA chain then
       // delivers S - m directly and the per-element subtraction is needed only in the (rare) sub-tiles that raise the maximum
@@ -272,18 +319,55 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
 #endif
       }
       float sc[16];
-      if (MASK == 1) {
+      if (MODE == MODE6_KEYPAD) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = s0[r] + padbias[sub * 32 + mfma_row(r, half)];
-      } else if (MASK >= 2) {
+      } else if (need_mask) {
+        // visibility of the 32 keys of this sub-tile for this lane's query as a bit mask (bit i <-> key ks0 + i):
+        //   keys of earlier timesteps: all; of the query's timestep: every state token (offset % 3 == 0) and the query's
+        //   own agent's tokens up to the query itself; later timesteps and keys >= Lk: none.
+        asm volatile("" ::: "memory");   // keep this a real (scalar) branch: hipcc otherwise speculates the mask math for every sub-tile
+        auto ones = [](int n) -> unsigned { return n >= 32 ? 0xFFFFFFFFu : (n <= 0 ? 0u : ((1u << n) - 1u)); };
+        unsigned vis_all, bias_all = 0u;
+        if (rep_tile) {
+          // representative keys j = 3 t + k: visible while j <= 3 tq (earlier steps, and the state token of the query's step),
+          // m-fold; the representative's own queries also see their tokens 1..kq of step tq, once
+          const int bias_end = 3 * tq + 1 - j0;
+          bias_all = ones(min(bias_end, rep_keys - j0));
+          vis_all = ones(min(bias_end + (rep_q ? kq : 0), rep_keys - j0));
+        } else {
+        const int same0 = tq * A3 - ks0;                                   // first key of the query's timestep
+        const unsigned before = ones(same0);
+        const unsigned same = ones(min(same0 + A3, Lk - ks0)) & ~before;
+        int off3 = (ks_t0 - ks0) % 3;                                      // ks_t0 <= ks0: first state token at or after ks0
+        off3 = off3 < 0 ? off3 + 3 : off3;
+        const unsigned every3 = (unsigned)(0x249249249249ull << off3);
+        // variant 3 (Decision Transformer, token order rtg, state, action — kept in the slots state, rtg, action): a state
+        // token also sees its own agent's rtg token, one position AFTER it
+        const unsigned own = rep_q ? 0u : (ones(pos - ks0 + 1 + ((variant == 3 && kq == 0) ? 1 : 0)) & ~ones(pos - kq - ks0));
+        vis_all = before | ((every3 | own) & same);
+        if (variant) {
+          // the 3-slot token layout is kept for the baselines of cfgs/model/{il,trajeglish}.yaml; the token types they do not
+          // have are dead as keys.  IL (state, action): rtg keys invisible.  Trajeglish (action only): action keys of earlier
+          // steps and of the WHOLE current step (get_causal_mask with one token type: every same-step token is "the state").
+          int o2 = off3 + 2;
+          o2 = o2 >= 3 ? o2 - 3 : o2;
+          const unsigned actions = (unsigned)(0x249249249249ull << o2);
+          if (variant == 1) vis_all &= every3 | actions;
+          else if (variant == 2) vis_all = (before | same) & actions;
+        }
+        }
         const unsigned vis = vis_all >> (4 * half);
-        const unsigned bia = bias_all >> (4 * half);
+        if (rep_tile) {
+          const unsigned bia = bias_all >> (4 * half);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const unsigned bit = 1u << ((r & 3) + 8 * (r >> 2));
-          float x = s0[r];
-          if (MASK == 3) x += (bia & bit) ? log2m : 0.f;
-          sc[r] = (vis & bit) ? x : NEG_INF;
+          for (int r = 0; r < 16; ++r) {
+            const unsigned bit = 1u << ((r & 3) + 8 * (r >> 2));
+            sc[r] = (vis & bit) ? s0[r] + ((bia & bit) ? log2m : 0.f) : NEG_INF;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc[r] = (vis & (1u << ((r & 3) + 8 * (r >> 2)))) ? s0[r] : NEG_INF;
         }
       } else {
 #pragma unroll
@@ -381,84 +465,6 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
 #pragma unroll
         for (int p = 0; p < NPL; ++p) { asm volatile("" ::"v"(v0f[p]), "v"(v1f[p]), "v"(pf[0][p]), "v"(pf[1][p])); }
 #endif
-      }
-  };
-  typedef std::integral_constant<int, 0> M_NONE;
-  typedef std::integral_constant<int, 1> M_PAD;
-  typedef std::integral_constant<int, 2> M_VIS;
-  typedef std::integral_constant<int, 3> M_BIAS;
-
-  int cur = 0;
-  for (int it = 0; it < n_it; ++it, cur ^= 1) {
-    const bool more = it + 1 < n_it;
-    if (more) gload(tile_k0(it + 1), cur ^ 1);
-    TSTAMP(0) TCOUNT(7)
-    const op_t* Ks = arena + cur * BUF;
-    const op_t* Vs = Ks + NPL * K_PLANE;
-    const float* padbias = reinterpret_cast<const float*>(Vs + NPL * V_PLANE);
-
-    if (it < n_reg) {
-      const int k0 = it * KT6;
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
-        const int ks0 = k0 + sub * 32;
-        // timestep of the first / last key of this sub-tile (tracked incrementally: no divisions in the loop)
-        const int t_lo = tk_t, t_hi = min(tk_t + (tk_r + 31 >= A3 ? (tk_r + 31 - A3 >= A3 ? (tk_r + 31) / A3 : 1) : 0), t_last);
-        const int ks_t0 = ks0 - tk_r;                 // position of the first key of timestep t_lo
-        tk_r += 32;
-        while (tk_r >= A3) { tk_r -= A3; ++tk_t; }
-        if (ks0 >= k_end) continue;
-        if (MODE == MODE6_KEYPAD) {
-          sub_tile(Ks, Vs, padbias, sub, M_PAD{}, 0u, 0u);
-          continue;
-        }
-        if (t_lo > tq_max_w) continue;
-        const bool need_mask = !(t_hi < tq_min_w && ks0 + 31 < Lk) || variant != 0;   // IL / Trajeglish: dead key types everywhere
-        if (!need_mask) {
-          sub_tile(Ks, Vs, padbias, sub, M_NONE{}, 0u, 0u);
-          continue;
-        }
-        // visibility of the 32 keys of this sub-tile for this lane's query as a bit mask (bit i <-> key ks0 + i):
-        //   keys of earlier timesteps: all; of the query's timestep: every state token (offset % 3 == 0) and the query's
-        //   own agent's tokens up to the query itself; later timesteps and keys >= Lk: none.
-        asm volatile("" ::: "memory");   // keep this a real (scalar) branch: hipcc otherwise speculates the mask math for every sub-tile
-        auto ones = [](int n) -> unsigned { return n >= 32 ? 0xFFFFFFFFu : (n <= 0 ? 0u : ((1u << n) - 1u)); };
-        const int same0 = tq * A3 - ks0;                                   // first key of the query's timestep
-        const unsigned before = ones(same0);
-        const unsigned same = ones(min(same0 + A3, Lk - ks0)) & ~before;
-        int off3 = (ks_t0 - ks0) % 3;                                      // ks_t0 <= ks0: first state token at or after ks0
-        off3 = off3 < 0 ? off3 + 3 : off3;
-        const unsigned every3 = (unsigned)(0x249249249249ull << off3);
-        // variant 3 (Decision Transformer, token order rtg, state, action — kept in the slots state, rtg, action): a state
-        // token also sees its own agent's rtg token, one position AFTER it
-        const unsigned own = rep_q ? 0u
-                                   : (ones(pos - ks0 + 1 + ((variant == 3 && kq == 0) ? 1 : 0)) & ~ones(pos - kq - ks0));
-        unsigned vis_all = before | ((every3 | own) & same);
-        if (variant) {
-          // the 3-slot token layout is kept for the baselines of cfgs/model/{il,trajeglish}.yaml; the token types they do not
-          // have are dead as keys.  IL (state, action): rtg keys invisible.  Trajeglish (action only): action keys of earlier
-          // steps and of the WHOLE current step (get_causal_mask with one token type: every same-step token is "the state").
-          int o2 = off3 + 2;
-          o2 = o2 >= 3 ? o2 - 3 : o2;
-          const unsigned actions = (unsigned)(0x249249249249ull << o2);
-          if (variant == 1) vis_all &= every3 | actions;
-          else if (variant == 2) vis_all = (before | same) & actions;
-        }
-        sub_tile(Ks, Vs, padbias, sub, M_VIS{}, vis_all, 0u);
-      }
-    } else if (MODE == MODE6_CAUSAL) {
-      // representative keys j = 3 t + k of this tile: visible while j <= 3 tq (earlier steps, and the state token of the
-      // query's step), m-fold; the representative's own queries also see their tokens 1..kq of step tq, once
-      const int r0 = (it - n_reg) * KT6;
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
-        const int j0 = r0 + sub * 32;
-        if (j0 >= rep_need || j0 > 3 * tq_max_w + 2) continue;
-        auto ones = [](int n) -> unsigned { return n >= 32 ? 0xFFFFFFFFu : (n <= 0 ? 0u : ((1u << n) - 1u)); };
-        const int bias_end = 3 * tq + 1 - j0;
-        const unsigned bias_all = ones(min(bias_end, rep_keys - j0));
-        const unsigned vis_all = ones(min(bias_end + (rep_q ? kq : 0), rep_keys - j0));
-        sub_tile(Ks, Vs, padbias, sub, M_BIAS{}, vis_all, bias_all);
       }
     }
     if (more) sstore(cur ^ 1);
@@ -630,6 +636,13 @@ static double attn_pairs(int mode, const int* q_pos, int Lq, int Lk, int A, int 
   return (double)Lq * (double)(Lk + rep_keys);
 }
 
+// Host description of one class of a multi-class launch (launch_attention_classes)
+struct AttnClassHost {
+  int B, Lq, Lk, A, rep_keys, rep_mult, rep_pos0, nkt;
+  long q_row0, q_bs, o_row0, o_bs, img_tile0, pad_off;     // first Q / O row of the class (rows of ldq / ldo floats), first tile
+  const int* q_pos;
+};
+
 int launch_attention_bf16x6(int mode, const float* Q, int ldq, long q_batch_stride, const float* K, const float* V,
                             int ldkv, long kv_batch_stride, float* O, int ldo, long o_batch_stride, const int* q_pos,
                             const unsigned char* key_pad, int B, int Lq, int Lk, int A, hipStream_t st) {
@@ -638,50 +651,76 @@ int launch_attention_bf16x6(int mode, const float* Q, int ldq, long q_batch_stri
   if (mode < 0 || mode > 4 || (mode == MODE6_KEYPAD && !key_pad)) return CTRLSIM_EINVAL;
   const int variant = mode >= MODE6_CAUSAL ? mode - MODE6_CAUSAL : 0;   // mode 1 CtRL-Sim mask, 2 IL, 3 Trajeglish, 4 DT
   mode = mode >= MODE6_CAUSAL ? MODE6_CAUSAL : MODE6_KEYPAD;
-  dim3 g((Lq + 127) / 128, NHEAD, B), blk(256);
+  AttnBatch ab;
+  ab.n = 1;
+  ab.c[0] = AttnClass{0, 0, 0, 0, q_batch_stride, o_batch_stride, kv_batch_stride, q_pos, Lq, Lk, A, 0, Lk, (Lq + 127) / 128, 0, 0.f};
+  dim3 g(ab.c[0].qblocks * NHEAD * B), blk(256);
   const float scale = 0.17677669529663687f * 1.4426950408889634f;  // log2(e)/sqrt(32)
   prof_before(PROF_ATTN, st);
   if (mode == MODE6_CAUSAL) {
-    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, false>), g, blk, 0, st, Q, ldq, q_batch_stride, K, V, ldkv,
-                       kv_batch_stride, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale, variant, 0, 0.f, 0);
+    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, false>), g, blk, 0, st, Q, ldq, K, V, ldkv, O, ldo, key_pad, scale,
+                       variant, ab);
   } else {
-    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, false>), g, blk, 0, st, Q, ldq, q_batch_stride, K, V, ldkv,
-                       kv_batch_stride, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale, 0, 0, 0.f, 0);
+    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, false>), g, blk, 0, st, Q, ldq, K, V, ldkv, O, ldo, key_pad, scale, 0,
+                       ab);
   }
   prof_after(PROF_ATTN, attn_pairs(mode, q_pos, Lq, Lk, A) * 128.0 * NHEAD * B, st,
              (double)B * (8.0 * DM * Lq + 8.0 * DM * Lk));
   return ctrlsim_launch_status();
 }
 
-// K / V from split images (launch_kv_split*): img holds nkt tiles per (context, head).
-// rep_keys > 0 (causal mask of the CtRL-Sim model only): compact contexts — Lk regular keys in tiles [0, ceil(Lk / 64)), and
-// rep_keys representative keys of multiplicity rep_mult in the tiles from ceil(rep_pos0 / 64) on (see the kernel header);
-// rep_pos0 >= Lk is the regular length of the full window (the K/V cache layout); query positions (row index, or q_pos)
-// >= rep_pos0 address the representative's own tokens.
+// K / V from split images (launch_kv_split*), n classes of contexts in one launch (n <= 8).  Per class: nkt tiles per (context,
+// head) from tile img_tile0 of `img` on.  rep_keys > 0 (causal mask of the CtRL-Sim model only): compact contexts — Lk regular
+// keys in tiles [0, ceil(Lk / 64)), and rep_keys representative keys of multiplicity rep_mult in the tiles from
+// ceil(rep_pos0 / 64) on (see the kernel header); rep_pos0 >= Lk is the regular length of the full window (the K/V cache
+// layout); query positions (row index, or q_pos) >= rep_pos0 address the representative's own tokens.
+int launch_attention_classes(int mode, const float* Q, int ldq, const void* img, float* O, int ldo, const unsigned char* key_pad,
+                             int n, const AttnClassHost* cls, hipStream_t st) {
+  if (n < 1 || n > 8 || !cls || (ldq & 3) || !img) return CTRLSIM_EINVAL;
+  if (mode < 0 || mode > 4 || (mode == MODE6_KEYPAD && !key_pad)) return CTRLSIM_EINVAL;
+  const int variant = mode >= MODE6_CAUSAL ? mode - MODE6_CAUSAL : 0;
+  mode = mode >= MODE6_CAUSAL ? MODE6_CAUSAL : MODE6_KEYPAD;
+  AttnBatch ab;
+  ab.n = 0;
+  int wg = 0;
+  double flops = 0.0, bytes = 0.0;
+  for (int k = 0; k < n; ++k) {
+    AttnClassHost c = cls[k];
+    if (c.B <= 0 || c.Lq <= 0) continue;
+    if (c.rep_keys == 0) c.rep_pos0 = c.Lk;
+    if (c.Lk <= 0 || c.rep_keys < 0 || c.rep_pos0 < c.Lk ||
+        c.nkt < (c.rep_pos0 + KT6 - 1) / KT6 + (c.rep_keys + KT6 - 1) / KT6)
+      return CTRLSIM_EINVAL;
+    if (c.rep_keys > 0 && (mode != MODE6_CAUSAL || variant || c.rep_mult < 1 || c.Lk % (3 * c.A) || c.rep_pos0 % (3 * c.A)))
+      return CTRLSIM_EINVAL;
+    const int qblocks = (c.Lq + 127) / 128;
+    ab.c[ab.n++] = AttnClass{c.q_row0 * ldq, c.o_row0 * ldo, c.img_tile0, c.pad_off, c.q_bs, c.o_bs, (long)c.nkt, c.q_pos,
+                             c.Lq, c.Lk, c.A, c.rep_keys, c.rep_pos0, qblocks, wg,
+                             c.rep_keys > 0 ? log2f((float)c.rep_mult) : 0.f};
+    wg += qblocks * NHEAD * c.B;
+    flops += attn_pairs(mode, c.q_pos, c.Lq, c.Lk, c.A, c.rep_keys) * 128.0 * NHEAD * c.B;
+    bytes += (double)c.B * (8.0 * DM * c.Lq + 4.0 * NPL * DM * (c.Lk + c.rep_keys));   // Q in + O out (fp32), K and V images (NPL planes)
+  }
+  if (ab.n == 0) return CTRLSIM_OK;
+  dim3 g(wg), blk(256);
+  const float scale = 0.17677669529663687f * 1.4426950408889634f;
+  const float* imgf = static_cast<const float*>(img);
+  prof_before(PROF_ATTN, st);
+  if (mode == MODE6_CAUSAL) {
+    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, true>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale,
+                       variant, ab);
+  } else {
+    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, true>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale, 0,
+                       ab);
+  }
+  prof_after(PROF_ATTN, flops, st, bytes);
+  return ctrlsim_launch_status();
+}
+
 int launch_attention_bf16x6_pre(int mode, const float* Q, int ldq, long q_batch_stride, const void* img, int nkt, float* O,
                                 int ldo, long o_batch_stride, const int* q_pos, const unsigned char* key_pad, int B, int Lq,
                                 int Lk, int A, int rep_keys, int rep_mult, int rep_pos0, hipStream_t st) {
   if (B <= 0 || Lq <= 0) return CTRLSIM_OK;
-  if (Lk <= 0 || (ldq & 3) || !img || rep_keys < 0) return CTRLSIM_EINVAL;
-  if (rep_keys == 0) rep_pos0 = Lk;
-  if (rep_pos0 < Lk || nkt < (rep_pos0 + KT6 - 1) / KT6 + (rep_keys + KT6 - 1) / KT6) return CTRLSIM_EINVAL;
-  if (mode < 0 || mode > 4 || (mode == MODE6_KEYPAD && !key_pad)) return CTRLSIM_EINVAL;
-  if (rep_keys > 0 && (mode != MODE6_CAUSAL || rep_mult < 1 || Lk % (3 * A) || rep_pos0 % (3 * A))) return CTRLSIM_EINVAL;
-  const int variant = mode >= MODE6_CAUSAL ? mode - MODE6_CAUSAL : 0;
-  mode = mode >= MODE6_CAUSAL ? MODE6_CAUSAL : MODE6_KEYPAD;
-  dim3 g((Lq + 127) / 128, NHEAD, B), blk(256);
-  const float scale = 0.17677669529663687f * 1.4426950408889634f;
-  const float* imgf = static_cast<const float*>(img);
-  const float log2m = rep_keys > 0 ? log2f((float)rep_mult) : 0.f;
-  prof_before(PROF_ATTN, st);
-  if (mode == MODE6_CAUSAL) {
-    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, true>), g, blk, 0, st, Q, ldq, q_batch_stride, imgf, nullptr, 0,
-                       (long)nkt, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale, variant, rep_keys, log2m, rep_pos0);
-  } else {
-    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, true>), g, blk, 0, st, Q, ldq, q_batch_stride, imgf, nullptr, 0,
-                       (long)nkt, O, ldo, o_batch_stride, q_pos, key_pad, Lq, Lk, A, scale, 0, 0, 0.f, 0);
-  }
-  prof_after(PROF_ATTN, attn_pairs(mode, q_pos, Lq, Lk, A, rep_keys) * 128.0 * NHEAD * B, st,
-             (double)B * (8.0 * DM * Lq + 4.0 * NPL * DM * (Lk + rep_keys)));   // Q in + O out (fp32), K and V images (NPL 16-bit planes each)
-  return ctrlsim_launch_status();
+  const AttnClassHost c{B, Lq, Lk, A, rep_keys, rep_mult, rep_pos0, nkt, 0, q_batch_stride, 0, o_batch_stride, 0, 0, q_pos};
+  return launch_attention_classes(mode, Q, ldq, img, O, ldo, key_pad, 1, &c, st);
 }

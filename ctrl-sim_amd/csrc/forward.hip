@@ -36,8 +36,16 @@ int launch_ffn_fused_bf16x6(const float*, int, const void*, const float*, const 
                             float*, int, int, int, hipStream_t);
 int launch_kv_split(const float*, const float*, int, long, int, int, int, void*, hipStream_t);
 int launch_kv_split_rows(const float*, const float*, int, long, const int*, int, int, int, void*, hipStream_t);
-int launch_attention_bf16x6_pre(int, const float*, int, long, const void*, int, float*, int, long, const int*,
-                                const unsigned char*, int, int, int, int, int, int, int, hipStream_t);
+struct AttnClassHost {
+  int B, Lq, Lk, A, rep_keys, rep_mult, rep_pos0, nkt;
+  long q_row0, q_bs, o_row0, o_bs, img_tile0, pad_off;
+  const int* q_pos;
+};
+int launch_attention_classes(int, const float*, int, const void*, float*, int, const unsigned char*, int, const AttnClassHost*,
+                             hipStream_t);
+struct KvClassHost { int B, L, Lreg, rep_k0, nkt; long tile0; };
+int launch_gemm_nt_bf16x6_kvc(const float*, int, const void*, int, int, const float*, const float*, int, float*, int, int, int, int,
+                              int, const float*, const float*, void*, int, int, const KvClassHost*, hipStream_t);
 int launch_in_mlp(const float*, int, int, const float*, const float*, const float*, const float*, float*, int, int,
                   hipStream_t);
 int launch_row_copy(const float*, int, float*, int, const int*, int, int, int, hipStream_t);
@@ -172,16 +180,18 @@ extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_w
 
 extern "C" void ctrlsim_model_destroy(ctrlsim_model* m) { delete m; }
 
-// ------------------------------------------------------------------------------------------------ workspace
+// ------------------------------------------------------------------------------------------------ batch of context classes
 namespace {
-// Shape of a uniform batch of contexts.  Token rows of agent slots that do not exist anywhere in the window are all equal
-// (every embedding is multiplied by the existence flag before embed_ln, modules/encoder.py:127-133) and stay equal through the
-// decoder (no key padding on the targets; the structured mask treats all of them alike), so a context with n < A vehicles
-// can be evaluated with Actx >= n + 1 slots: Areg = Actx - 1 regular slots, and ONE representative slot standing for the
+// Shape of a CLASS of contexts.  Token rows of agent slots that do not exist anywhere in the window are all equal (every
+// embedding is multiplied by the existence flag before embed_ln, modules/encoder.py:127-133) and stay equal through the decoder
+// (no key padding on the targets; the structured mask treats all of them alike), so a context with n < A vehicles can be
+// evaluated with Actx >= n + 1 slots: Areg = Actx - 1 regular slots, and ONE representative slot standing for the
 // mult = A - Areg padded slots of the reference's 24-slot layout (attention_bf16x6.hip: multiplicity of its keys).  A context's
 // L token rows: regular (tt, a < Areg, k) at (tt*Areg + a)*3 + k, representative (tt, k) at Lreg + 3*tt + k; its keys sit in
-// the tiles from key rep_k0 = 64*ceil(Lreg/64) on.  Actx == A: the plain layout (rep = 0).  Exact in real arithmetic; the engine
-// sorts the contexts of a step into a few such shapes (engine.py).
+// the tiles from key rep_k0 = 64*ceil(Lreg/64) on.  Actx == A: the plain layout (rep = 0).  Exact in real arithmetic.
+// A model BATCH is up to 8 classes (the engine sorts the contexts of a step by vehicle count); every row-wise kernel
+// (Linear, LayerNorm, feed-forward) runs ONCE over the rows of all classes, the two shape-aware kernels (attention, the
+// K/V-image epilogue of the QKV projection) take a class table, the small index / gather kernels run per class.
 struct Shape {
   int A, Areg, rep, mult;
   int rows(int Tq) const { return Tq * 3 * (Areg + rep); }
@@ -193,6 +203,44 @@ Shape shape_of(const ctrlsim_dims& d, int Actx) {
   Shape s;
   s.A = Actx; s.rep = Actx < d.A ? 1 : 0; s.Areg = Actx - s.rep; s.mult = d.A - s.Areg;
   return s;
+}
+struct Cls {
+  Shape sh;
+  int B, L, Lreg, M, nkt_dec, nkt_mem;
+  // first row of this class in the buffers indexed by: token rows, (b, tt, slot), (b, slot), scene rows, polylines, query rows, new rows
+  long rL, rS, rA, rM, rP, rQ, rN;
+  long tile_dec, tile_mem;                 // first image tile (per layer buffer)
+  int ioff;                                // offset of the class's [A]-sized index lists; 4 * ioff for the [4A]-sized ones
+  long koff;                               // offset of its key_all list
+  const ctrlsim_ctx* ctx;
+};
+struct Batch {
+  int n, Btot;
+  Cls c[8];
+  long rL, rS, rA, rM, rP, rQ, rN, tiles_dec, tiles_mem, isum, ksum;
+};
+// Tw: window steps of the row / image layout (T for the K/V-cached phase); Tn: window rows held by the context tensors
+int make_batch(const ctrlsim_dims& d, int n, const int* B, const int* A, const ctrlsim_ctx* ctx, int Tw, int Tn, int Rn_mul,
+               Batch& bt) {
+  if (n < 1 || n > 8 || !B || !A || !ctx) return CTRLSIM_EINVAL;
+  bt = Batch{};
+  for (int k = 0; k < n; ++k) {
+    if (B[k] <= 0) continue;
+    if (A[k] < 2 || A[k] > d.A) return CTRLSIM_EINVAL;
+    Cls& c = bt.c[bt.n++];
+    c.sh = shape_of(d, A[k]);
+    c.B = B[k]; c.L = c.sh.rows(Tw); c.Lreg = c.sh.lreg(Tw); c.M = d.P + A[k];
+    c.nkt_dec = c.sh.nkt(Tw); c.nkt_mem = (c.M + 63) / 64;
+    c.rL = bt.rL; c.rS = bt.rS; c.rA = bt.rA; c.rM = bt.rM; c.rP = bt.rP; c.rQ = bt.rQ; c.rN = bt.rN;
+    c.tile_dec = bt.tiles_dec; c.tile_mem = bt.tiles_mem; c.ioff = (int)bt.isum; c.koff = bt.ksum;
+    c.ctx = ctx + k;
+    bt.rL += (long)c.B * c.L; bt.rS += (long)c.B * Tn * A[k]; bt.rA += (long)c.B * A[k]; bt.rM += (long)c.B * c.M;
+    bt.rP += (long)c.B * d.P; bt.rQ += (long)c.B * c.sh.Areg; bt.rN += (long)c.B * Rn_mul * A[k];
+    bt.tiles_dec += (long)c.B * NHEAD * c.nkt_dec; bt.tiles_mem += (long)c.B * NHEAD * c.nkt_mem;
+    bt.isum += A[k]; bt.ksum += c.L;
+    bt.Btot += c.B;
+  }
+  return bt.n ? CTRLSIM_OK : CTRLSIM_EINVAL;
 }
 
 struct Ws {
@@ -206,14 +254,14 @@ struct Ws {
   float *xn, *tmpn, *attn_n, *qkvn, *qcn, *ffnn;
   int *pos_new, *key_new, *src_new, *idx_new, *idx_state_in_new;
   // split-bf16 K/V images (attention_bf16x6.hip: kv_split_kernel): decoder self-attention per layer, memory K/V per
-  // layer, scene encoder (reused by its layers); nkt = 64-key tiles per context
+  // layer, scene encoder (reused by its layers)
   void *img_dec[8], *img_mem[8], *img_enc;
-  int nkt_dec, nkt_mem;
   size_t img_dec_bytes;
   size_t bytes;
 };
 
-Ws carve(const ctrlsim_dims& d, const Shape& sh, int B, int Tq, char* base) {
+// Sizes by the batch totals (every buffer holds the classes one after the other); Tn = window rows of the context tensors
+Ws carve(const ctrlsim_dims& d, const Batch& bt, char* base) {
   Ws w;
   size_t off = 0;
   auto take = [&](size_t nbytes) -> char* {
@@ -221,9 +269,9 @@ Ws carve(const ctrlsim_dims& d, const Shape& sh, int B, int Tq, char* base) {
     off += (nbytes + 255) & ~size_t(255);
     return p;
   };
-  const size_t L = (size_t)sh.rows(Tq), M = (size_t)d.P + sh.A;
-  const size_t rL = B * L, rM = B * M, rA = (size_t)B * sh.A, rS = (size_t)B * Tq * sh.A, rP = (size_t)B * d.P;
+  const size_t rL = bt.rL, rM = bt.rM, rA = bt.rA, rS = bt.rS, rP = bt.rP;
   auto F = [&](size_t rows, size_t cols) { return reinterpret_cast<float*>(take(rows * cols * sizeof(float))); };
+  auto I = [&](size_t n) { return reinterpret_cast<int*>(take(n * sizeof(int))); };
   w.hS = F(rS, DM); w.S2 = F(rS, DM); w.hG = F(rA, DM); w.Gp = F(rA, DM);
   w.X = F(rL, DM); w.src = F(rM, DM);
   w.attn_pre = F(rP, DM); w.m1 = F(rP, DM); w.m2 = F(rP, DM); w.cat = F(rP, 2 * DM); w.tfh = F(rP, DM);
@@ -234,42 +282,33 @@ Ws carve(const ctrlsim_dims& d, const Shape& sh, int B, int Tq, char* base) {
   w.xc = F(rA, DM); w.xc2 = F(rA, DM); w.tmpc = F(rA, DM); w.attc = F(rA, DM); w.qkvc = F(rA, 3 * DM);
   w.qcc = F(rA, DM); w.ffnc = F(rA, d.F); w.headh = F(rA, DM);
   w.src_pad = reinterpret_cast<unsigned char*>(take(rM));
-  w.pos_state = reinterpret_cast<int*>(take(sh.A * sizeof(int)));
-  w.pos_rtg = reinterpret_cast<int*>(take(sh.A * sizeof(int)));
-  w.idx_state = reinterpret_cast<int*>(take(rA * sizeof(int)));
-  w.idx_rtg = reinterpret_cast<int*>(take(rA * sizeof(int)));
-  w.idx_poly = reinterpret_cast<int*>(take(rP * sizeof(int)));
-  w.key_all = reinterpret_cast<int*>(take(L * sizeof(int)));
+  w.pos_state = I(bt.isum); w.pos_rtg = I(bt.isum);
+  w.idx_state = I(rA); w.idx_rtg = I(rA); w.idx_poly = I(rP); w.key_all = I(bt.ksum);
   const size_t rN = rA * 4;
   w.xn = F(rN, DM); w.tmpn = F(rN, DM); w.attn_n = F(rN, DM); w.qkvn = F(rN, 3 * DM); w.qcn = F(rN, DM); w.ffnn = F(rN, d.F);
-  w.pos_new = reinterpret_cast<int*>(take(4 * sh.A * sizeof(int)));
-  w.key_new = reinterpret_cast<int*>(take(4 * sh.A * sizeof(int)));
-  w.src_new = reinterpret_cast<int*>(take(4 * sh.A * sizeof(int)));
-  w.idx_new = reinterpret_cast<int*>(take(rN * sizeof(int)));
-  w.idx_state_in_new = reinterpret_cast<int*>(take(rA * sizeof(int)));
-  w.nkt_dec = sh.nkt(Tq);
-  w.nkt_mem = (int)((M + 63) / 64);
+  w.pos_new = I(4 * bt.isum); w.key_new = I(4 * bt.isum); w.src_new = I(4 * bt.isum);
+  w.idx_new = I(rN); w.idx_state_in_new = I(rA);
   const size_t tile_bytes = (size_t)2 * NPL * 64 * HD * 2;   // 8 KB per plane pair of a (context, head, tile) image
-  w.img_dec_bytes = (size_t)B * NHEAD * w.nkt_dec * tile_bytes;
+  w.img_dec_bytes = (size_t)bt.tiles_dec * tile_bytes;
   for (int i = 0; i < d.ND; ++i) w.img_dec[i] = take(w.img_dec_bytes);
-  for (int i = 0; i < d.ND; ++i) w.img_mem[i] = take((size_t)B * NHEAD * w.nkt_mem * tile_bytes);
-  w.img_enc = take((size_t)B * NHEAD * w.nkt_mem * tile_bytes);
+  for (int i = 0; i < d.ND; ++i) w.img_mem[i] = take((size_t)bt.tiles_mem * tile_bytes);
+  w.img_enc = take((size_t)bt.tiles_mem * tile_bytes);
   w.bytes = off;
   return w;
 }
 
-// qoff: token type whose rows feed the first pass's head (0 = state tokens; 2 = action tokens, Trajeglish).  Index lists of the
-// Areg current-step query rows per context (positions in the context's row order; regular rows: position == key), the
-// polyline rows of the scene-encoder source, and key_all: row -> key position in the K/V images (Tq window steps).
-__global__ void fill_index_kernel(int B, int Areg, int L, int Lreg, int rep_k0, int ti, int P, int M, int qoff, int* pos_state,
-                                  int* pos_rtg, int* idx_state, int* idx_rtg, int* idx_poly, int* key_all) {
+// qoff: token type whose rows feed the first pass's head (0 = state tokens; 2 = action tokens, Trajeglish).  Index lists of ONE
+// class: the Areg current-step query rows per context (positions in the context's row order — regular rows: position == key —
+// and global row indices), the polyline rows of the scene-encoder source, key_all: row -> key position in the K/V images.
+__global__ void fill_index_kernel(int B, int Areg, int L, int Lreg, int rep_k0, int ti, int P, int M, int qoff, long rL, long rM,
+                                  int* pos_state, int* pos_rtg, int* idx_state, int* idx_rtg, int* idx_poly, int* key_all) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < B * P) idx_poly[i] = (i / P) * M + (i % P);
+  if (i < B * P) idx_poly[i] = (int)rM + (i / P) * M + (i % P);
   if (i < Areg) { pos_state[i] = (ti * Areg + i) * 3 + qoff; pos_rtg[i] = (ti * Areg + i) * 3 + 1; }
   if (i < B * Areg) {
     const int b = i / Areg, a = i - b * Areg;
-    idx_state[i] = b * L + (ti * Areg + a) * 3 + qoff;
-    idx_rtg[i] = b * L + (ti * Areg + a) * 3 + 1;
+    idx_state[i] = (int)rL + b * L + (ti * Areg + a) * 3 + qoff;
+    idx_rtg[i] = (int)rL + b * L + (ti * Areg + a) * 3 + 1;
   }
   if (i < L) key_all[i] = i < Lreg ? i : rep_k0 + (i - Lreg);
 }
@@ -302,54 +341,111 @@ int ffn_block(const Lin& l1, const Lin& l2, const LNp& n, const void* w1p, const
   return gemm_ln(l2, n, hidden, F, x, DM, x, DM, tmp, rows, F, 0, st);
 }
 
-// Attention over K/V given both as fp32 rows and (when the split-bf16 path is selected) as pre-split images.
-// Rep: the representative-token region of a compact context (split-operand path only; rep_keys == 0: none).
-struct Rep { int keys = 0, mult = 1, pos0 = 0; };
 inline bool presplit() { return ctrlsim_option(OPT_ATTN_IMPL) == 1; }
-int attention_kv(int mode, const float* Q, int ldq, long qbs, const float* K, const float* V, int ldkv, long kbs,
-                 const void* img, int nkt, float* O, int ldo, long obs, const int* q_pos, const unsigned char* key_pad, int B,
-                 int Lq, int Lk, int A, hipStream_t st, Rep rep = Rep()) {
-  if (presplit())
-    return launch_attention_bf16x6_pre(mode, Q, ldq, qbs, img, nkt, O, ldo, obs, q_pos, key_pad, B, Lq, Lk, A, rep.keys, rep.mult,
-                                       rep.pos0, st);
-  if (rep.keys) return CTRLSIM_EINVAL;
-  return launch_attention(mode, Q, ldq, qbs, K, V, ldkv, kbs, O, ldo, obs, q_pos, key_pad, B, Lq, Lk, A, st);
-}
-int kv_split(const float* K, const float* V, int ldkv, long kbs, int B, int Lk, int nkt, void* img, hipStream_t st) {
-  return presplit() ? launch_kv_split(K, V, ldkv, kbs, B, Lk, nkt, img, st) : 0;
-}
-int kv_split_rows(const float* K, const float* V, int ldkv, long kbs, const int* pos, int B, int R, int nkt, void* img,
-                  hipStream_t st) {
-  return presplit() ? launch_kv_split_rows(K, V, ldkv, kbs, pos, B, R, nkt, img, st) : 0;
-}
-// Linear whose last 512 output columns are attention keys / values of B contexts x Lk rows: y[:, :kcol0] as fp32 rows,
-// K / V as split images straight from the GEMM epilogue when both bf16x6 kernels are selected (the fp32 K / V columns
-// of y are then NOT written); otherwise GEMM + kv_split.  Rows >= Lreg of a context go to the keys from rep_k0 on
-// (compact contexts; Lreg == Lk: plain layout); key_all = the row -> key list of the fallback.
-int gemm_kv(const Lin& L, const float* x, int ldx, float* y, int ldy, int B, int Lk, int n, int k, int kcol0, void* img, int nkt,
-            hipStream_t st, int Lreg = 0, int rep_k0 = 0, const int* key_all = nullptr, size_t img_bytes = 0) {
-  const int rows = B * Lk;
-  if (Lreg <= 0 || Lreg >= Lk) { Lreg = Lk; rep_k0 = 0; }
-  if (presplit() && L.w3 && k % 16 == 0 && ctrlsim_option(OPT_GEMM_IMPL) == 1 && !(Lk & 3) && !(Lreg & 3) && Lk >= 32) {
-    CHK(launch_kv_zero_tail(B, 0, Lreg, nkt, img, st));
-    if (Lreg < Lk) CHK(launch_kv_zero_tail(B, rep_k0, Lk - Lreg, nkt, img, st));
-    return launch_gemm_nt_bf16x6_kv(x, ldx, L.w3, L.ntot ? L.ntot : n, L.n0, L.b, nullptr, 0, y, ldy, rows, n, k, 0, nullptr,
-                                    nullptr, img, Lk, nkt, kcol0, Lreg, rep_k0, st);
+
+// What the queries / keys of an attention call are, per class
+enum QKind { Q_ALL, Q_SCENE, Q_STATE, Q_RTG, Q_NEW };   // all L token rows | the M scene rows | the Areg state (first-pass) rows |
+                                                         // the Areg rtg rows | the cached path's new rows
+struct AttnCall {
+  int mode;                      // 0 key padding (memory / scene keys), >= 1 causal
+  QKind q;
+  const float* Q; int ldq;       // Q rows in class order (Q_ALL: the token rows; else the compact rows)
+  const float* Kf; const float* Vf; int ldkv;   // fp32 K / V rows (f32-input fallback only)
+  const void* img; bool mem;     // images: decoder self-attention tiles (mem = false) or memory / scene tiles
+  float* O;
+  int Tk;                        // causal: window steps whose keys are attended (Lk = Tk * 3 * Areg, rep_keys = 3 * Tk)
+  int Tw;                        // window steps of the row layout (rep_pos0 = lreg(Tw))
+  int Rn_mul;                    // Q_NEW: rows per context = Rn_mul * A
+};
+int attention(const ctrlsim_dims& d, const Batch& bt, const Ws& w, const AttnCall& a, hipStream_t st) {
+  AttnClassHost h[8];
+  for (int k = 0; k < bt.n; ++k) {
+    const Cls& c = bt.c[k];
+    const Shape& sh = c.sh;
+    AttnClassHost& x = h[k];
+    x = AttnClassHost{};
+    x.B = c.B;
+    x.A = sh.Areg;
+    long qrow0 = 0;
+    switch (a.q) {
+      case Q_ALL: x.Lq = c.L; qrow0 = c.rL; x.q_pos = nullptr; break;
+      case Q_SCENE: x.Lq = c.M; qrow0 = c.rM; x.q_pos = nullptr; break;
+      case Q_STATE: x.Lq = sh.Areg; qrow0 = c.rQ; x.q_pos = w.pos_state + c.ioff; break;
+      case Q_RTG: x.Lq = sh.Areg; qrow0 = c.rQ; x.q_pos = w.pos_rtg + c.ioff; break;
+      case Q_NEW: x.Lq = a.Rn_mul * sh.A; qrow0 = c.rN; x.q_pos = w.pos_new + 4 * c.ioff; break;
+    }
+    x.q_row0 = qrow0; x.o_row0 = qrow0;
+    x.q_bs = (long)x.Lq * a.ldq; x.o_bs = (long)x.Lq * DM;
+    if (a.mode == 0) {
+      x.Lk = c.M; x.nkt = c.nkt_mem; x.img_tile0 = c.tile_mem; x.pad_off = c.rM; x.q_pos = nullptr;
+    } else {
+      x.Lk = a.Tk * 3 * sh.Areg; x.rep_keys = sh.rep * 3 * a.Tk; x.rep_mult = sh.mult; x.rep_pos0 = sh.lreg(a.Tw);
+      x.nkt = c.nkt_dec; x.img_tile0 = c.tile_dec; x.pad_off = 0;
+    }
   }
-  CHK(gemm(L, x, ldx, nullptr, 0, y, ldy, rows, n, k, 0, st));
-  if (Lreg == Lk) return kv_split(y + kcol0, y + kcol0 + DM, ldy, (long)Lk * ldy, B, Lk, nkt, img, st);
-  if (!presplit()) return CTRLSIM_EINVAL;
-  if (hipMemsetAsync(img, 0, img_bytes, st) != hipSuccess) return CTRLSIM_ELAUNCH;
-  return kv_split_rows(y + kcol0, y + kcol0 + DM, ldy, (long)Lk * ldy, key_all, B, Lk, nkt, img, st);
+  if (presplit()) return launch_attention_classes(a.mode, a.Q, a.ldq, a.img, a.O, DM, w.src_pad, bt.n, h, st);
+  // f32-input MFMA path: one launch per class, plain layout only
+  for (int k = 0; k < bt.n; ++k) {
+    const Cls& c = bt.c[k];
+    const AttnClassHost& x = h[k];
+    if (x.rep_keys) return CTRLSIM_EINVAL;
+    const long krow0 = a.mode == 0 ? c.rM : c.rL, kbs = (long)(a.mode == 0 ? c.M : c.L) * a.ldkv;
+    CHK(launch_attention(a.mode, a.Q + x.q_row0 * a.ldq, a.ldq, x.q_bs, a.Kf + krow0 * a.ldkv, a.Vf + krow0 * a.ldkv, a.ldkv, kbs,
+                         a.O + x.o_row0 * DM, DM, x.o_bs, x.q_pos, a.mode == 0 ? w.src_pad + c.rM : nullptr, c.B, x.Lq, x.Lk, x.A,
+                         st));
+  }
+  return 0;
 }
 
-// index lists of the cached path: the new rows of step t are the action tokens of step t-1 (t > 0) and the three tokens of step
-// t, of the Areg regular slots and then of the representative; cache rows live at b * Lf + position with Lf = rows of the
-// full window.  pos_new = position in the row order (= the query position the mask uses), key_new = key in the K/V images,
-// src_new = ((tt - tt_first) * Actx + slot) * 3 + k in the context tensors.
-__global__ void fill_index_cached_kernel(int B, int Actx, int Areg, int Lf, int Lreg_f, int rep_k0, int t, int Rn, int* pos_new,
-                                         int* key_new, int* src_new, int* idx_new, int* idx_state_in_new, int* pos_rtg,
-                                         int* idx_rtg) {
+// Linear whose last 512 output columns are attention keys / values: y[:, :kcol0] as fp32 rows, K / V as split images straight from
+// the GEMM epilogue when both bf16x6 kernels are selected (the fp32 K / V columns of y are then NOT written); otherwise GEMM +
+// a split pass per class.  mem: the scene / memory rows (M per context, plain key order) instead of the token rows.
+int gemm_kv(const ctrlsim_dims& d, const Batch& bt, const Ws& w, const Lin& L, const float* x, float* y, int ldy, int n, int kcol0,
+            void* img, bool mem, hipStream_t st) {
+  const long rows = mem ? bt.rM : bt.rL;
+  bool fused = presplit() && L.w3 && ctrlsim_option(OPT_GEMM_IMPL) == 1;
+  KvClassHost kc[8];
+  for (int k = 0; k < bt.n; ++k) {
+    const Cls& c = bt.c[k];
+    const int Lk = mem ? c.M : c.L, Lreg = mem ? c.M : c.Lreg;
+    kc[k] = KvClassHost{c.B, Lk, Lreg, mem ? 0 : c.sh.rep_k0(c.Lreg / (3 * c.sh.Areg)), mem ? c.nkt_mem : c.nkt_dec,
+                        mem ? c.tile_mem : c.tile_dec};
+    fused = fused && !(Lk & 3) && !(Lreg & 3) && Lk >= 32;
+  }
+  const size_t KIMG = (size_t)2 * NPL * 64 * HD;      // 16-bit elements per tile
+  if (fused) {
+    for (int k = 0; k < bt.n; ++k) {
+      op_t* base = static_cast<op_t*>(img) + (size_t)kc[k].tile0 * KIMG;
+      CHK(launch_kv_zero_tail(kc[k].B, 0, kc[k].Lreg, kc[k].nkt, base, st));
+      if (kc[k].Lreg < kc[k].L) CHK(launch_kv_zero_tail(kc[k].B, kc[k].rep_k0, kc[k].L - kc[k].Lreg, kc[k].nkt, base, st));
+    }
+    return launch_gemm_nt_bf16x6_kvc(x, DM, L.w3, L.ntot ? L.ntot : n, L.n0, L.b, nullptr, 0, y, ldy, (int)rows, n, DM, 0, nullptr,
+                                     nullptr, img, kcol0, bt.n, kc, st);
+  }
+  CHK(gemm(L, x, DM, nullptr, 0, y, ldy, (int)rows, n, DM, 0, st));
+  if (!presplit()) return 0;
+  for (int k = 0; k < bt.n; ++k) {
+    const Cls& c = bt.c[k];
+    const long r0 = mem ? c.rM : c.rL;
+    op_t* base = static_cast<op_t*>(img) + (size_t)kc[k].tile0 * KIMG;
+    const float* Kp = y + r0 * ldy + kcol0;
+    if (kc[k].Lreg == kc[k].L) {
+      CHK(launch_kv_split(Kp, Kp + DM, ldy, (long)kc[k].L * ldy, c.B, kc[k].L, kc[k].nkt, base, st));
+    } else {
+      if (hipMemsetAsync(base, 0, (size_t)c.B * NHEAD * kc[k].nkt * KIMG * sizeof(op_t), st) != hipSuccess) return CTRLSIM_ELAUNCH;
+      CHK(launch_kv_split_rows(Kp, Kp + DM, ldy, (long)kc[k].L * ldy, w.key_all + c.koff, c.B, kc[k].L, kc[k].nkt, base, st));
+    }
+  }
+  return 0;
+}
+
+// index lists of the cached path (one class): the new rows of step t are the action tokens of step t-1 (t > 0) and the three tokens
+// of step t, of the Areg regular slots and then of the representative; cache rows live at rL + b * Lf + position with Lf = rows
+// of the full window.  pos_new = position in the row order (= the query position the mask uses), key_new = key in the K/V
+// images, src_new = ((tt - tt_first) * Actx + slot) * 3 + k in the context tensors.
+__global__ void fill_index_cached_kernel(int B, int Actx, int Areg, int Lf, int Lreg_f, int rep_k0, int t, int Rn, long rL, long rN,
+                                         int* pos_new, int* key_new, int* src_new, int* idx_new, int* idx_state_in_new,
+                                         int* pos_rtg, int* idx_rtg) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int off = t > 0 ? Actx : 0;
   // entry j -> (window step tt, slot a, token k)
@@ -372,12 +468,12 @@ __global__ void fill_index_cached_kernel(int B, int Actx, int Areg, int Lf, int 
   if (i < B * Rn) {
     int tt, a, k;
     decode(i % Rn, tt, a, k);
-    idx_new[i] = (i / Rn) * Lf + pos_of(tt, a, k);
+    idx_new[i] = (int)rL + (i / Rn) * Lf + pos_of(tt, a, k);
   }
   if (i < B * Areg) {
     const int b = i / Areg, a = i - b * Areg;
-    idx_state_in_new[i] = b * Rn + off + 3 * a;
-    idx_rtg[i] = b * Lf + (t * Areg + a) * 3 + 1;
+    idx_state_in_new[i] = (int)rN + b * Rn + off + 3 * a;
+    idx_rtg[i] = (int)rL + b * Lf + (t * Areg + a) * 3 + 1;
   }
 }
 
@@ -389,29 +485,30 @@ int mlp_tail(const Mlp& m, const float* h_in, int rows, float* hid, float* out, 
 }
 
 // cross-attention + FFN sub-blocks shared by the full-row and compact-row paths (post-LN, residual fused in GEMM)
-int cross_and_ffn(const ctrlsim_model* m, const Shape& sh, const DecLayer& Ld, int layer, const Ws& w, float* x, float* tmp,
-                  float* att, float* qc, float* ffn, int rows, int B, int rows_per_b, hipStream_t st) {
+int cross_and_ffn(const ctrlsim_model* m, const Batch& bt, const DecLayer& Ld, int layer, const Ws& w, float* x, float* tmp,
+                  float* att, float* qc, float* ffn, long rows, QKind q, int Rn_mul, hipStream_t st) {
   const ctrlsim_dims& d = m->d;
-  const int M = d.P + sh.A;
-  CHK(gemm(Ld.cq, x, DM, nullptr, 0, qc, DM, rows, DM, DM, 0, st));
-  CHK(attention_kv(0, qc, DM, (long)rows_per_b * DM, w.memkv[layer], w.memkv[layer] + DM, 2 * DM, (long)M * 2 * DM,
-                   w.img_mem[layer], w.nkt_mem, att, DM, (long)rows_per_b * DM, nullptr, w.src_pad, B, rows_per_b, M, sh.A, st));
-  CHK(gemm_ln(Ld.cout, Ld.n2, att, DM, x, DM, x, DM, tmp, rows, DM, 0, st));
-  CHK(ffn_block(Ld.lin1, Ld.lin2, Ld.n3, Ld.w1p, Ld.w2p, x, ffn, tmp, rows, d.F, st));
+  CHK(gemm(Ld.cq, x, DM, nullptr, 0, qc, DM, (int)rows, DM, DM, 0, st));
+  CHK(attention(d, bt, w, AttnCall{0, q, qc, DM, w.memkv[layer], w.memkv[layer] + DM, 2 * DM, w.img_mem[layer], true, att, 0, 0,
+                                   Rn_mul}, st));
+  CHK(gemm_ln(Ld.cout, Ld.n2, att, DM, x, DM, x, DM, tmp, (int)rows, DM, 0, st));
+  CHK(ffn_block(Ld.lin1, Ld.lin2, Ld.n3, Ld.w1p, Ld.w2p, x, ffn, tmp, (int)rows, d.F, st));
   return 0;
 }
 // map encoder + scene encoder + per-layer memory K/V (everything that only depends on the frame of the context)
-int scene_side(const ctrlsim_model* m, const Shape& sh, const Ws& w, const ctrlsim_ctx* c, int B, float* dbg_seg_emb,
-               hipStream_t st) {
+int scene_side(const ctrlsim_model* m, const Batch& bt, const Ws& w, float* dbg_seg_emb, hipStream_t st) {
   const ctrlsim_dims& d = m->d;
-  const int A = sh.A, P = d.P, M = P + A, rM = B * M, rP = B * P;
+  const int P = d.P, rM = (int)bt.rM, rP = (int)bt.rP;
   // ---- map encoder (map_encoder.py:34-53): rows of `src` 0..P-1 per context
-  CHK(launch_map_pool(B, P, d.NP, M, c->road_pts, m->mp, w.attn_pre, w.src_pad, st));
+  for (int k = 0; k < bt.n; ++k) {
+    const Cls& c = bt.c[k];
+    CHK(launch_map_pool(c.B, P, d.NP, c.M, c.ctx->road_pts, m->mp, w.attn_pre + c.rP * DM, w.src_pad + c.rM, st));
+    CHK(launch_in_mlp(c.ctx->road_types, 8, 8, m->road_type.l0.w, m->road_type.l0.b, m->road_type.ln.g, m->road_type.ln.b,
+                      w.tfh + c.rP * DM, DM, c.B * P, st));
+  }
   CHK(gemm_ln(m->map_out, m->map_n1, w.attn_pre, DM, nullptr, 0, w.m1, DM, w.m1, rP, DM, 0, st));            // emb
   CHK(gemm_ln(m->map_feats.l0, m->map_feats.ln, w.m1, DM, nullptr, 0, w.m2, DM, w.m2, rP, DM, 1, st));
   CHK(gemm_ln(m->map_feats.l3, m->map_n2, w.m2, DM, w.m1, DM, w.cat, 2 * DM, w.attn_pre, rP, DM, 0, st));   // cat[:, :256]
-  CHK(launch_in_mlp(c->road_types, 8, 8, m->road_type.l0.w, m->road_type.l0.b, m->road_type.ln.g, m->road_type.ln.b, w.tfh,
-                    DM, rP, st));
   CHK(gemm(m->road_type.l3, w.tfh, DM, nullptr, 0, w.cat + DM, 2 * DM, rP, DM, DM, 0, st));                                                                                  // cat[:, 256:]
   CHK(gemm_ln(m->road_fuse.l0, m->road_fuse.ln, w.cat, 2 * DM, nullptr, 0, w.m2, DM, w.m2, rP, 2 * DM, 1, st));
   // final Linear -> compact [B*P,256], then scattered into the scene-encoder source rows [b, 0..P-1]
@@ -424,26 +521,58 @@ int scene_side(const ctrlsim_model* m, const Shape& sh, const Ws& w, const ctrls
   // ---- scene encoder (encoder.py:155-168): post-LN layers over [polylines || initial states] with key padding
   for (int i = 0; i < d.NE; ++i) {
     const EncLayer& Le = m->enc[i];
-    CHK(gemm_kv(Le.qkv, w.src, DM, w.eqkv, 3 * DM, B, M, 3 * DM, DM, DM, w.img_enc, w.nkt_mem, st));
-    CHK(attention_kv(0, w.eqkv, 3 * DM, (long)M * 3 * DM, w.eqkv + DM, w.eqkv + 2 * DM, 3 * DM, (long)M * 3 * DM, w.img_enc,
-                     w.nkt_mem, w.eatt, DM, (long)M * DM, nullptr, w.src_pad, B, M, M, A, st));
+    CHK(gemm_kv(d, bt, w, Le.qkv, w.src, w.eqkv, 3 * DM, 3 * DM, DM, w.img_enc, true, st));
+    CHK(attention(d, bt, w, AttnCall{0, Q_SCENE, w.eqkv, 3 * DM, w.eqkv + DM, w.eqkv + 2 * DM, 3 * DM, w.img_enc, true, w.eatt, 0, 0, 0},
+                  st));
     CHK(gemm_ln(Le.out, Le.n1, w.eatt, DM, w.src, DM, w.src, DM, w.etmp, rM, DM, 0, st));
     CHK(ffn_block(Le.lin1, Le.lin2, Le.n2, Le.w1p, Le.w2p, w.src, w.effn, w.etmp, rM, d.F, st));
   }
   // memory K/V of every decoder layer (cached for pass 2)
-  for (int i = 0; i < d.ND; ++i) {
-    CHK(gemm_kv(m->dec[i].ckv, w.src, DM, w.memkv[i], 2 * DM, B, M, 2 * DM, DM, 0, w.img_mem[i], w.nkt_mem, st));
-  }
+  for (int i = 0; i < d.ND; ++i) CHK(gemm_kv(d, bt, w, m->dec[i].ckv, w.src, w.memkv[i], 2 * DM, 2 * DM, 0, w.img_mem[i], true, st));
   return 0;
 }
 
-bool actx_ok(const ctrlsim_dims& d, int Actx) { return Actx >= 2 && Actx <= d.A && (Actx == d.A || (d.variant == 0 && presplit())); }
+bool classes_ok(const ctrlsim_dims& d, const Batch& bt) {
+  for (int k = 0; k < bt.n; ++k)
+    if (bt.c[k].sh.rep && (d.variant != 0 || !presplit())) return false;
+  return true;
+}
+int launch_fill_index(const Batch& bt, const Ws& w, int P, int ti, int Tq, int qoff, hipStream_t st) {
+  for (int k = 0; k < bt.n; ++k) {
+    const Cls& c = bt.c[k];
+    const int nidx = max(max(c.B * c.sh.A, c.B * P), c.L);
+    hipLaunchKernelGGL(fill_index_kernel, dim3((nidx + 255) / 256), dim3(256), 0, st, c.B, c.sh.Areg, c.L, c.Lreg, c.sh.rep_k0(Tq), ti,
+                       P, c.M, qoff, c.rL, c.rM, w.pos_state + c.ioff, w.pos_rtg + c.ioff, w.idx_state + c.rQ, w.idx_rtg + c.rQ,
+                       w.idx_poly + c.rP, w.key_all + c.koff);
+  }
+  return ctrlsim_launch_status();
+}
+// first embedding layers: in_mlp per class (the context tensors of the classes are separate arrays), then the folded Linear once
+int embed_inputs(const ctrlsim_model* m, const Batch& bt, const Ws& w, int Tn, bool goals, hipStream_t st) {
+  for (int k = 0; k < bt.n; ++k) {
+    const Cls& c = bt.c[k];
+    CHK(launch_in_mlp(c.ctx->st12, 12, 12, m->embed_state.l0.w, m->embed_state.l0.b, m->embed_state.ln.g, m->embed_state.ln.b,
+                      w.hS + c.rS * DM, DM, c.B * Tn * c.sh.A, st));
+    if (goals)
+      CHK(launch_in_mlp(c.ctx->goal5, 5, 5, m->embed_goal.l0.w, m->embed_goal.l0.b, m->embed_goal.ln.g, m->embed_goal.ln.b,
+                        w.hG + c.rA * DM, DM, c.B * c.sh.A, st));
+  }
+  CHK(gemm(m->fold_state, w.hS, DM, nullptr, 0, w.S2, DM, (int)bt.rS, DM, DM, 0, st));
+  if (goals) CHK(gemm(m->fold_goal, w.hG, DM, nullptr, 0, w.Gp, DM, (int)bt.rA, DM, DM, 0, st));
+  return 0;
+}
 
 }  // namespace
 
+extern "C" int64_t ctrlsim_forward_workspace_bytes_c(const ctrlsim_dims* d, int n, const int* B, const int* A, int Tq) {
+  if (!d || Tq < 1 || Tq > d->T) return CTRLSIM_EINVAL;
+  Batch bt;
+  ctrlsim_ctx dummy[8] = {};
+  if (n < 1 || n > 8 || make_batch(*d, n, B, A, dummy, Tq, Tq, 4, bt) != CTRLSIM_OK) return CTRLSIM_EINVAL;
+  return (int64_t)carve(*d, bt, nullptr).bytes;
+}
 extern "C" int64_t ctrlsim_forward_workspace_bytes_a(const ctrlsim_dims* d, int B, int Tq, int Actx) {
-  if (!d || B < 1 || Tq < 1 || Tq > d->T || Actx < 2 || Actx > d->A) return CTRLSIM_EINVAL;
-  return (int64_t)carve(*d, shape_of(*d, Actx), B, Tq, nullptr).bytes;
+  return ctrlsim_forward_workspace_bytes_c(d, 1, &B, &Actx, Tq);
 }
 extern "C" int64_t ctrlsim_forward_workspace_bytes(const ctrlsim_dims* d, int B, int Tq) {
   return d ? ctrlsim_forward_workspace_bytes_a(d, B, Tq, d->A) : CTRLSIM_EINVAL;
@@ -452,51 +581,45 @@ extern "C" int64_t ctrlsim_forward_workspace_bytes(const ctrlsim_dims* d, int B,
 // ------------------------------------------------------------------------------------------------ pass 1
 namespace {
 // The full forward over the first Tq window steps; logits of the head that the first pass of the variant needs, for the Areg
-// regular slots of every context ([B*Areg, .] rows):
+// regular slots of every context (rows in class order, [sum_k B_k*Areg_k, .]):
 // CtRL-Sim: predict_rtg on the state tokens of the current step; IL: predict_action on the same rows; Trajeglish:
 // predict_action on the action tokens (decoder.py:55-77).
-int forward_full(const ctrlsim_model* m, int B, int Tq, int Actx, const ctrlsim_ctx* c, void* workspace, float* logits,
-                 float* dbg_seg_emb, hipStream_t st) {
+int forward_full(const ctrlsim_model* m, int n, const int* Bk, const int* Ak, const ctrlsim_ctx* ctx, int Tq, void* workspace,
+                 float* logits, float* dbg_seg_emb, hipStream_t st) {
   const ctrlsim_dims& d = m->d;
   const int variant = d.variant, amode = 1 + variant, qoff = variant == 2 ? 2 : 0;
   if (variant && !presplit()) return CTRLSIM_EINVAL;       // the IL / Trajeglish masks live in the split-bf16 attention only
-  if (!actx_ok(d, Actx)) return CTRLSIM_EINVAL;
-  const Shape sh = shape_of(d, Actx);
-  const Ws w = carve(d, sh, B, Tq, static_cast<char*>(workspace));
-  const int A = sh.A, Ar = sh.Areg, P = d.P, M = P + A, L = sh.rows(Tq), Lreg = sh.lreg(Tq), ti = Tq - 1;
-  const int rL = B * L, rA = B * A, rQ = B * Ar, rS = B * Tq * A, rP = B * P;
-  const Rep rep{sh.rep * 3 * Tq, sh.mult, Lreg};
-  const int nidx = max(max(rA, rP), L);
-  hipLaunchKernelGGL(fill_index_kernel, dim3((nidx + 255) / 256), dim3(256), 0, st, B, Ar, L, Lreg, sh.rep_k0(Tq), ti, P, M, qoff,
-                     w.pos_state, w.pos_rtg, w.idx_state, w.idx_rtg, w.idx_poly, w.key_all);
+  Batch bt;
+  CHK(make_batch(d, n, Bk, Ak, ctx, Tq, Tq, 4, bt));
+  if (!classes_ok(d, bt)) return CTRLSIM_EINVAL;
+  const Ws w = carve(d, bt, static_cast<char*>(workspace));
+  const int P = d.P, ti = Tq - 1, rL = (int)bt.rL, rQ = (int)bt.rQ;
+  CHK(launch_fill_index(bt, w, P, ti, Tq, qoff, st));
   // ---- token embeddings (encoder.py:95-153)
-  CHK(launch_in_mlp(c->st12, 12, 12, m->embed_state.l0.w, m->embed_state.l0.b, m->embed_state.ln.g, m->embed_state.ln.b,
-                    w.hS, DM, rS, st));
-  CHK(gemm(m->fold_state, w.hS, DM, nullptr, 0, w.S2, DM, rS, DM, DM, 0, st));
-  CHK(launch_in_mlp(c->goal5, 5, 5, m->embed_goal.l0.w, m->embed_goal.l0.b, m->embed_goal.ln.g, m->embed_goal.ln.b, w.hG,
-                    DM, rA, st));
-  CHK(gemm(m->fold_goal, w.hG, DM, nullptr, 0, w.Gp, DM, rA, DM, DM, 0, st));
-  CHK(launch_assemble_tokens(B, Tq, A, Ar, w.S2, w.Gp, c->exist, c->act_tok, c->rtg_bin, c->tstep, m->tb, w.X, w.src, M, P,
-                             w.src_pad, st));
-  CHK(scene_side(m, sh, w, c, B, dbg_seg_emb, st));
-  // ---- decoder (decoder.py:52): layers 0..ND-2 on all L tokens
+  CHK(embed_inputs(m, bt, w, Tq, true, st));
+  for (int k = 0; k < bt.n; ++k) {
+    const Cls& c = bt.c[k];
+    CHK(launch_assemble_tokens(c.B, Tq, c.sh.A, c.sh.Areg, w.S2 + c.rS * DM, w.Gp + c.rA * DM, c.ctx->exist, c.ctx->act_tok,
+                               c.ctx->rtg_bin, c.ctx->tstep, m->tb, w.X + c.rL * DM, w.src + c.rM * DM, c.M, P, w.src_pad + c.rM, st));
+  }
+  CHK(scene_side(m, bt, w, dbg_seg_emb, st));
+  // ---- decoder (decoder.py:52): layers 0..ND-2 on all tokens
   for (int i = 0; i < d.ND; ++i) {
     const DecLayer& Ld = m->dec[i];
-    CHK(gemm_kv(Ld.qkv, w.X, DM, w.qkv[i], 3 * DM, B, L, 3 * DM, DM, DM, w.img_dec[i], w.nkt_dec, st, Lreg, sh.rep_k0(Tq),
-                w.key_all, w.img_dec_bytes));
+    CHK(gemm_kv(d, bt, w, Ld.qkv, w.X, w.qkv[i], 3 * DM, 3 * DM, DM, w.img_dec[i], false, st));
     if (i < d.ND - 1) {
-      CHK(attention_kv(amode, w.qkv[i], 3 * DM, (long)L * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
-                       w.img_dec[i], w.nkt_dec, w.att, DM, (long)L * DM, nullptr, nullptr, B, L, Lreg, Ar, st, rep));
+      CHK(attention(d, bt, w, AttnCall{amode, Q_ALL, w.qkv[i], 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, w.img_dec[i], false,
+                                       w.att, Tq, Tq, 0}, st));
       CHK(gemm_ln(Ld.out, Ld.n1, w.att, DM, w.X, DM, w.X, DM, w.tmp, rL, DM, 0, st));
-      CHK(cross_and_ffn(m, sh, Ld, i, w, w.X, w.tmp, w.att, w.qc, w.ffn, rL, B, L, st));
+      CHK(cross_and_ffn(m, bt, Ld, i, w, w.X, w.tmp, w.att, w.qc, w.ffn, bt.rL, Q_ALL, 0, st));
     } else {
       // last layer: only the queried tokens of the current timestep (state tokens; Trajeglish: action tokens) of the regular slots
       CHK(launch_row_copy(w.X, DM, w.xc, DM, w.idx_state, rQ, DM, 0, st));
       CHK(launch_row_copy(w.qkv[i], 3 * DM, w.qkvc, 3 * DM, w.idx_state, rQ, 3 * DM, 0, st));
-      CHK(attention_kv(amode, w.qkvc, 3 * DM, (long)Ar * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
-                       w.img_dec[i], w.nkt_dec, w.attc, DM, (long)Ar * DM, w.pos_state, nullptr, B, Ar, Lreg, Ar, st, rep));
+      CHK(attention(d, bt, w, AttnCall{amode, Q_STATE, w.qkvc, 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, w.img_dec[i], false,
+                                       w.attc, Tq, Tq, 0}, st));
       CHK(gemm_ln(Ld.out, Ld.n1, w.attc, DM, w.xc, DM, w.xc, DM, w.tmpc, rQ, DM, 0, st));
-      CHK(cross_and_ffn(m, sh, Ld, i, w, w.xc, w.tmpc, w.attc, w.qcc, w.ffnc, rQ, B, Ar, st));
+      CHK(cross_and_ffn(m, bt, Ld, i, w, w.xc, w.tmpc, w.attc, w.qcc, w.ffnc, bt.rQ, Q_STATE, 0, st));
     }
   }
   // ---- predict_rtg head on the state tokens (decoder.py:74-77) / predict_action for the baselines (decoder.py:58-64)
@@ -505,10 +628,14 @@ int forward_full(const ctrlsim_model* m, int B, int Tq, int Actx, const ctrlsim_
 }
 }  // namespace
 
+extern "C" int ctrlsim_dt_forward_pass1_c(const ctrlsim_model* m, int n, const int* B, const int* A, const ctrlsim_ctx* ctx, int Tq,
+                                          void* workspace, float* rtg_logits, float* dbg_seg_emb, hipStream_t st) {
+  if (!m || !ctx || !workspace || !rtg_logits || Tq < 1 || Tq > m->d.T || m->d.variant != 0) return CTRLSIM_EINVAL;
+  return forward_full(m, n, B, A, ctx, Tq, workspace, rtg_logits, dbg_seg_emb, st);
+}
 extern "C" int ctrlsim_dt_forward_pass1_a(const ctrlsim_model* m, int B, int Tq, int Actx, const ctrlsim_ctx* c, void* workspace,
                                           float* rtg_logits, float* dbg_seg_emb, hipStream_t st) {
-  if (!m || !c || !workspace || !rtg_logits || B < 1 || Tq < 1 || Tq > m->d.T || m->d.variant != 0) return CTRLSIM_EINVAL;
-  return forward_full(m, B, Tq, Actx, c, workspace, rtg_logits, dbg_seg_emb, st);
+  return ctrlsim_dt_forward_pass1_c(m, 1, &B, &Actx, c, Tq, workspace, rtg_logits, dbg_seg_emb, st);
 }
 extern "C" int ctrlsim_dt_forward_pass1(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* c, void* workspace,
                                         float* rtg_logits, float* dbg_seg_emb, hipStream_t st) {
@@ -517,38 +644,58 @@ extern "C" int ctrlsim_dt_forward_pass1(const ctrlsim_model* m, int B, int Tq, c
 extern "C" int ctrlsim_dt_forward_actions(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* c, void* workspace,
                                           float* act_logits, hipStream_t st) {
   if (!m || !c || !workspace || !act_logits || B < 1 || Tq < 1 || Tq > m->d.T || m->d.variant == 0) return CTRLSIM_EINVAL;
-  return forward_full(m, B, Tq, m->d.A, c, workspace, act_logits, nullptr, st);
+  const int A = m->d.A;
+  return forward_full(m, 1, &B, &A, c, Tq, workspace, act_logits, nullptr, st);
 }
 
 // ------------------------------------------------------------------------------------------------ pass 2
-extern "C" int ctrlsim_dt_forward_pass2_a(const ctrlsim_model* m, int B, int Tq, int Actx, int t, int N, int Tmax,
-                                          const ctrlsim_ctx* c, const int* ctx_scn, const int* hist_rtg, void* workspace,
+extern "C" int ctrlsim_dt_forward_pass2_c(const ctrlsim_model* m, int n, const int* Bk, const int* Ak, const ctrlsim_ctx* ctx, int Tq,
+                                          int t, int N, int Tmax, const int* ctx_scn, const int* hist_rtg, void* workspace,
                                           float* act_logits, int cached, hipStream_t st) {
-  if (!m || !c || !workspace || !act_logits || B < 1 || Tq < 1 || Tq > m->d.T || m->d.variant != 0) return CTRLSIM_EINVAL;
+  if (!m || !ctx || !workspace || !act_logits || Tq < 1 || Tq > m->d.T || m->d.variant != 0) return CTRLSIM_EINVAL;
   const ctrlsim_dims& d = m->d;
-  if (!actx_ok(d, Actx)) return CTRLSIM_EINVAL;
-  const Shape sh = shape_of(d, Actx);
-  // cached mode: the workspace is carved for the full window (K/V cache rows at b * rows(T) + position) and the context
+  // cached mode: the workspace is carved for the full window (K/V cache rows at rows(T) per context) and the context
   // tensors hold only the last Tn = min(Tq, 2) window rows
   const int Tw = cached ? d.T : Tq;
-  const Ws w = carve(d, sh, B, Tw, static_cast<char*>(workspace));
-  const int Ar = sh.Areg, L = sh.rows(Tw), rQ = B * Ar;
   const int ctx_rows = cached ? (Tq < 2 ? Tq : 2) : Tq, ti = ctx_rows - 1;
-  const Rep rep{sh.rep * 3 * Tq, sh.mult, sh.lreg(Tw)};
-  CHK(launch_assemble_rtg_rows(B, Ar, sh.A, ctx_rows, ti, t, N, Tmax, ctx_scn, c->slot_gid, hist_rtg, c->exist, c->tstep, m->tb,
-                               m->zero_rtg, w.xc2, st));
+  Batch bt, lay;
+  CHK(make_batch(d, n, Bk, Ak, ctx, Tw, ctx_rows, 4, bt));
+  CHK(make_batch(d, n, Bk, Ak, ctx, Tw, cached ? 2 : ctx_rows, 4, lay));   // cached: the layout of ctrlsim_dt_forward_pass1_cached_c
+  if (!classes_ok(d, bt)) return CTRLSIM_EINVAL;
+  const Ws w = carve(d, lay, static_cast<char*>(workspace));
+  const int rQ = (int)bt.rQ;
+  int c0 = 0;
+  for (int k = 0; k < bt.n; ++k) {
+    const Cls& c = bt.c[k];
+    CHK(launch_assemble_rtg_rows(c.B, c.sh.Areg, c.sh.A, ctx_rows, ti, t, N, Tmax, ctx_scn + c0, c.ctx->slot_gid, hist_rtg,
+                                 c.ctx->exist, c.ctx->tstep, m->tb, m->zero_rtg, w.xc2 + c.rQ * DM, st));
+    c0 += c.B;
+  }
   for (int i = 0; i < d.ND; ++i) {
     const DecLayer& Ld = m->dec[i];
     CHK(gemm(Ld.qkv, w.xc2, DM, nullptr, 0, w.qkvc, 3 * DM, rQ, 3 * DM, DM, 0, st));
     CHK(launch_row_copy(w.qkvc, 3 * DM, w.qkv[i], 3 * DM, w.idx_rtg, rQ, 3 * DM, 1, st));   // refresh the rtg rows' K/V
-    CHK(kv_split_rows(w.qkvc + DM, w.qkvc + 2 * DM, 3 * DM, (long)Ar * 3 * DM, w.pos_rtg, B, Ar, w.nkt_dec, w.img_dec[i], st));
-    CHK(attention_kv(1, w.qkvc, 3 * DM, (long)Ar * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)L * 3 * DM,
-                     w.img_dec[i], w.nkt_dec, w.attc, DM, (long)Ar * DM, w.pos_rtg, nullptr, B, Ar, Tq * Ar * 3, Ar, st, rep));   // keys: steps <= current
+    if (presplit()) {
+      const size_t KIMG = (size_t)2 * NPL * 64 * HD;
+      for (int k = 0; k < bt.n; ++k) {
+        const Cls& c = bt.c[k];
+        const float* Kp = w.qkvc + c.rQ * 3 * DM + DM;
+        CHK(launch_kv_split_rows(Kp, Kp + DM, 3 * DM, (long)c.sh.Areg * 3 * DM, w.pos_rtg + c.ioff, c.B, c.sh.Areg, c.nkt_dec,
+                                 static_cast<op_t*>(w.img_dec[i]) + (size_t)c.tile_dec * KIMG, st));
+      }
+    }
+    CHK(attention(d, bt, w, AttnCall{1, Q_RTG, w.qkvc, 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, w.img_dec[i], false, w.attc,
+                                     Tq, Tw, 0}, st));   // keys: steps <= current
     CHK(gemm_ln(Ld.out, Ld.n1, w.attc, DM, w.xc2, DM, w.xc2, DM, w.tmpc, rQ, DM, 0, st));
-    CHK(cross_and_ffn(m, sh, Ld, i, w, w.xc2, w.tmpc, w.attc, w.qcc, w.ffnc, rQ, B, Ar, st));
+    CHK(cross_and_ffn(m, bt, Ld, i, w, w.xc2, w.tmpc, w.attc, w.qcc, w.ffnc, bt.rQ, Q_RTG, 0, st));
   }
   CHK(mlp_tail(m->head_action, w.xc2, rQ, w.headh, act_logits, d.V, st));
   return CTRLSIM_OK;
+}
+extern "C" int ctrlsim_dt_forward_pass2_a(const ctrlsim_model* m, int B, int Tq, int Actx, int t, int N, int Tmax,
+                                          const ctrlsim_ctx* c, const int* ctx_scn, const int* hist_rtg, void* workspace,
+                                          float* act_logits, int cached, hipStream_t st) {
+  return ctrlsim_dt_forward_pass2_c(m, 1, &B, &Actx, c, Tq, t, N, Tmax, ctx_scn, hist_rtg, workspace, act_logits, cached, st);
 }
 extern "C" int ctrlsim_dt_forward_pass2(const ctrlsim_model* m, int B, int Tq, int t, int N, int Tmax,
                                         const ctrlsim_ctx* c, const int* ctx_scn, const int* hist_rtg, void* workspace,
@@ -560,62 +707,85 @@ extern "C" int ctrlsim_dt_forward_pass2(const ctrlsim_model* m, int B, int Tq, i
 // ------------------------------------------------------------------------------------------------ pass 1, cached
 // While t < T the window starts at step 0, so the frame of a context (focal pose at window index 0), its membership
 // and its map never change: the scene side is computed once (t == 0) and the decoder K/V of every layer are cached at
-// fixed rows (b * rows(T) + position).  Step t only evaluates the rows whose inputs changed — the action tokens of step
+// fixed rows (rows(T) per context).  Step t only evaluates the rows whose inputs changed — the action tokens of step
 // t-1 (placeholder -> applied action) and the three tokens of step t of every slot — against the cache: 4A rows instead of
 // 3A*(t+1).  No other hidden state changes: an action token is visible only to later timesteps and to itself (mask closed form).
-// ctx holds the window rows [max(t-1,0), t]; the workspace must be the one used at t-1 (sized with Tq = T).
-extern "C" int ctrlsim_dt_forward_pass1_cached_a(const ctrlsim_model* m, int B, int t, int Actx, const ctrlsim_ctx* c,
-                                                 void* workspace, float* rtg_logits, hipStream_t st) {
-  if (!m || !c || !workspace || !rtg_logits || B < 1 || t < 0 || t >= m->d.T || m->d.variant != 0) return CTRLSIM_EINVAL;
+// ctx holds the window rows [max(t-1,0), t]; the workspace must be the one used at t-1 (same classes, sized with Tq = T).
+extern "C" int ctrlsim_dt_forward_pass1_cached_c(const ctrlsim_model* m, int n, const int* Bk, const int* Ak, const ctrlsim_ctx* ctx,
+                                                 int t, void* workspace, float* rtg_logits, hipStream_t st) {
+  if (!m || !ctx || !workspace || !rtg_logits || t < 0 || t >= m->d.T || m->d.variant != 0) return CTRLSIM_EINVAL;
   const ctrlsim_dims& d = m->d;
-  if (!actx_ok(d, Actx)) return CTRLSIM_EINVAL;
-  const Shape sh = shape_of(d, Actx);
-  const Ws w = carve(d, sh, B, d.T, static_cast<char*>(workspace));
-  const int A = sh.A, Ar = sh.Areg, P = d.P, M = P + A, Lf = sh.rows(d.T), Lreg_f = sh.lreg(d.T);
-  const int Rn = (t > 0 ? 4 : 3) * A, tt_first = t > 0 ? t - 1 : 0, Tn = t + 1 - tt_first;
-  const int rA = B * A, rQ = B * Ar, rN = B * Rn, rS = B * Tn * A;
-  const Rep rep{sh.rep * 3 * (t + 1), sh.mult, Lreg_f};
+  const int P = d.P, mul = t > 0 ? 4 : 3, tt_first = t > 0 ? t - 1 : 0, Tn = t + 1 - tt_first;
+  Batch bt;
+  CHK(make_batch(d, n, Bk, Ak, ctx, d.T, Tn, mul, bt));
+  if (!classes_ok(d, bt)) return CTRLSIM_EINVAL;
+  Batch bt4;                                       // the workspace layout never changes with t: carve with 4A new rows
+  CHK(make_batch(d, n, Bk, Ak, ctx, d.T, 2, 4, bt4));
+  Ws w = carve(d, bt4, static_cast<char*>(workspace));
+  const int rQ = (int)bt.rQ, rN = (int)bt.rN;
   auto fill_cached = [&]() {
-    hipLaunchKernelGGL(fill_index_cached_kernel, dim3((rN + 255) / 256), dim3(256), 0, st, B, A, Ar, Lf, Lreg_f, sh.rep_k0(d.T), t,
-                       Rn, w.pos_new, w.key_new, w.src_new, w.idx_new, w.idx_state_in_new, w.pos_rtg, w.idx_rtg);
+    for (int k = 0; k < bt.n; ++k) {
+      const Cls& c = bt.c[k];
+      const int Rn = mul * c.sh.A;
+      hipLaunchKernelGGL(fill_index_cached_kernel, dim3((c.B * Rn + 255) / 256), dim3(256), 0, st, c.B, c.sh.A, c.sh.Areg, c.L, c.Lreg,
+                         c.sh.rep_k0(d.T), t, Rn, c.rL, c.rN, w.pos_new + 4 * c.ioff, w.key_new + 4 * c.ioff, w.src_new + 4 * c.ioff,
+                         w.idx_new + c.rN, w.idx_state_in_new + c.rQ, w.pos_rtg + c.ioff, w.idx_rtg + c.rQ);
+    }
   };
   fill_cached();
-  CHK(launch_in_mlp(c->st12, 12, 12, m->embed_state.l0.w, m->embed_state.l0.b, m->embed_state.ln.g, m->embed_state.ln.b,
-                    w.hS, DM, rS, st));
-  CHK(gemm(m->fold_state, w.hS, DM, nullptr, 0, w.S2, DM, rS, DM, DM, 0, st));
+  CHK(embed_inputs(m, bt, w, Tn, t == 0, st));
   if (t == 0) {
-    CHK(launch_in_mlp(c->goal5, 5, 5, m->embed_goal.l0.w, m->embed_goal.l0.b, m->embed_goal.ln.g, m->embed_goal.ln.b, w.hG,
-                      DM, rA, st));
-    CHK(gemm(m->fold_goal, w.hG, DM, nullptr, 0, w.Gp, DM, rA, DM, DM, 0, st));
-    const int nidx = max(max(rA, B * P), 3 * A);
-    hipLaunchKernelGGL(fill_index_kernel, dim3((nidx + 255) / 256), dim3(256), 0, st, B, Ar, 3 * A, 3 * Ar, 0, 0, P, M, 0,
-                       w.pos_state, w.pos_rtg, w.idx_state, w.idx_rtg, w.idx_poly, w.key_all);
-    // token order of assemble_tokens at Tq = 1 is the pos_new order (regular (a, k), then the representative); it also writes
-    // the initial-state rows of `src`
-    CHK(launch_assemble_tokens(B, 1, A, Ar, w.S2, w.Gp, c->exist, c->act_tok, c->rtg_bin, c->tstep, m->tb, w.xn, w.src, M, P,
-                               w.src_pad, st));
-    CHK(scene_side(m, sh, w, c, B, nullptr, st));
-    fill_cached();                                 // pos_rtg / idx_rtg for the cache layout
+    // index lists of the Tq = 1 layout for the scene side (idx_poly); pos_rtg / idx_rtg are rewritten for the cache layout below
+    for (int k = 0; k < bt.n; ++k) {
+      const Cls& c = bt.c[k];
+      const int nidx = max(max(c.B * c.sh.A, c.B * P), 3 * c.sh.A);
+      hipLaunchKernelGGL(fill_index_kernel, dim3((nidx + 255) / 256), dim3(256), 0, st, c.B, c.sh.Areg, 3 * c.sh.A, 3 * c.sh.Areg, 0, 0, P,
+                         c.M, 0, c.rN, c.rM, w.pos_state + c.ioff, w.pos_rtg + c.ioff, w.idx_state + c.rQ, w.idx_rtg + c.rQ,
+                         w.idx_poly + c.rP, w.key_all + c.koff);
+      // token order of assemble_tokens at Tq = 1 is the pos_new order (regular (a, k), then the representative); it also writes
+      // the initial-state rows of `src`
+      CHK(launch_assemble_tokens(c.B, 1, c.sh.A, c.sh.Areg, w.S2 + c.rS * DM, w.Gp + c.rA * DM, c.ctx->exist, c.ctx->act_tok,
+                                 c.ctx->rtg_bin, c.ctx->tstep, m->tb, w.xn + c.rN * DM, w.src + c.rM * DM, c.M, P, w.src_pad + c.rM,
+                                 st));
+    }
+    CHK(scene_side(m, bt, w, nullptr, st));
+    fill_cached();
   } else {
-    CHK(launch_assemble_rows(B, Rn, A, tt_first, Tn, w.src_new, w.S2, w.Gp, c->exist, c->act_tok, c->rtg_bin, c->tstep, m->tb,
-                             w.xn, st));
+    for (int k = 0; k < bt.n; ++k) {
+      const Cls& c = bt.c[k];
+      CHK(launch_assemble_rows(c.B, mul * c.sh.A, c.sh.A, tt_first, Tn, w.src_new + 4 * c.ioff, w.S2 + c.rS * DM, w.Gp + c.rA * DM,
+                               c.ctx->exist, c.ctx->act_tok, c.ctx->rtg_bin, c.ctx->tstep, m->tb, w.xn + c.rN * DM, st));
+    }
   }
+  const size_t KIMG = (size_t)2 * NPL * 64 * HD;
   for (int i = 0; i < d.ND; ++i) {
     const DecLayer& Ld = m->dec[i];
     CHK(gemm(Ld.qkv, w.xn, DM, nullptr, 0, w.qkvn, 3 * DM, rN, 3 * DM, DM, 0, st));
     CHK(launch_row_copy(w.qkvn, 3 * DM, w.qkv[i], 3 * DM, w.idx_new, rN, 3 * DM, 1, st));       // K/V (and Q) into the cache
-    if (t == 0 && presplit()) {   // image tiles are read whole: stale bits beyond the written rows must at least be finite
-      if (hipMemsetAsync(w.img_dec[i], 0, w.img_dec_bytes, st) != hipSuccess) return CTRLSIM_ELAUNCH;
+    if (presplit()) {
+      if (t == 0) {   // image tiles are read whole: stale bits beyond the written rows must at least be finite
+        if (hipMemsetAsync(w.img_dec[i], 0, w.img_dec_bytes, st) != hipSuccess) return CTRLSIM_ELAUNCH;
+      }
+      for (int k = 0; k < bt.n; ++k) {
+        const Cls& c = bt.c[k];
+        const int Rn = mul * c.sh.A;
+        const float* Kp = w.qkvn + c.rN * 3 * DM + DM;
+        CHK(launch_kv_split_rows(Kp, Kp + DM, 3 * DM, (long)Rn * 3 * DM, w.key_new + 4 * c.ioff, c.B, Rn, c.nkt_dec,
+                                 static_cast<op_t*>(w.img_dec[i]) + (size_t)c.tile_dec * KIMG, st));
+      }
     }
-    CHK(kv_split_rows(w.qkvn + DM, w.qkvn + 2 * DM, 3 * DM, (long)Rn * 3 * DM, w.key_new, B, Rn, w.nkt_dec, w.img_dec[i], st));
-    CHK(attention_kv(1, w.qkvn, 3 * DM, (long)Rn * 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, (long)Lf * 3 * DM,
-                     w.img_dec[i], w.nkt_dec, w.attn_n, DM, (long)Rn * DM, w.pos_new, nullptr, B, Rn, (t + 1) * Ar * 3, Ar, st, rep));
+    CHK(attention(d, bt, w, AttnCall{1, Q_NEW, w.qkvn, 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, w.img_dec[i], false, w.attn_n,
+                                     t + 1, d.T, mul}, st));
     CHK(gemm_ln(Ld.out, Ld.n1, w.attn_n, DM, w.xn, DM, w.xn, DM, w.tmpn, rN, DM, 0, st));
-    CHK(cross_and_ffn(m, sh, Ld, i, w, w.xn, w.tmpn, w.attn_n, w.qcn, w.ffnn, rN, B, Rn, st));
+    CHK(cross_and_ffn(m, bt, Ld, i, w, w.xn, w.tmpn, w.attn_n, w.qcn, w.ffnn, bt.rN, Q_NEW, mul, st));
   }
   CHK(launch_row_copy(w.xn, DM, w.xc, DM, w.idx_state_in_new, rQ, DM, 0, st));
   CHK(mlp_tail(m->head_rtg, w.xc, rQ, w.headh, rtg_logits, d.R * d.C, st));
   return CTRLSIM_OK;
+}
+extern "C" int ctrlsim_dt_forward_pass1_cached_a(const ctrlsim_model* m, int B, int t, int Actx, const ctrlsim_ctx* c,
+                                                 void* workspace, float* rtg_logits, hipStream_t st) {
+  return ctrlsim_dt_forward_pass1_cached_c(m, 1, &B, &Actx, c, t, workspace, rtg_logits, st);
 }
 extern "C" int ctrlsim_dt_forward_pass1_cached(const ctrlsim_model* m, int B, int t, const ctrlsim_ctx* c, void* workspace,
                                                float* rtg_logits, hipStream_t st) {

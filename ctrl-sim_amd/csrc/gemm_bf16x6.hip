@@ -44,8 +44,22 @@ __device__ __forceinline__ void term(f32x16 (&acc)[MR][2], const opx8 (&fa)[MR][
 // KVIMG = true (2x2 tiles, plain Linear): output columns >= kv.k_col0 are attention keys (256 columns) and values (the
 // next 256) and are written NOT as fp32 rows but directly as the split-bf16 K / V^T tile images the attention kernel
 // stages by DMA (attention_bf16x6.hip: layout at kv_split_kernel) — the K/V split costs no extra pass over HBM.
-struct KvImg { op_t* img; int L; int nkt; int k_col0; int Lreg; int rep_k0; };   // L = rows per context; rows >= Lreg (the
-// representative tokens of a compact context, attention_bf16x6.hip) are keys rep_k0 + (row - Lreg), the others key = row
+// Up to 8 classes of contexts share one launch (rows [row0, next row0) belong to class c): L rows per context, of which the rows
+// >= Lreg (the representative tokens of a compact context, attention_bf16x6.hip) are keys rep_k0 + (row - Lreg), the others
+// key = row; nkt tiles per (context, head), the class's images start at tile tile0.
+struct KvClass { int row0, L, Lreg, rep_k0, nkt; long tile0; };
+struct KvImg { op_t* img; int k_col0; int n; KvClass c[8]; };
+__device__ __forceinline__ void kv_locate(const KvImg& kv, int grow, int& b, int& pos, int& nkt, long& tile0) {
+  int ci = 0;
+  while (ci + 1 < kv.n && grow >= kv.c[ci + 1].row0) ++ci;
+  const KvClass& c = kv.c[ci];
+  const int r = grow - c.row0;
+  b = r / c.L;
+  const int row = r - b * c.L;
+  pos = row < c.Lreg ? row : c.rep_k0 + (row - c.Lreg);
+  nkt = c.nkt;
+  tile0 = c.tile0;
+}
 
 template <int WR, int WC, int MR, bool RELU, bool RESID, bool LN, bool KVIMG = false>
 #ifndef GEMM_OCC_22
@@ -297,7 +311,9 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
           const int lr = tid & 63;
           const int grow = cbm + (lr >> 5) * WMR + a * 32 + (lr & 31);
           if (grow < M) {
-            const int b = grow / kv.L, row = grow - b * kv.L, pos = row < kv.Lreg ? row : kv.rep_k0 + (row - kv.Lreg);
+            int b, pos, nkt;
+            long tile0;
+            kv_locate(kv, grow, b, pos, nkt, tile0);
             const int kt = pos >> 6, key = pos & 63;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -311,7 +327,7 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
               u32x2 pa[NPL], pb[NPL];
               split_quad(x0, pa);
               split_quad(x1, pb);
-              op_t* dst = kv.img + (((size_t)b * NHEAD + head0 + hh) * kv.nkt + kt) * KIMG + (dg * 64 + key) * 8;
+              op_t* dst = kv.img + (tile0 + ((size_t)b * NHEAD + head0 + hh) * nkt + kt) * KIMG + (dg * 64 + key) * 8;
 #pragma unroll
               for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x4*>(dst + q * KPL) = u32x4{pa[q][0], pa[q][1], pb[q][0], pb[q][1]};
             }
@@ -324,13 +340,15 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
             const int lr0 = ((tid >> 7) + 2 * i) * 4;                      // a key quad: 4 consecutive rows of one segment
             const int grow0 = cbm + (lr0 >> 5) * WMR + a * 32 + (lr0 & 31);
             if (grow0 < M) {                                               // L % 4 == Lreg % 4 == 0: quads never straddle contexts / regions
-              const int b = grow0 / kv.L, row = grow0 - b * kv.L, pos = row < kv.Lreg ? row : kv.rep_k0 + (row - kv.Lreg);
+              int b, pos, nkt;
+              long tile0;
+              kv_locate(kv, grow0, b, pos, nkt, tile0);
               const int kt = pos >> 6, q = (pos & 63) >> 2;
               const float x0 = Cs[(lr0 + 0) * CP + col] + bv, x1 = Cs[(lr0 + 1) * CP + col] + bv;
               const float x2 = Cs[(lr0 + 2) * CP + col] + bv, x3 = Cs[(lr0 + 3) * CP + col] + bv;
               u32x2 pv[NPL];
               split_quad(f32x4{x0, x1, x2, x3}, pv);
-              op_t* dst = kv.img + (((size_t)b * NHEAD + head0 + hh) * kv.nkt + kt) * KIMG + NPL * KPL + (q * HD + d) * 4;
+              op_t* dst = kv.img + (tile0 + ((size_t)b * NHEAD + head0 + hh) * nkt + kt) * KIMG + NPL * KPL + (q * HD + d) * 4;
 #pragma unroll
               for (int qq = 0; qq < NPL; ++qq) *reinterpret_cast<u32x2*>(dst + qq * KPL) = pv[qq];
             }
@@ -392,15 +410,16 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
   }
 }
 
-int launch_gemm_nt_bf16x6_kv(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias,
-                             const float* R, int ldr, float* C, int ldc, int M, int N, int K, int relu,
-                             const float* ln_gamma, const float* ln_beta, void* kv_img, int kv_L, int kv_nkt, int kv_col0,
-                             int kv_Lreg, int kv_rep_k0, hipStream_t st);
+struct KvClassHost { int B, L, Lreg, rep_k0, nkt; long tile0; };   // B contexts of L rows; class rows follow each other in A / C
+int launch_gemm_nt_bf16x6_kvc(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias,
+                              const float* R, int ldr, float* C, int ldc, int M, int N, int K, int relu,
+                              const float* ln_gamma, const float* ln_beta, void* kv_img, int kv_col0, int kv_n,
+                              const KvClassHost* kv_cls, hipStream_t st);
 int launch_gemm_nt_bf16x6(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias,
                           const float* R, int ldr, float* C, int ldc, int M, int N, int K, int relu,
                           const float* ln_gamma, const float* ln_beta, hipStream_t st) {
-  return launch_gemm_nt_bf16x6_kv(A, lda, W3, n_total, n0, bias, R, ldr, C, ldc, M, N, K, relu, ln_gamma, ln_beta, nullptr, 0, 0,
-                                  0, 0, 0, st);
+  return launch_gemm_nt_bf16x6_kvc(A, lda, W3, n_total, n0, bias, R, ldr, C, ldc, M, N, K, relu, ln_gamma, ln_beta, nullptr, 0, 0,
+                                   nullptr, st);
 }
 // kv_img != NULL: columns [kv_col0, kv_col0 + 512) are keys / values of 8 heads x 32 and go to the split images of
 // kv_nkt 64-key tiles per context of kv_L rows (kv_L % 4 == 0, kv_L >= 32, kv_col0 % 128 == 0, M % kv_L == 0); rows >= kv_Lreg of a
@@ -409,13 +428,34 @@ int launch_gemm_nt_bf16x6_kv(const float* A, int lda, const void* W3, int n_tota
                              const float* R, int ldr, float* C, int ldc, int M, int N, int K, int relu,
                              const float* ln_gamma, const float* ln_beta, void* kv_img, int kv_L, int kv_nkt, int kv_col0,
                              int kv_Lreg, int kv_rep_k0, hipStream_t st) {
+  if (!kv_img) return launch_gemm_nt_bf16x6(A, lda, W3, n_total, n0, bias, R, ldr, C, ldc, M, N, K, relu, ln_gamma, ln_beta, st);
+  if (kv_L <= 0 || M % kv_L) return CTRLSIM_EINVAL;
+  if (kv_Lreg <= 0) { kv_Lreg = kv_L; kv_rep_k0 = 0; }
+  const KvClassHost c{M / kv_L, kv_L, kv_Lreg, kv_rep_k0, kv_nkt, 0};
+  return launch_gemm_nt_bf16x6_kvc(A, lda, W3, n_total, n0, bias, R, ldr, C, ldc, M, N, K, relu, ln_gamma, ln_beta, kv_img, kv_col0,
+                                   1, &c, st);
+}
+int launch_gemm_nt_bf16x6_kvc(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias,
+                              const float* R, int ldr, float* C, int ldc, int M, int N, int K, int relu,
+                              const float* ln_gamma, const float* ln_beta, void* kv_img, int kv_col0, int kv_n,
+                              const KvClassHost* kv_cls, hipStream_t st) {
   if (M <= 0) return CTRLSIM_OK;
-  if (kv_img && kv_Lreg <= 0) { kv_Lreg = kv_L; kv_rep_k0 = 0; }
-  if (kv_img && (ln_gamma || R || relu || (kv_L & 3) || kv_L < 32 || (kv_col0 & 127) || N != kv_col0 + 2 * DM || M % kv_L ||
-                 (kv_Lreg & 3) || kv_Lreg > kv_L || (kv_rep_k0 & 63) || (kv_Lreg < kv_L && kv_rep_k0 < kv_Lreg) ||
-                 kv_nkt * 64 < (kv_Lreg < kv_L ? kv_rep_k0 + (kv_L - kv_Lreg) : kv_L)))
-    return CTRLSIM_EINVAL;
-  const KvImg kv{static_cast<op_t*>(kv_img), kv_L, kv_nkt, kv_col0, kv_Lreg, kv_rep_k0};
+  KvImg kv;
+  kv.img = static_cast<op_t*>(kv_img); kv.k_col0 = kv_col0; kv.n = 0;
+  if (kv_img) {
+    if (ln_gamma || R || relu || (kv_col0 & 127) || N != kv_col0 + 2 * DM || kv_n < 1 || kv_n > 8 || !kv_cls) return CTRLSIM_EINVAL;
+    int row0 = 0;
+    for (int k = 0; k < kv_n; ++k) {
+      const KvClassHost& c = kv_cls[k];
+      if (c.B <= 0) continue;
+      if ((c.L & 3) || c.L < 32 || (c.Lreg & 3) || c.Lreg > c.L || c.Lreg <= 0 || (c.rep_k0 & 63) ||
+          (c.Lreg < c.L && c.rep_k0 < c.Lreg) || c.nkt * 64 < (c.Lreg < c.L ? c.rep_k0 + (c.L - c.Lreg) : c.L))
+        return CTRLSIM_EINVAL;
+      kv.c[kv.n++] = KvClass{row0, c.L, c.Lreg, c.rep_k0, c.nkt, c.tile0};
+      row0 += c.B * c.L;
+    }
+    if (row0 != M) return CTRLSIM_EINVAL;
+  }
   if (K % XK != 0 || (lda & 3) || N <= 0 || !W3 || n0 < 0 || n0 + N > n_total) return CTRLSIM_EINVAL;
   const bool ln = ln_gamma != nullptr;
   if (ln && (N != 256 || (ldc & 3) || (R && (ldr & 3)))) return CTRLSIM_EINVAL;

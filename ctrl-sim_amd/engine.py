@@ -203,7 +203,7 @@ class RolloutEngine:
         # workspace bytes per context of each class (the carve is linear in B up to alignment), + a fixed allowance per class
         wb = self.model.workspace_bytes
         self._bpc = [(wb(257, self.dims.T, a) - wb(1, self.dims.T, a)) / 256.0 for a in self.sizes]
-        self._ws_fixed = sum(wb(1, self.dims.T, a) for a in self.sizes)
+        self._ws_fixed = sum(wb(1, self.dims.T, a) for a in self.sizes) + (1 << 20)
         self.n_lanes = max(1, int(lanes))
         self.lanes = [_Lane(self, i, self.n_lanes > 1) for i in range(self.n_lanes)]
         L0 = self.lanes[0]                   # the synchronous single-stream entry points (policy_step / step) use lane 0
@@ -321,23 +321,25 @@ class RolloutEngine:
         chunks.append((base + s0, base + len(hist), hist[s0:].sum(0)))
         return [(a, b, [int(x) for x in c]) for (a, b, c) in chunks if b > a]
 
-    def _class_plan(self, counts, Tw, Tn):
-        """Per non-empty size class of a model batch: (B_k, A_k, first context, first logits row, workspace offset, ctx struct).
-        Tw = window steps the workspace is carved for, Tn = window rows held by the context tensors."""
-        d = self.dims
-        plan, c0, r0, w0 = [], 0, 0, 0
-        structs = None
+    def _class_plan(self, L, counts, Tw, Tn):
+        """The non-empty size classes of a model batch as the arguments of the batch entry points: ([(B_k, A_k, first context,
+        ctx struct)], n, B[] (c_int array), A[], ctx[] (ctrlsim_ctx array)).  Tw = window steps the workspace is carved for,
+        Tn = window rows held by the context tensors."""
         classes = [(B, A) for B, A in zip(counts, self.sizes)]
+        structs = L.ctx.class_structs(classes, Tn)
+        plan, c0 = [], 0
         for k, (B, A) in enumerate(classes):
             if B > 0:
-                if structs is None:
-                    structs = self._plan_lane.ctx.class_structs(classes, Tn)
-                plan.append((B, A, c0, r0, w0, structs[k]))
-                w0 += (self.model.workspace_bytes(B, Tw, A) + 255) // 256 * 256
+                plan.append((B, A, c0, structs[k]))
             c0 += B
-            r0 += B * (A - 1 if A < d.A else A)
-        assert w0 <= self._ws_cap, "model batch exceeds the lane workspace"
-        return plan
+        n = len(plan)
+        Bs = (C.c_int * max(n, 1))(*[q[0] for q in plan])
+        As = (C.c_int * max(n, 1))(*[q[1] for q in plan])
+        cs = (_lib.Ctx * max(n, 1))(*[q[3] for q in plan])
+        if n:
+            need = self.lib.ctrlsim_forward_workspace_bytes_c(C.byref(self.model.cdims), n, Bs, As, Tw)
+            assert 0 < need <= self._ws_cap, "model batch exceeds the lane workspace"
+        return plan, n, Bs, As, cs
 
     # ------------------------------------------------------------------ kernels of one step, on explicit streams
     def sim_step(self, t, act_f64=None, s0=0, s1=None, stream=None):
@@ -424,7 +426,7 @@ class RolloutEngine:
     def _build_contexts(self, L, plan, t, Tq, tt_first, st):
         lib, p, d = self.lib, _lib.ptr, self.dims
         Tmax = self.steps
-        for (B, A, c0, r0, w0, cs) in plan:
+        for (B, A, c0, cs) in plan:
             _lib.check(lib.ctrlsim_build_context(B, self.N, A, d.T, t, Tq, tt_first, Tmax + 1, Tmax, self.P_all, d.P, d.NP,
                                                  p(L.ctx_scn[c0:]), p(L.ctx_grp[c0:]), p(self.grp_focal), p(self.grp_ids),
                                                  p(self.hist_states), p(self.hist_tok), p(self.hist_rtg), p(self.goals),
@@ -453,19 +455,16 @@ class RolloutEngine:
         lib, p, st, d = self.lib, _lib.ptr, self._main.cuda_stream, self.dims
         N, Tmax = self.N, self.steps
         Tq, tt_first = t + 1, max(t - 1, 0)
-        self._plan_lane = L
-        plan = self._class_plan(counts, d.T, Tq - tt_first)
-        RC, V = d.R * d.C * 4, d.V * 4
+        plan, n, Bs, As, cs = self._class_plan(L, counts, d.T, Tq - tt_first)
         self._ctx_index(L, s0, s1, st)
         self._build_contexts(L, plan, t, Tq, tt_first, st)
-        for (B, A, c0, r0, w0, cs) in plan:
-            _lib.check(lib.ctrlsim_dt_forward_pass1_cached_a(self.model.handle, B, t, A, C.byref(cs), L.ws.data_ptr() + w0,
-                                                             L.rtg_logits.data_ptr() + r0 * RC, st), "pass1_cached")
+        if n:
+            _lib.check(lib.ctrlsim_dt_forward_pass1_cached_c(self.model.handle, n, Bs, As, cs, t, p(L.ws), p(L.rtg_logits), st),
+                       "pass1_cached")
         self._sample_rtg(L, t, s0, s1, st)
-        for (B, A, c0, r0, w0, cs) in plan:
-            _lib.check(lib.ctrlsim_dt_forward_pass2_a(self.model.handle, B, Tq, A, t, N, Tmax, C.byref(cs), p(L.ctx_scn[c0:]),
-                                                      p(self.hist_rtg), L.ws.data_ptr() + w0, L.act_logits.data_ptr() + r0 * V, 1,
-                                                      st), "pass2_cached")
+        if n:
+            _lib.check(lib.ctrlsim_dt_forward_pass2_c(self.model.handle, n, Bs, As, cs, Tq, t, N, Tmax, p(L.ctx_scn),
+                                                      p(self.hist_rtg), p(L.ws), p(L.act_logits), 1, st), "pass2_cached")
         self._sample_action(L, t, s0, s1, st)
 
     def _policy_chunks(self, L, t, hist, lo, hi, noise_rtg=None, noise_act=None):
@@ -474,25 +473,21 @@ class RolloutEngine:
         lib, p, st, d = self.lib, _lib.ptr, self._main.cuda_stream, self.dims
         N, Tmax = self.N, self.steps
         Tq = min(t, d.T - 1) + 1
-        RC, V = d.R * d.C * 4, d.V * 4
-        self._plan_lane = L
         for (s0, s1, counts) in self._chunks(hist, lo):
-            plan = self._class_plan(counts, Tq, Tq)
+            plan, n, Bs, As, cs = self._class_plan(L, counts, Tq, Tq)
             self._ctx_index(L, s0, s1, st)
             self._build_contexts(L, plan, t, Tq, 0, st)
-            for (B, A, c0, r0, w0, cs) in plan:
-                if d.VARIANT:                                # IL / Trajeglish: no RTG tokens, one forward (predict_rtgs False)
-                    _lib.check(lib.ctrlsim_dt_forward_actions(self.model.handle, B, Tq, C.byref(cs), L.ws.data_ptr() + w0,
-                                                              L.act_logits.data_ptr() + r0 * V, st), "forward_actions")
-                else:
-                    _lib.check(lib.ctrlsim_dt_forward_pass1_a(self.model.handle, B, Tq, A, C.byref(cs), L.ws.data_ptr() + w0,
-                                                              L.rtg_logits.data_ptr() + r0 * RC, None, st), "pass1")
+            if n and d.VARIANT:                              # IL / Trajeglish: no RTG tokens, one forward (predict_rtgs False)
+                _lib.check(lib.ctrlsim_dt_forward_actions(self.model.handle, plan[0][0], Tq, cs, p(L.ws), p(L.act_logits), st),
+                           "forward_actions")
+            elif n:
+                _lib.check(lib.ctrlsim_dt_forward_pass1_c(self.model.handle, n, Bs, As, cs, Tq, p(L.ws), p(L.rtg_logits), None, st),
+                           "pass1")
             if not d.VARIANT:
                 self._sample_rtg(L, t, s0, s1, st, noise_rtg)
-                for (B, A, c0, r0, w0, cs) in plan:
-                    _lib.check(lib.ctrlsim_dt_forward_pass2_a(self.model.handle, B, Tq, A, t, N, Tmax, C.byref(cs),
-                                                              p(L.ctx_scn[c0:]), p(self.hist_rtg), L.ws.data_ptr() + w0,
-                                                              L.act_logits.data_ptr() + r0 * V, 0, st), "pass2")
+                if n:
+                    _lib.check(lib.ctrlsim_dt_forward_pass2_c(self.model.handle, n, Bs, As, cs, Tq, t, N, Tmax, p(L.ctx_scn),
+                                                              p(self.hist_rtg), p(L.ws), p(L.act_logits), 0, st), "pass2")
             self._sample_action(L, t, s0, s1, st, noise_act)
 
     # ------------------------------------------------------------------ a lane's rollout as a generator

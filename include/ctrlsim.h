@@ -138,6 +138,18 @@ int ctrlsim_dt_forward_pass2_a(const ctrlsim_model* m, int B, int Tq, int Actx, 
                                hipStream_t stream);
 int ctrlsim_dt_forward_pass1_cached_a(const ctrlsim_model* m, int B, int t, int Actx, const ctrlsim_ctx* ctx, void* workspace,
                                       float* rtg_logits, hipStream_t stream);
+/* The *_c forms take a model BATCH of n <= 8 classes of compact contexts (class k: B[k] contexts of A[k] slots, context tensors
+ * ctx[k]; host arrays): every row-wise kernel runs once over the rows of all classes, the attention kernel and the K/V-image
+ * epilogue of the QKV projection work from a class table.  Logits rows come class after class, context after context,
+ * regular slot after regular slot (ctrlsim_ctx_index_classes' ctx_row0).  ctx_scn lists the contexts in that same order. */
+int64_t ctrlsim_forward_workspace_bytes_c(const ctrlsim_dims* dims, int n, const int* B, const int* A, int Tq);
+int ctrlsim_dt_forward_pass1_c(const ctrlsim_model* m, int n, const int* B, const int* A, const ctrlsim_ctx* ctx, int Tq,
+                               void* workspace, float* rtg_logits, float* dbg_seg_emb, hipStream_t stream);
+int ctrlsim_dt_forward_pass2_c(const ctrlsim_model* m, int n, const int* B, const int* A, const ctrlsim_ctx* ctx, int Tq, int t,
+                               int N, int Tmax, const int* ctx_scn, const int* hist_rtg, void* workspace, float* act_logits,
+                               int cached, hipStream_t stream);
+int ctrlsim_dt_forward_pass1_cached_c(const ctrlsim_model* m, int n, const int* B, const int* A, const ctrlsim_ctx* ctx, int t,
+                                      void* workspace, float* rtg_logits, hipStream_t stream);
 /* pass 1: rtg_logits [B,A,R*C] of the current-timestep state tokens; caches per-layer K/V in `workspace`. */
 int ctrlsim_dt_forward_pass1(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* ctx, void* workspace,
                              float* rtg_logits, float* dbg_seg_emb /*nullable [B,P,D]*/, hipStream_t stream);
