@@ -207,6 +207,11 @@ class PolicyEvaluator:
             for veh in vehicles:
                 veh.expert_control = False
                 veh.physics_simulated = True
+            if self.cfg.eval.eval_mode != "multi_agent":
+                # one_agent / two_agent pick vehicles with find_interesting_agent / find_interesting_pair
+                # (policy_evaluator.py:308-433, planner evaluation); running multi_agent under that name would evaluate a
+                # different vehicle set than the cfg asks for
+                raise NotImplementedError(f"eval_mode {self.cfg.eval.eval_mode!r}: only 'multi_agent' (policy_evaluator.py:450-454)")
             thr = self.cfg.eval.multi_agent_eval_threshold
             self.vehicles_to_evaluate = random.sample(moving, thr) if len(moving) > thr else moving
             if not self.vehicles_to_evaluate:
@@ -239,11 +244,11 @@ class PolicyEvaluator:
                 vdd[veh.getID()]["acceleration"].append(0)
                 vdd[veh.getID()]["steering"].append(0)
             self.last_vehicle_data_dict = vdd
-            self.update_running_statistics(vdd, scn, gt_data_dict)
+            self.update_running_statistics(vdd, scn, gt_data_dict, goal_dict)
         return self.compute_metrics()
 
     # ---- policy_evaluator.py:162-248 on arrays
-    def update_running_statistics(self, vdd, scn, gt_data_dict):
+    def update_running_statistics(self, vdd, scn, gt_data_dict, goal_dict=None):
         ids = list(vdd.keys())
         T1 = self.steps + 1
         st = np.zeros((len(ids), T1, 8))
@@ -260,8 +265,14 @@ class PolicyEvaluator:
             accel[i] = d["acceleration"]
             tr = gt_data_dict[v]["traj"]
             gt[i] = tr[:, [0, 1, 2, 3, 4]]
-        self.acc.add_scenario(st, coll, accel, gt, scn.goal_pos.astype(np.float64), scn.goal_heading.astype(np.float64),
-                              scn.goal_speed.astype(np.float64), self.cfg, eval_ids=[ids.index(v) for v in self.vehicles_to_evaluate])
+        # goals as the loop used them (initialize_goal_dict moves the goal of a vehicle that leaves the log to its last logged pose;
+        # the reference reads the 'goal' flag from the rewards computed with that goal_dict, policy_evaluator.py:162-186)
+        if goal_dict is None:
+            goal_dict = {v: self.initialize_goal_dict(scn, v, np.array(gt_data_dict[v]["traj"])) for v in ids}
+        gp = np.array([np.asarray(goal_dict[v]["pos"], np.float64) for v in ids])
+        gh = np.array([float(goal_dict[v]["heading"]) for v in ids])
+        gs = np.array([float(goal_dict[v]["speed"]) for v in ids])
+        self.acc.add_scenario(st, coll, accel, gt, gp, gh, gs, self.cfg, eval_ids=[ids.index(v) for v in self.vehicles_to_evaluate])
 
     def compute_metrics(self):
         return self.acc.compute()

@@ -108,8 +108,8 @@ class MetricAccumulators:
             self._h("lin_gt", np.clip(gt_states[v, m, 3], 0, 30), "lin")
             self._h("ang_sim", np.clip(states[v, m, 4] / dt, -50, 50), "ang")     # "angular speed" as written, :219-220
             self._h("ang_gt", np.clip(gt_states[v, m, 2] / dt, -50, 50), "ang")
-            gt_acc = np.zeros(T1)
-            gt_acc[1:-1] = (gt_states[v, 2:, 3] - gt_states[v, :-2, 3]) / (2 * dt)
+            gt_acc = np.zeros(T1)                        # central difference for 0 < t < steps - 1, else 0 (policy_evaluator.py:106-111:
+            gt_acc[1:T1 - 2] = (gt_states[v, 2:T1 - 1, 3] - gt_states[v, :T1 - 3, 3]) / (2 * dt)   # steps - 1 and steps are both 0)
             am = np.ones(m.sum(), bool)
             am[0] = am[-1] = False
             ga = gt_acc[m][am]

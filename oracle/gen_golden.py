@@ -276,6 +276,155 @@ def gen_closed_loop_full():
     save("closed_loop_full", **out)
 
 
+# --------------------------------------------------------------------------------------------- E2: evaluator metrics
+def _install_evaluator_stubs():
+    """Make the reference's evaluators/policy_evaluator.py importable: it pulls in nocturne (pybind, unbuildable here), imageio,
+    matplotlib, hydra and the dataset package at module top.  Only the pybind surface is faked (an enum and a class name); the
+    arithmetic under test — Evaluator.initialize_goal_dict / compute_goal_dist_normalizer / compute_nearest_dist_all,
+    PolicyEvaluator.update_vehicle_data_dict / update_running_statistics / compute_metrics, utils.sim.compute_reward,
+    RLWaymoDataset.compute_dist_to_nearest_vehicle_rewards, scipy's jensenshannon — is the reference's own code."""
+    import types
+    ref_shims.install()
+    if "evaluators.policy_evaluator" in sys.modules:
+        return
+    REF = ref_shims.REF
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class CollisionType:
+        UNCOLLIDED, VEHICLE_VEHICLE, VEHICLE_ROAD = 0, 1, 2
+    noct = stub("nocturne", Simulation=object, CollisionType=CollisionType)
+    noct.__path__ = [f"{REF}/nocturne"]                  # nocturne.bicycle_model is plain Python
+    for name in ("imageio", "matplotlib", "matplotlib.pyplot", "pdb"):
+        try:
+            __import__(name)
+        except Exception:
+            stub(name)
+    cfgmod = sys.modules["cfgs.config"]
+    cfgmod.set_display_window = lambda: None
+    cfgmod.get_scenario_dict = lambda cfg: {}
+    stub("utils.viz")
+    rw = sys.modules["datasets.rl_waymo"]
+    from datasets.rl_waymo.dataset import RLWaymoDataset
+    rw.RLWaymoDatasetCtRLSim = RLWaymoDataset
+    rw.RLWaymoDatasetCTGPlusPlus = type("RLWaymoDatasetCTGPlusPlus", (), {})
+    pol = sys.modules["policies"]
+    from policies.autoregressive_policy import AutoregressivePolicy
+    pol.AutoregressivePolicy = AutoregressivePolicy
+    pol.CTGPlusPlusPolicy = type("CTGPlusPlusPolicy", (), {})
+    ev = types.ModuleType("evaluators")
+    ev.__path__ = [f"{REF}/evaluators"]
+    sys.modules["evaluators"] = ev
+
+
+class _XY:
+    def __init__(self, x, y):
+        self.x, self.y = x, y
+
+
+class _ReplayVeh:
+    """The read side of the pybind Vehicle (pybind11/src/object.cc:33-99) replaying recorded states."""
+
+    def __init__(self, i, scn, states, coll):
+        self.i, self.scn, self.states, self.coll, self.t = i, scn, states, coll, 0
+        self.target_position = _XY(float(scn.goal_pos[i, 0]), float(scn.goal_pos[i, 1]))
+        self.target_heading, self.target_speed = float(scn.goal_heading[i]), float(scn.goal_speed[i])
+
+    def getID(self): return self.i
+    def getWidth(self): return float(self.scn.width[self.i])
+    def getLength(self): return float(self.scn.length[self.i])
+    def getPosition(self): return _XY(self.states[self.i, self.t, 0], self.states[self.i, self.t, 1])
+    def velocity(self): return _XY(self.states[self.i, self.t, 2], self.states[self.i, self.t, 3])
+    def getHeading(self): return self.states[self.i, self.t, 4]
+    @property
+    def position(self): return self.getPosition()
+    @property
+    def speed(self): return float(np.hypot(self.states[self.i, self.t, 2], self.states[self.i, self.t, 3]))
+    @property
+    def heading(self): return self.getHeading()
+    @property
+    def collision_type_veh(self): return 1 if self.coll[self.i, self.t, 0] else 0
+    @property
+    def collision_type_edge(self): return 2 if self.coll[self.i, self.t, 1] else 0
+
+
+def metrics_cases():
+    """(tag, closed-loop fixture tag, history_steps, vehicles that leave the log at step (veh, t), evaluated vehicles)."""
+    return (("a", "a", 1, (), (0, 1, 2, 3, 4, 5, 6, 7)), ("b", "b", 5, ((1, 12), (3, 3), (7, 19)), (0, 1, 3, 4, 7, 9)),
+            ("c", "c", 3, ((0, 8),), (0, 2, 5, 6, 8)))
+
+
+def gen_metrics():
+    """The reference's evaluator bookkeeping on recorded rollouts (the reference closed loops of closed_loop.npz): per-step
+    rewards / nearest distances (update_vehicle_data_dict -> compute_reward, compute_nearest_dist_all), goal relocation for
+    vehicles that leave the log (initialize_goal_dict), the running statistics and the 9 metrics incl. scipy's Jensen-Shannon
+    distance (policy_evaluator.py:162-305)."""
+    import types as _t
+    _install_evaluator_stubs()
+    from evaluators.policy_evaluator import PolicyEvaluator
+    from ctrlsim_amd.scenarios import standin_log
+    g = np.load(os.path.join(GOLD, "closed_loop.npz"))
+    out = {}
+    base = spec.make_cfg(**LOOP)
+    ev = PolicyEvaluator.__new__(PolicyEvaluator)
+    ev.cfg, ev.cfg_rl_waymo = base, base.dataset.waymo
+    ev.steps, ev.dt = base.nocturne.steps, base.nocturne.dt
+    ev.policy = _t.SimpleNamespace(real_time_rewards=False)
+    ev.preprocessed_dset = ref_shims.build_reference_dataset(base)
+    ev.reset()
+    d = spec.Dims(base)
+    for tag, src, hist, leave, evals in metrics_cases():
+        rc = g[f"{src}_recipe"]
+        scn = scenarios.make_scenario(int(rc[0]), int(rc[1]), n_agents=int(rc[2]), n_polylines=int(rc[3]), n_points=d.NP,
+                                      extent=float(rc[4]))
+        states, coll, actions = g[f"{src}_states"], g[f"{src}_coll"], g[f"{src}_actions"]
+        N, T1 = states.shape[:2]
+        gt = standin_log(scn, ev.steps, ev.dt)
+        for v, t0 in leave:
+            gt[v]["traj"][t0:, 4] = 0.0
+        ev.history_steps = hist
+        ev.vehicles_to_evaluate = list(evals)
+        vehs = [_ReplayVeh(i, scn, states, coll) for i in range(N)]
+        vdd, goal_dict, goal_norm = {}, {}, {}
+        for veh in vehs:
+            v = veh.getID()
+            goal_dict[v] = ev.initialize_goal_dict(veh, np.array(gt[v]["traj"]))
+            # the list fields of initialize_vehicle_data_dict (policy_evaluator.py:70-96; its scalar fields are not read here)
+            vdd[v] = {k: [] for k in ("gt_position", "gt_speed", "gt_heading", "gt_acceleration", "gt_nearest_dist", "position",
+                                      "velocity", "heading", "nearest_dist", "existence", "acceleration", "steering", "reward",
+                                      "dense_reward", "timestep", "rtgs")}
+            goal_norm[v] = ev.compute_goal_dist_normalizer(veh, goal_dict[v]["pos"])
+        for t in range(T1):
+            for veh in vehs:
+                veh.t = t
+            vdd = ev.update_vehicle_data_dict(t, vehs, vdd, goal_dict, goal_norm, gt, None, None)
+            for v in range(N):
+                vdd[v]["acceleration"].append(actions[v, t, 0] if t < ev.steps else 0)
+        n0 = [len(x) for x in (ev.goal_achieved_all, ev.collision_rate_scenario, ev.ades_all)]
+        ev.update_running_statistics(vdd)
+        out[f"{tag}_gt"] = np.stack([np.array(gt[v]["traj"]) for v in range(N)])
+        out[f"{tag}_reward"] = np.array([vdd[v]["reward"] for v in range(N)], np.float64)
+        out[f"{tag}_existence"] = np.array([vdd[v]["existence"] for v in range(N)], np.float64)
+        out[f"{tag}_nearest"] = np.array([vdd[v]["nearest_dist"] for v in range(N)], np.float64)
+        out[f"{tag}_gt_nearest"] = np.array([vdd[v]["gt_nearest_dist"] for v in range(N)], np.float64)
+        out[f"{tag}_goal"] = np.array([[*goal_dict[v]["pos"], goal_dict[v]["heading"], goal_dict[v]["speed"]] for v in range(N)])
+        out[f"{tag}_goal_achieved"] = np.array(ev.goal_achieved_all[n0[0]:])
+        out[f"{tag}_coll_off"] = np.array([ev.collision_rate_scenario[n0[1]:], ev.offroad_rate_scenario[n0[1]:]]).reshape(2, -1)
+        out[f"{tag}_ade_fde"] = np.array([ev.ades_all[n0[2]:], ev.fdes_all[n0[2]:]])
+    m, _ = ev.compute_metrics()
+    out["metric_names"] = np.array(list(m.keys()))
+    out["metric_values"] = np.array([m[k] for k in m])
+    for k in ("lin_speed_sim_all", "lin_speed_gt_all", "ang_speed_sim_all", "ang_speed_gt_all", "accel_sim_all", "accel_gt_all",
+              "nearest_dist_sim_all", "nearest_dist_gt_all"):
+        out["samples_" + k[:-4]] = np.concatenate(getattr(ev, k), 0)[:, 0]
+    print({k: float(v) for k, v in m.items()})
+    save("metrics", **out)
+
+
 # --------------------------------------------------------------------------------------------- G4 features
 def gen_features():
     """Reference get_data() on hand-built policy buffers: exercises select_relevant_agents (first call and
@@ -925,7 +1074,7 @@ def gen_dt_loop():
 
 
 ALL = dict(model=gen_model, features=gen_features, sampling=gen_sampling, physics=gen_physics,
-           collision=gen_collision, closed_loop=gen_closed_loop, closed_loop_full=gen_closed_loop_full, bicycle=gen_bicycle, contacts=gen_contacts,
+           collision=gen_collision, closed_loop=gen_closed_loop, closed_loop_full=gen_closed_loop_full, metrics=gen_metrics, bicycle=gen_bicycle, contacts=gen_contacts,
            planner_adversary=gen_planner_adversary, ingest=gen_ingest,
            variants=gen_variants, dense_reward=gen_dense_reward, dt_loop=gen_dt_loop)
 
