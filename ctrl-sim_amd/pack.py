@@ -99,8 +99,13 @@ def _planes3(W: np.ndarray):
     npl, scale = split_scheme()
     W = np.ascontiguousarray(W, np.float32) * np.float32(scale)
     if npl == 2:
-        hi = W.astype(np.float16)                                        # round-to-nearest-even, like v_cvt_pk_f16_f32
-        lo = (W - hi.astype(np.float32)).astype(np.float16)
+        with np.errstate(over="ignore", invalid="ignore"):
+            hi = W.astype(np.float16)                                    # round-to-nearest-even, like v_cvt_pk_f16_f32
+            lo = (W - hi.astype(np.float32)).astype(np.float16)
+        if not (np.isfinite(hi).all() and np.isfinite(lo).all()):
+            raise FloatingPointError(f"weight magnitude {float(np.abs(W).max()) / scale:.4g} is beyond the fp16 range of the "
+                                     f"two-plane operand split (|w| < {65504.0 / scale:.0f}): rebuild the library with "
+                                     "-DCTRLSIM_F16X3=0 (three bf16 planes, csrc/split.h)")
         return np.stack([hi.view(np.uint16), lo.view(np.uint16)], 0)
     hi = bf16_rne(W)
     r1 = W - bf16_to_f32(hi)

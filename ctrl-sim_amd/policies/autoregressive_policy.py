@@ -102,6 +102,9 @@ class AutoregressivePolicy(Policy):
         eng.goals.copy_(torch.from_numpy(self.goals[:, 0][None]).to(dev))
         eng.policy_step(t)
         torch.cuda.synchronize(dev)
+        bad = int(eng.lib.ctrlsim_nonfinite_count(1))      # NaN logits (fp16 overflow of the split operands, bad weights) must not
+        if bad:                                            # pass as "rtg bin 0 / zero action": same guard as RolloutEngine.results()
+            raise FloatingPointError(f"{bad} sampling races had no finite logit at step {t} (csrc/split.h: activation range)")
         bins = eng.hist_rtg[0, :, t].cpu().numpy()
         toks = eng.act_now[0].cpu().numpy()
         own = eng.own_ctx[0].cpu().numpy()

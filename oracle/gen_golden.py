@@ -425,6 +425,17 @@ def gen_metrics():
     save("metrics", **out)
 
 
+def gen_state_dict():
+    """Names and shapes of the reference modules' state_dict() (the `state_dict` of the Lightning checkpoint that
+    CtRLSim.load_from_checkpoint reads, models/ctrl_sim.py:19-25, eval_sim.py:52)."""
+    cfg = spec.make_cfg()
+    d = spec.Dims(cfg)
+    sd = ref_shims.build_reference_model(cfg, weights.generate(d, 0)).state_dict()
+    names = list(sd.keys())
+    save("state_dict", ctrl_sim_names=np.array(names), ctrl_sim_ndim=np.array([sd[n].dim() for n in names]),
+         ctrl_sim_shapes=np.array([list(sd[n].shape) + [0] * (4 - sd[n].dim()) for n in names]))
+
+
 # --------------------------------------------------------------------------------------------- G4 features
 def gen_features():
     """Reference get_data() on hand-built policy buffers: exercises select_relevant_agents (first call and
@@ -1074,7 +1085,7 @@ def gen_dt_loop():
 
 
 ALL = dict(model=gen_model, features=gen_features, sampling=gen_sampling, physics=gen_physics,
-           collision=gen_collision, closed_loop=gen_closed_loop, closed_loop_full=gen_closed_loop_full, metrics=gen_metrics, bicycle=gen_bicycle, contacts=gen_contacts,
+           collision=gen_collision, closed_loop=gen_closed_loop, closed_loop_full=gen_closed_loop_full, metrics=gen_metrics, state_dict=gen_state_dict, bicycle=gen_bicycle, contacts=gen_contacts,
            planner_adversary=gen_planner_adversary, ingest=gen_ingest,
            variants=gen_variants, dense_reward=gen_dense_reward, dt_loop=gen_dt_loop)
 

@@ -125,3 +125,47 @@ def test_synthetic_scenarios_are_deterministic_and_well_formed():
     dist = np.sqrt(dx ** 2 + dy ** 2) + np.eye(16) * 1e9
     assert dist.min() > 4.0
     assert sorted(a.eval_order.tolist()) == list(range(16))
+
+
+def test_load_from_checkpoint_reads_a_lightning_shaped_file(tmp_path):
+    """CtRLSim.load_from_checkpoint (models/ctrl_sim.py:19-25 via eval_sim.py:52): a file with the reference modules' own
+    state_dict names / shapes (tests/golden/state_dict.npz, taken from the imported reference Encoder / Decoder) under
+    'state_dict' and the cfg under 'hyper_parameters' -> the weights the HIP model packs.  Missing / mis-shaped entries raise."""
+    import torch
+    from helpers import golden
+    from ctrlsim_amd.models import CtRLSim
+    g = golden("state_dict")
+    cfg = spec.make_cfg()
+    d = spec.Dims(cfg)
+    names = [str(n) for n in g["ctrl_sim_names"]]
+    shapes = {n: tuple(int(x) for x in sh[:nd]) for n, sh, nd in zip(names, g["ctrl_sim_shapes"], g["ctrl_sim_ndim"])}
+    table = {n: tuple(sh) for n, sh, _, _ in weights.param_table(d)}
+    assert table == shapes                                  # every reference parameter, nothing else, same shapes
+    w = weights.generate(d, 3)
+    sd = {n: torch.from_numpy(w[n].copy()) for n in names}
+    sd["decoder.some_buffer_lightning_adds"] = torch.zeros(3)        # unknown extras are ignored
+    path = tmp_path / "model.ckpt"
+    torch.save({"state_dict": sd, "hyper_parameters": {"cfg": cfg}, "epoch": 7, "pytorch-lightning_version": "2.0"}, path)
+    m = CtRLSim.load_from_checkpoint(str(path))
+    assert m.cfg.model.hidden_dim == cfg.model.hidden_dim and set(m.weights) == set(names)
+    for n in names:
+        assert m.weights[n].dtype == np.float32 and np.array_equal(m.weights[n], w[n]), n
+    bad = dict(sd); del bad["encoder.embed_ln.weight"]
+    torch.save({"state_dict": bad, "hyper_parameters": {"cfg": cfg}}, path)
+    with pytest.raises(KeyError):
+        CtRLSim.load_from_checkpoint(str(path))
+    bad = dict(sd); bad["decoder.predict_action.mlp.3.weight"] = torch.zeros(5, 5)
+    torch.save({"state_dict": bad, "hyper_parameters": {"cfg": cfg}}, path)
+    with pytest.raises(ValueError):
+        CtRLSim.load_from_checkpoint(str(path))
+
+
+def test_weight_planes_refuse_values_beyond_the_fp16_range():
+    """pack-time guard (csrc/split.h): with the two-fp16-plane split a weight of magnitude >= 65504 / 2^8 has no finite planes."""
+    from ctrlsim_amd import pack
+    W = np.zeros((32, 32), np.float32)
+    pack.split3_planes(W + 1.0)
+    if pack.split_scheme()[0] == 2:
+        W[3, 5] = 300.0
+        with pytest.raises(FloatingPointError):
+            pack.split3_planes(W)
