@@ -64,6 +64,12 @@ __global__ __launch_bounds__(256) void assemble_tokens_kernel(
   if (tt == 0) {
     *reinterpret_cast<f32x4*>(src + ((size_t)b * M + P + a) * DM + c4) = v;
     if (lane == 0) src_pad[(size_t)b * M + P + a] = ex != 0.f ? 0 : 1;
+    if (a == A - 1) {                              // filler rows up to M (forward.hip: M is rounded up to a multiple of 4): zero, key-padded
+      for (int e = P + A; e < M; ++e) {
+        *reinterpret_cast<f32x4*>(src + ((size_t)b * M + e) * DM + c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (lane == 0) src_pad[(size_t)b * M + e] = 1;
+      }
+    }
   }
   *reinterpret_cast<f32x4*>(xo) = ln256(v, g, be);
   // rtg

@@ -229,7 +229,9 @@ int make_batch(const ctrlsim_dims& d, int n, const int* B, const int* A, const c
     if (A[k] < 2 || A[k] > d.A) return CTRLSIM_EINVAL;
     Cls& c = bt.c[bt.n++];
     c.sh = shape_of(d, A[k]);
-    c.B = B[k]; c.L = c.sh.rows(Tw); c.Lreg = c.sh.lreg(Tw); c.M = d.P + A[k];
+    c.B = B[k]; c.L = c.sh.rows(Tw); c.Lreg = c.sh.lreg(Tw);
+    c.M = (d.P + A[k] + 3) & ~3;             // scene rows per context: polylines, initial states, key-padded filler up to a multiple of 4
+                                              // (the K/V-image epilogue of the memory projections works on key quads)
     c.nkt_dec = c.sh.nkt(Tw); c.nkt_mem = (c.M + 63) / 64;
     c.rL = bt.rL; c.rS = bt.rS; c.rA = bt.rA; c.rM = bt.rM; c.rP = bt.rP; c.rQ = bt.rQ; c.rN = bt.rN;
     c.tile_dec = bt.tiles_dec; c.tile_mem = bt.tiles_mem; c.ioff = (int)bt.isum; c.koff = bt.ksum;

@@ -65,6 +65,23 @@ if 'attn' in FILT or not FILT:
     f = lambda: lib.ctrlsim_attention_presplit(0, p(Q), 256, L * 256, p(img2), 4, p(O), 256, L * 256, None, p(pad), B, L, 224, 24, st)
     report('attn cross presplit Lk=224', sustained(f), L * 224 * 128 * 8 * B)
     del qkv, O, img, Q, KV, img2
+if 'compact' in FILT:
+    # compact contexts (representative slot): Actx slots -> Areg = Actx - 1 regular + 1 representative of multiplicity 25 - Actx
+    T = 32
+    for Actx in (4, 8, 12, 16, 20):
+        Ar = Actx - 1
+        Lreg = T * 3 * Ar; Lq = Lreg + 3 * T
+        nkt = (Lreg + 63) // 64 + 2
+        Bc = max(64, int(B * 2304 / Lq))
+        qkv = torch.randn(Bc, Lq, 768, device=DEV); O = torch.empty(Bc, Lq, 256, device=DEV)
+        img = torch.randn(Bc * 8 * nkt * 4096 * (2 if NPROD == 3 else 3), device=DEV).to(torch.float16).view(torch.int16)
+        A3 = 3 * Ar
+        pairs = A3 * A3 * T * (T - 1) / 2 + T * Ar * (3 * Ar + 3)
+        pairs += A3 * (3 * T * (T - 1) / 2 + T) + 3 * A3 * T * (T - 1) / 2 + 3 * Ar * T + 9 * T * (T - 1) / 2 + 6 * T
+        f = lambda: lib.ctrlsim_attention_compact(p(qkv), 768, Lq * 768, p(img), nkt, p(O), 256, Lq * 256, None, Bc, Lq, Lreg, Ar,
+                                                  3 * T, 25 - Actx, Lreg, st)
+        report(f'attn compact Actx={Actx} L={Lq} B={Bc}', sustained(f), pairs * 128 * 8 * Bc)
+        del qkv, O, img
 if 'gemm' in FILT or not FILT:
     for (N, K, relu, res, ln, name) in [(768, 256, 0, 0, 0, 'qkv (fp32 out)'), (256, 256, 0, 0, 0, 'cross-q'), (256, 256, 0, 1, 1, 'out+res+LN')]:
         A = torch.randn(M, K, device=DEV); W = torch.randn(N, K) * 0.05; b = torch.randn(N, device=DEV)
