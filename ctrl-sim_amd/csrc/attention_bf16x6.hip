@@ -606,6 +606,98 @@ int launch_kv_zero_tail(int B, int key0, int n, int nkt, void* img, hipStream_t 
   hipLaunchKernelGGL(kv_zero_tail_kernel, dim3(B * NHEAD), dim3(256), 0, st, n % KT6, tile, nkt, static_cast<op_t*>(img));
   return ctrlsim_launch_status();
 }
+// The same for up to 16 (class, key region) entries in ONE launch: entry e covers the images from tile tile0 on of B contexts
+struct KvTailEntry { int wg0, nkt, tile, k0; long tile0; };
+struct KvTailBatch { int n; KvTailEntry e[16]; };
+__global__ __launch_bounds__(256) void kv_zero_tails_kernel(KvTailBatch tb, op_t* __restrict__ img) {
+  constexpr int K_PLANE = KT6 * HD, V_PLANE = HD * KT6;
+  int ei = 0;
+  while (ei + 1 < tb.n && (int)blockIdx.x >= tb.e[ei + 1].wg0) ++ei;
+  const KvTailEntry& e = tb.e[ei];
+  const int k0 = e.k0;
+  op_t* base = img + ((size_t)e.tile0 + (size_t)((int)blockIdx.x - e.wg0) * e.nkt + e.tile) * KV_IMG;
+  const int nk = KT6 - k0;
+  for (int i = threadIdx.x; i < 4 * NPL * nk * 4; i += 256) {
+    const int run = i / (nk * 4), off = i - run * (nk * 4);
+    reinterpret_cast<unsigned*>(base + run * KT6 * 8 + k0 * 8)[off] = 0u;
+  }
+  const int q0 = k0 >> 2, nq = 16 - q0;
+  for (int i = threadIdx.x; i < NPL * nq * 64; i += 256) {
+    const int pl = i / (nq * 64), off = i - pl * (nq * 64);
+    reinterpret_cast<unsigned*>(base + NPL * K_PLANE + pl * V_PLANE + q0 * HD * 4)[off] = 0u;
+  }
+}
+struct KvTailHost { int B, key0, n, nkt; long tile0; };
+int launch_kv_zero_tails(int n, const KvTailHost* t, void* img, hipStream_t st) {
+  if (n < 0 || n > 16 || !img) return CTRLSIM_EINVAL;
+  KvTailBatch tb;
+  tb.n = 0;
+  int wg = 0;
+  for (int i = 0; i < n; ++i) {
+    if (t[i].B <= 0 || t[i].n % KT6 == 0) continue;
+    const int tile = (t[i].key0 + t[i].n) / KT6;
+    if ((t[i].n & 3) || (t[i].key0 & 63) || tile >= t[i].nkt) return CTRLSIM_EINVAL;
+    tb.e[tb.n++] = KvTailEntry{wg, t[i].nkt, tile, t[i].n % KT6, t[i].tile0};
+    wg += t[i].B * NHEAD;
+  }
+  if (tb.n == 0) return CTRLSIM_OK;
+  hipLaunchKernelGGL(kv_zero_tails_kernel, dim3(wg), dim3(256), 0, st, tb, static_cast<op_t*>(img));
+  return ctrlsim_launch_status();
+}
+
+// Rows mode for up to 8 classes in one launch: class c holds B contexts of R rows starting at row row0 of K / V (row stride ldkv,
+// context stride R * ldkv), written at key pos[r] of the images from tile tile0 on (nkt tiles per (context, head)).
+struct KvRowsClass { long g0, row0, tile0; const int* pos; int R, nkt; };
+struct KvRowsBatch { int n; KvRowsClass c[8]; };
+__global__ __launch_bounds__(256) void kv_split_rows_classes_kernel(const float* __restrict__ K, const float* __restrict__ V, int ldkv,
+                                                                    KvRowsBatch kb, long total, op_t* __restrict__ img) {
+  constexpr int K_PLANE = KT6 * HD, V_PLANE = HD * KT6;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  int ci = 0;
+  while (ci + 1 < kb.n && gid >= kb.c[ci + 1].g0) ++ci;
+  const KvRowsClass& c = kb.c[ci];
+  const long l = gid - c.g0;
+  const int g = (int)(l & 63), r = (int)((l >> 6) % c.R), b = (int)((l >> 6) / c.R);
+  const int col = g * 4, h = col >> 5, d = col & 31;
+  const int p = c.pos[r], kt = p >> 6, key = p & 63;
+  const size_t row = (size_t)c.row0 + (size_t)b * c.R + r;
+  const f32x4 kx = *reinterpret_cast<const f32x4*>(K + row * ldkv + col);
+  const f32x4 vx = *reinterpret_cast<const f32x4*>(V + row * ldkv + col);
+  op_t* Kd = img + ((size_t)c.tile0 + ((size_t)b * NHEAD + h) * c.nkt + kt) * KV_IMG;
+  op_t* Vd = Kd + NPL * K_PLANE;
+  u32x2 kp[NPL];
+  split_quad(kx, kp);
+  const int ko = ((d >> 3) * KT6 + key) * 8 + (d & 7);
+#pragma unroll
+  for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x2*>(Kd + q * K_PLANE + ko) = kp[q];
+  unsigned short* Vs = reinterpret_cast<unsigned short*>(Vd);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    unsigned vp[NPL];
+    split_pair(vx[e], 0.f, vp);
+    const int vo = ((key >> 2) * HD + (d + e)) * 4 + (key & 3);
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) Vs[q * V_PLANE + vo] = (unsigned short)vp[q];
+  }
+}
+struct KvRowsHost { int B, R, nkt; long row0, tile0; const int* pos; };
+int launch_kv_split_rows_classes(const float* K, const float* V, int ldkv, int n, const KvRowsHost* cls, void* img, hipStream_t st) {
+  if (n < 0 || n > 8 || !K || !V || !img || (ldkv & 3)) return CTRLSIM_EINVAL;
+  KvRowsBatch kb;
+  kb.n = 0;
+  long total = 0;
+  for (int i = 0; i < n; ++i) {
+    if (cls[i].B <= 0 || cls[i].R <= 0) continue;
+    if (!cls[i].pos) return CTRLSIM_EINVAL;
+    kb.c[kb.n++] = KvRowsClass{total, cls[i].row0, cls[i].tile0, cls[i].pos, cls[i].R, cls[i].nkt};
+    total += (long)cls[i].B * cls[i].R * 64;
+  }
+  if (kb.n == 0) return CTRLSIM_OK;
+  hipLaunchKernelGGL(kv_split_rows_classes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, K, V, ldkv, kb, total,
+                     static_cast<op_t*>(img));
+  return ctrlsim_launch_status();
+}
 
 int launch_kv_split(const float* K, const float* V, int ldkv, long kv_batch_stride, int B, int Lk, int nkt, void* img,
                     hipStream_t st) {

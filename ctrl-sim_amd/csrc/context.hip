@@ -203,7 +203,9 @@ __global__ __launch_bounds__(256) void group_size_hist_kernel(int S, int N, cons
 
 // ctx_index with the contexts of scenarios [s0, s1) SORTED by size class (stable in (scenario, group) order inside a class):
 // class k occupies contexts [start_k, start_k + count_k).  ctx_row0[c] = first logits row of context c when every class
-// writes (slots - 1, or A for the last class) rows per context, classes in order.  One block.
+// writes (slots - 1, or A for the last class) rows per context, classes in order.  One block of 256 threads: thread i owns
+// scenarios i, i + 256, ... of the chunk in turn; per round a block-wide exclusive scan of the threads' per-class counts gives
+// every scenario its first context of each class (<= 4095 scenarios per chunk: 16 rounds).
 __global__ __launch_bounds__(256) void ctx_index_classes_kernel(int s0, int s1, int N, int A, const int* __restrict__ n_groups,
                                                                 const unsigned long long* __restrict__ grp_ids,
                                                                 const int* __restrict__ own_g, const int* __restrict__ mem_g,
@@ -212,30 +214,59 @@ __global__ __launch_bounds__(256) void ctx_index_classes_kernel(int s0, int s1, 
                                                                 int* __restrict__ ctx_of_group,   // [S, N] scratch
                                                                 int* __restrict__ own_ctx, int* __restrict__ own_slot,
                                                                 int* __restrict__ mem_ctx, int* __restrict__ mem_slot) {
-  __shared__ int start[9], row0[9], fill[8];
-  const int ns = s1 - s0;
-  if (threadIdx.x == 0) {
-    int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < ns; ++i)
-      for (int g = 0; g < n_groups[s0 + i]; ++g) ++cnt[size_class(__popcll(grp_ids[(size_t)(s0 + i) * N + g]), sc.sizes, sc.nb)];
+  __shared__ int scan[8][256];
+  __shared__ int total[8], start[8], row0[8], carry[8];
+  const int ns = s1 - s0, tid = threadIdx.x, nb = sc.nb;
+  // ---- class totals of the chunk
+  int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = tid; i < ns; i += 256)
+    for (int g = 0; g < n_groups[s0 + i]; ++g) ++cnt[size_class(__popcll(grp_ids[(size_t)(s0 + i) * N + g]), sc.sizes, nb)];
+  if (tid < 8) total[tid] = 0;
+  __syncthreads();
+  for (int k = 0; k < nb; ++k)
+    if (cnt[k]) atomicAdd(&total[k], cnt[k]);
+  __syncthreads();
+  if (tid == 0) {
     int acc = 0, racc = 0;
-    for (int k = 0; k < sc.nb; ++k) {
-      start[k] = acc; row0[k] = racc; fill[k] = 0;
-      acc += cnt[k];
-      racc += cnt[k] * (sc.sizes[k] < A ? sc.sizes[k] - 1 : A);
+    for (int k = 0; k < nb; ++k) {
+      start[k] = acc; row0[k] = racc; carry[k] = 0;
+      acc += total[k];
+      racc += total[k] * (sc.sizes[k] < A ? sc.sizes[k] - 1 : A);
     }
-    for (int i = 0; i < ns; ++i)
+  }
+  __syncthreads();
+  // ---- rounds of 256 scenarios, in scenario order
+  for (int base = 0; base < ns; base += 256) {
+    const int i = base + tid;
+    int mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (i < ns)
+      for (int g = 0; g < n_groups[s0 + i]; ++g) ++mine[size_class(__popcll(grp_ids[(size_t)(s0 + i) * N + g]), sc.sizes, nb)];
+    for (int k = 0; k < nb; ++k) scan[k][tid] = mine[k];
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {          // inclusive Hillis-Steele scan per class
+      int v[8];
+      for (int k = 0; k < nb; ++k) v[k] = tid >= off ? scan[k][tid - off] : 0;
+      __syncthreads();
+      for (int k = 0; k < nb; ++k) scan[k][tid] += v[k];
+      __syncthreads();
+    }
+    if (i < ns) {
+      int fill[8];
+      for (int k = 0; k < nb; ++k) fill[k] = carry[k] + scan[k][tid] - mine[k];
       for (int g = 0; g < n_groups[s0 + i]; ++g) {
-        const int k = size_class(__popcll(grp_ids[(size_t)(s0 + i) * N + g]), sc.sizes, sc.nb);
+        const int k = size_class(__popcll(grp_ids[(size_t)(s0 + i) * N + g]), sc.sizes, nb);
         const int c = start[k] + fill[k];
         ctx_scn[c] = s0 + i; ctx_grp[c] = g;
         ctx_row0[c] = row0[k] + fill[k] * (sc.sizes[k] < A ? sc.sizes[k] - 1 : A);
         ctx_of_group[(size_t)(s0 + i) * N + g] = c;
         ++fill[k];
       }
+    }
+    __syncthreads();
+    if (tid < nb) carry[tid] += scan[tid][255];
+    __syncthreads();
   }
-  __syncthreads();
-  for (int k = threadIdx.x; k < ns * N; k += blockDim.x) {
+  for (int k = tid; k < ns * N; k += blockDim.x) {
     const int i = k / N, v = k - i * N;
     const size_t sv = (size_t)(s0 + i) * N + v;
     const int og = own_g[sv], mg = mem_g[sv];

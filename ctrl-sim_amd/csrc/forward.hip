@@ -32,6 +32,10 @@ int launch_layernorm256(const float*, int, const float*, int, const float*, cons
 int launch_gemm_nt_bf16x6_kv(const float*, int, const void*, int, int, const float*, const float*, int, float*, int, int, int,
                              int, int, const float*, const float*, void*, int, int, int, int, int, hipStream_t);
 int launch_kv_zero_tail(int, int, int, int, void*, hipStream_t);
+struct KvTailHost { int B, key0, n, nkt; long tile0; };
+int launch_kv_zero_tails(int, const KvTailHost*, void*, hipStream_t);
+struct KvRowsHost { int B, R, nkt; long row0, tile0; const int* pos; };
+int launch_kv_split_rows_classes(const float*, const float*, int, int, const KvRowsHost*, void*, hipStream_t);
 int launch_ffn_fused_bf16x6(const float*, int, const void*, const float*, const void*, const float*, const float*, const float*,
                             float*, int, int, int, hipStream_t);
 int launch_kv_split(const float*, const float*, int, long, int, int, int, void*, hipStream_t);
@@ -416,11 +420,13 @@ int gemm_kv(const ctrlsim_dims& d, const Batch& bt, const Ws& w, const Lin& L, c
   }
   const size_t KIMG = (size_t)2 * NPL * 64 * HD;      // 16-bit elements per tile
   if (fused) {
-    for (int k = 0; k < bt.n; ++k) {
-      op_t* base = static_cast<op_t*>(img) + (size_t)kc[k].tile0 * KIMG;
-      CHK(launch_kv_zero_tail(kc[k].B, 0, kc[k].Lreg, kc[k].nkt, base, st));
-      if (kc[k].Lreg < kc[k].L) CHK(launch_kv_zero_tail(kc[k].B, kc[k].rep_k0, kc[k].L - kc[k].Lreg, kc[k].nkt, base, st));
+    KvTailHost tails[16];
+    int nt = 0;
+    for (int k = 0; k < bt.n; ++k) {                  // the epilogue writes rows: the tails of the last tiles of both key regions stay
+      tails[nt++] = KvTailHost{kc[k].B, 0, kc[k].Lreg, kc[k].nkt, kc[k].tile0};
+      if (kc[k].Lreg < kc[k].L) tails[nt++] = KvTailHost{kc[k].B, kc[k].rep_k0, kc[k].L - kc[k].Lreg, kc[k].nkt, kc[k].tile0};
     }
+    CHK(launch_kv_zero_tails(nt, tails, img, st));
     return launch_gemm_nt_bf16x6_kvc(x, DM, L.w3, L.ntot ? L.ntot : n, L.n0, L.b, nullptr, 0, y, ldy, (int)rows, n, DM, 0, nullptr,
                                      nullptr, img, kcol0, bt.n, kc, st);
   }
@@ -678,13 +684,12 @@ extern "C" int ctrlsim_dt_forward_pass2_c(const ctrlsim_model* m, int n, const i
     CHK(gemm(Ld.qkv, w.xc2, DM, nullptr, 0, w.qkvc, 3 * DM, rQ, 3 * DM, DM, 0, st));
     CHK(launch_row_copy(w.qkvc, 3 * DM, w.qkv[i], 3 * DM, w.idx_rtg, rQ, 3 * DM, 1, st));   // refresh the rtg rows' K/V
     if (presplit()) {
-      const size_t KIMG = (size_t)2 * NPL * 64 * HD;
+      KvRowsHost kr[8];
       for (int k = 0; k < bt.n; ++k) {
         const Cls& c = bt.c[k];
-        const float* Kp = w.qkvc + c.rQ * 3 * DM + DM;
-        CHK(launch_kv_split_rows(Kp, Kp + DM, 3 * DM, (long)c.sh.Areg * 3 * DM, w.pos_rtg + c.ioff, c.B, c.sh.Areg, c.nkt_dec,
-                                 static_cast<op_t*>(w.img_dec[i]) + (size_t)c.tile_dec * KIMG, st));
+        kr[k] = KvRowsHost{c.B, c.sh.Areg, c.nkt_dec, c.rQ, c.tile_dec, w.pos_rtg + c.ioff};
       }
+      CHK(launch_kv_split_rows_classes(w.qkvc + DM, w.qkvc + 2 * DM, 3 * DM, bt.n, kr, w.img_dec[i], st));
     }
     CHK(attention(d, bt, w, AttnCall{1, Q_RTG, w.qkvc, 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, w.img_dec[i], false, w.attc,
                                      Tq, Tw, 0}, st));   // keys: steps <= current
@@ -759,7 +764,6 @@ extern "C" int ctrlsim_dt_forward_pass1_cached_c(const ctrlsim_model* m, int n, 
                                c.ctx->exist, c.ctx->act_tok, c.ctx->rtg_bin, c.ctx->tstep, m->tb, w.xn + c.rN * DM, st));
     }
   }
-  const size_t KIMG = (size_t)2 * NPL * 64 * HD;
   for (int i = 0; i < d.ND; ++i) {
     const DecLayer& Ld = m->dec[i];
     CHK(gemm(Ld.qkv, w.xn, DM, nullptr, 0, w.qkvn, 3 * DM, rN, 3 * DM, DM, 0, st));
@@ -768,13 +772,12 @@ extern "C" int ctrlsim_dt_forward_pass1_cached_c(const ctrlsim_model* m, int n, 
       if (t == 0) {   // image tiles are read whole: stale bits beyond the written rows must at least be finite
         if (hipMemsetAsync(w.img_dec[i], 0, w.img_dec_bytes, st) != hipSuccess) return CTRLSIM_ELAUNCH;
       }
+      KvRowsHost kr[8];
       for (int k = 0; k < bt.n; ++k) {
         const Cls& c = bt.c[k];
-        const int Rn = mul * c.sh.A;
-        const float* Kp = w.qkvn + c.rN * 3 * DM + DM;
-        CHK(launch_kv_split_rows(Kp, Kp + DM, 3 * DM, (long)Rn * 3 * DM, w.key_new + 4 * c.ioff, c.B, Rn, c.nkt_dec,
-                                 static_cast<op_t*>(w.img_dec[i]) + (size_t)c.tile_dec * KIMG, st));
+        kr[k] = KvRowsHost{c.B, mul * c.sh.A, c.nkt_dec, c.rN, c.tile_dec, w.key_new + 4 * c.ioff};
       }
+      CHK(launch_kv_split_rows_classes(w.qkvn + DM, w.qkvn + 2 * DM, 3 * DM, bt.n, kr, w.img_dec[i], st));
     }
     CHK(attention(d, bt, w, AttnCall{1, Q_NEW, w.qkvn, 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, w.img_dec[i], false, w.attn_n,
                                      t + 1, d.T, mul}, st));
