@@ -37,6 +37,8 @@ SIGNATURES = {
     "ctrlsim_prof_enable": (None, [I]),
     "ctrlsim_prof_collect": (I, [P, P, P]),
     "ctrlsim_prof_bytes": (I, [P]),
+    "ctrlsim_metrics_size": (I, []),
+    "ctrlsim_metrics_pack": (I, [I, I, I, I, I, D, P, P, P, P, P, P, P, P, P, P]),
     "ctrlsim_gemm_nt": (I, [P, I, P, I, P, P, I, P, I, I, I, I, I, P]),
     "ctrlsim_gemm_nt_bf16x6": (I, [P, I, P, I, I, P, P, I, P, I, I, I, I, I, P, P, P]),
     "ctrlsim_gemm_nt_kv": (I, [P, I, P, I, I, P, P, I, I, I, I, P, I, I, I, P]),

@@ -9,7 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRCS = {"gemm": "", "gemm_bf16x6": "", "ffn_fused": "", "attention": "", "attention_bf16x6": "", "sim": "-ffp-contract=off", "context": "-ffp-contract=off", "embed": "",
-        "map_encoder": "", "sample": "", "forward": "", "api": ""}
+        "map_encoder": "", "sample": "", "metrics": "-ffp-contract=off", "forward": "", "api": ""}
 OUT = os.path.join(HERE, "libctrlsim_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 

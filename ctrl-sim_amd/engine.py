@@ -590,6 +590,28 @@ class RolloutEngine:
         self.groups_per_step[t] = hist.sum(1)
         self._policy_chunks(L, t, hist, 0, self.S, noise_rtg, noise_act)
 
+    def metrics_pack(self, gt, goals4, eval_mask=None, out=None):
+        """Evaluator statistics of the loaded scenarios' finished rollouts, accumulated on the device (ctrlsim_metrics_pack):
+        -> float64 device tensor in MetricAccumulators.pack() order (add into `out` if given).  gt [S,N,T1,5] float64 = logged
+        x, y, heading, speed, exist; goals4 [S,N,4] float64 = goal x, y, heading, speed; eval_mask [S,N] uint8 or None."""
+        from .metrics import MetricAccumulators
+        dev, w, p = self.device, self.w, _lib.ptr
+        n = int(self.lib.ctrlsim_metrics_size())
+        if out is None:
+            out = torch.zeros(n, dtype=torch.float64, device=dev)
+        E = MetricAccumulators.EDGES
+        edges = torch.from_numpy(np.concatenate([E["lin"], E["ang"], E["accel"], E["nd"]]).astype(np.float64)).to(dev)
+        as_dev = lambda a, dt: (a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))).to(dev, dt).contiguous()
+        gt_d, g4_d = as_dev(gt, torch.float64), as_dev(goals4, torch.float64)
+        em_d = as_dev(eval_mask, torch.uint8) if eval_mask is not None else None
+        assert tuple(gt_d.shape) == (self.S, self.N, self.steps + 1, 5) and tuple(g4_d.shape) == (self.S, self.N, 4)
+        params = (C.c_double * 5)(float(self.cfg.nocturne.rew_cfg["position_target_tolerance"]), w.min_accel, w.max_accel,
+                                  w.accel_discretization, w.steer_discretization)
+        _lib.check(self.lib.ctrlsim_metrics_pack(self.S, self.N, self.steps + 1, self.steps, int(self.cfg.nocturne.history_steps),
+                                                 float(self.dt), p(self.hist_states), p(self.coll), p(self.hist_tok), p(gt_d),
+                                                 p(g4_d), p(em_d), params, p(edges), p(out), _lib.stream_ptr()), "metrics_pack")
+        return out
+
     def results(self):
         torch.cuda.synchronize(self.device)
         bad = int(self.lib.ctrlsim_nonfinite_count(1))

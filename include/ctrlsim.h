@@ -194,6 +194,21 @@ int ctrlsim_sample_action(const float* act_logits, int A, int V, const int* mem_
                           uint64_t seed, const int64_t* scenario_id, int t, int* hist_tok, int* act_now /*[S,N]*/,
                           int S, int N, int Tmax, int zero_token, hipStream_t stream);
 
+/* ---- metrics ----------------------------------------------------------------------------------------------------
+ * Replaces PolicyEvaluator.update_running_statistics (evaluators/policy_evaluator.py:162-248) with compute_reward's goal latch
+ * (utils/sim.py:99-104) and compute_nearest_dist_all (evaluators/evaluator.py:87-103) for S finished rollouts: out[0 ..
+ * ctrlsim_metrics_size()) += the packed accumulators — sums and counts of (goal, per-scenario collision rate, per-scenario
+ * off-road rate, ADE, FDE) and the eight histograms compute_metrics builds (policy_evaluator.py:251-305), in the order of
+ * ctrlsim_amd/metrics.py:MetricAccumulators.pack.  This vector is what the ranks all-reduce (the only collective of a
+ * multi-GPU run).  gt [S,N,T1,5] = logged x, y, heading, speed, exist; goals4 [S,N,4] = goal x, y, heading, speed (after
+ * initialize_goal_dict); eval_mask [S,N] (NULL = all vehicles evaluated); params5 (host) = position tolerance, min_accel,
+ * max_accel, n_accel_bins, n_steer_bins; edges (device) = the histogram edges lin[201] ang[201] accel[21] nearest[201].  The applied
+ * acceleration of a step is the centre of the sampled token's acceleration bin. */
+int ctrlsim_metrics_size(void);
+int ctrlsim_metrics_pack(int S, int N, int T1, int Tmax, int hist_steps, double dt, const float* hist_states, const uint8_t* coll,
+                         const int* hist_tok, const double* gt, const double* goals4, const uint8_t* eval_mask,
+                         const double* params5, const double* edges, double* out, hipStream_t stream);
+
 /* ---- building blocks (exported for parity tests and profiling) ------------------------------------------------ */
 int ctrlsim_gemm_nt(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr,
                     float* C, int ldc, int M, int N, int K, int relu, hipStream_t stream);

@@ -3,6 +3,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -44,25 +45,33 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_metric_allreduce_world2_equals_single_process():
+@pytest.mark.parametrize("world", [2, 4])
+def test_metric_allreduce_equals_single_process(world):
+    """The only collective of a multi-GPU run — one SUM all-reduce of the packed accumulators — over `world` gloo ranks holding
+    the interleaved scenario shards (shard_ids) equals the single-process accumulation over the union."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=120)
+    got = q.get(timeout=180)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=90)
         assert p.exitcode == 0
     cfg = spec.make_cfg(nocturne__steps=20, nocturne__history_steps=1)
-    ref = _accumulate(cfg, range(6))                      # ids 0..5 == union of the two interleaved shards
+    ref = _accumulate(cfg, range(3 * world))              # ids 0..3W-1 == union of the interleaved shards
     np.testing.assert_allclose(got, ref.pack(), rtol=1e-12, atol=1e-12)
     m, lines = metrics.MetricAccumulators().unpack(got).compute()
     assert set(m) == {"goal", "collision_rate", "offroad_rate", "fde", "ade", "lin_speed_jsd", "ang_speed_jsd",
                       "accel_jsd", "nearest_dist_jsd"}     # evaluators/policy_evaluator.py:251-305
 
 
-def test_shard_ids_partition():
-    ids = sorted(sum((shard_ids(r, 4, 5) for r in range(4)), []))
-    assert ids == list(range(20))
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_shard_ids_partition(world):
+    """Interleaved shards: every global id on exactly one rank, and a given id at the same place of its rank's list for every
+    world size that divides it the same way (id = rank + i * world)."""
+    shards = [shard_ids(r, world, 5) for r in range(world)]
+    assert sorted(sum(shards, [])) == list(range(5 * world))
+    for r, sh in enumerate(shards):
+        assert all(g % world == r for g in sh)

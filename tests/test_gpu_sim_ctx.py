@@ -579,3 +579,82 @@ def test_nonfinite_logits_are_counted_and_fail_loudly():
     assert lib.ctrlsim_nonfinite_count(0) == 1 + 3                     # one action race, three RTG components
     assert hist[0, 1, 0].item() == 524 and (hr[0, 2, 0] == 0).all()
     assert 0 <= hist[0, 0, 0].item() < V and lib.ctrlsim_nonfinite_count(1) == 4 and lib.ctrlsim_nonfinite_count(0) == 0
+
+
+def test_device_metric_accumulators_match_host():
+    """ctrlsim_metrics_pack (the all-reduce payload built on the device) against ctrlsim_amd.metrics — itself pinned to the
+    reference's evaluator code by tests/test_metrics_pinned.py — on real rollouts: a vehicle that reaches its goal, collisions,
+    vehicles missing from the log, a history_steps cut and a subset of evaluated vehicles."""
+    from ctrlsim_amd import metrics
+    cfg = spec.make_cfg(**{**dict(dataset__waymo__max_num_agents=6, dataset__waymo__train_context_length=8,
+                                  dataset__waymo__max_num_road_polylines=12, dataset__waymo__max_num_road_pts_per_polyline=10,
+                                  nocturne__steps=20), "nocturne__history_steps": 3})
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    scns = [scenarios.make_scenario(61, i, n_agents=10, n_polylines=12, n_points=d.NP, extent=20.0 + 10 * (i % 2)) for i in range(5)]
+    eng = RolloutEngine(cfg, w, DEV, max_ctx=48, seed=8)
+    eng.load_scenarios(scns, steps=20)
+    r = eng.run(20).results()
+    S, N, T1 = len(scns), 10, 21
+    rs = np.random.RandomState(5)
+    gt = np.zeros((S, N, T1, 5))
+    goals4 = np.zeros((S, N, 4))
+    emask = (rs.uniform(size=(S, N)) < 0.7).astype(np.uint8)
+    for i, scn in enumerate(scns):
+        log = scenarios.standin_log(scn, 20)
+        gt[i] = np.stack([log[v]["traj"][:, :5] for v in range(N)])
+        goals4[i] = np.concatenate([scn.goal_pos, scn.goal_heading[:, None], scn.goal_speed[:, None]], 1)
+    goals4[0, 2, :2] = r["states"][0][2, 9, :2]            # a goal on the driven path: reached at step 9, latched afterwards
+    states = r["states"].astype(np.float64)
+    acc = metrics.MetricAccumulators()
+    for i in range(S):
+        tok = r["tokens"][i]
+        accel = np.concatenate([(tok // d.NS) / (d.NA - 1) * (cfg.dataset.waymo.max_accel - cfg.dataset.waymo.min_accel)
+                                + cfg.dataset.waymo.min_accel, np.zeros((N, 1))], 1)
+        acc.add_scenario(states[i], r["coll"][i], accel, gt[i], goals4[i, :, :2], goals4[i, :, 2], goals4[i, :, 3], cfg,
+                         eval_ids=list(np.where(emask[i])[0]))
+    dev_vec = eng.metrics_pack(gt, goals4, emask).cpu().numpy()
+    host_vec = acc.pack()
+    assert dev_vec.shape == host_vec.shape
+    np.testing.assert_allclose(dev_vec[:10], host_vec[:10], rtol=1e-11, atol=1e-11)        # sums and counts
+    assert host_vec[0] >= 1 and host_vec[5:10].min() > 0
+    np.testing.assert_array_equal(dev_vec[10:], host_vec[10:])                              # the eight histograms, bin for bin
+    m_dev, _ = metrics.MetricAccumulators().unpack(dev_vec).compute()
+    m_host, _ = acc.compute()
+    for k in m_host:
+        np.testing.assert_allclose(m_dev[k], m_host[k], rtol=1e-10, err_msg=k)
+
+
+def test_rollout_of_a_scenario_does_not_depend_on_the_world_size():
+    """Multi-GPU layout without a multi-GPU node: the scenarios a rank would hold under shard_ids(rank, W, .) for W = 1, 2, 4 are
+    rolled out as separate engine batches on this one GPU (2 lanes, as the bench runs them).  A scenario's tokens, RTG bins,
+    states and flags depend on its GLOBAL id only (sampling noise is keyed by it), so every world size gives the same
+    per-scenario results, and the summed device accumulators of the shards equal the single-rank vector."""
+    from ctrlsim_amd.dist import shard_ids
+    cfg = cfg_of("loop")
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    G = 8
+    make = lambda gid: scenarios.make_scenario(71, gid, n_agents=9, n_polylines=14, n_points=d.NP, extent=34.0)
+
+    def run(ids):
+        scns = [make(g) for g in ids]
+        eng = RolloutEngine(cfg, w, DEV, max_ctx=24, seed=12, lanes=2)
+        eng.load_scenarios(scns, steps=20)
+        r = eng.run(20).results()
+        gt = np.stack([np.stack([scenarios.standin_log(s, 20)[v]["traj"][:, :5] for v in range(9)]) for s in scns])
+        g4 = np.stack([np.concatenate([s.goal_pos, s.goal_heading[:, None], s.goal_speed[:, None]], 1) for s in scns])
+        return {g: {k: r[k][i] for k in ("tokens", "rtg_bins", "states", "coll")} for i, g in enumerate(ids)}, \
+            eng.metrics_pack(gt, g4).cpu().numpy()
+
+    ref, ref_vec = run(list(range(G)))
+    for W in (2, 4):
+        total = np.zeros_like(ref_vec)
+        for rank in range(W):
+            out, vec = run(shard_ids(rank, W, G // W))
+            total += vec
+            for g, o in out.items():
+                for k in o:
+                    assert np.array_equal(o[k], ref[g][k]), (W, rank, g, k)
+        np.testing.assert_allclose(total[:10], ref_vec[:10], rtol=1e-12)
+        np.testing.assert_array_equal(total[10:], ref_vec[10:])
