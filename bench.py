@@ -124,7 +124,7 @@ def main():
     def bench_step(i):                                        # one 90-step closed-loop rollout of slice i
         a, b = cuts[i % K], cuts[i % K + 1]
         eng.reset(a, b)
-        eng.run(R, s0=a, s1=b)
+        eng.run(R, s0=a, s1=b)                                # (finite-logit guard: after the timed region, below)
 
     for i in range(args.warmup):
         bench_step(i)

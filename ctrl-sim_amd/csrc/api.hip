@@ -1,5 +1,6 @@
 // extern "C" exports of the C ABI declared in include/ctrlsim.h (thin wrappers over the kernel launchers).
-#include "split.h"
+#include "common.h"
+#include "classes.h"
 #include "../../include/ctrlsim.h"
 
 int launch_gemm_nt(const float*, int, const float*, int, const float*, const float*, int, float*, int, int, int, int, int,
@@ -64,9 +65,25 @@ void prof_after(int cls, double flops, hipStream_t st, double bytes) {
   g_recs.push_back(ProfRec{g_pending[cls], b, cls, flops, bytes});
 }
 
-static int g_options[OPT_COUNT] = {1, 1, 0, 1};
-int nonfinite_count(int reset);
-extern "C" int ctrlsim_split_scheme() { return CTRLSIM_F16X3; }
+static int g_options[OPT_COUNT] = {1, 1, 0, 1, 1};
+// the process-wide non-finite counter (common.h): 4 bytes of device memory, allocated on first use on the then-current device
+int* ctrlsim_nonfinite_ptr() {
+  static int* p = nullptr;
+  if (!p) {
+    if (hipMalloc(reinterpret_cast<void**>(&p), sizeof(int)) != hipSuccess) { p = nullptr; return nullptr; }
+    (void)hipMemset(p, 0, sizeof(int));
+  }
+  return p;
+}
+// events counted since the last reset (synchronises the device)
+static int nonfinite_count(int reset) {
+  int* p = ctrlsim_nonfinite_ptr();
+  int n = 0;
+  if (!p || hipMemcpy(&n, p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return CTRLSIM_ELAUNCH;
+  if (reset && n && hipMemset(p, 0, sizeof(int)) != hipSuccess) return CTRLSIM_ELAUNCH;
+  return n;
+}
+extern "C" int ctrlsim_split_scheme() { return g_options[OPT_SPLIT] ? 1 : 0; }
 extern "C" int ctrlsim_nonfinite_count(int reset) { return nonfinite_count(reset); }
 int ctrlsim_option(int key) { return (key >= 0 && key < OPT_COUNT) ? g_options[key] : 0; }
 

@@ -22,6 +22,8 @@
 #include "split.h"
 #include <type_traits>
 
+namespace SPLIT_NS {
+
 #ifndef ATT_PMAX
 #define ATT_PMAX 32768.0f     // row-sum bound of the speculative softmax path: every probability then fits the fp16 plane
 #endif
@@ -627,7 +629,6 @@ __global__ __launch_bounds__(256) void kv_zero_tails_kernel(KvTailBatch tb, op_t
     reinterpret_cast<unsigned*>(base + NPL * K_PLANE + pl * V_PLANE + q0 * HD * 4)[off] = 0u;
   }
 }
-struct KvTailHost { int B, key0, n, nkt; long tile0; };
 int launch_kv_zero_tails(int n, const KvTailHost* t, void* img, hipStream_t st) {
   if (n < 0 || n > 16 || !img) return CTRLSIM_EINVAL;
   KvTailBatch tb;
@@ -681,7 +682,6 @@ __global__ __launch_bounds__(256) void kv_split_rows_classes_kernel(const float*
     for (int q = 0; q < NPL; ++q) Vs[q * V_PLANE + vo] = (unsigned short)vp[q];
   }
 }
-struct KvRowsHost { int B, R, nkt; long row0, tile0; const int* pos; };
 int launch_kv_split_rows_classes(const float* K, const float* V, int ldkv, int n, const KvRowsHost* cls, void* img, hipStream_t st) {
   if (n < 0 || n > 8 || !K || !V || !img || (ldkv & 3)) return CTRLSIM_EINVAL;
   KvRowsBatch kb;
@@ -727,13 +727,6 @@ static double attn_pairs(int mode, const int* q_pos, int Lq, int Lk, int A, int 
   }
   return (double)Lq * (double)(Lk + rep_keys);
 }
-
-// Host description of one class of a multi-class launch (launch_attention_classes)
-struct AttnClassHost {
-  int B, Lq, Lk, A, rep_keys, rep_mult, rep_pos0, nkt;
-  long q_row0, q_bs, o_row0, o_bs, img_tile0, pad_off;     // first Q / O row of the class (rows of ldq / ldo floats), first tile
-  const int* q_pos;
-};
 
 int launch_attention_bf16x6(int mode, const float* Q, int ldq, long q_batch_stride, const float* K, const float* V,
                             int ldkv, long kv_batch_stride, float* O, int ldo, long o_batch_stride, const int* q_pos,
@@ -816,3 +809,5 @@ int launch_attention_bf16x6_pre(int mode, const float* Q, int ldq, long q_batch_
   const AttnClassHost c{B, Lq, Lk, A, rep_keys, rep_mult, rep_pos0, nkt, 0, q_batch_stride, 0, o_batch_stride, 0, 0, q_pos};
   return launch_attention_classes(mode, Q, ldq, img, O, ldo, key_pad, 1, &c, st);
 }
+
+}  // namespace SPLIT_NS

@@ -8,8 +8,11 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = {"gemm": "", "gemm_bf16x6": "", "ffn_fused": "", "attention": "", "attention_bf16x6": "", "sim": "-ffp-contract=off", "context": "-ffp-contract=off", "embed": "",
-        "map_encoder": "", "sample": "", "metrics": "-ffp-contract=off", "forward": "", "api": ""}
+# sources -> extra flags.  The three split-operand kernel files are compiled ONCE PER SCHEME (csrc/split.h: -DCTRLSIM_F16X3=1 two fp16
+# planes, =0 three bf16 planes; each build lives in its own namespace) and dispatch.hip picks one at run time.
+SPLIT_SRCS = ("gemm_bf16x6", "ffn_fused", "attention_bf16x6")
+SRCS = {"gemm": "", "attention": "", "sim": "-ffp-contract=off", "context": "-ffp-contract=off", "embed": "",
+        "map_encoder": "", "sample": "", "metrics": "-ffp-contract=off", "forward": "", "dispatch": "", "api": ""}
 OUT = os.path.join(HERE, "libctrlsim_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
@@ -19,12 +22,14 @@ def _newer(a, b):
 
 
 def build(force=False, verbose=False):
-    deps = [os.path.join(HERE, "common.h"), os.path.join(HERE, "split.h"), os.path.join(HERE, "..", "..", "include", "ctrlsim.h")]
+    deps = [os.path.join(HERE, "common.h"), os.path.join(HERE, "split.h"), os.path.join(HERE, "classes.h"), os.path.join(HERE, "..", "..", "include", "ctrlsim.h")]
     objs = []
     procs = []
-    for name, extra in SRCS.items():
+    jobs = [(name, name, extra) for name, extra in SRCS.items()]
+    jobs += [(name, f"{name}_s{sch}", f"-DCTRLSIM_F16X3={sch}") for name in SPLIT_SRCS for sch in (1, 0)]
+    for name, objname, extra in jobs:
         src = os.path.join(HERE, name + ".hip")
-        obj = os.path.join(HERE, "build", name + ".o")
+        obj = os.path.join(HERE, "build", objname + ".o")
         os.makedirs(os.path.dirname(obj), exist_ok=True)
         objs.append(obj)
         if force or _newer(src, obj) or any(_newer(d, obj) for d in deps):
@@ -32,7 +37,7 @@ def build(force=False, verbose=False):
             cmd += os.environ.get("CTRLSIM_EXTRA_DEFS", "").split()   # A/B tuning knobs, e.g. -DGEMM_TBK=16
             if verbose:
                 print(" ".join(cmd))
-            procs.append((name, subprocess.Popen(cmd)))
+            procs.append((objname, subprocess.Popen(cmd)))
     for name, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {name}.hip")

@@ -59,6 +59,15 @@ __device__ __host__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   return z ^ (z >> 31);
 }
 
+// ---- non-finite guard.  One device counter per process (allocated on first use, ctrlsim_nonfinite_count reads / clears it).
+// The samplers count races that no finite logit won; every fused LayerNorm (GEMM / feed-forward epilogues, layernorm256) counts
+// rows whose variance is not finite.  The second matters: ReLU (v_max_f32) maps NaN to 0, so a row that overflowed the fp16
+// range of the two-plane operand split (csrc/split.h) would otherwise come out of the MLP heads as finite, wrong logits.
+int* ctrlsim_nonfinite_ptr();
+__device__ __forceinline__ void count_nonfinite_row(float var, int lane, int* __restrict__ counter) {
+  if (lane == 0 && !(var <= 3.0e38f)) atomicAdd(counter, 1);
+}
+
 // ---- optional per-launch HIP-event timing of the two MFMA kernel classes and four satellite kernels (bench.py's roofline numbers).
 // Disabled by default (zero overhead); when enabled every GEMM / attention launch is bracketed by two events on the
 // launch stream and tagged with its algorithmic FLOPs; nothing synchronises until ctrlsim_prof_collect().
@@ -72,5 +81,10 @@ void prof_after(int cls, double flops, hipStream_t st, double bytes = 0.0);   //
 enum { OPT_ATTN_IMPL = 0, OPT_GEMM_IMPL = 1,   // 0 = f32-input MFMA, 1 = split-bf16 (bf16x6) MFMA
        OPT_GEMM6_TILE = 2,                       // bf16x6 GEMM tile: 0 = auto, 1 = 128x128, 2 = 64x256 (tuning knob)
        OPT_FFN_FUSED = 3,                        // 1 = linear1-ReLU-linear2-residual-LayerNorm as one kernel (ffn_fused.hip)
-       OPT_COUNT = 4 };
+       OPT_SPLIT = 4,                            // operand split of the split-operand kernels (csrc/split.h): 1 = two fp16 planes, three
+                                                 // products (default), 0 = three bf16 planes, six products (full fp32 exponent range)
+       OPT_COUNT = 5 };
+// run-time view of the selected split (dispatch.hip): planes per operand, 16-bit elements per (context, head, tile) K/V image
+int split_npl();
+inline size_t split_kimg() { return (size_t)2 * split_npl() * 64 * 32; }
 int ctrlsim_option(int key);

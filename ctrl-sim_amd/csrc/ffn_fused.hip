@@ -22,6 +22,8 @@
 #include "split.h"
 #include <type_traits>
 
+namespace SPLIT_NS {
+
 namespace {
 
 constexpr int FF_BLK = NPL * 16 * 2 * 32 * 8;      // 16-bit elements of one weight block (W1: [NPL][16][2][32][8]; W2: [NPL][2][2][256][8])
@@ -43,7 +45,7 @@ constexpr size_t FF_RING_BYTES = (size_t)FF_RING * FF_BLK * sizeof(op_t) > (size
 __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
     const float* X, int ldx, const op_t* __restrict__ W1p, const float* __restrict__ b1,   // X may alias Y: no restrict
     const op_t* __restrict__ W2p, const float* __restrict__ b2, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float* Y, int ldy, int M, int nhb) {
+    const float* __restrict__ beta, float* Y, int ldy, int M, int nhb, int* __restrict__ nonfinite) {
   extern __shared__ __attribute__((aligned(16))) op_t ring[];      // FF_RING blocks of 48 KB, then b1 (F floats)
   float* b1s = reinterpret_cast<float*>(reinterpret_cast<char*>(ring) + FF_RING_BYTES);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
@@ -221,6 +223,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
         const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
         const f32x4 dv = v - mean;
         const float var = wave_sum(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2] + dv[3] * dv[3]) * (1.f / 256.f);
+        count_nonfinite_row(var, lane, nonfinite);
         const f32x4 y = dv * (1.0f / sqrtf(var + 1e-5f)) * gg + be;
         *reinterpret_cast<f32x4*>(Y + (size_t)grow * ldy + col) = y;
       }
@@ -248,7 +251,9 @@ int launch_ffn_fused_bf16x6(const float* X, int ldx, const void* W1p, const floa
   if (!attr_ok) return CTRLSIM_EINVAL;
   prof_before(PROF_GEMM, st);
   hipLaunchKernelGGL(ffn_fused_bf16x6_kernel, dim3(grid), dim3(256), shm, st, X, ldx, static_cast<const op_t*>(W1p), b1,
-                     static_cast<const op_t*>(W2p), b2, gamma, beta, Y, ldy, M, F / 32);
+                     static_cast<const op_t*>(W2p), b2, gamma, beta, Y, ldy, M, F / 32, ctrlsim_nonfinite_ptr());
   prof_after(PROF_GEMM, 4.0 * (double)M * DM * (double)F, st, 12.0 * (double)M * DM + 4.0 * NPL * (double)DM * F);   // x read as operand and as residual, y written; W1 / W2 as NPL planes
   return ctrlsim_launch_status();
 }
+
+}  // namespace SPLIT_NS

@@ -19,7 +19,8 @@
 #include <unordered_map>
 #include <vector>
 
-#include "split.h"
+#include "common.h"
+#include "classes.h"
 #include "../../include/ctrlsim.h"
 
 // launchers from the other translation units
@@ -32,22 +33,14 @@ int launch_layernorm256(const float*, int, const float*, int, const float*, cons
 int launch_gemm_nt_bf16x6_kv(const float*, int, const void*, int, int, const float*, const float*, int, float*, int, int, int,
                              int, int, const float*, const float*, void*, int, int, int, int, int, hipStream_t);
 int launch_kv_zero_tail(int, int, int, int, void*, hipStream_t);
-struct KvTailHost { int B, key0, n, nkt; long tile0; };
 int launch_kv_zero_tails(int, const KvTailHost*, void*, hipStream_t);
-struct KvRowsHost { int B, R, nkt; long row0, tile0; const int* pos; };
 int launch_kv_split_rows_classes(const float*, const float*, int, int, const KvRowsHost*, void*, hipStream_t);
 int launch_ffn_fused_bf16x6(const float*, int, const void*, const float*, const void*, const float*, const float*, const float*,
                             float*, int, int, int, hipStream_t);
 int launch_kv_split(const float*, const float*, int, long, int, int, int, void*, hipStream_t);
 int launch_kv_split_rows(const float*, const float*, int, long, const int*, int, int, int, void*, hipStream_t);
-struct AttnClassHost {
-  int B, Lq, Lk, A, rep_keys, rep_mult, rep_pos0, nkt;
-  long q_row0, q_bs, o_row0, o_bs, img_tile0, pad_off;
-  const int* q_pos;
-};
 int launch_attention_classes(int, const float*, int, const void*, float*, int, const unsigned char*, int, const AttnClassHost*,
                              hipStream_t);
-struct KvClassHost { int B, L, Lreg, rep_k0, nkt; long tile0; };
 int launch_gemm_nt_bf16x6_kvc(const float*, int, const void*, int, int, const float*, const float*, int, float*, int, int, int, int,
                               int, const float*, const float*, void*, int, int, const KvClassHost*, hipStream_t);
 int launch_in_mlp(const float*, int, int, const float*, const float*, const float*, const float*, float*, int, int,
@@ -67,11 +60,17 @@ int launch_map_pool(int, int, int, int, const float*, MapPoolWeights, float*, un
 
 namespace {
 
-struct Lin { const float* w; const float* b; const void* w3 = nullptr; int ntot = 0; int n0 = 0; };
+struct Lin {
+  const float* w; const float* b;
+  const void* w3s[2] = {nullptr, nullptr};      // operand planes per split scheme (OPT_SPLIT 0 / 1)
+  int ntot = 0; int n0 = 0;
+  const void* w3() const { return w3s[ctrlsim_option(OPT_SPLIT) ? 1 : 0]; }
+};
 struct LNp { const float* g; const float* b; };
 struct Mlp { Lin l0; LNp ln; Lin l3; };
-struct EncLayer { Lin qkv, out, lin1, lin2; LNp n1, n2; const void *w1p = nullptr, *w2p = nullptr; };
-struct DecLayer { Lin qkv, out, cq, ckv, cout, lin1, lin2; LNp n1, n2, n3; const void *w1p = nullptr, *w2p = nullptr; };
+struct FfnPlanes { const void *w1[2] = {nullptr, nullptr}, *w2[2] = {nullptr, nullptr}; };
+struct EncLayer { Lin qkv, out, lin1, lin2; LNp n1, n2; FfnPlanes fp; };
+struct DecLayer { Lin qkv, out, cq, ckv, cout, lin1, lin2; LNp n1, n2, n3; FfnPlanes fp; };
 
 }  // namespace
 
@@ -111,23 +110,31 @@ extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_w
     if (it == tab.end()) { ok = false; return nullptr; }
     return it->second;
   };
-  auto P3 = [&](const std::string& k) -> const void* {     // optional bf16x3 planes
-    auto it = tab.find(k + "#bf3");
-    return it == tab.end() ? nullptr : static_cast<const void*>(it->second);
-  };
   auto PX = [&](const std::string& k) -> const void* {     // optional extra operand images
     auto it = tab.find(k);
     return it == tab.end() ? nullptr : static_cast<const void*>(it->second);
   };
-  auto lin = [&](const std::string& k) { return Lin{P(k + ".weight"), P(k + ".bias"), P3(k + ".weight"), 0, 0}; };
+  auto mk = [&](const float* w, const float* b, const std::string& planes_of, int ntot, int n0) {   // operand planes of both schemes
+    Lin L{w, b};
+    L.w3s[0] = PX(planes_of + "#pl0"); L.w3s[1] = PX(planes_of + "#pl1");
+    L.ntot = ntot; L.n0 = n0;
+    return L;
+  };
+  auto ffnp = [&](const std::string& p) {
+    FfnPlanes f;
+    f.w1[0] = PX(p + ".ffn#w1p#pl0"); f.w1[1] = PX(p + ".ffn#w1p#pl1");
+    f.w2[0] = PX(p + ".ffn#w2p#pl0"); f.w2[1] = PX(p + ".ffn#w2p#pl1");
+    return f;
+  };
+  auto lin = [&](const std::string& k) { return mk(P(k + ".weight"), P(k + ".bias"), k + ".weight", 0, 0); };
   auto lnp = [&](const std::string& k) { return LNp{P(k + ".weight"), P(k + ".bias")}; };
   auto mlp = [&](const std::string& k) { return Mlp{lin(k + ".mlp.0"), lnp(k + ".mlp.1"), lin(k + ".mlp.3")}; };
   ctrlsim_model* m = new ctrlsim_model();
   m->d = *dims;
   m->embed_state = mlp("encoder.embed_state");
   m->embed_goal = mlp("encoder.embed_goal");
-  m->fold_state = Lin{P("fold.embed_state.w"), nullptr, P3("fold.embed_state.w"), 0, 0};
-  m->fold_goal = Lin{P("fold.embed_goal.w"), P("fold.embed_goal.b"), P3("fold.embed_goal.w"), 0, 0};
+  m->fold_state = mk(P("fold.embed_state.w"), nullptr, "fold.embed_state.w", 0, 0);
+  m->fold_goal = mk(P("fold.embed_goal.w"), P("fold.embed_goal.b"), "fold.embed_goal.w", 0, 0);
   m->tb = EmbedTables{P("encoder.embed_action.weight"), P("fold.rtg_table_goal"), P("fold.rtg_table_veh"),
                       P("fold.rtg_table_road"), P("fold.rtg_bias"), P("encoder.embed_timestep.weight"),
                       P("encoder.embed_agent_id.weight"), P("encoder.embed_ln.weight"), P("encoder.embed_ln.bias"),
@@ -144,34 +151,31 @@ extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_w
   for (int i = 0; i < dims->NE; ++i) {
     const std::string p = "encoder.transformer_encoder.layers." + std::to_string(i);
     EncLayer L;
-    L.qkv = Lin{P(p + ".self_attn.in_proj_weight"), P(p + ".self_attn.in_proj_bias"), P3(p + ".self_attn.in_proj_weight"), 3 * DM, 0};
+    L.qkv = mk(P(p + ".self_attn.in_proj_weight"), P(p + ".self_attn.in_proj_bias"), p + ".self_attn.in_proj_weight", 3 * DM, 0);
     L.out = lin(p + ".self_attn.out_proj");
     L.lin1 = lin(p + ".linear1");
     L.lin2 = lin(p + ".linear2");
     L.n1 = lnp(p + ".norm1");
     L.n2 = lnp(p + ".norm2");
-    L.w1p = PX(p + ".ffn#w1p");
-    L.w2p = PX(p + ".ffn#w2p");
+    L.fp = ffnp(p);
     m->enc.push_back(L);
   }
   for (int i = 0; i < dims->ND; ++i) {
     const std::string p = "decoder.transformer_decoder.layers." + std::to_string(i);
     DecLayer L;
-    L.qkv = Lin{P(p + ".self_attn.in_proj_weight"), P(p + ".self_attn.in_proj_bias"), P3(p + ".self_attn.in_proj_weight"), 3 * DM, 0};
+    L.qkv = mk(P(p + ".self_attn.in_proj_weight"), P(p + ".self_attn.in_proj_bias"), p + ".self_attn.in_proj_weight", 3 * DM, 0);
     L.out = lin(p + ".self_attn.out_proj");
     const float* cw = P(p + ".multihead_attn.in_proj_weight");
     const float* cb = P(p + ".multihead_attn.in_proj_bias");
-    const void* cw3 = P3(p + ".multihead_attn.in_proj_weight");
-    L.cq = Lin{cw, cb, cw3, 3 * DM, 0};
-    L.ckv = Lin{cw ? cw + DM * DM : nullptr, cb ? cb + DM : nullptr, cw3, 3 * DM, DM};
+    L.cq = mk(cw, cb, p + ".multihead_attn.in_proj_weight", 3 * DM, 0);
+    L.ckv = mk(cw ? cw + DM * DM : nullptr, cb ? cb + DM : nullptr, p + ".multihead_attn.in_proj_weight", 3 * DM, DM);
     L.cout = lin(p + ".multihead_attn.out_proj");
     L.lin1 = lin(p + ".linear1");
     L.lin2 = lin(p + ".linear2");
     L.n1 = lnp(p + ".norm1");
     L.n2 = lnp(p + ".norm2");
     L.n3 = lnp(p + ".norm3");
-    L.w1p = PX(p + ".ffn#w1p");
-    L.w2p = PX(p + ".ffn#w2p");
+    L.fp = ffnp(p);
     m->dec.push_back(L);
   }
   m->head_action = mlp("decoder.predict_action");
@@ -294,7 +298,7 @@ Ws carve(const ctrlsim_dims& d, const Batch& bt, char* base) {
   w.xn = F(rN, DM); w.tmpn = F(rN, DM); w.attn_n = F(rN, DM); w.qkvn = F(rN, 3 * DM); w.qcn = F(rN, DM); w.ffnn = F(rN, d.F);
   w.pos_new = I(4 * bt.isum); w.key_new = I(4 * bt.isum); w.src_new = I(4 * bt.isum);
   w.idx_new = I(rN); w.idx_state_in_new = I(rA);
-  const size_t tile_bytes = (size_t)2 * NPL * 64 * HD * 2;   // 8 KB per plane pair of a (context, head, tile) image
+  const size_t tile_bytes = split_kimg() * 2;   // 8 KB per plane pair of a (context, head, tile) image
   w.img_dec_bytes = (size_t)bt.tiles_dec * tile_bytes;
   for (int i = 0; i < d.ND; ++i) w.img_dec[i] = take(w.img_dec_bytes);
   for (int i = 0; i < d.ND; ++i) w.img_mem[i] = take((size_t)bt.tiles_mem * tile_bytes);
@@ -322,8 +326,8 @@ __global__ void fill_index_kernel(int B, int Areg, int L, int Lreg, int rep_k0, 
 // y = act(x W^T + b [+ R]) through the bf16x6 MFMA kernel when the packed planes exist, else the f32-input MFMA kernel
 int gemm(const Lin& L, const float* x, int ldx, const float* R, int ldr, float* y, int ldy, int rows, int n, int k, int relu,
          hipStream_t st) {
-  if (L.w3 && k % 32 == 0 && ctrlsim_option(OPT_GEMM_IMPL) == 1)
-    return launch_gemm_nt_bf16x6(x, ldx, L.w3, L.ntot ? L.ntot : n, L.n0, L.b, R, ldr, y, ldy, rows, n, k, relu, nullptr,
+  if (L.w3() && k % 32 == 0 && ctrlsim_option(OPT_GEMM_IMPL) == 1)
+    return launch_gemm_nt_bf16x6(x, ldx, L.w3(), L.ntot ? L.ntot : n, L.n0, L.b, R, ldr, y, ldy, rows, n, k, relu, nullptr,
                                  nullptr, st);
   return launch_gemm_nt(x, ldx, L.w, k, L.b, R, ldr, y, ldy, rows, n, k, relu, st);
 }
@@ -332,15 +336,17 @@ int gemm(const Lin& L, const float* x, int ldx, const float* R, int ldr, float* 
 // y may alias R), GEMM into `tmp` + layernorm256 on the f32-input path
 int gemm_ln(const Lin& L, const LNp& n, const float* x, int ldx, const float* R, int ldr, float* y, int ldy, float* tmp,
             int rows, int k, int relu, hipStream_t st) {
-  if (L.w3 && k % 32 == 0 && ctrlsim_option(OPT_GEMM_IMPL) == 1)
-    return launch_gemm_nt_bf16x6(x, ldx, L.w3, L.ntot ? L.ntot : DM, L.n0, L.b, R, ldr, y, ldy, rows, DM, k, relu, n.g, n.b, st);
+  if (L.w3() && k % 32 == 0 && ctrlsim_option(OPT_GEMM_IMPL) == 1)
+    return launch_gemm_nt_bf16x6(x, ldx, L.w3(), L.ntot ? L.ntot : DM, L.n0, L.b, R, ldr, y, ldy, rows, DM, k, relu, n.g, n.b, st);
   CHK(launch_gemm_nt(x, ldx, L.w, k, L.b, R, ldr, tmp, DM, rows, DM, k, 0, st));
   return launch_layernorm256(tmp, DM, nullptr, 0, n.g, n.b, y, ldy, rows, relu, st);
 }
 
 // x <- LayerNorm(x + linear2(relu(linear1(x)))): one fused kernel (hidden tile in registers) or Linear + Linear/LN
-int ffn_block(const Lin& l1, const Lin& l2, const LNp& n, const void* w1p, const void* w2p, float* x, float* hidden, float* tmp,
+int ffn_block(const Lin& l1, const Lin& l2, const LNp& n, const FfnPlanes& fp, float* x, float* hidden, float* tmp,
               int rows, int F, hipStream_t st) {
+  const int sch = ctrlsim_option(OPT_SPLIT) ? 1 : 0;
+  const void *w1p = fp.w1[sch], *w2p = fp.w2[sch];
   if (w1p && w2p && !(F & 31) && ctrlsim_option(OPT_FFN_FUSED) >= 1 && ctrlsim_option(OPT_GEMM_IMPL) == 1)
     return launch_ffn_fused_bf16x6(x, DM, w1p, l1.b, w2p, l2.b, n.g, n.b, x, DM, rows, F, st);
   CHK(gemm(l1, x, DM, nullptr, 0, hidden, F, rows, F, DM, 1, st));
@@ -409,7 +415,7 @@ int attention(const ctrlsim_dims& d, const Batch& bt, const Ws& w, const AttnCal
 int gemm_kv(const ctrlsim_dims& d, const Batch& bt, const Ws& w, const Lin& L, const float* x, float* y, int ldy, int n, int kcol0,
             void* img, bool mem, hipStream_t st) {
   const long rows = mem ? bt.rM : bt.rL;
-  bool fused = presplit() && L.w3 && ctrlsim_option(OPT_GEMM_IMPL) == 1;
+  bool fused = presplit() && L.w3() && ctrlsim_option(OPT_GEMM_IMPL) == 1;
   KvClassHost kc[8];
   for (int k = 0; k < bt.n; ++k) {
     const Cls& c = bt.c[k];
@@ -418,7 +424,7 @@ int gemm_kv(const ctrlsim_dims& d, const Batch& bt, const Ws& w, const Lin& L, c
                         mem ? c.tile_mem : c.tile_dec};
     fused = fused && !(Lk & 3) && !(Lreg & 3) && Lk >= 32;
   }
-  const size_t KIMG = (size_t)2 * NPL * 64 * HD;      // 16-bit elements per tile
+  const size_t KIMG = split_kimg();      // 16-bit elements per tile
   if (fused) {
     KvTailHost tails[16];
     int nt = 0;
@@ -427,7 +433,7 @@ int gemm_kv(const ctrlsim_dims& d, const Batch& bt, const Ws& w, const Lin& L, c
       if (kc[k].Lreg < kc[k].L) tails[nt++] = KvTailHost{kc[k].B, kc[k].rep_k0, kc[k].L - kc[k].Lreg, kc[k].nkt, kc[k].tile0};
     }
     CHK(launch_kv_zero_tails(nt, tails, img, st));
-    return launch_gemm_nt_bf16x6_kvc(x, DM, L.w3, L.ntot ? L.ntot : n, L.n0, L.b, nullptr, 0, y, ldy, (int)rows, n, DM, 0, nullptr,
+    return launch_gemm_nt_bf16x6_kvc(x, DM, L.w3(), L.ntot ? L.ntot : n, L.n0, L.b, nullptr, 0, y, ldy, (int)rows, n, DM, 0, nullptr,
                                      nullptr, img, kcol0, bt.n, kc, st);
   }
   CHK(gemm(L, x, DM, nullptr, 0, y, ldy, (int)rows, n, DM, 0, st));
@@ -435,12 +441,12 @@ int gemm_kv(const ctrlsim_dims& d, const Batch& bt, const Ws& w, const Lin& L, c
   for (int k = 0; k < bt.n; ++k) {
     const Cls& c = bt.c[k];
     const long r0 = mem ? c.rM : c.rL;
-    op_t* base = static_cast<op_t*>(img) + (size_t)kc[k].tile0 * KIMG;
+    unsigned short* base = static_cast<unsigned short*>(img) + (size_t)kc[k].tile0 * KIMG;
     const float* Kp = y + r0 * ldy + kcol0;
     if (kc[k].Lreg == kc[k].L) {
       CHK(launch_kv_split(Kp, Kp + DM, ldy, (long)kc[k].L * ldy, c.B, kc[k].L, kc[k].nkt, base, st));
     } else {
-      if (hipMemsetAsync(base, 0, (size_t)c.B * NHEAD * kc[k].nkt * KIMG * sizeof(op_t), st) != hipSuccess) return CTRLSIM_ELAUNCH;
+      if (hipMemsetAsync(base, 0, (size_t)c.B * NHEAD * kc[k].nkt * KIMG * sizeof(unsigned short), st) != hipSuccess) return CTRLSIM_ELAUNCH;
       CHK(launch_kv_split_rows(Kp, Kp + DM, ldy, (long)kc[k].L * ldy, w.key_all + c.koff, c.B, kc[k].L, kc[k].nkt, base, st));
     }
   }
@@ -500,7 +506,7 @@ int cross_and_ffn(const ctrlsim_model* m, const Batch& bt, const DecLayer& Ld, i
   CHK(attention(d, bt, w, AttnCall{0, q, qc, DM, w.memkv[layer], w.memkv[layer] + DM, 2 * DM, w.img_mem[layer], true, att, 0, 0,
                                    Rn_mul}, st));
   CHK(gemm_ln(Ld.cout, Ld.n2, att, DM, x, DM, x, DM, tmp, (int)rows, DM, 0, st));
-  CHK(ffn_block(Ld.lin1, Ld.lin2, Ld.n3, Ld.w1p, Ld.w2p, x, ffn, tmp, (int)rows, d.F, st));
+  CHK(ffn_block(Ld.lin1, Ld.lin2, Ld.n3, Ld.fp, x, ffn, tmp, (int)rows, d.F, st));
   return 0;
 }
 // map encoder + scene encoder + per-layer memory K/V (everything that only depends on the frame of the context)
@@ -533,7 +539,7 @@ int scene_side(const ctrlsim_model* m, const Batch& bt, const Ws& w, float* dbg_
     CHK(attention(d, bt, w, AttnCall{0, Q_SCENE, w.eqkv, 3 * DM, w.eqkv + DM, w.eqkv + 2 * DM, 3 * DM, w.img_enc, true, w.eatt, 0, 0, 0},
                   st));
     CHK(gemm_ln(Le.out, Le.n1, w.eatt, DM, w.src, DM, w.src, DM, w.etmp, rM, DM, 0, st));
-    CHK(ffn_block(Le.lin1, Le.lin2, Le.n2, Le.w1p, Le.w2p, w.src, w.effn, w.etmp, rM, d.F, st));
+    CHK(ffn_block(Le.lin1, Le.lin2, Le.n2, Le.fp, w.src, w.effn, w.etmp, rM, d.F, st));
   }
   // memory K/V of every decoder layer (cached for pass 2)
   for (int i = 0; i < d.ND; ++i) CHK(gemm_kv(d, bt, w, m->dec[i].ckv, w.src, w.memkv[i], 2 * DM, 2 * DM, 0, w.img_mem[i], true, st));

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void layernorm256_kernel(const float* X, int l
                                                            const float* Radd, int ldr,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* Y,
-                                                           int ldy, int rows) {
+                                                           int ldy, int rows, int* __restrict__ nonfinite) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -188,6 +188,7 @@ __global__ __launch_bounds__(256) void layernorm256_kernel(const float* X, int l
   const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
   const f32x4 d = v - mean;
   const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / 256.f);
+  count_nonfinite_row(var, lane, nonfinite);
   const float rstd = 1.0f / sqrtf(var + 1e-5f);
   const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + lane * 4);
   const f32x4 b = *reinterpret_cast<const f32x4*>(beta + lane * 4);
@@ -285,9 +286,9 @@ int launch_layernorm256(const float* X, int ldx, const float* Radd, int ldr, con
   if (rows <= 0) return CTRLSIM_OK;
   dim3 g((rows + 3) / 4), b(256);
   if (relu)
-    hipLaunchKernelGGL((layernorm256_kernel<true>), g, b, 0, st, X, ldx, Radd, ldr, gamma, beta, Y, ldy, rows);
+    hipLaunchKernelGGL((layernorm256_kernel<true>), g, b, 0, st, X, ldx, Radd, ldr, gamma, beta, Y, ldy, rows, ctrlsim_nonfinite_ptr());
   else
-    hipLaunchKernelGGL((layernorm256_kernel<false>), g, b, 0, st, X, ldx, Radd, ldr, gamma, beta, Y, ldy, rows);
+    hipLaunchKernelGGL((layernorm256_kernel<false>), g, b, 0, st, X, ldx, Radd, ldr, gamma, beta, Y, ldy, rows, ctrlsim_nonfinite_ptr());
   return ctrlsim_launch_status();
 }
 

@@ -26,6 +26,8 @@
 #include "split.h"
 #include <type_traits>
 
+namespace SPLIT_NS {
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define XK 16
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
     const float* __restrict__ A, int lda, const op_t* __restrict__ W3,   // [K/16][NPL][2][n_total][8]
     const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* R, int ldr, float* C, int ldc, int M, int N, int K, int m_tiles, int n_tiles,   // C may alias R: no restrict
-    int n_total, int n0, KvImg kv) {
+    int n_total, int n0, KvImg kv, int* __restrict__ nonfinite) {
   // W3 holds all n_total rows of the packed matrix; this GEMM uses rows [n0, n0 + N) (e.g. the q / kv halves of an
   // in_proj_weight)
   constexpr int WMR = 32 * MR;                     // rows of a wave tile (MR x 2 MFMA tiles of 32 x 32)
@@ -371,6 +373,7 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
           const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
           const f32x4 dv = v - mean;
           const float var = wave_sum(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2] + dv[3] * dv[3]) * (1.f / 256.f);
+          count_nonfinite_row(var, lane, nonfinite);
           f32x4 y = dv * (1.0f / sqrtf(var + 1e-5f)) * *reinterpret_cast<const f32x4*>(gamma + gcol) +
                     *reinterpret_cast<const f32x4*>(beta + gcol);
           if (RELU) {
@@ -410,7 +413,6 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
   }
 }
 
-struct KvClassHost { int B, L, Lreg, rep_k0, nkt; long tile0; };   // B contexts of L rows; class rows follow each other in A / C
 int launch_gemm_nt_bf16x6_kvc(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias,
                               const float* R, int ldr, float* C, int ldc, int M, int N, int K, int relu,
                               const float* ln_gamma, const float* ln_beta, void* kv_img, int kv_col0, int kv_n,
@@ -482,8 +484,9 @@ int launch_gemm_nt_bf16x6_kvc(const float* A, int lda, const void* W3, int n_tot
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) == hipSuccess;                      \
     if (!attr_ok) return CTRLSIM_EINVAL;                                                                              \
     hipLaunchKernelGGL((gemm_nt_bf16x6_kernel<WR_, WC_, MR_, RELU_, RESID_, LN_, KV_>), g, b, shm, st, A, lda, w, bias,    \
-                       ln_gamma, ln_beta, R, ldr, C, ldc, M, N, K, m_tiles, n_tiles, n_total, n0, kv);                \
+                       ln_gamma, ln_beta, R, ldr, C, ldc, M, N, K, m_tiles, n_tiles, n_total, n0, kv, nonfinite);                \
   } while (0)
+  int* nonfinite = ctrlsim_nonfinite_ptr();
   prof_before(PROF_GEMM, st);
   if (kv_img) {
     if (small) GEMM6_LAUNCH_(2, 2, 1, false, false, false, true);
@@ -516,3 +519,5 @@ int launch_gemm_nt_bf16x6_kvc(const float* A, int lda, const void* W3, int n_tot
   }
   return ctrlsim_launch_status();
 }
+
+}  // namespace SPLIT_NS

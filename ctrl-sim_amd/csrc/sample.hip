@@ -35,8 +35,8 @@ struct ArgBest {
 };
 
 // Races that no finite score won (NaN logits: e.g. an activation beyond the fp16 range of the split operands, csrc/split.h):
-// counted here, the token falls back to a valid id, and ctrlsim_nonfinite_count lets the host fail loudly.
-__device__ int g_nonfinite = 0;
+// counted in the process-wide non-finite counter (common.h), the token falls back to a valid id, and ctrlsim_nonfinite_count
+// lets the host fail loudly.
 
 __device__ __forceinline__ ArgBest wave_argmax(double s, int i) {
 #pragma unroll
@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void sample_rtg_kernel(const float* __restrict
                                                          const double* __restrict__ tilt_scn,  // [S,3] or null (uniform)
                                                          const float* __restrict__ noise,      // [S*N, 3, R] or null
                                                          uint64_t seed, const int64_t* __restrict__ scenario_id, int t,
-                                                         int* __restrict__ hist_rtg, int N, int Tmax, int SN) {
+                                                         int* __restrict__ hist_rtg, int N, int Tmax, int SN,
+                                                         int* __restrict__ g_nonfinite) {
   const int sv = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (sv >= SN) return;
   const int ctx = own_ctx[sv];
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void sample_rtg_kernel(const float* __restrict
       if (sc > best) { best = sc; bi = i; }
     }
     ArgBest r = wave_argmax(best, bi);
-    if (r.i >= R) { r.i = 0; if (lane == 0) atomicAdd(&g_nonfinite, 1); }
+    if (r.i >= R) { r.i = 0; if (lane == 0) atomicAdd(g_nonfinite, 1); }
     if (lane == 0) hist_rtg[((size_t)sv * Tmax + t) * 3 + c] = r.i;
   }
 }
@@ -96,7 +97,8 @@ __global__ __launch_bounds__(256) void sample_action_kernel(const float* __restr
                                                             double top_p, const float* __restrict__ noise,  // [S*N, V] or null
                                                             uint64_t seed, const int64_t* __restrict__ scenario_id,
                                                             int t, int* __restrict__ hist_tok, int* __restrict__ act_now,
-                                                            int N, int Tmax, int SN, int zero_token) {
+                                                            int N, int Tmax, int SN, int zero_token,
+                                                            int* __restrict__ g_nonfinite) {
   extern __shared__ double pbuf[];                  // [4][V] when nucleus sampling is on
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int sv = blockIdx.x * 4 + w;
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256) void sample_action_kernel(const float* __restr
     if (sc > best) { best = sc; bi = i; }
   }
   ArgBest r = wave_argmax(best, bi);
-  if (r.i >= V) { r.i = zero_token; if (lane == 0) atomicAdd(&g_nonfinite, 1); }
+  if (r.i >= V) { r.i = zero_token; if (lane == 0) atomicAdd(g_nonfinite, 1); }
   if (lane == 0) { hist_tok[(size_t)sv * Tmax + t] = r.i; act_now[sv] = r.i; }
 }
 
@@ -156,7 +158,7 @@ int launch_sample_rtg(const float* rtg_logits, int A, int R, const int* own_ctx,
   if (SN <= 0) return CTRLSIM_OK;
   if (t < 0 || t >= Tmax) return CTRLSIM_EINVAL;
   hipLaunchKernelGGL(sample_rtg_kernel, dim3((SN + 3) / 4), dim3(256), 0, st, rtg_logits, A, R, own_ctx, own_slot, ctx_row0, tilted,
-                     tilt3[0], tilt3[1], tilt3[2], tilt_scn, noise, seed, scenario_id, t, hist_rtg, N, Tmax, SN);
+                     tilt3[0], tilt3[1], tilt3[2], tilt_scn, noise, seed, scenario_id, t, hist_rtg, N, Tmax, SN, ctrlsim_nonfinite_ptr());
   return ctrlsim_launch_status();
 }
 
@@ -169,17 +171,8 @@ int launch_sample_action(const float* act_logits, int A, int V, const int* mem_c
   if (t < 0 || t >= Tmax || temperature <= 0.f) return CTRLSIM_EINVAL;
   const size_t shm = top_p > 0.0 ? (size_t)4 * V * sizeof(double) : 0;
   hipLaunchKernelGGL(sample_action_kernel, dim3((SN + 3) / 4), dim3(256), shm, st, act_logits, A, V, mem_ctx, mem_slot, ctx_row0,
-                     temperature, top_p, noise, seed, scenario_id, t, hist_tok, act_now, N, Tmax, SN, zero_token);
+                     temperature, top_p, noise, seed, scenario_id, t, hist_tok, act_now, N, Tmax, SN, zero_token,
+                     ctrlsim_nonfinite_ptr());
   return ctrlsim_launch_status();
 }
 
-// number of sampling races without a finite score since the last reset (synchronises the device)
-int nonfinite_count(int reset) {
-  int n = 0;
-  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_nonfinite), sizeof(int)) != hipSuccess) return CTRLSIM_ELAUNCH;
-  if (reset) {
-    const int z = 0;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_nonfinite), &z, sizeof(int)) != hipSuccess) return CTRLSIM_ELAUNCH;
-  }
-  return n;
-}

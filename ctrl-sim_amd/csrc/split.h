@@ -14,6 +14,7 @@
 // the product list, the weight scale.  ctrlsim_amd/pack.py asks the library (ctrlsim_split_scheme) and packs accordingly.
 #pragma once
 #include "common.h"
+#include "classes.h"
 
 #ifndef CTRLSIM_F16X3
 #define CTRLSIM_F16X3 1
@@ -22,7 +23,10 @@
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// Both schemes are built into the library (build.py compiles gemm_bf16x6.hip, ffn_fused.hip and attention_bf16x6.hip once per
+// scheme); everything in those files lives in the namespace SPLIT_NS and dispatch.hip picks one at run time (OPT_SPLIT).
 #if CTRLSIM_F16X3
+#define SPLIT_NS s1
 #define NPL 2
 #define NPROD 3
 #define WSCALE 256.0f
@@ -46,6 +50,7 @@ __device__ __forceinline__ float op_hi(unsigned u) { return (float)__builtin_bit
   ACC = MFMA_OP(A[0], B[0], ACC);
 #define PROD_LIST(X) X(1, 0) X(0, 1) X(0, 0)          /* (plane of A, plane of B), smallest product first */
 #else
+#define SPLIT_NS s0
 #define NPL 3
 #define NPROD 6
 #define WSCALE 1.0f

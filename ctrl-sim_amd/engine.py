@@ -143,8 +143,8 @@ class _Lane:
         B = eng.ctx_cap                                           # contexts per model batch (compact ones are cheap: see _chunks)
         self.idx = idx
         self.ctx = CtxBuffers(d, B, dev)
-        self.ws = torch.empty(eng.model.workspace_bytes(eng.max_ctx, d.T) + eng._ws_fixed + (1 << 20), dtype=torch.uint8,
-                              device=dev)             # max_ctx plain contexts always fit, whatever the class mix
+        self.ws = torch.empty(eng._ws_bytes + (1 << 20), dtype=torch.uint8, device=dev)   # max_ctx plain contexts always fit,
+                                                                                            # whatever the class mix and the split
         self.rtg_logits = torch.empty(B, d.A, d.R * d.C, device=dev)
         self.act_logits = torch.empty(B, d.A, d.V, device=dev)
         self.ctx_scn = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -161,7 +161,7 @@ class _Lane:
 class RolloutEngine:
     def __init__(self, cfg, weights: dict, device="cuda:0", max_ctx=256, seed=0, tilt=(0.0, 0.0, 0.0),
                  temperature=None, nucleus=None, top_p=None, kinematic=False, model=None, use_cache=True, contacts=True,
-                 lanes=1, compact=True):
+                 lanes=1, compact=True, split="auto"):
         self.cfg = cfg
         self.w = cfg.dataset.waymo
         self.dims = Dims(cfg)
@@ -169,6 +169,12 @@ class RolloutEngine:
         torch.cuda.set_device(self.device)
         self.model = model if model is not None else HipModel(cfg, weights, device)
         self.lib = self.model.lib
+        # operand split of the matrix kernels (csrc/split.h; the option is process-global): "f16x3" two fp16 planes, three products;
+        # "bf16x6" three bf16 planes, six products — half the speed, the whole fp32 exponent range; "auto" = f16x3, and a rollout
+        # whose sampling met non-finite logits (an operand beyond the fp16 range: trained weights can do that) is repeated with bf16x6
+        assert split in ("auto", "f16x3", "bf16x6")
+        self.split = split
+        self._set_split(0 if split == "bf16x6" else 1)
         pol = cfg.eval.policy
         self.temperature = float(pol.action_temperature if temperature is None else temperature)
         nuc = bool(pol.nucleus_sampling if nucleus is None else nucleus)
@@ -204,9 +210,14 @@ class RolloutEngine:
         self._sizes_c = (C.c_int * len(self.sizes))(*self.sizes)
         self.ctx_cap = self.max_ctx * (4 if len(self.sizes) > 1 else 1)
         # workspace bytes per context of each class (the carve is linear in B up to alignment), + a fixed allowance per class
+        cur = int(self.lib.ctrlsim_split_scheme())
+        if self.split == "auto":
+            self._set_split(0)                      # size the workspace for the larger (three-plane) K/V images
         wb = self.model.workspace_bytes
         self._bpc = [(wb(257, self.dims.T, a) - wb(1, self.dims.T, a)) / 256.0 for a in self.sizes]
         self._ws_fixed = sum(wb(1, self.dims.T, a) for a in self.sizes) + (1 << 20)
+        self._ws_bytes = wb(self.max_ctx, self.dims.T) + self._ws_fixed
+        self._set_split(cur)
         self.n_lanes = max(1, int(lanes))
         self.lanes = [_Lane(self, i, self.n_lanes > 1) for i in range(self.n_lanes)]
         L0 = self.lanes[0]                   # the synchronous single-stream entry points (policy_step / step) use lane 0
@@ -215,6 +226,9 @@ class RolloutEngine:
         self._ws_cap = L0.ws.numel()
         self._main = torch.cuda.current_stream(self.device)
         self.S = 0
+
+    def _set_split(self, scheme):
+        _lib.check(self.lib.ctrlsim_set_option(4, int(scheme)), "set_option(OPT_SPLIT)")
 
     # ------------------------------------------------------------------ scenario upload / reset
     def load_scenarios(self, scns, steps=None):
@@ -286,6 +300,7 @@ class RolloutEngine:
         st = _lib.stream_ptr()
         s1 = self.S if s1 is None else s1
         sl = slice(s0, s1)
+        self._fresh = (s0, s1)
         self.hist_states[sl].zero_()
         self.coll[sl].zero_()
         self.hist_tok[sl].fill_(ZERO_ACTION_TOKEN)
@@ -542,6 +557,8 @@ class RolloutEngine:
         rollout).  noise_fn(t) -> (noise_rtg, noise_act): explicit sampling noise, synchronous single-lane path."""
         steps = self.steps if steps is None else steps
         s1 = self.S if s1 is None else s1
+        self._last_run = (steps, s0, s1) if (noise_fn is None and getattr(self, "_fresh", None) == (s0, s1)) else None
+        self._fresh = None
         if self.dims.VARIANT == 3:
             raise NotImplementedError("the Decision-Transformer policy conditions on real-time rewards computed by the rollout "
                                       "driver: run it through PolicyEvaluator (hist_rtg is fed per step), not RolloutEngine.run")
@@ -612,12 +629,37 @@ class RolloutEngine:
                                                  p(g4_d), p(em_d), params, p(edges), p(out), _lib.stream_ptr()), "metrics_pack")
         return out
 
-    def results(self):
+    def check_finite(self):
+        """Synchronise and look at the samplers' non-finite-logit counter.  With split="auto" a rollout that started from reset()
+        and met such logits under the two-fp16-plane split is repeated with three bf16 planes (which stay selected); -> True if
+        that happened.  Anything else non-finite raises."""
         torch.cuda.synchronize(self.device)
         bad = int(self.lib.ctrlsim_nonfinite_count(1))
-        if bad:
-            raise FloatingPointError(f"{bad} sampling races had no finite logit (NaN in the forward pass: an activation beyond "
-                                     "the fp16 range of the split operands, csrc/split.h, or bad weights)")
+        if not bad:
+            return False
+        last = getattr(self, "_last_run", None)
+        if self.split == "auto" and int(self.lib.ctrlsim_split_scheme()) == 1 and last is not None:
+            self._set_split(0)
+            steps, s0, s1 = last
+            self.reset(s0, s1)
+            self.run(steps, s0=s0, s1=s1)
+            torch.cuda.synchronize(self.device)
+            bad = int(self.lib.ctrlsim_nonfinite_count(1))
+            if not bad:
+                return True
+        raise FloatingPointError(f"{bad} sampling races had no finite logit (NaN in the forward pass: an activation beyond "
+                                 "the fp16 range of the split operands, csrc/split.h, or bad weights)")
+
+    def rollout(self, steps=None, s0=0, s1=None):
+        """reset + run + check_finite of scenarios [s0, s1): a complete closed-loop rollout, repeated with the range-safe operand
+        split if the fast one overflowed (split="auto")."""
+        self.reset(s0, s1)
+        self.run(steps, s0=s0, s1=s1)
+        self.check_finite()
+        return self
+
+    def results(self):
+        self.check_finite()
         return dict(tokens=self.hist_tok.cpu().numpy(), rtg_bins=self.hist_rtg.cpu().numpy(),
                     states=self.hist_states.cpu().numpy(), coll=self.coll.cpu().numpy(),
                     n_groups=self.groups_per_step.copy())

@@ -94,9 +94,13 @@ def split_scheme():
     return (2, 256.0) if int(_lib.lib().ctrlsim_split_scheme()) == 1 else (3, 1.0)
 
 
-def _planes3(W: np.ndarray):
-    """[rows, cols] float32 -> the operand planes [NPL][rows][cols] as 16-bit words: W * scale = sum of the planes."""
-    npl, scale = split_scheme()
+SCHEMES = {1: (2, 256.0), 0: (3, 1.0)}        # ctrlsim_set_option(OPT_SPLIT): 1 = two fp16 planes (x 2^8), 0 = three bf16 planes
+
+
+def _planes3(W: np.ndarray, scheme=None):
+    """[rows, cols] float32 -> the operand planes [NPL][rows][cols] as 16-bit words: W * scale = sum of the planes.
+    scheme None = the one currently selected in the library."""
+    npl, scale = split_scheme() if scheme is None else SCHEMES[scheme]
     W = np.ascontiguousarray(W, np.float32) * np.float32(scale)
     if npl == 2:
         with np.errstate(over="ignore", invalid="ignore"):
@@ -104,8 +108,8 @@ def _planes3(W: np.ndarray):
             lo = (W - hi.astype(np.float32)).astype(np.float16)
         if not (np.isfinite(hi).all() and np.isfinite(lo).all()):
             raise FloatingPointError(f"weight magnitude {float(np.abs(W).max()) / scale:.4g} is beyond the fp16 range of the "
-                                     f"two-plane operand split (|w| < {65504.0 / scale:.0f}): rebuild the library with "
-                                     "-DCTRLSIM_F16X3=0 (three bf16 planes, csrc/split.h)")
+                                     f"two-plane operand split (|w| < {65504.0 / scale:.0f}): select the three-bf16-plane scheme "
+                                     "(ctrlsim_set_option(OPT_SPLIT = 4, 0); RolloutEngine(split='bf16x6'))")
         return np.stack([hi.view(np.uint16), lo.view(np.uint16)], 0)
     hi = bf16_rne(W)
     r1 = W - bf16_to_f32(hi)
@@ -114,21 +118,21 @@ def _planes3(W: np.ndarray):
     return np.stack([hi, mid, lo], 0)                                     # [NPL][rows][cols] uint16
 
 
-def split3_planes(W: np.ndarray) -> np.ndarray:
+def split3_planes(W: np.ndarray, scheme=None) -> np.ndarray:
     """[N,K] float32 -> slab-major operand planes [K/16][NPL][2][N][8] (uint16), each 16-wide k-step stored as two 8-wide half
     planes — the operand layout of csrc/gemm_bf16x6.hip."""
     W = np.ascontiguousarray(W, np.float32)
     N, K = W.shape
     assert K % 16 == 0
-    pl = _planes3(W)
+    pl = _planes3(W, scheme)
     planes = pl.reshape(pl.shape[0], N, K // 16, 2, 8)                    # [NPL][N][K/16][2][8]
     return np.ascontiguousarray(planes.transpose(2, 0, 3, 1, 4))         # [K/16][NPL][2][N][8]
 
 
-BF3_SUFFIX = "#bf3"
+PLANES_SUFFIX = {1: "#pl1", 0: "#pl0"}
 
 
-def ffn_planes(W1: np.ndarray, W2: np.ndarray):
+def ffn_planes(W1: np.ndarray, W2: np.ndarray, scheme=None):
     """Operand images of the fused FFN kernel (csrc/ffn_fused.hip), one 48 KB block per 32 hidden units hb:
       W1p[hb][p 3][ks K/16][half 2][row 32][8]   = plane_p(W1)[32 hb + row, 16 ks + 8 half + e]
       W2p[hb][p 3][kk 2][half 2][o D][8]         = plane_p(W2)[o, 32 hb + 16 kk + (j & 3) + 8 (j >> 2) + 4 half]
@@ -137,7 +141,7 @@ def ffn_planes(W1: np.ndarray, W2: np.ndarray):
     F, K = W1.shape
     D = W2.shape[0]
     assert W2.shape[1] == F and F % 32 == 0 and K % 16 == 0
-    pl1 = _planes3(W1)
+    pl1 = _planes3(W1, scheme)
     p1 = pl1.reshape(pl1.shape[0], F // 32, 32, K // 16, 2, 8)            # [p][hb][row][ks][half][e]
     w1p = np.ascontiguousarray(p1.transpose(1, 0, 3, 4, 2, 5))            # [hb][p][ks][half][row][e]
     j = np.arange(8)
@@ -145,7 +149,7 @@ def ffn_planes(W1: np.ndarray, W2: np.ndarray):
     for kk in range(2):
         for half in range(2):
             idx[kk, half] = 16 * kk + (j & 3) + 8 * (j >> 2) + 4 * half
-    pl2 = _planes3(W2)
+    pl2 = _planes3(W2, scheme)
     p2 = pl2.reshape(pl2.shape[0], D, F // 32, 32)                        # [p][o][hb][hid]
     p2 = p2[:, :, :, idx]                                                 # [p][o][hb][kk][half][j]
     w2p = np.ascontiguousarray(p2.transpose(2, 0, 3, 4, 1, 5))            # [hb][p][kk][half][o][j]
@@ -161,15 +165,25 @@ def pack(dims: Dims, w: dict):
         v = allw[k]
         if v.ndim == 2 and v.shape[1] % 16 == 0 and v.shape[1] >= 32 and (k.endswith("weight") or k.endswith(".w")) \
                 and "embed_action" not in k and "embed_rtg_" not in k and "rtg_table" not in k and "embed_timestep" not in k and "embed_agent_id" not in k:
-            planes = split3_planes(v)
-            allw[k + BF3_SUFFIX] = planes.reshape(-1).view(np.float32)
+            for sch, suffix in PLANES_SUFFIX.items():      # both operand splits travel: the scheme is a run-time option
+                try:
+                    allw[k + suffix] = split3_planes(v, sch).reshape(-1).view(np.float32)
+                except FloatingPointError:
+                    if sch == 0:
+                        raise                                  # fp16 planes out of range: that model runs with bf16 planes only
     # fused-FFN operand images of every transformer layer (post-LN block: linear1 -> ReLU -> linear2 -> +x -> LayerNorm)
     for k in list(w.keys()):
         if k.endswith(".linear1.weight"):
             pre = k[:-len(".linear1.weight")]
-            w1p, w2p = ffn_planes(np.asarray(w[k], np.float32), np.asarray(w[pre + ".linear2.weight"], np.float32))
-            allw[pre + ".ffn#w1p"] = w1p.reshape(-1).view(np.float32)
-            allw[pre + ".ffn#w2p"] = w2p.reshape(-1).view(np.float32)
+            for sch, suffix in PLANES_SUFFIX.items():
+                try:
+                    w1p, w2p = ffn_planes(np.asarray(w[k], np.float32), np.asarray(w[pre + ".linear2.weight"], np.float32), sch)
+                except FloatingPointError:
+                    if sch == 0:
+                        raise
+                    continue
+                allw[pre + ".ffn#w1p" + suffix] = w1p.reshape(-1).view(np.float32)
+                allw[pre + ".ffn#w2p" + suffix] = w2p.reshape(-1).view(np.float32)
     names, offsets, chunks = [], [], []
     off = 0
     for k, v in allw.items():

@@ -103,7 +103,12 @@ class AutoregressivePolicy(Policy):
         eng.policy_step(t)
         torch.cuda.synchronize(dev)
         bad = int(eng.lib.ctrlsim_nonfinite_count(1))      # NaN logits (fp16 overflow of the split operands, bad weights) must not
-        if bad:                                            # pass as "rtg bin 0 / zero action": same guard as RolloutEngine.results()
+        if bad and eng.split == "auto" and int(eng.lib.ctrlsim_split_scheme()) == 1:
+            eng._set_split(0)                              # pass as "rtg bin 0 / zero action": redo the step with the range-safe
+            eng.policy_step(t)                             # three-bf16-plane operands (they stay selected), csrc/split.h
+            torch.cuda.synchronize(dev)
+            bad = int(eng.lib.ctrlsim_nonfinite_count(1))
+        if bad:
             raise FloatingPointError(f"{bad} sampling races had no finite logit at step {t} (csrc/split.h: activation range)")
         bins = eng.hist_rtg[0, :, t].cpu().numpy()
         toks = eng.act_now[0].cpu().numpy()

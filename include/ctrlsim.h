@@ -276,9 +276,12 @@ int ctrlsim_set_option(int key, int value);
 /* Operand split compiled into the library (csrc/split.h): 1 = two fp16 planes / three products (weights pre-scaled by 2^8), 0 = three
  * bf16 planes / six products.  ctrlsim_amd/pack.py packs weight planes and sizes the K/V images accordingly. */
 int ctrlsim_split_scheme(void);
-/* Sampling races (ctrlsim_sample_rtg / _action) that no finite score won since the last reset — NaN logits, e.g. from an
- * activation beyond the fp16 range of the split operands.  Such a token falls back to a valid id; callers check this count
- * (>= 0; synchronises the device) and fail.  reset != 0 clears it. */
+/* Non-finite events since the last reset: sampling races (ctrlsim_sample_rtg / _action) that no finite score won, and rows whose
+ * LayerNorm variance was not finite in any fused LayerNorm of the forward (the ReLUs of the MLP heads map NaN to 0, so the logits
+ * alone do not show an overflow of the fp16 range of the two-plane operand split).  Callers check this count (>= 0;
+ * synchronises the device) and fail or repeat with ctrlsim_set_option(4, 0).  reset != 0 clears it.  The counter is one word of
+ * device memory per process, allocated at first use on the current device: one host thread and one device per process, like the
+ * options and the profiling hooks. */
 int ctrlsim_nonfinite_count(int reset);
 
 const char* ctrlsim_version(void);

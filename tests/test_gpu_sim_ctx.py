@@ -658,3 +658,38 @@ def test_rollout_of_a_scenario_does_not_depend_on_the_world_size():
                     assert np.array_equal(o[k], ref[g][k]), (W, rank, g, k)
         np.testing.assert_allclose(total[:10], ref_vec[:10], rtol=1e-12)
         np.testing.assert_array_equal(total[10:], ref_vec[10:])
+
+
+def test_operand_split_is_a_runtime_choice_with_automatic_fallback():
+    """Both operand splits are in the library (csrc/split.h, dispatch.hip).  (i) The same rollout under f16x3 and under bf16x6
+    gives the oracle's tokens.  (ii) A model whose activations leave the fp16 range (embed_ln gain x 3e4: token rows of
+    magnitude 1e5 — trained checkpoints are not bounded like the random init) yields non-finite logits under f16x3: split="f16x3"
+    fails loudly, split="auto" repeats the rollout with three bf16 planes and matches the fp32 oracle."""
+    cfg = cfg_of("loop")
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    scn = scenarios.make_scenario(81, 0, n_agents=8, n_polylines=14, n_points=d.NP, extent=30.0)
+    steps = 10
+    o = rollout_oracle.RolloutOracle(cfg, w, seed=4).run(scn, steps, sim_libs.OracleSim)
+    for split in ("f16x3", "bf16x6"):
+        eng = RolloutEngine(cfg, w, DEV, max_ctx=24, seed=4, split=split)
+        assert int(eng.lib.ctrlsim_split_scheme()) == (1 if split == "f16x3" else 0)
+        eng.load_scenarios([scn], steps=steps)
+        r = eng.run(steps).results()
+        assert np.array_equal(r["tokens"][0][:, :steps], o["tokens"]), split
+        np.testing.assert_allclose(r["states"][0], o["states"], atol=1e-4, rtol=0)
+    hot = dict(w)
+    hot["encoder.embed_ln.weight"] = w["encoder.embed_ln.weight"] * np.float32(3e4)
+    oh = rollout_oracle.RolloutOracle(cfg, hot, seed=4).run(scn, steps, sim_libs.OracleSim)
+    eng = RolloutEngine(cfg, hot, DEV, max_ctx=24, seed=4, split="f16x3")
+    eng.load_scenarios([scn], steps=steps)
+    with pytest.raises(FloatingPointError):
+        eng.run(steps).results()
+    eng = RolloutEngine(cfg, hot, DEV, max_ctx=24, seed=4, split="auto")
+    eng.load_scenarios([scn], steps=steps)
+    r = eng.run(steps).results()
+    assert int(eng.lib.ctrlsim_split_scheme()) == 0            # fell back, and stays on the range-safe split
+    assert np.array_equal(r["tokens"][0][:, :steps], oh["tokens"])
+    np.testing.assert_allclose(r["states"][0], oh["states"], atol=1e-4, rtol=0)
+    RolloutEngine(cfg, w, DEV, max_ctx=24, seed=4)             # a new engine selects its own split again (process-global option)
+    assert int(eng.lib.ctrlsim_split_scheme()) == 1
