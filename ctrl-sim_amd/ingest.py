@@ -13,9 +13,19 @@ What the reference does on the way from a scenario file to model inputs, restate
   into chunks of `max_num_road_pts_per_polyline` points with an existence channel, the last chunk zero-padded, a stop sign =
   its position repeated along the chunk, one-hot road types (utils/data.py:334-337).
 
-`roads_to_polylines` is pinned against the reference's own `get_roads` (tests/golden/ingest.npz); the JSON side has no
-reference binary to run against here (the loader needs SFML to build) — it follows the C++ line by line and is checked by
-a write / read round trip.  `scenario_to_nocturne_json` is the inverse (exports a synthetic scene in the same format)."""
+* the preprocessed dataset the evaluators read map features and initial RTGs from (`Evaluator.load_preprocessed_data`,
+  evaluators/evaluator.py:44-57 -> `RLWaymoDataset.get`, datasets/rl_waymo/dataset.py:458-500 -> `RLWaymoDatasetCtRLSim.get_data`,
+  dataset_ctrl_sim.py:38-97): `preprocess_scene` builds the `*_physics.pkl` dictionary from a simulated scene in the evaluators'
+  export format (`extract_rawdata`, the road-edge / nearest-vehicle distance rewards: dataset.py:111-237), `load_preprocessed`
+  turns such a dictionary (or pickle file) into `{'rtgs', 'road_points', 'road_types'}` (`compute_rewards` + reverse cumulative
+  sum: dataset.py:240-275, dataset_ctrl_sim.py:92-97).
+
+`roads_to_polylines`, `preprocess_scene` and `load_preprocessed` are pinned against the reference's own dataset code run on
+synthetic scenes (tests/golden/ingest.npz, preprocessed.npz).  The Nocturne JSON object loader has no reference binary to run
+against here (Scenario::LoadObjects needs SFML to build): it follows the C++ line by line, is checked by a write / read round
+trip, and its output is pinned only as far as the reference's PYTHON layer goes — `get_ground_truth_states` / `get_road_data`
+(utils/sim.py:20-79) run on a replay of the same file give the same rows (tests/golden/ingest_gt.npz).
+`scenario_to_nocturne_json` is the inverse (exports a synthetic scene in the same format)."""
 from __future__ import annotations
 
 import json
@@ -176,3 +186,79 @@ def scenario_to_nocturne_json(scn: Scenario, log, name="synthetic"):
         n = int(pl[:, 2].sum())
         roads.append({"geometry": [{"x": float(p[0]), "y": float(p[1])} for p in pl[:n]], "type": inv[int(np.argmax(ty))]})
     return {"name": name, "objects": objects, "roads": roads, "tl_states": {}}
+
+
+# ------------------------------------------------------------------------------------------------ preprocessed dataset (*_physics.pkl)
+def object_type_onehot(name):
+    """utils/data.py get_object_type_onehot: one-hot over (unset, vehicle, pedestrian, cyclist, other)."""
+    return np.eye(len(OBJECT_TYPES))[OBJECT_TYPES.index(name if name in OBJECT_TYPES else "other")]
+
+
+def preprocess_scene(data, w, idx=0):
+    """The dictionary `RLWaymoDatasetCtRLSim.get_data` pickles for one simulated scene (dataset_ctrl_sim.py:54-90): `data` is the
+    evaluators' export {"objects": [{position, velocity, heading, existence, acceleration, steering, reward, goal_position,
+    goal_heading, goal_speed, length, width, type}], "roads": get_road_data(...)}; w = cfg.dataset.waymo."""
+    from .rewards import signed_distance_to_road_edges
+    from .metrics import nearest_vehicle_distance
+    objs = data["objects"]
+    road_points, road_types, edge_polys = roads_to_polylines(data["roads"], w.max_num_road_pts_per_polyline)
+    ag_data, ag_actions, ag_rewards, ag_types, ag_goals, incomplete, last_exist = [], [], [], [], [], [], []
+    for n, o in enumerate(objs):                                  # extract_rawdata, dataset.py:111-186
+        pos = np.array([[p["x"], p["y"]] for p in o["position"]], np.float64)
+        vel = np.array([[p["x"], p["y"]] for p in o["velocity"]], np.float64)
+        heading = np.array(o["heading"], np.float64).reshape(-1, 1)
+        ex = np.array(o["existence"], np.float64).reshape(-1, 1)
+        gone = np.where(ex == 0.0)[0]
+        if len(gone) > 0:
+            assert np.all(ex[gone[0]:] == 0.0), "existence must not come back"
+        if len(gone) > 0 and gone[0] == 0:
+            incomplete.append(n)
+            last_exist.append(-1)
+        else:
+            last_exist.append(int(np.where(ex == 1.0)[0][-1]))
+        T = len(pos)
+        gh, gs = o["goal_heading"], o["goal_speed"]
+        goal = np.array([o["goal_position"]["x"], o["goal_position"]["y"], gs * np.cos(gh), gs * np.sin(gh), gh])
+        ag_data.append(np.concatenate([pos, vel, heading, np.ones((T, 1)) * o["length"], np.ones((T, 1)) * o["width"], ex], -1))
+        ag_actions.append(np.column_stack((o["acceleration"], o["steering"])))
+        ag_rewards.append(np.array(o["reward"], np.float64) * ex)
+        ag_types.append(object_type_onehot(o["type"]))
+        ag_goals.append(np.repeat(goal[None], T, 0))
+    ag_data = np.array(ag_data)
+    # distance rewards (dataset.py:187-237), zeroed where the vehicle does not exist
+    edge = np.array([-signed_distance_to_road_edges(ag_data[n, :, :2], edge_polys) / w.dist_to_road_edge_scaling_factor
+                     for n in range(len(objs))]) * ag_data[:, :, -1]
+    nd = nearest_vehicle_distance(ag_data[:, :, :2], ag_data[:, :, -1])
+    veh = np.nan_to_num(np.clip(nd, 0.0, w.max_veh_veh_distance) / w.max_veh_veh_distance) * ag_data[:, :, -1]
+    return dict(idx=idx, num_agents=len(objs), road_points=road_points, road_types=road_types, ag_data=ag_data,
+                ag_actions=np.array(ag_actions), ag_types=np.array(ag_types), last_exist_timesteps=np.array(last_exist),
+                veh_edge_dist_rewards=edge, veh_veh_dist_rewards=veh, ag_rewards=np.array(ag_rewards),
+                filtered_ag_ids=[i for i in range(len(objs)) if i not in incomplete], ag_goals=np.array(ag_goals))
+
+
+def load_preprocessed(src, w):
+    """`Evaluator.load_preprocessed_data` -> `RLWaymoDataset.get` in eval mode: the preprocessed dictionary (or the path of its
+    pickle) -> {'rtgs' [N,T,5] returns-to-go per reward component (goal position, heading, speed, vehicle, road edge),
+    'road_points', 'road_types'} (dataset.py:240-275, 493-498; dataset_ctrl_sim.py:92-97)."""
+    if not isinstance(src, dict):
+        import pickle
+        with open(src, "rb") as fh:
+            src = pickle.load(fh)
+    ag_data = np.asarray(src["ag_data"], np.float64)
+    r = np.asarray(src["ag_rewards"], np.float64)
+    ex = ag_data[:, :, -1:]
+    edge, veh = np.asarray(src["veh_edge_dist_rewards"]), np.asarray(src["veh_veh_dist_rewards"])
+    if w.remove_shaped_goal:
+        goal = r[:, :, 0] * w.pos_target_achieved_rew_multiplier
+    else:
+        goal = r[:, :, 0] * w.pos_target_achieved_rew_multiplier + \
+            (np.clip(r[:, :, 3], w.pos_goal_shaped_min, w.pos_goal_shaped_max) - w.pos_goal_shaped_max) * (1 / w.pos_goal_shaped_max)
+    head = r[:, :, 1] + r[:, :, 5]
+    speed = r[:, :, 2] + r[:, :, 4]
+    vv = (-1 * r[:, :, 6] * w.veh_veh_collision_rew_multiplier) if w.remove_shaped_veh_reward else \
+        (veh - r[:, :, 6] * w.veh_veh_collision_rew_multiplier)
+    ve = (-1 * r[:, :, 7] * w.veh_edge_collision_rew_multiplier) if w.remove_shaped_edge_reward else \
+        (np.clip(np.abs(edge) * w.dist_to_road_edge_scaling_factor, 0, 5) / 5. - r[:, :, 7] * w.veh_edge_collision_rew_multiplier)
+    allr = np.concatenate([x[:, :, None] * ex for x in (goal, head, speed, vv, ve)], -1)
+    rtgs = np.cumsum(allr[:, ::-1], axis=1)[:, ::-1]
+    return {"rtgs": rtgs, "road_points": src["road_points"], "road_types": src["road_types"]}

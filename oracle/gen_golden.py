@@ -436,6 +436,162 @@ def gen_state_dict():
          ctrl_sim_shapes=np.array([list(sd[n].shape) + [0] * (4 - sd[n].dim()) for n in names]))
 
 
+# --------------------------------------------------------------------------------------------- (f3) preprocessed dataset
+def export_scene(scn, states, coll_unused, actions, rewards, existence, goals):
+    """A simulated scene in the evaluators' export format (policy_evaluator.py:559-570: objects with per-step lists + roads from
+    get_road_data) built from a recorded rollout."""
+    inv = {v: k for k, v in scenarios.ROAD_TYPES.items()}
+    N, T1 = states.shape[:2]
+    objs = []
+    for v in range(N):
+        objs.append({"position": [{"x": float(states[v, t, 0]), "y": float(states[v, t, 1])} for t in range(T1)],
+                     "velocity": [{"x": float(states[v, t, 2]), "y": float(states[v, t, 3])} for t in range(T1)],
+                     "heading": [float(states[v, t, 4]) for t in range(T1)],
+                     "existence": [float(e) for e in existence[v]],
+                     "acceleration": [float(actions[v, t, 0]) if t < T1 - 1 else 0 for t in range(T1)],
+                     "steering": [float(actions[v, t, 1]) if t < T1 - 1 else 0 for t in range(T1)],
+                     "reward": [[float(x) for x in rewards[v, t]] for t in range(T1)],
+                     "goal_position": {"x": float(goals[v, 0]), "y": float(goals[v, 1])},
+                     "goal_heading": float(goals[v, 2]), "goal_speed": float(goals[v, 3]),
+                     "width": float(scn.width[v]), "length": float(scn.length[v]), "type": "vehicle"})
+    roads = []
+    for pl, ty in zip(scn.road_points, scn.road_types):
+        n = int(pl[:, 2].sum())
+        roads.append({"geometry": [{"x": float(q[0]), "y": float(q[1])} for q in pl[:n]], "type": inv[int(np.argmax(ty))]})
+    return {"name": "synthetic", "objects": objs, "roads": roads}
+
+
+def gen_preprocessed():
+    """The reference's dataset code on simulated scenes: RLWaymoDatasetCtRLSim.get_data in preprocessing mode writes the
+    *_physics.pkl dictionary (extract_rawdata, distance rewards), and RLWaymoDataset.get in eval mode reads it back as
+    {'rtgs', 'road_points', 'road_types'} — what Evaluator.load_preprocessed_data hands the evaluators and policies."""
+    import json as _json
+    import pickle
+    import tempfile
+    import types as _t
+    _install_evaluator_stubs()
+    for name in ("matplotlib", "matplotlib.pyplot"):
+        if name not in sys.modules:
+            sys.modules[name] = _t.ModuleType(name)
+    from datasets.rl_waymo.dataset_ctrl_sim import RLWaymoDatasetCtRLSim
+    g, gm = np.load(os.path.join(GOLD, "closed_loop.npz")), np.load(os.path.join(GOLD, "metrics.npz"))
+    out = {}
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "raw", "test"))
+    cfg = spec.make_cfg(**LOOP)
+    d = spec.Dims(cfg)
+    for tag in ("a", "b", "c"):
+        rc = g[f"{tag}_recipe"]
+        scn = scenarios.make_scenario(int(rc[0]), int(rc[1]), n_agents=int(rc[2]), n_polylines=int(rc[3]), n_points=d.NP,
+                                      extent=float(rc[4]))
+        ex = gm[f"{tag}_existence"]
+        data = export_scene(scn, g[f"{tag}_states"], None, g[f"{tag}_actions"], gm[f"{tag}_reward"], ex, gm[f"{tag}_goal"])
+        with open(os.path.join(tmp, "raw", "test", f"scene_{tag}.json"), "w") as fh:
+            _json.dump(data, fh)
+    w = cfg.dataset.waymo
+    w.dataset_path, w.preprocess_dir = os.path.join(tmp, "raw"), os.path.join(tmp, "pre")
+    w.preprocess, w.preprocess_real_data = False, True
+    writer = RLWaymoDatasetCtRLSim(cfg, split_name="test", mode="eval")
+    for i, f in enumerate(writer.files):
+        with open(f) as fh:
+            writer.get_data(_json.load(fh), i)
+    w.preprocess, w.preprocess_real_data = True, False
+    reader = RLWaymoDatasetCtRLSim(cfg, split_name="test", mode="eval")
+    assert len(reader.files) == 3
+    for i, f in enumerate(reader.files):
+        tag = os.path.basename(f)[6]
+        with open(f, "rb") as fh:
+            pk = pickle.load(fh)
+        dd = reader.get(i)
+        for k in ("ag_data", "ag_actions", "ag_types", "last_exist_timesteps", "veh_edge_dist_rewards", "veh_veh_dist_rewards",
+                  "ag_rewards", "ag_goals", "road_points", "road_types"):
+            out[f"{tag}_pkl_{k}"] = np.asarray(pk[k])
+        out[f"{tag}_pkl_filtered_ag_ids"] = np.asarray(pk["filtered_ag_ids"])
+        out[f"{tag}_rtgs"] = dd["rtgs"]
+        assert np.array_equal(dd["road_points"], pk["road_points"])
+        print(tag, "rtgs", dd["rtgs"].shape, "rtg range", dd["rtgs"].min(), dd["rtgs"].max())
+    save("preprocessed", **out)
+
+
+def gen_ingest_gt():
+    """The reference's PYTHON layer over a scenario file (utils/sim.py:20-79: get_ground_truth_states, get_road_data) run on a
+    REPLAY of a Nocturne-format file: a stand-in `Simulation` whose expert-controlled vehicles walk through the file's own
+    position / heading / velocity lists (what Scenario::LoadObjects + expert control do in C++, nocturne/cpp/src/scenario.cc —
+    that C++ cannot be built here, so this pins the row layout, the existence rule (x != -10000), the steps + 1 length and the
+    road-data ordering of the Python layer, not the C++ loader itself)."""
+    import json as _json
+    import tempfile
+    import types as _t
+    _install_evaluator_stubs()
+    from ctrlsim_amd import ingest
+    from ctrlsim_amd.scenarios import standin_log
+    import utils.sim as ref_sim
+    scn = scenarios.make_scenario(91, 0, n_agents=6, n_polylines=9, n_points=10, extent=30.0)
+    steps = 20
+    log = standin_log(scn, steps)
+    log[2]["traj"][13:, 4] = 0.0                              # leaves the log
+    log[4]["traj"][6:, 4] = 0.0
+    data = ingest.scenario_to_nocturne_json(scn, log, name="replay")
+    data["roads"].append({"geometry": [{"x": 3.25, "y": -7.5}], "type": "stop_sign"})
+    tmp = tempfile.mkdtemp()
+    with open(os.path.join(tmp, "replay.json"), "w") as fh:
+        _json.dump(data, fh)
+
+    RT = scenarios.ROAD_TYPES
+
+    class _Veh:
+        def __init__(self, i, obj, sim):
+            self.i, self.o, self.sim, self.expert_control = i, obj, sim, False
+        def getID(self): return self.i
+        def _t(self): return min(self.sim.t, len(self.o["position"]) - 1)
+        def getPosition(self): p = self.o["position"][self._t()]; return _XY(np.float32(p["x"]), np.float32(p["y"]))
+        def getHeading(self):                                   # NormalizeAngle(Radians(deg)) in float (scenario.cc:934-935)
+            r = np.float32(np.float64(np.float32(self.o["heading"][self._t()])) / 180.0 * np.pi)
+            r = np.float32(np.fmod(np.float64(r), 2.0 * np.pi))
+            return np.float32(np.float64(r) - 2 * np.pi) if r > np.pi else (np.float32(np.float64(r) + 2 * np.pi) if r < -np.pi else r)
+        def getSpeed(self): v = self.o["velocity"][self._t()]; return np.float32(np.sqrt(np.float32(v["x"]) ** 2 + np.float32(v["y"]) ** 2))
+        def getGoalPosition(self): g = self.o["goalPosition"]; return _XY(np.float32(g["x"]), np.float32(g["y"]))
+        def getType(self): return _t.SimpleNamespace(value=1)
+        def getLength(self): return np.float32(self.o["length"])
+        def getWidth(self): return np.float32(self.o["width"])
+
+    class _Line:
+        def __init__(self, road): self.road, self.road_type = road, RT[road["type"]]
+        def geometry_points(self): return [_XY(np.float32(p["x"]), np.float32(p["y"])) for p in self.road["geometry"]]
+
+    class _Stop:
+        def __init__(self, road): self.road = road
+        def position(self): p = self.road["geometry"][0]; return _XY(np.float32(p["x"]), np.float32(p["y"]))
+
+    class _Sim:
+        def __init__(self, scenario_path, config):
+            with open(scenario_path) as fh:
+                self.data = _json.load(fh)
+            self.t = 0
+            self.vehs = [_Veh(i, o, self) for i, o in enumerate(self.data["objects"]) if o["valid"][0]]
+        def getScenario(self): return self
+        def vehicles(self): return self.vehs
+        def getObjectsThatMoved(self): return self.vehs
+        def getRoadLines(self): return [_Line(r) for r in self.data["roads"] if r["type"] != "stop_sign"]
+        def stop_signs(self): return [_Stop(r) for r in self.data["roads"] if r["type"] == "stop_sign"]
+        def step(self, dt): self.t += 1
+        def reset(self): self.t = 0
+
+    ref_sim.Simulation = _Sim
+    cfg = spec.make_cfg()
+    gt = ref_sim.get_ground_truth_states(cfg, tmp, ["replay.json"], 0, 0.1, steps)
+    road_data = ref_sim.get_road_data(_Sim(os.path.join(tmp, "replay.json"), None))
+    ids = sorted(gt.keys())
+    out = {"json": np.array(_json.dumps(data)), "ids": np.array(ids),
+           "traj": np.array([gt[i]["traj"] for i in ids], np.float64), "type": np.array([gt[i]["type"] for i in ids], np.float64),
+           "road_types": np.array([r["type"] for r in road_data]),
+           "road_n": np.array([1 if isinstance(r["geometry"], dict) else len(r["geometry"]) for r in road_data]),
+           "road_xy": np.array([[q["x"], q["y"]] for r in road_data
+                                for q in ([r["geometry"]] if isinstance(r["geometry"], dict) else r["geometry"])], np.float64)}
+    print("gt", out["traj"].shape, "roads", len(road_data))
+    save("ingest_gt", **out)
+
+
 # --------------------------------------------------------------------------------------------- G4 features
 def gen_features():
     """Reference get_data() on hand-built policy buffers: exercises select_relevant_agents (first call and
@@ -1085,7 +1241,7 @@ def gen_dt_loop():
 
 
 ALL = dict(model=gen_model, features=gen_features, sampling=gen_sampling, physics=gen_physics,
-           collision=gen_collision, closed_loop=gen_closed_loop, closed_loop_full=gen_closed_loop_full, metrics=gen_metrics, state_dict=gen_state_dict, bicycle=gen_bicycle, contacts=gen_contacts,
+           collision=gen_collision, closed_loop=gen_closed_loop, closed_loop_full=gen_closed_loop_full, metrics=gen_metrics, preprocessed=gen_preprocessed, ingest_gt=gen_ingest_gt, state_dict=gen_state_dict, bicycle=gen_bicycle, contacts=gen_contacts,
            planner_adversary=gen_planner_adversary, ingest=gen_ingest,
            variants=gen_variants, dense_reward=gen_dense_reward, dt_loop=gen_dt_loop)
 
