@@ -20,6 +20,14 @@ class Dims(C.Structure):
     _fields_ = [(k, C.c_int) for k in ("A", "T", "P", "NP", "D", "H", "F", "V", "R", "C", "NE", "ND", "MAXT", "variant")]
 
 
+class DtRewardCfg(C.Structure):
+    """ctrlsim_dt_reward_cfg (include/ctrlsim.h)."""
+    _fields_ = [(k, C.c_double) for k in ("pos_tol", "shaped_unit", "goal_mult", "shaped_min", "shaped_max", "veh_mult",
+                                          "max_veh_dist", "edge_mult", "edge_scale")] + \
+               [("rtg_lo", C.c_double * 3), ("rtg_hi", C.c_double * 3)] + \
+               [(k, C.c_int) for k in ("remove_shaped_goal", "remove_shaped_veh", "remove_shaped_edge", "pad_")]
+
+
 class Ctx(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("st12", "exist", "goal5", "act_tok", "rtg_bin", "tstep", "slot_gid",
                                            "road_pts", "road_types")]
@@ -38,6 +46,7 @@ SIGNATURES = {
     "ctrlsim_prof_collect": (I, [P, P, P]),
     "ctrlsim_prof_bytes": (I, [P]),
     "ctrlsim_metrics_size": (I, []),
+    "ctrlsim_dt_ledger_step": (I, [I, I, I, I, I, I, P, P, P, P, P, C.POINTER(DtRewardCfg), P, P, P, P]),
     "ctrlsim_metrics_pack": (I, [I, I, I, I, I, D, P, P, P, P, P, P, P, P, P, P]),
     "ctrlsim_gemm_nt": (I, [P, I, P, I, P, P, I, P, I, I, I, I, I, P]),
     "ctrlsim_gemm_nt_bf16x6": (I, [P, I, P, I, I, P, P, I, P, I, I, I, I, I, P, P, P]),
@@ -72,6 +81,7 @@ SIGNATURES = {
     "ctrlsim_sample_action_rows": (I, [P, P, I, P, P, F, D, P, U64, P, I, P, P, I, I, I, I, P]),
     "ctrlsim_dt_forward_pass1": (I, [P, I, I, C.POINTER(Ctx), P, P, P, P]),
     "ctrlsim_dt_forward_actions": (I, [P, I, I, C.POINTER(Ctx), P, P, P]),
+    "ctrlsim_forward_all": (I, [P, I, I, C.POINTER(Ctx), P, P, P, P, P]),
     "ctrlsim_dt_forward_pass2": (I, [P, I, I, I, I, I, C.POINTER(Ctx), P, P, P, P, I, P]),
     "ctrlsim_dt_forward_pass1_cached": (I, [P, I, I, C.POINTER(Ctx), P, P, P]),
     "ctrlsim_sample_rtg": (I, [P, I, I, P, P, P, P, P, P, U64, P, I, P, I, I, I, P]),

@@ -19,6 +19,7 @@
 //                 map of the S^T tile, so P never moves between lanes.
 // One accumulator chain per product: with three waves per SIMD the matrix pipe stays fed across the dependent MFMAs
 // (measured: 1829 vs 1966 TFLOP/s register-only), and the merge adds / second rescale / 32 registers go away.
+#define SPLIT_MIX   // f16x3: residual plane of the P split by v_fma_mixlo/hi_f16 (3 instructions per pair instead of 6; same bits)
 #include "split.h"
 #include <type_traits>
 

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # planes, =0 three bf16 planes; each build lives in its own namespace) and dispatch.hip picks one at run time.
 SPLIT_SRCS = ("gemm_bf16x6", "ffn_fused", "attention_bf16x6")
 SRCS = {"gemm": "", "attention": "", "sim": "-ffp-contract=off", "context": "-ffp-contract=off", "embed": "",
-        "map_encoder": "", "sample": "", "metrics": "-ffp-contract=off", "forward": "", "dispatch": "", "api": ""}
+        "map_encoder": "", "sample": "", "metrics": "-ffp-contract=off", "rewards": "-ffp-contract=off", "forward": "", "dispatch": "", "api": ""}
 OUT = os.path.join(HERE, "libctrlsim_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 

@@ -87,7 +87,8 @@ struct ctrlsim_model {
   Mlp map_feats, road_type, road_fuse;
   std::vector<EncLayer> enc;
   std::vector<DecLayer> dec;
-  Mlp head_action, head_rtg;
+  Mlp head_action, head_rtg, head_fut;
+  bool has_fut = false;
   int zero_rtg[3];
 };
 
@@ -180,6 +181,10 @@ extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_w
   }
   m->head_action = mlp("decoder.predict_action");
   if (dims->variant == 0) m->head_rtg = mlp("decoder.predict_rtg");      // the IL / Trajeglish models have no such head
+  if (tab.count("decoder.predict_future_states.mlp.0.weight")) {        // model.predict_future_states (decoder.py:29-30): training-time
+    m->head_fut = mlp("decoder.predict_future_states");                 // auxiliary head, only read by ctrlsim_forward_all
+    m->has_fut = true;
+  }
   m->zero_rtg[0] = 0; m->zero_rtg[1] = 35; m->zero_rtg[2] = 35;
   if (!ok) { delete m; return CTRLSIM_EINVAL; }
   *out = m;
@@ -491,9 +496,9 @@ __global__ void fill_index_cached_kernel(int B, int Actx, int Areg, int Lf, int 
   }
 }
 
-int mlp_tail(const Mlp& m, const float* h_in, int rows, float* hid, float* out, int n_out, hipStream_t st) {
+int mlp_tail(const Mlp& m, const float* h_in, int rows, float* hid, float* out, int n_out, hipStream_t st, int ld_in = DM) {
   // Linear(256->256) -> LN -> ReLU -> Linear(256->n_out)
-  CHK(gemm_ln(m.l0, m.ln, h_in, DM, nullptr, 0, hid, DM, hid, rows, DM, 1, st));
+  CHK(gemm_ln(m.l0, m.ln, h_in, ld_in, nullptr, 0, hid, DM, hid, rows, DM, 1, st));
   CHK(gemm(m.l3, hid, DM, nullptr, 0, out, n_out, rows, n_out, DM, 0, st));
   return 0;
 }
@@ -598,8 +603,9 @@ namespace {
 // regular slots of every context (rows in class order, [sum_k B_k*Areg_k, .]):
 // CtRL-Sim: predict_rtg on the state tokens of the current step; IL: predict_action on the same rows; Trajeglish:
 // predict_action on the action tokens (decoder.py:55-77).
+struct AllOut { float *act, *rtg, *fut; };       // ctrlsim_forward_all: heads on every token, rows (b, tt, a)
 int forward_full(const ctrlsim_model* m, int n, const int* Bk, const int* Ak, const ctrlsim_ctx* ctx, int Tq, void* workspace,
-                 float* logits, float* dbg_seg_emb, hipStream_t st) {
+                 float* logits, float* dbg_seg_emb, hipStream_t st, const AllOut* all = nullptr) {
   const ctrlsim_dims& d = m->d;
   const int variant = d.variant, amode = 1 + variant, qoff = variant == 2 ? 2 : 0;
   if (variant && !presplit()) return CTRLSIM_EINVAL;       // the IL / Trajeglish masks live in the split-bf16 attention only
@@ -621,7 +627,7 @@ int forward_full(const ctrlsim_model* m, int n, const int* Bk, const int* Ak, co
   for (int i = 0; i < d.ND; ++i) {
     const DecLayer& Ld = m->dec[i];
     CHK(gemm_kv(d, bt, w, Ld.qkv, w.X, w.qkv[i], 3 * DM, 3 * DM, DM, w.img_dec[i], false, st));
-    if (i < d.ND - 1) {
+    if (i < d.ND - 1 || all) {
       CHK(attention(d, bt, w, AttnCall{amode, Q_ALL, w.qkv[i], 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, w.img_dec[i], false,
                                        w.att, Tq, Tq, 0}, st));
       CHK(gemm_ln(Ld.out, Ld.n1, w.att, DM, w.X, DM, w.X, DM, w.tmp, rL, DM, 0, st));
@@ -635,6 +641,16 @@ int forward_full(const ctrlsim_model* m, int n, const int* Bk, const int* Ak, co
       CHK(gemm_ln(Ld.out, Ld.n1, w.attc, DM, w.xc, DM, w.xc, DM, w.tmpc, rQ, DM, 0, st));
       CHK(cross_and_ffn(m, bt, Ld, i, w, w.xc, w.tmpc, w.attc, w.qcc, w.ffnc, bt.rQ, Q_STATE, 0, st));
     }
+  }
+  if (all) {
+    // every head on every token of its type (decoder.py:55-77): token type k of (b, tt, a) is row ((b*Tq + tt)*A + a)*3 + k, so a
+    // type is a strided view of X (leading dimension 3*DM).  Action head: the rtg token (CtRL-Sim), the state token (IL, and DT,
+    // whose token order is rtg, state, action), the action token (Trajeglish); rtg head: state tokens; future states: action tokens.
+    const int rows = rL / 3, k_act = variant == 0 ? 1 : variant == 2 ? 2 : 0;
+    CHK(mlp_tail(m->head_action, w.X + k_act * DM, rows, w.att, all->act, d.V, st, 3 * DM));
+    if (all->rtg) CHK(mlp_tail(m->head_rtg, w.X, rows, w.att, all->rtg, d.R * d.C, st, 3 * DM));
+    if (all->fut) CHK(mlp_tail(m->head_fut, w.X + 2 * DM, rows, w.att, all->fut, 2 * d.T, st, 3 * DM));
+    return CTRLSIM_OK;
   }
   // ---- predict_rtg head on the state tokens (decoder.py:74-77) / predict_action for the baselines (decoder.py:58-64)
   if (variant) return mlp_tail(m->head_action, w.xc, rQ, w.headh, logits, d.V, st);
@@ -660,6 +676,18 @@ extern "C" int ctrlsim_dt_forward_actions(const ctrlsim_model* m, int B, int Tq,
   if (!m || !c || !workspace || !act_logits || B < 1 || Tq < 1 || Tq > m->d.T || m->d.variant == 0) return CTRLSIM_EINVAL;
   const int A = m->d.A;
   return forward_full(m, 1, &B, &A, c, Tq, workspace, act_logits, nullptr, st);
+}
+
+// The reference's return contract of CtRLSim.forward (models/ctrl_sim.py:41-45, decoder.py:52-77): teacher-forced, every head on
+// every token of the window.  Outputs in token-row order [B,Tq,A,.] (the reference permutes to [B,A,T,.]); rtg_preds /
+// state_preds may be NULL and must be NULL for models without those heads (IL, Trajeglish, DT).  Not on the rollout path.
+extern "C" int ctrlsim_forward_all(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* c, void* workspace, float* action_preds,
+                                   float* rtg_preds, float* state_preds, hipStream_t st) {
+  if (!m || !c || !workspace || !action_preds || B < 1 || Tq < 1 || Tq > m->d.T) return CTRLSIM_EINVAL;
+  if ((rtg_preds && m->d.variant != 0) || (state_preds && !m->has_fut)) return CTRLSIM_EINVAL;
+  const int A = m->d.A;
+  const AllOut all{action_preds, rtg_preds, state_preds};
+  return forward_full(m, 1, &B, &A, c, Tq, workspace, nullptr, nullptr, st, &all);
 }
 
 // ------------------------------------------------------------------------------------------------ pass 2

@@ -79,11 +79,21 @@ __device__ __forceinline__ float op_hi(unsigned u) { return __uint_as_float(u & 
 
 // two fp32 values -> NPL dwords, plane p holding the p-th terms of both (first value in the low half)
 __device__ __forceinline__ void split_pair(float a, float b, unsigned (&pl)[NPL]) {
+#if CTRLSIM_F16X3 && defined(SPLIT_MIX)
+  // residual plane straight from the mixed-precision FMA: lo = f16(a - (float)hi), written into the half it belongs to
+  // (v_fma_mixlo_f16 / v_fma_mixhi_f16 read hi as fp16 and a as fp32): three instructions per pair instead of six
+  pl[0] = op_cvt_pk(a, b);
+  unsigned lo;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(pl[0]), "v"(a));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(pl[0]), "v"(b));
+  pl[1] = lo;
+#else
 #pragma unroll
   for (int p = 0; p < NPL; ++p) {
     pl[p] = op_cvt_pk(a, b);
     if (p + 1 < NPL) { a -= op_lo(pl[p]); b -= op_hi(pl[p]); }
   }
+#endif
 }
 // four consecutive values -> NPL (two-dword) plane entries
 __device__ __forceinline__ void split_quad(const f32x4 x, u32x2 (&pl)[NPL]) {

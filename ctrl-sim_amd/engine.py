@@ -188,6 +188,7 @@ class RolloutEngine:
         self.kinematic = int(bool(kinematic))
         self.max_ctx = int(max_ctx)
         self.use_cache = bool(use_cache) and not self.dims.VARIANT    # the K/V-cached phase is built for the CtRL-Sim tokens
+        self.device_ledger = self.dims.VARIANT == 3    # DT: RTG rows from the device reward ledger (the plugin surface feeds hist_rtg itself)
         self.contacts = bool(contacts) and not kinematic
         self.dt = float(cfg.nocturne.dt)
         w = self.w
@@ -271,6 +272,10 @@ class RolloutEngine:
         self.coll = z(S, N, Tmax1, 2, dt=torch.uint8)
         self.hist_tok = z(S, N, Tmax, dt=torch.int32)
         self.hist_rtg = z(S, N, Tmax, 3, dt=torch.int32)
+        if self.dims.VARIANT == 3:      # Decision Transformer: real-time reward ledger on the device (csrc/rewards.hip)
+            self.dt_ledger = z(S, N, 10, dt=torch.float64)
+            self.dt_rtg_raw = z(S, N, Tmax, 3, dt=torch.float64)
+            self.dt_init_rtg = None                          # [S,N,3] float64 tensor, or None = (10, 90, 90) (max_return)
         self.act_now = z(S, N, dt=torch.int32)
         self.applied = z(S, N, Tmax, 2, dt=torch.float64)
         self.persist = z(S, N, dt=torch.int64)
@@ -485,12 +490,40 @@ class RolloutEngine:
                                                       p(self.hist_rtg), p(L.ws), p(L.act_logits), 1, st), "pass2_cached")
         self._sample_action(L, t, s0, s1, st)
 
+    def _dt_cfg(self):
+        w, rc = self.w, self.cfg.nocturne.rew_cfg
+        c = _lib.DtRewardCfg()
+        c.pos_tol = float(rc["position_target_tolerance"])
+        c.shaped_unit = float(rc.get("shaped_goal_distance_scaling", 1.0)) / float(rc["reward_scaling"])
+        c.goal_mult, c.shaped_min, c.shaped_max = float(w.pos_target_achieved_rew_multiplier), float(w.pos_goal_shaped_min), float(w.pos_goal_shaped_max)
+        c.veh_mult, c.max_veh_dist = float(w.veh_veh_collision_rew_multiplier), float(w.max_veh_veh_distance)
+        c.edge_mult, c.edge_scale = float(w.veh_edge_collision_rew_multiplier), float(w.dist_to_road_edge_scaling_factor)
+        for k, (lo, hi) in enumerate(((w.min_rtg_pos, w.max_rtg_pos), (w.min_rtg_veh, w.max_rtg_veh), (w.min_rtg_road, w.max_rtg_road))):
+            c.rtg_lo[k], c.rtg_hi[k] = float(lo), float(hi)
+        c.remove_shaped_goal, c.remove_shaped_veh, c.remove_shaped_edge = int(bool(w.remove_shaped_goal)), \
+            int(bool(w.remove_shaped_veh_reward)), int(bool(w.remove_shaped_edge_reward))
+        return c
+
+    def _dt_ledger(self, t, s0, s1, st):
+        """Decision-Transformer policy (cfgs/policy/dt.yaml): the RTG row of step t from the real-time rewards, on the device
+        (ctrlsim_dt_ledger_step) — what PolicyEvaluator's per-vehicle bookkeeping feeds on the plugin surface."""
+        p, sl = _lib.ptr, slice(s0, s1)
+        if getattr(self, "_dt_cfg_c", None) is None:
+            self._dt_cfg_c = self._dt_cfg()
+        _lib.check(self.lib.ctrlsim_dt_ledger_step(s1 - s0, self.N, self.E, t, self.steps + 1, self.steps, p(self.hist_states[sl]),
+                                                   p(self.coll[sl]), p(self.goals[sl]), p(self.edges[sl]),
+                                                   p(self.dt_init_rtg[sl]) if self.dt_init_rtg is not None else None,
+                                                   C.byref(self._dt_cfg_c), p(self.dt_ledger[sl]), p(self.dt_rtg_raw[sl]),
+                                                   p(self.hist_rtg[sl]), st), "dt_ledger_step")
+
     def _policy_chunks(self, L, t, hist, lo, hi, noise_rtg=None, noise_act=None):
         """Full-recompute policy for scenarios [lo, hi) (hist = their group counts per size class), cut into model batches, on
         the main stream with lane L's buffers."""
         lib, p, st, d = self.lib, _lib.ptr, self._main.cuda_stream, self.dims
         N, Tmax = self.N, self.steps
         Tq = min(t, d.T - 1) + 1
+        if d.VARIANT == 3 and self.device_ledger:
+            self._dt_ledger(t, lo, hi, st)
         for (s0, s1, counts) in self._chunks(hist, lo):
             plan, n, Bs, As, cs = self._class_plan(L, counts, Tq, Tq)
             self._ctx_index(L, s0, s1, st)
@@ -559,9 +592,6 @@ class RolloutEngine:
         s1 = self.S if s1 is None else s1
         self._last_run = (steps, s0, s1) if (noise_fn is None and getattr(self, "_fresh", None) == (s0, s1)) else None
         self._fresh = None
-        if self.dims.VARIANT == 3:
-            raise NotImplementedError("the Decision-Transformer policy conditions on real-time rewards computed by the rollout "
-                                      "driver: run it through PolicyEvaluator (hist_rtg is fed per step), not RolloutEngine.run")
         if noise_fn is not None:
             assert s0 == 0 and s1 == self.S
             for t in range(steps):

@@ -4,8 +4,8 @@ The reference class is a LightningModule whose only rollout-relevant members are
 `forward(data, eval) -> {'action_preds','rtg_preds','state_preds'}`; `load_from_checkpoint(path)` builds it from a
 Lightning checkpoint whose `hyper_parameters` carry the cfg (eval_sim.py:52, policies/policy.py:28-29).
 Here the object owns the packed device weights (`HipModel`); the HIP forward is driven by the policy/engine through
-the C ABI, so `forward` on reference-layout tensors is provided for API parity and debugging (it returns the logits
-of the queried timestep only — the one slice AutoregressivePolicy reads)."""
+the C ABI; `forward` on reference-layout tensors is the reference's return contract ([B,A,T,.] logits of every head,
+teacher-forced), or — with `token_index` — the two-pass logits of one timestep, the slice AutoregressivePolicy reads."""
 from __future__ import annotations
 
 import numpy as np
@@ -47,28 +47,51 @@ class CtRLSim:
             self._hip = HipModel(self.cfg, self.weights, self.device)
         return self._hip
 
-    def __call__(self, data, eval=True, token_index=-1):
+    def __call__(self, data, eval=False, token_index=None):
         return self.forward(data, eval, token_index)
 
-    def forward(self, data, eval=True, token_index=-1):
-        """data: reference MotionData-like mapping (data['agent'].agent_states ...).  Returns logits at `token_index`
-        for every context slot: {'rtg_preds': [B,A,R*C], 'action_preds': [B,A,V]} (two-pass HIP forward with the rtg
-        bins already present in data, i.e. what the reference's second call computes)."""
+    def _arrays(self, data):
+        ag, mp = data["agent"], data["map"]
+        g = lambda o, k: (o[k] if isinstance(o, dict) else getattr(o, k))
+        host = lambda v: np.asarray(v.cpu() if hasattr(v, "cpu") else v)
+        arrs = {k: host(g(ag, k)) for k in ("agent_states", "agent_types", "goals", "actions", "rtgs", "timesteps")}
+        arrs["road_points"], arrs["road_types"] = host(g(mp, "road_points")), host(g(mp, "road_types"))
+        return arrs
+
+    def forward(self, data, eval=False, token_index=None):
+        """data: reference MotionData-like mapping (data['agent'].agent_states ...).
+        token_index None (the reference's contract, models/ctrl_sim.py:41-45 + decoder.py:52-77): one teacher-forced forward,
+        {'action_preds': [B,A,T,V], 'rtg_preds': [B,A,T,R*C], 'state_preds': [B,A,T,2T]} (the keys the model's heads provide).
+        token_index given: the logits of that window step for every slot, {'rtg_preds': [B,A,R*C], 'action_preds': [B,A,V]},
+        from the two-pass HIP forward with the rtg bins already present in data (what the reference's second call computes)."""
         import ctypes as C
         import torch
         from .. import _lib
         from ..engine import ctx_from_reference_layout
         d = self.dims
-        ag, mp = data["agent"], data["map"]
-        g = lambda o, k: (o[k] if isinstance(o, dict) else getattr(o, k))
-        arrs = {k: np.asarray(g(ag, k).cpu() if hasattr(g(ag, k), "cpu") else g(ag, k))
-                for k in ("agent_states", "agent_types", "goals", "actions", "rtgs", "timesteps")}
-        arrs["road_points"] = np.asarray(g(mp, "road_points").cpu() if hasattr(g(mp, "road_points"), "cpu") else g(mp, "road_points"))
-        arrs["road_types"] = np.asarray(g(mp, "road_types").cpu() if hasattr(g(mp, "road_types"), "cpu") else g(mp, "road_types"))
+        arrs = self._arrays(data)
         B = arrs["agent_states"].shape[0]
+        dev = self.device
+        lib, st = _lib.lib(), _lib.stream_ptr()
+        if token_index is None:
+            cb = ctx_from_reference_layout(d, arrs, d.T, dev)
+            cb.slot_gid.copy_(torch.arange(d.A, dtype=torch.int32, device=dev).expand(B, d.A))
+            ws = torch.empty(self.hip.workspace_bytes(B, d.T), dtype=torch.uint8, device=dev)
+            act = torch.empty(B, d.T, d.A, d.V, device=dev)
+            rtg = torch.empty(B, d.T, d.A, d.R * d.C, device=dev) if d.VARIANT == 0 else None
+            fut = torch.empty(B, d.T, d.A, d.FUT, device=dev) if "decoder.predict_future_states.mlp.0.weight" in self.weights else None
+            _lib.check(lib.ctrlsim_forward_all(self.hip.handle, B, d.T, C.byref(cb.struct), ws.data_ptr(), act.data_ptr(),
+                                               rtg.data_ptr() if rtg is not None else None,
+                                               fut.data_ptr() if fut is not None else None, st), "forward_all")
+            torch.cuda.synchronize()
+            out = {"action_preds": act.permute(0, 2, 1, 3)}
+            if fut is not None:
+                out["state_preds"] = fut.permute(0, 2, 1, 3)
+            if rtg is not None:
+                out["rtg_preds"] = rtg.permute(0, 2, 1, 3)
+            return out
         ti = token_index if token_index >= 0 else d.T + token_index
         Tq = ti + 1
-        dev = self.device
         cb = ctx_from_reference_layout(d, arrs, Tq, dev)
         cb.slot_gid.copy_(torch.arange(d.A, dtype=torch.int32, device=dev).expand(B, d.A))
         ws = torch.empty(self.hip.workspace_bytes(B, Tq), dtype=torch.uint8, device=dev)
@@ -77,7 +100,6 @@ class CtRLSim:
         hist = torch.zeros(B, d.A, 1, 3, dtype=torch.int32, device=dev)
         hist[:, :, 0] = torch.from_numpy(arrs["rtgs"][:, :, ti].astype(np.int32)).to(dev)
         scn = torch.arange(B, dtype=torch.int32, device=dev)
-        lib, st = _lib.lib(), _lib.stream_ptr()
         _lib.check(lib.ctrlsim_dt_forward_pass1(self.hip.handle, B, Tq, C.byref(cb.struct), ws.data_ptr(), rtg.data_ptr(), None, st))
         _lib.check(lib.ctrlsim_dt_forward_pass2(self.hip.handle, B, Tq, 0, d.A, 1, C.byref(cb.struct), scn.data_ptr(),
                                                 hist.data_ptr(), ws.data_ptr(), act.data_ptr(), 0, st))

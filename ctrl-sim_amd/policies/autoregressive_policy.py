@@ -69,6 +69,7 @@ class AutoregressivePolicy(Policy):
         eng = RolloutEngine(self.model.cfg, self.model.weights, self.model.device, max_ctx=max(16, n),
                             seed=int(self.cfg.eval.seed), tilt=tilt, temperature=self.action_temperature,
                             nucleus=self.nucleus_sampling, top_p=self.nucleus_threshold, model=self.model.hip)
+        eng.device_ledger = False      # real_time_rewards: the evaluator's own bookkeeping feeds hist_rtg (predict below)
         eng.load_scenarios([scn], steps=self.steps)
         self._session = eng
         self._session_key = (tuple(ids), rp.shape)

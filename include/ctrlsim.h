@@ -159,6 +159,13 @@ int ctrlsim_dt_forward_pass1(const ctrlsim_model* m, int B, int Tq, const ctrlsi
  * these models and this call refuses the CtRL-Sim model. */
 int ctrlsim_dt_forward_actions(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* ctx, void* workspace,
                                float* act_logits, hipStream_t stream);
+/* The reference's full return contract of CtRLSim.forward (models/ctrl_sim.py:41-45; decoder.py:52-77): teacher-forced, every
+ * head on every token of the Tq window steps.  action_preds [B,Tq,A,V], rtg_preds [B,Tq,A,R*C], state_preds [B,Tq,A,2T] in
+ * token-row order (the reference returns the [B,A,T,.] permutation of these).  rtg_preds / state_preds are nullable and must be
+ * NULL for models without the head (predict_rtg / predict_future_states false: il, trajeglish, dt yaml).  Workspace as pass 1.
+ * Training-time / debugging contract — the rollout reads one timestep and uses the pass1 / pass2 entry points. */
+int ctrlsim_forward_all(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* ctx, void* workspace, float* action_preds,
+                        float* rtg_preds, float* state_preds, hipStream_t stream);
 /* pass 2 (same workspace, after ctrlsim_sample_rtg wrote hist_rtg[...,t,:]): act_logits [B,A,V].
  * cached = 1 pairs with ctrlsim_dt_forward_pass1_cached (workspace sized with Tq = T, ctx = last min(Tq,2) window rows). */
 int ctrlsim_dt_forward_pass2(const ctrlsim_model* m, int B, int Tq, int t, int N, int Tmax, const ctrlsim_ctx* ctx,
@@ -193,6 +200,28 @@ int ctrlsim_sample_action(const float* act_logits, int A, int V, const int* mem_
                           float temperature, double top_p /*<=0: off*/, const float* noise /*[S*N,V] or NULL*/,
                           uint64_t seed, const int64_t* scenario_id, int t, int* hist_tok, int* act_now /*[S,N]*/,
                           int S, int N, int Tmax, int zero_token, hipStream_t stream);
+
+/* ---- real-time reward ledger (Decision-Transformer baseline) --------------------------------------------------------
+ * Replaces the host bookkeeping of a policy with real_time_rewards (cfgs/policy/dt.yaml): PolicyEvaluator.update_vehicle_data_dict
+ * (evaluators/policy_evaluator.py:122-147: RTG_0, RTG_t = RTG_{t-1} - dense_reward_{t-1}) + Evaluator.compute_dense_reward
+ * (evaluators/evaluator.py:106-140; datasets/rl_waymo/dataset.py:187-275; utils/data.py:152-290) + the clip-normalisation of
+ * AutoregressivePolicy.get_data (policies/autoregressive_policy.py:73-78).  Call once per step t, after the simulator wrote the
+ * states of step t and before the contexts of step t are built: hist_rtg[S,N,Tmax,3][.., t, :] <- float bits of the normalised
+ * RTG (what a variant-3 model reads); `ledger` [S,N,10] float64 carries RTG / dense reward / step-0 reward flags between calls
+ * (t = 0 initialises it); init_rtg [S,N,3] float64 or NULL = (10, 90, 90) (max_return); rtg_raw [S,N,Tmax,3] float64 nullable.
+ * `edges` is the simulator's road-edge segment table [S,E,4]. */
+typedef struct ctrlsim_dt_reward_cfg {
+  double pos_tol;        // cfg.nocturne.rew_cfg.position_target_tolerance
+  double shaped_unit;    // shaped_goal_distance_scaling / reward_scaling (utils/sim.py:112-118)
+  double goal_mult, shaped_min, shaped_max;     // pos_target_achieved_rew_multiplier, pos_goal_shaped_min / _max
+  double veh_mult, max_veh_dist;                // veh_veh_collision_rew_multiplier, max_veh_veh_distance
+  double edge_mult, edge_scale;                 // veh_edge_collision_rew_multiplier, dist_to_road_edge_scaling_factor
+  double rtg_lo[3], rtg_hi[3];                  // min / max_rtg_pos, _veh, _road
+  int remove_shaped_goal, remove_shaped_veh, remove_shaped_edge, pad_;
+} ctrlsim_dt_reward_cfg;
+int ctrlsim_dt_ledger_step(int S, int N, int E, int t, int T1, int Tmax, const float* hist_states, const uint8_t* coll,
+                           const double* goals /*[S,N,5]: x, y first*/, const float* edges, const double* init_rtg,
+                           const ctrlsim_dt_reward_cfg* cfg, double* ledger, double* rtg_raw, int* hist_rtg, hipStream_t stream);
 
 /* ---- metrics ----------------------------------------------------------------------------------------------------
  * Replaces PolicyEvaluator.update_running_statistics (evaluators/policy_evaluator.py:162-248) with compute_reward's goal latch

@@ -145,3 +145,43 @@ def test_compact_contexts_equal_plain_contexts(kind, n_agents, Actx, Tqs):
         np.testing.assert_allclose(rtg_c[:, :n_agents], rtg[:, :n_agents], atol=2e-5, rtol=0)
         np.testing.assert_allclose(act_c[:, :n_agents], act[:, :n_agents], atol=2e-5, rtol=0)
         assert np.isfinite(rtg_c).all() and rtg_c.shape[1] == Ar
+
+
+def _motion_data(inp):
+    return {"agent": {k: inp[k] for k in ("agent_states", "agent_types", "goals", "actions", "rtgs", "timesteps")},
+            "map": {k: inp[k] for k in ("road_points", "road_types")}}
+
+
+def test_forward_full_return_contract_matches_reference_and_oracle():
+    """`CtRLSim.forward(data)` is the reference's contract (models/ctrl_sim.py:41-45, decoder.py:52-77): all three heads on every
+    token, [B,A,T,.].  tests/golden/model_tiny.npz holds those tensors from the UNMODIFIED reference (including state_preds of
+    the predict_future_states head); at full dims the oracle (pinned to the reference on the queried slices) is the checker."""
+    from ctrlsim_amd.models import CtRLSim
+    for kind in ("tiny", "full"):
+        cfg = cfg_of(kind)
+        d = spec.Dims(cfg)
+        w = weights.generate(d, 0)
+        model = CtRLSim(cfg, w, device=DEV)
+        g = golden(f"model_{kind}")
+        for seed in (1, 2):
+            _, t_fill, n_ag, n_pl = [int(v) for v in g[f"s{seed}_recipe"]]
+            inp = synth_inputs.random_context(d, seed, B=1, t_fill=t_fill, n_agents=n_ag, n_polys=n_pl)
+            out = model(_motion_data(inp))
+            assert set(out) == {"action_preds", "rtg_preds", "state_preds"}
+            assert out["state_preds"].shape == (1, d.A, d.T, 2 * d.T)
+            if kind == "tiny":
+                for k in out:
+                    np.testing.assert_allclose(out[k].cpu().numpy(), g[f"s{seed}_{k}"], atol=TOL, rtol=0, err_msg=k)
+            else:
+                ti = t_fill - 1
+                np.testing.assert_allclose(out["action_preds"][0, :, ti].cpu().numpy(), g[f"s{seed}_action_logits"], atol=TOL, rtol=0)
+                np.testing.assert_allclose(out["rtg_preds"][0, :, ti].cpu().numpy(), g[f"s{seed}_rtg_logits"], atol=TOL, rtol=0)
+                with torch.no_grad():
+                    ref = mo.forward(mo.as_torch_weights(w), synth_inputs.to_torch(inp), d)
+                for k in out:
+                    np.testing.assert_allclose(out[k].cpu().numpy(), ref[k].numpy(), atol=TOL, rtol=0, err_msg=k)
+            # the sliced two-pass call agrees with the full contract at the queried step
+            ti = t_fill - 1
+            sl = model(_motion_data(inp), token_index=ti)
+            np.testing.assert_allclose(sl["rtg_preds"].cpu().numpy(), out["rtg_preds"][:, :, ti].cpu().numpy(), atol=TOL, rtol=0)
+            np.testing.assert_allclose(sl["action_preds"].cpu().numpy(), out["action_preds"][:, :, ti].cpu().numpy(), atol=TOL, rtol=0)

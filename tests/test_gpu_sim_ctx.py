@@ -559,6 +559,41 @@ def test_decision_transformer_logits_match_reference_fixture():
         np.testing.assert_allclose(logits[0].cpu().numpy(), g[f"decision_transformer_loop_s{seed}_action"], atol=1e-4, rtol=0)
 
 
+def test_decision_transformer_rollout_with_device_reward_ledger_matches_reference_fixture():
+    """cfgs/policy/dt.yaml in the BATCHED engine: ctrlsim_dt_ledger_step keeps the real-time RTG ledger on the device (RTG_0 = max
+    return, minus the dense reward of every step: nearest road-edge distance, nearest-vehicle distance, step-0 flags) and feeds
+    the variant-3 model — vs tests/golden/dt_loop.npz (unmodified reference policy + the reference's reward functions + real
+    FreeCar/Box2D): sampled actions identical, RTG ledger and states within 1e-4; and vs the CPU oracle on a packed scene."""
+    g = golden("dt_loop")
+    rc = g["loop_recipe"]
+    cfg = cfg_of("loop", variant="decision_transformer")
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    steps = 14
+    scn = scenarios.make_scenario(int(rc[0]), int(rc[1]), n_agents=int(rc[2]), n_polylines=int(rc[3]), n_points=d.NP,
+                                  extent=float(rc[4]))
+    eng = RolloutEngine(cfg, w, DEV, max_ctx=32, seed=int(rc[5]))
+    eng.load_scenarios([scn, scn], steps=steps)
+    r = eng.run(steps).results()
+    raw = eng.dt_rtg_raw.cpu().numpy()
+    for s in range(2):
+        assert np.array_equal(r["tokens"][s][:, :steps], g["loop_tokens"])
+        np.testing.assert_allclose(raw[s], g["loop_rtgs"], atol=1e-4, rtol=0)
+        np.testing.assert_allclose(r["states"][s][:, :, 0], g["loop_states"][:, :, 0], atol=1e-4, rtol=0)
+    assert np.abs(g["loop_rtgs"][:, -1] - g["loop_rtgs"][:, 0]).max() > 1.0          # the ledger moved
+    # a packed scene (vehicles within the 15 m nearest-vehicle range, collisions) against the oracle's ledger
+    scn2 = scenarios.make_scenario(43, 5, n_agents=9, n_polylines=12, n_points=d.NP, extent=12.0)
+    eng2 = RolloutEngine(cfg, w, DEV, max_ctx=32, seed=3)
+    eng2.load_scenarios([scn2], steps=12)
+    r2 = eng2.run(12).results()
+    o = rollout_oracle.RolloutOracle(cfg, w, seed=3).run(scn2, 12, sim_libs.OracleSim)
+    assert o["coll"][..., 0].sum() > 0
+    assert np.array_equal(r2["tokens"][0][:, :12], o["tokens"])
+    np.testing.assert_allclose(eng2.dt_rtg_raw.cpu().numpy()[0], o["rtgs"], atol=1e-4, rtol=0)   # positions agree to 1e-4
+    np.testing.assert_allclose(r2["states"][0], o["states"], atol=1e-4, rtol=0)
+    assert np.array_equal(r2["coll"][0], o["coll"])
+
+
 def test_nonfinite_logits_are_counted_and_fail_loudly():
     """NaN logits (what an activation beyond the fp16 range of the split operands would produce) never become an out-of-range
     token: the race falls back to a valid id, ctrlsim_nonfinite_count reports it and RolloutEngine.results() raises."""
