@@ -187,6 +187,15 @@ def main():
                 break
         keys = ("gemm_nt_bf16x6_kernel", "attention_bf16x6_kernel")
 
+        def traffic(i, alg):
+            """HBM bytes per launch of class i: the PMC run's measured-over-algorithmic ratio (same kernels and shapes, smaller
+            launches: counter passes serialise the kernels) applied to THIS run's algorithmic bytes per launch; a profile without
+            the ratio (round 1) is quoted as measured."""
+            e = pmc.get(keys[i], {})
+            if "hbm_over_algorithmic" in e:
+                return e["hbm_over_algorithmic"] * alg
+            return e.get("hbm_bytes_per_launch")
+
         def cls(i):
             a = fl[i] / (ms[i] * 1e-3) / 1e12 if ms[i] > 0 else None
             n = max(cnt[i], 1)
@@ -195,7 +204,7 @@ def main():
                     "launches": int(cnt[i]), "time_share_of_step": ms[i] * 1e-3 / elapsed,
                     "mfma_executed_tflops": nprod * a if a else None, "mfma_peak_tflops": PEAK_16BIT_MFMA_TFLOPS,
                     "algorithmic_flops_per_launch": fl[i] / n, "algorithmic_hbm_bytes_per_launch": by[i] / n,
-                    "traffic": pmc.get(keys[i], {}).get("hbm_bytes_per_launch"), "traffic_source": pmc_src,
+                    "traffic": traffic(i, by[i] / n), "traffic_source": pmc_src, "traffic_measured": pmc.get(keys[i]),
                     "hbm_rate_at_algorithmic_bytes_TBps": by[i] / (ms[i] * 1e-3) / 1e12 if ms[i] > 0 else None}
 
         def sat(i):                                           # satellite kernels: algorithmic bytes / event time vs the HBM roof
@@ -209,8 +218,9 @@ def main():
                 "note": "achieved = algorithmic fp32 FLOPs (2MNK per Linear; 128 per visible (q,k) pair and head) / summed "
                         f"HIP-event time of the class; peak = dense 16-bit MFMA peak / {nprod} because each fp32 product costs {nprod} "
                         f"MFMA products ({scheme} products, fp32-class accuracy: csrc/split.h); the f32-input MFMA path (157.3 TF peak) is "
-                        "selectable with ctrlsim_set_option; traffic = HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, PMC, separate "
-                        "rocprofv3 --pmc passes over this command, committed under profiles/)",
+                        "selectable with ctrlsim_set_option; traffic = HBM bytes per launch: (FETCH_SIZE + WRITE_SIZE) / algorithmic bytes measured "
+                        "by separate rocprofv3 --pmc passes over a smaller run of this workload (traffic_measured, committed under "
+                        "profiles/) x this run's algorithmic bytes per launch",
                 "other": cls(1 - dom),
                 "satellite": {CLASS_KEYS[i]: sat(i) for i in range(2, ncls)},
                 "satellite_note": "HBM-side kernels (SURVEY 8d): algorithmic bytes (DESIGN.md 4) / HIP-event time vs the 8 TB/s HBM "

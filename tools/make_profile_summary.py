@@ -1,5 +1,9 @@
-"""Turn gpurun_out/{bench_r01.json, prof_r01/r01_kernel_stats.csv, pmc_bench/summary.json, pmc_cal/summary.json} into the
-committed summaries profiles/r01_b_kernel_stats.md and profiles/r01_pmc_traffic.json.  Usage: python tools/make_profile_summary.py"""
+"""Turn one round's GPU-box outputs into the committed summaries under profiles/.  Usage: python tools/make_profile_summary.py r02
+Inputs (written by tools/profile_round.sh on the GPU box, merged back under gpurun_out/):
+  gpurun_out/bench_<r>.json                        the un-profiled bench line of the profiled command
+  gpurun_out/prof_<r>/<r>_kernel_stats.csv         rocprofv3 --kernel-trace --stats of that command
+  gpurun_out/pmc_<r>/summary.json, FETCH_SIZE.log  tools/pmc_traffic.sh over a smaller run of the same workload (its bench line is in the log)
+Outputs: profiles/<r>_b_kernel_stats.md, profiles/<r>_pmc_traffic.json, profiles/<r>_bench_line.json"""
 import collections
 import csv
 import json
@@ -24,64 +28,92 @@ def short(n):
 
 
 def main():
-    rows = list(csv.DictReader(open("gpurun_out/prof_r01/r01_kernel_stats.csv")))
+    import sys
+    R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    rows = list(csv.DictReader(open(f"gpurun_out/prof_{R}/{R}_kernel_stats.csv")))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
-    b = json.load(open("gpurun_out/bench_r01.json"))
-    lines = ["# r01_b — rocprofv3 --kernel-trace --stats of the default `python bench.py` (1x MI355X)", "",
-             "Command: `rocprofv3 --kernel-trace --stats -d gpurun_out/prof_r01 -o r01 --output-format csv -- python bench.py`",
-             f"({b['config']['scenarios_per_gpu']} scenarios x 64 vehicles x 90 steps x 512 polylines, model batch 512 contexts, warmup 1 + timed 1 rollout; the",
-             "kernel table therefore covers TWO rollouts).  Un-profiled run of the same command, same box:", "",
-             f"`value` = **{b['value']:.0f} agent-steps/s**, {b['ms_per_step']:.0f} ms per 90-step rollout, cpu_baseline "
-             f"{b['cpu_baseline']['value']:.1f} agent-steps/s on {b['cpu_baseline']['cores']} threads "
-             f"({b['cpu_baseline']['sample'].split(';')[0]}).", "",
+    b = json.load(open(f"gpurun_out/bench_{R}.json"))
+    cmd = open(f"gpurun_out/prof_{R}/command.txt").read().strip()
+    c = b["config"]
+    lines = [f"# {R}_b — rocprofv3 --kernel-trace --stats of a bench.py run (1x MI355X)", "",
+             f"Command: `rocprofv3 --kernel-trace --stats -d gpurun_out/prof_{R} -o {R} --output-format csv -- {cmd}`",
+             f"({c['scenarios_per_gpu']} scenarios x {c['agents']} vehicles x {c['rollout_steps']} steps x {c['polylines']} polylines, "
+             f"{b['warmup']} warm-up + {b['steps']} timed bench steps = rollouts of {c['scenarios_per_step']} scenarios, {c['lanes']} lanes; the kernel",
+             "table covers warm-up and timed steps).  Un-profiled run of the same command, same box:", "",
+             f"`value` = **{b['value']:.0f} agent-steps/s**, {b['ms_per_step']:.0f} ms per bench step"
+             + (f", cpu_baseline {b['cpu_baseline']['value']:.1f} agent-steps/s on {b['cpu_baseline']['cores']} threads "
+                f"({b['cpu_baseline']['sample'].split(';')[0]})." if b.get("cpu_baseline") else "."), "",
              "| kernel | calls | total ms | avg us | % of kernel time |", "|---|---|---|---|---|"]
     agg = collections.OrderedDict()
     for r in rows:
         a = agg.setdefault(short(r["Name"]), [0, 0.0])
         a[0] += int(r["Calls"]); a[1] += float(r["TotalDurationNs"])
-    for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
-        lines.append(f"| `{k}` | {c} | {t / 1e6:.1f} | {t / c / 1e3:.1f} | {100 * t / tot:.2f} |")
+    for k, (cc, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:32]:
+        lines.append(f"| `{k}` | {cc} | {t / 1e6:.1f} | {t / cc / 1e3:.1f} | {100 * t / tot:.2f} |")
 
     def cls(keys):
-        c = sum(v[0] for k, v in agg.items() if any(x in k for x in keys))
+        cc = sum(v[0] for k, v in agg.items() if any(x in k for x in keys))
         t = sum(v[1] for k, v in agg.items() if any(x in k for x in keys))
-        return c, t
+        return cc, t
     gc, gt = cls(GEMM_KEYS); ac, at = cls(ATTN_KEYS)
     r = b["roofline"]; o = r["other"]
     if "attention" in r["kernel"]:
         r, o = o, r
-    lines += ["", f"total kernel time {tot / 1e6:.0f} ms over {sum(int(x['Calls']) for x in rows)} dispatches (two rollouts).", "",
-              "## Agreement with bench.py's live HIP-event timing (timed rollout only)", "",
-              "| class | rocprofv3 avg per launch (both rollouts) | bench.py HIP-event avg per launch | launches (rocprof / bench) | share of kernel time |",
+    scale = (b["warmup"] + b["steps"]) / b["steps"]
+    lines += ["", f"total kernel time {tot / 1e6:.0f} ms over {sum(int(x['Calls']) for x in rows)} dispatches.", "",
+              "## Agreement with bench.py's live HIP-event timing (timed steps only)", "",
+              "| class | rocprofv3 avg per launch (warm-up + timed) | bench.py HIP-event avg per launch | launches (rocprof / bench) | share of kernel time |",
               "|---|---|---|---|---|",
               f"| Linear class: gemm_nt_bf16x6_kernel (all variants) + ffn_fused_bf16x6_kernel | {gt / gc / 1e6:.4f} ms | {r['avg_launch_ms']:.4f} ms | {gc} / {r['launches']} | {100 * gt / tot:.1f} % |",
               f"| attention_bf16x6_kernel (causal + key-padding) | {at / ac / 1e6:.4f} ms | {o['avg_launch_ms']:.4f} ms | {ac} / {o['launches']} | {100 * at / tot:.1f} % |",
               "",
+              f"(rocprofv3 counts the warm-up step too: {scale:.2f}x the timed launches.)",
               f"Roofline line of that run: Linear class {r['achieved']:.1f} TFLOP/s fp32-equivalent = {r['frac']:.3f} of the {r['peak']:.1f} TFLOP/s split-operand roof",
               f"({r['mfma_executed_tflops']:.0f} TFLOP/s of 16-bit MFMA issued), {100 * r['time_share_of_step']:.1f} % of the step; attention class {o['achieved']:.1f} TFLOP/s",
               f"fp32-equivalent = {o['frac']:.3f}, {100 * o['time_share_of_step']:.1f} % of the step.", "",
-              "The HIP-event interval brackets each launch on the launch stream, so it includes a few microseconds of dispatch gap; the two",
-              "averages agree to within that gap."]
-    open("profiles/r01_b_kernel_stats.md", "w").write("\n".join(lines) + "\n")
+              "Satellite kernels (algorithmic HBM bytes / HIP-event time, bench.py `roofline.satellite`):", "",
+              "| class | avg launch ms | launches | algorithmic MB / launch | TB/s | of 8 TB/s | share of step |", "|---|---|---|---|---|---|---|"]
+    for k, v in (b["roofline"].get("satellite") or {}).items():
+        if v:
+            lines.append(f"| {k} | {v['avg_launch_ms']:.3f} | {v['launches']} | {v['algorithmic_hbm_bytes_per_launch'] / 1e6:.1f} | {v['achieved']:.3f} | "
+                         f"{v['frac']:.3f} | {100 * v['time_share_of_step']:.1f} % |")
+    lines += ["", "The HIP-event interval brackets each launch on the launch stream, so it includes a few microseconds of dispatch gap; with two",
+              "lanes a side-stream kernel (sim_step, group_build) can share the chip with the bracketed kernel, which lengthens both a little."]
+    open(f"profiles/{R}_b_kernel_stats.md", "w").write("\n".join(lines) + "\n")
+    json.dump(b, open(f"profiles/{R}_bench_line.json", "w"), indent=1)
 
-    d = json.load(open("gpurun_out/pmc_bench/summary.json"))
+    d = json.load(open(f"gpurun_out/pmc_{R}/summary.json"))
+    pb = None
+    for ln in open(f"gpurun_out/pmc_{R}/FETCH_SIZE.log"):
+        if ln.startswith("{") and '"roofline"' in ln:
+            pb = json.loads(ln)
+    pr = pb["roofline"]; po = pr["other"]
+    if "attention" in pr["kernel"]:
+        pr, po = po, pr
     out = {}
-    for name, keys in (("gemm_nt_bf16x6_kernel", GEMM_KEYS), ("attention_bf16x6_kernel", ATTN_KEYS)):
+    for name, keys, br in (("gemm_nt_bf16x6_kernel", GEMM_KEYS, pr), ("attention_bf16x6_kernel", ATTN_KEYS, po)):
         n = f = w = 0
         for k, v in d.items():
             if any(x in k for x in keys):
                 n += v["launches"]; f += v.get("FETCH_SIZE_raw_sum", 0); w += v.get("WRITE_SIZE_raw_sum", 0)
+        # the PMC passes see every launch of the command (warm-up included); bench.py's algorithmic bytes cover the timed launches —
+        # both are per-launch means over the same kernels at the same shapes
+        alg = br["algorithmic_hbm_bytes_per_launch"]
         out[name] = {"launches": n, "fetch_bytes_per_launch": f * 1024 / n, "write_bytes_per_launch": w * 1024 / n,
-                     "hbm_bytes_per_launch": (f + w) * 1024 / n}
-    out["_how"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --no-cpu-baseline` "
+                     "hbm_bytes_per_launch": (f + w) * 1024 / n, "algorithmic_bytes_per_launch_same_run": alg,
+                     "hbm_over_algorithmic": (f + w) * 1024 / n / alg}
+    out["_command"] = open(f"gpurun_out/pmc_{R}/command.txt").read().strip()
+    out["_how"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (no tracing flags) over the command above "
                    "(tools/pmc_traffic.sh; the Linear class = gemm_nt_bf16x6_kernel variants + ffn_fused_bf16x6_kernel); counter units of "
-                   "1024 B; calibrated on micro-launches with known byte counts (FFN-1 shape 147456x1024x256: WRITE_SIZE = 603,979,776 B = "
+                   "1024 B; calibrated in round 1 on micro-launches with known byte counts (FFN-1 shape 147456x1024x256: WRITE_SIZE = 603,979,776 B = "
                    "M*N*4 exactly; FETCH_SIZE = 156.5 MB vs 151.0 MB of A + 1.6 MB of weight planes) => factor 1.0 for these kernels' access "
                    "patterns (64-byte row segments / 16-byte DMA pieces); the guide's x2 applies to 128-byte wide streaming reads and would "
-                   "double-count here")
-    json.dump(out, open("profiles/r01_pmc_traffic.json", "w"), indent=1)
-    print("\n".join(lines[-12:]))
-    print(json.dumps({k: v for k, v in out.items() if k != "_how"}, indent=1))
+                   "double-count here.  The PMC run is a smaller batch than the driver's bench (counter passes serialise the kernels), so "
+                   "bench.py reports roofline.traffic = hbm_over_algorithmic x ITS OWN algorithmic bytes per launch (same kernels, same "
+                   "shapes per context, different launch sizes) and keeps the raw numbers of this file next to it")
+    json.dump(out, open(f"profiles/{R}_pmc_traffic.json", "w"), indent=1)
+    print("\n".join(lines[-22:]))
+    print(json.dumps({k: v for k, v in out.items() if not k.startswith("_")}, indent=1))
 
 
 if __name__ == "__main__":
