@@ -66,8 +66,12 @@ def test_log_replay_history_steps_and_model_call():
     import synth_inputs
     d = spec.Dims(cfg)
     inp = synth_inputs.random_context(d, 4, B=2)
-    out = model(synth_inputs.to_motion_data(inp), eval=True)
-    assert out["rtg_preds"].shape == (2, d.A, d.R * d.C) and out["action_preds"].shape == (2, d.A, d.V)
+    out = model(synth_inputs.to_motion_data(inp), eval=True)                      # the reference's contract: [B,A,T,.] per head
+    assert out["rtg_preds"].shape == (2, d.A, d.T, d.R * d.C) and out["action_preds"].shape == (2, d.A, d.T, d.V)
+    assert out["state_preds"].shape == (2, d.A, d.T, 2 * d.T)
+    sl = model(synth_inputs.to_motion_data(inp), eval=True, token_index=-1)       # the slice the policy reads (two-pass path)
+    assert sl["rtg_preds"].shape == (2, d.A, d.R * d.C) and sl["action_preds"].shape == (2, d.A, d.V)
+    np.testing.assert_allclose(sl["action_preds"].cpu().numpy(), out["action_preds"][:, :, -1].cpu().numpy(), atol=1e-4, rtol=0)
 
 
 def _role_policy(cfg, model, pol, key_dict):

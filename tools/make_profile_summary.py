@@ -16,15 +16,29 @@ ATTN_KEYS = ("attention_bf16x6",)
 def short(n):
     n = n.replace("void ", "").replace("(anonymous namespace)::", "")
     if n.startswith("_Z"):                      # rocprofv3 leaves names with _Float16 parameters mangled: recover name<template args>
-        m = re.match(r"_Z+N?(?:12_GLOBAL__N_1)?(\d+)", n)
-        if m:
-            k = int(m.group(1)); start = m.end(); name = n[start:start + k]; rest = n[start + k:]
-            t = re.match(r"I((?:L[ib]\d+E)+)E", rest)
+        pos = 2
+        nested = n[pos] == "N"
+        pos += nested
+        name = None
+        while True:                             # length-prefixed components (namespaces s0 / s1, _GLOBAL__N_1, the function)
+            m = re.match(r"(\d+)", n[pos:])
+            if not m:
+                break
+            k = int(m.group(1)); pos += len(m.group(1))
+            comp = n[pos:pos + k]; pos += k
+            if comp in ("s0", "s1"):
+                ns = comp
+            if not comp.startswith("_GLOBAL__N_") and comp not in ("s0", "s1"):
+                name = comp
+            if not nested:
+                break
+        if name:
+            t = re.match(r"I((?:L[ib]\d+E)+)E", n[pos:])
             if t:
                 vals = re.findall(r"L([ib])(\d+)E", t.group(1))
                 name += "<" + ", ".join(v if ty == "i" else ("true" if v == "1" else "false") for ty, v in vals) + ">"
             return name
-    return n.split("(")[0]
+    return re.sub(r"^s[01]::", "", n).split("(")[0]
 
 
 def main():
