@@ -81,6 +81,7 @@ SIGNATURES = {
     "ctrlsim_sample_action_rows": (I, [P, P, I, P, P, F, D, P, U64, P, I, P, P, I, I, I, I, P]),
     "ctrlsim_dt_forward_pass1": (I, [P, I, I, C.POINTER(Ctx), P, P, P, P]),
     "ctrlsim_dt_forward_actions": (I, [P, I, I, C.POINTER(Ctx), P, P, P]),
+    "ctrlsim_map_pool": (I, [P, I, P, P, P, P]),
     "ctrlsim_forward_all": (I, [P, I, I, C.POINTER(Ctx), P, P, P, P, P]),
     "ctrlsim_dt_forward_pass2": (I, [P, I, I, I, I, I, C.POINTER(Ctx), P, P, P, P, I, P]),
     "ctrlsim_dt_forward_pass1_cached": (I, [P, I, I, C.POINTER(Ctx), P, P, P]),

@@ -690,6 +690,14 @@ extern "C" int ctrlsim_forward_all(const ctrlsim_model* m, int B, int Tq, const 
   return forward_full(m, 1, &B, &A, c, Tq, workspace, nullptr, nullptr, st, &all);
 }
 
+// Component-level entry (tests, micro-benchmarks): the folded point MLP + seed-attention pooling of B*P polylines,
+// modules/map_encoder.py:28-46 up to (not including) out_proj.  attn_pre [B*P,256]; pad [B,P] <- 1 for polylines without a point.
+extern "C" int ctrlsim_map_pool(const ctrlsim_model* m, int B, const float* road_pts, float* attn_pre, unsigned char* pad,
+                                hipStream_t st) {
+  if (!m || !road_pts || !attn_pre || !pad || B < 1) return CTRLSIM_EINVAL;
+  return launch_map_pool(B, m->d.P, m->d.NP, m->d.P, road_pts, m->mp, attn_pre, pad, st);
+}
+
 // ------------------------------------------------------------------------------------------------ pass 2
 extern "C" int ctrlsim_dt_forward_pass2_c(const ctrlsim_model* m, int n, const int* Bk, const int* Ak, const ctrlsim_ctx* ctx, int Tq,
                                           int t, int N, int Tmax, const int* ctx_scn, const int* hist_rtg, void* workspace,

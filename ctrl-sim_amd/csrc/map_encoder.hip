@@ -30,28 +30,54 @@ struct MapPoolWeights {
   const float* mb;      // [256]
 };
 
-// G polylines per workgroup (2 when a polyline has <= 128 points): the thread-per-point phase then uses 200 of the 256 lanes
-// instead of 100 — that phase is 60 % of the kernel's instructions.
+// G polylines per workgroup (2 when a polyline has <= 128 points).  Only VISIBLE points are evaluated: a padded point has softmax
+// weight exp(-inf) = 0 and adds an exact zero to every sum, so the points of the workgroup's polylines are first compacted (order
+// kept) and the thread-per-point phase, the softmax and the pooling loop run over the compact list — bit-identical results, and a
+// polyline with 40 of 100 points costs 40 % of a full one (the thread-per-point phase is 60 % of the kernel's instructions).
 __global__ __launch_bounds__(256) void map_pool_kernel(int NP, int P, int M, int G, int total, const float* __restrict__ road_pts,
                                                        MapPoolWeights w, float* __restrict__ attn_pre,
                                                        unsigned char* __restrict__ src_pad) {
-  __shared__ float pts[MAXNP][3];
-  __shared__ float stat[MAXNP];
-  __shared__ float sc[MAXNP][8];
-  __shared__ float pooled[2][8][DM];
-  __shared__ int any_exist[2];
-  const int bp0 = blockIdx.x * G, tid = threadIdx.x;
+  // the pooled vectors reuse the point / score arrays (16 KB per workgroup instead of 28: twice the resident waves to hide the
+  // scalar-load latency of the weight stream); a barrier separates the last read of `sc` from the first write of `pooled`
+  __shared__ float lds_[2 * 8 * DM];
+  float (*pts)[3] = reinterpret_cast<float (*)[3]>(lds_);                         // visible points, compacted  [MAXNP][3]
+  float* stat = lds_ + MAXNP * 3;                                                 // [MAXNP]
+  float (*sc)[8] = reinterpret_cast<float (*)[8]>(lds_ + MAXNP * 4);              // [MAXNP][8]
+  float (*pooled)[8][DM] = reinterpret_cast<float (*)[8][DM]>(lds_);              // [2][8][DM]
+  static_assert(MAXNP * 12 <= 2 * 8 * DM, "alias layout");
+  __shared__ int any_exist[2], wcnt[4], q0[3];     // q0[g] .. q0[g+1]: compact range of polyline g
+  const int bp0 = blockIdx.x * G, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g_here = min(G, total - bp0);                              // polylines of this block
   const int n_pts = g_here * NP;
   const float* src = road_pts + (size_t)bp0 * NP * 3;
   if (tid < 2) any_exist[tid] = 0;
   __syncthreads();
-  for (int i = tid; i < n_pts * 3; i += blockDim.x) pts[i / 3][i % 3] = src[i];
-  __syncthreads();
-  // ---- phase 1: per point LN statistics and head scores
+  float x = 0.f, y = 0.f, e = 0.f;
   if (tid < n_pts) {
-    const float x = pts[tid][0], y = pts[tid][1], e = pts[tid][2];
+    x = src[tid * 3]; y = src[tid * 3 + 1]; e = src[tid * 3 + 2];
     if (e != 0.f) any_exist[tid >= NP] = 1;
+  }
+  __syncthreads();
+  // key padding: non-existing points; a polyline without any existing point un-masks its point 0 (map_encoder.py:31)
+  const int g_of = tid >= NP, p_in = tid - g_of * NP;
+  const bool vis = tid < n_pts && (e != 0.f || (any_exist[g_of] == 0 && p_in == 0));
+  const unsigned long long bal = __ballot(vis);
+  if (lane == 0) wcnt[wv] = __popcll(bal);
+  __syncthreads();
+  int before = __popcll(bal & ((1ull << lane) - 1ull));
+  for (int k = 0; k < wv; ++k) before += wcnt[k];
+  if (vis) { pts[before][0] = x; pts[before][1] = y; pts[before][2] = e; }
+  if (tid == 0) q0[0] = 0;
+  if (tid == NP && g_here > 1) q0[1] = before;
+  if (tid == 255) {
+    const int all = before + (vis ? 1 : 0);       // lane 255 sees every earlier flag
+    q0[g_here] = all;
+  }
+  __syncthreads();
+  const int n_vis = q0[g_here];
+  // ---- phase 1: per visible point LN statistics and head scores
+  if (tid < n_vis) {
+    const float x = pts[tid][0], y = pts[tid][1], e = pts[tid][2];
     // LayerNorm statistics in closed form (the layer is affine in the point: pack.py); the mean drops out of the centred weights
     const float* G = w.G;
     const float var = x * (G[0] * x + 2.f * (G[1] * y + G[2] * e + G[3])) + y * (G[4] * y + 2.f * (G[5] * e + G[6])) +
@@ -71,43 +97,42 @@ __global__ __launch_bounds__(256) void map_pool_kernel(int NP, int P, int M, int
     for (int h = 0; h < 8; ++h) sc[tid][h] = s8[h];
   }
   __syncthreads();
-  // ---- softmax over the points of a polyline, per head (key padding: non-existing points; all padded -> point 0 visible)
+  // ---- softmax over the visible points of a polyline, per head
   if (tid < 8 * g_here) {
-    const int g = tid >> 3, hd = tid & 7, p0 = g * NP;
-    const bool none = any_exist[g] == 0;
+    const int g = tid >> 3, hd = tid & 7, a = q0[g], b = q0[g + 1];
     float mx = -__builtin_inff();
-    for (int p = 0; p < NP; ++p) {
-      const bool vis = pts[p0 + p][2] != 0.f || (none && p == 0);
-      if (vis) mx = fmaxf(mx, sc[p0 + p][hd]);
-    }
+    for (int p = a; p < b; ++p) mx = fmaxf(mx, sc[p][hd]);
     float z = 0.f;
-    for (int p = 0; p < NP; ++p) {
-      const bool vis = pts[p0 + p][2] != 0.f || (none && p == 0);
-      const float ev = vis ? expf(sc[p0 + p][hd] - mx) : 0.f;
-      sc[p0 + p][hd] = ev;
+    for (int p = a; p < b; ++p) {
+      const float ev = expf(sc[p][hd] - mx);
+      sc[p][hd] = ev;
       z += ev;
     }
     const float inv = 1.0f / z;
-    for (int p = 0; p < NP; ++p) sc[p0 + p][hd] *= inv;
+    for (int p = a; p < b; ++p) sc[p][hd] *= inv;
   }
   __syncthreads();
   // ---- phase 2: thread = channel; pooled[g][h][c] = sum_pt a[pt,h] * h1[pt,c]
   {
     const int c = tid;
     const float w0 = w.Wc[c * 4], w1 = w.Wc[c * 4 + 1], w2 = w.Wc[c * 4 + 2], bb = w.Wc[c * 4 + 3], be = w.ln_b[c];
-    for (int g = 0; g < g_here; ++g) {
-      float acc[8];
+    float acc[2][8];
+    for (int g = 0; g < 2; ++g) {
 #pragma unroll
-      for (int h = 0; h < 8; ++h) acc[h] = 0.f;
-      for (int p = g * NP; p < (g + 1) * NP; ++p) {
-        const float d = fmaf(w2, pts[p][2], fmaf(w1, pts[p][1], fmaf(w0, pts[p][0], bb)));
-        const float hv = fmaxf(fmaf(d, stat[p], be), 0.f);
+      for (int h = 0; h < 8; ++h) acc[g][h] = 0.f;
+      if (g < g_here)
+        for (int p = q0[g]; p < q0[g + 1]; ++p) {
+          const float d = fmaf(w2, pts[p][2], fmaf(w1, pts[p][1], fmaf(w0, pts[p][0], bb)));
+          const float hv = fmaxf(fmaf(d, stat[p], be), 0.f);
 #pragma unroll
-        for (int h = 0; h < 8; ++h) acc[h] = fmaf(sc[p][h], hv, acc[h]);
-      }
-#pragma unroll
-      for (int h = 0; h < 8; ++h) pooled[g][h][c] = acc[h];
+          for (int h = 0; h < 8; ++h) acc[g][h] = fmaf(sc[p][h], hv, acc[g][h]);
+        }
     }
+    __syncthreads();                       // every read of pts / stat / sc is done: `pooled` may overwrite them
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int h = 0; h < 8; ++h) pooled[g][h][c] = acc[g][h];
   }
   __syncthreads();
   // ---- phase 3: thread = output channel j of head j>>5

@@ -159,6 +159,9 @@ int ctrlsim_dt_forward_pass1(const ctrlsim_model* m, int B, int Tq, const ctrlsi
  * these models and this call refuses the CtRL-Sim model. */
 int ctrlsim_dt_forward_actions(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* ctx, void* workspace,
                                float* act_logits, hipStream_t stream);
+/* Component-level entry (tests, micro-benchmarks): MapEncoder's point MLP + seed-attention pooling (modules/map_encoder.py:28-46,
+ * before out_proj) of B*P polylines road_pts [B,P,NP,3] -> attn_pre [B*P,256]; pad [B,P] <- 1 for polylines without any point. */
+int ctrlsim_map_pool(const ctrlsim_model* m, int B, const float* road_pts, float* attn_pre, uint8_t* pad, hipStream_t stream);
 /* The reference's full return contract of CtRLSim.forward (models/ctrl_sim.py:41-45; decoder.py:52-77): teacher-forced, every
  * head on every token of the Tq window steps.  action_preds [B,Tq,A,V], rtg_preds [B,Tq,A,R*C], state_preds [B,Tq,A,2T] in
  * token-row order (the reference returns the [B,A,T,.] permutation of these).  rtg_preds / state_preds are nullable and must be
