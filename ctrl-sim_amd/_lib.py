@@ -65,6 +65,7 @@ SIGNATURES = {
     "ctrlsim_ctx_index_classes": (I, [I, I, I, I, P, P, P, P, I, P, P, P, P, P, P, P, P, P, P]),
     "ctrlsim_ctx_index": (I, [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "ctrlsim_build_context": (I, [I] * 12 + [P] * 12 + [C.POINTER(Ctx), P]),
+    "ctrlsim_build_context_c": (I, [I, P, P, C.POINTER(Ctx)] + [I] * 10 + [P] * 12 + [P]),
     "ctrlsim_model_create": (I, [C.POINTER(Dims), P, I, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(P)]),
     "ctrlsim_model_destroy": (None, [P]),
     "ctrlsim_forward_workspace_bytes": (L, [C.POINTER(Dims), I, I]),

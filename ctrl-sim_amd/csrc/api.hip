@@ -30,6 +30,9 @@ int launch_ctx_index(int, int, int, const int*, const int*, const unsigned long 
 int launch_groups_changed(int, int, const int*, const int*, const unsigned long long*, const int*, const int*,
                           const unsigned long long*, int*, hipStream_t);
 struct CtxOut { float *st12, *exist, *goal5; int *act_tok, *rtg_bin, *tstep, *slot_gid; float *road_pts, *road_types; };
+int launch_build_context_classes(int, const int*, const int*, const CtxOut*, int, int, int, int, int, int, int, int, int, int, const int*,
+                                 const int*, const int*, const unsigned long long*, const float*, const int*, const int*,
+                                 const double*, const float*, const float*, const float*, const int*, hipStream_t);
 int launch_build_context(int, int, int, int, int, int, int, int, int, int, int, int, const int*, const int*, const int*,
                          const unsigned long long*, const float*, const int*, const int*, const double*, const float*,
                          const float*, const float*, const int*, CtxOut, hipStream_t);
@@ -207,6 +210,20 @@ int ctrlsim_build_context(int B, int N, int A, int T, int t, int Tq, int tt_firs
   return launch_build_context(B, N, A, T, t, Tq, tt_first, Tmax1, Tmax, P_all, P, NP, ctx_scn, ctx_grp, grp_focal,
                               (const unsigned long long*)grp_ids, hist_states, hist_tok, hist_rtg, goals, types, roads,
                               road_types, zero4, o, st);
+}
+int ctrlsim_build_context_c(int n, const int* B, const int* A, const ctrlsim_ctx* out, int N, int T, int t, int Tq, int tt_first,
+                            int Tmax1, int Tmax, int P_all, int P, int NP, const int* ctx_scn, const int* ctx_grp,
+                            const int* grp_focal, const uint64_t* grp_ids, const float* hist_states, const int* hist_tok,
+                            const int* hist_rtg, const double* goals, const float* types, const float* roads,
+                            const float* road_types, const int* zero4, hipStream_t st) {
+  if (!out || !zero4 || !B || !A || n < 1 || n > 8) return CTRLSIM_EINVAL;
+  CtxOut o[8];
+  for (int k = 0; k < n; ++k)
+    o[k] = CtxOut{out[k].st12, out[k].exist, out[k].goal5, out[k].act_tok, out[k].rtg_bin, out[k].tstep, out[k].slot_gid,
+                  out[k].road_pts, out[k].road_types};
+  return launch_build_context_classes(n, B, A, o, N, T, t, Tq, tt_first, Tmax1, Tmax, P_all, P, NP, ctx_scn, ctx_grp, grp_focal,
+                                      (const unsigned long long*)grp_ids, hist_states, hist_tok, hist_rtg, goals, types, roads,
+                                      road_types, zero4, st);
 }
 int ctrlsim_sample_rtg(const float* rtg_logits, int A, int R, const int* own_ctx, const int* own_slot, const uint8_t* tilted,
                        const double* tilt3, const double* tilt_scn, const float* noise, uint64_t seed, const int64_t* scenario_id,

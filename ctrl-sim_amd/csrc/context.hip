@@ -291,22 +291,31 @@ struct CtxOut {
   float* road_types;      // [B, P, 8]
 };
 
+// Up to 8 classes of contexts (different slot counts A, separate output arrays) in ONE launch: class k holds the contexts
+// [c0[k], c0[k+1]) of the batch's context list.  One launch per class left most of the chip idle — a class of a model batch is
+// 50-150 contexts = workgroups, and a workgroup's float64 chain takes ~150 us whatever the grid.
+struct CtxBatch { int n; int c0[9]; int A[8]; CtxOut o[8]; };
+
 // One block per context.  Agent part: threads over (tt, slot).  Road part: two sweeps over P_all x NP points.
 // Window rows [tt_first, Tq) are emitted (Tn = Tq - tt_first rows per context): the cached incremental forward only needs
 // the last one or two timesteps; tt_first = 0 gives the whole window.
 __global__ __launch_bounds__(256) void build_context_kernel(
-    int N, int A, int T, int t, int Tq, int tt_first, int Tmax1, int Tmax, int P_all, int P, int NP,
+    int N, int T, int t, int Tq, int tt_first, int Tmax1, int Tmax, int P_all, int P, int NP,
     const int* __restrict__ ctx_scn, const int* __restrict__ ctx_grp, const int* __restrict__ grp_focal,
     const unsigned long long* __restrict__ grp_ids, const float* __restrict__ hist_states,
     const int* __restrict__ hist_tok, const int* __restrict__ hist_rtg, const double* __restrict__ goals,  // [S,N,5] f64
     const float* __restrict__ types,                                                                     // [S,N,5]
     const float* __restrict__ roads, const float* __restrict__ rtypes,                                    // [S,P_all,NP,3], [S,P_all,8]
-    int zero_tok, int zr0, int zr1, int zr2, CtxOut o) {
+    int zero_tok, int zr0, int zr1, int zr2, CtxBatch cb) {
   extern __shared__ double far_[];                 // [P_all] distance key, then int rank/sel arrays behind it
   __shared__ int slot_of[64];
   __shared__ int gid_of[64];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int s = ctx_scn[b], g = ctx_grp[b];
+  const int tid = threadIdx.x;
+  int k_ = 0;
+  while (k_ + 1 < cb.n && (int)blockIdx.x >= cb.c0[k_ + 1]) ++k_;      // wave-uniform: the class of this context
+  const int A = cb.A[k_], b = blockIdx.x - cb.c0[k_];                  // b: index within the class's output arrays
+  const CtxOut o = cb.o[k_];
+  const int s = ctx_scn[blockIdx.x], g = ctx_grp[blockIdx.x];
   const int focal = grp_focal[(size_t)s * N + g];
   const unsigned long long ids = grp_ids[(size_t)s * N + g];
   const int n_ids = __popcll(ids);
@@ -465,23 +474,41 @@ int launch_ctx_index(int s0, int s1, int N, const int* n_groups, const int* grp_
   return ctrlsim_launch_status();
 }
 
+int launch_build_context_classes(int n, const int* Bk, const int* Ak, const CtxOut* ok, int N, int T, int t, int Tq, int tt_first,
+                                 int Tmax1, int Tmax, int P_all, int P, int NP, const int* ctx_scn, const int* ctx_grp,
+                                 const int* grp_focal, const unsigned long long* grp_ids, const float* hist_states,
+                                 const int* hist_tok, const int* hist_rtg, const double* goals, const float* types,
+                                 const float* roads, const float* rtypes, const int* zero4, hipStream_t st) {
+  if (n < 1 || n > 8 || N > 64 || Tq < 1 || tt_first < 0 || tt_first >= Tq) return CTRLSIM_EINVAL;
+  CtxBatch cb;
+  cb.n = 0; cb.c0[0] = 0;
+  double bytes = 0.0;
+  for (int k = 0; k < n; ++k) {
+    if (Bk[k] < 0 || Ak[k] < 1 || Ak[k] > 64) return CTRLSIM_EINVAL;
+    if (Bk[k] == 0) continue;
+    cb.A[cb.n] = Ak[k]; cb.o[cb.n] = ok[k];
+    cb.c0[cb.n + 1] = cb.c0[cb.n] + Bk[k];
+    ++cb.n;
+    // per context: the scenario's road points in once (P_all x NP x 12 B; the selection sweep re-reads them from cache), the P
+    // selected polylines + types out, the window rows of A agents in (8 floats + token + 3 bins) and out (12 floats + 5 ints)
+    bytes += (double)Bk[k] * (12.0 * P_all * NP + 12.0 * P * NP + 32.0 * P + (double)(Tq - tt_first) * Ak[k] * (48.0 + 68.0));
+  }
+  if (cb.n == 0) return CTRLSIM_OK;
+  const size_t shm = (size_t)P_all * sizeof(double) + (size_t)(P > 0 ? P : 1) * sizeof(int);
+  prof_before(PROF_CTX, st);
+  hipLaunchKernelGGL(build_context_kernel, dim3(cb.c0[cb.n]), dim3(256), shm, st, N, T, t, Tq, tt_first, Tmax1, Tmax, P_all, P, NP,
+                     ctx_scn, ctx_grp, grp_focal, grp_ids, hist_states, hist_tok, hist_rtg, goals, types, roads, rtypes, zero4[0],
+                     zero4[1], zero4[2], zero4[3], cb);
+  prof_after(PROF_CTX, 0.0, st, bytes);
+  return ctrlsim_launch_status();
+}
 int launch_build_context(int B, int N, int A, int T, int t, int Tq, int tt_first, int Tmax1, int Tmax, int P_all, int P, int NP,
                          const int* ctx_scn, const int* ctx_grp, const int* grp_focal,
                          const unsigned long long* grp_ids, const float* hist_states, const int* hist_tok,
                          const int* hist_rtg, const double* goals, const float* types, const float* roads,
                          const float* rtypes, const int* zero4, CtxOut o, hipStream_t st) {
-  if (B <= 0) return CTRLSIM_OK;
-  if (N > 64 || A > 64 || Tq < 1 || tt_first < 0 || tt_first >= Tq) return CTRLSIM_EINVAL;
-  const size_t shm = (size_t)P_all * sizeof(double) + (size_t)(P > 0 ? P : 1) * sizeof(int);
-  prof_before(PROF_CTX, st);
-  hipLaunchKernelGGL(build_context_kernel, dim3(B), dim3(256), shm, st, N, A, T, t, Tq, tt_first, Tmax1, Tmax, P_all, P, NP, ctx_scn,
-                     ctx_grp, grp_focal, grp_ids, hist_states, hist_tok, hist_rtg, goals, types, roads, rtypes, zero4[0],
-                     zero4[1], zero4[2], zero4[3], o);
-  // per context: the scenario's road points in once (P_all x NP x 12 B; the selection sweep re-reads them from cache), the P
-  // selected polylines + types out, the window rows of A agents in (8 floats + token + 3 bins) and out (12 floats + 5 ints)
-  prof_after(PROF_CTX, 0.0, st, (double)B * (12.0 * P_all * NP + 12.0 * P * NP + 32.0 * P +
-                                             (double)(Tq - tt_first) * A * (48.0 + 68.0)));
-  return ctrlsim_launch_status();
+  return launch_build_context_classes(1, &B, &A, &o, N, T, t, Tq, tt_first, Tmax1, Tmax, P_all, P, NP, ctx_scn, ctx_grp, grp_focal,
+                                      grp_ids, hist_states, hist_tok, hist_rtg, goals, types, roads, rtypes, zero4, st);
 }
 
 int launch_groups_changed(int S, int N, const int* n_groups, const int* grp_focal, const unsigned long long* grp_ids,

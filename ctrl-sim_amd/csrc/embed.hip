@@ -39,6 +39,63 @@ struct EmbedTables {
 // Compact contexts (forward.hip): the context tensors hold A slots per step, of which the first Areg are "regular" and — when
 // Areg < A — the last one is the representative of the padded slots; a context's L token rows are the regular ones,
 // (tt*Areg + a)*3 + k, followed from row Lreg on by the representative's, Lreg + 3*tt + k.  Areg == A: the plain layout.
+// Classes of contexts in one launch: rows [row0[k], row0[k+1]) of the flat (context, step, slot) list belong to class k with
+// A[k] slots (Areg[k] regular), L[k] / Lreg[k] token rows and M[k] scene rows per context; its token rows start at X row
+// xrow[k], its scene rows at srow[k], its (context, slot) goal rows at grow[k], its (context, step) timestep entries at trow[k].
+// The per-(context, step, slot) inputs (S2, exist, act_tok, rtg_bin) are indexed by the flat row.
+struct AsmClasses { int n; int row0[9]; int A[8], Areg[8], L[8], Lreg[8], M[8]; long xrow[8], srow[8], grow[8], trow[8]; };
+
+__global__ __launch_bounds__(256) void assemble_tokens_classes_kernel(
+    AsmClasses ac, int Tq, const float* __restrict__ S2, const float* __restrict__ Gp, const float* __restrict__ exist,
+    const int* __restrict__ act_tok, const int* __restrict__ rtg_bin, const int* __restrict__ tstep, EmbedTables tb,
+    float* __restrict__ X, float* __restrict__ src, int P, unsigned char* __restrict__ src_pad) {
+  const int grow_ = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (grow_ >= ac.row0[ac.n]) return;
+  int k = 0;
+  while (k + 1 < ac.n && grow_ >= ac.row0[k + 1]) ++k;
+  k = __builtin_amdgcn_readfirstlane(k);
+  const int A = ac.A[k], Areg = ac.Areg[k], L = ac.L[k], Lreg = ac.Lreg[k], M = ac.M[k];
+  const int row = grow_ - ac.row0[k];                       // (b, tt, a) within the class
+  const int lane = threadIdx.x & 63, c4 = lane * 4;
+  const int a = row % A, bt = row / A, tt = bt % Tq, b = bt / Tq;
+  const float ex = exist[grow_];
+  const int ts = tstep[ac.trow[k] + (size_t)b * Tq + tt];
+  const f32x4 g = *reinterpret_cast<const f32x4*>(tb.ln_g + c4);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(tb.ln_b + c4);
+  const f32x4 pos = *reinterpret_cast<const f32x4*>(tb.tstep + (size_t)ts * DM + c4) +
+                    *reinterpret_cast<const f32x4*>(tb.agent + (size_t)a * DM + c4);
+  float* xo = X + (ac.xrow[k] + (size_t)b * L + (a < Areg ? ((size_t)tt * Areg + a) * 3 : (size_t)Lreg + 3 * tt)) * DM + c4;
+  f32x4 v = (*reinterpret_cast<const f32x4*>(S2 + (size_t)grow_ * DM + c4) +
+             *reinterpret_cast<const f32x4*>(Gp + (ac.grow[k] + (size_t)b * A + a) * DM + c4) + pos) * ex;
+  if (tt == 0) {
+    const size_t s0 = ac.srow[k] + (size_t)b * M;
+    *reinterpret_cast<f32x4*>(src + (s0 + P + a) * DM + c4) = v;
+    if (lane == 0) src_pad[s0 + P + a] = ex != 0.f ? 0 : 1;
+    if (a == A - 1) {
+      for (int e = P + A; e < M; ++e) {
+        *reinterpret_cast<f32x4*>(src + (s0 + e) * DM + c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (lane == 0) src_pad[s0 + e] = 1;
+      }
+    }
+  }
+  *reinterpret_cast<f32x4*>(xo) = ln256(v, g, be);
+  const int* rb = rtg_bin + (size_t)grow_ * 3;
+  if (tb.rtg_linear) {
+    v = (*reinterpret_cast<const f32x4*>(tb.rtg_g + c4) * __int_as_float(rb[0]) +
+         *reinterpret_cast<const f32x4*>(tb.rtg_v + c4) * __int_as_float(rb[1]) +
+         *reinterpret_cast<const f32x4*>(tb.rtg_r + c4) * __int_as_float(rb[2]) +
+         *reinterpret_cast<const f32x4*>(tb.rtg_bias + c4) + pos) * ex;
+  } else {
+    v = (*reinterpret_cast<const f32x4*>(tb.rtg_g + (size_t)rb[0] * DM + c4) +
+         *reinterpret_cast<const f32x4*>(tb.rtg_v + (size_t)rb[1] * DM + c4) +
+         *reinterpret_cast<const f32x4*>(tb.rtg_r + (size_t)rb[2] * DM + c4) +
+         *reinterpret_cast<const f32x4*>(tb.rtg_bias + c4) + pos) * ex;
+  }
+  *reinterpret_cast<f32x4*>(xo + DM) = ln256(v, g, be);
+  v = (*reinterpret_cast<const f32x4*>(tb.act + (size_t)act_tok[grow_] * DM + c4) + pos) * ex;
+  *reinterpret_cast<f32x4*>(xo + 2 * DM) = ln256(v, g, be);
+}
+
 __global__ __launch_bounds__(256) void assemble_tokens_kernel(
     int rows, int Tq, int A, int Areg, int L, int Lreg,
     const float* __restrict__ S2,   // [B*Tq*A, 256] state content (without goal part)
@@ -184,6 +241,32 @@ int launch_assemble_tokens(int B, int Tq, int A, int Areg, const float* S2, cons
                      rtg_bin, tstep, tb, X, src, M, P, src_pad);
   // per (context, step, agent): the state row in (1 KB), three token rows out (3 KB), 24 B of ids / existence; embedding
   // tables stay cache-resident
+  prof_after(PROF_EMBED, 0.0, st, (double)rows * (4.0 * DM * 4.0 + 24.0));
+  return ctrlsim_launch_status();
+}
+
+// assemble_tokens for n classes whose context tensors (and S2 / Gp / X / src rows) lie back to back: one launch
+int launch_assemble_tokens_classes(int n, const int* B, const int* A, const int* Areg, const int* M, const long* xrow,
+                                   const long* srow, const long* grow, int Tq, const float* S2,
+                                   const float* Gp, const float* exist, const int* act_tok, const int* rtg_bin, const int* tstep,
+                                   EmbedTables tb, float* X, float* src, int P, unsigned char* src_pad, hipStream_t st) {
+  if (n < 1 || n > 8) return CTRLSIM_EINVAL;
+  AsmClasses ac;
+  ac.n = n; ac.row0[0] = 0;
+  long tr = 0;
+  for (int k = 0; k < n; ++k) {
+    if (Areg[k] < 1 || Areg[k] > A[k] || A[k] - Areg[k] > 1) return CTRLSIM_EINVAL;
+    ac.A[k] = A[k]; ac.Areg[k] = Areg[k]; ac.M[k] = M[k];
+    ac.Lreg[k] = Tq * Areg[k] * 3; ac.L[k] = ac.Lreg[k] + (A[k] - Areg[k]) * 3 * Tq;
+    ac.xrow[k] = xrow[k]; ac.srow[k] = srow[k]; ac.grow[k] = grow[k]; ac.trow[k] = tr;
+    ac.row0[k + 1] = ac.row0[k] + B[k] * Tq * A[k];
+    tr += (long)B[k] * Tq;
+  }
+  const int rows = ac.row0[n];
+  if (rows <= 0) return CTRLSIM_OK;
+  prof_before(PROF_EMBED, st);
+  hipLaunchKernelGGL(assemble_tokens_classes_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, ac, Tq, S2, Gp, exist, act_tok, rtg_bin,
+                     tstep, tb, X, src, P, src_pad);
   prof_after(PROF_EMBED, 0.0, st, (double)rows * (4.0 * DM * 4.0 + 24.0));
   return ctrlsim_launch_status();
 }

@@ -57,6 +57,11 @@ int launch_assemble_rtg_rows(int, int, int, int, int, int, int, int, const int*,
                              const int*, EmbedTables, const int*, float*, hipStream_t);
 struct MapPoolWeights { const float *Wc, *G, *ln_b, *U, *cb, *Mt, *mb; };
 int launch_map_pool(int, int, int, int, const float*, MapPoolWeights, float*, unsigned char*, hipStream_t);
+int launch_map_pool_classes(int, const int*, const int*, const long*, int, int, const float*, MapPoolWeights, float*, unsigned char*,
+                            hipStream_t);
+int launch_assemble_tokens_classes(int, const int*, const int*, const int*, const int*, const long*, const long*, const long*, int,
+                                   const float*, const float*, const float*, const int*, const int*, const int*, EmbedTables, float*,
+                                   float*, int, unsigned char*, hipStream_t);
 
 namespace {
 
@@ -228,6 +233,7 @@ struct Cls {
   const ctrlsim_ctx* ctx;
 };
 struct Batch {
+  bool contig = false;                    // the classes' context tensors lie back to back (ctx_contiguous): merged launches
   int n, Btot;
   Cls c[8];
   long rL, rS, rA, rM, rP, rQ, rN, tiles_dec, tiles_mem, isum, ksum;
@@ -514,16 +520,41 @@ int cross_and_ffn(const ctrlsim_model* m, const Batch& bt, const DecLayer& Ld, i
   CHK(ffn_block(Ld.lin1, Ld.lin2, Ld.n3, Ld.fp, x, ffn, tmp, (int)rows, d.F, st));
   return 0;
 }
+// The engine carves the context tensors of a batch's classes out of shared buffers back to back (CtxBuffers.class_structs);
+// then the per-(context, step, slot) / per-polyline kernels can run ONCE over all classes instead of once per class — a class of
+// a model batch is too small a grid to fill the chip.  Tn = window rows held by the context tensors.
+bool ctx_contiguous(const ctrlsim_dims& d, const Batch& bt, int Tn) {
+  for (int k = 0; k + 1 < bt.n; ++k) {
+    const Cls& c = bt.c[k];
+    const ctrlsim_ctx* a = c.ctx; const ctrlsim_ctx* b = bt.c[k + 1].ctx;
+    const long rows = (long)c.B * Tn * c.sh.A;
+    if (b->st12 != a->st12 + rows * 12 || b->exist != a->exist + rows || b->act_tok != a->act_tok + rows ||
+        b->rtg_bin != a->rtg_bin + rows * 3 || b->tstep != a->tstep + (long)c.B * Tn || b->goal5 != a->goal5 + (long)c.B * c.sh.A * 5 ||
+        b->road_pts != a->road_pts + (long)c.B * d.P * d.NP * 3 || b->road_types != a->road_types + (long)c.B * d.P * 8)
+      return false;
+  }
+  return true;
+}
+
 // map encoder + scene encoder + per-layer memory K/V (everything that only depends on the frame of the context)
 int scene_side(const ctrlsim_model* m, const Batch& bt, const Ws& w, float* dbg_seg_emb, hipStream_t st) {
   const ctrlsim_dims& d = m->d;
   const int P = d.P, rM = (int)bt.rM, rP = (int)bt.rP;
   // ---- map encoder (map_encoder.py:34-53): rows of `src` 0..P-1 per context
-  for (int k = 0; k < bt.n; ++k) {
-    const Cls& c = bt.c[k];
-    CHK(launch_map_pool(c.B, P, d.NP, c.M, c.ctx->road_pts, m->mp, w.attn_pre + c.rP * DM, w.src_pad + c.rM, st));
-    CHK(launch_in_mlp(c.ctx->road_types, 8, 8, m->road_type.l0.w, m->road_type.l0.b, m->road_type.ln.g, m->road_type.ln.b,
-                      w.tfh + c.rP * DM, DM, c.B * P, st));
+  if (bt.contig) {
+    int Bk[8], Mk[8];
+    long pad0[8];
+    for (int k = 0; k < bt.n; ++k) { Bk[k] = bt.c[k].B; Mk[k] = bt.c[k].M; pad0[k] = bt.c[k].rM; }
+    CHK(launch_map_pool_classes(bt.n, Bk, Mk, pad0, P, d.NP, bt.c[0].ctx->road_pts, m->mp, w.attn_pre, w.src_pad, st));
+    CHK(launch_in_mlp(bt.c[0].ctx->road_types, 8, 8, m->road_type.l0.w, m->road_type.l0.b, m->road_type.ln.g, m->road_type.ln.b,
+                      w.tfh, DM, rP, st));
+  } else {
+    for (int k = 0; k < bt.n; ++k) {
+      const Cls& c = bt.c[k];
+      CHK(launch_map_pool(c.B, P, d.NP, c.M, c.ctx->road_pts, m->mp, w.attn_pre + c.rP * DM, w.src_pad + c.rM, st));
+      CHK(launch_in_mlp(c.ctx->road_types, 8, 8, m->road_type.l0.w, m->road_type.l0.b, m->road_type.ln.g, m->road_type.ln.b,
+                        w.tfh + c.rP * DM, DM, c.B * P, st));
+    }
   }
   CHK(gemm_ln(m->map_out, m->map_n1, w.attn_pre, DM, nullptr, 0, w.m1, DM, w.m1, rP, DM, 0, st));            // emb
   CHK(gemm_ln(m->map_feats.l0, m->map_feats.ln, w.m1, DM, nullptr, 0, w.m2, DM, w.m2, rP, DM, 1, st));
@@ -568,6 +599,13 @@ int launch_fill_index(const Batch& bt, const Ws& w, int P, int ti, int Tq, int q
 }
 // first embedding layers: in_mlp per class (the context tensors of the classes are separate arrays), then the folded Linear once
 int embed_inputs(const ctrlsim_model* m, const Batch& bt, const Ws& w, int Tn, bool goals, hipStream_t st) {
+  if (bt.contig) {
+    CHK(launch_in_mlp(bt.c[0].ctx->st12, 12, 12, m->embed_state.l0.w, m->embed_state.l0.b, m->embed_state.ln.g, m->embed_state.ln.b,
+                      w.hS, DM, (int)bt.rS, st));
+    if (goals)
+      CHK(launch_in_mlp(bt.c[0].ctx->goal5, 5, 5, m->embed_goal.l0.w, m->embed_goal.l0.b, m->embed_goal.ln.g, m->embed_goal.ln.b,
+                        w.hG, DM, (int)bt.rA, st));
+  } else
   for (int k = 0; k < bt.n; ++k) {
     const Cls& c = bt.c[k];
     CHK(launch_in_mlp(c.ctx->st12, 12, 12, m->embed_state.l0.w, m->embed_state.l0.b, m->embed_state.ln.g, m->embed_state.ln.b,
@@ -612,15 +650,28 @@ int forward_full(const ctrlsim_model* m, int n, const int* Bk, const int* Ak, co
   Batch bt;
   CHK(make_batch(d, n, Bk, Ak, ctx, Tq, Tq, 4, bt));
   if (!classes_ok(d, bt)) return CTRLSIM_EINVAL;
+  bt.contig = bt.n > 1 && ctx_contiguous(d, bt, Tq);
   const Ws w = carve(d, bt, static_cast<char*>(workspace));
   const int P = d.P, ti = Tq - 1, rL = (int)bt.rL, rQ = (int)bt.rQ;
   CHK(launch_fill_index(bt, w, P, ti, Tq, qoff, st));
   // ---- token embeddings (encoder.py:95-153)
   CHK(embed_inputs(m, bt, w, Tq, true, st));
-  for (int k = 0; k < bt.n; ++k) {
-    const Cls& c = bt.c[k];
-    CHK(launch_assemble_tokens(c.B, Tq, c.sh.A, c.sh.Areg, w.S2 + c.rS * DM, w.Gp + c.rA * DM, c.ctx->exist, c.ctx->act_tok,
-                               c.ctx->rtg_bin, c.ctx->tstep, m->tb, w.X + c.rL * DM, w.src + c.rM * DM, c.M, P, w.src_pad + c.rM, st));
+  if (bt.contig) {
+    int Bk[8], Ak[8], Ar[8], Mk[8];
+    long xrow[8], srow[8], grow[8];
+    for (int k = 0; k < bt.n; ++k) {
+      const Cls& c = bt.c[k];
+      Bk[k] = c.B; Ak[k] = c.sh.A; Ar[k] = c.sh.Areg; Mk[k] = c.M; xrow[k] = c.rL; srow[k] = c.rM; grow[k] = c.rA;
+    }
+    CHK(launch_assemble_tokens_classes(bt.n, Bk, Ak, Ar, Mk, xrow, srow, grow, Tq, w.S2, w.Gp, bt.c[0].ctx->exist,
+                                       bt.c[0].ctx->act_tok, bt.c[0].ctx->rtg_bin, bt.c[0].ctx->tstep, m->tb, w.X, w.src, P,
+                                       w.src_pad, st));
+  } else {
+    for (int k = 0; k < bt.n; ++k) {
+      const Cls& c = bt.c[k];
+      CHK(launch_assemble_tokens(c.B, Tq, c.sh.A, c.sh.Areg, w.S2 + c.rS * DM, w.Gp + c.rA * DM, c.ctx->exist, c.ctx->act_tok,
+                                 c.ctx->rtg_bin, c.ctx->tstep, m->tb, w.X + c.rL * DM, w.src + c.rM * DM, c.M, P, w.src_pad + c.rM, st));
+    }
   }
   CHK(scene_side(m, bt, w, dbg_seg_emb, st));
   // ---- decoder (decoder.py:52): layers 0..ND-2 on all tokens

@@ -34,7 +34,12 @@ struct MapPoolWeights {
 // weight exp(-inf) = 0 and adds an exact zero to every sum, so the points of the workgroup's polylines are first compacted (order
 // kept) and the thread-per-point phase, the softmax and the pooling loop run over the compact list — bit-identical results, and a
 // polyline with 40 of 100 points costs 40 % of a full one (the thread-per-point phase is 60 % of the kernel's instructions).
-__global__ __launch_bounds__(256) void map_pool_kernel(int NP, int P, int M, int G, int total, const float* __restrict__ road_pts,
+// Classes of contexts in one launch (forward.hip: a model batch): the polylines of all classes are one flat list; only the
+// padding byte goes to a class-dependent place (scene rows per context M differ with the slot count): polylines
+// [bp0[k], bp0[k+1]) belong to class k, whose padding rows start at pad0[k] with M[k] rows per context.
+struct MapClasses { int n; int bp0[9]; int M[8]; long pad0[8]; };
+
+__global__ __launch_bounds__(256) void map_pool_kernel(int NP, int P, MapClasses mc, int G, int total, const float* __restrict__ road_pts,
                                                        MapPoolWeights w, float* __restrict__ attn_pre,
                                                        unsigned char* __restrict__ src_pad) {
   // the pooled vectors reuse the point / score arrays (16 KB per workgroup instead of 28: twice the resident waves to hide the
@@ -145,18 +150,39 @@ __global__ __launch_bounds__(256) void map_pool_kernel(int NP, int P, int M, int
     }
   }
   if (tid < g_here) {
-    const int bp = bp0 + tid, b = bp / P, p = bp - b * P;
-    src_pad[(size_t)b * M + p] = any_exist[tid] ? 0 : 1;
+    const int bp = bp0 + tid;
+    int k = 0;
+    while (k + 1 < mc.n && bp >= mc.bp0[k + 1]) ++k;
+    const int rel = bp - mc.bp0[k], b = rel / P, p = rel - b * P;
+    src_pad[mc.pad0[k] + (size_t)b * mc.M[k] + p] = any_exist[tid] ? 0 : 1;
   }
 }
 
+// n classes: B[k] contexts, M[k] scene rows per context, padding rows of class k from src_pad + pad0[k]; road_pts / attn_pre
+// hold the classes back to back
+int launch_map_pool_classes(int n, const int* B, const int* M, const long* pad0, int P, int NP, const float* road_pts,
+                            MapPoolWeights w, float* attn_pre, unsigned char* src_pad, hipStream_t st) {
+  if (n < 1 || n > 8 || NP < 1 || NP > MAXNP) return CTRLSIM_EINVAL;
+  MapClasses mc;
+  mc.n = n; mc.bp0[0] = 0;
+  for (int k = 0; k < n; ++k) { mc.bp0[k + 1] = mc.bp0[k] + B[k] * P; mc.M[k] = M[k]; mc.pad0[k] = pad0[k]; }
+  const int G = NP <= 128 ? 2 : 1, total = mc.bp0[n];
+  if (total <= 0) return CTRLSIM_OK;
+  prof_before(PROF_MAP, st);
+  hipLaunchKernelGGL(map_pool_kernel, dim3((total + G - 1) / G), dim3(256), 0, st, NP, P, mc, G, total, road_pts, w, attn_pre,
+                     src_pad);
+  prof_after(PROF_MAP, 1.5e6 * (double)total, st, (double)total * (12.0 * NP + 4.0 * DM + 1.0));
+  return ctrlsim_launch_status();
+}
 int launch_map_pool(int B, int P, int NP, int M, const float* road_pts, MapPoolWeights w, float* attn_pre,
                     unsigned char* src_pad, hipStream_t st) {
   if (B * P <= 0) return CTRLSIM_OK;
   if (NP < 1 || NP > MAXNP) return CTRLSIM_EINVAL;
   const int G = NP <= 128 ? 2 : 1, total = B * P;
+  MapClasses mc;
+  mc.n = 1; mc.bp0[0] = 0; mc.bp0[1] = total; mc.M[0] = M; mc.pad0[0] = 0;
   prof_before(PROF_MAP, st);
-  hipLaunchKernelGGL(map_pool_kernel, dim3((total + G - 1) / G), dim3(256), 0, st, NP, P, M, G, total, road_pts, w, attn_pre,
+  hipLaunchKernelGGL(map_pool_kernel, dim3((total + G - 1) / G), dim3(256), 0, st, NP, P, mc, G, total, road_pts, w, attn_pre,
                      src_pad);
   // per polyline: NP points x 12 B in, one 256-float row + a padding byte out; ~1.5 MFLOP of folded point MLP + seed attention
   prof_after(PROF_MAP, 1.5e6 * (double)total, st, (double)total * (12.0 * NP + 4.0 * DM + 1.0));

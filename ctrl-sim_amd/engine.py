@@ -449,12 +449,16 @@ class RolloutEngine:
     def _build_contexts(self, L, plan, t, Tq, tt_first, st):
         lib, p, d = self.lib, _lib.ptr, self.dims
         Tmax = self.steps
-        for (B, A, c0, cs) in plan:
-            _lib.check(lib.ctrlsim_build_context(B, self.N, A, d.T, t, Tq, tt_first, Tmax + 1, Tmax, self.P_all, d.P, d.NP,
-                                                 p(L.ctx_scn[c0:]), p(L.ctx_grp[c0:]), p(self.grp_focal), p(self.grp_ids),
-                                                 p(self.hist_states), p(self.hist_tok), p(self.hist_rtg), p(self.goals),
-                                                 p(self.types), p(self.roads), p(self.rtypes), self._zero4, C.byref(cs), st),
-                       "build_context")
+        if not plan:
+            return
+        n = len(plan)                                           # the plan's classes are back to back in the lane's context list
+        assert plan[0][2] == 0 and all(plan[k + 1][2] == plan[k][2] + plan[k][0] for k in range(n - 1))
+        Bs = (C.c_int * n)(*[q[0] for q in plan]); As = (C.c_int * n)(*[q[1] for q in plan])
+        cs = (_lib.Ctx * n)(*[q[3] for q in plan])
+        _lib.check(lib.ctrlsim_build_context_c(n, Bs, As, cs, self.N, d.T, t, Tq, tt_first, Tmax + 1, Tmax, self.P_all, d.P, d.NP,
+                                               p(L.ctx_scn), p(L.ctx_grp), p(self.grp_focal), p(self.grp_ids),
+                                               p(self.hist_states), p(self.hist_tok), p(self.hist_rtg), p(self.goals),
+                                               p(self.types), p(self.roads), p(self.rtypes), self._zero4, st), "build_context")
 
     def _sample_rtg(self, L, t, s0, s1, st, noise_rtg=None):
         lib, p, d, sl = self.lib, _lib.ptr, self.dims, slice(s0, s1)

@@ -117,6 +117,13 @@ int ctrlsim_build_context(int B, int N, int A, int T, int t, int Tq, int tt_firs
                           const float* roads /*[S,P_all,NP,3]*/, const float* road_types /*[S,P_all,8]*/,
                           const int* zero4 /*{zero action token, rtg bins x3}*/, const ctrlsim_ctx* out,
                           hipStream_t stream);
+/* The same for a model batch of up to 8 context size classes in ONE launch (class k: B[k] contexts of A[k] slots written to
+ * out[k]; the batch's context list ctx_scn / ctx_grp holds the classes back to back). */
+int ctrlsim_build_context_c(int n, const int* B, const int* A, const ctrlsim_ctx* out, int N, int T, int t, int Tq, int tt_first,
+                            int Tmax1, int Tmax, int P_all, int P, int NP, const int* ctx_scn, const int* ctx_grp,
+                            const int* grp_focal, const uint64_t* grp_ids, const float* hist_states, const int* hist_tok,
+                            const int* hist_rtg, const double* goals, const float* types, const float* roads,
+                            const float* road_types, const int* zero4, hipStream_t stream);
 
 /* ---- model ----------------------------------------------------------------------------------------------------
  * Replaces CtRLSim.load_from_checkpoint + CtRLSim.forward (models/ctrl_sim.py:19-45; modules/encoder.py,
