@@ -93,7 +93,12 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
   constexpr int K_PLANE = KT6 * HD;              // bf16 elements: [ks 2][half 2][64 keys][8]
   constexpr int V_PLANE = HD * KT6;              // [16 quads][32 d][4 keys]
   constexpr int BUF = NPL * (K_PLANE + V_PLANE) + 2 * KT6;   // + KT6 floats of key-padding bias
-  __shared__ __attribute__((aligned(16))) op_t arena[2 * BUF];
+#ifdef ATT_RING3
+  constexpr int NBUF = PRE ? 3 : 2;              // pre-split images: a ring of three stages, the DMA runs two tiles ahead
+#else
+  constexpr int NBUF = 2;
+#endif
+  __shared__ __attribute__((aligned(16))) op_t arena[NBUF * BUF];
   __shared__ int blk_tmax[4];
   static_assert(2 * BUF * 2 >= 4 * 32 * 33 * 4, "output transpose must fit");
 
@@ -213,6 +218,8 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
     if (MODE == MODE6_KEYPAD && tid < KT6) {
       const int kr = k0 + tid;
       ppad = (kr < Lk && !key_pad[(size_t)b * Lk + kr]) ? 0.f : NEG_INF;
+      // three-stage ring: the stage is free when its DMA is issued (and ppad would be overwritten by the next request)
+      if (NBUF == 3) reinterpret_cast<float*>(arena + buf * BUF + NPL * (K_PLANE + V_PLANE))[tid] = ppad;
     }
   };
   auto sstore = [&](int buf) {
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
       }
     }
     }
-    if (MODE == MODE6_KEYPAD && tid < KT6) reinterpret_cast<float*>(Vd + NPL * V_PLANE)[tid] = ppad;
+    if (NBUF != 3 && MODE == MODE6_KEYPAD && tid < KT6) reinterpret_cast<float*>(Vd + NPL * V_PLANE)[tid] = ppad;
   };
 
   // ---- tile schedule: the regular tiles [0, n_reg) that hold keys < k_end, then the representative tiles (compact contexts)
@@ -251,9 +258,14 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
     gload(tile_k0(0), 0);
     sstore(0);
   }
+  if (NBUF == 3 && n_it > 1) {
+    gload(tile_k0(1), 1);
+    asm volatile("s_waitcnt vmcnt(%0) ; KV-DMA of tile 0 landed" :: "n"(KV_PIECES) : "memory");
+  } else {
 #ifndef ATT_DMA_BUILTIN
   if (PRE) asm volatile("s_waitcnt vmcnt(0) ; KV-DMA landed" ::: "memory");
 #endif
+  }
   __syncthreads();
 #ifdef ATT_TIMING
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -261,9 +273,12 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
 #endif
 
   int cur = 0;
-  for (int it = 0; it < n_it; ++it, cur ^= 1) {
+  for (int it = 0; it < n_it; ++it, cur = (NBUF == 3 ? (cur == 2 ? 0 : cur + 1) : cur ^ 1)) {
     const bool more = it + 1 < n_it;
-    if (more) gload(tile_k0(it + 1), cur ^ 1);
+    const bool more2 = NBUF == 3 && it + 2 < n_it;
+    if (NBUF == 3) {
+      if (more2) gload(tile_k0(it + 2), cur == 0 ? 2 : cur - 1);      // (cur + 2) % 3: the stage tile it-1 has just left
+    } else if (more) gload(tile_k0(it + 1), cur ^ 1);
     const bool rep_tile = it >= n_reg;               // wave-uniform: a tile of representative keys (compact contexts)
     const int k0 = it * KT6;
     TSTAMP(0) TCOUNT(7)
@@ -291,14 +306,19 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
         }
       } else if (j0 >= rep_need || j0 > 3 * tq_max_w + 2) {
         continue;
+      } else {
+        // representative keys of steps before every query of this wave: all 32 visible, all m-fold -> no mask, and the
+        // multiplicity enters through the accumulator seed below
+        need_mask = !(j0 + 31 <= 3 * tq_min_w && j0 + 32 <= rep_keys);
       }
       // ---- S^T = K . Q^T : one accumulator chain, k-steps d 0-15 and d 16-31, six partial products each
       // the accumulator starts at -m_base (the running maximum, 0 before the first visible key): the MFMA chain then
       // delivers S - m directly and the per-element subtraction is needed only in the (rare) sub-tiles that raise the maximum
       const float m_base = (m_run == NEG_INF) ? 0.f : m_run;
+      const float seed = (rep_tile && !need_mask) ? log2m - m_base : -m_base;
       f32x16 s0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s0[r] = -m_base;
+      for (int r = 0; r < 16; ++r) s0[r] = seed;
       {
         const op_t* kr_ = Ks + (half * KT6 + sub * 32 + l31) * 8;
         opx8 k0f[NPL], k1f[NPL];
@@ -470,10 +490,14 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
 #endif
       }
     }
-    if (more) sstore(cur ^ 1);
+    if (more) sstore(NBUF == 3 ? (cur == 2 ? 0 : cur + 1) : cur ^ 1);
     TSTAMP(4)
 #ifndef ATT_DMA_BUILTIN
-    if (PRE) asm volatile("s_waitcnt vmcnt(0) ; KV-DMA landed" ::: "memory");
+    if (NBUF == 3) {
+      // tile it+1 (requested one iteration ago) must have landed; tile it+2's pieces (this iteration's) stay in flight
+      if (more2) asm volatile("s_waitcnt vmcnt(%0) ; KV-DMA of the next tile landed" :: "n"(KV_PIECES) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) ; KV-DMA landed" ::: "memory");
+    } else if (PRE) asm volatile("s_waitcnt vmcnt(0) ; KV-DMA landed" ::: "memory");
 #endif
     __syncthreads();
     TSTAMP(5)
