@@ -619,10 +619,11 @@ __device__ void tree_move_proxy(Tree T, const float* fat, int i) {
   tree_insert_leaf(T, id);
 }
 
-// b2BroadPhase::UpdatePairs + QueryCallback + b2ContactManager::AddPair, one lane.  tail: see CS_TAIL; one tree query per
-// buffered proxy, hits in the tree's stack order (child2 before child1).
-__device__ void find_new_contacts(float* cs, int N, int NP, Tree T, int* stack) {   // stack: 64 ints of LDS (a private array would live in scratch memory: ~500 cycles per push / pop)
-  float* tail = cs + (size_t)NP * CS_STRIDE;
+// b2BroadPhase::UpdatePairs + QueryCallback + b2ContactManager::AddPair.  tail: the scenario's broad-phase state (CS_TAIL layout),
+// global or its LDS copy.  One tree query per buffered proxy, hits in the tree's stack order (child2 before child1); contacts are
+// created in (move-buffer order, hit order) — that order is what the creation stamps record and the solver later follows.
+// Serial form (one lane); stack: 64 ints of LDS (a private array would live in scratch memory: ~500 cycles per push / pop).
+__device__ void find_new_contacts(float* cs, float* tail, int N, int NP, Tree T, int* stack) {
   float* fat = tail + CS_TAIL;
   float* moved = fat + 4 * N;
   float* move_buf = moved + N + 3 * N;
@@ -652,8 +653,62 @@ __device__ void find_new_contacts(float* cs, int N, int NP, Tree T, int* stack) 
   tail[1] = (float)stamp;
   tail[3] = 0.f;
 }
-__device__ __forceinline__ void buffer_move(float* cs, int N, int NP, int i) {
-  float* tail = cs + (size_t)NP * CS_STRIDE;
+// The same, called by ALL lanes of one wave: the queries are read-only walks of the tree, so lane k walks it for buffered proxy
+// k (its stack and hit list in `scratch`: QW_STACK ints + QW_HITS bytes per lane) and lane 0 then creates the contacts in the
+// serial order.  More than 64 buffered proxies, a deeper stack or more hits than the lists hold: the serial form.
+#define QW_STACK 24
+#define QW_HITS 32
+#define QW_BYTES (64 * QW_STACK * 4 + 64 * QW_HITS + 64 * 4)
+__device__ void find_new_contacts_wave(float* cs, float* tail, int N, int NP, Tree T, void* scratch, int* serial_stack) {
+  const int lane = threadIdx.x & 63;
+  int* qstack = static_cast<int*>(scratch) + lane * QW_STACK;
+  unsigned char* qhits = reinterpret_cast<unsigned char*>(static_cast<int*>(scratch) + 64 * QW_STACK);
+  int* nhits = reinterpret_cast<int*>(qhits + 64 * QW_HITS);
+  float* fat = tail + CS_TAIL;
+  float* moved = fat + 4 * N;
+  float* move_buf = moved + N + 3 * N;
+  const int n_move = (int)tail[3];
+  bool bad = n_move > 64;
+  if (!bad && lane < n_move) {
+    const int q = (int)move_buf[lane];
+    const float* fq = fat + 4 * q;
+    int sc = 0, nh = 0;
+    qstack[sc++] = T.root();
+    while (sc > 0) {
+      const int id = qstack[--sc];
+      if (id < 0 || !aabb_overlap(T.bb(id), fq)) continue;
+      if (!T.leaf(id)) {
+        if (sc + 2 <= QW_STACK) { qstack[sc++] = T.c1(id); qstack[sc++] = T.c2(id); } else bad = true;
+        continue;
+      }
+      if (nh < QW_HITS) qhits[lane * QW_HITS + nh++] = (unsigned char)tree_veh_of(id); else bad = true;
+    }
+    nhits[lane] = nh;
+  }
+  bad = __any(bad);
+  __builtin_amdgcn_wave_barrier();
+  if (lane != 0) return;
+  if (bad) { find_new_contacts(cs, tail, N, NP, T, serial_stack); return; }
+  int stamp = (int)tail[1];
+  for (int k = 0; k < n_move; ++k) {
+    const int q = (int)move_buf[k];
+    for (int h = 0; h < nhits[k]; ++h) {
+      const int o = qhits[k * QW_HITS + h];
+      if (o == q) continue;
+      if (moved[o] != 0.f && o > q) continue;
+      const int i = o < q ? o : q, j = o < q ? q : o;
+      float* m = cs + (size_t)(i * (2 * N - i - 1) / 2 + (j - i - 1)) * CS_STRIDE;
+      if (m[CS_EXISTS] != 0.f) continue;
+      for (int z = 0; z < CS_STRIDE; ++z) m[z] = 0.f;
+      m[CS_EXISTS] = 1.f;
+      m[CS_STAMP] = (float)(++stamp);
+    }
+  }
+  for (int k = 0; k < n_move; ++k) moved[(int)move_buf[k]] = 0.f;
+  tail[1] = (float)stamp;
+  tail[3] = 0.f;
+}
+__device__ __forceinline__ void buffer_move(float* tail, int N, int i) {
   float* moved = tail + CS_TAIL + 4 * N;
   float* move_buf = moved + N + 3 * N;
   const int n = (int)tail[3];
@@ -963,11 +1018,11 @@ __global__ __launch_bounds__(256) void sim_init_kernel(int N, int E, const float
       fat[4 * i] = bb[0] - B2_AABB_EXT; fat[4 * i + 1] = bb[1] - B2_AABB_EXT;
       fat[4 * i + 2] = bb[2] + B2_AABB_EXT; fat[4 * i + 3] = bb[3] + B2_AABB_EXT;
       tree_create_proxy(T, fat, i);
-      buffer_move(cs, N, NP, i);
+      buffer_move(tail, N, i);
       Xf xfa; xfa.p = v2(0.f, 0.f); xfa.q.s = sinf(p[P_A]); xfa.q.c = cosf(p[P_A]);
-      if (synchronize_fixture(fat + 4 * i, b, xfa, xfa)) { tree_move_proxy(T, fat, i); buffer_move(cs, N, NP, i); }
+      if (synchronize_fixture(fat + 4 * i, b, xfa, xfa)) { tree_move_proxy(T, fat, i); buffer_move(tail, N, i); }
       Xf xfp = xfa; xfp.p = v2(p[P_PX], p[P_PY]);
-      if (synchronize_fixture(fat + 4 * i, b, xfp, xfp)) { tree_move_proxy(T, fat, i); buffer_move(cs, N, NP, i); }
+      if (synchronize_fixture(fat + 4 * i, b, xfp, xfp)) { tree_move_proxy(T, fat, i); buffer_move(tail, N, i); }
     }
     tail[2] = 1.f;                                       // m_newContacts
   }
@@ -990,6 +1045,10 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
   __shared__ V2 isl_pc[64], isl_vv[64];
   __shared__ float isl_pa[64], isl_vw[64];
   __shared__ Constraint isl_c[MAX_ISLAND_CONTACTS];
+  static_assert(sizeof(Constraint) * MAX_ISLAND_CONTACTS >= QW_BYTES, "the pair search borrows the constraint array between island solves");
+  __shared__ int isl_b0[64], isl_nb[64], isl_c0[64], isl_nc[64], isl_count;    // islands of this step: spans in isl_bodies / isl_c
+  __shared__ float pair_stamp[64 * 63 / 2];                                     // creation stamp of every TOUCHING contact (LDS copy for the DFS)
+  __shared__ unsigned char pair_mark[64 * 63 / 2];                              // contact already taken into an island
   __shared__ float corner[64][8];
   __shared__ __attribute__((aligned(16))) float box[64][4];
   __shared__ int flag_veh[64], flag_edge[64];
@@ -1086,16 +1145,18 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
     // ================================================================================================ b2World::Step
     const int NP = N * (N - 1) / 2;
     float* cs = contact_state ? contact_state + (size_t)s * CS_PER(N) : nullptr;
-    float* tail = cs ? cs + (size_t)NP * CS_STRIDE : nullptr;
-    float* fat = cs ? tail + CS_TAIL : nullptr;
-    float* sweep0 = cs ? fat + 4 * N + N : nullptr;
+    // the scenario's broad-phase state (CS_TAIL words, fat boxes, moved flags, sweep origins, move buffer, the dynamic tree) works
+    // from LDS for the whole step — the serial parts (proxy moves, pair search) touch nothing else — and is written back at the end
+    __shared__ float tail_lds[CS_TAIL + 12 * 64 + 2 * 64 * TN_STRIDE];
+    float* gtail = cs ? cs + (size_t)NP * CS_STRIDE : nullptr;
+    const int n_tail = CS_TAIL + 12 * N + 2 * N * TN_STRIDE;
+    float* tail = tail_lds;
+    float* fat = tail + CS_TAIL;
+    float* sweep0 = fat + 4 * N + N;
     // the dynamic tree of this world works from LDS (one lane walks it; written back at the end of the step)
-    __shared__ float tree_lds[2 * 64 * TN_STRIDE + 2];
-    Tree T{tree_lds, tree_lds + 2 * 64 * TN_STRIDE};
-    if (cs) {
-      for (int i = tid; i < 2 * N * TN_STRIDE; i += blockDim.x) tree_lds[i] = fat[12 * N + i];
-      if (tid < 2) T.rf[tid] = tail[4 + tid];
-    }
+    Tree T{fat + 12 * N, tail + 4};
+    if (cs)
+      for (int i = tid; i < n_tail; i += blockDim.x) tail_lds[i] = gtail[i];
     __syncthreads();
     SIMT(0)
     if (cs) {
@@ -1106,16 +1167,22 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
             const size_t si = (size_t)s * N + i;
             const Box b = box_of(size[si * 2 + 1], size[si * 2]);
             Xf xf; xf.p = v2(B.px[i], B.py[i]); xf.q.s = sinf(B.a[i]); xf.q.c = cosf(B.a[i]);
-            if (synchronize_fixture(fat + 4 * i, b, xf, xf)) { tree_move_proxy(T, fat, i); buffer_move(cs, N, NP, i); }
+            if (synchronize_fixture(fat + 4 * i, b, xf, xf)) { tree_move_proxy(T, fat, i); buffer_move(tail, N, i); }
             tail[2] = 1.f;
           }
-        if (tail[2] != 0.f) { find_new_contacts(cs, N, NP, T, isl_stack); tail[2] = 0.f; }
+      }
+      if (tid < 64) {                                      // wave 0 (lane 0's writes above are in program order for its own wave)
+        __builtin_amdgcn_wave_barrier();
+        if (tail[2] != 0.f) find_new_contacts_wave(cs, tail, N, NP, T, isl_c, isl_stack);
+        __builtin_amdgcn_wave_barrier();
+        if (tid == 0) tail[2] = 0.f;
       }
       __syncthreads();
       SIMT(1)
       // ---- b2ContactManager::Collide / b2Contact::Update over the existing contacts (i < j: fixture A = i, B = j)
       for (int pr = tid; pr < NP; pr += blockDim.x) {
         float* m = cs + (size_t)pr * CS_STRIDE;
+        pair_mark[pr] = 0;
         if (m[CS_EXISTS] == 0.f) continue;
         int i = 0, rem = pr;                              // pair index -> (i, j), rows of lengths N-1, N-2, ...
         while (rem >= N - 1 - i) { rem -= N - 1 - i; ++i; }
@@ -1148,7 +1215,7 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
         const bool touching = cnt > 0;
         m[CS_TOUCH] = touching ? 1.f : 0.f;
         if (touching != was_touching) { wake[i] = 1; wake[j] = 1; }
-        if (touching) { atomicOr(&B.adj[i], 1ull << j); atomicOr(&B.adj[j], 1ull << i); }
+        if (touching) { atomicOr(&B.adj[i], 1ull << j); atomicOr(&B.adj[j], 1ull << i); pair_stamp[pr] = m[CS_STAMP]; }
       }
       __syncthreads();
       // pairs of two sleeping bodies were skipped above: their (unchanged) touching flag still links them
@@ -1158,6 +1225,7 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
         const int j = i + 1 + rem;
         if (!B.awake[i] && !B.awake[j] && cs[(size_t)pr * CS_STRIDE + CS_TOUCH] != 0.f) {
           atomicOr(&B.adj[i], 1ull << j); atomicOr(&B.adj[j], 1ull << i);
+          pair_stamp[pr] = cs[(size_t)pr * CS_STRIDE + CS_STAMP];
         }
       }
       if (tid < N && wake[tid]) { B.awake[tid] = 1; B.sleep[tid] = 0.f; }     // b2Body::SetAwake(true)
@@ -1192,17 +1260,20 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
       B.vx[tid] = vx; B.vy[tid] = vy; B.w[tid] = w; B.sleep[tid] = sleep_t;
     }
     SIMT(3)
-    // ---- islands with contacts: b2World::Solve's depth-first search and the sequential solver, on lane 0
+    // ---- islands with contacts.  Lane 0 runs b2World::Solve's depth-first search (island membership and, inside an island, the
+    // order of bodies and contacts are Box2D's: newest body first, newest contact first) over LDS copies of the contact stamps;
+    // the islands themselves are independent — disjoint bodies, disjoint contacts — so each is then solved by its own lane of
+    // wave 0 with the sequential-impulse solver, all of them in lockstep (the time of the largest island, not the sum).
     if (cs && tid == 0) {
-      const float dt_ratio = cs[(size_t)NP * CS_STRIDE] * dt;
       unsigned long long in_island = 0ull;
+      int n_isl = 0, boff = 0, coff = 0;
       for (int seed = N - 1; seed >= 0; --seed) {          // m_bodyList: newest body first
         if (B.adj[seed] == 0ull || ((in_island >> seed) & 1ull) || !B.awake[seed]) continue;
         int nb = 0, nc = 0, sc = 0;
         isl_stack[sc++] = seed; in_island |= 1ull << seed;
         while (sc > 0) {
           const int b = isl_stack[--sc];
-          isl_index[b] = nb; isl_bodies[nb++] = b;
+          isl_index[b] = nb; isl_bodies[boff + nb++] = b;
           B.awake[b] = 1;                                  // woken without resetting the sleep timer
           in_isl[b] = 1;
           unsigned long long rem_edges = B.adj[b];         // touching contacts of b, newest contact first
@@ -1211,31 +1282,38 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
             for (unsigned long long r2 = rem_edges; r2; r2 &= r2 - 1) {
               const int c = __ffsll((long long)r2) - 1;
               const int i2 = b < c ? b : c, j2 = b < c ? c : b;
-              const float st = cs[(size_t)(i2 * (2 * N - i2 - 1) / 2 + (j2 - i2 - 1)) * CS_STRIDE + CS_STAMP];
+              const float st = pair_stamp[i2 * (2 * N - i2 - 1) / 2 + (j2 - i2 - 1)];
               if (st > best) { best = st; o = c; }
             }
             rem_edges &= ~(1ull << o);
             const int i = b < o ? b : o, j = b < o ? o : b;
             const int pr = i * (2 * N - i - 1) / 2 + (j - i - 1);   // rows i of length N-1-i
-            float* m = cs + (size_t)pr * CS_STRIDE;
-            if (m[CS_TOUCH] == 2.f) continue;              // already in this island (flag restored below)
-            m[CS_TOUCH] = 2.f;
-            if (nc < MAX_ISLAND_CONTACTS) { isl_c[nc].m = m; isl_c[nc].ia = i; isl_c[nc].ib = j; ++nc; }
+            if (pair_mark[pr]) continue;                   // already in this island
+            pair_mark[pr] = 1;
+            if (coff + nc < MAX_ISLAND_CONTACTS) {         // (never exceeded: the touching graph of disjoint boxes is planar)
+              isl_c[coff + nc].m = cs + (size_t)pr * CS_STRIDE; isl_c[coff + nc].ia = i; isl_c[coff + nc].ib = j; ++nc;
+            }
             if ((in_island >> o) & 1ull) continue;
             isl_stack[sc++] = o; in_island |= 1ull << o;
           }
         }
         for (int c = 0; c < nc; ++c) {
-          isl_c[c].ia = isl_index[isl_c[c].ia]; isl_c[c].ib = isl_index[isl_c[c].ib];
-          isl_c[c].m[CS_TOUCH] = 1.f;
+          isl_c[coff + c].ia = isl_index[isl_c[coff + c].ia]; isl_c[coff + c].ib = isl_index[isl_c[coff + c].ib];
         }
-        island_solve(B, isl_bodies, nb, isl_c, nc, dt, dt_ratio, isl_pc, isl_pa, isl_vv, isl_vw);
+        isl_b0[n_isl] = boff; isl_nb[n_isl] = nb; isl_c0[n_isl] = coff; isl_nc[n_isl] = nc;
+        ++n_isl; boff += nb; coff += nc;
       }
-      // contacts beyond MAX_ISLAND_CONTACTS keep their island mark: restore it
-      for (int pr = 0; pr < NP; ++pr)
-        if (cs[(size_t)pr * CS_STRIDE + CS_TOUCH] == 2.f) cs[(size_t)pr * CS_STRIDE + CS_TOUCH] = 1.f;
-      cs[(size_t)NP * CS_STRIDE] = dt > 0.0f ? 1.0f / dt : 0.0f;                // m_inv_dt0
+      isl_count = n_isl;
     }
+    __syncthreads();
+    if (cs && tid < isl_count) {
+      const float dt_ratio = tail[0] * dt;
+      const int b0 = isl_b0[tid], c0 = isl_c0[tid];
+      island_solve(B, isl_bodies + b0, isl_nb[tid], isl_c + c0, isl_nc[tid], dt, dt_ratio, isl_pc + b0, isl_pa + b0, isl_vv + b0,
+                   isl_vw + b0);
+    }
+    __syncthreads();
+    if (cs && tid == 0) tail[0] = dt > 0.0f ? 1.0f / dt : 0.0f;                                   // m_inv_dt0
     SIMT(4)
     __syncthreads();
     if (cs) {
@@ -1256,14 +1334,16 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
       SIMT(5)
       if (tid == 0) {
         for (int b = N - 1; b >= 0; --b)                   // m_bodyList order: newest body first
-          if (moved_now[b]) { tree_move_proxy(T, fat, b); buffer_move(cs, N, NP, b); }
+          if (moved_now[b]) { tree_move_proxy(T, fat, b); buffer_move(tail, N, b); }
         SIMT(6)
-        find_new_contacts(cs, N, NP, T, isl_stack);
+      }
+      if (tid < 64) {
+        __builtin_amdgcn_wave_barrier();
+        find_new_contacts_wave(cs, tail, N, NP, T, isl_c, isl_stack);
         SIMT(7)
       }
       __syncthreads();
-      for (int i = tid; i < 2 * N * TN_STRIDE; i += blockDim.x) fat[12 * N + i] = tree_lds[i];
-      if (tid < 2) tail[4 + tid] = T.rf[tid];
+      for (int i = tid; i < n_tail; i += blockDim.x) gtail[i] = tail_lds[i];
     }
     if (tid < N) {
       const size_t sn = (size_t)s * N + tid;
