@@ -118,6 +118,9 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
   // ---- this lane's query: fragment of Q^T (B operand), k-step ks covers d = 16*ks + 8*half .. +7
   const int qi = qb + wave * 32 + l31;
   const bool qvalid = qi < Lq;
+  // a wave whose 32 query slots all lie beyond Lq (few-query calls: the second pass, the last decoder layer, the K/V-cached
+  // steps fill one wave of the four) stages tiles and keeps the barriers, but skips the products and the softmax
+  const bool wave_live = __builtin_amdgcn_readfirstlane(qb + wave * 32) < Lq;
   const int qrow = qvalid ? qi : (Lq - 1);
   const int pos = q_pos ? q_pos[qrow] : qrow;
   int tq = 0, aq = 0, kq = 0;
@@ -288,6 +291,7 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
 
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
+      if (!wave_live) continue;
       const int ks0 = k0 + sub * 32;
       int t_lo = 0, t_hi = 0, ks_t0 = 0;
       bool need_mask = true;

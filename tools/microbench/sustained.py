@@ -65,6 +65,17 @@ if 'attn' in FILT or not FILT:
     f = lambda: lib.ctrlsim_attention_presplit(0, p(Q), 256, L * 256, p(img2), 4, p(O), 256, L * 256, None, p(pad), B, L, 224, 24, st)
     report('attn cross presplit Lk=224', sustained(f), L * 224 * 128 * 8 * B)
     del qkv, O, img, Q, KV, img2
+if 'few' in FILT:
+    # few-query causal calls (second pass / last layer / K/V-cached steps): Bf contexts x 8 heads, one query block each
+    T = 32
+    for (Bf, Lq_) in ((77, 24), (77, 96), (512, 24)):
+        nkt = 36
+        qkv = torch.randn(Bf, Lq_, 768, device=DEV); O = torch.empty(Bf, Lq_, 256, device=DEV)
+        img = torch.randn(Bf * 8 * nkt * 4096 * (2 if NPROD == 3 else 3), device=DEV).to(torch.float16).view(torch.int16)
+        qpos = torch.arange(L - Lq_, L, dtype=torch.int32, device=DEV)
+        f = lambda: lib.ctrlsim_attention_presplit(1, p(qkv), 768, Lq_ * 768, p(img), nkt, p(O), 256, Lq_ * 256, p(qpos), None, Bf, Lq_, L, 24, st)
+        report(f'attn few-query B={Bf} Lq={Lq_} keys={L}', sustained(f), Lq_ * L * 128 * 8 * Bf)
+        del qkv, O, img
 if 'compact' in FILT:
     # compact contexts (representative slot): Actx slots -> Areg = Actx - 1 regular + 1 representative of multiplicity 25 - Actx
     T = 32
