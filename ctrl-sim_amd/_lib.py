@@ -45,6 +45,7 @@ SIGNATURES = {
     "ctrlsim_prof_enable": (None, [I]),
     "ctrlsim_prof_collect": (I, [P, P, P]),
     "ctrlsim_prof_bytes": (I, [P]),
+    "ctrlsim_prof_collect_stream": (I, [P, I, P, P, P, P]),
     "ctrlsim_metrics_size": (I, []),
     "ctrlsim_dt_ledger_step": (I, [I, I, I, I, I, I, P, P, P, P, P, C.POINTER(DtRewardCfg), P, P, P, P]),
     "ctrlsim_metrics_pack": (I, [I, I, I, I, I, D, P, P, P, P, P, P, P, P, P, P]),

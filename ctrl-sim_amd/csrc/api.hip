@@ -46,7 +46,7 @@ int launch_sample_action(const float*, int, int, const int*, const int*, const i
 
 #include <vector>
 namespace {
-struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; };
+struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; hipStream_t st; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_recs;
 std::vector<hipEvent_t> g_pool;
@@ -65,7 +65,7 @@ void prof_after(int cls, double flops, hipStream_t st, double bytes) {
   if (!g_prof_on) return;
   hipEvent_t b = take_event();
   hipEventRecord(b, st);
-  g_recs.push_back(ProfRec{g_pending[cls], b, cls, flops, bytes});
+  g_recs.push_back(ProfRec{g_pending[cls], b, cls, flops, bytes, st});
 }
 
 static int g_options[OPT_COUNT] = {1, 1, 0, 1, 1};
@@ -112,6 +112,20 @@ int ctrlsim_prof_collect(double* ms, int64_t* count, double* flops) {
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return CTRLSIM_ELAUNCH;
     ms[r.cls] += t; count[r.cls] += 1; flops[r.cls] += r.flops;
+  }
+  return CTRLSIM_OK;
+}
+
+// the same restricted to the launches ON stream st (on_stream != 0) or on any OTHER stream (on_stream == 0): with several streams
+// in flight the intervals of concurrently running kernels overlap, so a caller that wants per-kernel rates of the kernels that
+// own the chip (the main stream) separates them from the few-row kernels it deliberately runs underneath them
+int ctrlsim_prof_collect_stream(hipStream_t st, int on_stream, double* ms, int64_t* count, double* flops, double* bytes) {
+  for (int c = 0; c < PROF_CLASSES; ++c) { ms[c] = 0; count[c] = 0; flops[c] = 0; bytes[c] = 0; }
+  for (auto& r : g_recs) {
+    if ((r.st == st) != (on_stream != 0)) continue;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return CTRLSIM_ELAUNCH;
+    ms[r.cls] += t; count[r.cls] += 1; flops[r.cls] += r.flops; bytes[r.cls] += r.bytes;
   }
   return CTRLSIM_OK;
 }

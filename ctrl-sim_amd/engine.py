@@ -154,7 +154,7 @@ class _Lane:
         self.host_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.host_hist = None                                    # pinned [S, classes] int32, sized by load_scenarios
         self.side = torch.cuda.Stream(device=dev) if own_stream else None
-        self.ev_fwd, self.ev_ready = torch.cuda.Event(), torch.cuda.Event()
+        self.ev_fwd, self.ev_ready, self.ev_p2 = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
         self.pending = (0, 0, False)                             # scenario range (+ compare flag) of the read-back in flight
 
 
@@ -188,6 +188,7 @@ class RolloutEngine:
         self.kinematic = int(bool(kinematic))
         self.max_ctx = int(max_ctx)
         self.use_cache = bool(use_cache) and not self.dims.VARIANT    # the K/V-cached phase is built for the CtRL-Sim tokens
+        self.pass2_on_side = True                      # second pass on the lane's side stream (see _policy_chunks)
         self.device_ledger = self.dims.VARIANT == 3    # DT: RTG rows from the device reward ledger (the plugin surface feeds hist_rtg itself)
         self.contacts = bool(contacts) and not kinematic
         self.dt = float(cfg.nocturne.dt)
@@ -488,6 +489,10 @@ class RolloutEngine:
         if n:
             _lib.check(lib.ctrlsim_dt_forward_pass1_cached_c(self.model.handle, n, Bs, As, cs, t, p(L.ws), p(L.rtg_logits), st),
                        "pass1_cached")
+        if L.side is not None and self.pass2_on_side:        # as in _policy_chunks: the second pass under the other lane's kernels
+            L.ev_fwd.record(self._main)
+            L.side.wait_event(L.ev_fwd)
+            st = L.side.cuda_stream
         self._sample_rtg(L, t, s0, s1, st)
         if n:
             _lib.check(lib.ctrlsim_dt_forward_pass2_c(self.model.handle, n, Bs, As, cs, Tq, t, N, Tmax, p(L.ctx_scn),
@@ -528,7 +533,15 @@ class RolloutEngine:
         Tq = min(t, d.T - 1) + 1
         if d.VARIANT == 3 and self.device_ledger:
             self._dt_ledger(t, lo, hi, st)
+        # The second pass touches Areg rows per context: a string of few-row kernels that leave most of the chip idle.  With a
+        # side stream it runs THERE (sampling, second pass, sampling, then the simulator step that follows anyway), underneath the
+        # other lane's first pass on the main stream; the lane's buffers are handed back to the main stream by an event.
+        on_side = L.side is not None and not d.VARIANT and self.pass2_on_side
+        first = True
         for (s0, s1, counts) in self._chunks(hist, lo):
+            if on_side and not first:
+                self._main.wait_event(L.ev_p2)               # the previous batch's second pass still reads the lane's buffers
+            first = False
             plan, n, Bs, As, cs = self._class_plan(L, counts, Tq, Tq)
             self._ctx_index(L, s0, s1, st)
             self._build_contexts(L, plan, t, Tq, 0, st)
@@ -538,12 +551,19 @@ class RolloutEngine:
             elif n:
                 _lib.check(lib.ctrlsim_dt_forward_pass1_c(self.model.handle, n, Bs, As, cs, Tq, p(L.ws), p(L.rtg_logits), None, st),
                            "pass1")
+            st2 = st
+            if on_side:
+                L.ev_fwd.record(self._main)
+                L.side.wait_event(L.ev_fwd)
+                st2 = L.side.cuda_stream
             if not d.VARIANT:
-                self._sample_rtg(L, t, s0, s1, st, noise_rtg)
+                self._sample_rtg(L, t, s0, s1, st2, noise_rtg)
                 if n:
                     _lib.check(lib.ctrlsim_dt_forward_pass2_c(self.model.handle, n, Bs, As, cs, Tq, t, N, Tmax, p(L.ctx_scn),
-                                                              p(self.hist_rtg), p(L.ws), p(L.act_logits), 0, st), "pass2")
-            self._sample_action(L, t, s0, s1, st, noise_act)
+                                                              p(self.hist_rtg), p(L.ws), p(L.act_logits), 0, st2), "pass2")
+            self._sample_action(L, t, s0, s1, st2, noise_act)
+            if on_side:
+                L.ev_p2.record(L.side)
 
     # ------------------------------------------------------------------ a lane's rollout as a generator
     def _lane_gen(self, L, lo, hi, steps):

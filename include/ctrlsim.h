@@ -308,6 +308,9 @@ int ctrlsim_prof_classes(void);
 void ctrlsim_prof_enable(int on);
 int ctrlsim_prof_collect(double* ms, int64_t* count, double* flops);
 int ctrlsim_prof_bytes(double* bytes);
+/* ctrlsim_prof_collect + ctrlsim_prof_bytes restricted to the launches on `stream` (on_stream != 0) or on every other stream
+ * (on_stream == 0): intervals of kernels that run concurrently on different streams overlap in time. */
+int ctrlsim_prof_collect_stream(hipStream_t stream, int on_stream, double* ms, int64_t* count, double* flops, double* bytes);
 
 /* Runtime options: key 0 = attention path, key 1 = GEMM path of the forward; value 0 = f32-input MFMA
  * (v_mfma_f32_32x32x2_f32), 1 = split-bf16 "bf16x6" MFMA with fp32-class accuracy (default). */
