@@ -484,15 +484,16 @@ class RolloutEngine:
         N, Tmax = self.N, self.steps
         Tq, tt_first = t + 1, max(t - 1, 0)
         plan, n, Bs, As, cs = self._class_plan(L, counts, d.T, Tq - tt_first)
+        if L.side is not None and self.pass2_on_side:
+            # every kernel of a cached step touches a few rows per context: the whole step runs on the lane's OWN stream, so the
+            # lanes' cached phases run side by side instead of taking turns on the main stream (which waits for the lane at
+            # the first sliding step, _main_waits)
+            st = L.side.cuda_stream
         self._ctx_index(L, s0, s1, st)
         self._build_contexts(L, plan, t, Tq, tt_first, st)
         if n:
             _lib.check(lib.ctrlsim_dt_forward_pass1_cached_c(self.model.handle, n, Bs, As, cs, t, p(L.ws), p(L.rtg_logits), st),
                        "pass1_cached")
-        if L.side is not None and self.pass2_on_side:        # as in _policy_chunks: the second pass under the other lane's kernels
-            L.ev_fwd.record(self._main)
-            L.side.wait_event(L.ev_fwd)
-            st = L.side.cuda_stream
         self._sample_rtg(L, t, s0, s1, st)
         if n:
             _lib.check(lib.ctrlsim_dt_forward_pass2_c(self.model.handle, n, Bs, As, cs, Tq, t, N, Tmax, p(L.ctx_scn),
