@@ -73,6 +73,7 @@ SIGNATURES = {
     "ctrlsim_forward_workspace_bytes_a": (L, [C.POINTER(Dims), I, I, I]),
     "ctrlsim_forward_workspace_bytes_c": (L, [C.POINTER(Dims), I, P, P, I]),
     "ctrlsim_dt_forward_pass1_c": (I, [P, I, P, P, P, I, P, P, P, P]),
+    "ctrlsim_dt_forward_pass1_c2": (I, [P, I, P, P, P, I, P, P, P, P]),
     "ctrlsim_dt_forward_pass2_c": (I, [P, I, P, P, P, I, I, I, I, P, P, P, P, I, P]),
     "ctrlsim_dt_forward_pass1_cached_c": (I, [P, I, P, P, P, I, P, P, P]),
     "ctrlsim_dt_forward_pass1_a": (I, [P, I, I, I, C.POINTER(Ctx), P, P, P, P]),

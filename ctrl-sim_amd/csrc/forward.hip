@@ -94,6 +94,7 @@ struct ctrlsim_model {
   std::vector<DecLayer> dec;
   Mlp head_action, head_rtg, head_fut;
   bool has_fut = false;
+  hipEvent_t ev_tail = nullptr;           // orders the few-row tail of a first pass behind its full-row part when the tail runs on another stream
   int zero_rtg[3];
 };
 
@@ -192,11 +193,15 @@ extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_w
   }
   m->zero_rtg[0] = 0; m->zero_rtg[1] = 35; m->zero_rtg[2] = 35;
   if (!ok) { delete m; return CTRLSIM_EINVAL; }
+  if (hipEventCreateWithFlags(&m->ev_tail, hipEventDisableTiming) != hipSuccess) { delete m; return CTRLSIM_ELAUNCH; }
   *out = m;
   return CTRLSIM_OK;
 }
 
-extern "C" void ctrlsim_model_destroy(ctrlsim_model* m) { delete m; }
+extern "C" void ctrlsim_model_destroy(ctrlsim_model* m) {
+  if (m && m->ev_tail) (void)hipEventDestroy(m->ev_tail);
+  delete m;
+}
 
 // ------------------------------------------------------------------------------------------------ batch of context classes
 namespace {
@@ -643,7 +648,8 @@ namespace {
 // predict_action on the action tokens (decoder.py:55-77).
 struct AllOut { float *act, *rtg, *fut; };       // ctrlsim_forward_all: heads on every token, rows (b, tt, a)
 int forward_full(const ctrlsim_model* m, int n, const int* Bk, const int* Ak, const ctrlsim_ctx* ctx, int Tq, void* workspace,
-                 float* logits, float* dbg_seg_emb, hipStream_t st, const AllOut* all = nullptr) {
+                 float* logits, float* dbg_seg_emb, hipStream_t st, const AllOut* all = nullptr, hipStream_t st_tail = nullptr,
+                 bool split_tail = false) {
   const ctrlsim_dims& d = m->d;
   const int variant = d.variant, amode = 1 + variant, qoff = variant == 2 ? 2 : 0;
   if (variant && !presplit()) return CTRLSIM_EINVAL;       // the IL / Trajeglish masks live in the split-bf16 attention only
@@ -684,7 +690,13 @@ int forward_full(const ctrlsim_model* m, int n, const int* Bk, const int* Ak, co
       CHK(gemm_ln(Ld.out, Ld.n1, w.att, DM, w.X, DM, w.X, DM, w.tmp, rL, DM, 0, st));
       CHK(cross_and_ffn(m, bt, Ld, i, w, w.X, w.tmp, w.att, w.qc, w.ffn, bt.rL, Q_ALL, 0, st));
     } else {
-      // last layer: only the queried tokens of the current timestep (state tokens; Trajeglish: action tokens) of the regular slots
+      // last layer: only the queried tokens of the current timestep (state tokens; Trajeglish: action tokens) of the regular slots.
+      // From here on every kernel touches Areg rows per context; a caller with a second stream gets this tail there, ordered
+      // behind the full-row part by an event, so that the next batch's full-row kernels need not wait for it.
+      if (split_tail && st_tail != st) {
+        if (hipEventRecord(m->ev_tail, st) != hipSuccess || hipStreamWaitEvent(st_tail, m->ev_tail, 0) != hipSuccess) return CTRLSIM_ELAUNCH;
+        st = st_tail;
+      }
       CHK(launch_row_copy(w.X, DM, w.xc, DM, w.idx_state, rQ, DM, 0, st));
       CHK(launch_row_copy(w.qkv[i], 3 * DM, w.qkvc, 3 * DM, w.idx_state, rQ, 3 * DM, 0, st));
       CHK(attention(d, bt, w, AttnCall{amode, Q_STATE, w.qkvc, 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, w.img_dec[i], false,
@@ -713,6 +725,13 @@ extern "C" int ctrlsim_dt_forward_pass1_c(const ctrlsim_model* m, int n, const i
                                           void* workspace, float* rtg_logits, float* dbg_seg_emb, hipStream_t st) {
   if (!m || !ctx || !workspace || !rtg_logits || Tq < 1 || Tq > m->d.T || m->d.variant != 0) return CTRLSIM_EINVAL;
   return forward_full(m, n, B, A, ctx, Tq, workspace, rtg_logits, dbg_seg_emb, st);
+}
+// The same with the few-row tail (last decoder layer on the queried rows + the head) enqueued on `tail_stream`, behind the
+// full-row part on `stream` (event-ordered inside the call).  rtg_logits are complete in tail_stream order.
+extern "C" int ctrlsim_dt_forward_pass1_c2(const ctrlsim_model* m, int n, const int* B, const int* A, const ctrlsim_ctx* ctx, int Tq,
+                                           void* workspace, float* rtg_logits, hipStream_t st, hipStream_t tail_stream) {
+  if (!m || !ctx || !workspace || !rtg_logits || Tq < 1 || Tq > m->d.T || m->d.variant != 0) return CTRLSIM_EINVAL;
+  return forward_full(m, n, B, A, ctx, Tq, workspace, rtg_logits, nullptr, st, nullptr, tail_stream, true);
 }
 extern "C" int ctrlsim_dt_forward_pass1_a(const ctrlsim_model* m, int B, int Tq, int Actx, const ctrlsim_ctx* c, void* workspace,
                                           float* rtg_logits, float* dbg_seg_emb, hipStream_t st) {

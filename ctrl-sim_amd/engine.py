@@ -549,12 +549,15 @@ class RolloutEngine:
             if n and d.VARIANT:                              # IL / Trajeglish: no RTG tokens, one forward (predict_rtgs False)
                 _lib.check(lib.ctrlsim_dt_forward_actions(self.model.handle, plan[0][0], Tq, cs, p(L.ws), p(L.act_logits), st),
                            "forward_actions")
+            elif n and on_side:                              # the few-row tail of the first pass goes to the side stream too
+                _lib.check(lib.ctrlsim_dt_forward_pass1_c2(self.model.handle, n, Bs, As, cs, Tq, p(L.ws), p(L.rtg_logits), st,
+                                                           L.side.cuda_stream), "pass1")
             elif n:
                 _lib.check(lib.ctrlsim_dt_forward_pass1_c(self.model.handle, n, Bs, As, cs, Tq, p(L.ws), p(L.rtg_logits), None, st),
                            "pass1")
             st2 = st
             if on_side:
-                L.ev_fwd.record(self._main)
+                L.ev_fwd.record(self._main)                  # (also covers n == 0: sampling follows the context index kernels)
                 L.side.wait_event(L.ev_fwd)
                 st2 = L.side.cuda_stream
             if not d.VARIANT:

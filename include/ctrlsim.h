@@ -155,6 +155,11 @@ int ctrlsim_dt_forward_pass1_c(const ctrlsim_model* m, int n, const int* B, cons
 int ctrlsim_dt_forward_pass2_c(const ctrlsim_model* m, int n, const int* B, const int* A, const ctrlsim_ctx* ctx, int Tq, int t,
                                int N, int Tmax, const int* ctx_scn, const int* hist_rtg, void* workspace, float* act_logits,
                                int cached, hipStream_t stream);
+/* ctrlsim_dt_forward_pass1_c with its few-row tail (last decoder layer on the queried rows, the head) on `tail_stream`, ordered
+ * behind the full-row part on `stream` by an event inside the call: the caller's next full-row work on `stream` need not wait
+ * for it; rtg_logits are complete in tail_stream order. */
+int ctrlsim_dt_forward_pass1_c2(const ctrlsim_model* m, int n, const int* B, const int* A, const ctrlsim_ctx* ctx, int Tq,
+                                void* workspace, float* rtg_logits, hipStream_t stream, hipStream_t tail_stream);
 int ctrlsim_dt_forward_pass1_cached_c(const ctrlsim_model* m, int n, const int* B, const int* A, const ctrlsim_ctx* ctx, int t,
                                       void* workspace, float* rtg_logits, hipStream_t stream);
 /* pass 1: rtg_logits [B,A,R*C] of the current-timestep state tokens; caches per-layer K/V in `workspace`. */
