@@ -215,6 +215,7 @@ def main():
                     "traffic": traffic(i, by[i] / n), "traffic_source": pmc_src, "traffic_measured": pmc.get(keys[i]),
                     "hbm_rate_at_algorithmic_bytes_TBps": by[i] / (ms[i] * 1e-3) / 1e12 if ms[i] > 0 else None,
                     "side_stream": {"launches": int(scnt[i]), "event_ms_total": sms[i], "flop_share": sfl[i] / max(fl[i] + sfl[i], 1.0),
+                                    "algorithmic_hbm_bytes_total": sby[i],
                                     "note": "few-row launches of the second pass, run on the lanes' side streams underneath the "
                                             "main stream's kernels (their intervals overlap those above and are not in them)"}}
 

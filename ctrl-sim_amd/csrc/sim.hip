@@ -1228,6 +1228,9 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
           pair_stamp[pr] = cs[(size_t)pr * CS_STRIDE + CS_STAMP];
         }
       }
+      // the loop above must see the awake flags the FIRST loop saw (it links exactly the pairs that one skipped): the wake-ups
+      // are applied behind a barrier — without it a fast wave 0 could wake bodies while other waves still read the flags
+      __syncthreads();
       if (tid < N && wake[tid]) { B.awake[tid] = 1; B.sleep[tid] = 0.f; }     // b2Body::SetAwake(true)
       if (tid < N) { sweep0[3 * tid] = B.cx[tid]; sweep0[3 * tid + 1] = B.cy[tid]; sweep0[3 * tid + 2] = B.a[tid]; }
       __syncthreads();

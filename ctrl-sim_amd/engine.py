@@ -154,7 +154,7 @@ class _Lane:
         self.host_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.host_hist = None                                    # pinned [S, classes] int32, sized by load_scenarios
         self.side = torch.cuda.Stream(device=dev) if own_stream else None
-        self.ev_fwd, self.ev_ready, self.ev_p2 = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+        self.ev_fwd, self.ev_ready, self.ev_p2, self.ev_p1 = (torch.cuda.Event() for _ in range(4))
         self.pending = (0, 0, False)                             # scenario range (+ compare flag) of the read-back in flight
 
 
@@ -188,7 +188,16 @@ class RolloutEngine:
         self.kinematic = int(bool(kinematic))
         self.max_ctx = int(max_ctx)
         self.use_cache = bool(use_cache) and not self.dims.VARIANT    # the K/V-cached phase is built for the CtRL-Sim tokens
-        self.pass2_on_side = True                      # second pass on the lane's side stream (see _policy_chunks)
+        # Few-row kernels on the lanes' side streams (second pass, the tail of the first pass, whole K/V-cached steps) underneath
+        # the other lane's full-row kernels: +4 % throughput (109.0 -> 113.6 k agent-steps/s), but OFF by default — with three
+        # queues busy all the time, rollouts stopped being reproducible on the MI355X boxes used here: in ~1 of 3 runs a simulator
+        # block produced different outputs from bit-identical inputs (a 16-lane group of a wave's values zeroed, or a box-box test
+        # flipping), with any version of the simulator kernel, with its LDS pre-filled, without register spills anywhere, and never
+        # with these switches off (40 / 40 identical) or with a host synchronisation before the simulator launch.  The wave state
+        # changes under a kernel that is itself deterministic (tools/microbench notes in profiles/README.md): not root-caused.
+        self.pass2_on_side = False
+        self.tail_on_side = False
+        self.cached_on_side = False
         self.device_ledger = self.dims.VARIANT == 3    # DT: RTG rows from the device reward ledger (the plugin surface feeds hist_rtg itself)
         self.contacts = bool(contacts) and not kinematic
         self.dt = float(cfg.nocturne.dt)
@@ -484,7 +493,7 @@ class RolloutEngine:
         N, Tmax = self.N, self.steps
         Tq, tt_first = t + 1, max(t - 1, 0)
         plan, n, Bs, As, cs = self._class_plan(L, counts, d.T, Tq - tt_first)
-        if L.side is not None and self.pass2_on_side:
+        if L.side is not None and self.pass2_on_side and self.cached_on_side:
             # every kernel of a cached step touches a few rows per context: the whole step runs on the lane's OWN stream, so the
             # lanes' cached phases run side by side instead of taking turns on the main stream (which waits for the lane at
             # the first sliding step, _main_waits)
@@ -549,7 +558,7 @@ class RolloutEngine:
             if n and d.VARIANT:                              # IL / Trajeglish: no RTG tokens, one forward (predict_rtgs False)
                 _lib.check(lib.ctrlsim_dt_forward_actions(self.model.handle, plan[0][0], Tq, cs, p(L.ws), p(L.act_logits), st),
                            "forward_actions")
-            elif n and on_side:                              # the few-row tail of the first pass goes to the side stream too
+            elif n and on_side and self.tail_on_side:        # the few-row tail of the first pass goes to the side stream too
                 _lib.check(lib.ctrlsim_dt_forward_pass1_c2(self.model.handle, n, Bs, As, cs, Tq, p(L.ws), p(L.rtg_logits), st,
                                                            L.side.cuda_stream), "pass1")
             elif n:
@@ -557,8 +566,8 @@ class RolloutEngine:
                            "pass1")
             st2 = st
             if on_side:
-                L.ev_fwd.record(self._main)                  # (also covers n == 0: sampling follows the context index kernels)
-                L.side.wait_event(L.ev_fwd)
+                L.ev_p1.record(self._main)                   # (also covers n == 0: sampling follows the context index kernels)
+                L.side.wait_event(L.ev_p1)
                 st2 = L.side.cuda_stream
             if not d.VARIANT:
                 self._sample_rtg(L, t, s0, s1, st2, noise_rtg)

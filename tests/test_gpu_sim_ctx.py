@@ -448,7 +448,8 @@ def test_kv_cached_phase_equals_full_recompute(kind, n_ag, n_pl, steps):
 def test_full_size_rollout_is_invariant_to_batching_and_cache():
     """BASELINE configs[2] shape (64 vehicles, 512 polylines x 100 points, 90 steps, full model): too large for the CPU oracle,
     so parity is carried by size-independent properties — a scenario's rollout must not depend on which other scenarios
-    share its model batch, on how the batch is cut into forward chunks, on the scenario order, or on the KV-cached phase:
+    share its model batch, on how the batch is cut into forward chunks, on the scenario order, on the KV-cached phase or on the
+    number of engine lanes / streams:
     tokens / RTG bins / collision flags bit-identical, trajectories bit-identical (every kernel is row-independent)."""
     cfg = cfg_of("full")
     cfg = spec.make_cfg(nocturne__steps=90, nocturne__history_steps=1)
@@ -457,9 +458,11 @@ def test_full_size_rollout_is_invariant_to_batching_and_cache():
     scns = [scenarios.make_scenario(7, i, n_agents=64, n_polylines=512) for i in range(3)]
     model = None
     runs = {}
-    for tag, order, max_ctx, cache in (("ref", [0, 1, 2], 64, True), ("rechunk", [2, 0, 1], 24, True),
-                                       ("nocache", [1, 2, 0], 64, False)):
-        eng = RolloutEngine(cfg, w, DEV, max_ctx=max_ctx, seed=3, use_cache=cache, model=model)
+    # "one_lane": a single lane has no side stream — every kernel in program order on one stream; the default two lanes run the
+    # second pass, the simulator step and the cached steps on side streams ordered by events (a missing dependency would show here)
+    for tag, order, max_ctx, cache, lanes in (("ref", [0, 1, 2], 64, True, 2), ("rechunk", [2, 0, 1], 24, True, 2),
+                                              ("nocache", [1, 2, 0], 64, False, 2), ("one_lane", [0, 1, 2], 64, True, 1)):
+        eng = RolloutEngine(cfg, w, DEV, max_ctx=max_ctx, seed=3, use_cache=cache, model=model, lanes=lanes)
         model = eng.model
         eng.load_scenarios([scns[i] for i in order], steps=90)
         r = eng.run(90).results()
@@ -469,13 +472,13 @@ def test_full_size_rollout_is_invariant_to_batching_and_cache():
         a = runs["ref"][i]
         assert np.isfinite(a["states"]).all() and a["tokens"].min() >= 0 and a["tokens"].max() < d.V
         assert a["n_groups"].min() >= 3          # 64 vehicles need at least ceil(64 / 24) focal groups
-        for tag in ("rechunk", "nocache"):
+        for tag in ("rechunk", "nocache", "one_lane"):
             b = runs[tag][i]
             assert np.array_equal(a["n_groups"], b["n_groups"]), tag
             assert np.array_equal(a["tokens"], b["tokens"]), tag
             assert np.array_equal(a["rtg_bins"], b["rtg_bins"]), tag
             assert np.array_equal(a["coll"], b["coll"]), tag
-            if tag == "rechunk":
+            if tag in ("rechunk", "one_lane"):
                 assert np.array_equal(a["states"], b["states"]), tag
             else:
                 np.testing.assert_allclose(a["states"], b["states"], atol=1e-4, rtol=0)

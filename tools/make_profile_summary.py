@@ -74,14 +74,24 @@ def main():
     if "attention" in r["kernel"]:
         r, o = o, r
     scale = (b["warmup"] + b["steps"]) / b["steps"]
+
+    def all_streams(x):        # bench.py keeps main-stream and side-stream launches apart; rocprofv3 sees them all
+        sd = x.get("side_stream") or {"launches": 0, "event_ms_total": 0.0}
+        n = x["launches"] + sd["launches"]
+        return (x["avg_launch_ms"] * x["launches"] + sd["event_ms_total"]) / n, n
+    r_avg, r_n = all_streams(r)
+    o_avg, o_n = all_streams(o)
     lines += ["", f"total kernel time {tot / 1e6:.0f} ms over {sum(int(x['Calls']) for x in rows)} dispatches.", "",
               "## Agreement with bench.py's live HIP-event timing (timed steps only)", "",
-              "| class | rocprofv3 avg per launch (warm-up + timed) | bench.py HIP-event avg per launch | launches (rocprof / bench) | share of kernel time |",
+              "| class | rocprofv3 avg per launch (warm-up + timed) | bench.py HIP-event avg per launch (main + side streams) | launches (rocprof / bench) | share of kernel time |",
               "|---|---|---|---|---|",
-              f"| Linear class: gemm_nt_bf16x6_kernel (all variants) + ffn_fused_bf16x6_kernel | {gt / gc / 1e6:.4f} ms | {r['avg_launch_ms']:.4f} ms | {gc} / {r['launches']} | {100 * gt / tot:.1f} % |",
-              f"| attention_bf16x6_kernel (causal + key-padding) | {at / ac / 1e6:.4f} ms | {o['avg_launch_ms']:.4f} ms | {ac} / {o['launches']} | {100 * at / tot:.1f} % |",
+              f"| Linear class: gemm_nt_bf16x6_kernel (all variants) + ffn_fused_bf16x6_kernel | {gt / gc / 1e6:.4f} ms | {r_avg:.4f} ms | {gc} / {r_n} | {100 * gt / tot:.1f} % |",
+              f"| attention_bf16x6_kernel (causal + key-padding) | {at / ac / 1e6:.4f} ms | {o_avg:.4f} ms | {ac} / {o_n} | {100 * at / tot:.1f} % |",
               "",
               f"(rocprofv3 counts the warm-up step too: {scale:.2f}x the timed launches.)",
+              f"bench.py's roofline uses the MAIN-stream launches only ({r['launches']} Linear-class launches averaging {r['avg_launch_ms']:.3f} ms, {o['launches']} attention",
+              f"launches averaging {o['avg_launch_ms']:.3f} ms): the few-row launches of the second pass / cached steps run on the lanes' side streams underneath",
+              "them and their intervals overlap (DESIGN.md section 6).",
               f"Roofline line of that run: Linear class {r['achieved']:.1f} TFLOP/s fp32-equivalent = {r['frac']:.3f} of the {r['peak']:.1f} TFLOP/s split-operand roof",
               f"({r['mfma_executed_tflops']:.0f} TFLOP/s of 16-bit MFMA issued), {100 * r['time_share_of_step']:.1f} % of the step; attention class {o['achieved']:.1f} TFLOP/s",
               f"fp32-equivalent = {o['frac']:.3f}, {100 * o['time_share_of_step']:.1f} % of the step.", "",
@@ -112,7 +122,9 @@ def main():
                 n += v["launches"]; f += v.get("FETCH_SIZE_raw_sum", 0); w += v.get("WRITE_SIZE_raw_sum", 0)
         # the PMC passes see every launch of the command (warm-up included); bench.py's algorithmic bytes cover the timed launches —
         # both are per-launch means over the same kernels at the same shapes
-        alg = br["algorithmic_hbm_bytes_per_launch"]
+        sd = br.get("side_stream") or {}
+        alg = (br["algorithmic_hbm_bytes_per_launch"] * br["launches"] + sd.get("algorithmic_hbm_bytes_total", 0.0)) / \
+              (br["launches"] + sd.get("launches", 0))            # every launch of the class, main and side streams, as the counters see them
         out[name] = {"launches": n, "fetch_bytes_per_launch": f * 1024 / n, "write_bytes_per_launch": w * 1024 / n,
                      "hbm_bytes_per_launch": (f + w) * 1024 / n, "algorithmic_bytes_per_launch_same_run": alg,
                      "hbm_over_algorithmic": (f + w) * 1024 / n / alg}
