@@ -337,16 +337,27 @@ __device__ __forceinline__ Box box_of(float width, float length) {   // SetAsBox
 }
 struct ClipV { V2 v; unsigned ia, ib, ta, tb; };
 
-__device__ float find_max_separation(int* edge, const Box& p1, Xf xf1, const Box& p2, Xf xf2) {
+// Vertices / normals of SetAsBox(hx, hy) by index, without arrays: collide_boxes selects its reference / incident polygon and
+// their edges at run time, and a run-time index into a local array (or a reference chosen by `flip`) would put the polygons into
+// scratch memory (240 bytes per lane, written and re-read per contact).  This kernel keeps nothing there (tests/test_isa_checks.py).
+struct HBox { float hx, hy; };
+__device__ __forceinline__ HBox hbox_of(const Box& b) { HBox h; h.hx = b.v[2].x; h.hy = b.v[2].y; return h; }
+__device__ __forceinline__ V2 hb_v(HBox b, int i) { return v2((i == 1 || i == 2) ? b.hx : -b.hx, i >= 2 ? b.hy : -b.hy); }
+__device__ __forceinline__ V2 hb_n(int i) { return v2(i == 1 ? 1.0f : (i == 3 ? -1.0f : 0.0f), i == 0 ? -1.0f : (i == 2 ? 1.0f : 0.0f)); }
+
+__device__ float find_max_separation(int* edge, HBox p1, Xf xf1, HBox p2, Xf xf2) {
   const Xf xf = xf_mulT_xf(xf2, xf1);
   int best = 0;
   float max_sep = -B2_FLT_MAX;
+#pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const V2 n = rot_mul(xf.q, p1.n[i]);
-    const V2 v1 = xf_mul(xf, p1.v[i]);
+    const V2 n = rot_mul(xf.q, hb_n(i));
+    const V2 v1 = xf_mul(xf, hb_v(p1, i));
     float si = B2_FLT_MAX;
+#pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float sij = dot2(n, v2(p2.v[j].x - v1.x, p2.v[j].y - v1.y));
+      const V2 pj = hb_v(p2, j);
+      const float sij = dot2(n, v2(pj.x - v1.x, pj.y - v1.y));
       if (sij < si) si = sij;
     }
     if (si > max_sep) { max_sep = si; best = i; }
@@ -354,25 +365,32 @@ __device__ float find_max_separation(int* edge, const Box& p1, Xf xf1, const Box
   *edge = best;
   return max_sep;
 }
-__device__ int clip_segment(ClipV* out, const ClipV* in, V2 normal, float offset, int vertex_index_a) {
-  int count = 0;
-  const float d0 = dot2(normal, in[0].v) - offset;
-  const float d1 = dot2(normal, in[1].v) - offset;
-  if (d0 <= 0.0f) out[count++] = in[0];
-  if (d1 <= 0.0f) out[count++] = in[1];
-  if (d0 * d1 < 0.0f) {
+// b2ClipSegmentToLine for the only outcome the caller uses (two output points; anything else makes it return 0 points):
+//   both inputs behind the plane -> (in0, in1);  in0 behind, in1 in front -> (in0, intersection);  in1 behind, in0 in front ->
+//   (in1, intersection) — the order in which the reference appends them.  No arrays: see hb_v.
+__device__ __forceinline__ bool clip_segment2(ClipV& o0, ClipV& o1, const ClipV& i0, const ClipV& i1, V2 normal, float offset,
+                                              int vertex_index_a) {
+  const float d0 = dot2(normal, i0.v) - offset;
+  const float d1 = dot2(normal, i1.v) - offset;
+  const bool b0 = d0 <= 0.0f, b1 = d1 <= 0.0f, cross = d0 * d1 < 0.0f;
+  const int count = (b0 ? 1 : 0) + (b1 ? 1 : 0) + (cross ? 1 : 0);
+  if (count != 2) return false;                    // (three is impossible: both behind excludes a crossing)
+  ClipV x;
+  {
     const float interp = d0 / (d0 - d1);
-    out[count].v = v2(in[0].v.x + interp * (in[1].v.x - in[0].v.x), in[0].v.y + interp * (in[1].v.y - in[0].v.y));
-    out[count].ia = (unsigned)vertex_index_a;
-    out[count].ib = in[0].ib;
-    out[count].ta = 0;      // e_vertex
-    out[count].tb = 1;      // e_face
-    ++count;
+    x.v = v2(i0.v.x + interp * (i1.v.x - i0.v.x), i0.v.y + interp * (i1.v.y - i0.v.y));
+    x.ia = (unsigned)vertex_index_a;
+    x.ib = i0.ib;
+    x.ta = 0;      // e_vertex
+    x.tb = 1;      // e_face
   }
-  return count;
+  o0 = b0 ? i0 : i1;
+  o1 = (b0 && b1) ? i1 : x;
+  return true;
 }
 // b2CollidePolygons into the contact record m (point impulses are set by the caller); returns the point count
-__device__ int collide_boxes(float* m, const Box& A, Xf xfA, const Box& B, Xf xfB) {
+__device__ int collide_boxes(float* m, const Box& A_, Xf xfA, const Box& B_, Xf xfB) {
+  const HBox A = hbox_of(A_), B = hbox_of(B_);
   const float total_radius = B2_POLY_RADIUS + B2_POLY_RADIUS;
   int edgeA = 0, edgeB = 0;
   const float sepA = find_max_separation(&edgeA, A, xfA, B, xfB);
@@ -381,25 +399,27 @@ __device__ int collide_boxes(float* m, const Box& A, Xf xfA, const Box& B, Xf xf
   if (sepB > total_radius) return 0;
   const float k_tol = 0.1f * B2_LINEAR_SLOP;
   const bool flip = sepB > sepA + k_tol;
-  const Box& p1 = flip ? B : A;
-  const Box& p2 = flip ? A : B;
+  HBox p1, p2;
+  p1.hx = flip ? B.hx : A.hx; p1.hy = flip ? B.hy : A.hy;
+  p2.hx = flip ? A.hx : B.hx; p2.hy = flip ? A.hy : B.hy;
   const Xf xf1 = flip ? xfB : xfA, xf2 = flip ? xfA : xfB;
   const int edge1 = flip ? edgeB : edgeA;
-  ClipV inc[2];
+  ClipV inc0, inc1;
   {
-    const V2 normal1 = rot_mulT(xf2.q, rot_mul(xf1.q, p1.n[edge1]));
+    const V2 normal1 = rot_mulT(xf2.q, rot_mul(xf1.q, hb_n(edge1)));
     int index = 0;
     float min_dot = B2_FLT_MAX;
+#pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float d = dot2(normal1, p2.n[i]);
+      const float d = dot2(normal1, hb_n(i));
       if (d < min_dot) { min_dot = d; index = i; }
     }
     const int i1 = index, i2 = i1 + 1 < 4 ? i1 + 1 : 0;
-    inc[0].v = xf_mul(xf2, p2.v[i1]); inc[0].ia = (unsigned)edge1; inc[0].ib = (unsigned)i1; inc[0].ta = 1; inc[0].tb = 0;
-    inc[1].v = xf_mul(xf2, p2.v[i2]); inc[1].ia = (unsigned)edge1; inc[1].ib = (unsigned)i2; inc[1].ta = 1; inc[1].tb = 0;
+    inc0.v = xf_mul(xf2, hb_v(p2, i1)); inc0.ia = (unsigned)edge1; inc0.ib = (unsigned)i1; inc0.ta = 1; inc0.tb = 0;
+    inc1.v = xf_mul(xf2, hb_v(p2, i2)); inc1.ia = (unsigned)edge1; inc1.ib = (unsigned)i2; inc1.ta = 1; inc1.tb = 0;
   }
   const int iv1 = edge1, iv2 = edge1 + 1 < 4 ? edge1 + 1 : 0;
-  V2 v11 = p1.v[iv1], v12 = p1.v[iv2];
+  V2 v11 = hb_v(p1, iv1), v12 = hb_v(p1, iv2);
   V2 lt = v2(v12.x - v11.x, v12.y - v11.y);
   {
     const float len = sqrtf(lt.x * lt.x + lt.y * lt.y);
@@ -414,21 +434,21 @@ __device__ int collide_boxes(float* m, const Box& A, Xf xfA, const Box& B, Xf xf
   const float front_offset = dot2(normal, v11);
   const float side1 = -dot2(tangent, v11) + total_radius;
   const float side2 = dot2(tangent, v12) + total_radius;
-  ClipV c1[2], c2[2];
-  int np = clip_segment(c1, inc, v2(-tangent.x, -tangent.y), side1, iv1);
-  if (np < 2) return 0;
-  np = clip_segment(c2, c1, tangent, side2, iv2);
-  if (np < 2) return 0;
+  ClipV c10, c11, c20, c21;
+  if (!clip_segment2(c10, c11, inc0, inc1, v2(-tangent.x, -tangent.y), side1, iv1)) return 0;
+  if (!clip_segment2(c20, c21, c10, c11, tangent, side2, iv2)) return 0;
   m[CS_LN] = local_normal.x; m[CS_LN + 1] = local_normal.y;
   m[CS_LP] = plane_point.x; m[CS_LP + 1] = plane_point.y;
   m[CS_TYPE] = flip ? 2.0f : 1.0f;                         // e_faceB : e_faceA
   int pc = 0;
+#pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const float separation = dot2(normal, c2[i].v) - front_offset;
+    const ClipV c = i == 0 ? c20 : c21;
+    const float separation = dot2(normal, c.v) - front_offset;
     if (separation <= total_radius) {
-      const V2 lp = xf_mulT(xf2, c2[i].v);
+      const V2 lp = xf_mulT(xf2, c.v);
       m[5 * pc + 0] = lp.x; m[5 * pc + 1] = lp.y;
-      unsigned ia = c2[i].ia, ib = c2[i].ib, ta = c2[i].ta, tb = c2[i].tb;
+      unsigned ia = c.ia, ib = c.ib, ta = c.ta, tb = c.tb;
       if (flip) { unsigned t = ia; ia = ib; ib = t; t = ta; ta = tb; tb = t; }
       m[5 * pc + 4] = __uint_as_float(ia | (ib << 8) | (ta << 16) | (tb << 24));
       ++pc;
