@@ -2,9 +2,11 @@
 
 Rolls three full-size scenarios (64 vehicles x 512 polylines x 90 steps) once on a single stream and then `runs` times with two
 lanes and the chosen side-stream switches; every run must reproduce the single-stream tokens and trajectories bit for bit.
-    python tools/stress_streams.py [runs=12] [p2=0] [tail=0] [cached=0]
+    python tools/stress_streams.py [runs=12] [p2=0] [tail=0] [cached=0] [kernels=111]
 With all switches 0 (the defaults) 40 of 40 runs were identical on MI355X; with p2=1 about one run in three was not."""
+import ctypes as C
 import sys
+import threading
 
 sys.path.insert(0, '.')
 import numpy as np
@@ -16,20 +18,46 @@ from ctrlsim_amd.engine import RolloutEngine
 
 runs = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 p2, tail, cached = (bool(int(sys.argv[i])) if len(sys.argv) > i else False for i in (2, 3, 4))
+# kernel selection (ctrlsim_set_option 0 / 1 / 3): "a g f" digits, e.g. 101 = split attention, f32 GEMMs, fused FFN flag on; default 111
+sel = sys.argv[5] if len(sys.argv) > 5 else "111"
+pollute = len(sys.argv) > 6 and bool(int(sys.argv[6]))
+f32 = sel[0] == "0"                                       # f32 attention has no compact contexts
 cfg = spec.make_cfg(nocturne__steps=90, nocturne__history_steps=1)
 d = spec.Dims(cfg)
 w = weights.generate(d, 0)
 scns = [scenarios.make_scenario(7, i, n_agents=64, n_polylines=512) for i in range(3)]
 model = None
+launches = [0]
+if pollute:
+    plib = C.CDLL("tools/microbench/variants/pollute.so")
+    sink = torch.zeros(4, dtype=torch.int32, device="cuda:0")
+    pst = torch.cuda.Stream()
 
 
 def run(lanes, p2, tail, cached):
     global model
-    eng = RolloutEngine(cfg, w, 'cuda:0', max_ctx=64, seed=3, model=model, lanes=lanes)
+    eng = RolloutEngine(cfg, w, 'cuda:0', max_ctx=64, seed=3, model=model, lanes=lanes, compact=not f32)
+    for key, ch in zip((0, 1, 3), sel):
+        eng.lib.ctrlsim_set_option(key, int(ch))
     model = eng.model
     eng.pass2_on_side, eng.tail_on_side, eng.cached_on_side = p2, tail, cached
     eng.load_scenarios(scns, steps=90)
+    stop = threading.Event()
+    if pollute and lanes > 1:
+        def loop():
+            k = 0
+            while not stop.is_set():
+                rc = plib.pollute_launch(C.c_void_p(sink.data_ptr()), k, 1024, C.c_void_p(pst.cuda_stream))
+                assert rc == 0, rc
+                k += 1
+                launches[0] += 1
+                if k % 8 == 0:
+                    pst.synchronize()
+        th = threading.Thread(target=loop); th.start()
     r = eng.run(90).results()
+    stop.set()
+    if pollute and lanes > 1:
+        th.join(); pst.synchronize()
     return r["tokens"].copy(), r["states"].copy()
 
 
@@ -41,4 +69,6 @@ for k in range(runs):
     ds = float(np.abs(ref[1] - b[1]).max())
     bad += nt > 0 or ds > 0
     print(f"run {k}: token differences {nt}, max |state difference| {ds}", flush=True)
+if pollute:
+    print(f"{launches[0]} polluter launches")
 print(f"{bad} of {runs} runs differ from the single-stream rollout (p2={int(p2)} tail={int(tail)} cached={int(cached)})")
