@@ -195,6 +195,42 @@ class PolicyEvaluator:
                 pos, heading, speed = gt_traj[i, :2], gt_traj[i, 2], gt_traj[i, 3]
         return {"pos": pos, "heading": heading, "speed": speed}
 
+    # ---- policy_evaluator.py:308-414
+    def find_interesting_pair(self, scn, gt_data_dict, moving):
+        """An ordered pair of moving vehicles whose goals are close in space and time, drawn with `random.choice` from every such
+        pair in row-major order (policy_evaluator.py:362-414); find_interesting_agent (:308-359) is its first element and draws
+        the same random number.  Goals are the relocated ones (last logged position of a vehicle that leaves the log, :326-331),
+        both trajectories must hold at least interesting_traj_len_threshold logged steps after the history.  None: no such pair."""
+        e = self.cfg.eval
+        ids = [v for v in range(scn.N) if v in moving]                 # `vehicles` order, moving ones only (:319-322)
+        if not ids:
+            return None
+        goals = np.zeros((len(ids), 2))
+        goal_t = np.zeros(len(ids), np.int64)
+        long_enough = np.zeros(len(ids), bool)
+        for k, v in enumerate(ids):
+            traj = np.array(gt_data_dict[v]["traj"])
+            pos, i_goal = scn.goal_pos[v].astype(np.float64), self.steps - 1
+            gone = np.where(traj[:, 4] == 0)[0]
+            if len(gone) > 0:
+                i_goal = gone[0] - 1
+                if np.linalg.norm(traj[i_goal, :2] - pos) > 0.0:
+                    pos = traj[i_goal, :2]
+            goals[k], goal_t[k] = pos, i_goal - self.history_steps
+            long_enough[k] = traj[self.history_steps:, 4].sum() >= e.interesting_traj_len_threshold
+        dist = np.linalg.norm(goals[None] - goals[:, None], 2, -1)
+        ok = (dist < e.interesting_goal_dist_threshold) & (dist > 0) & long_enough[:, None] & long_enough[None, :] & \
+             (np.abs(goal_t[:, None] - goal_t[None, :]) < e.interesting_timestep_diff_threshold)
+        pairs = list(zip(*np.where(ok)))
+        if not pairs:
+            return None
+        a, b = random.choice(pairs)
+        return [ids[a], ids[b]]
+
+    def find_interesting_agent(self, scn, gt_data_dict, moving):
+        pair = self.find_interesting_pair(scn, gt_data_dict, moving)
+        return None if pair is None else pair[0]
+
     def evaluate_policy(self):
         self.reset()
         n_done = 0
@@ -207,13 +243,16 @@ class PolicyEvaluator:
             for veh in vehicles:
                 veh.expert_control = False
                 veh.physics_simulated = True
-            if self.cfg.eval.eval_mode != "multi_agent":
-                # one_agent / two_agent pick vehicles with find_interesting_agent / find_interesting_pair
-                # (policy_evaluator.py:308-433, planner evaluation); running multi_agent under that name would evaluate a
-                # different vehicle set than the cfg asks for
-                raise NotImplementedError(f"eval_mode {self.cfg.eval.eval_mode!r}: only 'multi_agent' (policy_evaluator.py:450-454)")
-            thr = self.cfg.eval.multi_agent_eval_threshold
-            self.vehicles_to_evaluate = random.sample(moving, thr) if len(moving) > thr else moving
+            # policy_evaluator.py:448-466 — the only consumer of `random`: models seeded alike evaluate the same vehicles
+            mode = self.cfg.eval.eval_mode
+            if mode == "multi_agent":
+                thr = self.cfg.eval.multi_agent_eval_threshold
+                self.vehicles_to_evaluate = random.sample(moving, thr) if len(moving) > thr else moving
+            elif mode in ("one_agent", "two_agent"):
+                picked = self.find_interesting_pair(scn, gt_data_dict, moving)
+                self.vehicles_to_evaluate = [] if picked is None else (picked[:1] if mode == "one_agent" else picked)
+            else:
+                raise ValueError(f"eval_mode {mode!r}: one_agent, two_agent or multi_agent (cfgs/eval/base.yaml:13-14)")
             if not self.vehicles_to_evaluate:
                 continue
             n_done += 1

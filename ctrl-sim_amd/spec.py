@@ -89,6 +89,9 @@ POLICY = dict(
 EVAL = dict(
     seed=0, eval_mode="multi_agent", multi_agent_eval_threshold=8, history_steps=10, num_files_to_evaluate=1000,
     partitions=1, partition=0, visualize=False, verbose=False,
+    # one_agent / two_agent vehicle selection (find_interesting_agent / find_interesting_pair); the reference's base.yaml ships
+    # eval_mode: one_agent, the rollout metric of BASELINE.json is the multi_agent one
+    interesting_traj_len_threshold=60, interesting_goal_dist_threshold=10, interesting_timestep_diff_threshold=20,
 )
 
 # cfgs/eval_planner_adversary/base.yaml with cfgs/policy/ctrl_sim_{planner,adversary}.yaml mounted at .planner / .adversary

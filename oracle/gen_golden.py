@@ -425,6 +425,54 @@ def gen_metrics():
     save("metrics", **out)
 
 
+def interesting_cases():
+    """(tag, vehicles, history_steps, steps, seed for the goals / logs, seed handed to `random`)."""
+    return (("a", 14, 10, 90, 1, 0), ("b", 24, 10, 90, 2, 5), ("c", 9, 1, 90, 3, 2), ("none", 6, 10, 90, 4, 0))
+
+
+def gen_interesting():
+    """eval_mode one_agent / two_agent: the reference's find_interesting_agent / find_interesting_pair
+    (policy_evaluator.py:308-414) on goals and logs with close goals, short logs, early exits and stationary vehicles."""
+    import random as _random
+    import types as _t
+    _install_evaluator_stubs()
+    from evaluators.policy_evaluator import PolicyEvaluator
+    out = {}
+    for tag, N, hist, steps, seed, rseed in interesting_cases():
+        rng = np.random.default_rng(seed)
+        goals = rng.uniform(-40, 40, (N, 2)) if tag != "none" else np.arange(2 * N, dtype=np.float64).reshape(N, 2) * 30.0
+        for k in range(1, N if tag != "none" else 0, 3):           # clusters of close goals (some exactly equal: dist > 0 filter)
+            goals[k] = goals[k - 1] + (rng.uniform(-6, 6, 2) if k % 2 else 0.0)
+        traj = np.zeros((N, steps + 1, 6))
+        traj[..., :2] = goals[:, None] + rng.normal(0, 20, (N, 1, 2)) * np.linspace(1, 0, steps + 1)[None, :, None]
+        traj[..., 4] = 1.0
+        for v in range(N):
+            r = rng.random()
+            if r < 0.35:
+                traj[v, int(rng.integers(30, steps)):, 4] = 0.0     # leaves the log: goal relocates, goal timestep moves
+            elif r < 0.45:
+                traj[v, :int(rng.integers(hist + 5, 50)), 4] = 0.0  # appears late: fewer logged steps after the history
+        moving = [v for v in range(N) if rng.random() < 0.8]
+        ev = PolicyEvaluator.__new__(PolicyEvaluator)
+        ev.cfg = spec.make_cfg()
+        ev.steps, ev.history_steps, ev.vehicles_to_evaluate = steps, hist, list(moving)
+        vehs = [_t.SimpleNamespace(getID=(lambda v=v: v), target_position=_XY(float(goals[v, 0]), float(goals[v, 1]))) for v in range(N)]
+        gt = {v: {"traj": traj[v]} for v in range(N)}
+        picks_a, picks_p = [], []
+        for draw in range(6):
+            _random.seed(rseed + draw)
+            a = ev.find_interesting_agent(vehs, dict(gt))
+            _random.seed(rseed + draw)
+            pr = ev.find_interesting_pair(vehs, dict(gt))
+            picks_a.append(-1 if a is None else a)
+            picks_p.append([-1, -1] if pr is None else pr)
+        out[f"{tag}_goals"], out[f"{tag}_traj"], out[f"{tag}_moving"] = goals, traj, np.array(moving)
+        out[f"{tag}_cfg"] = np.array([hist, steps, rseed])
+        out[f"{tag}_agent"], out[f"{tag}_pair"] = np.array(picks_a), np.array(picks_p)
+        print(tag, "agents", picks_a, "pairs", picks_p)
+    save("interesting", **out)
+
+
 def gen_state_dict():
     """Names and shapes of the reference modules' state_dict() (the `state_dict` of the Lightning checkpoint that
     CtRLSim.load_from_checkpoint reads, models/ctrl_sim.py:19-25, eval_sim.py:52)."""
@@ -1241,7 +1289,7 @@ def gen_dt_loop():
 
 
 ALL = dict(model=gen_model, features=gen_features, sampling=gen_sampling, physics=gen_physics,
-           collision=gen_collision, closed_loop=gen_closed_loop, closed_loop_full=gen_closed_loop_full, metrics=gen_metrics, preprocessed=gen_preprocessed, ingest_gt=gen_ingest_gt, state_dict=gen_state_dict, bicycle=gen_bicycle, contacts=gen_contacts,
+           collision=gen_collision, closed_loop=gen_closed_loop, closed_loop_full=gen_closed_loop_full, metrics=gen_metrics, interesting=gen_interesting, preprocessed=gen_preprocessed, ingest_gt=gen_ingest_gt, state_dict=gen_state_dict, bicycle=gen_bicycle, contacts=gen_contacts,
            planner_adversary=gen_planner_adversary, ingest=gen_ingest,
            variants=gen_variants, dense_reward=gen_dense_reward, dt_loop=gen_dt_loop)
 

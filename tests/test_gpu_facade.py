@@ -234,3 +234,21 @@ def test_decision_transformer_policy_matches_reference_fixture():
     np.testing.assert_allclose(rt, g["loop_rtgs"], atol=1e-4, rtol=0)
     xs = np.array([[vdd[v]["position"][t]["x"] for t in range(steps + 1)] for v in range(n)])
     np.testing.assert_allclose(xs, g["loop_states"][:, :, 0], atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize("mode,n_eval", [("one_agent", 1), ("two_agent", 2)])
+def test_one_agent_and_two_agent_modes_hand_only_the_picked_vehicles_to_the_policy(mode, n_eval):
+    """cfgs/eval/base.yaml:13-14: the picked vehicle(s) are policy-controlled, every other vehicle replays its log
+    (policy_evaluator.py:455-466, 534-540)."""
+    cfg = cfg_of("loop")
+    cfg.eval.eval_mode = mode
+    cfg.eval.interesting_traj_len_threshold = 5          # 20-step scenes: the 60-step default would reject every vehicle
+    cfg.eval.interesting_goal_dist_threshold = 60
+    cfg.eval.seed = 1
+    cfg.eval["synthetic"] = dict(num_scenarios=2, n_agents=8, n_polylines=12, seed=11, extent=40.0)
+    model, policy = _make(cfg)
+    ev = PolicyEvaluator(cfg, policy)
+    m, _ = ev.evaluate_policy()
+    assert len(ev.vehicles_to_evaluate) == n_eval and len(set(ev.vehicles_to_evaluate)) == n_eval
+    assert all(np.isfinite(v) for v in m.values())
+    assert ev.acc.counts["goal"] == 2 * n_eval           # per evaluated vehicle and scenario (policy_evaluator.py:162-186)

@@ -81,3 +81,29 @@ def test_running_statistics_and_metrics_match_reference():
     # pack / unpack (the all-reduce payload) keeps them
     m2, _ = metrics.MetricAccumulators().unpack(acc.pack()).compute()
     assert m2 == m
+
+
+INTERESTING = (("a", 14), ("b", 24), ("c", 9), ("none", 6))      # oracle/gen_golden.py::interesting_cases
+
+
+@pytest.mark.parametrize("tag,N", INTERESTING)
+def test_one_agent_and_two_agent_selection_match_reference(tag, N):
+    """eval_mode one_agent / two_agent (cfgs/eval/base.yaml:13-14): find_interesting_agent / find_interesting_pair
+    (policy_evaluator.py:308-414) pick the same vehicles from the same `random` state."""
+    import random
+    import types
+    g = golden("interesting")
+    hist, steps, rseed = (int(x) for x in g[f"{tag}_cfg"])
+    ev = PolicyEvaluator.__new__(PolicyEvaluator)
+    ev.cfg, ev.steps, ev.history_steps = spec.make_cfg(), steps, hist
+    scn = types.SimpleNamespace(N=N, goal_pos=g[f"{tag}_goals"])
+    gt = {v: {"traj": g[f"{tag}_traj"][v]} for v in range(N)}
+    moving = [int(v) for v in g[f"{tag}_moving"]]
+    for draw in range(6):
+        random.seed(rseed + draw)
+        a = ev.find_interesting_agent(scn, gt, moving)
+        random.seed(rseed + draw)
+        pr = ev.find_interesting_pair(scn, gt, moving)
+        assert (-1 if a is None else a) == g[f"{tag}_agent"][draw]
+        assert list([-1, -1] if pr is None else pr) == list(g[f"{tag}_pair"][draw])
+    assert (g["none_agent"] == -1).all() and (g["b_agent"] >= 0).all()
