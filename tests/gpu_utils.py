@@ -8,6 +8,51 @@ from ctrlsim_amd import _lib
 DEV = "cuda:0"
 
 
+def build_pollute_lib():
+    """tests/pollute/pollute.hip -> tests/pollute/libpollute.so (hipcc cross-compiles without a GPU; __graft_entry__.build() calls
+    this so that the library travels to the GPU box prebuilt)."""
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pollute")
+    src, so = os.path.join(here, "pollute.hip"), os.path.join(here, "libpollute.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-o", so, src])
+    return so
+
+
+class Polluter:
+    """Context manager: launches pollute_kernel in a loop on its own stream from a host thread while the body runs (fresh waves of
+    the kernels under test then start on register files and LDS full of NaN patterns)."""
+
+    def __init__(self, blocks=1024):
+        self.lib = C.CDLL(build_pollute_lib())
+        self.sink = torch.zeros(4, dtype=torch.int32, device=DEV)
+        self.stream = torch.cuda.Stream()
+        self.blocks, self.launches = blocks, 0
+
+    def _loop(self):
+        k = 0
+        while not self._stop.is_set():
+            rc = self.lib.pollute_launch(C.c_void_p(self.sink.data_ptr()), k, self.blocks, C.c_void_p(self.stream.cuda_stream))
+            assert rc == 0, rc
+            k += 1
+            if k % 8 == 0:
+                self.stream.synchronize()
+        self.launches = k
+
+    def __enter__(self):
+        import threading
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._loop)
+        self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._th.join()
+        self.stream.synchronize()
+
+
 def dev(a, dt=None):
     t = torch.from_numpy(np.ascontiguousarray(a))
     if dt is not None:

@@ -1,7 +1,7 @@
-// Debug aid for tools/stress_streams.py: a kernel that leaves NaN / huge-integer patterns in every VGPR it can get and in
+// Test infrastructure (tests/test_gpu_sim_ctx.py, tools/stress_streams.py; NOT part of libctrlsim_hip.so): a kernel that leaves NaN / huge-integer patterns in every VGPR it can get and in
 // 64 KB of LDS, then exits.  Launched in a loop on its own stream during a rollout, it makes any kernel that reads a register
 // or LDS word it never wrote (fresh waves inherit whatever the previous occupant left) produce run-dependent results.
-//   hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o tools/microbench/variants/pollute.so tools/microbench/pollute.hip
+// Built by tests/gpu_utils.py::pollute_lib (hipcc --offload-arch=gfx950 -O3 -shared -fPIC) into tests/pollute/libpollute.so.
 #include <hip/hip_runtime.h>
 extern "C" __global__ __launch_bounds__(64) void pollute_kernel(unsigned* sink, unsigned seed) {
   extern __shared__ unsigned lds[];

@@ -14,7 +14,7 @@ import features_oracle as fo  # noqa: E402
 import rollout_oracle  # noqa: E402
 import sim_libs  # noqa: E402
 import synth_inputs  # noqa: E402
-from gpu_utils import DEV, dev  # noqa: E402
+from gpu_utils import DEV, dev, Polluter  # noqa: E402
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -449,7 +449,9 @@ def test_full_size_rollout_is_invariant_to_batching_and_cache():
     """BASELINE configs[2] shape (64 vehicles, 512 polylines x 100 points, 90 steps, full model): too large for the CPU oracle,
     so parity is carried by size-independent properties — a scenario's rollout must not depend on which other scenarios
     share its model batch, on how the batch is cut into forward chunks, on the scenario order, on the KV-cached phase or on the
-    number of engine lanes / streams:
+    number of engine lanes / streams, or on what the register files and LDS held before a kernel's waves started ("dirty": the
+    default run repeated while tests/pollute's kernel fills all 512 registers per lane and 64 KB of LDS per CU with NaN patterns
+    from a fourth stream — an uninitialised read anywhere in the step would show):
     tokens / RTG bins / collision flags bit-identical, trajectories bit-identical (every kernel is row-independent)."""
     cfg = cfg_of("full")
     cfg = spec.make_cfg(nocturne__steps=90, nocturne__history_steps=1)
@@ -461,24 +463,30 @@ def test_full_size_rollout_is_invariant_to_batching_and_cache():
     # "one_lane": a single lane has no side stream — every kernel in program order on one stream; the default two lanes run the
     # second pass, the simulator step and the cached steps on side streams ordered by events (a missing dependency would show here)
     for tag, order, max_ctx, cache, lanes in (("ref", [0, 1, 2], 64, True, 2), ("rechunk", [2, 0, 1], 24, True, 2),
-                                              ("nocache", [1, 2, 0], 64, False, 2), ("one_lane", [0, 1, 2], 64, True, 1)):
+                                              ("nocache", [1, 2, 0], 64, False, 2), ("one_lane", [0, 1, 2], 64, True, 1),
+                                              ("dirty", [0, 1, 2], 64, True, 2)):
         eng = RolloutEngine(cfg, w, DEV, max_ctx=max_ctx, seed=3, use_cache=cache, model=model, lanes=lanes)
         model = eng.model
         eng.load_scenarios([scns[i] for i in order], steps=90)
-        r = eng.run(90).results()
+        if tag == "dirty":
+            with Polluter() as pol:
+                r = eng.run(90).results()
+            assert pol.launches > 100
+        else:
+            r = eng.run(90).results()
         runs[tag] = {i: {k: (r[k][pos] if k != "n_groups" else r[k][:, pos]) for k in ("tokens", "rtg_bins", "states", "coll", "n_groups")}
                      for pos, i in enumerate(order)}
     for i in range(3):
         a = runs["ref"][i]
         assert np.isfinite(a["states"]).all() and a["tokens"].min() >= 0 and a["tokens"].max() < d.V
         assert a["n_groups"].min() >= 3          # 64 vehicles need at least ceil(64 / 24) focal groups
-        for tag in ("rechunk", "nocache", "one_lane"):
+        for tag in ("rechunk", "nocache", "one_lane", "dirty"):
             b = runs[tag][i]
             assert np.array_equal(a["n_groups"], b["n_groups"]), tag
             assert np.array_equal(a["tokens"], b["tokens"]), tag
             assert np.array_equal(a["rtg_bins"], b["rtg_bins"]), tag
             assert np.array_equal(a["coll"], b["coll"]), tag
-            if tag in ("rechunk", "one_lane"):
+            if tag in ("rechunk", "one_lane", "dirty"):
                 assert np.array_equal(a["states"], b["states"]), tag
             else:
                 np.testing.assert_allclose(a["states"], b["states"], atol=1e-4, rtol=0)

@@ -4,9 +4,7 @@ Rolls three full-size scenarios (64 vehicles x 512 polylines x 90 steps) once on
 lanes and the chosen side-stream switches; every run must reproduce the single-stream tokens and trajectories bit for bit.
     python tools/stress_streams.py [runs=12] [p2=0] [tail=0] [cached=0] [kernels=111]
 With all switches 0 (the defaults) 40 of 40 runs were identical on MI355X; with p2=1 about one run in three was not."""
-import ctypes as C
 import sys
-import threading
 
 sys.path.insert(0, '.')
 import numpy as np
@@ -29,10 +27,8 @@ scns = [scenarios.make_scenario(7, i, n_agents=64, n_polylines=512) for i in ran
 model = None
 launches = [0]
 if pollute:
-    plib = C.CDLL("tools/microbench/variants/pollute.so")
-    sink = torch.zeros(4, dtype=torch.int32, device="cuda:0")
-    pst = torch.cuda.Stream()
-
+    sys.path.insert(0, 'tests')
+    from gpu_utils import Polluter
 
 def run(lanes, p2, tail, cached):
     global model
@@ -42,22 +38,12 @@ def run(lanes, p2, tail, cached):
     model = eng.model
     eng.pass2_on_side, eng.tail_on_side, eng.cached_on_side = p2, tail, cached
     eng.load_scenarios(scns, steps=90)
-    stop = threading.Event()
     if pollute and lanes > 1:
-        def loop():
-            k = 0
-            while not stop.is_set():
-                rc = plib.pollute_launch(C.c_void_p(sink.data_ptr()), k, 1024, C.c_void_p(pst.cuda_stream))
-                assert rc == 0, rc
-                k += 1
-                launches[0] += 1
-                if k % 8 == 0:
-                    pst.synchronize()
-        th = threading.Thread(target=loop); th.start()
-    r = eng.run(90).results()
-    stop.set()
-    if pollute and lanes > 1:
-        th.join(); pst.synchronize()
+        with Polluter() as pol:
+            r = eng.run(90).results()
+        launches[0] += pol.launches
+    else:
+        r = eng.run(90).results()
     return r["tokens"].copy(), r["states"].copy()
 
 
