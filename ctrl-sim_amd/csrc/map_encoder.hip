@@ -143,11 +143,16 @@ __global__ __launch_bounds__(256) void map_pool_kernel(int NP, int P, MapClasses
   // ---- phase 3: thread = output channel j of head j>>5
   {
     const int j = tid, h = j >> 5;
-    for (int g = 0; g < g_here; ++g) {
-      float o = w.mb[j];
-      for (int c = 0; c < DM; ++c) o = fmaf(pooled[g][h][c], w.Mt[c * DM + j], o);
-      attn_pre[(size_t)(bp0 + g) * DM + j] = o;
+    // both polylines of the workgroup per pass over the folded matrix (its 256 KB come from L2 once, not once per polyline)
+    float o0 = w.mb[j], o1 = o0;
+#pragma unroll 8
+    for (int c = 0; c < DM; ++c) {
+      const float m = w.Mt[c * DM + j];
+      o0 = fmaf(pooled[0][h][c], m, o0);
+      o1 = fmaf(pooled[1][h][c], m, o1);
     }
+    attn_pre[(size_t)bp0 * DM + j] = o0;
+    if (g_here > 1) attn_pre[(size_t)(bp0 + 1) * DM + j] = o1;
   }
   if (tid < g_here) {
     const int bp = bp0 + tid;
