@@ -154,7 +154,8 @@ class _Lane:
         self.host_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.host_hist = None                                    # pinned [S, classes] int32, sized by load_scenarios
         self.side = torch.cuda.Stream(device=dev) if own_stream else None
-        self.ev_fwd, self.ev_ready, self.ev_p2, self.ev_p1 = (torch.cuda.Event() for _ in range(4))
+        self.ev_fwd, self.ev_ready, self.ev_p2, self.ev_p1, self.ev_sim = (torch.cuda.Event() for _ in range(5))
+        self.sim_in_flight = False                               # a simulator step of this lane may still run on its side stream
         self.pending = (0, 0, False)                             # scenario range (+ compare flag) of the read-back in flight
 
 
@@ -443,6 +444,19 @@ class RolloutEngine:
             L.ev_fwd.record(self._main)
             side.wait_event(L.ev_fwd)
         self.sim_step(t, s0=s0, s1=s1, stream=side.cuda_stream)
+        if L.side is not None:
+            L.ev_sim.record(side)
+            L.sim_in_flight = True
+
+    def _forward_waits(self, st):
+        """Before a forward pass is queued on stream st: the simulator steps of ALL lanes must have finished.  A lane's step may run
+        underneath the other lane's grouping / context kernels, but not underneath its matrix kernels — with that overlap
+        (provoked by delaying the simulator step, tools/stress_streams.py) rollouts stopped being reproducible.
+        In the natural timing the step is long finished when the forward starts and the wait costs nothing."""
+        for L2 in self.lanes:
+            if L2.sim_in_flight:
+                st.wait_event(L2.ev_sim)
+                L2.sim_in_flight = False
 
     def _main_waits(self, L):
         if L.side is not None:
@@ -500,6 +514,7 @@ class RolloutEngine:
             st = L.side.cuda_stream
         self._ctx_index(L, s0, s1, st)
         self._build_contexts(L, plan, t, Tq, tt_first, st)
+        self._forward_waits(L.side if st != self._main.cuda_stream else self._main)
         if n:
             _lib.check(lib.ctrlsim_dt_forward_pass1_cached_c(self.model.handle, n, Bs, As, cs, t, p(L.ws), p(L.rtg_logits), st),
                        "pass1_cached")
@@ -555,6 +570,7 @@ class RolloutEngine:
             plan, n, Bs, As, cs = self._class_plan(L, counts, Tq, Tq)
             self._ctx_index(L, s0, s1, st)
             self._build_contexts(L, plan, t, Tq, 0, st)
+            self._forward_waits(self._main)
             if n and d.VARIANT:                              # IL / Trajeglish: no RTG tokens, one forward (predict_rtgs False)
                 _lib.check(lib.ctrlsim_dt_forward_actions(self.model.handle, plan[0][0], Tq, cs, p(L.ws), p(L.act_logits), st),
                            "forward_actions")

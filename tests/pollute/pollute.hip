@@ -23,3 +23,14 @@ extern "C" int pollute_launch(unsigned* sink, unsigned seed, int blocks, hipStre
   hipLaunchKernelGGL(pollute_kernel, dim3(blocks), dim3(64), 65536, st, sink, seed);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+
+// one wave that waits `ticks` of the 100 MHz real-time counter: delays whatever follows it on its stream (tools/stress_streams.py)
+extern "C" __global__ void spin_kernel(unsigned long long ticks, unsigned* sink) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+  if (ticks == ~0ull) sink[1] = 1;
+}
+extern "C" int spin_launch(unsigned us, unsigned* sink, hipStream_t st) {
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st, (unsigned long long)us * 100ull, sink);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}

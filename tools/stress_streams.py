@@ -3,7 +3,8 @@
 Rolls three full-size scenarios (64 vehicles x 512 polylines x 90 steps) once on a single stream and then `runs` times with two
 lanes and the chosen side-stream switches; every run must reproduce the single-stream tokens and trajectories bit for bit.
     python tools/stress_streams.py [runs=12] [p2=0] [tail=0] [cached=0] [kernels=111]
-With all switches 0 (the defaults) 40 of 40 runs were identical on MI355X; with p2=1 about one run in three was not."""
+With all switches 0 (the defaults) 40 of 40 runs were identical on MI355X; with p2=1 about one run in three was not.
+sim_delay_us: before the engine's _forward_waits guard existed, 600-1500 us made 8 of 72 default-mode runs differ (0 of 72 with it)."""
 import sys
 
 sys.path.insert(0, '.')
@@ -19,6 +20,8 @@ p2, tail, cached = (bool(int(sys.argv[i])) if len(sys.argv) > i else False for i
 # kernel selection (ctrlsim_set_option 0 / 1 / 3): "a g f" digits, e.g. 101 = split attention, f32 GEMMs, fused FFN flag on; default 111
 sel = sys.argv[5] if len(sys.argv) > 5 else "111"
 pollute = len(sys.argv) > 6 and bool(int(sys.argv[6]))
+delay_us = int(sys.argv[7]) if len(sys.argv) > 7 else 0      # the simulator step waits this long on its stream first (it then
+                                                            # overlaps later kernels of the other lane's step)
 f32 = sel[0] == "0"                                       # f32 attention has no compact contexts
 cfg = spec.make_cfg(nocturne__steps=90, nocturne__history_steps=1)
 d = spec.Dims(cfg)
@@ -38,6 +41,18 @@ def run(lanes, p2, tail, cached):
     model = eng.model
     eng.pass2_on_side, eng.tail_on_side, eng.cached_on_side = p2, tail, cached
     eng.load_scenarios(scns, steps=90)
+    if delay_us and lanes > 1:
+        import ctypes as C
+        sys.path.insert(0, 'tests')
+        import gpu_utils
+        plib = C.CDLL(gpu_utils.build_pollute_lib())
+        sink = torch.zeros(4, dtype=torch.int32, device='cuda:0')
+        inner = eng.sim_step
+
+        def delayed(t, s0=0, s1=None, stream=None):
+            assert plib.spin_launch(delay_us, C.c_void_p(sink.data_ptr()), C.c_void_p(stream)) == 0
+            return inner(t, s0=s0, s1=s1, stream=stream)
+        eng.sim_step = delayed
     if pollute and lanes > 1:
         with Polluter() as pol:
             r = eng.run(90).results()
