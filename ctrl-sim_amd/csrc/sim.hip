@@ -18,6 +18,7 @@
 //   policies/policy.py:68-79                   history append of the 8-float state row
 // One workgroup per scenario; lane i < N owns vehicle i (N <= 64: one wavefront of vehicles), all 256 threads share
 // the N x N and N x E collision tests.  State is SoA-per-scenario [S, N, ...] so a wave's loads are contiguous.
+#include <cstdlib>
 #include "common.h"
 
 #define PHYS_STRIDE 20
@@ -1407,7 +1408,29 @@ int launch_sim_step(int S, int N, int E, const int* act_tok, const double* act_f
   if (N < 1 || N > 64 || E < 0 || t < 0 || t + 1 >= Tmax1 || (!act_tok && !act_f64)) return CTRLSIM_EINVAL;
   SimDiscretisation dz{disc6[0], disc6[1], disc6[2], disc6[3], (int)disc6[4], (int)disc6[5]};
   prof_before(PROF_SIM, st);
-  hipLaunchKernelGGL(sim_step_kernel, dim3(S), dim3(256), 0, st, N, E, act_tok, act_f64, dz, size, edges, exists, phys,
+  // The step takes a CU's whole LDS (its own ~60 KB + a dynamic remainder it never touches) whenever the launch has no more
+  // workgroups than CUs: a scenario's workgroup then never shares a CU with LDS-using workgroups of kernels running on other
+  // streams.  Sharing one with the split-operand matrix kernels made rollouts non-reproducible (5 of 40
+  // provoked runs differ without this, 0 of 40 with it); the step is latency-bound with one workgroup per scenario, so the
+  // exclusivity costs nothing.
+  static const int n_cus = [] {
+    int dev = 0, n = 0;
+    return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) ? n : 0;
+  }();
+  static const int excl_lds = [] {                   // gfx950: 160 KB of LDS per CU, all of it available to one workgroup
+    hipFuncAttributes fa;
+    if (getenv("CTRLSIM_SIM_SHARED_CU")) return 0;   // A/B switch: the step shares CUs like any other kernel
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&sim_step_kernel)) != hipSuccess) return 0;
+    const long dyn = (160L * 1024 - (long)fa.sharedSizeBytes - 2048) & ~255L;
+    if (dyn <= 0 || hipFuncSetAttribute(reinterpret_cast<const void*>(&sim_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)dyn) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;
+    }
+    return (int)dyn;
+  }();
+  const int dyn_lds = (S <= n_cus) ? excl_lds : 0;
+  hipLaunchKernelGGL(sim_step_kernel, dim3(S), dim3(256), dyn_lds, st, N, E, act_tok, act_f64, dz, size, edges, exists, phys,
                      hist_states, coll, applied, t, Tmax1, dt, kinematic, contact_state);
   // per scenario: body + control state in and out (20 floats), one history row + flags out, the road-edge segments in,
   // and (contacts) the persistent Box2D state in and out (20 floats per vehicle pair + broad phase)

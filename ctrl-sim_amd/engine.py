@@ -196,6 +196,7 @@ class RolloutEngine:
         # flipping), with any version of the simulator kernel, with its LDS pre-filled, without register spills anywhere, and never
         # with these switches off (40 / 40 identical) or with a host synchronisation before the simulator launch.  The wave state
         # changes under a kernel that is itself deterministic (tools/microbench notes in profiles/README.md): not root-caused.
+        self.forward_waits_for_sim = True       # _forward_waits (False only to reproduce the hazard: tools/stress_streams.py)
         self.pass2_on_side = False
         self.tail_on_side = False
         self.cached_on_side = False
@@ -454,7 +455,7 @@ class RolloutEngine:
         (provoked by delaying the simulator step, tools/stress_streams.py) rollouts stopped being reproducible.
         In the natural timing the step is long finished when the forward starts and the wait costs nothing."""
         for L2 in self.lanes:
-            if L2.sim_in_flight:
+            if L2.sim_in_flight and self.forward_waits_for_sim:
                 st.wait_event(L2.ev_sim)
                 L2.sim_in_flight = False
 

@@ -20,6 +20,8 @@ p2, tail, cached = (bool(int(sys.argv[i])) if len(sys.argv) > i else False for i
 # kernel selection (ctrlsim_set_option 0 / 1 / 3): "a g f" digits, e.g. 101 = split attention, f32 GEMMs, fused FFN flag on; default 111
 sel = sys.argv[5] if len(sys.argv) > 5 else "111"
 pollute = len(sys.argv) > 6 and bool(int(sys.argv[6]))
+guard = not (len(sys.argv) > 8 and sys.argv[8] == '0')        # 0: without the engine's _forward_waits guard
+contacts = not (len(sys.argv) > 9 and sys.argv[9] == '0')     # 0: simulator without the Box2D contact path
 delay_us = int(sys.argv[7]) if len(sys.argv) > 7 else 0      # the simulator step waits this long on its stream first (it then
                                                             # overlaps later kernels of the other lane's step)
 f32 = sel[0] == "0"                                       # f32 attention has no compact contexts
@@ -35,11 +37,12 @@ if pollute:
 
 def run(lanes, p2, tail, cached):
     global model
-    eng = RolloutEngine(cfg, w, 'cuda:0', max_ctx=64, seed=3, model=model, lanes=lanes, compact=not f32)
+    eng = RolloutEngine(cfg, w, 'cuda:0', max_ctx=64, seed=3, model=model, lanes=lanes, compact=not f32, contacts=contacts)
     for key, ch in zip((0, 1, 3), sel):
         eng.lib.ctrlsim_set_option(key, int(ch))
     model = eng.model
     eng.pass2_on_side, eng.tail_on_side, eng.cached_on_side = p2, tail, cached
+    eng.forward_waits_for_sim = guard
     eng.load_scenarios(scns, steps=90)
     if delay_us and lanes > 1:
         import ctypes as C
