@@ -20,6 +20,21 @@ def build_pollute_lib():
     return so
 
 
+def delay_simulator_steps(eng, delay_us):
+    """Every simulator step of `eng` first waits delay_us on its stream (tests/pollute's spin kernel): on a two-lane engine the
+    step then runs underneath LATER kernels of the other lane's policy step than it naturally would."""
+    lib = C.CDLL(build_pollute_lib())
+    sink = torch.zeros(4, dtype=torch.int32, device=DEV)
+    inner = eng.sim_step
+
+    def delayed(t, act_f64=None, s0=0, s1=None, stream=None):
+        st = _lib.stream_ptr() if stream is None else stream
+        assert lib.spin_launch(int(delay_us), C.c_void_p(sink.data_ptr()), C.c_void_p(st)) == 0
+        return inner(t, act_f64=act_f64, s0=s0, s1=s1, stream=stream)
+    eng.sim_step = delayed
+    eng._delay_sink = sink
+
+
 class Polluter:
     """Context manager: launches pollute_kernel in a loop on its own stream from a host thread while the body runs (fresh waves of
     the kernels under test then start on register files and LDS full of NaN patterns)."""

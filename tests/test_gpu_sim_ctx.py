@@ -14,7 +14,7 @@ import features_oracle as fo  # noqa: E402
 import rollout_oracle  # noqa: E402
 import sim_libs  # noqa: E402
 import synth_inputs  # noqa: E402
-from gpu_utils import DEV, dev, Polluter  # noqa: E402
+from gpu_utils import DEV, dev, Polluter, delay_simulator_steps  # noqa: E402
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -490,6 +490,28 @@ def test_full_size_rollout_is_invariant_to_batching_and_cache():
                 assert np.array_equal(a["states"], b["states"]), tag
             else:
                 np.testing.assert_allclose(a["states"], b["states"], atol=1e-4, rtol=0)
+
+
+def test_two_lane_rollout_is_reproducible_when_the_simulator_step_is_delayed():
+    """The timing that used to break reproducibility: a lane's simulator step held back by 0.6-1.5 ms on its
+    side stream would run underneath the OTHER lane's forward pass and share CUs with its matrix kernels — 8 of 72 such runs differed
+    from the single-stream rollout.  The engine makes a forward pass wait for every pending simulator step and the step takes its CU's
+    whole LDS; every delayed run must now reproduce the single-stream rollout bit for bit."""
+    cfg = spec.make_cfg(nocturne__steps=90, nocturne__history_steps=1)
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    scns = [scenarios.make_scenario(7, i, n_agents=64, n_polylines=512) for i in range(3)]
+    eng = RolloutEngine(cfg, w, DEV, max_ctx=64, seed=3, lanes=1)
+    eng.load_scenarios(scns, steps=90)
+    ref = eng.run(90).results()
+    for k, delay_us in enumerate((600, 1000, 1000, 1500, 1000, 800)):
+        e2 = RolloutEngine(cfg, w, DEV, max_ctx=64, seed=3, model=eng.model, lanes=2)
+        e2.load_scenarios(scns, steps=90)
+        delay_simulator_steps(e2, delay_us)
+        r = e2.run(90).results()
+        assert np.array_equal(ref["tokens"], r["tokens"]), (k, delay_us)
+        assert np.array_equal(ref["states"], r["states"]), (k, delay_us)
+        assert np.array_equal(ref["coll"], r["coll"]), (k, delay_us)
 
 
 @pytest.mark.parametrize("name", ["il", "trajeglish"])

@@ -45,17 +45,9 @@ def run(lanes, p2, tail, cached):
     eng.forward_waits_for_sim = guard
     eng.load_scenarios(scns, steps=90)
     if delay_us and lanes > 1:
-        import ctypes as C
         sys.path.insert(0, 'tests')
         import gpu_utils
-        plib = C.CDLL(gpu_utils.build_pollute_lib())
-        sink = torch.zeros(4, dtype=torch.int32, device='cuda:0')
-        inner = eng.sim_step
-
-        def delayed(t, s0=0, s1=None, stream=None):
-            assert plib.spin_launch(delay_us, C.c_void_p(sink.data_ptr()), C.c_void_p(stream)) == 0
-            return inner(t, s0=s0, s1=s1, stream=stream)
-        eng.sim_step = delayed
+        gpu_utils.delay_simulator_steps(eng, delay_us)
     if pollute and lanes > 1:
         with Polluter() as pol:
             r = eng.run(90).results()
