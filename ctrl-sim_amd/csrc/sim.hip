@@ -20,6 +20,22 @@
 // the N x N and N x E collision tests.  State is SoA-per-scenario [S, N, ...] so a wave's loads are contiguous.
 #include <cstdlib>
 #include "common.h"
+// -DSIM_JITTER (tools only): random per-wave stalls around every workgroup barrier of the step — a missing barrier / a data race
+// between the waves of a scenario's workgroup then shows as a run-to-run difference even with nothing else on the device
+#ifdef SIM_JITTER
+__device__ __forceinline__ void sim_jitter(int point) {
+  unsigned h = ((unsigned)__builtin_amdgcn_s_memtime() ^ ((threadIdx.x >> 6) * 0x9E3779B9u + point * 0x85EBCA6Bu)) * 2654435761u;
+  h = __builtin_amdgcn_readfirstlane(h);
+  if ((h >> 29) < 3) {
+    const int n = (h >> 20) & 15;
+    for (int k = 0; k < n; ++k) __builtin_amdgcn_s_sleep(100);
+  }
+}
+#define SYNCJ() do { sim_jitter(__LINE__); __syncthreads(); sim_jitter(__LINE__ + 4096); } while (0)
+#else
+#define SYNCJ() __syncthreads()
+#endif
+
 
 #define PHYS_STRIDE 20
 enum { P_CX = 0, P_CY, P_A, P_VX, P_VY, P_W, P_SLEEP, P_AWAKE, P_THR, P_BRK, P_STEER, P_LCX, P_LCY, P_PX, P_PY,
@@ -195,7 +211,7 @@ __device__ void collide_and_record(int s, int N, int E, const float* __restrict_
     row[6] = Wd;
     row[7] = exists[(size_t)s * N + tid] ? 1.0f : 0.0f;
   }
-  __syncthreads();
+  SYNCJ();
   SIMT(10)
   for (int p = tid; p < N * N; p += blockDim.x) {
     const int i = p / N, j = p - i * N;
@@ -227,7 +243,7 @@ __device__ void collide_and_record(int s, int N, int E, const float* __restrict_
     }
     if (tid == 0) { gbox[0] = m0; gbox[1] = m1; gbox[2] = m2; gbox[3] = m3; gany = m2 >= m0 ? 1 : 0; }
   }
-  __syncthreads();
+  SYNCJ();
   if (gany) {
     const float gx0 = gbox[0], gy0 = gbox[1];
     const float ihx = (float)GRID / fmaxf(gbox[2] - gx0, 1e-3f), ihy = (float)GRID / fmaxf(gbox[3] - gy0, 1e-3f);
@@ -241,7 +257,7 @@ __device__ void collide_and_record(int s, int N, int E, const float* __restrict_
           else atomicOr(&cell_hi[y * GRID + x], 1u << (tid - 32));
         }
     }
-    __syncthreads();
+    SYNCJ();
     for (int e = tid; e < E; e += blockDim.x) {
       const f32x4 sg = *reinterpret_cast<const f32x4*>(eg + (size_t)e * 4);
       const float s0 = fminf(sg[0], sg[2]), s1 = fminf(sg[1], sg[3]), s2 = fmaxf(sg[0], sg[2]), s3 = fmaxf(sg[1], sg[3]);
@@ -262,7 +278,7 @@ __device__ void collide_and_record(int s, int N, int E, const float* __restrict_
       }
     }
   }
-  __syncthreads();
+  SYNCJ();
   if (tid < N) {
     unsigned char* c = coll + (((size_t)s * N + tid) * Tmax1 + t_row) * 2;
     c[0] = (unsigned char)flag_veh[tid];
@@ -1178,7 +1194,7 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
     Tree T{fat + 12 * N, tail + 4};
     if (cs)
       for (int i = tid; i < n_tail; i += blockDim.x) tail_lds[i] = gtail[i];
-    __syncthreads();
+    SYNCJ();
     SIMT(0)
     if (cs) {
       if (tid == 0) {
@@ -1198,7 +1214,7 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
         __builtin_amdgcn_wave_barrier();
         if (tid == 0) tail[2] = 0.f;
       }
-      __syncthreads();
+      SYNCJ();
       SIMT(1)
       // ---- b2ContactManager::Collide / b2Contact::Update over the existing contacts (i < j: fixture A = i, B = j)
       for (int pr = tid; pr < NP; pr += blockDim.x) {
@@ -1238,7 +1254,7 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
         if (touching != was_touching) { wake[i] = 1; wake[j] = 1; }
         if (touching) { atomicOr(&B.adj[i], 1ull << j); atomicOr(&B.adj[j], 1ull << i); pair_stamp[pr] = m[CS_STAMP]; }
       }
-      __syncthreads();
+      SYNCJ();
       // pairs of two sleeping bodies were skipped above: their (unchanged) touching flag still links them
       for (int pr = tid; pr < NP; pr += blockDim.x) {
         int i = 0, rem = pr;
@@ -1251,10 +1267,10 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
       }
       // the loop above must see the awake flags the FIRST loop saw (it links exactly the pairs that one skipped): the wake-ups
       // are applied behind a barrier — without it a fast wave 0 could wake bodies while other waves still read the flags
-      __syncthreads();
+      SYNCJ();
       if (tid < N && wake[tid]) { B.awake[tid] = 1; B.sleep[tid] = 0.f; }     // b2Body::SetAwake(true)
       if (tid < N) { sweep0[3 * tid] = B.cx[tid]; sweep0[3 * tid + 1] = B.cy[tid]; sweep0[3 * tid + 2] = B.a[tid]; }
-      __syncthreads();
+      SYNCJ();
       SIMT(2)
     }
     // ---- islands of one body: integrate on their own lanes (b2Island::Solve without contacts)
@@ -1329,17 +1345,17 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
       }
       isl_count = n_isl;
     }
-    __syncthreads();
+    SYNCJ();
     if (cs && tid < isl_count) {
       const float dt_ratio = tail[0] * dt;
       const int b0 = isl_b0[tid], c0 = isl_c0[tid];
       island_solve(B, isl_bodies + b0, isl_nb[tid], isl_c + c0, isl_nc[tid], dt, dt_ratio, isl_pc + b0, isl_pa + b0, isl_vv + b0,
                    isl_vw + b0);
     }
-    __syncthreads();
+    SYNCJ();
     if (cs && tid == 0) tail[0] = dt > 0.0f ? 1.0f / dt : 0.0f;                                   // m_inv_dt0
     SIMT(4)
-    __syncthreads();
+    SYNCJ();
     if (cs) {
       // ---- b2Body::SynchronizeFixtures of every body that was in an island, then b2ContactManager::FindNewContacts
       if (tid < N && in_isl[tid]) {
@@ -1354,7 +1370,7 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
         }
         moved_now[tid] = synchronize_fixture(fat + 4 * tid, b, xf1, xf2) ? 1 : 0;
       }
-      __syncthreads();
+      SYNCJ();
       SIMT(5)
       if (tid == 0) {
         for (int b = N - 1; b >= 0; --b)                   // m_bodyList order: newest body first
@@ -1366,7 +1382,7 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
         find_new_contacts_wave(cs, tail, N, NP, T, isl_c, isl_stack);
         SIMT(7)
       }
-      __syncthreads();
+      SYNCJ();
       for (int i = tid; i < n_tail; i += blockDim.x) gtail[i] = tail_lds[i];
     }
     if (tid < N) {
@@ -1383,7 +1399,7 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
       p[P_HEADING] = hd[tid]; p[P_SPEED] = sp[tid];
     }
   }
-  __syncthreads();
+  SYNCJ();
   SIMT(8)
   collide_and_record(s, N, E, size, edges, exists, hist_states, coll, t + 1, Tmax1, corner, box, flag_veh, flag_edge, px,
                      py, hd, sp);

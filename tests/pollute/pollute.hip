@@ -34,3 +34,48 @@ extern "C" int spin_launch(unsigned us, unsigned* sink, hipStream_t st) {
   hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st, (unsigned long long)us * 100ull, sink);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+
+// Victim probe (tools/victim_probe.py): every workgroup fills `lds_bytes` of dynamic LDS and 48 registers per lane with a
+// pattern and keeps re-checking both for `ticks` of the 100 MHz counter, with workgroup barriers in between, while other
+// kernels' workgroups come and go on its CU.  log: [0] LDS mismatches, [1] register mismatches, then up to 64 records of
+// (block, word offset or register index, expected, got, iteration, kind).
+extern "C" __global__ __launch_bounds__(256) void victim_kernel(unsigned long long ticks, int lds_words, unsigned seed, unsigned* log) {
+  extern __shared__ unsigned vl[];
+  const unsigned tid = threadIdx.x, blk = blockIdx.x;
+  auto pat = [&](unsigned i) { return (seed ^ (blk * 0x9E3779B9u)) + i * 0x85EBCA6Bu; };
+  for (int i = tid; i < lds_words; i += 256) vl[i] = pat(i);
+  unsigned r[48];
+#pragma unroll
+  for (int k = 0; k < 48; ++k) { r[k] = pat(0x100000u + tid * 64 + k); asm volatile("" : "+v"(r[k])); }
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned it = 0;
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+    for (int i = tid; i < lds_words; i += 256) {
+      const unsigned got = vl[i], want = pat(i);
+      if (got != want) {
+        const unsigned n = atomicAdd(&log[0], 1u);
+        if (n < 48) { unsigned* e = log + 8 + 6 * n; e[0] = blk; e[1] = i; e[2] = want; e[3] = got; e[4] = it; e[5] = 0; }
+        vl[i] = want;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 48; ++k) {
+      asm volatile("" : "+v"(r[k]));
+      const unsigned want = pat(0x100000u + tid * 64 + k);
+      if (r[k] != want) {
+        const unsigned n = atomicAdd(&log[1], 1u);
+        if (n < 16) { unsigned* e = log + 8 + 6 * (48 + n); e[0] = blk; e[1] = tid * 64 + k; e[2] = want; e[3] = r[k]; e[4] = it; e[5] = 1; }
+        r[k] = want;
+      }
+    }
+    __syncthreads();
+    ++it;
+  }
+  if (tid == 0) atomicAdd(&log[2], it);
+}
+extern "C" int victim_launch(unsigned ms, int blocks, int lds_bytes, unsigned seed, unsigned* log, hipStream_t st) {
+  if (hipFuncSetAttribute((const void*)victim_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return -1;
+  hipLaunchKernelGGL(victim_kernel, dim3(blocks), dim3(256), lds_bytes, st, (unsigned long long)ms * 100000ull, lds_bytes / 4, seed, log);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
