@@ -760,6 +760,11 @@ struct BodyLds {
   unsigned long long adj[64];
 };
 
+// the touching graph: bit j of adj[i] and bit i of adj[j]
+__device__ __forceinline__ void adj_link(BodyLds& B, int i, int j) {
+  atomicOr(&B.adj[i], 1ull << j);
+  atomicOr(&B.adj[j], 1ull << i);
+}
 // one island with contacts, solved by a single lane (b2Island::Solve + b2ContactSolver)
 struct Constraint {
   int ia, ib, count, vcount;
@@ -1252,7 +1257,7 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
         const bool touching = cnt > 0;
         m[CS_TOUCH] = touching ? 1.f : 0.f;
         if (touching != was_touching) { wake[i] = 1; wake[j] = 1; }
-        if (touching) { atomicOr(&B.adj[i], 1ull << j); atomicOr(&B.adj[j], 1ull << i); pair_stamp[pr] = m[CS_STAMP]; }
+        if (touching) { adj_link(B, i, j); pair_stamp[pr] = m[CS_STAMP]; }
       }
       SYNCJ();
       // pairs of two sleeping bodies were skipped above: their (unchanged) touching flag still links them
@@ -1261,7 +1266,7 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
         while (rem >= N - 1 - i) { rem -= N - 1 - i; ++i; }
         const int j = i + 1 + rem;
         if (!B.awake[i] && !B.awake[j] && cs[(size_t)pr * CS_STRIDE + CS_TOUCH] != 0.f) {
-          atomicOr(&B.adj[i], 1ull << j); atomicOr(&B.adj[j], 1ull << i);
+          adj_link(B, i, j);
           pair_stamp[pr] = cs[(size_t)pr * CS_STRIDE + CS_STAMP];
         }
       }

@@ -47,6 +47,17 @@ if agg == "gemm_ln":
     f = make(W, True, True)
 elif agg == "gemm":
     f = make(W3, False, False)
+elif agg == "rollout":            # the whole closed-loop step (every kernel of the forward pass) on the main stream
+    from ctrlsim_amd import spec, weights, scenarios
+    from ctrlsim_amd.engine import RolloutEngine
+    cfg = spec.make_cfg(nocturne__steps=90, nocturne__history_steps=1)
+    eng = RolloutEngine(cfg, weights.generate(spec.Dims(cfg), 0), DEV, max_ctx=64, seed=3, lanes=1)
+    eng.load_scenarios([scenarios.make_scenario(7, i, n_agents=64, n_polylines=512) for i in range(3)], steps=90)
+
+    def f():
+        eng.reset(0, 3)
+        eng.run(90)
+        return None
 elif agg == "none":
     f = lambda: None
 else:
