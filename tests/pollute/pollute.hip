@@ -60,13 +60,30 @@ extern "C" __global__ __launch_bounds__(256) void victim_kernel(unsigned long lo
       }
     }
 #pragma unroll
-    for (int k = 0; k < 48; ++k) {
+    for (int k = 1; k < 48; ++k) {
       asm volatile("" : "+v"(r[k]));
       const unsigned want = pat(0x100000u + tid * 64 + k);
       if (r[k] != want) {
         const unsigned n = atomicAdd(&log[1], 1u);
         if (n < 16) { unsigned* e = log + 8 + 6 * (48 + n); e[0] = blk; e[1] = tid * 64 + k; e[2] = want; e[3] = r[k]; e[4] = it; e[5] = 1; }
         r[k] = want;
+      }
+    }
+    // arithmetic check: a chain of the operations the simulator's narrow phase uses (sqrt, IEEE division, sin / cos, fma) on
+    // fixed inputs must give the same bits every time
+    {
+      float acc = 0.f;
+#pragma unroll 4
+      for (int k = 0; k < 16; ++k) {
+        const float a = 1.0f + (float)((pat(k + tid) >> 8) & 0xFFFF) * (1.0f / 1024.0f);
+        const float c = sinf(a) * cosf(a * 0.37f) + sqrtf(a) / (a + 0.25f);
+        acc = fmaf(acc, 0.75f, c);
+      }
+      const unsigned bits = __float_as_uint(acc);
+      if (it == 0) r[0] = bits ^ pat(0x100000u + tid * 64);       // remember (register slot 0 holds pattern ^ first result)
+      else if ((r[0] ^ pat(0x100000u + tid * 64)) != bits) {
+        const unsigned n = atomicAdd(&log[3], 1u);
+        if (n < 16) { unsigned* e = log + 8 + 6 * (48 + n); e[0] = blk; e[1] = tid; e[2] = r[0] ^ pat(0x100000u + tid * 64); e[3] = bits; e[4] = it; e[5] = 2; }
       }
     }
     __syncthreads();

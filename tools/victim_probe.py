@@ -77,7 +77,7 @@ while not ev.query():
 torch.cuda.synchronize()
 l = log.cpu().numpy().view(np.uint32)
 print(f"aggressor {agg}: {n} launches beside a {kb} KB victim for {ms} ms; victim iterations {l[2]}, LDS mismatches {l[0]}, "
-      f"register mismatches {l[1]}; aggressor outputs that differ from a solo run: {bad}")
+      f"register mismatches {l[1]}, arithmetic mismatches {l[3]}; aggressor outputs that differ from a solo run: {bad}")
 for k in range(min(int(l[0]), 48)):
     e = l[8 + 6 * k: 14 + 6 * k]
     print(f"  LDS  block {e[0]} word {e[1]} want {e[2]:#010x} got {e[3]:#010x} iteration {e[4]}")
