@@ -39,7 +39,7 @@ extern "C" int spin_launch(unsigned us, unsigned* sink, hipStream_t st) {
 // pattern and keeps re-checking both for `ticks` of the 100 MHz counter, with workgroup barriers in between, while other
 // kernels' workgroups come and go on its CU.  log: [0] LDS mismatches, [1] register mismatches, then up to 64 records of
 // (block, word offset or register index, expected, got, iteration, kind).
-extern "C" __global__ __launch_bounds__(256) void victim_kernel(unsigned long long ticks, int lds_words, unsigned seed, unsigned* log) {
+extern "C" __global__ __launch_bounds__(256) void victim_kernel(unsigned long long ticks, int lds_words, unsigned seed, unsigned* log, float* gbuf) {
   extern __shared__ unsigned vl[];
   const unsigned tid = threadIdx.x, blk = blockIdx.x;
   auto pat = [&](unsigned i) { return (seed ^ (blk * 0x9E3779B9u)) + i * 0x85EBCA6Bu; };
@@ -86,13 +86,34 @@ extern "C" __global__ __launch_bounds__(256) void victim_kernel(unsigned long lo
         if (n < 16) { unsigned* e = log + 8 + 6 * (48 + n); e[0] = blk; e[1] = tid; e[2] = r[0] ^ pat(0x100000u + tid * 64); e[3] = bits; e[4] = it; e[5] = 2; }
       }
     }
+    // global-memory hand-over between the waves of the workgroup, the way sim_step's contact records travel: thread t writes
+    // 20-float records t, t + 256, ... of the block's slab, a barrier, then reads the records of thread t + 64 (the next wave)
+    if (gbuf) {
+      float* slab = gbuf + (size_t)blk * 2048 * 20;
+      for (int rec = tid; rec < 2048; rec += 256) {
+        float* m = slab + rec * 20;
+        float old0 = m[0];
+        for (int z = 0; z < 20; ++z) m[z] = (float)(it * 7 + rec + z);
+        if (it > 0 && old0 != (float)((it - 1) * 7 + rec)) atomicAdd(&log[5], 1u);
+      }
+      __syncthreads();
+      for (int rec = (tid + 64) & 255; rec < 2048; rec += 256) {
+        const float* m = slab + rec * 20;
+        bool ok = true;
+        for (int z = 0; z < 20; ++z) ok = ok && m[z] == (float)(it * 7 + rec + z);
+        if (!ok) {
+          const unsigned n = atomicAdd(&log[4], 1u);
+          if (n < 8) { unsigned* e = log + 8 + 6 * (56 + n); e[0] = blk; e[1] = rec; e[2] = it; e[3] = __float_as_uint(m[0]); e[4] = __float_as_uint(m[19]); e[5] = 3; }
+        }
+      }
+    }
     __syncthreads();
     ++it;
   }
   if (tid == 0) atomicAdd(&log[2], it);
 }
-extern "C" int victim_launch(unsigned ms, int blocks, int lds_bytes, unsigned seed, unsigned* log, hipStream_t st) {
+extern "C" int victim_launch(unsigned ms, int blocks, int lds_bytes, unsigned seed, unsigned* log, float* gbuf, hipStream_t st) {
   if (hipFuncSetAttribute((const void*)victim_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) return -1;
-  hipLaunchKernelGGL(victim_kernel, dim3(blocks), dim3(256), lds_bytes, st, (unsigned long long)ms * 100000ull, lds_bytes / 4, seed, log);
+  hipLaunchKernelGGL(victim_kernel, dim3(blocks), dim3(256), lds_bytes, st, (unsigned long long)ms * 100000ull, lds_bytes / 4, seed, log, gbuf);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -66,7 +66,8 @@ f(); torch.cuda.synchronize()
 ref = f()
 ref = None if ref is None else ref.clone()
 torch.cuda.synchronize()
-assert lib.victim_launch(ms, 256, kb * 1024, 12345, C.c_void_p(log.data_ptr()), C.c_void_p(side.cuda_stream)) == 0
+gbuf = torch.zeros(256 * 2048 * 20, device=DEV)
+assert lib.victim_launch(ms, 256, kb * 1024, 12345, C.c_void_p(log.data_ptr()), C.c_void_p(gbuf.data_ptr()), C.c_void_p(side.cuda_stream)) == 0
 ev = torch.cuda.Event(); ev.record(side)
 n = bad = 0
 while not ev.query():
@@ -77,7 +78,7 @@ while not ev.query():
 torch.cuda.synchronize()
 l = log.cpu().numpy().view(np.uint32)
 print(f"aggressor {agg}: {n} launches beside a {kb} KB victim for {ms} ms; victim iterations {l[2]}, LDS mismatches {l[0]}, "
-      f"register mismatches {l[1]}, arithmetic mismatches {l[3]}; aggressor outputs that differ from a solo run: {bad}")
+      f"register mismatches {l[1]}, arithmetic mismatches {l[3]}, cross-wave global hand-over mismatches {l[4]} (own read-back {l[5]}); aggressor outputs that differ from a solo run: {bad}")
 for k in range(min(int(l[0]), 48)):
     e = l[8 + 6 * k: 14 + 6 * k]
     print(f"  LDS  block {e[0]} word {e[1]} want {e[2]:#010x} got {e[3]:#010x} iteration {e[4]}")
