@@ -230,8 +230,8 @@ int ctrlsim_build_context_c(int n, const int* B, const int* A, const ctrlsim_ctx
                             const int* grp_focal, const uint64_t* grp_ids, const float* hist_states, const int* hist_tok,
                             const int* hist_rtg, const double* goals, const float* types, const float* roads,
                             const float* road_types, const int* zero4, hipStream_t st) {
-  if (!out || !zero4 || !B || !A || n < 1 || n > 8) return CTRLSIM_EINVAL;
-  CtxOut o[8];
+  if (!out || !zero4 || !B || !A || n < 1 || n > MAXC) return CTRLSIM_EINVAL;
+  CtxOut o[MAXC];
   for (int k = 0; k < n; ++k)
     o[k] = CtxOut{out[k].st12, out[k].exist, out[k].goal5, out[k].act_tok, out[k].rtg_bin, out[k].tstep, out[k].slot_gid,
                   out[k].road_pts, out[k].road_types};

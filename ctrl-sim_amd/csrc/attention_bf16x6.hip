@@ -53,7 +53,7 @@ __device__ unsigned long long g_att_t[8];
 // PRE = true: K / V arrive already split, as per-(context, head, 64-key tile) images of exactly the LDS stage layout
 // (kv_split_kernel below; K = the image base, V / ldkv unused, kv_batch_stride = tiles per context): staging is six
 // 16-byte LDS-DMA pieces per thread and tile — no registers, no VALU, no ds_write.
-// One launch serves up to 8 CLASSES of contexts (uniform shape inside a class; the engine sorts the compact contexts of a model
+// One launch serves up to MAXC CLASSES of contexts (uniform shape inside a class; the engine sorts the compact contexts of a model
 // batch by slot count): the 1-D grid is the concatenation of the classes' (query block, head, context) grids and a workgroup
 // reads its class's shape from the table.  Offsets are in elements of the common Q / O / image / key_pad buffers.
 struct AttnClass {
@@ -63,7 +63,7 @@ struct AttnClass {
   int Lq, Lk, A, rep_keys, rep_pos0, qblocks, wg0;
   float log2m;
 };
-struct AttnBatch { int n; AttnClass c[8]; };
+struct AttnBatch { int n; AttnClass c[MAXC]; };
 
 template <int MODE, bool PRE>
 __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
@@ -637,9 +637,9 @@ int launch_kv_zero_tail(int B, int key0, int n, int nkt, void* img, hipStream_t 
   hipLaunchKernelGGL(kv_zero_tail_kernel, dim3(B * NHEAD), dim3(256), 0, st, n % KT6, tile, nkt, static_cast<op_t*>(img));
   return ctrlsim_launch_status();
 }
-// The same for up to 16 (class, key region) entries in ONE launch: entry e covers the images from tile tile0 on of B contexts
+// The same for up to 2 * MAXC (class, key region) entries in ONE launch: entry e covers the images from tile tile0 on of B contexts
 struct KvTailEntry { int wg0, nkt, tile, k0; long tile0; };
-struct KvTailBatch { int n; KvTailEntry e[16]; };
+struct KvTailBatch { int n; KvTailEntry e[2 * MAXC]; };
 __global__ __launch_bounds__(256) void kv_zero_tails_kernel(KvTailBatch tb, op_t* __restrict__ img) {
   constexpr int K_PLANE = KT6 * HD, V_PLANE = HD * KT6;
   int ei = 0;
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(256) void kv_zero_tails_kernel(KvTailBatch tb, op_t
   }
 }
 int launch_kv_zero_tails(int n, const KvTailHost* t, void* img, hipStream_t st) {
-  if (n < 0 || n > 16 || !img) return CTRLSIM_EINVAL;
+  if (n < 0 || n > 2 * MAXC || !img) return CTRLSIM_EINVAL;
   KvTailBatch tb;
   tb.n = 0;
   int wg = 0;
@@ -675,10 +675,10 @@ int launch_kv_zero_tails(int n, const KvTailHost* t, void* img, hipStream_t st) 
   return ctrlsim_launch_status();
 }
 
-// Rows mode for up to 8 classes in one launch: class c holds B contexts of R rows starting at row row0 of K / V (row stride ldkv,
+// Rows mode for up to MAXC classes in one launch: class c holds B contexts of R rows starting at row row0 of K / V (row stride ldkv,
 // context stride R * ldkv), written at key pos[r] of the images from tile tile0 on (nkt tiles per (context, head)).
 struct KvRowsClass { long g0, row0, tile0; const int* pos; int R, nkt; };
-struct KvRowsBatch { int n; KvRowsClass c[8]; };
+struct KvRowsBatch { int n; KvRowsClass c[MAXC]; };
 __global__ __launch_bounds__(256) void kv_split_rows_classes_kernel(const float* __restrict__ K, const float* __restrict__ V, int ldkv,
                                                                     KvRowsBatch kb, long total, op_t* __restrict__ img) {
   constexpr int K_PLANE = KT6 * HD, V_PLANE = HD * KT6;
@@ -712,7 +712,7 @@ __global__ __launch_bounds__(256) void kv_split_rows_classes_kernel(const float*
   }
 }
 int launch_kv_split_rows_classes(const float* K, const float* V, int ldkv, int n, const KvRowsHost* cls, void* img, hipStream_t st) {
-  if (n < 0 || n > 8 || !K || !V || !img || (ldkv & 3)) return CTRLSIM_EINVAL;
+  if (n < 0 || n > MAXC || !K || !V || !img || (ldkv & 3)) return CTRLSIM_EINVAL;
   KvRowsBatch kb;
   kb.n = 0;
   long total = 0;
@@ -783,14 +783,14 @@ int launch_attention_bf16x6(int mode, const float* Q, int ldq, long q_batch_stri
   return ctrlsim_launch_status();
 }
 
-// K / V from split images (launch_kv_split*), n classes of contexts in one launch (n <= 8).  Per class: nkt tiles per (context,
+// K / V from split images (launch_kv_split*), n classes of contexts in one launch (n <= MAXC).  Per class: nkt tiles per (context,
 // head) from tile img_tile0 of `img` on.  rep_keys > 0 (causal mask of the CtRL-Sim model only): compact contexts — Lk regular
 // keys in tiles [0, ceil(Lk / 64)), and rep_keys representative keys of multiplicity rep_mult in the tiles from
 // ceil(rep_pos0 / 64) on (see the kernel header); rep_pos0 >= Lk is the regular length of the full window (the K/V cache
 // layout); query positions (row index, or q_pos) >= rep_pos0 address the representative's own tokens.
 int launch_attention_classes(int mode, const float* Q, int ldq, const void* img, float* O, int ldo, const unsigned char* key_pad,
                              int n, const AttnClassHost* cls, hipStream_t st) {
-  if (n < 1 || n > 8 || !cls || (ldq & 3) || !img) return CTRLSIM_EINVAL;
+  if (n < 1 || n > MAXC || !cls || (ldq & 3) || !img) return CTRLSIM_EINVAL;
   if (mode < 0 || mode > 4 || (mode == MODE6_KEYPAD && !key_pad)) return CTRLSIM_EINVAL;
   const int variant = mode >= MODE6_CAUSAL ? mode - MODE6_CAUSAL : 0;
   mode = mode >= MODE6_CAUSAL ? MODE6_CAUSAL : MODE6_KEYPAD;

@@ -15,6 +15,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define HD 32            // head dim (hidden 256 / 8 heads)
 #define DM 256           // hidden dim
 #define NHEAD 8
+#ifndef MAXC
+#define MAXC 16          // context size classes per model batch / launch (class tables travel by value in the kernel arguments)
+#endif
 
 static inline int ctrlsim_launch_status() {
   hipError_t e = hipGetLastError();

@@ -183,20 +183,20 @@ __global__ __launch_bounds__(256) void ctx_index_kernel(int s0, int s1, int N, c
 }
 
 // Compact contexts (forward.hip: Shape): a context with n vehicles is evaluated with the smallest slot count of `sizes`
-// (ascending, nb <= 8, last = A) that is >= n + 1 — or A itself.  hist[s, k] = focal groups of scenario s that fall into
+// (ascending, nb <= MAXC, last = A) that is >= n + 1 — or A itself.  hist[s, k] = focal groups of scenario s that fall into
 // size class k: what the host needs (with n_groups) to cut a step into model batches.
 __device__ __forceinline__ int size_class(int n, const int* sizes, int nb) {
   int k = 0;
   while (k < nb - 1 && sizes[k] < n + 1) ++k;
   return k;
 }
-struct SizeClasses { int nb; int sizes[8]; };
+struct SizeClasses { int nb; int sizes[MAXC]; };
 __global__ __launch_bounds__(256) void group_size_hist_kernel(int S, int N, const int* __restrict__ n_groups,
                                                               const unsigned long long* __restrict__ grp_ids, SizeClasses sc,
                                                               int* __restrict__ hist) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= S) return;
-  int h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int h[MAXC] = {};
   for (int g = 0; g < n_groups[s]; ++g) ++h[size_class(__popcll(grp_ids[(size_t)s * N + g]), sc.sizes, sc.nb)];
   for (int k = 0; k < sc.nb; ++k) hist[(size_t)s * sc.nb + k] = h[k];
 }
@@ -214,14 +214,14 @@ __global__ __launch_bounds__(256) void ctx_index_classes_kernel(int s0, int s1, 
                                                                 int* __restrict__ ctx_of_group,   // [S, N] scratch
                                                                 int* __restrict__ own_ctx, int* __restrict__ own_slot,
                                                                 int* __restrict__ mem_ctx, int* __restrict__ mem_slot) {
-  __shared__ int scan[8][256];
-  __shared__ int total[8], start[8], row0[8], carry[8];
+  __shared__ int scan[MAXC][256];
+  __shared__ int total[MAXC], start[MAXC], row0[MAXC], carry[MAXC];
   const int ns = s1 - s0, tid = threadIdx.x, nb = sc.nb;
   // ---- class totals of the chunk
-  int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int cnt[MAXC] = {};
   for (int i = tid; i < ns; i += 256)
     for (int g = 0; g < n_groups[s0 + i]; ++g) ++cnt[size_class(__popcll(grp_ids[(size_t)(s0 + i) * N + g]), sc.sizes, nb)];
-  if (tid < 8) total[tid] = 0;
+  if (tid < MAXC) total[tid] = 0;
   __syncthreads();
   for (int k = 0; k < nb; ++k)
     if (cnt[k]) atomicAdd(&total[k], cnt[k]);
@@ -238,20 +238,20 @@ __global__ __launch_bounds__(256) void ctx_index_classes_kernel(int s0, int s1, 
   // ---- rounds of 256 scenarios, in scenario order
   for (int base = 0; base < ns; base += 256) {
     const int i = base + tid;
-    int mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int mine[MAXC] = {};
     if (i < ns)
       for (int g = 0; g < n_groups[s0 + i]; ++g) ++mine[size_class(__popcll(grp_ids[(size_t)(s0 + i) * N + g]), sc.sizes, nb)];
     for (int k = 0; k < nb; ++k) scan[k][tid] = mine[k];
     __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {          // inclusive Hillis-Steele scan per class
-      int v[8];
+      int v[MAXC];
       for (int k = 0; k < nb; ++k) v[k] = tid >= off ? scan[k][tid - off] : 0;
       __syncthreads();
       for (int k = 0; k < nb; ++k) scan[k][tid] += v[k];
       __syncthreads();
     }
     if (i < ns) {
-      int fill[8];
+      int fill[MAXC];
       for (int k = 0; k < nb; ++k) fill[k] = carry[k] + scan[k][tid] - mine[k];
       for (int g = 0; g < n_groups[s0 + i]; ++g) {
         const int k = size_class(__popcll(grp_ids[(size_t)(s0 + i) * N + g]), sc.sizes, nb);
@@ -291,10 +291,10 @@ struct CtxOut {
   float* road_types;      // [B, P, 8]
 };
 
-// Up to 8 classes of contexts (different slot counts A, separate output arrays) in ONE launch: class k holds the contexts
+// Up to MAXC classes of contexts (different slot counts A, separate output arrays) in ONE launch: class k holds the contexts
 // [c0[k], c0[k+1]) of the batch's context list.  One launch per class left most of the chip idle — a class of a model batch is
 // 50-150 contexts = workgroups, and a workgroup's float64 chain takes ~150 us whatever the grid.
-struct CtxBatch { int n; int c0[9]; int A[8]; CtxOut o[8]; };
+struct CtxBatch { int n; int c0[MAXC + 1]; int A[MAXC]; CtxOut o[MAXC]; };
 
 // One block per context.  Agent part: threads over (tt, slot).  Road part: two sweeps over P_all x NP points.
 // Window rows [tt_first, Tq) are emitted (Tn = Tq - tt_first rows per context): the cached incremental forward only needs
@@ -479,7 +479,7 @@ int launch_build_context_classes(int n, const int* Bk, const int* Ak, const CtxO
                                  const int* grp_focal, const unsigned long long* grp_ids, const float* hist_states,
                                  const int* hist_tok, const int* hist_rtg, const double* goals, const float* types,
                                  const float* roads, const float* rtypes, const int* zero4, hipStream_t st) {
-  if (n < 1 || n > 8 || N > 64 || Tq < 1 || tt_first < 0 || tt_first >= Tq) return CTRLSIM_EINVAL;
+  if (n < 1 || n > MAXC || N > 64 || Tq < 1 || tt_first < 0 || tt_first >= Tq) return CTRLSIM_EINVAL;
   CtxBatch cb;
   cb.n = 0; cb.c0[0] = 0;
   double bytes = 0.0;
@@ -523,10 +523,10 @@ int launch_groups_changed(int S, int N, const int* n_groups, const int* grp_foca
 int launch_group_size_hist(int S, int N, const int* n_groups, const unsigned long long* grp_ids, int nb, const int* sizes,
                            int* hist, hipStream_t st) {
   if (S <= 0) return CTRLSIM_OK;
-  if (!n_groups || !grp_ids || !sizes || !hist || nb < 1 || nb > 8) return CTRLSIM_EINVAL;
+  if (!n_groups || !grp_ids || !sizes || !hist || nb < 1 || nb > MAXC) return CTRLSIM_EINVAL;
   SizeClasses sc;
   sc.nb = nb;
-  for (int k = 0; k < 8; ++k) sc.sizes[k] = k < nb ? sizes[k] : 0;
+  for (int k = 0; k < MAXC; ++k) sc.sizes[k] = k < nb ? sizes[k] : 0;
   hipLaunchKernelGGL(group_size_hist_kernel, dim3((S + 255) / 256), dim3(256), 0, st, S, N, n_groups, grp_ids, sc, hist);
   return ctrlsim_launch_status();
 }
@@ -535,10 +535,10 @@ int launch_ctx_index_classes(int s0, int s1, int N, int A, const int* n_groups, 
                              int* ctx_row0, int* ctx_of_group, int* own_ctx, int* own_slot, int* mem_ctx, int* mem_slot,
                              hipStream_t st) {
   if (s1 <= s0) return CTRLSIM_OK;
-  if (nb < 1 || nb > 8 || !sizes || sizes[nb - 1] != A) return CTRLSIM_EINVAL;
+  if (nb < 1 || nb > MAXC || !sizes || sizes[nb - 1] != A) return CTRLSIM_EINVAL;
   SizeClasses sc;
   sc.nb = nb;
-  for (int k = 0; k < 8; ++k) sc.sizes[k] = k < nb ? sizes[k] : 0;
+  for (int k = 0; k < MAXC; ++k) sc.sizes[k] = k < nb ? sizes[k] : 0;
   hipLaunchKernelGGL(ctx_index_classes_kernel, dim3(1), dim3(256), 0, st, s0, s1, N, A, n_groups, grp_ids, own_g, mem_g, sc,
                      ctx_scn, ctx_grp, ctx_row0, ctx_of_group, own_ctx, own_slot, mem_ctx, mem_slot);
   return ctrlsim_launch_status();

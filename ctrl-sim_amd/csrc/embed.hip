@@ -43,7 +43,7 @@ struct EmbedTables {
 // A[k] slots (Areg[k] regular), L[k] / Lreg[k] token rows and M[k] scene rows per context; its token rows start at X row
 // xrow[k], its scene rows at srow[k], its (context, slot) goal rows at grow[k], its (context, step) timestep entries at trow[k].
 // The per-(context, step, slot) inputs (S2, exist, act_tok, rtg_bin) are indexed by the flat row.
-struct AsmClasses { int n; int row0[9]; int A[8], Areg[8], L[8], Lreg[8], M[8]; long xrow[8], srow[8], grow[8], trow[8]; };
+struct AsmClasses { int n; int row0[MAXC + 1]; int A[MAXC], Areg[MAXC], L[MAXC], Lreg[MAXC], M[MAXC]; long xrow[MAXC], srow[MAXC], grow[MAXC], trow[MAXC]; };
 
 __global__ __launch_bounds__(256) void assemble_tokens_classes_kernel(
     AsmClasses ac, int Tq, const float* __restrict__ S2, const float* __restrict__ Gp, const float* __restrict__ exist,
@@ -250,7 +250,7 @@ int launch_assemble_tokens_classes(int n, const int* B, const int* A, const int*
                                    const long* srow, const long* grow, int Tq, const float* S2,
                                    const float* Gp, const float* exist, const int* act_tok, const int* rtg_bin, const int* tstep,
                                    EmbedTables tb, float* X, float* src, int P, unsigned char* src_pad, hipStream_t st) {
-  if (n < 1 || n > 8) return CTRLSIM_EINVAL;
+  if (n < 1 || n > MAXC) return CTRLSIM_EINVAL;
   AsmClasses ac;
   ac.n = n; ac.row0[0] = 0;
   long tr = 0;

@@ -212,7 +212,7 @@ namespace {
 // mult = A - Areg padded slots of the reference's 24-slot layout (attention_bf16x6.hip: multiplicity of its keys).  A context's
 // L token rows: regular (tt, a < Areg, k) at (tt*Areg + a)*3 + k, representative (tt, k) at Lreg + 3*tt + k; its keys sit in
 // the tiles from key rep_k0 = 64*ceil(Lreg/64) on.  Actx == A: the plain layout (rep = 0).  Exact in real arithmetic.
-// A model BATCH is up to 8 classes (the engine sorts the contexts of a step by vehicle count); every row-wise kernel
+// A model BATCH is up to MAXC classes (the engine sorts the contexts of a step by vehicle count); every row-wise kernel
 // (Linear, LayerNorm, feed-forward) runs ONCE over the rows of all classes, the two shape-aware kernels (attention, the
 // K/V-image epilogue of the QKV projection) take a class table, the small index / gather kernels run per class.
 struct Shape {
@@ -240,13 +240,13 @@ struct Cls {
 struct Batch {
   bool contig = false;                    // the classes' context tensors lie back to back (ctx_contiguous): merged launches
   int n, Btot;
-  Cls c[8];
+  Cls c[MAXC];
   long rL, rS, rA, rM, rP, rQ, rN, tiles_dec, tiles_mem, isum, ksum;
 };
 // Tw: window steps of the row / image layout (T for the K/V-cached phase); Tn: window rows held by the context tensors
 int make_batch(const ctrlsim_dims& d, int n, const int* B, const int* A, const ctrlsim_ctx* ctx, int Tw, int Tn, int Rn_mul,
                Batch& bt) {
-  if (n < 1 || n > 8 || !B || !A || !ctx) return CTRLSIM_EINVAL;
+  if (n < 1 || n > MAXC || !B || !A || !ctx) return CTRLSIM_EINVAL;
   bt = Batch{};
   for (int k = 0; k < n; ++k) {
     if (B[k] <= 0) continue;
@@ -386,7 +386,7 @@ struct AttnCall {
   int Rn_mul;                    // Q_NEW: rows per context = Rn_mul * A
 };
 int attention(const ctrlsim_dims& d, const Batch& bt, const Ws& w, const AttnCall& a, hipStream_t st) {
-  AttnClassHost h[8];
+  AttnClassHost h[MAXC];
   for (int k = 0; k < bt.n; ++k) {
     const Cls& c = bt.c[k];
     const Shape& sh = c.sh;
@@ -432,7 +432,7 @@ int gemm_kv(const ctrlsim_dims& d, const Batch& bt, const Ws& w, const Lin& L, c
             void* img, bool mem, hipStream_t st) {
   const long rows = mem ? bt.rM : bt.rL;
   bool fused = presplit() && L.w3() && ctrlsim_option(OPT_GEMM_IMPL) == 1;
-  KvClassHost kc[8];
+  KvClassHost kc[MAXC];
   for (int k = 0; k < bt.n; ++k) {
     const Cls& c = bt.c[k];
     const int Lk = mem ? c.M : c.L, Lreg = mem ? c.M : c.Lreg;
@@ -442,7 +442,7 @@ int gemm_kv(const ctrlsim_dims& d, const Batch& bt, const Ws& w, const Lin& L, c
   }
   const size_t KIMG = split_kimg();      // 16-bit elements per tile
   if (fused) {
-    KvTailHost tails[16];
+    KvTailHost tails[2 * MAXC];
     int nt = 0;
     for (int k = 0; k < bt.n; ++k) {                  // the epilogue writes rows: the tails of the last tiles of both key regions stay
       tails[nt++] = KvTailHost{kc[k].B, 0, kc[k].Lreg, kc[k].nkt, kc[k].tile0};
@@ -547,8 +547,8 @@ int scene_side(const ctrlsim_model* m, const Batch& bt, const Ws& w, float* dbg_
   const int P = d.P, rM = (int)bt.rM, rP = (int)bt.rP;
   // ---- map encoder (map_encoder.py:34-53): rows of `src` 0..P-1 per context
   if (bt.contig) {
-    int Bk[8], Mk[8];
-    long pad0[8];
+    int Bk[MAXC], Mk[MAXC];
+    long pad0[MAXC];
     for (int k = 0; k < bt.n; ++k) { Bk[k] = bt.c[k].B; Mk[k] = bt.c[k].M; pad0[k] = bt.c[k].rM; }
     CHK(launch_map_pool_classes(bt.n, Bk, Mk, pad0, P, d.NP, bt.c[0].ctx->road_pts, m->mp, w.attn_pre, w.src_pad, st));
     CHK(launch_in_mlp(bt.c[0].ctx->road_types, 8, 8, m->road_type.l0.w, m->road_type.l0.b, m->road_type.ln.g, m->road_type.ln.b,
@@ -629,8 +629,8 @@ int embed_inputs(const ctrlsim_model* m, const Batch& bt, const Ws& w, int Tn, b
 extern "C" int64_t ctrlsim_forward_workspace_bytes_c(const ctrlsim_dims* d, int n, const int* B, const int* A, int Tq) {
   if (!d || Tq < 1 || Tq > d->T) return CTRLSIM_EINVAL;
   Batch bt;
-  ctrlsim_ctx dummy[8] = {};
-  if (n < 1 || n > 8 || make_batch(*d, n, B, A, dummy, Tq, Tq, 4, bt) != CTRLSIM_OK) return CTRLSIM_EINVAL;
+  ctrlsim_ctx dummy[MAXC] = {};
+  if (n < 1 || n > MAXC || make_batch(*d, n, B, A, dummy, Tq, Tq, 4, bt) != CTRLSIM_OK) return CTRLSIM_EINVAL;
   return (int64_t)carve(*d, bt, nullptr).bytes;
 }
 extern "C" int64_t ctrlsim_forward_workspace_bytes_a(const ctrlsim_dims* d, int B, int Tq, int Actx) {
@@ -663,8 +663,8 @@ int forward_full(const ctrlsim_model* m, int n, const int* Bk, const int* Ak, co
   // ---- token embeddings (encoder.py:95-153)
   CHK(embed_inputs(m, bt, w, Tq, true, st));
   if (bt.contig) {
-    int Bk[8], Ak[8], Ar[8], Mk[8];
-    long xrow[8], srow[8], grow[8];
+    int Bk[MAXC], Ak[MAXC], Ar[MAXC], Mk[MAXC];
+    long xrow[MAXC], srow[MAXC], grow[MAXC];
     for (int k = 0; k < bt.n; ++k) {
       const Cls& c = bt.c[k];
       Bk[k] = c.B; Ak[k] = c.sh.A; Ar[k] = c.sh.Areg; Mk[k] = c.M; xrow[k] = c.rL; srow[k] = c.rM; grow[k] = c.rA;
@@ -796,7 +796,7 @@ extern "C" int ctrlsim_dt_forward_pass2_c(const ctrlsim_model* m, int n, const i
     CHK(gemm(Ld.qkv, w.xc2, DM, nullptr, 0, w.qkvc, 3 * DM, rQ, 3 * DM, DM, 0, st));
     CHK(launch_row_copy(w.qkvc, 3 * DM, w.qkv[i], 3 * DM, w.idx_rtg, rQ, 3 * DM, 1, st));   // refresh the rtg rows' K/V
     if (presplit()) {
-      KvRowsHost kr[8];
+      KvRowsHost kr[MAXC];
       for (int k = 0; k < bt.n; ++k) {
         const Cls& c = bt.c[k];
         kr[k] = KvRowsHost{c.B, c.sh.Areg, c.nkt_dec, c.rQ, c.tile_dec, w.pos_rtg + c.ioff};
@@ -884,7 +884,7 @@ extern "C" int ctrlsim_dt_forward_pass1_cached_c(const ctrlsim_model* m, int n, 
       if (t == 0) {   // image tiles are read whole: stale bits beyond the written rows must at least be finite
         if (hipMemsetAsync(w.img_dec[i], 0, w.img_dec_bytes, st) != hipSuccess) return CTRLSIM_ELAUNCH;
       }
-      KvRowsHost kr[8];
+      KvRowsHost kr[MAXC];
       for (int k = 0; k < bt.n; ++k) {
         const Cls& c = bt.c[k];
         kr[k] = KvRowsHost{c.B, mul * c.sh.A, c.nkt_dec, c.rN, c.tile_dec, w.key_new + 4 * c.ioff};

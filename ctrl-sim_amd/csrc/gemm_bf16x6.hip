@@ -51,17 +51,17 @@ __device__ __forceinline__ void term(f32x16 (&acc)[MR][2], const opx8 (&fa)[MR][
 // KVIMG = true (2x2 tiles, plain Linear): output columns >= kv.k_col0 are attention keys (256 columns) and values (the
 // next 256) and are written NOT as fp32 rows but directly as the split-bf16 K / V^T tile images the attention kernel
 // stages by DMA (attention_bf16x6.hip: layout at kv_split_kernel) — the K/V split costs no extra pass over HBM.
-// Up to 8 classes of contexts share one launch (rows [row0, next row0) belong to class c): L rows per context, of which the rows
+// Up to MAXC classes of contexts share one launch (rows [row0, next row0) belong to class c): L rows per context, of which the rows
 // >= Lreg (the representative tokens of a compact context, attention_bf16x6.hip) are keys rep_k0 + (row - Lreg), the others
 // key = row; nkt tiles per (context, head), the class's images start at tile tile0.
 struct KvClass { int row0, L, Lreg, rep_k0, nkt; long tile0; };
-struct KvImg { op_t* img; int k_col0; int n; KvClass c[8]; };
+struct KvImg { op_t* img; int k_col0; int n; KvClass c[MAXC]; };
 // (class tables are indexed with compile-time indices only: a run-time index into the by-value kernel argument makes the
 // compiler copy the table to scratch memory)
 __device__ __forceinline__ void kv_locate(const KvImg& kv, int grow, int& b, int& pos, int& nkt, long& tile0) {
   KvClass c = kv.c[0];
 #pragma unroll
-  for (int k = 1; k < 8; ++k)
+  for (int k = 1; k < MAXC; ++k)
     if (k < kv.n && grow >= kv.c[k].row0) c = kv.c[k];
   const int r = grow - c.row0;
   b = r / c.L;
@@ -81,10 +81,10 @@ __device__ __forceinline__ KvTile kv_tile(const KvImg& kv, int cbm, int rows) {
   KvClass c = kv.c[0];
   int next_row0 = kv.n > 1 ? kv.c[1].row0 : 0x7fffffff;
 #pragma unroll
-  for (int k = 1; k < 8; ++k)
+  for (int k = 1; k < MAXC; ++k)
     if (k < kv.n && cbm >= kv.c[k].row0) {
       c = kv.c[k];
-      next_row0 = (k + 1 < 8 && k + 1 < kv.n) ? kv.c[k + 1 < 8 ? k + 1 : 7].row0 : 0x7fffffff;
+      next_row0 = (k + 1 < MAXC && k + 1 < kv.n) ? kv.c[k + 1 < MAXC ? k + 1 : MAXC - 1].row0 : 0x7fffffff;
     }
   KvTile t;
   t.fast = cbm + rows - 1 < next_row0 && c.L >= rows;
@@ -527,7 +527,7 @@ int launch_gemm_nt_bf16x6_kvc(const float* A, int lda, const void* W3, int n_tot
   KvImg kv;
   kv.img = static_cast<op_t*>(kv_img); kv.k_col0 = kv_col0; kv.n = 0;
   if (kv_img) {
-    if (ln_gamma || R || relu || (kv_col0 & 127) || N != kv_col0 + 2 * DM || kv_n < 1 || kv_n > 8 || !kv_cls) return CTRLSIM_EINVAL;
+    if (ln_gamma || R || relu || (kv_col0 & 127) || N != kv_col0 + 2 * DM || kv_n < 1 || kv_n > MAXC || !kv_cls) return CTRLSIM_EINVAL;
     int row0 = 0;
     for (int k = 0; k < kv_n; ++k) {
       const KvClassHost& c = kv_cls[k];

@@ -37,7 +37,7 @@ struct MapPoolWeights {
 // Classes of contexts in one launch (forward.hip: a model batch): the polylines of all classes are one flat list; only the
 // padding byte goes to a class-dependent place (scene rows per context M differ with the slot count): polylines
 // [bp0[k], bp0[k+1]) belong to class k, whose padding rows start at pad0[k] with M[k] rows per context.
-struct MapClasses { int n; int bp0[9]; int M[8]; long pad0[8]; };
+struct MapClasses { int n; int bp0[MAXC + 1]; int M[MAXC]; long pad0[MAXC]; };
 
 __global__ __launch_bounds__(256) void map_pool_kernel(int NP, int P, MapClasses mc, int G, int total, const float* __restrict__ road_pts,
                                                        MapPoolWeights w, float* __restrict__ attn_pre,
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void map_pool_kernel(int NP, int P, MapClasses
 // hold the classes back to back
 int launch_map_pool_classes(int n, const int* B, const int* M, const long* pad0, int P, int NP, const float* road_pts,
                             MapPoolWeights w, float* attn_pre, unsigned char* src_pad, hipStream_t st) {
-  if (n < 1 || n > 8 || NP < 1 || NP > MAXNP) return CTRLSIM_EINVAL;
+  if (n < 1 || n > MAXC || NP < 1 || NP > MAXNP) return CTRLSIM_EINVAL;
   MapClasses mc;
   mc.n = n; mc.bp0[0] = 0;
   for (int k = 0; k < n; ++k) { mc.bp0[k + 1] = mc.bp0[k] + B[k] * P; mc.M[k] = M[k]; mc.pad0[k] = pad0[k]; }

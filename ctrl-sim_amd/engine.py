@@ -162,7 +162,7 @@ class _Lane:
 class RolloutEngine:
     def __init__(self, cfg, weights: dict, device="cuda:0", max_ctx=256, seed=0, tilt=(0.0, 0.0, 0.0),
                  temperature=None, nucleus=None, top_p=None, kinematic=False, model=None, use_cache=True, contacts=True,
-                 lanes=1, compact=True, split="auto"):
+                 lanes=1, compact=True, split="auto", sizes=None):
         self.cfg = cfg
         self.w = cfg.dataset.waymo
         self.dims = Dims(cfg)
@@ -217,8 +217,15 @@ class RolloutEngine:
         # with n vehicles runs with the first size >= n + 1; the CtRL-Sim model only (the baselines keep the plain layout).
         A = self.dims.A
         # The 24-slot set is fitted to the occupancy of the bench's scenes (tools/microbench/nstat.py: mean 9.3 vehicles per
-        # context in the sliding-window phase): 1.10x the rows of exact per-context sizes, against 1.18x for steps of four.
-        tuned = (6, 8, 10, 12, 14, 16, 20, 24) if A == 24 else tuple(sorted({a for a in range(4, A, 2)} | {A}))[-8:]
+        # context in the sliding-window phase, 92 % of the contexts hold 3..15): with the 16 classes a launch's class tables
+        # hold (CTRLSIM_MAX_CLASSES) 1.014x the rows and 1.033x the attention pairs of exact per-context sizes — the eight classes
+        # of round 2 (6, 8, 10, 12, 14, 16, 20, 24) cost 1.080x / 1.142x.  Row-wise kernels run once over all classes and the
+        # attention grid is a concatenation, so a class costs nothing but a few index launches.
+        tuned = (4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 24) if A == 24 else \
+            tuple(sorted({a for a in range(max(2, A - 15), A)} | {A}))[-16:]
+        if sizes is not None:                       # explicit class set (A/B measurements, tests): ascending slot counts, A last
+            tuned = tuple(int(a) for a in sizes)
+            assert tuned == tuple(sorted(set(tuned))) and tuned[-1] == A and tuned[0] >= 2 and len(tuned) <= 16
         self.sizes = tuned if (compact and not self.dims.VARIANT) else (A,)
         self._sizes_c = (C.c_int * len(self.sizes))(*self.sizes)
         self.ctx_cap = self.max_ctx * (4 if len(self.sizes) > 1 else 1)

@@ -23,6 +23,9 @@
 
 #include <stdint.h>
 
+/* context size classes a model batch / class-table launch may hold (csrc/common.h: MAXC) */
+#define CTRLSIM_MAX_CLASSES 16
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -96,7 +99,7 @@ int ctrlsim_groups_changed(int S, int N, const int* n_groups, const int* grp_foc
  * through all layers, so a context with n vehicles may be evaluated with any slot count Actx >= n + 1: Actx - 1 regular slots and
  * ONE representative slot standing for the dims.A - (Actx - 1) padded slots of the reference layout (its keys carry that
  * multiplicity in the attention: ctrlsim_attention_compact).  Exact in real arithmetic.  `sizes` = the ascending slot counts a
- * caller uses (nb <= 8, last = dims.A; a context takes the first size >= n + 1, or dims.A).
+ * caller uses (nb <= CTRLSIM_MAX_CLASSES, last = dims.A; a context takes the first size >= n + 1, or dims.A).
  * ctrlsim_group_size_hist: hist[s, k] = focal groups of scenario s in size class k (with n_groups: what the host needs to cut a
  * step into model batches).  ctrlsim_ctx_index_classes: ctrlsim_ctx_index with the contexts SORTED by size class (class k =
  * contexts [sum_{j<k} count_j, ...)); ctx_row0[c] = first logits row of context c when class k emits (sizes[k] - 1, or dims.A
@@ -117,7 +120,7 @@ int ctrlsim_build_context(int B, int N, int A, int T, int t, int Tq, int tt_firs
                           const float* roads /*[S,P_all,NP,3]*/, const float* road_types /*[S,P_all,8]*/,
                           const int* zero4 /*{zero action token, rtg bins x3}*/, const ctrlsim_ctx* out,
                           hipStream_t stream);
-/* The same for a model batch of up to 8 context size classes in ONE launch (class k: B[k] contexts of A[k] slots written to
+/* The same for a model batch of up to CTRLSIM_MAX_CLASSES context size classes in ONE launch (class k: B[k] contexts of A[k] slots written to
  * out[k]; the batch's context list ctx_scn / ctx_grp holds the classes back to back). */
 int ctrlsim_build_context_c(int n, const int* B, const int* A, const ctrlsim_ctx* out, int N, int T, int t, int Tq, int tt_first,
                             int Tmax1, int Tmax, int P_all, int P, int NP, const int* ctx_scn, const int* ctx_grp,
@@ -145,7 +148,7 @@ int ctrlsim_dt_forward_pass2_a(const ctrlsim_model* m, int B, int Tq, int Actx, 
                                hipStream_t stream);
 int ctrlsim_dt_forward_pass1_cached_a(const ctrlsim_model* m, int B, int t, int Actx, const ctrlsim_ctx* ctx, void* workspace,
                                       float* rtg_logits, hipStream_t stream);
-/* The *_c forms take a model BATCH of n <= 8 classes of compact contexts (class k: B[k] contexts of A[k] slots, context tensors
+/* The *_c forms take a model BATCH of n <= CTRLSIM_MAX_CLASSES classes of compact contexts (class k: B[k] contexts of A[k] slots, context tensors
  * ctx[k]; host arrays): every row-wise kernel runs once over the rows of all classes, the attention kernel and the K/V-image
  * epilogue of the QKV projection work from a class table.  Logits rows come class after class, context after context,
  * regular slot after regular slot (ctrlsim_ctx_index_classes' ctx_row0).  ctx_scn lists the contexts in that same order. */

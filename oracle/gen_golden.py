@@ -276,6 +276,34 @@ def gen_closed_loop_full():
     save("closed_loop_full", **out)
 
 
+
+def gen_closed_loop_wide():
+    """The HEADLINE shape (BASELINE configs[2]) against the reference itself: ONE scene of 64 vehicles x 512 polylines (the bench's
+    generator and extent), full model dims, unmodified reference policy + real FreeCar/Box2D for 36 steps — ~14 focal groups
+    per step, the nearest-200-of-512 polyline selection, vehicles dropped from 24-slot contexts, 4 steps past the window slide
+    (autoregressive_policy.py:55-70,96-163, datasets/rl_waymo/dataset.py:278-319,390-428)."""
+    import time
+    steps = 36
+    cfg = spec.make_cfg(nocturne__steps=steps)
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    seed0, idx, n_ag, n_pl, extent, seed, tilt = 0, 5, 64, 512, 100.0, 9, (0.0, 0.0, 0.0)
+    scn = scenarios.make_scenario(seed0, idx, n_agents=n_ag, n_polylines=n_pl, n_points=d.NP, extent=extent)
+    t0 = time.time()
+    r = ref_closed_loop(cfg, w, scn, steps, seed=seed, tilt=tilt)
+    print(f"{time.time() - t0:.0f} s; groups/step", r["n_groups"], "min race margin", r["margins"].min(),
+          "collisions", r["coll"].sum(0).sum(0))
+    out = {}
+    for k in ("tokens", "rtg_cont", "states", "coll", "actions", "n_groups", "margins"):
+        out[f"a_{k}"] = r[k]
+    g = r["groups"]
+    out["a_groups_t_focal"] = np.array([(t, f) for t, f, _, _ in g])
+    out["a_groups_ids"] = np.array([ids + [-1] * (d.A - len(ids)) for _, _, ids, _ in g])
+    out["a_groups_members"] = np.array([m + [-1] * (n_ag - len(m)) for _, _, _, m in g])
+    out["a_recipe"] = np.array([seed0, idx, n_ag, n_pl, extent, seed, *tilt, steps])
+    save("closed_loop_wide", **out)
+
+
 # --------------------------------------------------------------------------------------------- E2: evaluator metrics
 def _install_evaluator_stubs():
     """Make the reference's evaluators/policy_evaluator.py importable: it pulls in nocturne (pybind, unbuildable here), imageio,
@@ -1289,7 +1317,7 @@ def gen_dt_loop():
 
 
 ALL = dict(model=gen_model, features=gen_features, sampling=gen_sampling, physics=gen_physics,
-           collision=gen_collision, closed_loop=gen_closed_loop, closed_loop_full=gen_closed_loop_full, metrics=gen_metrics, interesting=gen_interesting, preprocessed=gen_preprocessed, ingest_gt=gen_ingest_gt, state_dict=gen_state_dict, bicycle=gen_bicycle, contacts=gen_contacts,
+           collision=gen_collision, closed_loop=gen_closed_loop, closed_loop_full=gen_closed_loop_full, closed_loop_wide=gen_closed_loop_wide, metrics=gen_metrics, interesting=gen_interesting, preprocessed=gen_preprocessed, ingest_gt=gen_ingest_gt, state_dict=gen_state_dict, bicycle=gen_bicycle, contacts=gen_contacts,
            planner_adversary=gen_planner_adversary, ingest=gen_ingest,
            variants=gen_variants, dense_reward=gen_dense_reward, dt_loop=gen_dt_loop)
 

@@ -309,6 +309,35 @@ def test_closed_loop_full_dims_through_sliding_window_matches_reference_fixture(
             assert np.array_equal(r["coll"][s], g[f"{tag}_coll"])
 
 
+def test_headline_shape_closed_loop_matches_reference_fixture():
+    """BASELINE configs[2]'s scene shape against the REFERENCE ITSELF (tests/golden/closed_loop_wide.npz,
+    oracle/gen_golden.py::gen_closed_loop_wide): 64 vehicles x 512 polylines, full model, unmodified reference policy + real
+    FreeCar/Box2D for 36 steps — 14 focal groups per step, nearest-200-of-512 polyline selection, vehicles dropped from the
+    24-slot contexts, 4 steps past the window slide (autoregressive_policy.py:55-70,96-163, dataset.py:278-319,390-428).
+    Engine defaults of the bench: compact contexts (16 size classes), two lanes, K/V-cached phase.  Groups, tokens, RTG bins
+    and collision flags identical; float32 states within 1e-4."""
+    g = golden("closed_loop_wide")
+    rc = g["a_recipe"]
+    steps = int(rc[9])
+    cfg = spec.make_cfg(nocturne__steps=steps)
+    d = spec.Dims(cfg)
+    scn = scenarios.make_scenario(int(rc[0]), int(rc[1]), n_agents=int(rc[2]), n_polylines=int(rc[3]), n_points=d.NP,
+                                  extent=float(rc[4]))
+    assert scn.N == 64 and scn.road_points.shape[0] == 512 and steps > d.T + 2
+    eng = RolloutEngine(cfg, weights.generate(d, 0), DEV, max_ctx=64, seed=int(rc[5]), tilt=tuple(rc[6:9]), lanes=2)
+    assert len(eng.sizes) == 16
+    eng.load_scenarios([scn, scn, scn], steps=steps)   # three copies over two lanes: every copy must agree with the fixture
+    r = eng.run(steps).results()
+    assert g["a_n_groups"].min() >= 12 and g["a_coll"].sum() > 100
+    for s in range(3):
+        assert np.array_equal(r["n_groups"][:, s], g["a_n_groups"])
+        bad = np.argwhere(r["tokens"][s] != g["a_tokens"])
+        assert len(bad) == 0, (s, bad[:5])
+        np.testing.assert_allclose(fo.undiscretize_rtgs(r["rtg_bins"][s], cfg.dataset.waymo), g["a_rtg_cont"], atol=1e-9)
+        np.testing.assert_allclose(r["states"][s], g["a_states"], atol=1e-4, rtol=0)
+        assert np.array_equal(r["coll"][s], g["a_coll"])
+
+
 def test_tilt_sweep_in_one_batch_matches_oracle_per_tilt():
     """BASELINE configs[4] against the CPU oracle (not against the HIP path itself): scenario i of one batch runs with its own
     tilt triple (`tilt_scn`); the oracle runs each scenario alone with that triple as the policy's tilt_dict

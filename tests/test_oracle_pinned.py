@@ -271,6 +271,32 @@ def test_rollout_oracle_matches_reference_closed_loop(tag):
     assert g[f"{tag}_margins"].min() > 1e-4                     # no sampling race was a near-tie
 
 
+def test_rollout_oracle_matches_reference_on_the_headline_shape():
+    """The oracle against tests/golden/closed_loop_wide.npz (64 vehicles x 512 polylines, full model, the unmodified reference
+    policy + real physics): the first 3 steps — 14 focal groups and 28 dense forwards per step (the whole 36 steps
+    through the window slide are the GPU test's job: the oracle needs ~20 CPU-seconds per step once the window is full)."""
+    g = golden("closed_loop_wide")
+    rc = g["a_recipe"]
+    cfg = spec.make_cfg(nocturne__steps=int(rc[9]))
+    d = spec.Dims(cfg)
+    scn = scenarios.make_scenario(int(rc[0]), int(rc[1]), n_agents=int(rc[2]), n_polylines=int(rc[3]), n_points=d.NP,
+                                  extent=float(rc[4]))
+    ro = rollout_oracle.RolloutOracle(cfg, weights.generate(d, 0), tilt=tuple(rc[6:9]), seed=int(rc[5]))
+    K = 3
+    r = ro.run(scn, K, sim_libs.OracleSim, record_groups=True)
+    assert np.array_equal(r["tokens"][:, :K], g["a_tokens"][:, :K])
+    assert np.array_equal(r["n_groups"][:K], g["a_n_groups"][:K])
+    np.testing.assert_allclose(fo.undiscretize_rtgs(r["rtg_bins"][:, :K], cfg.dataset.waymo), g["a_rtg_cont"][:, :K], atol=1e-9)
+    assert np.array_equal(r["states"][:, :K + 1], g["a_states"][:, :K + 1])
+    assert np.array_equal(r["coll"][:, :K + 1], g["a_coll"][:, :K + 1])
+    tf = g["a_groups_t_focal"]
+    n0 = int((tf[:, 0] < K).sum())
+    assert [(x["t"], x["focal"]) for x in r["groups"]] == [tuple(v) for v in tf[:n0]]
+    for x, ids, mem in zip(r["groups"], g["a_groups_ids"][:n0], g["a_groups_members"][:n0]):
+        assert x["ids"] == [int(v) for v in ids if v >= 0]
+        assert x["members"] == [int(v) for v in mem if v >= 0]
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_rollout_oracle_matches_reference_planner_vs_adversary(tag):
     """Planner-vs-adversary driver (evaluators/planner_adversary_evaluator.py:497-546): two unmodified reference policies
