@@ -58,7 +58,9 @@ def main():
     ap.add_argument("--tilt", type=float, nargs=3, default=(0.0, 0.0, 0.0))
     ap.add_argument("--tilt-sweep", action="store_true",
                     help="BASELINE configs[4]: scenario i runs with goal = veh = road tilt TILT_SWEEP[i %% 8] (one batch)")
+    ap.add_argument("--sizes", type=str, default="", help="A/B only: explicit context size classes, e.g. 6,8,10,12,14,16,20,24 (round 2's set)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spot-check", type=int, default=4, help="scenarios re-rolled alone after the timed region (bit-identity check; 0 = off)")
     ap.add_argument("--cpu-sample-scenarios", type=int, default=4)
     ap.add_argument("--cpu-sample-steps", type=int, default=2)
     args = ap.parse_args()
@@ -73,9 +75,19 @@ def main():
     shared_gpu = os.environ.get("CTRLSIM_BENCH_DEBUG_SHARED_GPU") == "1"
     if shared_gpu:
         local_rank %= torch.cuda.device_count()
-    if world > 1:
+    # CTRLSIM_BENCH_FORCE_DIST=1: initialise torch.distributed (backend nccl = RCCL) even at world size 1, so that the job's one
+    # collective and its barriers run through RCCL on a single-GPU box exactly as they do on 8 (tests/test_gpu_dist.py)
+    force_dist = os.environ.get("CTRLSIM_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(port)), ("RANK", "0"), ("WORLD_SIZE", "1")):
+                os.environ.setdefault(k, v)
         if shared_gpu:
             dist.init_process_group("gloo")
         else:
@@ -106,7 +118,8 @@ def main():
     if args.tilt_sweep:                                       # the sweep values of config 5
         sweep = np.array([-20.0, -10.0, -5.0, 0.0, 5.0, 10.0, 20.0, 30.0])
         tilt = np.repeat(sweep[np.array(ids) % 8][:, None], 3, axis=1)
-    eng = RolloutEngine(cfg, w, device, max_ctx=args.max_ctx, seed=args.seed, tilt=tilt, lanes=args.lanes)
+    eng = RolloutEngine(cfg, w, device, max_ctx=args.max_ctx, seed=args.seed, tilt=tilt, lanes=args.lanes,
+                        sizes=tuple(int(x) for x in args.sizes.split(",")) if args.sizes else None)
     torch.cuda.synchronize()
     t_up = time.perf_counter()
     eng.load_scenarios(scns, steps=R)                         # host -> HBM: the only PCIe traffic of a rollout (untimed)
@@ -140,11 +153,14 @@ def main():
     # stream (the current one) and, underneath them on the lanes' side streams, the few-row kernels of the second pass, the
     # simulator step and the grouping: intervals on different streams overlap in time, so the per-class rates below are taken
     # from the launches of the main stream (> 98 % of the FLOPs) and the side-stream launches are reported next to them.
+    nsub = int(lib.ctrlsim_prof_subclasses())
+    kms = (C.c_double * nsub)(); kcnt = (C.c_int64 * nsub)(); kfl = (C.c_double * nsub)(); kby = (C.c_double * nsub)()
     ms = (C.c_double * ncls)(); cnt = (C.c_int64 * ncls)(); fl = (C.c_double * ncls)(); by = (C.c_double * ncls)()
     sms = (C.c_double * ncls)(); scnt = (C.c_int64 * ncls)(); sfl = (C.c_double * ncls)(); sby = (C.c_double * ncls)()
     main_stream = _lib.stream_ptr()
     _lib.check(lib.ctrlsim_prof_collect_stream(main_stream, 1, ms, cnt, fl, by), "prof_collect")
     _lib.check(lib.ctrlsim_prof_collect_stream(main_stream, 0, sms, scnt, sfl, sby), "prof_collect")
+    _lib.check(lib.ctrlsim_prof_collect_sub(main_stream, 1, kms, kcnt, kfl, kby), "prof_collect_sub")
     for i in range(2, ncls):                                  # satellites: wherever they ran
         ms[i] += sms[i]; cnt[i] += scnt[i]; fl[i] += sfl[i]; by[i] += sby[i]
     lib.ctrlsim_prof_enable(0)
@@ -152,6 +168,27 @@ def main():
     if dist is not None:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
     elapsed = float(t_el.item())
+
+    # ---- parity spot check (untimed): a few scenarios of the batch are rolled again, ALONE, by a second engine (one lane, small model
+    # batches, no other scenario in their forward chunks): tokens, RTG bins, collision flags and float32 trajectories must be
+    # BIT-identical to what the timed rollout left in HBM — a regression of the batching / lane / class machinery shows here
+    spot = None
+    if rank == 0 and args.spot_check > 0:
+        pick = sorted({int(x) for x in np.linspace(0, S - 1, args.spot_check)})
+        tl = tilt[pick] if isinstance(tilt, np.ndarray) else tilt
+        e2 = RolloutEngine(cfg, w, device, max_ctx=64, seed=args.seed, tilt=tl, lanes=1, model=eng.model)
+        e2.load_scenarios([scns[i] for i in pick], steps=R)
+        r2 = e2.rollout(R)
+        torch.cuda.synchronize()
+        ix = torch.tensor(pick, device=device)
+        same = {k: bool(torch.equal(getattr(eng, k)[ix], getattr(e2, k))) for k in ("hist_tok", "hist_rtg", "coll")}
+        dstate = float((eng.hist_states[ix] - e2.hist_states).abs().max().item())
+        spot = {"scenarios_rerolled_alone": [ids[i] for i in pick], "tokens_identical": same["hist_tok"], "rtg_bins_identical": same["hist_rtg"],
+                "collision_flags_identical": same["coll"], "max_abs_state_difference": dstate,
+                "identical": all(same.values()) and dstate == 0.0,
+                "note": "second engine, one lane, the scenarios alone in their model batches vs the timed two-lane multi-class rollout"}
+        del e2, r2
+        eng._bind()
 
     # ---- metrics: the evaluator's accumulators are built on the device (ctrlsim_metrics_pack: rank-side work independent of S)
     # and combined by ONE all-reduce of that ~10 KB vector — the only collective of the job.  The synthetic
@@ -166,8 +203,8 @@ def main():
     goals4 = np.concatenate([f64("goal_pos"), f64("goal_heading")[..., None], f64("goal_speed")[..., None]], -1)
     vec = eng.metrics_pack(gt, goals4)
     torch.cuda.synchronize()
-    if int(lib.ctrlsim_nonfinite_count(0)):
-        raise FloatingPointError("NaN logits during the rollout (csrc/split.h: activation range)")
+    if eng.nonfinite(reset=False):
+        raise FloatingPointError("guard events during the rollout (csrc/split.h: activation range; csrc/sim.hip: contact table)")
     vec = vec.to(coll_device)
     if dist is not None:
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
@@ -178,7 +215,7 @@ def main():
         value = agent_steps / elapsed
         ctx_per_rollout = int(res["n_groups"].sum())
         dom = 0 if ms[0] >= ms[1] else 1
-        f16 = int(lib.ctrlsim_split_scheme()) == 1
+        f16 = eng.scheme == 1
         nprod, scheme = (3, "two fp16 planes, 3") if f16 else (6, "three bf16 planes, 6")
         PEAK_FP32_EQUIV_TFLOPS = PEAK_16BIT_MFMA_TFLOPS / nprod
         names = ("gemm_nt_bf16x6_kernel + ffn_fused_bf16x6_kernel (every nn.Linear incl. fused LayerNorm / K-V image epilogues and the fused "
@@ -188,7 +225,7 @@ def main():
         # HBM bytes per launch from the PMC counters: rocprofv3 cannot run inside this process, so they come from separate
         # --pmc passes over this same command (tools/pmc_traffic.sh), committed with their calibration under profiles/
         pmc, pmc_src = {}, None
-        for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for cand in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             pmc_path = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(pmc_path):
                 pmc, pmc_src = json.load(open(pmc_path)), "profiles/" + cand
@@ -226,6 +263,25 @@ def main():
             return {"achieved": rate, "peak": PEAK_HBM_TBPS, "unit": "TB/s", "frac": rate / PEAK_HBM_TBPS,
                     "avg_launch_ms": ms[i] / cnt[i], "launches": int(cnt[i]), "time_share_of_step": ms[i] * 1e-3 / elapsed,
                     "algorithmic_hbm_bytes_per_launch": by[i] / cnt[i]}
+        KNAMES = ("other", "Linear + K/V-image epilogue (QKV, memory K/V): gemm_nt_bf16x6_kernel<2,2,2,..,KVIMG>",
+                  "Linear + residual + LayerNorm epilogue (attention out-projections, MLP layers): gemm_nt_bf16x6_kernel<1,4,2,..,LN>",
+                  "plain Linear (cross-attention query projection, heads, map / embedding layers): gemm_nt_bf16x6_kernel<2,2,2>",
+                  "fused feed-forward block: ffn_fused_bf16x6_kernel", "causal self-attention: attention_bf16x6_kernel<1,true>",
+                  "key-padded scene / cross attention: attention_bf16x6_kernel<0,true>")
+
+        def kernel_rows():
+            """Main-stream launches by kernel (2 * kind + few-row flag, include/ctrlsim.h: ctrlsim_prof_collect_sub)."""
+            rows = []
+            for i in range(nsub):
+                if kcnt[i] == 0 or kms[i] <= 0:
+                    continue
+                a = kfl[i] / (kms[i] * 1e-3) / 1e12
+                rows.append({"kernel": KNAMES[i // 2] + (" — few-row launches (last layer on the queried rows, second pass, cached steps)" if i % 2 else ""),
+                             "achieved": a, "frac": a / PEAK_FP32_EQUIV_TFLOPS, "unit": "TFLOP/s", "avg_launch_ms": kms[i] / kcnt[i],
+                             "launches": int(kcnt[i]), "time_share_of_step": kms[i] * 1e-3 / elapsed,
+                             "hbm_rate_at_algorithmic_bytes_TBps": kby[i] / (kms[i] * 1e-3) / 1e12})
+            return sorted(rows, key=lambda r: -r["time_share_of_step"])
+        e2e = (sum(fl[i] for i in range(ncls)) + sfl[0] + sfl[1]) / elapsed / 1e12
         roof = {"bound": "mfma", **cls(dom),
                 "note": "achieved = algorithmic fp32 FLOPs (2MNK per Linear; 128 per visible (q,k) pair and head) / summed "
                         f"HIP-event time of the class; peak = dense 16-bit MFMA peak / {nprod} because each fp32 product costs {nprod} "
@@ -236,10 +292,15 @@ def main():
                 "other": cls(1 - dom),
                 "satellite": {CLASS_KEYS[i]: sat(i) for i in range(2, ncls)},
                 "satellite_note": "HBM-side kernels (SURVEY 8d): algorithmic bytes (DESIGN.md 4) / HIP-event time vs the 8 TB/s HBM "
-                                  "peak; sim_step is latency-bound (one workgroup per scenario) and runs on a side stream "
-                                  "concurrently with the other lane's matrix kernels"}
+                                  "peak; sim_step is latency-bound (one workgroup per scenario, alone on its CU) and runs on the lane's "
+                                  "side stream underneath the other lane's grouping / context kernels — a forward pass waits for "
+                                  "every pending simulator step (engine._forward_waits), so it never runs beside matrix kernels",
+                "kernels": kernel_rows(),
+                "end_to_end": {"achieved": e2e, "peak": PEAK_FP32_EQUIV_TFLOPS, "unit": "TFLOP/s", "frac": e2e / PEAK_FP32_EQUIV_TFLOPS,
+                               "note": "ALL algorithmic fp32 FLOPs of the timed region (both MFMA classes on every stream + the folded map "
+                                       "encoder) / wall time of the timed region / the split-operand roof"}}
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:                          # rank 0's host cores, whatever the world size
             cpu = cpu_baseline(cfg, w, scns, args)
         m, _ = acc.compute()
         sizes = sorted({cuts[i + 1] - cuts[i] for i in range(K)})
@@ -253,7 +314,12 @@ def main():
             "config": {"workload": f"{S} synthetic Waymo-shaped scenarios resident per GPU x {N} agents x {R} steps, "
                                    f"{args.polylines} road polylines x 100 points, CtRL-Sim base model (8.29M params, "
                                    f"random init), context A=24/T=32/P=200"
-                                   + (" = BASELINE.json configs[2]" if (S, N, R, args.polylines) == (2048, 64, 90, 512) else
+                                   + (" = BASELINE.json configs[4] (reward-tilt sweep: 8 tilt values x 1024 scenarios)"
+                                      if (args.tilt_sweep and S * world == 8192 and (N, R, args.polylines) == (64, 90, 512)) else
+                                      " = BASELINE.json configs[3] (8192 scenarios sharded over the ranks)"
+                                      if (world > 1 and S * world == 8192 and (N, R, args.polylines) == (64, 90, 512)) else
+                                      " = BASELINE.json configs[2]" + (" per GPU" if world > 1 else "")
+                                      if (S, N, R, args.polylines) == (2048, 64, 90, 512) else
                                       " = BASELINE.json configs[1]" if (S, N, R, args.polylines) == (256, 32, 90, 200) else "")
                                    + f"; one bench step = the {R}-step closed-loop rollout of one slice of {'/'.join(map(str, sizes))} "
                                      f"scenarios, the {K} timed steps cover the {S} scenarios exactly once",
@@ -263,8 +329,11 @@ def main():
                        "mean_focal_groups_per_scenario_step": ctx_per_rollout / (S * R),
                        "scenario_upload_ms_untimed": upload_ms, "scenario_generation_s_untimed": gen_s,
                        "tilt": "sweep of 8 values, one per scenario (configs[4])" if args.tilt_sweep else list(args.tilt),
+                       "size_classes": list(eng.sizes),
+                       "collective": (f"one all-reduce (SUM) of the {int(vec.numel())}-double metric vector + barriers, backend "
+                                      f"{dist.get_backend() if dist is not None else 'none (single process)'}, world {world}"),
                        "parallelism": f"scenario-sharded x{world}"},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "parity_spot_check": spot,
             "rollout_metrics": {k: (None if v != v else v) for k, v in m.items()},
         }
         print(json.dumps(out))

@@ -13,7 +13,9 @@ import os
 import torch  # noqa: F401  (must precede the CDLL: shares the already-loaded HIP runtime)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libctrlsim_hip.so")
+# CTRLSIM_LIB: another build of the SAME library (tools/: ablation variants of one kernel source); never a fallback — a missing
+# file raises in lib() either way
+LIB_PATH = os.environ.get("CTRLSIM_LIB") or os.path.join(HERE, "csrc", "libctrlsim_hip.so")
 
 
 class Dims(C.Structure):
@@ -41,11 +43,15 @@ SIGNATURES = {
     "ctrlsim_set_option": (I, [I, I]),
     "ctrlsim_split_scheme": (I, []),
     "ctrlsim_nonfinite_count": (I, [I]),
+    "ctrlsim_bind": (I, [I, P]),
+    "ctrlsim_unbind": (I, [P]),
     "ctrlsim_prof_classes": (I, []),
     "ctrlsim_prof_enable": (None, [I]),
     "ctrlsim_prof_collect": (I, [P, P, P]),
     "ctrlsim_prof_bytes": (I, [P]),
     "ctrlsim_prof_collect_stream": (I, [P, I, P, P, P, P]),
+    "ctrlsim_prof_subclasses": (I, []),
+    "ctrlsim_prof_collect_sub": (I, [P, I, P, P, P, P]),
     "ctrlsim_metrics_size": (I, []),
     "ctrlsim_dt_ledger_step": (I, [I, I, I, I, I, I, P, P, P, P, P, C.POINTER(DtRewardCfg), P, P, P, P]),
     "ctrlsim_metrics_pack": (I, [I, I, I, I, I, D, P, P, P, P, P, P, P, P, P, P]),

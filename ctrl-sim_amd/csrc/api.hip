@@ -46,7 +46,7 @@ int launch_sample_action(const float*, int, int, const int*, const int*, const i
 
 #include <vector>
 namespace {
-struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; hipStream_t st; };
+struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; hipStream_t st; int sub; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_recs;
 std::vector<hipEvent_t> g_pool;
@@ -61,16 +61,21 @@ void prof_before(int cls, hipStream_t st) {
   g_pending[cls] = take_event();
   hipEventRecord(g_pending[cls], st);
 }
-void prof_after(int cls, double flops, hipStream_t st, double bytes) {
+static bool g_prof_few = false;
+void prof_few(bool on) { g_prof_few = on; }
+void prof_after(int cls, double flops, hipStream_t st, double bytes, int kind) {
   if (!g_prof_on) return;
   hipEvent_t b = take_event();
   hipEventRecord(b, st);
-  g_recs.push_back(ProfRec{g_pending[cls], b, cls, flops, bytes, st});
+  g_recs.push_back(ProfRec{g_pending[cls], b, cls, flops, bytes, st, 2 * kind + (g_prof_few ? 1 : 0)});
 }
 
 static int g_options[OPT_COUNT] = {1, 1, 0, 1, 1};
-// the process-wide non-finite counter (common.h): 4 bytes of device memory, allocated on first use on the then-current device
+// Guard counter (common.h): the counter the CALLER bound with ctrlsim_bind — an engine's own 4 bytes of device memory — or,
+// for callers that never bind one, a library-owned word allocated on first use on the then-current device.
+static int* g_guard = nullptr;
 int* ctrlsim_nonfinite_ptr() {
+  if (g_guard) return g_guard;
   static int* p = nullptr;
   if (!p) {
     if (hipMalloc(reinterpret_cast<void**>(&p), sizeof(int)) != hipSuccess) { p = nullptr; return nullptr; }
@@ -92,6 +97,22 @@ int ctrlsim_option(int key) { return (key >= 0 && key < OPT_COUNT) ? g_options[k
 
 extern "C" {
 
+// Per-engine state of the library, re-asserted by the caller at the top of every run: the operand split its weight planes / K/V
+// images / workspace were built for (0 / 1; -1 = leave) and its guard counter (device int32 it owns and reads itself; NULL = the
+// library's own word).  Everything launched until the next bind uses them.
+int ctrlsim_bind(int split_scheme, int* guard_counter) {
+  if (split_scheme == 0 || split_scheme == 1) g_options[OPT_SPLIT] = split_scheme;
+  else if (split_scheme != -1) return CTRLSIM_EINVAL;
+  g_guard = guard_counter;
+  return CTRLSIM_OK;
+}
+
+// the owner of `guard_counter` is about to free it: back to the library's own word if it is the bound one
+int ctrlsim_unbind(const int* guard_counter) {
+  if (g_guard == guard_counter) g_guard = nullptr;
+  return CTRLSIM_OK;
+}
+
 int ctrlsim_set_option(int key, int value) {
   if (key < 0 || key >= OPT_COUNT) return CTRLSIM_EINVAL;
   g_options[key] = value;
@@ -112,6 +133,19 @@ int ctrlsim_prof_collect(double* ms, int64_t* count, double* flops) {
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return CTRLSIM_ELAUNCH;
     ms[r.cls] += t; count[r.cls] += 1; flops[r.cls] += r.flops;
+  }
+  return CTRLSIM_OK;
+}
+
+// kernel-level rows (2 * PKIND_* + few, common.h) of the launches on stream st (on_stream != 0) or elsewhere: arrays of ctrlsim_prof_subclasses()
+int ctrlsim_prof_subclasses(void) { return PSUB_COUNT; }
+int ctrlsim_prof_collect_sub(hipStream_t st, int on_stream, double* ms, int64_t* count, double* flops, double* bytes) {
+  for (int c = 0; c < PSUB_COUNT; ++c) { ms[c] = 0; count[c] = 0; flops[c] = 0; bytes[c] = 0; }
+  for (auto& r : g_recs) {
+    if ((r.st == st) != (on_stream != 0) || r.cls > PROF_ATTN || r.sub < 0 || r.sub >= PSUB_COUNT) continue;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return CTRLSIM_ELAUNCH;
+    ms[r.sub] += t; count[r.sub] += 1; flops[r.sub] += r.flops; bytes[r.sub] += r.bytes;
   }
   return CTRLSIM_OK;
 }

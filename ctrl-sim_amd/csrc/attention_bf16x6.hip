@@ -779,7 +779,8 @@ int launch_attention_bf16x6(int mode, const float* Q, int ldq, long q_batch_stri
                        ab);
   }
   prof_after(PROF_ATTN, attn_pairs(mode, q_pos, Lq, Lk, A) * 128.0 * NHEAD * B, st,
-             (double)B * (8.0 * DM * Lq + 8.0 * DM * Lk));
+             (double)B * (8.0 * DM * Lq + 8.0 * DM * Lk),
+             mode == MODE6_CAUSAL ? PKIND_ATTN_CAUSAL : PKIND_ATTN_KEYPAD);
   return ctrlsim_launch_status();
 }
 
@@ -827,7 +828,7 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
     hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, true>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale, 0,
                        ab);
   }
-  prof_after(PROF_ATTN, flops, st, bytes);
+  prof_after(PROF_ATTN, flops, st, bytes, mode == MODE6_CAUSAL ? PKIND_ATTN_CAUSAL : PKIND_ATTN_KEYPAD);
   return ctrlsim_launch_status();
 }
 

@@ -77,8 +77,18 @@ __device__ __forceinline__ void count_nonfinite_row(float var, int lane, int* __
 enum { PROF_GEMM = 0, PROF_ATTN = 1,                         // the two MFMA kernel classes
        PROF_CTX = 2, PROF_EMBED = 3, PROF_SIM = 4, PROF_MAP = 5,   // HBM / latency satellites: build_context, assemble_tokens, sim_step, map_pool
        PROF_CLASSES = 6 };
+// kernel-level rows inside the two MFMA classes (ctrlsim_prof_collect_sub; bench.py names them): row = 2 * kind + few, few = the
+// launch belongs to a few-row section of the forward (last decoder layer on the queried rows, second pass, K/V-cached steps:
+// prof_few() brackets them in forward.hip)
+enum { PKIND_OTHER = 0, PKIND_GEMM_QKV_KV = 1,  // Linear whose K / V columns leave as split tile images (QKV, memory K/V)
+       PKIND_GEMM_LN = 2,                         // Linear + residual + LayerNorm (+ReLU) epilogue, 64 x 256 tiles
+       PKIND_GEMM_PLAIN = 3,                      // plain Linear (cross-attention query projection, heads, map / embedding layers)
+       PKIND_FFN = 4,                             // fused feed-forward block
+       PKIND_ATTN_CAUSAL = 5, PKIND_ATTN_KEYPAD = 6,   // decoder self-attention / scene + cross attention
+       PKIND_COUNT = 7, PSUB_COUNT = 2 * PKIND_COUNT };
+void prof_few(bool on);
 void prof_before(int cls, hipStream_t st);
-void prof_after(int cls, double flops, hipStream_t st, double bytes = 0.0);   // bytes = compulsory (algorithmic) HBM traffic
+void prof_after(int cls, double flops, hipStream_t st, double bytes = 0.0, int kind = PKIND_OTHER);   // bytes = compulsory (algorithmic) HBM traffic
 
 // ---- runtime options (ctrlsim_set_option): which MFMA path the matrix kernels take
 enum { OPT_ATTN_IMPL = 0, OPT_GEMM_IMPL = 1,   // 0 = f32-input MFMA, 1 = split-bf16 (bf16x6) MFMA

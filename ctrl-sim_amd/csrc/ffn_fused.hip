@@ -272,7 +272,7 @@ int launch_ffn_fused_bf16x6(const float* X, int ldx, const void* W1p, const floa
   prof_before(PROF_GEMM, st);
   hipLaunchKernelGGL(ffn_fused_bf16x6_kernel, dim3(grid), dim3(256), shm, st, X, ldx, static_cast<const op_t*>(W1p), b1,
                      static_cast<const op_t*>(W2p), b2, gamma, beta, Y, ldy, M, F / 32, ctrlsim_nonfinite_ptr());
-  prof_after(PROF_GEMM, 4.0 * (double)M * DM * (double)F, st, 12.0 * (double)M * DM + 4.0 * NPL * (double)DM * F);   // x read as operand and as residual, y written; W1 / W2 as NPL planes
+  prof_after(PROF_GEMM, 4.0 * (double)M * DM * (double)F, st, 12.0 * (double)M * DM + 4.0 * NPL * (double)DM * F, PKIND_FFN);   // x read as operand and as residual, y written; W1 / W2 as NPL planes
   return ctrlsim_launch_status();
 }
 

@@ -656,6 +656,8 @@ int forward_full(const ctrlsim_model* m, int n, const int* Bk, const int* Ak, co
   Batch bt;
   CHK(make_batch(d, n, Bk, Ak, ctx, Tq, Tq, 4, bt));
   if (!classes_ok(d, bt)) return CTRLSIM_EINVAL;
+  struct FewScope { ~FewScope() { prof_few(false); } } few_scope;    // profiling rows: full-row part, then the few-row tail
+  prof_few(false);
   bt.contig = bt.n > 1 && ctx_contiguous(d, bt, Tq);
   const Ws w = carve(d, bt, static_cast<char*>(workspace));
   const int P = d.P, ti = Tq - 1, rL = (int)bt.rL, rQ = (int)bt.rQ;
@@ -697,6 +699,7 @@ int forward_full(const ctrlsim_model* m, int n, const int* Bk, const int* Ak, co
         if (hipEventRecord(m->ev_tail, st) != hipSuccess || hipStreamWaitEvent(st_tail, m->ev_tail, 0) != hipSuccess) return CTRLSIM_ELAUNCH;
         st = st_tail;
       }
+      prof_few(true);
       CHK(launch_row_copy(w.X, DM, w.xc, DM, w.idx_state, rQ, DM, 0, st));
       CHK(launch_row_copy(w.qkv[i], 3 * DM, w.qkvc, 3 * DM, w.idx_state, rQ, 3 * DM, 0, st));
       CHK(attention(d, bt, w, AttnCall{amode, Q_STATE, w.qkvc, 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, w.img_dec[i], false,
@@ -778,6 +781,7 @@ extern "C" int ctrlsim_dt_forward_pass2_c(const ctrlsim_model* m, int n, const i
   // tensors hold only the last Tn = min(Tq, 2) window rows
   const int Tw = cached ? d.T : Tq;
   const int ctx_rows = cached ? (Tq < 2 ? Tq : 2) : Tq, ti = ctx_rows - 1;
+  struct FewScope { FewScope() { prof_few(true); } ~FewScope() { prof_few(false); } } few_scope;   // profiling rows: few-row launches
   Batch bt, lay;
   CHK(make_batch(d, n, Bk, Ak, ctx, Tw, ctx_rows, 4, bt));
   CHK(make_batch(d, n, Bk, Ak, ctx, Tw, cached ? 2 : ctx_rows, 4, lay));   // cached: the layout of ctrlsim_dt_forward_pass1_cached_c
@@ -835,6 +839,7 @@ extern "C" int ctrlsim_dt_forward_pass1_cached_c(const ctrlsim_model* m, int n, 
   if (!m || !ctx || !workspace || !rtg_logits || t < 0 || t >= m->d.T || m->d.variant != 0) return CTRLSIM_EINVAL;
   const ctrlsim_dims& d = m->d;
   const int P = d.P, mul = t > 0 ? 4 : 3, tt_first = t > 0 ? t - 1 : 0, Tn = t + 1 - tt_first;
+  struct FewScope { FewScope() { prof_few(true); } ~FewScope() { prof_few(false); } } few_scope;   // profiling rows: few-row launches
   Batch bt;
   CHK(make_batch(d, n, Bk, Ak, ctx, d.T, Tn, mul, bt));
   if (!classes_ok(d, bt)) return CTRLSIM_EINVAL;

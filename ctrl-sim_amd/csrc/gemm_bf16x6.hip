@@ -597,7 +597,8 @@ int launch_gemm_nt_bf16x6_kvc(const float* A, int lda, const void* W3, int n_tot
     const double MN = (double)M * N, kvN = kv_img ? 2.0 * DM : 0.0;
     const double out_bytes = 4.0 * (double)M * (N - kvN) + 2.0 * NPL * (double)M * kvN;   // K / V columns leave as NPL 16-bit planes
     prof_after(PROF_GEMM, 2.0 * MN * (double)K, st,
-               4.0 * (double)M * K + out_bytes + (R ? 4.0 * MN : 0.0) + 2.0 * NPL * (double)N * K);   // weights: NPL 16-bit planes
+               4.0 * (double)M * K + out_bytes + (R ? 4.0 * MN : 0.0) + 2.0 * NPL * (double)N * K,   // weights: NPL 16-bit planes
+               kv_img ? PKIND_GEMM_QKV_KV : ln ? PKIND_GEMM_LN : PKIND_GEMM_PLAIN);
   }
   return ctrlsim_launch_status();
 }

@@ -32,6 +32,10 @@ __device__ __forceinline__ void sim_jitter(int point) {
   }
 }
 #define SYNCJ() do { sim_jitter(__LINE__); __syncthreads(); sim_jitter(__LINE__ + 4096); } while (0)
+#elif defined(SIM_FENCE)
+// (tools only) every workgroup barrier also releases / acquires global memory at agent scope (L2 write-back, L1 invalidate): if the
+// co-residency hazard of DESIGN.md section 4 travels through the vector-memory caches, this build does not show it
+#define SYNCJ() do { __threadfence(); __syncthreads(); __threadfence(); } while (0)
 #else
 #define SYNCJ() __syncthreads()
 #endif
@@ -231,6 +235,7 @@ __device__ void collide_and_record(int s, int N, int E, const float* __restrict_
   __shared__ unsigned cell_lo[GRID * GRID], cell_hi[GRID * GRID];
   __shared__ float gbox[4];
   __shared__ int gany;
+  __shared__ unsigned live_lo, live_hi;                        // existing vehicles (the ones the grid bins)
   for (int c = tid; c < GRID * GRID; c += blockDim.x) { cell_lo[c] = 0u; cell_hi[c] = 0u; }
   if (tid < 64) {                                              // wave 0: bounding box of the existing vehicles
     const bool live = tid < N && exists[(size_t)s * N + tid];
@@ -241,7 +246,11 @@ __device__ void collide_and_record(int s, int N, int E, const float* __restrict_
       m0 = fminf(m0, __shfl_xor(m0, o)); m1 = fminf(m1, __shfl_xor(m1, o));
       m2 = fmaxf(m2, __shfl_xor(m2, o)); m3 = fmaxf(m3, __shfl_xor(m3, o));
     }
-    if (tid == 0) { gbox[0] = m0; gbox[1] = m1; gbox[2] = m2; gbox[3] = m3; gany = m2 >= m0 ? 1 : 0; }
+    const unsigned long long lm = __ballot(live);
+    if (tid == 0) {
+      gbox[0] = m0; gbox[1] = m1; gbox[2] = m2; gbox[3] = m3; gany = m2 >= m0 ? 1 : 0;
+      live_lo = (unsigned)lm; live_hi = (unsigned)(lm >> 32);
+    }
   }
   SYNCJ();
   if (gany) {
@@ -264,7 +273,7 @@ __device__ void collide_and_record(int s, int N, int E, const float* __restrict_
       if (!(s2 > gbox[0] && s0 < gbox[2] && s3 > gbox[1] && s1 < gbox[3])) continue;     // misses every existing vehicle's box
       const int x0 = cellx(s0), x1 = cellx(s2), y0 = celly(s1), y1 = celly(s3);
       unsigned lo = 0u, hi = 0u;
-      if ((x1 - x0 + 1) * (y1 - y0 + 1) > 16) { lo = hi = 0xFFFFFFFFu; }                  // a very long segment: every vehicle
+      if ((x1 - x0 + 1) * (y1 - y0 + 1) > 16) { lo = live_lo; hi = live_hi; }             // a very long segment: every binned vehicle
       else
         for (int y = y0; y <= y1; ++y)
           for (int x = x0; x <= x1; ++x) { lo |= cell_lo[y * GRID + x]; hi |= cell_hi[y * GRID + x]; }
@@ -1081,7 +1090,8 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
                                                        float* __restrict__ phys, float* __restrict__ hist_states,
                                                        unsigned char* __restrict__ coll, double* __restrict__ applied,
                                                        int t, int Tmax1, float dt, int kinematic,
-                                                       float* __restrict__ contact_state) {
+                                                       float* __restrict__ contact_state, int s_base,
+                                                       int* __restrict__ guard) {
   __shared__ BodyLds B;
   __shared__ int isl_bodies[64], isl_stack[64], isl_index[64], wake[64], tele[64], in_isl[64], moved_now[64];
   __shared__ V2 isl_pc[64], isl_vv[64];
@@ -1095,7 +1105,7 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
   __shared__ __attribute__((aligned(16))) float box[64][4];
   __shared__ int flag_veh[64], flag_edge[64];
   __shared__ float px[64], py[64], hd[64], sp[64];
-  const int s = blockIdx.x, tid = threadIdx.x;
+  const int s = blockIdx.x + s_base, tid = threadIdx.x;     // s_base: launches are cut into chunks of <= one workgroup per CU
 #ifdef SIM_TIMING
   unsigned long long tl_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -1335,8 +1345,10 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
             const int pr = i * (2 * N - i - 1) / 2 + (j - i - 1);   // rows i of length N-1-i
             if (pair_mark[pr]) continue;                   // already in this island
             pair_mark[pr] = 1;
-            if (coff + nc < MAX_ISLAND_CONTACTS) {         // (never exceeded: the touching graph of disjoint boxes is planar)
+            if (coff + nc < MAX_ISLAND_CONTACTS) {         // (the touching graph of disjoint boxes is planar: <= 3 N - 6 contacts)
               isl_c[coff + nc].m = cs + (size_t)pr * CS_STRIDE; isl_c[coff + nc].ia = i; isl_c[coff + nc].ib = j; ++nc;
+            } else if (guard) {
+              atomicAdd(guard, 1);                         // deeply overlapping boxes: the contact is NOT solved — counted, never silent
             }
             if ((in_island >> o) & 1ull) continue;
             isl_stack[sc++] = o; in_island |= 1ull << o;
@@ -1429,9 +1441,8 @@ int launch_sim_step(int S, int N, int E, const int* act_tok, const double* act_f
   if (N < 1 || N > 64 || E < 0 || t < 0 || t + 1 >= Tmax1 || (!act_tok && !act_f64)) return CTRLSIM_EINVAL;
   SimDiscretisation dz{disc6[0], disc6[1], disc6[2], disc6[3], (int)disc6[4], (int)disc6[5]};
   prof_before(PROF_SIM, st);
-  // The step takes a CU's whole LDS (its own ~60 KB + a dynamic remainder it never touches) whenever the launch has no more
-  // workgroups than CUs: a scenario's workgroup then never shares a CU with LDS-using workgroups of kernels running on other
-  // streams.  Sharing one with the split-operand matrix kernels made rollouts non-reproducible (5 of 40
+  // The step takes a CU's whole LDS (its own ~60 KB + a dynamic remainder it never touches): a scenario's workgroup then never
+  // shares a CU with LDS-using workgroups of kernels running on other streams.  Sharing one with the split-operand matrix kernels made rollouts non-reproducible (5 of 40
   // provoked runs differ without this, 0 of 40 with it); the step is latency-bound with one workgroup per scenario, so the
   // exclusivity costs nothing.
   static const int n_cus = [] {
@@ -1450,9 +1461,14 @@ int launch_sim_step(int S, int N, int E, const int* act_tok, const double* act_f
     }
     return (int)dyn;
   }();
-  const int dyn_lds = (S <= n_cus) ? excl_lds : 0;
-  hipLaunchKernelGGL(sim_step_kernel, dim3(S), dim3(256), dyn_lds, st, N, E, act_tok, act_f64, dz, size, edges, exists, phys,
-                     hist_states, coll, applied, t, Tmax1, dt, kinematic, contact_state);
+  // More scenarios than CUs: the launch is cut into chunks of n_cus workgroups (back to back on the stream), so that the
+  // exclusivity holds whatever the batch size — a single 1024-workgroup launch would have to share CUs (four per CU fit).
+  const int chunk = (excl_lds > 0 && n_cus > 0) ? n_cus : S;
+  for (int s0 = 0; s0 < S; s0 += chunk) {
+    const int n = S - s0 < chunk ? S - s0 : chunk;
+    hipLaunchKernelGGL(sim_step_kernel, dim3(n), dim3(256), excl_lds, st, N, E, act_tok, act_f64, dz, size, edges, exists, phys,
+                       hist_states, coll, applied, t, Tmax1, dt, kinematic, contact_state, s0, ctrlsim_nonfinite_ptr());
+  }
   // per scenario: body + control state in and out (20 floats), one history row + flags out, the road-edge segments in,
   // and (contacts) the persistent Box2D state in and out (20 floats per vehicle pair + broad phase)
   prof_after(PROF_SIM, 0.0, st, (double)S * (N * (2.0 * 80 + 32 + 2 + 4) + 16.0 * E +

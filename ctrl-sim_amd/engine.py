@@ -58,6 +58,8 @@ class HipModel:
         _lib.check(self.lib.ctrlsim_model_create(C.byref(self.cdims), self.flat.data_ptr(), len(names), self._names,
                                                  self._offsets, C.byref(h)), "model_create")
         self.handle = h
+        self.split_fallback = False     # an engine of this model met non-finite values under f16x3: later split="auto" engines
+                                        # (the policy surface opens one per scenario session) start on bf16x6 right away
 
     def workspace_bytes(self, B, Tq, A=None):
         n = self.lib.ctrlsim_forward_workspace_bytes_a(C.byref(self.cdims), B, Tq, self.dims.A if A is None else A)
@@ -175,7 +177,14 @@ class RolloutEngine:
         # whose sampling met non-finite logits (an operand beyond the fp16 range: trained weights can do that) is repeated with bf16x6
         assert split in ("auto", "f16x3", "bf16x6")
         self.split = split
-        self._set_split(0 if split == "bf16x6" else 1)
+        # Per-ENGINE library state (ctrlsim_bind, re-asserted at the top of every run / step): the operand split this engine's K/V
+        # images and workspace are used with, and its own guard counter (non-finite LayerNorm rows / sampling races, simulator
+        # contact-table overflows) — several engines (planner and adversary policies, a second model) take turns in one process
+        # without changing each other's kernels or reading each other's events.
+        self.guard = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.scheme = 0 if (split == "bf16x6" or (split == "auto" and self.model.split_fallback)) else 1
+        self._unchecked = []                    # fresh-from-reset runs since the last check_finite: (steps, s0, s1)
+        self._bind()
         pol = cfg.eval.policy
         self.temperature = float(pol.action_temperature if temperature is None else temperature)
         nuc = bool(pol.nucleus_sampling if nucleus is None else nucleus)
@@ -230,14 +239,13 @@ class RolloutEngine:
         self._sizes_c = (C.c_int * len(self.sizes))(*self.sizes)
         self.ctx_cap = self.max_ctx * (4 if len(self.sizes) > 1 else 1)
         # workspace bytes per context of each class (the carve is linear in B up to alignment), + a fixed allowance per class
-        cur = int(self.lib.ctrlsim_split_scheme())
         if self.split == "auto":
-            self._set_split(0)                      # size the workspace for the larger (three-plane) K/V images
+            self.lib.ctrlsim_bind(0, self.guard.data_ptr())    # size the workspace for the larger (three-plane) K/V images
         wb = self.model.workspace_bytes
         self._bpc = [(wb(257, self.dims.T, a) - wb(1, self.dims.T, a)) / 256.0 for a in self.sizes]
         self._ws_fixed = sum(wb(1, self.dims.T, a) for a in self.sizes) + (1 << 20)
         self._ws_bytes = wb(self.max_ctx, self.dims.T) + self._ws_fixed
-        self._set_split(cur)
+        self._bind()
         self.n_lanes = max(1, int(lanes))
         self.lanes = [_Lane(self, i, self.n_lanes > 1) for i in range(self.n_lanes)]
         L0 = self.lanes[0]                   # the synchronous single-stream entry points (policy_step / step) use lane 0
@@ -247,8 +255,28 @@ class RolloutEngine:
         self._main = torch.cuda.current_stream(self.device)
         self.S = 0
 
+    def _bind(self):
+        _lib.check(self.lib.ctrlsim_bind(int(self.scheme), self.guard.data_ptr()), "bind")
+
+    def __del__(self):
+        try:                                    # the library must not keep a pointer into memory torch is about to recycle
+            self.lib.ctrlsim_unbind(self.guard.data_ptr())
+        except Exception:
+            pass
+
     def _set_split(self, scheme):
-        _lib.check(self.lib.ctrlsim_set_option(4, int(scheme)), "set_option(OPT_SPLIT)")
+        self.scheme = int(scheme)
+        if self.split == "auto" and self.scheme == 0:
+            self.model.split_fallback = True
+        self._bind()
+
+    def nonfinite(self, reset=True):
+        """Synchronise and read this engine's guard counter (non-finite LayerNorm rows / sampling races, contact-table overflows)."""
+        torch.cuda.synchronize(self.device)
+        n = int(self.guard.item())
+        if n and reset:
+            self.guard.zero_()
+        return n
 
     # ------------------------------------------------------------------ scenario upload / reset
     def load_scenarios(self, scns, steps=None):
@@ -316,7 +344,8 @@ class RolloutEngine:
         self.ctx_base = z(S, dt=torch.int32)
         self._zero_rtg_row = torch.tensor(self.zero_rtg, dtype=torch.int32, device=dev)
         self.groups_per_step = np.zeros((self.steps, S), np.int32)
-        self.lib.ctrlsim_nonfinite_count(1)
+        self.guard.zero_()
+        self._unchecked = []
         self.reset()
 
     def reset(self, s0=0, s1=None):
@@ -387,6 +416,8 @@ class RolloutEngine:
     def sim_step(self, t, act_f64=None, s0=0, s1=None, stream=None):
         """Simulator step of scenarios [s0, s1) (default: all)."""
         lib, p = self.lib, _lib.ptr
+        if stream is None:
+            self._bind()                        # direct calls (plugin surface); run() binds once for its whole schedule
         st = _lib.stream_ptr() if stream is None else stream
         s1 = self.S if s1 is None else s1
         sl = slice(s0, s1)
@@ -651,7 +682,11 @@ class RolloutEngine:
         rollout).  noise_fn(t) -> (noise_rtg, noise_act): explicit sampling noise, synchronous single-lane path."""
         steps = self.steps if steps is None else steps
         s1 = self.S if s1 is None else s1
-        self._last_run = (steps, s0, s1) if (noise_fn is None and getattr(self, "_fresh", None) == (s0, s1)) else None
+        self._bind()
+        # what check_finite may repeat with the range-safe split: runs that started from reset(); anything else makes it raise
+        self._unchecked.append((steps, s0, s1) if (noise_fn is None and getattr(self, "_fresh", None) == (s0, s1)) else None)
+        if len(self._unchecked) > 4096:
+            self._unchecked = [None]            # nobody checked for thousands of runs: not repeatable any more, still loud
         self._fresh = None
         if noise_fn is not None:
             assert s0 == 0 and s1 == self.S
@@ -688,6 +723,7 @@ class RolloutEngine:
     def policy_step(self, t, noise_rtg=None, noise_act=None):
         """AutoregressivePolicy.predict for every scenario: writes hist_rtg[..., t, :], hist_tok[..., t], act_now."""
         self._main = torch.cuda.current_stream(self.device)
+        self._bind()
         L = self.lanes[0]
         side, L.side = L.side, None                   # everything on the caller's stream
         try:
@@ -721,25 +757,27 @@ class RolloutEngine:
         return out
 
     def check_finite(self):
-        """Synchronise and look at the samplers' non-finite-logit counter.  With split="auto" a rollout that started from reset()
-        and met such logits under the two-fp16-plane split is repeated with three bf16 planes (which stay selected); -> True if
-        that happened.  Anything else non-finite raises."""
-        torch.cuda.synchronize(self.device)
-        bad = int(self.lib.ctrlsim_nonfinite_count(1))
+        """Synchronise and look at this engine's guard counter.  With split="auto", runs that started from reset() and met
+        non-finite values under the two-fp16-plane split are ALL repeated (every range rolled since the last check, not only the
+        last one) with three bf16 planes, which stay selected for this engine and later engines of the model; -> True if that
+        happened.  Anything else raises, naming the ranges."""
+        bad = self.nonfinite()
+        runs, self._unchecked = self._unchecked, []
         if not bad:
             return False
-        last = getattr(self, "_last_run", None)
-        if self.split == "auto" and int(self.lib.ctrlsim_split_scheme()) == 1 and last is not None:
+        if self.split == "auto" and self.scheme == 1 and runs and all(r is not None for r in runs):
             self._set_split(0)
-            steps, s0, s1 = last
-            self.reset(s0, s1)
-            self.run(steps, s0=s0, s1=s1)
-            torch.cuda.synchronize(self.device)
-            bad = int(self.lib.ctrlsim_nonfinite_count(1))
+            for steps, s0, s1 in runs:
+                self.reset(s0, s1)
+                self.run(steps, s0=s0, s1=s1)
+            bad = self.nonfinite()
+            self._unchecked = []
             if not bad:
                 return True
-        raise FloatingPointError(f"{bad} sampling races had no finite logit (NaN in the forward pass: an activation beyond "
-                                 "the fp16 range of the split operands, csrc/split.h, or bad weights)")
+        raise FloatingPointError(f"{bad} guard events in the rollouts of scenario ranges {[r[1:] if r else '?' for r in runs]}: sampling "
+                                 "races without a finite logit / LayerNorm rows with a non-finite variance (an activation beyond the "
+                                 "fp16 range of the split operands, csrc/split.h, or bad weights), or simulator contacts beyond the "
+                                 "island solver's table (csrc/sim.hip: MAX_ISLAND_CONTACTS)")
 
     def rollout(self, steps=None, s0=0, s1=None):
         """reset + run + check_finite of scenarios [s0, s1): a complete closed-loop rollout, repeated with the range-safe operand

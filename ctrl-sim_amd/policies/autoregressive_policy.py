@@ -102,13 +102,11 @@ class AutoregressivePolicy(Policy):
             eng.hist_rtg.copy_(torch.from_numpy(dz.discretize_rtgs_from_raw(self.rtgs, w).astype(np.int32)[None]).to(dev))
         eng.goals.copy_(torch.from_numpy(self.goals[:, 0][None]).to(dev))
         eng.policy_step(t)
-        torch.cuda.synchronize(dev)
-        bad = int(eng.lib.ctrlsim_nonfinite_count(1))      # NaN logits (fp16 overflow of the split operands, bad weights) must not
-        if bad and eng.split == "auto" and int(eng.lib.ctrlsim_split_scheme()) == 1:
+        bad = eng.nonfinite()                              # NaN logits (fp16 overflow of the split operands, bad weights) must not
+        if bad and eng.split == "auto" and eng.scheme == 1:
             eng._set_split(0)                              # pass as "rtg bin 0 / zero action": redo the step with the range-safe
-            eng.policy_step(t)                             # three-bf16-plane operands (they stay selected), csrc/split.h
-            torch.cuda.synchronize(dev)
-            bad = int(eng.lib.ctrlsim_nonfinite_count(1))
+            eng.policy_step(t)                             # three-bf16-plane operands (they stay selected for this model: every
+            bad = eng.nonfinite()                          # later session starts on them), csrc/split.h
         if bad:
             raise FloatingPointError(f"{bad} sampling races had no finite logit at step {t} (csrc/split.h: activation range)")
         bins = eng.hist_rtg[0, :, t].cpu().numpy()

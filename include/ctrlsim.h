@@ -319,6 +319,12 @@ int ctrlsim_prof_bytes(double* bytes);
 /* ctrlsim_prof_collect + ctrlsim_prof_bytes restricted to the launches on `stream` (on_stream != 0) or on every other stream
  * (on_stream == 0): intervals of kernels that run concurrently on different streams overlap in time. */
 int ctrlsim_prof_collect_stream(hipStream_t stream, int on_stream, double* ms, int64_t* count, double* flops, double* bytes);
+/* Kernel-level rows inside the two MFMA classes, same restriction by stream.  Row 2 * kind + few: kind 0 other, 1 Linear with K/V
+ * image epilogue (QKV / memory K-V projections), 2 Linear + residual + LayerNorm, 3 plain Linear, 4 fused feed-forward block,
+ * 5 causal self-attention, 6 key-padded (scene / cross) attention; few = 1 for the few-row launches (last decoder layer on the
+ * queried rows, second pass, K/V-cached steps).  Arrays hold ctrlsim_prof_subclasses() entries. */
+int ctrlsim_prof_subclasses(void);
+int ctrlsim_prof_collect_sub(hipStream_t stream, int on_stream, double* ms, int64_t* count, double* flops, double* bytes);
 
 /* Runtime options: key 0 = attention path, key 1 = GEMM path of the forward; value 0 = f32-input MFMA
  * (v_mfma_f32_32x32x2_f32), 1 = split-bf16 "bf16x6" MFMA with fp32-class accuracy (default). */
@@ -333,6 +339,16 @@ int ctrlsim_split_scheme(void);
  * device memory per process, allocated at first use on the current device: one host thread and one device per process, like the
  * options and the profiling hooks. */
 int ctrlsim_nonfinite_count(int reset);
+/* Per-caller state instead of the process-wide defaults: split_scheme (0 / 1; -1 = leave as is) selects the operand split the
+ * caller's weight planes, K/V images and workspace were built for, guard_counter is a device int32 the CALLER owns (zeroed and read
+ * by the caller: the library neither allocates nor synchronises for it) that receives every guard event until the next bind — the
+ * non-finite events above and contacts of a simulator island beyond the solver's table (ctrlsim_sim_step).  NULL = the library's
+ * own word behind ctrlsim_nonfinite_count.  An engine re-asserts its pair at the top of every run, so several engines (planner and
+ * adversary policies, a second model) can take turns in one process; still one host thread at a time.  Replaces nothing in the
+ * reference: its per-process analogue is nocturne's global Box2D world (physics/Singletons.cpp:5-25). */
+int ctrlsim_bind(int split_scheme, int* guard_counter);
+/* Before the caller frees a bound counter: un-binds it if it is the bound one (no-op otherwise). */
+int ctrlsim_unbind(const int* guard_counter);
 
 const char* ctrlsim_version(void);
 

@@ -16,7 +16,7 @@ def build_pollute_lib():
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pollute")
     src, so = os.path.join(here, "pollute.hip"), os.path.join(here, "libpollute.so")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-o", so, src])
+        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-o", so, src])
     return so
 
 

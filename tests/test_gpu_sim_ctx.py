@@ -338,6 +338,45 @@ def test_headline_shape_closed_loop_matches_reference_fixture():
         assert np.array_equal(r["coll"][s], g["a_coll"])
 
 
+def test_at_scale_token_agreement_between_the_split_and_the_f32_kernel_families():
+    """Token agreement at the HEADLINE shape, at scale, teacher-forced (no divergence compounding): every step of a 40-step
+    rollout of 24 scenes x 64 vehicles x 512 polylines (~340 contexts per step, 8 steps past the window slide) is sampled twice
+    from the SAME history and the same in-kernel noise — by the shipped path (two-fp16-plane split operands, compact contexts in
+    16 size classes, multi-class batches) and by the independent f32-input MFMA kernel family (exact fp32 products, plain 24-slot
+    contexts; pinned to the reference's golden logits by test_gpu_model.py).  ~245 000 sampled ids (action tokens + three RTG
+    components).  Two fp32-class evaluations differ by ~1e-5 in a logit, so a race whose two best candidates are closer than that
+    may legitimately resolve differently: the rate of such flips is bounded here (and printed), not assumed to be zero."""
+    steps, S = 40, 24
+    cfg = spec.make_cfg(nocturne__steps=steps)
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    scns = scenarios.make_batch(3, range(S), n_agents=64, n_polylines=512)
+    a = RolloutEngine(cfg, w, DEV, max_ctx=128, seed=17, lanes=1)
+    b = RolloutEngine(cfg, w, DEV, max_ctx=512, seed=17, lanes=1, compact=False, model=a.model)
+    a.load_scenarios(scns, steps=steps)
+    b.load_scenarios(scns, steps=steps)
+    lib = a.lib
+    flips_tok = flips_rtg = total = 0
+    try:
+        for t in range(steps):
+            for k in ("hist_states", "hist_tok", "hist_rtg", "persist", "coll"):
+                getattr(b, k).copy_(getattr(a, k))
+            a.step(t)
+            lib.ctrlsim_set_option(0, 0); lib.ctrlsim_set_option(1, 0)
+            b.policy_step(t)
+            torch.cuda.synchronize()
+            lib.ctrlsim_set_option(0, 1); lib.ctrlsim_set_option(1, 1)
+            assert torch.equal(a.n_groups, b.n_groups)
+            flips_tok += int((a.hist_tok[:, :, t] != b.hist_tok[:, :, t]).sum())
+            flips_rtg += int((a.hist_rtg[:, :, t] != b.hist_rtg[:, :, t]).sum())
+            total += S * 64 * 4
+    finally:
+        lib.ctrlsim_set_option(0, 1); lib.ctrlsim_set_option(1, 1)
+    assert a.nonfinite() == 0 and b.nonfinite() == 0
+    print(f"at-scale agreement: {flips_tok} action-token and {flips_rtg} RTG-bin differences in {total} sampled ids")
+    assert flips_tok + flips_rtg <= 12, (flips_tok, flips_rtg, total)          # < 5e-5 of the samples
+
+
 def test_tilt_sweep_in_one_batch_matches_oracle_per_tilt():
     """BASELINE configs[4] against the CPU oracle (not against the HIP path itself): scenario i of one batch runs with its own
     tilt triple (`tilt_scn`); the oracle runs each scenario alone with that triple as the policy's tilt_dict
@@ -785,8 +824,96 @@ def test_operand_split_is_a_runtime_choice_with_automatic_fallback():
     eng = RolloutEngine(cfg, hot, DEV, max_ctx=24, seed=4, split="auto")
     eng.load_scenarios([scn], steps=steps)
     r = eng.run(steps).results()
-    assert int(eng.lib.ctrlsim_split_scheme()) == 0            # fell back, and stays on the range-safe split
+    assert eng.scheme == 0 and eng.model.split_fallback        # fell back, and stays on the range-safe split
     assert np.array_equal(r["tokens"][0][:, :steps], oh["tokens"])
     np.testing.assert_allclose(r["states"][0], oh["states"], atol=1e-4, rtol=0)
-    RolloutEngine(cfg, w, DEV, max_ctx=24, seed=4)             # a new engine selects its own split again (process-global option)
-    assert int(eng.lib.ctrlsim_split_scheme()) == 1
+    later = RolloutEngine(cfg, hot, DEV, max_ctx=24, seed=4, split="auto", model=eng.model)
+    assert later.scheme == 0                                   # a later session of the SAME model starts on it (no repeated NaN step)
+    other = RolloutEngine(cfg, w, DEV, max_ctx=24, seed=4)     # another model makes its own choice
+    assert other.scheme == 1 and eng.scheme == 0
+
+
+def test_two_engines_with_different_splits_take_turns_in_one_process():
+    """The operand split and the guard counter are per-engine state (ctrlsim_bind, re-asserted at the top of every step): an f16x3
+    engine and a bf16x6 engine stepped alternately — the planner / adversary pattern — each reproduce the oracle, and a guard
+    event of one engine is not seen by the other."""
+    cfg = cfg_of("loop")
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    scn = scenarios.make_scenario(81, 1, n_agents=8, n_polylines=14, n_points=d.NP, extent=30.0)
+    steps = 6
+    o = rollout_oracle.RolloutOracle(cfg, w, seed=4).run(scn, steps, sim_libs.OracleSim)
+    ea = RolloutEngine(cfg, w, DEV, max_ctx=24, seed=4, split="f16x3")
+    eb = RolloutEngine(cfg, w, DEV, max_ctx=24, seed=4, split="bf16x6")
+    ea.load_scenarios([scn], steps=steps)
+    eb.load_scenarios([scn], steps=steps)
+    for t in range(steps):
+        ea.step(t)
+        eb.step(t)
+    eb.guard.fill_(3)                                            # an event in B's counter only
+    assert ea.nonfinite() == 0 and eb.nonfinite() == 3
+    for e in (ea, eb):
+        assert np.array_equal(e.hist_tok.cpu().numpy()[0][:, :steps], o["tokens"]), e.split
+        np.testing.assert_allclose(e.hist_states.cpu().numpy()[0], o["states"], atol=1e-4, rtol=0)
+
+
+def test_unchecked_earlier_slice_is_repeated_too():
+    """check_finite() repeats EVERY fresh range rolled since the last check, not only the last one: slice 0 overflows the fp16
+    range, slice 1 is rolled after it without a check in between — both end up as the fp32 oracle's rollouts."""
+    cfg = cfg_of("loop")
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    hot = dict(w)
+    hot["encoder.embed_ln.weight"] = w["encoder.embed_ln.weight"] * np.float32(3e4)
+    scns = [scenarios.make_scenario(81, i, n_agents=8, n_polylines=14, n_points=d.NP, extent=30.0) for i in range(2)]
+    steps = 6
+    eng = RolloutEngine(cfg, hot, DEV, max_ctx=24, seed=4, split="auto")
+    eng.load_scenarios(scns, steps=steps)
+    eng.reset(0, 1); eng.run(steps, s0=0, s1=1)
+    eng.reset(1, 2); eng.run(steps, s0=1, s1=2)
+    r = eng.results()
+    assert eng.scheme == 0
+    for i, scn in enumerate(scns):
+        oh = rollout_oracle.RolloutOracle(cfg, hot, seed=4).run(scn, steps, sim_libs.OracleSim)
+        assert np.array_equal(r["tokens"][i][:, :steps], oh["tokens"]), i
+
+
+def test_two_lanes_with_more_scenarios_than_cus_match_single_stream():
+    """Each lane holds more scenarios than the chip has CUs: sim_step launches are cut into chunks of one workgroup per CU so that
+    every scenario's workgroup is alone on its CU (csrc/sim.hip: launch_sim_step), whatever the batch size.  600 small scenes with
+    vehicles colliding (contact solver in the loop), two lanes, simulator steps delayed into the other lane's forward — bit-identical
+    to the single-stream rollout."""
+    cfg = cfg_of("loop")
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    S = 2 * ncu + 88
+    scns = [scenarios.make_scenario(91, i, n_agents=8, n_polylines=10, n_points=d.NP, extent=14.0) for i in range(S)]
+    steps = 10
+    ref = RolloutEngine(cfg, w, DEV, max_ctx=256, seed=2, lanes=1)
+    ref.load_scenarios(scns, steps=steps)
+    r0 = ref.run(steps).results()
+    assert r0["coll"][..., 0].sum() > 0                          # vehicles do collide
+    eng = RolloutEngine(cfg, w, DEV, max_ctx=256, seed=2, lanes=2, model=ref.model)
+    eng.load_scenarios(scns, steps=steps)
+    delay_simulator_steps(eng, 300)
+    r1 = eng.run(steps).results()
+    for k in ("tokens", "rtg_bins", "coll", "states"):
+        assert np.array_equal(r0[k], r1[k]), k
+
+
+def test_contact_table_overflow_is_counted_not_silent():
+    """More touching pairs in one island than the island solver's table holds (40 boxes stacked on one spot: 780 contacts against
+    MAX_ISLAND_CONTACTS = 192 — not a traffic scene; disjoint boxes are bounded by planarity): the dropped contacts are counted
+    in the engine's guard counter and results() raises instead of returning a rollout Box2D would not have produced."""
+    cfg = cfg_of("loop")
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    scn = scenarios.make_scenario(93, 0, n_agents=40, n_polylines=10, n_points=d.NP, extent=60.0)
+    scn.x[:] = scn.x[0] + np.linspace(0, 0.4, 40).astype(np.float32)
+    scn.y[:] = scn.y[0]
+    eng = RolloutEngine(cfg, w, DEV, max_ctx=64, seed=2)
+    eng.load_scenarios([scn], steps=3)
+    eng.run(3)
+    with pytest.raises(FloatingPointError):
+        eng.results()
