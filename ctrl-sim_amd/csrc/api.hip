@@ -21,6 +21,7 @@ int launch_ffn_fused_bf16x6(const float*, int, const void*, const float*, const 
                             float*, int, int, int, hipStream_t);
 int launch_sim_init(int, int, int, const float*, const float*, const float*, const unsigned char*, float*, float*,
                     unsigned char*, int, float*, hipStream_t);
+int launch_sim_set_position(int, int, const float*, float*, hipStream_t);
 int launch_sim_step(int, int, int, const int*, const double*, const double*, const float*, const float*,
                     const unsigned char*, float*, float*, unsigned char*, double*, int, int, float, int, float*, hipStream_t);
 int launch_group_build(int, int, int, int, int, int, double, const float*, const int*, int, unsigned long long*, int*, int*,
@@ -220,6 +221,9 @@ int ctrlsim_attention(int mode, const float* Q, int ldq, int64_t qbs, const floa
 int ctrlsim_sim_init(int S, int N, int E, const float* init_pose, const float* size, const float* edges, const uint8_t* exists,
                      float* phys, float* hist_states, uint8_t* coll, int Tmax1, float* contact_state, hipStream_t st) {
   return launch_sim_init(S, N, E, init_pose, size, edges, exists, phys, hist_states, coll, Tmax1, contact_state, st);
+}
+int ctrlsim_sim_set_position(int S, int N, const float* xy, float* phys, hipStream_t st) {
+  return launch_sim_set_position(S, N, xy, phys, st);
 }
 int64_t ctrlsim_sim_contact_floats(int N) { return N < 1 ? 0 : (int64_t)N * (N - 1) / 2 * 20 + 6 + 28 * (int64_t)N; }
 int ctrlsim_sim_step(int S, int N, int E, const int* act_tok, const double* act_f64, const double* disc6, const float* size,

@@ -43,7 +43,8 @@ __device__ __forceinline__ void sim_jitter(int point) {
 
 #define PHYS_STRIDE 20
 enum { P_CX = 0, P_CY, P_A, P_VX, P_VY, P_W, P_SLEEP, P_AWAKE, P_THR, P_BRK, P_STEER, P_LCX, P_LCY, P_PX, P_PY,
-       P_HEADING, P_SPEED };   // P_HEADING/P_SPEED: Object-level heading_/speed_ (what Python reads)
+       P_HEADING, P_SPEED,     // P_HEADING/P_SPEED: Object-level heading_/speed_ (what Python reads)
+       P_TELE, P_TX, P_TY };   // a pending Vehicle::set_position(x, y) (ctrlsim_sim_set_position), applied by the next step
 
 #define B2_PI 3.14159265359f
 #define B2_MAXTRANSLATION 5.0f
@@ -1119,7 +1120,13 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
       accel = 0.0; steer = 0.0;
       set_transform(p, -1000000.f, -1000000.f, p[P_A]);
       tele[tid] = 1;
-    } else if (act_f64) {
+    } else {
+      if (p[P_TELE] != 0.f) {                            // Vehicle::set_position -> BaseCar::SetPosition -> b2Body::SetTransform
+        set_transform(p, p[P_TX], p[P_TY], p[P_A]);      // (vehicle.cc:75-87, BaseCar.cpp:28-32): before this step's controls
+        p[P_TELE] = 0.f;
+        tele[tid] = 1;
+      }
+      if (act_f64) {
       accel = act_f64[sn * 2 + 0];
       steer = act_f64[sn * 2 + 1];
     } else {                                             // dataset.py:322-338 undiscretize_actions (float64)
@@ -1128,6 +1135,7 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
       steer = (double)(tok % dz.n_steer) / (double)(dz.n_steer - 1);
       accel = accel * (dz.max_accel - dz.min_accel) + dz.min_accel;
       steer = steer * (dz.max_steer - dz.min_steer) + dz.min_steer;
+    }
     }
     if (applied) { applied[sn * 2 + 0] = accel; applied[sn * 2 + 1] = steer; }
     if (kinematic) {                                     // Object::KinematicBicycleStep, object.cc:126-137 (optional mode)
@@ -1430,6 +1438,23 @@ int launch_sim_init(int S, int N, int E, const float* init_pose, const float* si
   if (N < 1 || N > 64 || E < 0) return CTRLSIM_EINVAL;
   hipLaunchKernelGGL(sim_init_kernel, dim3(S), dim3(256), 0, st, N, E, init_pose, size, edges, exists, phys, hist_states,
                      coll, Tmax1, contact_state);
+  return ctrlsim_launch_status();
+}
+
+// Vehicle::set_position(x, y) for the vehicles whose xy entry is not NaN: the request is parked in the body record and applied
+// (b2Body::SetTransform, proxy synchronisation, new-contact search) at the top of the next step, before that step's controls
+__global__ void sim_set_position_kernel(int n, const float* __restrict__ xy, float* __restrict__ phys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = xy[2 * i], y = xy[2 * i + 1];
+  if (x != x || y != y) return;
+  float* p = phys + (size_t)i * PHYS_STRIDE;
+  p[P_TX] = x; p[P_TY] = y; p[P_TELE] = 1.f;
+}
+int launch_sim_set_position(int S, int N, const float* xy, float* phys, hipStream_t st) {
+  if (S <= 0) return CTRLSIM_OK;
+  if (N < 1 || N > 64 || !xy || !phys) return CTRLSIM_EINVAL;
+  hipLaunchKernelGGL(sim_set_position_kernel, dim3((S * N + 255) / 256), dim3(256), 0, st, S * N, xy, phys);
   return ctrlsim_launch_status();
 }
 

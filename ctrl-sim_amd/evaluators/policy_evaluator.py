@@ -67,8 +67,8 @@ class PolicyEvaluator:
                 float(veh.collision_type_edge == CollisionType.VEHICLE_ROAD)]
 
     # ---- policy_evaluator.py:99-159 (real_time_rewards=False branch)
-    def update_vehicle_data_dict(self, t, vehicles, vdd, goal_dict, goal_norm, gt_data_dict):
-        for veh in vehicles:
+    def update_vehicle_data_dict(self, t, vehicles, vdd, goal_dict, goal_norm, gt_data_dict, preproc_data=None):
+        for veh_idx, veh in enumerate(vehicles):
             v = veh.getID()
             gt = np.array(gt_data_dict[v]["traj"])
             d = vdd[v]
@@ -87,12 +87,21 @@ class PolicyEvaluator:
             if self.policy.real_time_rewards:                      # policy_evaluator.py:122-147: the RTG the policy is fed
                 key = self.policy.key_dict["rtgs"]
                 if t == 0:
-                    if not (self.policy.max_return or self.policy.min_return):
-                        raise NotImplementedError("initial RTGs from the preprocessed dataset (preproc_data['rtgs']) need logged "
-                                                  "rewards; use max_return / min_return as cfgs/policy/dt.yaml does")
-                    rtg = np.array([10.0, 90.0, 90.0])             # the maximum achievable return
+                    # policy_evaluator.py:123-146: the logged return-to-go of the preprocessed dataset — components (goal position,
+                    # heading, speed, vehicle, road edge) -> (goal position, vehicle, road edge) — unless the policy asks for the
+                    # maximum / minimum achievable return
+                    if preproc_data is not None and "rtgs" in preproc_data:
+                        r5 = np.asarray(preproc_data["rtgs"][veh_idx, t], np.float64)
+                        rtg = np.concatenate([r5[:1], r5[3:]], axis=-1)
+                    elif self.policy.max_return or self.policy.min_return:
+                        rtg = np.zeros(3)
+                    else:
+                        raise ValueError("real_time_rewards without max_return / min_return starts from the preprocessed dataset's "
+                                         "RTGs: pass cfg.eval.preprocessed_files (ctrlsim_amd.ingest.load_preprocessed)")
+                    if self.policy.max_return or self.policy.min_return:
+                        rtg[:] = (10.0, 90.0, 90.0)                # the maximum achievable return
                     if self.policy.min_return and not self.policy.max_return and v in self.vehicles_to_evaluate:
-                        rtg = np.array([0.0, -10.0, -10.0])        # evaluated vehicles: the minimum possible return
+                        rtg[:] = (0.0, -10.0, -10.0)               # evaluated vehicles: the minimum possible return
                     d[key].append(rtg)
                 else:
                     d[key].append(d[key][-1] - d["dense_reward"][-1])
@@ -174,16 +183,19 @@ class PolicyEvaluator:
         files = self.cfg.eval.get("scenario_files")
         if files:
             from .. import ingest
+            pre_files = self.cfg.eval.get("preprocessed_files") or [None] * len(files)
             for k, path in enumerate(files):
                 scn, info = ingest.load_nocturne_json(path, index=k, max_pts=d_model.NP, steps=self.steps)
                 gt = {i: info["gt_data_dict"][int(vid)] for i, vid in enumerate(info["ids"])}
-                yield scn, gt, [i for i in range(scn.N) if info["moving"][i]]
+                # Evaluator.load_preprocessed_data (evaluators/evaluator.py:44-57): the scene's *_physics.pkl, if there is one
+                pre = ingest.load_preprocessed(pre_files[k], self.cfg_rl_waymo) if pre_files[k] is not None else None
+                yield scn, gt, [i for i in range(scn.N) if info["moving"][i]], pre
             return
         for k in range(int(syn["num_scenarios"])):
             scn = _scn.make_scenario(int(syn.get("seed", 0)), k, n_agents=int(syn["n_agents"]),
                                      n_polylines=int(syn["n_polylines"]), n_points=d_model.NP,
                                      extent=float(syn.get("extent", 100.0)))
-            yield scn, self._ground_truth(scn), list(range(scn.N))
+            yield scn, self._ground_truth(scn), list(range(scn.N)), None
 
     # ---- evaluators/evaluator.py:60-76
     def initialize_goal_dict(self, scn, v, gt_traj):
@@ -234,7 +246,7 @@ class PolicyEvaluator:
     def evaluate_policy(self):
         self.reset()
         n_done = 0
-        for scn, gt_data_dict, moving in self._scenes(self.synthetic):
+        for scn, gt_data_dict, moving, pre in self._scenes(self.synthetic):
             if n_done == self.cfg.eval.num_files_to_evaluate // self.cfg.eval.partitions:
                 break
             self.policy.scenario_index = scn.index
@@ -258,6 +270,8 @@ class PolicyEvaluator:
             n_done += 1
             self.road_edge_polylines = self.extract_road_edge_polylines(scn)
             preproc_data = {"road_points": scn.road_points.astype(np.float64), "road_types": scn.road_types.copy()}
+            if pre is not None:
+                preproc_data["rtgs"] = pre["rtgs"]
             vdd, goal_dict, goal_norm = {}, {}, {}
             for veh in vehicles:
                 v = veh.getID()
@@ -266,7 +280,7 @@ class PolicyEvaluator:
                 goal_norm[v] = np.linalg.norm(np.array([veh.getPosition().x, veh.getPosition().y]) - goal_dict[v]["pos"])
             self.policy.reset(vdd)
             for t in range(self.steps):
-                vdd = self.update_vehicle_data_dict(t, vehicles, vdd, goal_dict, goal_norm, gt_data_dict)
+                vdd = self.update_vehicle_data_dict(t, vehicles, vdd, goal_dict, goal_norm, gt_data_dict, preproc_data)
                 self.policy.update_state(vdd, self.vehicles_to_evaluate, t)
                 vdd = self.policy.predict(vdd, gt_data_dict, preproc_data, None, self.vehicles_to_evaluate, t)
                 for veh in vehicles:
@@ -278,7 +292,7 @@ class PolicyEvaluator:
                     vdd[v]["acceleration"].append(act[0])
                     vdd[v]["steering"].append(act[1])
                 sim.step(self.dt)
-            vdd = self.update_vehicle_data_dict(self.steps, vehicles, vdd, goal_dict, goal_norm, gt_data_dict)
+            vdd = self.update_vehicle_data_dict(self.steps, vehicles, vdd, goal_dict, goal_norm, gt_data_dict, preproc_data)
             for veh in vehicles:
                 vdd[veh.getID()]["acceleration"].append(0)
                 vdd[veh.getID()]["steering"].append(0)

@@ -78,18 +78,17 @@ class AutoregressivePolicy(Policy):
         super().reset(vehicle_data_dict)
         self._session = None
 
-    def get_data(self, gt_data_dict, preproc_data, dset, vehicles_to_evaluate, t):
-        raise NotImplementedError("context construction runs on the device (ctrlsim_build_context); see predict()")
-
-    def predict(self, vehicle_data_dict, gt_data_dict, preproc_data, dset, vehicles_to_evaluate, t):
+    def _sync_session(self, vehicle_data_dict, gt_data_dict, preproc_data, vehicles_to_evaluate, t):
+        """Open the device session at t == 0 (or when none is open) and mirror the host history buffers into it."""
         import torch
         w = self.cfg_rl_waymo
         if self._session is None or t == 0:
+            if vehicle_data_dict is None:        # get_data without a preceding predict: what reset() / update_state() hold
+                vehicle_data_dict = self._dict_from_buffers()
             self._open_session(vehicle_data_dict, preproc_data, gt_data_dict, vehicles_to_evaluate)
         eng = self._session
         dev = eng.device
         n = self.states.shape[0]
-        # mirror the host buffers (rows <= t are meaningful; goals are constant in time)
         hs = np.zeros((1, n, self.steps + 1, 8), np.float32)
         hs[0, :, :self.steps] = self.states
         eng.hist_states.copy_(torch.from_numpy(hs).to(dev))
@@ -101,6 +100,92 @@ class AutoregressivePolicy(Policy):
         else:
             eng.hist_rtg.copy_(torch.from_numpy(dz.discretize_rtgs_from_raw(self.rtgs, w).astype(np.int32)[None]).to(dev))
         eng.goals.copy_(torch.from_numpy(self.goals[:, 0][None]).to(dev))
+        return eng
+
+    def _dict_from_buffers(self):
+        """The per-vehicle fields _open_session reads, rebuilt from the Policy buffers (row 0)."""
+        out = {}
+        kinds = ("unset", "vehicle", "pedestrian", "cyclist", "other")
+        for i, v in self.idx_to_veh_id.items():
+            g = self.goals[i, 0]
+            out[v] = {"length": self.states[i, 0, 5], "width": self.states[i, 0, 6], "position": [{"x": self.states[i, 0, 0], "y": self.states[i, 0, 1]}],
+                      "heading": [self.states[i, 0, 4]], "goal_position": {"x": g[0], "y": g[1]}, "goal_heading": g[4] if len(g) > 4 else 0.0,
+                      "goal_speed": float(np.hypot(g[2], g[3])) if len(g) > 3 else 0.0, "type": kinds[int(np.argmax(self.types[i]))]}
+        return out
+
+    def get_data(self, gt_data_dict, preproc_data, dset, vehicles_to_evaluate, t, vehicle_data_dict=None):
+        """The reference's return contract (autoregressive_policy.py:51-165): (motion_datas {focal veh id: {'agent': {agent_states
+        [1,A,T,8], agent_types [1,A,5], goals [1,A,5], actions [1,A,T] token ids, rtgs [1,A,T,3] bins, timesteps [1,A,T],
+        moving_agent_mask [1,A]}, 'map': {road_points [1,P,NP,3], road_types [1,P,8]}} as torch tensors}, dead_agent_veh_ids,
+        new_agent_idx_dicts {focal: {agent index: context slot}}, data_veh_ids {focal: [veh ids it answers for]}).  The tensors
+        are built by the device kernels predict() runs (ctrlsim_group_build / ctrlsim_build_context, the plain 24-slot layout) and
+        copied back; `dset` is not used.  The context membership the policy persists from step to step is left as it was, so a
+        call before (or instead of) predict() does not change what predict() does."""
+        import ctypes as C
+        import torch
+        from .. import _lib
+        from ..engine import CtxBuffers
+        eng = self._sync_session(vehicle_data_dict, gt_data_dict, preproc_data, vehicles_to_evaluate, t)
+        lib, p, st, d = eng.lib, _lib.ptr, _lib.stream_ptr(), eng.dims
+        N, Tmax, w = eng.N, eng.steps, self.cfg_rl_waymo
+        persist0 = eng.persist.clone()
+        _lib.check(lib.ctrlsim_group_build(1, N, d.A, d.T, t, Tmax + 1, float(w.agent_dist_threshold), p(eng.hist_states),
+                                           p(eng.eval_order), 1 if eng.P_all > 0 else 0, p(eng.persist), p(eng.n_groups),
+                                           p(eng.grp_focal), p(eng.grp_ids), p(eng.grp_members), p(eng.own_g), p(eng.mem_g),
+                                           p(eng.tilted), st), "group_build")
+        G = int(eng.n_groups.cpu()[0])
+        _lib.check(lib.ctrlsim_ctx_index(0, 1, N, p(eng.n_groups), p(eng.grp_focal), p(eng.grp_ids), p(eng.own_g), p(eng.mem_g),
+                                         p(eng.ctx_scn), p(eng.ctx_grp), p(eng.own_ctx), p(eng.own_slot), p(eng.mem_ctx),
+                                         p(eng.mem_slot), p(eng.ctx_base), st), "ctx_index")
+        cb = CtxBuffers(d, max(G, 1), eng.device)
+        zero4 = (C.c_int * 4)(*eng._zero4)
+        if G:
+            _lib.check(lib.ctrlsim_build_context(G, N, d.A, d.T, t, d.T, 0, Tmax + 1, Tmax, eng.P_all, d.P, d.NP, p(eng.ctx_scn),
+                                                 p(eng.ctx_grp), p(eng.grp_focal), p(eng.grp_ids), p(eng.hist_states),
+                                                 p(eng.hist_tok), p(eng.hist_rtg), p(eng.goals), p(eng.types), p(eng.roads),
+                                                 p(eng.rtypes), zero4, C.byref(cb.struct), st), "build_context")
+        torch.cuda.synchronize(eng.device)
+        focal = eng.grp_focal.cpu().numpy()[0, :G]
+        ids = eng.grp_ids.cpu().numpy().astype(np.uint64)[0, :G]
+        mem = eng.grp_members.cpu().numpy().astype(np.uint64)[0, :G]
+        mem_g = eng.mem_g.cpu().numpy()[0]
+        eng.persist.copy_(persist0)
+        bits = lambda m: [i for i in range(64) if (int(m) >> i) & 1]
+        order = {int(v): k for k, v in enumerate(eng.eval_order.cpu().numpy()[0]) if v >= 0}
+        moving = np.linalg.norm(self.states[:, 0, :2] - self.goals[:, 0, :2], axis=1) > w.moving_threshold
+        st12 = cb.st12.cpu().numpy().reshape(-1)[:G * d.T * d.A * 12].reshape(G, d.T, d.A, 12)
+        ex = cb.exist.cpu().numpy().reshape(-1)[:G * d.T * d.A].reshape(G, d.T, d.A)
+        tok = cb.act_tok.cpu().numpy().reshape(-1)[:G * d.T * d.A].reshape(G, d.T, d.A)
+        rb = cb.rtg_bin.cpu().numpy().reshape(-1)[:G * d.T * d.A * 3].reshape(G, d.T, d.A, 3)
+        ts = cb.tstep.cpu().numpy().reshape(-1)[:G * d.T].reshape(G, d.T)
+        g5, rp, rt = cb.goal5.cpu().numpy()[:G], cb.road_pts.cpu().numpy()[:G], cb.road_types.cpu().numpy()[:G]
+        motion_datas, idx_dicts, data_veh_ids = {}, {}, {}
+        for gi in range(G):
+            fid = self.idx_to_veh_id[int(focal[gi])]
+            slots = bits(ids[gi])                                       # agent indices in slot order
+            states = np.concatenate([st12[gi, :, :, :7], ex[gi][..., None]], -1).transpose(1, 0, 2)       # [A,T,8]
+            mm = np.zeros(d.A, bool)
+            mm[:len(slots)] = moving[slots]
+            rtgs = rb[gi].transpose(1, 0, 2)
+            if self.model.dims.VARIANT == 3:
+                rtgs = np.ascontiguousarray(rtgs).view(np.float32)
+            tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)[None])
+            motion_datas[fid] = {"agent": {"agent_states": tt(states), "agent_types": tt(st12[gi, 0, :, 7:]), "goals": tt(g5[gi]),
+                                           "actions": tt(tok[gi].T), "rtgs": tt(rtgs),
+                                           "timesteps": tt(np.repeat(ts[gi][None], d.A, 0)), "moving_agent_mask": tt(mm)},
+                                 "map": {"road_points": tt(rp[gi]), "road_types": tt(rt[gi])}}
+            idx_dicts[fid] = {a: k for k, a in enumerate(slots)}
+            others = sorted((a for a in bits(mem[gi]) if a != int(focal[gi])), key=lambda a: order.get(a, 1 << 30))
+            data_veh_ids[fid] = [fid] + [self.idx_to_veh_id[a] for a in others]
+        dead = [v for v in vehicles_to_evaluate if mem_g[self.veh_id_to_idx[v]] < 0]
+        return motion_datas, dead, idx_dicts, data_veh_ids
+
+    def predict(self, vehicle_data_dict, gt_data_dict, preproc_data, dset, vehicles_to_evaluate, t):
+        import torch
+        w = self.cfg_rl_waymo
+        eng = self._sync_session(vehicle_data_dict, gt_data_dict, preproc_data, vehicles_to_evaluate, t)
+        dev = eng.device
+        n = self.states.shape[0]
         eng.policy_step(t)
         bad = eng.nonfinite()                              # NaN logits (fp16 overflow of the split operands, bad weights) must not
         if bad and eng.split == "auto" and eng.scheme == 1:

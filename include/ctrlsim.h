@@ -74,6 +74,12 @@ int ctrlsim_sim_init(int S, int N, int E, const float* init_pose /*[S,N,4] x,y,h
                      const float* size /*[S,N,2] length,width*/, const float* edges /*[S,E,4]*/,
                      const uint8_t* exists /*[S,N]*/, float* phys, float* hist_states, uint8_t* coll, int Tmax1,
                      float* contact_state, hipStream_t stream);
+/* Object.setPosition(x, y) / set_position (nocturne/pybind11/src/object.cc:52-54,87-90 -> Vehicle::set_position, vehicle.cc:75-87 ->
+ * BaseCar::SetPosition = b2Body::SetTransform at the current angle, physics/BaseCar.cpp:28-32): xy [S,N,2], NaN = leave the vehicle
+ * where it is.  The request is parked in `phys` and applied at the top of the next ctrlsim_sim_step, before that step's controls
+ * (the reference applies it immediately; nothing observes the body in between).  The rollout's own use of it — vehicles that
+ * stopped existing are parked at (-1e6, -1e6) every step, autoregressive_policy.py:260-263 — is what `exists` = 0 does. */
+int ctrlsim_sim_set_position(int S, int N, const float* xy, float* phys, hipStream_t stream);
 /* act_tok [S,N] (token id, or -1 = zero action) or act_f64 [S,N,2] (accel, steer); disc6 = {min_accel, max_accel,
  * min_steer, max_steer, n_accel, n_steer}; applied (nullable) [S,N,2] f64 receives the continuous actions.
  * mode 0 = FreeCar/Box2D (what eval_sim.py executes), 1 = Object::KinematicBicycleStep (object.cc:126-137). */

@@ -252,3 +252,118 @@ def test_one_agent_and_two_agent_modes_hand_only_the_picked_vehicles_to_the_poli
     assert len(ev.vehicles_to_evaluate) == n_eval and len(set(ev.vehicles_to_evaluate)) == n_eval
     assert all(np.isfinite(v) for v in m.values())
     assert ev.acc.counts["goal"] == 2 * n_eval           # per evaluated vehicle and scenario (policy_evaluator.py:162-186)
+
+
+def test_get_data_returns_the_reference_contract_and_leaves_predict_alone():
+    """AutoregressivePolicy.get_data (autoregressive_policy.py:51-165): focal groups, slot dictionaries, the vehicles each group
+    answers for and the normalised context tensors — from the device kernels — against the feature oracle (itself pinned
+    bit-exactly to the reference's get_data: tests/golden/features.npz); a call to get_data changes nothing predict() does."""
+    import features_oracle as fo
+    cfg = cfg_of("loop")
+    cfg.nocturne.history_steps = 1
+    cfg.eval.seed = 3
+    d = spec.Dims(cfg)
+    w = cfg.dataset.waymo
+    scn = scenarios.make_scenario(7, 2, n_agents=10, n_polylines=20, n_points=d.NP, extent=40.0)
+    gt = scenarios.standin_log(scn, cfg.nocturne.steps, cfg.nocturne.dt)
+    preproc = {"road_points": scn.road_points.astype(np.float64), "road_types": scn.road_types.copy()}
+    to_eval = list(range(scn.N))
+
+    def vdd0():
+        out = {}
+        for i in range(scn.N):
+            out[i] = {"position": [{"x": float(scn.x[i]), "y": float(scn.y[i])}],
+                      "velocity": [{"x": float(scn.speed[i] * np.cos(scn.heading[i])), "y": float(scn.speed[i] * np.sin(scn.heading[i]))}],
+                      "heading": [float(scn.heading[i])], "existence": [1.0], "acceleration": [], "steering": [], "timestep": [0],
+                      "rtgs": [], "next_acceleration": 0.0, "next_steering": 0.0,
+                      "goal_position": {"x": float(scn.goal_pos[i, 0]), "y": float(scn.goal_pos[i, 1])},
+                      "goal_heading": float(scn.goal_heading[i]), "goal_speed": float(scn.goal_speed[i]),
+                      "width": float(scn.width[i]), "length": float(scn.length[i]), "type": "vehicle"}
+        return out
+    outs = []
+    for call_get_data in (True, False):
+        model, policy = _make(cfg)
+        vdd = vdd0()
+        policy.reset(vdd)
+        policy.update_state(vdd, to_eval, 0)
+        if call_get_data:
+            md, dead, idx_dicts, veh_ids = policy.get_data(gt, preproc, None, to_eval, 0, vehicle_data_dict=vdd)
+            buf = fo.PolicyBuffers(scn.N, cfg.nocturne.steps)
+            for k in ("states", "types", "actions", "rtgs", "goals", "timesteps"):
+                getattr(buf, k)[:] = getattr(policy, k)
+            lengths = [int(np.array(gt[v]["traj"])[:, 4].sum()) for v in to_eval]
+            order = list(np.array(to_eval)[np.argsort(np.array(lengths))[::-1]])
+            groups, odead = fo.build_contexts(buf, w, 0, order, preproc["road_points"], preproc["road_types"])
+            assert list(md.keys()) == [g["focal"] for g in groups] and sorted(dead) == sorted(odead)
+            for g in groups:
+                f = g["focal"]
+                assert list(idx_dicts[f].keys()) == g["ids"] and veh_ids[f] == g["members"]
+                ref = g["data"]
+                np.testing.assert_allclose(md[f]["agent"]["agent_states"].numpy(), ref["agent_states"].astype(np.float32), atol=2e-5, rtol=1e-6)
+                assert np.array_equal(md[f]["agent"]["actions"].numpy(), ref["actions"].astype(np.int32))
+                assert np.array_equal(md[f]["agent"]["rtgs"].numpy(), ref["rtgs"].astype(np.int32))
+                np.testing.assert_allclose(md[f]["map"]["road_points"].numpy(), ref["road_points"].astype(np.float32), atol=2e-5, rtol=1e-6)
+                assert np.array_equal(md[f]["map"]["road_types"].numpy(), ref["road_types"].astype(np.float32))
+        vdd = policy.predict(vdd, gt, preproc, None, to_eval, 0)
+        outs.append([(vdd[v]["next_acceleration"], vdd[v]["next_steering"], tuple(vdd[v]["rtgs"][-1])) for v in to_eval])
+    assert outs[0] == outs[1]
+
+
+def test_simulation_surface_general_set_position_and_scenario_file(tmp_path):
+    """The pybind slice beyond what the rollout itself calls: Simulation(scenario_path, config) through the JSON loader,
+    getRoadLines() / stop_signs() in get_road_data's shape (utils/sim.py:61-74), object ids / types / moving objects, and the
+    GENERAL Object.setPosition(x, y) (object.cc:52-54 -> vehicle.cc:75-87 -> b2Body::SetTransform): a vehicle dropped onto
+    another one mid-run, against the C oracle (pinned to the real FreeCar / Box2D on the same script: tests/test_oracle_pinned.py)."""
+    import json
+    import sim_libs
+    from ctrlsim_amd import ingest
+    from ctrlsim_amd.simulation import Simulation, RoadType
+    sim_libs.build_oracle()
+    cfg = cfg_of("loop")
+    d = spec.Dims(cfg)
+    scn = scenarios.make_scenario(5, 1, n_agents=6, n_polylines=12, n_points=d.NP, extent=30.0)
+    log = scenarios.standin_log(scn, 20, 0.1)
+    js = ingest.scenario_to_nocturne_json(scn, log, name="unit")
+    js["roads"].append({"geometry": [{"x": 1.5, "y": -2.5}], "type": "stop_sign"})
+    path = tmp_path / "scene.json"
+    path.write_text(json.dumps(js))
+    with pytest.raises(ValueError):
+        Simulation("", {"start_time": 0})
+    with pytest.raises(KeyError):
+        Simulation(str(path), {})                                   # config.at("start_time")
+    sim = Simulation(str(path), {"start_time": 0, "allow_non_vehicles": False}, steps=20)
+    sc = sim.getScenario()
+    vehs = sc.vehicles()
+    assert [v.getID() for v in vehs] == list(range(6)) and all(v.getType().value == 1 for v in vehs) and sc.name == "unit"
+    assert len(sc.getObjectsThatMoved()) <= len(vehs)
+    lines, signs = sc.getRoadLines(), sc.stop_signs()
+    assert len(signs) == 1 and (signs[0].position().x, signs[0].position().y) == (1.5, -2.5)
+    assert len(lines) == 12 and all(len(l.geometry_points()) >= 2 for l in lines)
+    assert sum(l.check_collision for l in lines) == sum(int(l.road_type) == int(RoadType.ROAD_EDGE) for l in lines) > 0
+    # scripted run with a general teleport at step 5: vehicle 2 is put on top of vehicle 0
+    s2 = sim.scn                                                   # what the loader read (float32 headings from degrees)
+    osim = sim_libs.OracleSim(s2.length, s2.width, s2.x, s2.y, s2.heading, s2.speed, s2.edge_segments)
+    rs = np.random.RandomState(3)
+    for t in range(12):
+        acts = np.stack([rs.uniform(-3, 3, 6), rs.uniform(-0.3, 0.3, 6)], 1)
+        if t == 5:
+            p0 = vehs[0].getPosition()
+            vehs[2].setPosition(float(p0.x) + 0.5, float(p0.y) + 0.25)
+            osim.set_position(2, float(p0.x) + 0.5, float(p0.y) + 0.25)
+            assert abs(vehs[2].getPosition().x - (float(p0.x) + 0.5)) < 1e-5      # Object::position_ changes at once
+        for i, v in enumerate(vehs):
+            if acts[i, 0] > 0:
+                v.acceleration = acts[i, 0]
+            else:
+                v.brake(abs(acts[i, 0]))
+            v.steering = acts[i, 1]
+            osim.set_action(i, float(acts[i, 0]), float(acts[i, 1]))
+        sim.step(0.1)
+        osim.step(0.1)
+        st, cv, ce = osim.state()
+        got = np.array([[v.getPosition().x, v.getPosition().y, v.getHeading(), v.getSpeed()] for v in vehs])
+        np.testing.assert_allclose(got[:, :2], st[:, :2], atol=1e-4, rtol=0)
+        np.testing.assert_allclose(got[:, 2], st[:, 2], atol=1e-4, rtol=0)
+        assert [int(v.collision_type_veh) for v in vehs] == [int(c) for c in cv], t
+    assert any(int(v.collision_type_veh) for v in vehs)             # the teleported vehicle does collide
+    osim.close()

@@ -169,3 +169,43 @@ def test_weight_planes_refuse_values_beyond_the_fp16_range():
         W[3, 5] = 300.0
         with pytest.raises(FloatingPointError):
             pack.split3_planes(W)
+
+
+def test_real_time_reward_policy_starts_from_the_preprocessed_rtgs():
+    """policy_evaluator.py:122-146: with real_time_rewards the RTG fed at t = 0 is the preprocessed dataset's return-to-go of the
+    vehicle — components (goal position, heading, speed, vehicle, road edge) reduced to (goal position, vehicle, road edge) — unless
+    max_return / min_return overrides it; later steps subtract the dense reward."""
+    from types import SimpleNamespace as NS
+    from ctrlsim_amd import spec
+    from ctrlsim_amd.evaluators.policy_evaluator import PolicyEvaluator
+    cfg = spec.make_cfg(nocturne__steps=5)
+    rt = np.arange(2 * 6 * 5, dtype=np.float64).reshape(2, 6, 5)
+
+    class Veh:
+        def __init__(self, i): self.i = i
+        def getID(self): return self.i
+        def getPosition(self): return NS(x=1.0 * self.i, y=0.0)
+        position = property(getPosition)
+        def velocity(self): return NS(x=0.0, y=0.0)
+        def getHeading(self): return 0.0
+        heading, speed = 0.0, 0.0
+        collision_type_veh = collision_type_edge = 0
+    for max_r, min_r, expect in ((False, False, [[0, 3, 4], [30, 33, 34]]), (True, False, [[10, 90, 90]] * 2),
+                                 (False, True, [[0, -10, -10], [10, 90, 90]])):
+        pol = NS(real_time_rewards=True, max_return=max_r, min_return=min_r, key_dict={"rtgs": "rtgs"}, model=NS(dims=None))
+        ev = PolicyEvaluator(cfg, pol)
+        ev.vehicles_to_evaluate = [0]
+        ev.road_edge_polylines = []
+        vehs = [Veh(0), Veh(1)]
+        goal = {i: {"pos": np.array([5.0, 0.0]), "heading": 0.0, "speed": 0.0} for i in range(2)}
+        vdd = {i: ev.initialize_vehicle_data_dict(NS(getWidth=lambda: 2.0, getLength=lambda: 4.5), goal[i]) for i in range(2)}
+        gt = {i: {"traj": np.ones((6, 6))} for i in range(2)}
+        ev.compute_dense_reward = lambda t, v: v                    # the dense-reward bookkeeping is pinned elsewhere (dense_reward.npz)
+        ev.update_vehicle_data_dict(0, vehs, vdd, goal, {0: 5.0, 1: 4.0}, gt, {"rtgs": rt})
+        assert [list(vdd[i]["rtgs"][0]) for i in range(2)] == expect
+    pol = NS(real_time_rewards=True, max_return=False, min_return=False, key_dict={"rtgs": "rtgs"}, model=NS(dims=None))
+    ev = PolicyEvaluator(cfg, pol)
+    ev.vehicles_to_evaluate = [0]
+    with pytest.raises(ValueError):
+        ev.update_vehicle_data_dict(0, vehs, {i: ev.initialize_vehicle_data_dict(NS(getWidth=lambda: 2.0, getLength=lambda: 4.5), goal[i])
+                                              for i in range(2)}, goal, {0: 5.0, 1: 4.0}, gt, None)

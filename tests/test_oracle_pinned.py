@@ -441,3 +441,35 @@ def test_rollout_oracle_matches_reference_decision_transformer_loop():
     np.testing.assert_allclose(r["rtgs"], g["loop_rtgs"], rtol=0, atol=1e-9)
     assert np.array_equal(r["states"], g["loop_states"]) and np.array_equal(r["coll"], g["loop_coll"])
     assert g["loop_rtgs"][:, -1, 1].max() < 90.0               # the vehicle-distance RTG is being spent
+
+
+@pytest.mark.skipif(not sim_libs.RefSim.available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_oracle_general_set_position_matches_real_box2d_live():
+    """Vehicle::set_position at an ARBITRARY target (vehicle.cc:75-87 -> BaseCar::SetPosition = b2Body::SetTransform at the current
+    angle, physics/BaseCar.cpp:28-32) — not only the (-1e6, -1e6) parking the rollout uses: a vehicle is dropped onto another one
+    mid-run, a second one moved away and back.  The C oracle against the real FreeCar + Box2D, bit-exact, through the contacts
+    that follow."""
+    scn = scenarios.make_scenario(5, 1, n_agents=6, n_polylines=12, n_points=10, extent=30.0)
+    sims = [cls(scn.length, scn.width, scn.x, scn.y, scn.heading, scn.speed, scn.edge_segments) for cls in (sim_libs.RefSim, sim_libs.OracleSim)]
+    rs = np.random.RandomState(3)
+    hit = 0
+    for t in range(16):
+        acts = np.stack([rs.uniform(-3, 3, 6), rs.uniform(-0.3, 0.3, 6)], 1)
+        st0 = sims[0].state()[0]
+        for sm in sims:
+            if t == 5:
+                sm.set_position(2, float(st0[0, 0]) + 0.5, float(st0[0, 1]) + 0.25)      # onto vehicle 0
+            if t == 8:
+                sm.set_position(4, 500.0, -300.0)
+            if t == 11:
+                sm.set_position(4, float(st0[1, 0]) - 1.0, float(st0[1, 1]))             # back, onto vehicle 1
+            for i in range(6):
+                sm.set_action(i, float(acts[i, 0]), float(acts[i, 1]))
+            sm.step(0.1)
+        (a, av, ae), (b, bv, be) = sims[0].state(), sims[1].state()
+        assert np.array_equal(a, b), t
+        assert np.array_equal(av, bv) and np.array_equal(ae, be), t
+        hit += int(av.sum())
+    assert hit > 0
+    for sm in sims:
+        sm.close()

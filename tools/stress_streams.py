@@ -54,7 +54,7 @@ def run(lanes, p2, tail, cached):
         launches[0] += pol.launches
     else:
         r = eng.run(90).results()
-    return r["tokens"].copy(), r["states"].copy()
+    return r["tokens"].copy(), r["states"].copy(), r["coll"].copy()
 
 
 ref = run(1, False, False, False)
@@ -65,6 +65,17 @@ for k in range(runs):
     ds = float(np.abs(ref[1] - b[1]).max())
     bad += nt > 0 or ds > 0
     print(f"run {k}: token differences {nt}, max |state difference| {ds}", flush=True)
+    if nt > 0 or ds > 0:
+        # where: (scenario, vehicle, step, field) of the EARLIEST differing state rows, fields x y vx vy heading length width exist
+        w = np.argwhere(ref[1] != b[1])
+        w = w[np.argsort(w[:, 2], kind="stable")][:12]
+        print("   first state differences (scn, veh, t, field: ref -> got):",
+              [(int(s_), int(v_), int(t_), int(f_), float(ref[1][s_, v_, t_, f_]), float(b[1][s_, v_, t_, f_])) for s_, v_, t_, f_ in w], flush=True)
+        tw = np.argwhere(ref[0] != b[0])
+        cw = np.argwhere(ref[2] != b[2])
+        print("   earliest token difference (scn, veh, t):", tw[np.argsort(tw[:, 2], kind='stable')][:3].tolist() if len(tw) else None,
+              " earliest collision-flag difference:", cw[np.argsort(cw[:, 2], kind='stable')][:3].tolist() if len(cw) else None,
+              " steps with any state difference:", sorted(set(np.argwhere(ref[1] != b[1])[:, 2].tolist()))[:20], flush=True)
 if pollute:
     print(f"{launches[0]} polluter launches")
 print(f"{bad} of {runs} runs differ from the single-stream rollout (p2={int(p2)} tail={int(tail)} cached={int(cached)})")
