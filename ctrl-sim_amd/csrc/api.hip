@@ -54,24 +54,24 @@ std::vector<hipEvent_t> g_pool;
 hipEvent_t g_pending[PROF_CLASSES];
 hipEvent_t take_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
-  hipEvent_t e; hipEventCreate(&e); return e;
+  hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
 }
 }  // namespace
 void prof_before(int cls, hipStream_t st) {
   if (!g_prof_on) return;
   g_pending[cls] = take_event();
-  hipEventRecord(g_pending[cls], st);
+  (void)hipEventRecord(g_pending[cls], st);
 }
 static bool g_prof_few = false;
 void prof_few(bool on) { g_prof_few = on; }
 void prof_after(int cls, double flops, hipStream_t st, double bytes, int kind) {
   if (!g_prof_on) return;
   hipEvent_t b = take_event();
-  hipEventRecord(b, st);
+  (void)hipEventRecord(b, st);
   g_recs.push_back(ProfRec{g_pending[cls], b, cls, flops, bytes, st, 2 * kind + (g_prof_few ? 1 : 0)});
 }
 
-static int g_options[OPT_COUNT] = {1, 1, 0, 1, 1};
+static int g_options[OPT_COUNT] = {1, 1, 0, 1, 1, 0};
 // Guard counter (common.h): the counter the CALLER bound with ctrlsim_bind — an engine's own 4 bytes of device memory — or,
 // for callers that never bind one, a library-owned word allocated on first use on the then-current device.
 static int* g_guard = nullptr;

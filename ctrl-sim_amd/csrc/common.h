@@ -96,7 +96,8 @@ enum { OPT_ATTN_IMPL = 0, OPT_GEMM_IMPL = 1,   // 0 = f32-input MFMA, 1 = split-
        OPT_FFN_FUSED = 3,                        // 1 = linear1-ReLU-linear2-residual-LayerNorm as one kernel (ffn_fused.hip)
        OPT_SPLIT = 4,                            // operand split of the split-operand kernels (csrc/split.h): 1 = two fp16 planes, three
                                                  // products (default), 0 = three bf16 planes, six products (full fp32 exponent range)
-       OPT_COUNT = 5 };
+       OPT_MAP_MFMA = 5,                         // map-encoder point pooling: 1 = matrix-pipe kernel (two-fp16-plane split only), 0 = fp32 VALU kernel
+       OPT_COUNT = 6 };
 // run-time view of the selected split (dispatch.hip): planes per operand, 16-bit elements per (context, head, tile) K/V image
 int split_npl();
 inline size_t split_kimg() { return (size_t)2 * split_npl() * 64 * 32; }

@@ -329,3 +329,42 @@ def test_ffn_fused_block(M, F):
     _lib.check(_lib.lib().ctrlsim_ffn_fused(p(Z), 256, p(w1d), p(b1), p(w2d), p(b2), p(gam), p(bet), p(Z), 256, M, F,
                                             _lib.stream_ptr()), "ffn_fused in place")
     assert torch.equal(Z, Y)
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_map_pool_on_the_matrix_pipe_matches_the_fp32_valu_kernel(B):
+    """map_pool_mfma_kernel (two-fp16-plane operands in the k-slots of v_mfma_f32_16x16x32_f16, both register layouts of the hidden
+    tile by swapping the MFMA operands: csrc/map_encoder.hip) against the fp32 VALU kernel it replaces (pinned through the forward
+    fixtures to modules/map_encoder.py:28-46): polylines with 0, 1, 2, 31, 32, 33, 99 and 100 visible points, points missing in
+    the middle, an odd polyline count in the last pass; padding bytes identical, pooled vectors to fp32-class accuracy."""
+    from ctrlsim_amd import spec, weights
+    from ctrlsim_amd.engine import HipModel
+    cfg = spec.make_cfg()
+    d = spec.Dims(cfg)
+    model = HipModel(cfg, weights.generate(d, 0), DEV)
+    lib, p, st = _lib.lib(), _lib.ptr, _lib.stream_ptr()
+    rs = np.random.RandomState(B)
+    npts = rs.randint(0, d.NP + 1, (B, d.P))
+    npts[0, :8] = [0, 1, 2, 31, 32, 33, 99, 100]
+    ex = (np.arange(d.NP)[None, None] < npts[..., None]).astype(np.float32)
+    ex[0, 9, 5:40] = 0.0                                        # holes: existence is a per-point flag, not a prefix
+    ex[0, 10, ::2] = 0.0
+    rp = np.concatenate([(rs.randn(B, d.P, d.NP, 2) * 60).astype(np.float32), ex[..., None]], -1)
+    rp[..., :2] *= ex[..., None]
+    road = torch.from_numpy(rp).to(DEV)
+    outs = {}
+    try:
+        for mode in (0, 1):
+            lib.ctrlsim_set_option(5, mode)
+            out = torch.full((B * d.P, d.D), float("nan"), device=DEV)
+            pad = torch.full((B, d.P), 7, dtype=torch.uint8, device=DEV)
+            _lib.check(lib.ctrlsim_map_pool(model.handle, B, p(road), p(out), p(pad), st))
+            torch.cuda.synchronize()
+            outs[mode] = (out.cpu().numpy().astype(np.float64), pad.cpu().numpy())
+    finally:
+        lib.ctrlsim_set_option(5, 0)
+    (a, pa), (b, pb) = outs[0], outs[1]
+    assert np.array_equal(pa, pb) and np.isfinite(b).all()
+    scale = np.abs(a).max(1, keepdims=True) + 1e-3
+    err = np.abs(a - b) / scale
+    assert err.max() < 3e-6, (err.max(), np.unravel_index(err.argmax(), err.shape))
