@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--tilt-sweep", action="store_true",
                     help="BASELINE configs[4]: scenario i runs with goal = veh = road tilt TILT_SWEEP[i %% 8] (one batch)")
     ap.add_argument("--sizes", type=str, default="", help="A/B only: explicit context size classes, e.g. 6,8,10,12,14,16,20,24 (round 2's set)")
+    ap.add_argument("--side", type=str, default=None,
+                    help="few-row kernels on the lanes' side streams: comma list of p2, tail, cached ('' = none; default: the engine's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spot-check", type=int, default=4, help="scenarios re-rolled alone after the timed region (bit-identity check; 0 = off)")
     ap.add_argument("--cpu-sample-scenarios", type=int, default=4)
@@ -120,6 +122,9 @@ def main():
         tilt = np.repeat(sweep[np.array(ids) % 8][:, None], 3, axis=1)
     eng = RolloutEngine(cfg, w, device, max_ctx=args.max_ctx, seed=args.seed, tilt=tilt, lanes=args.lanes,
                         sizes=tuple(int(x) for x in args.sizes.split(",")) if args.sizes else None)
+    if args.side is not None:
+        on = set(filter(None, args.side.split(",")))
+        eng.pass2_on_side, eng.tail_on_side, eng.cached_on_side = "p2" in on, "tail" in on, "cached" in on
     torch.cuda.synchronize()
     t_up = time.perf_counter()
     eng.load_scenarios(scns, steps=R)                         # host -> HBM: the only PCIe traffic of a rollout (untimed)
@@ -330,6 +335,8 @@ def main():
                        "scenario_upload_ms_untimed": upload_ms, "scenario_generation_s_untimed": gen_s,
                        "tilt": "sweep of 8 values, one per scenario (configs[4])" if args.tilt_sweep else list(args.tilt),
                        "size_classes": list(eng.sizes),
+                       "few_row_kernels_on_side_streams": {"second_pass": eng.pass2_on_side, "first_pass_tail": eng.tail_on_side,
+                                                           "cached_steps": eng.cached_on_side},
                        "collective": (f"one all-reduce (SUM) of the {int(vec.numel())}-double metric vector + barriers, backend "
                                       f"{dist.get_backend() if dist is not None else 'none (single process)'}, world {world}"),
                        "parallelism": f"scenario-sharded x{world}"},

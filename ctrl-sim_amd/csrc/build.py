@@ -11,10 +11,20 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # sources -> extra flags.  The three split-operand kernel files are compiled ONCE PER SCHEME (csrc/split.h: -DCTRLSIM_F16X3=1 two fp16
 # planes, =0 three bf16 planes; each build lives in its own namespace) and dispatch.hip picks one at run time.
 SPLIT_SRCS = ("gemm_bf16x6", "ffn_fused", "attention_bf16x6")
-SRCS = {"gemm": "", "attention": "", "sim": "-ffp-contract=off", "context": "-ffp-contract=off", "embed": "",
+# sim.hip additionally with -fno-slp-vectorize: with clang's SLP vectoriser on (packed-f32 math, 64 / 128-bit LDS accesses stitched
+# from neighbouring scalar ones) a simulator workgroup that shares its CU with LDS-heavy workgroups of another kernel produced
+# different results from identical inputs (lanes 48-63 of a wave: wrong x-velocity); 0 of 96 provoked runs differ without it, 23 of
+# 48 with it, no cost (tools/stress_streams.py, tools/sim_variants.sh).
+SRCS = {"gemm": "", "attention": "", "sim": "-ffp-contract=off -fno-slp-vectorize", "context": "-ffp-contract=off", "embed": "",
         "map_encoder": "", "sample": "", "metrics": "-ffp-contract=off", "rewards": "-ffp-contract=off", "forward": "", "dispatch": "", "api": ""}
 OUT = os.path.join(HERE, "libctrlsim_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# CTRLSIM_VARIANT=<name> (tools only): a complete second library built with CTRLSIM_EXTRA_DEFS into its own object directory,
+# tools/microbench/variants/all_<name>.so (selected at run time with CTRLSIM_LIB=<path>); the product library is untouched
+VARIANT = os.environ.get("CTRLSIM_VARIANT", "")
+OBJDIR = "build_" + VARIANT if VARIANT else "build"
+if VARIANT:
+    OUT = os.path.join(HERE, "..", "..", "tools", "microbench", "variants", f"all_{VARIANT}.so")
 
 
 def _newer(a, b):
@@ -29,7 +39,7 @@ def build(force=False, verbose=False):
     jobs += [(name, f"{name}_s{sch}", f"-DCTRLSIM_F16X3={sch}") for name in SPLIT_SRCS for sch in (1, 0)]
     for name, objname, extra in jobs:
         src = os.path.join(HERE, name + ".hip")
-        obj = os.path.join(HERE, "build", objname + ".o")
+        obj = os.path.join(HERE, OBJDIR, objname + ".o")
         os.makedirs(os.path.dirname(obj), exist_ok=True)
         objs.append(obj)
         if force or _newer(src, obj) or any(_newer(d, obj) for d in deps):

@@ -201,19 +201,24 @@ __global__ __launch_bounds__(256, 2) void map_pool_mfma_kernel(int NP, int P, Ma
                                                                unsigned char* __restrict__ src_pad) {
   __shared__ __attribute__((aligned(16))) opx8 cw[16 * 64];                    // (Wc | ln_b) fragments, 16 channel tiles
   __shared__ __attribute__((aligned(16))) opx8 cu[8 * 64];                     // 2^8 U fragments, 8 k-steps of 32 channels
-  __shared__ __attribute__((aligned(16))) union { opx8 xfrag[(MP_PTS / 16) * 64]; float pooled[2][8][DM]; } u;   // 16 KB
+  __shared__ __attribute__((aligned(16))) struct { opx8 xfrag[(MP_PTS / 16) * 64]; float pooled[2][8][DM]; } u;   // 16 KB + 16 KB
   __shared__ __attribute__((aligned(16))) float pts[MP_PTS][4];                // x, y, e, rstd of the compacted points
   __shared__ __attribute__((aligned(16))) float sc[MP_PTS][8];
   __shared__ __attribute__((aligned(16))) _Float16 atab[16][MP_PTS];           // rows 0-7: hi plane of a rstd 2^k per head, 8-15: lo
   __shared__ float inv_scale[2][8];
   __shared__ int any_exist[2], wcnt[4], wc0[4];
-  static_assert(sizeof(u) == 16384, "xfrag / pooled alias");
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m16 = lane & 15, g4 = lane >> 4;
   {
     const opx8* wg = static_cast<const opx8*>(w.wfrag);
     const opx8* ug = static_cast<const opx8*>(w.ufrag);
     for (int i = tid; i < 16 * 64; i += 256) cw[i] = wg[i];
     for (int i = tid; i < 8 * 64; i += 256) cu[i] = ug[i];
+  }
+  {
+    // the point fragments are cleared ONCE: slot groups 2 / 3 stay zero for good, and entries left over from an earlier pass (points
+    // beyond this pass's ranges) are finite and meet zero weights in the pooling product, unread scores in the first
+    const opx8 z = {};
+    for (int i = tid; i < (MP_PTS / 16) * 64; i += 256) u.xfrag[i] = z;
   }
   const int n_pairs = (total + 1) >> 1;
   for (int pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
@@ -224,7 +229,6 @@ __global__ __launch_bounds__(256, 2) void map_pool_mfma_kernel(int NP, int P, Ma
     // ---- (a) clear the per-pass operand tables
     {
       const opx8 z = {};
-      for (int i = tid; i < (MP_PTS / 16) * 64; i += 256) u.xfrag[i] = z;
       opx8* at = reinterpret_cast<opx8*>(&atab[0][0]);
       for (int i = tid; i < 16 * MP_PTS / 8; i += 256) at[i] = z;
       if (tid < 2) any_exist[tid] = 0;
@@ -277,32 +281,44 @@ __global__ __launch_bounds__(256, 2) void map_pool_mfma_kernel(int NP, int P, Ma
       u.xfrag[t * 64 + 16 + mm] = __builtin_bit_cast(opx8, f1);
     }
     __syncthreads();
+#ifndef MP_ABL_NO_P1
     // ---- (d) phase 1: scores.  A wave takes 16-point tiles; per k-step of 32 channels: two D^T tiles, relu, split, two score MFMAs
     const int n_tiles = (e1 + 15) >> 4;
-    for (int t = wv; t < n_tiles; t += 4) {
-      const opx8 xf = u.xfrag[t * 64 + lane];
-      f32x4_ accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+    // (two tiles per trip: two independent MFMA -> relu / split -> MFMA chains in flight per wave; a tile index past the end
+    // computes on left-over fragments and is not stored)
+    for (int t = wv; t < n_tiles; t += 8) {
+      const int t2 = t + 4;
+      const opx8 xf = u.xfrag[t * 64 + lane], xg = u.xfrag[(t2 < MP_PTS / 16 ? t2 : t) * 64 + lane];
+      f32x4_ accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f}, accC = {0.f, 0.f, 0.f, 0.f}, accD = {0.f, 0.f, 0.f, 0.f};
       const f32x4_ z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        const f32x4_ d0 = MFMA16(cw[(2 * s) * 64 + lane], xf, z4);
-        const f32x4_ d1 = MFMA16(cw[(2 * s + 1) * 64 + lane], xf, z4);
-        opx8 rf[NPL];
+        const opx8 w0 = cw[(2 * s) * 64 + lane], w1 = cw[(2 * s + 1) * 64 + lane], uf = cu[s * 64 + lane];
+        const f32x4_ d0 = MFMA16(w0, xf, z4), d1 = MFMA16(w1, xf, z4);
+        const f32x4_ e0_ = MFMA16(w0, xg, z4), e1_ = MFMA16(w1, xg, z4);
+        opx8 rf[NPL], rg[NPL];
         relu_split8(d0, d1, rf);
-        const opx8 uf = cu[s * 64 + lane];
+        relu_split8(e0_, e1_, rg);
         accA = MFMA16(uf, rf[0], accA);                          // rows 0-7: U_hi R_hi, rows 8-15: U_lo R_hi
         accB = MFMA16(uf, rf[1], accB);                          // rows 0-7: U_hi R_lo
+        accC = MFMA16(uf, rg[0], accC);
+        accD = MFMA16(uf, rg[1], accD);
       }
-      float oth[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) oth[r] = __shfl_xor(accA[r], 32);   // the U_lo rows of the same heads live 32 lanes up
-      const int p = t * 16 + m16;
-      if (g4 < 2 && p < e1) {
-        const float rs = pts[p][3] * 0.00390625f;               // rstd / 2^8 (the U fragments carry 2^8)
+      for (int half = 0; half < 2; ++half) {
+        const f32x4_ qa = half ? accC : accA, qb = half ? accD : accB;
+        float oth[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sc[p][4 * g4 + r] = fmaf(rs, (accA[r] + accB[r]) + oth[r], w.cb[4 * g4 + r]);
+        for (int r = 0; r < 4; ++r) oth[r] = __shfl_xor(qa[r], 32);    // the U_lo rows of the same heads live 32 lanes up
+        const int p = (half ? t2 : t) * 16 + m16;
+        if (g4 < 2 && p < e1) {
+          const float rs = pts[p][3] * 0.00390625f;             // rstd / 2^8 (the U fragments carry 2^8)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sc[p][4 * g4 + r] = fmaf(rs, (qa[r] + qb[r]) + oth[r], w.cb[4 * g4 + r]);
+        }
       }
     }
+#endif
     __syncthreads();
     // ---- (e) softmax over the points of a polyline per head; a rstd scaled into the fp16 planes of the pooling operand
     for (int id = wv * 4; id < wv * 4 + 4; ++id) {
@@ -338,6 +354,7 @@ __global__ __launch_bounds__(256, 2) void map_pool_mfma_kernel(int NP, int P, Ma
     for (int gi = 0; gi < 2; ++gi)
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) { pa[gi][ct] = f32x4_{0.f, 0.f, 0.f, 0.f}; pb[gi][ct] = f32x4_{0.f, 0.f, 0.f, 0.f}; }
+#ifndef MP_ABL_NO_P2
 #pragma unroll
     for (int gi = 0; gi < 2; ++gi) {
       if (gi >= g_here) continue;
@@ -360,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void map_pool_mfma_kernel(int NP, int P, Ma
         }
       }
     }
-    __syncthreads();                                             // every read of xfrag is done: `pooled` may overwrite it
+#endif
 #pragma unroll
     for (int gi = 0; gi < 2; ++gi)
 #pragma unroll
@@ -380,12 +397,16 @@ __global__ __launch_bounds__(256, 2) void map_pool_mfma_kernel(int NP, int P, Ma
     {
       const int j = tid, h = j >> 5;
       float o0 = w.mb[j], o1 = o0;
-#pragma unroll 8
+#ifndef MP_ABL_NO_P3
+#pragma unroll 32
       for (int c = 0; c < DM; ++c) {
         const float mm = w.Mt[c * DM + j];
         o0 = fmaf(u.pooled[0][h][c], mm, o0);
         o1 = fmaf(u.pooled[1][h][c], mm, o1);
       }
+#else
+      o0 += u.pooled[0][h][j]; o1 += u.pooled[1][h][j];
+#endif
       attn_pre[(size_t)bp0 * DM + j] = o0;
       if (g_here > 1) attn_pre[(size_t)(bp0 + 1) * DM + j] = o1;
     }
