@@ -42,9 +42,12 @@ def build(force=False, verbose=False):
         obj = os.path.join(HERE, OBJDIR, objname + ".o")
         os.makedirs(os.path.dirname(obj), exist_ok=True)
         objs.append(obj)
-        if force or _newer(src, obj) or any(_newer(d, obj) for d in deps):
-            cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj] + extra.split()
-            cmd += os.environ.get("CTRLSIM_EXTRA_DEFS", "").split()   # A/B tuning knobs, e.g. -DGEMM_TBK=16
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj] + extra.split()
+        cmd += os.environ.get("CTRLSIM_EXTRA_DEFS", "").split()   # A/B tuning knobs, e.g. -DGEMM_TBK=16
+        stamp = obj + ".flags"                                     # an object is stale when its command line changed, too
+        same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(cmd)
+        if force or not same_flags or _newer(src, obj) or any(_newer(d, obj) for d in deps):
+            open(stamp, "w").write(" ".join(cmd))
             if verbose:
                 print(" ".join(cmd))
             procs.append((objname, subprocess.Popen(cmd)))
