@@ -1,0 +1,27 @@
+"""Regression test of the co-residency hazard of DESIGN.md section 4.
+
+Provoking configuration (tools/stress_streams.py): two lanes, the simulator step of a lane delayed by 1 ms on its side stream so
+that it runs underneath the OTHER lane's matrix kernels, no stream guard (engine.forward_waits_for_sim = False), no exclusive CU
+(CTRLSIM_SIM_SHARED_CU=1: a simulator workgroup shares its CU with workgroups of the split-operand GEMM / attention / FFN
+kernels), 8 full-size scenes.  With csrc/sim.hip compiled WITH clang's SLP vectoriser 44 % of such rollouts differed from the
+single-stream rollout (lanes 48-63 of the simulator's wave 0: wrong x-velocity); without it (ctrlsim_amd/csrc/build.py) none of
+several hundred.  16 rollouts here: a library built the old way passes with probability 1e-4."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_simulator_step_beside_matrix_kernels_is_reproducible():
+    env = dict(os.environ, CTRLSIM_SIM_SHARED_CU="1", STRESS_SCENARIOS="8")
+    env.pop("CTRLSIM_LIB", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_streams.py"), "16", "0", "0", "0", "111", "0", "1000", "0", "1"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.startswith("0 of 16 runs differ"), r.stdout[-3000:]
