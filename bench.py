@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--sizes", type=str, default="", help="A/B only: explicit context size classes, e.g. 6,8,10,12,14,16,20,24 (round 2's set)")
     ap.add_argument("--side", type=str, default=None,
                     help="few-row kernels on the lanes' side streams: comma list of p2, tail, cached ('' = none; default: the engine's)")
-    ap.add_argument("--no-sim-guard", action="store_true", help="A/B: a forward pass does not wait for pending simulator steps")
+    ap.add_argument("--sim-guard", action="store_true", help="A/B: the round-2 stream guard (a forward pass waits for pending simulator steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spot-check", type=int, default=4, help="scenarios re-rolled alone after the timed region (bit-identity check; 0 = off)")
     ap.add_argument("--cpu-sample-scenarios", type=int, default=4)
@@ -123,8 +123,8 @@ def main():
         tilt = np.repeat(sweep[np.array(ids) % 8][:, None], 3, axis=1)
     eng = RolloutEngine(cfg, w, device, max_ctx=args.max_ctx, seed=args.seed, tilt=tilt, lanes=args.lanes,
                         sizes=tuple(int(x) for x in args.sizes.split(",")) if args.sizes else None)
-    if args.no_sim_guard:
-        eng.forward_waits_for_sim = False
+    if args.sim_guard:
+        eng.forward_waits_for_sim = True
     if args.side is not None:
         on = set(filter(None, args.side.split(",")))
         eng.pass2_on_side, eng.tail_on_side, eng.cached_on_side = "p2" in on, "tail" in on, "cached" in on

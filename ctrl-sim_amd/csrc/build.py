@@ -11,11 +11,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # sources -> extra flags.  The three split-operand kernel files are compiled ONCE PER SCHEME (csrc/split.h: -DCTRLSIM_F16X3=1 two fp16
 # planes, =0 three bf16 planes; each build lives in its own namespace) and dispatch.hip picks one at run time.
 SPLIT_SRCS = ("gemm_bf16x6", "ffn_fused", "attention_bf16x6")
-# sim.hip additionally with -fno-slp-vectorize: with clang's SLP vectoriser on (packed-f32 math, 64 / 128-bit LDS accesses stitched
-# from neighbouring scalar ones) a simulator workgroup that shares its CU with LDS-heavy workgroups of another kernel produced
-# different results from identical inputs (lanes 48-63 of a wave: wrong x-velocity); 0 of 96 provoked runs differ without it, 23 of
-# 48 with it, no cost (tools/stress_streams.py, tools/sim_variants.sh).
-SRCS = {"gemm": "", "attention": "", "sim": "-ffp-contract=off -fno-slp-vectorize", "context": "-ffp-contract=off", "embed": "",
+# EVERY source is compiled with -fno-slp-vectorize (COMMON below).  With clang's SLP vectoriser on — it stitches neighbouring scalar
+# float operations into packed-fp32 instructions with operand swizzles (v_pk_mul_f32 ... op_sel:[1,0], v_pk_mov_b32) and neighbouring
+# LDS accesses into 64 / 128-bit ones — a workgroup that SHARES ITS CU with matrix-pipe workgroups of ANOTHER kernel now and then
+# produced different results from identical inputs (the simulator step beside the split-operand GEMM: lanes 48-63 of a wave with a
+# wrong x-velocity; few-row matrix kernels beside full-row ones: a flipped token).  Provoked rollouts that differ from the
+# single-stream rollout (tools/stress_streams.py, 8 scenes): simulator beside matrix kernels 23/48 with SLP, 0/176 at -O1, 0/112
+# with -fno-slp-vectorize, 0/48 with SLP but without packed-fp32 instructions (-target-feature -packed-fp32-ops); few-row kernels on
+# the side streams 16/64 with SLP in the matrix kernels, 0/64 without.  No throughput cost (113.39 k vs 113.38 k).
+COMMON = "-fno-slp-vectorize"
+SRCS = {"gemm": "", "attention": "", "sim": "-ffp-contract=off", "context": "-ffp-contract=off", "embed": "",
         "map_encoder": "", "sample": "", "metrics": "-ffp-contract=off", "rewards": "-ffp-contract=off", "forward": "", "dispatch": "", "api": ""}
 OUT = os.path.join(HERE, "libctrlsim_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -42,7 +47,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(HERE, OBJDIR, objname + ".o")
         os.makedirs(os.path.dirname(obj), exist_ok=True)
         objs.append(obj)
-        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj] + extra.split()
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj] + COMMON.split() + extra.split()
         cmd += os.environ.get("CTRLSIM_EXTRA_DEFS", "").split()   # A/B tuning knobs, e.g. -DGEMM_TBK=16
         stamp = obj + ".flags"                                     # an object is stale when its command line changed, too
         same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(cmd)

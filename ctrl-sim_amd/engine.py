@@ -198,17 +198,17 @@ class RolloutEngine:
         self.kinematic = int(bool(kinematic))
         self.max_ctx = int(max_ctx)
         self.use_cache = bool(use_cache) and not self.dims.VARIANT    # the K/V-cached phase is built for the CtRL-Sim tokens
-        # Few-row kernels on the lanes' side streams (second pass, the tail of the first pass, whole K/V-cached steps) underneath
-        # the other lane's full-row kernels: +4 % throughput (109.0 -> 113.6 k agent-steps/s), but OFF by default — with three
-        # queues busy all the time, rollouts stopped being reproducible on the MI355X boxes used here: in ~1 of 3 runs a simulator
-        # block produced different outputs from bit-identical inputs (a 16-lane group of a wave's values zeroed, or a box-box test
-        # flipping), with any version of the simulator kernel, with its LDS pre-filled, without register spills anywhere, and never
-        # with these switches off (40 / 40 identical) or with a host synchronisation before the simulator launch.  The wave state
-        # changes under a kernel that is itself deterministic (tools/microbench notes in profiles/README.md): not root-caused.
-        self.forward_waits_for_sim = True       # _forward_waits (False only to reproduce the hazard: tools/stress_streams.py)
-        self.pass2_on_side = False
-        self.tail_on_side = False
-        self.cached_on_side = False
+        # Few-row kernels on the lanes' side streams (second pass, the tail of the first pass, whole K/V-cached steps) underneath the
+        # other lane's full-row kernels: +6.5 % throughput (113.4 -> 120.7 k agent-steps/s).  ON by default since round 3: the
+        # irreproducibility that kept them off in round 2 was traced to code of clang's SLP vectoriser (packed-fp32 instructions with
+        # operand swizzles) in workgroups that share a CU with another kernel's matrix-pipe workgroups; the library is built without
+        # that pass (csrc/build.py) and provoked rollouts are bit-identical to single-stream ones (DESIGN.md section 4,
+        # tests/test_gpu_hazard.py).  forward_waits_for_sim is the round-2 stream guard (a forward pass waits for every pending
+        # simulator step): not needed any more, and it serialises exactly the overlap the switches create; kept as an A/B switch.
+        self.forward_waits_for_sim = False
+        self.pass2_on_side = True
+        self.tail_on_side = True
+        self.cached_on_side = True
         self.device_ledger = self.dims.VARIANT == 3    # DT: RTG rows from the device reward ledger (the plugin surface feeds hist_rtg itself)
         self.contacts = bool(contacts) and not kinematic
         self.dt = float(cfg.nocturne.dt)
@@ -488,10 +488,10 @@ class RolloutEngine:
             L.sim_in_flight = True
 
     def _forward_waits(self, st):
-        """Before a forward pass is queued on stream st: the simulator steps of ALL lanes must have finished.  A lane's step may run
-        underneath the other lane's grouping / context kernels, but not underneath its matrix kernels — with that overlap
-        (provoked by delaying the simulator step, tools/stress_streams.py) rollouts stopped being reproducible.
-        In the natural timing the step is long finished when the forward starts and the wait costs nothing."""
+        """The round-2 stream guard, OFF by default (forward_waits_for_sim): before a forward pass is queued on stream st, wait for the
+        simulator steps of ALL lanes.  It kept a simulator step from running underneath another lane's matrix kernels while that
+        overlap made rollouts irreproducible; the cause (SLP-vectorised code beside matrix-pipe workgroups) is
+        gone from the build, and the wait would serialise the second pass on a side stream behind the other lane's first pass."""
         for L2 in self.lanes:
             if L2.sim_in_flight and self.forward_waits_for_sim:
                 st.wait_event(L2.ev_sim)
