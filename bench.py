@@ -169,6 +169,8 @@ def main():
     _lib.check(lib.ctrlsim_prof_collect_stream(main_stream, 1, ms, cnt, fl, by), "prof_collect")
     _lib.check(lib.ctrlsim_prof_collect_stream(main_stream, 0, sms, scnt, sfl, sby), "prof_collect")
     _lib.check(lib.ctrlsim_prof_collect_sub(main_stream, 1, kms, kcnt, kfl, kby), "prof_collect_sub")
+    skms = (C.c_double * nsub)(); skcnt = (C.c_int64 * nsub)(); skfl = (C.c_double * nsub)(); skby = (C.c_double * nsub)()
+    _lib.check(lib.ctrlsim_prof_collect_sub(main_stream, 0, skms, skcnt, skfl, skby), "prof_collect_sub")
     for i in range(2, ncls):                                  # satellites: wherever they ran
         ms[i] += sms[i]; cnt[i] += scnt[i]; fl[i] += sfl[i]; by[i] += sby[i]
     lib.ctrlsim_prof_enable(0)
@@ -277,8 +279,8 @@ def main():
                   "fused feed-forward block: ffn_fused_bf16x6_kernel", "causal self-attention: attention_bf16x6_kernel<1,true>",
                   "key-padded scene / cross attention: attention_bf16x6_kernel<0,true>")
 
-        def kernel_rows():
-            """Main-stream launches by kernel (2 * kind + few-row flag, include/ctrlsim.h: ctrlsim_prof_collect_sub)."""
+        def kernel_rows(kms=kms, kcnt=kcnt, kfl=kfl, kby=kby):
+            """Launches by kernel (2 * kind + few-row flag, include/ctrlsim.h: ctrlsim_prof_collect_sub): main stream by default."""
             rows = []
             for i in range(nsub):
                 if kcnt[i] == 0 or kms[i] <= 0:
@@ -304,6 +306,10 @@ def main():
                                   "side stream underneath the other lane's grouping / context kernels — a forward pass waits for "
                                   "every pending simulator step (engine._forward_waits), so it never runs beside matrix kernels",
                 "kernels": kernel_rows(),
+                "kernels_on_side_streams": kernel_rows(skms, skcnt, skfl, skby),
+                "kernels_note": "main-stream launches run back to back and own the chip: their event intervals are kernel times; the "
+                                "few-row launches on the lanes' side streams run UNDERNEATH them (their intervals overlap those and "
+                                "each other: time_share is event time / wall time, not a share of the critical path)",
                 "end_to_end": {"achieved": e2e, "peak": PEAK_FP32_EQUIV_TFLOPS, "unit": "TFLOP/s", "frac": e2e / PEAK_FP32_EQUIV_TFLOPS,
                                "note": "ALL algorithmic fp32 FLOPs of the timed region (both MFMA classes on every stream + the folded map "
                                        "encoder) / wall time of the timed region / the split-operand roof"}}

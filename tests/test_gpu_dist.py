@@ -37,5 +37,6 @@ def test_bench_collective_runs_through_rccl_at_world_size_one():
         assert rccl["rollout_metrics"][k] == pytest.approx(v, rel=1e-12, abs=1e-15), k
     for out in (plain, rccl):
         assert out["parity_spot_check"]["identical"] is True, out["parity_spot_check"]
-        assert out["roofline"]["kernels"] and out["roofline"]["end_to_end"]["frac"] > 0
+        r = out["roofline"]          # (an 8-step rollout is all K/V-cached steps: its kernels run on the lanes' side streams)
+        assert (r["kernels"] or r["kernels_on_side_streams"]) and r["end_to_end"]["frac"] > 0
         assert len(out["config"]["size_classes"]) == 16

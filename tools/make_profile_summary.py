@@ -103,6 +103,30 @@ def main():
                          f"{v['frac']:.3f} | {100 * v['time_share_of_step']:.1f} % |")
     lines += ["", "The HIP-event interval brackets each launch on the launch stream, so it includes a few microseconds of dispatch gap; with two",
               "lanes a side-stream kernel (sim_step, group_build) can share the chip with the bracketed kernel, which lengthens both a little."]
+    import os
+    if os.path.exists(f"gpurun_out/prof_{R}s/{R}s_kernel_stats.csv"):
+        # the serialised twin of the command (--side ""): no kernel overlaps another, so rocprofv3's averages and the HIP-event averages
+        # of bench.py measure the same intervals
+        rs = list(csv.DictReader(open(f"gpurun_out/prof_{R}s/{R}s_kernel_stats.csv")))
+        bs = json.load(open(f"gpurun_out/bench_{R}s.json"))
+        ag = collections.OrderedDict()
+        for r_ in rs:
+            a_ = ag.setdefault(short(r_["Name"]), [0, 0.0])
+            a_[0] += int(r_["Calls"]); a_[1] += float(r_["TotalDurationNs"])
+        def cls2(keys):
+            return (sum(v[0] for k, v in ag.items() if any(x in k for x in keys)), sum(v[1] for k, v in ag.items() if any(x in k for x in keys)))
+        (g2c, g2t), (a2c, a2t) = cls2(GEMM_KEYS), cls2(ATTN_KEYS)
+        r2 = bs["roofline"]; o2 = r2["other"]
+        if "attention" in r2["kernel"]:
+            r2, o2 = o2, r2
+        lines += ["", "## Serialised twin of the command (`--side \"\"`: every kernel on one stream) — agreement of the two clocks", "",
+                  f"`value` = {bs['value']:.0f} agent-steps/s un-profiled.  With the side streams on (the default, above) an event interval on a side stream",
+                  "also holds the kernel's wait for free CUs and kernel durations overlap; serialised, both clocks bracket the same intervals:", "",
+                  "| class | rocprofv3 avg per launch (warm-up + timed) | bench.py HIP-event avg per launch | launches (rocprof / bench) |", "|---|---|---|---|",
+                  f"| Linear class | {g2t / g2c / 1e6:.4f} ms | {r2['avg_launch_ms']:.4f} ms | {g2c} / {r2['launches']} |",
+                  f"| attention class | {a2t / a2c / 1e6:.4f} ms | {o2['avg_launch_ms']:.4f} ms | {a2c} / {o2['launches']} |", "",
+                  f"Serialised roofline: Linear class {r2['achieved']:.1f} TFLOP/s = {r2['frac']:.3f}, attention class {o2['achieved']:.1f} = {o2['frac']:.3f} "
+                  "(all launches, few-row ones included, as in round 2)."]
     open(f"profiles/{R}_b_kernel_stats.md", "w").write("\n".join(lines) + "\n")
     json.dump(b, open(f"profiles/{R}_bench_line.json", "w"), indent=1)
 

@@ -14,6 +14,14 @@ ROOT=$(pwd)
 ( cd /tmp && export TMPDIR=/tmp && cd "$ROOT" && rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$R -o $R --output-format csv -- $CMD --no-cpu-baseline > gpurun_out/prof_$R/run.log 2>&1 )
 find gpurun_out/prof_$R -name "*_kernel_trace.csv" -delete          # tens of MB; the stats csv is what is summarised
 find gpurun_out/prof_$R -name "*kernel_stats.csv" -exec cp {} gpurun_out/prof_$R/${R}_kernel_stats.csv \; 2>/dev/null
+# the same command with every kernel on ONE stream (--side ""): kernel durations then do not overlap and rocprofv3's per-kernel averages
+# can be compared one to one with bench.py's HIP-event averages (with the side streams on, an event interval on a side stream also
+# holds the kernel's wait for free CUs)
+mkdir -p gpurun_out/prof_${R}s
+$CMD --side "" --no-cpu-baseline > gpurun_out/bench_${R}s.json 2> gpurun_out/bench_${R}s.err
+( cd /tmp && export TMPDIR=/tmp && cd "$ROOT" && rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${R}s -o ${R}s --output-format csv -- $CMD --side "" --no-cpu-baseline > gpurun_out/prof_${R}s/run.log 2>&1 )
+find gpurun_out/prof_${R}s -name "*_kernel_trace.csv" -delete
+find gpurun_out/prof_${R}s -name "*kernel_stats.csv" -exec cp {} gpurun_out/prof_${R}s/${R}s_kernel_stats.csv \; 2>/dev/null
 bash tools/pmc_traffic.sh gpurun_out/pmc_$R -- $PMC > /dev/null
 find gpurun_out/pmc_$R -name "*counter_collection.csv" -delete      # summarised in summary.json
 ls -la gpurun_out/prof_$R gpurun_out/pmc_$R; tail -c 600 gpurun_out/bench_$R.json
