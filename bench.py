@@ -219,6 +219,12 @@ def main():
     if dist is not None:
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
     acc = metrics.MetricAccumulators().unpack(vec.cpu().numpy())
+    n_vec = int(vec.numel())
+    backend = dist.get_backend() if dist is not None else "none (single process)"
+    if dist is not None:                      # every collective of the job is done: the ranks part here, rank 0 goes on to the (untimed)
+        dist.barrier()                        # CPU baseline and the report without holding seven idle ranks in a process group
+        dist.destroy_process_group()
+        dist = None
 
     if rank == 0:
         agent_steps = S * N * R * world
@@ -346,15 +352,12 @@ def main():
                        "size_classes": list(eng.sizes),
                        "few_row_kernels_on_side_streams": {"second_pass": eng.pass2_on_side, "first_pass_tail": eng.tail_on_side,
                                                            "cached_steps": eng.cached_on_side},
-                       "collective": (f"one all-reduce (SUM) of the {int(vec.numel())}-double metric vector + barriers, backend "
-                                      f"{dist.get_backend() if dist is not None else 'none (single process)'}, world {world}"),
+                       "collective": (f"one all-reduce (SUM) of the {n_vec}-double metric vector + barriers, backend {backend}, world {world}"),
                        "parallelism": f"scenario-sharded x{world}"},
             "roofline": roof, "cpu_baseline": cpu, "parity_spot_check": spot,
             "rollout_metrics": {k: (None if v != v else v) for k, v in m.items()},
         }
         print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 def cpu_model():
