@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
   // tokens (earlier steps, and the state tokens of their step).
   constexpr int K_PLANE = KT6 * HD;              // bf16 elements: [ks 2][half 2][64 keys][8]
   constexpr int V_PLANE = HD * KT6;              // [16 quads][32 d][4 keys]
-  constexpr int BUF = NPL * (K_PLANE + V_PLANE) + 2 * KT6;   // + KT6 floats of key-padding bias
+  constexpr int BUF = NPL * (K_PLANE + V_PLANE) + 2 * KT6 + 8;   // + KT6 floats of key-padding bias + two "sub-tile has padded keys" flags
 #ifdef ATT_RING3
   constexpr int NBUF = PRE ? 3 : 2;              // pre-split images: a ring of three stages, the DMA runs two tiles ahead
 #else
@@ -184,6 +184,7 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
   // staging registers: K rows (idx -> row, 4 consecutive d), V row PAIRS (thread -> keys 2rp, 2rp+1, 4 consecutive d)
   f32x4 pk[2], pv[2];
   float ppad = 0.f;
+  unsigned long long ppad_bal = ~0ull;             // wave 0: which of the staged tile's 64 keys are padded
   const op_t* img = PRE ? reinterpret_cast<const op_t*>(K) + (cd.img_off + ((size_t)b * NHEAD + h) * (size_t)kv_batch_stride) * KV_IMG : nullptr;
   auto gload = [&](int k0, int buf) {
     if (PRE) {
@@ -221,8 +222,13 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
     if (MODE == MODE6_KEYPAD && tid < KT6) {
       const int kr = k0 + tid;
       ppad = (kr < Lk && !key_pad[(size_t)b * Lk + kr]) ? 0.f : NEG_INF;
+      ppad_bal = __ballot(ppad != 0.f);
       // three-stage ring: the stage is free when its DMA is issued (and ppad would be overwritten by the next request)
-      if (NBUF == 3) reinterpret_cast<float*>(arena + buf * BUF + NPL * (K_PLANE + V_PLANE))[tid] = ppad;
+      if (NBUF == 3) {
+        float* pb_ = reinterpret_cast<float*>(arena + buf * BUF + NPL * (K_PLANE + V_PLANE));
+        pb_[tid] = ppad;
+        if (tid < 2) reinterpret_cast<int*>(pb_ + KT6)[tid] = 1;
+      }
     }
   };
   auto sstore = [&](int buf) {
@@ -250,7 +256,13 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
       }
     }
     }
-    if (NBUF != 3 && MODE == MODE6_KEYPAD && tid < KT6) reinterpret_cast<float*>(Vd + NPL * V_PLANE)[tid] = ppad;
+    if (NBUF != 3 && MODE == MODE6_KEYPAD && tid < KT6) {
+      float* pb_ = reinterpret_cast<float*>(Vd + NPL * V_PLANE);
+      pb_[tid] = ppad;
+      // a 32-key sub-tile without a padded key (the rule: every polyline and vehicle row of a scene is a valid key) skips the bias
+      // reads and adds in the loop below
+      if (tid < 2) reinterpret_cast<int*>(pb_ + KT6)[tid] = (unsigned)(ppad_bal >> (32 * tid)) != 0u;
+    }
   };
 
   // ---- tile schedule: the regular tiles [0, n_reg) that hold keys < k_end, then the representative tiles (compact contexts)
@@ -288,6 +300,11 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
     const op_t* Ks = arena + cur * BUF;
     const op_t* Vs = Ks + NPL * K_PLANE;
     const float* padbias = reinterpret_cast<const float*>(Vs + NPL * V_PLANE);
+    int padflag[2] = {1, 1};
+    if (MODE == MODE6_KEYPAD) {
+      padflag[0] = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(padbias + KT6)[0]);
+      padflag[1] = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(padbias + KT6)[1]);
+    }
 
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
@@ -346,10 +363,10 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
 #endif
       }
       float sc[16];
-      if (MODE == MODE6_KEYPAD) {
+      if (MODE == MODE6_KEYPAD && padflag[sub]) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = s0[r] + padbias[sub * 32 + mfma_row(r, half)];
-      } else if (need_mask) {
+      } else if (MODE == MODE6_CAUSAL && need_mask) {
         // visibility of the 32 keys of this sub-tile for this lane's query as a bit mask (bit i <-> key ks0 + i):
         //   keys of earlier timesteps: all; of the query's timestep: every state token (offset % 3 == 0) and the query's
         //   own agent's tokens up to the query itself; later timesteps and keys >= Lk: none.
