@@ -301,10 +301,12 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
     const op_t* Vs = Ks + NPL * K_PLANE;
     const float* padbias = reinterpret_cast<const float*>(Vs + NPL * V_PLANE);
     int padflag[2] = {1, 1};
+#ifndef ATT_NO_PADSKIP      // (A/B switch of tools/microbench: every sub-tile takes the bias path)
     if (MODE == MODE6_KEYPAD) {
       padflag[0] = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(padbias + KT6)[0]);
       padflag[1] = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(padbias + KT6)[1]);
     }
+#endif
 
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
