@@ -97,7 +97,8 @@ enum { OPT_ATTN_IMPL = 0, OPT_GEMM_IMPL = 1,   // 0 = f32-input MFMA, 1 = split-
        OPT_SPLIT = 4,                            // operand split of the split-operand kernels (csrc/split.h): 1 = two fp16 planes, three
                                                  // products (default), 0 = three bf16 planes, six products (full fp32 exponent range)
        OPT_MAP_MFMA = 5,                         // map-encoder point pooling: 1 = matrix-pipe kernel (two-fp16-plane split only), 0 = fp32 VALU kernel
-       OPT_COUNT = 6 };
+       OPT_GEMM_WS = 6,                          // Linear(256 -> 256) [+ LayerNorm]: 1 = weight-stationary streaming kernel (gemm_bf16x6.hip)
+       OPT_COUNT = 7 };
 // run-time view of the selected split (dispatch.hip): planes per operand, 16-bit elements per (context, head, tile) K/V image
 int split_npl();
 inline size_t split_kimg() { return (size_t)2 * split_npl() * 64 * 32; }

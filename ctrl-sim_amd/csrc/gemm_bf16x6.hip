@@ -519,6 +519,212 @@ int launch_gemm_nt_bf16x6_kv(const float* A, int lda, const void* W3, int n_tota
   return launch_gemm_nt_bf16x6_kvc(A, lda, W3, n_total, n0, bias, R, ldr, C, ldc, M, N, K, relu, ln_gamma, ln_beta, kv_img, kv_col0,
                                    1, &c, st);
 }
+
+#if CTRLSIM_F16X3
+// ---- Weight-stationary Linear(256 -> 256) [+ residual] [+ LayerNorm] [+ ReLU] for tall row matrices (OPT_GEMM_WS).
+// The tiled kernel above re-streams the 256 KB of weight planes for every 64-row tile and keeps three phases per k-step in
+// barrier lock-step; on this shape (3 KB of HBM traffic per row against 0.26 MFLOP) it reaches about 60 % of its HBM floor.
+// Here the WEIGHTS stay in registers for the life of a persistent workgroup: 8 waves, wave w owns output columns
+// [32 w, 32 w + 32) and holds their 16 k-steps x 2 planes as MFMA A-operand fragments (128 VGPRs).  Rows stream through in
+// blocks of 32, and every byte of global traffic is a whole 1 KB row per instruction:
+//   * activation rows AND residual rows arrive as raw fp32 by LDS-DMA (padded LDS rows: conflict-free 16-byte fragment reads),
+//     requested two blocks ahead (two buffers each), so a block's loads have a whole iteration to land;
+//   * every wave splits the activation rows it reads in registers (the same values in all 8 waves: 12 VALU instructions per
+//     k-step beside the 3 MFMAs) and computes D^T = W_slab . A^T, so a lane ends up with 16 columns of ONE row: bias /
+//     residual / LayerNorm / ReLU run in registers; the per-wave LayerNorm partials (mean and centred sum of squares of 32
+//     columns) are merged with the parallel-variance formula after the block's first barrier;
+//   * results are written over the residual rows in LDS (same lane, same addresses) and leave, after the second barrier, as
+//     whole rows (16 bytes per lane, nontemporal).
+// The first barrier is taken after `s_waitcnt vmcnt(0)`: it also tells every wave that the next block's rows have landed and
+// that the activation buffer the k-loop just read may be refilled.  The DMA is issued as inline asm (see
+// attention_bf16x6.hip: the compiler answers the builtin with a full drain before the next ds_read).
+#define WS_ROWS 32
+#ifndef WS_AHEAD
+#define WS_AHEAD 2
+#endif
+// eight fp32 values -> hi / residual fp16 fragments; the residual straight from the mixed-precision FMA (lo = f16(a - (float)hi):
+// the same bits as convert - subtract - convert, half the instructions)
+__device__ __forceinline__ void ws_split8(const f32x4 a, const f32x4 b, opx8 (&f)[NPL]) {
+  u32x4 hi, lo;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float x0 = i < 2 ? a[2 * i] : b[2 * i - 4], x1 = i < 2 ? a[2 * i + 1] : b[2 * i - 3];
+    const unsigned h = op_cvt_pk(x0, x1);
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(x1));
+    hi[i] = h; lo[i] = l;
+  }
+  f[0] = __builtin_bit_cast(opx8, hi);
+  f[1] = __builtin_bit_cast(opx8, lo);
+}
+#define WS_LD 260          // floats per LDS row (1040 B: the 16 lanes of a ds_read_b128 group hit 16 different bank quads)
+#define WS_LDS_BYTES ((4 * WS_ROWS * WS_LD + 3 * 256 + 8 * WS_ROWS * 2) * 4)
+template <bool RELU, bool RESID, bool LN>
+__global__ __launch_bounds__(512, 2) void gemm_ws256_kernel(const float* A, int lda, const op_t* __restrict__ W3,
+                                                            const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* R, int ldr, float* C,
+                                                            int ldc, int M, int n_total, int n0, int* __restrict__ nonfinite) {
+  extern __shared__ __attribute__((aligned(16))) float ws_lds[];
+  float* const abuf = ws_lds;                               // [2][WS_ROWS * WS_LD]  activation rows
+  float* const rbuf = ws_lds + 2 * WS_ROWS * WS_LD;         // [2][WS_ROWS * WS_LD]  residual rows in, result rows out
+  float* const cvec = ws_lds + 4 * WS_ROWS * WS_LD;         // [3][256]              bias, gamma, beta
+  float* const part = cvec + 3 * 256;                       // [8][WS_ROWS][2]       LayerNorm partials
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int nblk = (M + WS_ROWS - 1) / WS_ROWS;
+  if ((int)blockIdx.x >= nblk) return;
+
+  // rows 4 wave .. 4 wave + 3 of block (blockIdx.x + j * gridDim.x) into buffer j & 1
+  auto dma = [&](const float* src0, int ld, float* dst0, int j) {
+    const int blk = blockIdx.x + j * gridDim.x;
+    if (blk >= nblk) return;
+#ifdef WS_ABL_NODMA
+    if (M > 0) return;
+#endif
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = 4 * wave + q;
+      int grow = blk * WS_ROWS + r;
+      grow = grow < M ? grow : M - 1;                                          // rows past the end: any valid row (never stored)
+      const float* src = src0 + (size_t)grow * ld + lane * 4;
+      const unsigned lds_addr = (unsigned)(size_t)((__attribute__((address_space(3))) float*)(dst0 + (j & 1) * WS_ROWS * WS_LD + r * WS_LD));
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off ; WS-DMA"
+                   :: "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(src) : "memory");
+    }
+  };
+  dma(A, lda, abuf, 0);
+  if (RESID) dma(R, ldr, rbuf, 0);
+
+  opx8 wf[16][NPL];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+      wf[ks][p] = *reinterpret_cast<const opx8*>(W3 + ((((size_t)ks * NPL + p) * 2 + half) * n_total + n0 + 32 * wave + l31) * 8);
+  if (tid < 256) {
+    cvec[tid] = bias ? bias[tid] : 0.f;
+    cvec[256 + tid] = LN ? gamma[tid] : 0.f;
+    cvec[512 + tid] = LN ? beta[tid] : 0.f;
+  }
+  dma(A, lda, abuf, 1);
+  if (RESID) dma(R, ldr, rbuf, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int c0 = 32 * wave + 4 * half;            // this lane's columns: c0 + 8 q + j
+  const int njobs = (nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  for (int it = 0; it < njobs; ++it) {
+    const int blk = blockIdx.x + it * gridDim.x;
+    const float* ab = abuf + (it & 1) * WS_ROWS * WS_LD;
+    float* rb = rbuf + (it & 1) * WS_ROWS * WS_LD;
+    f32x16 acc, acc1, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = acc2[r] = 0.f;
+    const float* ap = ab + l31 * WS_LD + 8 * half;
+#ifndef WS_ABL_NOK
+    // fragment reads run WS_AHEAD k-steps ahead of the MFMAs that consume them (two waves per SIMD do not hide an LDS round
+    // trip per k-step on their own; the scheduling barriers keep the compiler from sinking the reads back to their use)
+    f32x4 xq[WS_AHEAD + 1][2];
+#pragma unroll
+    for (int ks = 0; ks < WS_AHEAD; ++ks) {
+      xq[ks][0] = *reinterpret_cast<const f32x4*>(ap + ks * 16);
+      xq[ks][1] = *reinterpret_cast<const f32x4*>(ap + ks * 16 + 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const f32x4 lo = xq[ks % (WS_AHEAD + 1)][0], hi = xq[ks % (WS_AHEAD + 1)][1];
+      opx8 fb[NPL];
+      ws_split8(lo, hi, fb);
+      acc1 = MFMA_OP(wf[ks][1], fb[0], acc1);             // one accumulator per partial product: no MFMA waits for the one before
+      acc2 = MFMA_OP(wf[ks][0], fb[1], acc2);
+      if (ks + WS_AHEAD < 16) {
+        xq[(ks + WS_AHEAD) % (WS_AHEAD + 1)][0] = *reinterpret_cast<const f32x4*>(ap + (ks + WS_AHEAD) * 16);
+        xq[(ks + WS_AHEAD) % (WS_AHEAD + 1)][1] = *reinterpret_cast<const f32x4*>(ap + (ks + WS_AHEAD) * 16 + 4);
+      }
+      acc = MFMA_OP(wf[ks][0], fb[0], acc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acc1[r] + acc2[r];   // (W_lo x_hi + W_hi x_lo) + W_hi x_hi; element-wise on purpose: the
+                                                                // vector form becomes packed-fp32 adds (see build.py on those)
+#else
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) asm volatile("" :: "v"(wf[ks][0]), "v"(wf[ks][1]));
+    acc[0] = ap[0];
+#endif
+    float v[16];
+    float* yrow = rb + l31 * WS_LD + c0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 t = *reinterpret_cast<const f32x4*>(cvec + c0 + 8 * q);
+      if (RESID) t += *reinterpret_cast<const f32x4*>(yrow + 8 * q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[4 * q + j] = acc[4 * q + j] * WSCALE_INV + t[j];
+    }
+    if (LN) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += v[r];
+      s += __shfl_xor(s, 32);
+      const float mw = s * (1.f / 32.f);
+      float m2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m2 += (v[r] - mw) * (v[r] - mw);
+      m2 += __shfl_xor(m2, 32);
+      if (half == 0) *reinterpret_cast<f32x2*>(part + (wave * WS_ROWS + l31) * 2) = f32x2{mw, m2};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next block's rows (and this wave's older stores) are done ...
+    __syncthreads();                                      // ... for every wave; LayerNorm partials visible; ab is free
+    dma(A, lda, abuf, it + 2);
+    if (LN) {
+      f32x2 pw[8];
+#pragma unroll
+      for (int w = 0; w < 8; ++w) pw[w] = *reinterpret_cast<const f32x2*>(part + (w * WS_ROWS + l31) * 2);
+      float mean = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) mean += pw[w][0];
+      mean *= (1.f / 8.f);
+      float m2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) m2 += pw[w][1] + 32.f * (pw[w][0] - mean) * (pw[w][0] - mean);
+      const float var = m2 * (1.f / 256.f);
+      if (wave == 0 && half == 0 && blk * WS_ROWS + l31 < M && !(var <= 3.0e38f)) atomicAdd(nonfinite, 1);
+      const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(cvec + 256 + c0 + 8 * q);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(cvec + 512 + c0 + 8 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * q + j] = (v[4 * q + j] - mean) * rstd * g4[j] + b4[j];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 y = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+      if (RELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = fmaxf(y[j], 0.f);
+      }
+      *reinterpret_cast<f32x4*>(yrow + 8 * q) = y;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = 4 * wave + q, grow = blk * WS_ROWS + r;
+#ifdef WS_ABL_NOST
+      if (grow < M && grow == -5)
+#else
+      if (grow < M)
+#endif
+        __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(rb + r * WS_LD + lane * 4),
+                                    reinterpret_cast<f32x4*>(C + (size_t)grow * ldc + lane * 4));
+    }
+    if (RESID) dma(R, ldr, rbuf, it + 2);                 // this wave's four rows of rb: read by its own stores above only
+  }
+}
+#endif
+
 int launch_gemm_nt_bf16x6_kvc(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias,
                               const float* R, int ldr, float* C, int ldc, int M, int N, int K, int relu,
                               const float* ln_gamma, const float* ln_beta, void* kv_img, int kv_col0, int kv_n,
@@ -544,6 +750,43 @@ int launch_gemm_nt_bf16x6_kvc(const float* A, int lda, const void* W3, int n_tot
   const bool ln = ln_gamma != nullptr;
   if (ln && (N != 256 || (ldc & 3) || (R && (ldr & 3)))) return CTRLSIM_EINVAL;
   if (!ln && R && relu) return CTRLSIM_EINVAL;
+#if CTRLSIM_F16X3
+  // OPT_GEMM_WS: bit 0 = launches of at least two row blocks per CU, bit 1 = the smaller ones
+  if (!kv_img && N == 256 && K == 256 && !(ldc & 3) && (!R || !(ldr & 3)) &&
+      (ctrlsim_option(OPT_GEMM_WS) & (M >= 2 * WS_ROWS * 256 ? 1 : 2))) {
+    const int nblk = (M + WS_ROWS - 1) / WS_ROWS;
+    static const int cus = [] {
+      int dev = 0, n = 0;
+      return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }();
+    dim3 g(nblk < cus ? nblk : cus), b(512);
+    const op_t* w = static_cast<const op_t*>(W3);
+    int* nonfinite = ctrlsim_nonfinite_ptr();
+    prof_before(PROF_GEMM, st);
+#define WS_LAUNCH(RELU_, RESID_, LN_)                                                                                  \
+  do {                                                                                                                 \
+    static const bool attr_ok =                                                                                        \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ws256_kernel<RELU_, RESID_, LN_>),                     \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES) == hipSuccess;                   \
+    if (!attr_ok) return CTRLSIM_EINVAL;                                                                               \
+    hipLaunchKernelGGL((gemm_ws256_kernel<RELU_, RESID_, LN_>), g, b, WS_LDS_BYTES, st, A, lda, w, bias, ln_gamma,     \
+                       ln_beta, R, ldr, C, ldc, M, n_total, n0, nonfinite);                                            \
+  } while (0)
+    if (ln) {
+      if (R && relu) WS_LAUNCH(true, true, true);
+      else if (R) WS_LAUNCH(false, true, true);
+      else if (relu) WS_LAUNCH(true, false, true);
+      else WS_LAUNCH(false, false, true);
+    } else if (R) WS_LAUNCH(false, true, false);
+    else if (relu) WS_LAUNCH(true, false, false);
+    else WS_LAUNCH(false, false, false);
+#undef WS_LAUNCH
+    const double MN = (double)M * N;
+    prof_after(PROF_GEMM, 2.0 * MN * (double)K, st, 4.0 * (double)M * K + 4.0 * MN + (R ? 4.0 * MN : 0.0) + 2.0 * NPL * (double)N * K,
+               ln ? PKIND_GEMM_LN : PKIND_GEMM_PLAIN);
+    return ctrlsim_launch_status();
+  }
+#endif
   const int tile_opt = ctrlsim_option(OPT_GEMM6_TILE);          // 0 = auto, 1 = 128x128, 2 = 64x256 (A/B knob)
   const bool wide = !kv_img && (ln || tile_opt == 2);
   const bool small = !wide && tile_opt == 3;                     // 64x128 tiles (wave tile 32x64), 4 workgroups per CU
