@@ -542,6 +542,10 @@ int launch_gemm_nt_bf16x6_kv(const float* A, int lda, const void* W3, int n_tota
 #ifndef WS_AHEAD
 #define WS_AHEAD 2
 #endif
+__device__ __forceinline__ f32x16 ws_fake_mfma(opx8 a, opx8 b, f32x16 c) {      // ablation builds only
+  c[0] += (float)a[0] * (float)b[0];
+  return c;
+}
 // eight fp32 values -> hi / residual fp16 fragments; the residual straight from the mixed-precision FMA (lo = f16(a - (float)hi):
 // the same bits as convert - subtract - convert, half the instructions)
 __device__ __forceinline__ void ws_split8(const f32x4 a, const f32x4 b, opx8 (&f)[NPL]) {
@@ -560,11 +564,21 @@ __device__ __forceinline__ void ws_split8(const f32x4 a, const f32x4 b, opx8 (&f
 }
 #define WS_LD 260          // floats per LDS row (1040 B: the 16 lanes of a ds_read_b128 group hit 16 different bank quads)
 #define WS_LDS_BYTES ((4 * WS_ROWS * WS_LD + 3 * 256 + 8 * WS_ROWS * 2) * 4)
-template <bool RELU, bool RESID, bool LN>
+// KV = true (plain Linear, N = 256 G, one column group of 256 per blockIdx.y: the workgroups of group 0 are dispatched first,
+// the others as compute units come free): groups at or beyond kv.k_col0 are the attention keys, then the values, and leave as
+// the split K / V^T tile images (layout and class tables: see the tiled kernel above) straight from the staged result rows.
+template <bool RELU, bool RESID, bool LN, bool KV = false>
 __global__ __launch_bounds__(512, 2) void gemm_ws256_kernel(const float* A, int lda, const op_t* __restrict__ W3,
                                                             const float* __restrict__ bias, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* R, int ldr, float* C,
-                                                            int ldc, int M, int n_total, int n0, int* __restrict__ nonfinite) {
+                                                            int ldc, int M, int n_total, int n0, int* __restrict__ nonfinite,
+                                                            const KvImg kv) {
+  static_assert(!KV || (!RELU && !RESID && !LN), "the K / V image epilogue belongs to the plain Linear");
+  const int grp = KV ? (int)blockIdx.y : 0;
+  n0 += 256 * grp;
+  if (KV && bias) bias += 256 * grp;
+  const int kv_kind = !KV ? 0 : (256 * grp < kv.k_col0 ? 0 : (256 * grp == kv.k_col0 ? 1 : 2));    // 0 = fp32 rows, 1 = keys, 2 = values
+  if (KV) C += 256 * grp;
   extern __shared__ __attribute__((aligned(16))) float ws_lds[];
   float* const abuf = ws_lds;                               // [2][WS_ROWS * WS_LD]  activation rows
   float* const rbuf = ws_lds + 2 * WS_ROWS * WS_LD;         // [2][WS_ROWS * WS_LD]  residual rows in, result rows out
@@ -613,17 +627,66 @@ __global__ __launch_bounds__(512, 2) void gemm_ws256_kernel(const float* A, int 
 
   const int c0 = 32 * wave + 4 * half;            // this lane's columns: c0 + 8 q + j
   const int njobs = (nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  for (int it = 0; it < njobs; ++it) {
-    const int blk = blockIdx.x + it * gridDim.x;
-    const float* ab = abuf + (it & 1) * WS_ROWS * WS_LD;
-    float* rb = rbuf + (it & 1) * WS_ROWS * WS_LD;
-    f32x16 acc, acc1, acc2;
+  const float* const ap0 = abuf + l31 * WS_LD + 8 * half;
+  const float* const cv = cvec + c0;
+
+  // LayerNorm / ReLU of block `it` (values v, a lane's 16 columns of one row), cut into 16 slots that ride in the VALU gaps of
+  // the NEXT block's k-loop (slot s runs between the MFMAs of k-step s).  Slots 0-3: merge the eight per-wave partials
+  // (parallel-variance formula); 4-11: two columns each; 12-15: one result quad each into the row's place in rb.
+  float v[16];
+  f32x2 pw[8];
+  f32x2 gq, bq;
+  float mean = 0.f, rstd = 1.f, nmr = 0.f;
+  auto epi_slot = [&](int s, float* yrow, bool live_row) {
+    if (LN) {
+      if (s == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = acc2[r] = 0.f;
-    const float* ap = ab + l31 * WS_LD + 8 * half;
+        for (int w = 0; w < 8; ++w) pw[w] = *reinterpret_cast<const f32x2*>(part + (w * WS_ROWS + l31) * 2);
+      } else if (s == 1) {
+        mean = ((pw[0][0] + pw[1][0]) + (pw[2][0] + pw[3][0])) + ((pw[4][0] + pw[5][0]) + (pw[6][0] + pw[7][0]));
+        mean *= (1.f / 8.f);
+      } else if (s == 2) {
+        float m2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) m2 += pw[w][1] + 32.f * (pw[w][0] - mean) * (pw[w][0] - mean);
+        rstd = m2 * (1.f / 256.f);                       // the variance, until slot 3
+      } else if (s == 3) {
+        if (wave == 0 && half == 0 && live_row && !(rstd <= 3.0e38f)) atomicAdd(nonfinite, 1);
+        rstd = 1.0f / sqrtf(rstd + 1e-5f);
+        nmr = -mean * rstd;
+        gq = *reinterpret_cast<const f32x2*>(cv + 256);
+        bq = *reinterpret_cast<const f32x2*>(cv + 512);
+      } else if (s < 12) {
+        const int e = 2 * (s - 4);                       // columns e, e + 1 of the lane's 16: c0 + 8 (e >> 2) + (e & 3)
+        const f32x2 g2 = gq, b2 = bq;
+        if (s < 11) {
+          const int en = e + 2, off = 8 * (en >> 2) + (en & 3);
+          gq = *reinterpret_cast<const f32x2*>(cv + 256 + off);
+          bq = *reinterpret_cast<const f32x2*>(cv + 512 + off);
+        }
+        v[e] = (v[e] * rstd + nmr) * g2[0] + b2[0];
+        v[e + 1] = (v[e + 1] * rstd + nmr) * g2[1] + b2[1];
+      }
+    }
+    if (s >= 12) {
+      const int q = s - 12;
+      f32x4 y = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+      if (RELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = fmaxf(y[j], 0.f);
+      }
+      *reinterpret_cast<f32x4*>(yrow + 8 * q) = y;
+    }
+  };
+
+  // one block's 48 MFMAs; fragment reads run WS_AHEAD k-steps ahead (two waves per SIMD do not hide an LDS round trip per
+  // k-step on their own; the scheduling barriers keep the compiler from sinking the reads back to their use).  EPI: the
+  // previous block's epilogue slots ride along.
+  f32x16 acc, acc1;
+  auto kloop = [&](const float* ap, auto epi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = 0.f;
 #ifndef WS_ABL_NOK
-    // fragment reads run WS_AHEAD k-steps ahead of the MFMAs that consume them (two waves per SIMD do not hide an LDS round
-    // trip per k-step on their own; the scheduling barriers keep the compiler from sinking the reads back to their use)
     f32x4 xq[WS_AHEAD + 1][2];
 #pragma unroll
     for (int ks = 0; ks < WS_AHEAD; ++ks) {
@@ -635,32 +698,47 @@ __global__ __launch_bounds__(512, 2) void gemm_ws256_kernel(const float* A, int 
     for (int ks = 0; ks < 16; ++ks) {
       const f32x4 lo = xq[ks % (WS_AHEAD + 1)][0], hi = xq[ks % (WS_AHEAD + 1)][1];
       opx8 fb[NPL];
+#ifdef WS_ABL_NOSPLIT
+      fb[0] = __builtin_bit_cast(opx8, lo); fb[1] = __builtin_bit_cast(opx8, hi);
+#else
       ws_split8(lo, hi, fb);
-      acc1 = MFMA_OP(wf[ks][1], fb[0], acc1);             // one accumulator per partial product: no MFMA waits for the one before
-      acc2 = MFMA_OP(wf[ks][0], fb[1], acc2);
+#endif
+#ifdef WS_ABL_NOMFMA
+#define WS_MFMA(A_, B_, C_) ws_fake_mfma(A_, B_, C_)
+#else
+#define WS_MFMA(A_, B_, C_) MFMA_OP(A_, B_, C_)
+#endif
+      acc1 = WS_MFMA(wf[ks][1], fb[0], acc1);            // the two small products share an accumulator, W_hi x_hi has its own:
+      acc = WS_MFMA(wf[ks][0], fb[0], acc);              // no MFMA waits for the one issued just before it
       if (ks + WS_AHEAD < 16) {
         xq[(ks + WS_AHEAD) % (WS_AHEAD + 1)][0] = *reinterpret_cast<const f32x4*>(ap + (ks + WS_AHEAD) * 16);
         xq[(ks + WS_AHEAD) % (WS_AHEAD + 1)][1] = *reinterpret_cast<const f32x4*>(ap + (ks + WS_AHEAD) * 16 + 4);
       }
-      acc = MFMA_OP(wf[ks][0], fb[0], acc);
+#ifndef WS_ABL_NOEPI
+      epi(ks);
+#endif
+      acc1 = WS_MFMA(wf[ks][0], fb[1], acc1);
       __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] += acc1[r] + acc2[r];   // (W_lo x_hi + W_hi x_lo) + W_hi x_hi; element-wise on purpose: the
-                                                                // vector form becomes packed-fp32 adds (see build.py on those)
 #else
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) asm volatile("" :: "v"(wf[ks][0]), "v"(wf[ks][1]));
+    for (int ks = 0; ks < 16; ++ks) { asm volatile("" :: "v"(wf[ks][0]), "v"(wf[ks][1])); epi(ks); }
     acc[0] = ap[0];
 #endif
-    float v[16];
+  };
+  kloop(ap0, [](int) {});
+
+  for (int it = 0; it < njobs; ++it) {
+    const int blk = blockIdx.x + it * gridDim.x;
+    float* rb = rbuf + (it & 1) * WS_ROWS * WS_LD;
     float* yrow = rb + l31 * WS_LD + c0;
+    const bool live_row = blk * WS_ROWS + l31 < M;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      f32x4 t = *reinterpret_cast<const f32x4*>(cvec + c0 + 8 * q);
+      f32x4 t = *reinterpret_cast<const f32x4*>(cv + 8 * q);
       if (RESID) t += *reinterpret_cast<const f32x4*>(yrow + 8 * q);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[4 * q + j] = acc[4 * q + j] * WSCALE_INV + t[j];
+      for (int j = 0; j < 4; ++j) v[4 * q + j] = (acc1[4 * q + j] + acc[4 * q + j]) * WSCALE_INV + t[j];
     }
     if (LN) {
       float s = 0.f;
@@ -674,51 +752,85 @@ __global__ __launch_bounds__(512, 2) void gemm_ws256_kernel(const float* A, int 
       m2 += __shfl_xor(m2, 32);
       if (half == 0) *reinterpret_cast<f32x2*>(part + (wave * WS_ROWS + l31) * 2) = f32x2{mw, m2};
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next block's rows (and this wave's older stores) are done ...
-    __syncthreads();                                      // ... for every wave; LayerNorm partials visible; ab is free
-    dma(A, lda, abuf, it + 2);
-    if (LN) {
-      f32x2 pw[8];
+    // Requests of this wave still in flight, oldest first: activation rows of block it + 1 (4), result rows of block it - 1 (4),
+    // residual rows of block it + 1 (4).  Only the first four are needed now: the others stay in flight across the barrier
+    // (vmcnt counts in issue order; raw s_barrier: __syncthreads would drain the counter).
+    if (RESID) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if (KV && kv_kind == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");     // a value block leaves as 8 stores per lane
+    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // block it + 1 has landed for every wave; partials visible
+    dma(A, lda, abuf, it + 2);                            // into the buffer block it was computed from (before the last barrier)
+    if (it + 1 < njobs) kloop(ap0 + ((it + 1) & 1) * WS_ROWS * WS_LD, [&](int s) { epi_slot(s, yrow, live_row); });
+    else {
 #pragma unroll
-      for (int w = 0; w < 8; ++w) pw[w] = *reinterpret_cast<const f32x2*>(part + (w * WS_ROWS + l31) * 2);
-      float mean = 0.f;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) mean += pw[w][0];
-      mean *= (1.f / 8.f);
-      float m2 = 0.f;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) m2 += pw[w][1] + 32.f * (pw[w][0] - mean) * (pw[w][0] - mean);
-      const float var = m2 * (1.f / 256.f);
-      if (wave == 0 && half == 0 && blk * WS_ROWS + l31 < M && !(var <= 3.0e38f)) atomicAdd(nonfinite, 1);
-      const float rstd = 1.0f / sqrtf(var + 1e-5f);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 g4 = *reinterpret_cast<const f32x4*>(cvec + 256 + c0 + 8 * q);
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(cvec + 512 + c0 + 8 * q);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[4 * q + j] = (v[4 * q + j] - mean) * rstd * g4[j] + b4[j];
-      }
+      for (int s = 0; s < 16; ++s) epi_slot(s, yrow, live_row);
     }
+    if (RESID) {                                          // residual rows of block it + 1 (younger: the 4 activation rows just requested, if any)
+      if (it + 2 < njobs) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                         // result rows complete in rb
+    if (KV && kv_kind != 0) {
+      constexpr int KIMG = 2 * NPL * 64 * HD, KPL = 64 * HD;    // image / plane sizes in 16-bit elements
+      const int cbm = blk * WS_ROWS;
+      const KvTile kt_ = kv_tile(kv, __builtin_amdgcn_readfirstlane(cbm), WS_ROWS);
+      if (kv_kind == 1) {
+        // keys: lane -> row tid & 31 and two of the tile's 32 groups of 8 dims (head c >> 2, dim group c & 3); 16 bytes per plane
+        const int r = tid & 31, grow = cbm + r;
+        if (grow < M) {
+          int b, pos, nkt;
+          long tile0;
+          kv_place(kv, kt_, cbm, grow, b, pos, nkt, tile0);
+          const int kt = pos >> 6, key = pos & 63;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int c = (tid >> 5) + 16 * i, hh = c >> 2, dg = c & 3;
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(rb + r * WS_LD + c * 8);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(rb + r * WS_LD + c * 8 + 4);
+            u32x2 pa[NPL], pb[NPL];
+            split_quad(x0, pa);
+            split_quad(x1, pb);
+            op_t* dst = kv.img + (tile0 + ((size_t)b * NHEAD + hh) * nkt + kt) * KIMG + (dg * 64 + key) * 8;
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x4*>(dst + q * KPL) = u32x4{pa[q][0], pa[q][1], pb[q][0], pb[q][1]};
+          }
+        }
+      } else {
+        // values: lane -> column tid & 255 (head col >> 5, dim col & 31) and four of the block's 8 key quads; 8 bytes per plane
+        const int col = tid & 255, hh = col >> 5, d = col & 31;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int lr0 = ((tid >> 8) + 2 * i) * 4, grow0 = cbm + lr0;
+          if (grow0 < M) {                                               // L % 4 == Lreg % 4 == 0: quads never straddle contexts / regions
+            int b, pos, nkt;
+            long tile0;
+            kv_place(kv, kt_, cbm, grow0, b, pos, nkt, tile0);
+            const int kt = pos >> 6, q = (pos & 63) >> 2;
+            const f32x4 x = {rb[(lr0 + 0) * WS_LD + col], rb[(lr0 + 1) * WS_LD + col], rb[(lr0 + 2) * WS_LD + col], rb[(lr0 + 3) * WS_LD + col]};
+            u32x2 pv[NPL];
+            split_quad(x, pv);
+            op_t* dst = kv.img + (tile0 + ((size_t)b * NHEAD + hh) * nkt + kt) * KIMG + NPL * KPL + (q * HD + d) * 4;
+#pragma unroll
+            for (int qq = 0; qq < NPL; ++qq) *reinterpret_cast<u32x2*>(dst + qq * KPL) = pv[qq];
+          }
+        }
+      }
+      continue;
+    }
+    f32x4 yo[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) yo[q] = *reinterpret_cast<const f32x4*>(rb + (4 * wave + q) * WS_LD + lane * 4);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      f32x4 y = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-      if (RELU) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] = fmaxf(y[j], 0.f);
-      }
-      *reinterpret_cast<f32x4*>(yrow + 8 * q) = y;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = 4 * wave + q, grow = blk * WS_ROWS + r;
+      const int grow = blk * WS_ROWS + 4 * wave + q;
 #ifdef WS_ABL_NOST
       if (grow < M && grow == -5)
 #else
       if (grow < M)
 #endif
-        __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(rb + r * WS_LD + lane * 4),
-                                    reinterpret_cast<f32x4*>(C + (size_t)grow * ldc + lane * 4));
+        __builtin_nontemporal_store(yo[q], reinterpret_cast<f32x4*>(C + (size_t)grow * ldc + lane * 4));
     }
     if (RESID) dma(R, ldr, rbuf, it + 2);                 // this wave's four rows of rb: read by its own stores above only
   }
@@ -751,18 +863,32 @@ int launch_gemm_nt_bf16x6_kvc(const float* A, int lda, const void* W3, int n_tot
   if (ln && (N != 256 || (ldc & 3) || (R && (ldr & 3)))) return CTRLSIM_EINVAL;
   if (!ln && R && relu) return CTRLSIM_EINVAL;
 #if CTRLSIM_F16X3
-  // OPT_GEMM_WS: bit 0 = launches of at least two row blocks per CU, bit 1 = the smaller ones
-  if (!kv_img && N == 256 && K == 256 && !(ldc & 3) && (!R || !(ldr & 3)) &&
-      (ctrlsim_option(OPT_GEMM_WS) & (M >= 2 * WS_ROWS * 256 ? 1 : 2))) {
+  // OPT_GEMM_WS: bit 0 = launches of at least two row blocks per CU, bit 1 = the smaller ones, bit 2 = the K / V-image Linears
+  const bool ws_kv = kv_img && K == 256 && !(N & 255) && !(kv_col0 & 255) && !(ldc & 3) && (ctrlsim_option(OPT_GEMM_WS) & 4);
+  if (ws_kv || (!kv_img && N == 256 && K == 256 && !(ldc & 3) && (!R || !(ldr & 3)) &&
+                (ctrlsim_option(OPT_GEMM_WS) & (M >= 2 * WS_ROWS * 256 ? 1 : 2)))) {
     const int nblk = (M + WS_ROWS - 1) / WS_ROWS;
     static const int cus = [] {
       int dev = 0, n = 0;
       return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
     }();
-    dim3 g(nblk < cus ? nblk : cus), b(512);
+    dim3 g(nblk < cus ? nblk : cus, ws_kv ? N / 256 : 1), b(512);
     const op_t* w = static_cast<const op_t*>(W3);
     int* nonfinite = ctrlsim_nonfinite_ptr();
     prof_before(PROF_GEMM, st);
+    if (ws_kv) {
+      static const bool attr_ok =
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ws256_kernel<false, false, false, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES) == hipSuccess;
+      if (!attr_ok) return CTRLSIM_EINVAL;
+      hipLaunchKernelGGL((gemm_ws256_kernel<false, false, false, true>), g, b, WS_LDS_BYTES, st, A, lda, w, bias, nullptr, nullptr,
+                         nullptr, 0, C, ldc, M, n_total, n0, nonfinite, kv);
+      const double MN = (double)M * N, kvN = 2.0 * DM;
+      prof_after(PROF_GEMM, 2.0 * MN * (double)K, st,
+                 4.0 * (double)M * K + 4.0 * (double)M * (N - kvN) + 2.0 * NPL * (double)M * kvN + 2.0 * NPL * (double)N * K,
+                 PKIND_GEMM_QKV_KV);
+      return ctrlsim_launch_status();
+    }
 #define WS_LAUNCH(RELU_, RESID_, LN_)                                                                                  \
   do {                                                                                                                 \
     static const bool attr_ok =                                                                                        \
@@ -770,7 +896,7 @@ int launch_gemm_nt_bf16x6_kvc(const float* A, int lda, const void* W3, int n_tot
                             hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES) == hipSuccess;                   \
     if (!attr_ok) return CTRLSIM_EINVAL;                                                                               \
     hipLaunchKernelGGL((gemm_ws256_kernel<RELU_, RESID_, LN_>), g, b, WS_LDS_BYTES, st, A, lda, w, bias, ln_gamma,     \
-                       ln_beta, R, ldr, C, ldc, M, n_total, n0, nonfinite);                                            \
+                       ln_beta, R, ldr, C, ldc, M, n_total, n0, nonfinite, kv);                                        \
   } while (0)
     if (ln) {
       if (R && relu) WS_LAUNCH(true, true, true);

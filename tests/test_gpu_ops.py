@@ -91,6 +91,69 @@ def test_gemm_bf16x6_fused_layernorm(M, K, relu, resid, ldc):
         assert torch.equal(out[:, 256:], before[:, 256:])     # columns beyond N untouched
 
 
+@pytest.fixture(params=[0, 7], ids=["tiled", "weight-stationary"])
+def ws_option(request):
+    """OPT_GEMM_WS (csrc/common.h): every Linear(256 -> 256 G) family through the tiled kernel, or through the weight-stationary one."""
+    _lib.lib().ctrlsim_set_option(6, request.param)
+    yield request.param
+    _lib.lib().ctrlsim_set_option(6, 7)
+
+
+@pytest.mark.parametrize("M,relu,resid,ln", [(5000, False, False, False), (8191, False, True, False), (4097, True, False, False),
+                                              (31, False, True, True), (32, True, True, True), (33, False, False, True),
+                                              (16385, False, True, True), (20000, True, False, True)])
+def test_linear256_both_kernels(ws_option, M, relu, resid, ln):
+    """Linear(256 -> 256) [+ residual] [+ LayerNorm] [+ ReLU] against float64, for both kernels that serve the shape (row counts
+    around the 32-row block of the weight-stationary kernel and beyond one block per compute unit)."""
+    g = torch.Generator().manual_seed(M)
+    A = (torch.randn(M, 256, generator=g) * torch.exp(0.5 * torch.randn(M, 1, generator=g))).to(DEV)
+    W = torch.randn(512, 256, generator=g) * 0.1
+    b = torch.randn(256, generator=g).to(DEV)
+    gam = torch.randn(256, generator=g).to(DEV); bet = torch.randn(256, generator=g).to(DEV)
+    buf = torch.randn(M, 256, generator=g).to(DEV)
+    before = buf.clone()
+    out = gemm_bf16x6(A, W, b, buf if resid else None, relu, n0=256, n=256, ln=(gam, bet) if ln else None, out=buf)
+    ref = A.double() @ W[256:].to(DEV).double().T + b.double() + (before.double() if resid else 0)
+    if ln:
+        ref = torch.nn.functional.layer_norm(ref, (256,), gam.double(), bet.double(), 1e-5)
+    if relu:
+        ref = ref.clamp_min(0)
+    scale = (A.double().abs() @ W[256:].to(DEV).double().abs().T + 1).max().item() if not ln else 1.0
+    assert (out.double() - ref).abs().max().item() < 2e-5 * max(1.0, scale / 50)
+
+
+@pytest.mark.parametrize("B,L,col0", [(3, 224, 256), (2, 96, 256), (5, 160, 0), (1, 2304, 256)])
+def test_linear_with_kv_image_epilogue(ws_option, B, L, col0):
+    """The in_proj Linear whose key / value columns leave as split K / V tile images (ctrlsim_gemm_nt_kv): the images must drive
+    the attention kernel to the same output as images split from the fp32 result of the plain Linear, and the fp32 (query)
+    columns must match it."""
+    g = torch.Generator().manual_seed(B * L + col0)
+    N, M, nkt = col0 + 512, B * L, (L + 63) // 64
+    A = torch.randn(M, 256, generator=g).to(DEV)
+    W = torch.randn(N, 256, generator=g) * 0.08
+    b = torch.randn(N, generator=g).to(DEV)
+    y = gemm_bf16x6(A, W, b)                                   # fp32 rows [M, N] (tiled kernel: N is not 256)
+    p = _lib.ptr
+    lib, st = _lib.lib(), _lib.stream_ptr()
+    img_ref = _kv_images(y.data_ptr() + 4 * col0, y.data_ptr() + 4 * (col0 + 256), N, L * N, B, L, nkt)
+    from ctrlsim_amd.pack import split3_planes
+    planes = torch.from_numpy(split3_planes(W.numpy()).view(np.int16).copy()).to(DEV)
+    C = torch.full((M, max(col0, 4)), float("nan"), device=DEV)
+    img = torch.zeros_like(img_ref)                            # the caller zeroes the tiles' tails
+    _lib.check(lib.ctrlsim_gemm_nt_kv(p(A), 256, p(planes), N, 0, p(b), p(C), C.stride(0), M, N, 256, p(img), L, nkt, col0, st))
+    if col0:
+        assert (C - y[:, :col0]).abs().max().item() < 1e-5
+    Q = torch.randn(B, L, 256, generator=g).to(DEV)
+    O0 = torch.zeros(B, L, 256, device=DEV); O1 = torch.zeros_like(O0)
+    pad = torch.zeros(B, L, dtype=torch.uint8, device=DEV)
+    for im, O in ((img_ref, O0), (img, O1)):
+        _lib.check(lib.ctrlsim_attention_presplit(0, p(Q), 256, L * 256, p(im), nkt, p(O), 256, L * 256, None, p(pad), B, L, L, 1, st))
+    assert torch.isfinite(O1).all() and (O0 - O1).abs().max().item() < 2e-5
+    used = B * 8 * nkt * (8192 if lib.ctrlsim_split_scheme() == 1 else 12288)
+    same = (img.view(-1)[:used] == img_ref.view(-1)[:used]).float().mean().item()   # the leading planes agree bit for bit almost everywhere
+    assert same > 0.6, same
+
+
 def test_layernorm_and_in_place():
     g = torch.Generator().manual_seed(1)
     X = torch.randn(1003, 256, generator=g).to(DEV) * 3 + 1

@@ -4,6 +4,7 @@ Each kernel is run back to back for `secs` seconds after a warm-up of the same l
 sustains in the rollout (burst timings of a few launches ran 5-15 % fast in round 1 and rewarded the wrong changes).
 Usage: python tools/microbench/sustained.py [B=384] [secs=1.5] [filter]
 Prints one line per kernel: ms per launch, fp32-equivalent TFLOP/s, fraction of the split-operand roof (2500 / NPROD)."""
+import os
 import sys
 import time
 
@@ -19,7 +20,10 @@ DEV = 'cuda:0'
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 384
 SECS = float(sys.argv[2]) if len(sys.argv) > 2 else 1.5
 FILT = sys.argv[3] if len(sys.argv) > 3 else ''
+OPTIONS = [kv.split('=') for kv in filter(None, os.environ.get('CTRLSIM_OPTIONS', '').split(','))]   # '<option>=<value>,...'
 lib = _lib.lib(); p = _lib.ptr; st = _lib.stream_ptr()
+for _k, _v in OPTIONS:
+    lib.ctrlsim_set_option(int(_k), int(_v))
 NPROD = 3 if lib.ctrlsim_split_scheme() == 1 else 6
 ROOF = 2500.0 / NPROD
 
