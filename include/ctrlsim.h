@@ -332,8 +332,12 @@ int ctrlsim_prof_collect_stream(hipStream_t stream, int on_stream, double* ms, i
 int ctrlsim_prof_subclasses(void);
 int ctrlsim_prof_collect_sub(hipStream_t stream, int on_stream, double* ms, int64_t* count, double* flops, double* bytes);
 
-/* Runtime options: key 0 = attention path, key 1 = GEMM path of the forward; value 0 = f32-input MFMA
- * (v_mfma_f32_32x32x2_f32), 1 = split-bf16 "bf16x6" MFMA with fp32-class accuracy (default). */
+/* Runtime options (csrc/common.h: OPT_*).  Keys 0 / 1 = attention / GEMM path of the forward: value 0 = f32-input MFMA
+ * (v_mfma_f32_32x32x2_f32), 1 = split-operand 16-bit MFMA with fp32-class accuracy (default).  Key 2 = tile shape of the tiled
+ * split-operand GEMM (0 auto; tuning).  Key 3 = fused feed-forward block (default 1).  Key 4 = operand split (1 two fp16 planes,
+ * 0 three bf16 planes; per engine through ctrlsim_bind).  Key 5 = map-encoder pooling on the matrix pipe (default 0).
+ * Key 6 = weight-stationary kernel for the Linear(256 -> 256 G) shapes, bit mask: 1 = launches of at least two 32-row blocks per
+ * compute unit, 2 = smaller launches, 4 = the in_proj Linears with K / V-image epilogue (default 7; 0 = tiled kernel everywhere). */
 int ctrlsim_set_option(int key, int value);
 /* Operand split compiled into the library (csrc/split.h): 1 = two fp16 planes / three products (weights pre-scaled by 2^8), 0 = three
  * bf16 planes / six products.  ctrlsim_amd/pack.py packs weight planes and sizes the K/V images accordingly. */
