@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--agents", type=int, default=64)
     ap.add_argument("--polylines", type=int, default=512)
     ap.add_argument("--rollout-steps", type=int, default=90)
-    ap.add_argument("--max-ctx", type=int, default=512, help="model batch (contexts per forward chunk)")
+    ap.add_argument("--max-ctx", type=int, default=1024, help="model batch (contexts per forward chunk; the two lanes' workspaces take 2 x 84 GB of the 288 GB at 1024)")
     ap.add_argument("--lanes", type=int, default=2, help="scenario sets in flight per GPU (engine.py)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--tilt", type=float, nargs=3, default=(0.0, 0.0, 0.0))
@@ -309,8 +309,11 @@ def main():
                 "satellite": {CLASS_KEYS[i]: sat(i) for i in range(2, ncls)},
                 "satellite_note": "HBM-side kernels (SURVEY 8d): algorithmic bytes (DESIGN.md 4) / HIP-event time vs the 8 TB/s HBM "
                                   "peak; sim_step is latency-bound (one workgroup per scenario, alone on its CU) and runs on the lane's "
-                                  "side stream underneath the other lane's grouping / context kernels — a forward pass waits for "
-                                  "every pending simulator step (engine._forward_waits), so it never runs beside matrix kernels",
+                                  "side stream " + ("underneath the other lane's grouping / context kernels — with --sim-guard a forward pass "
+                                                    "waits for every pending simulator step, so it never runs beside matrix kernels"
+                                                    if args.sim_guard else
+                                                    "underneath the other lane's kernels, matrix kernels included (the co-residency hazard that "
+                                                    "forbade this in round 2 is gone from the build: DESIGN.md section 4)"),
                 "kernels": kernel_rows(),
                 "kernels_on_side_streams": kernel_rows(skms, skcnt, skfl, skby),
                 "kernels_note": "main-stream launches run back to back and own the chip: their event intervals are kernel times; the "
