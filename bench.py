@@ -121,8 +121,20 @@ def main():
     if args.tilt_sweep:                                       # the sweep values of config 5
         sweep = np.array([-20.0, -10.0, -5.0, 0.0, 5.0, 10.0, 20.0, 30.0])
         tilt = np.repeat(sweep[np.array(ids) % 8][:, None], 3, axis=1)
-    eng = RolloutEngine(cfg, w, device, max_ctx=args.max_ctx, seed=args.seed, tilt=tilt, lanes=args.lanes,
-                        sizes=tuple(int(x) for x in args.sizes.split(",")) if args.sizes else None)
+    eng = None
+    while eng is None:                                        # the lanes' workspaces are sized for max_ctx plain contexts: if the
+        try:                                                  # device does not have that much free, halve the model batch
+            eng = RolloutEngine(cfg, w, device, max_ctx=args.max_ctx, seed=args.seed, tilt=tilt, lanes=args.lanes,
+                                sizes=tuple(int(x) for x in args.sizes.split(",")) if args.sizes else None)
+        except torch.OutOfMemoryError:
+            if args.max_ctx <= 128:
+                raise
+            args.max_ctx //= 2
+            print(f"[bench] out of device memory: model batch reduced to {args.max_ctx} contexts", file=sys.stderr)
+        if eng is None:                                       # (outside the handler: the traceback no longer pins the half-built engine)
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
     if args.sim_guard:
         eng.forward_waits_for_sim = True
     if args.side is not None:
