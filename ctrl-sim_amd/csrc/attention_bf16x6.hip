@@ -406,14 +406,34 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
         const unsigned vis = vis_all >> (4 * half);
         if (rep_tile) {
           const unsigned bia = bias_all >> (4 * half);
+#ifndef ATT_NO_BFI
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int pos_r = (r & 3) + 8 * (r >> 2);
+            const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)vis, pos_r, 1), mb = (unsigned)__builtin_amdgcn_sbfe((int)bia, pos_r, 1);
+            const float v = s0[r] + __uint_as_float(__float_as_uint(log2m) & mb);
+            sc[r] = __uint_as_float((__float_as_uint(v) & m) | (0xFF800000u & ~m));
+          }
+#else
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const unsigned bit = 1u << ((r & 3) + 8 * (r >> 2));
             sc[r] = (vis & bit) ? s0[r] + ((bia & bit) ? log2m : 0.f) : NEG_INF;
           }
+#endif
         } else {
+#ifndef ATT_NO_BFI
+          // two instructions per score: the key's bit sign-extended to a word mask (v_bfe_i32), then a bit-field insert that keeps the
+          // score where the mask is set and -inf elsewhere (v_bfi_b32) — instead of and / compare / select
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)vis, (r & 3) + 8 * (r >> 2), 1);
+            sc[r] = __uint_as_float((__float_as_uint(s0[r]) & m) | (0xFF800000u & ~m));
+          }
+#else
 #pragma unroll
           for (int r = 0; r < 16; ++r) sc[r] = (vis & (1u << ((r & 3) + 8 * (r >> 2)))) ? s0[r] : NEG_INF;
+#endif
         }
       } else {
 #pragma unroll
