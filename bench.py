@@ -122,6 +122,7 @@ def main():
         sweep = np.array([-20.0, -10.0, -5.0, 0.0, 5.0, 10.0, 20.0, 30.0])
         tilt = np.repeat(sweep[np.array(ids) % 8][:, None], 3, axis=1)
     eng = None
+    max_ctx_asked = args.max_ctx
     while eng is None:                                        # the lanes' workspaces are sized for max_ctx plain contexts: if the
         try:                                                  # device does not have that much free, halve the model batch
             eng = RolloutEngine(cfg, w, device, max_ctx=args.max_ctx, seed=args.seed, tilt=tilt, lanes=args.lanes,
@@ -163,11 +164,14 @@ def main():
         bench_step(i)
     barrier()
     lib.ctrlsim_prof_enable(1)
+    eng.record_phases, eng.phase_events = True, []
     t0 = time.perf_counter()
     for i in range(K):
         bench_step(i)
     barrier()
     elapsed = time.perf_counter() - t0
+    eng.record_phases = False
+    cached_s, sliding_s = eng.phase_times()
     ncls = int(lib.ctrlsim_prof_classes())
     # Launch intervals (HIP events on the launch stream).  The engine runs the big kernels of both lanes back to back on ONE
     # stream (the current one) and, underneath them on the lanes' side streams, the few-row kernels of the second pass, the
@@ -211,6 +215,11 @@ def main():
                 "note": "second engine, one lane, the scenarios alone in their model batches vs the timed two-lane multi-class rollout"}
         del e2, r2
         eng._bind()
+        if not spot["identical"]:
+            # a run-time defence, not a report: a rollout that depends on what shares its model batch / lanes / streams is wrong
+            # (the co-residency hazard of DESIGN.md section 4 showed exactly like this) and must not produce a bench line
+            print(json.dumps({"parity_spot_check": spot}), file=sys.stderr)
+            raise RuntimeError("parity spot check failed: scenarios re-rolled alone differ from the timed rollout")
 
     # ---- metrics: the evaluator's accumulators are built on the device (ctrlsim_metrics_pack: rank-side work independent of S)
     # and combined by ONE all-reduce of that ~10 KB vector — the only collective of the job.  The synthetic
@@ -360,6 +369,10 @@ def main():
                                      f"scenarios, the {K} timed steps cover the {S} scenarios exactly once",
                        "scenarios_per_gpu": S, "scenarios_per_step": sizes, "agents": N, "rollout_steps": R,
                        "polylines": args.polylines, "model_batch_contexts": args.max_ctx, "lanes": args.lanes,
+                       "phases": {"cached_s": cached_s, "sliding_s": sliding_s,
+                                  "note": "main-stream time of the timed rollouts until the last lane of a slice left its K/V-cached steps "
+                                          "(t < 32: few-row kernels only, on the side streams) / after it (full recompute per step)"},
+                       "model_batch_reduced": args.max_ctx != max_ctx_asked, "model_batch_contexts_requested": max_ctx_asked,
                        "contexts_per_rollout_rank0": ctx_per_rollout,
                        "mean_focal_groups_per_scenario_step": ctx_per_rollout / (S * R),
                        "scenario_upload_ms_untimed": upload_ms, "scenario_generation_s_untimed": gen_s,

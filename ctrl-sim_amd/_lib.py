@@ -87,6 +87,9 @@ SIGNATURES = {
     "ctrlsim_dt_forward_pass2_a": (I, [P, I, I, I, I, I, I, C.POINTER(Ctx), P, P, P, P, I, P]),
     "ctrlsim_dt_forward_pass1_cached_a": (I, [P, I, I, I, C.POINTER(Ctx), P, P, P]),
     "ctrlsim_attention_compact": (I, [P, I, L, P, I, P, I, L, P, I, I, I, I, I, I, I, P]),
+    "ctrlsim_attention_mask_table_bytes": (L, [I, I]),
+    "ctrlsim_attention_mask_table": (I, [I, I, I, I, I, I, P, P]),
+    "ctrlsim_attention_tbl": (I, [P, I, L, P, I, P, I, L, I, I, I, I, I, I, P, P]),
     "ctrlsim_sample_rtg_rows": (I, [P, P, I, P, P, P, P, P, P, U64, P, I, P, I, I, I, P]),
     "ctrlsim_sample_action_rows": (I, [P, P, I, P, P, F, D, P, U64, P, I, P, P, I, I, I, I, P]),
     "ctrlsim_dt_forward_pass1": (I, [P, I, I, C.POINTER(Ctx), P, P, P, P]),

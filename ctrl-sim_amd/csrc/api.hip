@@ -16,7 +16,9 @@ int launch_attention(int, const float*, int, long, const float*, const float*, i
 int launch_kv_split(const float*, const float*, int, long, int, int, int, void*, hipStream_t);
 int launch_kv_split_rows(const float*, const float*, int, long, const int*, int, int, int, void*, hipStream_t);
 int launch_attention_bf16x6_pre(int, const float*, int, long, const void*, int, float*, int, long, const int*,
-                                const unsigned char*, int, int, int, int, int, int, int, hipStream_t);
+                                const unsigned char*, int, int, int, int, int, int, int, const void*, hipStream_t);
+int launch_attn_mask_tables(int, const AttnClassHost*, hipStream_t);
+size_t attn_mask_table_bytes(int, int);
 int launch_ffn_fused_bf16x6(const float*, int, const void*, const float*, const void*, const float*, const float*, const float*,
                             float*, int, int, int, hipStream_t);
 int launch_sim_init(int, int, int, const float*, const float*, const float*, const unsigned char*, float*, float*,
@@ -71,7 +73,7 @@ void prof_after(int cls, double flops, hipStream_t st, double bytes, int kind) {
   g_recs.push_back(ProfRec{g_pending[cls], b, cls, flops, bytes, st, 2 * kind + (g_prof_few ? 1 : 0)});
 }
 
-static int g_options[OPT_COUNT] = {1, 1, 0, 1, 1, 0, 7};
+static int g_options[OPT_COUNT] = {1, 1, 0, 1, 1, 0, 7, 1};
 // Guard counter (common.h): the counter the CALLER bound with ctrlsim_bind — an engine's own 4 bytes of device memory — or,
 // for callers that never bind one, a library-owned word allocated on first use on the then-current device.
 static int* g_guard = nullptr;
@@ -205,13 +207,27 @@ int ctrlsim_attention_presplit(int mode, const float* Q, int ldq, int64_t qbs, c
                                int64_t obs, const int* q_pos, const uint8_t* key_pad, int B, int Lq, int Lk, int A,
                                hipStream_t st) {
   return launch_attention_bf16x6_pre(mode, Q, ldq, (long)qbs, img, nkt, O, ldo, (long)obs, q_pos, key_pad, B, Lq, Lk, A, 0, 1, Lk,
-                                     st);
+                                     nullptr, st);
 }
 int ctrlsim_attention_compact(const float* Q, int ldq, int64_t qbs, const void* img, int nkt, float* O, int ldo, int64_t obs,
                               const int* q_pos, int B, int Lq, int Lk, int A, int rep_keys, int rep_mult, int rep_pos0,
                               hipStream_t st) {
   return launch_attention_bf16x6_pre(1, Q, ldq, (long)qbs, img, nkt, O, ldo, (long)obs, q_pos, nullptr, B, Lq, Lk, A, rep_keys,
-                                     rep_mult, rep_pos0, st);
+                                     rep_mult, rep_pos0, nullptr, st);
+}
+int64_t ctrlsim_attention_mask_table_bytes(int Lq, int nkt) {
+  return (Lq > 0 && nkt > 0) ? (int64_t)attn_mask_table_bytes(Lq, nkt) : CTRLSIM_EINVAL;
+}
+int ctrlsim_attention_mask_table(int Lq, int Lk, int A, int rep_keys, int rep_pos0, int nkt, void* tbl, hipStream_t st) {
+  if (!tbl) return CTRLSIM_EINVAL;
+  const AttnClassHost c{1, Lq, Lk, A, rep_keys, 1, rep_pos0, nkt, 0, 0, 0, 0, 0, 0, nullptr, tbl};
+  return launch_attn_mask_tables(1, &c, st);
+}
+int ctrlsim_attention_tbl(const float* Q, int ldq, int64_t qbs, const void* img, int nkt, float* O, int ldo, int64_t obs, int B, int Lq,
+                          int Lk, int A, int rep_keys, int rep_mult, const void* mask_tbl, hipStream_t st) {
+  if (!mask_tbl) return CTRLSIM_EINVAL;
+  return launch_attention_bf16x6_pre(1, Q, ldq, (long)qbs, img, nkt, O, ldo, (long)obs, nullptr, nullptr, B, Lq, Lk, A, rep_keys,
+                                     rep_mult, Lk, mask_tbl, st);
 }
 int ctrlsim_attention(int mode, const float* Q, int ldq, int64_t qbs, const float* K, const float* V, int ldkv, int64_t kbs,
                       float* O, int ldo, int64_t obs, const int* q_pos, const uint8_t* key_pad, int B, int Lq, int Lk, int A,

@@ -60,12 +60,69 @@ struct AttnClass {
   long q_off, o_off, img_off, pad_off;     // class's first Q row / O row / image tile / key_pad byte
   long q_bs, o_bs, kv_bs;                  // batch strides (kv_bs: tiles per (context, head) with images, else fp32 row stride)
   const int* q_pos;
+  const unsigned long long* tbl;           // TBL kernel: the class's visibility-mask table (attn_mask_table_kernel below)
   int Lq, Lk, A, rep_keys, rep_pos0, qblocks, wg0;
   float log2m;
 };
 struct AttnBatch { int n; AttnClass c[MAXC]; };
 
-template <int MODE, bool PRE>
+// ---- visibility-mask tables (round 4) --------------------------------------------------------------------------------------------
+// The structured mask (utils/train_utils.py:81-129, get_causal_mask; compact contexts: the representative's rules in the kernel header
+// below) depends on the CLASS and on (query position, key position) only — not on the context, the head or the layer.  For the
+// launches whose query rows are the token rows themselves (q_pos == nullptr: the first pass over all tokens, > 90 % of the attention
+// time) it is therefore evaluated ONCE per forward pass into a table, in exactly the form the kernel consumes: for query group g
+// (rows 32 g .. 32 g + 31 = one wave) and 32-key sub-tile j (regular sub-tiles in key order, then the representative tiles' ones) sixteen
+// 64-bit LANE masks, one per accumulator register r of the S^T tile: bit (l31 + 32 half) <-> query 32 g + l31 sees key
+// 32 j' + mfma_row(r, half).  The kernel loads an entry with scalar loads (wave-uniform address) and applies it with ONE
+// v_cndmask_b32 per score, the SGPR pair as the lane mask — instead of building the 32-bit visibility word of every query from
+// ~70 vector + 40-100 scalar instructions and applying it with two more per score.  Entry = 32 x u64: vis[16], then nob[16] = the
+// representative's own tokens (multiplicity 1, where every other visible representative key counts m-fold; TBL kernel: the seed of a
+// representative sub-tile always carries log2 m and these bits take it back).
+#define TBL_ENTRY 32      // u64 per (query group, sub-tile)
+#define AS4 __attribute__((address_space(4)))   // constant address space: wave-uniform loads from it are scalar loads
+typedef unsigned long long u64;
+struct TblClass { u64* tbl; int Lq, Lk, A, rep_keys, rep_pos0, nkt, groups, wg0; };
+struct TblBatch { int n; TblClass c[MAXC]; };
+__global__ __launch_bounds__(256) void attn_mask_table_kernel(TblBatch tb) {
+  int ci = 0;
+  while (ci + 1 < tb.n && (int)blockIdx.x >= tb.c[ci + 1].wg0) ++ci;
+  const TblClass& c = tb.c[ci];
+  const int g = (int)blockIdx.x - c.wg0, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+  const int A3 = 3 * c.A, nsub = 2 * c.nkt, nsub_reg = 2 * ((c.rep_pos0 + KT6 - 1) / KT6);
+  // this lane's query (rows past the end repeat the last row: such lanes must not keep a wave on the no-base-yet path)
+  const int pos = min(32 * g + l31, c.Lq - 1);
+  const bool rep_q = c.rep_keys > 0 && pos >= c.rep_pos0;
+  int tq, aq = -1, kq;
+  if (rep_q) { tq = (pos - c.rep_pos0) / 3; kq = (pos - c.rep_pos0) - 3 * tq; }
+  else { tq = pos / A3; const int rem = pos - tq * A3; aq = rem / 3; kq = rem - 3 * aq; }
+  for (int j = wave; j < nsub; j += 4) {
+    u64 mine = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kl = mfma_row(r, half);
+      bool vis = false, nob = false;
+      if (j < nsub_reg) {
+        const int kp = 32 * j + kl;                  // regular key (tk, ak, kk)
+        if (kp < c.Lk) {
+          const int tk = kp / A3, rem = kp - tk * A3, ak = rem / 3, kk = rem - 3 * ak;
+          vis = tk < tq || (tk == tq && (kk == 0 || (ak == aq && kk <= kq)));
+        }
+      } else {
+        const int jk = 32 * (j - nsub_reg) + kl;     // representative key 3 t + k: m-fold up to the state token of the query's step
+        if (jk < c.rep_keys) {
+          vis = jk <= 3 * tq + (rep_q ? kq : 0);
+          nob = vis && jk > 3 * tq;
+        }
+      }
+      const u64 bv = __ballot(vis), bn = __ballot(nob);
+      if (lane == r) mine = bv;
+      if (lane == 16 + r) mine = bn;
+    }
+    if (lane < TBL_ENTRY) c.tbl[((size_t)g * nsub + j) * TBL_ENTRY + lane] = mine;
+  }
+}
+
+template <int MODE, bool PRE, bool TBL = false>
 __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
     const float* __restrict__ Qb_, int ldq, const float* __restrict__ K, const float* __restrict__ V, int ldkv,
     float* __restrict__ Ob_, int ldo, const unsigned char* __restrict__ key_pad_, float scale_log2e, int variant, AttnBatch ab) {
@@ -98,7 +155,7 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
 #else
   constexpr int NBUF = 2;
 #endif
-  __shared__ __attribute__((aligned(16))) op_t arena[NBUF * BUF];
+  constexpr int BUF_ = BUF, NBUF_ = NBUF;
   __shared__ int blk_tmax[4];
   static_assert(2 * BUF * 2 >= 4 * 32 * 33 * 4, "output transpose must fit");
 
@@ -114,6 +171,33 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int A3 = 3 * A;
   const float NEG_INF = -__builtin_inff();
+
+  // ---- tile 0's K/V image pieces are requested before anything else (PRE: every query block needs tile 0; the request needs only
+  // (context, head)): the L2 / HBM latency of the first tile then runs underneath the Q loads and the mask bookkeeping
+  const op_t* img = PRE ? reinterpret_cast<const op_t*>(K) + (cd.img_off + ((size_t)b * NHEAD + h) * (size_t)cd.kv_bs) * KV_IMG : nullptr;
+  __shared__ __attribute__((aligned(16))) op_t arena[NBUF_ * BUF_];
+  auto dma_tile = [&](int tile, int buf) {
+    const op_t* src = img + (size_t)tile * KV_IMG + tid * 8;
+#pragma unroll
+    for (int i = 0; i < KV_PIECES; ++i) {
+      op_t* dst = arena + buf * BUF_ + (wave * 64 + 256 * i) * 8;          // wave-uniform LDS base (+ 16 B per lane)
+#ifdef ATT_DMA_BUILTIN
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 256 * 8 * i),
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+#else
+      // Issued as inline asm on purpose: hipcc answers the builtin with `s_waitcnt vmcnt(0)` in front of the NEXT ds_read
+      // of any LDS address (it cannot tell the two stage buffers apart), i.e. every wave sat out the whole L2 / HBM
+      // latency of the tile it had just requested before touching the tile it already had.  The compiler does not see
+      // this load; the wave waits for its own pieces explicitly right before the end-of-tile barrier (dma_wait).
+      const unsigned lds_addr = (unsigned)(size_t)((__attribute__((address_space(3))) op_t*)dst);
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off ; KV-DMA"
+                   :: "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(src + 256 * 8 * i) : "memory");
+#endif
+    }
+  };
+#ifndef ATT_NO_EARLY_DMA
+  if (PRE) dma_tile(0, 0);
+#endif
 
   // ---- this lane's query: fragment of Q^T (B operand), k-step ks covers d = 16*ks + 8*half .. +7
   const int qi = qb + wave * 32 + l31;
@@ -170,6 +254,10 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
     rep_need = __builtin_amdgcn_readfirstlane(min(rep_keys, (bt + 1) * 3));
   }
 
+  // TBL: this wave's query group in the class's mask table; does the wave hold representative queries (wave-uniform)
+  const int qgrp = __builtin_amdgcn_readfirstlane(qblk * 4 + wave), nsub_tbl = 2 * (int)kv_batch_stride;
+  const bool wave_rep_q = TBL && rep_keys > 0 && __builtin_amdgcn_readfirstlane(qb + wave * 32 + 31) >= rep_pos0;
+
   f32x16 oa;                                       // O^T accumulator
 #pragma unroll
   for (int r = 0; r < 16; ++r) oa[r] = 0.f;
@@ -185,26 +273,9 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
   f32x4 pk[2], pv[2];
   float ppad = 0.f;
   unsigned long long ppad_bal = ~0ull;             // wave 0: which of the staged tile's 64 keys are padded
-  const op_t* img = PRE ? reinterpret_cast<const op_t*>(K) + (cd.img_off + ((size_t)b * NHEAD + h) * (size_t)kv_batch_stride) * KV_IMG : nullptr;
-  auto gload = [&](int k0, int buf) {
+  auto gload = [&](int k0, int buf, bool dma = true) {
     if (PRE) {
-      const op_t* src = img + (size_t)(k0 / KT6) * KV_IMG + tid * 8;
-#pragma unroll
-      for (int i = 0; i < KV_PIECES; ++i) {
-        op_t* dst = arena + buf * BUF + (wave * 64 + 256 * i) * 8;          // wave-uniform LDS base (+ 16 B per lane)
-#ifdef ATT_DMA_BUILTIN
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 256 * 8 * i),
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-#else
-        // Issued as inline asm on purpose: hipcc answers the builtin with `s_waitcnt vmcnt(0)` in front of the NEXT ds_read
-        // of any LDS address (it cannot tell the two stage buffers apart), i.e. every wave sat out the whole L2 / HBM
-        // latency of the tile it had just requested before touching the tile it already had.  The compiler does not see
-        // this load; the wave waits for its own pieces explicitly right before the end-of-tile barrier (dma_wait).
-        const unsigned lds_addr = (unsigned)(size_t)((__attribute__((address_space(3))) op_t*)dst);
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off ; KV-DMA"
-                     :: "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(src + 256 * 8 * i) : "memory");
-#endif
-      }
+      if (dma) dma_tile(k0 / KT6, buf);
     } else {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -270,7 +341,11 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
   const int nkt_reg = (rep_pos0 + KT6 - 1) / KT6;
   auto tile_k0 = [&](int it) { return (it < n_reg ? it : nkt_reg + (it - n_reg)) * KT6; };
   if (n_it > 0) {
+#ifndef ATT_NO_EARLY_DMA
+    gload(tile_k0(0), 0, false);                 // PRE: tile 0 (always a regular tile: k_end >= 1) was requested at the top
+#else
     gload(tile_k0(0), 0);
+#endif
     sstore(0);
   }
   if (NBUF == 3 && n_it > 1) {
@@ -338,7 +413,17 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
       // the accumulator starts at -m_base (the running maximum, 0 before the first visible key): the MFMA chain then
       // delivers S - m directly and the per-element subtraction is needed only in the (rare) sub-tiles that raise the maximum
       const float m_base = (m_run == NEG_INF) ? 0.f : m_run;
-      const float seed = (rep_tile && !need_mask) ? log2m - m_base : -m_base;
+      // TBL: every representative sub-tile is seeded with the multiplicity; the table's `nob` bits take it back where a key counts once
+      const float seed = (rep_tile && (TBL || !need_mask)) ? log2m - m_base : -m_base;
+      // TBL: this sub-tile's lane masks, requested (scalar loads, wave-uniform address) before the score products
+      u64 mk[16];
+      const AS4 u64* tbl_e = nullptr;
+      if (TBL && MODE == MODE6_CAUSAL && need_mask) {
+        const int jsub = (rep_tile ? nkt_reg + (it - n_reg) : it) * 2 + sub;
+        tbl_e = (const AS4 u64*)(cd.tbl) + ((size_t)qgrp * nsub_tbl + jsub) * TBL_ENTRY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mk[r] = tbl_e[r];
+      }
       f32x16 s0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s0[r] = seed;
@@ -368,6 +453,23 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
       if (MODE == MODE6_KEYPAD && padflag[sub]) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = s0[r] + padbias[sub * 32 + mfma_row(r, half)];
+      } else if (TBL && MODE == MODE6_CAUSAL && need_mask) {
+        // one v_cndmask_b32 per score, the table's SGPR pair as the lane mask
+        const float ninf = NEG_INF;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sc[r]) : "v"(ninf), "v"(s0[r]), "s"(mk[r]));
+        if (rep_tile && wave_rep_q) {
+          // the representative's own tokens of its step count once: take the multiplicity back (three query groups per context only)
+          const float lm = log2m, zero = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const u64 nb = tbl_e[16 + r];
+            float dlt;
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(dlt) : "v"(zero), "v"(lm), "s"(nb));
+            sc[r] -= dlt;
+          }
+        }
       } else if (MODE == MODE6_CAUSAL && need_mask) {
         // visibility of the 32 keys of this sub-tile for this lane's query as a bit mask (bit i <-> key ks0 + i):
         //   keys of earlier timesteps: all; of the query's timestep: every state token (offset % 3 == 0) and the query's
@@ -806,7 +908,7 @@ int launch_attention_bf16x6(int mode, const float* Q, int ldq, long q_batch_stri
   mode = mode >= MODE6_CAUSAL ? MODE6_CAUSAL : MODE6_KEYPAD;
   AttnBatch ab;
   ab.n = 1;
-  ab.c[0] = AttnClass{0, 0, 0, 0, q_batch_stride, o_batch_stride, kv_batch_stride, q_pos, Lq, Lk, A, 0, Lk, (Lq + 127) / 128, 0, 0.f};
+  ab.c[0] = AttnClass{0, 0, 0, 0, q_batch_stride, o_batch_stride, kv_batch_stride, q_pos, nullptr, Lq, Lk, A, 0, Lk, (Lq + 127) / 128, 0, 0.f};
   dim3 g(ab.c[0].qblocks * NHEAD * B), blk(256);
   const float scale = 0.17677669529663687f * 1.4426950408889634f;  // log2(e)/sqrt(32)
   prof_before(PROF_ATTN, st);
@@ -838,6 +940,7 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
   ab.n = 0;
   int wg = 0;
   double flops = 0.0, bytes = 0.0;
+  bool use_tbl = mode == MODE6_CAUSAL && variant == 0 && ctrlsim_option(OPT_ATTN_TBL) != 0;
   for (int k = 0; k < n; ++k) {
     AttnClassHost c = cls[k];
     if (c.B <= 0 || c.Lq <= 0) continue;
@@ -848,8 +951,10 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
     if (c.rep_keys > 0 && (mode != MODE6_CAUSAL || variant || c.rep_mult < 1 || c.Lk % (3 * c.A) || c.rep_pos0 % (3 * c.A)))
       return CTRLSIM_EINVAL;
     const int qblocks = (c.Lq + 127) / 128;
+    // mask-table kernel: every class brings its table, the query rows are the token rows, CtRL-Sim mask, keys = the whole row layout
+    use_tbl = use_tbl && c.mask_tbl && !c.q_pos && (c.rep_keys == 0 || c.rep_pos0 == c.Lk);
     ab.c[ab.n++] = AttnClass{c.q_row0 * ldq, c.o_row0 * ldo, c.img_tile0, c.pad_off, c.q_bs, c.o_bs, (long)c.nkt, c.q_pos,
-                             c.Lq, c.Lk, c.A, c.rep_keys, c.rep_pos0, qblocks, wg,
+                             static_cast<const unsigned long long*>(c.mask_tbl), c.Lq, c.Lk, c.A, c.rep_keys, c.rep_pos0, qblocks, wg,
                              c.rep_keys > 0 ? log2f((float)c.rep_mult) : 0.f};
     wg += qblocks * NHEAD * c.B;
     flops += attn_pairs(mode, c.q_pos, c.Lq, c.Lk, c.A, c.rep_keys) * 128.0 * NHEAD * c.B;
@@ -860,7 +965,10 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
   const float scale = 0.17677669529663687f * 1.4426950408889634f;
   const float* imgf = static_cast<const float*>(img);
   prof_before(PROF_ATTN, st);
-  if (mode == MODE6_CAUSAL) {
+  if (mode == MODE6_CAUSAL && use_tbl) {
+    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, true, true>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale,
+                       variant, ab);
+  } else if (mode == MODE6_CAUSAL) {
     hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, true>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale,
                        variant, ab);
   } else {
@@ -871,11 +979,32 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
   return ctrlsim_launch_status();
 }
 
+// Mask tables of n classes (cls[k].mask_tbl: attn_mask_table_bytes(Lq, nkt) bytes each; classes without a table are skipped), one launch
+size_t attn_mask_table_bytes(int Lq, int nkt) { return (size_t)4 * ((Lq + 127) / 128) * 2 * nkt * TBL_ENTRY * sizeof(u64); }
+int launch_attn_mask_tables(int n, const AttnClassHost* cls, hipStream_t st) {
+  if (n < 0 || n > MAXC || !cls) return CTRLSIM_EINVAL;
+  TblBatch tb;
+  tb.n = 0;
+  int wg = 0;
+  for (int k = 0; k < n; ++k) {
+    const AttnClassHost& c = cls[k];
+    if (c.B <= 0 || c.Lq <= 0 || !c.mask_tbl) continue;
+    const int rp0 = c.rep_keys ? c.rep_pos0 : c.Lk;
+    if (c.Lk <= 0 || c.A <= 0 || c.nkt < (rp0 + KT6 - 1) / KT6 + (c.rep_keys + KT6 - 1) / KT6) return CTRLSIM_EINVAL;
+    const int groups = 4 * ((c.Lq + 127) / 128);
+    tb.c[tb.n++] = TblClass{static_cast<u64*>(const_cast<void*>(c.mask_tbl)), c.Lq, c.Lk, c.A, c.rep_keys, rp0, c.nkt, groups, wg};
+    wg += groups;
+  }
+  if (tb.n == 0) return CTRLSIM_OK;
+  hipLaunchKernelGGL(attn_mask_table_kernel, dim3(wg), dim3(256), 0, st, tb);
+  return ctrlsim_launch_status();
+}
+
 int launch_attention_bf16x6_pre(int mode, const float* Q, int ldq, long q_batch_stride, const void* img, int nkt, float* O,
                                 int ldo, long o_batch_stride, const int* q_pos, const unsigned char* key_pad, int B, int Lq,
-                                int Lk, int A, int rep_keys, int rep_mult, int rep_pos0, hipStream_t st) {
+                                int Lk, int A, int rep_keys, int rep_mult, int rep_pos0, const void* mask_tbl, hipStream_t st) {
   if (B <= 0 || Lq <= 0) return CTRLSIM_OK;
-  const AttnClassHost c{B, Lq, Lk, A, rep_keys, rep_mult, rep_pos0, nkt, 0, q_batch_stride, 0, o_batch_stride, 0, 0, q_pos};
+  const AttnClassHost c{B, Lq, Lk, A, rep_keys, rep_mult, rep_pos0, nkt, 0, q_batch_stride, 0, o_batch_stride, 0, 0, q_pos, mask_tbl};
   return launch_attention_classes(mode, Q, ldq, img, O, ldo, key_pad, 1, &c, st);
 }
 

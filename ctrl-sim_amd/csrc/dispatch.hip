@@ -18,7 +18,9 @@
   int launch_attention_bf16x6(int, const float*, int, long, const float*, const float*, int, long, float*, int, long, const int*, \
                               const unsigned char*, int, int, int, int, hipStream_t);                                            \
   int launch_attention_bf16x6_pre(int, const float*, int, long, const void*, int, float*, int, long, const int*,                  \
-                                  const unsigned char*, int, int, int, int, int, int, int, hipStream_t);                         \
+                                  const unsigned char*, int, int, int, int, int, int, int, const void*, hipStream_t);            \
+  int launch_attn_mask_tables(int, const AttnClassHost*, hipStream_t);                                                            \
+  size_t attn_mask_table_bytes(int, int);                                                                                         \
   int launch_attention_classes(int, const float*, int, const void*, float*, int, const unsigned char*, int, const AttnClassHost*, \
                                hipStream_t);                                                                                      \
   int launch_kv_split(const float*, const float*, int, long, int, int, int, void*, hipStream_t);                                  \
@@ -59,10 +61,12 @@ int launch_attention_bf16x6(int mode, const float* Q, int ldq, long qbs, const f
 }
 int launch_attention_bf16x6_pre(int mode, const float* Q, int ldq, long qbs, const void* img, int nkt, float* O, int ldo, long obs,
                                 const int* q_pos, const unsigned char* key_pad, int B, int Lq, int Lk, int A, int rep_keys,
-                                int rep_mult, int rep_pos0, hipStream_t st) {
+                                int rep_mult, int rep_pos0, const void* mask_tbl, hipStream_t st) {
   return PICK(launch_attention_bf16x6_pre(mode, Q, ldq, qbs, img, nkt, O, ldo, obs, q_pos, key_pad, B, Lq, Lk, A, rep_keys, rep_mult,
-                                          rep_pos0, st));
+                                          rep_pos0, mask_tbl, st));
 }
+int launch_attn_mask_tables(int n, const AttnClassHost* cls, hipStream_t st) { return PICK(launch_attn_mask_tables(n, cls, st)); }
+size_t attn_mask_table_bytes(int Lq, int nkt) { return s1::attn_mask_table_bytes(Lq, nkt); }   // the table does not depend on the split
 int launch_attention_classes(int mode, const float* Q, int ldq, const void* img, float* O, int ldo, const unsigned char* key_pad, int n,
                              const AttnClassHost* cls, hipStream_t st) {
   return PICK(launch_attention_classes(mode, Q, ldq, img, O, ldo, key_pad, n, cls, st));

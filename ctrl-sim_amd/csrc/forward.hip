@@ -39,6 +39,8 @@ int launch_ffn_fused_bf16x6(const float*, int, const void*, const float*, const 
                             float*, int, int, int, hipStream_t);
 int launch_kv_split(const float*, const float*, int, long, int, int, int, void*, hipStream_t);
 int launch_kv_split_rows(const float*, const float*, int, long, const int*, int, int, int, void*, hipStream_t);
+int launch_attn_mask_tables(int, const AttnClassHost*, hipStream_t);
+size_t attn_mask_table_bytes(int, int);
 int launch_attention_classes(int, const float*, int, const void*, float*, int, const unsigned char*, int, const AttnClassHost*,
                              hipStream_t);
 int launch_gemm_nt_bf16x6_kvc(const float*, int, const void*, int, int, const float*, const float*, int, float*, int, int, int, int,
@@ -284,6 +286,8 @@ struct Ws {
   // layer, scene encoder (reused by its layers)
   void *img_dec[8], *img_mem[8], *img_enc;
   size_t img_dec_bytes;
+  // visibility-mask tables of the classes (attention_bf16x6.hip), rebuilt by every full forward pass: class k at mask_tbl[k]
+  char* mask_tbl[MAXC];
   size_t bytes;
 };
 
@@ -320,6 +324,7 @@ Ws carve(const ctrlsim_dims& d, const Batch& bt, char* base) {
   for (int i = 0; i < d.ND; ++i) w.img_dec[i] = take(w.img_dec_bytes);
   for (int i = 0; i < d.ND; ++i) w.img_mem[i] = take((size_t)bt.tiles_mem * tile_bytes);
   w.img_enc = take((size_t)bt.tiles_mem * tile_bytes);
+  for (int k = 0; k < MAXC; ++k) w.mask_tbl[k] = k < bt.n ? take(attn_mask_table_bytes(bt.c[k].L, bt.c[k].nkt_dec)) : nullptr;
   w.bytes = off;
   return w;
 }
@@ -385,6 +390,7 @@ struct AttnCall {
   int Tk;                        // causal: window steps whose keys are attended (Lk = Tk * 3 * Areg, rep_keys = 3 * Tk)
   int Tw;                        // window steps of the row layout (rep_pos0 = lreg(Tw))
   int Rn_mul;                    // Q_NEW: rows per context = Rn_mul * A
+  bool tbl = false;              // Q_ALL, causal: the classes' mask tables (Ws::mask_tbl) were built for this pass (build_mask_tables)
 };
 int attention(const ctrlsim_dims& d, const Batch& bt, const Ws& w, const AttnCall& a, hipStream_t st) {
   AttnClassHost h[MAXC];
@@ -410,6 +416,7 @@ int attention(const ctrlsim_dims& d, const Batch& bt, const Ws& w, const AttnCal
     } else {
       x.Lk = a.Tk * 3 * sh.Areg; x.rep_keys = sh.rep * 3 * a.Tk; x.rep_mult = sh.mult; x.rep_pos0 = sh.lreg(a.Tw);
       x.nkt = c.nkt_dec; x.img_tile0 = c.tile_dec; x.pad_off = 0;
+      if (a.tbl && a.q == Q_ALL) x.mask_tbl = w.mask_tbl[k];
     }
   }
   if (presplit()) return launch_attention_classes(a.mode, a.Q, a.ldq, a.img, a.O, DM, w.src_pad, bt.n, h, st);
@@ -424,6 +431,18 @@ int attention(const ctrlsim_dims& d, const Batch& bt, const Ws& w, const AttnCal
                          st));
   }
   return 0;
+}
+
+// The classes' visibility-mask tables for the causal launches over all token rows of a full pass over Tq window steps (one small launch)
+int build_mask_tables(const Batch& bt, const Ws& w, int Tq, hipStream_t st) {
+  AttnClassHost h[MAXC];
+  for (int k = 0; k < bt.n; ++k) {
+    const Cls& c = bt.c[k];
+    h[k] = AttnClassHost{};
+    h[k].B = c.B; h[k].Lq = c.L; h[k].Lk = Tq * 3 * c.sh.Areg; h[k].A = c.sh.Areg; h[k].rep_keys = c.sh.rep * 3 * Tq;
+    h[k].rep_mult = c.sh.mult; h[k].rep_pos0 = c.sh.lreg(Tq); h[k].nkt = c.nkt_dec; h[k].mask_tbl = w.mask_tbl[k];
+  }
+  return launch_attn_mask_tables(bt.n, h, st);
 }
 
 // Linear whose last 512 output columns are attention keys / values: y[:, :kcol0] as fp32 rows, K / V as split images straight from
@@ -683,13 +702,15 @@ int forward_full(const ctrlsim_model* m, int n, const int* Bk, const int* Ak, co
     }
   }
   CHK(scene_side(m, bt, w, dbg_seg_emb, st));
+  const bool use_tbl = variant == 0 && presplit() && ctrlsim_option(OPT_ATTN_TBL) != 0;
+  if (use_tbl) CHK(build_mask_tables(bt, w, Tq, st));
   // ---- decoder (decoder.py:52): layers 0..ND-2 on all tokens
   for (int i = 0; i < d.ND; ++i) {
     const DecLayer& Ld = m->dec[i];
     CHK(gemm_kv(d, bt, w, Ld.qkv, w.X, w.qkv[i], 3 * DM, 3 * DM, DM, w.img_dec[i], false, st));
     if (i < d.ND - 1 || all) {
       CHK(attention(d, bt, w, AttnCall{amode, Q_ALL, w.qkv[i], 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, w.img_dec[i], false,
-                                       w.att, Tq, Tq, 0}, st));
+                                       w.att, Tq, Tq, 0, use_tbl}, st));
       CHK(gemm_ln(Ld.out, Ld.n1, w.att, DM, w.X, DM, w.X, DM, w.tmp, rL, DM, 0, st));
       CHK(cross_and_ffn(m, bt, Ld, i, w, w.X, w.tmp, w.att, w.qc, w.ffn, bt.rL, Q_ALL, 0, st));
     } else {

@@ -206,6 +206,8 @@ class RolloutEngine:
         # tests/test_gpu_hazard.py).  forward_waits_for_sim is the round-2 stream guard (a forward pass waits for every pending
         # simulator step): not needed any more, and it serialises exactly the overlap the switches create; kept as an A/B switch.
         self.forward_waits_for_sim = False
+        self.record_phases = False              # bench.py: main-stream events at the end of every lane's K/V-cached phase
+        self.phase_events = []
         self.pass2_on_side = True
         self.tail_on_side = True
         self.cached_on_side = True
@@ -668,6 +670,12 @@ class RolloutEngine:
                     if t + 1 < nT:
                         self._enqueue_groups(L, t + 1, s0, s1, compare=True)
             t0 = nT
+        if self.record_phases:                       # end of the lane's K/V-cached phase on its streams (bench.py: config.phases)
+            for stream in (self._main, L.side):      # the cached steps' kernels run on the lane's side stream (cached_on_side) or on main
+                if stream is not None:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record(stream)
+                    self.phase_events[-1][1].append(ev)
         for t in range(t0, steps):
             self._enqueue_groups(L, t, lo, hi)
             yield
@@ -695,6 +703,10 @@ class RolloutEngine:
                 self.step(t, nr, na)
             return self
         main = self._main = torch.cuda.current_stream(self.device)
+        if self.record_phases:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record(main)
+            self.phase_events.append([ev0, [], None])
         n = min(self.n_lanes, max(1, s1 - s0))
         cuts = [s0 + (s1 - s0) * i // n for i in range(n + 1)]
         gens = []
@@ -711,7 +723,24 @@ class RolloutEngine:
         for L in self.lanes[:n]:
             if L.side is not None:
                 main.wait_stream(L.side)
+        if self.record_phases:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record(main)
+            self.phase_events[-1][2] = ev1
         return self
+
+    def phase_times(self):
+        """(seconds until the LAST lane left its K/V-cached phase, seconds after that) summed over the recorded runs, in main-stream
+        time (call after a synchronise; record_phases must have been set before the runs)."""
+        cached = sliding = 0.0
+        for ev0, mids, ev1 in self.phase_events:
+            if ev1 is None:
+                continue
+            mid = max((ev0.elapsed_time(m) for m in mids), default=0.0)
+            tot = ev0.elapsed_time(ev1)
+            cached += mid * 1e-3
+            sliding += (tot - mid) * 1e-3
+        return cached, sliding
 
     # ------------------------------------------------------------------ synchronous single-stream steps (plugin surface)
     def step(self, t, noise_rtg=None, noise_act=None):

@@ -312,6 +312,18 @@ int ctrlsim_attention_compact(const float* Q, int ldq, int64_t q_batch_stride, c
                               int64_t o_batch_stride, const int* q_pos, int B, int Lq, int Lk, int A, int rep_keys, int rep_mult,
                               int rep_pos0, hipStream_t stream);
 
+/* Visibility-mask table of one class of causal launches over the TOKEN ROWS (query row i = position i; round 4).  The structured mask of
+ * utils/train_utils.py:81-129 (get_causal_mask) — and the representative's rules above — depends on (query position, key position) of the
+ * class only, so the forward evaluates it once per pass instead of per (context, head, layer, query).  Layout (csrc/attention_bf16x6.hip):
+ * per query group of 32 rows and per 32-key sub-tile (2 * nkt of them: the regular tiles, then the representative's) 32 x uint64 — sixteen
+ * lane masks of the visible (query, key) pairs in the kernel's accumulator order, then sixteen of the representative's count-once keys.
+ * ctrlsim_attention_tbl = ctrlsim_attention_compact with q_pos == NULL and rep_pos0 == Lk, masks taken from the table (same results). */
+int64_t ctrlsim_attention_mask_table_bytes(int Lq, int nkt);
+int ctrlsim_attention_mask_table(int Lq, int Lk, int A, int rep_keys, int rep_pos0, int nkt, void* tbl, hipStream_t stream);
+int ctrlsim_attention_tbl(const float* Q, int ldq, int64_t q_batch_stride, const void* img, int nkt, float* O, int ldo,
+                          int64_t o_batch_stride, int B, int Lq, int Lk, int A, int rep_keys, int rep_mult, const void* mask_tbl,
+                          hipStream_t stream);
+
 /* ---- measurement hooks (bench.py): HIP-event timing of every launch of ctrlsim_prof_classes() kernel classes on its own
  * launch stream — 0 GEMM (all Linear layers incl. the fused feed-forward block), 1 attention, 2 build_context, 3 assemble_tokens,
  * 4 sim_step, 5 map_pool.  enable(1) clears and starts recording; after the caller synchronised, collect() returns per class
@@ -337,7 +349,8 @@ int ctrlsim_prof_collect_sub(hipStream_t stream, int on_stream, double* ms, int6
  * split-operand GEMM (0 auto; tuning).  Key 3 = fused feed-forward block (default 1).  Key 4 = operand split (1 two fp16 planes,
  * 0 three bf16 planes; per engine through ctrlsim_bind).  Key 5 = map-encoder pooling on the matrix pipe (default 0).
  * Key 6 = weight-stationary kernel for the Linear(256 -> 256 G) shapes, bit mask: 1 = launches of at least two 32-row blocks per
- * compute unit, 2 = smaller launches, 4 = the in_proj Linears with K / V-image epilogue (default 7; 0 = tiled kernel everywhere). */
+ * compute unit, 2 = smaller launches, 4 = the in_proj Linears with K / V-image epilogue (default 7; 0 = tiled kernel everywhere).
+ * Key 7 = causal self-attention over the token rows takes its visibility masks from the per-class table (default 1; 0 = built per query). */
 int ctrlsim_set_option(int key, int value);
 /* Operand split compiled into the library (csrc/split.h): 1 = two fp16 planes / three products (weights pre-scaled by 2^8), 0 = three
  * bf16 planes / six products.  ctrlsim_amd/pack.py packs weight planes and sizes the K/V images accordingly. */

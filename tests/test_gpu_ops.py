@@ -321,6 +321,72 @@ def _kv_images(K_ptr, V_ptr, ldkv, kbs, B, rows, nkt, pos=None, img=None):
     return img
 
 
+def _compact_masks(Areg, T, rep):
+    """(visible, m-fold) boolean matrices [L, L] of a compact context's row order — regular rows (t, a < Areg, k) at (t Areg + a) 3 + k,
+    then, with rep, the representative's rows (t, k) at Lreg + 3 t + k — written from the rules, not from the kernel: a query of step
+    tq sees every key of an earlier step, of its own step the state tokens (k = 0) and its own slot's tokens up to itself
+    (utils/train_utils.py:81-129); the representative stands for `mult` equal padded slots, so its keys count mult-fold, except that its
+    own later tokens of the step are seen by itself only once (csrc/attention_bf16x6.hip, kernel header)."""
+    rows = [(t, a, k) for t in range(T) for a in range(Areg) for k in range(3)]
+    if rep:
+        rows += [(t, -1, k) for t in range(T) for k in range(3)]
+    n = len(rows)
+    vis = torch.zeros(n, n, dtype=torch.bool); mul = torch.zeros(n, n, dtype=torch.bool)
+    for i, (tq, aq, kq) in enumerate(rows):
+        for j, (tk, ak, kk) in enumerate(rows):
+            if tk < tq or (tk == tq and kk == 0):
+                vis[i, j] = True; mul[i, j] = ak < 0
+            elif tk == tq and ak == aq and kk <= kq:
+                vis[i, j] = True                                  # own tokens of the step (the representative's: once)
+    return vis, mul
+
+
+@pytest.mark.parametrize("Actx,T", [(24, 32), (8, 32), (12, 32), (5, 7), (4, 32), (16, 9), (20, 3), (7, 1)])
+def test_attention_with_mask_tables_equals_in_kernel_masks_and_float64(Actx, T):
+    """Round 4: the causal launches over the token rows take their visibility masks from a per-class table (ctrlsim_attention_mask_table,
+    one v_cndmask per score) instead of building them per query.  Plain (24-slot) and compact classes, full and short windows (key ranges
+    that end inside a sub-tile, query groups that straddle the regular / representative boundary): against float64 with the mask written
+    from the rules, and against the in-kernel-mask kernel (bit-identical for plain contexts: same arithmetic, same order)."""
+    lib, st, p = _lib.lib(), _lib.stream_ptr(), _lib.ptr
+    B, H = 2, 8
+    rep = 1 if Actx < 24 else 0
+    Areg = Actx - rep
+    mult = 24 - Areg
+    Lreg = T * 3 * Areg
+    L = Lreg + rep * 3 * T
+    rep_k0 = (Lreg + 63) // 64 * 64
+    nkt = (Lreg + 63) // 64 + rep * ((3 * T + 63) // 64)
+    g = torch.Generator().manual_seed(Actx * 100 + T)
+    qkv = torch.randn(B, L, 768, generator=g).to(DEV)
+    Kp, Vp = qkv.data_ptr() + 1024, qkv.data_ptr() + 2048
+    key_pos = torch.tensor([i if i < Lreg else rep_k0 + (i - Lreg) for i in range(L)], dtype=torch.int32, device=DEV)
+    nel = 8192 if lib.ctrlsim_split_scheme() == 1 else 12288
+    img = torch.zeros(B * 8 * nkt * nel, dtype=torch.int16, device=DEV)
+    _kv_images(Kp, Vp, 768, L * 768, B, L, nkt, pos=key_pos, img=img)
+    O_old = torch.zeros(B, L, 256, device=DEV); O_new = torch.full_like(O_old, float("nan"))
+    _lib.check(lib.ctrlsim_attention_compact(p(qkv), 768, L * 768, p(img), nkt, p(O_old), 256, L * 256, None, B, L, Lreg, Areg,
+                                             rep * 3 * T, mult, Lreg, st))
+    nbytes = lib.ctrlsim_attention_mask_table_bytes(L, nkt)
+    assert nbytes > 0
+    tbl = torch.full((nbytes // 8,), -1, dtype=torch.int64, device=DEV)          # all-ones: an unwritten entry would show
+    _lib.check(lib.ctrlsim_attention_mask_table(L, Lreg, Areg, rep * 3 * T, Lreg, nkt, p(tbl), st))
+    _lib.check(lib.ctrlsim_attention_tbl(p(qkv), 768, L * 768, p(img), nkt, p(O_new), 256, L * 256, B, L, Lreg, Areg, rep * 3 * T, mult,
+                                         p(tbl), st))
+    vis, mul = _compact_masks(Areg, T, rep)
+    q, k, v = [qkv[..., i * 256:(i + 1) * 256].view(B, L, H, 32).transpose(1, 2) for i in range(3)]
+    sc = (q.double() @ k.double().transpose(-1, -2)) / math.sqrt(32)
+    sc = sc + math.log(mult) * mul.to(DEV)[None, None].double() if rep else sc
+    sc = sc.masked_fill(~vis.to(DEV)[None, None], float("-inf"))
+    ref = (torch.softmax(sc, -1) @ v.double()).transpose(1, 2).reshape(B, L, 256)
+    assert torch.isfinite(O_new).all()
+    assert (O_old.double() - ref).abs().max().item() < 2e-5
+    assert (O_new.double() - ref).abs().max().item() < 2e-5
+    if rep == 0:
+        assert torch.equal(O_old, O_new)
+    else:
+        assert (O_old - O_new).abs().max().item() < 5e-6
+
+
 @pytest.mark.parametrize("A,T", [(24, 32), (6, 8), (24, 7)])
 def test_attention_presplit_images_match_in_kernel_split(A, T):
     """K/V split once into bf16 images + DMA staging must give bit-identical output to the in-kernel split, for the

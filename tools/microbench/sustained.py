@@ -62,6 +62,10 @@ if 'attn' in FILT or not FILT:
     lib.ctrlsim_kv_split(qkv.data_ptr() + 1024, qkv.data_ptr() + 2048, 768, L * 768, None, B, L, nkt, p(img), st)
     f = lambda: lib.ctrlsim_attention_presplit(1, p(qkv), 768, L * 768, p(img), nkt, p(O), 256, L * 256, None, None, B, L, L, 24, st)
     report(f'attn causal presplit L={L}', sustained(f), pairs * 128 * 8 * B)
+    tbl = torch.zeros(lib.ctrlsim_attention_mask_table_bytes(L, nkt) // 8, dtype=torch.int64, device=DEV)
+    lib.ctrlsim_attention_mask_table(L, L, 24, 0, L, nkt, p(tbl), st)
+    f = lambda: lib.ctrlsim_attention_tbl(p(qkv), 768, L * 768, p(img), nkt, p(O), 256, L * 256, B, L, L, 24, 0, 1, p(tbl), st)
+    report(f'attn causal mask-table L={L}', sustained(f), pairs * 128 * 8 * B)
     Q = torch.randn(B, L, 256, device=DEV); KV = torch.randn(B, 224, 512, device=DEV)
     pad = torch.zeros(B, 224, dtype=torch.uint8, device=DEV)
     img2 = torch.zeros(B * 8 * 4 * 4096 * (2 if NPROD == 3 else 3), dtype=torch.int16, device=DEV)
@@ -83,7 +87,7 @@ if 'few' in FILT:
 if 'compact' in FILT:
     # compact contexts (representative slot): Actx slots -> Areg = Actx - 1 regular + 1 representative of multiplicity 25 - Actx
     T = 32
-    for Actx in (4, 8, 12, 16, 20):
+    for Actx in (int(a) for a in os.environ.get('SUSTAINED_CLASSES', '4,8,12,16,20').split(',')):
         Ar = Actx - 1
         Lreg = T * 3 * Ar; Lq = Lreg + 3 * T
         nkt = (Lreg + 63) // 64 + 2
@@ -96,6 +100,11 @@ if 'compact' in FILT:
         f = lambda: lib.ctrlsim_attention_compact(p(qkv), 768, Lq * 768, p(img), nkt, p(O), 256, Lq * 256, None, Bc, Lq, Lreg, Ar,
                                                   3 * T, 25 - Actx, Lreg, st)
         report(f'attn compact Actx={Actx} L={Lq} B={Bc}', sustained(f), pairs * 128 * 8 * Bc)
+        tbl = torch.zeros(lib.ctrlsim_attention_mask_table_bytes(Lq, nkt) // 8, dtype=torch.int64, device=DEV)
+        lib.ctrlsim_attention_mask_table(Lq, Lreg, Ar, 3 * T, Lreg, nkt, p(tbl), st)
+        f = lambda: lib.ctrlsim_attention_tbl(p(qkv), 768, Lq * 768, p(img), nkt, p(O), 256, Lq * 256, Bc, Lq, Lreg, Ar, 3 * T, 25 - Actx,
+                                              p(tbl), st)
+        report(f'attn mask-table Actx={Actx} L={Lq} B={Bc}', sustained(f), pairs * 128 * 8 * Bc)
         del qkv, O, img
 if 'gemm' in FILT or not FILT:
     for (N, K, relu, res, ln, name) in [(768, 256, 0, 0, 0, 'qkv (fp32 out)'), (256, 256, 0, 0, 0, 'cross-q'), (256, 256, 0, 1, 1, 'out+res+LN')]:

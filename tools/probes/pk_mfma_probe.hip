@@ -43,6 +43,50 @@ __global__ __launch_bounds__(256) void victim(unsigned iters, unsigned long long
   if (nbad) atomicAdd(bad, nbad);
 }
 
+// Round 4: the same for v_pk_mov_b32 — the one packed instruction -fno-slp-vectorize removes ENTIRELY from the library (the packed
+// arithmetic stays, in plain and in swizzled forms).  Three forms as clang emits them in sim_step: the in-place swap of a register pair
+// (dst = src0 = src1, op_sel:[1,0]), a gather from two pairs with op_sel:[1,0], and one with op_sel:[0,1]; each against v_mov_b32 / v_swap_b32.
+__global__ __launch_bounds__(256) void victim_mov(unsigned iters, unsigned long long* bad, unsigned long long* hist) {
+  __shared__ float pad[13 * 1024];
+  const unsigned tid = threadIdx.x, lane = tid & 63;
+  pad[tid] = (float)tid;
+  __syncthreads();
+  f32x2 p = {1.0f + 0.001f * tid, 0.5f - 0.002f * tid}, q = p;
+  const f32x2 a = {1.0000001f, 0.9999999f}, b = {1e-3f * pad[tid & 255], -2e-3f};
+  unsigned long long nbad = 0;
+  for (unsigned it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      // packed-move path (the arithmetic itself is scalar in both paths)
+      float t0, t1;
+      asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t0) : "v"(p[0]), "v"(a[0]));
+      asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t1) : "v"(p[1]), "v"(a[1]));
+      f32x2 t = {t0, t1}, g, h;
+      asm volatile("v_pk_mov_b32 %0, %0, %0 op_sel:[1,0]" : "+v"(t));                           // swap in place
+      asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(g) : "v"(t), "v"(b));          // g = {t.hi, b.lo}
+      asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]" : "=v"(h) : "v"(t), "v"(b));          // h = {t.lo, b.hi}
+      asm volatile("v_add_f32 %0, %1, %2" : "=v"(p[0]) : "v"(g[0]), "v"(h[1]));                 // t0 + b.hi   (t swapped: t.hi = t0)
+      asm volatile("v_add_f32 %0, %1, %2" : "=v"(p[1]) : "v"(h[0]), "v"(g[1]));                 // t1 + b.lo
+      // scalar path
+      float s0, s1, u0, u1, w0, w1;
+      asm volatile("v_mul_f32 %0, %1, %2" : "=v"(s0) : "v"(q[0]), "v"(a[0]));
+      asm volatile("v_mul_f32 %0, %1, %2" : "=v"(s1) : "v"(q[1]), "v"(a[1]));
+      asm volatile("v_swap_b32 %0, %1" : "+v"(s0), "+v"(s1));
+      asm volatile("v_mov_b32 %0, %1" : "=v"(u0) : "v"(s1));
+      asm volatile("v_mov_b32 %0, %1" : "=v"(u1) : "v"(b[0]));
+      asm volatile("v_mov_b32 %0, %1" : "=v"(w0) : "v"(s0));
+      asm volatile("v_mov_b32 %0, %1" : "=v"(w1) : "v"(b[1]));
+      asm volatile("v_add_f32 %0, %1, %2" : "=v"(q[0]) : "v"(u0), "v"(w1));
+      asm volatile("v_add_f32 %0, %1, %2" : "=v"(q[1]) : "v"(w0), "v"(u1));
+    }
+    const bool m = __builtin_bit_cast(unsigned, p[0]) != __builtin_bit_cast(unsigned, q[0]) ||
+                   __builtin_bit_cast(unsigned, p[1]) != __builtin_bit_cast(unsigned, q[1]);
+    if (m) { ++nbad; atomicAdd(&hist[lane >> 4], 1ull); p = q; }
+    if ((it & 1023u) == 0) { p[0] = q[0] = 1.0f + 0.001f * tid; p[1] = q[1] = 0.5f - 0.002f * tid; }
+  }
+  if (nbad) atomicAdd(bad, nbad);
+}
+
 __global__ __launch_bounds__(256, 3) void aggressor(const float* __restrict__ src, size_t n_floats, unsigned iters, float* sink) {
   extern __shared__ __attribute__((aligned(16))) float lds[];       // 40 KB
   const unsigned tid = threadIdx.x, wave = tid >> 6;
@@ -90,16 +134,18 @@ int main(int argc, char** argv) {
   int cus = 256;
   hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
   hipFuncSetAttribute(reinterpret_cast<const void*>(&aggressor), hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024);
-  for (int with_aggr = 0; with_aggr < 2; ++with_aggr) {
+  for (int arm = 0; arm < 4; ++arm) {
+    const int with_aggr = arm & 1, mov = arm >> 1;
     hipMemset(bad, 0, 8); hipMemset(hist, 0, 32);
     hipDeviceSynchronize();
     const unsigned iters = 400000u * (unsigned)ms / 400u;
-    if (with_aggr) hipLaunchKernelGGL(aggressor, dim3(cus * 3), dim3(256), 40 * 1024, s2, src, n, iters / 24, sink);
-    hipLaunchKernelGGL(victim, dim3(cus), dim3(256), 0, s1, iters, bad, hist);
+    if (with_aggr) hipLaunchKernelGGL(aggressor, dim3(cus * 3), dim3(256), 40 * 1024, s2, src, n, iters / (mov ? 16 : 24), sink);
+    if (mov) hipLaunchKernelGGL(victim_mov, dim3(cus), dim3(256), 0, s1, iters, bad, hist);
+    else hipLaunchKernelGGL(victim, dim3(cus), dim3(256), 0, s1, iters, bad, hist);
     hipDeviceSynchronize();
     unsigned long long hb = 0, hh[4] = {0, 0, 0, 0};
     hipMemcpy(&hb, bad, 8, hipMemcpyDeviceToHost); hipMemcpy(hh, hist, 32, hipMemcpyDeviceToHost);
-    printf("packed vs scalar fp32, aggressor %d: %llu mismatching iterations of %u x %d threads (by 16-lane group: %llu %llu %llu %llu)\n", with_aggr, hb, iters,
+    printf("%s, aggressor %d: %llu mismatching iterations of %u x %d threads (by 16-lane group: %llu %llu %llu %llu)\n", mov ? "v_pk_mov_b32 vs v_mov / v_swap" : "packed vs scalar fp32", with_aggr, hb, iters,
            cus * 256, hh[0], hh[1], hh[2], hh[3]);
     fflush(stdout);
   }
