@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--side", type=str, default=None,
                     help="few-row kernels on the lanes' side streams: comma list of p2, tail, cached ('' = none; default: the engine's)")
     ap.add_argument("--sim-guard", action="store_true", help="A/B: the round-2 stream guard (a forward pass waits for pending simulator steps)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="A/B: one run() per slice, both lanes starting at t = 0 together (rounds 1-3) instead of the pipelined lanes (engine.run_jobs)")
+    ap.add_argument("--no-class-profile", action="store_true", help="skip the untimed extra slice with per-class attention cycle accounting")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spot-check", type=int, default=4, help="scenarios re-rolled alone after the timed region (bit-identity check; 0 = off)")
     ap.add_argument("--cpu-sample-scenarios", type=int, default=4)
@@ -160,14 +163,27 @@ def main():
         eng.reset(a, b)
         eng.run(R, s0=a, s1=b)                                # (finite-logit guard: after the timed region, below)
 
-    for i in range(args.warmup):
-        bench_step(i)
+    def bench_steps(first, n):
+        """Bench steps first .. first + n - 1.  Pipelined (default): the lanes take half-slices as they come free and stay about half a
+        rollout apart (engine.run_jobs), so the steps overlap in time; every slice is still reset and rolled exactly once."""
+        if args.no_pipeline:
+            for i in range(first, first + n):
+                bench_step(i)
+            return
+        jobs = []
+        for i in range(first, first + n):
+            a, b = cuts[i % K], cuts[i % K + 1]
+            m = max(1, min(args.lanes, b - a))
+            jobs += [(a + (b - a) * j // m, a + (b - a) * (j + 1) // m) for j in range(m)]
+        eng.run_jobs(jobs, R)
+
+    bench_steps(0, args.warmup)
     barrier()
     lib.ctrlsim_prof_enable(1)
-    eng.record_phases, eng.phase_events = True, []
+    eng.record_phases, eng.phase_events = args.no_pipeline, []
+    eng.full_pass_contexts = np.zeros(len(eng.sizes), np.int64)
     t0 = time.perf_counter()
-    for i in range(K):
-        bench_step(i)
+    bench_steps(0, K)
     barrier()
     elapsed = time.perf_counter() - t0
     eng.record_phases = False
@@ -220,6 +236,38 @@ def main():
             # (the co-residency hazard of DESIGN.md section 4 showed exactly like this) and must not produce a bench line
             print(json.dumps({"parity_spot_check": spot}), file=sys.stderr)
             raise RuntimeError("parity spot check failed: scenarios re-rolled alone differ from the timed rollout")
+
+    # ---- causal self-attention by context size class (untimed): the first slice is rolled once more with the kernel's per-class cycle
+    # accounting on (one atomic per workgroup: not inside the timed region) — where the largest single kernel spends its time
+    attn_by_class = None
+    full_ctx = np.asarray(eng.full_pass_contexts, np.int64).copy()
+    if rank == 0 and not args.no_class_profile:
+        a, b = cuts[0], cuts[1]
+        _lib.check(lib.ctrlsim_attn_class_prof(1, None), "attn_class_prof")
+        eng.reset(a, b)
+        eng.run(R, s0=a, s1=b)
+        torch.cuda.synchronize()
+        buf = (C.c_uint64 * 64)()
+        _lib.check(lib.ctrlsim_attn_class_prof(0, buf), "attn_class_prof")
+        eng._unchecked = eng._unchecked[:-1]                          # (the extra roll is not part of what check_finite may repeat)
+        tot = float(sum(buf[2 * s] for s in range(32))) or 1.0
+        T_ = d.T
+        attn_by_class = []
+        for k, A_ in enumerate(eng.sizes):
+            cyc, wgs = int(buf[2 * A_]), int(buf[2 * A_ + 1])
+            if wgs == 0:
+                continue
+            rep = 1 if A_ < d.A else 0
+            Ar = A_ - rep
+            A3 = 3.0 * Ar
+            pairs = A3 * A3 * T_ * (T_ - 1) / 2.0 + T_ * Ar * (3.0 * Ar + 3.0)
+            if rep:
+                pairs += A3 * (3.0 * T_ * (T_ - 1) / 2.0 + T_) + 3.0 * A3 * T_ * (T_ - 1) / 2.0 + 3.0 * Ar * T_ + 9.0 * T_ * (T_ - 1) / 2.0 + 6.0 * T_
+            attn_by_class.append({"context_slots": int(A_), "rows_per_context": int(3 * T_ * A_), "workgroups": wgs,
+                                  "share_of_workgroup_cycles": cyc / tot, "visible_pairs_per_context_and_head": pairs,
+                                  "contexts_in_timed_full_passes": int(full_ctx[k]),
+                                  "cycles_per_1e6_visible_pairs": cyc / max(wgs / ((3 * T_ * A_ + 127) // 128), 1) / pairs * 1e6})
+        eng._bind()
 
     # ---- metrics: the evaluator's accumulators are built on the device (ctrlsim_metrics_pack: rank-side work independent of S)
     # and combined by ONE all-reduce of that ~10 KB vector — the only collective of the job.  The synthetic
@@ -336,6 +384,11 @@ def main():
                                                     "underneath the other lane's kernels, matrix kernels included (the co-residency hazard that "
                                                     "forbade this in round 2 is gone from the build: DESIGN.md section 4)"),
                 "kernels": kernel_rows(),
+                "causal_attention_by_size_class": attn_by_class,
+                "causal_attention_by_size_class_note": "untimed extra roll of the first slice with ctrlsim_attn_class_prof: share of the causal "
+                                                        "kernel's workgroup cycles (full-row launches) per context size class; cycles per 1e6 visible "
+                                                        "(query, key) pairs and head = the per-class efficiency (lower is better; the plain 24-slot "
+                                                        "class is the reference)",
                 "kernels_on_side_streams": kernel_rows(skms, skcnt, skfl, skby),
                 "kernels_note": "main-stream launches run back to back and own the chip: their event intervals are kernel times; the "
                                 "few-row launches on the lanes' side streams run UNDERNEATH them (their intervals overlap those and "
@@ -369,7 +422,8 @@ def main():
                                      f"scenarios, the {K} timed steps cover the {S} scenarios exactly once",
                        "scenarios_per_gpu": S, "scenarios_per_step": sizes, "agents": N, "rollout_steps": R,
                        "polylines": args.polylines, "model_batch_contexts": args.max_ctx, "lanes": args.lanes,
-                       "phases": {"cached_s": cached_s, "sliding_s": sliding_s,
+                       "lanes_pipelined": not args.no_pipeline,
+                       "phases": None if not args.no_pipeline else {"cached_s": cached_s, "sliding_s": sliding_s,
                                   "note": "main-stream time of the timed rollouts until the last lane of a slice left its K/V-cached steps "
                                           "(t < 32: few-row kernels only, on the side streams) / after it (full recompute per step)"},
                        "model_batch_reduced": args.max_ctx != max_ctx_asked, "model_batch_contexts_requested": max_ctx_asked,

@@ -87,6 +87,7 @@ SIGNATURES = {
     "ctrlsim_dt_forward_pass2_a": (I, [P, I, I, I, I, I, I, C.POINTER(Ctx), P, P, P, P, I, P]),
     "ctrlsim_dt_forward_pass1_cached_a": (I, [P, I, I, I, C.POINTER(Ctx), P, P, P]),
     "ctrlsim_attention_compact": (I, [P, I, L, P, I, P, I, L, P, I, I, I, I, I, I, I, P]),
+    "ctrlsim_attn_class_prof": (I, [I, P]),
     "ctrlsim_attention_mask_table_bytes": (L, [I, I]),
     "ctrlsim_attention_mask_table": (I, [I, I, I, I, I, I, P, P]),
     "ctrlsim_attention_tbl": (I, [P, I, L, P, I, P, I, L, I, I, I, I, I, I, P, P]),

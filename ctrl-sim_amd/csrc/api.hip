@@ -94,6 +94,22 @@ static int nonfinite_count(int reset) {
   if (reset && n && hipMemset(p, 0, sizeof(int)) != hipSuccess) return CTRLSIM_ELAUNCH;
   return n;
 }
+// Per-class cycle accounting of the causal self-attention launches over the token rows (profiling runs: bench.py's untimed extra slice).
+// 32 slot counts x {workgroup cycles, workgroups}; library-owned device words like the guard counter, allocated on first enable.
+static unsigned long long* g_cprof = nullptr;
+static bool g_cprof_on = false;
+unsigned long long* ctrlsim_attn_cprof_ptr() { return g_cprof_on ? g_cprof : nullptr; }
+extern "C" int ctrlsim_attn_class_prof(int enable, unsigned long long* host_out) {
+  if (enable) {
+    if (!g_cprof && hipMalloc(reinterpret_cast<void**>(&g_cprof), 64 * sizeof(unsigned long long)) != hipSuccess) { g_cprof = nullptr; return CTRLSIM_ELAUNCH; }
+    if (hipMemset(g_cprof, 0, 64 * sizeof(unsigned long long)) != hipSuccess) return CTRLSIM_ELAUNCH;
+    g_cprof_on = true;
+    return CTRLSIM_OK;
+  }
+  g_cprof_on = false;
+  if (host_out && g_cprof && hipMemcpy(host_out, g_cprof, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return CTRLSIM_ELAUNCH;
+  return CTRLSIM_OK;
+}
 extern "C" int ctrlsim_split_scheme() { return g_options[OPT_SPLIT] ? 1 : 0; }
 extern "C" int ctrlsim_nonfinite_count(int reset) { return nonfinite_count(reset); }
 int ctrlsim_option(int key) { return (key >= 0 && key < OPT_COUNT) ? g_options[key] : 0; }

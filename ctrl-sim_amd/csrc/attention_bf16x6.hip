@@ -64,7 +64,9 @@ struct AttnClass {
   int Lq, Lk, A, rep_keys, rep_pos0, qblocks, wg0;
   float log2m;
 };
-struct AttnBatch { int n; AttnClass c[MAXC]; };
+// cprof (profiling runs only, else null): per slot count A two 64-bit words — shader cycles spent by the workgroups of the class (start of
+// the kernel to the end of the last store, summed over workgroups) and the workgroup count (ctrlsim_attn_class_prof, bench.py)
+struct AttnBatch { int n; unsigned long long* cprof; AttnClass c[MAXC]; };
 
 // ---- visibility-mask tables (round 4) --------------------------------------------------------------------------------------------
 // The structured mask (utils/train_utils.py:81-129, get_causal_mask; compact contexts: the representative's rules in the kernel header
@@ -126,6 +128,7 @@ template <int MODE, bool PRE, bool TBL = false>
 __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
     const float* __restrict__ Qb_, int ldq, const float* __restrict__ K, const float* __restrict__ V, int ldkv,
     float* __restrict__ Ob_, int ldo, const unsigned char* __restrict__ key_pad_, float scale_log2e, int variant, AttnBatch ab) {
+  const unsigned long long t_start = ab.cprof ? __builtin_amdgcn_s_memtime() : 0ull;
   int ci = 0;
   while (ci + 1 < ab.n && (int)blockIdx.x >= ab.c[ci + 1].wg0) ++ci;
   const AttnClass& cd = ab.c[ci];
@@ -258,6 +261,9 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
   const int qgrp = __builtin_amdgcn_readfirstlane(qblk * 4 + wave), nsub_tbl = 2 * (int)kv_batch_stride;
   const bool wave_rep_q = TBL && rep_keys > 0 && __builtin_amdgcn_readfirstlane(qb + wave * 32 + 31) >= rep_pos0;
 
+#ifdef ATT_TBL_DEBUG
+  float dbg_bad = 0.f, dbg_first = -1.f;
+#endif
   f32x16 oa;                                       // O^T accumulator
 #pragma unroll
   for (int r = 0; r < 16; ++r) oa[r] = 0.f;
@@ -454,21 +460,33 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = s0[r] + padbias[sub * 32 + mfma_row(r, half)];
       } else if (TBL && MODE == MODE6_CAUSAL && need_mask) {
-        // one v_cndmask_b32 per score, the table's SGPR pair as the lane mask
-        const float ninf = NEG_INF;
+        // one v_cndmask_b32 per score, the table's SGPR pair as the lane mask.  (Through the inverse-ballot builtin, NOT inline asm: a
+        // hand-written VALU instruction that reads the accumulator of the MFMA just issued gets no wait states from hipcc's hazard
+        // recognizer and reads the registers before the matrix pipe has written them — the first version of this path did.)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sc[r]) : "v"(ninf), "v"(s0[r]), "s"(mk[r]));
-        if (rep_tile && wave_rep_q) {
-          // the representative's own tokens of its step count once: take the multiplicity back (three query groups per context only)
-          const float lm = log2m, zero = 0.f;
+        for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_inverse_ballot_w64(mk[r]) ? s0[r] : NEG_INF;
+#ifdef ATT_TBL_DEBUG   // scratch builds: compare the table's bits with the in-kernel mask words (regular tiles), per lane
+        if (!rep_tile) {
+          auto ones = [](int n) -> unsigned { return n >= 32 ? 0xFFFFFFFFu : (n <= 0 ? 0u : ((1u << n) - 1u)); };
+          const int same0 = tq * A3 - ks0;
+          const unsigned before = ones(same0);
+          const unsigned same = ones(min(same0 + A3, Lk - ks0)) & ~before;
+          int off3 = (ks_t0 - ks0) % 3;
+          off3 = off3 < 0 ? off3 + 3 : off3;
+          const unsigned every3 = (unsigned)(0x249249249249ull << off3);
+          const unsigned own = rep_q ? 0u : (ones(pos - ks0 + 1) & ~ones(pos - kq - ks0));
+          const unsigned vis = (before | ((every3 | own) & same)) >> (4 * half);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const u64 nb = tbl_e[16 + r];
-            float dlt;
-            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(dlt) : "v"(zero), "v"(lm), "s"(nb));
-            sc[r] -= dlt;
+            const bool want = (vis >> ((r & 3) + 8 * (r >> 2))) & 1u, got = (mk[r] >> lane) & 1ull;
+            if (want != got) { dbg_bad += 1.f; if (dbg_first < 0.f) dbg_first = (float)(it * 2 + sub); }
           }
+        }
+#endif
+        if (rep_tile && wave_rep_q) {
+          // the representative's own tokens of its step count once: take the multiplicity back (three query groups per context only)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc[r] -= __builtin_amdgcn_inverse_ballot_w64(tbl_e[16 + r]) ? log2m : 0.f;
         }
       } else if (MODE == MODE6_CAUSAL && need_mask) {
         // visibility of the 32 keys of this sub-tile for this lane's query as a bit mask (bit i <-> key ks0 + i):
@@ -659,6 +677,9 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
     l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
   }
+#ifdef ATT_TBL_DEBUG
+  if (TBL) { oa[0] = dbg_bad; oa[1] = dbg_first; oa[2] = (float)qgrp; oa[3] = (float)nsub_tbl; l_run = 1.f; }
+#endif
   const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
   float* ot = reinterpret_cast<float*>(arena) + wave * (32 * 33);
 #pragma unroll
@@ -669,6 +690,14 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
     const int q = i * 2 + half;
     const int gq = qb + wave * 32 + q;
     if (gq < Lq) O[(size_t)b * o_batch_stride + (size_t)gq * ldo + h * HD + l31] = ot[q * 33 + l31];
+  }
+  if (ab.cprof) {
+    __syncthreads();
+    if (tid == 0) {
+      const int slot = 2 * min(A + (rep_keys > 0 ? 1 : 0), 31);        // context slots A' (compact classes: regular + representative)
+      atomicAdd(ab.cprof + slot, __builtin_amdgcn_s_memtime() - t_start);
+      atomicAdd(ab.cprof + slot + 1, 1ull);
+    }
   }
 }
 
@@ -908,6 +937,7 @@ int launch_attention_bf16x6(int mode, const float* Q, int ldq, long q_batch_stri
   mode = mode >= MODE6_CAUSAL ? MODE6_CAUSAL : MODE6_KEYPAD;
   AttnBatch ab;
   ab.n = 1;
+  ab.cprof = nullptr;
   ab.c[0] = AttnClass{0, 0, 0, 0, q_batch_stride, o_batch_stride, kv_batch_stride, q_pos, nullptr, Lq, Lk, A, 0, Lk, (Lq + 127) / 128, 0, 0.f};
   dim3 g(ab.c[0].qblocks * NHEAD * B), blk(256);
   const float scale = 0.17677669529663687f * 1.4426950408889634f;  // log2(e)/sqrt(32)
@@ -938,6 +968,7 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
   mode = mode >= MODE6_CAUSAL ? MODE6_CAUSAL : MODE6_KEYPAD;
   AttnBatch ab;
   ab.n = 0;
+  ab.cprof = (mode == MODE6_CAUSAL && cls[0].q_pos == nullptr) ? ctrlsim_attn_cprof_ptr() : nullptr;   // the launches over the token rows
   int wg = 0;
   double flops = 0.0, bytes = 0.0;
   bool use_tbl = mode == MODE6_CAUSAL && variant == 0 && ctrlsim_option(OPT_ATTN_TBL) != 0;

@@ -67,6 +67,7 @@ __device__ __host__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 // rows whose variance is not finite.  The second matters: ReLU (v_max_f32) maps NaN to 0, so a row that overflowed the fp16
 // range of the two-plane operand split (csrc/split.h) would otherwise come out of the MLP heads as finite, wrong logits.
 int* ctrlsim_nonfinite_ptr();
+unsigned long long* ctrlsim_attn_cprof_ptr();     // per-class cycle counters of the causal attention launches (api.hip), null unless enabled
 __device__ __forceinline__ void count_nonfinite_row(float var, int lane, int* __restrict__ counter) {
   if (lane == 0 && !(var <= 3.0e38f)) atomicAdd(counter, 1);
 }

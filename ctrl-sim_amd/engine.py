@@ -206,6 +206,8 @@ class RolloutEngine:
         # tests/test_gpu_hazard.py).  forward_waits_for_sim is the round-2 stream guard (a forward pass waits for every pending
         # simulator step): not needed any more, and it serialises exactly the overlap the switches create; kept as an A/B switch.
         self.forward_waits_for_sim = False
+        self._max_sliding, self._sliding, self._holds_slot = 0, 0, []
+        self.full_pass_contexts = 0             # np.int64 [classes] once the first full pass ran
         self.record_phases = False              # bench.py: main-stream events at the end of every lane's K/V-cached phase
         self.phase_events = []
         self.pass2_on_side = True
@@ -609,6 +611,7 @@ class RolloutEngine:
                 self._main.wait_event(L.ev_p2)               # the previous batch's second pass still reads the lane's buffers
             first = False
             plan, n, Bs, As, cs = self._class_plan(L, counts, Tq, Tq)
+            self.full_pass_contexts += np.asarray(counts, np.int64)      # contexts per size class of the full-recompute passes (bench.py)
             self._ctx_index(L, s0, s1, st)
             self._build_contexts(L, plan, t, Tq, 0, st)
             self._forward_waits(self._main)
@@ -636,7 +639,7 @@ class RolloutEngine:
                 L.ev_p2.record(L.side)
 
     # ------------------------------------------------------------------ a lane's rollout as a generator
-    def _lane_gen(self, L, lo, hi, steps):
+    def _lane_gen(self, L, lo, hi, steps, lane_idx=None):
         """Closed-loop rollout of scenarios [lo, hi) on lane L.  Yields wherever the host needs the lane's group counts
         back: the scheduler (run) then queues another lane's step before this one blocks on its read-back."""
         T = self.dims.T
@@ -656,6 +659,8 @@ class RolloutEngine:
                 if nT > 1:
                     self._snapshot_groups(L, s0, s1)
                 for t in range(nT):
+                    if lane_idx is not None:
+                        self._lane_t[lane_idx] = t
                     if t > 0:
                         yield
                         h, changed = self._await_groups(L)
@@ -670,6 +675,13 @@ class RolloutEngine:
                     if t + 1 < nT:
                         self._enqueue_groups(L, t + 1, s0, s1, compare=True)
             t0 = nT
+        if lane_idx is not None and self._max_sliding:
+            # pipelined jobs (run_jobs): at most _max_sliding lanes run full-recompute steps at a time — a lane that has finished its cached
+            # steps early (they run underneath the others' full-row kernels) parks here until a slot comes free
+            while self._sliding >= self._max_sliding:
+                yield
+            self._sliding += 1
+            self._holds_slot[lane_idx] = True
         if self.record_phases:                       # end of the lane's K/V-cached phase on its streams (bench.py: config.phases)
             for stream in (self._main, L.side):      # the cached steps' kernels run on the lane's side stream (cached_on_side) or on main
                 if stream is not None:
@@ -677,6 +689,8 @@ class RolloutEngine:
                     ev.record(stream)
                     self.phase_events[-1][1].append(ev)
         for t in range(t0, steps):
+            if lane_idx is not None:
+                self._lane_t[lane_idx] = t
             self._enqueue_groups(L, t, lo, hi)
             yield
             hist, _ = self._await_groups(L)
@@ -727,6 +741,66 @@ class RolloutEngine:
             ev1 = torch.cuda.Event(enable_timing=True)
             ev1.record(main)
             self.phase_events[-1][2] = ev1
+        return self
+
+    def run_jobs(self, jobs, steps=None, stagger=True, max_sliding=None):
+        """Pipelined rollouts (round 4): every job (s0, s1) — a scenario range — is reset and rolled `steps` steps by ONE lane, and the
+        lanes take jobs from the list as they come free.  With `stagger`, lane i > 0 starts its first job only when lane 0 has left the
+        K/V-cached steps of ITS first job (t = T): from then on the lanes stay about half a rollout apart, so that one lane's cached
+        phase — strings of few-row kernels on its side stream that leave most of the chip idle — always runs underneath another lane's
+        full-recompute steps instead of beside the other lane's cached phase (run() starts every lane at t = 0 together:
+        policies/autoregressive_policy.py:55-70 is the window rule that creates the two phases).  Scenario results do not depend on
+        which lane rolls them or on what runs beside them (tests/test_gpu_sim_ctx.py)."""
+        steps = self.steps if steps is None else steps
+        jobs = [(int(a), int(b)) for a, b in jobs if b > a]
+        self._bind()
+        self._fresh = None
+        main = self._main = torch.cuda.current_stream(self.device)
+        for a, b in jobs:
+            self._unchecked.append((steps, a, b))
+        if len(self._unchecked) > 4096:
+            self._unchecked = [None]
+        lanes = self.lanes[:max(1, min(self.n_lanes, len(jobs)))]
+        todo = list(reversed(jobs))
+        self._lane_t = [0] * len(self.lanes)
+        nT = min(self.dims.T, steps) if self.use_cache else 0
+        done0 = [False]
+        # max_sliding (default: 2 when there are more lanes than that): the EXTRA lanes run the cached steps of the next jobs ahead of time
+        self._max_sliding = int(max_sliding) if max_sliding else (2 if len(lanes) > 2 else 0)
+        self._sliding, self._holds_slot = 0, [False] * len(self.lanes)
+        if self._max_sliding:
+            stagger = False                                  # the slots stagger the lanes by themselves
+
+        def lane_loop(L, idx):
+            if L.side is not None:
+                L.side.wait_stream(main)
+            if stagger and idx > 0:
+                while not done0[0] and self._lane_t[0] < nT:      # lane 0 still inside the cached steps of its first job
+                    yield
+            while todo:
+                lo, hi = todo.pop()
+                with torch.cuda.stream(self._side(L)):             # the job's reset in the lane's own stream order
+                    self.reset(lo, hi)
+                self._fresh = None
+                self._lane_t[idx] = 0
+                yield from self._lane_gen(L, lo, hi, steps, idx)
+                if self._holds_slot[idx]:
+                    self._holds_slot[idx] = False
+                    self._sliding -= 1
+            if idx == 0:
+                done0[0] = True
+
+        gens = [lane_loop(L, i) for i, L in enumerate(lanes)]
+        while gens:
+            for g in list(gens):
+                try:
+                    next(g)
+                except StopIteration:
+                    gens.remove(g)
+        for L in lanes:
+            if L.side is not None:
+                main.wait_stream(L.side)
+        self._max_sliding = 0
         return self
 
     def phase_times(self):

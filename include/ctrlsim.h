@@ -344,6 +344,11 @@ int ctrlsim_prof_collect_stream(hipStream_t stream, int on_stream, double* ms, i
 int ctrlsim_prof_subclasses(void);
 int ctrlsim_prof_collect_sub(hipStream_t stream, int on_stream, double* ms, int64_t* count, double* flops, double* bytes);
 
+/* Per-size-class accounting of the causal self-attention launches over the token rows (profiling runs only: one atomic per workgroup).
+ * enable != 0: clear and start; enable == 0: stop and (host_out != NULL, 64 x uint64, synchronises) copy out — host_out[2 s] = shader
+ * cycles of the workgroups of the classes with s context slots (kernel entry to last store, summed), host_out[2 s + 1] = workgroups. */
+int ctrlsim_attn_class_prof(int enable, unsigned long long* host_out);
+
 /* Runtime options (csrc/common.h: OPT_*).  Keys 0 / 1 = attention / GEMM path of the forward: value 0 = f32-input MFMA
  * (v_mfma_f32_32x32x2_f32), 1 = split-operand 16-bit MFMA with fp32-class accuracy (default).  Key 2 = tile shape of the tiled
  * split-operand GEMM (0 auto; tuning).  Key 3 = fused feed-forward block (default 1).  Key 4 = operand split (1 two fp16 planes,

@@ -902,6 +902,34 @@ def test_two_lanes_with_more_scenarios_than_cus_match_single_stream():
         assert np.array_equal(r0[k], r1[k]), k
 
 
+@pytest.mark.parametrize("stagger,lanes", [(True, 2), (False, 2), (False, 3)])
+def test_pipelined_jobs_equal_one_run_per_range(stagger, lanes):
+    """Round 4 (engine.run_jobs): scenario ranges are reset and rolled by whichever lane comes free, the lanes about half a rollout apart
+    (one lane's K/V-cached steps underneath the other's full-recompute steps) — the bench's default schedule.  A scenario's tokens, RTG
+    bins, collision flags and trajectories must be bit-identical to the single-lane, one-range-at-a-time rollout; ragged job sizes, more
+    jobs than lanes, a job of one scenario, the window sliding (steps > T of the small model)."""
+    cfg = cfg_of("loop")
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    S, steps = 23, d.T + 7
+    scns = [scenarios.make_scenario(57, i, n_agents=9, n_polylines=14, n_points=d.NP, extent=22.0) for i in range(S)]
+    ref = RolloutEngine(cfg, w, DEV, max_ctx=64, seed=5, lanes=1)
+    ref.load_scenarios(scns, steps=steps)
+    r0 = ref.rollout(steps).results()
+    # (three lanes: two run full-recompute steps at a time, the third rolls the cached steps of the next job ahead and parks)
+    eng = RolloutEngine(cfg, w, DEV, max_ctx=64, seed=5, lanes=lanes, model=ref.model)
+    eng.load_scenarios(scns, steps=steps)
+    jobs = [(0, 5), (5, 6), (6, 14), (14, 14), (14, 19), (19, 23)]
+    eng.run_jobs(jobs, steps, stagger=stagger)
+    r1 = eng.results()
+    for k in ("tokens", "rtg_bins", "coll", "states", "n_groups"):
+        assert np.array_equal(r0[k], r1[k]), k
+    eng.run_jobs([(3, 9), (0, 3)], steps, stagger=stagger)          # again, other cuts: ranges are reset by the job itself
+    r2 = eng.results()
+    for k in ("tokens", "rtg_bins", "coll", "states"):
+        assert np.array_equal(r0[k], r2[k]), k
+
+
 def test_contact_table_overflow_is_counted_not_silent():
     """More touching pairs in one island than the island solver's table holds (40 boxes stacked on one spot: 780 contacts against
     MAX_ISLAND_CONTACTS = 192 — not a traffic scene; disjoint boxes are bounded by planarity): the dropped contacts are counted

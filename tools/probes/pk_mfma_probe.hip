@@ -87,6 +87,37 @@ __global__ __launch_bounds__(256) void victim_mov(unsigned iters, unsigned long 
   if (nbad) atomicAdd(bad, nbad);
 }
 
+// Round 4, after the assembly bisect named the form (profiles/r04_hazard.md): packed arithmetic whose LOW lane reads the HIGH half of a source
+// pair — the op_sel forms clang's SLP vectoriser emits in sim_step (op_sel:[1,0]; op_sel:[0,1] op_sel_hi:[1,0] with neg modifiers).
+__global__ __launch_bounds__(256) void victim_cross(unsigned iters, unsigned long long* bad, unsigned long long* hist) {
+  __shared__ float pad[13 * 1024];
+  const unsigned tid = threadIdx.x, lane = tid & 63;
+  pad[tid] = (float)tid;
+  __syncthreads();
+  f32x2 p = {1.0f + 0.001f * tid, 0.5f - 0.002f * tid}, q = p;
+  const f32x2 a = {1.0000001f, 0.9999999f}, b = {1e-3f * pad[tid & 255], -2e-3f};
+  unsigned long long nbad = 0;
+  for (unsigned it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      f32x2 t;
+      asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(t) : "v"(p), "v"(a));                                       // t = {p.hi a.lo, p.hi a.hi}
+      asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(p) : "v"(t), "v"(b));  // p = {t.lo - b.hi, t.hi - b.lo}
+      float s0, s1, u0, u1;
+      asm volatile("v_mul_f32 %0, %1, %2" : "=v"(s0) : "v"(q[1]), "v"(a[0]));
+      asm volatile("v_mul_f32 %0, %1, %2" : "=v"(s1) : "v"(q[1]), "v"(a[1]));
+      asm volatile("v_sub_f32 %0, %1, %2" : "=v"(u0) : "v"(s0), "v"(b[1]));
+      asm volatile("v_sub_f32 %0, %1, %2" : "=v"(u1) : "v"(s1), "v"(b[0]));
+      q[0] = u0; q[1] = u1;
+    }
+    const bool m = __builtin_bit_cast(unsigned, p[0]) != __builtin_bit_cast(unsigned, q[0]) ||
+                   __builtin_bit_cast(unsigned, p[1]) != __builtin_bit_cast(unsigned, q[1]);
+    if (m) { ++nbad; atomicAdd(&hist[lane >> 4], 1ull); p = q; }
+    if ((it & 1023u) == 0) { p[0] = q[0] = 1.0f + 0.001f * tid; p[1] = q[1] = 0.5f - 0.002f * tid; }
+  }
+  if (nbad) atomicAdd(bad, nbad);
+}
+
 __global__ __launch_bounds__(256, 3) void aggressor(const float* __restrict__ src, size_t n_floats, unsigned iters, float* sink) {
   extern __shared__ __attribute__((aligned(16))) float lds[];       // 40 KB
   const unsigned tid = threadIdx.x, wave = tid >> 6;
@@ -134,18 +165,19 @@ int main(int argc, char** argv) {
   int cus = 256;
   hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
   hipFuncSetAttribute(reinterpret_cast<const void*>(&aggressor), hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024);
-  for (int arm = 0; arm < 4; ++arm) {
+  for (int arm = 0; arm < 6; ++arm) {
     const int with_aggr = arm & 1, mov = arm >> 1;
     hipMemset(bad, 0, 8); hipMemset(hist, 0, 32);
     hipDeviceSynchronize();
     const unsigned iters = 400000u * (unsigned)ms / 400u;
     if (with_aggr) hipLaunchKernelGGL(aggressor, dim3(cus * 3), dim3(256), 40 * 1024, s2, src, n, iters / (mov ? 16 : 24), sink);
-    if (mov) hipLaunchKernelGGL(victim_mov, dim3(cus), dim3(256), 0, s1, iters, bad, hist);
+    if (mov == 2) hipLaunchKernelGGL(victim_cross, dim3(cus), dim3(256), 0, s1, iters, bad, hist);
+    else if (mov) hipLaunchKernelGGL(victim_mov, dim3(cus), dim3(256), 0, s1, iters, bad, hist);
     else hipLaunchKernelGGL(victim, dim3(cus), dim3(256), 0, s1, iters, bad, hist);
     hipDeviceSynchronize();
     unsigned long long hb = 0, hh[4] = {0, 0, 0, 0};
     hipMemcpy(&hb, bad, 8, hipMemcpyDeviceToHost); hipMemcpy(hh, hist, 32, hipMemcpyDeviceToHost);
-    printf("%s, aggressor %d: %llu mismatching iterations of %u x %d threads (by 16-lane group: %llu %llu %llu %llu)\n", mov ? "v_pk_mov_b32 vs v_mov / v_swap" : "packed vs scalar fp32", with_aggr, hb, iters,
+    printf("%s, aggressor %d: %llu mismatching iterations of %u x %d threads (by 16-lane group: %llu %llu %llu %llu)\n", mov == 2 ? "op_sel packed fp32 vs scalar" : mov ? "v_pk_mov_b32 vs v_mov / v_swap" : "packed vs scalar fp32", with_aggr, hb, iters,
            cus * 256, hh[0], hh[1], hh[2], hh[3]);
     fflush(stdout);
   }
