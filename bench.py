@@ -62,8 +62,10 @@ def main():
     ap.add_argument("--side", type=str, default=None,
                     help="few-row kernels on the lanes' side streams: comma list of p2, tail, cached ('' = none; default: the engine's)")
     ap.add_argument("--sim-guard", action="store_true", help="A/B: the round-2 stream guard (a forward pass waits for pending simulator steps)")
-    ap.add_argument("--no-pipeline", action="store_true",
-                    help="A/B: one run() per slice, both lanes starting at t = 0 together (rounds 1-3) instead of the pipelined lanes (engine.run_jobs)")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="A/B: pipelined lanes (engine.run_jobs: a lane's K/V-cached steps underneath the other lanes' full-recompute steps; with "
+                         "--lanes 3 the third lane rolls the next job's cached steps ahead) instead of one run() per slice with both lanes "
+                         "starting at t = 0 together.  Measured in round 4: no gain (profiles/README.md) — the default stays one run() per slice")
     ap.add_argument("--no-class-profile", action="store_true", help="skip the untimed extra slice with per-class attention cycle accounting")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spot-check", type=int, default=4, help="scenarios re-rolled alone after the timed region (bit-identity check; 0 = off)")
@@ -166,7 +168,7 @@ def main():
     def bench_steps(first, n):
         """Bench steps first .. first + n - 1.  Pipelined (default): the lanes take half-slices as they come free and stay about half a
         rollout apart (engine.run_jobs), so the steps overlap in time; every slice is still reset and rolled exactly once."""
-        if args.no_pipeline:
+        if not args.pipeline:
             for i in range(first, first + n):
                 bench_step(i)
             return
@@ -180,7 +182,7 @@ def main():
     bench_steps(0, args.warmup)
     barrier()
     lib.ctrlsim_prof_enable(1)
-    eng.record_phases, eng.phase_events = args.no_pipeline, []
+    eng.record_phases, eng.phase_events = not args.pipeline, []
     eng.full_pass_contexts = np.zeros(len(eng.sizes), np.int64)
     t0 = time.perf_counter()
     bench_steps(0, K)
@@ -422,8 +424,8 @@ def main():
                                      f"scenarios, the {K} timed steps cover the {S} scenarios exactly once",
                        "scenarios_per_gpu": S, "scenarios_per_step": sizes, "agents": N, "rollout_steps": R,
                        "polylines": args.polylines, "model_batch_contexts": args.max_ctx, "lanes": args.lanes,
-                       "lanes_pipelined": not args.no_pipeline,
-                       "phases": None if not args.no_pipeline else {"cached_s": cached_s, "sliding_s": sliding_s,
+                       "lanes_pipelined": bool(args.pipeline),
+                       "phases": None if args.pipeline else {"cached_s": cached_s, "sliding_s": sliding_s,
                                   "note": "main-stream time of the timed rollouts until the last lane of a slice left its K/V-cached steps "
                                           "(t < 32: few-row kernels only, on the side streams) / after it (full recompute per step)"},
                        "model_batch_reduced": args.max_ctx != max_ctx_asked, "model_batch_contexts_requested": max_ctx_asked,

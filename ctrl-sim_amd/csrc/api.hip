@@ -77,8 +77,7 @@ static int g_options[OPT_COUNT] = {1, 1, 0, 1, 1, 0, 7, 1};
 // Guard counter (common.h): the counter the CALLER bound with ctrlsim_bind — an engine's own 4 bytes of device memory — or,
 // for callers that never bind one, a library-owned word allocated on first use on the then-current device.
 static int* g_guard = nullptr;
-int* ctrlsim_nonfinite_ptr() {
-  if (g_guard) return g_guard;
+static int* own_guard_word() {
   static int* p = nullptr;
   if (!p) {
     if (hipMalloc(reinterpret_cast<void**>(&p), sizeof(int)) != hipSuccess) { p = nullptr; return nullptr; }
@@ -86,9 +85,11 @@ int* ctrlsim_nonfinite_ptr() {
   }
   return p;
 }
-// events counted since the last reset (synchronises the device)
+int* ctrlsim_nonfinite_ptr() { return g_guard ? g_guard : own_guard_word(); }
+// events counted in the LIBRARY'S OWN word since the last reset (synchronises the device).  A caller that bound its own counter
+// (ctrlsim_bind) reads that counter itself: this function never touches it, whatever is bound at the moment.
 static int nonfinite_count(int reset) {
-  int* p = ctrlsim_nonfinite_ptr();
+  int* p = own_guard_word();
   int n = 0;
   if (!p || hipMemcpy(&n, p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return CTRLSIM_ELAUNCH;
   if (reset && n && hipMemset(p, 0, sizeof(int)) != hipSuccess) return CTRLSIM_ELAUNCH;

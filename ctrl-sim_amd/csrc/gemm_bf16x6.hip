@@ -755,6 +755,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ws256_kernel(const float* A, int 
     // Requests of this wave still in flight, oldest first: activation rows of block it + 1 (4), result rows of block it - 1 (4),
     // residual rows of block it + 1 (4).  Only the first four are needed now: the others stay in flight across the barrier
     // (vmcnt counts in issue order; raw s_barrier: __syncthreads would drain the counter).
+    // The constants follow from the issue counts per wave and block, all UNCONDITIONAL so that the count is exact: dma() issues 4 row
+    // requests (one per q), the row-store epilogue 4 stores (one per q), the key-image epilogue 2 x NPL = 4 stores, the value-image
+    // epilogue 4 x NPL = 8 stores.  A lane whose row lies beyond M still issues its dma (clamped row) but skips its stores — that happens
+    // only in the matrix's last, partial block, which is the LAST job of its workgroup (blocks are dealt round-robin), so no later wait
+    // counts on those stores.
+    static_assert(NPL == 2 && WS_ROWS == 32, "the counted vmcnt waits below assume 4 requests per dma(), 4 / 4 / 8 stores per epilogue");
     if (RESID) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     else if (KV && kv_kind == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");     // a value block leaves as 8 stores per lane
     else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");

@@ -1119,6 +1119,7 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
     if (!exists[sn]) {                                   // autoregressive_policy.py:260-263
       accel = 0.0; steer = 0.0;
       set_transform(p, -1000000.f, -1000000.f, p[P_A]);
+      p[P_TELE] = 0.f;                                   // a parked vehicle drops a pending set_position request (it must not fire on revival)
       tele[tid] = 1;
     } else {
       if (p[P_TELE] != 0.f) {                            // Vehicle::set_position -> BaseCar::SetPosition -> b2Body::SetTransform
@@ -1356,7 +1357,8 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
             if (coff + nc < MAX_ISLAND_CONTACTS) {         // (the touching graph of disjoint boxes is planar: <= 3 N - 6 contacts)
               isl_c[coff + nc].m = cs + (size_t)pr * CS_STRIDE; isl_c[coff + nc].ia = i; isl_c[coff + nc].ib = j; ++nc;
             } else if (guard) {
-              atomicAdd(guard, 1);                         // deeply overlapping boxes: the contact is NOT solved — counted, never silent
+              atomicAdd(guard, SIM_GUARD_UNIT);            // deeply overlapping boxes: the contact is NOT solved — counted, never silent
+                                                           // (in the HIGH half of the guard word: not a non-finite event of the model)
             }
             if ((in_island >> o) & 1ull) continue;
             isl_stack[sc++] = o; in_island |= 1ull << o;

@@ -644,6 +644,9 @@ class RolloutEngine:
         back: the scheduler (run) then queues another lane's step before this one blocks on its read-back."""
         T = self.dims.T
         t0 = 0
+        # pipelined jobs: the host never BLOCKS on a lane's read-back — a lane whose group counts are not back yet (its cached steps crawl
+        # underneath the other lanes' full-row kernels) yields, so that the lanes in full-recompute steps keep the main stream fed
+        poll = lane_idx is not None
         if self.use_cache and steps > 0:
             # steps 0 .. nT-1 chunk by chunk: while t < T the window starts at step 0, so a context's frame, membership and map
             # are constant and its decoder K/V can be cached across steps (csrc/forward.hip).  A chunk whose context set does
@@ -651,6 +654,8 @@ class RolloutEngine:
             nT = min(T, steps)
             self._enqueue_groups(L, 0, lo, hi)
             yield
+            while poll and not L.ev_ready.query():
+                yield
             hist, _ = self._await_groups(L)
             self.groups_per_step[0, lo:hi] = hist.sum(1)
             for (s0, s1, counts) in self._chunks(hist, lo):
@@ -663,6 +668,8 @@ class RolloutEngine:
                         self._lane_t[lane_idx] = t
                     if t > 0:
                         yield
+                        while poll and not L.ev_ready.query():
+                            yield
                         h, changed = self._await_groups(L)
                         self.groups_per_step[t, s0:s1] = h.sum(1)
                         cached_ok = cached_ok and not changed
@@ -693,6 +700,8 @@ class RolloutEngine:
                 self._lane_t[lane_idx] = t
             self._enqueue_groups(L, t, lo, hi)
             yield
+            while poll and not L.ev_ready.query():
+                yield
             hist, _ = self._await_groups(L)
             self.groups_per_step[t, lo:hi] = hist.sum(1)
             self._main_waits(L)
@@ -868,6 +877,12 @@ class RolloutEngine:
         runs, self._unchecked = self._unchecked, []
         if not bad:
             return False
+        if bad >= 65536:
+            # simulator events (units of 2^16 of the guard word, csrc/common.h): contacts beyond the island solver's table.  Not a matter
+            # of the operand split — no fallback, no permanent switch of the model to three planes: raise at once
+            raise FloatingPointError(f"{bad >> 16} simulator contacts beyond the island solver's table (csrc/sim.hip: MAX_ISLAND_CONTACTS) in the "
+                                     f"rollouts of scenario ranges {[r[1:] if r else '?' for r in runs]}"
+                                     + (f"; also {bad & 65535} non-finite events" if bad & 65535 else ""))
         if self.split == "auto" and self.scheme == 1 and runs and all(r is not None for r in runs):
             self._set_split(0)
             for steps, s0, s1 in runs:

@@ -171,6 +171,7 @@ class Vehicle:
         i = self._i
         if x == -1000000.0 and y == -1000000.0:
             self._sim.alive[i] = 0
+            self._sim.tele.pop(i, None)       # a parked vehicle takes no earlier set_position request of this step with it
         else:
             self._sim.alive[i] = 1
             self._sim.tele[i] = (x, y)
@@ -282,6 +283,7 @@ class Simulation:
         # (cfgs/dataset/waymo/base.yaml:13-16,41-42) for callers that pass token ids through the same entry point
         self.disc6 = (C.c_double * 6)(-10, 10, -0.7, 0.7, 20, 50)
         self.vehs = [Vehicle(self, i) for i in range(self.N)]
+        self.guard = torch.zeros(1, dtype=torch.int32, device=dev)
         self.speed = None
         self.reset()
 
@@ -318,6 +320,9 @@ class Simulation:
         if self.t >= self.steps:
             raise RuntimeError("rollout longer than the allocated history")
         p = _lib.ptr
+        # the step's guard events (contacts beyond the island solver's table) go to THIS simulation's counter, not to whichever engine
+        # bound its own last (ctrlsim_bind: per-caller state); read back with the state row below
+        _lib.check(self.lib.ctrlsim_bind(-1, p(self.guard)), "bind")
         self.exists.copy_(torch.from_numpy(self.alive[None]).to(self.device))
         if self.tele:
             xy = np.full((1, self.N, 2), np.nan, np.float32)
@@ -332,3 +337,8 @@ class Simulation:
                                              self.steps + 1, float(dt), 0, p(self.contact_state), _lib.stream_ptr()), "sim_step")
         self.t += 1
         self._read()
+        self.lib.ctrlsim_unbind(p(self.guard))
+        n = int(self.guard.item())
+        if n:
+            self.guard.zero_()
+            raise FloatingPointError(f"{n >> 16} simulator contacts beyond the island solver's table in this step (csrc/sim.hip: MAX_ISLAND_CONTACTS)")

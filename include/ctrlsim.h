@@ -365,7 +365,9 @@ int ctrlsim_split_scheme(void);
  * alone do not show an overflow of the fp16 range of the two-plane operand split).  Callers check this count (>= 0;
  * synchronises the device) and fail or repeat with ctrlsim_set_option(4, 0).  reset != 0 clears it.  The counter is one word of
  * device memory per process, allocated at first use on the current device: one host thread and one device per process, like the
- * options and the profiling hooks. */
+ * options and the profiling hooks.  It receives the events of launches made while NO caller-owned counter is bound (ctrlsim_bind below);
+ * this function always reads the library's own word, never a bound one.  Units: a non-finite event adds 1, a simulator contact beyond
+ * the island solver's table (ctrlsim_sim_step) adds 65536 — count % 65536 and count / 65536 tell them apart. */
 int ctrlsim_nonfinite_count(int reset);
 /* Per-caller state instead of the process-wide defaults: split_scheme (0 / 1; -1 = leave as is) selects the operand split the
  * caller's weight planes, K/V images and workspace were built for, guard_counter is a device int32 the CALLER owns (zeroed and read

@@ -122,7 +122,9 @@ def test_linear256_both_kernels(ws_option, M, relu, resid, ln):
     assert (out.double() - ref).abs().max().item() < 2e-5 * max(1.0, scale / 50)
 
 
-@pytest.mark.parametrize("B,L,col0", [(3, 224, 256), (2, 96, 256), (5, 160, 0), (1, 2304, 256)])
+# (160 x 288 = 46 080 rows = 1 440 row blocks of 32: more than four per compute unit, so every persistent workgroup of the weight-stationary
+#  kernel runs its multi-job ring with result stores and the next blocks' requests in flight across the counted-vmcnt barriers)
+@pytest.mark.parametrize("B,L,col0", [(3, 224, 256), (2, 96, 256), (5, 160, 0), (1, 2304, 256), (160, 288, 256), (150, 292, 0)])
 def test_linear_with_kv_image_epilogue(ws_option, B, L, col0):
     """The in_proj Linear whose key / value columns leave as split K / V tile images (ctrlsim_gemm_nt_kv): the images must drive
     the attention kernel to the same output as images split from the fp32 result of the plain Linear, and the fp32 (query)

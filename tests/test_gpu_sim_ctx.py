@@ -943,5 +943,9 @@ def test_contact_table_overflow_is_counted_not_silent():
     eng = RolloutEngine(cfg, w, DEV, max_ctx=64, seed=2)
     eng.load_scenarios([scn], steps=3)
     eng.run(3)
-    with pytest.raises(FloatingPointError):
+    with pytest.raises(FloatingPointError, match="simulator contacts"):
         eng.results()
+    # a simulator event is not an overflow of the operand split: no fallback to three planes, no permanent switch of the model
+    assert eng.scheme == 1 and not eng.model.split_fallback
+    # the library's own word (launches without a bound counter) was not touched by the engine's launches
+    assert _lib.lib().ctrlsim_nonfinite_count(1) == 0

@@ -18,9 +18,9 @@ PY
 }
 for rep in 1 2; do
   run base2_1024_$rep --lanes 2 --no-pipeline --max-ctx 1024
-  run base2_768_$rep --lanes 2 --no-pipeline --max-ctx 768
+  run pipe2_1024_$rep --lanes 2 --max-ctx 1024
   run pipe3_768_$rep --lanes 3 --max-ctx 768
-  run pipe3_832_$rep --lanes 3 --max-ctx 832
+  run pipe4_640_$rep --lanes 4 --max-ctx 640
 done
 python - <<'PY'
 import json
