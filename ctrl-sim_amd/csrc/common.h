@@ -103,7 +103,8 @@ enum { OPT_ATTN_IMPL = 0, OPT_GEMM_IMPL = 1,   // 0 = f32-input MFMA, 1 = split-
        OPT_GEMM_WS = 6,                          // Linear(256 -> 256) [+ LayerNorm]: 1 = weight-stationary streaming kernel (gemm_bf16x6.hip)
        OPT_ATTN_TBL = 7,                         // causal self-attention over the token rows: 1 = visibility masks from the per-class table
                                                  // (one v_cndmask per score), 0 = masks built per query in the kernel
-       OPT_COUNT = 8 };
+       OPT_LAST_KV = 8,                          // last decoder layer of a rollout pass: 1 = in_proj of keys / values only + queries of the queried rows
+       OPT_COUNT = 9 };
 // run-time view of the selected split (dispatch.hip): planes per operand, 16-bit elements per (context, head, tile) K/V image
 int split_npl();
 inline size_t split_kimg() { return (size_t)2 * split_npl() * 64 * 32; }

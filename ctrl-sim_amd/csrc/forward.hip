@@ -77,7 +77,9 @@ struct LNp { const float* g; const float* b; };
 struct Mlp { Lin l0; LNp ln; Lin l3; };
 struct FfnPlanes { const void *w1[2] = {nullptr, nullptr}, *w2[2] = {nullptr, nullptr}; };
 struct EncLayer { Lin qkv, out, lin1, lin2; LNp n1, n2; FfnPlanes fp; };
-struct DecLayer { Lin qkv, out, cq, ckv, cout, lin1, lin2; LNp n1, n2, n3; FfnPlanes fp; };
+// sq / skv: the query rows / the key + value rows of the self-attention in_proj as Linears of their own (the last decoder layer of a full
+// pass projects keys and values of every token but queries of the A queried tokens only)
+struct DecLayer { Lin qkv, sq, skv, out, cq, ckv, cout, lin1, lin2; LNp n1, n2, n3; FfnPlanes fp; };
 
 }  // namespace
 
@@ -174,6 +176,12 @@ extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_w
     const std::string p = "decoder.transformer_decoder.layers." + std::to_string(i);
     DecLayer L;
     L.qkv = mk(P(p + ".self_attn.in_proj_weight"), P(p + ".self_attn.in_proj_bias"), p + ".self_attn.in_proj_weight", 3 * DM, 0);
+    {
+      const float* sw = P(p + ".self_attn.in_proj_weight");
+      const float* sb = P(p + ".self_attn.in_proj_bias");
+      L.sq = mk(sw, sb, p + ".self_attn.in_proj_weight", 3 * DM, 0);
+      L.skv = mk(sw ? sw + DM * DM : nullptr, sb ? sb + DM : nullptr, p + ".self_attn.in_proj_weight", 3 * DM, DM);
+    }
     L.out = lin(p + ".self_attn.out_proj");
     const float* cw = P(p + ".multihead_attn.in_proj_weight");
     const float* cb = P(p + ".multihead_attn.in_proj_bias");
@@ -707,8 +715,13 @@ int forward_full(const ctrlsim_model* m, int n, const int* Bk, const int* Ak, co
   // ---- decoder (decoder.py:52): layers 0..ND-2 on all tokens
   for (int i = 0; i < d.ND; ++i) {
     const DecLayer& Ld = m->dec[i];
-    CHK(gemm_kv(d, bt, w, Ld.qkv, w.X, w.qkv[i], 3 * DM, 3 * DM, DM, w.img_dec[i], false, st));
-    if (i < d.ND - 1 || all) {
+    const bool last_few = !(i < d.ND - 1 || all);
+    const bool kv_only = last_few && ctrlsim_option(OPT_LAST_KV) != 0;
+    // the last layer of a rollout pass reads the queries of the A queried tokens only: keys and values of every token (two of the
+    // in_proj's three column groups), queries from the gathered rows below — a twelfth of the pass's in_proj work less
+    if (kv_only) CHK(gemm_kv(d, bt, w, Ld.skv, w.X, w.qkv[i] + DM, 3 * DM, 2 * DM, 0, w.img_dec[i], false, st));
+    else CHK(gemm_kv(d, bt, w, Ld.qkv, w.X, w.qkv[i], 3 * DM, 3 * DM, DM, w.img_dec[i], false, st));
+    if (!last_few) {
       CHK(attention(d, bt, w, AttnCall{amode, Q_ALL, w.qkv[i], 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, w.img_dec[i], false,
                                        w.att, Tq, Tq, 0, use_tbl}, st));
       CHK(gemm_ln(Ld.out, Ld.n1, w.att, DM, w.X, DM, w.X, DM, w.tmp, rL, DM, 0, st));
@@ -723,7 +736,8 @@ int forward_full(const ctrlsim_model* m, int n, const int* Bk, const int* Ak, co
       }
       prof_few(true);
       CHK(launch_row_copy(w.X, DM, w.xc, DM, w.idx_state, rQ, DM, 0, st));
-      CHK(launch_row_copy(w.qkv[i], 3 * DM, w.qkvc, 3 * DM, w.idx_state, rQ, 3 * DM, 0, st));
+      if (kv_only) CHK(gemm(Ld.sq, w.xc, DM, nullptr, 0, w.qkvc, 3 * DM, rQ, DM, DM, 0, st));        // queries of the queried rows
+      else CHK(launch_row_copy(w.qkv[i], 3 * DM, w.qkvc, 3 * DM, w.idx_state, rQ, 3 * DM, 0, st));
       CHK(attention(d, bt, w, AttnCall{amode, Q_STATE, w.qkvc, 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, w.img_dec[i], false,
                                        w.attc, Tq, Tq, 0}, st));
       CHK(gemm_ln(Ld.out, Ld.n1, w.attc, DM, w.xc, DM, w.xc, DM, w.tmpc, rQ, DM, 0, st));

@@ -355,7 +355,9 @@ int ctrlsim_attn_class_prof(int enable, unsigned long long* host_out);
  * 0 three bf16 planes; per engine through ctrlsim_bind).  Key 5 = map-encoder pooling on the matrix pipe (default 0).
  * Key 6 = weight-stationary kernel for the Linear(256 -> 256 G) shapes, bit mask: 1 = launches of at least two 32-row blocks per
  * compute unit, 2 = smaller launches, 4 = the in_proj Linears with K / V-image epilogue (default 7; 0 = tiled kernel everywhere).
- * Key 7 = causal self-attention over the token rows takes its visibility masks from the per-class table (default 1; 0 = built per query). */
+ * Key 7 = causal self-attention over the token rows takes its visibility masks from the per-class table (default 1; 0 = built per query).
+ * Key 8 = the last decoder layer of a rollout pass projects keys / values of every token and queries of the queried tokens only (default 1;
+ * 0 = the whole in_proj for every token, then a gather). */
 int ctrlsim_set_option(int key, int value);
 /* Operand split compiled into the library (csrc/split.h): 1 = two fp16 planes / three products (weights pre-scaled by 2^8), 0 = three
  * bf16 planes / six products.  ctrlsim_amd/pack.py packs weight planes and sizes the K/V images accordingly. */
