@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--no-class-profile", action="store_true", help="skip the untimed extra slice with per-class attention cycle accounting")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spot-check", type=int, default=4, help="scenarios re-rolled alone after the timed region (bit-identity check; 0 = off)")
-    ap.add_argument("--cpu-sample-scenarios", type=int, default=4)
+    ap.add_argument("--cpu-sample-scenarios", type=int, default=2)
     ap.add_argument("--cpu-sample-steps", type=int, default=2)
     args = ap.parse_args()
 
@@ -463,19 +463,24 @@ def cpu_baseline(cfg, w, scns, args):
     sim_libs.build_oracle()
     cores = os.cpu_count() or 1
     threads = max(1, min(cores, 64))
+    import model_oracle
+    model_oracle.FUSED_SDPA = True                     # attention through torch's fused op, as nn.MultiheadAttention evaluates it in the reference
     ro = rollout_oracle.RolloutOracle(cfg, w, seed=args.seed, threads=threads)
     k, ns = args.cpu_sample_steps, min(args.cpu_sample_scenarios, len(scns))
     groups = 0
     t0 = time.perf_counter()
     for scn in scns[:ns]:
-        o = ro.run(scn, k, sim_libs.OracleSim)
+        o = ro.run(scn, k, sim_libs.OracleSim, dense_window=True)     # the reference forwards the full T = 32 window at every step
         groups += int(o["n_groups"].sum())
     el = time.perf_counter() - t0
     return {"value": ns * scns[0].N * k / el, "unit": "agent-steps/s", "cores": threads, "kind": "port",
             "cpu_model": cpu_model(), "host_logical_cpus": cores,
             "sample": f"{ns} scenarios x {scns[0].N} agents x {k} rollout steps ({groups} focal-group steps, "
-                      f"{el:.1f} s); oracle/rollout_oracle.py + oracle/sim_oracle.c, torch {torch.__version__} CPU, "
-                      f"{threads} threads"}
+                      f"{el:.1f} s: two dense T = 32 forwards per focal-group step, as the reference); oracle/rollout_oracle.py + "
+                      f"oracle/sim_oracle.c, torch {torch.__version__} CPU, {threads} threads",
+            "note": "rounds 1-3 timed the port on its first steps with buffers of `steps` rows, i.e. 2-step windows instead of the reference's "
+                    "32: their cpu_baseline values (21-32 agent-steps/s) were several times too fast; on the build container's 8 cores the port "
+                    "and the UNMODIFIED reference take 0.86 s and 0.94 s per focal-group step (profiles/r04_cpu_port_vs_reference.txt)"}
 
 
 if __name__ == "__main__":

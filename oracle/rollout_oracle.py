@@ -119,13 +119,17 @@ class RolloutOracle:
             next_act[v] = np.zeros(2)
         return processed, tokens, next_act, dead, len(groups)
 
-    def run(self, scn, steps, sim_cls, explicit_noise=None, record_groups=False, dt=0.1):
+    def run(self, scn, steps, sim_cls, explicit_noise=None, record_groups=False, dt=0.1, dense_window=False):
         """Roll one scenario.  Returns dict(tokens[N,steps], rtg_bins[N,steps,3], states[N,steps+1,8] f32-valued,
-        coll[N,steps+1,2], actions[N,steps,2], n_groups[steps])."""
+        coll[N,steps+1,2], actions[N,steps,2], n_groups[steps]).
+        dense_window: the policy's buffers hold at least train_context_length steps, as the reference's do (policies/policy.py:45-66 sizes
+        them by cfg.nocturne.steps = 90), so that EVERY forward runs over the full T-step window — the reference's cost per step, whatever
+        t is.  Without it a rollout of fewer than T steps forwards a `steps`-long window: the same tokens (the mask is causal), a fraction
+        of the cost — what the parity tests want, and NOT what a CPU baseline should time (bench.py passes True)."""
         w = self.w
         N = scn.N
         sim = sim_cls(scn.length, scn.width, scn.x, scn.y, scn.heading, scn.speed, scn.edge_segments)
-        buf = fo.PolicyBuffers(N, steps)
+        buf = fo.PolicyBuffers(N, max(steps, w.train_context_length) if dense_window else steps)
         buf.types[:] = scn.types
         goals5 = scn.goals5()
         states = np.zeros((N, steps + 1, 8))

@@ -33,9 +33,11 @@ r = gen_golden.ref_closed_loop(cfg, w, scn, steps, seed=9)
 t_ref = time.perf_counter() - t0
 g_ref = int(r["n_groups"].sum())
 
+import model_oracle
+model_oracle.FUSED_SDPA = True          # the reference's attention op (bench.py's cpu_baseline sets it too)
 ro = rollout_oracle.RolloutOracle(cfg, w, seed=9, threads=threads)
 t0 = time.perf_counter()
-o = ro.run(scn, steps, sim_libs.OracleSim)
+o = ro.run(scn, steps, sim_libs.OracleSim, dense_window=True)      # full T-step windows, as the reference forwards them
 t_port = time.perf_counter() - t0
 g_port = int(o["n_groups"].sum())
 same = np.array_equal(o["tokens"], r["tokens"])
