@@ -66,6 +66,7 @@ SIGNATURES = {
     "ctrlsim_sim_init": (I, [I, I, I, P, P, P, P, P, P, P, I, P, P]),
     "ctrlsim_sim_contact_floats": (L, [I]),
     "ctrlsim_sim_step": (I, [I, I, I, P, P, P, P, P, P, P, P, P, P, I, I, F, I, P, P]),
+    "ctrlsim_sim_step_expert": (I, [I, I, I, P, P, P, P, P, P, P, P, P, P, I, I, F, P, P, P]),
     "ctrlsim_sim_set_position": (I, [I, I, P, P, P]),
     "ctrlsim_group_build": (I, [I, I, I, I, I, I, D, P, P, I, P, P, P, P, P, P, P, P, P]),
     "ctrlsim_groups_changed": (I, [I, I, P, P, P, P, P, P, P, P]),

@@ -25,7 +25,8 @@ int launch_sim_init(int, int, int, const float*, const float*, const float*, con
                     unsigned char*, int, float*, hipStream_t);
 int launch_sim_set_position(int, int, const float*, float*, hipStream_t);
 int launch_sim_step(int, int, int, const int*, const double*, const double*, const float*, const float*,
-                    const unsigned char*, float*, float*, unsigned char*, double*, int, int, float, int, float*, hipStream_t);
+                    const unsigned char*, float*, float*, unsigned char*, double*, int, int, float, int, float*, const float*,
+                    hipStream_t);
 int launch_group_build(int, int, int, int, int, int, double, const float*, const int*, int, unsigned long long*, int*, int*,
                        unsigned long long*, unsigned long long*, int*, int*, unsigned char*, hipStream_t);
 int launch_ctx_index(int, int, int, const int*, const int*, const unsigned long long*, const int*, const int*, int*, int*,
@@ -264,7 +265,14 @@ int ctrlsim_sim_step(int S, int N, int E, const int* act_tok, const double* act_
                      double* applied, int t, int Tmax1, float dt, int mode, float* contact_state, hipStream_t st) {
   if (!disc6) return CTRLSIM_EINVAL;
   return launch_sim_step(S, N, E, act_tok, act_f64, disc6, size, edges, exists, phys, hist_states, coll, applied, t, Tmax1, dt,
-                         mode, contact_state, st);
+                         mode, contact_state, nullptr, st);
+}
+int ctrlsim_sim_step_expert(int S, int N, int E, const int* act_tok, const double* act_f64, const double* disc6, const float* size,
+                            const float* edges, const uint8_t* exists, float* phys, float* hist_states, uint8_t* coll,
+                            double* applied, int t, int Tmax1, float dt, float* contact_state, const float* expert, hipStream_t st) {
+  if (!disc6) return CTRLSIM_EINVAL;
+  return launch_sim_step(S, N, E, act_tok, act_f64, disc6, size, edges, exists, phys, hist_states, coll, applied, t, Tmax1, dt, 0,
+                         contact_state, expert, st);
 }
 int ctrlsim_group_build(int S, int N, int A, int T, int t, int Tmax1, double dist_thresh, const float* hist_states,
                         const int* eval_order, int has_roads, uint64_t* persist, int* n_groups, int* grp_focal,

@@ -124,8 +124,16 @@ __global__ __launch_bounds__(256) void attn_mask_table_kernel(TblBatch tb) {
   }
 }
 
+// Five workgroups per compute unit for the mask-table kernel (ATT_TBL_WG5 builds): it needs 81 VGPRs (the in-kernel mask arithmetic is
+// gone), so five waves per SIMD fit without the spills that sank the earlier attempts; the two stages must then be exactly 32 KB
+// (no key-padding bias region in causal mode, the block-maximum words alias the second stage).
+#ifdef ATT_TBL_WG5
+#define ATT_OCC(TBL_) ((TBL_) ? 5 : 3)
+#else
+#define ATT_OCC(TBL_) 3
+#endif
 template <int MODE, bool PRE, bool TBL = false>
-__global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
+__global__ __launch_bounds__(256, ATT_OCC(TBL)) void attention_bf16x6_kernel(
     const float* __restrict__ Qb_, int ldq, const float* __restrict__ K, const float* __restrict__ V, int ldkv,
     float* __restrict__ Ob_, int ldo, const unsigned char* __restrict__ key_pad_, float scale_log2e, int variant, AttnBatch ab) {
   const unsigned long long t_start = ab.cprof ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -152,14 +160,20 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
   // tokens (earlier steps, and the state tokens of their step).
   constexpr int K_PLANE = KT6 * HD;              // bf16 elements: [ks 2][half 2][64 keys][8]
   constexpr int V_PLANE = HD * KT6;              // [16 quads][32 d][4 keys]
+#ifdef ATT_TBL_WG5
+  constexpr int BUF = NPL * (K_PLANE + V_PLANE) + (TBL ? 0 : 2 * KT6 + 8);
+#else
   constexpr int BUF = NPL * (K_PLANE + V_PLANE) + 2 * KT6 + 8;   // + KT6 floats of key-padding bias + two "sub-tile has padded keys" flags
+#endif
 #ifdef ATT_RING3
   constexpr int NBUF = PRE ? 3 : 2;              // pre-split images: a ring of three stages, the DMA runs two tiles ahead
 #else
   constexpr int NBUF = 2;
 #endif
   constexpr int BUF_ = BUF, NBUF_ = NBUF;
+#ifndef ATT_TBL_WG5
   __shared__ int blk_tmax[4];
+#endif
   static_assert(2 * BUF * 2 >= 4 * 32 * 33 * 4, "output transpose must fit");
 
   // XCD-aware work map: workgroups are dealt round-robin to the 8 XCDs (linear id % 8) and each XCD has its own L2, so all
@@ -200,6 +214,9 @@ __global__ __launch_bounds__(256, 3) void attention_bf16x6_kernel(
   };
 #ifndef ATT_NO_EARLY_DMA
   if (PRE) dma_tile(0, 0);
+#endif
+#ifdef ATT_TBL_WG5
+  int* const blk_tmax = reinterpret_cast<int*>(arena + BUF_);       // the second stage: free until tile 1 is requested (after the prologue's barriers)
 #endif
 
   // ---- this lane's query: fragment of Q^T (B operand), k-step ks covers d = 16*ks + 8*half .. +7

@@ -1092,9 +1092,9 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
                                                        unsigned char* __restrict__ coll, double* __restrict__ applied,
                                                        int t, int Tmax1, float dt, int kinematic,
                                                        float* __restrict__ contact_state, int s_base,
-                                                       int* __restrict__ guard) {
+                                                       int* __restrict__ guard, const float* __restrict__ expert) {
   __shared__ BodyLds B;
-  __shared__ int isl_bodies[64], isl_stack[64], isl_index[64], wake[64], tele[64], in_isl[64], moved_now[64];
+  __shared__ int isl_bodies[64], isl_stack[64], isl_index[64], wake[64], tele[64], in_isl[64], moved_now[64], expt[64];
   __shared__ V2 isl_pc[64], isl_vv[64];
   __shared__ float isl_pa[64], isl_vw[64];
   __shared__ Constraint isl_c[MAX_ISLAND_CONTACTS];
@@ -1116,6 +1116,7 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
     const float L = size[sn * 2 + 0];
     double accel, steer;
     tele[tid] = 0; in_isl[tid] = 0; moved_now[tid] = 0;
+    expt[tid] = (expert && expert[sn * 4] == expert[sn * 4]) ? 1 : 0;      // x = NaN: not expert-controlled in this step
     if (!exists[sn]) {                                   // autoregressive_policy.py:260-263
       accel = 0.0; steer = 0.0;
       set_transform(p, -1000000.f, -1000000.f, p[P_A]);
@@ -1410,8 +1411,38 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
         SIMT(7)
       }
       SYNCJ();
-      for (int i = tid; i < n_tail; i += blockDim.x) gtail[i] = tail_lds[i];
     }
+    // ---- Scenario::Step for EXPERT-CONTROLLED objects (nocturne/cpp/src/scenario.cc:276-283), after the world step, in object order:
+    // Vehicle::set_position (vehicle.cc:82-87: b2Body::SetTransform at the current angle), set_heading (vehicle.cc:89-94: SetTransform
+    // at the current position, angle = heading - pi/2), set_speed (vehicle.cc:96-105: SetLinearVelocity, which wakes the body when the
+    // velocity is not zero).  Each SetTransform synchronises the proxy (the dynamic tree's shape decides the order of later contacts)
+    // and flags the new-contact search of the next step's top.
+    if (expert && tid == 0) {
+      for (int i = 0; i < N; ++i) {
+        if (!expt[i]) continue;
+        const size_t si = (size_t)s * N + i;
+        const float ex = expert[si * 4], ey = expert[si * 4 + 1], eh = expert[si * 4 + 2], es = expert[si * 4 + 3];
+        const Box b = box_of(size[si * 2 + 1], size[si * 2]);
+        for (int pass = 0; pass < 2; ++pass) {
+          const float ang = pass == 0 ? B.a[i] : (float)((double)eh - M_PI_D * 0.5f);
+          const float qs = sinf(ang), qc = cosf(ang);
+          B.px[i] = ex; B.py[i] = ey; B.a[i] = ang;
+          B.cx[i] = (qc * B.lcx[i] - qs * B.lcy[i]) + ex;
+          B.cy[i] = (qs * B.lcx[i] + qc * B.lcy[i]) + ey;
+          if (cs) {
+            Xf xf; xf.p = v2(ex, ey); xf.q.s = qs; xf.q.c = qc;
+            if (synchronize_fixture(fat + 4 * i, b, xf, xf)) { tree_move_proxy(T, fat, i); buffer_move(tail, N, i); }
+            tail[2] = 1.f;                                           // b2World::m_newContacts
+          }
+        }
+        const float nvx = es * cosf(eh), nvy = es * sinf(eh);
+        if (nvx * nvx + nvy * nvy > 0.0f) { B.awake[i] = 1; B.sleep[i] = 0.f; }
+        B.vx[i] = nvx; B.vy[i] = nvy;
+      }
+    }
+    SYNCJ();
+    if (cs)
+      for (int i = tid; i < n_tail; i += blockDim.x) gtail[i] = tail_lds[i];
     if (tid < N) {
       const size_t sn = (size_t)s * N + tid;
       float* p = phys + sn * PHYS_STRIDE;
@@ -1423,6 +1454,11 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
       py[tid] = B.py[tid];
       sp[tid] = sqrtf(B.vx[tid] * B.vx[tid] + B.vy[tid] * B.vy[tid]);
       hd[tid] = (float)((double)B.a[tid] + M_PI_D * 0.5f);
+      if (expt[tid]) {                                    // Object::heading_ / speed_ of an expert-controlled object are the logged values
+        const size_t se = ((size_t)s * N + tid) * 4;
+        hd[tid] = expert[se + 2];
+        sp[tid] = expert[se + 3];
+      }
       p[P_HEADING] = hd[tid]; p[P_SPEED] = sp[tid];
     }
   }
@@ -1463,9 +1499,10 @@ int launch_sim_set_position(int S, int N, const float* xy, float* phys, hipStrea
 int launch_sim_step(int S, int N, int E, const int* act_tok, const double* act_f64, const double* disc6,
                     const float* size, const float* edges, const unsigned char* exists, float* phys,
                     float* hist_states, unsigned char* coll, double* applied, int t, int Tmax1, float dt, int kinematic,
-                    float* contact_state, hipStream_t st) {
+                    float* contact_state, const float* expert, hipStream_t st) {
   if (S <= 0) return CTRLSIM_OK;
   if (N < 1 || N > 64 || E < 0 || t < 0 || t + 1 >= Tmax1 || (!act_tok && !act_f64)) return CTRLSIM_EINVAL;
+  if (expert && kinematic) return CTRLSIM_EINVAL;        // expert replay is defined on the FreeCar / Box2D integrator (scenario.cc:266-292)
   SimDiscretisation dz{disc6[0], disc6[1], disc6[2], disc6[3], (int)disc6[4], (int)disc6[5]};
   prof_before(PROF_SIM, st);
   // The step takes a CU's whole LDS (its own ~60 KB + a dynamic remainder it never touches): a scenario's workgroup then never
@@ -1494,7 +1531,7 @@ int launch_sim_step(int S, int N, int E, const int* act_tok, const double* act_f
   for (int s0 = 0; s0 < S; s0 += chunk) {
     const int n = S - s0 < chunk ? S - s0 : chunk;
     hipLaunchKernelGGL(sim_step_kernel, dim3(n), dim3(256), excl_lds, st, N, E, act_tok, act_f64, dz, size, edges, exists, phys,
-                       hist_states, coll, applied, t, Tmax1, dt, kinematic, contact_state, s0, ctrlsim_nonfinite_ptr());
+                       hist_states, coll, applied, t, Tmax1, dt, kinematic, contact_state, s0, ctrlsim_nonfinite_ptr(), expert);
   }
   // per scenario: body + control state in and out (20 floats), one history row + flags out, the road-edge segments in,
   // and (contacts) the persistent Box2D state in and out (20 floats per vehicle pair + broad phase)

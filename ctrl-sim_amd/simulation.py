@@ -14,8 +14,10 @@ stop_sign.cc:21):
 
 State lives on the GPU ([1, N, ...] arrays of include/ctrlsim.h); one `step` is one ctrlsim_sim_step launch (preceded by
 ctrlsim_sim_set_position when a vehicle was moved) plus one small device->host read of the new state row (the evaluator reads
-every vehicle every step anyway).  Not provided: expert replay inside step() (`expert_control = True` is stored, not acted on — the
-evaluators replay logs through the inverse bicycle model, evaluators/policy_evaluator.py), rendering, visible-state features."""
+every vehicle every step anyway).  `veh.expert_control = True` (object.cc:58-59) is acted on as Scenario::Step does
+(nocturne/cpp/src/scenario.cc:272-284): the physics step moves every body, then the vehicle is put on the logged position, heading
+and speed of the new time step (ctrlsim_sim_step_expert) — what utils/sim.py:20-65 get_ground_truth_states relies on.  It needs the log
+of a scenario FILE; a synthetic Scenario has none (ValueError).  Not provided: rendering, visible-state features."""
 from __future__ import annotations
 
 import ctypes as C
@@ -295,6 +297,8 @@ class Simulation:
 
     def reset(self):
         dev, N, T1 = self.device, self.N, self.steps + 1
+        for v in self.vehs:                                 # simulation.cc:29-38: reset() loads the scenario again — fresh objects
+            v.expert_control, v.physics_simulated = False, True
         self.exists = torch.ones(1, N, dtype=torch.uint8, device=dev)
         self.phys = torch.zeros(1, N, 20, device=dev)
         self.hist = torch.zeros(1, N, T1, 8, device=dev)
@@ -332,9 +336,28 @@ class Simulation:
                                                          _lib.stream_ptr()), "sim_set_position")
             self.tele = {}
         act = torch.from_numpy(self.act[None].copy()).to(self.device)
-        _lib.check(self.lib.ctrlsim_sim_step(1, self.N, self.E, None, p(act), self.disc6, p(self.size), p(self.edges),
-                                             p(self.exists), p(self.phys), p(self.hist), p(self.coll), None, self.t,
-                                             self.steps + 1, float(dt), 0, p(self.contact_state), _lib.stream_ptr()), "sim_step")
+        expert = None
+        if any(v.expert_control for v in self.vehs):
+            # Scenario::Step, scenario.cc:276-283: expert_trajectories_ / _headings_ / _speeds_ .at(id).at(current_time_) of the NEW time
+            if getattr(self, "gt_data_dict", None) is None:
+                raise ValueError("expert_control needs the logged trajectories of a scenario file (Simulation(scenario_path, config))")
+            ex = np.full((1, self.N, 4), np.nan, np.float32)
+            for i, v in enumerate(self.vehs):
+                if v.expert_control:
+                    tr = self.gt_data_dict[int(self.ids[i])]["traj"]
+                    if self.t + 1 >= len(tr):
+                        raise IndexError("expert trajectory shorter than the rollout (std::out_of_range in the reference)")
+                    ex[0, i] = tr[self.t + 1, :4]
+            expert = torch.from_numpy(ex).to(self.device)
+        if expert is None:
+            _lib.check(self.lib.ctrlsim_sim_step(1, self.N, self.E, None, p(act), self.disc6, p(self.size), p(self.edges),
+                                                 p(self.exists), p(self.phys), p(self.hist), p(self.coll), None, self.t,
+                                                 self.steps + 1, float(dt), 0, p(self.contact_state), _lib.stream_ptr()), "sim_step")
+        else:
+            _lib.check(self.lib.ctrlsim_sim_step_expert(1, self.N, self.E, None, p(act), self.disc6, p(self.size), p(self.edges),
+                                                        p(self.exists), p(self.phys), p(self.hist), p(self.coll), None, self.t,
+                                                        self.steps + 1, float(dt), p(self.contact_state), p(expert),
+                                                        _lib.stream_ptr()), "sim_step_expert")
         self.t += 1
         self._read()
         self.lib.ctrlsim_unbind(p(self.guard))

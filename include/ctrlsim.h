@@ -87,6 +87,16 @@ int ctrlsim_sim_step(int S, int N, int E, const int* act_tok, const double* act_
                      const float* size, const float* edges, const uint8_t* exists, float* phys, float* hist_states,
                      uint8_t* coll, double* applied, int t, int Tmax1, float dt, int mode, float* contact_state,
                      hipStream_t stream);
+/* The same step (mode 0) with EXPERT-CONTROLLED objects (Object.expert_control = True, nocturne/pybind11/src/object.cc:58-59;
+ * Scenario::Step, nocturne/cpp/src/scenario.cc:272-284; utils/sim.py:20-65 get_ground_truth_states): expert [S,N,4] = logged x, y,
+ * heading, speed of step t + 1, x = NaN for the vehicles under policy control.  The world step moves every body; an expert vehicle is then
+ * put on its logged state through Vehicle::set_position / set_heading / set_speed (vehicle.cc:75-105: two b2Body::SetTransform with proxy
+ * synchronisation and the new-contact search of the next step, SetLinearVelocity) before the collision flags are taken; its history
+ * row holds the logged values.  expert == NULL: ctrlsim_sim_step. */
+int ctrlsim_sim_step_expert(int S, int N, int E, const int* act_tok, const double* act_f64, const double* disc6,
+                            const float* size, const float* edges, const uint8_t* exists, float* phys, float* hist_states,
+                            uint8_t* coll, double* applied, int t, int Tmax1, float dt, float* contact_state,
+                            const float* expert, hipStream_t stream);
 
 /* ---- focal grouping + context tensors ------------------------------------------------------------------------
  * Replaces AutoregressivePolicy.get_data (policies/autoregressive_policy.py:51-165) with

@@ -9,7 +9,8 @@
 // restated below, each block citing what it follows:
 //   Vehicle::CreatePhysicsBody        nocturne/cpp/src/vehicle.cc:137-179
 //   Vehicle::set_acceleration/brake/set_steering/set_position   vehicle.cc:75-135
-//   Scenario::Step / Vehicle::Step    scenario.cc:266-292, vehicle.cc:25-55
+//   Scenario::Step / Vehicle::Step    scenario.cc:266-292, vehicle.cc:25-55 (expert_control objects: scenario.cc:276-283,
+//                                     Vehicle::set_position / set_heading / set_speed vehicle.cc:75-105)
 //   Object::BoundingPolygon           object.cc:14-28
 //   Scenario::UpdateCollision         scenario.cc:294-328  (BVH candidates == strict AABB overlap,
 //                                     bvh.h:181-193 + aabb.h:47-50, evaluated brute force)
@@ -40,6 +41,8 @@ struct Veh {
   float heading, speed;
   physics::FreeCar* car;
   bool coll_veh, coll_edge;
+  bool expert = false;            // Object::expert_control_ for the next step, with the logged state of that step
+  float ex_x = 0.f, ex_y = 0.f, ex_heading = 0.f, ex_speed = 0.f;
 };
 
 struct Sim {
@@ -140,12 +143,33 @@ void refsim_step(void* h, float dt) {                               // scenario.
   physics::GetPhysicsSimulation()->Step(dt);
   for (Veh& v : s->vehs) {
     v.coll_veh = v.coll_edge = false;                               // ResetCollision
-    b2Vec2 pos = v.car->GetPosition();                              // vehicle.cc:45-55
-    v.position = Vector2D(pos.x, pos.y);
-    v.speed = v.car->GetSpeed();
-    v.heading = v.car->GetAngle() + M_PI * 0.5f;
+    if (!v.expert) {
+      b2Vec2 pos = v.car->GetPosition();                            // vehicle.cc:45-55
+      v.position = Vector2D(pos.x, pos.y);
+      v.speed = v.car->GetSpeed();
+      v.heading = v.car->GetAngle() + M_PI * 0.5f;
+    } else {
+      // scenario.cc:279-283: set_position, set_heading, set_speed of the logged state, each through the Vehicle override
+      v.position = Vector2D(v.ex_x, v.ex_y);                        // vehicle.cc:82-87
+      v.car->SetPosition(b2Vec2(v.position.x(), v.position.y()));
+      v.heading = v.ex_heading;                                     // vehicle.cc:89-94
+      v.car->SetAngle(v.heading - M_PI * 0.5f);
+      v.speed = v.ex_speed;                                         // vehicle.cc:96-105 (ClipSpeed: max_speed_ is the float maximum)
+      float c = cosf(v.heading);
+      float sn = sinf(v.heading);
+      b2Vec2 speed_v(v.ex_speed * c, v.ex_speed * sn);
+      v.car->SetSpeed(speed_v);
+      v.expert = false;
+    }
   }
   UpdateCollision(s);
+}
+
+// the object is expert-controlled in the NEXT step (Object::set_expert_control(true), pybind object.cc:58-59) and the log holds this state for it
+void refsim_set_expert(void* h, int i, float x, float y, float heading, float speed) {
+  Veh& v = static_cast<Sim*>(h)->vehs[i];
+  v.expert = true;
+  v.ex_x = x; v.ex_y = y; v.ex_heading = heading; v.ex_speed = speed;
 }
 
 // out[n,6] = x, y, heading, speed, vx, vy  (velocity = PolarToVector2D(speed, heading), object.h:152-154)

@@ -36,6 +36,7 @@ def _bind(lib, prefix):
     g("create").argtypes = [C.c_int, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int, _f32p]
     g("set_action").argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
     g("set_position").argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float]
+    g("set_expert").argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
     g("step").argtypes = [C.c_void_p, C.c_float]
     g("get_state").argtypes = [C.c_void_p, _f32p, _u8p, _u8p]
     g("get_body").argtypes = [C.c_void_p, _f32p]
@@ -72,6 +73,11 @@ class _Sim:
 
     def set_position(self, i, x, y):
         self._g("set_position")(self.h, i, x, y)
+
+    def set_expert(self, i, x, y, heading, speed):
+        """Vehicle i is expert-controlled in the NEXT step: after the physics step it is put on this logged state
+        (nocturne/cpp/src/scenario.cc:276-283)."""
+        self._g("set_expert")(self.h, i, x, y, heading, speed)
 
     def step(self, dt=0.1):
         self._g("step")(self.h, dt)

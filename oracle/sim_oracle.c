@@ -60,6 +60,9 @@ typedef struct {
   /* FreeCar controls */
   float throttle, brake, steer;
   unsigned char coll_veh, coll_edge;
+  /* Object::expert_control_ for the next step + the logged state of that step (orasim_set_expert) */
+  int ex_on;
+  float ex_x, ex_y, ex_heading, ex_speed;
 } Veh;
 
 /* b2Manifold of one vehicle pair (i < j: fixture A = vehicle i, B = vehicle j) with the accumulated impulses */
@@ -1064,10 +1067,37 @@ void orasim_step(void* h, float dt) {
   for (int i = 0; i < s->n; ++i) {
     Veh* v = &s->v[i];
     v->coll_veh = v->coll_edge = 0;             /* position_ <- m_xf.p (already in px,py) */
-    v->speed = sqrtf(v->vx * v->vx + v->vy * v->vy);
-    v->heading = (float)((double)v->a + M_PI * 0.5f);
+    if (!v->ex_on) {
+      v->speed = sqrtf(v->vx * v->vx + v->vy * v->vy);
+      v->heading = (float)((double)v->a + M_PI * 0.5f);
+    } else {
+      /* Scenario::Step for an expert-controlled object (nocturne/cpp/src/scenario.cc:276-283): the three Vehicle setters, in order.
+       * set_position (vehicle.cc:82-87 -> BaseCar::SetPosition -> b2Body::SetTransform at the current angle): proxy synchronised,
+       * new contacts looked for at the top of the next world step; set_heading (vehicle.cc:89-94 -> SetAngle(heading - pi/2) ->
+       * SetTransform at the current position); set_speed (vehicle.cc:96-105 -> b2Body::SetLinearVelocity, which wakes the body
+       * when the velocity is not zero; Object::ClipSpeed clips at max_speed_ = the float maximum: a no-op). */
+      set_transform(v, v->ex_x, v->ex_y, v->a);
+      synchronize_fixture(s, i, body_xf(v), body_xf(v));
+      v->heading = v->ex_heading;
+      set_transform(v, v->px, v->py, (float)((double)v->heading - M_PI * 0.5f));
+      synchronize_fixture(s, i, body_xf(v), body_xf(v));
+      s->new_contacts = 1;
+      v->speed = v->ex_speed;
+      {
+        float c = cosf(v->heading), sn = sinf(v->heading);
+        float nvx = v->ex_speed * c, nvy = v->ex_speed * sn;
+        if (nvx * nvx + nvy * nvy > 0.0f) set_awake_true(v);
+        v->vx = nvx; v->vy = nvy;
+      }
+      v->ex_on = 0;
+    }
   }
   update_collision(s);
+}
+
+void orasim_set_expert(void* h, int i, float x, float y, float heading, float speed) {
+  Veh* v = &((Sim*)h)->v[i];
+  v->ex_on = 1; v->ex_x = x; v->ex_y = y; v->ex_heading = heading; v->ex_speed = speed;
 }
 
 void orasim_get_state(void* h, float* out, unsigned char* cv, unsigned char* ce) {

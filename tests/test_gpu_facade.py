@@ -367,3 +367,81 @@ def test_simulation_surface_general_set_position_and_scenario_file(tmp_path):
         assert [int(v.collision_type_veh) for v in vehs] == [int(c) for c in cv], t
     assert any(int(v.collision_type_veh) for v in vehs)             # the teleported vehicle does collide
     osim.close()
+
+
+def test_simulation_expert_control_replays_the_log_like_scenario_step(tmp_path):
+    """Round 4: `veh.expert_control = True` is acted on as Scenario::Step does (nocturne/cpp/src/scenario.cc:272-284) — the world step
+    moves every body, then an expert vehicle is put on the logged position / heading / speed of the new step through the three Vehicle
+    setters (ctrlsim_sim_step_expert).  (i) utils/sim.py:20-65 get_ground_truth_states: every vehicle expert-controlled -> the states read
+    back ARE the log, bit for bit; (ii) a mixed scene — two experts whose logs run into policy-controlled vehicles, a switch back to
+    free control mid-run — against the C oracle, which tests/test_oracle_pinned.py pins to the real FreeCar / Box2D on the same
+    protocol: positions / headings within 1e-4, collision flags identical; (iii) a synthetic Scenario has no log: ValueError."""
+    import json
+    import sim_libs
+    from ctrlsim_amd import ingest
+    from ctrlsim_amd.simulation import Simulation
+    sim_libs.build_oracle()
+    cfg = cfg_of("loop")
+    d = spec.Dims(cfg)
+    scn = scenarios.make_scenario(11, 2, n_agents=6, n_polylines=12, n_points=d.NP, extent=30.0)
+    scn.speed[0] = 0.0                                               # vehicle 0 stands (and brakes below): the expert's path crosses it
+    T = 20
+    log = scenarios.standin_log(scn, T, 0.1)
+    # vehicle 1's log runs over vehicle 0's start position
+    tr1 = np.asarray(log[1]["traj"], np.float64).copy()
+    tr1[1:, 0] = scn.x[0] - 6.0 + 0.7 * np.arange(1, T + 1)
+    tr1[1:, 1] = scn.y[0] + 0.3
+    tr1[1:, 2] = 0.05
+    tr1[1:, 3] = 7.0
+    log[1]["traj"] = tr1
+    path = tmp_path / "scene.json"
+    path.write_text(json.dumps(ingest.scenario_to_nocturne_json(scn, log, name="expert")))
+    sim = Simulation(str(path), {"start_time": 0, "allow_non_vehicles": False}, steps=T)
+    vehs = sim.getScenario().vehicles()
+    # (i) get_ground_truth_states (utils/sim.py:42-57)
+    for v in vehs:
+        v.expert_control = True
+    for t in range(T):
+        sim.step(0.1)
+        for i, v in enumerate(vehs):
+            want = np.asarray(sim.gt_data_dict[v.getID()]["traj"][t + 1, :4], np.float32)
+            got = np.array([v.getPosition().x, v.getPosition().y, v.getHeading(), v.getSpeed()], np.float32)
+            assert np.array_equal(got, want), (t, i)
+    sim.reset()
+    assert not any(v.expert_control for v in vehs)
+    # (ii) mixed control against the oracle
+    s2 = sim.scn
+    osim = sim_libs.OracleSim(s2.length, s2.width, s2.x, s2.y, s2.heading, s2.speed, s2.edge_segments)
+    rs = np.random.RandomState(4)
+    hit = 0
+    for t in range(T):
+        acts = np.stack([rs.uniform(-3, 3, 6), rs.uniform(-0.3, 0.3, 6)], 1)
+        experts = {1, 4} if not (8 <= t < 12) else {1}
+        acts[0] = (-3.0, 0.0)
+        for i, v in enumerate(vehs):
+            v.expert_control = i in experts
+            if acts[i, 0] > 0:
+                v.acceleration = acts[i, 0]
+            else:
+                v.brake(abs(acts[i, 0]))
+            v.steering = acts[i, 1]
+            osim.set_action(i, float(acts[i, 0]), float(acts[i, 1]))
+            if i in experts:
+                r = np.asarray(sim.gt_data_dict[v.getID()]["traj"][t + 1, :4], np.float32)
+                osim.set_expert(i, float(r[0]), float(r[1]), float(r[2]), float(r[3]))
+        sim.step(0.1)
+        osim.step(0.1)
+        st, cv, ce = osim.state()
+        got = np.array([[v.getPosition().x, v.getPosition().y, v.getHeading(), v.getSpeed()] for v in vehs])
+        np.testing.assert_allclose(got[:, :2], st[:, :2], atol=1e-4, rtol=0)
+        np.testing.assert_allclose(got[:, 2:4], st[:, 2:4], atol=1e-4, rtol=0)
+        assert [int(v.collision_type_veh) for v in vehs] == [int(c) for c in cv], t
+        assert [int(bool(v.collision_type_edge)) for v in vehs] == [int(c) for c in ce], t
+        hit += int(cv.sum())
+    assert hit > 0                                                   # the expert does run into a policy-controlled vehicle
+    osim.close()
+    # (iii)
+    syn = Simulation(scn, steps=4)
+    syn.getScenario().vehicles()[0].expert_control = True
+    with pytest.raises(ValueError):
+        syn.step(0.1)

@@ -473,3 +473,45 @@ def test_oracle_general_set_position_matches_real_box2d_live():
     assert hit > 0
     for sm in sims:
         sm.close()
+
+
+def test_oracle_expert_controlled_vehicles_match_real_box2d_live():
+    """Scenario::Step with expert-controlled objects (nocturne/cpp/src/scenario.cc:272-284): the physics step moves every body, then an
+    expert vehicle is put on the LOGGED position, heading and speed through Vehicle::set_position / set_heading / set_speed
+    (vehicle.cc:75-105: two b2Body::SetTransform — proxy synchronisation, new-contact search at the top of the next step — and
+    SetLinearVelocity, which wakes the body).  Two of six vehicles follow a log that drives one of them THROUGH a policy vehicle, a third
+    switches between expert and free control mid-run, one expert stands still (zero velocity: not woken).  The C oracle against the real
+    FreeCar + Box2D, bit for bit, collision flags included."""
+    scn = scenarios.make_scenario(11, 2, n_agents=6, n_polylines=12, n_points=10, extent=30.0)
+    sims = [cls(scn.length, scn.width, scn.x, scn.y, scn.heading, scn.speed, scn.edge_segments) for cls in (sim_libs.RefSim, sim_libs.OracleSim)]
+    rs = np.random.RandomState(7)
+    T = 24
+    # logs: vehicle 1 drives a straight line through vehicle 0's start position; vehicle 3 circles; vehicle 5 stands still
+    tt = np.arange(1, T + 1, dtype=np.float32)
+    log = {1: np.stack([scn.x[0] - 6.0 + 0.6 * tt, np.full(T, scn.y[0] + 0.3, np.float32), np.full(T, 0.05, np.float32), np.full(T, 6.0, np.float32)], 1),
+           3: np.stack([scn.x[3] + 4 * np.cos(0.2 * tt), scn.y[3] + 4 * np.sin(0.2 * tt), 0.2 * tt + np.float32(np.pi / 2), np.full(T, 0.8, np.float32)], 1),
+           5: np.stack([np.full(T, scn.x[5]), np.full(T, scn.y[5]), np.full(T, scn.heading[5]), np.zeros(T, np.float32)], 1)}
+    hit = 0
+    for t in range(T):
+        acts = np.stack([rs.uniform(-3, 3, 6), rs.uniform(-0.3, 0.3, 6)], 1)
+        st0 = sims[0].state()[0]
+        if 5 <= t < 12:                                         # the log of vehicle 1 runs over vehicle 0 for a while
+            log[1][t, 0], log[1][t, 1] = st0[0, 0] + np.float32(1.5 - 0.4 * (t - 5)), st0[0, 1] + np.float32(0.3)
+        for sm in sims:
+            for i in range(6):
+                sm.set_action(i, float(acts[i, 0]), float(acts[i, 1]))
+            for i, lg in log.items():
+                if i == 3 and 8 <= t < 14:
+                    continue                                    # free control for a while, then expert again
+                sm.set_expert(i, float(lg[t, 0]), float(lg[t, 1]), float(lg[t, 2]), float(lg[t, 3]))
+            sm.step(0.1)
+        (a, av, ae), (b, bv, be) = sims[0].state(), sims[1].state()
+        assert np.array_equal(a, b), t
+        assert np.array_equal(av, bv) and np.array_equal(ae, be), t
+        assert np.array_equal(sims[0].body(), sims[1].body()), t
+        if not (8 <= t < 14):
+            assert np.array_equal(a[3, :4], log[3][t].astype(np.float32)), t      # an expert vehicle reads back its log
+        hit += int(av.sum())
+    assert hit > 0
+    for sm in sims:
+        sm.close()
