@@ -126,6 +126,9 @@ def main():
     if args.tilt_sweep:                                       # the sweep values of config 5
         sweep = np.array([-20.0, -10.0, -5.0, 0.0, 5.0, 10.0, 20.0, 30.0])
         tilt = np.repeat(sweep[np.array(ids) % 8][:, None], 3, axis=1)
+    if os.environ.get("CTRLSIM_MAIN_CU_MASK"):                # A/B experiment: the main stream on a subset of the compute units
+        from ctrlsim_amd.engine import _new_stream
+        torch.cuda.set_stream(_new_stream(torch.device(device), os.environ["CTRLSIM_MAIN_CU_MASK"]))
     eng = None
     max_ctx_asked = args.max_ctx
     while eng is None:                                        # the lanes' workspaces are sized for max_ctx plain contexts: if the
@@ -312,7 +315,7 @@ def main():
         # HBM bytes per launch from the PMC counters: rocprofv3 cannot run inside this process, so they come from separate
         # --pmc passes over this same command (tools/pmc_traffic.sh), committed with their calibration under profiles/
         pmc, pmc_src = {}, None
-        for cand in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for cand in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             pmc_path = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(pmc_path):
                 pmc, pmc_src = json.load(open(pmc_path)), "profiles/" + cand

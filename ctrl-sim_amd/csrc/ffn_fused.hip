@@ -138,6 +138,32 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
         ld1(0, wf[0]);
         ld1(1, wf[1]);
         if (FFN_PF == 3) ld1(2, wf[2]);
+#ifdef FFN_2CHAIN
+        // two accumulator chains, the 48 products dealt alternately: with one wave per SIMD a single dependent chain leaves the matrix
+        // pipe waiting for its own result (r01_c: ~73 %); the two-plane split leaves the 16 registers the second chain needs
+        f32x16 hacc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hacc1[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          if (ks + FFN_PF < 16) ld1(ks + FFN_PF, wf[(ks + FFN_PF) & 3]);
+#ifndef ABL_NO_DMA
+          if (ks < FF_PIECES) dma_piece(dsrc_a, ddst_a, ks);
+#endif
+          static_assert(NPROD == 3 || NPROD == 6, "product list");
+          if (ks & 1) {
+            hacc1 = MFMA_OP(wf[ks & 3][1], xT[ks][0], hacc1);
+            hacc = MFMA_OP(wf[ks & 3][0], xT[ks][1], hacc);
+            hacc1 = MFMA_OP(wf[ks & 3][0], xT[ks][0], hacc1);
+          } else {
+            hacc = MFMA_OP(wf[ks & 3][1], xT[ks][0], hacc);
+            hacc1 = MFMA_OP(wf[ks & 3][0], xT[ks][1], hacc1);
+            hacc = MFMA_OP(wf[ks & 3][0], xT[ks][0], hacc);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hacc[r] += hacc1[r];
+#else
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
           if (ks + FFN_PF < 16) ld1(ks + FFN_PF, wf[(ks + FFN_PF) & 3]);
@@ -146,6 +172,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
 #endif
           FFN_TERMS(hacc, wf[ks & 3], xT[ks])
         }
+#endif
       }
       // ReLU + split: k-step kk of the second product uses accumulator registers 8 kk .. 8 kk + 7
       opx8 hf[2][NPL];
@@ -184,6 +211,32 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
           { f[p] = hf[i & 1][p]; asm volatile("" : "+v"(f[p])); }
 #endif
         };
+#ifdef FFN_2CHAIN
+        // step j = (k-step kk = j >> 3, output block ob = j & 7): two output blocks at a time, their products interleaved (no MFMA
+        // waits for the accumulator of the one issued just before it); the first eight steps need only the first half of H
+        auto ld2j = [&](int j, opx8 (&f)[NPL]) {
+#pragma unroll
+          for (int p = 0; p < NPL; ++p)
+            f[p] = *reinterpret_cast<const opx8*>(w2 + (((p * 2 + (j >> 3)) * 2) * 256 + (j & 7) * 32) * 8);
+        };
+        ld2j(0, wf[0]);
+        ld2j(1, wf[1]);
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+          if (j + 2 < 16) { ld2j(j + 2, wf[(j + 2) & 3]); ld2j(j + 3, wf[(j + 3) & 3]); }
+#ifndef ABL_NO_DMA
+          if (j < FF_PIECES) dma_piece(dsrc_b, ddst_b, j);
+          if (j + 1 < FF_PIECES) dma_piece(dsrc_b, ddst_b, j + 1);
+#endif
+          const int kk = j >> 3, o0 = j & 7, o1 = o0 + 1;
+          yacc[o0] = MFMA_OP(wf[j & 3][1], hf[kk][0], yacc[o0]);
+          yacc[o1] = MFMA_OP(wf[(j + 1) & 3][1], hf[kk][0], yacc[o1]);
+          yacc[o0] = MFMA_OP(wf[j & 3][0], hf[kk][1], yacc[o0]);
+          yacc[o1] = MFMA_OP(wf[(j + 1) & 3][0], hf[kk][1], yacc[o1]);
+          yacc[o0] = MFMA_OP(wf[j & 3][0], hf[kk][0], yacc[o0]);
+          yacc[o1] = MFMA_OP(wf[(j + 1) & 3][0], hf[kk][0], yacc[o1]);
+        }
+#else
         ld2(0, wf[0]);
         ld2(1, wf[1]);
         if (FFN_PF == 3) ld2(2, wf[2]);
@@ -195,6 +248,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
 #endif
           FFN_TERMS(yacc[i >> 1], wf[i & 3], hf[i & 1])
         }
+#endif
       }
       phase_barrier(true);
       slot = slot == FF_RING - 1 ? 0 : slot + 1;

@@ -28,6 +28,7 @@ Per step t:
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -136,6 +137,21 @@ def ctx_from_reference_layout(d: Dims, data: dict, Tq: int, device):
     return cb
 
 
+def _new_stream(dev, cu_mask=None):
+    """A stream of its own; cu_mask (A/B experiments: "w0,w1,..." 32-bit hex words, bit i = compute unit i enabled) creates it with
+    hipExtStreamCreateWithCUMask so that its kernels run on those compute units only (CU partition experiment)."""
+    if not cu_mask:
+        return torch.cuda.Stream(device=dev)
+    words = [int(w, 16) for w in cu_mask.split(",")]
+    arr = (C.c_uint32 * len(words))(*words)
+    hip = C.CDLL("libamdhip64.so")
+    st = C.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(C.byref(st), C.c_uint32(len(words)), arr)
+    if rc != 0:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed: {rc}")
+    return torch.cuda.ExternalStream(st.value, device=dev)
+
+
 class _Lane:
     """A scenario set in flight: model workspace (K/V cache included), context tensors, logits, chunk index lists, a side
     stream for its simulator step / grouping / count read-back, and the two events that order it against the main stream."""
@@ -155,7 +171,7 @@ class _Lane:
         self.flag = torch.zeros(1, dtype=torch.int32, device=dev)
         self.host_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.host_hist = None                                    # pinned [S, classes] int32, sized by load_scenarios
-        self.side = torch.cuda.Stream(device=dev) if own_stream else None
+        self.side = _new_stream(dev, os.environ.get("CTRLSIM_SIDE_CU_MASK")) if own_stream else None
         self.ev_fwd, self.ev_ready, self.ev_p2, self.ev_p1, self.ev_sim = (torch.cuda.Event() for _ in range(5))
         self.sim_in_flight = False                               # a simulator step of this lane may still run on its side stream
         self.pending = (0, 0, False)                             # scenario range (+ compare flag) of the read-back in flight
