@@ -172,7 +172,7 @@ class _Lane:
         self.host_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.host_hist = None                                    # pinned [S, classes] int32, sized by load_scenarios
         self.side = _new_stream(dev, os.environ.get("CTRLSIM_SIDE_CU_MASK")) if own_stream else None
-        self.ev_fwd, self.ev_ready, self.ev_p2, self.ev_p1, self.ev_sim = (torch.cuda.Event() for _ in range(5))
+        self.ev_fwd, self.ev_ready, self.ev_p2, self.ev_p1, self.ev_sim, self.ev_ctx = (torch.cuda.Event() for _ in range(6))
         self.sim_in_flight = False                               # a simulator step of this lane may still run on its side stream
         self.pending = (0, 0, False)                             # scenario range (+ compare flag) of the read-back in flight
 
@@ -222,6 +222,8 @@ class RolloutEngine:
         # tests/test_gpu_hazard.py).  forward_waits_for_sim is the round-2 stream guard (a forward pass waits for every pending
         # simulator step): not needed any more, and it serialises exactly the overlap the switches create; kept as an A/B switch.
         self.forward_waits_for_sim = False
+        # context build on the lane's side stream (round 4 experiment: 129.44 -> 129.73 k, inside the noise — off by default)
+        self.ctx_on_side = os.environ.get("CTRLSIM_CTX_ON_SIDE", "0") == "1"
         self._max_sliding, self._sliding, self._holds_slot = 0, 0, []
         self.full_pass_contexts = 0             # np.int64 [classes] once the first full pass ran
         self.record_phases = False              # bench.py: main-stream events at the end of every lane's K/V-cached phase
@@ -628,8 +630,19 @@ class RolloutEngine:
             first = False
             plan, n, Bs, As, cs = self._class_plan(L, counts, Tq, Tq)
             self.full_pass_contexts += np.asarray(counts, np.int64)      # contexts per size class of the full-recompute passes (bench.py)
-            self._ctx_index(L, s0, s1, st)
-            self._build_contexts(L, plan, t, Tq, 0, st)
+            if on_side and self.ctx_on_side:                     # (needs the second pass on the side stream too: stream order then keeps
+                                                                 #  the next batch's context build behind this batch's readers of L.ctx)
+                # the context index lists and tensors (two latency-bound kernels of 50-150 workgroups with long float64 chains: 2.6 % of
+                # the step when they hold the main stream) are built on the lane's side stream, underneath the other lane's matrix
+                # kernels; the forward pass waits for them by an event
+                cst = L.side.cuda_stream
+                self._ctx_index(L, s0, s1, cst)
+                self._build_contexts(L, plan, t, Tq, 0, cst)
+                L.ev_ctx.record(L.side)
+                self._main.wait_event(L.ev_ctx)
+            else:
+                self._ctx_index(L, s0, s1, st)
+                self._build_contexts(L, plan, t, Tq, 0, st)
             self._forward_waits(self._main)
             if n and d.VARIANT:                              # IL / Trajeglish: no RTG tokens, one forward (predict_rtgs False)
                 _lib.check(lib.ctrlsim_dt_forward_actions(self.model.handle, plan[0][0], Tq, cs, p(L.ws), p(L.act_logits), st),

@@ -4,8 +4,8 @@
 #   (FETCH_SIZE / WRITE_SIZE, separate, no tracing flags) over a smaller run of the same workload.
 # usage (from the repo root, on the GPU box):  bash tools/profile_round.sh r02
 R=${1:-r02}
-CMD="python bench.py --scenarios 204 --steps 2 --warmup 1 --spot-check 0"
-PMC="python bench.py --scenarios 102 --steps 1 --warmup 0 --no-cpu-baseline --spot-check 0"
+CMD="python bench.py --scenarios 204 --steps 2 --warmup 1 --spot-check 0 --no-class-profile"
+PMC="python bench.py --scenarios 102 --steps 1 --warmup 0 --no-cpu-baseline --spot-check 0 --no-class-profile"
 mkdir -p gpurun_out/prof_$R gpurun_out/pmc_$R
 $CMD > gpurun_out/bench_$R.json 2> gpurun_out/bench_$R.err
 echo "$CMD --no-cpu-baseline" > gpurun_out/prof_$R/command.txt
