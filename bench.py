@@ -356,7 +356,8 @@ def main():
         KNAMES = ("other", "Linear + K/V-image epilogue (QKV, memory K/V): gemm_ws256_kernel<..,KV> (weight-stationary; tiled gemm_nt_bf16x6_kernel<2,2,2,..,KVIMG> when K != 256)",
                   "Linear + residual + LayerNorm epilogue (attention out-projections, MLP layers): gemm_ws256_kernel<..,LN> (weight-stationary; tiled gemm_nt_bf16x6_kernel<1,4,2,..,LN> when K != 256)",
                   "plain Linear (cross-attention query projection, heads, map / embedding layers): gemm_ws256_kernel (256 -> 256) / gemm_nt_bf16x6_kernel<2,2,2>",
-                  "fused feed-forward block: ffn_fused_bf16x6_kernel", "causal self-attention: attention_bf16x6_kernel<1,true>",
+                  "fused feed-forward block: ffn_fused_bf16x6_kernel",
+                  "causal self-attention: attention_bf16x6_kernel<1,true,true> (masks from the per-class table; <1,true,false> for the few-row launches)",
                   "key-padded scene / cross attention: attention_bf16x6_kernel<0,true>")
 
         def kernel_rows(kms=kms, kcnt=kcnt, kfl=kfl, kby=kby):
