@@ -29,7 +29,15 @@ namespace {
 
 constexpr int FF_BLK = NPL * 16 * 2 * 32 * 8;      // 16-bit elements of one weight block (W1: [NPL][16][2][32][8]; W2: [NPL][2][2][256][8])
 constexpr int FF_PIECES = FF_BLK / (256 * 8);      // 16-byte-per-thread LDS-DMA pieces of a block (8 / 12)
+#if defined(FFN_RING4) && CTRLSIM_F16X3
+// four ring slots (128 KB with two planes): both blocks of the NEXT hidden block are requested while the current one is computed, and
+// the workgroup meets once per hidden block (after the second product) instead of once per product
+constexpr int FF_RING = 4;
+#define FFN_PAIR_BARRIER 1
+#else
 constexpr int FF_RING = 3;
+#define FFN_PAIR_BARRIER 0
+#endif
 #ifndef FFN_PF
 #define FFN_PF (NPL == 2 ? 3 : 2)                   // LDS fragment prefetch distance in k-steps (four register buffers); 3 needs the
 #endif                                             // registers the two-plane scheme frees (+1.5 %), with three planes it spilled
@@ -112,7 +120,11 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
       // (into a slot nobody reads any more; drained before the epilogue): the phases stay branch-free.
       const int hb_next = hb + 1 < nhb ? hb + 1 : nhb - 1;
       const op_t* dsrc_a = W1p + (size_t)hb_next * FF_BLK + tid * 8;
+#if FFN_PAIR_BARRIER
+      op_t* ddst_a = ring + ((slot + 2) & 3) * FF_BLK + wave * 64 * 8;        // block 2 hb + 2 -> the slot block 2 hb - 2 left a pair ago
+#else
       op_t* ddst_a = ring + (slot == 0 ? 2 : slot - 1) * FF_BLK + wave * 64 * 8;
+#endif
       f32x16 hacc;
       {
         const float* bp = b1s + hb * 32 + 4 * half;                    // register r <-> hidden (r & 3) + 8 (r >> 2) + 4 half
@@ -193,12 +205,20 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
           }
 #endif
       }
+#if FFN_PAIR_BARRIER
+      // (no meeting here: block 2 hb + 1 landed before this pair began and nothing overwrites a slot inside a pair)
+#else
       phase_barrier(true);                               // block 2 hb + 1 has landed; everyone is done with this slot
+#endif
       slot = slot == FF_RING - 1 ? 0 : slot + 1;
 
       // ---------------- phase 2 hb + 1: Y^T += W2_blk . H^T, block 2 hb + 1 in slot (2 hb + 1) % 3
       const op_t* dsrc_b = W2p + (size_t)hb_next * FF_BLK + tid * 8;
+#if FFN_PAIR_BARRIER
+      op_t* ddst_b = ring + ((slot + 2) & 3) * FF_BLK + wave * 64 * 8;        // block 2 hb + 3 -> the slot of block 2 hb - 1
+#else
       op_t* ddst_b = ring + (slot == 0 ? 2 : slot - 1) * FF_BLK + wave * 64 * 8;
+#endif
       {
         const op_t* w2 = ring + slot * FF_BLK + (half * 256 + l31) * 8;   // [p][kk][half][o][8]
         opx8 wf[4][NPL];
@@ -250,7 +270,11 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
         }
 #endif
       }
+#if FFN_PAIR_BARRIER
+      phase_barrier(false);                              // vmcnt(0): the next hidden block's two weight blocks have landed for every wave
+#else
       phase_barrier(true);
+#endif
       slot = slot == FF_RING - 1 ? 0 : slot + 1;
     }
     __syncthreads();                                                  // drain everything before the ring is reused as staging
