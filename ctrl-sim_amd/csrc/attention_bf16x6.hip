@@ -278,9 +278,6 @@ __global__ __launch_bounds__(256, ATT_OCC(TBL)) void attention_bf16x6_kernel(
   const int qgrp = __builtin_amdgcn_readfirstlane(qblk * 4 + wave), nsub_tbl = 2 * (int)kv_batch_stride;
   const bool wave_rep_q = TBL && rep_keys > 0 && __builtin_amdgcn_readfirstlane(qb + wave * 32 + 31) >= rep_pos0;
 
-#ifdef ATT_TBL_DEBUG
-  float dbg_bad = 0.f, dbg_first = -1.f;
-#endif
   f32x16 oa;                                       // O^T accumulator
 #pragma unroll
   for (int r = 0; r < 16; ++r) oa[r] = 0.f;
@@ -482,24 +479,6 @@ __global__ __launch_bounds__(256, ATT_OCC(TBL)) void attention_bf16x6_kernel(
         // recognizer and reads the registers before the matrix pipe has written them — the first version of this path did.)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_inverse_ballot_w64(mk[r]) ? s0[r] : NEG_INF;
-#ifdef ATT_TBL_DEBUG   // scratch builds: compare the table's bits with the in-kernel mask words (regular tiles), per lane
-        if (!rep_tile) {
-          auto ones = [](int n) -> unsigned { return n >= 32 ? 0xFFFFFFFFu : (n <= 0 ? 0u : ((1u << n) - 1u)); };
-          const int same0 = tq * A3 - ks0;
-          const unsigned before = ones(same0);
-          const unsigned same = ones(min(same0 + A3, Lk - ks0)) & ~before;
-          int off3 = (ks_t0 - ks0) % 3;
-          off3 = off3 < 0 ? off3 + 3 : off3;
-          const unsigned every3 = (unsigned)(0x249249249249ull << off3);
-          const unsigned own = rep_q ? 0u : (ones(pos - ks0 + 1) & ~ones(pos - kq - ks0));
-          const unsigned vis = (before | ((every3 | own) & same)) >> (4 * half);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const bool want = (vis >> ((r & 3) + 8 * (r >> 2))) & 1u, got = (mk[r] >> lane) & 1ull;
-            if (want != got) { dbg_bad += 1.f; if (dbg_first < 0.f) dbg_first = (float)(it * 2 + sub); }
-          }
-        }
-#endif
         if (rep_tile && wave_rep_q) {
           // the representative's own tokens of its step count once: take the multiplicity back (three query groups per context only)
 #pragma unroll
@@ -694,9 +673,6 @@ __global__ __launch_bounds__(256, ATT_OCC(TBL)) void attention_bf16x6_kernel(
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
     l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
   }
-#ifdef ATT_TBL_DEBUG
-  if (TBL) { oa[0] = dbg_bad; oa[1] = dbg_first; oa[2] = (float)qgrp; oa[3] = (float)nsub_tbl; l_run = 1.f; }
-#endif
   const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
   float* ot = reinterpret_cast<float*>(arena) + wave * (32 * 33);
 #pragma unroll

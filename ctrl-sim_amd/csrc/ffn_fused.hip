@@ -12,8 +12,9 @@
 //     with b1), ReLU + split in registers, and — exactly like P in the attention kernel — the accumulator-register
 //     order IS the k-slot order of the second product  Y^T += W2_blk . H^T  (96 MFMA): H never moves between lanes.
 //     W2's k-slots are permuted accordingly at pack time (ctrlsim_amd/pack.py:ffn_planes).
-//   * the weight blocks (48 KB each: W1_blk, W2_blk alternating) stream through a 3-slot LDS ring by LDS-DMA, each
-//     issued two phases ahead; the 4 waves of a workgroup (128 rows) share them.  One barrier per phase (96 MFMA).
+//   * the weight blocks (48 KB each: W1_blk, W2_blk alternating) stream through an LDS ring by LDS-DMA (four 32 KB slots
+//     and one barrier per hidden block with two fp16 planes, round 4: +1.1 % on the kernel; three 48 KB slots with three bf16 planes), each
+//     issued two phases ahead; the 4 waves of a workgroup (128 rows) share them.  One barrier per phase (96 MFMA); per pair of phases with four slots.
 //   * epilogue: Y^T through LDS (the ring is free by then) to row-major, + b2 + x, LayerNorm, 16-byte stores.
 //
 // HBM traffic: x read twice (operand + residual, the second an L2 hit) and y written once = 2-3 KB per row, against
@@ -29,7 +30,7 @@ namespace {
 
 constexpr int FF_BLK = NPL * 16 * 2 * 32 * 8;      // 16-bit elements of one weight block (W1: [NPL][16][2][32][8]; W2: [NPL][2][2][256][8])
 constexpr int FF_PIECES = FF_BLK / (256 * 8);      // 16-byte-per-thread LDS-DMA pieces of a block (8 / 12)
-#if defined(FFN_RING4) && CTRLSIM_F16X3
+#if CTRLSIM_F16X3 && !defined(FFN_RING3)
 // four ring slots (128 KB with two planes): both blocks of the NEXT hidden block are requested while the current one is computed, and
 // the workgroup meets once per hidden block (after the second product) instead of once per product
 constexpr int FF_RING = 4;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
   const int n_rb = (M + 127) / 128;
   for (int i = tid; i < nhb * 32; i += 256) b1s[i] = b1[i];          // global loads inside a phase would queue behind its DMA
 
-  // block i of the weight stream: W1 of hidden block i/2 (even i) or W2 of it (odd i); lives in ring slot i % 3
+  // block i of the weight stream: W1 of hidden block i/2 (even i) or W2 of it (odd i); lives in ring slot i % FF_RING
   auto dma_block = [&](int i, int to_slot) {
     const op_t* src = ((i & 1) ? W2p : W1p) + (size_t)(i >> 1) * FF_BLK + tid * 8;
     op_t* dst = ring + to_slot * FF_BLK + wave * 64 * 8;            // wave-uniform LDS base (+ 16 B per lane)
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
 
     int slot = 0;                                                     // ring slot of the block the current phase reads
     for (int hb = 0; hb < nhb; ++hb) {
-      // ---------------- phase 2 hb: H^T = W1_blk . X^T (+ b1), block 2 hb in slot (2 hb) % 3
+      // ---------------- phase 2 hb: H^T = W1_blk . X^T (+ b1), block 2 hb in slot (2 hb) % FF_RING
       // the block two ahead goes to the slot read last phase.  Past the end of the stream the last block is fetched again
       // (into a slot nobody reads any more; drained before the epilogue): the phases stay branch-free.
       const int hb_next = hb + 1 < nhb ? hb + 1 : nhb - 1;
@@ -150,32 +151,6 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
         ld1(0, wf[0]);
         ld1(1, wf[1]);
         if (FFN_PF == 3) ld1(2, wf[2]);
-#ifdef FFN_2CHAIN
-        // two accumulator chains, the 48 products dealt alternately: with one wave per SIMD a single dependent chain leaves the matrix
-        // pipe waiting for its own result (r01_c: ~73 %); the two-plane split leaves the 16 registers the second chain needs
-        f32x16 hacc1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hacc1[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          if (ks + FFN_PF < 16) ld1(ks + FFN_PF, wf[(ks + FFN_PF) & 3]);
-#ifndef ABL_NO_DMA
-          if (ks < FF_PIECES) dma_piece(dsrc_a, ddst_a, ks);
-#endif
-          static_assert(NPROD == 3 || NPROD == 6, "product list");
-          if (ks & 1) {
-            hacc1 = MFMA_OP(wf[ks & 3][1], xT[ks][0], hacc1);
-            hacc = MFMA_OP(wf[ks & 3][0], xT[ks][1], hacc);
-            hacc1 = MFMA_OP(wf[ks & 3][0], xT[ks][0], hacc1);
-          } else {
-            hacc = MFMA_OP(wf[ks & 3][1], xT[ks][0], hacc);
-            hacc1 = MFMA_OP(wf[ks & 3][0], xT[ks][1], hacc1);
-            hacc = MFMA_OP(wf[ks & 3][0], xT[ks][0], hacc);
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hacc[r] += hacc1[r];
-#else
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
           if (ks + FFN_PF < 16) ld1(ks + FFN_PF, wf[(ks + FFN_PF) & 3]);
@@ -184,7 +159,6 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
 #endif
           FFN_TERMS(hacc, wf[ks & 3], xT[ks])
         }
-#endif
       }
       // ReLU + split: k-step kk of the second product uses accumulator registers 8 kk .. 8 kk + 7
       opx8 hf[2][NPL];
@@ -212,7 +186,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
 #endif
       slot = slot == FF_RING - 1 ? 0 : slot + 1;
 
-      // ---------------- phase 2 hb + 1: Y^T += W2_blk . H^T, block 2 hb + 1 in slot (2 hb + 1) % 3
+      // ---------------- phase 2 hb + 1: Y^T += W2_blk . H^T, block 2 hb + 1 in slot (2 hb + 1) % FF_RING
       const op_t* dsrc_b = W2p + (size_t)hb_next * FF_BLK + tid * 8;
 #if FFN_PAIR_BARRIER
       op_t* ddst_b = ring + ((slot + 2) & 3) * FF_BLK + wave * 64 * 8;        // block 2 hb + 3 -> the slot of block 2 hb - 1
@@ -231,32 +205,6 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
           { f[p] = hf[i & 1][p]; asm volatile("" : "+v"(f[p])); }
 #endif
         };
-#ifdef FFN_2CHAIN
-        // step j = (k-step kk = j >> 3, output block ob = j & 7): two output blocks at a time, their products interleaved (no MFMA
-        // waits for the accumulator of the one issued just before it); the first eight steps need only the first half of H
-        auto ld2j = [&](int j, opx8 (&f)[NPL]) {
-#pragma unroll
-          for (int p = 0; p < NPL; ++p)
-            f[p] = *reinterpret_cast<const opx8*>(w2 + (((p * 2 + (j >> 3)) * 2) * 256 + (j & 7) * 32) * 8);
-        };
-        ld2j(0, wf[0]);
-        ld2j(1, wf[1]);
-#pragma unroll
-        for (int j = 0; j < 16; j += 2) {
-          if (j + 2 < 16) { ld2j(j + 2, wf[(j + 2) & 3]); ld2j(j + 3, wf[(j + 3) & 3]); }
-#ifndef ABL_NO_DMA
-          if (j < FF_PIECES) dma_piece(dsrc_b, ddst_b, j);
-          if (j + 1 < FF_PIECES) dma_piece(dsrc_b, ddst_b, j + 1);
-#endif
-          const int kk = j >> 3, o0 = j & 7, o1 = o0 + 1;
-          yacc[o0] = MFMA_OP(wf[j & 3][1], hf[kk][0], yacc[o0]);
-          yacc[o1] = MFMA_OP(wf[(j + 1) & 3][1], hf[kk][0], yacc[o1]);
-          yacc[o0] = MFMA_OP(wf[j & 3][0], hf[kk][1], yacc[o0]);
-          yacc[o1] = MFMA_OP(wf[(j + 1) & 3][0], hf[kk][1], yacc[o1]);
-          yacc[o0] = MFMA_OP(wf[j & 3][0], hf[kk][0], yacc[o0]);
-          yacc[o1] = MFMA_OP(wf[(j + 1) & 3][0], hf[kk][0], yacc[o1]);
-        }
-#else
         ld2(0, wf[0]);
         ld2(1, wf[1]);
         if (FFN_PF == 3) ld2(2, wf[2]);
@@ -268,7 +216,6 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
 #endif
           FFN_TERMS(yacc[i >> 1], wf[i & 3], hf[i & 1])
         }
-#endif
       }
 #if FFN_PAIR_BARRIER
       phase_barrier(false);                              // vmcnt(0): the next hidden block's two weight blocks have landed for every wave
