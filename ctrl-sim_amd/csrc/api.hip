@@ -9,6 +9,8 @@ int launch_gemm_nt_bf16x6(const float*, int, const void*, int, int, const float*
                           int, int, const float*, const float*, hipStream_t);
 int launch_gemm_nt_bf16x6_kv(const float*, int, const void*, int, int, const float*, const float*, int, float*, int, int, int,
                              int, int, const float*, const float*, void*, int, int, int, int, int, hipStream_t);
+int launch_inproj_rs(const float*, int, const void*, const float*, float*, int, int, int, void*, int, int, const KvClassHost*,
+                     hipStream_t);
 int launch_layernorm256(const float*, int, const float*, int, const float*, const float*, float*, int, int, int,
                         hipStream_t);
 int launch_attention(int, const float*, int, long, const float*, const float*, int, long, float*, int, long, const int*,
@@ -74,7 +76,7 @@ void prof_after(int cls, double flops, hipStream_t st, double bytes, int kind) {
   g_recs.push_back(ProfRec{g_pending[cls], b, cls, flops, bytes, st, 2 * kind + (g_prof_few ? 1 : 0)});
 }
 
-static int g_options[OPT_COUNT] = {1, 1, 0, 1, 1, 0, 7, 1, 1};
+static int g_options[OPT_COUNT] = {1, 1, 0, 1, 1, 0, 15, 1, 1};
 // Guard counter (common.h): the counter the CALLER bound with ctrlsim_bind — an engine's own 4 bytes of device memory — or,
 // for callers that never bind one, a library-owned word allocated on first use on the then-current device.
 static int* g_guard = nullptr;
@@ -207,6 +209,12 @@ int ctrlsim_gemm_nt_kv(const float* A, int lda, const void* W3, int n_total, int
                        int M, int N, int K, void* kv_img, int kv_L, int kv_nkt, int kv_col0, hipStream_t st) {
   return launch_gemm_nt_bf16x6_kv(A, lda, W3, n_total, n0, bias, nullptr, 0, C, ldc, M, N, K, 0, nullptr, nullptr, kv_img, kv_L,
                                   kv_nkt, kv_col0, 0, 0, st);
+}
+int ctrlsim_gemm_kv_blocks(const float* A, int lda, const void* Wblk, const float* bias, float* C, int ldc, int M, int N,
+                           void* kv_img, int kv_L, int kv_nkt, int kv_col0, hipStream_t st) {
+  if (kv_L <= 0 || M % kv_L) return CTRLSIM_EINVAL;
+  const KvClassHost c{M / kv_L, kv_L, kv_L, 0, kv_nkt, 0};
+  return launch_inproj_rs(A, lda, Wblk, bias, C, ldc, M, N, kv_img, kv_col0, 1, &c, st);
 }
 int ctrlsim_ffn_fused(const float* X, int ldx, const void* W1p, const float* b1, const void* W2p, const float* b2,
                       const float* gamma, const float* beta, float* Y, int ldy, int M, int F, hipStream_t st) {

@@ -13,6 +13,8 @@
                                int, int, const float*, const float*, void*, int, int, int, int, int, hipStream_t);                \
   int launch_gemm_nt_bf16x6_kvc(const float*, int, const void*, int, int, const float*, const float*, int, float*, int, int, int, \
                                 int, int, const float*, const float*, void*, int, int, const KvClassHost*, hipStream_t);          \
+  int launch_inproj_rs(const float*, int, const void*, const float*, float*, int, int, int, void*, int, int, const KvClassHost*,  \
+                       hipStream_t);                                                                                              \
   int launch_ffn_fused_bf16x6(const float*, int, const void*, const float*, const void*, const float*, const float*, const float*, \
                               float*, int, int, int, hipStream_t);                                                               \
   int launch_attention_bf16x6(int, const float*, int, long, const float*, const float*, int, long, float*, int, long, const int*, \
@@ -49,6 +51,10 @@ int launch_gemm_nt_bf16x6_kvc(const float* A, int lda, const void* W3, int n_tot
                               float* C, int ldc, int M, int N, int K, int relu, const float* g, const float* b, void* img, int col0,
                               int n, const KvClassHost* cls, hipStream_t st) {
   return PICK(launch_gemm_nt_bf16x6_kvc(A, lda, W3, n_total, n0, bias, R, ldr, C, ldc, M, N, K, relu, g, b, img, col0, n, cls, st));
+}
+int launch_inproj_rs(const float* A, int lda, const void* Wblk, const float* bias, float* C, int ldc, int M, int N, void* img, int col0,
+                     int n, const KvClassHost* cls, hipStream_t st) {
+  return PICK(launch_inproj_rs(A, lda, Wblk, bias, C, ldc, M, N, img, col0, n, cls, st));
 }
 int launch_ffn_fused_bf16x6(const float* X, int ldx, const void* W1p, const float* b1, const void* W2p, const float* b2,
                             const float* g, const float* b, float* Y, int ldy, int M, int F, hipStream_t st) {

@@ -43,6 +43,7 @@ int launch_attn_mask_tables(int, const AttnClassHost*, hipStream_t);
 size_t attn_mask_table_bytes(int, int);
 int launch_attention_classes(int, const float*, int, const void*, float*, int, const unsigned char*, int, const AttnClassHost*,
                              hipStream_t);
+int launch_inproj_rs(const float*, int, const void*, const float*, float*, int, int, int, void*, int, int, const KvClassHost*, hipStream_t);
 int launch_gemm_nt_bf16x6_kvc(const float*, int, const void*, int, int, const float*, const float*, int, float*, int, int, int, int,
                               int, const float*, const float*, void*, int, int, const KvClassHost*, hipStream_t);
 int launch_in_mlp(const float*, int, int, const float*, const float*, const float*, const float*, float*, int, int,
@@ -71,6 +72,7 @@ struct Lin {
   const float* w; const float* b;
   const void* w3s[2] = {nullptr, nullptr};      // operand planes per split scheme (OPT_SPLIT 0 / 1)
   int ntot = 0; int n0 = 0;
+  const void* wblk = nullptr;                   // 32-column operand blocks from column n0 on (two-fp16-plane scheme; pack.py:row_blocks)
   const void* w3() const { return w3s[ctrlsim_option(OPT_SPLIT) ? 1 : 0]; }
 };
 struct LNp { const float* g; const float* b; };
@@ -129,6 +131,8 @@ extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_w
     Lin L{w, b};
     L.w3s[0] = PX(planes_of + "#pl0"); L.w3s[1] = PX(planes_of + "#pl1");
     L.ntot = ntot; L.n0 = n0;
+    if (const void* blk = PX(planes_of + "#blk#pl1"))       // [cb][2 planes][16][2][32][8] 16-bit words: 32 KB per 32 columns
+      L.wblk = static_cast<const char*>(blk) + (size_t)(n0 / 32) * 32768;
     return L;
   };
   auto ffnp = [&](const std::string& p) {
@@ -477,6 +481,8 @@ int gemm_kv(const ctrlsim_dims& d, const Batch& bt, const Ws& w, const Lin& L, c
       if (kc[k].Lreg < kc[k].L) tails[nt++] = KvTailHost{kc[k].B, kc[k].rep_k0, kc[k].L - kc[k].Lreg, kc[k].nkt, kc[k].tile0};
     }
     CHK(launch_kv_zero_tails(nt, tails, img, st));
+    if (L.wblk && ctrlsim_option(OPT_SPLIT) && (ctrlsim_option(OPT_GEMM_WS) & 8) && !(L.n0 & 31))
+      return launch_inproj_rs(x, DM, L.wblk, L.b, y, ldy, (int)rows, n, img, kcol0, bt.n, kc, st);
     return launch_gemm_nt_bf16x6_kvc(x, DM, L.w3(), L.ntot ? L.ntot : n, L.n0, L.b, nullptr, 0, y, ldy, (int)rows, n, DM, 0, nullptr,
                                      nullptr, img, kcol0, bt.n, kc, st);
   }

@@ -843,6 +843,250 @@ __global__ __launch_bounds__(512, 2) void gemm_ws256_kernel(const float* A, int 
 }
 #endif
 
+#if CTRLSIM_F16X3
+// ---- Row-stationary Linear(256 -> 32 nb) whose key / value columns leave as K / V^T tile images (OPT_GEMM_WS bit 3; round 4).
+// The weight-stationary kernel above reads every activation row once per 256-column group and keeps the one resident workgroup of a
+// CU in matrix / vector / memory lock-step (0.26 of the split roof on the in_proj).  Here the roles are those of the fused feed-forward
+// kernel's first product: a wave keeps 32 ROWS as split operand fragments in registers (128 VGPRs) for the life of a 256-row job, the
+// weights stream through a four-slot LDS ring by LDS-DMA as 32 KB blocks of 32 output columns (pack.py:row_blocks, the layout of the
+// FFN's W1 blocks; 3 KB of L2 reads per row, shared by the 8 waves), and every block is 48 MFMAs per wave into a fresh accumulator:
+//   * activation rows are read from HBM ONCE (1 KB per row instead of 1 KB per column group);
+//   * 8 waves per CU = two per SIMD with independent accumulator chains: one wave's epilogue (split + stores) runs beside the other's
+//     MFMAs; one barrier per block ("the next block has landed for every wave"), taken BEFORE the block's stores;
+//   * a 32-column block is exactly one head: query blocks leave as fp32 rows (D^T = W_blk . X^T: a lane owns one row, 4 x 16 bytes),
+//     key blocks in the same orientation as 8-byte plane entries ([dim group][key][8]: the two halves of a key are adjacent), value
+//     blocks with the operands SWAPPED (D = X . W_blk^T: a lane owns one dim and 4 x 4 consecutive keys = the V^T image's entries).
+// Counted waits: per block and wave the kernel issues RS_PIECES DMA requests and RS_E(kind) stores, unconditionally except in a job
+// that reaches past row M (the last job of its workgroup), which drains instead of counting.
+constexpr int RS_BLK = NPL * 16 * 2 * 32 * 8;        // 16-bit elements of one weight block (32 columns x 256 k x NPL planes = 32 KB)
+constexpr int RS_RING = 4;
+constexpr int RS_PIECES = RS_BLK / (512 * 8);        // 16-byte-per-thread DMA pieces of a block (4)
+constexpr int RS_MAXB = 3 * DM / 32;                 // column blocks of the largest launch (in_proj: 24)
+#define RS_LDS_BYTES (RS_RING * RS_BLK * 2 + RS_MAXB * 32 * 4)
+__global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restrict__ A, int lda, const op_t* __restrict__ Wb,
+                                                           const float* __restrict__ bias, float* __restrict__ C, int ldc, int M,
+                                                           int nb, const KvImg kv) {
+  static_assert(NPL == 2 && RS_PIECES == 4, "the counted vmcnt waits below assume 4 DMA pieces per block and 4 / 8 / 8 stores per epilogue");
+  extern __shared__ __attribute__((aligned(16))) op_t rs_ring[];
+  float* const bs = reinterpret_cast<float*>(rs_ring + RS_RING * RS_BLK);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int n_rb = (M + 255) / 256;
+  if ((int)blockIdx.x >= n_rb) return;
+  for (int i = tid; i < nb * 32; i += 512) bs[i] = bias ? bias[i] : 0.f;
+  const int njobs = (n_rb - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  auto dma_piece = [&](int blk, int slot, int j) {
+    const op_t* src = Wb + (size_t)blk * RS_BLK + (j * 512 + tid) * 8;
+    op_t* dst = rs_ring + slot * RS_BLK + (j * 512 + wave * 64) * 8;       // wave-uniform LDS base (+ 16 B per lane)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+#pragma unroll
+  for (int j = 0; j < RS_PIECES; ++j) dma_piece(0, 0, j);
+#pragma unroll
+  for (int j = 0; j < RS_PIECES; ++j) dma_piece(1 % nb, 1, j);
+  const int kb0 = kv.k_col0 >> 5;                     // first key block; values from kb0 + 8
+  constexpr int KIMG = 2 * NPL * 64 * HD, KPL = 64 * HD;
+  int slot = 0, nxt = 2 % nb;                         // ring slot of the current block; column block two phases ahead
+  int e_prev = 0;                                     // stores this wave issued in the previous phase
+  for (int job = 0; job < njobs; ++job) {
+    const int rb = (int)blockIdx.x + job * (int)gridDim.x;
+    const int cbm = __builtin_amdgcn_readfirstlane(rb * 256 + wave * 32);
+    const int row = cbm + l31;
+    const bool partial = rb * 256 + 256 > M;          // workgroup-uniform: some lane of this job issues no stores
+    // where this lane's row (key blocks) and its four row quads (value blocks) go in the images of head 0: resolved ONCE per job, before
+    // the operand fragments are live (the class table stays out of the block loop); tile index < 0 = beyond M, nothing to store
+    int k_tile = -1, k_meta = 0;                      // tile index; key in the tile (value blocks: key quad) | tiles per head << 6
+    int v_tile[4], v_meta[4];
+    {
+      const KvTile kt_ = kv_tile(kv, cbm, 32);
+      int b, pos, nkt;
+      long tile0;
+      if (row < M) {
+        kv_place(kv, kt_, cbm, row, b, pos, nkt, tile0);
+        k_tile = (int)tile0 + b * NHEAD * nkt + (pos >> 6); k_meta = (pos & 63) | (nkt << 6);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int grow0 = cbm + 8 * g + 4 * half;                          // rows grow0 .. grow0 + 3: L % 4 == Lreg % 4 == 0, a quad never straddles
+        v_tile[g] = -1; v_meta[g] = 0;
+        if (grow0 < M) {
+          kv_place(kv, kt_, cbm, grow0, b, pos, nkt, tile0);
+          v_tile[g] = (int)tile0 + b * NHEAD * nkt + (pos >> 6); v_meta[g] = ((pos & 63) >> 2) | (nkt << 6);
+        }
+      }
+    }
+    // the wave's 32 rows as split operand fragments: k-step ks covers k = 16 ks + 8 half .. + 7.  Loaded in four groups of four k-steps,
+    // one group ahead (the raw rows of all 16 k-steps beside the finished fragments would not fit 256 registers)
+    opx8 xT[16][NPL];
+    {
+      const float* xp = A + (size_t)(row < M ? row : M - 1) * lda + half * 8;
+      f32x4 raw[2][8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        raw[0][2 * i] = *reinterpret_cast<const f32x4*>(xp + i * 16);
+        raw[0][2 * i + 1] = *reinterpret_cast<const f32x4*>(xp + i * 16 + 4);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (g + 1 < 4) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            raw[(g + 1) & 1][2 * i] = *reinterpret_cast<const f32x4*>(xp + (4 * (g + 1) + i) * 16);
+            raw[(g + 1) & 1][2 * i + 1] = *reinterpret_cast<const f32x4*>(xp + (4 * (g + 1) + i) * 16 + 4);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x4 x0 = raw[g & 1][2 * i], x1 = raw[g & 1][2 * i + 1];
+          const float xs[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+          split_frag(xs, xT[4 * g + i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (job == 0) __syncthreads();                    // (vmcnt(0) + barrier) blocks 0 and 1 are in LDS, the bias vector is visible
+    for (int cb = 0; cb < nb; ++cb) {
+      const int kind = cb < kb0 ? 0 : (cb < kb0 + NHEAD ? 1 : 2);          // 0 = fp32 rows, 1 = keys, 2 = values
+      const op_t* w1 = rs_ring + slot * RS_BLK + (half * 32 + l31) * 8;    // [p][ks][half][col][8]
+      const int nslot = (slot + 2) & 3;
+      f32x16 acc;
+      if (kind != 2) {
+        const float* bp = bs + cb * 32 + 4 * half;                         // register r <-> column (r & 3) + 8 (r >> 2) + 4 half
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + 8 * g);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[4 * g + j] = bv[j] * WSCALE;
+        }
+      } else {
+        const float bv = bs[cb * 32 + l31] * WSCALE;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bv;
+      }
+      {
+        opx8 wf[3][NPL];
+        auto ld1 = [&](int ks, opx8 (&f)[NPL]) {
+#pragma unroll
+          for (int p = 0; p < NPL; ++p) f[p] = *reinterpret_cast<const opx8*>(w1 + ((p * 16 + ks) * 2) * 32 * 8);
+        };
+        ld1(0, wf[0]);
+        ld1(1, wf[1]);
+        __builtin_amdgcn_sched_barrier(0);             // (keeps the fragment reads two k-steps ahead instead of all at the top: 256 registers)
+        if (kind != 2) {
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) {
+            if (ks + 2 < 16) ld1(ks + 2, wf[(ks + 2) % 3]);
+#ifndef RS_ABL_NODMA
+            if (ks < RS_PIECES) dma_piece(nxt, nslot, ks);
+#endif
+            SPLIT_TERMS(acc, wf[ks % 3], xT[ks])                           // one chain: the SIMD's other wave fills the matrix pipe's dependency gaps
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) {
+            if (ks + 2 < 16) ld1(ks + 2, wf[(ks + 2) % 3]);
+#ifndef RS_ABL_NODMA
+            if (ks < RS_PIECES) dma_piece(nxt, nslot, ks);
+#endif
+            SPLIT_TERMS(acc, xT[ks], wf[ks % 3])
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      // the block of the NEXT phase (requested a phase ago) must have landed; younger requests of this wave, in issue order: last
+      // phase's stores, then this phase's RS_PIECES pieces (vmcnt counts in order; stores count)
+      if (partial) __builtin_amdgcn_s_waitcnt(0x0070);                                 // vmcnt(0) lgkmcnt(0)
+      else if (e_prev == 8) __builtin_amdgcn_s_waitcnt(0x0070 | (8 + RS_PIECES));
+      else if (e_prev == 4) __builtin_amdgcn_s_waitcnt(0x0070 | (4 + RS_PIECES));
+      else __builtin_amdgcn_s_waitcnt(0x0070 | RS_PIECES);
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] *= WSCALE_INV;
+#ifdef RS_ABL_NOSTORE
+      const bool st_ok = M < 0 || !((RS_ABL_NOSTORE >> kind) & 1);      // ablation: bit k switches the stores of kind k off
+#else
+      const bool st_ok = true;
+#endif
+      if (kind == 0) {
+        if (row < M && st_ok) {
+          float* cp = C + (size_t)row * ldc + cb * 32 + 4 * half;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(cp + 8 * q) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        }
+        e_prev = 4;
+      } else if (kind == 1) {
+        if (k_tile >= 0 && st_ok) {
+          op_t* dst = kv.img + (size_t)(k_tile + (cb - kb0) * (k_meta >> 6)) * KIMG + (k_meta & 63) * 8 + 4 * half;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            u32x2 pa[NPL];
+            split_quad(f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]}, pa);
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<u32x2*>(dst + pl * KPL + q * 64 * 8) = pa[pl];
+          }
+        }
+        e_prev = 8;
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (v_tile[g] >= 0 && st_ok) {
+            u32x2 pv[NPL];
+            split_quad(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, pv);
+            op_t* dst = kv.img + (size_t)(v_tile[g] + (cb - kb0 - NHEAD) * (v_meta[g] >> 6)) * KIMG + NPL * KPL + ((v_meta[g] & 63) * HD + l31) * 4;
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<u32x2*>(dst + pl * KPL) = pv[pl];
+          }
+        }
+        e_prev = 8;
+      }
+      slot = (slot + 1) & 3;
+      nxt = nxt + 1 == nb ? 0 : nxt + 1;
+    }
+  }
+}
+
+int launch_inproj_rs(const float* A, int lda, const void* Wblk, const float* bias, float* C, int ldc, int M, int N, void* kv_img,
+                     int kv_col0, int kv_n, const KvClassHost* kv_cls, hipStream_t st) {
+  if (M <= 0) return CTRLSIM_OK;
+  if (!A || !Wblk || !kv_img || !kv_cls || (lda & 3) || (ldc & 3) || (N & 31) || N > 32 * RS_MAXB || (kv_col0 & 31) || N != kv_col0 + 2 * DM ||
+      (kv_col0 && !C) || kv_n < 1 || kv_n > MAXC)
+    return CTRLSIM_EINVAL;
+  KvImg kv;
+  kv.img = static_cast<op_t*>(kv_img); kv.k_col0 = kv_col0; kv.n = 0;
+  int row0 = 0;
+  for (int k = 0; k < kv_n; ++k) {
+    const KvClassHost& c = kv_cls[k];
+    if (c.B <= 0) continue;
+    if ((c.L & 3) || c.L < 32 || (c.Lreg & 3) || c.Lreg > c.L || c.Lreg <= 0 || (c.rep_k0 & 63) ||
+        (c.Lreg < c.L && c.rep_k0 < c.Lreg) || c.nkt * 64 < (c.Lreg < c.L ? c.rep_k0 + (c.L - c.Lreg) : c.L))
+      return CTRLSIM_EINVAL;
+    kv.c[kv.n++] = KvClass{row0, c.L, c.Lreg, c.rep_k0, c.nkt, c.tile0};
+    row0 += c.B * c.L;
+  }
+  if (row0 != M) return CTRLSIM_EINVAL;
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }();
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&inproj_rs_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS_BYTES) == hipSuccess;
+  if (!attr_ok) return CTRLSIM_EINVAL;
+  const int n_rb = (M + 255) / 256;
+  prof_before(PROF_GEMM, st);
+  hipLaunchKernelGGL(inproj_rs_kernel, dim3(n_rb < cus ? n_rb : cus), dim3(512), RS_LDS_BYTES, st, A, lda, static_cast<const op_t*>(Wblk),
+                     bias, C, ldc, M, N / 32, kv);
+  const double MN = (double)M * N, kvN = 2.0 * DM;
+  prof_after(PROF_GEMM, 2.0 * MN * (double)DM, st,
+             4.0 * (double)M * DM + 4.0 * (double)M * (N - kvN) + 2.0 * NPL * (double)M * kvN + 2.0 * NPL * (double)N * DM, PKIND_GEMM_QKV_KV);
+  return ctrlsim_launch_status();
+}
+#else
+int launch_inproj_rs(const float*, int, const void*, const float*, float*, int, int, int, void*, int, int, const KvClassHost*, hipStream_t) {
+  return CTRLSIM_EINVAL;                               // two-fp16-plane scheme only
+}
+#endif
+
 int launch_gemm_nt_bf16x6_kvc(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias,
                               const float* R, int ldr, float* C, int ldc, int M, int N, int K, int relu,
                               const float* ln_gamma, const float* ln_beta, void* kv_img, int kv_col0, int kv_n,

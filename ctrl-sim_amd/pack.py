@@ -178,6 +178,17 @@ def map_frags(Wc: np.ndarray, ln_b: np.ndarray, U: np.ndarray):
     return wfrag.view(np.uint16), ufrag.view(np.uint16)
 
 
+def row_blocks(W: np.ndarray, scheme=None) -> np.ndarray:
+    """[N, K] float32 -> operand blocks of 32 output columns [N/32][p][ks K/16][half 2][col 32][8] (uint16) = plane_p(W)[32 cb + col,
+    16 ks + 8 half + e]: what the row-stationary in_proj kernel (csrc/gemm_bf16x6.hip: inproj_rs_kernel) streams through LDS, and the
+    layout of the fused FFN's W1 blocks."""
+    N, K = W.shape
+    assert N % 32 == 0 and K % 16 == 0
+    pl = _planes3(W, scheme)
+    p1 = pl.reshape(pl.shape[0], N // 32, 32, K // 16, 2, 8)              # [p][cb][col][ks][half][e]
+    return np.ascontiguousarray(p1.transpose(1, 0, 3, 4, 2, 5))           # [cb][p][ks][half][col][e]
+
+
 def ffn_planes(W1: np.ndarray, W2: np.ndarray, scheme=None):
     """Operand images of the fused FFN kernel (csrc/ffn_fused.hip), one 48 KB block per 32 hidden units hb:
       W1p[hb][p 3][ks K/16][half 2][row 32][8]   = plane_p(W1)[32 hb + row, 16 ks + 8 half + e]
@@ -230,6 +241,13 @@ def pack(dims: Dims, w: dict):
                     continue
                 allw[pre + ".ffn#w1p" + suffix] = w1p.reshape(-1).view(np.float32)
                 allw[pre + ".ffn#w2p" + suffix] = w2p.reshape(-1).view(np.float32)
+    # 32-column operand blocks of every attention in_proj (two-fp16-plane scheme: the row-stationary kernel)
+    for k in list(w.keys()):
+        if k.endswith("in_proj_weight") and np.asarray(w[k]).shape == (3 * 256, 256):
+            try:
+                allw[k + "#blk" + PLANES_SUFFIX[1]] = row_blocks(np.asarray(w[k], np.float32), 1).reshape(-1).view(np.float32)
+            except FloatingPointError:
+                pass                                               # out of the fp16 range: that model runs with bf16 planes
     # map-encoder point pooling on the matrix pipe (two-fp16-plane scheme): constant operand fragments, raw 16-bit words
     try:
         wf, uf = map_frags(allw["fold.map.Wc"], np.asarray(w["encoder.map_encoder.road_pts_encoder.mlp.1.bias"], np.float32),

@@ -290,6 +290,11 @@ int ctrlsim_gemm_nt_bf16x6(const float* A, int lda, const void* W3, int n_total,
  * preparation. */
 int ctrlsim_gemm_nt_kv(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias, float* C, int ldc,
                        int M, int N, int K, void* kv_img, int kv_L, int kv_nkt, int kv_col0, hipStream_t stream);
+/* The same operation through the row-stationary kernel (two-fp16-plane scheme only; CTRLSIM_EINVAL otherwise): Wblk = the weight as
+ * 32-column operand blocks (ctrlsim_amd/pack.py:row_blocks of rows [n0, n0 + N) of the weight; N = kv_col0 + 512, a multiple of 32, at
+ * most 768), bias = its N entries; K = 256.  Every activation row is read once; outputs as for ctrlsim_gemm_nt_kv. */
+int ctrlsim_gemm_kv_blocks(const float* A, int lda, const void* Wblk, const float* bias, float* C, int ldc, int M, int N,
+                           void* kv_img, int kv_L, int kv_nkt, int kv_col0, hipStream_t stream);
 /* Post-LN feed-forward block of nn.TransformerEncoderLayer / DecoderLayer as one kernel:
  * Y = LayerNorm(X + W2 relu(W1 X + b1) + b2) * gamma + beta, rows of 256, F hidden units (multiple of 32); W1p / W2p are the
  * operand images of ctrlsim_amd/pack.py:ffn_planes; Y may alias X.  The hidden activation never touches memory. */
@@ -364,7 +369,9 @@ int ctrlsim_attn_class_prof(int enable, unsigned long long* host_out);
  * split-operand GEMM (0 auto; tuning).  Key 3 = fused feed-forward block (default 1).  Key 4 = operand split (1 two fp16 planes,
  * 0 three bf16 planes; per engine through ctrlsim_bind).  Key 5 = map-encoder pooling on the matrix pipe (default 0).
  * Key 6 = weight-stationary kernel for the Linear(256 -> 256 G) shapes, bit mask: 1 = launches of at least two 32-row blocks per
- * compute unit, 2 = smaller launches, 4 = the in_proj Linears with K / V-image epilogue (default 7; 0 = tiled kernel everywhere).
+ * compute unit, 2 = smaller launches, 4 = the in_proj Linears with K / V-image epilogue, 8 = those through the ROW-stationary kernel
+ * (rows in registers, 32-column weight blocks streamed through LDS, every activation row read once; needs the block images of
+ * pack.py:row_blocks in the packed weights) inside the forward (default 15; 0 = tiled kernel everywhere).
  * Key 7 = causal self-attention over the token rows takes its visibility masks from the per-class table (default 1; 0 = built per query).
  * Key 8 = the last decoder layer of a rollout pass projects keys / values of every token and queries of the queried tokens only (default 1;
  * 0 = the whole in_proj for every token, then a gather). */

@@ -156,6 +156,49 @@ def test_linear_with_kv_image_epilogue(ws_option, B, L, col0):
     assert same > 0.6, same
 
 
+@pytest.mark.parametrize("B,L,col0", [(3, 224, 256), (2, 96, 256), (5, 160, 0), (1, 2304, 256), (160, 288, 256), (300, 288, 256), (450, 292, 0)])
+def test_row_stationary_linear_with_kv_images(B, L, col0):
+    """The same in_proj through the ROW-stationary kernel (ctrlsim_gemm_kv_blocks: rows in registers, 32-column weight blocks streamed
+    through LDS; one job = 256 rows, so the cases cover a partial single job, one job per compute unit, and more than one job per
+    workgroup with the counted waits in flight and a partial last job): query columns and attention driven by its K / V images against the
+    plain Linear + split pass."""
+    lib = _lib.lib()
+    if lib.ctrlsim_split_scheme() != 1:
+        pytest.skip("two-fp16-plane scheme only")
+    g = torch.Generator().manual_seed(7 * B * L + col0)
+    N, M, nkt = col0 + 512, B * L, (L + 63) // 64
+    A = (torch.randn(M, 256, generator=g) * torch.exp(0.3 * torch.randn(M, 1, generator=g))).to(DEV)
+    W = torch.randn(N, 256, generator=g) * 0.08
+    b = torch.randn(N, generator=g).to(DEV)
+    y = gemm_bf16x6(A, W, b)
+    p, st = _lib.ptr, _lib.stream_ptr()
+    img_ref = _kv_images(y.data_ptr() + 4 * col0, y.data_ptr() + 4 * (col0 + 256), N, L * N, B, L, nkt)
+    from ctrlsim_amd.pack import row_blocks
+    blocks = torch.from_numpy(row_blocks(W.numpy(), 1).view(np.int16).copy()).to(DEV)
+    C = torch.full((M, max(col0, 4)), float("nan"), device=DEV)
+    img = torch.zeros_like(img_ref)
+    _lib.check(lib.ctrlsim_gemm_kv_blocks(p(A), 256, p(blocks), p(b), p(C), C.stride(0), M, N, p(img), L, nkt, col0, st))
+    if col0:
+        ref = A.double() @ W[:col0].to(DEV).double().T + b[:col0].double()
+        scale = (A.double().abs() @ W[:col0].to(DEV).double().abs().T + 1).max().item()
+        assert (C.double() - ref).abs().max().item() < 2e-5 * max(1.0, scale / 50)
+        assert (C - y[:, :col0]).abs().max().item() < 1e-5 * max(1.0, scale / 50)
+    Q = torch.randn(B, L, 256, generator=g).to(DEV)
+    O0 = torch.zeros(B, L, 256, device=DEV); O1 = torch.zeros_like(O0)
+    pad = torch.zeros(B, L, dtype=torch.uint8, device=DEV)
+    for im, O in ((img_ref, O0), (img, O1)):
+        _lib.check(lib.ctrlsim_attention_presplit(0, p(Q), 256, L * 256, p(im), nkt, p(O), 256, L * 256, None, p(pad), B, L, L, 1, st))
+    assert torch.isfinite(O1).all() and (O0 - O1).abs().max().item() < 2e-5
+    used = B * 8 * nkt * 8192
+    same = (img.view(-1)[:used] == img_ref.view(-1)[:used]).float().mean().item()
+    assert same > 0.6, same
+    # the tails of the last tiles were left alone (the caller zeroes them)
+    if L % 64:
+        v = img.view(-1)[:used].view(B * 8, nkt, 2, 2, 64 * 32)       # [ctx*head][tile][K|V][plane][...]
+        ktail = v[:, -1, 0].reshape(B * 8, 2, 4, 64, 8)[:, :, :, L % 64:, :]
+        assert (ktail == 0).all()
+
+
 def test_layernorm_and_in_place():
     g = torch.Generator().manual_seed(1)
     X = torch.randn(1003, 256, generator=g).to(DEV) * 3 + 1

@@ -123,6 +123,16 @@ if 'gemm' in FILT or not FILT:
     img = torch.zeros(B * 8 * nkt * 4096 * (2 if NPROD == 3 else 3), dtype=torch.int16, device=DEV)
     f = lambda: lib.ctrlsim_gemm_nt_kv(p(A), 256, p(planes), 768, 0, p(b), p(Cm), 768, M, 768, 256, p(img), L, nkt, 256, st)
     report('gemm qkv + K/V images N=768 K=256', sustained(f), 2.0 * M * 768 * 256)
+    if NPROD == 3:
+        from ctrlsim_amd.pack import row_blocks
+        blocks = torch.from_numpy(row_blocks(W.numpy(), 1).view(np.int16).copy()).to(DEV)
+        f = lambda: lib.ctrlsim_gemm_kv_blocks(p(A), 256, p(blocks), p(b), p(Cm), 768, M, 768, p(img), L, nkt, 256, st)
+        report('gemm qkv + K/V images, row-stationary', sustained(f), 2.0 * M * 768 * 256)
+        Mq = M // 4
+        f = lambda: lib.ctrlsim_gemm_nt_kv(p(A), 256, p(planes), 768, 0, p(b), p(Cm), 768, Mq, 768, 256, p(img), L, nkt, 256, st)
+        report('gemm qkv + K/V images, quarter rows', sustained(f), 2.0 * Mq * 768 * 256)
+        f = lambda: lib.ctrlsim_gemm_kv_blocks(p(A), 256, p(blocks), p(b), p(Cm), 768, Mq, 768, p(img), L, nkt, 256, st)
+        report('gemm qkv + K/V images, row-stationary, quarter rows', sustained(f), 2.0 * Mq * 768 * 256)
     del A, Cm, img
 if 'ffn' in FILT or not FILT:
     F = 1024
