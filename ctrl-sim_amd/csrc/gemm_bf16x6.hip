@@ -863,6 +863,26 @@ constexpr int RS_RING = 4;
 constexpr int RS_PIECES = RS_BLK / (512 * 8);        // 16-byte-per-thread DMA pieces of a block (4)
 constexpr int RS_MAXB = 3 * DM / 32;                 // column blocks of the largest launch (in_proj: 24)
 #define RS_LDS_BYTES (RS_RING * RS_BLK * 2 + RS_MAXB * 32 * 4)
+#ifndef RS_PF
+#define RS_PF 2            // LDS fragment prefetch distance in k-steps
+#endif
+#ifndef RS_PLAIN_ST
+#define RS_ST(P, V) __builtin_nontemporal_store(V, P)     // 512-byte runs that nobody re-reads before the attention kernel: -4 %
+#else
+#define RS_ST(P, V) (*(P) = (V))
+#endif
+#ifdef RS_TIMING   // per-segment s_memtime accounting of wave 0 of every workgroup (variant builds only; tools/microbench/rs_timing.py)
+__device__ unsigned long long g_rs_t[8];
+extern "C" int ctrlsim_debug_rs_times(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rs_t), sizeof(g_rs_t)) != hipSuccess) return CTRLSIM_ELAUNCH;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_rs_t), z, sizeof(z)) != hipSuccess) return CTRLSIM_ELAUNCH; }
+  return CTRLSIM_OK;
+}
+#define RS_STAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+                      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); rs_tacc[i] += _t - rs_tlast; rs_tlast = _t; }
+#else
+#define RS_STAMP(i)
+#endif
 __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restrict__ A, int lda, const op_t* __restrict__ Wb,
                                                            const float* __restrict__ bias, float* __restrict__ C, int ldc, int M,
                                                            int nb, const KvImg kv) {
@@ -870,28 +890,55 @@ __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restri
   extern __shared__ __attribute__((aligned(16))) op_t rs_ring[];
   float* const bs = reinterpret_cast<float*>(rs_ring + RS_RING * RS_BLK);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  // the work is the sequence of (256-row job, 32-column block) phases, job-major; every workgroup takes an equal contiguous share of it
+  // (a share may begin and end inside a job: its rows are then loaded by two workgroups)
   const int n_rb = (M + 255) / 256;
-  if ((int)blockIdx.x >= n_rb) return;
+  const long total = (long)n_rb * nb;
+  const int p_begin = (int)(total * blockIdx.x / gridDim.x), p_end = (int)(total * (blockIdx.x + 1) / gridDim.x);
+  if (p_begin >= p_end) return;
   for (int i = tid; i < nb * 32; i += 512) bs[i] = bias ? bias[i] : 0.f;
-  const int njobs = (n_rb - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   auto dma_piece = [&](int blk, int slot, int j) {
     const op_t* src = Wb + (size_t)blk * RS_BLK + (j * 512 + tid) * 8;
     op_t* dst = rs_ring + slot * RS_BLK + (j * 512 + wave * 64) * 8;       // wave-uniform LDS base (+ 16 B per lane)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
+  int job = p_begin / nb, cb = p_begin - job * nb;
+  {
+    const int c1 = cb + 1 == nb ? 0 : cb + 1;
 #pragma unroll
-  for (int j = 0; j < RS_PIECES; ++j) dma_piece(0, 0, j);
+    for (int j = 0; j < RS_PIECES; ++j) dma_piece(cb, 0, j);
 #pragma unroll
-  for (int j = 0; j < RS_PIECES; ++j) dma_piece(1 % nb, 1, j);
+    for (int j = 0; j < RS_PIECES; ++j) dma_piece(c1, 1, j);
+  }
+  int nxt = cb + 2 >= nb ? cb + 2 - nb : cb + 2;     // column block two phases ahead (nb >= 2)
   const int kb0 = kv.k_col0 >> 5;                     // first key block; values from kb0 + 8
   constexpr int KIMG = 2 * NPL * 64 * HD, KPL = 64 * HD;
-  int slot = 0, nxt = 2 % nb;                         // ring slot of the current block; column block two phases ahead
-  int e_prev = 0;                                     // stores this wave issued in the previous phase
-  for (int job = 0; job < njobs; ++job) {
-    const int rb = (int)blockIdx.x + job * (int)gridDim.x;
-    const int cbm = __builtin_amdgcn_readfirstlane(rb * 256 + wave * 32);
+  int slot = 0;                                       // ring slot of the current block
+#ifdef RS_TIMING
+  unsigned long long rs_tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rs_tlast = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+  // The wave's 32 rows of a job arrive as 32 raw 16-byte loads per lane (k-step ks: k = 16 ks + 8 half .. + 7), all requested at the top
+  // of the job and converted in order as they land.  (Requested a block earlier — right after the previous job's last k-loop, when the
+  // fragment registers are dead — the job start shrinks from 20 % to 3 % of the wave's time and the barrier waits grow by the same
+  // amount: the kernel is bound by what it writes, not by latencies.  profiles/README.md, round 4.)
+  f32x4 raw[32];
+  auto issue_rows = [&](int job_) {
+    const int r_ = job_ * 256 + wave * 32 + l31;
+    const float* xp = A + (size_t)(r_ < M ? r_ : M - 1) * lda + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      raw[2 * ks] = *reinterpret_cast<const f32x4*>(xp + ks * 16);         // (plain loads: a 128-byte line is fetched by four of them)
+      raw[2 * ks + 1] = *reinterpret_cast<const f32x4*>(xp + ks * 16 + 4);
+    }
+  };
+  int p = p_begin;
+  while (p < p_end) {
+    issue_rows(job);
+    RS_STAMP(7)
+    const int cbm = __builtin_amdgcn_readfirstlane(job * 256 + wave * 32);
     const int row = cbm + l31;
-    const bool partial = rb * 256 + 256 > M;          // workgroup-uniform: some lane of this job issues no stores
+    const bool partial = job * 256 + 256 > M;         // workgroup-uniform: some lane of this job issues no stores
     // where this lane's row (key blocks) and its four row quads (value blocks) go in the images of head 0: resolved ONCE per job, before
     // the operand fragments are live (the class table stays out of the block loop); tile index < 0 = beyond M, nothing to store
     int k_tile = -1, k_meta = 0;                      // tile index; key in the tile (value blocks: key quad) | tiles per head << 6
@@ -914,38 +961,52 @@ __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restri
         }
       }
     }
-    // the wave's 32 rows as split operand fragments: k-step ks covers k = 16 ks + 8 half .. + 7.  Loaded in four groups of four k-steps,
-    // one group ahead (the raw rows of all 16 k-steps beside the finished fragments would not fit 256 registers)
+#ifdef RS_ABL_SAMEADDR
+    if (M > 0) { k_tile = wave; for (int g = 0; g < 4; ++g) v_tile[g] = wave; }      // ablation: every job writes the same few tiles (L2 only)
+#endif
     opx8 xT[16][NPL];
-    {
-      const float* xp = A + (size_t)(row < M ? row : M - 1) * lda + half * 8;
-      f32x4 raw[2][8];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        raw[0][2 * i] = *reinterpret_cast<const f32x4*>(xp + i * 16);
-        raw[0][2 * i + 1] = *reinterpret_cast<const f32x4*>(xp + i * 16 + 4);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        if (g + 1 < 4) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            raw[(g + 1) & 1][2 * i] = *reinterpret_cast<const f32x4*>(xp + (4 * (g + 1) + i) * 16);
-            raw[(g + 1) & 1][2 * i + 1] = *reinterpret_cast<const f32x4*>(xp + (4 * (g + 1) + i) * 16 + 4);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const f32x4 x0 = raw[g & 1][2 * i], x1 = raw[g & 1][2 * i + 1];
-          const float xs[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-          split_frag(xs, xT[4 * g + i]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
+    for (int ks = 0; ks < 16; ++ks) {
+      const f32x4 x0 = raw[2 * ks], x1 = raw[2 * ks + 1];
+      const float xs[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+      split_frag(xs, xT[ks]);
     }
-    if (job == 0) __syncthreads();                    // (vmcnt(0) + barrier) blocks 0 and 1 are in LDS, the bias vector is visible
-    for (int cb = 0; cb < nb; ++cb) {
+    RS_STAMP(0)
+    // (the fragment loads above were waited for with everything older complete: the next block's pieces have landed for this wave)
+    if (p == p_begin) __syncthreads();                // blocks 0 and 1 of the share are in LDS, the bias vector is visible
+    int e_prev = 0;                                   // stores this wave issued in the previous phase (0: waiting for the rows above drained them)
+    const int cb_last = (p_end - p) < (nb - cb) ? cb + (p_end - p) - 1 : nb - 1;   // last block of this job in the share
+    // one quarter (quad q) of a finished block: fp32 row pieces / key plane entries / value plane entries; 1 / 2 / 2 stores
+    auto epi_quad = [&](const f32x16& v, int knd, int cbv, int q) {
+      const f32x4 x = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]} * WSCALE_INV;
+#ifdef RS_ABL_NOSTORE
+      if (M > 0) return;
+#endif
+      if (knd == 0) {
+#ifdef RS_ABL_SAMEADDR
+        if (row < M) *reinterpret_cast<f32x4*>(C + (size_t)(row & 255) * ldc + cbv * 32 + 4 * half + 8 * q) = x;
+#else
+        if (row < M) *reinterpret_cast<f32x4*>(C + (size_t)row * ldc + cbv * 32 + 4 * half + 8 * q) = x;
+#endif
+      } else if (knd == 1) {
+        if (k_tile >= 0) {
+          u32x2 pa[NPL];
+          split_quad(x, pa);
+          op_t* dst = kv.img + (size_t)(k_tile + (cbv - kb0) * (k_meta >> 6)) * KIMG + (k_meta & 63) * 8 + 4 * half + q * 64 * 8;
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) RS_ST(reinterpret_cast<u32x2*>(dst + pl * KPL), pa[pl]);
+        }
+      } else {
+        if (v_tile[q] >= 0) {
+          u32x2 pv[NPL];
+          split_quad(x, pv);
+          op_t* dst = kv.img + (size_t)(v_tile[q] + (cbv - kb0 - NHEAD) * (v_meta[q] >> 6)) * KIMG + NPL * KPL + ((v_meta[q] & 63) * HD + l31) * 4;
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) RS_ST(reinterpret_cast<u32x2*>(dst + pl * KPL), pv[pl]);
+        }
+      }
+    };
+    for (; cb <= cb_last; ++cb, ++p) {
       const int kind = cb < kb0 ? 0 : (cb < kb0 + NHEAD ? 1 : 2);          // 0 = fp32 rows, 1 = keys, 2 = values
       const op_t* w1 = rs_ring + slot * RS_BLK + (half * 32 + l31) * 8;    // [p][ks][half][col][8]
       const int nslot = (slot + 2) & 3;
@@ -963,87 +1024,66 @@ __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = bv;
       }
-      {
-        opx8 wf[3][NPL];
+      // 48 MFMAs, the DMA pieces of the block two phases ahead at k-steps 0-3
+      // 48 MFMAs in one chain (two chains, and the two waves of a SIMD taking their epilogues at different ends of the barrier, measured
+      // no different: profiles/README.md), the DMA pieces of the block two phases ahead at k-steps 0-3
+      auto kloop = [&](auto ORI) {
+        constexpr int ori = decltype(ORI)::value;
+        opx8 wf[RS_PF + 1][NPL];
         auto ld1 = [&](int ks, opx8 (&f)[NPL]) {
 #pragma unroll
-          for (int p = 0; p < NPL; ++p) f[p] = *reinterpret_cast<const opx8*>(w1 + ((p * 16 + ks) * 2) * 32 * 8);
+          for (int pp = 0; pp < NPL; ++pp) f[pp] = *reinterpret_cast<const opx8*>(w1 + ((pp * 16 + ks) * 2) * 32 * 8);
         };
-        ld1(0, wf[0]);
-        ld1(1, wf[1]);
-        __builtin_amdgcn_sched_barrier(0);             // (keeps the fragment reads two k-steps ahead instead of all at the top: 256 registers)
-        if (kind != 2) {
 #pragma unroll
-          for (int ks = 0; ks < 16; ++ks) {
-            if (ks + 2 < 16) ld1(ks + 2, wf[(ks + 2) % 3]);
+        for (int i = 0; i < RS_PF; ++i) ld1(i, wf[i]);
+        __builtin_amdgcn_sched_barrier(0);             // (keeps the fragment reads RS_PF k-steps ahead instead of all at the top: 256 registers)
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          if (ks + RS_PF < 16) ld1(ks + RS_PF, wf[(ks + RS_PF) % (RS_PF + 1)]);
 #ifndef RS_ABL_NODMA
-            if (ks < RS_PIECES) dma_piece(nxt, nslot, ks);
+          if (ks < RS_PIECES) dma_piece(nxt, nslot, ks);
 #endif
-            SPLIT_TERMS(acc, wf[ks % 3], xT[ks])                           // one chain: the SIMD's other wave fills the matrix pipe's dependency gaps
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        } else {
-#pragma unroll
-          for (int ks = 0; ks < 16; ++ks) {
-            if (ks + 2 < 16) ld1(ks + 2, wf[(ks + 2) % 3]);
-#ifndef RS_ABL_NODMA
-            if (ks < RS_PIECES) dma_piece(nxt, nslot, ks);
-#endif
-            SPLIT_TERMS(acc, xT[ks], wf[ks % 3])
-            __builtin_amdgcn_sched_barrier(0);
-          }
+          const int c = ks % (RS_PF + 1);
+          if (ori == 0) { SPLIT_TERMS(acc, wf[c], xT[ks]) }                // D^T = W_blk . X^T: a lane owns one row
+          else { SPLIT_TERMS(acc, xT[ks], wf[c]) }                         // D = X . W_blk^T: a lane owns one dim
+          __builtin_amdgcn_sched_barrier(0);
         }
+      };
+      RS_STAMP(4)
+      if (kind == 2) kloop(std::integral_constant<int, 1>{});
+      else kloop(std::integral_constant<int, 0>{});
+      RS_STAMP(1)
+      const int e_cur = kind == 0 ? 4 : 8;
+      // the block of the NEXT phase (requested in the previous phase's k-steps 0-3) must have landed; younger requests of this wave, in
+      // issue order: the previous phase's stores, then this phase's RS_PIECES pieces.  vmcnt counts in order; stores count.
+      {
+        const int younger = partial ? 0 : e_prev + RS_PIECES;
+        if (younger == 0) __builtin_amdgcn_s_waitcnt(0x0070);                          // vmcnt(0) lgkmcnt(0)
+        else if (younger == 4) __builtin_amdgcn_s_waitcnt(0x0070 | 4);
+        else if (younger == 8) __builtin_amdgcn_s_waitcnt(0x0070 | 8);
+        else __builtin_amdgcn_s_waitcnt(0x0070 | 12);
       }
-      // the block of the NEXT phase (requested a phase ago) must have landed; younger requests of this wave, in issue order: last
-      // phase's stores, then this phase's RS_PIECES pieces (vmcnt counts in order; stores count)
-      if (partial) __builtin_amdgcn_s_waitcnt(0x0070);                                 // vmcnt(0) lgkmcnt(0)
-      else if (e_prev == 8) __builtin_amdgcn_s_waitcnt(0x0070 | (8 + RS_PIECES));
-      else if (e_prev == 4) __builtin_amdgcn_s_waitcnt(0x0070 | (4 + RS_PIECES));
-      else __builtin_amdgcn_s_waitcnt(0x0070 | RS_PIECES);
-      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();                   // taken BEFORE this block's stores: they leave underneath the next block's MFMAs
+      RS_STAMP(2)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] *= WSCALE_INV;
-#ifdef RS_ABL_NOSTORE
-      const bool st_ok = M < 0 || !((RS_ABL_NOSTORE >> kind) & 1);      // ablation: bit k switches the stores of kind k off
-#else
-      const bool st_ok = true;
+      for (int q = 0; q < 4; ++q) epi_quad(acc, kind, cb, q);
+      RS_STAMP(3)
+#ifdef RS_TIMING
+      rs_tacc[5] += 1;
 #endif
-      if (kind == 0) {
-        if (row < M && st_ok) {
-          float* cp = C + (size_t)row * ldc + cb * 32 + 4 * half;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(cp + 8 * q) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-        }
-        e_prev = 4;
-      } else if (kind == 1) {
-        if (k_tile >= 0 && st_ok) {
-          op_t* dst = kv.img + (size_t)(k_tile + (cb - kb0) * (k_meta >> 6)) * KIMG + (k_meta & 63) * 8 + 4 * half;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            u32x2 pa[NPL];
-            split_quad(f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]}, pa);
-#pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<u32x2*>(dst + pl * KPL + q * 64 * 8) = pa[pl];
-          }
-        }
-        e_prev = 8;
-      } else {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          if (v_tile[g] >= 0 && st_ok) {
-            u32x2 pv[NPL];
-            split_quad(f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]}, pv);
-            op_t* dst = kv.img + (size_t)(v_tile[g] + (cb - kb0 - NHEAD) * (v_meta[g] >> 6)) * KIMG + NPL * KPL + ((v_meta[g] & 63) * HD + l31) * 4;
-#pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<u32x2*>(dst + pl * KPL) = pv[pl];
-          }
-        }
-        e_prev = 8;
-      }
+      e_prev = e_cur;
       slot = (slot + 1) & 3;
       nxt = nxt + 1 == nb ? 0 : nxt + 1;
     }
+    if (cb == nb) cb = 0;
+    ++job;
   }
+#ifdef RS_TIMING
+  if (tid == 0 || tid == 256) {
+    rs_tacc[6] += 1;
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_rs_t[i], rs_tacc[i]);
+  }
+#endif
 }
 
 int launch_inproj_rs(const float* A, int lda, const void* Wblk, const float* bias, float* C, int ldc, int M, int N, void* kv_img,
@@ -1074,8 +1114,9 @@ int launch_inproj_rs(const float* A, int lda, const void* Wblk, const float* bia
   if (!attr_ok) return CTRLSIM_EINVAL;
   const int n_rb = (M + 255) / 256;
   prof_before(PROF_GEMM, st);
-  hipLaunchKernelGGL(inproj_rs_kernel, dim3(n_rb < cus ? n_rb : cus), dim3(512), RS_LDS_BYTES, st, A, lda, static_cast<const op_t*>(Wblk),
-                     bias, C, ldc, M, N / 32, kv);
+  const long shares = (long)n_rb * (N / 32) / 4;         // at least four (job, block) phases per workgroup
+  hipLaunchKernelGGL(inproj_rs_kernel, dim3(shares < 1 ? 1 : (shares < cus ? (int)shares : cus)), dim3(512), RS_LDS_BYTES, st, A, lda,
+                     static_cast<const op_t*>(Wblk), bias, C, ldc, M, N / 32, kv);
   const double MN = (double)M * N, kvN = 2.0 * DM;
   prof_after(PROF_GEMM, 2.0 * MN * (double)DM, st,
              4.0 * (double)M * DM + 4.0 * (double)M * (N - kvN) + 2.0 * NPL * (double)M * kvN + 2.0 * NPL * (double)N * DM, PKIND_GEMM_QKV_KV);
