@@ -308,7 +308,7 @@ def main():
         f16 = eng.scheme == 1
         nprod, scheme = (3, "two fp16 planes, 3") if f16 else (6, "three bf16 planes, 6")
         PEAK_FP32_EQUIV_TFLOPS = PEAK_16BIT_MFMA_TFLOPS / nprod
-        names = ("gemm_ws256_kernel + gemm_nt_bf16x6_kernel + ffn_fused_bf16x6_kernel (every nn.Linear incl. fused LayerNorm / K-V image epilogues and the fused "
+        names = ("inproj_rs_kernel + gemm_ws256_kernel + gemm_nt_bf16x6_kernel + ffn_fused_bf16x6_kernel (every nn.Linear incl. fused LayerNorm / K-V image epilogues and the fused "
                  f"feed-forward block; split-operand MFMA 32x32x16: {scheme} partial products per fp32 product)",
                  "attention_bf16x6_kernel (all multi-head attention; split-operand MFMA flash attention, structured mask)")
 
@@ -353,7 +353,7 @@ def main():
             return {"achieved": rate, "peak": PEAK_HBM_TBPS, "unit": "TB/s", "frac": rate / PEAK_HBM_TBPS,
                     "avg_launch_ms": ms[i] / cnt[i], "launches": int(cnt[i]), "time_share_of_step": ms[i] * 1e-3 / elapsed,
                     "algorithmic_hbm_bytes_per_launch": by[i] / cnt[i]}
-        KNAMES = ("other", "Linear + K/V-image epilogue (QKV, memory K/V): gemm_ws256_kernel<..,KV> (weight-stationary; tiled gemm_nt_bf16x6_kernel<2,2,2,..,KVIMG> when K != 256)",
+        KNAMES = ("other", "Linear + K/V-image epilogue (QKV, memory K/V): inproj_rs_kernel (row-stationary; weight-stationary gemm_ws256_kernel<..,KV> / tiled gemm_nt_bf16x6_kernel<2,2,2,..,KVIMG> by option or when K != 256)",
                   "Linear + residual + LayerNorm epilogue (attention out-projections, MLP layers): gemm_ws256_kernel<..,LN> (weight-stationary; tiled gemm_nt_bf16x6_kernel<1,4,2,..,LN> when K != 256)",
                   "plain Linear (cross-attention query projection, heads, map / embedding layers): gemm_ws256_kernel (256 -> 256) / gemm_nt_bf16x6_kernel<2,2,2>",
                   "fused feed-forward block: ffn_fused_bf16x6_kernel",

@@ -212,6 +212,7 @@ int ctrlsim_gemm_nt_kv(const float* A, int lda, const void* W3, int n_total, int
 }
 int ctrlsim_gemm_kv_blocks(const float* A, int lda, const void* Wblk, const float* bias, float* C, int ldc, int M, int N,
                            void* kv_img, int kv_L, int kv_nkt, int kv_col0, hipStream_t st) {
+  if (!kv_img) return launch_inproj_rs(A, lda, Wblk, bias, C, ldc, M, N, nullptr, N, 0, nullptr, st);     // plain Linear: fp32 rows only
   if (kv_L <= 0 || M % kv_L) return CTRLSIM_EINVAL;
   const KvClassHost c{M / kv_L, kv_L, kv_L, 0, kv_nkt, 0};
   return launch_inproj_rs(A, lda, Wblk, bias, C, ldc, M, N, kv_img, kv_col0, 1, &c, st);

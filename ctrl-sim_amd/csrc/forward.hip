@@ -360,9 +360,14 @@ __global__ void fill_index_kernel(int B, int Areg, int L, int Lreg, int rep_k0, 
 // y = act(x W^T + b [+ R]) through the bf16x6 MFMA kernel when the packed planes exist, else the f32-input MFMA kernel
 int gemm(const Lin& L, const float* x, int ldx, const float* R, int ldr, float* y, int ldy, int rows, int n, int k, int relu,
          hipStream_t st) {
-  if (L.w3() && k % 32 == 0 && ctrlsim_option(OPT_GEMM_IMPL) == 1)
+  if (L.w3() && k % 32 == 0 && ctrlsim_option(OPT_GEMM_IMPL) == 1) {
+    // tall plain Linears whose weight travels as 32-column blocks (the cross-attention query projection): row-stationary kernel
+    if (L.wblk && !R && !relu && k == DM && n == DM && rows >= 16384 && !(L.n0 & 31) && ctrlsim_option(OPT_SPLIT) &&
+        (ctrlsim_option(OPT_GEMM_WS) & 16))
+      return launch_inproj_rs(x, ldx, L.wblk, L.b, y, ldy, rows, n, nullptr, n, 0, nullptr, st);
     return launch_gemm_nt_bf16x6(x, ldx, L.w3(), L.ntot ? L.ntot : n, L.n0, L.b, R, ldr, y, ldy, rows, n, k, relu, nullptr,
                                  nullptr, st);
+  }
   return launch_gemm_nt(x, ldx, L.w, k, L.b, R, ldr, y, ldy, rows, n, k, relu, st);
 }
 

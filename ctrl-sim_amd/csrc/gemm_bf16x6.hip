@@ -863,6 +863,11 @@ constexpr int RS_RING = 4;
 constexpr int RS_PIECES = RS_BLK / (512 * 8);        // 16-byte-per-thread DMA pieces of a block (4)
 constexpr int RS_MAXB = 3 * DM / 32;                 // column blocks of the largest launch (in_proj: 24)
 #define RS_LDS_BYTES (RS_RING * RS_BLK * 2 + RS_MAXB * 32 * 4)
+#ifdef RS_Q_LINES          // query blocks with swapped operands, whole 128-byte lines per store (16 stores per lane): measured no different
+#define RS_Q_ORI 1
+#else
+#define RS_Q_ORI 0
+#endif
 #ifndef RS_PF
 #define RS_PF 2            // LDS fragment prefetch distance in k-steps
 #endif
@@ -886,7 +891,7 @@ extern "C" int ctrlsim_debug_rs_times(unsigned long long* out, int reset) {
 __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restrict__ A, int lda, const op_t* __restrict__ Wb,
                                                            const float* __restrict__ bias, float* __restrict__ C, int ldc, int M,
                                                            int nb, const KvImg kv) {
-  static_assert(NPL == 2 && RS_PIECES == 4, "the counted vmcnt waits below assume 4 DMA pieces per block and 4 / 8 / 8 stores per epilogue");
+  static_assert(NPL == 2 && RS_PIECES == 4, "the counted vmcnt waits below assume 4 DMA pieces per block and 16 (4) / 8 / 8 stores per epilogue");
   extern __shared__ __attribute__((aligned(16))) op_t rs_ring[];
   float* const bs = reinterpret_cast<float*>(rs_ring + RS_RING * RS_BLK);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
@@ -947,7 +952,7 @@ __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restri
       const KvTile kt_ = kv_tile(kv, cbm, 32);
       int b, pos, nkt;
       long tile0;
-      if (row < M) {
+      if (row < M && kv.img) {
         kv_place(kv, kt_, cbm, row, b, pos, nkt, tile0);
         k_tile = (int)tile0 + b * NHEAD * nkt + (pos >> 6); k_meta = (pos & 63) | (nkt << 6);
       }
@@ -955,7 +960,7 @@ __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restri
       for (int g = 0; g < 4; ++g) {
         const int grow0 = cbm + 8 * g + 4 * half;                          // rows grow0 .. grow0 + 3: L % 4 == Lreg % 4 == 0, a quad never straddles
         v_tile[g] = -1; v_meta[g] = 0;
-        if (grow0 < M) {
+        if (grow0 < M && kv.img) {
           kv_place(kv, kt_, cbm, grow0, b, pos, nkt, tile0);
           v_tile[g] = (int)tile0 + b * NHEAD * nkt + (pos >> 6); v_meta[g] = ((pos & 63) >> 2) | (nkt << 6);
         }
@@ -981,6 +986,18 @@ __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restri
       const f32x4 x = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]} * WSCALE_INV;
 #ifdef RS_ABL_NOSTORE
       if (M > 0) return;
+#endif
+#ifdef RS_Q_LINES
+      // fp32 rows: the block was computed with the operands swapped (like a value block), a lane owns column l31 of 16 rows — every store
+      // instruction writes two whole 128-byte lines (32-byte row pieces from the other orientation: 4x the write requests per byte)
+      if (knd == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r_ = cbm + 8 * q + 4 * half + j;
+          if (r_ < M) C[(size_t)r_ * ldc + cbv * 32 + l31] = x[j];
+        }
+        return;
+      }
 #endif
       if (knd == 0) {
 #ifdef RS_ABL_SAMEADDR
@@ -1011,7 +1028,7 @@ __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restri
       const op_t* w1 = rs_ring + slot * RS_BLK + (half * 32 + l31) * 8;    // [p][ks][half][col][8]
       const int nslot = (slot + 2) & 3;
       f32x16 acc;
-      if (kind != 2) {
+      if (kind == 1 || (kind == 0 && RS_Q_ORI == 0)) {
         const float* bp = bs + cb * 32 + 4 * half;                         // register r <-> column (r & 3) + 8 (r >> 2) + 4 half
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -1050,10 +1067,10 @@ __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restri
         }
       };
       RS_STAMP(4)
-      if (kind == 2) kloop(std::integral_constant<int, 1>{});
+      if (kind == 2 || (kind == 0 && RS_Q_ORI == 1)) kloop(std::integral_constant<int, 1>{});
       else kloop(std::integral_constant<int, 0>{});
       RS_STAMP(1)
-      const int e_cur = kind == 0 ? 4 : 8;
+      const int e_cur = kind == 0 ? (RS_Q_ORI ? 16 : 4) : 8;
       // the block of the NEXT phase (requested in the previous phase's k-steps 0-3) must have landed; younger requests of this wave, in
       // issue order: the previous phase's stores, then this phase's RS_PIECES pieces.  vmcnt counts in order; stores count.
       {
@@ -1061,7 +1078,8 @@ __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restri
         if (younger == 0) __builtin_amdgcn_s_waitcnt(0x0070);                          // vmcnt(0) lgkmcnt(0)
         else if (younger == 4) __builtin_amdgcn_s_waitcnt(0x0070 | 4);
         else if (younger == 8) __builtin_amdgcn_s_waitcnt(0x0070 | 8);
-        else __builtin_amdgcn_s_waitcnt(0x0070 | 12);
+        else if (younger == 12) __builtin_amdgcn_s_waitcnt(0x0070 | 12);
+        else __builtin_amdgcn_s_waitcnt(0x4070 | 4);                                   // 20 = 1 << 4 | 4 (vmcnt bits 3:0 and 15:14)
       }
       __builtin_amdgcn_s_barrier();                   // taken BEFORE this block's stores: they leave underneath the next block's MFMAs
       RS_STAMP(2)
@@ -1089,13 +1107,14 @@ __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restri
 int launch_inproj_rs(const float* A, int lda, const void* Wblk, const float* bias, float* C, int ldc, int M, int N, void* kv_img,
                      int kv_col0, int kv_n, const KvClassHost* kv_cls, hipStream_t st) {
   if (M <= 0) return CTRLSIM_OK;
-  if (!A || !Wblk || !kv_img || !kv_cls || (lda & 3) || (ldc & 3) || (N & 31) || N > 32 * RS_MAXB || (kv_col0 & 31) || N != kv_col0 + 2 * DM ||
-      (kv_col0 && !C) || kv_n < 1 || kv_n > MAXC)
-    return CTRLSIM_EINVAL;
+  if (!A || !Wblk || (lda & 3) || (ldc & 3) || (N & 31) || N < 64 || N > 32 * RS_MAXB) return CTRLSIM_EINVAL;
+  if (kv_img ? (!kv_cls || (kv_col0 & 31) || N != kv_col0 + 2 * DM || (kv_col0 && !C) || kv_n < 1 || kv_n > MAXC) : (!C || kv_col0 != N))
+    return CTRLSIM_EINVAL;                               // kv_img == NULL: a plain Linear, every block leaves as fp32 rows
   KvImg kv;
   kv.img = static_cast<op_t*>(kv_img); kv.k_col0 = kv_col0; kv.n = 0;
-  int row0 = 0;
-  for (int k = 0; k < kv_n; ++k) {
+  int row0 = kv_img ? 0 : M;
+  kv.c[0] = KvClass{0, 32, 32, 0, 1, 0};                 // (read, never used, by the kernel's placement code when there are no images)
+  for (int k = 0; kv_img && k < kv_n; ++k) {
     const KvClassHost& c = kv_cls[k];
     if (c.B <= 0) continue;
     if ((c.L & 3) || c.L < 32 || (c.Lreg & 3) || c.Lreg > c.L || c.Lreg <= 0 || (c.rep_k0 & 63) ||
@@ -1117,9 +1136,10 @@ int launch_inproj_rs(const float* A, int lda, const void* Wblk, const float* bia
   const long shares = (long)n_rb * (N / 32) / 4;         // at least four (job, block) phases per workgroup
   hipLaunchKernelGGL(inproj_rs_kernel, dim3(shares < 1 ? 1 : (shares < cus ? (int)shares : cus)), dim3(512), RS_LDS_BYTES, st, A, lda,
                      static_cast<const op_t*>(Wblk), bias, C, ldc, M, N / 32, kv);
-  const double MN = (double)M * N, kvN = 2.0 * DM;
+  const double MN = (double)M * N, kvN = kv_img ? 2.0 * DM : 0.0;
   prof_after(PROF_GEMM, 2.0 * MN * (double)DM, st,
-             4.0 * (double)M * DM + 4.0 * (double)M * (N - kvN) + 2.0 * NPL * (double)M * kvN + 2.0 * NPL * (double)N * DM, PKIND_GEMM_QKV_KV);
+             4.0 * (double)M * DM + 4.0 * (double)M * (N - kvN) + 2.0 * NPL * (double)M * kvN + 2.0 * NPL * (double)N * DM,
+             kv_img ? PKIND_GEMM_QKV_KV : PKIND_GEMM_PLAIN);
   return ctrlsim_launch_status();
 }
 #else

@@ -292,7 +292,8 @@ int ctrlsim_gemm_nt_kv(const float* A, int lda, const void* W3, int n_total, int
                        int M, int N, int K, void* kv_img, int kv_L, int kv_nkt, int kv_col0, hipStream_t stream);
 /* The same operation through the row-stationary kernel (two-fp16-plane scheme only; CTRLSIM_EINVAL otherwise): Wblk = the weight as
  * 32-column operand blocks (ctrlsim_amd/pack.py:row_blocks of rows [n0, n0 + N) of the weight; N = kv_col0 + 512, a multiple of 32, at
- * most 768), bias = its N entries; K = 256.  Every activation row is read once; outputs as for ctrlsim_gemm_nt_kv. */
+ * most 768), bias = its N entries; K = 256.  Every activation row is read once; outputs as for ctrlsim_gemm_nt_kv.  kv_img == NULL: a
+ * plain Linear (N a multiple of 32 in [64, 768]; kv_L / kv_nkt / kv_col0 ignored), all N columns as fp32 rows of C. */
 int ctrlsim_gemm_kv_blocks(const float* A, int lda, const void* Wblk, const float* bias, float* C, int ldc, int M, int N,
                            void* kv_img, int kv_L, int kv_nkt, int kv_col0, hipStream_t stream);
 /* Post-LN feed-forward block of nn.TransformerEncoderLayer / DecoderLayer as one kernel:

@@ -199,6 +199,27 @@ def test_row_stationary_linear_with_kv_images(B, L, col0):
         assert (ktail == 0).all()
 
 
+@pytest.mark.parametrize("M,N", [(300, 256), (65536, 256), (70001, 512), (16385, 64)])
+def test_row_stationary_plain_linear(M, N):
+    """ctrlsim_gemm_kv_blocks without images: a plain Linear(256 -> N) through the row-stationary kernel, against float64."""
+    lib = _lib.lib()
+    if lib.ctrlsim_split_scheme() != 1:
+        pytest.skip("two-fp16-plane scheme only")
+    g = torch.Generator().manual_seed(M + N)
+    A = (torch.randn(M, 256, generator=g) * torch.exp(0.3 * torch.randn(M, 1, generator=g))).to(DEV)
+    W = torch.randn(N, 256, generator=g) * 0.1
+    b = torch.randn(N, generator=g).to(DEV)
+    from ctrlsim_amd.pack import row_blocks
+    blocks = torch.from_numpy(row_blocks(W.numpy(), 1).view(np.int16).copy()).to(DEV)
+    C = torch.full((M, N + 4), float("nan"), device=DEV)
+    p = _lib.ptr
+    _lib.check(lib.ctrlsim_gemm_kv_blocks(p(A), 256, p(blocks), p(b), p(C), C.stride(0), M, N, None, 0, 0, 0, _lib.stream_ptr()))
+    ref = A.double() @ W.to(DEV).double().T + b.double()
+    scale = (A.double().abs() @ W.to(DEV).double().abs().T + 1).max().item()
+    assert (C[:, :N].double() - ref).abs().max().item() < 2e-5 * max(1.0, scale / 50)
+    assert torch.isnan(C[:, N:]).all()                        # columns beyond N untouched
+
+
 def test_layernorm_and_in_place():
     g = torch.Generator().manual_seed(1)
     X = torch.randn(1003, 256, generator=g).to(DEV) * 3 + 1

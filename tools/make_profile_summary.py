@@ -9,7 +9,7 @@ import csv
 import json
 import re
 
-GEMM_KEYS = ("gemm_nt_bf16x6", "gemm_ws256", "ffn_fused_bf16x6")
+GEMM_KEYS = ("gemm_nt_bf16x6", "gemm_ws256", "inproj_rs", "ffn_fused_bf16x6")
 ATTN_KEYS = ("attention_bf16x6",)
 
 
@@ -85,7 +85,7 @@ def main():
               "## Agreement with bench.py's live HIP-event timing (timed steps only)", "",
               "| class | rocprofv3 avg per launch (warm-up + timed) | bench.py HIP-event avg per launch (main + side streams) | launches (rocprof / bench) | share of kernel time |",
               "|---|---|---|---|---|",
-              f"| Linear class: gemm_ws256_kernel + gemm_nt_bf16x6_kernel (all variants) + ffn_fused_bf16x6_kernel | {gt / gc / 1e6:.4f} ms | {r_avg:.4f} ms | {gc} / {r_n} | {100 * gt / tot:.1f} % |",
+              f"| Linear class: inproj_rs_kernel + gemm_ws256_kernel + gemm_nt_bf16x6_kernel (all variants) + ffn_fused_bf16x6_kernel | {gt / gc / 1e6:.4f} ms | {r_avg:.4f} ms | {gc} / {r_n} | {100 * gt / tot:.1f} % |",
               f"| attention_bf16x6_kernel (causal + key-padding) | {at / ac / 1e6:.4f} ms | {o_avg:.4f} ms | {ac} / {o_n} | {100 * at / tot:.1f} % |",
               "",
               f"(rocprofv3 counts the warm-up step too: {scale:.2f}x the timed launches.)",
@@ -162,7 +162,7 @@ def main():
                      "hbm_over_algorithmic": (f + w) * 1024 / n / alg}
     out["_command"] = open(f"gpurun_out/pmc_{R}/command.txt").read().strip()
     out["_how"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (no tracing flags) over the command above "
-                   "(tools/pmc_traffic.sh; the Linear class = gemm_ws256_kernel / gemm_nt_bf16x6_kernel variants + ffn_fused_bf16x6_kernel); counter units of "
+                   "(tools/pmc_traffic.sh; the Linear class = inproj_rs_kernel / gemm_ws256_kernel / gemm_nt_bf16x6_kernel variants + ffn_fused_bf16x6_kernel); counter units of "
                    "1024 B; calibrated in round 1 on micro-launches with known byte counts (FFN-1 shape 147456x1024x256: WRITE_SIZE = 603,979,776 B = "
                    "M*N*4 exactly; FETCH_SIZE = 156.5 MB vs 151.0 MB of A + 1.6 MB of weight planes) => factor 1.0 for these kernels' access "
                    "patterns (64-byte row segments / 16-byte DMA pieces); the guide's x2 applies to 128-byte wide streaming reads and would "

@@ -133,6 +133,13 @@ if 'gemm' in FILT or not FILT:
         report('gemm qkv + K/V images, quarter rows', sustained(f), 2.0 * Mq * 768 * 256)
         f = lambda: lib.ctrlsim_gemm_kv_blocks(p(A), 256, p(blocks), p(b), p(Cm), 768, Mq, 768, p(img), L, nkt, 256, st)
         report('gemm qkv + K/V images, row-stationary, quarter rows', sustained(f), 2.0 * Mq * 768 * 256)
+    if NPROD == 3:
+        Wq = torch.randn(256, 256) * 0.05; bq = torch.randn(256, device=DEV)
+        blq = torch.from_numpy(row_blocks(Wq.numpy(), 1).view(np.int16).copy()).to(DEV)
+        Cq = torch.empty(M, 256, device=DEV)
+        f = lambda: lib.ctrlsim_gemm_kv_blocks(p(A), 256, p(blq), p(bq), p(Cq), 256, M, 256, None, 0, 0, 0, st)
+        report('gemm cross-q, row-stationary', sustained(f), 2.0 * M * 256 * 256)
+        del Cq
     del A, Cm, img
 if 'ffn' in FILT or not FILT:
     F = 1024
