@@ -101,7 +101,7 @@ enum { OPT_ATTN_IMPL = 0, OPT_GEMM_IMPL = 1,   // 0 = f32-input MFMA, 1 = split-
                                                  // products (default), 0 = three bf16 planes, six products (full fp32 exponent range)
        OPT_MAP_MFMA = 5,                         // map-encoder point pooling: 1 = matrix-pipe kernel (two-fp16-plane split only), 0 = fp32 VALU kernel
        OPT_GEMM_WS = 6,                          // Linear(256 -> 256 G) bit mask (gemm_bf16x6.hip): 1 / 2 = weight-stationary streaming kernel for large / small
-                                                 // launches, 4 = also for the K / V-image Linears, 8 = those through the ROW-stationary kernel (round 4)
+                                                 // launches, 4 = also for the K / V-image Linears, 8 = those through the ROW-stationary kernel (round 4), 16 = tall plain Linears too (off)
        OPT_ATTN_TBL = 7,                         // causal self-attention over the token rows: 1 = visibility masks from the per-class table
                                                  // (one v_cndmask per score), 0 = masks built per query in the kernel
        OPT_LAST_KV = 8,                          // last decoder layer of a rollout pass: 1 = in_proj of keys / values only + queries of the queried rows

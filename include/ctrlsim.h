@@ -372,7 +372,8 @@ int ctrlsim_attn_class_prof(int enable, unsigned long long* host_out);
  * Key 6 = weight-stationary kernel for the Linear(256 -> 256 G) shapes, bit mask: 1 = launches of at least two 32-row blocks per
  * compute unit, 2 = smaller launches, 4 = the in_proj Linears with K / V-image epilogue, 8 = those through the ROW-stationary kernel
  * (rows in registers, 32-column weight blocks streamed through LDS, every activation row read once; needs the block images of
- * pack.py:row_blocks in the packed weights) inside the forward (default 15; 0 = tiled kernel everywhere).
+ * pack.py:row_blocks in the packed weights) inside the forward, 16 = the tall plain 256 -> 256 Linears through it as well (measured
+ * slower: off) (default 15; 0 = tiled kernel everywhere).
  * Key 7 = causal self-attention over the token rows takes its visibility masks from the per-class table (default 1; 0 = built per query).
  * Key 8 = the last decoder layer of a rollout pass projects keys / values of every token and queries of the queried tokens only (default 1;
  * 0 = the whole in_proj for every token, then a gather). */
