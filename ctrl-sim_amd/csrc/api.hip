@@ -76,7 +76,7 @@ void prof_after(int cls, double flops, hipStream_t st, double bytes, int kind) {
   g_recs.push_back(ProfRec{g_pending[cls], b, cls, flops, bytes, st, 2 * kind + (g_prof_few ? 1 : 0)});
 }
 
-static int g_options[OPT_COUNT] = {1, 1, 0, 1, 1, 0, 15, 1, 1};
+static int g_options[OPT_COUNT] = {1, 1, 0, 1, 1, 0, 15, 1, 1, 1};
 // Guard counter (common.h): the counter the CALLER bound with ctrlsim_bind — an engine's own 4 bytes of device memory — or,
 // for callers that never bind one, a library-owned word allocated on first use on the then-current device.
 static int* g_guard = nullptr;

@@ -132,8 +132,13 @@ __global__ __launch_bounds__(256) void attn_mask_table_kernel(TblBatch tb) {
 #else
 #define ATT_OCC(TBL_) 3
 #endif
-template <int MODE, bool PRE, bool TBL = false>
-__global__ __launch_bounds__(256, ATT_OCC(TBL)) void attention_bf16x6_kernel(
+// DIR (few-query launches: the second pass, the last decoder layer on the queried rows, the K/V-cached steps): ONE wave per workgroup
+// = one 32-query group of one (context, head), and the K / V^T fragments come straight from the tile images in global memory — the image
+// layout IS the fragment layout (a lane's 16 / 8 bytes are contiguous), so a tile that a single wave uses once has no business in LDS.
+// The 256-thread form keeps one live wave and three idle ones per workgroup there, 33 KB of LDS each: three live waves per compute unit
+// for a kernel whose whole job is to stream K / V; this form has no stage memory, no barriers that matter, ~16 waves per compute unit.
+template <int MODE, bool PRE, bool TBL = false, bool DIR = false>
+__global__ __launch_bounds__(DIR ? 64 : 256, DIR ? 4 : ATT_OCC(TBL)) void attention_bf16x6_kernel(
     const float* __restrict__ Qb_, int ldq, const float* __restrict__ K, const float* __restrict__ V, int ldkv,
     float* __restrict__ Ob_, int ldo, const unsigned char* __restrict__ key_pad_, float scale_log2e, int variant, AttnBatch ab) {
   const unsigned long long t_start = ab.cprof ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -170,11 +175,14 @@ __global__ __launch_bounds__(256, ATT_OCC(TBL)) void attention_bf16x6_kernel(
 #else
   constexpr int NBUF = 2;
 #endif
-  constexpr int BUF_ = BUF, NBUF_ = NBUF;
+  static_assert(!DIR || (PRE && !TBL), "the streaming form reads pre-split images and builds its masks in the kernel");
+  constexpr int PADSZ = 2 * KT6 + 8;             // 16-bit elements of a stage's key-padding bias block
+  constexpr int BUF_ = DIR ? PADSZ : BUF, NBUF_ = NBUF;
+  constexpr int ARENA = DIR ? 2 * PADSZ + 32 * 33 * 2 : NBUF_ * BUF_;     // DIR: two bias blocks, then the 32 x 33 floats of the output transpose
 #ifndef ATT_TBL_WG5
   __shared__ int blk_tmax[4];
 #endif
-  static_assert(2 * BUF * 2 >= 4 * 32 * 33 * 4, "output transpose must fit");
+  static_assert(DIR || 2 * BUF * 2 >= 4 * 32 * 33 * 4, "output transpose must fit");
 
   // XCD-aware work map: workgroups are dealt round-robin to the 8 XCDs (linear id % 8) and each XCD has its own L2, so all
   // query blocks of one (context, head) — which re-read the same K/V tiles — are given to ONE XCD: head = linear id % 8.
@@ -184,16 +192,17 @@ __global__ __launch_bounds__(256, ATT_OCC(TBL)) void attention_bf16x6_kernel(
   const int h = lin & (NHEAD - 1), j = lin >> 3;
   const int qx = j % nqb, b = j / nqb;
   const int qblk = (MODE == MODE6_CAUSAL) ? (nqb - 1 - qx) : qx;
-  const int qb = qblk * 128;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int qb = qblk * (DIR ? 32 : 128);
+  const int tid = threadIdx.x, wave = DIR ? 0 : tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int A3 = 3 * A;
   const float NEG_INF = -__builtin_inff();
 
   // ---- tile 0's K/V image pieces are requested before anything else (PRE: every query block needs tile 0; the request needs only
   // (context, head)): the L2 / HBM latency of the first tile then runs underneath the Q loads and the mask bookkeeping
   const op_t* img = PRE ? reinterpret_cast<const op_t*>(K) + (cd.img_off + ((size_t)b * NHEAD + h) * (size_t)cd.kv_bs) * KV_IMG : nullptr;
-  __shared__ __attribute__((aligned(16))) op_t arena[NBUF_ * BUF_];
+  __shared__ __attribute__((aligned(16))) op_t arena[ARENA];
   auto dma_tile = [&](int tile, int buf) {
+    if (DIR) return;
     const op_t* src = img + (size_t)tile * KV_IMG + tid * 8;
 #pragma unroll
     for (int i = 0; i < KV_PIECES; ++i) {
@@ -269,7 +278,7 @@ __global__ __launch_bounds__(256, ATT_OCC(TBL)) void attention_bf16x6_kernel(
     tq_max_w = __builtin_amdgcn_readfirstlane(tmax);
     if (lane == 0) blk_tmax[wave] = tmax;
     __syncthreads();
-    const int bt = max(max(blk_tmax[0], blk_tmax[1]), max(blk_tmax[2], blk_tmax[3]));
+    const int bt = DIR ? tq_max_w : max(max(blk_tmax[0], blk_tmax[1]), max(blk_tmax[2], blk_tmax[3]));
     k_end = __builtin_amdgcn_readfirstlane(min(Lk, (bt + 1) * A3));
     rep_need = __builtin_amdgcn_readfirstlane(min(rep_keys, (bt + 1) * 3));
   }
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(256, ATT_OCC(TBL)) void attention_bf16x6_kernel(
     }
     }
     if (NBUF != 3 && MODE == MODE6_KEYPAD && tid < KT6) {
-      float* pb_ = reinterpret_cast<float*>(Vd + NPL * V_PLANE);
+      float* pb_ = DIR ? reinterpret_cast<float*>(arena + buf * PADSZ) : reinterpret_cast<float*>(Vd + NPL * V_PLANE);
       pb_[tid] = ppad;
       // a 32-key sub-tile without a padded key (the rule: every polyline and vehicle row of a scene is a valid key) skips the bias
       // reads and adds in the loop below
@@ -373,7 +382,7 @@ __global__ __launch_bounds__(256, ATT_OCC(TBL)) void attention_bf16x6_kernel(
     asm volatile("s_waitcnt vmcnt(%0) ; KV-DMA of tile 0 landed" :: "n"(KV_PIECES) : "memory");
   } else {
 #ifndef ATT_DMA_BUILTIN
-  if (PRE) asm volatile("s_waitcnt vmcnt(0) ; KV-DMA landed" ::: "memory");
+  if (PRE && !DIR) asm volatile("s_waitcnt vmcnt(0) ; KV-DMA landed" ::: "memory");
 #endif
   }
   __syncthreads();
@@ -392,9 +401,10 @@ __global__ __launch_bounds__(256, ATT_OCC(TBL)) void attention_bf16x6_kernel(
     const bool rep_tile = it >= n_reg;               // wave-uniform: a tile of representative keys (compact contexts)
     const int k0 = it * KT6;
     TSTAMP(0) TCOUNT(7)
-    const op_t* Ks = arena + cur * BUF;
+    // DIR: the fragments are read from the tile image itself (same layout as a stage: the DMA copies images verbatim)
+    const op_t* Ks = DIR ? img + (size_t)(tile_k0(it) / KT6) * KV_IMG : arena + cur * BUF;
     const op_t* Vs = Ks + NPL * K_PLANE;
-    const float* padbias = reinterpret_cast<const float*>(Vs + NPL * V_PLANE);
+    const float* padbias = DIR ? reinterpret_cast<const float*>(arena + cur * PADSZ) : reinterpret_cast<const float*>(Vs + NPL * V_PLANE);
     int padflag[2] = {1, 1};
 #ifndef ATT_NO_PADSKIP      // (A/B switch of tools/microbench: every sub-tile takes the bias path)
     if (MODE == MODE6_KEYPAD) {
@@ -656,9 +666,9 @@ __global__ __launch_bounds__(256, ATT_OCC(TBL)) void attention_bf16x6_kernel(
       // tile it+1 (requested one iteration ago) must have landed; tile it+2's pieces (this iteration's) stay in flight
       if (more2) asm volatile("s_waitcnt vmcnt(%0) ; KV-DMA of the next tile landed" :: "n"(KV_PIECES) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) ; KV-DMA landed" ::: "memory");
-    } else if (PRE) asm volatile("s_waitcnt vmcnt(0) ; KV-DMA landed" ::: "memory");
+    } else if (PRE && !DIR) asm volatile("s_waitcnt vmcnt(0) ; KV-DMA landed" ::: "memory");
 #endif
-    __syncthreads();
+    if (!DIR || MODE == MODE6_KEYPAD) __syncthreads();       // DIR: only the key-padding bias block goes through LDS
     TSTAMP(5)
   }
 #ifdef ATT_TIMING
@@ -674,7 +684,7 @@ __global__ __launch_bounds__(256, ATT_OCC(TBL)) void attention_bf16x6_kernel(
     l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
   }
   const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-  float* ot = reinterpret_cast<float*>(arena) + wave * (32 * 33);
+  float* ot = DIR ? reinterpret_cast<float*>(arena + 2 * PADSZ) : reinterpret_cast<float*>(arena) + wave * (32 * 33);
 #pragma unroll
   for (int r = 0; r < 16; ++r) ot[l31 * 33 + mfma_row(r, half)] = oa[r] * inv;
   __builtin_amdgcn_wave_barrier();
@@ -965,6 +975,12 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
   int wg = 0;
   double flops = 0.0, bytes = 0.0;
   bool use_tbl = mode == MODE6_CAUSAL && variant == 0 && ctrlsim_option(OPT_ATTN_TBL) != 0;
+  // few-query launches (at most three 32-query groups per context and head: the second pass, the last layer on the queried rows, the
+  // K/V-cached steps): the streaming form of the kernel, one wave per workgroup
+  bool dir = ctrlsim_option(OPT_ATTN_DIRECT) != 0;
+  for (int k = 0; k < n; ++k)
+    if (cls[k].B > 0 && cls[k].Lq > 96) dir = false;
+  if (dir) use_tbl = false;
   for (int k = 0; k < n; ++k) {
     AttnClassHost c = cls[k];
     if (c.B <= 0 || c.Lq <= 0) continue;
@@ -974,7 +990,7 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
       return CTRLSIM_EINVAL;
     if (c.rep_keys > 0 && (mode != MODE6_CAUSAL || variant || c.rep_mult < 1 || c.Lk % (3 * c.A) || c.rep_pos0 % (3 * c.A)))
       return CTRLSIM_EINVAL;
-    const int qblocks = (c.Lq + 127) / 128;
+    const int qblocks = dir ? (c.Lq + 31) / 32 : (c.Lq + 127) / 128;
     // mask-table kernel: every class brings its table, the query rows are the token rows, CtRL-Sim mask, keys = the whole row layout
     use_tbl = use_tbl && c.mask_tbl && !c.q_pos && (c.rep_keys == 0 || c.rep_pos0 == c.Lk);
     ab.c[ab.n++] = AttnClass{c.q_row0 * ldq, c.o_row0 * ldo, c.img_tile0, c.pad_off, c.q_bs, c.o_bs, (long)c.nkt, c.q_pos,
@@ -985,11 +1001,17 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
     bytes += (double)c.B * (8.0 * DM * c.Lq + 4.0 * NPL * DM * (c.Lk + c.rep_keys));   // Q in + O out (fp32), K and V images (NPL planes)
   }
   if (ab.n == 0) return CTRLSIM_OK;
-  dim3 g(wg), blk(256);
+  dim3 g(wg), blk(dir ? 64 : 256);
   const float scale = 0.17677669529663687f * 1.4426950408889634f;
   const float* imgf = static_cast<const float*>(img);
   prof_before(PROF_ATTN, st);
-  if (mode == MODE6_CAUSAL && use_tbl) {
+  if (dir && mode == MODE6_CAUSAL) {
+    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, true, false, true>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad,
+                       scale, variant, ab);
+  } else if (dir) {
+    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, true, false, true>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad,
+                       scale, 0, ab);
+  } else if (mode == MODE6_CAUSAL && use_tbl) {
     hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, true, true>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale,
                        variant, ab);
   } else if (mode == MODE6_CAUSAL) {

@@ -105,7 +105,9 @@ enum { OPT_ATTN_IMPL = 0, OPT_GEMM_IMPL = 1,   // 0 = f32-input MFMA, 1 = split-
        OPT_ATTN_TBL = 7,                         // causal self-attention over the token rows: 1 = visibility masks from the per-class table
                                                  // (one v_cndmask per score), 0 = masks built per query in the kernel
        OPT_LAST_KV = 8,                          // last decoder layer of a rollout pass: 1 = in_proj of keys / values only + queries of the queried rows
-       OPT_COUNT = 9 };
+       OPT_ATTN_DIRECT = 9,                      // few-query attention launches (<= 96 queries per context): 1 = streaming form, one wave per
+                                                 // workgroup, K / V fragments straight from the tile images (no LDS staging)
+       OPT_COUNT = 10 };
 // run-time view of the selected split (dispatch.hip): planes per operand, 16-bit elements per (context, head, tile) K/V image
 int split_npl();
 inline size_t split_kimg() { return (size_t)2 * split_npl() * 64 * 32; }

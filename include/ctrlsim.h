@@ -376,7 +376,10 @@ int ctrlsim_attn_class_prof(int enable, unsigned long long* host_out);
  * slower: off) (default 15; 0 = tiled kernel everywhere).
  * Key 7 = causal self-attention over the token rows takes its visibility masks from the per-class table (default 1; 0 = built per query).
  * Key 8 = the last decoder layer of a rollout pass projects keys / values of every token and queries of the queried tokens only (default 1;
- * 0 = the whole in_proj for every token, then a gather). */
+ * 0 = the whole in_proj for every token, then a gather).
+ * Key 9 = attention launches with at most 96 queries per context (second pass, last layer on the queried rows, K/V-cached steps) through
+ * the streaming form of the kernel: one wave per (context, head, 32 queries), K / V fragments read straight from the tile images
+ * (default 1; 0 = the LDS-staged 128-query form for every launch). */
 int ctrlsim_set_option(int key, int value);
 /* Operand split compiled into the library (csrc/split.h): 1 = two fp16 planes / three products (weights pre-scaled by 2^8), 0 = three
  * bf16 planes / six products.  ctrlsim_amd/pack.py packs weight planes and sizes the K/V images accordingly. */

@@ -453,6 +453,96 @@ def test_attention_with_mask_tables_equals_in_kernel_masks_and_float64(Actx, T):
         assert (O_old - O_new).abs().max().item() < 5e-6
 
 
+@pytest.mark.parametrize("Actx,T,which", [(24, 32, "last3"), (24, 32, "state"), (8, 32, "last3"), (12, 9, "last3"), (5, 32, "state"),
+                                          (16, 20, "mixed"), (4, 3, "last3")])
+def test_attention_few_query_streaming_form(Actx, T, which):
+    """Round 4, option 9: launches with at most 96 queries per context (the second pass, the last decoder layer on the queried rows, the
+    K/V-cached steps) run one wave per (context, head, 32 queries) with the K / V fragments read straight from the tile images.  Same
+    arithmetic in the same order as the LDS-staged form: bit-identical; and against float64 with the mask written from the rules.
+    Plain and compact contexts; the queries are the last step's tokens (representative's included), its state tokens, or a mix of steps."""
+    lib, st, p = _lib.lib(), _lib.stream_ptr(), _lib.ptr
+    B, H = 3, 8
+    rep = 1 if Actx < 24 else 0
+    Areg = Actx - rep
+    mult = 24 - Areg
+    Lreg = T * 3 * Areg
+    L = Lreg + rep * 3 * T
+    rep_k0 = (Lreg + 63) // 64 * 64
+    nkt = (Lreg + 63) // 64 + rep * ((3 * T + 63) // 64)
+    g = torch.Generator().manual_seed(Actx * 1000 + T)
+    qkv = torch.randn(B, L, 768, generator=g).to(DEV)
+    Kp, Vp = qkv.data_ptr() + 1024, qkv.data_ptr() + 2048
+    key_pos = torch.tensor([i if i < Lreg else rep_k0 + (i - Lreg) for i in range(L)], dtype=torch.int32, device=DEV)
+    nel = 8192 if lib.ctrlsim_split_scheme() == 1 else 12288
+    img = torch.zeros(B * 8 * nkt * nel, dtype=torch.int16, device=DEV)
+    _kv_images(Kp, Vp, 768, L * 768, B, L, nkt, pos=key_pos, img=img)
+    rows_of = lambda t, ks: [(t * Areg + a) * 3 + k for a in range(Areg) for k in ks] + ([Lreg + 3 * t + k for k in ks] if rep else [])
+    if which == "last3":
+        rows = rows_of(T - 1, (0, 1, 2))
+    elif which == "state":
+        rows = rows_of(T - 1, (0,))
+    else:
+        rows = rows_of(T - 1, (1, 2)) + rows_of(T // 2, (0, 2)) + rows_of(0, (0,))
+    rows = rows[:96]
+    Lq = len(rows)
+    # the kernel takes query POSITIONS in the window layout: regular rows as they are, the representative's rows from rep_pos0 = Lreg on
+    q_pos = torch.tensor(rows, dtype=torch.int32, device=DEV)
+    Q = qkv[:, rows, :256].contiguous()
+    outs = []
+    for opt in (1, 0):
+        lib.ctrlsim_set_option(9, opt)
+        O = torch.full((B, Lq, 256), float("nan"), device=DEV)
+        try:
+            _lib.check(lib.ctrlsim_attention_compact(p(Q), 256, Lq * 256, p(img), nkt, p(O), 256, Lq * 256, p(q_pos), B, Lq, Lreg, Areg,
+                                                     rep * 3 * T, mult, Lreg, st))
+        finally:
+            lib.ctrlsim_set_option(9, 1)
+        outs.append(O)
+    vis, mul = _compact_masks(Areg, T, rep)
+    q = Q.view(B, Lq, H, 32).transpose(1, 2)
+    k, v = [qkv[..., i * 256:(i + 1) * 256].view(B, L, H, 32).transpose(1, 2) for i in (1, 2)]
+    sc = (q.double() @ k.double().transpose(-1, -2)) / math.sqrt(32)
+    visq, mulq = vis[rows].to(DEV)[None, None], mul[rows].to(DEV)[None, None]
+    sc = sc + math.log(mult) * mulq.double() if rep else sc
+    sc = sc.masked_fill(~visq, float("-inf"))
+    ref = (torch.softmax(sc, -1) @ v.double()).transpose(1, 2).reshape(B, Lq, 256)
+    assert torch.isfinite(outs[0]).all()
+    assert (outs[0].double() - ref).abs().max().item() < 2e-5
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("Lq,Lk", [(24, 224), (72, 224), (1, 67), (96, 130)])
+def test_attention_few_query_streaming_form_key_padding(Lq, Lk):
+    """The same for the key-padding mode over pre-split images (cross attention of the few-row passes)."""
+    lib, st, p = _lib.lib(), _lib.stream_ptr(), _lib.ptr
+    B, H = 4, 8
+    g = torch.Generator().manual_seed(Lq * 7 + Lk)
+    Q = torch.randn(B, Lq, 256, generator=g).to(DEV)
+    KV = torch.randn(B, Lk, 512, generator=g).to(DEV)
+    pad = (torch.rand(B, Lk, generator=g) < 0.3); pad[:, 0] = False
+    pad[1] = False                                             # a context without padded keys: the bias path is skipped
+    pad_d = pad.to(torch.uint8).to(DEV)
+    nkt = (Lk + 63) // 64
+    img = _kv_images(p(KV), KV.data_ptr() + 1024, 512, Lk * 512, B, Lk, nkt)
+    outs = []
+    for opt in (1, 0):
+        lib.ctrlsim_set_option(9, opt)
+        O = torch.full((B, Lq, 256), float("nan"), device=DEV)
+        try:
+            _lib.check(lib.ctrlsim_attention_presplit(0, p(Q), 256, Lq * 256, p(img), nkt, p(O), 256, Lq * 256, None, p(pad_d), B, Lq, Lk,
+                                                      24, st))
+        finally:
+            lib.ctrlsim_set_option(9, 1)
+        outs.append(O)
+    q = Q.view(B, Lq, H, 32).transpose(1, 2)
+    k = KV[..., :256].reshape(B, Lk, H, 32).transpose(1, 2)
+    v = KV[..., 256:].reshape(B, Lk, H, 32).transpose(1, 2)
+    vis = (~pad).to(DEV)[:, None, None, :].expand(B, 1, Lq, Lk)
+    ref = _attn_ref(q, k, v, vis).transpose(1, 2).reshape(B, Lq, 256)
+    assert (outs[0].double() - ref).abs().max().item() < 2e-5
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("A,T", [(24, 32), (6, 8), (24, 7)])
 def test_attention_presplit_images_match_in_kernel_split(A, T):
     """K/V split once into bf16 images + DMA staging must give bit-identical output to the in-kernel split, for the
