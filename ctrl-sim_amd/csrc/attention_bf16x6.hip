@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void attn_mask_table_kernel(TblBatch tb) {
 // The 256-thread form keeps one live wave and three idle ones per workgroup there, 33 KB of LDS each: three live waves per compute unit
 // for a kernel whose whole job is to stream K / V; this form has no stage memory, no barriers that matter, ~16 waves per compute unit.
 template <int MODE, bool PRE, bool TBL = false, bool DIR = false>
-__global__ __launch_bounds__(DIR ? 64 : 256, DIR ? 4 : ATT_OCC(TBL)) void attention_bf16x6_kernel(
+__global__ __launch_bounds__(DIR ? 64 : 256, DIR ? 3 : ATT_OCC(TBL)) void attention_bf16x6_kernel(
     const float* __restrict__ Qb_, int ldq, const float* __restrict__ K, const float* __restrict__ V, int ldkv,
     float* __restrict__ Ob_, int ldo, const unsigned char* __restrict__ key_pad_, float scale_log2e, int variant, AttnBatch ab) {
   const unsigned long long t_start = ab.cprof ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -391,6 +391,23 @@ __global__ __launch_bounds__(DIR ? 64 : 256, DIR ? 4 : ATT_OCC(TBL)) void attent
   unsigned long long tlast = __builtin_amdgcn_s_memtime();
 #endif
 
+  // DIR: the K and V^T fragments of sub-tile i + 1 are requested (global loads into a second register set) before sub-tile i is
+  // computed — one wave has nothing else to cover the two memory round trips per sub-tile with (272 us per launch in the K/V-cached
+  // phase without it).  The sub-tile after the last one re-reads the last one (never used).
+  opx8 nk0[NPL], nk1[NPL], nv0[NPL], nv1[NPL];
+  auto dir_fetch = [&](int it_, int sub_) {
+    const op_t* Ks_ = img + (size_t)(tile_k0(it_) / KT6) * KV_IMG;
+    const op_t* kr_ = Ks_ + (half * KT6 + sub_ * 32 + l31) * 8;
+    const op_t* vr_ = Ks_ + NPL * K_PLANE + ((sub_ * 8 + half) * HD + l31) * 4;
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+      nk0[p] = *reinterpret_cast<const opx8*>(kr_ + p * K_PLANE);
+      nk1[p] = *reinterpret_cast<const opx8*>(kr_ + p * K_PLANE + 2 * KT6 * 8);
+      nv0[p] = cat8(*reinterpret_cast<const opx4*>(vr_ + p * V_PLANE), *reinterpret_cast<const opx4*>(vr_ + p * V_PLANE + 2 * HD * 4));
+      nv1[p] = cat8(*reinterpret_cast<const opx4*>(vr_ + p * V_PLANE + 4 * HD * 4), *reinterpret_cast<const opx4*>(vr_ + p * V_PLANE + 6 * HD * 4));
+    }
+  };
+  if (DIR && n_it > 0) dir_fetch(0, 0);
   int cur = 0;
   for (int it = 0; it < n_it; ++it, cur = (NBUF == 3 ? (cur == 2 ? 0 : cur + 1) : cur ^ 1)) {
     const bool more = it + 1 < n_it;
@@ -415,6 +432,13 @@ __global__ __launch_bounds__(DIR ? 64 : 256, DIR ? 4 : ATT_OCC(TBL)) void attent
 
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
+      opx8 ck0[NPL], ck1[NPL], cv0[NPL], cv1[NPL];
+      if (DIR) {
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) { ck0[p] = nk0[p]; ck1[p] = nk1[p]; cv0[p] = nv0[p]; cv1[p] = nv1[p]; }
+        const bool last_sub = sub == 1 && it + 1 >= n_it;
+        dir_fetch(sub == 0 || last_sub ? it : it + 1, last_sub ? 1 : sub ^ 1);
+      }
       if (!wave_live) continue;
       const int ks0 = k0 + sub * 32;
       int t_lo = 0, t_hi = 0, ks_t0 = 0;
@@ -462,6 +486,7 @@ __global__ __launch_bounds__(DIR ? 64 : 256, DIR ? 4 : ATT_OCC(TBL)) void attent
         opx8 k0f[NPL], k1f[NPL];
 #pragma unroll
         for (int p = 0; p < NPL; ++p) {
+          if (DIR) { k0f[p] = ck0[p]; k1f[p] = ck1[p]; continue; }
           k0f[p] = *reinterpret_cast<const opx8*>(kr_ + p * K_PLANE);                  // k-step 0 (d 0-15)
           k1f[p] = *reinterpret_cast<const opx8*>(kr_ + p * K_PLANE + 2 * KT6 * 8);    // k-step 1 (d 16-31)
         }
@@ -639,6 +664,7 @@ __global__ __launch_bounds__(DIR ? 64 : 256, DIR ? 4 : ATT_OCC(TBL)) void attent
         opx8 v0f[NPL], v1f[NPL];
 #pragma unroll
         for (int p = 0; p < NPL; ++p) {
+          if (DIR) { v0f[p] = cv0[p]; v1f[p] = cv1[p]; continue; }
           const opx4 a0 = *reinterpret_cast<const opx4*>(vr_ + p * V_PLANE);
           const opx4 a1 = *reinterpret_cast<const opx4*>(vr_ + p * V_PLANE + 2 * HD * 4);
           const opx4 b0 = *reinterpret_cast<const opx4*>(vr_ + p * V_PLANE + 4 * HD * 4);

@@ -141,7 +141,8 @@ def _new_stream(dev, cu_mask=None):
     """A stream of its own; cu_mask (A/B experiments: "w0,w1,..." 32-bit hex words, bit i = compute unit i enabled) creates it with
     hipExtStreamCreateWithCUMask so that its kernels run on those compute units only (CU partition experiment)."""
     if not cu_mask:
-        return torch.cuda.Stream(device=dev)
+        prio = os.environ.get("CTRLSIM_SIDE_PRIORITY")           # A/B switch: queue priority of the side streams (-1 = high)
+        return torch.cuda.Stream(device=dev, priority=int(prio)) if prio else torch.cuda.Stream(device=dev)
     words = [int(w, 16) for w in cu_mask.split(",")]
     arr = (C.c_uint32 * len(words))(*words)
     hip = C.CDLL("libamdhip64.so")
