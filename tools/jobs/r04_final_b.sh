@@ -16,3 +16,4 @@ for n in ("driver_style","configs1","configs4_1gpu","rccl_world1"):
         print(n, "ERR", e)
 PY
 tail -2 $O/r04_facade_rate.txt
+bash tools/jobs/r04_hazard_final.sh 96 200
