@@ -120,6 +120,9 @@ def lib():
             fn = getattr(l, name)      # AttributeError if an ABI symbol is missing
             fn.restype = res
             fn.argtypes = args
+        for kv in filter(None, os.environ.get("CTRLSIM_OPTIONS", "").split(",")):   # "<option>=<value>,...": kernel A/B runs only
+            k, v = kv.split("=")
+            l.ctrlsim_set_option(int(k), int(v))
         _lib = l
     return _lib
 

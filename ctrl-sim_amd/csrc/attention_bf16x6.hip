@@ -175,7 +175,7 @@ __global__ __launch_bounds__(DIR ? 64 : 256, DIR ? 3 : ATT_OCC(TBL)) void attent
 #else
   constexpr int NBUF = 2;
 #endif
-  static_assert(!DIR || (PRE && !TBL), "the streaming form reads pre-split images and builds its masks in the kernel");
+  static_assert(!DIR || PRE, "the streaming form reads pre-split images");
   constexpr int PADSZ = 2 * KT6 + 8;             // 16-bit elements of a stage's key-padding bias block
   constexpr int BUF_ = DIR ? PADSZ : BUF, NBUF_ = NBUF;
   constexpr int ARENA = DIR ? 2 * PADSZ + 32 * 33 * 2 : NBUF_ * BUF_;     // DIR: two bias blocks, then the 32 x 33 floats of the output transpose
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(DIR ? 64 : 256, DIR ? 3 : ATT_OCC(TBL)) void attent
   }
 
   // TBL: this wave's query group in the class's mask table; does the wave hold representative queries (wave-uniform)
-  const int qgrp = __builtin_amdgcn_readfirstlane(qblk * 4 + wave), nsub_tbl = 2 * (int)kv_batch_stride;
+  const int qgrp = __builtin_amdgcn_readfirstlane(DIR ? qblk : qblk * 4 + wave), nsub_tbl = 2 * (int)kv_batch_stride;
   const bool wave_rep_q = TBL && rep_keys > 0 && __builtin_amdgcn_readfirstlane(qb + wave * 32 + 31) >= rep_pos0;
 
   f32x16 oa;                                       // O^T accumulator
@@ -1003,10 +1003,11 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
   bool use_tbl = mode == MODE6_CAUSAL && variant == 0 && ctrlsim_option(OPT_ATTN_TBL) != 0;
   // few-query launches (at most three 32-query groups per context and head: the second pass, the last layer on the queried rows, the
   // K/V-cached steps): the streaming form of the kernel, one wave per workgroup
+  // (option value 2, an experiment: EVERY launch in the streaming form — each 32-query wave then re-reads its K / V range from L2)
   bool dir = ctrlsim_option(OPT_ATTN_DIRECT) != 0;
+  const bool dir_all = ctrlsim_option(OPT_ATTN_DIRECT) == 2;
   for (int k = 0; k < n; ++k)
-    if (cls[k].B > 0 && cls[k].Lq > 96) dir = false;
-  if (dir) use_tbl = false;
+    if (cls[k].B > 0 && cls[k].Lq > 96 && !dir_all) dir = false;
   for (int k = 0; k < n; ++k) {
     AttnClassHost c = cls[k];
     if (c.B <= 0 || c.Lq <= 0) continue;
@@ -1031,7 +1032,10 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
   const float scale = 0.17677669529663687f * 1.4426950408889634f;
   const float* imgf = static_cast<const float*>(img);
   prof_before(PROF_ATTN, st);
-  if (dir && mode == MODE6_CAUSAL) {
+  if (dir && mode == MODE6_CAUSAL && use_tbl) {
+    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, true, true, true>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad,
+                       scale, variant, ab);
+  } else if (dir && mode == MODE6_CAUSAL) {
     hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, true, false, true>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad,
                        scale, variant, ab);
   } else if (dir) {

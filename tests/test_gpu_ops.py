@@ -96,7 +96,7 @@ def ws_option(request):
     """OPT_GEMM_WS (csrc/common.h): every Linear(256 -> 256 G) family through the tiled kernel, or through the weight-stationary one."""
     _lib.lib().ctrlsim_set_option(6, request.param)
     yield request.param
-    _lib.lib().ctrlsim_set_option(6, 7)
+    _lib.lib().ctrlsim_set_option(6, 15)                    # the default (common.h: weight-stationary + row-stationary in_proj)
 
 
 @pytest.mark.parametrize("M,relu,resid,ln", [(5000, False, False, False), (8191, False, True, False), (4097, True, False, False),

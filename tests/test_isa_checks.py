@@ -61,7 +61,7 @@ def test_simulator_kernels_use_no_scratch_memory(tmp_path):
 # together with a fresh run of the provocations, tools/jobs/r04_hazard_final.sh).
 PACKED_BUDGET = {"gemm": (12, 92), "attention": (16, 16), "sim": (15, 83), "embed": (0, 0), "map_encoder": (0, 9),
                  "gemm_bf16x6_s1": (136, 872), "gemm_bf16x6_s0": (128, 864), "ffn_fused_s1": (64, 256), "ffn_fused_s0": (64, 256),
-                 "attention_bf16x6_s1": (56, 56), "attention_bf16x6_s0": (56, 56)}
+                 "attention_bf16x6_s1": (64, 64), "attention_bf16x6_s0": (64, 64)}
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
