@@ -868,6 +868,9 @@ constexpr int RS_MAXB = 3 * DM / 32;                 // column blocks of the lar
 #else
 #define RS_Q_ORI 0
 #endif
+#ifndef RS_AHEAD
+#define RS_AHEAD 2         // weight blocks are requested this many phases ahead (2 or 3 with the four ring slots; 3 measured 1 % slower)
+#endif
 #ifndef RS_PF
 #define RS_PF 2            // LDS fragment prefetch distance in k-steps
 #endif
@@ -914,8 +917,13 @@ __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restri
     for (int j = 0; j < RS_PIECES; ++j) dma_piece(cb, 0, j);
 #pragma unroll
     for (int j = 0; j < RS_PIECES; ++j) dma_piece(c1, 1, j);
+#if RS_AHEAD == 3
+    const int c2 = c1 + 1 == nb ? 0 : c1 + 1;
+#pragma unroll
+    for (int j = 0; j < RS_PIECES; ++j) dma_piece(c2, 2, j);
+#endif
   }
-  int nxt = cb + 2 >= nb ? cb + 2 - nb : cb + 2;     // column block two phases ahead (nb >= 2)
+  int nxt = (cb + RS_AHEAD) % nb;                     // column block RS_AHEAD phases ahead
   const int kb0 = kv.k_col0 >> 5;                     // first key block; values from kb0 + 8
   constexpr int KIMG = 2 * NPL * 64 * HD, KPL = 64 * HD;
   int slot = 0;                                       // ring slot of the current block
@@ -979,7 +987,7 @@ __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restri
     RS_STAMP(0)
     // (the fragment loads above were waited for with everything older complete: the next block's pieces have landed for this wave)
     if (p == p_begin) __syncthreads();                // blocks 0 and 1 of the share are in LDS, the bias vector is visible
-    int e_prev = 0;                                   // stores this wave issued in the previous phase (0: waiting for the rows above drained them)
+    int e_prev = 0, e_prev2 = 0;                      // stores this wave issued in the previous phase / the one before (0: waiting for the rows above drained them)
     const int cb_last = (p_end - p) < (nb - cb) ? cb + (p_end - p) - 1 : nb - 1;   // last block of this job in the share
     // one quarter (quad q) of a finished block: fp32 row pieces / key plane entries / value plane entries; 1 / 2 / 2 stores
     auto epi_quad = [&](const f32x16& v, int knd, int cbv, int q) {
@@ -1026,7 +1034,7 @@ __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restri
     for (; cb <= cb_last; ++cb, ++p) {
       const int kind = cb < kb0 ? 0 : (cb < kb0 + NHEAD ? 1 : 2);          // 0 = fp32 rows, 1 = keys, 2 = values
       const op_t* w1 = rs_ring + slot * RS_BLK + (half * 32 + l31) * 8;    // [p][ks][half][col][8]
-      const int nslot = (slot + 2) & 3;
+      const int nslot = (slot + RS_AHEAD) & 3;
       f32x16 acc;
       if (kind == 1 || (kind == 0 && RS_Q_ORI == 0)) {
         const float* bp = bs + cb * 32 + 4 * half;                         // register r <-> column (r & 3) + 8 (r >> 2) + 4 half
@@ -1074,12 +1082,22 @@ __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restri
       // the block of the NEXT phase (requested in the previous phase's k-steps 0-3) must have landed; younger requests of this wave, in
       // issue order: the previous phase's stores, then this phase's RS_PIECES pieces.  vmcnt counts in order; stores count.
       {
-        const int younger = partial ? 0 : e_prev + RS_PIECES;
-        if (younger == 0) __builtin_amdgcn_s_waitcnt(0x0070);                          // vmcnt(0) lgkmcnt(0)
-        else if (younger == 4) __builtin_amdgcn_s_waitcnt(0x0070 | 4);
-        else if (younger == 8) __builtin_amdgcn_s_waitcnt(0x0070 | 8);
-        else if (younger == 12) __builtin_amdgcn_s_waitcnt(0x0070 | 12);
-        else __builtin_amdgcn_s_waitcnt(0x4070 | 4);                                   // 20 = 1 << 4 | 4 (vmcnt bits 3:0 and 15:14)
+        // RS_AHEAD == 3: the awaited block was requested TWO phases ago — behind it in the queue: that phase's stores, the last phase's pieces
+        // and stores, this phase's pieces; what must have drained by now was issued three phases ago, not two
+        const int younger = partial ? 0 : (RS_AHEAD == 3 ? e_prev2 + e_prev + 2 * RS_PIECES : e_prev + RS_PIECES);
+        switch (younger) {                                                             // vmcnt: bits 3:0 and 15:14
+          case 0: __builtin_amdgcn_s_waitcnt(0x0070); break;
+          case 4: __builtin_amdgcn_s_waitcnt(0x0070 | 4); break;
+          case 8: __builtin_amdgcn_s_waitcnt(0x0070 | 8); break;
+          case 12: __builtin_amdgcn_s_waitcnt(0x0070 | 12); break;
+          case 16: __builtin_amdgcn_s_waitcnt(0x4070 | 0); break;
+          case 20: __builtin_amdgcn_s_waitcnt(0x4070 | 4); break;
+          case 24: __builtin_amdgcn_s_waitcnt(0x4070 | 8); break;
+          case 28: __builtin_amdgcn_s_waitcnt(0x4070 | 12); break;
+          case 32: __builtin_amdgcn_s_waitcnt(0x8070 | 0); break;
+          case 36: __builtin_amdgcn_s_waitcnt(0x8070 | 4); break;
+          default: __builtin_amdgcn_s_waitcnt(0x8070 | 8); break;                      // 40 = 16 + 16 + 8 (query-line variant)
+        }
       }
       __builtin_amdgcn_s_barrier();                   // taken BEFORE this block's stores: they leave underneath the next block's MFMAs
       RS_STAMP(2)
@@ -1089,6 +1107,7 @@ __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restri
 #ifdef RS_TIMING
       rs_tacc[5] += 1;
 #endif
+      e_prev2 = e_prev;
       e_prev = e_cur;
       slot = (slot + 1) & 3;
       nxt = nxt + 1 == nb ? 0 : nxt + 1;
