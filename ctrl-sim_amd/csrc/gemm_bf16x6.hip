@@ -905,6 +905,10 @@ __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restri
   const int p_begin = (int)(total * blockIdx.x / gridDim.x), p_end = (int)(total * (blockIdx.x + 1) / gridDim.x);
   if (p_begin >= p_end) return;
   for (int i = tid; i < nb * 32; i += 512) bs[i] = bias ? bias[i] : 0.f;
+#ifdef RS_STAGGER
+  // experiment: workgroups start a quarter of a block's time apart (their store bursts then do not coincide chip-wide)
+  for (int i = 0; i < ((int)blockIdx.x & 3); ++i) __builtin_amdgcn_s_sleep(RS_STAGGER);
+#endif
   auto dma_piece = [&](int blk, int slot, int j) {
     const op_t* src = Wb + (size_t)blk * RS_BLK + (j * 512 + tid) * 8;
     op_t* dst = rs_ring + slot * RS_BLK + (j * 512 + wave * 64) * 8;       // wave-uniform LDS base (+ 16 B per lane)
