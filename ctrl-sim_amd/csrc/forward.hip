@@ -486,7 +486,7 @@ int gemm_kv(const ctrlsim_dims& d, const Batch& bt, const Ws& w, const Lin& L, c
       if (kc[k].Lreg < kc[k].L) tails[nt++] = KvTailHost{kc[k].B, kc[k].rep_k0, kc[k].L - kc[k].Lreg, kc[k].nkt, kc[k].tile0};
     }
     CHK(launch_kv_zero_tails(nt, tails, img, st));
-    if (L.wblk && ctrlsim_option(OPT_SPLIT) && (ctrlsim_option(OPT_GEMM_WS) & 8) && !(L.n0 & 31))
+    if (L.wblk && ctrlsim_option(OPT_SPLIT) && (ctrlsim_option(OPT_GEMM_WS) & 8) && !(L.n0 & 31) && !(n & 31) && n <= 3 * DM && !(kcol0 & 31))
       return launch_inproj_rs(x, DM, L.wblk, L.b, y, ldy, (int)rows, n, img, kcol0, bt.n, kc, st);
     return launch_gemm_nt_bf16x6_kvc(x, DM, L.w3(), L.ntot ? L.ntot : n, L.n0, L.b, nullptr, 0, y, ldy, (int)rows, n, DM, 0, nullptr,
                                      nullptr, img, kcol0, bt.n, kc, st);
