@@ -95,7 +95,11 @@ __global__ __launch_bounds__(256) void map_pool_kernel(int NP, int P, MapClasses
     float s8[8];
 #pragma unroll
     for (int h = 0; h < 8; ++h) s8[h] = w.cb[h];
+#ifdef MPV_ABL_NO_P1
+    for (int c = 0; c < (x > 1e30f ? DM : 0); ++c) {
+#else
     for (int c = 0; c < DM; ++c) {
+#endif
       const float d = fmaf(w.Wc[c * 4 + 2], e, fmaf(w.Wc[c * 4 + 1], y, fmaf(w.Wc[c * 4], x, w.Wc[c * 4 + 3])));
       const float hv = fmaxf(fmaf(d, rstd, w.ln_b[c]), 0.f);
 #pragma unroll
@@ -129,7 +133,11 @@ __global__ __launch_bounds__(256) void map_pool_kernel(int NP, int P, MapClasses
     for (int g = 0; g < 2; ++g) {
 #pragma unroll
       for (int h = 0; h < 8; ++h) acc[g][h] = 0.f;
+#ifdef MPV_ABL_NO_P2
+      if (g < g_here && w0 > 1e30f)
+#else
       if (g < g_here)
+#endif
         for (int p = q0[g]; p < q0[g + 1]; ++p) {
           const float d = fmaf(w2, pts[p][2], fmaf(w1, pts[p][1], fmaf(w0, pts[p][0], bb)));
           const float hv = fmaxf(fmaf(d, stat[p], be), 0.f);
@@ -149,8 +157,12 @@ __global__ __launch_bounds__(256) void map_pool_kernel(int NP, int P, MapClasses
     const int j = tid, h = j >> 5;
     // both polylines of the workgroup per pass over the folded matrix (its 256 KB come from L2 once, not once per polyline)
     float o0 = w.mb[j], o1 = o0;
+#ifdef MPV_ABL_NO_P3
+    for (int c = 0; c < (o0 > 1e30f ? DM : 0); ++c) {
+#else
 #pragma unroll 8
     for (int c = 0; c < DM; ++c) {
+#endif
       const float m = w.Mt[c * DM + j];
       o0 = fmaf(pooled[0][h][c], m, o0);
       o1 = fmaf(pooled[1][h][c], m, o1);
