@@ -99,7 +99,7 @@ enum { OPT_ATTN_IMPL = 0, OPT_GEMM_IMPL = 1,   // 0 = f32-input MFMA, 1 = split-
        OPT_FFN_FUSED = 3,                        // 1 = linear1-ReLU-linear2-residual-LayerNorm as one kernel (ffn_fused.hip)
        OPT_SPLIT = 4,                            // operand split of the split-operand kernels (csrc/split.h): 1 = two fp16 planes, three
                                                  // products (default), 0 = three bf16 planes, six products (full fp32 exponent range)
-       OPT_MAP_MFMA = 5,                         // map-encoder point pooling: 1 = matrix-pipe kernel (two-fp16-plane split only), 0 = fp32 VALU kernel
+       OPT_RESERVED_5 = 5,                       // (rounds 2-3: map-encoder pooling on the matrix pipe; the kernel lost and was removed in round 4)
        OPT_GEMM_WS = 6,                          // Linear(256 -> 256 G) bit mask (gemm_bf16x6.hip): 1 / 2 = weight-stationary streaming kernel for large / small
                                                  // launches, 4 = also for the K / V-image Linears, 8 = those through the ROW-stationary kernel (round 4), 16 = tall plain Linears too (off)
        OPT_ATTN_TBL = 7,                         // causal self-attention over the token rows: 1 = visibility masks from the per-class table

@@ -16,9 +16,8 @@
 // One workgroup per polyline: phase 1 thread-per-point (LN statistics + 8 scores, weights are wave-uniform scalar
 // loads), phase 2 thread-per-channel (softmax-weighted pooling), phase 3 thread-per-output (256x256 folded matrix,
 // stored transposed so the wave reads it coalesced from L2).
-#define SPLIT_MIX
-#define CTRLSIM_F16X3 1      // the MFMA variant below exists for the two-fp16-plane operand split only (split.h helpers)
-#include "split.h"
+#include "common.h"
+#include "classes.h"
 
 #define MAXNP 256
 
@@ -30,8 +29,6 @@ struct MapPoolWeights {
   const float* cb;      // [8]
   const float* Mt;      // [256(c),256(j)]
   const float* mb;      // [256]
-  const void* wfrag;    // MFMA variant: fp16 operand fragments of (Wc | ln_b)   [16 channel tiles][64 lanes][8]  (pack.py: map_frags)
-  const void* ufrag;    //               fp16 operand fragments of 2^8 U, hi / lo [8 k-steps][64 lanes][8]
 };
 
 // G polylines per workgroup (2 when a polyline has <= 128 points).  Only VISIBLE points are evaluated: a padded point has softmax
@@ -179,271 +176,9 @@ __global__ __launch_bounds__(256) void map_pool_kernel(int NP, int P, MapClasses
   }
 }
 
-// ---------------------------------------------------------------------------------------------------- MFMA variant
-// The same function on the matrix pipe (two-fp16-plane operand split, fp32 accumulation: fp32-class results).  What makes it fit:
-//   * the first layer + LayerNorm is a K = 5 contraction:  LN(.)_c * std = Wc[c].(x, y, e, 1) + ln_b[c] * std =: D[c, pt], and with
-//     R = relu(D) the hidden vector is h1 = rstd * R (rstd > 0) — rstd moves out of both products below;
-//   * the operand split lives in the K dimension of ONE v_mfma_f32_16x16x32_f16: the 13 used k-slots are the partial products
-//     w_hi x_hi, w_lo x_hi, w_hi x_lo (x, y, std), w_hi e, w_lo e, w_hi 1, w_lo 1 — so a 16 x 16 tile of D costs one instruction;
-//   * D is produced in BOTH register layouts the two contractions need, by swapping the MFMA operands:  D^T = Wc X^T gives
-//     lane = point / registers = channels (the B operand of  scores^T = U^T R, contraction over channels), D = X Wc^T gives
-//     lane = channel / registers = points (the B operand of  pooled = (a rstd)^T R, contraction over points); the accumulator-register
-//     order IS the k-slot order of the consuming MFMA (constant operands are packed to match: pack.py map_frags), so R never
-//     moves between lanes — the trick of the attention kernel's P operand;
-//   * hi / lo planes of the small operand ride in the M dimension: rows 0-7 = U_hi (a_hi), rows 8-15 = U_lo (a_lo) of the 8 heads,
-//     so the three partial products cost two instructions (B = R_hi, B = R_lo) instead of three.
-// Per (point, channel) element: relu + split = 2.5 VALU in each layout instead of 13 + 13; the products themselves: 64 MFMA
-// cycles per point and SIMD.  Softmax weights are scaled per (polyline, head) by a power of two that puts max(a rstd) just
-// below 2^14 (exact; fp16 holds every term to 2^-22 of the largest) and unscaled after the sum.
-// Persistent workgroups (the operand fragments, 24 KB, are loaded into LDS once), two polylines per pass; each polyline's compacted
-// points start at a multiple of 32 so that a 32-point k-step of the pooling product never straddles two polylines.
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-typedef float f32x4_ __attribute__((ext_vector_type(4)));
-#define MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, C, 0, 0, 0)
-#define MP_PTS 256            // compact point slots of a pass (2 polylines x <= 128 points)
-
-__device__ __forceinline__ void relu_split8(const f32x4_ d0, const f32x4_ d1, opx8 (&rf)[NPL]) {
-  const float r[8] = {fmaxf(d0[0], 0.f), fmaxf(d0[1], 0.f), fmaxf(d0[2], 0.f), fmaxf(d0[3], 0.f),
-                      fmaxf(d1[0], 0.f), fmaxf(d1[1], 0.f), fmaxf(d1[2], 0.f), fmaxf(d1[3], 0.f)};
-  split_frag(r, rf);
-}
-
-__global__ __launch_bounds__(256, 2) void map_pool_mfma_kernel(int NP, int P, MapClasses mc, int total, const float* __restrict__ road_pts,
-                                                               MapPoolWeights w, float* __restrict__ attn_pre,
-                                                               unsigned char* __restrict__ src_pad) {
-  __shared__ __attribute__((aligned(16))) opx8 cw[16 * 64];                    // (Wc | ln_b) fragments, 16 channel tiles
-  __shared__ __attribute__((aligned(16))) opx8 cu[8 * 64];                     // 2^8 U fragments, 8 k-steps of 32 channels
-  __shared__ __attribute__((aligned(16))) struct { opx8 xfrag[(MP_PTS / 16) * 64]; float pooled[2][8][DM]; } u;   // 16 KB + 16 KB
-  __shared__ __attribute__((aligned(16))) float pts[MP_PTS][4];                // x, y, e, rstd of the compacted points
-  __shared__ __attribute__((aligned(16))) float sc[MP_PTS][8];
-  __shared__ __attribute__((aligned(16))) _Float16 atab[16][MP_PTS];           // rows 0-7: hi plane of a rstd 2^k per head, 8-15: lo
-  __shared__ float inv_scale[2][8];
-  __shared__ int any_exist[2], wcnt[4], wc0[4];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m16 = lane & 15, g4 = lane >> 4;
-  {
-    const opx8* wg = static_cast<const opx8*>(w.wfrag);
-    const opx8* ug = static_cast<const opx8*>(w.ufrag);
-    for (int i = tid; i < 16 * 64; i += 256) cw[i] = wg[i];
-    for (int i = tid; i < 8 * 64; i += 256) cu[i] = ug[i];
-  }
-  {
-    // the point fragments are cleared ONCE: slot groups 2 / 3 stay zero for good, and entries left over from an earlier pass (points
-    // beyond this pass's ranges) are finite and meet zero weights in the pooling product, unread scores in the first
-    const opx8 z = {};
-    for (int i = tid; i < (MP_PTS / 16) * 64; i += 256) u.xfrag[i] = z;
-  }
-  const int n_pairs = (total + 1) >> 1;
-  for (int pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
-    const int bp0 = pair * 2;
-    const int g_here = min(2, total - bp0);
-    const int n_pts = g_here * NP;
-    const float* src = road_pts + (size_t)bp0 * NP * 3;
-    // ---- (a) clear the per-pass operand tables
-    {
-      const opx8 z = {};
-      opx8* at = reinterpret_cast<opx8*>(&atab[0][0]);
-      for (int i = tid; i < 16 * MP_PTS / 8; i += 256) at[i] = z;
-      if (tid < 2) any_exist[tid] = 0;
-    }
-    __syncthreads();
-    // ---- (b) points, key padding (map_encoder.py:31), compaction: polyline 0 from slot 0, polyline 1 from the next multiple of 32
-    const int g_of = tid >= NP, p_in = tid - g_of * NP;
-    float x = 0.f, y = 0.f, e = 0.f;
-    if (tid < n_pts) {
-      x = src[tid * 3]; y = src[tid * 3 + 1]; e = src[tid * 3 + 2];
-      if (e != 0.f) any_exist[g_of] = 1;
-    }
-    __syncthreads();
-    const bool vis = tid < n_pts && (e != 0.f || (any_exist[g_of] == 0 && p_in == 0));
-    const unsigned long long bal = __ballot(vis);
-    {
-      const int first1 = NP - wv * 64;                          // lanes >= first1 of this wave belong to polyline 1
-      const unsigned long long m0 = first1 >= 64 ? ~0ull : (first1 <= 0 ? 0ull : ((1ull << first1) - 1ull));
-      if (lane == 0) { wcnt[wv] = __popcll(bal); wc0[wv] = __popcll(bal & m0); }
-    }
-    __syncthreads();
-    int before = __popcll(bal & ((1ull << lane) - 1ull));
-    for (int k = 0; k < wv; ++k) before += wcnt[k];
-    const int cnt0 = wc0[0] + wc0[1] + wc0[2] + wc0[3], n_all = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-    const int e0 = cnt0, q1 = (cnt0 + 31) & ~31, e1 = q1 + (n_all - cnt0);      // polyline 0: [0, e0), polyline 1: [q1, e1)
-    if (vis) {
-      const int idx = g_of ? q1 + (before - cnt0) : before;
-      pts[idx][0] = x; pts[idx][1] = y; pts[idx][2] = e;
-    }
-    __syncthreads();
-    // ---- (c) per point: LayerNorm statistics in closed form, operand fragment of (x, y, e, 1, std) with its partial-product slots
-    if (tid < e1 && (tid < e0 || tid >= q1)) {
-      const float px = pts[tid][0], py = pts[tid][1], pe = pts[tid][2];
-      const float* G = w.G;
-      const float var = px * (G[0] * px + 2.f * (G[1] * py + G[2] * pe + G[3])) + py * (G[4] * py + 2.f * (G[5] * pe + G[6])) +
-                        pe * (G[7] * pe + 2.f * G[8]) + G[9];
-      const float sd = sqrtf(fmaxf(var, 0.f) + 1e-5f);
-      pts[tid][3] = 1.0f / sd;
-      unsigned xs[NPL], ss[NPL];
-      split_pair(px, py, xs);                                   // low half: x planes, high half: y planes
-      split_pair(sd, 0.f, ss);
-      const unsigned xh = xs[0] & 0xffffu, xl = xs[1] & 0xffffu, yh = xs[0] >> 16, yl = xs[1] >> 16;
-      const unsigned sh = ss[0] & 0xffffu, sl = ss[1] & 0xffffu;
-      const unsigned eh = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)pe), one = 0x3c00u;
-      // slots (pairing with pack.py map_frags):  g0: x_hi x_hi x_lo y_hi y_hi y_lo e e     g1: 1 1 s_hi s_hi s_lo 0 0 0
-      const u32x4 f0 = {xh | (xh << 16), xl | (yh << 16), yh | (yl << 16), eh | (eh << 16)};
-      const u32x4 f1 = {one | (one << 16), sh | (sh << 16), sl, 0u};
-      const int t = tid >> 4, mm = tid & 15;
-      u.xfrag[t * 64 + mm] = __builtin_bit_cast(opx8, f0);
-      u.xfrag[t * 64 + 16 + mm] = __builtin_bit_cast(opx8, f1);
-    }
-    __syncthreads();
-#ifndef MP_ABL_NO_P1
-    // ---- (d) phase 1: scores.  A wave takes 16-point tiles; per k-step of 32 channels: two D^T tiles, relu, split, two score MFMAs
-    const int n_tiles = (e1 + 15) >> 4;
-    // (two tiles per trip: two independent MFMA -> relu / split -> MFMA chains in flight per wave; a tile index past the end
-    // computes on left-over fragments and is not stored)
-    for (int t = wv; t < n_tiles; t += 8) {
-      const int t2 = t + 4;
-      const opx8 xf = u.xfrag[t * 64 + lane], xg = u.xfrag[(t2 < MP_PTS / 16 ? t2 : t) * 64 + lane];
-      f32x4_ accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f}, accC = {0.f, 0.f, 0.f, 0.f}, accD = {0.f, 0.f, 0.f, 0.f};
-      const f32x4_ z4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const opx8 w0 = cw[(2 * s) * 64 + lane], w1 = cw[(2 * s + 1) * 64 + lane], uf = cu[s * 64 + lane];
-        const f32x4_ d0 = MFMA16(w0, xf, z4), d1 = MFMA16(w1, xf, z4);
-        const f32x4_ e0_ = MFMA16(w0, xg, z4), e1_ = MFMA16(w1, xg, z4);
-        opx8 rf[NPL], rg[NPL];
-        relu_split8(d0, d1, rf);
-        relu_split8(e0_, e1_, rg);
-        accA = MFMA16(uf, rf[0], accA);                          // rows 0-7: U_hi R_hi, rows 8-15: U_lo R_hi
-        accB = MFMA16(uf, rf[1], accB);                          // rows 0-7: U_hi R_lo
-        accC = MFMA16(uf, rg[0], accC);
-        accD = MFMA16(uf, rg[1], accD);
-      }
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const f32x4_ qa = half ? accC : accA, qb = half ? accD : accB;
-        float oth[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) oth[r] = __shfl_xor(qa[r], 32);    // the U_lo rows of the same heads live 32 lanes up
-        const int p = (half ? t2 : t) * 16 + m16;
-        if (g4 < 2 && p < e1) {
-          const float rs = pts[p][3] * 0.00390625f;             // rstd / 2^8 (the U fragments carry 2^8)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) sc[p][4 * g4 + r] = fmaf(rs, (qa[r] + qb[r]) + oth[r], w.cb[4 * g4 + r]);
-        }
-      }
-    }
-#endif
-    __syncthreads();
-    // ---- (e) softmax over the points of a polyline per head; a rstd scaled into the fp16 planes of the pooling operand
-    for (int id = wv * 4; id < wv * 4 + 4; ++id) {
-      const int gi = id >> 3, hd = id & 7;
-      if (gi >= g_here) continue;
-      const int a = gi ? q1 : 0, b = gi ? e1 : e0;
-      const int p0 = a + lane, p1 = a + 64 + lane;
-      const float v0 = p0 < b ? sc[p0][hd] : -__builtin_inff(), v1 = p1 < b ? sc[p1][hd] : -__builtin_inff();
-      const float mx = wave_max(fmaxf(v0, v1));
-      const float e0v = p0 < b ? expf(v0 - mx) : 0.f, e1v = p1 < b ? expf(v1 - mx) : 0.f;
-      const float inv = 1.0f / wave_sum(e0v + e1v);
-      const float ar0 = p0 < b ? e0v * inv * pts[p0][3] : 0.f, ar1 = p1 < b ? e1v * inv * pts[p1][3] : 0.f;
-      const float mxar = wave_max(fmaxf(ar0, ar1));
-      int ex = 0;
-      (void)frexpf(mxar, &ex);                                   // mxar = m 2^ex, m in [0.5, 1)
-      const float scl = ldexpf(1.0f, 14 - ex);                   // max(a rstd) 2^k in [2^13, 2^14)
-      if (lane == 0) inv_scale[gi][hd] = ldexpf(1.0f, ex - 14);
-      unsigned pl[NPL];
-      split_pair(ar0 * scl, ar1 * scl, pl);
-      if (p0 < b) {
-        atab[hd][p0] = __builtin_bit_cast(_Float16, (unsigned short)(pl[0] & 0xffffu));
-        atab[8 + hd][p0] = __builtin_bit_cast(_Float16, (unsigned short)(pl[1] & 0xffffu));
-      }
-      if (p1 < b) {
-        atab[hd][p1] = __builtin_bit_cast(_Float16, (unsigned short)(pl[0] >> 16));
-        atab[8 + hd][p1] = __builtin_bit_cast(_Float16, (unsigned short)(pl[1] >> 16));
-      }
-    }
-    __syncthreads();
-    // ---- (f) phase 2: pooled[g][h][c] = sum_pt (a rstd)[pt, h] R[pt, c].  A wave owns 4 channel tiles; k-steps of 32 points
-    f32x4_ pa[2][4], pb[2][4];
-#pragma unroll
-    for (int gi = 0; gi < 2; ++gi)
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) { pa[gi][ct] = f32x4_{0.f, 0.f, 0.f, 0.f}; pb[gi][ct] = f32x4_{0.f, 0.f, 0.f, 0.f}; }
-#ifndef MP_ABL_NO_P2
-#pragma unroll
-    for (int gi = 0; gi < 2; ++gi) {
-      if (gi >= g_here) continue;
-      const int ks0 = gi ? (q1 >> 5) : 0, ks1 = ((gi ? e1 : e0) + 31) >> 5;
-      for (int ks = ks0; ks < ks1; ++ks) {
-        const opx8 xf0 = u.xfrag[(2 * ks) * 64 + lane], xf1 = u.xfrag[(2 * ks + 1) * 64 + lane];
-        const h4 a_lo = *reinterpret_cast<const h4*>(&atab[m16][32 * ks + 4 * g4]);
-        const h4 a_hi = *reinterpret_cast<const h4*>(&atab[m16][32 * ks + 16 + 4 * g4]);
-        const opx8 af = __builtin_shufflevector(a_lo, a_hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        const f32x4_ z4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-          const opx8 wf = cw[(4 * wv + ct) * 64 + lane];
-          const f32x4_ d0 = MFMA16(xf0, wf, z4);                 // [16 points x 16 channels]: lane = channel, registers = points
-          const f32x4_ d1 = MFMA16(xf1, wf, z4);
-          opx8 rf[NPL];
-          relu_split8(d0, d1, rf);
-          pa[gi][ct] = MFMA16(af, rf[0], pa[gi][ct]);
-          pb[gi][ct] = MFMA16(af, rf[1], pb[gi][ct]);
-        }
-      }
-    }
-#endif
-#pragma unroll
-    for (int gi = 0; gi < 2; ++gi)
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        float oth[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) oth[r] = __shfl_xor(pa[gi][ct][r], 32);
-        if (g4 < 2) {
-          const int c = 16 * (4 * wv + ct) + m16;
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            u.pooled[gi][4 * g4 + r][c] = ((pa[gi][ct][r] + pb[gi][ct][r]) + oth[r]) * inv_scale[gi][4 * g4 + r];
-        }
-      }
-    __syncthreads();
-    // ---- (g) phase 3: thread = output channel j of head j >> 5 (the folded 256 x 256 matrix once for both polylines)
-    {
-      const int j = tid, h = j >> 5;
-      float o0 = w.mb[j], o1 = o0;
-#ifndef MP_ABL_NO_P3
-#pragma unroll 32
-      for (int c = 0; c < DM; ++c) {
-        const float mm = w.Mt[c * DM + j];
-        o0 = fmaf(u.pooled[0][h][c], mm, o0);
-        o1 = fmaf(u.pooled[1][h][c], mm, o1);
-      }
-#else
-      o0 += u.pooled[0][h][j]; o1 += u.pooled[1][h][j];
-#endif
-      attn_pre[(size_t)bp0 * DM + j] = o0;
-      if (g_here > 1) attn_pre[(size_t)(bp0 + 1) * DM + j] = o1;
-    }
-    if (tid < g_here) {
-      const int bp = bp0 + tid;
-      int k = 0;
-      while (k + 1 < mc.n && bp >= mc.bp0[k + 1]) ++k;
-      const int rel = bp - mc.bp0[k], bq = rel / P, pq = rel - bq * P;
-      src_pad[mc.pad0[k] + (size_t)bq * mc.M[k] + pq] = any_exist[tid] ? 0 : 1;
-    }
-    __syncthreads();                                             // the next pass clears xfrag (= pooled) and any_exist
-  }
-}
-
-static bool map_pool_use_mfma(int NP, const MapPoolWeights& w) {
-  return ctrlsim_option(OPT_MAP_MFMA) == 1 && ctrlsim_option(OPT_SPLIT) == 1 && NP <= 128 && w.wfrag && w.ufrag;
-}
-static int map_pool_mfma_grid(int total) {
-  static const int n_cus = [] {
-    int dev = 0, n = 0;
-    return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
-  }();
-  const int n_pairs = (total + 1) / 2;
-  return n_pairs < 2 * n_cus ? n_pairs : 2 * n_cus;             // two resident workgroups per CU (60 KB of LDS each)
-}
+// (Round 3 also built this function on the matrix pipe — operand split in the k-slots of v_mfma_f32_16x16x32_f16, both register layouts of
+// the hidden tile from swapped operands — correct to 3e-6 and 12 % slower than the kernel above: dependent MFMA -> relu / split -> MFMA
+// chains at two workgroups per CU.  Removed in round 4; numbers in profiles/README.md, the code in the history at 8eba46e.)
 
 // n classes: B[k] contexts, M[k] scene rows per context, padding rows of class k from src_pad + pad0[k]; road_pts / attn_pre
 // hold the classes back to back
@@ -456,9 +191,6 @@ int launch_map_pool_classes(int n, const int* B, const int* M, const long* pad0,
   const int G = NP <= 128 ? 2 : 1, total = mc.bp0[n];
   if (total <= 0) return CTRLSIM_OK;
   prof_before(PROF_MAP, st);
-  if (map_pool_use_mfma(NP, w))
-    hipLaunchKernelGGL(map_pool_mfma_kernel, dim3(map_pool_mfma_grid(total)), dim3(256), 0, st, NP, P, mc, total, road_pts, w, attn_pre, src_pad);
-  else
   hipLaunchKernelGGL(map_pool_kernel, dim3((total + G - 1) / G), dim3(256), 0, st, NP, P, mc, G, total, road_pts, w, attn_pre,
                      src_pad);
   prof_after(PROF_MAP, 1.5e6 * (double)total, st, (double)total * (12.0 * NP + 4.0 * DM + 1.0));
@@ -472,9 +204,6 @@ int launch_map_pool(int B, int P, int NP, int M, const float* road_pts, MapPoolW
   MapClasses mc;
   mc.n = 1; mc.bp0[0] = 0; mc.bp0[1] = total; mc.M[0] = M; mc.pad0[0] = 0;
   prof_before(PROF_MAP, st);
-  if (map_pool_use_mfma(NP, w))
-    hipLaunchKernelGGL(map_pool_mfma_kernel, dim3(map_pool_mfma_grid(total)), dim3(256), 0, st, NP, P, mc, total, road_pts, w, attn_pre, src_pad);
-  else
   hipLaunchKernelGGL(map_pool_kernel, dim3((total + G - 1) / G), dim3(256), 0, st, NP, P, mc, G, total, road_pts, w, attn_pre,
                      src_pad);
   // per polyline: NP points x 12 B in, one 256-float row + a padding byte out; ~1.5 MFLOP of folded point MLP + seed attention

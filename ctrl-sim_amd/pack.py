@@ -132,52 +132,6 @@ def split3_planes(W: np.ndarray, scheme=None) -> np.ndarray:
 PLANES_SUFFIX = {1: "#pl1", 0: "#pl0"}
 
 
-def _f16_planes(v):
-    """float32 array -> (hi, lo) fp16 planes with hi + lo = v to 2^-22 (round-to-nearest-even both times)."""
-    v = np.ascontiguousarray(v, np.float32)
-    with np.errstate(over="ignore", invalid="ignore"):
-        hi = v.astype(np.float16)
-        lo = (v - hi.astype(np.float32)).astype(np.float16)
-    if not (np.isfinite(hi).all() and np.isfinite(lo).all()):
-        raise FloatingPointError("map-encoder weight beyond the fp16 range")
-    return hi, lo
-
-
-def map_frags(Wc: np.ndarray, ln_b: np.ndarray, U: np.ndarray):
-    """Constant MFMA operand fragments of csrc/map_encoder.hip::map_pool_mfma_kernel (v_mfma_f32_16x16x32_f16: lane l holds 8 fp16
-    k-slots of row / column l & 15, slot group g = l >> 4).
-      wfrag [16 channel tiles][64 lanes][8]: channel c = 16 tile + (l & 15); the operand split lives in the k-slots, paired with the
-        point fragment  g0: x_hi x_hi x_lo y_hi y_hi y_lo e e / g1: 1 1 s_hi s_hi s_lo 0 0 0  built by the kernel:
-        g0: wx_hi wx_lo wx_hi wy_hi wy_lo wy_hi we_hi we_lo     g1: wb_hi wb_lo lnb_hi lnb_lo lnb_hi 0 0 0     g2, g3: 0
-        (Wc[c] = (wx, wy, we, wb); the sum over the slots is Wc[c].(x, y, e, 1) + ln_b[c] std to fp32 accuracy)
-      ufrag [8 k-steps][64 lanes][8]: row l & 15 = head h (rows 0-7: hi plane of 2^8 U[:, h], rows 8-15: lo plane), slot j of group g
-        <-> channel 32 s + 16 (j >> 2) + 4 g + (j & 3) — the accumulator-register order of two 16 x 16 output tiles.
-    -> two uint16 arrays."""
-    D, H = U.shape
-    assert D == 256 and H == 8 and Wc.shape == (D, 4) and ln_b.shape == (D,)
-    wh, wl = _f16_planes(Wc)
-    bh, bl = _f16_planes(ln_b)
-    wfrag = np.zeros((D // 16, 64, 8), np.float16)
-    for lane in range(64):
-        m, g = lane & 15, lane >> 4
-        c = np.arange(D // 16) * 16 + m
-        if g == 0:
-            wfrag[:, lane] = np.stack([wh[c, 0], wl[c, 0], wh[c, 0], wh[c, 1], wl[c, 1], wh[c, 1], wh[c, 2], wl[c, 2]], 1)
-        elif g == 1:
-            z = np.zeros(len(c), np.float16)
-            wfrag[:, lane] = np.stack([wh[c, 3], wl[c, 3], bh[c], bl[c], bh[c], z, z, z], 1)
-    uh, ul = _f16_planes(np.asarray(U, np.float32) * np.float32(256.0))
-    ufrag = np.zeros((D // 32, 64, 8), np.float16)
-    j = np.arange(8)
-    for lane in range(64):
-        m, g = lane & 15, lane >> 4
-        src = uh if m < 8 else ul
-        for s_ in range(D // 32):
-            ch = 32 * s_ + 16 * (j >> 2) + 4 * g + (j & 3)
-            ufrag[s_, lane] = src[ch, m & 7]
-    return wfrag.view(np.uint16), ufrag.view(np.uint16)
-
-
 def row_blocks(W: np.ndarray, scheme=None) -> np.ndarray:
     """[N, K] float32 -> operand blocks of 32 output columns [N/32][p][ks K/16][half 2][col 32][8] (uint16) = plane_p(W)[32 cb + col,
     16 ks + 8 half + e]: what the row-stationary in_proj kernel (csrc/gemm_bf16x6.hip: inproj_rs_kernel) streams through LDS, and the
@@ -248,14 +202,6 @@ def pack(dims: Dims, w: dict):
                 allw[k + "#blk" + PLANES_SUFFIX[1]] = row_blocks(np.asarray(w[k], np.float32), 1).reshape(-1).view(np.float32)
             except FloatingPointError:
                 pass                                               # out of the fp16 range: that model runs with bf16 planes
-    # map-encoder point pooling on the matrix pipe (two-fp16-plane scheme): constant operand fragments, raw 16-bit words
-    try:
-        wf, uf = map_frags(allw["fold.map.Wc"], np.asarray(w["encoder.map_encoder.road_pts_encoder.mlp.1.bias"], np.float32),
-                           allw["fold.map.U"])
-        allw["fold.map.wfrag#f16"] = wf.reshape(-1).view(np.float32)
-        allw["fold.map.ufrag#f16"] = uf.reshape(-1).view(np.float32)
-    except FloatingPointError:
-        pass                                                   # out of the fp16 range: the fp32 VALU kernel runs instead
     names, offsets, chunks = [], [], []
     off = 0
     for k, v in allw.items():

@@ -368,7 +368,7 @@ int ctrlsim_attn_class_prof(int enable, unsigned long long* host_out);
 /* Runtime options (csrc/common.h: OPT_*).  Keys 0 / 1 = attention / GEMM path of the forward: value 0 = f32-input MFMA
  * (v_mfma_f32_32x32x2_f32), 1 = split-operand 16-bit MFMA with fp32-class accuracy (default).  Key 2 = tile shape of the tiled
  * split-operand GEMM (0 auto; tuning).  Key 3 = fused feed-forward block (default 1).  Key 4 = operand split (1 two fp16 planes,
- * 0 three bf16 planes; per engine through ctrlsim_bind).  Key 5 = map-encoder pooling on the matrix pipe (default 0).
+ * 0 three bf16 planes; per engine through ctrlsim_bind).  Key 5 = reserved (rounds 2-3: a matrix-pipe variant of the map-encoder pooling, removed).
  * Key 6 = weight-stationary kernel for the Linear(256 -> 256 G) shapes, bit mask: 1 = launches of at least two 32-row blocks per
  * compute unit, 2 = smaller launches, 4 = the in_proj Linears with K / V-image epilogue, 8 = those through the ROW-stationary kernel
  * (rows in registers, 32-column weight blocks streamed through LDS, every activation row read once; needs the block images of

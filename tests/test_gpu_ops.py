@@ -617,16 +617,18 @@ def test_ffn_fused_block(M, F):
 
 
 @pytest.mark.parametrize("B", [1, 3])
-def test_map_pool_on_the_matrix_pipe_matches_the_fp32_valu_kernel(B):
-    """map_pool_mfma_kernel (two-fp16-plane operands in the k-slots of v_mfma_f32_16x16x32_f16, both register layouts of the hidden
-    tile by swapping the MFMA operands: csrc/map_encoder.hip) against the fp32 VALU kernel it replaces (pinned through the forward
-    fixtures to modules/map_encoder.py:28-46): polylines with 0, 1, 2, 31, 32, 33, 99 and 100 visible points, points missing in
-    the middle, an odd polyline count in the last pass; padding bytes identical, pooled vectors to fp32-class accuracy."""
+def test_map_pool_matches_the_unfolded_front_end_in_float64(B):
+    """map_pool_kernel (point MLP + single-seed attention pooling with every linear stage folded at pack time: csrc/map_encoder.hip) against
+    a float64 evaluation of the UNFOLDED front end written from modules/map_encoder.py:28-46 — Linear(3, 256) - LayerNorm - ReLU -
+    Linear(256, 256) per point, an 8-head attention whose only query is the learned seed, key padding = missing points, a polyline without
+    any point un-masks its point 0 — up to, not including, out_proj.  Polylines with 0, 1, 2, 31, 32, 33, 99 and 100 visible points, points
+    missing in the middle; padding bytes exact, pooled vectors to fp32 accuracy."""
     from ctrlsim_amd import spec, weights
     from ctrlsim_amd.engine import HipModel
     cfg = spec.make_cfg()
     d = spec.Dims(cfg)
-    model = HipModel(cfg, weights.generate(d, 0), DEV)
+    wts = weights.generate(d, 0)
+    model = HipModel(cfg, wts, DEV)
     lib, p, st = _lib.lib(), _lib.ptr, _lib.stream_ptr()
     rs = np.random.RandomState(B)
     npts = rs.randint(0, d.NP + 1, (B, d.P))
@@ -637,19 +639,31 @@ def test_map_pool_on_the_matrix_pipe_matches_the_fp32_valu_kernel(B):
     rp = np.concatenate([(rs.randn(B, d.P, d.NP, 2) * 60).astype(np.float32), ex[..., None]], -1)
     rp[..., :2] *= ex[..., None]
     road = torch.from_numpy(rp).to(DEV)
-    outs = {}
-    try:
-        for mode in (0, 1):
-            lib.ctrlsim_set_option(5, mode)
-            out = torch.full((B * d.P, d.D), float("nan"), device=DEV)
-            pad = torch.full((B, d.P), 7, dtype=torch.uint8, device=DEV)
-            _lib.check(lib.ctrlsim_map_pool(model.handle, B, p(road), p(out), p(pad), st))
-            torch.cuda.synchronize()
-            outs[mode] = (out.cpu().numpy().astype(np.float64), pad.cpu().numpy())
-    finally:
-        lib.ctrlsim_set_option(5, 0)
-    (a, pa), (b, pb) = outs[0], outs[1]
-    assert np.array_equal(pa, pb) and np.isfinite(b).all()
-    scale = np.abs(a).max(1, keepdims=True) + 1e-3
-    err = np.abs(a - b) / scale
-    assert err.max() < 3e-6, (err.max(), np.unravel_index(err.argmax(), err.shape))
+    out = torch.full((B * d.P, d.D), float("nan"), device=DEV)
+    pad = torch.full((B, d.P), 7, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.ctrlsim_map_pool(model.handle, B, p(road), p(out), p(pad), st))
+    torch.cuda.synchronize()
+    got, got_pad = out.cpu().numpy().astype(np.float64), pad.cpu().numpy()
+    # ---- the unfolded computation
+    W = {k.split("map_encoder.")[1]: np.asarray(v, np.float64) for k, v in wts.items() if "map_encoder." in k}
+    x = rp.reshape(-1, d.NP, 3).astype(np.float64)
+    h = x @ W["road_pts_encoder.mlp.0.weight"].T + W["road_pts_encoder.mlp.0.bias"]
+    h = (h - h.mean(-1, keepdims=True)) / np.sqrt(h.var(-1, keepdims=True) + 1e-5)
+    h = np.maximum(h * W["road_pts_encoder.mlp.1.weight"] + W["road_pts_encoder.mlp.1.bias"], 0.0)
+    h = h @ W["road_pts_encoder.mlp.3.weight"].T + W["road_pts_encoder.mlp.3.bias"]                # [polylines, NP, 256]
+    Wi, bi = W["road_pts_attn_layer.in_proj_weight"], W["road_pts_attn_layer.in_proj_bias"]
+    q = (Wi[:256] @ W["map_seeds"].reshape(256) + bi[:256]).reshape(8, 32)
+    k = (h @ Wi[256:512].T + bi[256:512]).reshape(-1, d.NP, 8, 32)
+    v = (h @ Wi[512:].T + bi[512:]).reshape(-1, d.NP, 8, 32)
+    vis = x[..., 2] != 0
+    empty = ~vis.any(1)
+    vis[empty, 0] = True                                          # map_encoder.py:31
+    sc = np.einsum("hd,pnhd->pnh", q, k) / np.sqrt(32.0)
+    sc = np.where(vis[..., None], sc, -np.inf)
+    a = np.exp(sc - sc.max(1, keepdims=True)); a /= a.sum(1, keepdims=True)
+    ref = np.einsum("pnh,pnhd->phd", a, v).reshape(-1, 256)
+    assert np.array_equal(got_pad.reshape(-1), empty.astype(np.uint8))
+    assert np.isfinite(got).all()
+    scale = np.abs(ref).max(1, keepdims=True) + 1e-3
+    err = np.abs(got - ref) / scale
+    assert err.max() < 2e-5, (err.max(), np.unravel_index(err.argmax(), err.shape))
