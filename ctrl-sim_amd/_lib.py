@@ -45,6 +45,10 @@ SIGNATURES = {
     "ctrlsim_nonfinite_count": (I, [I]),
     "ctrlsim_bind": (I, [I, P]),
     "ctrlsim_unbind": (I, [P]),
+    "ctrlsim_bound_guard": (P, []),
+    "ctrlsim_option_count": (I, []),
+    "ctrlsim_bind_options": (I, [P]),
+    "ctrlsim_get_option": (I, [I]),
     "ctrlsim_prof_classes": (I, []),
     "ctrlsim_prof_enable": (None, [I]),
     "ctrlsim_prof_collect": (I, [P, P, P]),

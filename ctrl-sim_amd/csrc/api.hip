@@ -76,27 +76,35 @@ void prof_after(int cls, double flops, hipStream_t st, double bytes, int kind) {
   g_recs.push_back(ProfRec{g_pending[cls], b, cls, flops, bytes, st, 2 * kind + (g_prof_few ? 1 : 0)});
 }
 
-static int g_options[OPT_COUNT] = {1, 1, 0, 1, 1, 0, 15, 1, 1, 1};
-// Guard counter (common.h): the counter the CALLER bound with ctrlsim_bind — an engine's own 4 bytes of device memory — or,
-// for callers that never bind one, a library-owned word allocated on first use on the then-current device.
+static int g_options[OPT_COUNT] = {1, 1, 0, 1, 1, 0, 15, 1, 1, 1};      // process defaults (ctrlsim_set_option)
+// the option table of the ENGINE that bound last (ctrlsim_bind_options): entry >= 0 overrides the process default, -1 inherits it
+static int g_bound_options[OPT_COUNT];
+static bool g_has_bound_options = false;
+// Guard counters (common.h): TWO device words — [0] non-finite events of the model, [1] simulator events — either the pair the CALLER
+// bound with ctrlsim_bind (an engine's own 8 bytes of device memory) or, for callers that never bind one, a library-owned pair
+// allocated on first use on the then-current device.  Two words, not two halves of one: thousands of non-finite LayerNorm rows of an
+// fp16 overflow at production batch sizes must not carry into the simulator's count (round-4 review).
 static int* g_guard = nullptr;
 static int* own_guard_word() {
   static int* p = nullptr;
   if (!p) {
-    if (hipMalloc(reinterpret_cast<void**>(&p), sizeof(int)) != hipSuccess) { p = nullptr; return nullptr; }
-    (void)hipMemset(p, 0, sizeof(int));
+    if (hipMalloc(reinterpret_cast<void**>(&p), 2 * sizeof(int)) != hipSuccess) { p = nullptr; return nullptr; }
+    (void)hipMemset(p, 0, 2 * sizeof(int));
   }
   return p;
 }
 int* ctrlsim_nonfinite_ptr() { return g_guard ? g_guard : own_guard_word(); }
-// events counted in the LIBRARY'S OWN word since the last reset (synchronises the device).  A caller that bound its own counter
-// (ctrlsim_bind) reads that counter itself: this function never touches it, whatever is bound at the moment.
+int* ctrlsim_simguard_ptr() { int* p = ctrlsim_nonfinite_ptr(); return p ? p + 1 : nullptr; }
+// events counted in the LIBRARY'S OWN words since the last reset (synchronises the device), in the legacy encoding: the non-finite
+// count saturated at 65535 in the low half, the simulator count saturated at 32767 in the high half.  A caller that bound its own
+// pair (ctrlsim_bind) reads it itself: this function never touches it, whatever is bound at the moment.
 static int nonfinite_count(int reset) {
   int* p = own_guard_word();
-  int n = 0;
-  if (!p || hipMemcpy(&n, p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return CTRLSIM_ELAUNCH;
-  if (reset && n && hipMemset(p, 0, sizeof(int)) != hipSuccess) return CTRLSIM_ELAUNCH;
-  return n;
+  int n[2] = {0, 0};
+  if (!p || hipMemcpy(n, p, 2 * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return CTRLSIM_ELAUNCH;
+  if (reset && (n[0] || n[1]) && hipMemset(p, 0, 2 * sizeof(int)) != hipSuccess) return CTRLSIM_ELAUNCH;
+  const unsigned lo = (unsigned)n[0] > 65535u ? 65535u : (unsigned)n[0], hi = (unsigned)n[1] > 32767u ? 32767u : (unsigned)n[1];
+  return (int)(hi * 65536u + lo);
 }
 // Per-class cycle accounting of the causal self-attention launches over the token rows (profiling runs: bench.py's untimed extra slice).
 // 32 slot counts x {workgroup cycles, workgroups}; library-owned device words like the guard counter, allocated on first enable.
@@ -114,9 +122,12 @@ extern "C" int ctrlsim_attn_class_prof(int enable, unsigned long long* host_out)
   if (host_out && g_cprof && hipMemcpy(host_out, g_cprof, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return CTRLSIM_ELAUNCH;
   return CTRLSIM_OK;
 }
-extern "C" int ctrlsim_split_scheme() { return g_options[OPT_SPLIT] ? 1 : 0; }
+extern "C" int ctrlsim_split_scheme() { return ctrlsim_option(OPT_SPLIT) ? 1 : 0; }
 extern "C" int ctrlsim_nonfinite_count(int reset) { return nonfinite_count(reset); }
-int ctrlsim_option(int key) { return (key >= 0 && key < OPT_COUNT) ? g_options[key] : 0; }
+int ctrlsim_option(int key) {
+  if (key < 0 || key >= OPT_COUNT) return 0;
+  return (g_has_bound_options && g_bound_options[key] >= 0) ? g_bound_options[key] : g_options[key];
+}
 
 extern "C" {
 
@@ -130,11 +141,25 @@ int ctrlsim_bind(int split_scheme, int* guard_counter) {
   return CTRLSIM_OK;
 }
 
-// the owner of `guard_counter` is about to free it: back to the library's own word if it is the bound one
+// the owner of `guard_counter` is about to free it: back to the library's own pair if it is the bound one
 int ctrlsim_unbind(const int* guard_counter) {
-  if (g_guard == guard_counter) g_guard = nullptr;
+  if (g_guard == guard_counter) { g_guard = nullptr; g_has_bound_options = false; }   // its option table goes with it
   return CTRLSIM_OK;
 }
+// the pair bound at the moment (NULL = the library's own): a caller that binds its own for one call restores this afterwards
+int* ctrlsim_bound_guard(void) { return g_guard; }
+
+// Per-engine option table: `values` = ctrlsim_option_count() ints (host memory, copied); entry >= 0 overrides the process default of
+// ctrlsim_set_option for every launch until the next bind, -1 inherits it.  NULL = back to the process defaults.  Like ctrlsim_bind an
+// engine re-asserts its table at the top of every run, so engines with different kernel options take turns in one process.
+int ctrlsim_option_count(void) { return OPT_COUNT; }
+int ctrlsim_bind_options(const int* values) {
+  g_has_bound_options = values != nullptr;
+  if (values)
+    for (int k = 0; k < OPT_COUNT; ++k) g_bound_options[k] = values[k];
+  return CTRLSIM_OK;
+}
+int ctrlsim_get_option(int key) { return (key < 0 || key >= OPT_COUNT) ? CTRLSIM_EINVAL : ctrlsim_option(key); }
 
 int ctrlsim_set_option(int key, int value) {
   if (key < 0 || key >= OPT_COUNT) return CTRLSIM_EINVAL;

@@ -59,9 +59,22 @@ def compile_cmd(name, extra, obj):
     return [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj] + COMMON.split() + extra.split()
 
 
+HOST_ONLY = ("dispatch", "api")            # objects without device code: an EMPTY disassembly is expected there and nowhere else
+
+
+def _llvm_tool(name):
+    path = os.path.join(LLVM_BIN, name)
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} not found: the ISA guard of the shipped build (csrc/build.py: isa_guard) needs llvm-objcopy, "
+                           "clang-offload-bundler and llvm-objdump; point CTRLSIM_LLVM_BIN at the directory that holds them")
+    return path
+
+
 def device_isa(obj):
     """Disassembly (text) of the gfx950 code object embedded in a host object / shared library built by hipcc."""
     import tempfile
+    for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump"):
+        _llvm_tool(t)
     with tempfile.TemporaryDirectory() as td:
         fat, co = os.path.join(td, "x.fatbin"), os.path.join(td, "x.co")
         # (objcopy with one file name rewrites that file in place: always name a scratch output)
@@ -96,7 +109,14 @@ def isa_guard(obj):
     """The build refuses an object that holds packed-fp32 arithmetic with op_sel set (the form the co-residency hazard follows: DESIGN.md
     section 4, profiles/r04_hazard.md) or v_pk_mov_b32 (only the SLP vectoriser emits it: its presence means the pass ran).  A compiler
     upgrade, a new pass or an edit that brings them back must not ship silently."""
-    mov, cross, swz, arith = packed_counts(device_isa(obj))
+    isa = device_isa(obj)
+    base = os.path.basename(obj).split(".")[0]
+    # a disassembler whose output format changed (or an extraction that silently produced nothing) must not read as "no packed code":
+    # every object with device code has to show machine instructions we know are in it
+    if base not in HOST_ONLY and ("s_endpgm" not in isa or "v_" not in isa):
+        raise RuntimeError(f"{os.path.basename(obj)}: no gfx950 disassembly extracted (llvm tools / bundle format changed?): the ISA guard "
+                           "cannot vouch for this object")
+    mov, cross, swz, arith = packed_counts(isa)
     if mov or cross:
         raise RuntimeError(f"{os.path.basename(obj)}: {cross} packed-fp32 instructions with op_sel, {mov} v_pk_mov_b32 in the device code "
                            "(co-residency hazard, DESIGN.md section 4): build with -fno-slp-vectorize, or the file without packed fp32 (NO_PK)")
@@ -131,17 +151,24 @@ def build(force=False, verbose=False):
             if verbose:
                 print(" ".join(cmd))
             procs.append((objname, obj, tmp, stamp, want, subprocess.Popen(run)))
-    failed = []
+    # every compiler process is waited for before anything is raised: a process left running would keep writing its *.tmp.o under the
+    # next build's feet.  Compile failures and guard refusals are collected and reported together.
+    failed, refused = [], []
     for name, obj, tmp, stamp, want, p in procs:
         if p.wait() != 0:
             failed.append(name)
             continue
         if not VARIANT or os.environ.get("CTRLSIM_ISA_GUARD", "1") != "0":
-            isa_guard(tmp)
+            try:
+                isa_guard(tmp)
+            except RuntimeError as e:
+                refused.append(str(e))
+                os.remove(tmp)
+                continue
         os.replace(tmp, obj)
         open(stamp, "w").write(want)
-    if failed:
-        raise RuntimeError("hipcc failed on " + ", ".join(failed))
+    if failed or refused:
+        raise RuntimeError("; ".join((["hipcc failed on " + ", ".join(failed)] if failed else []) + refused))
     if force or procs or not os.path.exists(OUT):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
         if verbose:

@@ -66,9 +66,11 @@ __device__ __host__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 // The samplers count races that no finite logit won; every fused LayerNorm (GEMM / feed-forward epilogues, layernorm256) counts
 // rows whose variance is not finite.  The second matters: ReLU (v_max_f32) maps NaN to 0, so a row that overflowed the fp16
 // range of the two-plane operand split (csrc/split.h) would otherwise come out of the MLP heads as finite, wrong logits.
-#define SIM_GUARD_UNIT 65536   // simulator events (contacts beyond the island solver's table) count in units of 2^16 of the guard word,
-                               // non-finite events of the model in units of 1: the reader tells them apart (engine.py: check_finite)
+// The guard is a PAIR of device words: [0] non-finite events of the model, [1] simulator events (contacts beyond the island solver's
+// table).  Readers (engine.py: nonfinite / check_finite; ctrlsim_nonfinite_count) report them as low half (saturated at 65535) and
+// high half (saturated at 32767) of one int — the legacy encoding — but the device never adds across the boundary.
 int* ctrlsim_nonfinite_ptr();
+int* ctrlsim_simguard_ptr();
 unsigned long long* ctrlsim_attn_cprof_ptr();     // per-class cycle counters of the causal attention launches (api.hip), null unless enabled
 __device__ __forceinline__ void count_nonfinite_row(float var, int lane, int* __restrict__ counter) {
   if (lane == 0 && !(var <= 3.0e38f)) atomicAdd(counter, 1);

@@ -1358,8 +1358,8 @@ __global__ __launch_bounds__(256) void sim_step_kernel(int N, int E, const int* 
             if (coff + nc < MAX_ISLAND_CONTACTS) {         // (the touching graph of disjoint boxes is planar: <= 3 N - 6 contacts)
               isl_c[coff + nc].m = cs + (size_t)pr * CS_STRIDE; isl_c[coff + nc].ia = i; isl_c[coff + nc].ib = j; ++nc;
             } else if (guard) {
-              atomicAdd(guard, SIM_GUARD_UNIT);            // deeply overlapping boxes: the contact is NOT solved — counted, never silent
-                                                           // (in the HIGH half of the guard word: not a non-finite event of the model)
+              atomicAdd(guard, 1);                         // deeply overlapping boxes: the contact is NOT solved — counted, never silent
+                                                           // (guard = the SIMULATOR word of the guard pair, common.h)
             }
             if ((in_island >> o) & 1ull) continue;
             isl_stack[sc++] = o; in_island |= 1ull << o;
@@ -1531,7 +1531,7 @@ int launch_sim_step(int S, int N, int E, const int* act_tok, const double* act_f
   for (int s0 = 0; s0 < S; s0 += chunk) {
     const int n = S - s0 < chunk ? S - s0 : chunk;
     hipLaunchKernelGGL(sim_step_kernel, dim3(n), dim3(256), excl_lds, st, N, E, act_tok, act_f64, dz, size, edges, exists, phys,
-                       hist_states, coll, applied, t, Tmax1, dt, kinematic, contact_state, s0, ctrlsim_nonfinite_ptr(), expert);
+                       hist_states, coll, applied, t, Tmax1, dt, kinematic, contact_state, s0, ctrlsim_simguard_ptr(), expert);
   }
   // per scenario: body + control state in and out (20 floats), one history row + flags out, the road-edge segments in,
   // and (contacts) the persistent Box2D state in and out (20 floats per vehicle pair + broad phase)

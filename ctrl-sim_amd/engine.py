@@ -181,7 +181,7 @@ class _Lane:
 class RolloutEngine:
     def __init__(self, cfg, weights: dict, device="cuda:0", max_ctx=256, seed=0, tilt=(0.0, 0.0, 0.0),
                  temperature=None, nucleus=None, top_p=None, kinematic=False, model=None, use_cache=True, contacts=True,
-                 lanes=1, compact=True, split="auto", sizes=None):
+                 lanes=1, compact=True, split="auto", sizes=None, options=None):
         self.cfg = cfg
         self.w = cfg.dataset.waymo
         self.dims = Dims(cfg)
@@ -198,7 +198,14 @@ class RolloutEngine:
         # images and workspace are used with, and its own guard counter (non-finite LayerNorm rows / sampling races, simulator
         # contact-table overflows) — several engines (planner and adversary policies, a second model) take turns in one process
         # without changing each other's kernels or reading each other's events.
-        self.guard = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # guard pair (include/ctrlsim.h: ctrlsim_bind): [0] non-finite events of the model, [1] simulator events — separate words, so
+        # that a real fp16 overflow at production scale (thousands of LayerNorm rows per step) cannot carry into the simulator's count
+        self.guard = torch.zeros(2, dtype=torch.int32, device=self.device)
+        # this engine's kernel options (include/ctrlsim.h: ctrlsim_bind_options; {key: value}, keys of ctrlsim_set_option): entries
+        # override the process defaults for this engine's launches only — two engines with different options take turns in one process
+        self._options = (C.c_int * int(self.lib.ctrlsim_option_count()))(*([-1] * int(self.lib.ctrlsim_option_count())))
+        for k, v in (options or {}).items():
+            self._options[int(k)] = int(v)
         self.scheme = 0 if (split == "bf16x6" or (split == "auto" and self.model.split_fallback)) else 1
         self._unchecked = []                    # fresh-from-reset runs since the last check_finite: (steps, s0, s1)
         self._bind()
@@ -280,6 +287,12 @@ class RolloutEngine:
 
     def _bind(self):
         _lib.check(self.lib.ctrlsim_bind(int(self.scheme), self.guard.data_ptr()), "bind")
+        _lib.check(self.lib.ctrlsim_bind_options(self._options), "bind_options")
+
+    def set_option(self, key, value):
+        """Kernel option `key` (include/ctrlsim.h: ctrlsim_set_option) for THIS engine's launches; value None = inherit the process default."""
+        self._options[int(key)] = -1 if value is None else int(value)
+        self._bind()
 
     def __del__(self):
         try:                                    # the library must not keep a pointer into memory torch is about to recycle
@@ -296,10 +309,12 @@ class RolloutEngine:
     def nonfinite(self, reset=True):
         """Synchronise and read this engine's guard counter (non-finite LayerNorm rows / sampling races, contact-table overflows)."""
         torch.cuda.synchronize(self.device)
-        n = int(self.guard.item())
-        if n and reset:
+        nf, sim = (int(v) for v in self.guard.tolist())
+        if (nf or sim) and reset:
             self.guard.zero_()
-        return n
+        # the legacy encoding of ctrlsim_nonfinite_count: low half = non-finite events of the model, high half = simulator events, both
+        # SATURATED — the device counts them in separate words, neither can carry into the other
+        return min(nf, 65535) + 65536 * min(sim, 32767)
 
     # ------------------------------------------------------------------ scenario upload / reset
     def load_scenarios(self, scns, steps=None):
@@ -803,18 +818,30 @@ class RolloutEngine:
         todo = list(reversed(jobs))
         self._lane_t = [0] * len(self.lanes)
         nT = min(self.dims.T, steps) if self.use_cache else 0
-        done0 = [False]
+        done0, first0 = [False], [False]
         # max_sliding (default: 2 when there are more lanes than that): the EXTRA lanes run the cached steps of the next jobs ahead of time
         self._max_sliding = int(max_sliding) if max_sliding else (2 if len(lanes) > 2 else 0)
         self._sliding, self._holds_slot = 0, [False] * len(self.lanes)
         if self._max_sliding:
             stagger = False                                  # the slots stagger the lanes by themselves
+        if steps <= nT:
+            stagger = False                                  # a rollout that never leaves the cached steps has no second phase to stagger against
+        # run()'s phase records describe ONE range rolled by all lanes together; here every lane has its own jobs: one record per call,
+        # the lanes' "left the cached phase" events all land in it (phase_times() takes the last one)
+        rec = None
+        if self.record_phases:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record(main)
+            rec = [ev0, [], None]
+            self.phase_events.append(rec)
 
         def lane_loop(L, idx):
             if L.side is not None:
                 L.side.wait_stream(main)
             if stagger and idx > 0:
-                while not done0[0] and self._lane_t[0] < nT:      # lane 0 still inside the cached steps of its first job
+                # lane 0 still inside the cached steps of its FIRST job (released as well when that job is over — _lane_t is reset
+                # per job — or when lane 0 has nothing left to do)
+                while not done0[0] and not first0[0] and self._lane_t[0] < nT:
                     yield
             while todo:
                 lo, hi = todo.pop()
@@ -823,6 +850,8 @@ class RolloutEngine:
                 self._fresh = None
                 self._lane_t[idx] = 0
                 yield from self._lane_gen(L, lo, hi, steps, idx)
+                if idx == 0:
+                    first0[0] = True
                 if self._holds_slot[idx]:
                     self._holds_slot[idx] = False
                     self._sliding -= 1
@@ -839,6 +868,9 @@ class RolloutEngine:
         for L in lanes:
             if L.side is not None:
                 main.wait_stream(L.side)
+        if rec is not None:
+            rec[2] = torch.cuda.Event(enable_timing=True)
+            rec[2].record(main)
         self._max_sliding = 0
         return self
 
@@ -908,7 +940,7 @@ class RolloutEngine:
         if not bad:
             return False
         if bad >= 65536:
-            # simulator events (units of 2^16 of the guard word, csrc/common.h): contacts beyond the island solver's table.  Not a matter
+            # simulator events (the second word of the guard pair, reported in the high half: csrc/common.h): contacts beyond the island solver's table.  Not a matter
             # of the operand split — no fallback, no permanent switch of the model to three planes: raise at once
             raise FloatingPointError(f"{bad >> 16} simulator contacts beyond the island solver's table (csrc/sim.hip: MAX_ISLAND_CONTACTS) in the "
                                      f"rollouts of scenario ranges {[r[1:] if r else '?' for r in runs]}"

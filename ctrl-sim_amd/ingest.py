@@ -140,7 +140,10 @@ def load_nocturne_json(src, index=0, max_pts=100, start_time=0, allow_non_vehicl
             tr[:, 5], tr[:, 6], tr[:, 7] = goal[0], goal[1], f32(obj["length"])
             # get_agent_type_onehot(veh.getType().value) = np.eye(3)[value], value = 1 vehicle, 2 pedestrian (utils/data.py:326-328;
             # a cyclist, value 3, is out of range there — zeros here)
-            gt[cur_id] = {"traj": tr, "type": [float(kind == "unset"), float(kind == "vehicle"), float(kind == "pedestrian")]}
+            # log_len = rows of the file's log from start_time on: the rows behind it are padding, and the reference's
+            # expert_trajectories_.at(id).at(current_time_) (scenario.cc:280) throws there
+            gt[cur_id] = {"traj": tr, "log_len": int(len(pos) - start_time),
+                          "type": [float(kind == "unset"), float(kind == "vehicle"), float(kind == "pedestrian")]}
         cur_id += 1                                          # every spawnable object consumes an id (scenario.cc:992-997)
 
     road_data = road_data_from_json(data.get("roads", []))

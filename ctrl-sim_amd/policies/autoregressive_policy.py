@@ -188,7 +188,7 @@ class AutoregressivePolicy(Policy):
         n = self.states.shape[0]
         eng.policy_step(t)
         bad = eng.nonfinite()                              # NaN logits (fp16 overflow of the split operands, bad weights) must not
-        if bad >= 65536:                                   # simulator events are counted in units of 2^16 (csrc/common.h): not a matter of the split
+        if bad >= 65536:                                   # simulator events: the second word of the guard pair, reported in the high half (csrc/common.h): not a matter of the split
             raise FloatingPointError(f"{bad >> 16} simulator contacts beyond the island solver's table before step {t} (csrc/sim.hip)")
         if bad and eng.split == "auto" and eng.scheme == 1:
             eng._set_split(0)                              # pass as "rtg bin 0 / zero action": redo the step with the range-safe

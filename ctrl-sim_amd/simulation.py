@@ -285,7 +285,7 @@ class Simulation:
         # (cfgs/dataset/waymo/base.yaml:13-16,41-42) for callers that pass token ids through the same entry point
         self.disc6 = (C.c_double * 6)(-10, 10, -0.7, 0.7, 20, 50)
         self.vehs = [Vehicle(self, i) for i in range(self.N)]
-        self.guard = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.guard = torch.zeros(2, dtype=torch.int32, device=dev)   # guard pair (ctrlsim_bind): [1] = simulator events
         self.speed = None
         self.reset()
 
@@ -304,6 +304,7 @@ class Simulation:
         self.hist = torch.zeros(1, N, T1, 8, device=dev)
         self.coll = torch.zeros(1, N, T1, 2, dtype=torch.uint8, device=dev)
         self.t = 0
+        self.log_t = 0                                      # index into the expert logs (scenario.cc:267: current_time_ - start_time)
         self.alive = np.ones(N, np.uint8)
         self.tele = {}                                      # vehicle -> (x, y): set_position requests of this step
         self.act = np.zeros((N, 2), np.float64)
@@ -324,44 +325,54 @@ class Simulation:
         if self.t >= self.steps:
             raise RuntimeError("rollout longer than the allocated history")
         p = _lib.ptr
-        # the step's guard events (contacts beyond the island solver's table) go to THIS simulation's counter, not to whichever engine
-        # bound its own last (ctrlsim_bind: per-caller state); read back with the state row below
-        _lib.check(self.lib.ctrlsim_bind(-1, p(self.guard)), "bind")
-        self.exists.copy_(torch.from_numpy(self.alive[None]).to(self.device))
-        if self.tele:
-            xy = np.full((1, self.N, 2), np.nan, np.float32)
-            for i, q in self.tele.items():
-                xy[0, i] = q
-            _lib.check(self.lib.ctrlsim_sim_set_position(1, self.N, p(torch.from_numpy(xy).to(self.device)), p(self.phys),
-                                                         _lib.stream_ptr()), "sim_set_position")
-            self.tele = {}
-        act = torch.from_numpy(self.act[None].copy()).to(self.device)
+        # Scenario::Step, scenario.cc:267: current_time_ += static_cast<int>(dt / 0.1) — the log index of the NEW time step
+        log_t = self.log_t + int(float(np.float32(dt)) / 0.1)
         expert = None
         if any(v.expert_control for v in self.vehs):
-            # Scenario::Step, scenario.cc:276-283: expert_trajectories_ / _headings_ / _speeds_ .at(id).at(current_time_) of the NEW time
+            # scenario.cc:276-283: expert_trajectories_ / _headings_ / _speeds_ .at(id).at(current_time_) of the new time.  Validated
+            # BEFORE anything is bound or launched: a raise must leave neither a dangling guard binding nor a half-applied step
             if getattr(self, "gt_data_dict", None) is None:
                 raise ValueError("expert_control needs the logged trajectories of a scenario file (Simulation(scenario_path, config))")
             ex = np.full((1, self.N, 4), np.nan, np.float32)
             for i, v in enumerate(self.vehs):
                 if v.expert_control:
-                    tr = self.gt_data_dict[int(self.ids[i])]["traj"]
-                    if self.t + 1 >= len(tr):
-                        raise IndexError("expert trajectory shorter than the rollout (std::out_of_range in the reference)")
-                    ex[0, i] = tr[self.t + 1, :4]
+                    g = self.gt_data_dict[int(self.ids[i])]
+                    tr = g["traj"]
+                    if log_t >= min(len(tr), int(g.get("log_len", len(tr)))):
+                        raise IndexError("expert trajectory shorter than the rollout (std::out_of_range in the reference, scenario.cc:280)")
+                    ex[0, i] = tr[log_t, :4]
             expert = torch.from_numpy(ex).to(self.device)
-        if expert is None:
-            _lib.check(self.lib.ctrlsim_sim_step(1, self.N, self.E, None, p(act), self.disc6, p(self.size), p(self.edges),
-                                                 p(self.exists), p(self.phys), p(self.hist), p(self.coll), None, self.t,
-                                                 self.steps + 1, float(dt), 0, p(self.contact_state), _lib.stream_ptr()), "sim_step")
-        else:
-            _lib.check(self.lib.ctrlsim_sim_step_expert(1, self.N, self.E, None, p(act), self.disc6, p(self.size), p(self.edges),
-                                                        p(self.exists), p(self.phys), p(self.hist), p(self.coll), None, self.t,
-                                                        self.steps + 1, float(dt), p(self.contact_state), p(expert),
-                                                        _lib.stream_ptr()), "sim_step_expert")
-        self.t += 1
-        self._read()
-        self.lib.ctrlsim_unbind(p(self.guard))
-        n = int(self.guard.item())
-        if n:
+        # the step's guard events (contacts beyond the island solver's table) go to THIS simulation's pair, not to whichever engine bound
+        # its own last (ctrlsim_bind: per-caller state); the binding found here is put back afterwards, whatever happens in between — an
+        # engine that bound once for a whole run keeps receiving its events, and the library never keeps a pointer to a freed tensor
+        prev = self.lib.ctrlsim_bound_guard()
+        _lib.check(self.lib.ctrlsim_bind(-1, p(self.guard)), "bind")
+        try:
+            self.exists.copy_(torch.from_numpy(self.alive[None]).to(self.device))
+            if self.tele:
+                xy = np.full((1, self.N, 2), np.nan, np.float32)
+                for i, q in self.tele.items():
+                    xy[0, i] = q
+                _lib.check(self.lib.ctrlsim_sim_set_position(1, self.N, p(torch.from_numpy(xy).to(self.device)), p(self.phys),
+                                                             _lib.stream_ptr()), "sim_set_position")
+                self.tele = {}
+            act = torch.from_numpy(self.act[None].copy()).to(self.device)
+            if expert is None:
+                _lib.check(self.lib.ctrlsim_sim_step(1, self.N, self.E, None, p(act), self.disc6, p(self.size), p(self.edges),
+                                                     p(self.exists), p(self.phys), p(self.hist), p(self.coll), None, self.t,
+                                                     self.steps + 1, float(dt), 0, p(self.contact_state), _lib.stream_ptr()), "sim_step")
+            else:
+                _lib.check(self.lib.ctrlsim_sim_step_expert(1, self.N, self.E, None, p(act), self.disc6, p(self.size), p(self.edges),
+                                                            p(self.exists), p(self.phys), p(self.hist), p(self.coll), None, self.t,
+                                                            self.steps + 1, float(dt), p(self.contact_state), p(expert),
+                                                            _lib.stream_ptr()), "sim_step_expert")
+            self.t += 1
+            self.log_t = log_t
+            self._read()                                        # synchronises: the step's events are in self.guard now
+        finally:
+            self.lib.ctrlsim_bind(-1, prev)
+        n = int(self.guard[1].item())
+        if n or int(self.guard[0].item()):
             self.guard.zero_()
-            raise FloatingPointError(f"{n >> 16} simulator contacts beyond the island solver's table in this step (csrc/sim.hip: MAX_ISLAND_CONTACTS)")
+        if n:
+            raise FloatingPointError(f"{n} simulator contacts beyond the island solver's table in this step (csrc/sim.hip: MAX_ISLAND_CONTACTS)")

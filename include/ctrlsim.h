@@ -368,7 +368,7 @@ int ctrlsim_attn_class_prof(int enable, unsigned long long* host_out);
 /* Runtime options (csrc/common.h: OPT_*).  Keys 0 / 1 = attention / GEMM path of the forward: value 0 = f32-input MFMA
  * (v_mfma_f32_32x32x2_f32), 1 = split-operand 16-bit MFMA with fp32-class accuracy (default).  Key 2 = tile shape of the tiled
  * split-operand GEMM (0 auto; tuning).  Key 3 = fused feed-forward block (default 1).  Key 4 = operand split (1 two fp16 planes,
- * 0 three bf16 planes; per engine through ctrlsim_bind).  Key 5 = reserved (rounds 2-3: a matrix-pipe variant of the map-encoder pooling, removed).
+ * 0 three bf16 planes; per engine through ctrlsim_bind).  These are the PROCESS DEFAULTS; an engine overrides them with its own table (ctrlsim_bind_options).  Key 5 = reserved (rounds 2-3: a matrix-pipe variant of the map-encoder pooling, removed).
  * Key 6 = weight-stationary kernel for the Linear(256 -> 256 G) shapes, bit mask: 1 = launches of at least two 32-row blocks per
  * compute unit, 2 = smaller launches, 4 = the in_proj Linears with K / V-image epilogue, 8 = those through the ROW-stationary kernel
  * (rows in registers, 32-column weight blocks streamed through LDS, every activation row read once; needs the block images of
@@ -384,25 +384,35 @@ int ctrlsim_set_option(int key, int value);
 /* Operand split compiled into the library (csrc/split.h): 1 = two fp16 planes / three products (weights pre-scaled by 2^8), 0 = three
  * bf16 planes / six products.  ctrlsim_amd/pack.py packs weight planes and sizes the K/V images accordingly. */
 int ctrlsim_split_scheme(void);
-/* Non-finite events since the last reset: sampling races (ctrlsim_sample_rtg / _action) that no finite score won, and rows whose
- * LayerNorm variance was not finite in any fused LayerNorm of the forward (the ReLUs of the MLP heads map NaN to 0, so the logits
- * alone do not show an overflow of the fp16 range of the two-plane operand split).  Callers check this count (>= 0;
- * synchronises the device) and fail or repeat with ctrlsim_set_option(4, 0).  reset != 0 clears it.  The counter is one word of
- * device memory per process, allocated at first use on the current device: one host thread and one device per process, like the
- * options and the profiling hooks.  It receives the events of launches made while NO caller-owned counter is bound (ctrlsim_bind below);
- * this function always reads the library's own word, never a bound one.  Units: a non-finite event adds 1, a simulator contact beyond
- * the island solver's table (ctrlsim_sim_step) adds 65536 — count % 65536 and count / 65536 tell them apart. */
+/* Guard events since the last reset.  The guard is a PAIR of device int32 words: [0] non-finite events of the model — sampling races
+ * (ctrlsim_sample_rtg / _action) that no finite score won, and rows whose LayerNorm variance was not finite in any fused LayerNorm of the
+ * forward (the ReLUs of the MLP heads map NaN to 0, so the logits alone do not show an overflow of the fp16 range of the two-plane operand
+ * split) — and [1] simulator events: contacts of an island beyond the solver's table (ctrlsim_sim_step).  Callers check the count (>= 0;
+ * synchronises the device) and fail or repeat with ctrlsim_set_option(4, 0).  reset != 0 clears it.  The library's own pair is allocated at
+ * first use on the current device; it receives the events of launches made while NO caller-owned pair is bound (ctrlsim_bind below), and
+ * this function always reads the library's own pair, never a bound one.  Return value: min(non-finite events, 65535) +
+ * 65536 * min(simulator events, 32767) — count % 65536 and count / 65536 tell them apart, and neither kind can carry into the other
+ * (the device counts them in separate words). */
 int ctrlsim_nonfinite_count(int reset);
 /* Per-caller state instead of the process-wide defaults: split_scheme (0 / 1; -1 = leave as is) selects the operand split the
- * caller's weight planes, K/V images and workspace were built for, guard_counter is a device int32 the CALLER owns (zeroed and read
- * by the caller: the library neither allocates nor synchronises for it) that receives every guard event until the next bind — the
- * non-finite events above and contacts of a simulator island beyond the solver's table (ctrlsim_sim_step).  NULL = the library's
- * own word behind ctrlsim_nonfinite_count.  An engine re-asserts its pair at the top of every run, so several engines (planner and
- * adversary policies, a second model) can take turns in one process; still one host thread at a time.  Replaces nothing in the
- * reference: its per-process analogue is nocturne's global Box2D world (physics/Singletons.cpp:5-25). */
+ * caller's weight planes, K/V images and workspace were built for, guard_counter points at TWO device int32 the CALLER owns (zeroed and
+ * read by the caller: the library neither allocates nor synchronises for them) that receive every guard event until the next bind —
+ * [0] the non-finite events above, [1] the simulator events.  NULL = the library's own pair behind ctrlsim_nonfinite_count.  An engine
+ * re-asserts its state at the top of every run, so several engines (planner and adversary policies, a second model) can take turns in one
+ * process; still one host thread at a time.  Replaces nothing in the reference: its per-process analogue is nocturne's global Box2D world
+ * (physics/Singletons.cpp:5-25). */
 int ctrlsim_bind(int split_scheme, int* guard_counter);
-/* Before the caller frees a bound counter: un-binds it if it is the bound one (no-op otherwise). */
+/* Before the caller frees a bound pair: un-binds it if it is the bound one (no-op otherwise). */
 int ctrlsim_unbind(const int* guard_counter);
+/* The pair bound at the moment (NULL = the library's own): a caller that binds its own for ONE call (Simulation.step) restores this one. */
+int* ctrlsim_bound_guard(void);
+/* Per-engine option table (round 5): values = ctrlsim_option_count() ints in host memory (copied); an entry >= 0 overrides the process
+ * default of ctrlsim_set_option for every launch until the next ctrlsim_bind_options, -1 inherits it; NULL = the process defaults.
+ * Re-asserted by an engine at the top of every run like ctrlsim_bind: two engines with different kernel options take turns in one process.
+ * ctrlsim_get_option = the value launches would use now. */
+int ctrlsim_option_count(void);
+int ctrlsim_bind_options(const int* values);
+int ctrlsim_get_option(int key);
 
 const char* ctrlsim_version(void);
 

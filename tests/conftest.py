@@ -37,3 +37,21 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.fixture(autouse=True)
+def _no_engine_state_leaks_between_tests(request):
+    """An engine's option table and guard pair stay bound until the next engine binds (include/ctrlsim.h: ctrlsim_bind /
+    ctrlsim_bind_options): tests that call the C ABI directly must start from the process defaults, whatever engine ran before."""
+    if "gpu" in request.keywords:
+        so = os.path.join(ROOT, "ctrl-sim_amd", "csrc", "libctrlsim_hip.so")
+        if os.path.exists(so):
+            import ctrlsim_amd  # noqa: F401
+            from ctrlsim_amd import _lib
+            l = _lib.lib()
+            l.ctrlsim_bind_options(None)
+            l.ctrlsim_bind(-1, None)
+    yield

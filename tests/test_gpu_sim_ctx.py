@@ -352,26 +352,26 @@ def test_at_scale_token_agreement_between_the_split_and_the_f32_kernel_families(
     w = weights.generate(d, 0)
     scns = scenarios.make_batch(3, range(S), n_agents=64, n_polylines=512)
     a = RolloutEngine(cfg, w, DEV, max_ctx=128, seed=17, lanes=1)
-    b = RolloutEngine(cfg, w, DEV, max_ctx=512, seed=17, lanes=1, compact=False, model=a.model)
+    # the f32-input kernel family is engine b's OWN option table (ctrlsim_bind_options, round 5): no process-wide switch is flipped
+    # between the two engines' steps, and the process defaults are the shipped ones before, during and after
+    b = RolloutEngine(cfg, w, DEV, max_ctx=512, seed=17, lanes=1, compact=False, model=a.model, options={0: 0, 1: 0})
     a.load_scenarios(scns, steps=steps)
     b.load_scenarios(scns, steps=steps)
     lib = a.lib
     flips_tok = flips_rtg = total = 0
-    try:
-        for t in range(steps):
-            for k in ("hist_states", "hist_tok", "hist_rtg", "persist", "coll"):
-                getattr(b, k).copy_(getattr(a, k))
-            a.step(t)
-            lib.ctrlsim_set_option(0, 0); lib.ctrlsim_set_option(1, 0)
-            b.policy_step(t)
-            torch.cuda.synchronize()
-            lib.ctrlsim_set_option(0, 1); lib.ctrlsim_set_option(1, 1)
-            assert torch.equal(a.n_groups, b.n_groups)
-            flips_tok += int((a.hist_tok[:, :, t] != b.hist_tok[:, :, t]).sum())
-            flips_rtg += int((a.hist_rtg[:, :, t] != b.hist_rtg[:, :, t]).sum())
-            total += S * 64 * 4
-    finally:
-        lib.ctrlsim_set_option(0, 1); lib.ctrlsim_set_option(1, 1)
+    for t in range(steps):
+        for k in ("hist_states", "hist_tok", "hist_rtg", "persist", "coll"):
+            getattr(b, k).copy_(getattr(a, k))
+        a.step(t)
+        assert lib.ctrlsim_get_option(0) == 1 and lib.ctrlsim_get_option(1) == 1
+        b.policy_step(t)
+        assert lib.ctrlsim_get_option(0) == 0 and lib.ctrlsim_get_option(1) == 0
+        assert torch.equal(a.n_groups, b.n_groups)
+        flips_tok += int((a.hist_tok[:, :, t] != b.hist_tok[:, :, t]).sum())
+        flips_rtg += int((a.hist_rtg[:, :, t] != b.hist_rtg[:, :, t]).sum())
+        total += S * 64 * 4
+    lib.ctrlsim_bind_options(None)
+    assert lib.ctrlsim_get_option(0) == 1 and lib.ctrlsim_get_option(1) == 1      # the process defaults were never touched
     assert a.nonfinite() == 0 and b.nonfinite() == 0
     print(f"at-scale agreement: {flips_tok} action-token and {flips_rtg} RTG-bin differences in {total} sampled ids")
     assert flips_tok + flips_rtg <= 12, (flips_tok, flips_rtg, total)          # < 5e-5 of the samples
@@ -850,11 +850,42 @@ def test_two_engines_with_different_splits_take_turns_in_one_process():
     for t in range(steps):
         ea.step(t)
         eb.step(t)
-    eb.guard.fill_(3)                                            # an event in B's counter only
+    eb.guard[0] = 3                                              # events in B's counter only
     assert ea.nonfinite() == 0 and eb.nonfinite() == 3
     for e in (ea, eb):
         assert np.array_equal(e.hist_tok.cpu().numpy()[0][:, :steps], o["tokens"]), e.split
         np.testing.assert_allclose(e.hist_states.cpu().numpy()[0], o["states"], atol=1e-4, rtol=0)
+
+
+def test_guard_words_do_not_carry_into_each_other():
+    """The guard is a pair of device words (include/ctrlsim.h: ctrlsim_bind).  At production scale an fp16 overflow produces far more than
+    2^16 non-finite LayerNorm rows before the rollout is checked: the count must stay a NON-FINITE count (the automatic fallback to three
+    bf16 planes must still engage) and must not read as simulator events — and 2^15 or more simulator events must not read as a negative
+    / non-finite count.  (Round-4 review: both kinds shared one word in units of 1 and 2^16.)"""
+    cfg = cfg_of("loop")
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    hot = dict(w)
+    hot["encoder.embed_ln.weight"] = w["encoder.embed_ln.weight"] * np.float32(3e4)
+    scn = scenarios.make_scenario(81, 0, n_agents=8, n_polylines=14, n_points=d.NP, extent=30.0)
+    steps = 6
+    oh = rollout_oracle.RolloutOracle(cfg, hot, seed=4).run(scn, steps, sim_libs.OracleSim)
+    eng = RolloutEngine(cfg, hot, DEV, max_ctx=24, seed=4, split="auto")
+    eng.load_scenarios([scn], steps=steps)
+    eng.guard[0] = 70000                                         # as if thousands of rows had already overflowed
+    eng.run(steps)
+    assert int(eng.guard[0]) > 70000 and int(eng.guard[1]) == 0  # the run's own events on top, none in the simulator's word
+    r = eng.results()                                            # check_finite: fallback, not "simulator contacts"
+    assert eng.scheme == 0 and eng.model.split_fallback
+    assert np.array_equal(r["tokens"][0][:, :steps], oh["tokens"])
+    eng.guard[0] = 2 ** 31 - 1                                   # saturates, stays positive
+    assert eng.nonfinite() == 65535
+    eng.guard[1] = 40000                                         # >= 2^15 simulator events: reported saturated, still a simulator event
+    n = eng.nonfinite(reset=False)
+    assert n >> 16 == 32767 and n & 65535 == 0
+    eng._unchecked = [(steps, 0, 1)]
+    with pytest.raises(FloatingPointError, match="simulator contacts"):
+        eng.check_finite()
 
 
 def test_unchecked_earlier_slice_is_repeated_too():
@@ -928,6 +959,38 @@ def test_pipelined_jobs_equal_one_run_per_range(stagger, lanes):
     r2 = eng.results()
     for k in ("tokens", "rtg_bins", "coll", "states"):
         assert np.array_equal(r0[k], r2[k]), k
+
+
+def test_pipelined_jobs_shorter_than_the_window_use_both_lanes_and_record_phases():
+    """run_jobs with rollouts that never leave the K/V-cached steps (steps <= T): lane 1 must not wait for lane 0 to drain every job (the
+    stagger rule keys on lane 0 leaving the cached steps, which never happens here), and record_phases must get its own record instead of
+    indexing the records of run() (round-4 advice)."""
+    cfg = cfg_of("loop")
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    S, steps = 12, d.T - 1
+    scns = [scenarios.make_scenario(57, i, n_agents=9, n_polylines=14, n_points=d.NP, extent=22.0) for i in range(S)]
+    ref = RolloutEngine(cfg, w, DEV, max_ctx=64, seed=5, lanes=1)
+    ref.load_scenarios(scns, steps=steps)
+    r0 = ref.rollout(steps).results()
+    eng = RolloutEngine(cfg, w, DEV, max_ctx=64, seed=5, lanes=2, model=ref.model)
+    eng.load_scenarios(scns, steps=steps)
+    eng.record_phases = True
+    started = []
+    orig = eng._lane_gen
+
+    def spy(L, lo, hi, st, idx=None):
+        started.append((L.idx, len(started)))
+        return orig(L, lo, hi, st, idx)
+    eng._lane_gen = spy
+    eng.run_jobs([(0, 3), (3, 6), (6, 9), (9, 12)], steps, stagger=True)
+    r1 = eng.results()
+    for k in ("tokens", "rtg_bins", "coll", "states", "n_groups"):
+        assert np.array_equal(r0[k], r1[k]), k
+    assert {l for l, _ in started} == {0, 1}                     # both lanes rolled jobs
+    assert [l for l, _ in started][:2] == [0, 1]                 # lane 1 took the SECOND job, not what lane 0 left over
+    assert len(eng.phase_events) == 1 and eng.phase_events[0][2] is not None
+    eng.phase_times()
 
 
 def test_contact_table_overflow_is_counted_not_silent():
