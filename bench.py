@@ -71,16 +71,23 @@ def main():
     ap.add_argument("--spot-check", type=int, default=4, help="scenarios re-rolled alone after the timed region (bit-identity check; 0 = off)")
     ap.add_argument("--cpu-sample-scenarios", type=int, default=2)
     ap.add_argument("--cpu-sample-steps", type=int, default=2)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU rehearsal of the MULTI-RANK FLOW only (tests/test_dist_cpu.py: world 8 over gloo, no GPU): a stand-in engine that "
+                         "sleeps instead of rolling, everything rank-dependent — scenario ids, tilt per global id, a model batch reduced on some "
+                         "ranks, barriers, the MAX / gather of the elapsed time, the SUM all-reduce of the metric vector, the parting barrier, "
+                         "rank 0's CPU sample after the others left — through the same code as a real run.  The line it prints is marked "
+                         "dry_run and is never a measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if not torch.cuda.is_available():
+    dry = bool(args.dry_run)
+    if not dry and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     # debugging aid only: several ranks on ONE GPU with gloo collectives, to exercise the multi-rank flow on a 1-GPU box
-    shared_gpu = os.environ.get("CTRLSIM_BENCH_DEBUG_SHARED_GPU") == "1"
+    shared_gpu = os.environ.get("CTRLSIM_BENCH_DEBUG_SHARED_GPU") == "1" and not dry
     if shared_gpu:
         local_rank %= torch.cuda.device_count()
     # CTRLSIM_BENCH_FORCE_DIST=1: initialise torch.distributed (backend nccl = RCCL) even at world size 1, so that the job's one
@@ -96,51 +103,57 @@ def main():
                 port = sk.getsockname()[1]
             for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(port)), ("RANK", "0"), ("WORLD_SIZE", "1")):
                 os.environ.setdefault(k, v)
-        if shared_gpu:
+        if shared_gpu or dry:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    device = f"cuda:{local_rank}"
-    coll_device = "cpu" if shared_gpu else device
-    torch.cuda.set_device(device)
+    device = "cpu" if dry else f"cuda:{local_rank}"
+    coll_device = "cpu" if (shared_gpu or dry) else device
+    if not dry:
+        torch.cuda.set_device(device)
 
     import ctrlsim_amd  # noqa: F401
-    from ctrlsim_amd import spec, weights, scenarios, metrics, _lib
-    from ctrlsim_amd.engine import RolloutEngine
-
-    for kv in filter(None, os.environ.get("CTRLSIM_OPTIONS", "").split(",")):   # "<option>=<value>,...": kernel A/B runs only
-        k, v = kv.split("=")
-        _lib.lib().ctrlsim_set_option(int(k), int(v))
+    from ctrlsim_amd import spec, weights, scenarios, metrics
+    from ctrlsim_amd.dist import rank_plan, gather_scalar
+    if not dry:
+        from ctrlsim_amd import _lib
+        from ctrlsim_amd.engine import RolloutEngine
+        for kv in filter(None, os.environ.get("CTRLSIM_OPTIONS", "").split(",")):   # "<option>=<value>,...": kernel A/B runs only
+            k, v = kv.split("=")
+            _lib.lib().ctrlsim_set_option(int(k), int(v))
     cfg = spec.make_cfg(nocturne__steps=args.rollout_steps, nocturne__history_steps=1)
     d = spec.Dims(cfg)
     w = weights.generate(d, 0)
     S, N, R, K = args.scenarios, args.agents, args.rollout_steps, args.steps
     if K < 1 or K > S:
         raise SystemExit("--steps must be in [1, --scenarios]: the timed steps are slices of the resident batch")
-    # global scenario ids: interleaved over ranks (rank r takes r, r+W, ...) so results do not depend on W
-    ids = [rank + i * world for i in range(S)]
+    # global scenario ids: interleaved over ranks (rank r takes r, r+W, ...) so results do not depend on W; with --tilt-sweep the tilt
+    # of a scenario follows its GLOBAL id (ctrlsim_amd/dist.py: rank_plan — the same function the CPU rehearsal of world 8 runs)
+    ids, sweep_tilt = rank_plan(rank, world, S, args.tilt_sweep)
     t_gen = time.perf_counter()
     scns = scenarios.make_batch(args.seed, ids, n_agents=N, n_polylines=args.polylines)
     gen_s = time.perf_counter() - t_gen
     tilt = tuple(args.tilt)
     if args.tilt_sweep:                                       # the sweep values of config 5
-        sweep = np.array([-20.0, -10.0, -5.0, 0.0, 5.0, 10.0, 20.0, 30.0])
-        tilt = np.repeat(sweep[np.array(ids) % 8][:, None], 3, axis=1)
-    if os.environ.get("CTRLSIM_MAIN_CU_MASK"):                # A/B experiment: the main stream on a subset of the compute units
+        tilt = sweep_tilt
+    if os.environ.get("CTRLSIM_MAIN_CU_MASK") and not dry:                # A/B experiment: the main stream on a subset of the compute units
         from ctrlsim_amd.engine import _new_stream
         torch.cuda.set_stream(_new_stream(torch.device(device), os.environ["CTRLSIM_MAIN_CU_MASK"]))
     eng = None
     max_ctx_asked = args.max_ctx
     while eng is None:                                        # the lanes' workspaces are sized for max_ctx plain contexts: if the
         try:                                                  # device does not have that much free, halve the model batch
-            eng = RolloutEngine(cfg, w, device, max_ctx=args.max_ctx, seed=args.seed, tilt=tilt, lanes=args.lanes,
-                                sizes=tuple(int(x) for x in args.sizes.split(",")) if args.sizes else None)
+            if dry:
+                eng = _DryEngine(cfg, rank, ids, args.max_ctx)
+            else:
+                eng = RolloutEngine(cfg, w, device, max_ctx=args.max_ctx, seed=args.seed, tilt=tilt, lanes=args.lanes,
+                                    sizes=tuple(int(x) for x in args.sizes.split(",")) if args.sizes else None)
         except torch.OutOfMemoryError:
             if args.max_ctx <= 128:
                 raise
             args.max_ctx //= 2
             print(f"[bench] out of device memory: model batch reduced to {args.max_ctx} contexts", file=sys.stderr)
-        if eng is None:                                       # (outside the handler: the traceback no longer pins the half-built engine)
+        if eng is None and not dry:                           # (outside the handler: the traceback no longer pins the half-built engine)
             import gc
             gc.collect()
             torch.cuda.empty_cache()
@@ -149,19 +162,20 @@ def main():
     if args.side is not None:
         on = set(filter(None, args.side.split(",")))
         eng.pass2_on_side, eng.tail_on_side, eng.cached_on_side = "p2" in on, "tail" in on, "cached" in on
-    torch.cuda.synchronize()
+    sync = (lambda: None) if dry else torch.cuda.synchronize
+    sync()
     t_up = time.perf_counter()
     eng.load_scenarios(scns, steps=R)                         # host -> HBM: the only PCIe traffic of a rollout (untimed)
-    torch.cuda.synchronize()
+    sync()
     upload_ms = (time.perf_counter() - t_up) * 1e3
-    lib = _lib.lib()
+    lib = None if dry else _lib.lib()
     cuts = [S * i // K for i in range(K + 1)]                 # K slices, sizes floor / ceil (S / K), sum = S
 
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     def bench_step(i):                                        # one 90-step closed-loop rollout of slice i
         a, b = cuts[i % K], cuts[i % K + 1]
@@ -184,15 +198,19 @@ def main():
 
     bench_steps(0, args.warmup)
     barrier()
-    lib.ctrlsim_prof_enable(1)
+    if not dry:
+        lib.ctrlsim_prof_enable(1)
     eng.record_phases, eng.phase_events = not args.pipeline, []
     eng.full_pass_contexts = np.zeros(len(eng.sizes), np.int64)
     t0 = time.perf_counter()
     bench_steps(0, K)
+    t_own = time.perf_counter() - t0                          # this rank's own time to its last kernel (before it waits for the others)
     barrier()
     elapsed = time.perf_counter() - t0
     eng.record_phases = False
     cached_s, sliding_s = eng.phase_times()
+    if dry:
+        return _finish_dry(args, dist, rank, world, eng, cfg, scns, ids, elapsed, t_own, max_ctx_asked, coll_device, gather_scalar, metrics, tilt)
     ncls = int(lib.ctrlsim_prof_classes())
     # Launch intervals (HIP events on the launch stream).  The engine runs the big kernels of both lanes back to back on ONE
     # stream (the current one) and, underneath them on the lanes' side streams, the few-row kernels of the second pass, the
@@ -211,10 +229,7 @@ def main():
     for i in range(2, ncls):                                  # satellites: wherever they ran
         ms[i] += sms[i]; cnt[i] += scnt[i]; fl[i] += sfl[i]; by[i] += sby[i]
     lib.ctrlsim_prof_enable(0)
-    t_el = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
-    if dist is not None:
-        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
-    elapsed = float(t_el.item())
+    elapsed, rank_times, rank_ctx = _reduce_times(dist, elapsed, t_own, args.max_ctx, coll_device, gather_scalar)
 
     # ---- parity spot check (untimed): a few scenarios of the batch are rolled again, ALONE, by a second engine (one lane, small model
     # batches, no other scenario in their forward chunks): tokens, RTG bins, collision flags and float32 trajectories must be
@@ -432,7 +447,9 @@ def main():
                        "phases": None if args.pipeline else {"cached_s": cached_s, "sliding_s": sliding_s,
                                   "note": "main-stream time of the timed rollouts until the last lane of a slice left its K/V-cached steps "
                                           "(t < 32: few-row kernels only, on the side streams) / after it (full recompute per step)"},
-                       "model_batch_reduced": args.max_ctx != max_ctx_asked, "model_batch_contexts_requested": max_ctx_asked,
+                       "model_batch_reduced": any(c != max_ctx_asked for c in rank_ctx), "model_batch_contexts_requested": max_ctx_asked,
+                       "model_batch_contexts_per_rank": rank_ctx,
+                       "rank_elapsed_s": rank_times,
                        "contexts_per_rollout_rank0": ctx_per_rollout,
                        "mean_focal_groups_per_scenario_step": ctx_per_rollout / (S * R),
                        "scenario_upload_ms_untimed": upload_ms, "scenario_generation_s_untimed": gen_s,
@@ -446,6 +463,94 @@ def main():
             "rollout_metrics": {k: (None if v != v else v) for k, v in m.items()},
         }
         print(json.dumps(out))
+
+
+def _reduce_times(dist, elapsed, t_own, max_ctx, coll_device, gather_scalar):
+    """The timed region's wall time is the MAX over ranks (the contract); next to it every rank's OWN time to its last kernel — a straggler
+    shows as max >> min in the driver's SCALE line — and every rank's model batch (a rank that ran out of device memory halves its own)."""
+    own = gather_scalar(dist, t_own, coll_device)
+    ctx = [int(round(v)) for v in gather_scalar(dist, float(max_ctx), coll_device)]
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
+    if dist is not None:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+    return float(t_el.item()), {"min": min(own), "max": max(own), "per_rank": own,
+                                "note": "each rank's own time from the start barrier to the end of its last rollout (before it waits at the "
+                                        "closing barrier); value is computed from the MAX over ranks of the barrier-to-barrier time"}, ctx
+
+
+class _DryEngine:
+    """--dry-run only: stands where RolloutEngine stands in main() so that the rank flow around it is the real one.  It rolls nothing — a
+    run() sleeps a time proportional to the scenarios of the slice (rank 3 a little longer: a straggler) — and its metric vector is the
+    packed accumulators of FAKE rollouts keyed by the GLOBAL scenario ids, so the all-reduced vector must equal a single process's over
+    the union of the ids whatever the world size.  Environment: CTRLSIM_BENCH_DRY_OOM_RANKS="3,5" makes those ranks fail their first
+    engine construction with torch.OutOfMemoryError, as a GPU with less free memory would."""
+    _failed_once = False
+
+    def __init__(self, cfg, rank, ids, max_ctx):
+        oom = {int(x) for x in filter(None, os.environ.get("CTRLSIM_BENCH_DRY_OOM_RANKS", "").split(","))}
+        if rank in oom and not _DryEngine._failed_once:
+            _DryEngine._failed_once = True
+            raise torch.OutOfMemoryError("dry run: simulated out of device memory")
+        self.cfg, self.rank, self.ids, self.max_ctx = cfg, rank, list(ids), max_ctx
+        self.sizes, self.record_phases, self.phase_events, self.full_pass_contexts = (24,), False, [], 0
+        self.rolled = []
+
+    def load_scenarios(self, scns, steps=None):
+        self.scns = scns
+
+    def reset(self, a, b):
+        pass
+
+    def run(self, steps, s0=0, s1=None):
+        time.sleep(0.002 * (s1 - s0) * (1.5 if self.rank == 3 else 1.0))
+        self.rolled.append((s0, s1))
+
+    def run_jobs(self, jobs, steps):
+        for a, b in jobs:
+            self.run(steps, a, b)
+
+    def phase_times(self):
+        return 0.0, 0.0
+
+    def fake_metric_vector(self, metrics):
+        acc = metrics.MetricAccumulators()
+        T1 = self.cfg.nocturne.steps + 1
+        for gid, scn in zip(self.ids, self.scns):
+            rs = np.random.RandomState(1000 + gid)
+            N = scn.N
+            st = np.zeros((N, T1, 8))
+            st[..., :2] = np.stack([scn.x, scn.y], 1)[:, None] + np.cumsum(rs.normal(0, 0.5, (N, T1, 2)), 1)
+            st[..., 2:4] = rs.normal(0, 3, (N, T1, 2)); st[..., 4] = rs.uniform(-3, 3, (N, T1)); st[..., 7] = 1
+            coll = (rs.uniform(size=(N, T1, 2)) < 0.01).astype(np.uint8)
+            gt = np.zeros((N, T1, 5)); gt[..., :2] = st[..., :2] + rs.normal(0, 1, (N, T1, 2)); gt[..., 3] = 5; gt[..., 4] = 1
+            acc.add_scenario(st, coll, rs.uniform(-10, 10, (N, T1)), gt, scn.goal_pos.astype(float), scn.goal_heading.astype(float),
+                             scn.goal_speed.astype(float), self.cfg)
+        return torch.from_numpy(acc.pack())
+
+
+def _finish_dry(args, dist, rank, world, eng, cfg, scns, ids, elapsed, t_own, max_ctx_asked, coll_device, gather_scalar, metrics, tilt):
+    """The tail of main() for --dry-run: the same collectives in the same order as the real run (time reduction, SUM all-reduce of the
+    metric vector, parting barrier, destroy), then rank 0 alone takes its CPU sample (here: a sleep) and prints."""
+    elapsed, rank_times, rank_ctx = _reduce_times(dist, elapsed, t_own, args.max_ctx, coll_device, gather_scalar)
+    vec = eng.fake_metric_vector(metrics).to(coll_device)
+    if dist is not None:
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+    backend = dist.get_backend() if dist is not None else "none (single process)"
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    time.sleep(float(os.environ.get("CTRLSIM_BENCH_DRY_CPU_S", "0")))     # rank 0's CPU baseline: the other ranks have left already
+    S, N, R, K = args.scenarios, args.agents, args.rollout_steps, args.steps
+    tl = np.asarray(tilt, np.float64)
+    print(json.dumps({"dry_run": True, "metric": "DRY RUN of the rank flow — not a measurement", "value": None, "n_gpus": world, "steps": K,
+                      "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "scaling": "weak",
+                      "config": {"scenario_ids_rank0": ids, "tilt_rank0": tl[:, 0].tolist() if tl.ndim == 2 else tl.tolist(),
+                                 "model_batch_contexts_requested": max_ctx_asked, "model_batch_contexts_per_rank": rank_ctx,
+                                 "model_batch_reduced": any(c != max_ctx_asked for c in rank_ctx), "rank_elapsed_s": rank_times,
+                                 "collective": f"one all-reduce (SUM) of the {int(vec.numel())}-double metric vector + barriers, backend {backend}, world {world}"},
+                      "agent_steps_counted": S * N * R * world, "metric_vector": vec.cpu().numpy().tolist()}))
 
 
 def cpu_model():

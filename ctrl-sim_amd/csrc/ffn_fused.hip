@@ -126,7 +126,13 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
 #else
       op_t* ddst_a = ring + (slot == 0 ? 2 : slot - 1) * FF_BLK + wave * 64 * 8;
 #endif
+#ifdef FFN_H2
+      f32x16 hacc, hacc2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hacc2[r] = 0.f;
+#else
       f32x16 hacc;
+#endif
       {
         const float* bp = b1s + hb * 32 + 4 * half;                    // register r <-> hidden (r & 3) + 8 (r >> 2) + 4 half
 #pragma unroll
@@ -157,7 +163,11 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
 #ifndef ABL_NO_DMA
           if (ks < FF_PIECES) dma_piece(dsrc_a, ddst_a, ks);
 #endif
+#ifdef FFN_H2
+          if (ks & 1) { FFN_TERMS(hacc2, wf[ks & 3], xT[ks]) } else { FFN_TERMS(hacc, wf[ks & 3], xT[ks]) }
+#else
           FFN_TERMS(hacc, wf[ks & 3], xT[ks])
+#endif
         }
       }
       // ReLU + split: k-step kk of the second product uses accumulator registers 8 kk .. 8 kk + 7
@@ -165,7 +175,11 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
       {
         float hv[16];
 #pragma unroll
+#ifdef FFN_H2
+        for (int r = 0; r < 16; ++r) hv[r] = fmaxf((hacc[r] + hacc2[r]) * WSCALE_INV, 0.f);
+#else
         for (int r = 0; r < 16; ++r) hv[r] = fmaxf(hacc[r] * WSCALE_INV, 0.f);
+#endif
 #ifndef ABL_NO_SPLIT
         split_frag(hv, hf[0]);
         split_frag(hv + 8, hf[1]);
@@ -196,11 +210,18 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
       {
         const op_t* w2 = ring + slot * FF_BLK + (half * 256 + l31) * 8;   // [p][kk][half][o][8]
         opx8 wf[4][NPL];
+#ifdef FFN_KKMAJOR
+#define FFN_OB(i) ((i) & 7)
+#define FFN_KK(i) ((i) >> 3)
+#else
+#define FFN_OB(i) ((i) >> 1)
+#define FFN_KK(i) ((i) & 1)
+#endif
         auto ld2 = [&](int i, opx8 (&f)[NPL]) {        // step i = (out block ob = i >> 1, k-step kk = i & 1)
 #pragma unroll
           for (int p = 0; p < NPL; ++p)
 #ifndef ABL_NO_FRAG
-            f[p] = *reinterpret_cast<const opx8*>(w2 + (((p * 2 + (i & 1)) * 2) * 256 + (i >> 1) * 32) * 8);
+            f[p] = *reinterpret_cast<const opx8*>(w2 + (((p * 2 + FFN_KK(i)) * 2) * 256 + FFN_OB(i) * 32) * 8);
 #else
           { f[p] = hf[i & 1][p]; asm volatile("" : "+v"(f[p])); }
 #endif
@@ -214,7 +235,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
 #ifndef ABL_NO_DMA
           if (i < FF_PIECES) dma_piece(dsrc_b, ddst_b, i);
 #endif
-          FFN_TERMS(yacc[i >> 1], wf[i & 3], hf[i & 1])
+          FFN_TERMS(yacc[FFN_OB(i)], wf[i & 3], hf[FFN_KK(i)])
         }
       }
 #if FFN_PAIR_BARRIER

@@ -14,6 +14,30 @@ def shard_ids(rank: int, world: int, per_rank: int):
     return [rank + i * world for i in range(per_rank)]
 
 
+TILT_SWEEP = (-20.0, -10.0, -5.0, 0.0, 5.0, 10.0, 20.0, 30.0)      # the eight tilt values of BASELINE configs[4]
+
+
+def rank_plan(rank: int, world: int, per_rank: int, tilt_sweep: bool = False):
+    """What rank `rank` of `world` rolls: (global scenario ids, per-scenario tilt triples [per_rank, 3] or None).  The tilt of a
+    scenario follows its GLOBAL id (id % 8 picks the sweep value for goal = vehicle = road-edge tilt), so the sweep — like the
+    scenarios and their noise streams — does not depend on the world size."""
+    ids = shard_ids(rank, world, per_rank)
+    tilt = None
+    if tilt_sweep:
+        tilt = np.repeat(np.asarray(TILT_SWEEP)[np.asarray(ids) % len(TILT_SWEEP)][:, None], 3, axis=1)
+    return ids, tilt
+
+
+def gather_scalar(dist, value: float, device="cpu"):
+    """[value of rank 0, ..., value of rank W-1] on every rank (all_gather of one double); [value] without a process group."""
+    if dist is None:
+        return [float(value)]
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
 def allreduce_metrics(acc, device="cpu"):
     """In-place SUM over all ranks of a MetricAccumulators; no-op without an initialised process group."""
     import torch.distributed as dist

@@ -73,6 +73,58 @@ def gen_model():
         save(f"model_{tag}", **out)
 
 
+def gen_model_trained():
+    """Round 5: the unmodified reference Encoder / Decoder at FULL dims with trained-like weights (weights.generate_trained_like:
+    LayerNorm gains in [0.5, 2], per-row / per-column matrix scales, embedding rows over three decades, query / key rows x 2, head
+    gain 15: |logit| up to ~30, max probabilities 0.3-0.96).  Next to the float32 reference logits the fixture holds the float64
+    evaluation of the same network (the oracle's functional form in double) so that tests can see how far float32 itself is from
+    exact arithmetic in this regime."""
+    cfg = spec.make_cfg()
+    d = spec.Dims(cfg)
+    out = {}
+    for wseed, (seed, t_fill, n_ag, n_pl) in ((0, (1, d.T, d.A - 3, d.P - 10)), (1, (2, 9, d.A, d.P)), (0, (3, d.T, 7, d.P - 40))):
+        w = weights.generate_trained_like(d, wseed)
+        ref = ref_shims.build_reference_model(cfg, w)
+        inp = synth_inputs.random_context(d, seed, B=1, t_fill=t_fill, n_agents=n_ag, n_polys=n_pl)
+        r = ref(synth_inputs.to_motion_data(inp), eval=True)
+        ti = t_fill - 1
+        with torch.no_grad():
+            orig = torch.Tensor.float
+            torch.Tensor.float = lambda self, *a, **k: self.double()
+            try:
+                o64 = model_oracle.forward({k: torch.from_numpy(v).double() for k, v in w.items()}, synth_inputs.to_torch(inp), d)
+            finally:
+                torch.Tensor.float = orig
+        for k, nm in (("action_preds", "action_logits"), ("rtg_preds", "rtg_logits")):
+            out[f"s{seed}_{nm}"] = r[k][0, :, ti].detach().numpy()
+            out[f"s{seed}_{nm}_f64"] = o64[k][0, :n_ag, ti].numpy()          # live slots only
+            e = np.abs(out[f"s{seed}_{nm}"][:n_ag] - out[f"s{seed}_{nm}_f64"]).max()
+            print(seed, nm, "max|logit|", np.abs(out[f"s{seed}_{nm}"][:n_ag]).max(), "reference fp32 vs float64", e)
+        out[f"s{seed}_recipe"] = np.array([seed, t_fill, n_ag, n_pl, wseed])
+    save("model_trained", **out)
+
+
+def gen_closed_loop_trained():
+    """Closed loops of the unmodified reference policy + real FreeCar / Box2D at the trained-like weights: "a" the small closed-loop
+    model (LOOP dims, 10 vehicles x 20 steps, sharp distributions: the sampled ids are mostly the arg max), "b" FULL dims, 10 vehicles
+    x 230 polylines x 34 steps (two past the window slide; the reference sizes its window by min(steps, T), so a full-dims loop needs
+    steps >= T)."""
+    out = {}
+    for tag, over, n_ag, n_pl, steps, extent, tilt in (("a", LOOP, 10, 14, 20, 40.0, (0.0, 0.0, 0.0)),
+                                                        ("b", dict(nocturne__steps=34), 10, 230, 34, 40.0, (5.0, -10.0, 10.0))):
+        cfg = spec.make_cfg(**over)
+        d = spec.Dims(cfg)
+        w = weights.generate_trained_like(d, 0)
+        scn = scenarios.make_scenario(13, {"a": 0, "b": 1}[tag], n_agents=n_ag, n_polylines=n_pl, n_points=d.NP, extent=extent)
+        r = ref_closed_loop(cfg, w, scn, steps, seed=6, tilt=tilt)
+        print(tag, "groups/step", r["n_groups"], "min race margin", r["margins"].min(), "collisions", r["coll"].sum(0).sum(0),
+              "distinct tokens", len(np.unique(r["tokens"])))
+        for k in ("tokens", "rtg_cont", "states", "coll", "actions", "n_groups", "margins"):
+            out[f"{tag}_{k}"] = r[k]
+        out[f"{tag}_recipe"] = np.array([13, {"a": 0, "b": 1}[tag], n_ag, n_pl, extent, 6, *tilt, steps])
+    save("closed_loop_trained", **out)
+
+
 # --------------------------------------------------------------------------------------------- reference closed loop
 class _FakeVeh:
     """The slice of the pybind Vehicle surface that Policy.act touches (pybind11/src/object.cc:33-99)."""
@@ -1316,7 +1368,7 @@ def gen_dt_loop():
     save("dt_loop", **out)
 
 
-ALL = dict(model=gen_model, features=gen_features, sampling=gen_sampling, physics=gen_physics,
+ALL = dict(model=gen_model, model_trained=gen_model_trained, closed_loop_trained=gen_closed_loop_trained, features=gen_features, sampling=gen_sampling, physics=gen_physics,
            collision=gen_collision, closed_loop=gen_closed_loop, closed_loop_full=gen_closed_loop_full, closed_loop_wide=gen_closed_loop_wide, metrics=gen_metrics, interesting=gen_interesting, preprocessed=gen_preprocessed, ingest_gt=gen_ingest_gt, state_dict=gen_state_dict, bicycle=gen_bicycle, contacts=gen_contacts,
            planner_adversary=gen_planner_adversary, ingest=gen_ingest,
            variants=gen_variants, dense_reward=gen_dense_reward, dt_loop=gen_dt_loop)

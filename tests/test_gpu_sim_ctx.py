@@ -309,6 +309,33 @@ def test_closed_loop_full_dims_through_sliding_window_matches_reference_fixture(
             assert np.array_equal(r["coll"][s], g[f"{tag}_coll"])
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("split", ["f16x3", "bf16x6"])
+def test_closed_loop_at_trained_like_weights_matches_reference_fixture(tag, split):
+    """Round 5: the unmodified reference policy + real FreeCar / Box2D rolled at TRAINED-LIKE weights (tests/golden/closed_loop_trained.npz;
+    weights.generate_trained_like: non-unit LayerNorm gains, rescaled matrices, embedding rows over three decades, |logit| ~ 30) — "a" the
+    small closed-loop model for 20 steps, "b" the full model for 34 steps (through the window slide) with tilts.  Sampled action tokens, RTG bins, focal groups and
+    collision flags identical, float32 states within 1e-4, under BOTH operand splits, with the engine's defaults (compact contexts,
+    K/V-cached steps); the guard pair stays clean (no fp16 overflow: split "f16x3" is forced, nothing falls back)."""
+    g = golden("closed_loop_trained")
+    rc = g[f"{tag}_recipe"]
+    steps = int(rc[9])
+    cfg = cfg_of("loop") if tag == "a" else spec.make_cfg(nocturne__steps=steps)
+    d = spec.Dims(cfg)
+    scn = scenarios.make_scenario(int(rc[0]), int(rc[1]), n_agents=int(rc[2]), n_polylines=int(rc[3]), n_points=d.NP, extent=float(rc[4]))
+    eng = RolloutEngine(cfg, weights.generate_trained_like(d, 0), DEV, max_ctx=32, seed=int(rc[5]), tilt=tuple(rc[6:9]), split=split)
+    eng.load_scenarios([scn, scn], steps=steps)
+    r = eng.run(steps).results()
+    assert eng.scheme == (1 if split == "f16x3" else 0)
+    for s in range(2):
+        assert np.array_equal(r["n_groups"][:steps, s], g[f"{tag}_n_groups"])
+        bad = np.argwhere(r["tokens"][s][:, :steps] != g[f"{tag}_tokens"])
+        assert len(bad) == 0, (split, bad[:5])
+        np.testing.assert_allclose(fo.undiscretize_rtgs(r["rtg_bins"][s][:, :steps], cfg.dataset.waymo), g[f"{tag}_rtg_cont"], atol=1e-9)
+        np.testing.assert_allclose(r["states"][s][:, :steps + 1], g[f"{tag}_states"], atol=1e-4, rtol=0)
+        assert np.array_equal(r["coll"][s][:, :steps + 1], g[f"{tag}_coll"])
+
+
 def test_headline_shape_closed_loop_matches_reference_fixture():
     """BASELINE configs[2]'s scene shape against the REFERENCE ITSELF (tests/golden/closed_loop_wide.npz,
     oracle/gen_golden.py::gen_closed_loop_wide): 64 vehicles x 512 polylines, full model, unmodified reference policy + real
