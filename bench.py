@@ -327,24 +327,48 @@ def main():
                  f"feed-forward block; split-operand MFMA 32x32x16: {scheme} partial products per fp32 product)",
                  "attention_bf16x6_kernel (all multi-head attention; split-operand MFMA flash attention, structured mask)")
 
-        # HBM bytes per launch from the PMC counters: rocprofv3 cannot run inside this process, so they come from separate
-        # --pmc passes over this same command (tools/pmc_traffic.sh), committed with their calibration under profiles/
+        # HBM bytes per launch from the PMC counters: rocprofv3 cannot run inside this process, so they come from separate --pmc passes over
+        # a smaller run of this same command (tools/pmc_traffic.sh), committed under profiles/ PER KERNEL with ONE counter convention for
+        # every file of the round: FETCH_SIZE x 2 (gfx950 tallies its 128-byte read requests at 64 B — calibrated in round 5 on known-byte
+        # launches of every access pattern and of each hot kernel: profiles/r05_pmc_calibration.json) + WRITE_SIZE x 1.
         pmc, pmc_src = {}, None
-        for cand in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for cand in ("r05_pmc_traffic.json",):
             pmc_path = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(pmc_path):
                 pmc, pmc_src = json.load(open(pmc_path)), "profiles/" + cand
                 break
-        keys = ("gemm_nt_bf16x6_kernel", "attention_bf16x6_kernel")
+        KIND_KEYS = ("other", "linear_kv_images", "linear_residual_layernorm", "linear_plain", "ffn_fused", "attention_causal", "attention_keypad")
+        CLASS_KINDS = ((0, 1, 2, 3, 4), (5, 6))             # kinds of the Linear class / the attention class
 
-        def traffic(i, alg):
-            """HBM bytes per launch of class i: the PMC run's measured-over-algorithmic ratio (same kernels and shapes, smaller
-            launches: counter passes serialise the kernels) applied to THIS run's algorithmic bytes per launch; a profile without
-            the ratio (round 1) is quoted as measured."""
-            e = pmc.get(keys[i], {})
-            if "hbm_over_algorithmic" in e:
-                return e["hbm_over_algorithmic"] * alg
-            return e.get("hbm_bytes_per_launch")
+        def kind_ratio(kind):
+            """measured HBM bytes / algorithmic bytes of kernel kind `kind` in the PMC run (same kernels and shapes per context, smaller
+            launches: counter passes serialise the kernels); None when the profile has no entry for it."""
+            e = pmc.get("kernels", {}).get(KIND_KEYS[kind])
+            return e.get("hbm_over_algorithmic") if e else None
+
+        def kind_bytes(kind, main_only=True):
+            """algorithmic bytes and launches of a kind in THIS run (main stream; full-row + few-row launches)."""
+            b = kby[2 * kind] + kby[2 * kind + 1] + (0.0 if main_only else skby[2 * kind] + skby[2 * kind + 1])
+            n = kcnt[2 * kind] + kcnt[2 * kind + 1] + (0 if main_only else skcnt[2 * kind] + skcnt[2 * kind + 1])
+            return b, n
+
+        def traffic(i, alg_per_launch):
+            """HBM bytes per launch of class i: every kind's measured-over-algorithmic ratio applied to THIS run's algorithmic bytes of
+            that kind, summed over the class's kinds, per launch of the class."""
+            tot_alg = tot_meas = 0.0
+            for kind in CLASS_KINDS[i]:
+                b, _ = kind_bytes(kind)
+                r = kind_ratio(kind)
+                if b <= 0:
+                    continue
+                if r is None:
+                    return None
+                tot_alg += b
+                tot_meas += r * b
+            return (tot_meas / tot_alg) * alg_per_launch if tot_alg > 0 else None
+
+        def traffic_measured(i):
+            return {KIND_KEYS[k]: pmc.get("kernels", {}).get(KIND_KEYS[k]) for k in CLASS_KINDS[i] if KIND_KEYS[k] in pmc.get("kernels", {})} or None
 
         def cls(i):
             a = fl[i] / (ms[i] * 1e-3) / 1e12 if ms[i] > 0 else None
@@ -354,7 +378,8 @@ def main():
                     "launches": int(cnt[i]), "time_share_of_step": ms[i] * 1e-3 / elapsed,
                     "mfma_executed_tflops": nprod * a if a else None, "mfma_peak_tflops": PEAK_16BIT_MFMA_TFLOPS,
                     "algorithmic_flops_per_launch": fl[i] / n, "algorithmic_hbm_bytes_per_launch": by[i] / n,
-                    "traffic": traffic(i, by[i] / n), "traffic_source": pmc_src, "traffic_measured": pmc.get(keys[i]),
+                    "traffic": traffic(i, by[i] / n), "traffic_source": pmc_src, "traffic_convention": pmc.get("_convention"),
+                    "traffic_measured": traffic_measured(i),
                     "hbm_rate_at_algorithmic_bytes_TBps": by[i] / (ms[i] * 1e-3) / 1e12 if ms[i] > 0 else None,
                     "side_stream": {"launches": int(scnt[i]), "event_ms_total": sms[i], "flop_share": sfl[i] / max(fl[i] + sfl[i], 1.0),
                                     "algorithmic_hbm_bytes_total": sby[i],
@@ -365,9 +390,24 @@ def main():
             if cnt[i] == 0 or ms[i] <= 0:
                 return None
             rate = by[i] / (ms[i] * 1e-3) / 1e12
-            return {"achieved": rate, "peak": PEAK_HBM_TBPS, "unit": "TB/s", "frac": rate / PEAK_HBM_TBPS,
-                    "avg_launch_ms": ms[i] / cnt[i], "launches": int(cnt[i]), "time_share_of_step": ms[i] * 1e-3 / elapsed,
-                    "algorithmic_hbm_bytes_per_launch": by[i] / cnt[i]}
+            row = {"achieved": rate, "peak": PEAK_HBM_TBPS, "unit": "TB/s", "frac": rate / PEAK_HBM_TBPS,
+                   "avg_launch_ms": ms[i] / cnt[i], "launches": int(cnt[i]), "time_share_of_step": ms[i] * 1e-3 / elapsed,
+                   "algorithmic_hbm_bytes_per_launch": by[i] / cnt[i]}
+            mp_path = os.path.join(ROOT, "profiles", "r05_c_pmc_map_pool.json")
+            if CLASS_KEYS[i] == "map_pool" and os.path.exists(mp_path):
+                # map_pool is a VECTOR-pipe kernel (no HBM roof: it moves its bytes once, at 0.1 TB/s): its roof is the vector issue rate.
+                # Instructions per polyline from the SQ counter passes (profiles/r05_c_pmc_map_pool.md), time from this run's HIP events.
+                mp = json.load(open(mp_path))
+                polylines = fl[i] / 1.5e6                          # launch_map_pool tags 1.5 MFLOP per polyline
+                inst_rate = polylines * mp["valu_insts_per_polyline"] / (ms[i] * 1e-3)
+                peak_rate = 256 * 4 * 0.5 * 2.4e9                  # a wave64 VALU instruction occupies a SIMD for 2 cycles (MI355X_MICROARCH.md)
+                row["vector_issue"] = {"bound": "valu", "achieved": inst_rate / 1e12, "peak": peak_rate / 1e12, "unit": "T wave-instructions/s",
+                                       "frac": inst_rate / peak_rate, "active_lanes_per_instruction": mp["active_lanes_per_valu_inst"],
+                                       "counter_frac_at_profiled_clock": mp["valu_issue_frac_measured"], "source": "profiles/r05_c_pmc_map_pool.md",
+                                       "note": "peak at the 2.4 GHz maximum clock; the counters' own cycle count (profiled run, 2.2 GHz) gives "
+                                               "counter_frac_at_profiled_clock; what keeps it from 0.75 is in the profile (five barrier-separated "
+                                               "phases, 59 % of a wave's residence parked, a scalar weight stream)"}
+            return row
         KNAMES = ("other", "Linear + K/V-image epilogue (QKV, memory K/V): inproj_rs_kernel (row-stationary; weight-stationary gemm_ws256_kernel<..,KV> / tiled gemm_nt_bf16x6_kernel<2,2,2,..,KVIMG> by option or when K != 256)",
                   "Linear + residual + LayerNorm epilogue (attention out-projections, MLP layers): gemm_ws256_kernel<..,LN> (weight-stationary; tiled gemm_nt_bf16x6_kernel<1,4,2,..,LN> when K != 256)",
                   "plain Linear (cross-attention query projection, heads, map / embedding layers): gemm_ws256_kernel (256 -> 256) / gemm_nt_bf16x6_kernel<2,2,2>",
@@ -382,9 +422,13 @@ def main():
                 if kcnt[i] == 0 or kms[i] <= 0:
                     continue
                 a = kfl[i] / (kms[i] * 1e-3) / 1e12
+                r = kind_ratio(i // 2)
                 rows.append({"kernel": KNAMES[i // 2] + (" — few-row launches (last layer on the queried rows, second pass, cached steps)" if i % 2 else ""),
+                             "kind": KIND_KEYS[i // 2],
                              "achieved": a, "frac": a / PEAK_FP32_EQUIV_TFLOPS, "unit": "TFLOP/s", "avg_launch_ms": kms[i] / kcnt[i],
                              "launches": int(kcnt[i]), "time_share_of_step": kms[i] * 1e-3 / elapsed,
+                             "algorithmic_hbm_bytes_per_launch": kby[i] / kcnt[i],
+                             "traffic": None if r is None else r * kby[i] / kcnt[i],
                              "hbm_rate_at_algorithmic_bytes_TBps": kby[i] / (kms[i] * 1e-3) / 1e12})
             return sorted(rows, key=lambda r: -r["time_share_of_step"])
         e2e = (sum(fl[i] for i in range(ncls)) + sfl[0] + sfl[1]) / elapsed / 1e12
@@ -392,9 +436,9 @@ def main():
                 "note": "achieved = algorithmic fp32 FLOPs (2MNK per Linear; 128 per visible (q,k) pair and head) / summed "
                         f"HIP-event time of the class; peak = dense 16-bit MFMA peak / {nprod} because each fp32 product costs {nprod} "
                         f"MFMA products ({scheme} products, fp32-class accuracy: csrc/split.h); the f32-input MFMA path (157.3 TF peak) is "
-                        "selectable with ctrlsim_set_option; traffic = HBM bytes per launch: (FETCH_SIZE + WRITE_SIZE) / algorithmic bytes measured "
-                        "by separate rocprofv3 --pmc passes over a smaller run of this workload (traffic_measured, committed under "
-                        "profiles/) x this run's algorithmic bytes per launch",
+                        "selectable per engine (ctrlsim_bind_options); traffic = HBM bytes per launch: per KERNEL (2 x FETCH_SIZE + WRITE_SIZE) / algorithmic "
+                        "bytes measured by separate rocprofv3 --pmc passes over a smaller run of this workload (traffic_measured, committed "
+                        "under profiles/ with the calibration of the counter factors) x this run's algorithmic bytes of that kernel",
                 "other": cls(1 - dom),
                 "satellite": {CLASS_KEYS[i]: sat(i) for i in range(2, ncls)},
                 "satellite_note": "HBM-side kernels (SURVEY 8d): algorithmic bytes (DESIGN.md 4) / HIP-event time vs the 8 TB/s HBM "
@@ -405,6 +449,8 @@ def main():
                                                     "underneath the other lane's kernels, matrix kernels included (the co-residency hazard that "
                                                     "forbade this in round 2 is gone from the build: DESIGN.md section 4)"),
                 "kernels": kernel_rows(),
+                "kernel_bytes_all_streams": {KIND_KEYS[k]: {"launches": int(kind_bytes(k, False)[1]), "algorithmic_hbm_bytes": kind_bytes(k, False)[0]}
+                                             for k in range(1, len(KIND_KEYS)) if kind_bytes(k, False)[1]},
                 "causal_attention_by_size_class": attn_by_class,
                 "causal_attention_by_size_class_note": "untimed extra roll of the first slice with ctrlsim_attn_class_prof: share of the causal "
                                                         "kernel's workgroup cycles (full-row launches) per context size class; cycles per 1e6 visible "

@@ -243,7 +243,193 @@ class PolicyEvaluator:
         pair = self.find_interesting_pair(scn, gt_data_dict, moving)
         return None if pair is None else pair[0]
 
+    def _choose_vehicles(self, scn, gt_data_dict, moving):
+        """policy_evaluator.py:448-466 — the only consumer of `random`: models seeded alike evaluate the same vehicles."""
+        mode = self.cfg.eval.eval_mode
+        if mode == "multi_agent":
+            thr = self.cfg.eval.multi_agent_eval_threshold
+            return random.sample(moving, thr) if len(moving) > thr else moving
+        if mode in ("one_agent", "two_agent"):
+            picked = self.find_interesting_pair(scn, gt_data_dict, moving)
+            return [] if picked is None else (picked[:1] if mode == "one_agent" else picked)
+        raise ValueError(f"eval_mode {mode!r}: one_agent, two_agent or multi_agent (cfgs/eval/base.yaml:13-14)")
+
+    def _batched_route_applies(self):
+        """The batched route serves this repo's AutoregressivePolicy with the policy's own RTGs (CtRL-Sim, IL, Trajeglish); a foreign
+        `Policy`, the Decision Transformer's real-time reward ledger (per-vehicle host bookkeeping) and cfg.eval.batched = False keep
+        the per-scenario loop."""
+        from ..policies.autoregressive_policy import AutoregressivePolicy
+        return (type(self.policy) is AutoregressivePolicy and not self.policy.real_time_rewards and hasattr(self.policy.model, "hip")
+                and bool(self.cfg.eval.get("batched", True)))
+
     def evaluate_policy(self):
+        if self._batched_route_applies():
+            return self._evaluate_policy_batched()
+        return self._evaluate_policy_per_scenario()
+
+    def _evaluate_policy_batched(self):
+        """evaluate_policy (policy_evaluator.py:426-576) with the scenario loop turned inside out: the scenes are chosen and their
+        vehicles drawn exactly as the per-scenario loop does (same `random` stream), then ALL scenes of equal shape are rolled together
+        by one RolloutEngine — one grouping / context / two-pass forward / sampling sequence per step for the whole batch
+        (engine.policy_step), the log-replay actions of the vehicles the policy does not control (Evaluator.apply_gt_action,
+        evaluators/evaluator.py:160-193: inverse bicycle model against the next logged state) computed for the whole batch in NumPy
+        float64 — the same code, hence the same bits, as the per-scenario route — and one simulator step for the batch.  The statistics
+        are the per-scenario route's (update_running_statistics on the same arrays): the metric dict is identical to it (1e-12: the
+        accumulation order of floating-point sums), at the engine's throughput instead of a host round trip per vehicle and step."""
+        from .. import discretize as dz
+        from ..engine import RolloutEngine
+        self.reset()
+        pol, w = self.policy, self.cfg_rl_waymo
+        T, T1, hsteps = self.steps, self.steps + 1, self.history_steps
+        chosen, n_done = [], 0
+        for scn, gt_data_dict, moving, pre in self._scenes(self.synthetic):
+            if n_done == self.cfg.eval.num_files_to_evaluate // self.cfg.eval.partitions:
+                break
+            to_eval = self._choose_vehicles(scn, gt_data_dict, moving)
+            if not to_eval:
+                continue
+            n_done += 1
+            chosen.append((scn, gt_data_dict, list(to_eval)))
+        groups = {}
+        for item in chosen:                                    # one engine batch = scenes of equal vehicle and polyline counts
+            groups.setdefault((item[0].N, item[0].road_points.shape[0]), []).append(item)
+        tilt = (pol.goal_tilt, pol.veh_veh_tilt, pol.veh_edge_tilt) if pol.tilt_dict["tilt"] else (0.0, 0.0, 0.0)
+        cap = int(self.cfg.eval.get("batch_scenarios", 256))
+        self.batched_scenes = 0
+        for (N, _), items in groups.items():
+            for c0 in range(0, len(items), cap):
+                self._roll_batch(items[c0:c0 + cap], N, tilt, dz, RolloutEngine, w, T, T1, hsteps)
+        return self.compute_metrics()
+
+    def _roll_batch(self, items, N, tilt, dz, RolloutEngine, w, T, T1, hsteps):
+        import copy
+        pol = self.policy
+        S = len(items)
+        gt = np.zeros((S, N, T1 + 1, 6))                       # x, y, heading, speed, exist, length (+ one row: apply_gt_action looks at t + 1)
+        scns, goal_dicts, evals = [], [], []
+        ctrl = np.zeros((S, N), bool)                          # vehicles_to_evaluate
+        for k, (scn, gtd, to_eval) in enumerate(items):
+            ids = list(range(scn.N))                           # Simulation's vehicle ids are the indices (synthetic) / follow the loader's order
+            gd = {}
+            for v in ids:
+                tr = np.asarray(gtd[v]["traj"], np.float64)
+                n = min(len(tr), T1 + 1)
+                gt[k, v, :n, :5] = tr[:n, :5]
+                gt[k, v, :n, 5] = tr[:n, -1]
+                gd[v] = self.initialize_goal_dict(scn, v, tr)
+            # the policy sees the goals the evaluator works with (initialize_goal_dict moves the goal of a vehicle that leaves the log)
+            s2 = copy.copy(scn)
+            s2.goal_pos = np.array([gd[v]["pos"] for v in ids], np.float32)
+            s2.goal_heading = np.array([gd[v]["heading"] for v in ids], np.float32)
+            s2.goal_speed = np.array([gd[v]["speed"] for v in ids], np.float32)
+            # processing order of the vehicles to evaluate: decreasing ground-truth length (autoregressive_policy.py:88-94)
+            lengths = [int(np.asarray(gtd[v]["traj"])[:, 4].sum()) for v in to_eval]
+            s2.eval_order = np.array(to_eval)[np.argsort(np.array(lengths))[::-1]].astype(np.int32)
+            scns.append(s2); goal_dicts.append(gd); evals.append(to_eval)
+            ctrl[k, to_eval] = True
+        eng = RolloutEngine(pol.model.cfg, pol.model.weights, pol.model.device, max_ctx=int(self.cfg.eval.get("batch_contexts", 256)),
+                            seed=int(self.cfg.eval.seed), tilt=tilt, temperature=pol.action_temperature, nucleus=pol.nucleus_sampling,
+                            top_p=pol.nucleus_threshold, model=pol.model.hip, lanes=1)
+        eng.load_scenarios(scns, steps=T)
+        dev = eng.device
+        exist = np.zeros((S, N, T1))
+        accel = np.zeros((S, N, T1))
+        steer = np.zeros((S, N, T1))
+        speeds = np.zeros((S, N, T1), np.float32)
+        own_last = np.zeros((T, N), np.int32)                  # last scene of the batch: does a context answer for the vehicle at step t
+        for t in range(T):
+            # update_vehicle_data_dict (:99-159): existence = the log's flag, latched at 0
+            exist[:, :, t] = gt[:, :, t, 4] if t == 0 else gt[:, :, t, 4] * (exist[:, :, t - 1] != 0)
+            eng.hist_states[:, :, t, 7] = torch.from_numpy(exist[:, :, t].astype(np.float32)).to(dev)
+            eng.policy_step(t)
+            row = eng.hist_states[:, :, t].cpu().numpy()       # synchronises: the step's tokens are sampled
+            toks = eng.act_now.cpu().numpy()
+            speed = eng.phys[:, :, 16].cpu().numpy()
+            bad = eng.nonfinite()
+            if bad and bad < 65536 and eng.split == "auto" and eng.scheme == 1:
+                eng._set_split(0)                              # as predict(): redo the step with the range-safe three-bf16-plane operands
+                eng.policy_step(t)
+                toks = eng.act_now.cpu().numpy()
+                bad = eng.nonfinite()
+            if bad:
+                raise FloatingPointError(f"{bad} guard events at step {t} of the batched evaluation (csrc/split.h: activation range)")
+            speeds[:, :, t] = speed
+            own_last[t] = eng.own_ctx[S - 1].cpu().numpy()
+            a = np.zeros((S, N)); st = np.zeros((S, N)); alive = np.ones((S, N), bool)
+            by_policy = ctrl & (t >= hsteps - 1)
+            # policy.act (autoregressive_policy.py:256-274): a vehicle that does not exist any more is parked; a vehicle no context
+            # answers for (dead_agent_veh_ids) gets (0, 0)
+            und = dz.undiscretize_actions(np.maximum(toks, 0), w)
+            live = by_policy & (exist[:, :, t] != 0)
+            a[live], st[live] = np.where(toks[live] >= 0, und[live][:, 0], 0.0), np.where(toks[live] >= 0, und[live][:, 1], 0.0)
+            alive[by_policy & (exist[:, :, t] == 0)] = False
+            # apply_gt_action (evaluators/evaluator.py:160-193) for everyone else
+            rep = ~by_policy
+            ok = rep & (gt[:, :, t, 4] != 0) & (gt[:, :, t + 1, 4] != 0) & ~((t > 0) & (exist[:, :, t] == 0))
+            if ok.any():
+                nxt = np.concatenate([gt[:, :, t + 1, :4][ok], gt[:, :, t + 1, 5][ok][:, None]], 1)
+                prev = np.stack([row[..., 0][ok], row[..., 1][ok], row[..., 4][ok], speed[ok]], 1).astype(np.float64)
+                a[ok], st[ok] = bicycle_backward(nxt, prev, self.dt)
+            alive[rep & ~ok] = False
+            accel[:, :, t] = a
+            steer[:, :, t] = st
+            act = torch.from_numpy(np.stack([a, st], -1)).to(dev)
+            # what update_state writes back as the action history of step t: the applied action, discretised (identity for a sampled token)
+            eng.hist_tok[:, :, t] = torch.from_numpy(dz.discretize_actions(np.stack([a, st], -1), w).astype(np.int32)).to(dev)
+            eng.exists.copy_(torch.from_numpy(alive.astype(np.uint8)).to(dev))
+            eng.sim_step(t, act)
+        exist[:, :, T] = gt[:, :, T, 4] * (exist[:, :, T - 1] != 0)
+        states = eng.hist_states.cpu().numpy()
+        coll = eng.coll.cpu().numpy()
+        speeds[:, :, T] = eng.phys[:, :, 16].cpu().numpy()
+        self.last_vehicle_data_dict = self._vehicle_data_dict_of(S - 1, items[S - 1][0], goal_dicts[S - 1], states, coll, speeds, exist, accel, steer, gt,
+                                                                 eng.hist_rtg[S - 1].cpu().numpy(), own_last, dz, w, T)
+        for k, (scn, gtd, to_eval) in enumerate(items):
+            stt = np.zeros((N, T1, 8))
+            stt[..., :5] = states[k, :, :, :5]
+            stt[..., 7] = exist[k]
+            g = gt[k, :, :T1, :5]
+            ids = list(range(N))
+            gp = np.array([np.asarray(goal_dicts[k][v]["pos"], np.float64) for v in ids])
+            gh = np.array([float(goal_dicts[k][v]["heading"]) for v in ids])
+            gs = np.array([float(goal_dicts[k][v]["speed"]) for v in ids])
+            self.vehicles_to_evaluate = to_eval
+            self.acc.add_scenario(stt, coll[k].astype(np.float64), accel[k], g, gp, gh, gs, self.cfg, eval_ids=[ids.index(v) for v in to_eval])
+            self.batched_scenes += 1
+
+    def _vehicle_data_dict_of(self, k, scn, goal_dict, states, coll, speeds, exist, accel, steer, gt, rtg_bins, own, dz, w, T):
+        """`last_vehicle_data_dict` of the batched route: scene k's rollout in the per-scenario loop's dict schema
+        (policy_evaluator.py:70-96) — what a caller inspecting the evaluator after evaluate_policy() reads."""
+        from types import SimpleNamespace as NS
+        vdd = {}
+        cont = dz.undiscretize_rtgs(rtg_bins, w) if self.policy.predict_rtgs else None
+        for v in range(scn.N):
+            veh0 = NS(getWidth=lambda v=v: float(scn.width[v]), getLength=lambda v=v: float(scn.length[v]))
+            d = self.initialize_vehicle_data_dict(veh0, goal_dict[v])
+            norm = np.linalg.norm(np.array([states[k, v, 0, 0], states[k, v, 0, 1]]) - goal_dict[v]["pos"])
+            for t in range(T + 1):
+                r = states[k, v, t]
+                d["position"].append({"x": r[0], "y": r[1]})
+                d["velocity"].append({"x": r[2], "y": r[3]})
+                d["heading"].append(r[4])
+                d["timestep"].append(t)
+                d["existence"].append(exist[k, v, t])
+                d["gt_position"].append({"x": gt[k, v, t, 0], "y": gt[k, v, t, 1]})
+                d["gt_heading"].append(gt[k, v, t, 2])
+                d["gt_speed"].append(gt[k, v, t, 3])
+                d["acceleration"].append(accel[k, v, t] if t < T else 0)
+                d["steering"].append(steer[k, v, t] if t < T else 0)
+                veh = NS(position=NS(x=r[0], y=r[1]), speed=speeds[k, v, t], heading=r[4],
+                         collision_type_veh=CollisionType.VEHICLE_VEHICLE if coll[k, v, t, 0] else CollisionType.NOT_COLLIDED,
+                         collision_type_edge=CollisionType.VEHICLE_ROAD if coll[k, v, t, 1] else CollisionType.NOT_COLLIDED)
+                d["reward"].append(self.compute_reward(veh, goal_dict[v], norm, d))
+                if cont is not None and t < T:
+                    d[self.policy.key_dict["rtgs"]].append(np.array(cont[v, t]) if own[t, v] >= 0 else
+                                                           np.array([0] * self.policy.cfg_model.num_reward_components))
+            vdd[v] = d
+        return vdd
+
+    def _evaluate_policy_per_scenario(self):
         self.reset()
         n_done = 0
         for scn, gt_data_dict, moving, pre in self._scenes(self.synthetic):
@@ -255,16 +441,7 @@ class PolicyEvaluator:
             for veh in vehicles:
                 veh.expert_control = False
                 veh.physics_simulated = True
-            # policy_evaluator.py:448-466 — the only consumer of `random`: models seeded alike evaluate the same vehicles
-            mode = self.cfg.eval.eval_mode
-            if mode == "multi_agent":
-                thr = self.cfg.eval.multi_agent_eval_threshold
-                self.vehicles_to_evaluate = random.sample(moving, thr) if len(moving) > thr else moving
-            elif mode in ("one_agent", "two_agent"):
-                picked = self.find_interesting_pair(scn, gt_data_dict, moving)
-                self.vehicles_to_evaluate = [] if picked is None else (picked[:1] if mode == "one_agent" else picked)
-            else:
-                raise ValueError(f"eval_mode {mode!r}: one_agent, two_agent or multi_agent (cfgs/eval/base.yaml:13-14)")
+            self.vehicles_to_evaluate = self._choose_vehicles(scn, gt_data_dict, moving)
             if not self.vehicles_to_evaluate:
                 continue
             n_done += 1

@@ -1,7 +1,7 @@
 """Throughput of the PLUGIN route (BASELINE configs[0]'s analogue): PolicyEvaluator -> AutoregressivePolicy.predict / act -> Simulation.step,
 one scenario at a time through the reference-shaped surface (per step: the history mirrored to the device, one policy step, a
 device -> host read of the sampled actions, one simulator step, a read of the new state row).  Plumbing, not the product's fast path
-(RolloutEngine, bench.py) — this gives it a number.   usage: python tools/facade_rate.py [scenarios=3] [agents=8] [steps=20]"""
+(RolloutEngine, bench.py) — this gives it a number.   usage: python tools/facade_rate.py [scenarios=3] [agents=8] [steps=20] [batched]"""
 import sys
 import time
 
@@ -27,7 +27,10 @@ policy = AutoregressivePolicy(cfg=cfg, model_path="", model=model, use_rtg=pol.u
                               tilt_dict={"tilt": True, "goal_tilt": 0, "veh_veh_tilt": 0, "veh_edge_tilt": 0}, name=pol.model,
                               action_temperature=pol.action_temperature, nucleus_sampling=pol.nucleus_sampling,
                               nucleus_threshold=pol.nucleus_threshold)
+BATCHED = len(sys.argv) > 4 and sys.argv[4] == "batched"      # round 5: every scene of the evaluation in one RolloutEngine batch (the default of evaluate_policy)
+cfg.eval["batched"] = BATCHED
 cfg1 = spec.make_cfg(nocturne__steps=T, nocturne__history_steps=1)
+cfg1.eval["batched"] = BATCHED
 cfg1.eval["synthetic"] = dict(num_scenarios=1, n_agents=N, n_polylines=200, seed=7, extent=60.0)
 cfg1.eval.num_files_to_evaluate = cfg1.eval.partitions
 PolicyEvaluator(cfg1, policy).evaluate_policy()              # warm-up: first launches, allocations
@@ -35,5 +38,5 @@ t0 = time.perf_counter()
 m, _ = PolicyEvaluator(cfg, policy).evaluate_policy()
 el = time.perf_counter() - t0
 n_scn = S + 1
-print(f"plugin route: {n_scn} scenarios x {N} vehicles x {T} steps, full model, in {el:.2f} s = {n_scn * N * T / el:.0f} agent-steps/s "
+print(f"plugin route ({'batched: one RolloutEngine batch' if BATCHED else 'per-scenario loop'}): {n_scn} scenarios x {N} vehicles x {T} steps, full model, in {el:.2f} s = {n_scn * N * T / el:.0f} agent-steps/s "
       f"({el / (n_scn * T) * 1e3:.1f} ms per scenario-step)")
