@@ -44,6 +44,7 @@ class AutoregressivePolicy(Policy):
             raise NotImplementedError("the Decision-Transformer model runs as in cfgs/policy/dt.yaml: use_rtg, real_time_rewards, "
                                       "continuous (not discretised, not predicted) RTGs")
         self._session = None
+        self._synced_t = None
         self.scenario_index = 0
 
     # ------------------------------------------------------------------ device session
@@ -77,29 +78,47 @@ class AutoregressivePolicy(Policy):
     def reset(self, vehicle_data_dict):
         super().reset(vehicle_data_dict)
         self._session = None
+        self._synced_t = None
 
     def _sync_session(self, vehicle_data_dict, gt_data_dict, preproc_data, vehicles_to_evaluate, t):
-        """Open the device session at t == 0 (or when none is open) and mirror the host history buffers into it."""
+        """Open the device session at t == 0 (or when none is open) and mirror the host history buffers into it.  A session that was
+        synchronised at step t - 1 receives only the rows `Policy.update_state` wrote since — the state row of step t, the action / RTG
+        rows of step t - 1 (and the RTG row of step t under real_time_rewards), policies/policy.py:68-105 — instead of the whole
+        [N, steps] history at every step (round-4 review: the full re-upload was most of the plugin route's per-step cost); any other
+        call order falls back to the full mirror."""
         import torch
         w = self.cfg_rl_waymo
-        if self._session is None or t == 0:
+        fresh = self._session is None or t == 0
+        if fresh:
             if vehicle_data_dict is None:        # get_data without a preceding predict: what reset() / update_state() hold
                 vehicle_data_dict = self._dict_from_buffers()
             self._open_session(vehicle_data_dict, preproc_data, gt_data_dict, vehicles_to_evaluate)
+            self._synced_t = None
         eng = self._session
         dev = eng.device
         n = self.states.shape[0]
-        hs = np.zeros((1, n, self.steps + 1, 8), np.float32)
-        hs[0, :, :self.steps] = self.states
-        eng.hist_states.copy_(torch.from_numpy(hs).to(dev))
-        eng.hist_tok.copy_(torch.from_numpy(dz.discretize_actions(self.actions, w).astype(np.int32)[None]).to(dev))
-        if self.model.dims.VARIANT == 3:                 # continuous RTGs, clip-normalised (get_data:73-78), as float bits
-            from ..rewards import normalize_rtgs
-            rt = np.ascontiguousarray(normalize_rtgs(self.rtgs, w), np.float32).view(np.int32)
-            eng.hist_rtg.copy_(torch.from_numpy(rt[None]).to(dev))
+        dt3 = self.model.dims.VARIANT == 3
+
+        def rtg_rows(rows):                                  # continuous RTGs, clip-normalised (get_data:73-78), as float bits (DT) / bins
+            if dt3:
+                from ..rewards import normalize_rtgs
+                return np.ascontiguousarray(normalize_rtgs(rows, w), np.float32).view(np.int32)
+            return dz.discretize_rtgs_from_raw(rows, w).astype(np.int32)
+
+        if self._synced_t is not None and t == self._synced_t + 1 and 0 < t < self.steps:
+            eng.hist_states[0, :, t].copy_(torch.from_numpy(self.states[:, t].astype(np.float32)).to(dev))
+            eng.hist_tok[0, :, t - 1].copy_(torch.from_numpy(dz.discretize_actions(self.actions[:, t - 1], w).astype(np.int32)).to(dev))
+            lo = t - 1
+            hi = t + 1 if (self.real_time_rewards and self.use_rtg) else t
+            eng.hist_rtg[0, :, lo:hi].copy_(torch.from_numpy(np.ascontiguousarray(rtg_rows(self.rtgs[:, lo:hi]))).to(dev))
         else:
-            eng.hist_rtg.copy_(torch.from_numpy(dz.discretize_rtgs_from_raw(self.rtgs, w).astype(np.int32)[None]).to(dev))
-        eng.goals.copy_(torch.from_numpy(self.goals[:, 0][None]).to(dev))
+            hs = np.zeros((1, n, self.steps + 1, 8), np.float32)
+            hs[0, :, :self.steps] = self.states
+            eng.hist_states.copy_(torch.from_numpy(hs).to(dev))
+            eng.hist_tok.copy_(torch.from_numpy(dz.discretize_actions(self.actions, w).astype(np.int32)[None]).to(dev))
+            eng.hist_rtg.copy_(torch.from_numpy(np.ascontiguousarray(rtg_rows(self.rtgs))[None]).to(dev))
+            eng.goals.copy_(torch.from_numpy(self.goals[:, 0][None]).to(dev))
+        self._synced_t = t
         return eng
 
     def _dict_from_buffers(self):
