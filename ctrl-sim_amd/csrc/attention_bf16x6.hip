@@ -25,9 +25,7 @@
 
 namespace SPLIT_NS {
 
-#ifndef ATT_PMAX
 #define ATT_PMAX 32768.0f     // row-sum bound of the speculative softmax path: every probability then fits the fp16 plane
-#endif
 
 
 #define KT6 64
@@ -40,15 +38,6 @@ __device__ __forceinline__ opx8 cat8(const opx4 a, const opx4 b) {
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-#ifdef ATT_TIMING   // scratch/att_timing.hip: per-segment s_memtime accounting of one wave's main loop
-__device__ unsigned long long g_att_t[8];
-#define TSTAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); tacc[i] += _t - tlast; tlast = _t; }
-#define TCOUNT(i) { tacc[i] += 1; }
-#else
-#define TSTAMP(i)
-#define TCOUNT(i)
-#endif
 
 // PRE = true: K / V arrive already split, as per-(context, head, 64-key tile) images of exactly the LDS stage layout
 // (kv_split_kernel below; K = the image base, V / ldkv unused, kv_batch_stride = tiles per context): staging is six
@@ -124,21 +113,15 @@ __global__ __launch_bounds__(256) void attn_mask_table_kernel(TblBatch tb) {
   }
 }
 
-// Five workgroups per compute unit for the mask-table kernel (ATT_TBL_WG5 builds): it needs 81 VGPRs (the in-kernel mask arithmetic is
-// gone), so five waves per SIMD fit without the spills that sank the earlier attempts; the two stages must then be exactly 32 KB
-// (no key-padding bias region in causal mode, the block-maximum words alias the second stage).
-#ifdef ATT_TBL_WG5
-#define ATT_OCC(TBL_) ((TBL_) ? 5 : 3)
-#else
-#define ATT_OCC(TBL_) 3
-#endif
+// (Tried and not kept, numbers in profiles/README.md: five workgroups per CU for the mask-table kernel; a three-stage K/V ring with the DMA
+// two tiles ahead; both score products of a tile before either softmax; 256 queries per workgroup — round 5, no change at any length.)
 // DIR (few-query launches: the second pass, the last decoder layer on the queried rows, the K/V-cached steps): ONE wave per workgroup
 // = one 32-query group of one (context, head), and the K / V^T fragments come straight from the tile images in global memory — the image
 // layout IS the fragment layout (a lane's 16 / 8 bytes are contiguous), so a tile that a single wave uses once has no business in LDS.
 // The 256-thread form keeps one live wave and three idle ones per workgroup there, 33 KB of LDS each: three live waves per compute unit
 // for a kernel whose whole job is to stream K / V; this form has no stage memory, no barriers that matter, ~16 waves per compute unit.
 template <int MODE, bool PRE, bool TBL = false, bool DIR = false>
-__global__ __launch_bounds__(DIR ? 64 : 256, DIR ? 3 : ATT_OCC(TBL)) void attention_bf16x6_kernel(
+__global__ __launch_bounds__(DIR ? 64 : 256, 3) void attention_bf16x6_kernel(
     const float* __restrict__ Qb_, int ldq, const float* __restrict__ K, const float* __restrict__ V, int ldkv,
     float* __restrict__ Ob_, int ldo, const unsigned char* __restrict__ key_pad_, float scale_log2e, int variant, AttnBatch ab) {
   const unsigned long long t_start = ab.cprof ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -165,23 +148,13 @@ __global__ __launch_bounds__(DIR ? 64 : 256, DIR ? 3 : ATT_OCC(TBL)) void attent
   // tokens (earlier steps, and the state tokens of their step).
   constexpr int K_PLANE = KT6 * HD;              // bf16 elements: [ks 2][half 2][64 keys][8]
   constexpr int V_PLANE = HD * KT6;              // [16 quads][32 d][4 keys]
-#ifdef ATT_TBL_WG5
-  constexpr int BUF = NPL * (K_PLANE + V_PLANE) + (TBL ? 0 : 2 * KT6 + 8);
-#else
   constexpr int BUF = NPL * (K_PLANE + V_PLANE) + 2 * KT6 + 8;   // + KT6 floats of key-padding bias + two "sub-tile has padded keys" flags
-#endif
-#ifdef ATT_RING3
-  constexpr int NBUF = PRE ? 3 : 2;              // pre-split images: a ring of three stages, the DMA runs two tiles ahead
-#else
   constexpr int NBUF = 2;
-#endif
   static_assert(!DIR || PRE, "the streaming form reads pre-split images");
   constexpr int PADSZ = 2 * KT6 + 8;             // 16-bit elements of a stage's key-padding bias block
   constexpr int BUF_ = DIR ? PADSZ : BUF, NBUF_ = NBUF;
   constexpr int ARENA = DIR ? 2 * PADSZ + 32 * 33 * 2 : NBUF_ * BUF_;     // DIR: two bias blocks, then the 32 x 33 floats of the output transpose
-#ifndef ATT_TBL_WG5
   __shared__ int blk_tmax[4];
-#endif
   static_assert(DIR || 2 * BUF * 2 >= 4 * 32 * 33 * 4, "output transpose must fit");
 
   // XCD-aware work map: workgroups are dealt round-robin to the 8 XCDs (linear id % 8) and each XCD has its own L2, so all
@@ -207,10 +180,6 @@ __global__ __launch_bounds__(DIR ? 64 : 256, DIR ? 3 : ATT_OCC(TBL)) void attent
 #pragma unroll
     for (int i = 0; i < KV_PIECES; ++i) {
       op_t* dst = arena + buf * BUF_ + (wave * 64 + 256 * i) * 8;          // wave-uniform LDS base (+ 16 B per lane)
-#ifdef ATT_DMA_BUILTIN
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 256 * 8 * i),
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-#else
       // Issued as inline asm on purpose: hipcc answers the builtin with `s_waitcnt vmcnt(0)` in front of the NEXT ds_read
       // of any LDS address (it cannot tell the two stage buffers apart), i.e. every wave sat out the whole L2 / HBM
       // latency of the tile it had just requested before touching the tile it already had.  The compiler does not see
@@ -218,15 +187,9 @@ __global__ __launch_bounds__(DIR ? 64 : 256, DIR ? 3 : ATT_OCC(TBL)) void attent
       const unsigned lds_addr = (unsigned)(size_t)((__attribute__((address_space(3))) op_t*)dst);
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off ; KV-DMA"
                    :: "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(src + 256 * 8 * i) : "memory");
-#endif
     }
   };
-#ifndef ATT_NO_EARLY_DMA
   if (PRE) dma_tile(0, 0);
-#endif
-#ifdef ATT_TBL_WG5
-  int* const blk_tmax = reinterpret_cast<int*>(arena + BUF_);       // the second stage: free until tile 1 is requested (after the prologue's barriers)
-#endif
 
   // ---- this lane's query: fragment of Q^T (B operand), k-step ks covers d = 16*ks + 8*half .. +7
   const int qi = qb + wave * 32 + l31;
@@ -310,25 +273,15 @@ __global__ __launch_bounds__(DIR ? 64 : 256, DIR ? 3 : ATT_OCC(TBL)) void attent
     for (int i = 0; i < 2; ++i) {
       const int idx = tid + 256 * i, r = idx >> 3, c = (idx & 7) * 4;
       const int kr = k0 + r;
-#ifndef ABL_NO_GLOAD
       pk[i] = kr < Lk ? *reinterpret_cast<const f32x4*>(Kb + (size_t)kr * ldkv + c) : zero4;
       const int vr = k0 + 2 * (tid >> 3) + i;
       pv[i] = vr < Lk ? *reinterpret_cast<const f32x4*>(Vb + (size_t)vr * ldkv + (tid & 7) * 4) : zero4;
-#else
-      pk[i] = zero4 + (float)kr; pv[i] = zero4 + (float)(kr + i);
-#endif
     }
     }
     if (MODE == MODE6_KEYPAD && tid < KT6) {
       const int kr = k0 + tid;
       ppad = (kr < Lk && !key_pad[(size_t)b * Lk + kr]) ? 0.f : NEG_INF;
       ppad_bal = __ballot(ppad != 0.f);
-      // three-stage ring: the stage is free when its DMA is issued (and ppad would be overwritten by the next request)
-      if (NBUF == 3) {
-        float* pb_ = reinterpret_cast<float*>(arena + buf * BUF + NPL * (K_PLANE + V_PLANE));
-        pb_[tid] = ppad;
-        if (tid < 2) reinterpret_cast<int*>(pb_ + KT6)[tid] = 1;
-      }
     }
   };
   auto sstore = [&](int buf) {
@@ -356,7 +309,7 @@ __global__ __launch_bounds__(DIR ? 64 : 256, DIR ? 3 : ATT_OCC(TBL)) void attent
       }
     }
     }
-    if (NBUF != 3 && MODE == MODE6_KEYPAD && tid < KT6) {
+    if (MODE == MODE6_KEYPAD && tid < KT6) {
       float* pb_ = DIR ? reinterpret_cast<float*>(arena + buf * PADSZ) : reinterpret_cast<float*>(Vd + NPL * V_PLANE);
       pb_[tid] = ppad;
       // a 32-key sub-tile without a padded key (the rule: every polyline and vehicle row of a scene is a valid key) skips the bias
@@ -370,26 +323,11 @@ __global__ __launch_bounds__(DIR ? 64 : 256, DIR ? 3 : ATT_OCC(TBL)) void attent
   const int nkt_reg = (rep_pos0 + KT6 - 1) / KT6;
   auto tile_k0 = [&](int it) { return (it < n_reg ? it : nkt_reg + (it - n_reg)) * KT6; };
   if (n_it > 0) {
-#ifndef ATT_NO_EARLY_DMA
     gload(tile_k0(0), 0, false);                 // PRE: tile 0 (always a regular tile: k_end >= 1) was requested at the top
-#else
-    gload(tile_k0(0), 0);
-#endif
     sstore(0);
   }
-  if (NBUF == 3 && n_it > 1) {
-    gload(tile_k0(1), 1);
-    asm volatile("s_waitcnt vmcnt(%0) ; KV-DMA of tile 0 landed" :: "n"(KV_PIECES) : "memory");
-  } else {
-#ifndef ATT_DMA_BUILTIN
   if (PRE && !DIR) asm volatile("s_waitcnt vmcnt(0) ; KV-DMA landed" ::: "memory");
-#endif
-  }
   __syncthreads();
-#ifdef ATT_TIMING
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long tlast = __builtin_amdgcn_s_memtime();
-#endif
 
   // DIR: the K and V^T fragments of sub-tile i + 1 are requested (global loads into a second register set) before sub-tile i is
   // computed — one wave has nothing else to cover the two memory round trips per sub-tile with (272 us per launch in the K/V-cached
@@ -409,26 +347,20 @@ __global__ __launch_bounds__(DIR ? 64 : 256, DIR ? 3 : ATT_OCC(TBL)) void attent
   };
   if (DIR && n_it > 0) dir_fetch(0, 0);
   int cur = 0;
-  for (int it = 0; it < n_it; ++it, cur = (NBUF == 3 ? (cur == 2 ? 0 : cur + 1) : cur ^ 1)) {
+  for (int it = 0; it < n_it; ++it, cur ^= 1) {
     const bool more = it + 1 < n_it;
-    const bool more2 = NBUF == 3 && it + 2 < n_it;
-    if (NBUF == 3) {
-      if (more2) gload(tile_k0(it + 2), cur == 0 ? 2 : cur - 1);      // (cur + 2) % 3: the stage tile it-1 has just left
-    } else if (more) gload(tile_k0(it + 1), cur ^ 1);
+    if (more) gload(tile_k0(it + 1), cur ^ 1);
     const bool rep_tile = it >= n_reg;               // wave-uniform: a tile of representative keys (compact contexts)
     const int k0 = it * KT6;
-    TSTAMP(0) TCOUNT(7)
     // DIR: the fragments are read from the tile image itself (same layout as a stage: the DMA copies images verbatim)
     const op_t* Ks = DIR ? img + (size_t)(tile_k0(it) / KT6) * KV_IMG : arena + cur * BUF;
     const op_t* Vs = Ks + NPL * K_PLANE;
     const float* padbias = DIR ? reinterpret_cast<const float*>(arena + cur * PADSZ) : reinterpret_cast<const float*>(Vs + NPL * V_PLANE);
     int padflag[2] = {1, 1};
-#ifndef ATT_NO_PADSKIP      // (A/B switch of tools/microbench: every sub-tile takes the bias path)
     if (MODE == MODE6_KEYPAD) {
       padflag[0] = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(padbias + KT6)[0]);
       padflag[1] = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(padbias + KT6)[1]);
     }
-#endif
 
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
@@ -490,19 +422,11 @@ __global__ __launch_bounds__(DIR ? 64 : 256, DIR ? 3 : ATT_OCC(TBL)) void attent
           k0f[p] = *reinterpret_cast<const opx8*>(kr_ + p * K_PLANE);                  // k-step 0 (d 0-15)
           k1f[p] = *reinterpret_cast<const opx8*>(kr_ + p * K_PLANE + 2 * KT6 * 8);    // k-step 1 (d 16-31)
         }
-#ifndef ABL_NO_MFMA
 #define QK(PA, PB)                       \
   s0 = MFMA_OP(k0f[PA], qf[0][PB], s0);  \
   s0 = MFMA_OP(k1f[PA], qf[1][PB], s0);
         PROD_LIST(QK)
 #undef QK
-        TSTAMP(1) TCOUNT(6)
-#else
-#pragma unroll
-        for (int p = 0; p < NPL; ++p) { asm volatile("" ::"v"(k0f[p]), "v"(k1f[p])); }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s0[r] = __builtin_bit_cast(float, (unsigned)(k0f[0][r & 7]) << 16) + 0.01f * r; }
-#endif
       }
       float sc[16];
       if (MODE == MODE6_KEYPAD && padflag[sub]) {
@@ -557,7 +481,6 @@ __global__ __launch_bounds__(DIR ? 64 : 256, DIR ? 3 : ATT_OCC(TBL)) void attent
         const unsigned vis = vis_all >> (4 * half);
         if (rep_tile) {
           const unsigned bia = bias_all >> (4 * half);
-#ifndef ATT_NO_BFI
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int pos_r = (r & 3) + 8 * (r >> 2);
@@ -565,15 +488,7 @@ __global__ __launch_bounds__(DIR ? 64 : 256, DIR ? 3 : ATT_OCC(TBL)) void attent
             const float v = s0[r] + __uint_as_float(__float_as_uint(log2m) & mb);
             sc[r] = __uint_as_float((__float_as_uint(v) & m) | (0xFF800000u & ~m));
           }
-#else
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const unsigned bit = 1u << ((r & 3) + 8 * (r >> 2));
-            sc[r] = (vis & bit) ? s0[r] + ((bia & bit) ? log2m : 0.f) : NEG_INF;
-          }
-#endif
         } else {
-#ifndef ATT_NO_BFI
           // two instructions per score: the key's bit sign-extended to a word mask (v_bfe_i32), then a bit-field insert that keeps the
           // score where the mask is set and -inf elsewhere (v_bfi_b32) — instead of and / compare / select
 #pragma unroll
@@ -581,10 +496,6 @@ __global__ __launch_bounds__(DIR ? 64 : 256, DIR ? 3 : ATT_OCC(TBL)) void attent
             const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)vis, (r & 3) + 8 * (r >> 2), 1);
             sc[r] = __uint_as_float((__float_as_uint(s0[r]) & m) | (0xFF800000u & ~m));
           }
-#else
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sc[r] = (vis & (1u << ((r & 3) + 8 * (r >> 2)))) ? s0[r] : NEG_INF;
-#endif
         }
       } else {
 #pragma unroll
@@ -603,11 +514,7 @@ __global__ __launch_bounds__(DIR ? 64 : 256, DIR ? 3 : ATT_OCC(TBL)) void attent
         float pe[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-#ifndef ABL_NO_EXP
           pe[r] = __builtin_amdgcn_exp2f(sc[r]);
-#else
-          pe[r] = sc[r];
-#endif
           psum += pe[r];
         }
         general = __any(!(psum < ATT_PMAX));
@@ -632,11 +539,7 @@ __global__ __launch_bounds__(DIR ? 64 : 256, DIR ? 3 : ATT_OCC(TBL)) void attent
         psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-#ifndef ABL_NO_EXP
           sc[r] = __builtin_amdgcn_exp2f(sc[r] - shift);
-#else
-          sc[r] = sc[r] - shift;
-#endif
           psum += sc[r];
         }
         l_run = l_run * alpha + psum;                                // per-lane partial (own 16 keys); halves are added at the end
@@ -644,18 +547,11 @@ __global__ __launch_bounds__(DIR ? 64 : 256, DIR ? 3 : ATT_OCC(TBL)) void attent
 #pragma unroll
         for (int r = 0; r < 16; ++r) oa[r] *= alpha;
       }
-      TSTAMP(2)
       // ---- P^T fragments: k-step kk uses accumulator registers 8*kk .. 8*kk+7 (slot j <-> register 8*kk + j)
       opx8 pf[2][NPL];
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-#ifndef ABL_NO_PSPLIT
         split_frag(sc + 8 * kk, pf[kk]);
-#else
-        { u32x4 u = {__float_as_uint(sc[8 * kk]), __float_as_uint(sc[8 * kk + 1]), __float_as_uint(sc[8 * kk + 2]), __float_as_uint(sc[8 * kk + 3])};
-          u32x4 w = {__float_as_uint(sc[8 * kk + 4]), __float_as_uint(sc[8 * kk + 5]), __float_as_uint(sc[8 * kk + 6]), __float_as_uint(sc[8 * kk + 7])};
-          pf[kk][0] = __builtin_bit_cast(opx8, u); pf[kk][1] = __builtin_bit_cast(opx8, w); pf[kk][NPL - 1] = pf[kk][0]; }
-#endif
       }
       // ---- O^T += V^T . P^T : A = V^T rows d = l31, slots 0-3 <-> keys 16kk+4half+0..3, slots 4-7 <-> +8
       {
@@ -672,37 +568,17 @@ __global__ __launch_bounds__(DIR ? 64 : 256, DIR ? 3 : ATT_OCC(TBL)) void attent
           v0f[p] = cat8(a0, a1);
           v1f[p] = cat8(b0, b1);
         }
-#ifndef ABL_NO_MFMA
 #define PV(PA, PB)                       \
   oa = MFMA_OP(v0f[PA], pf[0][PB], oa);  \
   oa = MFMA_OP(v1f[PA], pf[1][PB], oa);
         PROD_LIST(PV)
 #undef PV
-        TSTAMP(3)
-#else
-#pragma unroll
-        for (int p = 0; p < NPL; ++p) { asm volatile("" ::"v"(v0f[p]), "v"(v1f[p]), "v"(pf[0][p]), "v"(pf[1][p])); }
-#endif
       }
     }
-    if (more) sstore(NBUF == 3 ? (cur == 2 ? 0 : cur + 1) : cur ^ 1);
-    TSTAMP(4)
-#ifndef ATT_DMA_BUILTIN
-    if (NBUF == 3) {
-      // tile it+1 (requested one iteration ago) must have landed; tile it+2's pieces (this iteration's) stay in flight
-      if (more2) asm volatile("s_waitcnt vmcnt(%0) ; KV-DMA of the next tile landed" :: "n"(KV_PIECES) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0) ; KV-DMA landed" ::: "memory");
-    } else if (PRE && !DIR) asm volatile("s_waitcnt vmcnt(0) ; KV-DMA landed" ::: "memory");
-#endif
+    if (more) sstore(cur ^ 1);
+    if (PRE && !DIR) asm volatile("s_waitcnt vmcnt(0) ; KV-DMA landed" ::: "memory");
     if (!DIR || MODE == MODE6_KEYPAD) __syncthreads();       // DIR: only the key-padding bias block goes through LDS
-    TSTAMP(5)
   }
-#ifdef ATT_TIMING
-  if (lane == 0) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) atomicAdd(&g_att_t[i], tacc[i]);
-  }
-#endif
 
   // ---- normalise, transpose through LDS, store rows
   {

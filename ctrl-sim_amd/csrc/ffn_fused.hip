@@ -20,7 +20,6 @@
 // HBM traffic: x read twice (operand + residual, the second an L2 hit) and y written once = 2-3 KB per row, against
 // 13 KB per row for Linear / Linear+LN kernels with the hidden tensor in HBM.  Weights (3 MB of planes per block) come
 // from L2.
-#define FFN_XPRE 32   // epilogue: all 32 residual rows of the wave requested before the accumulators go through LDS (-4 %)
 #include "split.h"
 #include <type_traits>
 
@@ -30,18 +29,13 @@ namespace {
 
 constexpr int FF_BLK = NPL * 16 * 2 * 32 * 8;      // 16-bit elements of one weight block (W1: [NPL][16][2][32][8]; W2: [NPL][2][2][256][8])
 constexpr int FF_PIECES = FF_BLK / (256 * 8);      // 16-byte-per-thread LDS-DMA pieces of a block (8 / 12)
-#if CTRLSIM_F16X3 && !defined(FFN_RING3)
-// four ring slots (128 KB with two planes): both blocks of the NEXT hidden block are requested while the current one is computed, and
-// the workgroup meets once per hidden block (after the second product) instead of once per product
-constexpr int FF_RING = 4;
-#define FFN_PAIR_BARRIER 1
-#else
-constexpr int FF_RING = 3;
-#define FFN_PAIR_BARRIER 0
-#endif
-#ifndef FFN_PF
-#define FFN_PF (NPL == 2 ? 3 : 2)                   // LDS fragment prefetch distance in k-steps (four register buffers); 3 needs the
-#endif                                             // registers the two-plane scheme frees (+1.5 %), with three planes it spilled
+// two planes: four ring slots (128 KB) — both blocks of the NEXT hidden block are requested while the current one is computed, and the
+// workgroup meets once per hidden block (after the second product) instead of once per product; three planes: three 48 KB slots, a
+// meeting per product
+constexpr bool FF_PAIR = NPL == 2;
+constexpr int FF_RING = FF_PAIR ? 4 : 3;
+constexpr int FFN_PF = NPL == 2 ? 3 : 2;           // LDS fragment prefetch distance in k-steps (four register buffers); 3 needs the
+                                                   // registers the two-plane scheme frees (+1.5 %), with three planes it spilled
 constexpr int FF_CP = DM + 4;                      // row pitch (floats) of the epilogue staging
 // LDS: the ring, re-used by the epilogue as 4 x 32 rows of FF_CP floats — whichever is larger — then b1 (F floats)
 constexpr size_t FF_RING_BYTES = (size_t)FF_RING * FF_BLK * sizeof(op_t) > (size_t)4 * 32 * FF_CP * 4
@@ -82,9 +76,6 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
   // end of a phase: the block issued in the PREVIOUS phase must have landed (it is read next phase); the 12 pieces issued
   // in this phase may stay in flight (vmcnt counts in order).  LDS reads of this wave are complete (lgkmcnt(0)).
   auto phase_barrier = [&](bool issued_this_phase) {
-#ifdef ABL_NO_BARRIER
-    return;
-#endif
     if (issued_this_phase) __builtin_amdgcn_s_waitcnt(0x0070 | FF_PIECES);   // vmcnt(pieces) expcnt(7) lgkmcnt(0)  [gfx9: vmcnt = bits 3:0 + 15:14]
     else __builtin_amdgcn_s_waitcnt(0x0070);                          // nothing newer in flight: vmcnt(0)
     __builtin_amdgcn_s_barrier();
@@ -121,18 +112,9 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
       // (into a slot nobody reads any more; drained before the epilogue): the phases stay branch-free.
       const int hb_next = hb + 1 < nhb ? hb + 1 : nhb - 1;
       const op_t* dsrc_a = W1p + (size_t)hb_next * FF_BLK + tid * 8;
-#if FFN_PAIR_BARRIER
-      op_t* ddst_a = ring + ((slot + 2) & 3) * FF_BLK + wave * 64 * 8;        // block 2 hb + 2 -> the slot block 2 hb - 2 left a pair ago
-#else
-      op_t* ddst_a = ring + (slot == 0 ? 2 : slot - 1) * FF_BLK + wave * 64 * 8;
-#endif
-#ifdef FFN_H2
-      f32x16 hacc, hacc2;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) hacc2[r] = 0.f;
-#else
+      // pair barrier: block 2 hb + 2 -> the slot block 2 hb - 2 left a pair ago; otherwise the slot read last phase
+      op_t* ddst_a = ring + (FF_PAIR ? ((slot + 2) & 3) : (slot == 0 ? 2 : slot - 1)) * FF_BLK + wave * 64 * 8;
       f32x16 hacc;
-#endif
       {
         const float* bp = b1s + hb * 32 + 4 * half;                    // register r <-> hidden (r & 3) + 8 (r >> 2) + 4 half
 #pragma unroll
@@ -148,11 +130,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
         opx8 wf[4][NPL];
         auto ld1 = [&](int ks, opx8 (&f)[NPL]) {
 #pragma unroll
-#ifndef ABL_NO_FRAG
           for (int p = 0; p < NPL; ++p) f[p] = *reinterpret_cast<const opx8*>(w1 + ((p * 16 + ks) * 2) * 32 * 8);
-#else
-          for (int p = 0; p < NPL; ++p) { f[p] = xT[ks][p]; asm volatile("" : "+v"(f[p])); }
-#endif
         };
         ld1(0, wf[0]);
         ld1(1, wf[1]);
@@ -160,14 +138,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
           if (ks + FFN_PF < 16) ld1(ks + FFN_PF, wf[(ks + FFN_PF) & 3]);
-#ifndef ABL_NO_DMA
           if (ks < FF_PIECES) dma_piece(dsrc_a, ddst_a, ks);
-#endif
-#ifdef FFN_H2
-          if (ks & 1) { FFN_TERMS(hacc2, wf[ks & 3], xT[ks]) } else { FFN_TERMS(hacc, wf[ks & 3], xT[ks]) }
-#else
           FFN_TERMS(hacc, wf[ks & 3], xT[ks])
-#endif
         }
       }
       // ReLU + split: k-step kk of the second product uses accumulator registers 8 kk .. 8 kk + 7
@@ -175,56 +147,26 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
       {
         float hv[16];
 #pragma unroll
-#ifdef FFN_H2
-        for (int r = 0; r < 16; ++r) hv[r] = fmaxf((hacc[r] + hacc2[r]) * WSCALE_INV, 0.f);
-#else
         for (int r = 0; r < 16; ++r) hv[r] = fmaxf(hacc[r] * WSCALE_INV, 0.f);
-#endif
-#ifndef ABL_NO_SPLIT
         split_frag(hv, hf[0]);
         split_frag(hv + 8, hf[1]);
-#else
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-          for (int p = 0; p < NPL; ++p) {
-            u32x4 u = {__float_as_uint(hv[8 * kk + p]), __float_as_uint(hv[8 * kk + p + 1]), __float_as_uint(hv[8 * kk + p + 2]), __float_as_uint(hv[8 * kk + p + 3])};
-            hf[kk][p] = __builtin_bit_cast(opx8, u);
-          }
-#endif
       }
-#if FFN_PAIR_BARRIER
-      // (no meeting here: block 2 hb + 1 landed before this pair began and nothing overwrites a slot inside a pair)
-#else
-      phase_barrier(true);                               // block 2 hb + 1 has landed; everyone is done with this slot
-#endif
+      // (pair barrier: no meeting here — block 2 hb + 1 landed before this pair began and nothing overwrites a slot inside a pair)
+      if (!FF_PAIR) phase_barrier(true);                 // block 2 hb + 1 has landed; everyone is done with this slot
       slot = slot == FF_RING - 1 ? 0 : slot + 1;
 
       // ---------------- phase 2 hb + 1: Y^T += W2_blk . H^T, block 2 hb + 1 in slot (2 hb + 1) % FF_RING
       const op_t* dsrc_b = W2p + (size_t)hb_next * FF_BLK + tid * 8;
-#if FFN_PAIR_BARRIER
-      op_t* ddst_b = ring + ((slot + 2) & 3) * FF_BLK + wave * 64 * 8;        // block 2 hb + 3 -> the slot of block 2 hb - 1
-#else
-      op_t* ddst_b = ring + (slot == 0 ? 2 : slot - 1) * FF_BLK + wave * 64 * 8;
-#endif
+      op_t* ddst_b = ring + (FF_PAIR ? ((slot + 2) & 3) : (slot == 0 ? 2 : slot - 1)) * FF_BLK + wave * 64 * 8;   // block 2 hb + 3 -> the slot of block 2 hb - 1
       {
         const op_t* w2 = ring + slot * FF_BLK + (half * 256 + l31) * 8;   // [p][kk][half][o][8]
         opx8 wf[4][NPL];
-#ifdef FFN_KKMAJOR
-#define FFN_OB(i) ((i) & 7)
-#define FFN_KK(i) ((i) >> 3)
-#else
-#define FFN_OB(i) ((i) >> 1)
-#define FFN_KK(i) ((i) & 1)
-#endif
-        auto ld2 = [&](int i, opx8 (&f)[NPL]) {        // step i = (out block ob = i >> 1, k-step kk = i & 1)
+        // step i = (out block ob = i & 7, k-step kk = i >> 3): k-step-major — consecutive groups of three products go to DIFFERENT output
+        // accumulators (round 5: +1 % over out-block-major, where six dependent products queue on one accumulator)
+        auto ld2 = [&](int i, opx8 (&f)[NPL]) {
 #pragma unroll
           for (int p = 0; p < NPL; ++p)
-#ifndef ABL_NO_FRAG
-            f[p] = *reinterpret_cast<const opx8*>(w2 + (((p * 2 + FFN_KK(i)) * 2) * 256 + FFN_OB(i) * 32) * 8);
-#else
-          { f[p] = hf[i & 1][p]; asm volatile("" : "+v"(f[p])); }
-#endif
+            f[p] = *reinterpret_cast<const opx8*>(w2 + (((p * 2 + (i >> 3)) * 2) * 256 + (i & 7) * 32) * 8);
         };
         ld2(0, wf[0]);
         ld2(1, wf[1]);
@@ -232,34 +174,26 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           if (i + FFN_PF < 16) ld2(i + FFN_PF, wf[(i + FFN_PF) & 3]);
-#ifndef ABL_NO_DMA
           if (i < FF_PIECES) dma_piece(dsrc_b, ddst_b, i);
-#endif
-          FFN_TERMS(yacc[FFN_OB(i)], wf[i & 3], hf[FFN_KK(i)])
+          FFN_TERMS(yacc[(i & 7)], wf[i & 3], hf[(i >> 3)])
         }
       }
-#if FFN_PAIR_BARRIER
-      phase_barrier(false);                              // vmcnt(0): the next hidden block's two weight blocks have landed for every wave
-#else
-      phase_barrier(true);
-#endif
+      phase_barrier(!FF_PAIR);                           // pair barrier: vmcnt(0) — the next hidden block's two weight blocks have landed for every wave
       slot = slot == FF_RING - 1 ? 0 : slot + 1;
     }
     __syncthreads();                                                  // drain everything before the ring is reused as staging
 
     // ---------------- epilogue: Y^T -> LDS (own 32-row region), then row-major + b2 + x, LayerNorm, store
     float* Cs = reinterpret_cast<float*>(ring) + wave * 32 * FF_CP;
-#ifdef FFN_XPRE
     // the residual rows of this wave are requested before the accumulators go through LDS (the X^T fragment registers are dead
     // by now): their latency runs under the 128 ds_writes instead of in front of every row's reductions.  X may alias Y — all
     // of the wave's reads are issued before its first store.
-    f32x4 xpre[FFN_XPRE];
+    f32x4 xpre[32];       // all 32 residual rows of the wave, requested before the accumulators go through LDS (-4 %)
 #pragma unroll
-    for (int rr = 0; rr < FFN_XPRE; ++rr) {
+    for (int rr = 0; rr < 32; ++rr) {
       const int grow = rb * 128 + wave * 32 + rr;
       xpre[rr] = grow < M ? *reinterpret_cast<const f32x4*>(X + (size_t)grow * ldx + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-#endif
 #pragma unroll
     for (int ob = 0; ob < 8; ++ob)
 #pragma unroll
@@ -271,21 +205,13 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
       const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + col);
       const f32x4 gg = *reinterpret_cast<const f32x4*>(gamma + col);
       const f32x4 be = *reinterpret_cast<const f32x4*>(beta + col);
-#ifdef FFN_XPRE
 #pragma unroll
-#else
-#pragma unroll 4
-#endif
       for (int rr = 0; rr < 32; ++rr) {
         const int grow = rb * 128 + wave * 32 + rr;
         if (grow >= M) break;
         f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * FF_CP + col);
         v += bb;
-#ifdef FFN_XPRE
-        v += rr < FFN_XPRE ? xpre[rr < FFN_XPRE ? rr : 0] : *reinterpret_cast<const f32x4*>(X + (size_t)grow * ldx + col);
-#else
-        v += *reinterpret_cast<const f32x4*>(X + (size_t)grow * ldx + col);
-#endif
+        v += xpre[rr];
         const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
         const f32x4 dv = v - mean;
         const float var = wave_sum(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2] + dv[3] * dv[3]) * (1.f / 256.f);

@@ -24,9 +24,7 @@
 // the epilogue; the epilogue stages half the tile's rows at a time through LDS for 16-byte bias / residual / store
 // traffic and, for LN, normalises whole rows there (one wave per row).
 #define GEMM_NT_STORE   // fp32 output rows leave with nontemporal stores: they are far larger than L2 and only evict the operands (-2.5 %)
-#ifndef GEMM_RPRE_N
 #define GEMM_RPRE_N 8      // residual rows requested ahead per chunk (all eight: four VGPRs spill, still 9 % faster than four ahead)
-#endif
 #define GEMM_RPRE    // LayerNorm epilogue: residual rows requested before the accumulators go through LDS (0.58 -> 0.49 ms, out-proj + LN shape)
 #include "split.h"
 #include <type_traits>
@@ -114,12 +112,8 @@ __device__ __forceinline__ void kv_place(const KvImg& kv, const KvTile& t, int c
 }
 
 template <int WR, int WC, int MR, bool RELU, bool RESID, bool LN, bool KVIMG = false>
-#ifndef GEMM_OCC_22
 #define GEMM_OCC_22 3
-#endif
-#ifndef GEMM_OCC_14
 #define GEMM_OCC_14 3        // 1x4 (LayerNorm) tiles: 40 KB of LDS with two planes -> three workgroups per CU (+24 % on out_proj+LN)
-#endif
 __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC_22 : GEMM_OCC_14)) void gemm_nt_bf16x6_kernel(
     const float* __restrict__ A, int lda, const op_t* __restrict__ W3,   // [K/16][NPL][2][n_total][8]
     const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -168,16 +162,12 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
       const int idx = tid + 256 * i, r = idx >> 2, c = (idx & 3) * 4;
       int ga = bm + r;
       ga = ga < M ? ga : M - 1;
-#ifndef ABL_NO_ALOAD
       // inline asm: hipcc's own s_waitcnt insertion answers a register load that is consumed two k-steps later with vmcnt(0)
       // (draining the prefetches behind it); loads it does not see are waited for by the counted wait_a() below instead
       const float* src = A + (size_t)ga * lda + kt * XK + c;
       f32x4 t;                                     // (a local: clang rejects captured arrays as asm operands in a generic lambda)
       asm volatile("global_load_dwordx4 %0, %1, off ; A-PREFETCH" : "=v"(t) : "v"(src) : "memory");
       ra[set][i] = t;
-#else
-      ra[set][i] = f32x4{0.f, 0.f, 0.f, 0.f} + (float)(ga + kt);
-#endif
     }
   };
   auto dma_w = [&](int kt, int buf) {
@@ -197,7 +187,6 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
   auto wait_a = [&](auto SET, auto NEWER) {
     constexpr int set = decltype(SET)::value, newer = decltype(NEWER)::value;
     static_assert(newer < 64, "vmcnt is a 6-bit counter");
-#ifndef ABL_NO_ALOAD
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       f32x4 t = ra[set][i];
@@ -205,7 +194,6 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
       else asm volatile("" : "+v"(t));
       ra[set][i] = t;
     }
-#endif
   };
   auto sstore_a = [&](auto SET, int buf) {
     constexpr int set = decltype(SET)::value;
@@ -213,12 +201,7 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
     for (int i = 0; i < NA; ++i) {
       const int idx = tid + 256 * i, r = idx >> 2, c = (idx & 3) * 4;
       u32x2 pl[NPL];
-#ifndef ABL_NO_SPLIT
       split_quad(ra[set][i], pl);
-#else
-#pragma unroll
-      for (int q = 0; q < NPL; ++q) pl[q] = u32x2{__float_as_uint(ra[set][i][0]), __float_as_uint(ra[set][i][1 + (q & 1)])};
-#endif
       op_t* Ab = lds + buf * STAGE + (c >> 3) * (A_PLANE / 2) + r * 8 + (c & 7);
 #pragma unroll
       for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x2*>(Ab + q * A_PLANE) = pl[q];
@@ -260,16 +243,13 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
       // register set): a conditional issue makes the number of operations in flight path dependent, and both hipcc's own
       // vmcnt for the register set and the counted wait below would have to assume the worst (vmcnt(0): no prefetch at all)
       const int kpre = kt + 2 < nk ? kt + 2 : nk - 1;
-#ifndef ABL_NO_DMA
       if (RING == 3) dma_w(kpre, nxt + 1 == RING ? 0 : nxt + 1);     // stage of step kt - 1: released by its barrier
       else dma_w(kt + 1 < nk ? kt + 1 : nk - 1, nxt);
-#endif
       gload_a(kpre, SET);
       {
         const op_t* Ab = lds + cur * STAGE + half * (A_PLANE / 2) + (wr * WMR + l31) * 8;
         const op_t* Wb = lds + cur * STAGE + NPL * A_PLANE + half * (W_PLANE / 2) + (wc * 64 + l31) * 8;
         opx8 fa[MR][NPL], fb[2][NPL];
-#ifndef ABL_NO_FRAG
 #pragma unroll
         for (int p = 0; p < NPL; ++p) {
 #pragma unroll
@@ -277,15 +257,7 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
 #pragma unroll
           for (int b = 0; b < 2; ++b) fb[b][p] = *reinterpret_cast<const opx8*>(Wb + p * W_PLANE + b * 32 * 8);
         }
-#else
-#pragma unroll
-        for (int p = 0; p < NPL; ++p) {
-#pragma unroll
-          for (int a = 0; a < 2; ++a) { fa[a % MR][p] = opx8{}; fb[a][p] = opx8{}; asm volatile("" : "+v"(fa[a % MR][p]), "+v"(fb[a][p])); }
-        }
-#endif
         // the partial products, smallest first; term-major order keeps 4 independent accumulators between reuses
-#ifndef ABL_NO_MFMA
 #if CTRLSIM_F16X3
         term<1, 0, MR>(acc, fa, fb);
         term<0, 1, MR>(acc, fa, fb);
@@ -297,10 +269,6 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
         term<1, 0, MR>(acc, fa, fb);
         term<0, 1, MR>(acc, fa, fb);
         term<0, 0, MR>(acc, fa, fb);
-#endif
-#else
-#pragma unroll
-        for (int p = 0; p < NPL; ++p) { asm volatile("" ::"v"(fa[0][p]), "v"(fa[MR - 1][p]), "v"(fb[0][p]), "v"(fb[1][p])); }
 #endif
       }
       wait_a(other{}, std::integral_constant<int, NW + NA>{});   // younger: this step's two prefetches
@@ -337,16 +305,8 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
     while (nid < total_ids && !tile_of(nid, bm, bn)) nid += gridDim.x;
     const bool have_next = nid < total_ids;
     if (have_next) gload_a(0, set0{});
-#ifdef ABL_NO_EPI
-#pragma unroll
-    for (int a = 0; a < MR; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) asm volatile("" ::"v"(acc[a][b]));
-    if (tid == 0 && M < 0) C[0] = Cs[0];
-#else
 #pragma unroll
     for (int a = 0; a < MR; ++a) {
-#ifdef GEMM_RPRE
       // LayerNorm epilogue: the residual rows of this chunk are requested BEFORE the accumulators go through LDS, so their
       // HBM latency runs under the ds_write / barrier instead of in front of the row reductions
       constexpr int NRP_ALL = CR * (XN / 4) / 256;
@@ -360,7 +320,6 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
           rpre[i] = grow < M ? *reinterpret_cast<const f32x4*>(R + (size_t)grow * ldr + cbn + col) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
-#endif
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -426,11 +385,7 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
         continue;
       }
       constexpr int LPR = XN / 4;                  // lanes per row (f32x4 each): 32 (2x2) or 64 = one wave (1x4)
-#ifdef GEMM_RPRE
 #pragma unroll
-#else
-#pragma unroll 4
-#endif
       for (int i = 0; i < CR * LPR / 256; ++i) {
         const int idx = tid + 256 * i, lr = idx / LPR, col = (idx % LPR) * 4;
         const int grow = cbm + (lr >> 5) * WMR + a * 32 + (lr & 31), gcol = cbn + col;
@@ -439,11 +394,7 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
           if (grow >= M) continue;
           f32x4 v = *reinterpret_cast<const f32x4*>(Cs + lr * CP + col);
           if (bias) v += *reinterpret_cast<const f32x4*>(bias + gcol);
-#ifdef GEMM_RPRE
           if (RESID) v += i < NRP ? rpre[i < NRP ? i : 0] : *reinterpret_cast<const f32x4*>(R + (size_t)grow * ldr + gcol);
-#else
-          if (RESID) v += *reinterpret_cast<const f32x4*>(R + (size_t)grow * ldr + gcol);
-#endif
           const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
           const f32x4 dv = v - mean;
           const float var = wave_sum(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2] + dv[3] * dv[3]) * (1.f / 256.f);
@@ -454,11 +405,7 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
 #pragma unroll
             for (int c = 0; c < 4; ++c) y[c] = fmaxf(y[c], 0.f);
           }
-#ifdef GEMM_NT_STORE
           __builtin_nontemporal_store(y, reinterpret_cast<f32x4*>(C + (size_t)grow * ldc + gcol));
-#else
-          *reinterpret_cast<f32x4*>(C + (size_t)grow * ldc + gcol) = y;
-#endif
           continue;
         }
         if (grow >= M || gcol >= N) continue;
@@ -470,11 +417,7 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
           }
-#ifdef GEMM_NT_STORE
           __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(C + (size_t)grow * ldc + gcol));
-#else
-          *reinterpret_cast<f32x4*>(C + (size_t)grow * ldc + gcol) = v;
-#endif
         } else {
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
@@ -489,7 +432,6 @@ __global__ __launch_bounds__(256, MR == 1 ? 4 : ((WR == 2 && WC == 2) ? GEMM_OCC
       }
       __syncthreads();
     }
-#endif
     if (!have_next) break;
     id = nid;
   }
@@ -539,9 +481,7 @@ int launch_gemm_nt_bf16x6_kv(const float* A, int lda, const void* W3, int n_tota
 // that the activation buffer the k-loop just read may be refilled.  The DMA is issued as inline asm (see
 // attention_bf16x6.hip: the compiler answers the builtin with a full drain before the next ds_read).
 #define WS_ROWS 32
-#ifndef WS_AHEAD
 #define WS_AHEAD 2
-#endif
 __device__ __forceinline__ f32x16 ws_fake_mfma(opx8 a, opx8 b, f32x16 c) {      // ablation builds only
   c[0] += (float)a[0] * (float)b[0];
   return c;
@@ -592,9 +532,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ws256_kernel(const float* A, int 
   auto dma = [&](const float* src0, int ld, float* dst0, int j) {
     const int blk = blockIdx.x + j * gridDim.x;
     if (blk >= nblk) return;
-#ifdef WS_ABL_NODMA
-    if (M > 0) return;
-#endif
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int r = 4 * wave + q;
@@ -686,7 +623,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ws256_kernel(const float* A, int 
   auto kloop = [&](const float* ap, auto epi) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = 0.f;
-#ifndef WS_ABL_NOK
     f32x4 xq[WS_AHEAD + 1][2];
 #pragma unroll
     for (int ks = 0; ks < WS_AHEAD; ++ks) {
@@ -698,33 +634,18 @@ __global__ __launch_bounds__(512, 2) void gemm_ws256_kernel(const float* A, int 
     for (int ks = 0; ks < 16; ++ks) {
       const f32x4 lo = xq[ks % (WS_AHEAD + 1)][0], hi = xq[ks % (WS_AHEAD + 1)][1];
       opx8 fb[NPL];
-#ifdef WS_ABL_NOSPLIT
-      fb[0] = __builtin_bit_cast(opx8, lo); fb[1] = __builtin_bit_cast(opx8, hi);
-#else
       ws_split8(lo, hi, fb);
-#endif
-#ifdef WS_ABL_NOMFMA
-#define WS_MFMA(A_, B_, C_) ws_fake_mfma(A_, B_, C_)
-#else
 #define WS_MFMA(A_, B_, C_) MFMA_OP(A_, B_, C_)
-#endif
       acc1 = WS_MFMA(wf[ks][1], fb[0], acc1);            // the two small products share an accumulator, W_hi x_hi has its own:
       acc = WS_MFMA(wf[ks][0], fb[0], acc);              // no MFMA waits for the one issued just before it
       if (ks + WS_AHEAD < 16) {
         xq[(ks + WS_AHEAD) % (WS_AHEAD + 1)][0] = *reinterpret_cast<const f32x4*>(ap + (ks + WS_AHEAD) * 16);
         xq[(ks + WS_AHEAD) % (WS_AHEAD + 1)][1] = *reinterpret_cast<const f32x4*>(ap + (ks + WS_AHEAD) * 16 + 4);
       }
-#ifndef WS_ABL_NOEPI
       epi(ks);
-#endif
       acc1 = WS_MFMA(wf[ks][0], fb[1], acc1);
       __builtin_amdgcn_sched_barrier(0);
     }
-#else
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) { asm volatile("" :: "v"(wf[ks][0]), "v"(wf[ks][1])); epi(ks); }
-    acc[0] = ap[0];
-#endif
   };
   kloop(ap0, [](int) {});
 
@@ -831,11 +752,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ws256_kernel(const float* A, int 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int grow = blk * WS_ROWS + 4 * wave + q;
-#ifdef WS_ABL_NOST
-      if (grow < M && grow == -5)
-#else
       if (grow < M)
-#endif
         __builtin_nontemporal_store(yo[q], reinterpret_cast<f32x4*>(C + (size_t)grow * ldc + lane * 4));
     }
     if (RESID) dma(R, ldr, rbuf, it + 2);                 // this wave's four rows of rb: read by its own stores above only
@@ -863,34 +780,11 @@ constexpr int RS_RING = 4;
 constexpr int RS_PIECES = RS_BLK / (512 * 8);        // 16-byte-per-thread DMA pieces of a block (4)
 constexpr int RS_MAXB = 3 * DM / 32;                 // column blocks of the largest launch (in_proj: 24)
 #define RS_LDS_BYTES (RS_RING * RS_BLK * 2 + RS_MAXB * 32 * 4)
-#ifdef RS_Q_LINES          // query blocks with swapped operands, whole 128-byte lines per store (16 stores per lane): measured no different
-#define RS_Q_ORI 1
-#else
 #define RS_Q_ORI 0
-#endif
-#ifndef RS_AHEAD
 #define RS_AHEAD 2         // weight blocks are requested this many phases ahead (2 or 3 with the four ring slots; 3 measured 1 % slower)
-#endif
-#ifndef RS_PF
 #define RS_PF 2            // LDS fragment prefetch distance in k-steps
-#endif
-#ifndef RS_PLAIN_ST
 #define RS_ST(P, V) __builtin_nontemporal_store(V, P)     // 512-byte runs that nobody re-reads before the attention kernel: -4 %
-#else
-#define RS_ST(P, V) (*(P) = (V))
-#endif
-#ifdef RS_TIMING   // per-segment s_memtime accounting of wave 0 of every workgroup (variant builds only; tools/microbench/rs_timing.py)
-__device__ unsigned long long g_rs_t[8];
-extern "C" int ctrlsim_debug_rs_times(unsigned long long* out, int reset) {
-  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rs_t), sizeof(g_rs_t)) != hipSuccess) return CTRLSIM_ELAUNCH;
-  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_rs_t), z, sizeof(z)) != hipSuccess) return CTRLSIM_ELAUNCH; }
-  return CTRLSIM_OK;
-}
-#define RS_STAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
-                      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); rs_tacc[i] += _t - rs_tlast; rs_tlast = _t; }
-#else
 #define RS_STAMP(i)
-#endif
 __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restrict__ A, int lda, const op_t* __restrict__ Wb,
                                                            const float* __restrict__ bias, float* __restrict__ C, int ldc, int M,
                                                            int nb, const KvImg kv) {
@@ -905,10 +799,6 @@ __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restri
   const int p_begin = (int)(total * blockIdx.x / gridDim.x), p_end = (int)(total * (blockIdx.x + 1) / gridDim.x);
   if (p_begin >= p_end) return;
   for (int i = tid; i < nb * 32; i += 512) bs[i] = bias ? bias[i] : 0.f;
-#ifdef RS_STAGGER
-  // experiment: workgroups start a quarter of a block's time apart (their store bursts then do not coincide chip-wide)
-  for (int i = 0; i < ((int)blockIdx.x & 3); ++i) __builtin_amdgcn_s_sleep(RS_STAGGER);
-#endif
   auto dma_piece = [&](int blk, int slot, int j) {
     const op_t* src = Wb + (size_t)blk * RS_BLK + (j * 512 + tid) * 8;
     op_t* dst = rs_ring + slot * RS_BLK + (j * 512 + wave * 64) * 8;       // wave-uniform LDS base (+ 16 B per lane)
@@ -921,20 +811,11 @@ __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restri
     for (int j = 0; j < RS_PIECES; ++j) dma_piece(cb, 0, j);
 #pragma unroll
     for (int j = 0; j < RS_PIECES; ++j) dma_piece(c1, 1, j);
-#if RS_AHEAD == 3
-    const int c2 = c1 + 1 == nb ? 0 : c1 + 1;
-#pragma unroll
-    for (int j = 0; j < RS_PIECES; ++j) dma_piece(c2, 2, j);
-#endif
   }
   int nxt = (cb + RS_AHEAD) % nb;                     // column block RS_AHEAD phases ahead
   const int kb0 = kv.k_col0 >> 5;                     // first key block; values from kb0 + 8
   constexpr int KIMG = 2 * NPL * 64 * HD, KPL = 64 * HD;
   int slot = 0;                                       // ring slot of the current block
-#ifdef RS_TIMING
-  unsigned long long rs_tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rs_tlast = __builtin_amdgcn_s_memtime();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
   // The wave's 32 rows of a job arrive as 32 raw 16-byte loads per lane (k-step ks: k = 16 ks + 8 half .. + 7), all requested at the top
   // of the job and converted in order as they land.  (Requested a block earlier — right after the previous job's last k-loop, when the
   // fragment registers are dead — the job start shrinks from 20 % to 3 % of the wave's time and the barrier waits grow by the same
@@ -978,9 +859,6 @@ __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restri
         }
       }
     }
-#ifdef RS_ABL_SAMEADDR
-    if (M > 0) { k_tile = wave; for (int g = 0; g < 4; ++g) v_tile[g] = wave; }      // ablation: every job writes the same few tiles (L2 only)
-#endif
     opx8 xT[16][NPL];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
@@ -996,27 +874,8 @@ __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restri
     // one quarter (quad q) of a finished block: fp32 row pieces / key plane entries / value plane entries; 1 / 2 / 2 stores
     auto epi_quad = [&](const f32x16& v, int knd, int cbv, int q) {
       const f32x4 x = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]} * WSCALE_INV;
-#ifdef RS_ABL_NOSTORE
-      if (M > 0) return;
-#endif
-#ifdef RS_Q_LINES
-      // fp32 rows: the block was computed with the operands swapped (like a value block), a lane owns column l31 of 16 rows — every store
-      // instruction writes two whole 128-byte lines (32-byte row pieces from the other orientation: 4x the write requests per byte)
       if (knd == 0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int r_ = cbm + 8 * q + 4 * half + j;
-          if (r_ < M) C[(size_t)r_ * ldc + cbv * 32 + l31] = x[j];
-        }
-        return;
-      }
-#endif
-      if (knd == 0) {
-#ifdef RS_ABL_SAMEADDR
-        if (row < M) *reinterpret_cast<f32x4*>(C + (size_t)(row & 255) * ldc + cbv * 32 + 4 * half + 8 * q) = x;
-#else
         if (row < M) *reinterpret_cast<f32x4*>(C + (size_t)row * ldc + cbv * 32 + 4 * half + 8 * q) = x;
-#endif
       } else if (knd == 1) {
         if (k_tile >= 0) {
           u32x2 pa[NPL];
@@ -1069,9 +928,7 @@ __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restri
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
           if (ks + RS_PF < 16) ld1(ks + RS_PF, wf[(ks + RS_PF) % (RS_PF + 1)]);
-#ifndef RS_ABL_NODMA
           if (ks < RS_PIECES) dma_piece(nxt, nslot, ks);
-#endif
           const int c = ks % (RS_PF + 1);
           if (ori == 0) { SPLIT_TERMS(acc, wf[c], xT[ks]) }                // D^T = W_blk . X^T: a lane owns one row
           else { SPLIT_TERMS(acc, xT[ks], wf[c]) }                         // D = X . W_blk^T: a lane owns one dim
@@ -1108,9 +965,6 @@ __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restri
 #pragma unroll
       for (int q = 0; q < 4; ++q) epi_quad(acc, kind, cb, q);
       RS_STAMP(3)
-#ifdef RS_TIMING
-      rs_tacc[5] += 1;
-#endif
       e_prev2 = e_prev;
       e_prev = e_cur;
       slot = (slot + 1) & 3;
@@ -1119,12 +973,6 @@ __global__ __launch_bounds__(512, 2) void inproj_rs_kernel(const float* __restri
     if (cb == nb) cb = 0;
     ++job;
   }
-#ifdef RS_TIMING
-  if (tid == 0 || tid == 256) {
-    rs_tacc[6] += 1;
-    for (int i = 0; i < 8; ++i) atomicAdd(&g_rs_t[i], rs_tacc[i]);
-  }
-#endif
 }
 
 int launch_inproj_rs(const float* A, int lda, const void* Wblk, const float* bias, float* C, int ldc, int M, int N, void* kv_img,

@@ -337,15 +337,20 @@ class PolicyEvaluator:
         steer = np.zeros((S, N, T1))
         speeds = np.zeros((S, N, T1), np.float32)
         own_last = np.zeros((T, N), np.int32)                  # last scene of the batch: does a context answer for the vehicle at step t
+        import time
+        tm = self.batched_timing = {"policy_step_enqueue": 0.0, "read_back": 0.0, "host_actions": 0.0, "upload_and_sim": 0.0}
         for t in range(T):
+            t_a = time.perf_counter()
             # update_vehicle_data_dict (:99-159): existence = the log's flag, latched at 0
             exist[:, :, t] = gt[:, :, t, 4] if t == 0 else gt[:, :, t, 4] * (exist[:, :, t - 1] != 0)
             eng.hist_states[:, :, t, 7] = torch.from_numpy(exist[:, :, t].astype(np.float32)).to(dev)
             eng.policy_step(t)
+            t_b = time.perf_counter()
             row = eng.hist_states[:, :, t].cpu().numpy()       # synchronises: the step's tokens are sampled
             toks = eng.act_now.cpu().numpy()
             speed = eng.phys[:, :, 16].cpu().numpy()
             bad = eng.nonfinite()
+            t_c = time.perf_counter()
             if bad and bad < 65536 and eng.split == "auto" and eng.scheme == 1:
                 eng._set_split(0)                              # as predict(): redo the step with the range-safe three-bf16-plane operands
                 eng.policy_step(t)
@@ -373,11 +378,14 @@ class PolicyEvaluator:
             alive[rep & ~ok] = False
             accel[:, :, t] = a
             steer[:, :, t] = st
+            t_d = time.perf_counter()
             act = torch.from_numpy(np.stack([a, st], -1)).to(dev)
             # what update_state writes back as the action history of step t: the applied action, discretised (identity for a sampled token)
             eng.hist_tok[:, :, t] = torch.from_numpy(dz.discretize_actions(np.stack([a, st], -1), w).astype(np.int32)).to(dev)
             eng.exists.copy_(torch.from_numpy(alive.astype(np.uint8)).to(dev))
             eng.sim_step(t, act)
+            t_e = time.perf_counter()
+            tm["policy_step_enqueue"] += t_b - t_a; tm["read_back"] += t_c - t_b; tm["host_actions"] += t_d - t_c; tm["upload_and_sim"] += t_e - t_d
         exist[:, :, T] = gt[:, :, T, 4] * (exist[:, :, T - 1] != 0)
         states = eng.hist_states.cpu().numpy()
         coll = eng.coll.cpu().numpy()

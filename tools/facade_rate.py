@@ -35,8 +35,11 @@ cfg1.eval["synthetic"] = dict(num_scenarios=1, n_agents=N, n_polylines=200, seed
 cfg1.eval.num_files_to_evaluate = cfg1.eval.partitions
 PolicyEvaluator(cfg1, policy).evaluate_policy()              # warm-up: first launches, allocations
 t0 = time.perf_counter()
-m, _ = PolicyEvaluator(cfg, policy).evaluate_policy()
+EV = PolicyEvaluator(cfg, policy)
+m, _ = EV.evaluate_policy()
 el = time.perf_counter() - t0
 n_scn = S + 1
 print(f"plugin route ({'batched: one RolloutEngine batch' if BATCHED else 'per-scenario loop'}): {n_scn} scenarios x {N} vehicles x {T} steps, full model, in {el:.2f} s = {n_scn * N * T / el:.0f} agent-steps/s "
       f"({el / (n_scn * T) * 1e3:.1f} ms per scenario-step)")
+if BATCHED:
+    print("  batched route, seconds by phase of the step loop:", {k: round(v, 3) for k, v in getattr(EV, "batched_timing", {}).items()})
