@@ -439,6 +439,7 @@ def main():
                         "selectable per engine (ctrlsim_bind_options); traffic = HBM bytes per launch: per KERNEL (2 x FETCH_SIZE + WRITE_SIZE) / algorithmic "
                         "bytes measured by separate rocprofv3 --pmc passes over a smaller run of this workload (traffic_measured, committed "
                         "under profiles/ with the calibration of the counter factors) x this run's algorithmic bytes of that kernel",
+                "mfma_sustained_measured": _sustained(nprod, ms, fl, dom),
                 "other": cls(1 - dom),
                 "satellite": {CLASS_KEYS[i]: sat(i) for i in range(2, ncls)},
                 "satellite_note": "HBM-side kernels (SURVEY 8d): algorithmic bytes (DESIGN.md 4) / HIP-event time vs the 8 TB/s HBM "
@@ -509,6 +510,21 @@ def main():
             "rollout_metrics": {k: (None if v != v else v) for k, v in m.items()},
         }
         print(json.dumps(out))
+
+
+def _sustained(nprod, ms, fl, dom):
+    """The matrix rate the part SUSTAINS (profiles/r05_mfma_sustained.json: a register-only MFMA loop on random data runs at 1.48 PFLOP/s —
+    the chip clocks to its power budget, 1.42 GHz under a pure matrix load, where the data sheet's 2.5 PFLOP/s is 2.4 GHz) next to the
+    data-sheet peak the `frac` fields are quoted against."""
+    path = os.path.join(ROOT, "profiles", "r05_mfma_sustained.json")
+    if not os.path.exists(path) or ms[dom] <= 0:
+        return None
+    m = json.load(open(path))
+    peak = m["mfma_16bit_sustained_tflops"] / nprod
+    a = fl[dom] / (ms[dom] * 1e-3) / 1e12
+    return {"peak_fp32_equivalent": peak, "unit": "TFLOP/s", "frac_of_sustained": a / peak, "mfma_16bit_sustained_tflops": m["mfma_16bit_sustained_tflops"],
+            "implied_clock_ghz": m["implied_clock_ghz"], "source": "profiles/r05_mfma_sustained.json",
+            "note": "informational: `frac` above stays relative to the data-sheet peak (MI355X_MICROARCH.md)"}
 
 
 def _reduce_times(dist, elapsed, t_own, max_ctx, coll_device, gather_scalar):

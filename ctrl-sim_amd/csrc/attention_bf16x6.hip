@@ -120,8 +120,14 @@ __global__ __launch_bounds__(256) void attn_mask_table_kernel(TblBatch tb) {
 // layout IS the fragment layout (a lane's 16 / 8 bytes are contiguous), so a tile that a single wave uses once has no business in LDS.
 // The 256-thread form keeps one live wave and three idle ones per workgroup there, 33 KB of LDS each: three live waves per compute unit
 // for a kernel whose whole job is to stream K / V; this form has no stage memory, no barriers that matter, ~16 waves per compute unit.
-template <int MODE, bool PRE, bool TBL = false, bool DIR = false>
-__global__ __launch_bounds__(DIR ? 64 : 256, 3) void attention_bf16x6_kernel(
+#ifndef ATT_NW
+#define ATT_NW 4
+#endif
+#ifndef ATT_NW_OCC
+#define ATT_NW_OCC 4
+#endif
+template <int MODE, bool PRE, bool TBL = false, bool DIR = false, int NW = 4>
+__global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? ATT_NW_OCC : 3)) void attention_bf16x6_kernel(
     const float* __restrict__ Qb_, int ldq, const float* __restrict__ K, const float* __restrict__ V, int ldkv,
     float* __restrict__ Ob_, int ldo, const unsigned char* __restrict__ key_pad_, float scale_log2e, int variant, AttnBatch ab) {
   const unsigned long long t_start = ab.cprof ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -153,9 +159,10 @@ __global__ __launch_bounds__(DIR ? 64 : 256, 3) void attention_bf16x6_kernel(
   static_assert(!DIR || PRE, "the streaming form reads pre-split images");
   constexpr int PADSZ = 2 * KT6 + 8;             // 16-bit elements of a stage's key-padding bias block
   constexpr int BUF_ = DIR ? PADSZ : BUF, NBUF_ = NBUF;
-  constexpr int ARENA = DIR ? 2 * PADSZ + 32 * 33 * 2 : NBUF_ * BUF_;     // DIR: two bias blocks, then the 32 x 33 floats of the output transpose
-  __shared__ int blk_tmax[4];
-  static_assert(DIR || 2 * BUF * 2 >= 4 * 32 * 33 * 4, "output transpose must fit");
+  static_assert(NW == 4 || (PRE && !DIR), "more than four waves per workgroup: staged pre-split images only");
+  constexpr int ARENA_T = NW * 32 * 33 * 2;                               // 16-bit elements of the output transpose (NW x 32 x 33 floats)
+  constexpr int ARENA = DIR ? 2 * PADSZ + 32 * 33 * 2 : (NBUF_ * BUF_ > ARENA_T ? NBUF_ * BUF_ : ARENA_T);     // DIR: two bias blocks, then the 32 x 33 floats of the output transpose
+  __shared__ int blk_tmax[NW];
 
   // XCD-aware work map: workgroups are dealt round-robin to the 8 XCDs (linear id % 8) and each XCD has its own L2, so all
   // query blocks of one (context, head) — which re-read the same K/V tiles — are given to ONE XCD: head = linear id % 8.
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(DIR ? 64 : 256, 3) void attention_bf16x6_kernel(
   const int h = lin & (NHEAD - 1), j = lin >> 3;
   const int qx = j % nqb, b = j / nqb;
   const int qblk = (MODE == MODE6_CAUSAL) ? (nqb - 1 - qx) : qx;
-  const int qb = qblk * (DIR ? 32 : 128);
+  const int qb = qblk * (DIR ? 32 : 32 * NW);
   const int tid = threadIdx.x, wave = DIR ? 0 : tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int A3 = 3 * A;
   const float NEG_INF = -__builtin_inff();
@@ -178,15 +185,15 @@ __global__ __launch_bounds__(DIR ? 64 : 256, 3) void attention_bf16x6_kernel(
     if (DIR) return;
     const op_t* src = img + (size_t)tile * KV_IMG + tid * 8;
 #pragma unroll
-    for (int i = 0; i < KV_PIECES; ++i) {
-      op_t* dst = arena + buf * BUF_ + (wave * 64 + 256 * i) * 8;          // wave-uniform LDS base (+ 16 B per lane)
+    for (int i = 0; i < KV_PIECES * 4 / NW; ++i) {
+      op_t* dst = arena + buf * BUF_ + (wave * 64 + 64 * NW * i) * 8;      // wave-uniform LDS base (+ 16 B per lane)
       // Issued as inline asm on purpose: hipcc answers the builtin with `s_waitcnt vmcnt(0)` in front of the NEXT ds_read
       // of any LDS address (it cannot tell the two stage buffers apart), i.e. every wave sat out the whole L2 / HBM
       // latency of the tile it had just requested before touching the tile it already had.  The compiler does not see
       // this load; the wave waits for its own pieces explicitly right before the end-of-tile barrier (dma_wait).
       const unsigned lds_addr = (unsigned)(size_t)((__attribute__((address_space(3))) op_t*)dst);
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off ; KV-DMA"
-                   :: "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(src + 256 * 8 * i) : "memory");
+                   :: "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(src + 64 * NW * 8 * i) : "memory");
     }
   };
   if (PRE) dma_tile(0, 0);
@@ -241,13 +248,17 @@ __global__ __launch_bounds__(DIR ? 64 : 256, 3) void attention_bf16x6_kernel(
     tq_max_w = __builtin_amdgcn_readfirstlane(tmax);
     if (lane == 0) blk_tmax[wave] = tmax;
     __syncthreads();
-    const int bt = DIR ? tq_max_w : max(max(blk_tmax[0], blk_tmax[1]), max(blk_tmax[2], blk_tmax[3]));
+    int bt = tq_max_w;
+    if (!DIR) {
+#pragma unroll
+      for (int k = 0; k < NW; ++k) bt = max(bt, blk_tmax[k]);
+    }
     k_end = __builtin_amdgcn_readfirstlane(min(Lk, (bt + 1) * A3));
     rep_need = __builtin_amdgcn_readfirstlane(min(rep_keys, (bt + 1) * 3));
   }
 
   // TBL: this wave's query group in the class's mask table; does the wave hold representative queries (wave-uniform)
-  const int qgrp = __builtin_amdgcn_readfirstlane(DIR ? qblk : qblk * 4 + wave), nsub_tbl = 2 * (int)kv_batch_stride;
+  const int qgrp = __builtin_amdgcn_readfirstlane(DIR ? qblk : qblk * NW + wave), nsub_tbl = 2 * (int)kv_batch_stride;
   const bool wave_rep_q = TBL && rep_keys > 0 && __builtin_amdgcn_readfirstlane(qb + wave * 32 + 31) >= rep_pos0;
 
   f32x16 oa;                                       // O^T accumulator
@@ -893,7 +904,7 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
       return CTRLSIM_EINVAL;
     if (c.rep_keys > 0 && (mode != MODE6_CAUSAL || variant || c.rep_mult < 1 || c.Lk % (3 * c.A) || c.rep_pos0 % (3 * c.A)))
       return CTRLSIM_EINVAL;
-    const int qblocks = dir ? (c.Lq + 31) / 32 : (c.Lq + 127) / 128;
+    const int qblocks = dir ? (c.Lq + 31) / 32 : (c.Lq + 32 * ATT_NW - 1) / (32 * ATT_NW);
     // mask-table kernel: every class brings its table, the query rows are the token rows, CtRL-Sim mask, keys = the whole row layout
     use_tbl = use_tbl && c.mask_tbl && !c.q_pos && (c.rep_keys == 0 || c.rep_pos0 == c.Lk);
     ab.c[ab.n++] = AttnClass{c.q_row0 * ldq, c.o_row0 * ldo, c.img_tile0, c.pad_off, c.q_bs, c.o_bs, (long)c.nkt, c.q_pos,
@@ -904,7 +915,7 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
     bytes += (double)c.B * (8.0 * DM * c.Lq + 4.0 * NPL * DM * (c.Lk + c.rep_keys));   // Q in + O out (fp32), K and V images (NPL planes)
   }
   if (ab.n == 0) return CTRLSIM_OK;
-  dim3 g(wg), blk(dir ? 64 : 256);
+  dim3 g(wg), blk(dir ? 64 : 64 * ATT_NW);
   const float scale = 0.17677669529663687f * 1.4426950408889634f;
   const float* imgf = static_cast<const float*>(img);
   prof_before(PROF_ATTN, st);
@@ -918,13 +929,13 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
     hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, true, false, true>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad,
                        scale, 0, ab);
   } else if (mode == MODE6_CAUSAL && use_tbl) {
-    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, true, true>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale,
+    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, true, true, false, ATT_NW>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale,
                        variant, ab);
   } else if (mode == MODE6_CAUSAL) {
-    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, true>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale,
+    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, true, false, false, ATT_NW>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale,
                        variant, ab);
   } else {
-    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, true>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale, 0,
+    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, true, false, false, ATT_NW>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale, 0,
                        ab);
   }
   prof_after(PROF_ATTN, flops, st, bytes, mode == MODE6_CAUSAL ? PKIND_ATTN_CAUSAL : PKIND_ATTN_KEYPAD);
