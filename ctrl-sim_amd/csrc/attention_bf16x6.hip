@@ -120,14 +120,15 @@ __global__ __launch_bounds__(256) void attn_mask_table_kernel(TblBatch tb) {
 // layout IS the fragment layout (a lane's 16 / 8 bytes are contiguous), so a tile that a single wave uses once has no business in LDS.
 // The 256-thread form keeps one live wave and three idle ones per workgroup there, 33 KB of LDS each: three live waves per compute unit
 // for a kernel whose whole job is to stream K / V; this form has no stage memory, no barriers that matter, ~16 waves per compute unit.
-#ifndef ATT_NW
-#define ATT_NW 4
-#endif
-#ifndef ATT_NW_OCC
-#define ATT_NW_OCC 4
-#endif
+// NW = waves (32-query groups) per workgroup of the staged form.  The two full-row kernels of the rollout — causal with mask tables, key-padded
+// — run 8 waves per workgroup at SIX waves per SIMD (80 VGPRs; three workgroups of 33.8 KB per CU): the kernel is latency-bound per wave
+// (profiles/r05_c_pmc_attention.md: no pipe above 40 %, 3.35 waves resident per SIMD with 4 x 4), and 8-wave workgroups are what lets the LDS
+// hold 24 waves per CU.  Round 5, sustained: L = 2304 2.52 -> 2.37 ms, A' = 8 1.21 -> 1.11 ms, cross 0.576 -> 0.541 ms; rollout +1.0 %
+// (causal launches 2.215 -> 2.144 ms, key-padded 0.614 -> 0.594 ms).  The in-kernel-mask causal kernel (baselines, few-row non-streaming
+// launches) keeps 4 waves per workgroup: at 80 registers it spills.
+constexpr int ATT_NW_FULL = 8;
 template <int MODE, bool PRE, bool TBL = false, bool DIR = false, int NW = 4>
-__global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? ATT_NW_OCC : 3)) void attention_bf16x6_kernel(
+__global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) void attention_bf16x6_kernel(
     const float* __restrict__ Qb_, int ldq, const float* __restrict__ K, const float* __restrict__ V, int ldkv,
     float* __restrict__ Ob_, int ldo, const unsigned char* __restrict__ key_pad_, float scale_log2e, int variant, AttnBatch ab) {
   const unsigned long long t_start = ab.cprof ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -893,8 +894,15 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
   // (option value 2, an experiment: EVERY launch in the streaming form — each 32-query wave then re-reads its K / V range from L2)
   bool dir = ctrlsim_option(OPT_ATTN_DIRECT) != 0;
   const bool dir_all = ctrlsim_option(OPT_ATTN_DIRECT) == 2;
-  for (int k = 0; k < n; ++k)
-    if (cls[k].B > 0 && cls[k].Lq > 96 && !dir_all) dir = false;
+  for (int k = 0; k < n; ++k) {
+    const AttnClassHost& c = cls[k];
+    if (c.B <= 0 || c.Lq <= 0) continue;
+    if (c.Lq > 96 && !dir_all) dir = false;
+    // mask-table kernel: every class brings its table, the query rows are the token rows, CtRL-Sim mask, keys = the whole row layout
+    use_tbl = use_tbl && c.mask_tbl && !c.q_pos && (c.rep_keys == 0 || c.rep_pos0 == c.Lk);
+  }
+  // waves per workgroup of the staged form: 8 for the two full-row kernels (see ATT_NW_FULL), 4 for the in-kernel-mask causal kernel
+  const int nw = (mode == MODE6_KEYPAD || use_tbl) ? ATT_NW_FULL : 4;
   for (int k = 0; k < n; ++k) {
     AttnClassHost c = cls[k];
     if (c.B <= 0 || c.Lq <= 0) continue;
@@ -904,9 +912,7 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
       return CTRLSIM_EINVAL;
     if (c.rep_keys > 0 && (mode != MODE6_CAUSAL || variant || c.rep_mult < 1 || c.Lk % (3 * c.A) || c.rep_pos0 % (3 * c.A)))
       return CTRLSIM_EINVAL;
-    const int qblocks = dir ? (c.Lq + 31) / 32 : (c.Lq + 32 * ATT_NW - 1) / (32 * ATT_NW);
-    // mask-table kernel: every class brings its table, the query rows are the token rows, CtRL-Sim mask, keys = the whole row layout
-    use_tbl = use_tbl && c.mask_tbl && !c.q_pos && (c.rep_keys == 0 || c.rep_pos0 == c.Lk);
+    const int qblocks = dir ? (c.Lq + 31) / 32 : (c.Lq + 32 * nw - 1) / (32 * nw);
     ab.c[ab.n++] = AttnClass{c.q_row0 * ldq, c.o_row0 * ldo, c.img_tile0, c.pad_off, c.q_bs, c.o_bs, (long)c.nkt, c.q_pos,
                              static_cast<const unsigned long long*>(c.mask_tbl), c.Lq, c.Lk, c.A, c.rep_keys, c.rep_pos0, qblocks, wg,
                              c.rep_keys > 0 ? log2f((float)c.rep_mult) : 0.f};
@@ -915,7 +921,7 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
     bytes += (double)c.B * (8.0 * DM * c.Lq + 4.0 * NPL * DM * (c.Lk + c.rep_keys));   // Q in + O out (fp32), K and V images (NPL planes)
   }
   if (ab.n == 0) return CTRLSIM_OK;
-  dim3 g(wg), blk(dir ? 64 : 64 * ATT_NW);
+  dim3 g(wg), blk(dir ? 64 : 64 * nw);
   const float scale = 0.17677669529663687f * 1.4426950408889634f;
   const float* imgf = static_cast<const float*>(img);
   prof_before(PROF_ATTN, st);
@@ -929,13 +935,13 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
     hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, true, false, true>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad,
                        scale, 0, ab);
   } else if (mode == MODE6_CAUSAL && use_tbl) {
-    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, true, true, false, ATT_NW>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale,
+    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, true, true, false, ATT_NW_FULL>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale,
                        variant, ab);
   } else if (mode == MODE6_CAUSAL) {
-    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, true, false, false, ATT_NW>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale,
+    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, true>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale,
                        variant, ab);
   } else {
-    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, true, false, false, ATT_NW>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale, 0,
+    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, true, false, false, ATT_NW_FULL>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale, 0,
                        ab);
   }
   prof_after(PROF_ATTN, flops, st, bytes, mode == MODE6_CAUSAL ? PKIND_ATTN_CAUSAL : PKIND_ATTN_KEYPAD);

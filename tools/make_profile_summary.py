@@ -138,40 +138,19 @@ def main():
     except OSError:
         pass
 
-    d = json.load(open(f"gpurun_out/pmc_{R}/summary.json"))
-    pb = None
-    for ln in open(f"gpurun_out/pmc_{R}/FETCH_SIZE.log"):
-        if ln.startswith("{") and '"roofline"' in ln:
-            pb = json.loads(ln)
-    pr = pb["roofline"]; po = pr["other"]
-    if "attention" in pr["kernel"]:
-        pr, po = po, pr
-    out = {}
-    for name, keys, br in (("gemm_nt_bf16x6_kernel", GEMM_KEYS, pr), ("attention_bf16x6_kernel", ATTN_KEYS, po)):
-        n = f = w = 0
-        for k, v in d.items():
-            if any(x in k for x in keys):
-                n += v["launches"]; f += v.get("FETCH_SIZE_raw_sum", 0); w += v.get("WRITE_SIZE_raw_sum", 0)
-        # the PMC passes see every launch of the command (warm-up included); bench.py's algorithmic bytes cover the timed launches —
-        # both are per-launch means over the same kernels at the same shapes
-        sd = br.get("side_stream") or {}
-        alg = (br["algorithmic_hbm_bytes_per_launch"] * br["launches"] + sd.get("algorithmic_hbm_bytes_total", 0.0)) / \
-              (br["launches"] + sd.get("launches", 0))            # every launch of the class, main and side streams, as the counters see them
-        out[name] = {"launches": n, "fetch_bytes_per_launch": f * 1024 / n, "write_bytes_per_launch": w * 1024 / n,
-                     "hbm_bytes_per_launch": (f + w) * 1024 / n, "algorithmic_bytes_per_launch_same_run": alg,
-                     "hbm_over_algorithmic": (f + w) * 1024 / n / alg}
-    out["_command"] = open(f"gpurun_out/pmc_{R}/command.txt").read().strip()
-    out["_how"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (no tracing flags) over the command above "
-                   "(tools/pmc_traffic.sh; the Linear class = inproj_rs_kernel / gemm_ws256_kernel / gemm_nt_bf16x6_kernel variants + ffn_fused_bf16x6_kernel); counter units of "
-                   "1024 B; calibrated in round 1 on micro-launches with known byte counts (FFN-1 shape 147456x1024x256: WRITE_SIZE = 603,979,776 B = "
-                   "M*N*4 exactly; FETCH_SIZE = 156.5 MB vs 151.0 MB of A + 1.6 MB of weight planes) => factor 1.0 for these kernels' access "
-                   "patterns (64-byte row segments / 16-byte DMA pieces); the guide's x2 applies to 128-byte wide streaming reads and would "
-                   "double-count here.  The PMC run is a smaller batch than the driver's bench (counter passes serialise the kernels), so "
-                   "bench.py reports roofline.traffic = hbm_over_algorithmic x ITS OWN algorithmic bytes per launch (same kernels, same "
-                   "shapes per context, different launch sizes) and keeps the raw numbers of this file next to it")
+    # per-kernel HBM traffic (round 5 format: tools/pmc_traffic_summary.py already wrote it, one counter convention for every file)
+    out = json.load(open(f"gpurun_out/pmc_{R}/summary.json"))
+    out["_command"] = open(f"gpurun_out/pmc_{R}/command.txt").read().strip() + \
+        "  (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, no tracing flags: tools/pmc_traffic.sh; algorithmic bytes from the " \
+        "same run's own JSON line, roofline.kernel_bytes_all_streams; the PMC run is a smaller batch than the driver's bench — counter passes " \
+        "serialise the kernels — so bench.py applies each kernel's measured / algorithmic ratio to ITS OWN algorithmic bytes)"
+    for k in list(out.get("by_kernel_name", {})):
+        e = out["by_kernel_name"][k]
+        if e["kind"] is None and e["hbm_bytes_per_launch"] < 1e6:
+            del out["by_kernel_name"][k]
     json.dump(out, open(f"profiles/{R}_pmc_traffic.json", "w"), indent=1)
     print("\n".join(lines[-22:]))
-    print(json.dumps({k: v for k, v in out.items() if not k.startswith("_")}, indent=1))
+    print(json.dumps({k: round(v.get("hbm_over_algorithmic", float("nan")), 3) for k, v in out["kernels"].items()}, indent=1))
 
 
 if __name__ == "__main__":
