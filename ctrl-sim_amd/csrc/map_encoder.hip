@@ -107,19 +107,30 @@ __global__ __launch_bounds__(256) void map_pool_kernel(int NP, int P, MapClasses
     for (int h = 0; h < 8; ++h) sc[tid][h] = s8[h];
   }
   __syncthreads();
-  // ---- softmax over the visible points of a polyline, per head
-  if (tid < 8 * g_here) {
-    const int g = tid >> 3, hd = tid & 7, a = q0[g], b = q0[g + 1];
+  // ---- softmax over the visible points of a polyline, per head.  One 16-lane DPP row per (polyline, head) pair — 16 pairs = the 256
+  // threads — each lane takes every 16th point; maximum and sum are row reductions (round 5: the loop ran on 16 LANES of one wave, three
+  // dependent passes over ~60 points with an LDS round trip each, while the other three waves sat at the barrier)
+  {
+    const int pair = tid >> 4, sub = tid & 15, g = pair >> 3, hd = pair & 7;
+    const int a = g < g_here ? q0[g] : 0, b = g < g_here ? q0[g + 1] : 0;
     float mx = -__builtin_inff();
-    for (int p = a; p < b; ++p) mx = fmaxf(mx, sc[p][hd]);
+    for (int p = a + sub; p < b; p += 16) mx = fmaxf(mx, sc[p][hd]);
+    mx = fmaxf(mx, dpp_f32<0xB1>(mx));       // quad_perm [1,0,3,2]
+    mx = fmaxf(mx, dpp_f32<0x4E>(mx));       // quad_perm [2,3,0,1]
+    mx = fmaxf(mx, dpp_f32<0x141>(mx));      // row_half_mirror
+    mx = fmaxf(mx, dpp_f32<0x140>(mx));      // row_mirror: every lane of the row holds the row maximum
     float z = 0.f;
-    for (int p = a; p < b; ++p) {
+    for (int p = a + sub; p < b; p += 16) {
       const float ev = expf(sc[p][hd] - mx);
       sc[p][hd] = ev;
       z += ev;
     }
+    z += dpp_f32<0xB1>(z);
+    z += dpp_f32<0x4E>(z);
+    z += dpp_f32<0x141>(z);
+    z += dpp_f32<0x140>(z);
     const float inv = 1.0f / z;
-    for (int p = a; p < b; ++p) sc[p][hd] *= inv;
+    for (int p = a + sub; p < b; p += 16) sc[p][hd] *= inv;
   }
   __syncthreads();
   // ---- phase 2: thread = channel; pooled[g][h][c] = sum_pt a[pt,h] * h1[pt,c]
