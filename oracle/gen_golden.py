@@ -329,6 +329,29 @@ def gen_closed_loop_full():
 
 
 
+def gen_closed_loop_wide_trained():
+    """Round 5: a second scene of the HEADLINE shape (64 vehicles x 512 polylines, full model) rolled by the unmodified reference policy + real
+    FreeCar / Box2D, this time with TRAINED-LIKE weights (weights.generate_trained_like: sharp sampling distributions) and tilted RTG
+    sampling, 34 steps (two past the window slide): ~14 focal groups per step, 8 704 more sampled ids of the headline shape against the reference
+    itself, in the regime a trained checkpoint runs in."""
+    import time
+    steps = 34
+    cfg = spec.make_cfg(nocturne__steps=steps)
+    d = spec.Dims(cfg)
+    w = weights.generate_trained_like(d, 0)
+    seed0, idx, n_ag, n_pl, extent, seed, tilt = 0, 11, 64, 512, 100.0, 4, (5.0, -10.0, 10.0)
+    scn = scenarios.make_scenario(seed0, idx, n_agents=n_ag, n_polylines=n_pl, n_points=d.NP, extent=extent)
+    t0 = time.time()
+    r = ref_closed_loop(cfg, w, scn, steps, seed=seed, tilt=tilt)
+    print(f"{time.time() - t0:.0f} s; groups/step", r["n_groups"], "min race margin", r["margins"].min(),
+          "collisions", r["coll"].sum(0).sum(0), "distinct tokens", len(np.unique(r["tokens"])))
+    out = {}
+    for k in ("tokens", "rtg_cont", "states", "coll", "actions", "n_groups", "margins"):
+        out[f"a_{k}"] = r[k]
+    out["a_recipe"] = np.array([seed0, idx, n_ag, n_pl, extent, seed, *tilt, steps])
+    save("closed_loop_wide_trained", **out)
+
+
 def gen_closed_loop_wide():
     """The HEADLINE shape (BASELINE configs[2]) against the reference itself: ONE scene of 64 vehicles x 512 polylines (the bench's
     generator and extent), full model dims, unmodified reference policy + real FreeCar/Box2D for 36 steps — ~14 focal groups
@@ -1368,7 +1391,7 @@ def gen_dt_loop():
     save("dt_loop", **out)
 
 
-ALL = dict(model=gen_model, model_trained=gen_model_trained, closed_loop_trained=gen_closed_loop_trained, features=gen_features, sampling=gen_sampling, physics=gen_physics,
+ALL = dict(model=gen_model, model_trained=gen_model_trained, closed_loop_trained=gen_closed_loop_trained, closed_loop_wide_trained=gen_closed_loop_wide_trained, features=gen_features, sampling=gen_sampling, physics=gen_physics,
            collision=gen_collision, closed_loop=gen_closed_loop, closed_loop_full=gen_closed_loop_full, closed_loop_wide=gen_closed_loop_wide, metrics=gen_metrics, interesting=gen_interesting, preprocessed=gen_preprocessed, ingest_gt=gen_ingest_gt, state_dict=gen_state_dict, bicycle=gen_bicycle, contacts=gen_contacts,
            planner_adversary=gen_planner_adversary, ingest=gen_ingest,
            variants=gen_variants, dense_reward=gen_dense_reward, dt_loop=gen_dt_loop)

@@ -365,6 +365,33 @@ def test_headline_shape_closed_loop_matches_reference_fixture():
         assert np.array_equal(r["coll"][s], g["a_coll"])
 
 
+@pytest.mark.parametrize("split", ["f16x3", "bf16x6"])
+def test_headline_shape_closed_loop_at_trained_like_weights_matches_reference_fixture(split):
+    """Round 5: a second scene of BASELINE configs[2]'s shape against the REFERENCE ITSELF, at TRAINED-LIKE weights (tests/golden/
+    closed_loop_wide_trained.npz, oracle/gen_golden.py::gen_closed_loop_wide_trained): 64 vehicles x 512 polylines, full model, unmodified
+    reference policy + real FreeCar / Box2D, tilted RTG sampling, 34 steps (two past the window slide), sharp sampling distributions.  The
+    bench's engine defaults (16 size classes, two lanes, K/V-cached phase), both operand splits: groups, tokens, RTG bins, collision flags
+    identical, states within 1e-4 — 8 704 more sampled ids of the headline shape in the regime a trained checkpoint runs in."""
+    g = golden("closed_loop_wide_trained")
+    rc = g["a_recipe"]
+    steps = int(rc[9])
+    cfg = spec.make_cfg(nocturne__steps=steps)
+    d = spec.Dims(cfg)
+    scn = scenarios.make_scenario(int(rc[0]), int(rc[1]), n_agents=int(rc[2]), n_polylines=int(rc[3]), n_points=d.NP, extent=float(rc[4]))
+    assert scn.N == 64 and scn.road_points.shape[0] == 512 and steps > d.T + 1
+    eng = RolloutEngine(cfg, weights.generate_trained_like(d, 0), DEV, max_ctx=64, seed=int(rc[5]), tilt=tuple(rc[6:9]), lanes=2, split=split)
+    eng.load_scenarios([scn, scn], steps=steps)
+    r = eng.run(steps).results()
+    assert eng.scheme == (1 if split == "f16x3" else 0) and g["a_n_groups"].min() >= 10
+    for s in range(2):
+        assert np.array_equal(r["n_groups"][:, s], g["a_n_groups"])
+        bad = np.argwhere(r["tokens"][s] != g["a_tokens"])
+        assert len(bad) == 0, (split, s, bad[:5])
+        np.testing.assert_allclose(fo.undiscretize_rtgs(r["rtg_bins"][s], cfg.dataset.waymo), g["a_rtg_cont"], atol=1e-9)
+        np.testing.assert_allclose(r["states"][s], g["a_states"], atol=1e-4, rtol=0)
+        assert np.array_equal(r["coll"][s], g["a_coll"])
+
+
 def test_at_scale_token_agreement_between_the_split_and_the_f32_kernel_families():
     """Token agreement at the HEADLINE shape, at scale, teacher-forced (no divergence compounding): every step of a 40-step
     rollout of 24 scenes x 64 vehicles x 512 polylines (~340 contexts per step, 8 steps past the window slide) is sampled twice

@@ -341,6 +341,24 @@ def test_rollout_oracle_matches_reference_on_the_headline_shape():
         assert x["members"] == [int(v) for v in mem if v >= 0]
 
 
+def test_rollout_oracle_matches_reference_on_the_headline_shape_at_trained_like_weights():
+    """The oracle against tests/golden/closed_loop_wide_trained.npz (64 vehicles x 512 polylines, full model, trained-like weights, tilts;
+    the unmodified reference policy + real physics): the first 2 steps (the whole run is the GPU test's job)."""
+    g = golden("closed_loop_wide_trained")
+    rc = g["a_recipe"]
+    cfg = spec.make_cfg(nocturne__steps=int(rc[9]))
+    d = spec.Dims(cfg)
+    scn = scenarios.make_scenario(int(rc[0]), int(rc[1]), n_agents=int(rc[2]), n_polylines=int(rc[3]), n_points=d.NP, extent=float(rc[4]))
+    ro = rollout_oracle.RolloutOracle(cfg, weights.generate_trained_like(d, 0), tilt=tuple(rc[6:9]), seed=int(rc[5]))
+    K = 2
+    r = ro.run(scn, K, sim_libs.OracleSim)
+    assert np.array_equal(r["tokens"][:, :K], g["a_tokens"][:, :K])
+    assert np.array_equal(r["n_groups"][:K], g["a_n_groups"][:K])
+    np.testing.assert_allclose(fo.undiscretize_rtgs(r["rtg_bins"][:, :K], cfg.dataset.waymo), g["a_rtg_cont"][:, :K], atol=1e-9)
+    np.testing.assert_allclose(r["states"][:, :K + 1], g["a_states"][:, :K + 1], atol=1e-4, rtol=0)
+    assert np.array_equal(r["coll"][:, :K + 1], g["a_coll"][:, :K + 1])
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_rollout_oracle_matches_reference_planner_vs_adversary(tag):
     """Planner-vs-adversary driver (evaluators/planner_adversary_evaluator.py:497-546): two unmodified reference policies
