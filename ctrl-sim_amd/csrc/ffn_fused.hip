@@ -17,9 +17,18 @@
 //     issued two phases ahead; the 4 waves of a workgroup (128 rows) share them.  One barrier per phase (96 MFMA); per pair of phases with four slots.
 //   * epilogue: Y^T through LDS (the ring is free by then) to row-major, + b2 + x, LayerNorm, 16-byte stores.
 //
-// HBM traffic: x read twice (operand + residual, the second an L2 hit) and y written once = 2-3 KB per row, against
+// HBM traffic: x read twice (operand + residual) and y written once = 3 KB per row, against
 // 13 KB per row for Linear / Linear+LN kernels with the hidden tensor in HBM.  Weights (3 MB of planes per block) come
 // from L2.
+//
+// PRE (round 5, two-plane scheme): the post-LN block in FRONT of the feed-forward block — x <- LayerNorm(x + Wo . o + bo), the attention
+// out-projection with its residual and LayerNorm (decoder: multihead_attn.out_proj + norm2, encoder: self_attn.out_proj + norm1;
+// nn.TransformerDecoderLayer / EncoderLayer, modules/decoder.py:16-20, encoder.py:42-46) — runs as a LEADING product of the same kernel:
+// the wave's 32 rows of the attention output o are the first B operand, Wo streams through the ring as eight W1-shaped blocks into the Y
+// accumulators (8 x 48 MFMA), the LayerNorm runs in the accumulator layout (a lane holds 128 values of its row, the other 128 sit in lane ^ 32:
+// one v_permlane32_swap per statistic), its output is split IN PLACE into the X^T fragments — the accumulator-register order is the k-slot
+// order of a W1 image with bits 2 and 3 of k swapped (pack.py: ffn_planes_pre) — and stays in the accumulators as the residual of the
+// feed-forward block, so x is neither written nor re-read in between: 3 KB per row for both blocks instead of 6.
 #include "split.h"
 #include <type_traits>
 
@@ -46,8 +55,10 @@ constexpr size_t FF_RING_BYTES = (size_t)FF_RING * FF_BLK * sizeof(op_t) > (size
 // (Two independent accumulator chains per product were tried — a single dependent chain runs the matrix pipe at ~73 % with
 // one wave per SIMD — but at this register pressure hipcc answers with v_accvgpr_mov shuffles / spills and the result is
 // slower: profiles/r01_c_pmc_pipes.md.)
+struct FfnPre { const float* R; int ldr; const op_t* Wop; const float* bo; const float* g0; const float* be0; };   // PRE: residual rows, Wo blocks, bo, norm gain / bias
+template <bool PRE>
 __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
-    const float* X, int ldx, const op_t* __restrict__ W1p, const float* __restrict__ b1,   // X may alias Y: no restrict
+    const float* X, int ldx, FfnPre pa, const op_t* __restrict__ W1p, const float* __restrict__ b1,   // X may alias Y: no restrict (PRE: X = the attention output)
     const op_t* __restrict__ W2p, const float* __restrict__ b2, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* Y, int ldy, int M, int nhb, int* __restrict__ nonfinite) {
   extern __shared__ __attribute__((aligned(16))) op_t ring[];      // FF_RING blocks of 48 KB, then b1 (F floats)
@@ -55,10 +66,14 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int n_rb = (M + 127) / 128;
   for (int i = tid; i < nhb * 32; i += 256) b1s[i] = b1[i];          // global loads inside a phase would queue behind its DMA
+  static_assert(!PRE || FF_PAIR, "the leading product rides on the four-slot ring of the two-plane scheme");
+  float* pre_s = b1s + nhb * 32;                                     // PRE: bo, norm gain, norm bias, b2 (256 floats each)
+  if (PRE) { pre_s[tid] = pa.bo[tid]; pre_s[256 + tid] = pa.g0[tid]; pre_s[512 + tid] = pa.be0[tid]; pre_s[768 + tid] = b2[tid]; }
+  __syncthreads();
 
   // block i of the weight stream: W1 of hidden block i/2 (even i) or W2 of it (odd i); lives in ring slot i % FF_RING
   auto dma_block = [&](int i, int to_slot) {
-    const op_t* src = ((i & 1) ? W2p : W1p) + (size_t)(i >> 1) * FF_BLK + tid * 8;
+    const op_t* src = (PRE ? pa.Wop + (size_t)i * FF_BLK : ((i & 1) ? W2p : W1p) + (size_t)(i >> 1) * FF_BLK) + tid * 8;   // (called for blocks 0 and 1 only)
     op_t* dst = ring + to_slot * FF_BLK + wave * 64 * 8;            // wave-uniform LDS base (+ 16 B per lane)
 #pragma unroll
     for (int j = 0; j < FF_PIECES; ++j)
@@ -99,13 +114,120 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
       }
     }
     f32x16 yacc[8];
+    if (PRE) {
+      // the residual rows + bo go straight into the accumulators of the leading product, in the accumulator layout — lane (l31, half) holds, of
+      // row l31, the columns 32 ob + (r & 3) + 8 (r >> 2) + 4 half — and in the scale of the Wo planes
+      const float* rp = pa.R + (size_t)rowc * pa.ldr + 4 * half;
 #pragma unroll
-    for (int ob = 0; ob < 8; ++ob)
+      for (int ob = 0; ob < 8; ++ob)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) yacc[ob][r] = 0.f;
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 xr = *reinterpret_cast<const f32x4*>(rp + ob * 32 + 8 * g);
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(pre_s + ob * 32 + 8 * g + 4 * half);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) yacc[ob][4 * g + e] = (xr[e] + bb[e]) * WSCALE;
+        }
+    } else {
+#pragma unroll
+      for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yacc[ob][r] = 0.f;
+    }
     __syncthreads();                                                  // (vmcnt(0) + barrier) blocks 0 and 1 are in LDS
 
     int slot = 0;                                                     // ring slot of the block the current phase reads
+    // one product of the W1 shape: acc^T += Wblk . X^T with the 32 KB block in ring slot `slot_` (A fragments from LDS, fetched FFN_PF
+    // k-steps ahead of the MFMAs that consume them: one wave per SIMD, nothing else hides the LDS latency and hipcc does not hoist the
+    // reads by itself), B = the wave's X^T fragments; the pieces of a later block are requested between the MFMAs
+    auto product_w1 = [&](f32x16& acc, int slot_, const op_t* dsrc, op_t* ddst) {
+      // (opaque to the optimiser: the eight unrolled leading products otherwise get their 64-bit per-lane piece addresses hoisted out of the
+      // row-block loop — 128 registers of loop-invariant pointers, i.e. spills)
+      asm volatile("" : "+v"(dsrc));
+      const op_t* w1 = ring + slot_ * FF_BLK + (half * 32 + l31) * 8;   // [p][ks][half][row][8]
+      opx8 wf[4][NPL];
+      auto ld1 = [&](int ks, opx8 (&f)[NPL]) {
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) f[p] = *reinterpret_cast<const opx8*>(w1 + ((p * 16 + ks) * 2) * 32 * 8);
+      };
+      ld1(0, wf[0]);
+      ld1(1, wf[1]);
+      if (FFN_PF == 3) ld1(2, wf[2]);
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        if (ks + FFN_PF < 16) ld1(ks + FFN_PF, wf[(ks + FFN_PF) & 3]);
+        if (ks < FF_PIECES) dma_piece(dsrc, ddst, ks);
+        FFN_TERMS(acc, wf[ks & 3], xT[ks])
+      }
+    };
+    if (PRE) {
+      // ---------------- leading product: Y^T = Wo . O^T, eight W1-shaped blocks (two per barrier, like a hidden block's pair); the pair
+      // after the last one is the first hidden block's (W1, W2)
+#pragma unroll
+      for (int pi = 0; pi < 4; ++pi) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const op_t* dsrc = (pi < 3 ? pa.Wop + (size_t)(2 * (pi + 1) + s2) * FF_BLK : (s2 ? W2p : W1p)) + tid * 8;
+          op_t* ddst = ring + ((slot + 2) & 3) * FF_BLK + wave * 64 * 8;
+          product_w1(yacc[2 * pi + s2], slot, dsrc, ddst);
+          if (s2) phase_barrier(false);
+          slot = (slot + 1) & 3;
+        }
+      }
+      // ---------------- x <- LayerNorm(x + Wo o + bo) in the accumulator layout; the other half of a lane's row lives in lane ^ 32
+      float sum = 0.f;
+#pragma unroll
+      for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = yacc[ob][r] * WSCALE_INV;
+          yacc[ob][r] = v;
+          sum += v;
+        }
+      {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
+        sum = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+      }
+      const float mean = sum * (1.f / 256.f);
+      float sq = 0.f;
+#pragma unroll
+      for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float dv = yacc[ob][r] - mean; sq = fmaf(dv, dv, sq); }
+      {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sq), __float_as_uint(sq), false, false);
+        sq = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+      }
+      const float var = sq * (1.f / 256.f);
+      if (half == 0 && row < M && !(var <= 3.0e38f)) atomicAdd(nonfinite, 1);      // one count per row whose variance is not finite
+      const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+      for (int ob = 0; ob < 8; ++ob) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c0 = ob * 32 + 8 * g + 4 * half;
+          const f32x4 gg = *reinterpret_cast<const f32x4*>(pre_s + 256 + c0);
+          const f32x4 be = *reinterpret_cast<const f32x4*>(pre_s + 512 + c0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) yacc[ob][4 * g + e] = fmaf((yacc[ob][4 * g + e] - mean) * rstd, gg[e], be[e]);
+        }
+        // the LayerNorm output as the feed-forward block's B operand: k-step 2 ob + kk <- registers 8 kk .. 8 kk + 7 (W1 image with
+        // the matching k order), and — plus b2, in the scale of the W2 planes — as the initial value of its Y accumulators (the residual)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          float t8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) t8[j] = yacc[ob][8 * kk + j];
+          split_frag(t8, xT[2 * ob + kk]);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b2v = *reinterpret_cast<const f32x4*>(pre_s + 768 + ob * 32 + 8 * g + 4 * half);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) yacc[ob][4 * g + e] = (yacc[ob][4 * g + e] + b2v[e]) * WSCALE;
+        }
+        __builtin_amdgcn_sched_barrier(0);               // one out-block at a time: hipcc otherwise hoists all 96 LDS reads (spills)
+      }
+    }
     for (int hb = 0; hb < nhb; ++hb) {
       // ---------------- phase 2 hb: H^T = W1_blk . X^T (+ b1), block 2 hb in slot (2 hb) % FF_RING
       // the block two ahead goes to the slot read last phase.  Past the end of the stream the last block is fetched again
@@ -123,25 +245,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
           hacc[4 * g + 0] = bv[0] * WSCALE; hacc[4 * g + 1] = bv[1] * WSCALE; hacc[4 * g + 2] = bv[2] * WSCALE; hacc[4 * g + 3] = bv[3] * WSCALE;   // the W1 planes carry WSCALE
         }
       }
-      {
-        // fragments are fetched two k-steps ahead of the MFMAs that consume them (one wave per SIMD: nothing else hides
-        // the LDS latency; hipcc does not hoist the reads by itself)
-        const op_t* w1 = ring + slot * FF_BLK + (half * 32 + l31) * 8;   // [p][ks][half][row][8]
-        opx8 wf[4][NPL];
-        auto ld1 = [&](int ks, opx8 (&f)[NPL]) {
-#pragma unroll
-          for (int p = 0; p < NPL; ++p) f[p] = *reinterpret_cast<const opx8*>(w1 + ((p * 16 + ks) * 2) * 32 * 8);
-        };
-        ld1(0, wf[0]);
-        ld1(1, wf[1]);
-        if (FFN_PF == 3) ld1(2, wf[2]);
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          if (ks + FFN_PF < 16) ld1(ks + FFN_PF, wf[(ks + FFN_PF) & 3]);
-          if (ks < FF_PIECES) dma_piece(dsrc_a, ddst_a, ks);
-          FFN_TERMS(hacc, wf[ks & 3], xT[ks])
-        }
-      }
+      product_w1(hacc, slot, dsrc_a, ddst_a);
       // ReLU + split: k-step kk of the second product uses accumulator registers 8 kk .. 8 kk + 7
       opx8 hf[2][NPL];
       {
@@ -192,7 +296,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
 #pragma unroll
     for (int rr = 0; rr < 32; ++rr) {
       const int grow = rb * 128 + wave * 32 + rr;
-      xpre[rr] = grow < M ? *reinterpret_cast<const f32x4*>(X + (size_t)grow * ldx + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      xpre[rr] = (!PRE && grow < M) ? *reinterpret_cast<const f32x4*>(X + (size_t)grow * ldx + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int ob = 0; ob < 8; ++ob)
@@ -210,8 +314,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
         const int grow = rb * 128 + wave * 32 + rr;
         if (grow >= M) break;
         f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * FF_CP + col);
-        v += bb;
-        v += xpre[rr];
+        if (!PRE) { v += bb; v += xpre[rr]; }               // PRE: b2 and the residual are in the accumulators already
         const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
         const f32x4 dv = v - mean;
         const float var = wave_sum(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2] + dv[3] * dv[3]) * (1.f / 256.f);
@@ -237,15 +340,46 @@ int launch_ffn_fused_bf16x6(const float* X, int ldx, const void* W1p, const floa
   const int grid = n_rb < 256 ? n_rb : 256;                           // one persistent workgroup per CU
   const size_t shm = FF_RING_BYTES + (size_t)F * sizeof(float);
   // once per process (thread-safe static initialisation), sized for the largest F this launcher accepts
-  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_bf16x6_kernel),
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_bf16x6_kernel<false>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                                   (int)(FF_RING_BYTES + 4096 * sizeof(float))) == hipSuccess;
   if (!attr_ok) return CTRLSIM_EINVAL;
   prof_before(PROF_GEMM, st);
-  hipLaunchKernelGGL(ffn_fused_bf16x6_kernel, dim3(grid), dim3(256), shm, st, X, ldx, static_cast<const op_t*>(W1p), b1,
+  hipLaunchKernelGGL(ffn_fused_bf16x6_kernel<false>, dim3(grid), dim3(256), shm, st, X, ldx, FfnPre{}, static_cast<const op_t*>(W1p), b1,
                      static_cast<const op_t*>(W2p), b2, gamma, beta, Y, ldy, M, F / 32, ctrlsim_nonfinite_ptr());
   prof_after(PROF_GEMM, 4.0 * (double)M * DM * (double)F, st, 12.0 * (double)M * DM + 4.0 * NPL * (double)DM * F, PKIND_FFN);   // x read as operand and as residual, y written; W1 / W2 as NPL planes
   return ctrlsim_launch_status();
+}
+
+// y = LayerNorm3(x1 + W2 relu(W1 x1 + b1) + b2) with x1 = LayerNorm0(R + Wo O + bo): the attention out-projection + residual + LayerNorm
+// and the feed-forward block behind it as ONE kernel (PRE above).  O = the attention output rows, R = the residual rows (y may alias R or O);
+// Wop = pack.py:row_blocks(Wo) (eight 32-column blocks), W1q / W2p = pack.py:ffn_planes_pre.  Two-plane scheme only (CTRLSIM_EINVAL otherwise).
+int launch_ffn_fused_pre(const float* O, int ldo, const float* R, int ldr, const void* Wop, const float* bo, const float* g0,
+                         const float* be0, const void* W1q, const float* b1, const void* W2p, const float* b2, const float* gamma,
+                         const float* beta, float* Y, int ldy, int M, int F, hipStream_t st) {
+  if (M <= 0) return CTRLSIM_OK;
+  if (!O || !R || !Wop || !bo || !g0 || !be0 || !W1q || !W2p || !b1 || !b2 || !gamma || !beta || !Y || (ldo & 3) || (ldr & 3) || (ldy & 3) ||
+      F <= 0 || (F & 31) || F > 3072)
+    return CTRLSIM_EINVAL;
+  if constexpr (!FF_PAIR) {
+    return CTRLSIM_EINVAL;
+  } else {
+    const int n_rb = (M + 127) / 128;
+    const int grid = n_rb < 256 ? n_rb : 256;
+    const size_t shm = FF_RING_BYTES + (size_t)(F + 1024) * sizeof(float);
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_bf16x6_kernel<true>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    (int)(FF_RING_BYTES + (3072 + 1024) * sizeof(float))) == hipSuccess;
+    if (!attr_ok) return CTRLSIM_EINVAL;
+    prof_before(PROF_GEMM, st);
+    hipLaunchKernelGGL(ffn_fused_bf16x6_kernel<true>, dim3(grid), dim3(256), shm, st, O, ldo,
+                       FfnPre{R, ldr, static_cast<const op_t*>(Wop), bo, g0, be0}, static_cast<const op_t*>(W1q), b1,
+                       static_cast<const op_t*>(W2p), b2, gamma, beta, Y, ldy, M, F / 32, ctrlsim_nonfinite_ptr());
+    // attention output and residual rows in, y out; Wo + W1 + W2 as NPL planes
+    prof_after(PROF_GEMM, 4.0 * (double)M * DM * (double)F + 2.0 * (double)M * DM * DM, st,
+               12.0 * (double)M * DM + 2.0 * NPL * (double)DM * DM + 4.0 * NPL * (double)DM * F, PKIND_FFN);
+    return ctrlsim_launch_status();
+  }
 }
 
 }  // namespace SPLIT_NS

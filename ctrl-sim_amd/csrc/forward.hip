@@ -35,6 +35,8 @@ int launch_gemm_nt_bf16x6_kv(const float*, int, const void*, int, int, const flo
 int launch_kv_zero_tail(int, int, int, int, void*, hipStream_t);
 int launch_kv_zero_tails(int, const KvTailHost*, void*, hipStream_t);
 int launch_kv_split_rows_classes(const float*, const float*, int, int, const KvRowsHost*, void*, hipStream_t);
+int launch_ffn_fused_pre(const float*, int, const float*, int, const void*, const float*, const float*, const float*, const void*, const float*,
+                         const void*, const float*, const float*, const float*, float*, int, int, int, hipStream_t);
 int launch_ffn_fused_bf16x6(const float*, int, const void*, const float*, const void*, const float*, const float*, const float*,
                             float*, int, int, int, hipStream_t);
 int launch_kv_split(const float*, const float*, int, long, int, int, int, void*, hipStream_t);
@@ -77,7 +79,7 @@ struct Lin {
 };
 struct LNp { const float* g; const float* b; };
 struct Mlp { Lin l0; LNp ln; Lin l3; };
-struct FfnPlanes { const void *w1[2] = {nullptr, nullptr}, *w2[2] = {nullptr, nullptr}; };
+struct FfnPlanes { const void *w1[2] = {nullptr, nullptr}, *w2[2] = {nullptr, nullptr}, *wop = nullptr, *w1q = nullptr; };   // wop / w1q: pack.py:ffn_planes_pre
 struct EncLayer { Lin qkv, out, lin1, lin2; LNp n1, n2; FfnPlanes fp; };
 // sq / skv: the query rows / the key + value rows of the self-attention in_proj as Linears of their own (the last decoder layer of a full
 // pass projects keys and values of every token but queries of the A queried tokens only)
@@ -139,6 +141,7 @@ extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_w
     FfnPlanes f;
     f.w1[0] = PX(p + ".ffn#w1p#pl0"); f.w1[1] = PX(p + ".ffn#w1p#pl1");
     f.w2[0] = PX(p + ".ffn#w2p#pl0"); f.w2[1] = PX(p + ".ffn#w2p#pl1");
+    f.wop = PX(p + ".ffn#wop#pl1"); f.w1q = PX(p + ".ffn#w1q#pl1");
     return f;
   };
   auto lin = [&](const std::string& k) { return mk(P(k + ".weight"), P(k + ".bias"), k + ".weight", 0, 0); };
@@ -391,6 +394,17 @@ int ffn_block(const Lin& l1, const Lin& l2, const LNp& n, const FfnPlanes& fp, f
   return gemm_ln(l2, n, hidden, F, x, DM, x, DM, tmp, rows, F, 0, st);
 }
 
+// x <- FFN block( LayerNorm_o(x + att Wo^T + bo) ): the attention out-projection + residual + LayerNorm and the feed-forward block behind it —
+// ONE kernel where the two-plane scheme and the images of pack.py:ffn_planes_pre are there (option 3 = 2), the two kernels otherwise
+int outproj_ln_ffn(const Lin& lo, const LNp& no, const Lin& l1, const Lin& l2, const LNp& n, const FfnPlanes& fp, const float* att, float* x,
+                   float* hidden, float* tmp, int rows, int F, hipStream_t st) {
+  if (fp.wop && fp.w1q && fp.w2[1] && !(F & 31) && F <= 3072 && ctrlsim_option(OPT_SPLIT) && ctrlsim_option(OPT_FFN_FUSED) >= 2 &&
+      ctrlsim_option(OPT_GEMM_IMPL) == 1)
+    return launch_ffn_fused_pre(att, DM, x, DM, fp.wop, lo.b, no.g, no.b, fp.w1q, l1.b, fp.w2[1], l2.b, n.g, n.b, x, DM, rows, F, st);
+  CHK(gemm_ln(lo, no, att, DM, x, DM, x, DM, tmp, rows, DM, 0, st));
+  return ffn_block(l1, l2, n, fp, x, hidden, tmp, rows, F, st);
+}
+
 inline bool presplit() { return ctrlsim_option(OPT_ATTN_IMPL) == 1; }
 
 // What the queries / keys of an attention call are, per class
@@ -559,8 +573,7 @@ int cross_and_ffn(const ctrlsim_model* m, const Batch& bt, const DecLayer& Ld, i
   CHK(gemm(Ld.cq, x, DM, nullptr, 0, qc, DM, (int)rows, DM, DM, 0, st));
   CHK(attention(d, bt, w, AttnCall{0, q, qc, DM, w.memkv[layer], w.memkv[layer] + DM, 2 * DM, w.img_mem[layer], true, att, 0, 0,
                                    Rn_mul}, st));
-  CHK(gemm_ln(Ld.cout, Ld.n2, att, DM, x, DM, x, DM, tmp, (int)rows, DM, 0, st));
-  CHK(ffn_block(Ld.lin1, Ld.lin2, Ld.n3, Ld.fp, x, ffn, tmp, (int)rows, d.F, st));
+  CHK(outproj_ln_ffn(Ld.cout, Ld.n2, Ld.lin1, Ld.lin2, Ld.n3, Ld.fp, att, x, ffn, tmp, (int)rows, d.F, st));
   return 0;
 }
 // The engine carves the context tensors of a batch's classes out of shared buffers back to back (CtxBuffers.class_structs);
@@ -617,8 +630,7 @@ int scene_side(const ctrlsim_model* m, const Batch& bt, const Ws& w, float* dbg_
     CHK(gemm_kv(d, bt, w, Le.qkv, w.src, w.eqkv, 3 * DM, 3 * DM, DM, w.img_enc, true, st));
     CHK(attention(d, bt, w, AttnCall{0, Q_SCENE, w.eqkv, 3 * DM, w.eqkv + DM, w.eqkv + 2 * DM, 3 * DM, w.img_enc, true, w.eatt, 0, 0, 0},
                   st));
-    CHK(gemm_ln(Le.out, Le.n1, w.eatt, DM, w.src, DM, w.src, DM, w.etmp, rM, DM, 0, st));
-    CHK(ffn_block(Le.lin1, Le.lin2, Le.n2, Le.fp, w.src, w.effn, w.etmp, rM, d.F, st));
+    CHK(outproj_ln_ffn(Le.out, Le.n1, Le.lin1, Le.lin2, Le.n2, Le.fp, w.eatt, w.src, w.effn, w.etmp, rM, d.F, st));
   }
   // memory K/V of every decoder layer (cached for pass 2)
   for (int i = 0; i < d.ND; ++i) CHK(gemm_kv(d, bt, w, m->dec[i].ckv, w.src, w.memkv[i], 2 * DM, 2 * DM, 0, w.img_mem[i], true, st));

@@ -167,6 +167,19 @@ def ffn_planes(W1: np.ndarray, W2: np.ndarray, scheme=None):
     return w1p, w2p
 
 
+def ffn_planes_pre(Wo: np.ndarray, W1: np.ndarray, W2: np.ndarray, scheme=1):
+    """Operand images of the fused FFN kernel with the out-projection + LayerNorm in front of it as its leading product
+    (csrc/ffn_fused.hip, PRE): -> (Wop, W1q, W2p).  Wop = row_blocks(Wo): eight W1-shaped blocks of 32 output columns.  W1q = the W1
+    blocks with bits 2 and 3 of k swapped inside every 16-wide k-step — the kernel's first B operand is then the LayerNorm output in
+    ACCUMULATOR-register order: slot (half, e) of k-step ks holds k = 16 ks + 8 (e >> 2) + 4 half + (e & 3).  W2p as ffn_planes."""
+    W1 = np.asarray(W1, np.float32)
+    k = np.arange(W1.shape[1])
+    e, h, ks = k & 7, (k >> 3) & 1, k >> 4
+    perm = 16 * ks + 8 * (e >> 2) + 4 * h + (e & 3)          # W1q image column 16 ks + 8 h + e <- W1 column perm
+    w1q, w2p = ffn_planes(W1[:, perm], W2, scheme)
+    return row_blocks(np.asarray(Wo, np.float32), scheme), w1q, w2p
+
+
 def pack(dims: Dims, w: dict):
     """-> (flat float32 ndarray, names list, offsets int64 ndarray in floats)."""
     allw = dict(w)
@@ -195,6 +208,20 @@ def pack(dims: Dims, w: dict):
                     continue
                 allw[pre + ".ffn#w1p" + suffix] = w1p.reshape(-1).view(np.float32)
                 allw[pre + ".ffn#w2p" + suffix] = w2p.reshape(-1).view(np.float32)
+    # the out-projection + LayerNorm in front of a feed-forward block as its leading product (two-fp16-plane scheme): decoder layers
+    # multihead_attn.out_proj + norm2, encoder layers self_attn.out_proj + norm1
+    for k in list(w.keys()):
+        if k.endswith(".linear1.weight"):
+            pre = k[:-len(".linear1.weight")]
+            ok = pre + (".multihead_attn.out_proj.weight" if (pre + ".multihead_attn.out_proj.weight") in w else ".self_attn.out_proj.weight")
+            if ok in w and np.asarray(w[ok]).shape == (256, 256) and np.asarray(w[k]).shape[1] == 256:
+                try:
+                    wop, w1q, _ = ffn_planes_pre(np.asarray(w[ok], np.float32), np.asarray(w[k], np.float32),
+                                                 np.asarray(w[pre + ".linear2.weight"], np.float32), 1)
+                except FloatingPointError:
+                    continue
+                allw[pre + ".ffn#wop" + PLANES_SUFFIX[1]] = wop.reshape(-1).view(np.float32)
+                allw[pre + ".ffn#w1q" + PLANES_SUFFIX[1]] = w1q.reshape(-1).view(np.float32)
     # 32-column operand blocks of every attention in_proj (two-fp16-plane scheme: the row-stationary kernel)
     for k in list(w.keys()):
         if k.endswith("in_proj_weight") and np.asarray(w[k]).shape == (3 * 256, 256):

@@ -301,6 +301,14 @@ int ctrlsim_gemm_kv_blocks(const float* A, int lda, const void* Wblk, const floa
  * operand images of ctrlsim_amd/pack.py:ffn_planes; Y may alias X.  The hidden activation never touches memory. */
 int ctrlsim_ffn_fused(const float* X, int ldx, const void* W1p, const float* b1, const void* W2p, const float* b2,
                       const float* gamma, const float* beta, float* Y, int ldy, int M, int F, hipStream_t stream);
+/* The post-LN block in front of the feed-forward block fused into it (round 5, two-fp16-plane scheme only; CTRLSIM_EINVAL otherwise):
+ * X1 = LayerNorm0(R + Wo O + bo), Y = LayerNorm(X1 + W2 relu(W1 X1 + b1) + b2) — the attention out-projection with its residual and
+ * LayerNorm (nn.TransformerDecoderLayer: multihead_attn.out_proj + norm2; nn.TransformerEncoderLayer: self_attn.out_proj + norm1;
+ * modules/decoder.py:16-20, encoder.py:42-46) and the feed-forward block behind it as one kernel: X1 is neither written nor re-read.
+ * O = attention output rows, R = residual rows (Y may alias R or O), Wop / W1q / W2p = ctrlsim_amd/pack.py:ffn_planes_pre(Wo, W1, W2). */
+int ctrlsim_ffn_fused_pre(const float* O, int ldo, const float* R, int ldr, const void* Wop, const float* bo, const float* g0,
+                          const float* be0, const void* W1q, const float* b1, const void* W2p, const float* b2, const float* gamma,
+                          const float* beta, float* Y, int ldy, int M, int F, hipStream_t stream);
 int ctrlsim_layernorm256(const float* X, int ldx, const float* Radd, int ldr, const float* gamma, const float* beta,
                          float* Y, int ldy, int rows, int relu, hipStream_t stream);
 /* mode 0: key padding (key_pad [B,Lk], 1 = ignore); mode 1: CtRL-Sim structured causal mask (utils/train_utils.py:81-129) */
@@ -369,6 +377,8 @@ int ctrlsim_attn_class_prof(int enable, unsigned long long* host_out);
  * (v_mfma_f32_32x32x2_f32), 1 = split-operand 16-bit MFMA with fp32-class accuracy (default).  Key 2 = tile shape of the tiled
  * split-operand GEMM (0 auto; tuning).  Key 3 = fused feed-forward block (default 1).  Key 4 = operand split (1 two fp16 planes,
  * 0 three bf16 planes; per engine through ctrlsim_bind).  These are the PROCESS DEFAULTS; an engine overrides them with its own table (ctrlsim_bind_options).  Key 5 = reserved (rounds 2-3: a matrix-pipe variant of the map-encoder pooling, removed).
+ * Key 3 value 2 (default) = also the attention out-projection + residual + LayerNorm in front of a feed-forward block as its leading product
+ * (ctrlsim_ffn_fused_pre; two-plane scheme); 1 = the feed-forward block alone; 0 = separate Linear kernels.
  * Key 6 = weight-stationary kernel for the Linear(256 -> 256 G) shapes, bit mask: 1 = launches of at least two 32-row blocks per
  * compute unit, 2 = smaller launches, 4 = the in_proj Linears with K / V-image epilogue, 8 = those through the ROW-stationary kernel
  * (rows in registers, 32-column weight blocks streamed through LDS, every activation row read once; needs the block images of

@@ -616,6 +616,46 @@ def test_ffn_fused_block(M, F):
     assert torch.equal(Z, Y)
 
 
+@pytest.mark.parametrize("M,F", [(128, 1024), (1000, 1024), (37, 64), (4133, 512), (40000, 1024)])
+def test_outproj_layernorm_ffn_as_one_kernel(M, F):
+    """The post-LN block in front of a feed-forward block fused into it (ctrlsim_ffn_fused_pre): x1 = LayerNorm0(R + O Wo^T + bo),
+    y = LayerNorm(x1 + W2 relu(W1 x1 + b1) + b2) — nn.TransformerDecoderLayer's multihead_attn.out_proj + norm2 + feed-forward + norm3 /
+    nn.TransformerEncoderLayer's self_attn.out_proj + norm1 + feed-forward + norm2 (modules/decoder.py:16-20, encoder.py:42-46) — against
+    torch in float64, out of place and with y aliasing the residual rows; and against the two-kernel route it replaces."""
+    from ctrlsim_amd.pack import ffn_planes_pre, ffn_planes, split3_planes
+    if _lib.lib().ctrlsim_get_option(0) != 1:
+        pytest.skip("two-fp16-plane scheme only")
+    g = torch.Generator().manual_seed(M + F + 1)
+    O = torch.randn(M, 256, generator=g).to(DEV)
+    R = (torch.randn(M, 256, generator=g) * torch.exp(0.5 * torch.randn(M, 1, generator=g))).to(DEV)
+    Wo = torch.randn(256, 256, generator=g) * 0.07
+    W1 = torch.randn(F, 256, generator=g) * 0.08
+    W2 = torch.randn(256, F, generator=g) * 0.05
+    bo, g0, be0 = (torch.randn(256, generator=g).to(DEV) * s for s in (0.3, 1.0, 0.2))
+    b1 = torch.randn(F, generator=g).to(DEV) * 0.3
+    b2 = torch.randn(256, generator=g).to(DEV) * 0.3
+    gam = torch.randn(256, generator=g).to(DEV); bet = torch.randn(256, generator=g).to(DEV)
+    wop, w1q, w2p = ffn_planes_pre(Wo.numpy(), W1.numpy(), W2.numpy(), 1)
+    dev = lambda a: torch.from_numpy(a.view(np.int16).copy()).to(DEV)
+    wod, w1d, w2d = dev(wop), dev(w1q), dev(w2p)
+    Y = torch.empty_like(R)
+    p = _lib.ptr
+    call = lambda Rr, Yy: _lib.check(_lib.lib().ctrlsim_ffn_fused_pre(p(O), 256, p(Rr), 256, p(wod), p(bo), p(g0), p(be0), p(w1d), p(b1), p(w2d),
+                                                                      p(b2), p(gam), p(bet), p(Yy), 256, M, F, _lib.stream_ptr()), "ffn_fused_pre")
+    call(R, Y)
+    x1 = torch.nn.functional.layer_norm(R.double() + O.double() @ Wo.to(DEV).double().T + bo.double(), (256,), g0.double(), be0.double(), 1e-5)
+    h = torch.relu(x1 @ W1.to(DEV).double().T + b1.double())
+    ref = torch.nn.functional.layer_norm(x1 + h @ W2.to(DEV).double().T + b2.double(), (256,), gam.double(), bet.double(), 1e-5)
+    err = (Y.double() - ref).abs().max().item()
+    print("out-proj + LN + ffn as one kernel: max abs err", err)
+    assert err < 5e-5
+    Z = R.clone()
+    call(Z, Z)
+    assert torch.equal(Z, Y)
+    assert _lib.lib().ctrlsim_ffn_fused_pre(p(O), 256, p(R), 256, p(wod), p(bo), p(g0), p(be0), p(w1d), p(b1), p(w2d), p(b2), p(gam), p(bet),
+                                            p(Y), 256, M, 3104, _lib.stream_ptr()) != 0          # beyond the LDS the bias tables fit in
+
+
 @pytest.mark.parametrize("B", [1, 3])
 def test_map_pool_matches_the_unfolded_front_end_in_float64(B):
     """map_pool_kernel (point MLP + single-seed attention pooling with every linear stage folded at pack time: csrc/map_encoder.hip) against
