@@ -65,6 +65,7 @@ SIGNATURES = {
     "ctrlsim_gemm_kv_blocks": (I, [P, I, P, P, P, I, I, I, P, I, I, I, P]),
     "ctrlsim_ffn_fused": (I, [P, I, P, P, P, P, P, P, P, I, I, I, P]),
     "ctrlsim_ffn_fused_pre": (I, [P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
+    "ctrlsim_outproj_ln_q": (I, [P, I, P, I, P, P, P, P, P, P, P, I, P, I, I, P]),
     "ctrlsim_layernorm256": (I, [P, I, P, I, P, P, P, I, I, I, P]),
     "ctrlsim_kv_split": (I, [P, P, I, L, P, I, I, I, P, P]),
     "ctrlsim_attention_presplit": (I, [I, P, I, L, P, I, P, I, L, P, P, I, I, I, I, P]),

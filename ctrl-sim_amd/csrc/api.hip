@@ -25,6 +25,8 @@ int launch_ffn_fused_bf16x6(const float*, int, const void*, const float*, const 
                             float*, int, int, int, hipStream_t);
 int launch_ffn_fused_pre(const float*, int, const float*, int, const void*, const float*, const float*, const float*, const void*, const float*,
                          const void*, const float*, const float*, const float*, float*, int, int, int, hipStream_t);
+int launch_outproj_ln_q(const float*, int, const float*, int, const void*, const float*, const float*, const float*, const void*, const float*,
+                        float*, int, float*, int, int, hipStream_t);
 int launch_sim_init(int, int, int, const float*, const float*, const float*, const unsigned char*, float*, float*,
                     unsigned char*, int, float*, hipStream_t);
 int launch_sim_set_position(int, int, const float*, float*, hipStream_t);
@@ -78,7 +80,7 @@ void prof_after(int cls, double flops, hipStream_t st, double bytes, int kind) {
   g_recs.push_back(ProfRec{g_pending[cls], b, cls, flops, bytes, st, 2 * kind + (g_prof_few ? 1 : 0)});
 }
 
-static int g_options[OPT_COUNT] = {1, 1, 0, 2, 1, 0, 15, 1, 1, 1};      // process defaults (ctrlsim_set_option)
+static int g_options[OPT_COUNT] = {1, 1, 0, 3, 1, 0, 15, 1, 1, 1};      // process defaults (ctrlsim_set_option)
 // the option table of the ENGINE that bound last (ctrlsim_bind_options): entry >= 0 overrides the process default, -1 inherits it
 static int g_bound_options[OPT_COUNT];
 static bool g_has_bound_options = false;
@@ -252,6 +254,10 @@ int ctrlsim_ffn_fused_pre(const float* O, int ldo, const float* R, int ldr, cons
                           const void* W1q, const float* b1, const void* W2p, const float* b2, const float* gamma, const float* beta, float* Y,
                           int ldy, int M, int F, hipStream_t st) {
   return launch_ffn_fused_pre(O, ldo, R, ldr, Wop, bo, g0, be0, W1q, b1, W2p, b2, gamma, beta, Y, ldy, M, F, st);
+}
+int ctrlsim_outproj_ln_q(const float* O, int ldo, const float* R, int ldr, const void* Wop, const float* bo, const float* g0, const float* be0,
+                         const void* Wqp, const float* bq, float* X1, int ldx1, float* Q, int ldq, int M, hipStream_t st) {
+  return launch_outproj_ln_q(O, ldo, R, ldr, Wop, bo, g0, be0, Wqp, bq, X1, ldx1, Q, ldq, M, st);
 }
 int ctrlsim_layernorm256(const float* X, int ldx, const float* Radd, int ldr, const float* gamma, const float* beta, float* Y,
                          int ldy, int rows, int relu, hipStream_t st) {

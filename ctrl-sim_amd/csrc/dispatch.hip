@@ -17,6 +17,8 @@
                        hipStream_t);                                                                                              \
   int launch_ffn_fused_bf16x6(const float*, int, const void*, const float*, const void*, const float*, const float*, const float*, \
                               float*, int, int, int, hipStream_t);                                                               \
+  int launch_outproj_ln_q(const float*, int, const float*, int, const void*, const float*, const float*, const float*, const void*,       \
+                          const float*, float*, int, float*, int, int, hipStream_t);                                                       \
   int launch_ffn_fused_pre(const float*, int, const float*, int, const void*, const float*, const float*, const float*, const void*,      \
                            const float*, const void*, const float*, const float*, const float*, float*, int, int, int, hipStream_t);     \
   int launch_attention_bf16x6(int, const float*, int, long, const float*, const float*, int, long, float*, int, long, const int*, \
@@ -57,6 +59,10 @@ int launch_gemm_nt_bf16x6_kvc(const float* A, int lda, const void* W3, int n_tot
 int launch_inproj_rs(const float* A, int lda, const void* Wblk, const float* bias, float* C, int ldc, int M, int N, void* img, int col0,
                      int n, const KvClassHost* cls, hipStream_t st) {
   return PICK(launch_inproj_rs(A, lda, Wblk, bias, C, ldc, M, N, img, col0, n, cls, st));
+}
+int launch_outproj_ln_q(const float* O, int ldo, const float* R, int ldr, const void* Wop, const float* bo, const float* g0, const float* be0,
+                        const void* Wqp, const float* bq, float* X1, int ldx1, float* Q, int ldq, int M, hipStream_t st) {
+  return PICK(launch_outproj_ln_q(O, ldo, R, ldr, Wop, bo, g0, be0, Wqp, bq, X1, ldx1, Q, ldq, M, st));
 }
 int launch_ffn_fused_pre(const float* O, int ldo, const float* R, int ldr, const void* Wop, const float* bo, const float* g0, const float* be0,
                          const void* W1q, const float* b1, const void* W2p, const float* b2, const float* g, const float* b, float* Y, int ldy,

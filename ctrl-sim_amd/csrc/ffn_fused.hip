@@ -55,16 +55,24 @@ constexpr size_t FF_RING_BYTES = (size_t)FF_RING * FF_BLK * sizeof(op_t) > (size
 // (Two independent accumulator chains per product were tried — a single dependent chain runs the matrix pipe at ~73 % with
 // one wave per SIMD — but at this register pressure hipcc answers with v_accvgpr_mov shuffles / spills and the result is
 // slower: profiles/r01_c_pmc_pipes.md.)
-struct FfnPre { const float* R; int ldr; const op_t* Wop; const float* bo; const float* g0; const float* be0; };   // PRE: residual rows, Wo blocks, bo, norm gain / bias
-template <bool PRE>
+struct FfnPre {                      // PRE: residual rows, Wo blocks, bo, norm gain / bias; QP: where the LayerNorm output rows go
+  const float* R; int ldr; const op_t* Wop; const float* bo; const float* g0; const float* be0; float* X1; int ldx1;
+};
+// MODE 0 = the feed-forward block; 1 = PRE: out-projection + residual + LayerNorm in front of it; 2 = QP: that leading block followed by ONE
+// 256 -> 256 Linear instead of the feed-forward block (the cross-attention query projection: x1 and q leave, W1p = the eight blocks of Wq)
+template <int MODE>
 __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
     const float* X, int ldx, FfnPre pa, const op_t* __restrict__ W1p, const float* __restrict__ b1,   // X may alias Y: no restrict (PRE: X = the attention output)
     const op_t* __restrict__ W2p, const float* __restrict__ b2, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* Y, int ldy, int M, int nhb, int* __restrict__ nonfinite) {
+  constexpr bool PRE = MODE != 0, QP = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) op_t ring[];      // FF_RING blocks of 48 KB, then b1 (F floats)
   float* b1s = reinterpret_cast<float*>(reinterpret_cast<char*>(ring) + FF_RING_BYTES);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int n_rb = (M + 127) / 128;
+  // PRE / QP: the wave index as a scalar — the LDS-DMA destinations of the unrolled leading products (slot and piece are compile-time
+  // constants there) are then scalar arithmetic instead of 32 loop-invariant vector registers
+  const int wave_d = PRE ? __builtin_amdgcn_readfirstlane(wave) : wave;
   for (int i = tid; i < nhb * 32; i += 256) b1s[i] = b1[i];          // global loads inside a phase would queue behind its DMA
   static_assert(!PRE || FF_PAIR, "the leading product rides on the four-slot ring of the two-plane scheme");
   float* pre_s = b1s + nhb * 32;                                     // PRE: bo, norm gain, norm bias, b2 (256 floats each)
@@ -74,7 +82,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
   // block i of the weight stream: W1 of hidden block i/2 (even i) or W2 of it (odd i); lives in ring slot i % FF_RING
   auto dma_block = [&](int i, int to_slot) {
     const op_t* src = (PRE ? pa.Wop + (size_t)i * FF_BLK : ((i & 1) ? W2p : W1p) + (size_t)(i >> 1) * FF_BLK) + tid * 8;   // (called for blocks 0 and 1 only)
-    op_t* dst = ring + to_slot * FF_BLK + wave * 64 * 8;            // wave-uniform LDS base (+ 16 B per lane)
+    op_t* dst = ring + to_slot * FF_BLK + wave_d * 64 * 8;            // wave-uniform LDS base (+ 16 B per lane)
 #pragma unroll
     for (int j = 0; j < FF_PIECES; ++j)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 256 * 8),
@@ -139,10 +147,12 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
     // one product of the W1 shape: acc^T += Wblk . X^T with the 32 KB block in ring slot `slot_` (A fragments from LDS, fetched FFN_PF
     // k-steps ahead of the MFMAs that consume them: one wave per SIMD, nothing else hides the LDS latency and hipcc does not hoist the
     // reads by itself), B = the wave's X^T fragments; the pieces of a later block are requested between the MFMAs
-    auto product_w1 = [&](f32x16& acc, int slot_, const op_t* dsrc, op_t* ddst) {
-      // (opaque to the optimiser: the eight unrolled leading products otherwise get their 64-bit per-lane piece addresses hoisted out of the
-      // row-block loop — 128 registers of loop-invariant pointers, i.e. spills)
+    auto product_w1 = [&](f32x16& acc, int slot_, const op_t* dsrc, op_t* ddst, bool dma = true, size_t dsrc_off = 0) {
+      // (opaque to the optimiser: the unrolled leading products otherwise get their 64-bit per-lane piece addresses hoisted out of the
+      // row-block loop — 128 registers of loop-invariant pointers, i.e. spills; the block offset is added BEHIND the opaque point, so
+      // that one per-lane base is all that can be kept across iterations)
       asm volatile("" : "+v"(dsrc));
+      dsrc += dsrc_off;
       const op_t* w1 = ring + slot_ * FF_BLK + (half * 32 + l31) * 8;   // [p][ks][half][row][8]
       opx8 wf[4][NPL];
       auto ld1 = [&](int ks, opx8 (&f)[NPL]) {
@@ -155,7 +165,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
         if (ks + FFN_PF < 16) ld1(ks + FFN_PF, wf[(ks + FFN_PF) & 3]);
-        if (ks < FF_PIECES) dma_piece(dsrc, ddst, ks);
+        if (dma && ks < FF_PIECES) dma_piece(dsrc, ddst, ks);
         FFN_TERMS(acc, wf[ks & 3], xT[ks])
       }
     };
@@ -166,9 +176,9 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
       for (int pi = 0; pi < 4; ++pi) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          const op_t* dsrc = (pi < 3 ? pa.Wop + (size_t)(2 * (pi + 1) + s2) * FF_BLK : (s2 ? W2p : W1p)) + tid * 8;
-          op_t* ddst = ring + ((slot + 2) & 3) * FF_BLK + wave * 64 * 8;
-          product_w1(yacc[2 * pi + s2], slot, dsrc, ddst);
+          const op_t* dsrc = (pi < 3 ? pa.Wop : (QP || !s2) ? W1p : W2p) + tid * 8;
+          op_t* ddst = ring + ((slot + 2) & 3) * FF_BLK + wave_d * 64 * 8;
+          product_w1(yacc[2 * pi + s2], slot, dsrc, ddst, true, (size_t)(pi < 3 ? 2 * (pi + 1) + s2 : QP ? s2 : 0) * FF_BLK);
           if (s2) phase_barrier(false);
           slot = (slot + 1) & 3;
         }
@@ -209,6 +219,11 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
           const f32x4 be = *reinterpret_cast<const f32x4*>(pre_s + 512 + c0);
 #pragma unroll
           for (int e = 0; e < 4; ++e) yacc[ob][4 * g + e] = fmaf((yacc[ob][4 * g + e] - mean) * rstd, gg[e], be[e]);
+          // QP: the LayerNorm output rows leave from the accumulator layout (a lane pair writes 32 contiguous bytes of its row; the four
+          // stores of an out-block complete its 128-byte line in L2).  X1 may alias R: a lane overwrites exactly what it read.
+          if (QP && row < M)
+            *reinterpret_cast<f32x4*>(pa.X1 + (size_t)row * pa.ldx1 + c0) =
+                f32x4{yacc[ob][4 * g], yacc[ob][4 * g + 1], yacc[ob][4 * g + 2], yacc[ob][4 * g + 3]};
         }
         // the LayerNorm output as the feed-forward block's B operand: k-step 2 ob + kk <- registers 8 kk .. 8 kk + 7 (W1 image with
         // the matching k order), and — plus b2, in the scale of the W2 planes — as the initial value of its Y accumulators (the residual)
@@ -223,11 +238,24 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
         for (int g = 0; g < 4; ++g) {
           const f32x4 b2v = *reinterpret_cast<const f32x4*>(pre_s + 768 + ob * 32 + 8 * g + 4 * half);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) yacc[ob][4 * g + e] = (yacc[ob][4 * g + e] + b2v[e]) * WSCALE;
+          for (int e = 0; e < 4; ++e) yacc[ob][4 * g + e] = ((QP ? 0.f : yacc[ob][4 * g + e]) + b2v[e]) * WSCALE;
         }
         __builtin_amdgcn_sched_barrier(0);               // one out-block at a time: hipcc otherwise hoists all 96 LDS reads (spills)
       }
     }
+    if constexpr (QP) {
+      // ---------------- Q^T = Wq . X1^T + bq: eight more W1-shaped blocks, two per barrier; blocks 0 and 1 were requested under the last pair above
+#pragma unroll
+      for (int pi = 0; pi < 4; ++pi) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          op_t* ddst = ring + ((slot + 2) & 3) * FF_BLK + wave_d * 64 * 8;
+          product_w1(yacc[2 * pi + s2], slot, W1p + tid * 8, ddst, pi < 3, (size_t)(pi < 3 ? 2 * (pi + 1) + s2 : 0) * FF_BLK);
+          if (s2) phase_barrier(false);
+          slot = (slot + 1) & 3;
+        }
+      }
+    } else
     for (int hb = 0; hb < nhb; ++hb) {
       // ---------------- phase 2 hb: H^T = W1_blk . X^T (+ b1), block 2 hb in slot (2 hb) % FF_RING
       // the block two ahead goes to the slot read last phase.  Past the end of the stream the last block is fetched again
@@ -235,7 +263,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
       const int hb_next = hb + 1 < nhb ? hb + 1 : nhb - 1;
       const op_t* dsrc_a = W1p + (size_t)hb_next * FF_BLK + tid * 8;
       // pair barrier: block 2 hb + 2 -> the slot block 2 hb - 2 left a pair ago; otherwise the slot read last phase
-      op_t* ddst_a = ring + (FF_PAIR ? ((slot + 2) & 3) : (slot == 0 ? 2 : slot - 1)) * FF_BLK + wave * 64 * 8;
+      op_t* ddst_a = ring + (FF_PAIR ? ((slot + 2) & 3) : (slot == 0 ? 2 : slot - 1)) * FF_BLK + wave_d * 64 * 8;
       f32x16 hacc;
       {
         const float* bp = b1s + hb * 32 + 4 * half;                    // register r <-> hidden (r & 3) + 8 (r >> 2) + 4 half
@@ -261,7 +289,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
 
       // ---------------- phase 2 hb + 1: Y^T += W2_blk . H^T, block 2 hb + 1 in slot (2 hb + 1) % FF_RING
       const op_t* dsrc_b = W2p + (size_t)hb_next * FF_BLK + tid * 8;
-      op_t* ddst_b = ring + (FF_PAIR ? ((slot + 2) & 3) : (slot == 0 ? 2 : slot - 1)) * FF_BLK + wave * 64 * 8;   // block 2 hb + 3 -> the slot of block 2 hb - 1
+      op_t* ddst_b = ring + (FF_PAIR ? ((slot + 2) & 3) : (slot == 0 ? 2 : slot - 1)) * FF_BLK + wave_d * 64 * 8;   // block 2 hb + 3 -> the slot of block 2 hb - 1
       {
         const op_t* w2 = ring + slot * FF_BLK + (half * 256 + l31) * 8;   // [p][kk][half][o][8]
         opx8 wf[4][NPL];
@@ -315,6 +343,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
         if (grow >= M) break;
         f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * FF_CP + col);
         if (!PRE) { v += bb; v += xpre[rr]; }               // PRE: b2 and the residual are in the accumulators already
+        if (QP) { *reinterpret_cast<f32x4*>(Y + (size_t)grow * ldy + col) = v; continue; }     // a plain Linear: no LayerNorm behind it
         const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
         const f32x4 dv = v - mean;
         const float var = wave_sum(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2] + dv[3] * dv[3]) * (1.f / 256.f);
@@ -340,12 +369,12 @@ int launch_ffn_fused_bf16x6(const float* X, int ldx, const void* W1p, const floa
   const int grid = n_rb < 256 ? n_rb : 256;                           // one persistent workgroup per CU
   const size_t shm = FF_RING_BYTES + (size_t)F * sizeof(float);
   // once per process (thread-safe static initialisation), sized for the largest F this launcher accepts
-  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_bf16x6_kernel<false>),
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_bf16x6_kernel<0>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                                   (int)(FF_RING_BYTES + 4096 * sizeof(float))) == hipSuccess;
   if (!attr_ok) return CTRLSIM_EINVAL;
   prof_before(PROF_GEMM, st);
-  hipLaunchKernelGGL(ffn_fused_bf16x6_kernel<false>, dim3(grid), dim3(256), shm, st, X, ldx, FfnPre{}, static_cast<const op_t*>(W1p), b1,
+  hipLaunchKernelGGL(ffn_fused_bf16x6_kernel<0>, dim3(grid), dim3(256), shm, st, X, ldx, FfnPre{}, static_cast<const op_t*>(W1p), b1,
                      static_cast<const op_t*>(W2p), b2, gamma, beta, Y, ldy, M, F / 32, ctrlsim_nonfinite_ptr());
   prof_after(PROF_GEMM, 4.0 * (double)M * DM * (double)F, st, 12.0 * (double)M * DM + 4.0 * NPL * (double)DM * F, PKIND_FFN);   // x read as operand and as residual, y written; W1 / W2 as NPL planes
   return ctrlsim_launch_status();
@@ -367,17 +396,44 @@ int launch_ffn_fused_pre(const float* O, int ldo, const float* R, int ldr, const
     const int n_rb = (M + 127) / 128;
     const int grid = n_rb < 256 ? n_rb : 256;
     const size_t shm = FF_RING_BYTES + (size_t)(F + 1024) * sizeof(float);
-    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_bf16x6_kernel<true>),
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_bf16x6_kernel<1>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                                     (int)(FF_RING_BYTES + (3072 + 1024) * sizeof(float))) == hipSuccess;
     if (!attr_ok) return CTRLSIM_EINVAL;
     prof_before(PROF_GEMM, st);
-    hipLaunchKernelGGL(ffn_fused_bf16x6_kernel<true>, dim3(grid), dim3(256), shm, st, O, ldo,
-                       FfnPre{R, ldr, static_cast<const op_t*>(Wop), bo, g0, be0}, static_cast<const op_t*>(W1q), b1,
+    hipLaunchKernelGGL(ffn_fused_bf16x6_kernel<1>, dim3(grid), dim3(256), shm, st, O, ldo,
+                       FfnPre{R, ldr, static_cast<const op_t*>(Wop), bo, g0, be0, nullptr, 0}, static_cast<const op_t*>(W1q), b1,
                        static_cast<const op_t*>(W2p), b2, gamma, beta, Y, ldy, M, F / 32, ctrlsim_nonfinite_ptr());
     // attention output and residual rows in, y out; Wo + W1 + W2 as NPL planes
     prof_after(PROF_GEMM, 4.0 * (double)M * DM * (double)F + 2.0 * (double)M * DM * DM, st,
                12.0 * (double)M * DM + 2.0 * NPL * (double)DM * DM + 4.0 * NPL * (double)DM * F, PKIND_FFN);
+    return ctrlsim_launch_status();
+  }
+}
+
+// x1 = LayerNorm0(R + Wo O + bo) and q = Wq x1 + bq as ONE kernel (QP above): the self-attention out-projection + residual + LayerNorm of a
+// decoder layer and the cross-attention query projection behind it (nn.TransformerDecoderLayer: self_attn.out_proj + norm1, then the first
+// third of multihead_attn.in_proj) — x1 is written once and not re-read.  Wop = pack.py:row_blocks(Wo), Wqp = pack.py:row_blocks of Wq with
+// the k order of ffn_planes_pre.  X1 may alias R (or O).  Two-plane scheme only.
+int launch_outproj_ln_q(const float* O, int ldo, const float* R, int ldr, const void* Wop, const float* bo, const float* g0, const float* be0,
+                        const void* Wqp, const float* bq, float* X1, int ldx1, float* Q, int ldq, int M, hipStream_t st) {
+  if (M <= 0) return CTRLSIM_OK;
+  if (!O || !R || !Wop || !bo || !g0 || !be0 || !Wqp || !bq || !X1 || !Q || (ldo & 3) || (ldr & 3) || (ldx1 & 3) || (ldq & 3)) return CTRLSIM_EINVAL;
+  if constexpr (!FF_PAIR) {
+    return CTRLSIM_EINVAL;
+  } else {
+    const int n_rb = (M + 127) / 128;
+    const int grid = n_rb < 256 ? n_rb : 256;
+    const size_t shm = FF_RING_BYTES + (size_t)1024 * sizeof(float);
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_bf16x6_kernel<2>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FF_RING_BYTES + 1024 * sizeof(float))) == hipSuccess;
+    if (!attr_ok) return CTRLSIM_EINVAL;
+    prof_before(PROF_GEMM, st);
+    hipLaunchKernelGGL(ffn_fused_bf16x6_kernel<2>, dim3(grid), dim3(256), shm, st, O, ldo,
+                       FfnPre{R, ldr, static_cast<const op_t*>(Wop), bo, g0, be0, X1, ldx1}, static_cast<const op_t*>(Wqp), bq,
+                       static_cast<const op_t*>(Wqp), bq, g0, be0, Q, ldq, M, 0, ctrlsim_nonfinite_ptr());
+    // attention output and residual rows in, x1 and q out; Wo + Wq as NPL planes
+    prof_after(PROF_GEMM, 4.0 * (double)M * DM * DM, st, 16.0 * (double)M * DM + 4.0 * NPL * (double)DM * DM, PKIND_GEMM_LN);
     return ctrlsim_launch_status();
   }
 }

@@ -35,6 +35,8 @@ int launch_gemm_nt_bf16x6_kv(const float*, int, const void*, int, int, const flo
 int launch_kv_zero_tail(int, int, int, int, void*, hipStream_t);
 int launch_kv_zero_tails(int, const KvTailHost*, void*, hipStream_t);
 int launch_kv_split_rows_classes(const float*, const float*, int, int, const KvRowsHost*, void*, hipStream_t);
+int launch_outproj_ln_q(const float*, int, const float*, int, const void*, const float*, const float*, const float*, const void*, const float*,
+                        float*, int, float*, int, int, hipStream_t);
 int launch_ffn_fused_pre(const float*, int, const float*, int, const void*, const float*, const float*, const float*, const void*, const float*,
                          const void*, const float*, const float*, const float*, float*, int, int, int, hipStream_t);
 int launch_ffn_fused_bf16x6(const float*, int, const void*, const float*, const void*, const float*, const float*, const float*,
@@ -83,7 +85,10 @@ struct FfnPlanes { const void *w1[2] = {nullptr, nullptr}, *w2[2] = {nullptr, nu
 struct EncLayer { Lin qkv, out, lin1, lin2; LNp n1, n2; FfnPlanes fp; };
 // sq / skv: the query rows / the key + value rows of the self-attention in_proj as Linears of their own (the last decoder layer of a full
 // pass projects keys and values of every token but queries of the A queried tokens only)
-struct DecLayer { Lin qkv, sq, skv, out, cq, ckv, cout, lin1, lin2; LNp n1, n2, n3; FfnPlanes fp; };
+struct DecLayer {
+  Lin qkv, sq, skv, out, cq, ckv, cout, lin1, lin2; LNp n1, n2, n3; FfnPlanes fp;
+  const void *sq_wop = nullptr, *sq_wqp = nullptr;      // pack.py:outproj_q_planes(self_attn.out_proj, cross-attention Wq)
+};
 
 }  // namespace
 
@@ -200,6 +205,7 @@ extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_w
     L.n2 = lnp(p + ".norm2");
     L.n3 = lnp(p + ".norm3");
     L.fp = ffnp(p);
+    L.sq_wop = PX(p + ".selfq#wop#pl1"); L.sq_wqp = PX(p + ".selfq#wqp#pl1");
     m->dec.push_back(L);
   }
   m->head_action = mlp("decoder.predict_action");
@@ -566,11 +572,18 @@ int mlp_tail(const Mlp& m, const float* h_in, int rows, float* hid, float* out, 
   return 0;
 }
 
-// cross-attention + FFN sub-blocks shared by the full-row and compact-row paths (post-LN, residual fused in GEMM)
+// what follows a decoder layer's self-attention, shared by the full-row and compact-row paths (post-LN): out-projection + residual + norm1
+// and the cross-attention query projection (ONE kernel with option 3 = 3 and the images of pack.py:outproj_q_planes), cross-attention,
+// its out-projection + norm2 + feed-forward block.  att holds the self-attention output on entry.
 int cross_and_ffn(const ctrlsim_model* m, const Batch& bt, const DecLayer& Ld, int layer, const Ws& w, float* x, float* tmp,
                   float* att, float* qc, float* ffn, long rows, QKind q, int Rn_mul, hipStream_t st) {
   const ctrlsim_dims& d = m->d;
-  CHK(gemm(Ld.cq, x, DM, nullptr, 0, qc, DM, (int)rows, DM, DM, 0, st));
+  if (Ld.sq_wop && Ld.sq_wqp && ctrlsim_option(OPT_SPLIT) && ctrlsim_option(OPT_FFN_FUSED) >= 3 && ctrlsim_option(OPT_GEMM_IMPL) == 1) {
+    CHK(launch_outproj_ln_q(att, DM, x, DM, Ld.sq_wop, Ld.out.b, Ld.n1.g, Ld.n1.b, Ld.sq_wqp, Ld.cq.b, x, DM, qc, DM, (int)rows, st));
+  } else {
+    CHK(gemm_ln(Ld.out, Ld.n1, att, DM, x, DM, x, DM, tmp, (int)rows, DM, 0, st));
+    CHK(gemm(Ld.cq, x, DM, nullptr, 0, qc, DM, (int)rows, DM, DM, 0, st));
+  }
   CHK(attention(d, bt, w, AttnCall{0, q, qc, DM, w.memkv[layer], w.memkv[layer] + DM, 2 * DM, w.img_mem[layer], true, att, 0, 0,
                                    Rn_mul}, st));
   CHK(outproj_ln_ffn(Ld.cout, Ld.n2, Ld.lin1, Ld.lin2, Ld.n3, Ld.fp, att, x, ffn, tmp, (int)rows, d.F, st));
@@ -746,7 +759,6 @@ int forward_full(const ctrlsim_model* m, int n, const int* Bk, const int* Ak, co
     if (!last_few) {
       CHK(attention(d, bt, w, AttnCall{amode, Q_ALL, w.qkv[i], 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, w.img_dec[i], false,
                                        w.att, Tq, Tq, 0, use_tbl}, st));
-      CHK(gemm_ln(Ld.out, Ld.n1, w.att, DM, w.X, DM, w.X, DM, w.tmp, rL, DM, 0, st));
       CHK(cross_and_ffn(m, bt, Ld, i, w, w.X, w.tmp, w.att, w.qc, w.ffn, bt.rL, Q_ALL, 0, st));
     } else {
       // last layer: only the queried tokens of the current timestep (state tokens; Trajeglish: action tokens) of the regular slots.
@@ -762,7 +774,6 @@ int forward_full(const ctrlsim_model* m, int n, const int* Bk, const int* Ak, co
       else CHK(launch_row_copy(w.qkv[i], 3 * DM, w.qkvc, 3 * DM, w.idx_state, rQ, 3 * DM, 0, st));
       CHK(attention(d, bt, w, AttnCall{amode, Q_STATE, w.qkvc, 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, w.img_dec[i], false,
                                        w.attc, Tq, Tq, 0}, st));
-      CHK(gemm_ln(Ld.out, Ld.n1, w.attc, DM, w.xc, DM, w.xc, DM, w.tmpc, rQ, DM, 0, st));
       CHK(cross_and_ffn(m, bt, Ld, i, w, w.xc, w.tmpc, w.attc, w.qcc, w.ffnc, bt.rQ, Q_STATE, 0, st));
     }
   }
@@ -867,7 +878,6 @@ extern "C" int ctrlsim_dt_forward_pass2_c(const ctrlsim_model* m, int n, const i
     }
     CHK(attention(d, bt, w, AttnCall{1, Q_RTG, w.qkvc, 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, w.img_dec[i], false, w.attc,
                                      Tq, Tw, 0}, st));   // keys: steps <= current
-    CHK(gemm_ln(Ld.out, Ld.n1, w.attc, DM, w.xc2, DM, w.xc2, DM, w.tmpc, rQ, DM, 0, st));
     CHK(cross_and_ffn(m, bt, Ld, i, w, w.xc2, w.tmpc, w.attc, w.qcc, w.ffnc, bt.rQ, Q_RTG, 0, st));
   }
   CHK(mlp_tail(m->head_action, w.xc2, rQ, w.headh, act_logits, d.V, st));
@@ -956,7 +966,6 @@ extern "C" int ctrlsim_dt_forward_pass1_cached_c(const ctrlsim_model* m, int n, 
     }
     CHK(attention(d, bt, w, AttnCall{1, Q_NEW, w.qkvn, 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, w.img_dec[i], false, w.attn_n,
                                      t + 1, d.T, mul}, st));
-    CHK(gemm_ln(Ld.out, Ld.n1, w.attn_n, DM, w.xn, DM, w.xn, DM, w.tmpn, rN, DM, 0, st));
     CHK(cross_and_ffn(m, bt, Ld, i, w, w.xn, w.tmpn, w.attn_n, w.qcn, w.ffnn, bt.rN, Q_NEW, mul, st));
   }
   CHK(launch_row_copy(w.xn, DM, w.xc, DM, w.idx_state_in_new, rQ, DM, 0, st));

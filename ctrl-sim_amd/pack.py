@@ -173,11 +173,23 @@ def ffn_planes_pre(Wo: np.ndarray, W1: np.ndarray, W2: np.ndarray, scheme=1):
     blocks with bits 2 and 3 of k swapped inside every 16-wide k-step — the kernel's first B operand is then the LayerNorm output in
     ACCUMULATOR-register order: slot (half, e) of k-step ks holds k = 16 ks + 8 (e >> 2) + 4 half + (e & 3).  W2p as ffn_planes."""
     W1 = np.asarray(W1, np.float32)
-    k = np.arange(W1.shape[1])
-    e, h, ks = k & 7, (k >> 3) & 1, k >> 4
-    perm = 16 * ks + 8 * (e >> 2) + 4 * h + (e & 3)          # W1q image column 16 ks + 8 h + e <- W1 column perm
-    w1q, w2p = ffn_planes(W1[:, perm], W2, scheme)
+    w1q, w2p = ffn_planes(W1[:, acc_order_perm(W1.shape[1])], W2, scheme)
     return row_blocks(np.asarray(Wo, np.float32), scheme), w1q, w2p
+
+
+def acc_order_perm(K: int) -> np.ndarray:
+    """k order of a B operand that comes straight out of accumulator registers (csrc/ffn_fused.hip: the in-register LayerNorm): image
+    column 16 ks + 8 h + e <- column 16 ks + 8 (e >> 2) + 4 h + (e & 3)."""
+    k = np.arange(K)
+    e, h, ks = k & 7, (k >> 3) & 1, k >> 4
+    return 16 * ks + 8 * (e >> 2) + 4 * h + (e & 3)
+
+
+def outproj_q_planes(Wo: np.ndarray, Wq: np.ndarray, scheme=1):
+    """Operand images of ctrlsim_outproj_ln_q (csrc/ffn_fused.hip, QP): -> (Wop, Wqp), eight W1-shaped blocks of 32 output columns each;
+    Wqp in the k order of the LayerNorm output registers (acc_order_perm)."""
+    Wq = np.asarray(Wq, np.float32)
+    return row_blocks(np.asarray(Wo, np.float32), scheme), row_blocks(np.ascontiguousarray(Wq[:, acc_order_perm(Wq.shape[1])]), scheme)
 
 
 def pack(dims: Dims, w: dict):
@@ -222,6 +234,18 @@ def pack(dims: Dims, w: dict):
                     continue
                 allw[pre + ".ffn#wop" + PLANES_SUFFIX[1]] = wop.reshape(-1).view(np.float32)
                 allw[pre + ".ffn#w1q" + PLANES_SUFFIX[1]] = w1q.reshape(-1).view(np.float32)
+    # a decoder layer's self-attention out-projection + norm1 with the cross-attention query projection behind it (ctrlsim_outproj_ln_q)
+    for k in list(w.keys()):
+        if k.endswith(".multihead_attn.in_proj_weight"):
+            pre = k[:-len(".multihead_attn.in_proj_weight")]
+            ok = pre + ".self_attn.out_proj.weight"
+            if ok in w and np.asarray(w[ok]).shape == (256, 256) and np.asarray(w[k]).shape == (768, 256):
+                try:
+                    wop, wqp = outproj_q_planes(np.asarray(w[ok], np.float32), np.asarray(w[k], np.float32)[:256], 1)
+                except FloatingPointError:
+                    continue
+                allw[pre + ".selfq#wop" + PLANES_SUFFIX[1]] = wop.reshape(-1).view(np.float32)
+                allw[pre + ".selfq#wqp" + PLANES_SUFFIX[1]] = wqp.reshape(-1).view(np.float32)
     # 32-column operand blocks of every attention in_proj (two-fp16-plane scheme: the row-stationary kernel)
     for k in list(w.keys()):
         if k.endswith("in_proj_weight") and np.asarray(w[k]).shape == (3 * 256, 256):

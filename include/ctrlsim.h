@@ -309,6 +309,12 @@ int ctrlsim_ffn_fused(const float* X, int ldx, const void* W1p, const float* b1,
 int ctrlsim_ffn_fused_pre(const float* O, int ldo, const float* R, int ldr, const void* Wop, const float* bo, const float* g0,
                           const float* be0, const void* W1q, const float* b1, const void* W2p, const float* b2, const float* gamma,
                           const float* beta, float* Y, int ldy, int M, int F, hipStream_t stream);
+/* X1 = LayerNorm0(R + Wo O + bo) and Q = Wq X1 + bq as one kernel (round 5, two-fp16-plane scheme only): a decoder layer's
+ * self_attn.out_proj + residual + norm1 and the query third of multihead_attn.in_proj behind it (nn.TransformerDecoderLayer._sa_block /
+ * _mha_block; modules/decoder.py:16-20) — the row goes in once, x1 and q come out.  X1 may alias R.  Wop / Wqp =
+ * ctrlsim_amd/pack.py:outproj_q_planes(Wo, Wq). */
+int ctrlsim_outproj_ln_q(const float* O, int ldo, const float* R, int ldr, const void* Wop, const float* bo, const float* g0, const float* be0,
+                         const void* Wqp, const float* bq, float* X1, int ldx1, float* Q, int ldq, int M, hipStream_t stream);
 int ctrlsim_layernorm256(const float* X, int ldx, const float* Radd, int ldr, const float* gamma, const float* beta,
                          float* Y, int ldy, int rows, int relu, hipStream_t stream);
 /* mode 0: key padding (key_pad [B,Lk], 1 = ignore); mode 1: CtRL-Sim structured causal mask (utils/train_utils.py:81-129) */
@@ -377,8 +383,9 @@ int ctrlsim_attn_class_prof(int enable, unsigned long long* host_out);
  * (v_mfma_f32_32x32x2_f32), 1 = split-operand 16-bit MFMA with fp32-class accuracy (default).  Key 2 = tile shape of the tiled
  * split-operand GEMM (0 auto; tuning).  Key 3 = fused feed-forward block (default 1).  Key 4 = operand split (1 two fp16 planes,
  * 0 three bf16 planes; per engine through ctrlsim_bind).  These are the PROCESS DEFAULTS; an engine overrides them with its own table (ctrlsim_bind_options).  Key 5 = reserved (rounds 2-3: a matrix-pipe variant of the map-encoder pooling, removed).
- * Key 3 value 2 (default) = also the attention out-projection + residual + LayerNorm in front of a feed-forward block as its leading product
- * (ctrlsim_ffn_fused_pre; two-plane scheme); 1 = the feed-forward block alone; 0 = separate Linear kernels.
+ * Key 3 value 2 = also the attention out-projection + residual + LayerNorm in front of a feed-forward block as its leading product
+ * (ctrlsim_ffn_fused_pre; two-plane scheme); 3 (default) = and a decoder layer's self-attention out-projection + LayerNorm with the cross-attention
+ * query projection behind it as one kernel (ctrlsim_outproj_ln_q); 1 = the feed-forward block alone; 0 = separate Linear kernels.
  * Key 6 = weight-stationary kernel for the Linear(256 -> 256 G) shapes, bit mask: 1 = launches of at least two 32-row blocks per
  * compute unit, 2 = smaller launches, 4 = the in_proj Linears with K / V-image epilogue, 8 = those through the ROW-stationary kernel
  * (rows in registers, 32-column weight blocks streamed through LDS, every activation row read once; needs the block images of

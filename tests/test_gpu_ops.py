@@ -656,6 +656,37 @@ def test_outproj_layernorm_ffn_as_one_kernel(M, F):
                                             p(Y), 256, M, 3104, _lib.stream_ptr()) != 0          # beyond the LDS the bias tables fit in
 
 
+@pytest.mark.parametrize("M", [128, 1000, 37, 4133, 40000])
+def test_outproj_layernorm_query_projection_as_one_kernel(M):
+    """x1 = LayerNorm0(R + O Wo^T + bo), q = x1 Wq^T + bq (ctrlsim_outproj_ln_q): nn.TransformerDecoderLayer's self_attn.out_proj + norm1 and
+    the query third of multihead_attn.in_proj (modules/decoder.py:16-20) against torch in float64; x1 written over the residual rows."""
+    from ctrlsim_amd.pack import outproj_q_planes
+    if _lib.lib().ctrlsim_get_option(0) != 1:
+        pytest.skip("two-fp16-plane scheme only")
+    g = torch.Generator().manual_seed(M + 7)
+    O = torch.randn(M, 256, generator=g).to(DEV)
+    R = (torch.randn(M, 256, generator=g) * torch.exp(0.5 * torch.randn(M, 1, generator=g))).to(DEV)
+    Wo = torch.randn(256, 256, generator=g) * 0.07
+    Wq = torch.randn(256, 256, generator=g) * 0.09
+    bo, g0, be0, bq = (torch.randn(256, generator=g).to(DEV) * s for s in (0.3, 1.0, 0.2, 0.4))
+    wop, wqp = outproj_q_planes(Wo.numpy(), Wq.numpy(), 1)
+    dev = lambda a: torch.from_numpy(a.view(np.int16).copy()).to(DEV)
+    wod, wqd = dev(wop), dev(wqp)
+    X1 = torch.full((M, 256), float("nan"), device=DEV); Q = torch.full((M, 320), float("nan"), device=DEV)
+    p = _lib.ptr
+    call = lambda Rr, Xx, Qq, ldq: _lib.check(_lib.lib().ctrlsim_outproj_ln_q(p(O), 256, p(Rr), 256, p(wod), p(bo), p(g0), p(be0), p(wqd), p(bq),
+                                                                              p(Xx), 256, p(Qq), ldq, M, _lib.stream_ptr()), "outproj_ln_q")
+    call(R, X1, Q, 320)
+    x1 = torch.nn.functional.layer_norm(R.double() + O.double() @ Wo.to(DEV).double().T + bo.double(), (256,), g0.double(), be0.double(), 1e-5)
+    q = x1 @ Wq.to(DEV).double().T + bq.double()
+    e1 = (X1.double() - x1).abs().max().item(); e2 = (Q[:, :256].double() - q).abs().max().item()
+    print("out-proj + LN + q as one kernel: max abs err x1", e1, "q", e2)
+    assert e1 < 2e-5 and e2 < 3e-5 and torch.isnan(Q[:, 256:]).all()
+    Z = R.clone(); Q2 = torch.empty(M, 256, device=DEV)
+    call(Z, Z, Q2, 256)
+    assert torch.equal(Z, X1) and torch.equal(Q2, Q[:, :256])
+
+
 @pytest.mark.parametrize("B", [1, 3])
 def test_map_pool_matches_the_unfolded_front_end_in_float64(B):
     """map_pool_kernel (point MLP + single-seed attention pooling with every linear stage folded at pack time: csrc/map_encoder.hip) against
