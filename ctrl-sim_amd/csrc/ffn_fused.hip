@@ -111,7 +111,24 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
     dma_block(0, 0);
     dma_block(1, 1);
     opx8 xT[16][NPL];
-    {
+    if constexpr (PRE) {
+      // all 32 loads of the wave's rows are requested before the first is converted (left to itself hipcc, at this kernel's register
+      // pressure, requests two, waits for them, converts, requests the next two: sixteen round trips to HBM per row block)
+      const float* xp = X + (size_t)rowc * ldx + half * 8;
+      f32x4 raw[32];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        raw[2 * ks] = *reinterpret_cast<const f32x4*>(xp + ks * 16);
+        raw[2 * ks + 1] = *reinterpret_cast<const f32x4*>(xp + ks * 16 + 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const f32x4 x0 = raw[2 * ks], x1 = raw[2 * ks + 1];
+        const float xs[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        split_frag(xs, xT[ks]);
+      }
+    } else {
       const float* xp = X + (size_t)rowc * ldx + half * 8;
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
@@ -121,16 +138,22 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
         split_frag(xs, xT[ks]);
       }
     }
+    __syncthreads();                                                  // (vmcnt(0) + barrier) blocks 0 and 1 are in LDS
     f32x16 yacc[8];
     if (PRE) {
       // the residual rows + bo go straight into the accumulators of the leading product, in the accumulator layout — lane (l31, half) holds, of
-      // row l31, the columns 32 ob + (r & 3) + 8 (r >> 2) + 4 half — and in the scale of the Wo planes
+      // row l31, the columns 32 ob + (r & 3) + 8 (r >> 2) + 4 half — and in the scale of the Wo planes.  Requested BEHIND the barrier: out-block
+      // ob is first needed by product ob, so all but the first of these loads land underneath the leading product's MFMAs
       const float* rp = pa.R + (size_t)rowc * pa.ldr + 4 * half;
+      f32x4 rr[32];                                                   // (all requested before the first is used, like the rows above)
+#pragma unroll
+      for (int i = 0; i < 32; ++i) rr[i] = *reinterpret_cast<const f32x4*>(rp + (i >> 2) * 32 + 8 * (i & 3));
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ob = 0; ob < 8; ++ob)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const f32x4 xr = *reinterpret_cast<const f32x4*>(rp + ob * 32 + 8 * g);
+          const f32x4 xr = rr[4 * ob + g];
           const f32x4 bb = *reinterpret_cast<const f32x4*>(pre_s + ob * 32 + 8 * g + 4 * half);
 #pragma unroll
           for (int e = 0; e < 4; ++e) yacc[ob][4 * g + e] = (xr[e] + bb[e]) * WSCALE;
@@ -141,7 +164,6 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) yacc[ob][r] = 0.f;
     }
-    __syncthreads();                                                  // (vmcnt(0) + barrier) blocks 0 and 1 are in LDS
 
     int slot = 0;                                                     // ring slot of the block the current phase reads
     // one product of the W1 shape: acc^T += Wblk . X^T with the 32 KB block in ring slot `slot_` (A fragments from LDS, fetched FFN_PF
@@ -219,11 +241,6 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
           const f32x4 be = *reinterpret_cast<const f32x4*>(pre_s + 512 + c0);
 #pragma unroll
           for (int e = 0; e < 4; ++e) yacc[ob][4 * g + e] = fmaf((yacc[ob][4 * g + e] - mean) * rstd, gg[e], be[e]);
-          // QP: the LayerNorm output rows leave from the accumulator layout (a lane pair writes 32 contiguous bytes of its row; the four
-          // stores of an out-block complete its 128-byte line in L2).  X1 may alias R: a lane overwrites exactly what it read.
-          if (QP && row < M)
-            *reinterpret_cast<f32x4*>(pa.X1 + (size_t)row * pa.ldx1 + c0) =
-                f32x4{yacc[ob][4 * g], yacc[ob][4 * g + 1], yacc[ob][4 * g + 2], yacc[ob][4 * g + 3]};
         }
         // the LayerNorm output as the feed-forward block's B operand: k-step 2 ob + kk <- registers 8 kk .. 8 kk + 7 (W1 image with
         // the matching k order), and — plus b2, in the scale of the W2 planes — as the initial value of its Y accumulators (the residual)
@@ -234,27 +251,55 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
           for (int j = 0; j < 8; ++j) t8[j] = yacc[ob][8 * kk + j];
           split_frag(t8, xT[2 * ob + kk]);
         }
+        if (!QP) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 b2v = *reinterpret_cast<const f32x4*>(pre_s + 768 + ob * 32 + 8 * g + 4 * half);
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 b2v = *reinterpret_cast<const f32x4*>(pre_s + 768 + ob * 32 + 8 * g + 4 * half);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) yacc[ob][4 * g + e] = ((QP ? 0.f : yacc[ob][4 * g + e]) + b2v[e]) * WSCALE;
+            for (int e = 0; e < 4; ++e) yacc[ob][4 * g + e] = (yacc[ob][4 * g + e] + b2v[e]) * WSCALE;
+          }
         }
         __builtin_amdgcn_sched_barrier(0);               // one out-block at a time: hipcc otherwise hoists all 96 LDS reads (spills)
       }
     }
     if constexpr (QP) {
-      // ---------------- Q^T = Wq . X1^T + bq: eight more W1-shaped blocks, two per barrier; blocks 0 and 1 were requested under the last pair above
+      // ---------------- Q^T = Wq . X1^T + bq: eight more W1-shaped blocks, two per barrier; blocks 0 and 1 were requested under the last pair above.
+      // Both outputs leave from the ACCUMULATOR layout (a lane pair writes 32 contiguous bytes of its row; the four stores of an out-block
+      // complete its 128-byte line in L2), spread over the products so that they drain underneath the MFMAs: block ob of x1 right before its
+      // registers become the accumulator of q block ob, q block ob two products later.  X1 may alias R: a lane overwrites what it read.
+      auto store_q = [&](int ob) {
+        if (row < M) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(Y + (size_t)row * ldy + ob * 32 + 8 * g + 4 * half) =
+                f32x4{yacc[ob][4 * g], yacc[ob][4 * g + 1], yacc[ob][4 * g + 2], yacc[ob][4 * g + 3]} * WSCALE_INV;
+        }
+      };
 #pragma unroll
       for (int pi = 0; pi < 4; ++pi) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
+          const int ob = 2 * pi + s2;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int c0 = ob * 32 + 8 * g + 4 * half;
+            if (row < M)
+              *reinterpret_cast<f32x4*>(pa.X1 + (size_t)row * pa.ldx1 + c0) =
+                  f32x4{yacc[ob][4 * g], yacc[ob][4 * g + 1], yacc[ob][4 * g + 2], yacc[ob][4 * g + 3]};
+            const f32x4 bqv = *reinterpret_cast<const f32x4*>(pre_s + 768 + c0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) yacc[ob][4 * g + e] = bqv[e] * WSCALE;
+          }
+          if (ob >= 2) store_q(ob - 2);
           op_t* ddst = ring + ((slot + 2) & 3) * FF_BLK + wave_d * 64 * 8;
           product_w1(yacc[2 * pi + s2], slot, W1p + tid * 8, ddst, pi < 3, (size_t)(pi < 3 ? 2 * (pi + 1) + s2 : 0) * FF_BLK);
           if (s2) phase_barrier(false);
           slot = (slot + 1) & 3;
         }
       }
+      store_q(6);
+      store_q(7);
+      // (every wave is past the last pair's barrier: nobody reads the ring any more and no request is in flight — the next row block may start)
     } else
     for (int hb = 0; hb < nhb; ++hb) {
       // ---------------- phase 2 hb: H^T = W1_blk . X^T (+ b1), block 2 hb in slot (2 hb) % FF_RING
@@ -313,6 +358,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
       phase_barrier(!FF_PAIR);                           // pair barrier: vmcnt(0) — the next hidden block's two weight blocks have landed for every wave
       slot = slot == FF_RING - 1 ? 0 : slot + 1;
     }
+    if constexpr (!QP) {
     __syncthreads();                                                  // drain everything before the ring is reused as staging
 
     // ---------------- epilogue: Y^T -> LDS (own 32-row region), then row-major + b2 + x, LayerNorm, store
@@ -343,7 +389,6 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
         if (grow >= M) break;
         f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * FF_CP + col);
         if (!PRE) { v += bb; v += xpre[rr]; }               // PRE: b2 and the residual are in the accumulators already
-        if (QP) { *reinterpret_cast<f32x4*>(Y + (size_t)grow * ldy + col) = v; continue; }     // a plain Linear: no LayerNorm behind it
         const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
         const f32x4 dv = v - mean;
         const float var = wave_sum(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2] + dv[3] * dv[3]) * (1.f / 256.f);
@@ -353,6 +398,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
       }
     }
     __syncthreads();                                                  // the ring is reused by the next row block
+    }
   }
 }
 

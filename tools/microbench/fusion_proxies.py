@@ -4,7 +4,7 @@
   (a) out-proj + LN1 + cross-Q in one row-stationary kernel     ~  the row-stationary kernel as a plain Linear with N = 512 output columns (rows read
       once, two 256-column products' worth of weight stream and MFMAs, 2 KB per row of fp32 stores) — without the LayerNorm dependency between
       the two products, i.e. a LOWER bound of the fused kernel's time
-against the kernels they would replace.  usage: python tools/microbench/fusion_proxies.py [B=256]"""
+against the kernels they would replace.  and, since both were built later in the round, the fused kernels themselves.  usage: python tools/microbench/fusion_proxies.py [B=256]"""
 import sys
 import time
 sys.path.insert(0, '.')
@@ -58,6 +58,17 @@ for N in (256, 512):
     C = torch.empty(M, N, device=DEV)
     res[f"row-stationary plain 256 -> {N}"] = sustained(lambda: lib.ctrlsim_gemm_kv_blocks(p(X), 256, p(blk), p(bn), p(C), N, M, N, None, 0, 0, 0, st))
     del C
+# the fused kernels as built (round 5, options 3 = 2 / 3)
+from ctrlsim_amd.pack import ffn_planes_pre, outproj_q_planes
+O = torch.randn(M, 256, device=DEV)
+W1 = torch.randn(1024, 256) * 0.05; W2 = torch.randn(256, 1024) * 0.05; Wq = torch.randn(256, 256) * 0.05
+dev = lambda a: torch.from_numpy(a.view(np.int16).copy()).to(DEV)
+wod, w1q, w2d = (dev(a) for a in ffn_planes_pre(W.numpy(), W1.numpy(), W2.numpy(), 1))
+b1 = torch.randn(1024, device=DEV)
+res["BUILT (b): out-proj + LN + ffn F=1024"] = sustained(lambda: lib.ctrlsim_ffn_fused_pre(p(O), 256, p(X), 256, p(wod), p(b2), p(g), p(g), p(w1q), p(b1), p(w2d), p(b2), p(g), p(g), p(Y), 256, M, 1024, st))
+wod2, wqd = (dev(a) for a in outproj_q_planes(W.numpy(), Wq.numpy(), 1))
+Q = torch.empty(M, 256, device=DEV)
+res["BUILT (a): out-proj + LN + q"] = sustained(lambda: lib.ctrlsim_outproj_ln_q(p(O), 256, p(X), 256, p(wod2), p(b2), p(g), p(g), p(wqd), p(b2), p(Y), 256, p(Q), 256, M, st))
 for k, v in res.items():
     print(f"{k:40s} {v:7.3f} ms")
 print(f"(b) proxy: FFN(1152) - FFN(1024) = {res['ffn F=1152'] - res['ffn F=1024']:.3f} ms of extra fused work against {res['ws256 out-proj + residual + LN']:.3f} ms for the separate kernel")
