@@ -19,7 +19,9 @@ def kind_of(name):
     if "inproj_rs_kernel" in name:
         return "linear_kv_images"
     if "ffn_fused_bf16x6_kernel" in name:
-        return "ffn_fused"
+        # mode 2 = out-projection + LayerNorm + query projection (launch_outproj_ln_q books it as Linear + residual + LayerNorm); modes 0 / 1 =
+        # the feed-forward block without / with the out-projection in front of it
+        return "linear_residual_layernorm" if re.search(r"ffn_fused_bf16x6_kernel(?:ILi|<)2", name) else "ffn_fused"
     m = re.search(r"attention_bf16x6_kernel(?:ILi|<)(\d)", name)
     if m:
         return "attention_causal" if m.group(1) == "1" else "attention_keypad"
