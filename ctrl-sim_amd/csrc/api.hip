@@ -80,7 +80,7 @@ void prof_after(int cls, double flops, hipStream_t st, double bytes, int kind) {
   g_recs.push_back(ProfRec{g_pending[cls], b, cls, flops, bytes, st, 2 * kind + (g_prof_few ? 1 : 0)});
 }
 
-static int g_options[OPT_COUNT] = {1, 1, 0, 3, 1, 0, 15, 1, 1, 1};      // process defaults (ctrlsim_set_option)
+static int g_options[OPT_COUNT] = {1, 1, 0, 2, 1, 0, 15, 1, 1, 1};      // process defaults (ctrlsim_set_option)
 // the option table of the ENGINE that bound last (ctrlsim_bind_options): entry >= 0 overrides the process default, -1 inherits it
 static int g_bound_options[OPT_COUNT];
 static bool g_has_bound_options = false;

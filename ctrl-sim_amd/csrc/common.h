@@ -98,9 +98,10 @@ void prof_after(int cls, double flops, hipStream_t st, double bytes = 0.0, int k
 // ---- runtime options (ctrlsim_set_option): which MFMA path the matrix kernels take
 enum { OPT_ATTN_IMPL = 0, OPT_GEMM_IMPL = 1,   // 0 = f32-input MFMA, 1 = split-bf16 (bf16x6) MFMA
        OPT_GEMM6_TILE = 2,                       // bf16x6 GEMM tile: 0 = auto, 1 = 128x128, 2 = 64x256 (tuning knob)
-       OPT_FFN_FUSED = 3,                        // 1 = linear1-ReLU-linear2-residual-LayerNorm as one kernel (ffn_fused.hip); 2 = with the
-                                                 // attention out-projection + residual + LayerNorm in front of it as its leading product; 3 (default) = and the
-                                                 // self-attention out-projection + norm1 + cross-attention query projection as one kernel (round 5)
+       OPT_FFN_FUSED = 3,                        // 1 = linear1-ReLU-linear2-residual-LayerNorm as one kernel (ffn_fused.hip); 2 (default) = with the
+                                                 // attention out-projection + residual + LayerNorm in front of it as its leading product (+2.8 %); 3 = and the
+                                                 // self-attention out-projection + norm1 + cross-attention query projection as one kernel (built and
+                                                 // measured in round 5: -0.35 % against 2, profiles/r05_fusion_k256.md; off)
        OPT_SPLIT = 4,                            // operand split of the split-operand kernels (csrc/split.h): 1 = two fp16 planes, three
                                                  // products (default), 0 = three bf16 planes, six products (full fp32 exponent range)
        OPT_RESERVED_5 = 5,                       // (rounds 2-3: map-encoder pooling on the matrix pipe; the kernel lost and was removed in round 4)

@@ -383,9 +383,10 @@ int ctrlsim_attn_class_prof(int enable, unsigned long long* host_out);
  * (v_mfma_f32_32x32x2_f32), 1 = split-operand 16-bit MFMA with fp32-class accuracy (default).  Key 2 = tile shape of the tiled
  * split-operand GEMM (0 auto; tuning).  Key 3 = fused feed-forward block (default 1).  Key 4 = operand split (1 two fp16 planes,
  * 0 three bf16 planes; per engine through ctrlsim_bind).  These are the PROCESS DEFAULTS; an engine overrides them with its own table (ctrlsim_bind_options).  Key 5 = reserved (rounds 2-3: a matrix-pipe variant of the map-encoder pooling, removed).
- * Key 3 value 2 = also the attention out-projection + residual + LayerNorm in front of a feed-forward block as its leading product
- * (ctrlsim_ffn_fused_pre; two-plane scheme); 3 (default) = and a decoder layer's self-attention out-projection + LayerNorm with the cross-attention
- * query projection behind it as one kernel (ctrlsim_outproj_ln_q); 1 = the feed-forward block alone; 0 = separate Linear kernels.
+ * Key 3 value 2 (default) = also the attention out-projection + residual + LayerNorm in front of a feed-forward block as its leading product
+ * (ctrlsim_ffn_fused_pre; two-plane scheme); 3 = and a decoder layer's self-attention out-projection + LayerNorm with the cross-attention
+ * query projection behind it as one kernel (ctrlsim_outproj_ln_q; measured slightly slower than 2 in the rollout, kept selectable);
+ * 1 = the feed-forward block alone; 0 = separate Linear kernels.
  * Key 6 = weight-stationary kernel for the Linear(256 -> 256 G) shapes, bit mask: 1 = launches of at least two 32-row blocks per
  * compute unit, 2 = smaller launches, 4 = the in_proj Linears with K / V-image epilogue, 8 = those through the ROW-stationary kernel
  * (rows in registers, 32-column weight blocks streamed through LDS, every activation row read once; needs the block images of

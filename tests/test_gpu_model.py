@@ -117,6 +117,43 @@ def test_forward_matches_reference_logits_at_trained_like_weights(split):
             assert err <= 1e-5 * scale, (split, seed, nm, err, scale)
 
 
+@pytest.mark.parametrize("fused", [0, 1, 2, 3])
+def test_forward_golden_logits_at_every_setting_of_the_out_projection_fusion(fused):
+    """Option 3 (csrc/common.h: OPT_FFN_FUSED): 0 = separate Linear kernels, 1 = the feed-forward block as one kernel, 2 (default) = with the
+    attention out-projection + residual + LayerNorm in front of it as its leading product (ctrlsim_ffn_fused_pre), 3 = and the self-attention
+    out-projection + norm1 + cross-attention query projection as one kernel (ctrlsim_outproj_ln_q).  Every setting against the UNMODIFIED
+    reference's logits (tests/golden/model_full.npz, model_trained.npz), bound per call so that the process default stays untouched."""
+    cfg = cfg_of("full")
+    d = spec.Dims(cfg)
+    lib = _lib.lib()
+    n_opt = lib.ctrlsim_option_count()
+    vals = (C.c_int * n_opt)(*([-1] * n_opt))
+    vals[3] = fused
+    guard = torch.zeros(2, dtype=torch.int32, device=DEV)
+    for fixture, gen, seeds in (("model_full", lambda ws: weights.generate(d, 0), (1,)),
+                                ("model_trained", lambda ws: weights.generate_trained_like(d, ws), (1, 2))):
+        g = golden(fixture)
+        for seed in seeds:
+            rec = [int(v) for v in g[f"s{seed}_recipe"]]
+            t_fill, n_ag, n_pl = rec[1], rec[2], rec[3]
+            model = HipModel(cfg, gen(rec[4] if len(rec) > 4 else 0), DEV)
+            inp = synth_inputs.random_context(d, seed, B=1, t_fill=t_fill, n_agents=n_ag, n_polys=n_pl)
+            bins = inp["rtgs"][:, :, t_fill - 1].astype(np.int64)
+            _lib.check(lib.ctrlsim_bind(1, guard.data_ptr()))
+            _lib.check(lib.ctrlsim_bind_options(vals))
+            try:
+                assert lib.ctrlsim_get_option(3) == fused
+                rtg, act, _ = _run_both_passes(model, d, inp, t_fill, bins)
+            finally:
+                lib.ctrlsim_bind_options(None)
+                lib.ctrlsim_bind(1, None)
+            assert guard.tolist() == [0, 0]
+            for ours, nm in ((rtg, "rtg_logits"), (act, "action_logits")):
+                ref = g[f"s{seed}_{nm}"][:n_ag]
+                scale = max(np.abs(ref).max(), 10.0)
+                assert np.abs(ours[0, :n_ag] - ref).max() <= 1e-5 * scale, (fused, fixture, seed, nm)
+
+
 def test_forward_f32_mfma_kernels_selectable():
     """ctrlsim_set_option(0/1, 0) routes every Linear / attention through the f32-input MFMA kernels (separate LayerNorm
     kernel); the logits must agree with the default split-bf16 path to well inside the tolerance."""

@@ -278,12 +278,14 @@ def test_closed_loop_rollout_matches_reference_fixture(tag):
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])
-def test_closed_loop_full_dims_through_sliding_window_matches_reference_fixture(tag):
+@pytest.mark.parametrize("fused", [2, 3, 1])
+def test_closed_loop_full_dims_through_sliding_window_matches_reference_fixture(tag, fused):
     """The unmodified reference policy + real FreeCar/Box2D at the FULL model dims (A=24, T=32, P=200) for 40 / 36 steps
     (tests/golden/closed_loop_full.npz, oracle/gen_golden.py::gen_closed_loop_full): the last steps run in the
     sliding-window phase where the frame re-origins at the focal pose of window index 0 = t-31 every step
     (autoregressive_policy.py:55-70, dataset.py:390-394) — >90 % of the bench's run time.  Tokens / RTG bins / groups /
-    collision flags bit-exact, float32 states within 1e-4.  Run with and without the KV-cached phase."""
+    collision flags bit-exact, float32 states within 1e-4.  Run with and without the KV-cached phase, and at every setting of the
+    out-projection fusion (engine option 3: 2 = default, 3 = with the self-attention out-projection + query projection kernel, 1 = neither)."""
     cfg = spec.make_cfg()
     d = spec.Dims(cfg)
     g = golden("closed_loop_full")
@@ -296,7 +298,7 @@ def test_closed_loop_full_dims_through_sliding_window_matches_reference_fixture(
     model = None
     for cache in (True, False):
         eng = RolloutEngine(cfg, weights.generate(d, 0), DEV, max_ctx=16, seed=int(rc[5]), tilt=tuple(rc[6:9]), use_cache=cache,
-                            model=model)
+                            model=model, options={3: fused})
         model = eng.model
         eng.load_scenarios([scn, scn], steps=steps)
         r = eng.run(steps).results()

@@ -82,7 +82,8 @@ def main():
         if a:
             r["algorithmic_bytes_per_launch_same_run"] = a["algorithmic_hbm_bytes"] / max(a["launches"], 1)
             r["launches_counted_by_bench"] = a["launches"]
-            r["hbm_over_algorithmic"] = hbm / a["algorithmic_hbm_bytes"]
+            # per LAUNCH on both sides: the counters also see the warm-up steps' launches (same sizes), bench.py counts the timed ones
+            r["hbm_over_algorithmic"] = (hbm / n) / (a["algorithmic_hbm_bytes"] / max(a["launches"], 1))
         res[kd] = r
     print(json.dumps({"_convention": f"HBM bytes = {FETCH_FACTOR:g} x FETCH_SIZE + {WRITE_FACTOR:g} x WRITE_SIZE (counter units of 1024 B); factors calibrated on known-byte "
                                      "launches of every access pattern and of each hot kernel: profiles/r05_pmc_calibration.json",
