@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
   static_assert(!PRE || FF_PAIR, "the leading product rides on the four-slot ring of the two-plane scheme");
   float* pre_s = b1s + nhb * 32;                                     // PRE: bo, norm gain, norm bias, b2 (256 floats each)
   if (PRE) { pre_s[tid] = pa.bo[tid]; pre_s[256 + tid] = pa.g0[tid]; pre_s[512 + tid] = pa.be0[tid]; pre_s[768 + tid] = b2[tid]; }
+  if (PRE && !QP) { pre_s[1024 + tid] = gamma[tid]; pre_s[1280 + tid] = beta[tid]; }      // the closing LayerNorm's gain / bias
   __syncthreads();
 
   // block i of the weight stream: W1 of hidden block i/2 (even i) or W2 of it (odd i); lives in ring slot i % FF_RING
@@ -358,7 +359,55 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
       phase_barrier(!FF_PAIR);                           // pair barrier: vmcnt(0) — the next hidden block's two weight blocks have landed for every wave
       slot = slot == FF_RING - 1 ? 0 : slot + 1;
     }
-    if constexpr (!QP) {
+    if constexpr (PRE && !QP) {
+      // ---------------- epilogue of the PRE mode: the closing LayerNorm IN the accumulator layout, like the one in front (b2 and the residual are
+      // in the accumulators; a lane holds 128 of its row's 256 values, the other half is in lane ^ 32), rows leave as 16-byte stores (a lane pair
+      // writes 32 contiguous bytes, the four stores of an out-block complete its 128-byte line in L2).  No LDS staging, no barrier: every wave is
+      // past the last pair's barrier, nobody reads the ring any more and no request is in flight.  (s_memtime: the LDS-staged row-major epilogue
+      // below was 10.5 % of this mode, 23 000 ticks per row block against 8 000 for the in-register LayerNorm.)  Y may alias R or X: a wave
+      // read all of its rows long ago.
+      float sum = 0.f;
+#pragma unroll
+      for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = yacc[ob][r] * WSCALE_INV;
+          yacc[ob][r] = v;
+          sum += v;
+        }
+      {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
+        sum = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+      }
+      const float mean = sum * (1.f / 256.f);
+      float sq = 0.f;
+#pragma unroll
+      for (int ob = 0; ob < 8; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float dv = yacc[ob][r] - mean; sq = fmaf(dv, dv, sq); }
+      {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sq), __float_as_uint(sq), false, false);
+        sq = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+      }
+      const float var = sq * (1.f / 256.f);
+      if (half == 0 && row < M && !(var <= 3.0e38f)) atomicAdd(nonfinite, 1);      // one count per row whose variance is not finite
+      const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+      for (int ob = 0; ob < 8; ++ob) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c0 = ob * 32 + 8 * g + 4 * half;
+          const f32x4 gg = *reinterpret_cast<const f32x4*>(pre_s + 1024 + c0);
+          const f32x4 be = *reinterpret_cast<const f32x4*>(pre_s + 1280 + c0);
+          f32x4 y;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] = fmaf((yacc[ob][4 * g + e] - mean) * rstd, gg[e], be[e]);
+          if (row < M) *reinterpret_cast<f32x4*>(Y + (size_t)row * ldy + c0) = y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if constexpr (!PRE) {
     __syncthreads();                                                  // drain everything before the ring is reused as staging
 
     // ---------------- epilogue: Y^T -> LDS (own 32-row region), then row-major + b2 + x, LayerNorm, store
@@ -370,7 +419,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
 #pragma unroll
     for (int rr = 0; rr < 32; ++rr) {
       const int grow = rb * 128 + wave * 32 + rr;
-      xpre[rr] = (!PRE && grow < M) ? *reinterpret_cast<const f32x4*>(X + (size_t)grow * ldx + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      xpre[rr] = grow < M ? *reinterpret_cast<const f32x4*>(X + (size_t)grow * ldx + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int ob = 0; ob < 8; ++ob)
@@ -388,7 +437,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
         const int grow = rb * 128 + wave * 32 + rr;
         if (grow >= M) break;
         f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rr * FF_CP + col);
-        if (!PRE) { v += bb; v += xpre[rr]; }               // PRE: b2 and the residual are in the accumulators already
+        v += bb; v += xpre[rr];
         const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
         const f32x4 dv = v - mean;
         const float var = wave_sum(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2] + dv[3] * dv[3]) * (1.f / 256.f);
@@ -441,10 +490,10 @@ int launch_ffn_fused_pre(const float* O, int ldo, const float* R, int ldr, const
   } else {
     const int n_rb = (M + 127) / 128;
     const int grid = n_rb < 256 ? n_rb : 256;
-    const size_t shm = FF_RING_BYTES + (size_t)(F + 1024) * sizeof(float);
+    const size_t shm = FF_RING_BYTES + (size_t)(F + 1536) * sizeof(float);
     static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_bf16x6_kernel<1>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    (int)(FF_RING_BYTES + (3072 + 1024) * sizeof(float))) == hipSuccess;
+                                                    (int)(FF_RING_BYTES + (3072 + 1536) * sizeof(float))) == hipSuccess;
     if (!attr_ok) return CTRLSIM_EINVAL;
     prof_before(PROF_GEMM, st);
     hipLaunchKernelGGL(ffn_fused_bf16x6_kernel<1>, dim3(grid), dim3(256), shm, st, O, ldo,
