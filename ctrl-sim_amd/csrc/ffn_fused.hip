@@ -82,7 +82,9 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
 
   // block i of the weight stream: W1 of hidden block i/2 (even i) or W2 of it (odd i); lives in ring slot i % FF_RING
   auto dma_block = [&](int i, int to_slot) {
-    const op_t* src = (PRE ? pa.Wop + (size_t)i * FF_BLK : ((i & 1) ? W2p : W1p) + (size_t)(i >> 1) * FF_BLK) + tid * 8;   // (called for blocks 0 and 1 only)
+    const op_t* src = (PRE ? pa.Wop : (i & 1) ? W2p : W1p) + tid * 8;   // (called for blocks 0 and 1 only)
+    if (PRE) asm volatile("" : "+v"(src));                            // (PRE: or the sixteen piece addresses are kept across the row-block loop — in scratch)
+    src += (size_t)(PRE ? i : (i >> 1)) * FF_BLK;
     op_t* dst = ring + to_slot * FF_BLK + wave_d * 64 * 8;            // wave-uniform LDS base (+ 16 B per lane)
 #pragma unroll
     for (int j = 0; j < FF_PIECES; ++j)
@@ -105,6 +107,35 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
     __builtin_amdgcn_s_barrier();
   };
 
+  // PRE / QP: all 32 loads of the wave's rows are requested before the first is converted (left to itself hipcc, at this kernel's register
+  // pressure, requests two, waits for them, converts, requests the next two: sixteen round trips to HBM per row block).  MODE 1 requests the
+  // NEXT row block's rows in front of its epilogue — the fragment registers are dead there — so that they arrive underneath the closing
+  // LayerNorm and the stores (s_memtime: the wait for the rows was 6.4 % of the mode)
+  constexpr bool ROWS_AHEAD = MODE == 1;
+  f32x4 raw[PRE ? 32 : 1];
+  // (the lane index goes through an opaque point in these helpers: hipcc otherwise keeps the loop-invariant 64-bit part of every row address
+  // across the row-block loop — in scratch at this register pressure, and a scratch reload in front of a batch of loads is a vmcnt(0))
+  auto issue_rows = [&](int rb_) {
+    int ln_ = lane;
+    if (PRE) asm volatile("" : "+v"(ln_));
+    const int r_ = rb_ * 128 + wave * 32 + (ln_ & 31);
+    const float* xp = X + ((size_t)(r_ < M ? r_ : M - 1) * ldx + (ln_ >> 5) * 8);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      raw[2 * ks] = *reinterpret_cast<const f32x4*>(xp + ks * 16);
+      raw[2 * ks + 1] = *reinterpret_cast<const f32x4*>(xp + ks * 16 + 4);
+    }
+  };
+  f32x4 rr[PRE ? 32 : 1];                                             // the residual rows, in the accumulator layout (below)
+  auto issue_residual = [&](int rb_) {
+    int ln_ = lane;
+    asm volatile("" : "+v"(ln_));
+    const int r_ = rb_ * 128 + wave * 32 + (ln_ & 31);
+    const float* rp = pa.R + ((size_t)(r_ < M ? r_ : M - 1) * pa.ldr + 4 * (ln_ >> 5));
+#pragma unroll
+    for (int i = 0; i < 32; ++i) rr[i] = *reinterpret_cast<const f32x4*>(rp + (i >> 2) * 32 + 8 * (i & 3));
+  };
+  if constexpr (ROWS_AHEAD) { issue_rows(blockIdx.x); issue_residual(blockIdx.x); }
   for (int rb = blockIdx.x; rb < n_rb; rb += gridDim.x) {
     // ---- this wave's 32 rows of x as split B-operand fragments: k-step ks covers k = 16 ks + 8 half .. + 7
     const int row = rb * 128 + wave * 32 + l31;
@@ -113,15 +144,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
     dma_block(1, 1);
     opx8 xT[16][NPL];
     if constexpr (PRE) {
-      // all 32 loads of the wave's rows are requested before the first is converted (left to itself hipcc, at this kernel's register
-      // pressure, requests two, waits for them, converts, requests the next two: sixteen round trips to HBM per row block)
-      const float* xp = X + (size_t)rowc * ldx + half * 8;
-      f32x4 raw[32];
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        raw[2 * ks] = *reinterpret_cast<const f32x4*>(xp + ks * 16);
-        raw[2 * ks + 1] = *reinterpret_cast<const f32x4*>(xp + ks * 16 + 4);
-      }
+      if constexpr (!ROWS_AHEAD) issue_rows(rb);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
@@ -145,10 +168,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
       // the residual rows + bo go straight into the accumulators of the leading product, in the accumulator layout — lane (l31, half) holds, of
       // row l31, the columns 32 ob + (r & 3) + 8 (r >> 2) + 4 half — and in the scale of the Wo planes.  Requested BEHIND the barrier: out-block
       // ob is first needed by product ob, so all but the first of these loads land underneath the leading product's MFMAs
-      const float* rp = pa.R + (size_t)rowc * pa.ldr + 4 * half;
-      f32x4 rr[32];                                                   // (all requested before the first is used, like the rows above)
-#pragma unroll
-      for (int i = 0; i < 32; ++i) rr[i] = *reinterpret_cast<const f32x4*>(rp + (i >> 2) * 32 + 8 * (i & 3));
+      if constexpr (!ROWS_AHEAD) issue_residual(rb);  // (MODE 1: requested in front of the previous row block's epilogue, like the rows above)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ob = 0; ob < 8; ++ob)
@@ -366,6 +386,9 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
       // past the last pair's barrier, nobody reads the ring any more and no request is in flight.  (s_memtime: the LDS-staged row-major epilogue
       // below was 10.5 % of this mode, 23 000 ticks per row block against 8 000 for the in-register LayerNorm.)  Y may alias R or X: a wave
       // read all of its rows long ago.
+      issue_rows(rb + gridDim.x);                      // the next row block's rows (past the last one: a clamped row, never used)
+      issue_residual(rb + gridDim.x);                  // (rows of the NEXT row block: only this workgroup ever writes them, later)
+      __builtin_amdgcn_sched_barrier(0);
       float sum = 0.f;
 #pragma unroll
       for (int ob = 0; ob < 8; ++ob)
@@ -392,6 +415,9 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
       const float var = sq * (1.f / 256.f);
       if (half == 0 && row < M && !(var <= 3.0e38f)) atomicAdd(nonfinite, 1);      // one count per row whose variance is not finite
       const float rstd = 1.0f / sqrtf(var + 1e-5f);
+      int row_o = row;
+      asm volatile("" : "+v"(row_o));
+      float* const yrow = Y + (size_t)row_o * ldy;
 #pragma unroll
       for (int ob = 0; ob < 8; ++ob) {
 #pragma unroll
@@ -402,9 +428,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
           f32x4 y;
 #pragma unroll
           for (int e = 0; e < 4; ++e) y[e] = fmaf((yacc[ob][4 * g + e] - mean) * rstd, gg[e], be[e]);
-          if (row < M) *reinterpret_cast<f32x4*>(Y + (size_t)row * ldy + c0) = y;
+          if (row < M) *reinterpret_cast<f32x4*>(yrow + c0) = y;
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
     if constexpr (!PRE) {

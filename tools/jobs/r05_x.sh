@@ -1,0 +1,17 @@
+#!/bin/bash
+# Round 5, job X: PRE / QP rows in and out sixteen rows per wave instruction (v_permlane16_swap), next row block's rows requested in the epilogue
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05_x2; mkdir -p $O
+cd $R
+timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "outproj or ffn_fused" > $O/pytest_op.txt 2>&1; grep -a "passed\|failed\|Error" $O/pytest_op.txt | tail -3
+for v in new H3 new H3; do
+  if [ $v = new ]; then L=$R/ctrl-sim_amd/csrc/libctrlsim_hip.so; else L=$R/tools/microbench/variants/all_$v.so; fi
+  echo "$v: $(CTRLSIM_LIB=$L timeout 300 python tools/microbench/fusion_proxies.py 2>&1 | grep 'BUILT' | tr '\n' ' ')" | tee -a $O/pre_timing.txt
+done
+for v in new H3 new H3 new H3; do
+  if [ $v = new ]; then L=$R/ctrl-sim_amd/csrc/libctrlsim_hip.so; else L=$R/tools/microbench/variants/all_$v.so; fi
+  CTRLSIM_LIB=$L timeout 600 python bench.py --scenarios 408 --steps 4 --warmup 1 --no-cpu-baseline --spot-check 2 --no-class-profile > $O/b.json 2> $O/bench_err.txt
+  python - $O/b.json $v <<'PY' | tee -a $O/ab.txt
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[2], round(d["value"]), round(d["ms_per_step"],1), d["parity_spot_check"]["identical"])
+PY
+done
