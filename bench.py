@@ -332,7 +332,7 @@ def main():
         # every file of the round: FETCH_SIZE x 2 (gfx950 tallies its 128-byte read requests at 64 B — calibrated in round 5 on known-byte
         # launches of every access pattern and of each hot kernel: profiles/r05_pmc_calibration.json) + WRITE_SIZE x 1.
         pmc, pmc_src = {}, None
-        for cand in ("r05v_pmc_traffic.json", "r05_pmc_traffic.json"):
+        for cand in ("r05w_pmc_traffic.json", "r05_pmc_traffic.json"):
             pmc_path = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(pmc_path):
                 pmc, pmc_src = json.load(open(pmc_path)), "profiles/" + cand

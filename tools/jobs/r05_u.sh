@@ -1,10 +1,10 @@
 #!/bin/bash
 # Round 5, job U: the shipped default (option 3 = 2): new tests, driver command, kernel trace, per-kernel PMC traffic
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05_u; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05_u2; mkdir -p $O
 cd $R
-timeout 1500 python -m pytest tests/test_gpu_model.py tests/test_gpu_sim_ctx.py -m gpu -x -q -k "fusion or sliding_window" > $O/pytest_new.txt 2>&1; tail -3 $O/pytest_new.txt
+timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest.txt 2>&1; tail -3 $O/pytest.txt
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_style.json 2> $O/bench_driver_style.err; tail -c 200 $O/bench_driver_style.json; echo
-( cd /tmp && export TMPDIR=/tmp && cd $R && timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o r05v --output-format csv -- python bench.py --scenarios 204 --steps 2 --warmup 1 --spot-check 0 --no-class-profile --no-cpu-baseline > $O/prof_bench.json 2> $O/prof.err )
+( cd /tmp && export TMPDIR=/tmp && cd $R && timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o r05w --output-format csv -- python bench.py --scenarios 204 --steps 2 --warmup 1 --spot-check 0 --no-class-profile --no-cpu-baseline > $O/prof_bench.json 2> $O/prof.err )
 find $O/prof -name "*_kernel_trace.csv" -delete
 timeout 900 python bench.py --scenarios 204 --steps 2 --warmup 1 --spot-check 0 --no-class-profile > $O/unprofiled_bench.json 2> $O/unprofiled.err
 timeout 1500 bash tools/pmc_traffic.sh $O/pmc -- python bench.py --scenarios 204 --steps 2 --warmup 1 --spot-check 0 --no-class-profile --no-cpu-baseline 2>&1 | tail -8
