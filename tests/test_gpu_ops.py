@@ -656,6 +656,38 @@ def test_outproj_layernorm_ffn_as_one_kernel(M, F):
                                             p(Y), 256, M, 3104, _lib.stream_ptr()) != 0          # beyond the LDS the bias tables fit in
 
 
+@pytest.mark.parametrize("M", [1, 129, 33000])
+def test_outproj_layernorm_ffn_with_strided_rows_and_output_over_the_attention_rows(M):
+    """ctrlsim_ffn_fused_pre with three different leading dimensions (attention output 320, residual 288, output 272 floats) and with the
+    output written over the ATTENTION rows (the other aliasing the kernel allows): a wave reads all of its rows before its first store, the
+    rows of the next row block it requests ahead are not written by anybody else.  One row, one row past a row block, many row blocks per
+    workgroup (33 000 rows = 258 row blocks on 256 persistent workgroups: the ahead-of-time requests of the last trip are clamped)."""
+    from ctrlsim_amd.pack import ffn_planes_pre
+    if _lib.lib().ctrlsim_get_option(0) != 1:
+        pytest.skip("two-fp16-plane scheme only")
+    F = 256
+    g = torch.Generator().manual_seed(M)
+    Ob = torch.randn(M, 320, generator=g).to(DEV); Rb = torch.randn(M, 288, generator=g).to(DEV)
+    Wo = torch.randn(256, 256, generator=g) * 0.07; W1 = torch.randn(F, 256, generator=g) * 0.08; W2 = torch.randn(256, F, generator=g) * 0.05
+    bo, g0, be0, b2, gam, bet = (torch.randn(256, generator=g).to(DEV) * s for s in (0.3, 1.0, 0.2, 0.3, 1.0, 0.3))
+    b1 = torch.randn(F, generator=g).to(DEV) * 0.3
+    dev = lambda a: torch.from_numpy(a.view(np.int16).copy()).to(DEV)
+    wod, w1d, w2d = (dev(a) for a in ffn_planes_pre(Wo.numpy(), W1.numpy(), W2.numpy(), 1))
+    O, R = Ob[:, :256], Rb[:, :256]
+    x1 = torch.nn.functional.layer_norm(R.double() + O.double() @ Wo.to(DEV).double().T + bo.double(), (256,), g0.double(), be0.double(), 1e-5)
+    h = torch.relu(x1 @ W1.to(DEV).double().T + b1.double())
+    ref = torch.nn.functional.layer_norm(x1 + h @ W2.to(DEV).double().T + b2.double(), (256,), gam.double(), bet.double(), 1e-5)
+    p = _lib.ptr
+    Yb = torch.full((M, 272), float("nan"), device=DEV)
+    run = lambda Yp, ldy: _lib.check(_lib.lib().ctrlsim_ffn_fused_pre(p(Ob), 320, p(Rb), 288, p(wod), p(bo), p(g0), p(be0), p(w1d), p(b1), p(w2d), p(b2),
+                                                                      p(gam), p(bet), Yp, ldy, M, F, _lib.stream_ptr()), "ffn_fused_pre")
+    run(p(Yb), 272)
+    assert (Yb[:, :256].double() - ref).abs().max().item() < 5e-5 and torch.isnan(Yb[:, 256:]).all()
+    keep = Ob[:, 256:].clone()
+    run(p(Ob), 320)                                           # output over the attention rows
+    assert torch.equal(Ob[:, :256], Yb[:, :256]) and torch.equal(Ob[:, 256:], keep)
+
+
 @pytest.mark.parametrize("M", [128, 1000, 37, 4133, 40000])
 def test_outproj_layernorm_query_projection_as_one_kernel(M):
     """x1 = LayerNorm0(R + O Wo^T + bo), q = x1 Wq^T + bq (ctrlsim_outproj_ln_q): nn.TransformerDecoderLayer's self_attn.out_proj + norm1 and
