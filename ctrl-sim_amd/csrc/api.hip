@@ -161,6 +161,9 @@ int ctrlsim_bind_options(const int* values) {
   g_has_bound_options = values != nullptr;
   if (values)
     for (int k = 0; k < OPT_COUNT; ++k) g_bound_options[k] = values[k];
+  // the operand split is NOT an option of a table: it is bound with the weight planes / K/V images / workspace it was built for
+  // (ctrlsim_bind); a table entry for it would dispatch the other scheme's kernels on this engine's images
+  g_bound_options[OPT_SPLIT] = -1;
   return CTRLSIM_OK;
 }
 int ctrlsim_get_option(int key) { return (key < 0 || key >= OPT_COUNT) ? CTRLSIM_EINVAL : ctrlsim_option(key); }

@@ -1,6 +1,8 @@
 // Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the CtRL-Sim rollout path.
-// Wavefront = 64 lanes; fp32-input MFMA (v_mfma_f32_32x32x2_f32) is the matrix instruction used
-// throughout: token parity with the reference's fp32 path rules out bf16/fp8 operands.
+// Wavefront = 64 lanes.  The shipped matrix kernels evaluate every fp32 product as partial products of 16-bit operand planes on
+// v_mfma_f32_32x32x16_f16 / _bf16 with fp32 accumulation (split.h: two fp16 planes / three products, or three bf16 planes / six):
+// token parity with the reference's fp32 path rules out plain bf16 / fp8 operands, and the f32-input MFMA (v_mfma_f32_32x32x2_f32,
+// gemm.hip / attention.hip) tops out at 157 TFLOP/s — it stays built as the run-time selectable A/B family of the tests.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -388,6 +388,9 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
       // read all of its rows long ago.
       issue_rows(rb + gridDim.x);                      // the next row block's rows (past the last one: a clamped row, never used)
       issue_residual(rb + gridDim.x);                  // (rows of the NEXT row block: only this workgroup ever writes them, later)
+      // (Round 6: guarding the two requests with `rb + gridDim.x < n_rb` — so that nothing is requested past the last row block — costs the
+      // mode 644 bytes of scratch per lane at this register pressure (A 232 -> 256 + spills): not done.  Past the last block the lanes read
+      // row M - 1 on a clamped address, possibly while its owner stores it; the values are never used: see the ALIASING RULE at the launcher.)
       __builtin_amdgcn_sched_barrier(0);
       float sum = 0.f;
 #pragma unroll
@@ -502,6 +505,10 @@ int launch_ffn_fused_bf16x6(const float* X, int ldx, const void* W1p, const floa
 
 // y = LayerNorm3(x1 + W2 relu(W1 x1 + b1) + b2) with x1 = LayerNorm0(R + Wo O + bo): the attention out-projection + residual + LayerNorm
 // and the feed-forward block behind it as ONE kernel (PRE above).  O = the attention output rows, R = the residual rows (y may alias R or O);
+// ALIASING RULE: a wave reads all of its 32 rows (O and R) before it stores any, and only the wave that owns a row reads or writes it —
+// with one exception that callers may rely on being harmless: lanes whose row is >= M (the tail of the LAST row block, and MODE 1's request
+// for the row block past a workgroup's last one) read row M - 1 instead (clamped address), possibly while its owner stores it; what they
+// read only feeds accumulator columns that are never stored or counted.
 // Wop = pack.py:row_blocks(Wo) (eight 32-column blocks), W1q / W2p = pack.py:ffn_planes_pre.  Two-plane scheme only (CTRLSIM_EINVAL otherwise).
 int launch_ffn_fused_pre(const float* O, int ldo, const float* R, int ldr, const void* Wop, const float* bo, const float* g0,
                          const float* be0, const void* W1q, const float* b1, const void* W2p, const float* b2, const float* gamma,

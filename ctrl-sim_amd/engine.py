@@ -47,6 +47,7 @@ class HipModel:
 
     def __init__(self, cfg, weights: dict, device="cuda:0"):
         self.cfg = cfg
+        check_supported(cfg)                    # a cfg of another network (mask / token / map options) is refused by name
         self.dims = Dims(cfg)
         self.device = torch.device(device)
         self.lib = _lib.lib()
@@ -205,6 +206,7 @@ class RolloutEngine:
         # override the process defaults for this engine's launches only — two engines with different options take turns in one process
         self._options = (C.c_int * int(self.lib.ctrlsim_option_count()))(*([-1] * int(self.lib.ctrlsim_option_count())))
         for k, v in (options or {}).items():
+            self._check_option_key(k)
             self._options[int(k)] = int(v)
         self.scheme = 0 if (split == "bf16x6" or (split == "auto" and self.model.split_fallback)) else 1
         self._unchecked = []                    # fresh-from-reset runs since the last check_finite: (steps, s0, s1)
@@ -289,8 +291,18 @@ class RolloutEngine:
         _lib.check(self.lib.ctrlsim_bind(int(self.scheme), self.guard.data_ptr()), "bind")
         _lib.check(self.lib.ctrlsim_bind_options(self._options), "bind_options")
 
+    _OPT_SPLIT = 4                              # include/ctrlsim.h: the operand split is bound with the images it was built for
+
+    def _check_option_key(self, key):
+        if int(key) == self._OPT_SPLIT:
+            raise ValueError("option 4 (operand split) is not an engine option: the weight planes, K/V images and workspace of an engine are "
+                             "laid out for ONE split — choose it with RolloutEngine(split='f16x3' | 'bf16x6' | 'auto')")
+        if not 0 <= int(key) < len(self._options):
+            raise ValueError(f"unknown kernel option {key} (include/ctrlsim.h: 0 .. {len(self._options) - 1})")
+
     def set_option(self, key, value):
         """Kernel option `key` (include/ctrlsim.h: ctrlsim_set_option) for THIS engine's launches; value None = inherit the process default."""
+        self._check_option_key(key)
         self._options[int(key)] = -1 if value is None else int(value)
         self._bind()
 

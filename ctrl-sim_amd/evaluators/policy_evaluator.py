@@ -275,7 +275,12 @@ class PolicyEvaluator:
         evaluators/evaluator.py:160-193: inverse bicycle model against the next logged state) computed for the whole batch in NumPy
         float64 — the same code, hence the same bits, as the per-scenario route — and one simulator step for the batch.  The statistics
         are the per-scenario route's (update_running_statistics on the same arrays): the metric dict is identical to it (1e-12: the
-        accumulation order of floating-point sums), at the engine's throughput instead of a host round trip per vehicle and step."""
+        accumulation order of floating-point sums), at the engine's throughput instead of a host round trip per vehicle and step.
+
+        What this route does NOT do: it never drives the `policy` OBJECT — no `policy.reset()` / `update_state()` / `predict()` calls, so
+        the policy's own buffers (`policy.states`, `policy.actions`, `policy.rtgs`, ...) keep whatever an earlier per-scenario session
+        left in them; read the rollouts from `last_vehicle_data_dict` / the metric dict, or set `cfg.eval.batched = False` for the
+        reference's per-scenario loop.  One RolloutEngine (workspace of `cfg.eval.batch_contexts` contexts) serves all chunks."""
         from .. import discretize as dz
         from ..engine import RolloutEngine
         self.reset()
@@ -296,9 +301,13 @@ class PolicyEvaluator:
         tilt = (pol.goal_tilt, pol.veh_veh_tilt, pol.veh_edge_tilt) if pol.tilt_dict["tilt"] else (0.0, 0.0, 0.0)
         cap = int(self.cfg.eval.get("batch_scenarios", 256))
         self.batched_scenes = 0
-        for (N, _), items in groups.items():
-            for c0 in range(0, len(items), cap):
-                self._roll_batch(items[c0:c0 + cap], N, tilt, dz, RolloutEngine, w, T, T1, hsteps)
+        self._batch_engine = None
+        try:
+            for (N, _), items in groups.items():
+                for c0 in range(0, len(items), cap):
+                    self._roll_batch(items[c0:c0 + cap], N, tilt, dz, RolloutEngine, w, T, T1, hsteps)
+        finally:
+            self._batch_engine = None                          # the workspace goes back to torch's allocator with the evaluation
         return self.compute_metrics()
 
     def _roll_batch(self, items, N, tilt, dz, RolloutEngine, w, T, T1, hsteps):
@@ -327,9 +336,14 @@ class PolicyEvaluator:
             s2.eval_order = np.array(to_eval)[np.argsort(np.array(lengths))[::-1]].astype(np.int32)
             scns.append(s2); goal_dicts.append(gd); evals.append(to_eval)
             ctrl[k, to_eval] = True
-        eng = RolloutEngine(pol.model.cfg, pol.model.weights, pol.model.device, max_ctx=int(self.cfg.eval.get("batch_contexts", 256)),
-                            seed=int(self.cfg.eval.seed), tilt=tilt, temperature=pol.action_temperature, nucleus=pol.nucleus_sampling,
-                            top_p=pol.nucleus_threshold, model=pol.model.hip, lanes=1)
+        # ONE engine for every group / chunk of the evaluation (its workspace — the expensive allocation — depends on the model batch only;
+        # load_scenarios re-sizes the per-scenario tensors for each batch)
+        eng = getattr(self, "_batch_engine", None)
+        if eng is None:
+            eng = self._batch_engine = RolloutEngine(pol.model.cfg, pol.model.weights, pol.model.device,
+                                                     max_ctx=int(self.cfg.eval.get("batch_contexts", 256)), seed=int(self.cfg.eval.seed), tilt=tilt,
+                                                     temperature=pol.action_temperature, nucleus=pol.nucleus_sampling,
+                                                     top_p=pol.nucleus_threshold, model=pol.model.hip, lanes=1)
         eng.load_scenarios(scns, steps=T)
         dev = eng.device
         exist = np.zeros((S, N, T1))
@@ -357,7 +371,8 @@ class PolicyEvaluator:
                 toks = eng.act_now.cpu().numpy()
                 bad = eng.nonfinite()
             if bad:
-                raise FloatingPointError(f"{bad} guard events at step {t} of the batched evaluation (csrc/split.h: activation range)")
+                raise FloatingPointError(f"{bad} guard events at step {t} of the batched evaluation (csrc/split.h: activation range; csrc/sim.hip: "
+                                         f"contact table) in the batch of scenes {[int(getattr(it[0], 'index', -1)) for it in items]}")
             speeds[:, :, t] = speed
             own_last[t] = eng.own_ctx[S - 1].cpu().numpy()
             a = np.zeros((S, N)); st = np.zeros((S, N)); alive = np.ones((S, N), bool)

@@ -10,13 +10,14 @@ from __future__ import annotations
 
 import numpy as np
 
-from ..spec import Dims
+from ..spec import Dims, check_supported
 from .. import weights as _weights
 
 
 class CtRLSim:
     def __init__(self, cfg, weights=None, seed=0, device="cuda:0"):
         self.cfg = cfg
+        check_supported(cfg)                    # e.g. a checkpoint trained with attend_own_return_action=True: another mask
         self.dims = Dims(cfg)
         self.weights = weights if weights is not None else _weights.generate(self.dims, seed)
         self.device = device
@@ -30,6 +31,7 @@ class CtRLSim:
         ck = torch.load(path, map_location="cpu", weights_only=False)
         if cfg is None:
             cfg = ck["hyper_parameters"]["cfg"]
+        check_supported(cfg)
         d = Dims(cfg)
         return cls(cfg, _weights.from_state_dict(d, ck["state_dict"]), device=device)
 

@@ -119,6 +119,40 @@ def make_cfg(**overrides):
     return cfg
 
 
+# Model options the HIP path is built for ("Frozen constants": cfgs/model/base.yaml:10-19, ctrl_sim.yaml:4-9).  A
+# checkpoint whose cfg says otherwise describes a DIFFERENT network (another mask, other token rows, no map tokens): the kernels would run
+# and return logits of the wrong model, so the model layer refuses it by name instead.
+_FROZEN_MODEL_FLAGS = (
+    # (key, required value, what the other value changes in the reference)
+    ("attend_own_return_action", False, "the decoder mask hides other agents' past return / action tokens (utils/train_utils.py:114-129)"),
+    ("use_map", True, "no MapEncoder, no polyline tokens in the scene encoder (modules/encoder.py:18,155)"),
+    ("encode_initial_state", True, "no scene encoder memory at all (modules/encoder.py:84,111,135,159)"),
+    ("no_actions", False, "action embeddings are dropped from the token rows (modules/encoder.py:129)"),
+    ("local_frame_predictions", False, "future-state targets in the agent frame (models/ctrl_sim.py:114)"),
+    ("ctg_plus_plus", False, "the diffusion baseline is another model (models/ctg_plus_plus.py)"),
+    ("hidden_dim", 256, "the kernels are built for 256-wide rows (csrc/common.h: DM)"),
+    ("num_heads", 8, "the kernels are built for 8 heads of 32 (csrc/common.h: NHEAD, HD)"),
+    ("num_reward_components", 3, "three return components per token (csrc/sample.hip)"),
+)
+
+
+def check_supported(cfg):
+    """Raise NotImplementedError naming every model option of `cfg` the HIP path does not implement (see _FROZEN_MODEL_FLAGS).
+    `predict_rtg` must be on for the CtRL-Sim model and is ignored (as in the reference configs) for the IL / Trajeglish / DT baselines;
+    at most one of il / trajeglish / decision_transformer may be set."""
+    m = cfg.model
+    bad = [f"model.{k} = {m.get(k)!r} (built for {want!r}: {why})" for k, want, why in _FROZEN_MODEL_FLAGS
+           if k in m and m.get(k) != want]
+    variants = [k for k in ("il", "trajeglish", "decision_transformer") if bool(m.get(k, False))]
+    if len(variants) > 1:
+        bad.append(f"model.{' and model.'.join(variants)} are set together (one baseline at a time: cfgs/model/{{il,trajeglish,dt}}.yaml)")
+    if not variants and not bool(m.get("predict_rtg", True)):
+        bad.append("model.predict_rtg = False with the CtRL-Sim token layout (the rollout's first pass reads the return head: "
+                   "policies/autoregressive_policy.py:201-221)")
+    if bad:
+        raise NotImplementedError("the HIP rollout path does not implement this model configuration:\n  " + "\n  ".join(bad))
+
+
 class Dims:
     """Shape constants of one model context, derived from a cfg (SURVEY.md conventions)."""
 

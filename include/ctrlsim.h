@@ -427,7 +427,8 @@ int* ctrlsim_bound_guard(void);
 /* Per-engine option table (round 5): values = ctrlsim_option_count() ints in host memory (copied); an entry >= 0 overrides the process
  * default of ctrlsim_set_option for every launch until the next ctrlsim_bind_options, -1 inherits it; NULL = the process defaults.
  * Re-asserted by an engine at the top of every run like ctrlsim_bind: two engines with different kernel options take turns in one process.
- * ctrlsim_get_option = the value launches would use now. */
+ * The operand split (key 4) is the exception: it belongs to ctrlsim_bind, with the weight planes / K/V images / workspace laid out for it;
+ * a table's entry for key 4 is ignored.  ctrlsim_get_option = the value launches would use now. */
 int ctrlsim_option_count(void);
 int ctrlsim_bind_options(const int* values);
 int ctrlsim_get_option(int key);

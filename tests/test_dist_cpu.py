@@ -77,18 +77,21 @@ def test_shard_ids_partition(world):
         assert all(g % world == r for g in sh)
 
 
-def _bench_dry(world, scenarios_per_rank, extra_env=None, extra_args=()):
-    """bench.py --dry-run launched EXACTLY as the driver launches N > 1 (python -m torch.distributed.run ... bench.py --gpus N ...)."""
+def _bench_dry(world, scenarios_per_rank, extra_env=None, extra_args=(), launcher=True, tmp="/tmp"):
+    """bench.py --dry-run launched EXACTLY as the driver launches N > 1 (python -m torch.distributed.run ... bench.py --gpus N ...), or —
+    launcher=False — as plain `python bench.py --gpus N`, which must start the N ranks itself.  Returns (detail dict, wall seconds)
+    after checking the ONE stdout line: short enough for the driver's parser, valid JSON, naming the detail file."""
     import json
     import subprocess
     import sys
     import time
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    detail = os.path.join(str(tmp), f"bench_detail_dry_{world}_{int(launcher)}_{os.getpid()}.json")
     args = ["bench.py", "--gpus", str(world), "--dry-run", "--scenarios", str(scenarios_per_rank), "--agents", "4", "--polylines", "8",
-            "--steps", "3", "--warmup", "1", "--rollout-steps", "20", *extra_args]
+            "--steps", "3", "--warmup", "1", "--rollout-steps", "20", "--detail-file", detail, *extra_args]
     cmd = [sys.executable] + (["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-                               "--master-port", str(port)] if world > 1 else []) + args
+                               "--master-port", str(port)] if (world > 1 and launcher) else []) + args
     env = dict(os.environ, OMP_NUM_THREADS="1", **(extra_env or {}))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -97,7 +100,62 @@ def _bench_dry(world, scenarios_per_rank, extra_env=None, extra_args=()):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                     # ONE JSON line, from rank 0
-    return json.loads(lines[0]), time.time() - t0
+    assert r.stdout.strip().splitlines()[-1] == lines[0] and len(lines[0]) < 4096     # the LAST stdout line, < 4 KB (round 5's was 27 KB)
+    short = json.loads(lines[0])
+    assert short["n_gpus"] == world and short["detail_file"] == detail
+    with open(detail) as f:
+        out = json.load(f)
+    os.remove(detail)
+    assert out["n_gpus"] == short["n_gpus"] and out["agent_steps_counted"] == short["agent_steps_counted"]
+    return out, time.time() - t0
+
+
+def test_bench_gpus_flag_means_n_ranks_without_a_launcher():
+    """`python bench.py --gpus 8` with no torchrun around it starts 8 ranks itself (round-5 review: it used to run ONE rank and print
+    n_gpus 1), and a --gpus that disagrees with the launcher's world size is refused."""
+    import subprocess
+    import sys
+    out, _ = _bench_dry(8, 3, launcher=False)
+    assert out["n_gpus"] == 8 and out["agent_steps_counted"] == 3 * 4 * 20 * 8
+    assert "world 8" in out["config"]["collective"] and len(out["config"]["rank_elapsed_s"]["per_rank"]) == 8
+    assert out["config"]["scenario_ids_rank0"] == [0, 8, 16]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--dry-run", "--scenarios", "2", "--agents", "4", "--polylines", "8", "--steps", "1"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE = 1" in r.stderr
+
+
+def test_bench_short_line_of_a_full_report_stays_under_the_limit():
+    """bench.short_line on a detail dict as large as round 5's (per-kernel rows of both streams, 16 per-class attention rows, satellites,
+    long notes): < 4 KB, valid JSON, carries the contract's fields + roofline of the dominant kernel + cpu_baseline."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    row = lambda kind, share: {"kernel": "x" * 300, "kind": kind, "achieved": 333.3333333, "frac": 0.4000001, "unit": "TFLOP/s", "avg_launch_ms": 1.234567,
+                               "launches": 1234, "time_share_of_step": share, "algorithmic_hbm_bytes_per_launch": 1.23456789e9, "traffic": 1.3e9,
+                               "hbm_rate_at_algorithmic_bytes_TBps": 2.0}
+    detail = {"metric": "agent-steps/sec (closed-loop rollout), 64 agents x 90 steps", "value": 142631.123456, "unit": "agent-steps/s", "n_gpus": 8, "steps": 20,
+              "warmup": 5, "ms_per_step": 4137.123456, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype_short": "f32 (f16x3 split-operand MFMA, fp32 accumulate)",
+              "dtype": "y" * 200, "data": "synthetic",
+              "config": {"workload_tag": "BASELINE.json configs[2] per GPU: 2048 synthetic scenarios/GPU x 64 agents x 90 steps, 512 polylines, CtRL-Sim base model (random init)",
+                         "workload": "w" * 600, "scenarios_per_gpu": 2048, "agents": 64, "rollout_steps": 90, "polylines": 512, "model_batch_contexts": 1024, "lanes": 2,
+                         "parallelism": "scenario-sharded x8", "rank_elapsed_s": {"per_rank": [80.0] * 8}},
+              "roofline": {"bound": "mfma", "peak": 833.3333, "unit": "TFLOP/s", "frac": 0.33, "kernels": [row("ffn_fused", 0.27), row("attention_causal", 0.2)] + [row("linear_plain", 0.01)] * 12,
+                           "kernels_on_side_streams": [row("ffn_fused", 0.01)] * 14, "causal_attention_by_size_class": [{"n": "z" * 200}] * 16,
+                           "end_to_end": {"achieved": 224.3, "frac": 0.27}, "note": "n" * 3000},
+              "cpu_baseline": {"value": 10.9, "unit": "agent-steps/s", "cores": 64, "kind": "port", "sample": "s" * 500, "sample_short": "3 scenarios x 64 agents x 3 steps (126 focal-group steps, 61.0 s, oracle port, 64 threads)", "note": "n" * 600},
+              "parity_spot_check": {"identical": True, "note": "n" * 300}, "rollout_metrics": {"goal": 0.1}}
+    assert len(json.dumps(detail)) > 20000
+    line = json.dumps(bench.short_line(detail, "bench_detail.json"))
+    assert len(line) < 2048 < bench.SHORT_LINE_LIMIT
+    s = json.loads(line)
+    assert s["value"] == pytest.approx(142631.1, rel=1e-6) and s["roofline"]["kernel"] == "ffn_fused" and s["roofline"]["frac"] == pytest.approx(0.4, rel=1e-3)
+    assert s["roofline"]["bound"] == "mfma" and s["roofline"]["traffic"] == pytest.approx(1.3e9) and s["roofline"]["attention_causal_frac"] is not None
+    assert s["cpu_baseline"] == {"value": 10.9, "unit": "agent-steps/s", "cores": 64, "kind": "port", "sample": detail["cpu_baseline"]["sample_short"]}
+    assert s["config"]["workload"].startswith("BASELINE.json configs[2]") and "model" not in s["config"] and s["dtype"].startswith("f32")
 
 
 def test_bench_rank_flow_dry_run_world_8():

@@ -15,15 +15,33 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _bench(extra_env, *args):
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     env = dict(os.environ, **extra_env)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--scenarios", "6", "--steps", "2", "--warmup", "0",
                         "--agents", "12", "--polylines", "40", "--rollout-steps", "8", "--max-ctx", "32", "--no-cpu-baseline",
-                        "--spot-check", "2", *args], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+                        "--spot-check", "2", "--detail-file", os.path.join(ROOT, "gpurun_out", "bench_detail_test.json"), *args], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+    return _short_and_detail(r.stdout)
+
+
+def _short_and_detail(stdout):
+    """The run's ONE stdout line (what the driver parses: short, complete) and, returned, the detail file it names."""
+    lines = [ln for ln in stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), stdout[-2000:]       # nothing but the line on stdout
+    assert len(lines[0]) < 4096, len(lines[0])
+    short = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "parity_spot_check", "detail_file"):
+        assert k in short, k
+    assert "workload" in short["config"] and "model" not in short["config"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in short["roofline"], k
+    with open(os.path.join(ROOT, short["detail_file"])) as f:
+        detail = json.load(f)
+    assert short["value"] == pytest.approx(detail["value"], rel=1e-5) and short["n_gpus"] == detail["n_gpus"]
+    assert short["parity_spot_check"]["identical"] == detail["parity_spot_check"]["identical"]
+    return detail
 
 
 def test_bench_collective_runs_through_rccl_at_world_size_one():
@@ -51,11 +69,12 @@ def test_bench_at_world_size_two_on_the_one_gpu_that_exists():
     count both ranks, rank 0 alone prints the JSON line and both ranks exit cleanly (the reference's equivalent is a merge-less file
     partition, evaluators/policy_evaluator.py:466-490,578-593)."""
     import socket
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     common = ["--steps", "1", "--warmup", "0", "--agents", "12", "--polylines", "40", "--rollout-steps", "8", "--max-ctx", "32",
-              "--no-cpu-baseline", "--spot-check", "2"]
+              "--no-cpu-baseline", "--spot-check", "2", "--detail-file", os.path.join(ROOT, "gpurun_out", "bench_detail_test2.json")]
     env = dict(os.environ, CTRLSIM_BENCH_DEBUG_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -63,9 +82,7 @@ def test_bench_at_world_size_two_on_the_one_gpu_that_exists():
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scenarios", "3", *common],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])            # rank 1 left cleanly too
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]                                  # rank 0 only
-    two = json.loads(lines[0])
+    two = _short_and_detail(r.stdout)                                         # rank 0 only
     one = _bench({}, "--scenarios", "6", "--steps", "1")                      # ids 0..5 = the union of rank 0's (0, 2, 4) and rank 1's (1, 3, 5)
     assert two["n_gpus"] == 2 and two["scaling"] == "weak" and "gloo" in two["config"]["collective"]
     assert two["config"]["workload"].startswith("3 synthetic") and two["config"]["scenarios_per_gpu"] == 3

@@ -209,3 +209,34 @@ def test_real_time_reward_policy_starts_from_the_preprocessed_rtgs():
     with pytest.raises(ValueError):
         ev.update_vehicle_data_dict(0, vehs, {i: ev.initialize_vehicle_data_dict(NS(getWidth=lambda: 2.0, getLength=lambda: 4.5), goal[i])
                                               for i in range(2)}, goal, {0: 5.0, 1: 4.0}, gt, None)
+
+
+@pytest.mark.parametrize("key,value", [("attend_own_return_action", True), ("use_map", False), ("encode_initial_state", False), ("no_actions", True),
+                                       ("local_frame_predictions", True), ("ctg_plus_plus", True), ("hidden_dim", 128), ("num_heads", 4),
+                                       ("num_reward_components", 2), ("predict_rtg", False)])
+def test_model_layer_refuses_configurations_it_does_not_implement(key, value):
+    """Round-5 review: the model layer accepted any cfg silently.  Every option of cfgs/model/base.yaml that changes the NETWORK and that the
+    HIP path freezes is refused by name — by spec.check_supported, which HipModel and CtRLSim (constructor and
+    load_from_checkpoint) call before touching a weight.  (utils/train_utils.py:114-129, modules/encoder.py:18,84,129)."""
+    from ctrlsim_amd import spec
+    from ctrlsim_amd.models.ctrl_sim import CtRLSim
+    cfg = spec.make_cfg(**{"model__" + key: value})
+    with pytest.raises(NotImplementedError, match="model." + key):
+        spec.check_supported(cfg)
+    with pytest.raises(NotImplementedError, match="model." + key):
+        CtRLSim(cfg, weights={})
+    with pytest.raises(NotImplementedError):
+        import torch, tempfile, os
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "ck.ckpt")
+            torch.save({"state_dict": {}, "hyper_parameters": {"cfg": cfg}}, path)
+            CtRLSim.load_from_checkpoint(path)
+
+
+def test_model_layer_accepts_the_shipped_configurations():
+    from ctrlsim_amd import spec
+    spec.check_supported(spec.make_cfg())
+    for v in ("il", "trajeglish", "decision_transformer"):            # cfgs/model/{il,trajeglish,dt}.yaml switch predict_rtg off
+        spec.check_supported(spec.make_cfg(**{"model__" + v: True, "model__predict_rtg": False, "model__predict_future_states": False}))
+    with pytest.raises(NotImplementedError, match="set together"):
+        spec.check_supported(spec.make_cfg(model__il=True, model__trajeglish=True))
