@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--spot-check", type=int, default=4, help="scenarios re-rolled alone after the timed region (bit-identity check; 0 = off)")
     ap.add_argument("--cpu-sample-scenarios", type=int, default=4)
     ap.add_argument("--cpu-sample-steps", type=int, default=4)
-    ap.add_argument("--cpu-sample-budget-s", type=float, default=60.0,
+    ap.add_argument("--cpu-sample-budget-s", type=float, default=40.0,
                     help="time box of the CPU sample: no further scenario is started once this much CPU time is spent (at least one runs)")
     ap.add_argument("--detail-file", type=str, default=os.path.join(ROOT, "bench_detail.json"),
                     help="everything that does not fit the one short stdout line: per-kernel rows, satellites, per-class attention, notes")
@@ -607,6 +607,12 @@ def _emit(out, detail_path):
         rel = None
     print("[bench detail] " + blob, file=sys.stderr)
     sys.stderr.flush()
+    # whatever native libraries still hold in C stdio buffers (RCCL prints its version banner to stdout through one, and it would
+    # otherwise be flushed at process exit, i.e. AFTER the line) goes out first: the JSON line must be the LAST line of stdout
+    try:
+        C.CDLL(None).fflush(None)
+    except OSError:
+        pass
     line = json.dumps(short_line(out, rel))
     if len(line) >= SHORT_LINE_LIMIT:
         raise RuntimeError(f"bench line is {len(line)} bytes: the driver's parser needs < {SHORT_LINE_LIMIT}")

@@ -61,6 +61,7 @@ SIGNATURES = {
     "ctrlsim_metrics_pack": (I, [I, I, I, I, I, D, P, P, P, P, P, P, P, P, P, P]),
     "ctrlsim_gemm_nt": (I, [P, I, P, I, P, P, I, P, I, I, I, I, I, P]),
     "ctrlsim_gemm_nt_bf16x6": (I, [P, I, P, I, I, P, P, I, P, I, I, I, I, I, P, P, P]),
+    "ctrlsim_gemm256_rows": (I, [P, I, P, I, I, P, P, I, P, I, P]),
     "ctrlsim_gemm_nt_kv": (I, [P, I, P, I, I, P, P, I, I, I, I, P, I, I, I, P]),
     "ctrlsim_gemm_kv_blocks": (I, [P, I, P, P, P, I, I, I, P, I, I, I, P]),
     "ctrlsim_ffn_fused": (I, [P, I, P, P, P, P, P, P, P, I, I, I, P]),

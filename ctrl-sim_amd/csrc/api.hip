@@ -9,6 +9,7 @@ int launch_gemm_nt_bf16x6(const float*, int, const void*, int, int, const float*
                           int, int, const float*, const float*, hipStream_t);
 int launch_gemm_nt_bf16x6_kv(const float*, int, const void*, int, int, const float*, const float*, int, float*, int, int, int,
                              int, int, const float*, const float*, void*, int, int, int, int, int, hipStream_t);
+int launch_gemm256_rows(const float*, int, const void*, int, int, const float*, float*, int, const int*, int, hipStream_t);
 int launch_inproj_rs(const float*, int, const void*, const float*, float*, int, int, int, void*, int, int, const KvClassHost*,
                      hipStream_t);
 int launch_layernorm256(const float*, int, const float*, int, const float*, const float*, float*, int, int, int,
@@ -236,6 +237,10 @@ int ctrlsim_gemm_nt_bf16x6(const float* A, int lda, const void* W3, int n_total,
                            int ldr, float* C, int ldc, int M, int N, int K, int relu, const float* ln_gamma,
                            const float* ln_beta, hipStream_t st) {
   return launch_gemm_nt_bf16x6(A, lda, W3, n_total, n0, bias, R, ldr, C, ldc, M, N, K, relu, ln_gamma, ln_beta, st);
+}
+int ctrlsim_gemm256_rows(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias, float* C, int ldc,
+                         const int* c_rows, int M, hipStream_t st) {
+  return launch_gemm256_rows(A, lda, W3, n_total, n0, bias, C, ldc, c_rows, M, st);
 }
 int ctrlsim_gemm_nt_kv(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias, float* C, int ldc,
                        int M, int N, int K, void* kv_img, int kv_L, int kv_nkt, int kv_col0, hipStream_t st) {

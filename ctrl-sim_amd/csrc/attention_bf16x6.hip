@@ -70,8 +70,19 @@ struct AttnBatch { int n; unsigned long long* cprof; AttnClass c[MAXC]; };
 // representative's own tokens (multiplicity 1, where every other visible representative key counts m-fold; TBL kernel: the seed of a
 // representative sub-tile always carries log2 m and these bits take it back).
 #define TBL_ENTRY 32      // u64 per (query group, sub-tile)
+// Round 6: the table also carries the kernel's per-sub-tile CONTROL FLOW, so that the TBL kernel derives nothing from query positions at
+// run time (no divisions, no cross-lane minimum / maximum of timesteps, no block-maximum exchange through LDS + barrier, no incremental
+// timestep bookkeeping per sub-tile — 6.2 scalar + 1.4 branch instructions per MFMA in round 5's counters).  Behind the mask entries
+// of a class, per query group g, TBL_CTL(nkt) dwords:
+//   [0] tile schedule of the 256-query block the group belongs to: n_reg | n_rep << 16 (regular tiles that hold a key some query of the
+//       block sees, representative tiles likewise);  [1] the same for the group alone (32-query blocks of the streaming form);
+//   [2 + tile] four bits per 64-key tile of the class's images (tile index as in the images): code of sub-tile 0 | code of sub-tile 1 << 2,
+//       code 0 = no query of the group sees a key of the sub-tile: skip;  1 = every query sees every key (and none of them is one of the
+//       representative's own tokens): no mask;  2 = apply the entry's visibility masks;  3 = masks + the `nob` correction.
+#define TBL_CTL(nkt) (((nkt) + 3) & ~1)
 #define AS4 __attribute__((address_space(4)))   // constant address space: wave-uniform loads from it are scalar loads
 typedef unsigned long long u64;
+typedef unsigned int u32;
 struct TblClass { u64* tbl; int Lq, Lk, A, rep_keys, rep_pos0, nkt, groups, wg0; };
 struct TblBatch { int n; TblClass c[MAXC]; };
 __global__ __launch_bounds__(256) void attn_mask_table_kernel(TblBatch tb) {
@@ -80,14 +91,30 @@ __global__ __launch_bounds__(256) void attn_mask_table_kernel(TblBatch tb) {
   const TblClass& c = tb.c[ci];
   const int g = (int)blockIdx.x - c.wg0, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
   const int A3 = 3 * c.A, nsub = 2 * c.nkt, nsub_reg = 2 * ((c.rep_pos0 + KT6 - 1) / KT6);
+  __shared__ unsigned char codes[256];                 // per sub-tile (nsub <= 2 * 64: launch_attn_mask_tables checks nkt)
   // this lane's query (rows past the end repeat the last row: such lanes must not keep a wave on the no-base-yet path)
   const int pos = min(32 * g + l31, c.Lq - 1);
   const bool rep_q = c.rep_keys > 0 && pos >= c.rep_pos0;
   int tq, aq = -1, kq;
   if (rep_q) { tq = (pos - c.rep_pos0) / 3; kq = (pos - c.rep_pos0) - 3 * tq; }
   else { tq = pos / A3; const int rem = pos - tq * A3; aq = rem / 3; kq = rem - 3 * aq; }
+  u32* const ctl = reinterpret_cast<u32*>(c.tbl + (size_t)c.groups * nsub * TBL_ENTRY) + (size_t)g * TBL_CTL(c.nkt);
+  if (threadIdx.x == 0) {
+    // tile schedules: the largest timestep among the block's queries decides how many regular / representative keys matter
+    auto sched = [&](int p0, int p1) -> u32 {            // queries at positions [p0, p1], p1 < Lq
+      int bt = 0;
+      const int reg_hi = min(p1, (c.rep_keys > 0 ? c.rep_pos0 : c.Lq) - 1);
+      if (reg_hi >= p0) bt = reg_hi / A3;
+      if (c.rep_keys > 0 && p1 >= c.rep_pos0) bt = max(bt, (p1 - c.rep_pos0) / 3);
+      const int k_end = min(c.Lk, (bt + 1) * A3), rep_need = min(c.rep_keys, (bt + 1) * 3);
+      return (u32)((k_end + KT6 - 1) / KT6) | ((u32)((rep_need + KT6 - 1) / KT6) << 16);
+    };
+    const int b0 = (g >> 3) * 256;
+    ctl[0] = sched(b0, min(b0 + 255, c.Lq - 1));
+    ctl[1] = sched(32 * g < c.Lq ? 32 * g : c.Lq - 1, min(32 * g + 31, c.Lq - 1));
+  }
   for (int j = wave; j < nsub; j += 4) {
-    u64 mine = 0;
+    u64 mine = 0, all_v = ~0ull, any_v = 0, any_n = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int kl = mfma_row(r, half);
@@ -108,9 +135,14 @@ __global__ __launch_bounds__(256) void attn_mask_table_kernel(TblBatch tb) {
       const u64 bv = __ballot(vis), bn = __ballot(nob);
       if (lane == r) mine = bv;
       if (lane == 16 + r) mine = bn;
+      all_v &= bv; any_v |= bv; any_n |= bn;
     }
     if (lane < TBL_ENTRY) c.tbl[((size_t)g * nsub + j) * TBL_ENTRY + lane] = mine;
+    // (the two sub-tiles of a tile are evaluated by different waves: the codes meet in LDS and leave as one dword per tile below)
+    if (lane == 0) codes[j] = any_v == 0 ? 0 : (any_n ? 3 : (all_v == ~0ull ? 1 : 2));
   }
+  __syncthreads();
+  for (int t = threadIdx.x; t < c.nkt; t += 256) ctl[2 + t] = (u32)codes[2 * t] | ((u32)codes[2 * t + 1] << 2);
 }
 
 // (Tried and not kept, numbers in profiles/README.md: five workgroups per CU for the mask-table kernel; a three-stage K/V ring with the DMA
@@ -156,7 +188,15 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
   constexpr int K_PLANE = KT6 * HD;              // bf16 elements: [ks 2][half 2][64 keys][8]
   constexpr int V_PLANE = HD * KT6;              // [16 quads][32 d][4 keys]
   constexpr int BUF = NPL * (K_PLANE + V_PLANE) + 2 * KT6 + 8;   // + KT6 floats of key-padding bias + two "sub-tile has padded keys" flags
-  constexpr int NBUF = 2;
+  // Stage ring of the staged form (PRE, not DIR): NBUF buffers, the LDS-DMA of tile it + NBUF - 1 is requested at the top of tile it.
+  // NBUF = 3 (round 6, the 8-wave full-row kernels: 3 x 16.6 KB x three workgroups = 150 KB of the CU's 160 KB at the SAME six waves
+  // per SIMD — the round-3/4 trial of a three-stage ring had cost a workgroup of occupancy): a tile's image has two tiles of compute to
+  // land instead of one.  Still ONE barrier per tile: it publishes tile it + 1 and retires buffer it % NBUF, which the request at
+  // the top of tile it + 1 (for tile it + NBUF) refills.
+#ifndef ATT_NBUF_FULL
+#define ATT_NBUF_FULL 3
+#endif
+  constexpr int NBUF = (PRE && !DIR && NW == 8) ? ATT_NBUF_FULL : 2;
   static_assert(!DIR || PRE, "the streaming form reads pre-split images");
   constexpr int PADSZ = 2 * KT6 + 8;             // 16-bit elements of a stage's key-padding bias block
   constexpr int BUF_ = DIR ? PADSZ : BUF, NBUF_ = NBUF;
@@ -184,6 +224,9 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
   __shared__ __attribute__((aligned(16))) op_t arena[ARENA];
   auto dma_tile = [&](int tile, int buf) {
     if (DIR) return;
+#ifdef ATT_ABL_NODMA
+    return;                                                              // ablation: stale LDS contents (wrong results), no image traffic
+#endif
     const op_t* src = img + (size_t)tile * KV_IMG + tid * 8;
 #pragma unroll
     for (int i = 0; i < KV_PIECES * 4 / NW; ++i) {
@@ -209,7 +252,7 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
   const int pos = q_pos ? q_pos[qrow] : qrow;
   int tq = 0, aq = 0, kq = 0;
   bool rep_q = false;                               // this lane's query is a representative token
-  if (MODE == MODE6_CAUSAL) {
+  if (MODE == MODE6_CAUSAL && !TBL) {               // (TBL: masks, skips and the tile schedule all come from the class table)
     rep_q = rep_keys > 0 && pos >= rep_pos0;
     if (rep_q) {
       tq = (pos - rep_pos0) / 3;
@@ -238,7 +281,18 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
   // ---- key range
   int k_end = Lk, rep_need = 0;                    // regular keys [0, k_end) and representative keys [0, rep_need) matter
   int tq_min_w = 0, tq_max_w = 0;
-  if (MODE == MODE6_CAUSAL) {
+  // TBL: this wave's query group in the class's mask table, and the group's control words behind the class's mask entries
+  const int qgrp = __builtin_amdgcn_readfirstlane(DIR ? qblk : qblk * NW + wave), nsub_tbl = 2 * (int)kv_batch_stride;
+  const AS4 u32* ctl = nullptr;
+  int tbl_n_reg = 0, tbl_n_rep = 0;
+  if (TBL) {
+    const int groups = 4 * ((Lq + 127) / 128), live = (Lq + 31) >> 5;
+    // (a wave without queries — the tail of the last 256-query block — still stages tiles: it takes the schedule of the block's last live group)
+    ctl = (const AS4 u32*)(cd.tbl + (size_t)groups * nsub_tbl * TBL_ENTRY) + (size_t)min(qgrp, live - 1) * TBL_CTL((int)kv_batch_stride);
+    const u32 hdr = ctl[DIR ? 1 : 0];
+    tbl_n_reg = (int)(hdr & 0xffffu); tbl_n_rep = (int)(hdr >> 16);
+  }
+  if (MODE == MODE6_CAUSAL && !TBL) {
     int tmin = tq, tmax = tq;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -258,9 +312,6 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
     rep_need = __builtin_amdgcn_readfirstlane(min(rep_keys, (bt + 1) * 3));
   }
 
-  // TBL: this wave's query group in the class's mask table; does the wave hold representative queries (wave-uniform)
-  const int qgrp = __builtin_amdgcn_readfirstlane(DIR ? qblk : qblk * NW + wave), nsub_tbl = 2 * (int)kv_batch_stride;
-  const bool wave_rep_q = TBL && rep_keys > 0 && __builtin_amdgcn_readfirstlane(qb + wave * 32 + 31) >= rep_pos0;
 
   f32x16 oa;                                       // O^T accumulator
 #pragma unroll
@@ -331,7 +382,7 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
   };
 
   // ---- tile schedule: the regular tiles [0, n_reg) that hold keys < k_end, then the representative tiles (compact contexts)
-  const int n_reg = (k_end + KT6 - 1) / KT6, n_rep = (rep_need + KT6 - 1) / KT6, n_it = n_reg + n_rep;
+  const int n_reg = TBL ? tbl_n_reg : (k_end + KT6 - 1) / KT6, n_rep = TBL ? tbl_n_rep : (rep_need + KT6 - 1) / KT6, n_it = n_reg + n_rep;
   const int nkt_reg = (rep_pos0 + KT6 - 1) / KT6;
   auto tile_k0 = [&](int it) { return (it < n_reg ? it : nkt_reg + (it - n_reg)) * KT6; };
   if (n_it > 0) {
@@ -340,6 +391,11 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
   }
   if (PRE && !DIR) asm volatile("s_waitcnt vmcnt(0) ; KV-DMA landed" ::: "memory");
   __syncthreads();
+  if (PRE && !DIR) {
+#pragma unroll
+    for (int a = 1; a < NBUF - 1; ++a)                                  // NBUF = 3: tile 1 is requested here, tile it + 2 at the top of tile it
+      if (a < n_it) dma_tile(tile_k0(a) / KT6, a);
+  }
 
   // DIR: the K and V^T fragments of sub-tile i + 1 are requested (global loads into a second register set) before sub-tile i is
   // computed — one wave has nothing else to cover the two memory round trips per sub-tile with (272 us per launch in the K/V-cached
@@ -359,11 +415,18 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
   };
   if (DIR && n_it > 0) dir_fetch(0, 0);
   int cur = 0;
-  for (int it = 0; it < n_it; ++it, cur ^= 1) {
+  for (int it = 0; it < n_it; ++it, cur = (cur + 1 == NBUF ? 0 : cur + 1)) {
     const bool more = it + 1 < n_it;
-    if (more) gload(tile_k0(it + 1), cur ^ 1);
+    const int nxt = cur + 1 == NBUF ? 0 : cur + 1;                       // buffer of tile it + 1
+    const bool ahead = (PRE && !DIR) && it + NBUF - 1 < n_it;            // a tile to request now (tile it + NBUF - 1)
+    if (PRE && !DIR) {
+      if (ahead) dma_tile(tile_k0(it + NBUF - 1) / KT6, cur == 0 ? NBUF - 1 : cur - 1);
+      if (more) gload(tile_k0(it + 1), nxt, false);                      // (key-padding bias of the NEXT tile: registers now, LDS at the end)
+    } else if (more) gload(tile_k0(it + 1), nxt);
     const bool rep_tile = it >= n_reg;               // wave-uniform: a tile of representative keys (compact contexts)
     const int k0 = it * KT6;
+    u32 cw = 0;                                      // TBL: this tile's control word (requested here, first used behind the DMA issue above)
+    if (TBL && wave_live) cw = ctl[2 + tile_k0(it) / KT6];
     // DIR: the fragments are read from the tile image itself (same layout as a stage: the DMA copies images verbatim)
     const op_t* Ks = DIR ? img + (size_t)(tile_k0(it) / KT6) * KV_IMG : arena + cur * BUF;
     const op_t* Vs = Ks + NPL * K_PLANE;
@@ -388,7 +451,11 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
       int t_lo = 0, t_hi = 0, ks_t0 = 0;
       bool need_mask = true;
       const int j0 = (it - n_reg) * KT6 + sub * 32;   // first representative key of this sub-tile (rep_tile)
-      if (!rep_tile) {
+      const u32 code = (cw >> (2 * sub)) & 3u;
+      if (TBL) {
+        if (code == 0) continue;                      // no query of this wave sees a key of the sub-tile
+        need_mask = code >= 2;
+      } else if (!rep_tile) {
         // timestep of the first / last key of this sub-tile (tracked incrementally: no divisions in the loop)
         t_lo = tk_t;
         t_hi = min(tk_t + (tk_r + 31 >= A3 ? (tk_r + 31 - A3 >= A3 ? (tk_r + 31) / A3 : 1) : 0), t_last);
@@ -450,7 +517,7 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
         // recognizer and reads the registers before the matrix pipe has written them — the first version of this path did.)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_inverse_ballot_w64(mk[r]) ? s0[r] : NEG_INF;
-        if (rep_tile && wave_rep_q) {
+        if (code == 3) {
           // the representative's own tokens of its step count once: take the multiplicity back (three query groups per context only)
 #pragma unroll
           for (int r = 0; r < 16; ++r) sc[r] -= __builtin_amdgcn_inverse_ballot_w64(tbl_e[16 + r]) ? log2m : 0.f;
@@ -587,8 +654,13 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
 #undef PV
       }
     }
-    if (more) sstore(cur ^ 1);
-    if (PRE && !DIR) asm volatile("s_waitcnt vmcnt(0) ; KV-DMA landed" ::: "memory");
+    if (more) sstore(nxt);
+    if (PRE && !DIR) {
+      // tile it + 1 must have landed; the pieces of tile it + NBUF - 1 requested at the top of this tile (NBUF = 3) stay in flight across
+      // the barrier: requests return in order, so a count of this wave's younger pieces is exact
+      if (NBUF > 2 && ahead) asm volatile("s_waitcnt vmcnt(%0) ; KV-DMA landed (next tile)" :: "n"(KV_PIECES * 4 / NW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) ; KV-DMA landed" ::: "memory");
+    }
     if (!DIR || MODE == MODE6_KEYPAD) __syncthreads();       // DIR: only the key-padding bias block goes through LDS
   }
 
@@ -949,7 +1021,10 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
 }
 
 // Mask tables of n classes (cls[k].mask_tbl: attn_mask_table_bytes(Lq, nkt) bytes each; classes without a table are skipped), one launch
-size_t attn_mask_table_bytes(int Lq, int nkt) { return (size_t)4 * ((Lq + 127) / 128) * 2 * nkt * TBL_ENTRY * sizeof(u64); }
+size_t attn_mask_table_bytes(int Lq, int nkt) {
+  const size_t groups = (size_t)4 * ((Lq + 127) / 128);
+  return groups * 2 * nkt * TBL_ENTRY * sizeof(u64) + ((groups * TBL_CTL(nkt) * sizeof(u32) + 255) & ~size_t(255));
+}
 int launch_attn_mask_tables(int n, const AttnClassHost* cls, hipStream_t st) {
   if (n < 0 || n > MAXC || !cls) return CTRLSIM_EINVAL;
   TblBatch tb;
@@ -959,7 +1034,7 @@ int launch_attn_mask_tables(int n, const AttnClassHost* cls, hipStream_t st) {
     const AttnClassHost& c = cls[k];
     if (c.B <= 0 || c.Lq <= 0 || !c.mask_tbl) continue;
     const int rp0 = c.rep_keys ? c.rep_pos0 : c.Lk;
-    if (c.Lk <= 0 || c.A <= 0 || c.nkt < (rp0 + KT6 - 1) / KT6 + (c.rep_keys + KT6 - 1) / KT6) return CTRLSIM_EINVAL;
+    if (c.Lk <= 0 || c.A <= 0 || c.nkt < (rp0 + KT6 - 1) / KT6 + (c.rep_keys + KT6 - 1) / KT6 || c.nkt > 128) return CTRLSIM_EINVAL;
     const int groups = 4 * ((c.Lq + 127) / 128);
     tb.c[tb.n++] = TblClass{static_cast<u64*>(const_cast<void*>(c.mask_tbl)), c.Lq, c.Lk, c.A, c.rep_keys, rp0, c.nkt, groups, wg};
     wg += groups;

@@ -15,6 +15,7 @@
                                 int, int, const float*, const float*, void*, int, int, const KvClassHost*, hipStream_t);          \
   int launch_inproj_rs(const float*, int, const void*, const float*, float*, int, int, int, void*, int, int, const KvClassHost*,  \
                        hipStream_t);                                                                                              \
+  int launch_gemm256_rows(const float*, int, const void*, int, int, const float*, float*, int, const int*, int, hipStream_t);     \
   int launch_ffn_fused_bf16x6(const float*, int, const void*, const float*, const void*, const float*, const float*, const float*, \
                               float*, int, int, int, hipStream_t);                                                               \
   int launch_outproj_ln_q(const float*, int, const float*, int, const void*, const float*, const float*, const float*, const void*,       \
@@ -59,6 +60,10 @@ int launch_gemm_nt_bf16x6_kvc(const float* A, int lda, const void* W3, int n_tot
 int launch_inproj_rs(const float* A, int lda, const void* Wblk, const float* bias, float* C, int ldc, int M, int N, void* img, int col0,
                      int n, const KvClassHost* cls, hipStream_t st) {
   return PICK(launch_inproj_rs(A, lda, Wblk, bias, C, ldc, M, N, img, col0, n, cls, st));
+}
+int launch_gemm256_rows(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias, float* C, int ldc,
+                        const int* c_rows, int M, hipStream_t st) {
+  return PICK(launch_gemm256_rows(A, lda, W3, n_total, n0, bias, C, ldc, c_rows, M, st));
 }
 int launch_outproj_ln_q(const float* O, int ldo, const float* R, int ldr, const void* Wop, const float* bo, const float* g0, const float* be0,
                         const void* Wqp, const float* bq, float* X1, int ldx1, float* Q, int ldq, int M, hipStream_t st) {

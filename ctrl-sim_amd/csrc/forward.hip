@@ -53,6 +53,7 @@ int launch_gemm_nt_bf16x6_kvc(const float*, int, const void*, int, int, const fl
 int launch_in_mlp(const float*, int, int, const float*, const float*, const float*, const float*, float*, int, int,
                   hipStream_t);
 int launch_row_copy(const float*, int, float*, int, const int*, int, int, int, hipStream_t);
+int launch_gemm256_rows(const float*, int, const void*, int, int, const float*, float*, int, const int*, int, hipStream_t);
 int launch_attention(int, const float*, int, long, const float*, const float*, int, long, float*, int, long, const int*,
                      const unsigned char*, int, int, int, int, hipStream_t);
 struct EmbedTables { const float *act, *rtg_g, *rtg_v, *rtg_r, *rtg_bias, *tstep, *agent, *ln_g, *ln_b; int rtg_linear; };
@@ -630,9 +631,18 @@ int scene_side(const ctrlsim_model* m, const Batch& bt, const Ws& w, float* dbg_
   CHK(gemm_ln(m->map_feats.l3, m->map_n2, w.m2, DM, w.m1, DM, w.cat, 2 * DM, w.attn_pre, rP, DM, 0, st));   // cat[:, :256]
   CHK(gemm(m->road_type.l3, w.tfh, DM, nullptr, 0, w.cat + DM, 2 * DM, rP, DM, DM, 0, st));                                                                                  // cat[:, 256:]
   CHK(gemm_ln(m->road_fuse.l0, m->road_fuse.ln, w.cat, 2 * DM, nullptr, 0, w.m2, DM, w.m2, rP, 2 * DM, 1, st));
-  // final Linear -> compact [B*P,256], then scattered into the scene-encoder source rows [b, 0..P-1]
-  CHK(gemm(m->road_fuse.l3, w.m2, DM, nullptr, 0, w.m1, DM, rP, DM, DM, 0, st));
-  CHK(launch_row_copy(w.m1, DM, w.src, DM, w.idx_poly, rP, DM, 1, st));
+  // final Linear: its rows ARE the polyline rows [b, 0..P-1] of the scene-encoder source — written there by the Linear's own row store
+  // (weight-stationary kernel, scattered rows: round 6), or, where that kernel does not apply (bf16x6 split, f32-input family, a debug
+  // caller that wants the compact rows), compact [B*P,256] + a row copy
+  int scattered = 1;
+  const Lin& Lf = m->road_fuse.l3;
+  if (!dbg_seg_emb && Lf.w3() && ctrlsim_option(OPT_GEMM_IMPL) == 1 && ctrlsim_option(OPT_SPLIT))
+    scattered = launch_gemm256_rows(w.m2, DM, Lf.w3(), Lf.ntot ? Lf.ntot : DM, Lf.n0, Lf.b, w.src, DM, w.idx_poly, rP, st);
+  if (scattered < 0) return scattered;
+  if (scattered == 1) {
+    CHK(gemm(Lf, w.m2, DM, nullptr, 0, w.m1, DM, rP, DM, DM, 0, st));
+    CHK(launch_row_copy(w.m1, DM, w.src, DM, w.idx_poly, rP, DM, 1, st));
+  }
   if (dbg_seg_emb) {
     hipError_t e = hipMemcpyAsync(dbg_seg_emb, w.m1, (size_t)rP * DM * sizeof(float), hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return CTRLSIM_ELAUNCH;
@@ -867,7 +877,9 @@ extern "C" int ctrlsim_dt_forward_pass2_c(const ctrlsim_model* m, int n, const i
   for (int i = 0; i < d.ND; ++i) {
     const DecLayer& Ld = m->dec[i];
     CHK(gemm(Ld.qkv, w.xc2, DM, nullptr, 0, w.qkvc, 3 * DM, rQ, 3 * DM, DM, 0, st));
-    CHK(launch_row_copy(w.qkvc, 3 * DM, w.qkv[i], 3 * DM, w.idx_rtg, rQ, 3 * DM, 1, st));   // refresh the rtg rows' K/V
+    // refresh the rtg rows' K / V: in the tile images (what the split-operand attention reads), or — f32-input MFMA family, which
+    // attends over the fp32 rows themselves — in the fp32 rows of the pass-1 projection
+    if (!presplit()) CHK(launch_row_copy(w.qkvc, 3 * DM, w.qkv[i], 3 * DM, w.idx_rtg, rQ, 3 * DM, 1, st));
     if (presplit()) {
       KvRowsHost kr[MAXC];
       for (int k = 0; k < bt.n; ++k) {
@@ -952,7 +964,9 @@ extern "C" int ctrlsim_dt_forward_pass1_cached_c(const ctrlsim_model* m, int n, 
   for (int i = 0; i < d.ND; ++i) {
     const DecLayer& Ld = m->dec[i];
     CHK(gemm(Ld.qkv, w.xn, DM, nullptr, 0, w.qkvn, 3 * DM, rN, 3 * DM, DM, 0, st));
-    CHK(launch_row_copy(w.qkvn, 3 * DM, w.qkv[i], 3 * DM, w.idx_new, rN, 3 * DM, 1, st));       // K/V (and Q) into the cache
+    // K / V of the new rows into the cache: the tile images (split-operand attention) or the fp32 rows (f32-input MFMA family; nothing
+    // reads the fp32 cache rows on the split-operand path: queries come from qkvn, keys and values from the images)
+    if (!presplit()) CHK(launch_row_copy(w.qkvn, 3 * DM, w.qkv[i], 3 * DM, w.idx_new, rN, 3 * DM, 1, st));
     if (presplit()) {
       if (t == 0) {   // image tiles are read whole: stale bits beyond the written rows must at least be finite
         if (hipMemsetAsync(w.img_dec[i], 0, w.img_dec_bytes, st) != hipSuccess) return CTRLSIM_ELAUNCH;

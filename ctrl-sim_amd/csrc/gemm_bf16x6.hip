@@ -512,7 +512,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ws256_kernel(const float* A, int 
                                                             const float* __restrict__ bias, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* R, int ldr, float* C,
                                                             int ldc, int M, int n_total, int n0, int* __restrict__ nonfinite,
-                                                            const KvImg kv) {
+                                                            const KvImg kv, const int* __restrict__ c_rows = nullptr) {
+  // c_rows (row-store epilogue only): result row i leaves as row c_rows[i] of C (< 0: not stored) — a Linear whose output rows are
+  // scattered into a larger row space (the map encoder's last Linear writes the polyline rows of the scene-encoder source) needs no
+  // copy kernel behind it.  The index is read with a SCALAR load (the row is wave-uniform): the counted vmcnt waits below are unchanged.
   static_assert(!KV || (!RELU && !RESID && !LN), "the K / V image epilogue belongs to the plain Linear");
   const int grp = KV ? (int)blockIdx.y : 0;
   n0 += 256 * grp;
@@ -751,9 +754,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ws256_kernel(const float* A, int 
     for (int q = 0; q < 4; ++q) yo[q] = *reinterpret_cast<const f32x4*>(rb + (4 * wave + q) * WS_LD + lane * 4);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int grow = blk * WS_ROWS + 4 * wave + q;
-      if (grow < M)
-        __builtin_nontemporal_store(yo[q], reinterpret_cast<f32x4*>(C + (size_t)grow * ldc + lane * 4));
+      const int grow = __builtin_amdgcn_readfirstlane(blk * WS_ROWS + 4 * wave + q);
+      if (grow < M) {
+        int orow = grow;
+        if (c_rows) orow = ((const __attribute__((address_space(4))) int*)c_rows)[grow];
+        if (orow >= 0) __builtin_nontemporal_store(yo[q], reinterpret_cast<f32x4*>(C + (size_t)orow * ldc + lane * 4));
+      }
     }
     if (RESID) dma(R, ldr, rbuf, it + 2);                 // this wave's four rows of rb: read by its own stores above only
   }
@@ -1018,6 +1024,34 @@ int launch_inproj_rs(const float*, int, const void*, const float*, float*, int, 
   return CTRLSIM_EINVAL;                               // two-fp16-plane scheme only
 }
 #endif
+
+// Plain Linear 256 -> 256 whose result row i is written to row c_rows[i] of C (entries < 0 are not stored): the weight-stationary kernel
+// with a scattered row store.  Returns 1 (nothing launched) when that kernel does not apply — other split scheme, option off, other
+// shape — and the caller runs Linear + row copy instead.
+int launch_gemm256_rows(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias, float* C, int ldc,
+                        const int* c_rows, int M, hipStream_t st) {
+  if (M <= 0) return CTRLSIM_OK;
+#if CTRLSIM_F16X3
+  if (!A || !W3 || !C || !c_rows || (lda & 3) || (ldc & 3) || n0 < 0 || n0 + 256 > n_total) return CTRLSIM_EINVAL;
+  if (!(ctrlsim_option(OPT_GEMM_WS) & (M >= 2 * WS_ROWS * 256 ? 1 : 2))) return 1;
+  const int nblk = (M + WS_ROWS - 1) / WS_ROWS;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ws256_kernel<false, false, false>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES) == hipSuccess;
+  if (!attr_ok) return CTRLSIM_EINVAL;
+  KvImg kv;
+  kv.img = nullptr; kv.k_col0 = 0; kv.n = 0;
+  prof_before(PROF_GEMM, st);
+  hipLaunchKernelGGL((gemm_ws256_kernel<false, false, false>), dim3(nblk < cus ? nblk : cus), dim3(512), WS_LDS_BYTES, st, A, lda,
+                     static_cast<const op_t*>(W3), bias, nullptr, nullptr, nullptr, 0, C, ldc, M, n_total, n0, ctrlsim_nonfinite_ptr(), kv,
+                     c_rows);
+  prof_after(PROF_GEMM, 2.0 * (double)M * 256.0 * 256.0, st, 8.0 * (double)M * 256.0 + 2.0 * NPL * 256.0 * 256.0, PKIND_GEMM_PLAIN);
+  return ctrlsim_launch_status();
+#else
+  return 1;
+#endif
+}
 
 int launch_gemm_nt_bf16x6_kvc(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias,
                               const float* R, int ldr, float* C, int ldc, int M, int N, int K, int relu,

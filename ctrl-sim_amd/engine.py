@@ -34,7 +34,7 @@ import numpy as np
 import torch
 
 from . import _lib, pack as _pack
-from .spec import Dims, ZERO_ACTION_TOKEN, ZERO_RTG_BINS
+from .spec import Dims, ZERO_ACTION_TOKEN, ZERO_RTG_BINS, check_supported
 
 
 def _dims_struct(d: Dims):

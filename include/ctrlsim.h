@@ -283,6 +283,13 @@ int ctrlsim_gemm_nt(const float* A, int lda, const float* W, int ldw, const floa
 int ctrlsim_gemm_nt_bf16x6(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias, const float* R,
                            int ldr, float* C, int ldc, int M, int N, int K, int relu, const float* ln_gamma,
                            const float* ln_beta, hipStream_t stream);
+/* Plain Linear 256 -> 256 (W3 rows [n0, n0 + 256), K = 256, two-fp16-plane scheme) whose result row i is written to row c_rows[i] of C
+ * (device int32 list of M entries; an entry < 0 is not stored): the map encoder's last Linear (modules/map_encoder.py:53 feeding
+ * modules/encoder.py:155-158's concatenation) writes the polyline rows of the scene-encoder source [b, 0..P-1] itself, no copy kernel.
+ * Returns 1 — nothing launched — when the weight-stationary kernel does not apply (bf16x6 split selected, option 6 off): the caller
+ * runs ctrlsim_gemm_nt_bf16x6 + a row copy instead. */
+int ctrlsim_gemm256_rows(const float* A, int lda, const void* W3, int n_total, int n0, const float* bias, float* C, int ldc,
+                         const int* c_rows, int M, hipStream_t stream);
 /* The same Linear whose last 512 output columns [kv_col0, kv_col0 + 512) are the keys / values of 8 heads x 32 of contexts of
  * kv_L rows each: those columns leave the epilogue directly as the split K / V tile images of ctrlsim_kv_split (kv_nkt 64-key
  * tiles per context and head; the tail of the last tile must be zeroed by the caller), columns [0, kv_col0) as fp32 rows of C.

@@ -28,9 +28,10 @@ def _bench(extra_env, *args):
 def _short_and_detail(stdout):
     """The run's ONE stdout line (what the driver parses: short, complete) and, returned, the detail file it names."""
     lines = [ln for ln in stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1 and lines[0].startswith("{"), stdout[-2000:]       # nothing but the line on stdout
-    assert len(lines[0]) < 4096, len(lines[0])
-    short = json.loads(lines[0])
+    # exactly one JSON line, and it is the LAST line of stdout (RCCL's version banner, printed through C stdio, must not follow it)
+    assert sum(ln.startswith("{") for ln in lines) == 1 and lines[-1].startswith("{"), stdout[-2000:]
+    assert len(lines[-1]) < 4096, len(lines[-1])
+    short = json.loads(lines[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline", "parity_spot_check", "detail_file"):
         assert k in short, k

@@ -122,6 +122,35 @@ def test_linear256_both_kernels(ws_option, M, relu, resid, ln):
     assert (out.double() - ref).abs().max().item() < 2e-5 * max(1.0, scale / 50)
 
 
+@pytest.mark.parametrize("M", [33, 5000, 40000])
+def test_linear256_with_scattered_row_store(M):
+    """Round 6: the plain Linear(256 -> 256) of the weight-stationary kernel writing result row i to row c_rows[i] of a LARGER row space
+    (ctrlsim_gemm256_rows; the map encoder's last Linear fills the polyline rows of the scene-encoder source — modules/encoder.py:155-158's
+    concatenation — without a copy kernel): bit-identical to Linear + row copy, entries < 0 are not stored, every other row of the
+    destination is untouched."""
+    from ctrlsim_amd.pack import split3_planes
+    g = torch.Generator().manual_seed(M)
+    A = torch.randn(M, 256, generator=g).to(DEV)
+    W = torch.randn(512, 256, generator=g) * 0.1
+    b = torch.randn(256, generator=g).to(DEV)
+    ref = gemm_bf16x6(A, W, b, n0=256, n=256)
+    rows = M + M // 8 + 24                                               # 200 polyline rows + 24 vehicle rows per context, as the real map
+    perm = torch.randperm(rows, generator=g)[:M].to(torch.int32)
+    perm[::97] = -1
+    idx = perm.to(DEV)
+    dst = torch.full((rows, 256), 7.5, device=DEV)
+    planes = torch.from_numpy(split3_planes(W.numpy()).view(np.int16).copy()).to(DEV)
+    p = _lib.ptr
+    rc = _lib.lib().ctrlsim_gemm256_rows(p(A), 256, p(planes), 512, 256, p(b), p(dst), 256, p(idx), M, _lib.stream_ptr())
+    assert rc == 0, rc                                                   # (1 = kernel not applicable: the shipped default must take it)
+    torch.cuda.synchronize()
+    keep = idx >= 0
+    assert torch.equal(dst[idx[keep].long()], ref[keep])
+    untouched = torch.ones(rows, dtype=torch.bool, device=DEV)
+    untouched[idx[keep].long()] = False
+    assert bool((dst[untouched] == 7.5).all())
+
+
 # (160 x 288 = 46 080 rows = 1 440 row blocks of 32: more than four per compute unit, so every persistent workgroup of the weight-stationary
 #  kernel runs its multi-job ring with result stores and the next blocks' requests in flight across the counted-vmcnt barriers)
 @pytest.mark.parametrize("B,L,col0", [(3, 224, 256), (2, 96, 256), (5, 160, 0), (1, 2304, 256), (160, 288, 256), (150, 292, 0)])
