@@ -70,8 +70,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spot-check", type=int, default=4, help="scenarios re-rolled alone after the timed region (bit-identity check; 0 = off)")
     ap.add_argument("--cpu-sample-scenarios", type=int, default=4)
-    ap.add_argument("--cpu-sample-steps", type=int, default=4)
-    ap.add_argument("--cpu-sample-budget-s", type=float, default=40.0,
+    ap.add_argument("--cpu-sample-steps", type=int, default=3)
+    ap.add_argument("--cpu-sample-budget-s", type=float, default=35.0,
                     help="time box of the CPU sample: no further scenario is started once this much CPU time is spent (at least one runs)")
     ap.add_argument("--detail-file", type=str, default=os.path.join(ROOT, "bench_detail.json"),
                     help="everything that does not fit the one short stdout line: per-kernel rows, satellites, per-class attention, notes")
@@ -346,7 +346,7 @@ def main():
         # every file of the round: FETCH_SIZE x 2 (gfx950 tallies its 128-byte read requests at 64 B — calibrated in round 5 on known-byte
         # launches of every access pattern and of each hot kernel: profiles/r05_pmc_calibration.json) + WRITE_SIZE x 1.
         pmc, pmc_src = {}, None
-        for cand in ("r05w_pmc_traffic.json", "r05_pmc_traffic.json"):
+        for cand in ("r06_pmc_traffic.json", "r05w_pmc_traffic.json", "r05_pmc_traffic.json"):
             pmc_path = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(pmc_path):
                 pmc, pmc_src = json.load(open(pmc_path)), "profiles/" + cand

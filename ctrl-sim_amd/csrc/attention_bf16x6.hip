@@ -158,8 +158,18 @@ __global__ __launch_bounds__(256) void attn_mask_table_kernel(TblBatch tb) {
 // hold 24 waves per CU.  Round 5, sustained: L = 2304 2.52 -> 2.37 ms, A' = 8 1.21 -> 1.11 ms, cross 0.576 -> 0.541 ms; rollout +1.0 %
 // (causal launches 2.215 -> 2.144 ms, key-padded 0.614 -> 0.594 ms).  The in-kernel-mask causal kernel (baselines, few-row non-streaming
 // launches) keeps 4 waves per workgroup: at 80 registers it spills.
-constexpr int ATT_NW_FULL = 8;
-template <int MODE, bool PRE, bool TBL = false, bool DIR = false, int NW = 4>
+// QG (round 6) = 32-query groups PER WAVE of the two full-row kernels: a wave holds QG Q^T fragment sets, score tiles and output accumulators
+// and reads every K / V^T fragment from LDS ONCE for all of them.  Why: tools/probes/attn_qg_probe (the loop's instruction mix on an
+// LDS-resident tile, one barrier per tile, 256 queries per workgroup) sustains 97 MFMA / us / CU in the 8-wave x 32-query shape of round 5
+// and 161-167 with 4 waves x 64 queries (175 = the matrix pipe at 1.4 GHz): a 32-query wave re-reads the whole 16 KB tile for 24 MFMAs —
+// 128 KB of LDS reads per tile and workgroup beside 16 KB of DMA writes — and the loop was paced by the LDS, not by the pipes the counters
+// of round 5 showed idle.  With QG = 2: half the LDS bytes per MFMA, half the waves at the barrier, two independent MFMA -> softmax -> MFMA
+// chains in one instruction stream.  4 waves x 2 groups = the same 256 queries per workgroup, 3 workgroups per CU (168 VGPRs).
+#ifndef ATT_QG
+#define ATT_QG 1
+#endif
+constexpr int ATT_QG_FULL = ATT_QG, ATT_NW_FULL = 8 / ATT_QG;
+template <int MODE, bool PRE, bool TBL = false, bool DIR = false, int NW = 4, int QG = 1>
 __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) void attention_bf16x6_kernel(
     const float* __restrict__ Qb_, int ldq, const float* __restrict__ K, const float* __restrict__ V, int ldkv,
     float* __restrict__ Ob_, int ldo, const unsigned char* __restrict__ key_pad_, float scale_log2e, int variant, AttnBatch ab) {
@@ -189,19 +199,22 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
   constexpr int V_PLANE = HD * KT6;              // [16 quads][32 d][4 keys]
   constexpr int BUF = NPL * (K_PLANE + V_PLANE) + 2 * KT6 + 8;   // + KT6 floats of key-padding bias + two "sub-tile has padded keys" flags
   // Stage ring of the staged form (PRE, not DIR): NBUF buffers, the LDS-DMA of tile it + NBUF - 1 is requested at the top of tile it.
-  // NBUF = 3 (round 6, the 8-wave full-row kernels: 3 x 16.6 KB x three workgroups = 150 KB of the CU's 160 KB at the SAME six waves
-  // per SIMD — the round-3/4 trial of a three-stage ring had cost a workgroup of occupancy): a tile's image has two tiles of compute to
-  // land instead of one.  Still ONE barrier per tile: it publishes tile it + 1 and retires buffer it % NBUF, which the request at
-  // the top of tile it + 1 (for tile it + NBUF) refills.
+  // NBUF = 3 (-DATT_NBUF_FULL=3; round 6, the 8-wave full-row kernels: 3 x 16.6 KB x three workgroups = 150 KB of the CU's 160 KB at the SAME
+  // six waves per SIMD — the round-3/4 trial of a three-stage ring had cost a workgroup of occupancy): a tile's image has two tiles of
+  // compute to land instead of one.  Still ONE barrier per tile: it publishes tile it + 1 and retires buffer it % NBUF, which the request
+  // at the top of tile it + 1 (for tile it + NBUF) refills.  MEASURED (tools/jobs/r06_c.sh, sustained, same box): no change at any length
+  // (L = 2304 2.356 -> 2.357 ms, compact classes and cross attention within 0.5 %) although the kernel WITHOUT its image DMA
+  // (-DATT_ABL_NODMA, wrong results) runs 16 % (causal) / 22 % (cross) faster: what the DMA costs is not exposed latency.  Default 2.
 #ifndef ATT_NBUF_FULL
-#define ATT_NBUF_FULL 3
+#define ATT_NBUF_FULL 2
 #endif
   constexpr int NBUF = (PRE && !DIR && NW == 8) ? ATT_NBUF_FULL : 2;
   static_assert(!DIR || PRE, "the streaming form reads pre-split images");
   constexpr int PADSZ = 2 * KT6 + 8;             // 16-bit elements of a stage's key-padding bias block
   constexpr int BUF_ = DIR ? PADSZ : BUF, NBUF_ = NBUF;
   static_assert(NW == 4 || (PRE && !DIR), "more than four waves per workgroup: staged pre-split images only");
-  constexpr int ARENA_T = NW * 32 * 33 * 2;                               // 16-bit elements of the output transpose (NW x 32 x 33 floats)
+  static_assert(QG == 1 || (PRE && !DIR && (TBL || MODE == MODE6_KEYPAD)), "several query groups per wave: the two full-row kernels only");
+  constexpr int ARENA_T = NW * QG * 32 * 33 * 2;                          // 16-bit elements of the output transpose (NW x QG x 32 x 33 floats)
   constexpr int ARENA = DIR ? 2 * PADSZ + 32 * 33 * 2 : (NBUF_ * BUF_ > ARENA_T ? NBUF_ * BUF_ : ARENA_T);     // DIR: two bias blocks, then the 32 x 33 floats of the output transpose
   __shared__ int blk_tmax[NW];
 
@@ -213,7 +226,7 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
   const int h = lin & (NHEAD - 1), j = lin >> 3;
   const int qx = j % nqb, b = j / nqb;
   const int qblk = (MODE == MODE6_CAUSAL) ? (nqb - 1 - qx) : qx;
-  const int qb = qblk * (DIR ? 32 : 32 * NW);
+  const int qb = qblk * (DIR ? 32 : 32 * NW * QG);
   const int tid = threadIdx.x, wave = DIR ? 0 : tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int A3 = 3 * A;
   const float NEG_INF = -__builtin_inff();
@@ -243,11 +256,15 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
   if (PRE) dma_tile(0, 0);
 
   // ---- this lane's query: fragment of Q^T (B operand), k-step ks covers d = 16*ks + 8*half .. +7
-  const int qi = qb + wave * 32 + l31;
+  // (QG > 1: group g of this wave = queries qb + (wave * QG + g) * 32 + l31; everything per-query below is an array over g)
+  const int qi = qb + wave * QG * 32 + l31;
   const bool qvalid = qi < Lq;
   // a wave whose 32 query slots all lie beyond Lq (few-query calls: the second pass, the last decoder layer, the K/V-cached
   // steps fill one wave of the four) stages tiles and keeps the barriers, but skips the products and the softmax
-  const bool wave_live = __builtin_amdgcn_readfirstlane(qb + wave * 32) < Lq;
+  const bool wave_live = __builtin_amdgcn_readfirstlane(qb + wave * QG * 32) < Lq;
+  bool glive[QG];                                    // group g has queries (wave-uniform; a dead group follows only live ones)
+#pragma unroll
+  for (int g = 0; g < QG; ++g) glive[g] = __builtin_amdgcn_readfirstlane(qb + (wave * QG + g) * 32) < Lq;
   const int qrow = qvalid ? qi : (Lq - 1);
   const int pos = q_pos ? q_pos[qrow] : qrow;
   int tq = 0, aq = 0, kq = 0;
@@ -264,9 +281,11 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
       kq = rem - aq * 3;
     }
   }
-  opx8 qf[2][NPL];
-  {
-    const float* qp = Q + (size_t)b * q_batch_stride + (size_t)qrow * ldq + h * HD + half * 8;
+  opx8 qf[QG][2][NPL];
+#pragma unroll
+  for (int g = 0; g < QG; ++g) {
+    const int qrow_g = g == 0 ? qrow : min(qi + 32 * g, Lq - 1);
+    const float* qp = Q + (size_t)b * q_batch_stride + (size_t)qrow_g * ldq + h * HD + half * 8;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       f32x4 x0 = *reinterpret_cast<const f32x4*>(qp + ks * 16);
@@ -274,7 +293,7 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
       x0 *= scale_log2e;
       x1 *= scale_log2e;
       const float xs[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-      split_frag(xs, qf[ks]);
+      split_frag(xs, qf[g][ks]);
     }
   }
 
@@ -282,14 +301,20 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
   int k_end = Lk, rep_need = 0;                    // regular keys [0, k_end) and representative keys [0, rep_need) matter
   int tq_min_w = 0, tq_max_w = 0;
   // TBL: this wave's query group in the class's mask table, and the group's control words behind the class's mask entries
-  const int qgrp = __builtin_amdgcn_readfirstlane(DIR ? qblk : qblk * NW + wave), nsub_tbl = 2 * (int)kv_batch_stride;
-  const AS4 u32* ctl = nullptr;
+  static_assert(!TBL || DIR || NW * QG == 8, "the table's block schedules (TBL_CTL word 0) are those of 256-query blocks");
+  const int nsub_tbl = 2 * (int)kv_batch_stride;
+  int qgrp[QG];
+  const AS4 u32* ctl[QG];
   int tbl_n_reg = 0, tbl_n_rep = 0;
+#pragma unroll
+  for (int g = 0; g < QG; ++g) { qgrp[g] = __builtin_amdgcn_readfirstlane(DIR ? qblk : (qblk * NW + wave) * QG + g); ctl[g] = nullptr; }
   if (TBL) {
     const int groups = 4 * ((Lq + 127) / 128), live = (Lq + 31) >> 5;
     // (a wave without queries — the tail of the last 256-query block — still stages tiles: it takes the schedule of the block's last live group)
-    ctl = (const AS4 u32*)(cd.tbl + (size_t)groups * nsub_tbl * TBL_ENTRY) + (size_t)min(qgrp, live - 1) * TBL_CTL((int)kv_batch_stride);
-    const u32 hdr = ctl[DIR ? 1 : 0];
+#pragma unroll
+    for (int g = 0; g < QG; ++g)
+      ctl[g] = (const AS4 u32*)(cd.tbl + (size_t)groups * nsub_tbl * TBL_ENTRY) + (size_t)min(qgrp[g], live - 1) * TBL_CTL((int)kv_batch_stride);
+    const u32 hdr = ctl[0][DIR ? 1 : 0];
     tbl_n_reg = (int)(hdr & 0xffffu); tbl_n_rep = (int)(hdr >> 16);
   }
   if (MODE == MODE6_CAUSAL && !TBL) {
@@ -313,12 +338,16 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
   }
 
 
-  f32x16 oa;                                       // O^T accumulator
+  f32x16 oa[QG];                                   // O^T accumulators
 #pragma unroll
-  for (int r = 0; r < 16; ++r) oa[r] = 0.f;
+  for (int g = 0; g < QG; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oa[g][r] = 0.f;
   int tk_t = 0, tk_r = 0;                          // (timestep, offset in it) of the next sub-tile's first key
   const int t_last = (MODE == MODE6_CAUSAL) ? (Lk - 1) / A3 : 0;
-  float m_run = NEG_INF, l_run = 0.f;
+  float m_run[QG], l_run[QG];
+#pragma unroll
+  for (int g = 0; g < QG; ++g) { m_run[g] = NEG_INF; l_run[g] = 0.f; }
 
   const float* Kb = K + (size_t)b * kv_batch_stride + h * HD;
   const float* Vb = V + (size_t)b * kv_batch_stride + h * HD;
@@ -425,8 +454,9 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
     } else if (more) gload(tile_k0(it + 1), nxt);
     const bool rep_tile = it >= n_reg;               // wave-uniform: a tile of representative keys (compact contexts)
     const int k0 = it * KT6;
-    u32 cw = 0;                                      // TBL: this tile's control word (requested here, first used behind the DMA issue above)
-    if (TBL && wave_live) cw = ctl[2 + tile_k0(it) / KT6];
+    u32 cw[QG];                                      // TBL: this tile's control words (requested here, first used behind the DMA issue above)
+#pragma unroll
+    for (int g = 0; g < QG; ++g) cw[g] = (TBL && glive[g]) ? ctl[g][2 + tile_k0(it) / KT6] : 0u;
     // DIR: the fragments are read from the tile image itself (same layout as a stage: the DMA copies images verbatim)
     const op_t* Ks = DIR ? img + (size_t)(tile_k0(it) / KT6) * KV_IMG : arena + cur * BUF;
     const op_t* Vs = Ks + NPL * K_PLANE;
@@ -449,12 +479,18 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
       if (!wave_live) continue;
       const int ks0 = k0 + sub * 32;
       int t_lo = 0, t_hi = 0, ks_t0 = 0;
-      bool need_mask = true;
       const int j0 = (it - n_reg) * KT6 + sub * 32;   // first representative key of this sub-tile (rep_tile)
-      const u32 code = (cw >> (2 * sub)) & 3u;
+      // per query group of this wave: does it take part in this sub-tile (act), with masks (need_mask); TBL: the table's code
+      bool act[QG], need_mask[QG];
+      u32 code[QG];
+#pragma unroll
+      for (int g = 0; g < QG; ++g) { act[g] = glive[g]; need_mask[g] = true; code[g] = (cw[g] >> (2 * sub)) & 3u; }
       if (TBL) {
-        if (code == 0) continue;                      // no query of this wave sees a key of the sub-tile
-        need_mask = code >= 2;
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+          act[g] = code[g] != 0;                      // 0: no query of the group sees a key of the sub-tile (dead groups: cw = 0)
+          need_mask[g] = code[g] >= 2;
+        }
       } else if (!rep_tile) {
         // timestep of the first / last key of this sub-tile (tracked incrementally: no divisions in the loop)
         t_lo = tk_t;
@@ -465,64 +501,101 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
         if (ks0 >= k_end) continue;
         if (MODE == MODE6_CAUSAL) {
           if (t_lo > tq_max_w) continue;
-          need_mask = !(t_hi < tq_min_w && ks0 + 31 < Lk) || variant != 0;   // IL / Trajeglish: dead key types everywhere
+          need_mask[0] = !(t_hi < tq_min_w && ks0 + 31 < Lk) || variant != 0;   // IL / Trajeglish: dead key types everywhere
         }
       } else if (j0 >= rep_need || j0 > 3 * tq_max_w + 2) {
         continue;
       } else {
         // representative keys of steps before every query of this wave: all 32 visible, all m-fold -> no mask, and the
         // multiplicity enters through the accumulator seed below
-        need_mask = !(j0 + 31 <= 3 * tq_min_w && j0 + 32 <= rep_keys);
+        need_mask[0] = !(j0 + 31 <= 3 * tq_min_w && j0 + 32 <= rep_keys);
       }
-      // ---- S^T = K . Q^T : one accumulator chain, k-steps d 0-15 and d 16-31, six partial products each
-      // the accumulator starts at -m_base (the running maximum, 0 before the first visible key): the MFMA chain then
-      // delivers S - m directly and the per-element subtraction is needed only in the (rare) sub-tiles that raise the maximum
-      const float m_base = (m_run == NEG_INF) ? 0.f : m_run;
-      // TBL: every representative sub-tile is seeded with the multiplicity; the table's `nob` bits take it back where a key counts once
-      const float seed = (rep_tile && (TBL || !need_mask)) ? log2m - m_base : -m_base;
-      // TBL: this sub-tile's lane masks, requested (scalar loads, wave-uniform address) before the score products
-      u64 mk[16];
-      const AS4 u64* tbl_e = nullptr;
-      if (TBL && MODE == MODE6_CAUSAL && need_mask) {
-        const int jsub = (rep_tile ? nkt_reg + (it - n_reg) : it) * 2 + sub;
-        tbl_e = (const AS4 u64*)(cd.tbl) + ((size_t)qgrp * nsub_tbl + jsub) * TBL_ENTRY;
+      if (QG > 1) {
+        bool any = false;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mk[r] = tbl_e[r];
+        for (int g = 0; g < QG; ++g) any = any || act[g];
+        if (!any) continue;
+      } else if (!act[0]) {
+        continue;
       }
-      f32x16 s0;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s0[r] = seed;
+      // ---- K fragments of the sub-tile: read from LDS ONCE for all query groups of the wave
+      opx8 k0f[NPL], k1f[NPL];
       {
         const op_t* kr_ = Ks + (half * KT6 + sub * 32 + l31) * 8;
-        opx8 k0f[NPL], k1f[NPL];
 #pragma unroll
         for (int p = 0; p < NPL; ++p) {
           if (DIR) { k0f[p] = ck0[p]; k1f[p] = ck1[p]; continue; }
           k0f[p] = *reinterpret_cast<const opx8*>(kr_ + p * K_PLANE);                  // k-step 0 (d 0-15)
           k1f[p] = *reinterpret_cast<const opx8*>(kr_ + p * K_PLANE + 2 * KT6 * 8);    // k-step 1 (d 16-31)
         }
-#define QK(PA, PB)                       \
-  s0 = MFMA_OP(k0f[PA], qf[0][PB], s0);  \
-  s0 = MFMA_OP(k1f[PA], qf[1][PB], s0);
+      }
+      // ---- S^T = K . Q^T per group: one accumulator chain, k-steps d 0-15 and d 16-31, six partial products each
+      // the accumulator starts at -m_base (the running maximum, 0 before the first visible key): the MFMA chain then
+      // delivers S - m directly and the per-element subtraction is needed only in the (rare) sub-tiles that raise the maximum
+      f32x16 s0[QG];
+      u64 mk[QG][16];
+      const AS4 u64* tbl_e[QG];
+      float m_base[QG];
+#pragma unroll
+      for (int g = 0; g < QG; ++g) {
+        tbl_e[g] = nullptr;
+        m_base[g] = (m_run[g] == NEG_INF) ? 0.f : m_run[g];
+        if (!act[g]) continue;
+        // TBL: every representative sub-tile is seeded with the multiplicity; the table's `nob` bits take it back where a key counts once
+        const float seed = (rep_tile && (TBL || !need_mask[g])) ? log2m - m_base[g] : -m_base[g];
+        // TBL: this sub-tile's lane masks, requested (scalar loads, wave-uniform address) before the score products
+        if (TBL && MODE == MODE6_CAUSAL && need_mask[g]) {
+          const int jsub = (rep_tile ? nkt_reg + (it - n_reg) : it) * 2 + sub;
+          tbl_e[g] = (const AS4 u64*)(cd.tbl) + ((size_t)qgrp[g] * nsub_tbl + jsub) * TBL_ENTRY;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mk[g][r] = tbl_e[g][r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s0[g][r] = seed;
+#define QK(PA, PB)                                \
+  s0[g] = MFMA_OP(k0f[PA], qf[g][0][PB], s0[g]);  \
+  s0[g] = MFMA_OP(k1f[PA], qf[g][1][PB], s0[g]);
         PROD_LIST(QK)
 #undef QK
       }
+      // ---- V^T fragments: A = V^T rows d = l31, slots 0-3 <-> keys 16kk+4half+0..3, slots 4-7 <-> +8; read ONCE for all groups.
+      // QG > 1: requested here, their LDS latency runs underneath the score chains; QG = 1: right in front of the P^T . V^T products as in
+      // round 5 (at 80 registers the early request spills)
+      opx8 v0f[NPL], v1f[NPL];
+      auto load_v = [&]() {
+        // quad of subtile-local keys [4q', 4q'+3] is quad index sub*8 + q'; lane half h needs q' = 4kk + h and 4kk + 2 + h
+        const op_t* vr_ = Vs + ((sub * 8 + half) * HD + l31) * 4;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+          if (DIR) { v0f[p] = cv0[p]; v1f[p] = cv1[p]; continue; }
+          const opx4 a0 = *reinterpret_cast<const opx4*>(vr_ + p * V_PLANE);
+          const opx4 a1 = *reinterpret_cast<const opx4*>(vr_ + p * V_PLANE + 2 * HD * 4);
+          const opx4 b0 = *reinterpret_cast<const opx4*>(vr_ + p * V_PLANE + 4 * HD * 4);
+          const opx4 b1 = *reinterpret_cast<const opx4*>(vr_ + p * V_PLANE + 6 * HD * 4);
+          v0f[p] = cat8(a0, a1);
+          v1f[p] = cat8(b0, b1);
+        }
+      };
+      if (QG > 1) load_v();
+#pragma unroll
+      for (int g = 0; g < QG; ++g) {
+      if (!act[g]) continue;
       float sc[16];
       if (MODE == MODE6_KEYPAD && padflag[sub]) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = s0[r] + padbias[sub * 32 + mfma_row(r, half)];
-      } else if (TBL && MODE == MODE6_CAUSAL && need_mask) {
+        for (int r = 0; r < 16; ++r) sc[r] = s0[g][r] + padbias[sub * 32 + mfma_row(r, half)];
+      } else if (TBL && MODE == MODE6_CAUSAL && need_mask[g]) {
         // one v_cndmask_b32 per score, the table's SGPR pair as the lane mask.  (Through the inverse-ballot builtin, NOT inline asm: a
         // hand-written VALU instruction that reads the accumulator of the MFMA just issued gets no wait states from hipcc's hazard
         // recognizer and reads the registers before the matrix pipe has written them — the first version of this path did.)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_inverse_ballot_w64(mk[r]) ? s0[r] : NEG_INF;
-        if (code == 3) {
+        for (int r = 0; r < 16; ++r) sc[r] = __builtin_amdgcn_inverse_ballot_w64(mk[g][r]) ? s0[g][r] : NEG_INF;
+        if (code[g] == 3) {
           // the representative's own tokens of its step count once: take the multiplicity back (three query groups per context only)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) sc[r] -= __builtin_amdgcn_inverse_ballot_w64(tbl_e[16 + r]) ? log2m : 0.f;
+          for (int r = 0; r < 16; ++r) sc[r] -= __builtin_amdgcn_inverse_ballot_w64(tbl_e[g][16 + r]) ? log2m : 0.f;
         }
-      } else if (MODE == MODE6_CAUSAL && need_mask) {
+      } else if (MODE == MODE6_CAUSAL && need_mask[g]) {
         // visibility of the 32 keys of this sub-tile for this lane's query as a bit mask (bit i <-> key ks0 + i):
         //   keys of earlier timesteps: all; of the query's timestep: every state token (offset % 3 == 0) and the query's
         //   own agent's tokens up to the query itself; later timesteps and keys >= Lk: none.
@@ -564,7 +637,7 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
           for (int r = 0; r < 16; ++r) {
             const int pos_r = (r & 3) + 8 * (r >> 2);
             const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)vis, pos_r, 1), mb = (unsigned)__builtin_amdgcn_sbfe((int)bia, pos_r, 1);
-            const float v = s0[r] + __uint_as_float(__float_as_uint(log2m) & mb);
+            const float v = s0[g][r] + __uint_as_float(__float_as_uint(log2m) & mb);
             sc[r] = __uint_as_float((__float_as_uint(v) & m) | (0xFF800000u & ~m));
           }
         } else {
@@ -573,12 +646,12 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)vis, (r & 3) + 8 * (r >> 2), 1);
-            sc[r] = __uint_as_float((__float_as_uint(s0[r]) & m) | (0xFF800000u & ~m));
+            sc[r] = __uint_as_float((__float_as_uint(s0[g][r]) & m) | (0xFF800000u & ~m));
           }
         }
       } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = s0[r];
+        for (int r = 0; r < 16; ++r) sc[r] = s0[g][r];
       }
       // ---- online softmax (scores are relative to m_base)
       // Speculative fast path: exponentiate against the CURRENT base and look at the row sums only.  The base has to move when
@@ -588,7 +661,7 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
       // a query has no base yet and in the sub-tiles that fail the test — rare: moving the base at every new maximum sent
       // ~60 % of the sub-tiles of a 32-query wave through it (one of 32 queries sees a new maximum almost every time).
       float psum = 0.f;
-      bool general = __any(m_run == NEG_INF);
+      bool general = __any(m_run[g] == NEG_INF);
       if (!general) {
         float pe[16];
 #pragma unroll
@@ -600,7 +673,7 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
         if (!general) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) sc[r] = pe[r];
-          l_run += psum;
+          l_run[g] += psum;
         }
       }
       if (general) {
@@ -611,7 +684,7 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
           const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
           tmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
         }
-        const float m_rel_old = m_run - m_base;                       // 0, or -inf before the first visible key
+        const float m_rel_old = m_run[g] - m_base[g];                 // 0, or -inf before the first visible key
         const float m_rel_new = fmaxf(m_rel_old, tmax);
         const float shift = (m_rel_new == NEG_INF) ? 0.f : m_rel_new;
         const float alpha = __builtin_amdgcn_exp2f(m_rel_old - shift);
@@ -621,10 +694,10 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
           sc[r] = __builtin_amdgcn_exp2f(sc[r] - shift);
           psum += sc[r];
         }
-        l_run = l_run * alpha + psum;                                // per-lane partial (own 16 keys); halves are added at the end
-        m_run = (m_rel_new == NEG_INF) ? NEG_INF : m_base + shift;
+        l_run[g] = l_run[g] * alpha + psum;                          // per-lane partial (own 16 keys); halves are added at the end
+        m_run[g] = (m_rel_new == NEG_INF) ? NEG_INF : m_base[g] + shift;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oa[r] *= alpha;
+        for (int r = 0; r < 16; ++r) oa[g][r] *= alpha;
       }
       // ---- P^T fragments: k-step kk uses accumulator registers 8*kk .. 8*kk+7 (slot j <-> register 8*kk + j)
       opx8 pf[2][NPL];
@@ -632,25 +705,12 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
       for (int kk = 0; kk < 2; ++kk) {
         split_frag(sc + 8 * kk, pf[kk]);
       }
-      // ---- O^T += V^T . P^T : A = V^T rows d = l31, slots 0-3 <-> keys 16kk+4half+0..3, slots 4-7 <-> +8
-      {
-        // quad of subtile-local keys [4q', 4q'+3] is quad index sub*8 + q'; lane half h needs q' = 4kk + h and 4kk + 2 + h
-        const op_t* vr_ = Vs + ((sub * 8 + half) * HD + l31) * 4;
-        opx8 v0f[NPL], v1f[NPL];
-#pragma unroll
-        for (int p = 0; p < NPL; ++p) {
-          if (DIR) { v0f[p] = cv0[p]; v1f[p] = cv1[p]; continue; }
-          const opx4 a0 = *reinterpret_cast<const opx4*>(vr_ + p * V_PLANE);
-          const opx4 a1 = *reinterpret_cast<const opx4*>(vr_ + p * V_PLANE + 2 * HD * 4);
-          const opx4 b0 = *reinterpret_cast<const opx4*>(vr_ + p * V_PLANE + 4 * HD * 4);
-          const opx4 b1 = *reinterpret_cast<const opx4*>(vr_ + p * V_PLANE + 6 * HD * 4);
-          v0f[p] = cat8(a0, a1);
-          v1f[p] = cat8(b0, b1);
-        }
-#define PV(PA, PB)                       \
-  oa = MFMA_OP(v0f[PA], pf[0][PB], oa);  \
-  oa = MFMA_OP(v1f[PA], pf[1][PB], oa);
-        PROD_LIST(PV)
+      // ---- O^T += V^T . P^T
+      if (QG == 1) load_v();
+#define PV(PA, PB)                                \
+  oa[g] = MFMA_OP(v0f[PA], pf[0][PB], oa[g]);     \
+  oa[g] = MFMA_OP(v1f[PA], pf[1][PB], oa[g]);
+      PROD_LIST(PV)
 #undef PV
       }
     }
@@ -665,20 +725,24 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
   }
 
   // ---- normalise, transpose through LDS, store rows
-  {
-    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
-    l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-  }
-  const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-  float* ot = DIR ? reinterpret_cast<float*>(arena + 2 * PADSZ) : reinterpret_cast<float*>(arena) + wave * (32 * 33);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) ot[l31 * 33 + mfma_row(r, half)] = oa[r] * inv;
-  __builtin_amdgcn_wave_barrier();
+  for (int g = 0; g < QG; ++g) {
+    float lr = l_run[g];
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lr), __float_as_uint(lr), false, false);
+      lr = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    const float inv = lr > 0.f ? 1.0f / lr : 0.f;
+    float* ot = DIR ? reinterpret_cast<float*>(arena + 2 * PADSZ) : reinterpret_cast<float*>(arena) + (wave * QG + g) * (32 * 33);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int q = i * 2 + half;
-    const int gq = qb + wave * 32 + q;
-    if (gq < Lq) O[(size_t)b * o_batch_stride + (size_t)gq * ldo + h * HD + l31] = ot[q * 33 + l31];
+    for (int r = 0; r < 16; ++r) ot[l31 * 33 + mfma_row(r, half)] = oa[g][r] * inv;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int q = i * 2 + half;
+      const int gq = qb + (wave * QG + g) * 32 + q;
+      if (gq < Lq) O[(size_t)b * o_batch_stride + (size_t)gq * ldo + h * HD + l31] = ot[q * 33 + l31];
+    }
   }
   if (ab.cprof) {
     __syncthreads();
@@ -797,9 +861,15 @@ int launch_kv_zero_tail(int B, int key0, int n, int nkt, void* img, hipStream_t 
   return ctrlsim_launch_status();
 }
 // The same for up to 2 * MAXC (class, key region) entries in ONE launch: entry e covers the images from tile tile0 on of B contexts
+// Round 6: (i) the same entries applied to up to 8 image SETS of equal geometry in one launch (blockIdx.y: the scene encoder's images and the
+// memory K / V images of every decoder layer share the classes' tile offsets) — ten launches per forward pass became one; (ii) a tail that
+// is a whole 32-key sub-tile is not zeroed at all: no kernel ever computes a sub-tile without a valid key (mask-table code 0, `ks0 >= k_end`,
+// `j0 >= rep_need`), so only regions whose length is not a multiple of 32 have a tail anybody reads.
 struct KvTailEntry { int wg0, nkt, tile, k0; long tile0; };
 struct KvTailBatch { int n; KvTailEntry e[2 * MAXC]; };
-__global__ __launch_bounds__(256) void kv_zero_tails_kernel(KvTailBatch tb, op_t* __restrict__ img) {
+struct KvImgSets { op_t* img[8]; };
+__global__ __launch_bounds__(256) void kv_zero_tails_kernel(KvTailBatch tb, KvImgSets sets) {
+  op_t* __restrict__ img = sets.img[blockIdx.y];
   constexpr int K_PLANE = KT6 * HD, V_PLANE = HD * KT6;
   int ei = 0;
   while (ei + 1 < tb.n && (int)blockIdx.x >= tb.e[ei + 1].wg0) ++ei;
@@ -817,20 +887,25 @@ __global__ __launch_bounds__(256) void kv_zero_tails_kernel(KvTailBatch tb, op_t
     reinterpret_cast<unsigned*>(base + NPL * K_PLANE + pl * V_PLANE + q0 * HD * 4)[off] = 0u;
   }
 }
-int launch_kv_zero_tails(int n, const KvTailHost* t, void* img, hipStream_t st) {
-  if (n < 0 || n > 2 * MAXC || !img) return CTRLSIM_EINVAL;
+int launch_kv_zero_tails(int n, const KvTailHost* t, int nimg, void* const* imgs, hipStream_t st) {
+  if (n < 0 || n > 2 * MAXC || nimg < 1 || nimg > 8 || !imgs) return CTRLSIM_EINVAL;
+  KvImgSets sets;
+  for (int i = 0; i < 8; ++i) {
+    sets.img[i] = static_cast<op_t*>(imgs[i < nimg ? i : 0]);
+    if (!sets.img[i]) return CTRLSIM_EINVAL;
+  }
   KvTailBatch tb;
   tb.n = 0;
   int wg = 0;
   for (int i = 0; i < n; ++i) {
-    if (t[i].B <= 0 || t[i].n % KT6 == 0) continue;
+    if (t[i].B <= 0 || t[i].n % 32 == 0) continue;            // (a tail of whole sub-tiles is never read: see the kernel)
     const int tile = (t[i].key0 + t[i].n) / KT6;
     if ((t[i].n & 3) || (t[i].key0 & 63) || tile >= t[i].nkt) return CTRLSIM_EINVAL;
     tb.e[tb.n++] = KvTailEntry{wg, t[i].nkt, tile, t[i].n % KT6, t[i].tile0};
     wg += t[i].B * NHEAD;
   }
   if (tb.n == 0) return CTRLSIM_OK;
-  hipLaunchKernelGGL(kv_zero_tails_kernel, dim3(wg), dim3(256), 0, st, tb, static_cast<op_t*>(img));
+  hipLaunchKernelGGL(kv_zero_tails_kernel, dim3(wg, nimg), dim3(256), 0, st, tb, sets);
   return ctrlsim_launch_status();
 }
 
@@ -973,8 +1048,9 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
     // mask-table kernel: every class brings its table, the query rows are the token rows, CtRL-Sim mask, keys = the whole row layout
     use_tbl = use_tbl && c.mask_tbl && !c.q_pos && (c.rep_keys == 0 || c.rep_pos0 == c.Lk);
   }
-  // waves per workgroup of the staged form: 8 for the two full-row kernels (see ATT_NW_FULL), 4 for the in-kernel-mask causal kernel
-  const int nw = (mode == MODE6_KEYPAD || use_tbl) ? ATT_NW_FULL : 4;
+  // the two full-row kernels run ATT_NW_FULL waves of ATT_QG_FULL 32-query groups each (256 queries per workgroup), the
+  // in-kernel-mask causal kernel 4 waves of one group
+  const int nw = (mode == MODE6_KEYPAD || use_tbl) ? ATT_NW_FULL : 4, qg = (mode == MODE6_KEYPAD || use_tbl) ? ATT_QG_FULL : 1;
   for (int k = 0; k < n; ++k) {
     AttnClassHost c = cls[k];
     if (c.B <= 0 || c.Lq <= 0) continue;
@@ -984,7 +1060,7 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
       return CTRLSIM_EINVAL;
     if (c.rep_keys > 0 && (mode != MODE6_CAUSAL || variant || c.rep_mult < 1 || c.Lk % (3 * c.A) || c.rep_pos0 % (3 * c.A)))
       return CTRLSIM_EINVAL;
-    const int qblocks = dir ? (c.Lq + 31) / 32 : (c.Lq + 32 * nw - 1) / (32 * nw);
+    const int qblocks = dir ? (c.Lq + 31) / 32 : (c.Lq + 32 * nw * qg - 1) / (32 * nw * qg);
     ab.c[ab.n++] = AttnClass{c.q_row0 * ldq, c.o_row0 * ldo, c.img_tile0, c.pad_off, c.q_bs, c.o_bs, (long)c.nkt, c.q_pos,
                              static_cast<const unsigned long long*>(c.mask_tbl), c.Lq, c.Lk, c.A, c.rep_keys, c.rep_pos0, qblocks, wg,
                              c.rep_keys > 0 ? log2f((float)c.rep_mult) : 0.f};
@@ -1007,13 +1083,13 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
     hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, true, false, true>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad,
                        scale, 0, ab);
   } else if (mode == MODE6_CAUSAL && use_tbl) {
-    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, true, true, false, ATT_NW_FULL>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale,
+    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, true, true, false, ATT_NW_FULL, ATT_QG_FULL>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale,
                        variant, ab);
   } else if (mode == MODE6_CAUSAL) {
     hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, true>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale,
                        variant, ab);
   } else {
-    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, true, false, false, ATT_NW_FULL>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale, 0,
+    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, true, false, false, ATT_NW_FULL, ATT_QG_FULL>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale, 0,
                        ab);
   }
   prof_after(PROF_ATTN, flops, st, bytes, mode == MODE6_CAUSAL ? PKIND_ATTN_CAUSAL : PKIND_ATTN_KEYPAD);

@@ -34,7 +34,7 @@
   int launch_kv_split_rows(const float*, const float*, int, long, const int*, int, int, int, void*, hipStream_t);                 \
   int launch_kv_split_rows_classes(const float*, const float*, int, int, const KvRowsHost*, void*, hipStream_t);                  \
   int launch_kv_zero_tail(int, int, int, int, void*, hipStream_t);                                                                \
-  int launch_kv_zero_tails(int, const KvTailHost*, void*, hipStream_t);                                                           \
+  int launch_kv_zero_tails(int, const KvTailHost*, int, void* const*, hipStream_t);                                               \
   }
 SPLIT_LAUNCHERS(s1)
 SPLIT_LAUNCHERS(s0)
@@ -108,4 +108,6 @@ int launch_kv_split_rows_classes(const float* K, const float* V, int ldkv, int n
 int launch_kv_zero_tail(int B, int key0, int n, int nkt, void* img, hipStream_t st) {
   return PICK(launch_kv_zero_tail(B, key0, n, nkt, img, st));
 }
-int launch_kv_zero_tails(int n, const KvTailHost* t, void* img, hipStream_t st) { return PICK(launch_kv_zero_tails(n, t, img, st)); }
+int launch_kv_zero_tails(int n, const KvTailHost* t, int nimg, void* const* imgs, hipStream_t st) {
+  return PICK(launch_kv_zero_tails(n, t, nimg, imgs, st));
+}

@@ -33,7 +33,7 @@ int launch_layernorm256(const float*, int, const float*, int, const float*, cons
 int launch_gemm_nt_bf16x6_kv(const float*, int, const void*, int, int, const float*, const float*, int, float*, int, int, int,
                              int, int, const float*, const float*, void*, int, int, int, int, int, hipStream_t);
 int launch_kv_zero_tail(int, int, int, int, void*, hipStream_t);
-int launch_kv_zero_tails(int, const KvTailHost*, void*, hipStream_t);
+int launch_kv_zero_tails(int, const KvTailHost*, int, void* const*, hipStream_t);
 int launch_kv_split_rows_classes(const float*, const float*, int, int, const KvRowsHost*, void*, hipStream_t);
 int launch_outproj_ln_q(const float*, int, const float*, int, const void*, const float*, const float*, const float*, const void*, const float*,
                         float*, int, float*, int, int, hipStream_t);
@@ -485,8 +485,23 @@ int build_mask_tables(const Batch& bt, const Ws& w, int Tq, hipStream_t st) {
 // Linear whose last 512 output columns are attention keys / values: y[:, :kcol0] as fp32 rows, K / V as split images straight from
 // the GEMM epilogue when both bf16x6 kernels are selected (the fp32 K / V columns of y are then NOT written); otherwise GEMM +
 // a split pass per class.  mem: the scene / memory rows (M per context, plain key order) instead of the token rows.
+// The tails the row-wise epilogues leave in the last tiles of the key regions: classes' entries for the token rows (mem = false) or the
+// scene rows (mem = true), applied to nimg image sets of that geometry in ONE launch (tails of whole sub-tiles are skipped: nobody reads them)
+int zero_kv_tails(const Batch& bt, bool mem, int nimg, void* const* imgs, hipStream_t st) {
+  KvTailHost tails[2 * MAXC];
+  int nt = 0;
+  for (int k = 0; k < bt.n; ++k) {
+    const Cls& c = bt.c[k];
+    const int Lk = mem ? c.M : c.L, Lreg = mem ? c.M : c.Lreg, nkt = mem ? c.nkt_mem : c.nkt_dec;
+    const long tile0 = mem ? c.tile_mem : c.tile_dec;
+    tails[nt++] = KvTailHost{c.B, 0, Lreg, nkt, tile0};
+    if (Lreg < Lk) tails[nt++] = KvTailHost{c.B, c.sh.rep_k0(c.Lreg / (3 * c.sh.Areg)), Lk - Lreg, nkt, tile0};
+  }
+  return launch_kv_zero_tails(nt, tails, nimg, imgs, st);
+}
+
 int gemm_kv(const ctrlsim_dims& d, const Batch& bt, const Ws& w, const Lin& L, const float* x, float* y, int ldy, int n, int kcol0,
-            void* img, bool mem, hipStream_t st) {
+            void* img, bool mem, hipStream_t st, bool tails_done = false) {
   const long rows = mem ? bt.rM : bt.rL;
   bool fused = presplit() && L.w3() && ctrlsim_option(OPT_GEMM_IMPL) == 1;
   KvClassHost kc[MAXC];
@@ -499,13 +514,9 @@ int gemm_kv(const ctrlsim_dims& d, const Batch& bt, const Ws& w, const Lin& L, c
   }
   const size_t KIMG = split_kimg();      // 16-bit elements per tile
   if (fused) {
-    KvTailHost tails[2 * MAXC];
-    int nt = 0;
-    for (int k = 0; k < bt.n; ++k) {                  // the epilogue writes rows: the tails of the last tiles of both key regions stay
-      tails[nt++] = KvTailHost{kc[k].B, 0, kc[k].Lreg, kc[k].nkt, kc[k].tile0};
-      if (kc[k].Lreg < kc[k].L) tails[nt++] = KvTailHost{kc[k].B, kc[k].rep_k0, kc[k].L - kc[k].Lreg, kc[k].nkt, kc[k].tile0};
-    }
-    CHK(launch_kv_zero_tails(nt, tails, img, st));
+    // the epilogue writes rows: the tails of the last tiles of both key regions stay (zeroed here, unless the caller did it for
+    // several image sets at once)
+    if (!tails_done) { void* one[1] = {img}; CHK(zero_kv_tails(bt, mem, 1, one, st)); }
     if (L.wblk && ctrlsim_option(OPT_SPLIT) && (ctrlsim_option(OPT_GEMM_WS) & 8) && !(L.n0 & 31) && !(n & 31) && n <= 3 * DM && !(kcol0 & 31))
       return launch_inproj_rs(x, DM, L.wblk, L.b, y, ldy, (int)rows, n, img, kcol0, bt.n, kc, st);
     return launch_gemm_nt_bf16x6_kvc(x, DM, L.w3(), L.ntot ? L.ntot : n, L.n0, L.b, nullptr, 0, y, ldy, (int)rows, n, DM, 0, nullptr,
@@ -648,15 +659,24 @@ int scene_side(const ctrlsim_model* m, const Batch& bt, const Ws& w, float* dbg_
     if (e != hipSuccess) return CTRLSIM_ELAUNCH;
   }
   // ---- scene encoder (encoder.py:155-168): post-LN layers over [polylines || initial states] with key padding
+  // (the scene rows' image tails — the encoder's images and every decoder layer's memory K / V images share the geometry — in one launch)
+  {
+    void* sets[8];
+    int ns = 0;
+    sets[ns++] = w.img_enc;
+    for (int i = 0; i < d.ND && ns < 8; ++i) sets[ns++] = w.img_mem[i];
+    CHK(zero_kv_tails(bt, true, ns, sets, st));
+  }
+  const bool mem_tails_done = d.ND + 1 <= 8;
   for (int i = 0; i < d.NE; ++i) {
     const EncLayer& Le = m->enc[i];
-    CHK(gemm_kv(d, bt, w, Le.qkv, w.src, w.eqkv, 3 * DM, 3 * DM, DM, w.img_enc, true, st));
+    CHK(gemm_kv(d, bt, w, Le.qkv, w.src, w.eqkv, 3 * DM, 3 * DM, DM, w.img_enc, true, st, true));
     CHK(attention(d, bt, w, AttnCall{0, Q_SCENE, w.eqkv, 3 * DM, w.eqkv + DM, w.eqkv + 2 * DM, 3 * DM, w.img_enc, true, w.eatt, 0, 0, 0},
                   st));
     CHK(outproj_ln_ffn(Le.out, Le.n1, Le.lin1, Le.lin2, Le.n2, Le.fp, w.eatt, w.src, w.effn, w.etmp, rM, d.F, st));
   }
   // memory K/V of every decoder layer (cached for pass 2)
-  for (int i = 0; i < d.ND; ++i) CHK(gemm_kv(d, bt, w, m->dec[i].ckv, w.src, w.memkv[i], 2 * DM, 2 * DM, 0, w.img_mem[i], true, st));
+  for (int i = 0; i < d.ND; ++i) CHK(gemm_kv(d, bt, w, m->dec[i].ckv, w.src, w.memkv[i], 2 * DM, 2 * DM, 0, w.img_mem[i], true, st, mem_tails_done));
   return 0;
 }
 

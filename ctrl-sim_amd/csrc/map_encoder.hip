@@ -18,6 +18,7 @@
 // stored transposed so the wave reads it coalesced from L2).
 #include "common.h"
 #include "classes.h"
+#include <type_traits>
 
 #define MAXNP 256
 
@@ -81,8 +82,19 @@ __global__ __launch_bounds__(256) void map_pool_kernel(int NP, int P, MapClasses
   }
   __syncthreads();
   const int n_vis = q0[g_here];
-  // ---- phase 1: per visible point LN statistics and head scores
-  if (tid < n_vis) {
+  // ---- phase 1: per visible point LN statistics and head scores.  Round 6: the thread-per-point phase used to have work for
+  // ceil(n_vis / 64) of the four waves (two on the bench's scenes: the other two sat at the barrier through the kernel's longest phase).
+  // Now all four work: with nph = ceil(n_vis / 64) <= 2 point blocks the 256 channels are cut into parts = 4 / nph ranges, wave w takes
+  // point block w % nph and channel range w / nph, and the partial scores meet in the softmax below (scp[part][point][head] fills the
+  // same 8 KB as sc[point][head]).  Three or four point blocks: one wave each, all channels, as before.
+  const int nph = (n_vis + 63) >> 6, parts = nph <= 2 ? (nph == 1 ? 4 : 2) : 1;      // workgroup-uniform
+  const int wv_s = __builtin_amdgcn_readfirstlane(wv);      // scalar: the channel range must stay wave-uniform (weights by s_load)
+  const int my_ph = parts > 1 ? wv_s % nph : wv_s, my_part = parts > 1 ? wv_s / nph : 0;
+  const int c_lo = my_part * (DM / parts);
+  const int pt1 = my_ph * 64 + lane;
+  float (*scp)[8] = sc + my_part * (64 * nph);                                       // this wave's partial-score block
+  if (pt1 < n_vis && my_ph < nph) {
+    const int tid = pt1;                              // (the point index; shadows the thread index in this block on purpose)
     const float x = pts[tid][0], y = pts[tid][1], e = pts[tid][2];
     // LayerNorm statistics in closed form (the layer is affine in the point: pack.py); the mean drops out of the centred weights
     const float* G = w.G;
@@ -91,20 +103,26 @@ __global__ __launch_bounds__(256) void map_pool_kernel(int NP, int P, MapClasses
     const float rstd = 1.0f / sqrtf(fmaxf(var, 0.f) + 1e-5f);
     float s8[8];
 #pragma unroll
-    for (int h = 0; h < 8; ++h) s8[h] = w.cb[h];
-#ifdef MPV_ABL_NO_P1
-    for (int c = 0; c < (x > 1e30f ? DM : 0); ++c) {
-#else
-    for (int c = 0; c < DM; ++c) {
-#endif
-      const float d = fmaf(w.Wc[c * 4 + 2], e, fmaf(w.Wc[c * 4 + 1], y, fmaf(w.Wc[c * 4], x, w.Wc[c * 4 + 3])));
-      const float hv = fmaxf(fmaf(d, rstd, w.ln_b[c]), 0.f);
+    for (int h = 0; h < 8; ++h) s8[h] = my_part == 0 ? w.cb[h] : 0.f;
+    // (compile-time trip counts: with run-time bounds hipcc gave up the unrolling / scalar-load batching of this loop and the kernel
+    // lost 5-7 % — even in the unchanged one-range case)
+    auto channels = [&](auto NC) {
+      const float* Wc = w.Wc + c_lo * 4;
+      const float* lb = w.ln_b + c_lo;
+      const float* U = w.U + c_lo * 8;
+      for (int c = 0; c < decltype(NC)::value; ++c) {
+        const float d = fmaf(Wc[c * 4 + 2], e, fmaf(Wc[c * 4 + 1], y, fmaf(Wc[c * 4], x, Wc[c * 4 + 3])));
+        const float hv = fmaxf(fmaf(d, rstd, lb[c]), 0.f);
 #pragma unroll
-      for (int h = 0; h < 8; ++h) s8[h] = fmaf(hv, w.U[c * 8 + h], s8[h]);
-    }
-    stat[tid] = rstd;
+        for (int h = 0; h < 8; ++h) s8[h] = fmaf(hv, U[c * 8 + h], s8[h]);
+      }
+    };
+    if (parts == 1) channels(std::integral_constant<int, DM>{});
+    else if (parts == 2) channels(std::integral_constant<int, DM / 2>{});
+    else channels(std::integral_constant<int, DM / 4>{});
+    if (my_part == 0) stat[tid] = rstd;
 #pragma unroll
-    for (int h = 0; h < 8; ++h) sc[tid][h] = s8[h];
+    for (int h = 0; h < 8; ++h) scp[tid][h] = s8[h];
   }
   __syncthreads();
   // ---- softmax over the visible points of a polyline, per head.  One 16-lane DPP row per (polyline, head) pair — 16 pairs = the 256
@@ -114,7 +132,14 @@ __global__ __launch_bounds__(256) void map_pool_kernel(int NP, int P, MapClasses
     const int pair = tid >> 4, sub = tid & 15, g = pair >> 3, hd = pair & 7;
     const int a = g < g_here ? q0[g] : 0, b = g < g_here ? q0[g + 1] : 0;
     float mx = -__builtin_inff();
-    for (int p = a + sub; p < b; p += 16) mx = fmaxf(mx, sc[p][hd]);
+    for (int p = a + sub; p < b; p += 16) {
+      float t = sc[p][hd];
+      if (parts > 1) {                                 // the channel ranges' partial scores (every (point, head) belongs to one lane)
+        for (int q = 1; q < parts; ++q) t += sc[q * 64 * nph + p][hd];
+        sc[p][hd] = t;
+      }
+      mx = fmaxf(mx, t);
+    }
     mx = fmaxf(mx, dpp_f32<0xB1>(mx));       // quad_perm [1,0,3,2]
     mx = fmaxf(mx, dpp_f32<0x4E>(mx));       // quad_perm [2,3,0,1]
     mx = fmaxf(mx, dpp_f32<0x141>(mx));      // row_half_mirror

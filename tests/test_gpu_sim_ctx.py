@@ -621,31 +621,42 @@ def test_full_size_rollout_is_invariant_to_batching_and_cache():
     runs = {}
     # "one_lane": a single lane has no side stream — every kernel in program order on one stream; the default two lanes run the
     # second pass, the simulator step and the cached steps on side streams ordered by events (a missing dependency would show here)
+    # "poison" (round 6): every byte of the lanes' workspaces is 0xFF before the rollout — NaN as fp32, as fp16 and as bf16.  The
+    # K / V tile images live there and their producers write ROWS: the keys between the end of a key region and its tile boundary keep
+    # what the memory held.  Since round 6 only tails that are not whole 32-key sub-tiles are zeroed (one launch per pass for all
+    # scene-side image sets); a kernel that computed a sub-tile without a valid key, or a producer that left a partial tail, would
+    # multiply P = 0 by NaN and the rollout would differ (or trip the guard).
     for tag, order, max_ctx, cache, lanes in (("ref", [0, 1, 2], 64, True, 2), ("rechunk", [2, 0, 1], 24, True, 2),
                                               ("nocache", [1, 2, 0], 64, False, 2), ("one_lane", [0, 1, 2], 64, True, 1),
-                                              ("dirty", [0, 1, 2], 64, True, 2)):
+                                              ("dirty", [0, 1, 2], 64, True, 2), ("poison", [0, 1, 2], 64, True, 2),
+                                              ("poison_nocache", [0, 1, 2], 64, False, 2)):
         eng = RolloutEngine(cfg, w, DEV, max_ctx=max_ctx, seed=3, use_cache=cache, model=model, lanes=lanes)
         model = eng.model
         eng.load_scenarios([scns[i] for i in order], steps=90)
+        if tag.startswith("poison"):
+            for ln in eng.lanes:
+                ln.ws.fill_(0xFF)
+            torch.cuda.synchronize()
         if tag == "dirty":
             with Polluter() as pol:
                 r = eng.run(90).results()
             assert pol.launches > 100
         else:
             r = eng.run(90).results()
+        assert eng.scheme == 1, tag              # no guard event sent the rollout to the bf16x6 fallback (a NaN from a poisoned tail would)
         runs[tag] = {i: {k: (r[k][pos] if k != "n_groups" else r[k][:, pos]) for k in ("tokens", "rtg_bins", "states", "coll", "n_groups")}
                      for pos, i in enumerate(order)}
     for i in range(3):
         a = runs["ref"][i]
         assert np.isfinite(a["states"]).all() and a["tokens"].min() >= 0 and a["tokens"].max() < d.V
         assert a["n_groups"].min() >= 3          # 64 vehicles need at least ceil(64 / 24) focal groups
-        for tag in ("rechunk", "nocache", "one_lane", "dirty"):
+        for tag in ("rechunk", "nocache", "one_lane", "dirty", "poison", "poison_nocache"):
             b = runs[tag][i]
             assert np.array_equal(a["n_groups"], b["n_groups"]), tag
             assert np.array_equal(a["tokens"], b["tokens"]), tag
             assert np.array_equal(a["rtg_bins"], b["rtg_bins"]), tag
             assert np.array_equal(a["coll"], b["coll"]), tag
-            if tag in ("rechunk", "one_lane", "dirty"):
+            if tag in ("rechunk", "one_lane", "dirty", "poison"):
                 assert np.array_equal(a["states"], b["states"]), tag
             else:
                 np.testing.assert_allclose(a["states"], b["states"], atol=1e-4, rtol=0)

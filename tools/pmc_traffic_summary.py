@@ -56,6 +56,13 @@ def main():
     for ln in open(f"{out}/FETCH_SIZE.log"):
         if ln.startswith("{"):
             line = json.loads(ln)
+    # (round 6: the stdout line is the short one; the per-kernel byte counts are in the detail file it names)
+    if line and "kernel_bytes_all_streams" not in line.get("roofline", {}) and line.get("detail_file"):
+        import os
+        for cand in (line["detail_file"], os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", line["detail_file"])):
+            if os.path.exists(cand):
+                line = json.load(open(cand))
+                break
     alg = (line or {}).get("roofline", {}).get("kernel_bytes_all_streams", {})
     kinds = collections.defaultdict(lambda: {"launches": 0, "fetch_counter_bytes": 0.0, "write_counter_bytes": 0.0, "kernel_names": []})
     names = {}
