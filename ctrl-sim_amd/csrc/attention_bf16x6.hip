@@ -169,8 +169,14 @@ __global__ __launch_bounds__(256) void attn_mask_table_kernel(TblBatch tb) {
 #define ATT_QG 1
 #endif
 constexpr int ATT_QG_FULL = ATT_QG, ATT_NW_FULL = 8 / ATT_QG;
-template <int MODE, bool PRE, bool TBL = false, bool DIR = false, int NW = 4, int QG = 1>
-__global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) void attention_bf16x6_kernel(
+// RES (round 6, the key-padded full-row kernel): the keys of a (context, head) are FEW — 200 polylines + the vehicles = 3.5 tiles — and every
+// 256-query block used to stage them again (nine times at L = 2304) for four tiles of work between a prologue and an epilogue.  RES keeps
+// ALL tiles of the (context, head) resident in LDS (NBUF = 4 stages = 66.6 KB, two workgroups per CU, four waves per SIMD): one DMA burst and ONE
+// barrier per workgroup, then the workgroup walks its query blocks — Q rows in, four tiles of products, rows out (straight from the
+// accumulators, 16 bytes per lane and out-quad: the LDS transpose would alias the resident tiles) — with no barrier, no DMA and no wait
+// in the loop.  L2 -> LDS traffic of the launch: one image read per (context, head) instead of one per query block.
+template <int MODE, bool PRE, bool TBL = false, bool DIR = false, int NW = 4, int QG = 1, bool RES = false>
+__global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (RES ? 4 : (NW == 8 ? 6 : 3))) void attention_bf16x6_kernel(
     const float* __restrict__ Qb_, int ldq, const float* __restrict__ K, const float* __restrict__ V, int ldkv,
     float* __restrict__ Ob_, int ldo, const unsigned char* __restrict__ key_pad_, float scale_log2e, int variant, AttnBatch ab) {
   const unsigned long long t_start = ab.cprof ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -208,7 +214,8 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
 #ifndef ATT_NBUF_FULL
 #define ATT_NBUF_FULL 2
 #endif
-  constexpr int NBUF = (PRE && !DIR && NW == 8) ? ATT_NBUF_FULL : 2;
+  constexpr int NBUF = RES ? 4 : ((PRE && !DIR && NW == 8) ? ATT_NBUF_FULL : 2);
+  static_assert(!RES || (MODE == MODE6_KEYPAD && PRE && !DIR && !TBL && QG == 1), "resident keys: the key-padded staged kernel");
   static_assert(!DIR || PRE, "the streaming form reads pre-split images");
   constexpr int PADSZ = 2 * KT6 + 8;             // 16-bit elements of a stage's key-padding bias block
   constexpr int BUF_ = DIR ? PADSZ : BUF, NBUF_ = NBUF;
@@ -225,8 +232,10 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
   const int lin = (int)blockIdx.x - cd.wg0;
   const int h = lin & (NHEAD - 1), j = lin >> 3;
   const int qx = j % nqb, b = j / nqb;
-  const int qblk = (MODE == MODE6_CAUSAL) ? (nqb - 1 - qx) : qx;
-  const int qb = qblk * (DIR ? 32 : 32 * NW * QG);
+  // RES: nqb = workgroups per (context, head); workgroup qx walks the query blocks [q_lo, q_hi) of the nqb_total the class has
+  const int nqb_total = (Lq + 32 * NW * QG - 1) / (32 * NW * QG);
+  const int q_lo = RES ? qx * nqb_total / nqb : ((MODE == MODE6_CAUSAL) ? (nqb - 1 - qx) : qx);
+  const int q_hi = RES ? (qx + 1) * nqb_total / nqb : q_lo + 1;
   const int tid = threadIdx.x, wave = DIR ? 0 : tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
   const int A3 = 3 * A;
   const float NEG_INF = -__builtin_inff();
@@ -253,7 +262,38 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
                    :: "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(src + 64 * NW * 8 * i) : "memory");
     }
   };
-  if (PRE) dma_tile(0, 0);
+  if (PRE && !RES) dma_tile(0, 0);
+  if (RES) {
+    // every tile of the (context, head) + its key-padding bias block, once; ceil(Lk / 64) <= NBUF is the launcher's condition for this kernel
+    const int nt = (Lk + KT6 - 1) / KT6;
+    for (int t = 0; t < nt; ++t) {
+      dma_tile(t, t);
+      if (tid < KT6) {
+        const int kr = t * KT6 + tid;
+        const float pp = (kr < Lk && !key_pad[(size_t)b * Lk + kr]) ? 0.f : NEG_INF;
+        const unsigned long long bal = __ballot(pp != 0.f);
+        float* pb_ = reinterpret_cast<float*>(arena + t * BUF_ + NPL * (K_PLANE + V_PLANE));
+        pb_[tid] = pp;
+        if (tid < 2) reinterpret_cast<int*>(pb_ + KT6)[tid] = (unsigned)(bal >> (32 * tid)) != 0u;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) ; KV-DMA landed (all tiles)" ::: "memory");
+    __syncthreads();
+  }
+  // RES: the Q rows of the NEXT query block are requested while the current one is computed (a wave has nothing else in flight in its loop)
+  f32x4 qraw[RES ? 4 : 1];
+  auto q_request = [&](int qblk_) {
+    const int row = min(qblk_ * (32 * NW * QG) + wave * QG * 32 + l31, Lq - 1);
+    const float* qp = Q + (size_t)b * q_batch_stride + (size_t)row * ldq + h * HD + half * 8;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qraw[RES ? 2 * ks : 0] = *reinterpret_cast<const f32x4*>(qp + ks * 16);
+      qraw[RES ? 2 * ks + 1 : 0] = *reinterpret_cast<const f32x4*>(qp + ks * 16 + 4);
+    }
+  };
+  if (RES && q_lo < q_hi) q_request(q_lo);
+  for (int qblk = q_lo; qblk < q_hi; ++qblk) {          // (one query block per workgroup unless RES)
+  const int qb = qblk * (DIR ? 32 : 32 * NW * QG);
 
   // ---- this lane's query: fragment of Q^T (B operand), k-step ks covers d = 16*ks + 8*half .. +7
   // (QG > 1: group g of this wave = queries qb + (wave * QG + g) * 32 + l31; everything per-query below is an array over g)
@@ -288,14 +328,15 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
     const float* qp = Q + (size_t)b * q_batch_stride + (size_t)qrow_g * ldq + h * HD + half * 8;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      f32x4 x0 = *reinterpret_cast<const f32x4*>(qp + ks * 16);
-      f32x4 x1 = *reinterpret_cast<const f32x4*>(qp + ks * 16 + 4);
+      f32x4 x0 = RES ? qraw[RES ? 2 * ks : 0] : *reinterpret_cast<const f32x4*>(qp + ks * 16);
+      f32x4 x1 = RES ? qraw[RES ? 2 * ks + 1 : 0] : *reinterpret_cast<const f32x4*>(qp + ks * 16 + 4);
       x0 *= scale_log2e;
       x1 *= scale_log2e;
       const float xs[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
       split_frag(xs, qf[g][ks]);
     }
   }
+  if (RES && qblk + 1 < q_hi) q_request(qblk + 1);
 
   // ---- key range
   int k_end = Lk, rep_need = 0;                    // regular keys [0, k_end) and representative keys [0, rep_need) matter
@@ -414,13 +455,15 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
   const int n_reg = TBL ? tbl_n_reg : (k_end + KT6 - 1) / KT6, n_rep = TBL ? tbl_n_rep : (rep_need + KT6 - 1) / KT6, n_it = n_reg + n_rep;
   const int nkt_reg = (rep_pos0 + KT6 - 1) / KT6;
   auto tile_k0 = [&](int it) { return (it < n_reg ? it : nkt_reg + (it - n_reg)) * KT6; };
+  if (!RES) {
   if (n_it > 0) {
     gload(tile_k0(0), 0, false);                 // PRE: tile 0 (always a regular tile: k_end >= 1) was requested at the top
     sstore(0);
   }
   if (PRE && !DIR) asm volatile("s_waitcnt vmcnt(0) ; KV-DMA landed" ::: "memory");
   __syncthreads();
-  if (PRE && !DIR) {
+  }
+  if (PRE && !DIR && !RES) {
 #pragma unroll
     for (int a = 1; a < NBUF - 1; ++a)                                  // NBUF = 3: tile 1 is requested here, tile it + 2 at the top of tile it
       if (a < n_it) dma_tile(tile_k0(a) / KT6, a);
@@ -448,7 +491,9 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
     const bool more = it + 1 < n_it;
     const int nxt = cur + 1 == NBUF ? 0 : cur + 1;                       // buffer of tile it + 1
     const bool ahead = (PRE && !DIR) && it + NBUF - 1 < n_it;            // a tile to request now (tile it + NBUF - 1)
-    if (PRE && !DIR) {
+    if (RES) {
+      // (every tile is resident in buffer `it`: nothing to request, nothing to wait for)
+    } else if (PRE && !DIR) {
       if (ahead) dma_tile(tile_k0(it + NBUF - 1) / KT6, cur == 0 ? NBUF - 1 : cur - 1);
       if (more) gload(tile_k0(it + 1), nxt, false);                      // (key-padding bias of the NEXT tile: registers now, LDS at the end)
     } else if (more) gload(tile_k0(it + 1), nxt);
@@ -714,6 +759,7 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
 #undef PV
       }
     }
+    if (RES) continue;
     if (more) sstore(nxt);
     if (PRE && !DIR) {
       // tile it + 1 must have landed; the pieces of tile it + NBUF - 1 requested at the top of this tile (NBUF = 3) stay in flight across
@@ -733,6 +779,18 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
       lr = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
     const float inv = lr > 0.f ? 1.0f / lr : 0.f;
+    if (RES) {
+      // straight from the accumulators: lane (query l31, half) holds d = 8 q + 4 half + (0..3) in registers 4 q .. 4 q + 3 — four 16-byte
+      // stores into its query's row (a lane pair completes 32 contiguous bytes); the resident tiles leave no LDS for a transpose
+      const int gq = qb + wave * 32 + l31;
+      if (gq < Lq) {
+        float* orow = O + (size_t)b * o_batch_stride + (size_t)gq * ldo + h * HD + 4 * half;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(orow + 8 * q) = f32x4{oa[g][4 * q] * inv, oa[g][4 * q + 1] * inv, oa[g][4 * q + 2] * inv, oa[g][4 * q + 3] * inv};
+      }
+      continue;
+    }
     float* ot = DIR ? reinterpret_cast<float*>(arena + 2 * PADSZ) : reinterpret_cast<float*>(arena) + (wave * QG + g) * (32 * 33);
 #pragma unroll
     for (int r = 0; r < 16; ++r) ot[l31 * 33 + mfma_row(r, half)] = oa[g][r] * inv;
@@ -744,6 +802,7 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (NW == 8 ? 6 : 3)) vo
       if (gq < Lq) O[(size_t)b * o_batch_stride + (size_t)gq * ldo + h * HD + l31] = ot[q * 33 + l31];
     }
   }
+  }   // query blocks of this workgroup
   if (ab.cprof) {
     __syncthreads();
     if (tid == 0) {
@@ -1051,6 +1110,17 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
   // the two full-row kernels run ATT_NW_FULL waves of ATT_QG_FULL 32-query groups each (256 queries per workgroup), the
   // in-kernel-mask causal kernel 4 waves of one group
   const int nw = (mode == MODE6_KEYPAD || use_tbl) ? ATT_NW_FULL : 4, qg = (mode == MODE6_KEYPAD || use_tbl) ? ATT_QG_FULL : 1;
+  // key-padded launches whose keys fit four tiles per (context, head) (the scene: 200 polylines + the vehicles): the resident-keys kernel
+#ifndef ATT_KEYPAD_RES
+#define ATT_KEYPAD_RES 1
+#endif
+  bool res = ATT_KEYPAD_RES && mode == MODE6_KEYPAD && !dir && ATT_QG_FULL == 1 && !(ldo & 3);
+  long pairs_total = 0;
+  for (int k = 0; k < n; ++k) {
+    if (cls[k].B <= 0 || cls[k].Lq <= 0) continue;
+    res = res && (cls[k].Lk + KT6 - 1) / KT6 <= 4 && !cls[k].q_pos;
+    pairs_total += (long)cls[k].B * NHEAD;
+  }
   for (int k = 0; k < n; ++k) {
     AttnClassHost c = cls[k];
     if (c.B <= 0 || c.Lq <= 0) continue;
@@ -1060,7 +1130,13 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
       return CTRLSIM_EINVAL;
     if (c.rep_keys > 0 && (mode != MODE6_CAUSAL || variant || c.rep_mult < 1 || c.Lk % (3 * c.A) || c.rep_pos0 % (3 * c.A)))
       return CTRLSIM_EINVAL;
-    const int qblocks = dir ? (c.Lq + 31) / 32 : (c.Lq + 32 * nw * qg - 1) / (32 * nw * qg);
+    int qblocks = dir ? (c.Lq + 31) / 32 : (c.Lq + 32 * nw * qg - 1) / (32 * nw * qg);
+    if (res) {
+      // workgroups per (context, head): one walks all query blocks when the launch has enough (context, head) pairs to fill the chip
+      // (two workgroups per CU: 512 resident), else the blocks are dealt to a few
+      const int want = (int)((1536 + pairs_total - 1) / pairs_total);
+      qblocks = want < 1 ? 1 : (want > qblocks ? qblocks : want);
+    }
     ab.c[ab.n++] = AttnClass{c.q_row0 * ldq, c.o_row0 * ldo, c.img_tile0, c.pad_off, c.q_bs, c.o_bs, (long)c.nkt, c.q_pos,
                              static_cast<const unsigned long long*>(c.mask_tbl), c.Lq, c.Lk, c.A, c.rep_keys, c.rep_pos0, qblocks, wg,
                              c.rep_keys > 0 ? log2f((float)c.rep_mult) : 0.f};
@@ -1088,6 +1164,9 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
   } else if (mode == MODE6_CAUSAL) {
     hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, true>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale,
                        variant, ab);
+  } else if (res) {
+    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, true, false, false, 8, 1, true>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale, 0,
+                       ab);
   } else {
     hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, true, false, false, ATT_NW_FULL, ATT_QG_FULL>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale, 0,
                        ab);
