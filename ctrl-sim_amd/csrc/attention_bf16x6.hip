@@ -28,6 +28,9 @@ namespace SPLIT_NS {
 #define ATT_PMAX 32768.0f     // row-sum bound of the speculative softmax path: every probability then fits the fp16 plane
 
 
+#ifndef ATT_ALIGN_END
+#define ATT_ALIGN_END 0      // 1: the mask-table kernel's 256-query blocks end at the last row (the partial block is the FIRST one): see the kernel
+#endif
 #define KT6 64
 #define KV_IMG (2 * NPL * KT6 * HD)   // 16-bit elements of one (context, head, 64-key tile) image: K planes then V^T planes (8 KB per plane pair)
 #define KV_PIECES (2 * NPL)          // 16-byte-per-thread LDS-DMA pieces of an image
@@ -109,8 +112,10 @@ __global__ __launch_bounds__(256) void attn_mask_table_kernel(TblBatch tb) {
       const int k_end = min(c.Lk, (bt + 1) * A3), rep_need = min(c.rep_keys, (bt + 1) * 3);
       return (u32)((k_end + KT6 - 1) / KT6) | ((u32)((rep_need + KT6 - 1) / KT6) << 16);
     };
-    const int b0 = (g >> 3) * 256;
-    ctl[0] = sched(b0, min(b0 + 255, c.Lq - 1));
+    // (the kernel aligns its 256-query blocks to the END of the row range when the row count is a multiple of 32: ATT_ALIGN_END there)
+    const int shift = (ATT_ALIGN_END && (c.Lq & 31) == 0) ? (256 - c.Lq % 256) % 256 : 0;
+    const int b0 = ((g + (shift >> 5)) >> 3) * 256 - shift;
+    ctl[0] = sched(max(b0, 0), min(b0 + 255, c.Lq - 1));
     ctl[1] = sched(32 * g < c.Lq ? 32 * g : c.Lq - 1, min(32 * g + 31, c.Lq - 1));
   }
   for (int j = wave; j < nsub; j += 4) {
@@ -293,19 +298,30 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (RES ? 4 : (NW == 8 ?
   };
   if (RES && q_lo < q_hi) q_request(q_lo);
   for (int qblk = q_lo; qblk < q_hi; ++qblk) {          // (one query block per workgroup unless RES)
-  const int qb = qblk * (DIR ? 32 : 32 * NW * QG);
+  // TBL (round 6): the query blocks are aligned to the END of the row range — block k = rows [256 k - shift, 256 k - shift + 256), shift = the
+  // padding of the row count to a multiple of 256 — so that the PARTIAL block is the first one, whose queries see the fewest keys (3-5
+  // tiles), instead of the last one (the whole key range: up to 38 tiles with half or more of the workgroup's waves dead through all of them:
+  // L = 1056 left seven of eight waves idle for 19 tiles).  Groups stay 32-aligned (shift is a multiple of 32 when the row count is).
+  // MEASURED (tools/jobs/r06_l.sh, sustained, same box; -DATT_ALIGN_END=1): A' = 11 / 6 gain 4 / 2.5 %, A' = 4 / 9 / 14 / 20 LOSE 5 / 4 / 3.5 / 1 %,
+  // rollout 143.7 -> 143.3 k (-0.3 %, two pairs): dead waves do not hold the matrix pipe, and the full last blocks now all finish together.
+  // Off (default 0); tokens identical either way.
+  const int qshift = (ATT_ALIGN_END && TBL && !DIR && (Lq & 31) == 0) ? (32 * NW * QG - Lq % (32 * NW * QG)) % (32 * NW * QG) : 0;
+  const int qb = qblk * (DIR ? 32 : 32 * NW * QG) - qshift;
 
   // ---- this lane's query: fragment of Q^T (B operand), k-step ks covers d = 16*ks + 8*half .. +7
   // (QG > 1: group g of this wave = queries qb + (wave * QG + g) * 32 + l31; everything per-query below is an array over g)
   const int qi = qb + wave * QG * 32 + l31;
-  const bool qvalid = qi < Lq;
+  const bool qvalid = qi >= 0 && qi < Lq;
   // a wave whose 32 query slots all lie beyond Lq (few-query calls: the second pass, the last decoder layer, the K/V-cached
   // steps fill one wave of the four) stages tiles and keeps the barriers, but skips the products and the softmax
-  const bool wave_live = __builtin_amdgcn_readfirstlane(qb + wave * QG * 32) < Lq;
-  bool glive[QG];                                    // group g has queries (wave-uniform; a dead group follows only live ones)
+  bool glive[QG];                                    // group g has queries (wave-uniform): its first row lies in [0, Lq)
+  bool wave_live = false;
 #pragma unroll
-  for (int g = 0; g < QG; ++g) glive[g] = __builtin_amdgcn_readfirstlane(qb + (wave * QG + g) * 32) < Lq;
-  const int qrow = qvalid ? qi : (Lq - 1);
+  for (int g = 0; g < QG; ++g) {
+    glive[g] = (unsigned)__builtin_amdgcn_readfirstlane(qb + (wave * QG + g) * 32) < (unsigned)Lq;
+    wave_live = wave_live || glive[g];
+  }
+  const int qrow = qvalid ? qi : (qi < 0 ? 0 : Lq - 1);
   const int pos = q_pos ? q_pos[qrow] : qrow;
   int tq = 0, aq = 0, kq = 0;
   bool rep_q = false;                               // this lane's query is a representative token
@@ -324,7 +340,7 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (RES ? 4 : (NW == 8 ?
   opx8 qf[QG][2][NPL];
 #pragma unroll
   for (int g = 0; g < QG; ++g) {
-    const int qrow_g = g == 0 ? qrow : min(qi + 32 * g, Lq - 1);
+    const int qrow_g = g == 0 ? qrow : max(min(qi + 32 * g, Lq - 1), 0);
     const float* qp = Q + (size_t)b * q_batch_stride + (size_t)qrow_g * ldq + h * HD + half * 8;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -348,13 +364,13 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (RES ? 4 : (NW == 8 ?
   const AS4 u32* ctl[QG];
   int tbl_n_reg = 0, tbl_n_rep = 0;
 #pragma unroll
-  for (int g = 0; g < QG; ++g) { qgrp[g] = __builtin_amdgcn_readfirstlane(DIR ? qblk : (qblk * NW + wave) * QG + g); ctl[g] = nullptr; }
+  for (int g = 0; g < QG; ++g) { qgrp[g] = __builtin_amdgcn_readfirstlane(DIR ? qblk : (qblk * NW + wave) * QG + g - (qshift >> 5)); ctl[g] = nullptr; }
   if (TBL) {
     const int groups = 4 * ((Lq + 127) / 128), live = (Lq + 31) >> 5;
     // (a wave without queries — the tail of the last 256-query block — still stages tiles: it takes the schedule of the block's last live group)
 #pragma unroll
     for (int g = 0; g < QG; ++g)
-      ctl[g] = (const AS4 u32*)(cd.tbl + (size_t)groups * nsub_tbl * TBL_ENTRY) + (size_t)min(qgrp[g], live - 1) * TBL_CTL((int)kv_batch_stride);
+      ctl[g] = (const AS4 u32*)(cd.tbl + (size_t)groups * nsub_tbl * TBL_ENTRY) + (size_t)max(min(qgrp[g], live - 1), 0) * TBL_CTL((int)kv_batch_stride);
     const u32 hdr = ctl[0][DIR ? 1 : 0];
     tbl_n_reg = (int)(hdr & 0xffffu); tbl_n_rep = (int)(hdr >> 16);
   }
@@ -799,7 +815,7 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (RES ? 4 : (NW == 8 ?
     for (int i = 0; i < 16; ++i) {
       const int q = i * 2 + half;
       const int gq = qb + (wave * QG + g) * 32 + q;
-      if (gq < Lq) O[(size_t)b * o_batch_stride + (size_t)gq * ldo + h * HD + l31] = ot[q * 33 + l31];
+      if (gq >= 0 && gq < Lq) O[(size_t)b * o_batch_stride + (size_t)gq * ldo + h * HD + l31] = ot[q * 33 + l31];
     }
   }
   }   // query blocks of this workgroup
@@ -934,16 +950,18 @@ __global__ __launch_bounds__(256) void kv_zero_tails_kernel(KvTailBatch tb, KvIm
   while (ei + 1 < tb.n && (int)blockIdx.x >= tb.e[ei + 1].wg0) ++ei;
   const KvTailEntry& e = tb.e[ei];
   const int k0 = e.k0;
-  op_t* base = img + ((size_t)e.tile0 + (size_t)((int)blockIdx.x - e.wg0) * e.nkt + e.tile) * KV_IMG;
-  const int nk = KT6 - k0;
-  for (int i = threadIdx.x; i < 4 * NPL * nk * 4; i += 256) {
-    const int run = i / (nk * 4), off = i - run * (nk * 4);
-    reinterpret_cast<unsigned*>(base + run * KT6 * 8 + k0 * 8)[off] = 0u;
-  }
-  const int q0 = k0 >> 2, nq = 16 - q0;
-  for (int i = threadIdx.x; i < NPL * nq * 64; i += 256) {
-    const int pl = i / (nq * 64), off = i - pl * (nq * 64);
-    reinterpret_cast<unsigned*>(base + NPL * K_PLANE + pl * V_PLANE + q0 * HD * 4)[off] = 0u;
+  const int nk = KT6 - k0, q0 = k0 >> 2, nq = 16 - q0;
+  // one workgroup per CONTEXT (all eight heads: 41 000 workgroups of a few hundred stores each had made the launch dispatch-bound)
+  for (int h = 0; h < NHEAD; ++h) {
+    op_t* base = img + ((size_t)e.tile0 + ((size_t)((int)blockIdx.x - e.wg0) * NHEAD + h) * e.nkt + e.tile) * KV_IMG;
+    for (int i = threadIdx.x; i < 4 * NPL * nk * 4; i += 256) {
+      const int run = i / (nk * 4), off = i - run * (nk * 4);
+      reinterpret_cast<unsigned*>(base + run * KT6 * 8 + k0 * 8)[off] = 0u;
+    }
+    for (int i = threadIdx.x; i < NPL * nq * 64; i += 256) {
+      const int pl = i / (nq * 64), off = i - pl * (nq * 64);
+      reinterpret_cast<unsigned*>(base + NPL * K_PLANE + pl * V_PLANE + q0 * HD * 4)[off] = 0u;
+    }
   }
 }
 int launch_kv_zero_tails(int n, const KvTailHost* t, int nimg, void* const* imgs, hipStream_t st) {
@@ -961,7 +979,7 @@ int launch_kv_zero_tails(int n, const KvTailHost* t, int nimg, void* const* imgs
     const int tile = (t[i].key0 + t[i].n) / KT6;
     if ((t[i].n & 3) || (t[i].key0 & 63) || tile >= t[i].nkt) return CTRLSIM_EINVAL;
     tb.e[tb.n++] = KvTailEntry{wg, t[i].nkt, tile, t[i].n % KT6, t[i].tile0};
-    wg += t[i].B * NHEAD;
+    wg += t[i].B;
   }
   if (tb.n == 0) return CTRLSIM_OK;
   hipLaunchKernelGGL(kv_zero_tails_kernel, dim3(wg, nimg), dim3(256), 0, st, tb, sets);
