@@ -354,6 +354,9 @@ int ctrlsim_attention_compact(const float* Q, int ldq, int64_t q_batch_stride, c
  * class only, so the forward evaluates it once per pass instead of per (context, head, layer, query).  Layout (csrc/attention_bf16x6.hip):
  * per query group of 32 rows and per 32-key sub-tile (2 * nkt of them: the regular tiles, then the representative's) 32 x uint64 — sixteen
  * lane masks of the visible (query, key) pairs in the kernel's accumulator order, then sixteen of the representative's count-once keys.
+ * Round 6: behind the mask entries the table carries the kernel's control flow — per query group the tile schedule of its 256-query block
+ * (regular / representative tiles that hold a key some query of the block sees) and per (group, 64-key tile) one 32-bit word with a 2-bit
+ * code per sub-tile (0 skip, 1 every key visible, 2 apply the masks, 3 masks + count-once keys); ctrlsim_attention_mask_table_bytes covers both.
  * ctrlsim_attention_tbl = ctrlsim_attention_compact with q_pos == NULL and rep_pos0 == Lk, masks taken from the table (same results). */
 int64_t ctrlsim_attention_mask_table_bytes(int Lq, int nkt);
 int ctrlsim_attention_mask_table(int Lq, int Lk, int A, int rep_keys, int rep_pos0, int nkt, void* tbl, hipStream_t stream);
