@@ -68,6 +68,8 @@ def main():
                          "starting at t = 0 together.  Measured in round 4: no gain (profiles/README.md) — the default stays one run() per slice")
     ap.add_argument("--no-class-profile", action="store_true", help="skip the untimed extra slice with per-class attention cycle accounting")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-clock-samples", action="store_true",
+                    help="do not sample shader clock / socket power (rocm-smi, a host thread, every few seconds) during the timed region")
     ap.add_argument("--spot-check", type=int, default=4, help="scenarios re-rolled alone after the timed region (bit-identity check; 0 = off)")
     ap.add_argument("--cpu-sample-scenarios", type=int, default=4)
     ap.add_argument("--cpu-sample-steps", type=int, default=3)
@@ -216,11 +218,13 @@ def main():
         lib.ctrlsim_prof_enable(1)
     eng.record_phases, eng.phase_events = not args.pipeline, []
     eng.full_pass_contexts = np.zeros(len(eng.sizes), np.int64)
+    clocks = _ClockSampler(local_rank) if (rank == 0 and not dry and not args.no_clock_samples) else None
     t0 = time.perf_counter()
     bench_steps(0, K)
     t_own = time.perf_counter() - t0                          # this rank's own time to its last kernel (before it waits for the others)
     barrier()
     elapsed = time.perf_counter() - t0
+    clock_samples = clocks.stop() if clocks else None
     eng.record_phases = False
     cached_s, sliding_s = eng.phase_times()
     if dry:
@@ -529,11 +533,54 @@ def main():
                        "collective": (f"one all-reduce (SUM) of the {n_vec}-double metric vector + barriers, backend {backend}, world {world}"),
                        "parallelism": f"scenario-sharded x{world}"},
             "roofline": roof, "cpu_baseline": cpu, "parity_spot_check": spot,
+            "clock_power_during_timed_region": clock_samples,
             "rollout_metrics": {k: (None if v != v else v) for k, v in m.items()},
         }
         if args.fallback_slice and f16:
             out["fallback_bf16x6"] = _fallback_price(args, cfg, w, device, tilt, scns, cuts, R, N, value, eng)
         _emit(out, args.detail_file)
+
+
+class _ClockSampler:
+    """Shader clock and socket power of rank 0's GPU while the timed region runs (round 6: the kernels are POWER-bound — the socket sits at
+    its cap and the clock settles where the budget allows, profiles/r06_power_clocks.md — so the clock a run sustained belongs in its
+    record).  A host thread calls `rocm-smi --showclocks --showpower -d <gpu>` every few seconds (sysfs reads: nothing is queued on the
+    GPU); no rocm-smi, no samples."""
+
+    def __init__(self, gpu, period_s=4.0):
+        import shutil
+        import threading
+        self.gpu, self.period, self.samples = int(gpu), period_s, []
+        self.exe = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True) if self.exe else None
+        if self._th:
+            self._th.start()
+
+    def _run(self):
+        import re
+        import subprocess
+        while not self._stop.wait(self.period):
+            try:
+                out = subprocess.run([self.exe, "--showclocks", "--showpower", "-d", str(self.gpu)], capture_output=True, text=True, timeout=10).stdout
+            except (OSError, subprocess.SubprocessError):
+                continue
+            m = re.search(r"sclk clock level:[^(]*\((\d+)Mhz\)", out)
+            p = re.search(r"Power \(W\):\s*([\d.]+)", out)
+            if m and p:
+                self.samples.append((int(m.group(1)), float(p.group(1))))
+
+    def stop(self):
+        if not self._th:
+            return None
+        self._stop.set()
+        self._th.join(timeout=15)
+        if not self.samples:
+            return None
+        clk = sorted(s[0] for s in self.samples)
+        pw = sorted(s[1] for s in self.samples)
+        return {"samples": len(self.samples), "sclk_mhz_median": clk[len(clk) // 2], "sclk_mhz_min": clk[0], "sclk_mhz_max": clk[-1],
+                "socket_power_w_median": pw[len(pw) // 2], "socket_power_w_max": pw[-1], "source": "rocm-smi --showclocks --showpower, every 4 s"}
 
 
 def _self_launch(n):
@@ -591,6 +638,9 @@ def short_line(out, detail_path):
     }
     if out.get("fallback_bf16x6"):
         line["fallback_bf16x6_value"] = rnd(out["fallback_bf16x6"].get("value"))
+    cs = out.get("clock_power_during_timed_region")
+    if cs:
+        line["sclk_mhz"], line["socket_power_w"] = cs["sclk_mhz_median"], cs["socket_power_w_median"]
     return line
 
 
