@@ -1132,7 +1132,8 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
 #ifndef ATT_KEYPAD_RES
 #define ATT_KEYPAD_RES 1
 #endif
-  bool res = ATT_KEYPAD_RES && mode == MODE6_KEYPAD && !dir && ATT_QG_FULL == 1 && !(ldo & 3);
+  // (two-plane scheme only: four three-plane stages are 100 KB — one workgroup per CU)
+  bool res = ATT_KEYPAD_RES && NPL == 2 && mode == MODE6_KEYPAD && !dir && ATT_QG_FULL == 1 && !(ldo & 3);
   long pairs_total = 0;
   for (int k = 0; k < n; ++k) {
     if (cls[k].B <= 0 || cls[k].Lq <= 0) continue;
@@ -1183,8 +1184,9 @@ int launch_attention_classes(int mode, const float* Q, int ldq, const void* img,
     hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_CAUSAL, true>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale,
                        variant, ab);
   } else if (res) {
-    hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, true, false, false, 8, 1, true>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale, 0,
-                       ab);
+    if constexpr (NPL == 2)
+      hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, true, false, false, 8, 1, true>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale, 0,
+                         ab);
   } else {
     hipLaunchKernelGGL((attention_bf16x6_kernel<MODE6_KEYPAD, true, false, false, ATT_NW_FULL, ATT_QG_FULL>), g, blk, 0, st, Q, ldq, imgf, nullptr, 0, O, ldo, key_pad, scale, 0,
                        ab);
