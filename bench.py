@@ -15,9 +15,12 @@ configs[2] figure itself; the W warm-up steps roll out slices of the same size f
 independent, so ranks shard them with no data-path collective (weak scaling: S per GPU fixed); the only collective is
 one all-reduce of the metric accumulators after the rollouts.
 
-Printed by rank 0: ONE JSON line (metric, value = whole-job agent-steps/s, roofline of the dominant kernel class
-measured with HIP events on the launch stream during the timed region, satellite kernels against the HBM roof,
-cpu_baseline = the CPU oracle timed on this box's host cores on a bounded sample).
+Printed by rank 0: ONE JSON line on stdout — the LAST line of stdout, < 4 KB (SHORT_LINE_LIMIT): metric, value = whole-job
+agent-steps/s, roofline of the dominant KERNEL (HIP events on the launch stream during the timed region), cpu_baseline = the
+CPU oracle timed on this box's host cores on a bounded sample, the parity spot check, the sampled shader clock / socket power.
+Everything else — per-kernel rows of both streams, the class view, satellites against the HBM roof, per-class attention rows,
+phases, per-rank times, notes — goes to the detail file (--detail-file, default bench_detail.json) and, prefixed, to stderr.
+`python bench.py --gpus N` without a launcher starts the N ranks itself.
 """
 import argparse
 import ctypes as C
@@ -542,9 +545,9 @@ def main():
 
 
 class _ClockSampler:
-    """Shader clock and socket power of rank 0's GPU while the timed region runs (round 6: the kernels are POWER-bound — the socket sits at
-    its cap and the clock settles where the budget allows, profiles/r06_power_clocks.md — so the clock a run sustained belongs in its
-    record).  A host thread calls `rocm-smi --showclocks --showpower -d <gpu>` every few seconds (sysfs reads: nothing is queued on the
+    """Shader clock and socket power of rank 0's GPU while the timed region runs (round 6: run alone, every hot kernel drives the socket to
+    its 1.4 kW cap and the clock settles where the budget allows — 1.57 to 2.33 GHz, profiles/r06_power_clocks.md; the rollout averages
+    1.2 kW at 2.1-2.3 GHz — so the clock a run sustained belongs in its record).  A host thread calls `rocm-smi --showclocks --showpower -d <gpu>` every few seconds (sysfs reads: nothing is queued on the
     GPU); no rocm-smi, no samples."""
 
     def __init__(self, gpu, period_s=4.0):
