@@ -75,8 +75,8 @@ def main():
                     help="do not sample shader clock / socket power (rocm-smi, a host thread, every few seconds) during the timed region")
     ap.add_argument("--spot-check", type=int, default=4, help="scenarios re-rolled alone after the timed region (bit-identity check; 0 = off)")
     ap.add_argument("--cpu-sample-scenarios", type=int, default=4)
-    ap.add_argument("--cpu-sample-steps", type=int, default=3)
-    ap.add_argument("--cpu-sample-budget-s", type=float, default=35.0,
+    ap.add_argument("--cpu-sample-steps", type=int, default=4)
+    ap.add_argument("--cpu-sample-budget-s", type=float, default=60.0,
                     help="time box of the CPU sample: no further scenario is started once this much CPU time is spent (at least one runs)")
     ap.add_argument("--detail-file", type=str, default=os.path.join(ROOT, "bench_detail.json"),
                     help="everything that does not fit the one short stdout line: per-kernel rows, satellites, per-class attention, notes")
