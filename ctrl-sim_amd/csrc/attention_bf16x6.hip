@@ -181,7 +181,10 @@ constexpr int ATT_QG_FULL = ATT_QG, ATT_NW_FULL = 8 / ATT_QG;
 // accumulators, 16 bytes per lane and out-quad: the LDS transpose would alias the resident tiles) — with no barrier, no DMA and no wait
 // in the loop.  L2 -> LDS traffic of the launch: one image read per (context, head) instead of one per query block.
 template <int MODE, bool PRE, bool TBL = false, bool DIR = false, int NW = 4, int QG = 1, bool RES = false>
-__global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (RES ? 4 : (NW == 8 ? 6 : 3))) void attention_bf16x6_kernel(
+#ifndef ATT_V_EARLY
+#define ATT_V_EARLY 0     // 1 (experiment): the full-row kernels request the V^T fragments BEFORE the softmax, at five waves per SIMD (96 VGPRs)
+#endif
+__global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (RES ? 4 : (NW == 8 ? (ATT_V_EARLY ? 5 : 6) : 3))) void attention_bf16x6_kernel(
     const float* __restrict__ Qb_, int ldq, const float* __restrict__ K, const float* __restrict__ V, int ldkv,
     float* __restrict__ Ob_, int ldo, const unsigned char* __restrict__ key_pad_, float scale_log2e, int variant, AttnBatch ab) {
   const unsigned long long t_start = ab.cprof ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -637,7 +640,8 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (RES ? 4 : (NW == 8 ?
           v1f[p] = cat8(b0, b1);
         }
       };
-      if (QG > 1) load_v();
+      constexpr bool V_EARLY = QG > 1 || (ATT_V_EARLY && NW == 8 && !RES);
+      if (V_EARLY) load_v();
 #pragma unroll
       for (int g = 0; g < QG; ++g) {
       if (!act[g]) continue;
@@ -767,7 +771,7 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (RES ? 4 : (NW == 8 ?
         split_frag(sc + 8 * kk, pf[kk]);
       }
       // ---- O^T += V^T . P^T
-      if (QG == 1) load_v();
+      if (!V_EARLY) load_v();
 #define PV(PA, PB)                                \
   oa[g] = MFMA_OP(v0f[PA], pf[0][PB], oa[g]);     \
   oa[g] = MFMA_OP(v1f[PA], pf[1][PB], oa[g]);
