@@ -683,7 +683,22 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (RES ? 4 : (NW == 8 ?
         // variant 3 (Decision Transformer, token order rtg, state, action — kept in the slots state, rtg, action): a state
         // token also sees its own agent's rtg token, one position AFTER it
         const unsigned own = rep_q ? 0u : (ones(pos - ks0 + 1 + ((variant == 3 && kq == 0) ? 1 : 0)) & ~ones(pos - kq - ks0));
-        vis_all = before | ((every3 | own) & same);
+        unsigned before_v = before;
+        if (variant == 4) {
+          // cfg.model.attend_own_return_action (utils/train_utils.py:114-129; round 6): of the EARLIER timesteps a query sees the state
+          // tokens and its own agent's return / action tokens only.  Own tokens of type k sit at offset 3 aq + k of every timestep:
+          // bits (3 aq + k - r0) mod A3 + m A3 of this sub-tile, r0 = offset of its first key in its timestep (plain contexts only)
+          const int r0 = ks0 - ks_t0;
+          unsigned ownpat = 0u;
+#pragma unroll
+          for (int k = 1; k < 3; ++k) {
+            int f = (3 * aq + k - r0) % A3;
+            f = f < 0 ? f + A3 : f;
+            for (int p = f; p < 32; p += A3) ownpat |= 1u << p;
+          }
+          before_v &= every3 | ownpat;
+        }
+        vis_all = before_v | ((every3 | own) & same);
         if (variant) {
           // the 3-slot token layout is kept for the baselines of cfgs/model/{il,trajeglish}.yaml; the token types they do not
           // have are dead as keys.  IL (state, action): rtg keys invisible.  Trajeglish (action only): action keys of earlier
@@ -1077,8 +1092,8 @@ int launch_attention_bf16x6(int mode, const float* Q, int ldq, long q_batch_stri
                             const unsigned char* key_pad, int B, int Lq, int Lk, int A, hipStream_t st) {
   if (B <= 0 || Lq <= 0) return CTRLSIM_OK;
   if (Lk <= 0 || (ldq & 3) || (ldkv & 3)) return CTRLSIM_EINVAL;
-  if (mode < 0 || mode > 4 || (mode == MODE6_KEYPAD && !key_pad)) return CTRLSIM_EINVAL;
-  const int variant = mode >= MODE6_CAUSAL ? mode - MODE6_CAUSAL : 0;   // mode 1 CtRL-Sim mask, 2 IL, 3 Trajeglish, 4 DT
+  if (mode < 0 || mode > 5 || (mode == MODE6_KEYPAD && !key_pad)) return CTRLSIM_EINVAL;
+  const int variant = mode >= MODE6_CAUSAL ? mode - MODE6_CAUSAL : 0;   // mode 1 CtRL-Sim mask, 2 IL, 3 Trajeglish, 4 DT, 5 CtRL-Sim with attend_own_return_action
   mode = mode >= MODE6_CAUSAL ? MODE6_CAUSAL : MODE6_KEYPAD;
   AttnBatch ab;
   ab.n = 1;
@@ -1108,7 +1123,7 @@ int launch_attention_bf16x6(int mode, const float* Q, int ldq, long q_batch_stri
 int launch_attention_classes(int mode, const float* Q, int ldq, const void* img, float* O, int ldo, const unsigned char* key_pad,
                              int n, const AttnClassHost* cls, hipStream_t st) {
   if (n < 1 || n > MAXC || !cls || (ldq & 3) || !img) return CTRLSIM_EINVAL;
-  if (mode < 0 || mode > 4 || (mode == MODE6_KEYPAD && !key_pad)) return CTRLSIM_EINVAL;
+  if (mode < 0 || mode > 5 || (mode == MODE6_KEYPAD && !key_pad)) return CTRLSIM_EINVAL;
   const int variant = mode >= MODE6_CAUSAL ? mode - MODE6_CAUSAL : 0;
   mode = mode >= MODE6_CAUSAL ? MODE6_CAUSAL : MODE6_KEYPAD;
   AttnBatch ab;

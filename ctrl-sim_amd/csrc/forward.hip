@@ -73,6 +73,9 @@ int launch_assemble_tokens_classes(int, const int*, const int*, const int*, cons
 
 namespace {
 
+// ctrlsim_dims.variant 4 = the CtRL-Sim token layout and heads (variant 0) under cfg.model.attend_own_return_action (attention mask mode 5)
+inline int tok_variant(int v) { return v == 4 ? 0 : v; }
+
 struct Lin {
   const float* w; const float* b;
   const void* w3s[2] = {nullptr, nullptr};      // operand planes per split scheme (OPT_SPLIT 0 / 1)
@@ -121,7 +124,7 @@ struct ctrlsim_model {
 extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_weights, int n, const char* const* names,
                                     const int64_t* offsets, ctrlsim_model** out) {
   if (!dims || !dev_weights || !names || !offsets || !out) return CTRLSIM_EINVAL;
-  if (dims->D != DM || dims->H != NHEAD || dims->A < 1 || dims->A > 64 || dims->variant < 0 || dims->variant > 3)
+  if (dims->D != DM || dims->H != NHEAD || dims->A < 1 || dims->A > 64 || dims->variant < 0 || dims->variant > 4)
     return CTRLSIM_EINVAL;
   std::unordered_map<std::string, const float*> tab;
   for (int i = 0; i < n; ++i) tab[names[i]] = dev_weights + offsets[i];
@@ -210,7 +213,7 @@ extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_w
     m->dec.push_back(L);
   }
   m->head_action = mlp("decoder.predict_action");
-  if (dims->variant == 0) m->head_rtg = mlp("decoder.predict_rtg");      // the IL / Trajeglish models have no such head
+  if (tok_variant(dims->variant) == 0) m->head_rtg = mlp("decoder.predict_rtg");      // the IL / Trajeglish models have no such head
   if (tab.count("decoder.predict_future_states.mlp.0.weight")) {        // model.predict_future_states (decoder.py:29-30): training-time
     m->head_fut = mlp("decoder.predict_future_states");                 // auxiliary head, only read by ctrlsim_forward_all
     m->has_fut = true;
@@ -769,8 +772,9 @@ int forward_full(const ctrlsim_model* m, int n, const int* Bk, const int* Ak, co
                  float* logits, float* dbg_seg_emb, hipStream_t st, const AllOut* all = nullptr, hipStream_t st_tail = nullptr,
                  bool split_tail = false) {
   const ctrlsim_dims& d = m->d;
-  const int variant = d.variant, amode = 1 + variant, qoff = variant == 2 ? 2 : 0;
-  if (variant && !presplit()) return CTRLSIM_EINVAL;       // the IL / Trajeglish masks live in the split-bf16 attention only
+  // d.variant: token layout / heads (tok_variant: 4 = CtRL-Sim tokens) and, one to one, the attention mask mode 1 + d.variant
+  const int variant = tok_variant(d.variant), amode = 1 + d.variant, qoff = variant == 2 ? 2 : 0;
+  if (d.variant && !presplit()) return CTRLSIM_EINVAL;     // the IL / Trajeglish / own-return masks live in the split-operand attention only
   Batch bt;
   CHK(make_batch(d, n, Bk, Ak, ctx, Tq, Tq, 4, bt));
   if (!classes_ok(d, bt)) return CTRLSIM_EINVAL;
@@ -800,7 +804,7 @@ int forward_full(const ctrlsim_model* m, int n, const int* Bk, const int* Ak, co
     }
   }
   CHK(scene_side(m, bt, w, dbg_seg_emb, st));
-  const bool use_tbl = variant == 0 && presplit() && ctrlsim_option(OPT_ATTN_TBL) != 0;
+  const bool use_tbl = d.variant == 0 && presplit() && ctrlsim_option(OPT_ATTN_TBL) != 0;   // (own-return mask: in-kernel masks, like the baselines)
   if (use_tbl) CHK(build_mask_tables(bt, w, Tq, st));
   // ---- decoder (decoder.py:52): layers 0..ND-2 on all tokens
   for (int i = 0; i < d.ND; ++i) {
@@ -850,14 +854,14 @@ int forward_full(const ctrlsim_model* m, int n, const int* Bk, const int* Ak, co
 
 extern "C" int ctrlsim_dt_forward_pass1_c(const ctrlsim_model* m, int n, const int* B, const int* A, const ctrlsim_ctx* ctx, int Tq,
                                           void* workspace, float* rtg_logits, float* dbg_seg_emb, hipStream_t st) {
-  if (!m || !ctx || !workspace || !rtg_logits || Tq < 1 || Tq > m->d.T || m->d.variant != 0) return CTRLSIM_EINVAL;
+  if (!m || !ctx || !workspace || !rtg_logits || Tq < 1 || Tq > m->d.T || tok_variant(m->d.variant) != 0) return CTRLSIM_EINVAL;
   return forward_full(m, n, B, A, ctx, Tq, workspace, rtg_logits, dbg_seg_emb, st);
 }
 // The same with the few-row tail (last decoder layer on the queried rows + the head) enqueued on `tail_stream`, behind the
 // full-row part on `stream` (event-ordered inside the call).  rtg_logits are complete in tail_stream order.
 extern "C" int ctrlsim_dt_forward_pass1_c2(const ctrlsim_model* m, int n, const int* B, const int* A, const ctrlsim_ctx* ctx, int Tq,
                                            void* workspace, float* rtg_logits, hipStream_t st, hipStream_t tail_stream) {
-  if (!m || !ctx || !workspace || !rtg_logits || Tq < 1 || Tq > m->d.T || m->d.variant != 0) return CTRLSIM_EINVAL;
+  if (!m || !ctx || !workspace || !rtg_logits || Tq < 1 || Tq > m->d.T || tok_variant(m->d.variant) != 0) return CTRLSIM_EINVAL;
   return forward_full(m, n, B, A, ctx, Tq, workspace, rtg_logits, nullptr, st, nullptr, tail_stream, true);
 }
 extern "C" int ctrlsim_dt_forward_pass1_a(const ctrlsim_model* m, int B, int Tq, int Actx, const ctrlsim_ctx* c, void* workspace,
@@ -870,7 +874,7 @@ extern "C" int ctrlsim_dt_forward_pass1(const ctrlsim_model* m, int B, int Tq, c
 }
 extern "C" int ctrlsim_dt_forward_actions(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* c, void* workspace,
                                           float* act_logits, hipStream_t st) {
-  if (!m || !c || !workspace || !act_logits || B < 1 || Tq < 1 || Tq > m->d.T || m->d.variant == 0) return CTRLSIM_EINVAL;
+  if (!m || !c || !workspace || !act_logits || B < 1 || Tq < 1 || Tq > m->d.T || tok_variant(m->d.variant) == 0) return CTRLSIM_EINVAL;
   const int A = m->d.A;
   return forward_full(m, 1, &B, &A, c, Tq, workspace, act_logits, nullptr, st);
 }
@@ -881,7 +885,7 @@ extern "C" int ctrlsim_dt_forward_actions(const ctrlsim_model* m, int B, int Tq,
 extern "C" int ctrlsim_forward_all(const ctrlsim_model* m, int B, int Tq, const ctrlsim_ctx* c, void* workspace, float* action_preds,
                                    float* rtg_preds, float* state_preds, hipStream_t st) {
   if (!m || !c || !workspace || !action_preds || B < 1 || Tq < 1 || Tq > m->d.T) return CTRLSIM_EINVAL;
-  if ((rtg_preds && m->d.variant != 0) || (state_preds && !m->has_fut)) return CTRLSIM_EINVAL;
+  if ((rtg_preds && tok_variant(m->d.variant) != 0) || (state_preds && !m->has_fut)) return CTRLSIM_EINVAL;
   const int A = m->d.A;
   const AllOut all{action_preds, rtg_preds, state_preds};
   return forward_full(m, 1, &B, &A, c, Tq, workspace, nullptr, nullptr, st, &all);
@@ -899,7 +903,8 @@ extern "C" int ctrlsim_map_pool(const ctrlsim_model* m, int B, const float* road
 extern "C" int ctrlsim_dt_forward_pass2_c(const ctrlsim_model* m, int n, const int* Bk, const int* Ak, const ctrlsim_ctx* ctx, int Tq,
                                           int t, int N, int Tmax, const int* ctx_scn, const int* hist_rtg, void* workspace,
                                           float* act_logits, int cached, hipStream_t st) {
-  if (!m || !ctx || !workspace || !act_logits || Tq < 1 || Tq > m->d.T || m->d.variant != 0) return CTRLSIM_EINVAL;
+  if (!m || !ctx || !workspace || !act_logits || Tq < 1 || Tq > m->d.T || tok_variant(m->d.variant) != 0) return CTRLSIM_EINVAL;
+  if (m->d.variant && (cached || !presplit())) return CTRLSIM_EINVAL;   // own-return mask: full recompute, split-operand attention only
   const ctrlsim_dims& d = m->d;
   // cached mode: the workspace is carved for the full window (K/V cache rows at rows(T) per context) and the context
   // tensors hold only the last Tn = min(Tq, 2) window rows
@@ -933,7 +938,7 @@ extern "C" int ctrlsim_dt_forward_pass2_c(const ctrlsim_model* m, int n, const i
       }
       CHK(launch_kv_split_rows_classes(w.qkvc + DM, w.qkvc + 2 * DM, 3 * DM, bt.n, kr, w.img_dec[i], st));
     }
-    CHK(attention(d, bt, w, AttnCall{1, Q_RTG, w.qkvc, 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, w.img_dec[i], false, w.attc,
+    CHK(attention(d, bt, w, AttnCall{1 + d.variant, Q_RTG, w.qkvc, 3 * DM, w.qkv[i] + DM, w.qkv[i] + 2 * DM, 3 * DM, w.img_dec[i], false, w.attc,
                                      Tq, Tw, 0}, st));   // keys: steps <= current
     CHK(cross_and_ffn(m, bt, Ld, i, w, w.xc2, w.tmpc, w.attc, w.qcc, w.ffnc, bt.rQ, Q_RTG, 0, st));
   }

@@ -39,7 +39,7 @@ from .spec import Dims, ZERO_ACTION_TOKEN, ZERO_RTG_BINS, check_supported
 
 def _dims_struct(d: Dims):
     return _lib.Dims(A=d.A, T=d.T, P=d.P, NP=d.NP, D=d.D, H=d.H, F=d.F, V=d.V, R=d.R, C=d.C, NE=d.NE, ND=d.ND,
-                     MAXT=d.MAXT, variant=d.VARIANT)
+                     MAXT=d.MAXT, variant=4 if getattr(d, "MASK_OWN", False) else d.VARIANT)   # 4: CtRL-Sim tokens, own-return mask
 
 
 class HipModel:
@@ -223,7 +223,8 @@ class RolloutEngine:
         self.tilt = (C.c_double * 3)(*([0.0, 0.0, 0.0] if tilt.ndim == 2 else [float(x) for x in tilt]))
         self.kinematic = int(bool(kinematic))
         self.max_ctx = int(max_ctx)
-        self.use_cache = bool(use_cache) and not self.dims.VARIANT    # the K/V-cached phase is built for the CtRL-Sim tokens
+        # the K/V-cached phase is built for the CtRL-Sim tokens under the default mask (attend_own_return_action: full recompute every step)
+        self.use_cache = bool(use_cache) and not self.dims.VARIANT and not self.dims.MASK_OWN
         # Few-row kernels on the lanes' side streams (second pass, the tail of the first pass, whole K/V-cached steps) underneath the
         # other lane's full-row kernels: +6.5 % throughput (113.4 -> 120.7 k agent-steps/s).  ON by default since round 3: the
         # irreproducibility that kept them off in round 2 was traced to code of clang's SLP vectoriser (packed-fp32 instructions with
@@ -267,7 +268,8 @@ class RolloutEngine:
         if sizes is not None:                       # explicit class set (A/B measurements, tests): ascending slot counts, A last
             tuned = tuple(int(a) for a in sizes)
             assert tuned == tuple(sorted(set(tuned))) and tuned[-1] == A and tuned[0] >= 2 and len(tuned) <= 16
-        self.sizes = tuned if (compact and not self.dims.VARIANT) else (A,)
+        # (compact contexts rest on the default mask's treatment of padded slots: attend_own_return_action keeps the plain 24-slot layout)
+        self.sizes = tuned if (compact and not self.dims.VARIANT and not self.dims.MASK_OWN) else (A,)
         self._sizes_c = (C.c_int * len(self.sizes))(*self.sizes)
         self.ctx_cap = self.max_ctx * (4 if len(self.sizes) > 1 else 1)
         # workspace bytes per context of each class (the carve is linear in B up to alignment), + a fixed allowance per class

@@ -17,7 +17,7 @@ from .. import weights as _weights
 class CtRLSim:
     def __init__(self, cfg, weights=None, seed=0, device="cuda:0"):
         self.cfg = cfg
-        check_supported(cfg)                    # e.g. a checkpoint trained with attend_own_return_action=True: another mask
+        check_supported(cfg)                    # e.g. a checkpoint trained with use_map=False: another network
         self.dims = Dims(cfg)
         self.weights = weights if weights is not None else _weights.generate(self.dims, seed)
         self.device = device

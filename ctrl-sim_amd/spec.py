@@ -124,7 +124,6 @@ def make_cfg(**overrides):
 # and return logits of the wrong model, so the model layer refuses it by name instead.
 _FROZEN_MODEL_FLAGS = (
     # (key, required value, what the other value changes in the reference)
-    ("attend_own_return_action", False, "the decoder mask hides other agents' past return / action tokens (utils/train_utils.py:114-129)"),
     ("use_map", True, "no MapEncoder, no polyline tokens in the scene encoder (modules/encoder.py:18,155)"),
     ("encode_initial_state", True, "no scene encoder memory at all (modules/encoder.py:84,111,135,159)"),
     ("no_actions", False, "action embeddings are dropped from the token rows (modules/encoder.py:129)"),
@@ -146,6 +145,9 @@ def check_supported(cfg):
     variants = [k for k in ("il", "trajeglish", "decision_transformer") if bool(m.get(k, False))]
     if len(variants) > 1:
         bad.append(f"model.{' and model.'.join(variants)} are set together (one baseline at a time: cfgs/model/{{il,trajeglish,dt}}.yaml)")
+    if variants and bool(m.get("attend_own_return_action", False)):
+        bad.append("model.attend_own_return_action with a baseline token layout (utils/train_utils.py:114-129 assumes the three CtRL-Sim token "
+                   "types: `type_idx_j = index_j % 3`)")
     if not variants and not bool(m.get("predict_rtg", True)):
         bad.append("model.predict_rtg = False with the CtRL-Sim token layout (the rollout's first pass reads the return head: "
                    "policies/autoregressive_policy.py:201-221)")
@@ -166,6 +168,10 @@ class Dims:
         # 3 = Decision Transformer (cfgs/model/dt.yaml): continuous RTG embeddings, token order (rtg, state, action)
         self.VARIANT = 1 if bool(m.get("il", False)) else (2 if bool(m.get("trajeglish", False)) else
                                                             (3 if bool(m.get("decision_transformer", False)) else 0))
+        # cfg.model.attend_own_return_action (cfgs/model/base.yaml:15, default False; utils/train_utils.py:114-129): other agents' return /
+        # action tokens of EARLIER timesteps are hidden.  Built in round 6 as mask mode 5 of the in-kernel-mask attention path (plain
+        # 24-slot contexts, full recompute every step: engine.py)
+        self.MASK_OWN = bool(m.get("attend_own_return_action", False)) and self.VARIANT == 0
         self.L = self.A * self.T * self.K         # decoder tokens
         self.P = int(w.max_num_road_polylines)
         self.NP = int(w.max_num_road_pts_per_polyline)

@@ -39,7 +39,9 @@ typedef struct ctrlsim_dims {
   int variant; /* 0 CtRL-Sim (state, rtg, action tokens; cfgs/model/ctrl_sim.yaml), 1 IL (state, action; il.yaml),
                   2 Trajeglish (action tokens only; trajeglish.yaml), 3 Decision Transformer (continuous RTGs: ctx.rtg_bin
                   holds float bits; token order rtg, state, action; dt.yaml) — modules/encoder.py:27-34,116-152,
-                  decoder.py:29-64 */
+                  decoder.py:29-64; 4 (round 6) = the CtRL-Sim tokens and heads of 0 under cfg.model.attend_own_return_action
+                  (cfgs/model/base.yaml:15, utils/train_utils.py:114-129: other agents' return / action tokens of EARLIER
+                  timesteps are hidden; attention mask mode 5; plain 24-slot contexts, no K/V-cached entry point) */
 } ctrlsim_dims;
 
 /* Agent-local context tensors of B contexts (outputs of ctrlsim_build_context, inputs of the forward). */
@@ -324,7 +326,9 @@ int ctrlsim_outproj_ln_q(const float* O, int ldo, const float* R, int ldr, const
                          const void* Wqp, const float* bq, float* X1, int ldx1, float* Q, int ldq, int M, hipStream_t stream);
 int ctrlsim_layernorm256(const float* X, int ldx, const float* Radd, int ldr, const float* gamma, const float* beta,
                          float* Y, int ldy, int rows, int relu, hipStream_t stream);
-/* mode 0: key padding (key_pad [B,Lk], 1 = ignore); mode 1: CtRL-Sim structured causal mask (utils/train_utils.py:81-129) */
+/* mode 0: key padding (key_pad [B,Lk], 1 = ignore); mode 1: CtRL-Sim structured causal mask (utils/train_utils.py:81-129); modes 2 / 3 / 4
+ * (split-operand kernels only): the IL / Trajeglish / Decision-Transformer masks of the same function; mode 5 (round 6): mode 1 with
+ * cfg.model.attend_own_return_action (:114-129) — of the earlier timesteps a query sees the state tokens and its own agent's tokens only */
 int ctrlsim_attention(int mode, const float* Q, int ldq, int64_t q_batch_stride, const float* K, const float* V,
                       int ldkv, int64_t kv_batch_stride, float* O, int ldo, int64_t o_batch_stride, const int* q_pos,
                       const uint8_t* key_pad, int B, int Lq, int Lk, int A, hipStream_t stream);

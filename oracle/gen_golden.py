@@ -1247,6 +1247,50 @@ def gen_variants():
     save("variants", **out)
 
 
+def gen_own_return():
+    """cfg.model.attend_own_return_action = True (cfgs/model/base.yaml:15; utils/train_utils.py:114-129) through the UNMODIFIED reference:
+    the mask itself, logits of the reference Encoder / Decoder built with that cfg (tiny dims in full, loop dims at the last filled step, both
+    heads the policy reads) and a closed loop of the unmodified reference policy + real FreeCar / Box2D, 14 steps at the loop dims (the window
+    T = 8 slides from step 8 on), tilts on."""
+    ref_shims.install()
+    from utils.train_utils import get_causal_mask
+    out = {}
+    own = {"model__attend_own_return_action": True}
+    out["mask_tiny"] = (get_causal_mask(spec.make_cfg(**TINY, **own), 4, 3) == 0).numpy()
+    for tag, over in (("tiny", TINY), ("loop", LOOP)):
+        cfg = spec.make_cfg(**over, **own)
+        d = spec.Dims(cfg)
+        assert d.MASK_OWN
+        w = weights.generate(d, 0)
+        ref = ref_shims.build_reference_model(cfg, w)
+        cm = model_oracle.causal_mask_closed_form(d.A, d.T, 3, 0, True)
+        assert bool(((ref.decoder.causal_mask == 0) == cm).all()), "closed-form mask != get_causal_mask"
+        for seed, t_fill in ((1, d.T), (2, max(1, d.T // 2))):
+            inp = synth_inputs.random_context(d, seed, B=1, t_fill=t_fill, n_agents=d.A - 1, n_polys=d.P - 1)
+            r = ref(synth_inputs.to_motion_data(inp), eval=True)
+            for head in ("action_preds", "rtg_preds"):
+                v = r[head].detach().numpy()
+                out[f"{tag}_s{seed}_{head}"] = v if tag == "tiny" else v[0, :, t_fill - 1]
+            out[f"{tag}_s{seed}_recipe"] = np.array([seed, t_fill, d.A - 1, d.P - 1])
+    cfg = spec.make_cfg(**LOOP, **own)
+    d = spec.Dims(cfg)
+    w = weights.generate(d, 0)
+    for idx in range(60):
+        scn = scenarios.make_scenario(19, idx, n_agents=9, n_polylines=15, n_points=d.NP, extent=40.0)
+        r = ref_closed_loop(cfg, w, scn, 14, seed=5, tilt=(5.0, -10.0, 10.0))
+        if r["margins"].min() > 2e-4:
+            break
+    print("own_return scene", idx, "groups/step", r["n_groups"], "min race margin", r["margins"].min(), "veh-veh flags", r["coll"][..., 0].sum())
+    for k in ("tokens", "rtg_cont", "states", "coll", "actions", "n_groups", "margins"):
+        out[f"loop_{k}"] = r[k]
+    out["loop_recipe"] = np.array([19, idx, 9, 15, 40.0, 5, 5.0, -10.0, 10.0])
+    # the same scene under the DEFAULT mask must differ (the fixture is not vacuous)
+    r0 = ref_closed_loop(spec.make_cfg(**LOOP), w, scn, 14, seed=5, tilt=(5.0, -10.0, 10.0))
+    out["loop_tokens_default_mask"] = r0["tokens"]
+    print("tokens that differ from the default mask's rollout:", int((r0["tokens"] != r["tokens"]).sum()), "of", r["tokens"].size)
+    save("own_return", **out)
+
+
 # --------------------------------------------------------------------------------------------- real-time (dense) rewards
 def ref_dense_reward(dset, w, xy, exist, rewards, polys):
     """evaluators/evaluator.py:106-140, line by line, on the reference's dataset methods.  rewards [N, steps so far, 8].
@@ -1394,7 +1438,7 @@ def gen_dt_loop():
 ALL = dict(model=gen_model, model_trained=gen_model_trained, closed_loop_trained=gen_closed_loop_trained, closed_loop_wide_trained=gen_closed_loop_wide_trained, features=gen_features, sampling=gen_sampling, physics=gen_physics,
            collision=gen_collision, closed_loop=gen_closed_loop, closed_loop_full=gen_closed_loop_full, closed_loop_wide=gen_closed_loop_wide, metrics=gen_metrics, interesting=gen_interesting, preprocessed=gen_preprocessed, ingest_gt=gen_ingest_gt, state_dict=gen_state_dict, bicycle=gen_bicycle, contacts=gen_contacts,
            planner_adversary=gen_planner_adversary, ingest=gen_ingest,
-           variants=gen_variants, dense_reward=gen_dense_reward, dt_loop=gen_dt_loop)
+           variants=gen_variants, dense_reward=gen_dense_reward, dt_loop=gen_dt_loop, own_return=gen_own_return)
 
 if __name__ == "__main__":
     assert ref_shims.available(), "the reference tree is required to (re)generate golden vectors"

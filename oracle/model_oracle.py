@@ -34,10 +34,11 @@ def as_torch_weights(w):
     return {k: (torch.from_numpy(v) if not torch.is_tensor(v) else v) for k, v in w.items()}
 
 
-def causal_mask_closed_form(A: int, T: int, K: int = 3, state_index: int = 0) -> torch.Tensor:
-    """Boolean [L,L], True = visible (state_index 0, no attend_own_return_action); K = token types per agent-step:
-    3 CtRL-Sim, 2 IL, 1 Trajeglish (utils/train_utils.py:83-113 with num_types = K); state_index 1 = Decision Transformer
-    (token order rtg, state, action)."""
+def causal_mask_closed_form(A: int, T: int, K: int = 3, state_index: int = 0, own_return: bool = False) -> torch.Tensor:
+    """Boolean [L,L], True = visible; K = token types per agent-step: 3 CtRL-Sim, 2 IL, 1 Trajeglish (utils/train_utils.py:83-113
+    with num_types = K); state_index 1 = Decision Transformer (token order rtg, state, action).  own_return =
+    cfg.model.attend_own_return_action (utils/train_utils.py:114-129): of the EARLIER timesteps a token sees the state tokens and its
+    own agent's tokens only — the other agents' past return / action tokens are hidden."""
     L = A * T * K
     i = torch.arange(L)
     t = i // (A * K)
@@ -46,7 +47,10 @@ def causal_mask_closed_form(A: int, T: int, K: int = 3, state_index: int = 0) ->
     ti, tj = t[:, None], t[None, :]
     ai, aj = a[:, None], a[None, :]
     ki, kj = k[:, None], k[None, :]
-    return (tj < ti) | ((tj == ti) & (((aj == ai) & (kj <= ki)) | (kj == state_index)))
+    earlier = tj < ti
+    if own_return:
+        earlier = earlier & ((aj == ai) | (kj == state_index))
+    return earlier | ((tj == ti) & (((aj == ai) & (kj <= ki)) | (kj == state_index)))
 
 
 def _linear(x, w, name):
@@ -202,9 +206,10 @@ def forward(w, data, dims, return_hidden=False):
     B, A, T = data["agent_states"].shape[:3]
     variant = getattr(dims, "VARIANT", 0)
     K = {0: 3, 1: 2, 2: 1, 3: 3}[variant]                             # decoder.py:29-35
-    key = (A, T, K, variant == 3)
+    own = bool(getattr(dims, "MASK_OWN", False))
+    key = (A, T, K, variant == 3, own)
     if key not in _MASK_CACHE:
-        _MASK_CACHE[key] = causal_mask_closed_form(A, T, K, 1 if variant == 3 else 0)
+        _MASK_CACHE[key] = causal_mask_closed_form(A, T, K, 1 if variant == 3 else 0, own)
     tgt_mask = _MASK_CACHE[key]
     x = stacked
     for i in range(dims.ND):

@@ -367,6 +367,34 @@ def test_attention_mask_variants_of_the_baselines(A, T, mode):
     assert (Oc.double() - O[:, pos.long()].double()).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("A,T", [(24, 32), (6, 8), (24, 7), (5, 13), (2, 9)])
+def test_attention_mask_with_attend_own_return_action(A, T):
+    """Mode 5 (round 6): the CtRL-Sim mask under cfg.model.attend_own_return_action (utils/train_utils.py:114-129) — of the earlier
+    timesteps a query sees the state tokens and its own agent's return / action tokens only — against float64 attention under the
+    oracle's closed form (pinned to the reference's get_causal_mask: tests/golden/own_return.npz), over all rows and over the gathered
+    rows of the few-row launches (state tokens of the last step, rtg tokens of the last step)."""
+    B, H = 2, 8
+    L = A * T * 3
+    g = torch.Generator().manual_seed(A * T + 5)
+    qkv = torch.randn(B, L, 768, generator=g).to(DEV)
+    O = torch.zeros(B, L, 256, device=DEV)
+    p = _lib.ptr
+    _lib.check(_lib.lib().ctrlsim_attention(5, p(qkv), 768, L * 768, qkv.data_ptr() + 256 * 4, qkv.data_ptr() + 512 * 4, 768,
+                                            L * 768, p(O), 256, L * 256, None, None, B, L, L, A, _lib.stream_ptr()))
+    vis = mo.causal_mask_closed_form(A, T, 3, 0, True).to(DEV)[None, None]
+    assert not torch.equal(vis, mo.causal_mask_closed_form(A, T, 3, 0, False).to(DEV)[None, None]) or A == 1
+    q, k, v = [qkv[..., i * 256:(i + 1) * 256].view(B, L, H, 32).transpose(1, 2) for i in range(3)]
+    ref = _attn_ref(q, k, v, vis).transpose(1, 2).reshape(B, L, 256)
+    assert (O.double() - ref).abs().max().item() < 2e-5
+    for off in (0, 1):                                               # the last layer's queried rows / the second pass's rtg rows
+        pos = torch.tensor([((T - 1) * A + a) * 3 + off for a in range(A)], dtype=torch.int32, device=DEV)
+        qc = qkv[:, pos.long(), :].contiguous()
+        Oc = torch.zeros(B, A, 256, device=DEV)
+        _lib.check(_lib.lib().ctrlsim_attention(5, p(qc), 768, A * 768, qkv.data_ptr() + 256 * 4, qkv.data_ptr() + 512 * 4, 768,
+                                                L * 768, p(Oc), 256, A * 256, p(pos), None, B, A, L, A, _lib.stream_ptr()))
+        assert (Oc.double() - ref[:, pos.long()]).abs().max().item() < 2e-5
+
+
 @pytest.mark.parametrize("A,T", [(24, 32), (6, 8), (24, 7), (5, 13)])
 def test_attention_mask_of_the_decision_transformer(A, T):
     """Mode 4: get_causal_mask with state_index 1 for the token order (rtg, state, action), evaluated on tokens stored in the

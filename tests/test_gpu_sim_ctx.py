@@ -721,6 +721,57 @@ def test_baseline_variants_match_reference_fixture(name):
     assert g[f"{name}_loop_coll"][..., 0].sum() > 0
 
 
+def test_attend_own_return_action_matches_reference_fixture():
+    """cfg.model.attend_own_return_action = True (cfgs/model/base.yaml:15; built in round 6 as mask mode 5, plain contexts, full recompute):
+    both heads' logits of the two-pass forward against the reference Encoder / Decoder built with that cfg, then the closed loop against the
+    unmodified reference policy + real FreeCar / Box2D (tests/golden/own_return.npz: 14 steps through the window slide, tilts on) —
+    tokens, RTG bins and flags identical, states within 1e-4; the same scene under the default mask gives other tokens."""
+    from ctrlsim_amd.models.ctrl_sim import CtRLSim
+    from helpers import LOOP, TINY
+    g = golden("own_return")
+    own = {"model__attend_own_return_action": True}
+    # the reference's full contract at the tiny dims (every token of both heads), teacher-forced
+    cfg = spec.make_cfg(**TINY, **own)
+    d = spec.Dims(cfg)
+    net = CtRLSim(cfg, weights.generate(d, 0), device=DEV)
+    for seed in (1, 2):
+        _, t_fill, n_ag, n_pl = [int(v) for v in g[f"tiny_s{seed}_recipe"]]
+        inp = synth_inputs.random_context(d, seed, B=1, t_fill=t_fill, n_agents=n_ag, n_polys=n_pl)
+        out = net(synth_inputs.to_motion_data(inp), eval=True)
+        for head in ("action_preds", "rtg_preds"):
+            np.testing.assert_allclose(out[head].cpu().numpy(), g[f"tiny_s{seed}_{head}"], atol=1e-4, rtol=0, err_msg=head)
+    cfg = spec.make_cfg(**LOOP, **own)
+    d = spec.Dims(cfg)
+    assert d.MASK_OWN
+    w = weights.generate(d, 0)
+    net = CtRLSim(cfg, w, device=DEV)
+    for seed in (1, 2):                                             # the slice the policy reads: the two-pass forward
+        _, t_fill, n_ag, n_pl = [int(v) for v in g[f"loop_s{seed}_recipe"]]
+        inp = synth_inputs.random_context(d, seed, B=1, t_fill=t_fill, n_agents=n_ag, n_polys=n_pl)
+        out = net(synth_inputs.to_motion_data(inp), eval=True, token_index=t_fill - 1)
+        np.testing.assert_allclose(out["rtg_preds"][0].cpu().numpy(), g[f"loop_s{seed}_rtg_preds"], atol=1e-4, rtol=0)
+        np.testing.assert_allclose(out["action_preds"][0].cpu().numpy(), g[f"loop_s{seed}_action_preds"], atol=1e-4, rtol=0)
+    rc = g["loop_recipe"]
+    scn = scenarios.make_scenario(int(rc[0]), int(rc[1]), n_agents=int(rc[2]), n_polylines=int(rc[3]), n_points=d.NP, extent=float(rc[4]))
+    for lanes in (1, 2):
+        eng = RolloutEngine(cfg, w, DEV, max_ctx=32, seed=int(rc[5]), tilt=tuple(float(v) for v in rc[6:9]), model=net.hip, lanes=lanes)
+        assert eng.sizes == (d.A,) and not eng.use_cache          # plain contexts, full recompute
+        eng.load_scenarios([scn, scn], steps=14)
+        r = eng.run(14).results()
+        for s in range(2):
+            assert np.array_equal(r["n_groups"][:, s], g["loop_n_groups"])
+            assert np.array_equal(r["tokens"][s][:, :14], g["loop_tokens"])
+            np.testing.assert_allclose(r["states"][s], g["loop_states"], atol=1e-4, rtol=0)
+            assert np.array_equal(r["coll"][s], g["loop_coll"])
+    # the default mask on the same scene, seed and tilts: other tokens (as in the reference: loop_tokens_default_mask)
+    cfg0 = spec.make_cfg(**LOOP)
+    e0 = RolloutEngine(cfg0, w, DEV, max_ctx=32, seed=int(rc[5]), tilt=tuple(float(v) for v in rc[6:9]))
+    e0.load_scenarios([scn], steps=14)
+    r0 = e0.run(14).results()
+    assert np.array_equal(r0["tokens"][0][:, :14], g["loop_tokens_default_mask"])
+    assert (g["loop_tokens"] != g["loop_tokens_default_mask"]).sum() > 0
+
+
 def test_kinematic_integrator_mode_matches_oracle():
     """mode 1 of ctrlsim_sim_step = Object::KinematicBicycleStep (object.cc:126-137; not what eval_sim.py runs — optional,
     SURVEY 8a S6): scripted actions vs the oracle's restatement, which holds the reference's own known answers

@@ -211,7 +211,7 @@ def test_real_time_reward_policy_starts_from_the_preprocessed_rtgs():
                                               for i in range(2)}, goal, {0: 5.0, 1: 4.0}, gt, None)
 
 
-@pytest.mark.parametrize("key,value", [("attend_own_return_action", True), ("use_map", False), ("encode_initial_state", False), ("no_actions", True),
+@pytest.mark.parametrize("key,value", [("use_map", False), ("encode_initial_state", False), ("no_actions", True),
                                        ("local_frame_predictions", True), ("ctg_plus_plus", True), ("hidden_dim", 128), ("num_heads", 4),
                                        ("num_reward_components", 2), ("predict_rtg", False)])
 def test_model_layer_refuses_configurations_it_does_not_implement(key, value):
@@ -240,3 +240,14 @@ def test_model_layer_accepts_the_shipped_configurations():
         spec.check_supported(spec.make_cfg(**{"model__" + v: True, "model__predict_rtg": False, "model__predict_future_states": False}))
     with pytest.raises(NotImplementedError, match="set together"):
         spec.check_supported(spec.make_cfg(model__il=True, model__trajeglish=True))
+    # cfg.model.attend_own_return_action (cfgs/model/base.yaml:15): built in round 6 for the CtRL-Sim tokens (mask mode 5, dims.variant 4);
+    # with a baseline's token layout the reference's own mask code does not describe a network (utils/train_utils.py:114-129), so: refused
+    own = spec.make_cfg(model__attend_own_return_action=True)
+    spec.check_supported(own)
+    d = spec.Dims(own)
+    assert d.MASK_OWN and d.VARIANT == 0
+    assert not spec.Dims(spec.make_cfg()).MASK_OWN
+    for v in ("il", "trajeglish", "decision_transformer"):
+        with pytest.raises(NotImplementedError, match="attend_own_return_action"):
+            spec.check_supported(spec.make_cfg(**{"model__" + v: True, "model__predict_rtg": False, "model__predict_future_states": False,
+                                                  "model__attend_own_return_action": True}))

@@ -420,6 +420,39 @@ def test_variant_oracles_match_reference(name, K):
     assert np.array_equal(r["states"], g[f"{name}_loop_states"]) and np.array_equal(r["coll"], g[f"{name}_loop_coll"])
 
 
+def test_own_return_mask_oracles_match_reference():
+    """cfg.model.attend_own_return_action = True (cfgs/model/base.yaml:15, utils/train_utils.py:114-129; built in round 6): the closed-form
+    mask against the reference's `get_causal_mask`, the model oracle against the reference Encoder / Decoder built with that cfg (both
+    heads the policy reads), the rollout oracle against the unmodified reference policy + real FreeCar / Box2D (tests/golden/own_return.npz;
+    the same scene rolled under the default mask differs in 7 of 126 tokens: the fixture is not vacuous)."""
+    g = golden("own_return")
+    assert np.array_equal(mo.causal_mask_closed_form(4, 4, 3, 0, True).numpy(), g["mask_tiny"])
+    assert not np.array_equal(mo.causal_mask_closed_form(4, 4, 3, 0, False).numpy(), g["mask_tiny"])
+    own = {"model__attend_own_return_action": True}
+    from helpers import TINY, LOOP
+    for tag, over in (("tiny", TINY), ("loop", LOOP)):
+        cfg = spec.make_cfg(**over, **own)
+        d = spec.Dims(cfg)
+        assert d.MASK_OWN and d.VARIANT == 0
+        tw = mo.as_torch_weights(weights.generate(d, 0))
+        for seed in (1, 2):
+            _, t_fill, n_ag, n_pl = [int(v) for v in g[f"{tag}_s{seed}_recipe"]]
+            inp = synth_inputs.random_context(d, seed, B=1, t_fill=t_fill, n_agents=n_ag, n_polys=n_pl)
+            with torch.no_grad():
+                out = mo.forward(tw, synth_inputs.to_torch(inp), d)
+            for head in ("action_preds", "rtg_preds"):
+                got = out[head].numpy() if tag == "tiny" else out[head][0, :, t_fill - 1].numpy()
+                np.testing.assert_allclose(got, g[f"{tag}_s{seed}_{head}"], atol=2e-5, rtol=0)
+    rc = g["loop_recipe"]
+    cfg = spec.make_cfg(**LOOP, **own)
+    d = spec.Dims(cfg)
+    scn = scenarios.make_scenario(int(rc[0]), int(rc[1]), n_agents=int(rc[2]), n_polylines=int(rc[3]), n_points=d.NP, extent=float(rc[4]))
+    r = rollout_oracle.RolloutOracle(cfg, weights.generate(d, 0), seed=int(rc[5]), tilt=tuple(float(v) for v in rc[6:9])).run(scn, 14, sim_libs.OracleSim)
+    assert np.array_equal(r["tokens"], g["loop_tokens"]) and np.array_equal(r["n_groups"], g["loop_n_groups"])
+    assert np.array_equal(r["states"], g["loop_states"]) and np.array_equal(r["coll"], g["loop_coll"])
+    assert (g["loop_tokens"] != g["loop_tokens_default_mask"]).sum() > 0
+
+
 def test_inverse_bicycle_matches_reference():
     """G10: nocturne/bicycle_model.py:51-109 (log-replay actions)."""
     from ctrlsim_amd.kinematics import bicycle_backward
