@@ -63,7 +63,7 @@ int launch_assemble_rows(int, int, int, int, int, const int*, const float*, cons
                          const int*, EmbedTables, float*, hipStream_t);
 int launch_assemble_rtg_rows(int, int, int, int, int, int, int, int, const int*, const int*, const int*, const float*,
                              const int*, EmbedTables, const int*, float*, hipStream_t);
-struct MapPoolWeights { const float *Wc, *G, *ln_b, *U, *cb, *Mt, *mb; };
+struct MapPoolWeights { const float *Wc2, *Wc, *G, *ln_b, *U, *cb, *Mt, *mb; };
 int launch_map_pool(int, int, int, int, const float*, MapPoolWeights, float*, unsigned char*, hipStream_t);
 int launch_map_pool_classes(int, const int*, const int*, const long*, int, int, const float*, MapPoolWeights, float*, unsigned char*,
                             hipStream_t);
@@ -167,7 +167,7 @@ extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_w
                       P("encoder.embed_agent_id.weight"), P("encoder.embed_ln.weight"), P("encoder.embed_ln.bias"),
                       dims->variant == 3 ? 1 : 0};
   const std::string me = "encoder.map_encoder.";
-  m->mp = MapPoolWeights{P("fold.map.Wc"), P("fold.map.G"), P(me + "road_pts_encoder.mlp.1.bias"),
+  m->mp = MapPoolWeights{P("fold.map.Wc2"), P("fold.map.Wc"), P("fold.map.G"), P(me + "road_pts_encoder.mlp.1.bias"),
                          P("fold.map.U"), P("fold.map.cb"), P("fold.map.Mt"), P("fold.map.mb")};
   m->map_out = lin(me + "road_pts_attn_layer.out_proj");
   m->map_n1 = lnp(me + "norm1");

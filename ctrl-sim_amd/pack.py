@@ -8,7 +8,7 @@ the model function unchanged in exact arithmetic:
   fold.embed_goal.b    = W_sg[:, :D] b_state3 + W_sg[:, D:] b_goal3 + b_sg
   fold.rtg_table_{goal,veh,road} = E_c @ W_rtg[:, cD:(c+1)D]^T   embed_rtg over three embedding rows (:116-125)
   fold.map.U, fold.map.cb, fold.map.Mt, fold.map.mb         single-seed attention pooling of the map encoder
-  fold.map.Wc, fold.map.G                                   first point-MLP layer + its LayerNorm in closed form
+  fold.map.Wc, fold.map.Wc2, fold.map.G                                   first point-MLP layer + its LayerNorm in closed form
                                                              (modules/map_encoder.py:44-46; see csrc/map_encoder.hip)
 Tensors are laid out back to back in ONE float32 buffer, each aligned to 256 bytes; `names`/`offsets` (in floats)
 are handed to ctrlsim_model_create.
@@ -68,6 +68,8 @@ def fold(dims: Dims, w: dict) -> dict:
     Wt = np.concatenate([W1 - W1.mean(0, keepdims=True), (b1 - b1.mean())[:, None]], axis=1)      # [D, 4]
     G = Wt.T @ Wt / D
     out["fold.map.Wc"] = Wt * g1[:, None]
+    # the same with the channels of a pair interleaved per component, [D / 2, 4, 2]: the packed-fp32 kernel reads the pair as one scalar register pair
+    out["fold.map.Wc2"] = (Wt * g1[:, None]).reshape(D // 2, 2, 4).transpose(0, 2, 1).copy()
     out["fold.map.G"] = G[np.triu_indices(4)]                            # 00 01 02 03 11 12 13 22 23 33
     out["fold.map.U"] = U
     out["fold.map.cb"] = cb

@@ -776,23 +776,27 @@ def test_outproj_layernorm_query_projection_as_one_kernel(M):
     assert torch.equal(Z, X1) and torch.equal(Q2, Q[:, :256])
 
 
-@pytest.mark.parametrize("B", [1, 3])
-def test_map_pool_matches_the_unfolded_front_end_in_float64(B):
+@pytest.mark.parametrize("B,NP", [(1, 100), (3, 100), (2, 127), (2, 128), (1, 200), (1, 256)])
+def test_map_pool_matches_the_unfolded_front_end_in_float64(B, NP):
     """map_pool_kernel (point MLP + single-seed attention pooling with every linear stage folded at pack time: csrc/map_encoder.hip) against
     a float64 evaluation of the UNFOLDED front end written from modules/map_encoder.py:28-46 — Linear(3, 256) - LayerNorm - ReLU -
     Linear(256, 256) per point, an 8-head attention whose only query is the learned seed, key padding = missing points, a polyline without
     any point un-masks its point 0 — up to, not including, out_proj.  Polylines with 0, 1, 2, 31, 32, 33, 99 and 100 visible points, points
-    missing in the middle; padding bytes exact, pooled vectors to fp32 accuracy."""
+    missing in the middle; padding bytes exact, pooled vectors to fp32 accuracy.  Round 6 (packed-fp32 kernel: a polyline's compact point range
+    starts at an even slot and an odd range ends in a zero-weight pad point): 127 / 128 points per polyline (two polylines fill the 256 slots
+    with and without pads) and 200 / 256 (one polyline per workgroup)."""
     from ctrlsim_amd import spec, weights
     from ctrlsim_amd.engine import HipModel
-    cfg = spec.make_cfg()
+    cfg = spec.make_cfg(dataset__waymo__max_num_road_pts_per_polyline=NP)
     d = spec.Dims(cfg)
+    assert d.NP == NP
     wts = weights.generate(d, 0)
     model = HipModel(cfg, wts, DEV)
     lib, p, st = _lib.lib(), _lib.ptr, _lib.stream_ptr()
     rs = np.random.RandomState(B)
     npts = rs.randint(0, d.NP + 1, (B, d.P))
-    npts[0, :8] = [0, 1, 2, 31, 32, 33, 99, 100]
+    npts[0, :8] = [0, 1, 2, 31, 32, 33, NP - 1, NP]
+    npts[0, 12:16] = [NP, NP, NP - 1, NP]                        # full neighbours in one workgroup, odd + full
     ex = (np.arange(d.NP)[None, None] < npts[..., None]).astype(np.float32)
     ex[0, 9, 5:40] = 0.0                                        # holes: existence is a per-point flag, not a prefix
     ex[0, 10, ::2] = 0.0

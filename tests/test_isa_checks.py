@@ -61,11 +61,13 @@ def test_simulator_kernels_use_no_scratch_memory(tmp_path):
 # together with a fresh run of the provocations, tools/jobs/r04_hazard_final.sh).  Round 5: ffn_fused_s1 holds three kernels instead of one
 # (feed-forward block; with the out-projection + LayerNorm in front; out-projection + LayerNorm + query projection): 64 / 256 -> 192 / 448,
 # all of them op_sel_hi broadcasts of f32x4-times-scalar expressions; provocations re-run on that build (profiles/README.md, round-5 log).
-PACKED_BUDGET = {"gemm": (12, 92), "attention": (16, 16), "sim": (15, 83), "embed": (0, 0), "map_encoder": (0, 9),
+PACKED_BUDGET = {"gemm": (12, 92), "attention": (16, 16), "sim": (15, 83), "embed": (0, 0), "map_encoder": (120, 194),
                  "gemm_bf16x6_s1": (136, 872), "gemm_bf16x6_s0": (128, 864), "ffn_fused_s1": (192, 448), "ffn_fused_s0": (64, 256),
                  "attention_bf16x6_s1": (64, 72), "attention_bf16x6_s0": (64, 72)}
 # (round 6: attention_bf16x6_s* holds one more kernel, the resident-keys form of the key-padded kernel: its Q rows x scale_log2e are eight more
-#  unswizzled packed multiplies, 64 / 64 -> 64 / 72; tests/test_gpu_hazard.py re-run on that build with the whole GPU suite)
+#  unswizzled packed multiplies, 64 / 64 -> 64 / 72; tests/test_gpu_hazard.py re-run on that build with the whole GPU suite.
+#  map_encoder: the packed-fp32 form of map_pool (explicit f32x2 FMAs, no SLP): 0 / 9 -> 120 / 194, all swizzles op_sel_hi broadcasts of a LOW
+#  half — the forms round 4 cleared; provocations of tools/jobs/r06_u.sh on that build)
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
