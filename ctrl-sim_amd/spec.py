@@ -127,7 +127,8 @@ _FROZEN_MODEL_FLAGS = (
     ("use_map", True, "no MapEncoder, no polyline tokens in the scene encoder (modules/encoder.py:18,155)"),
     ("encode_initial_state", True, "no scene encoder memory at all (modules/encoder.py:84,111,135,159)"),
     ("no_actions", False, "action embeddings are dropped from the token rows (modules/encoder.py:129)"),
-    ("local_frame_predictions", False, "future-state targets in the agent frame (models/ctrl_sim.py:114)"),
+    # (local_frame_predictions is NOT here: it selects the TRAINING target of the predict_future_states head — world or agent frame,
+    #  models/ctrl_sim.py:114,151 — and nothing in the forward pass reads it: a checkpoint trained either way is the same network)
     ("ctg_plus_plus", False, "the diffusion baseline is another model (models/ctg_plus_plus.py)"),
     ("hidden_dim", 256, "the kernels are built for 256-wide rows (csrc/common.h: DM)"),
     ("num_heads", 8, "the kernels are built for 8 heads of 32 (csrc/common.h: NHEAD, HD)"),

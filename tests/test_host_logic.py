@@ -212,7 +212,7 @@ def test_real_time_reward_policy_starts_from_the_preprocessed_rtgs():
 
 
 @pytest.mark.parametrize("key,value", [("use_map", False), ("encode_initial_state", False), ("no_actions", True),
-                                       ("local_frame_predictions", True), ("ctg_plus_plus", True), ("hidden_dim", 128), ("num_heads", 4),
+                                       ("ctg_plus_plus", True), ("hidden_dim", 128), ("num_heads", 4),
                                        ("num_reward_components", 2), ("predict_rtg", False)])
 def test_model_layer_refuses_configurations_it_does_not_implement(key, value):
     """Round-5 review: the model layer accepted any cfg silently.  Every option of cfgs/model/base.yaml that changes the NETWORK and that the
@@ -242,6 +242,7 @@ def test_model_layer_accepts_the_shipped_configurations():
         spec.check_supported(spec.make_cfg(model__il=True, model__trajeglish=True))
     # cfg.model.attend_own_return_action (cfgs/model/base.yaml:15): built in round 6 for the CtRL-Sim tokens (mask mode 5, dims.variant 4);
     # with a baseline's token layout the reference's own mask code does not describe a network (utils/train_utils.py:114-129), so: refused
+    spec.check_supported(spec.make_cfg(model__local_frame_predictions=True))      # a training-target switch: the same network (models/ctrl_sim.py:114,151)
     own = spec.make_cfg(model__attend_own_return_action=True)
     spec.check_supported(own)
     d = spec.Dims(own)
