@@ -414,20 +414,21 @@ def main():
             row = {"achieved": rate, "peak": PEAK_HBM_TBPS, "unit": "TB/s", "frac": rate / PEAK_HBM_TBPS,
                    "avg_launch_ms": ms[i] / cnt[i], "launches": int(cnt[i]), "time_share_of_step": ms[i] * 1e-3 / elapsed,
                    "algorithmic_hbm_bytes_per_launch": by[i] / cnt[i]}
-            mp_path = os.path.join(ROOT, "profiles", "r05_c_pmc_map_pool.json")
+            mp_path = os.path.join(ROOT, "profiles", "r06_c_pmc_map_pool.json")
             if CLASS_KEYS[i] == "map_pool" and os.path.exists(mp_path):
-                # map_pool is a VECTOR-pipe kernel (no HBM roof: it moves its bytes once, at 0.1 TB/s): its roof is the vector issue rate.
-                # Instructions per polyline from the SQ counter passes (profiles/r05_c_pmc_map_pool.md), time from this run's HIP events.
+                # map_pool is a VECTOR-pipe kernel (no HBM roof: it moves its bytes once, at 0.1 TB/s): its roof is the vector pipe's time.
+                # Busy SIMD-cycles per polyline from the SQ counter passes (SQ_ACTIVE_INST_VALU, profiles/r06_c_pmc_map_pool.md: a wave64
+                # v_fma_f32 holds a SIMD's vector pipe for 2 cycles, a v_pk_fma_f32 for 4), time from this run's HIP events.
                 mp = json.load(open(mp_path))
                 polylines = fl[i] / 1.5e6                          # launch_map_pool tags 1.5 MFLOP per polyline
-                inst_rate = polylines * mp["valu_insts_per_polyline"] / (ms[i] * 1e-3)
-                peak_rate = 256 * 4 * 0.5 * 2.4e9                  # a wave64 VALU instruction occupies a SIMD for 2 cycles (MI355X_MICROARCH.md)
-                row["vector_issue"] = {"bound": "valu", "achieved": inst_rate / 1e12, "peak": peak_rate / 1e12, "unit": "T wave-instructions/s",
-                                       "frac": inst_rate / peak_rate, "active_lanes_per_instruction": mp["active_lanes_per_valu_inst"],
-                                       "counter_frac_at_profiled_clock": mp["valu_issue_frac_measured"], "source": "profiles/r05_c_pmc_map_pool.md",
-                                       "note": "peak at the 2.4 GHz maximum clock; the counters' own cycle count (profiled run, 2.2 GHz) gives "
-                                               "counter_frac_at_profiled_clock; what keeps it from 0.75 is in the profile (five barrier-separated "
-                                               "phases, 59 % of a wave's residence parked, a scalar weight stream)"}
+                busy_rate = polylines * mp["valu_busy_simd_cycles_per_polyline"] / (ms[i] * 1e-3)
+                peak_rate = mp["simds"] * 2.4e9                    # 1024 SIMDs x the 2.4 GHz maximum clock
+                row["vector_pipe"] = {"bound": "valu", "achieved": busy_rate / 1e12, "peak": peak_rate / 1e12, "unit": "T busy SIMD-cycles/s",
+                                      "frac": busy_rate / peak_rate, "kernel": mp["kernel"], "valu_insts_per_polyline": mp["valu_insts_per_polyline"],
+                                      "active_lanes_per_instruction": mp["active_lanes_per_valu_inst"],
+                                      "counter_frac_at_profiled_clock": mp["valu_busy_frac_measured"], "source": "profiles/r06_c_pmc_map_pool.md",
+                                      "note": "peak at the 2.4 GHz maximum clock; the counters' own cycle count (profiled run) gives "
+                                              "counter_frac_at_profiled_clock = 0.87: the kernel is at its FMA count (packed FMAs, round 6)"}
             return row
         KNAMES = ("other", "Linear + K/V-image epilogue (QKV, memory K/V): inproj_rs_kernel (row-stationary; weight-stationary gemm_ws256_kernel<..,KV> / tiled gemm_nt_bf16x6_kernel<2,2,2,..,KVIMG> by option or when K != 256)",
                   "Linear + residual + LayerNorm epilogue (attention out-projections, MLP layers): gemm_ws256_kernel<..,LN> (weight-stationary; tiled gemm_nt_bf16x6_kernel<1,4,2,..,LN> when K != 256)",
