@@ -51,6 +51,9 @@ constexpr size_t FF_RING_BYTES = (size_t)FF_RING * FF_BLK * sizeof(op_t) > (size
                                      ? (size_t)FF_RING * FF_BLK * sizeof(op_t) : (size_t)4 * 32 * FF_CP * 4;
 
 #define FFN_TERMS(ACC, A, B) SPLIT_TERMS(ACC, A, B)
+#ifndef FF_2CH
+#define FF_2CH 0          // 1: the W1-shaped products on two alternating accumulator chains (round 6 experiment)
+#endif
 
 // (Two independent accumulator chains per product were tried — a single dependent chain runs the matrix pipe at ~73 % with
 // one wave per SIMD — but at this register pressure hipcc answers with v_accvgpr_mov shuffles / spills and the result is
@@ -205,12 +208,36 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_bf16x6_kernel(
       ld1(0, wf[0]);
       ld1(1, wf[1]);
       if (FFN_PF == 3) ld1(2, wf[2]);
+#if FF_2CH
+      // two accumulator chains (even / odd k-steps), their MFMAs alternating: every MFMA then follows one on the OTHER accumulator.  The 48
+      // products of a block are otherwise ONE dependent chain with two LDS reads, a DMA piece and their waits between its links — and an
+      // issue slot between two MFMAs on the same accumulator costs ~43 cycles, between different accumulators ~6 (MI355X_MICROARCH.md)
+      f32x16 accb;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 16; ks += 2) {
+        // (the four fragment buffers hold the pair in flight and the next pair: requested one pair = six MFMAs ahead)
+        if (ks + 2 < 16 && !(FFN_PF == 3 && ks == 0)) ld1(ks + 2, wf[(ks + 2) & 3]);
+        if (ks + 3 < 16) ld1(ks + 3, wf[(ks + 3) & 3]);
+        if (dma && ks < FF_PIECES) dma_piece(dsrc, ddst, ks);
+        if (dma && ks + 1 < FF_PIECES) dma_piece(dsrc, ddst, ks + 1);
+#define FF_ALT(PA, PB)                                                   \
+  acc = MFMA_OP(wf[ks & 3][PA], xT[ks][PB], acc);                       \
+  accb = MFMA_OP(wf[(ks + 1) & 3][PA], xT[ks + 1][PB], accb);
+        PROD_LIST(FF_ALT)
+#undef FF_ALT
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += accb[r];
+#else
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
         if (ks + FFN_PF < 16) ld1(ks + FFN_PF, wf[(ks + FFN_PF) & 3]);
         if (dma && ks < FF_PIECES) dma_piece(dsrc, ddst, ks);
         FFN_TERMS(acc, wf[ks & 3], xT[ks])
       }
+#endif
     };
     if (PRE) {
       // ---------------- leading product: Y^T = Wo . O^T, eight W1-shaped blocks (two per barrier, like a hidden block's pair); the pair
