@@ -55,6 +55,10 @@ def main():
     ap.add_argument("--agents", type=int, default=64)
     ap.add_argument("--polylines", type=int, default=512)
     ap.add_argument("--rollout-steps", type=int, default=90)
+    ap.add_argument("--context-slots", type=int, default=0,
+                    help="NON-REFERENCE secondary of SURVEY.md 8(d): agent slots per context (cfg.dataset.waymo.max_num_agents; 0 = the reference's 24). "
+                         "64 = one wide context per 64-vehicle scenario instead of three focal groups")
+    ap.add_argument("--context-polylines", type=int, default=0, help="with --context-slots: polylines per context (0 = the reference's 200)")
     ap.add_argument("--max-ctx", type=int, default=1024, help="model batch (contexts per forward chunk; the two lanes' workspaces take 2 x 84 GB of the 288 GB at 1024)")
     ap.add_argument("--lanes", type=int, default=2, help="scenario sets in flight per GPU (engine.py)")
     ap.add_argument("--seed", type=int, default=0)
@@ -140,7 +144,12 @@ def main():
         for kv in filter(None, os.environ.get("CTRLSIM_OPTIONS", "").split(",")):   # "<option>=<value>,...": kernel A/B runs only
             k, v = kv.split("=")
             _lib.lib().ctrlsim_set_option(int(k), int(v))
-    cfg = spec.make_cfg(nocturne__steps=args.rollout_steps, nocturne__history_steps=1)
+    over = {}
+    if args.context_slots:
+        over["dataset__waymo__max_num_agents"] = args.context_slots
+    if args.context_polylines:
+        over["dataset__waymo__max_num_road_polylines"] = args.context_polylines
+    cfg = spec.make_cfg(nocturne__steps=args.rollout_steps, nocturne__history_steps=1, **over)
     d = spec.Dims(cfg)
     w = weights.generate(d, 0)
     S, N, R, K = args.scenarios, args.agents, args.rollout_steps, args.steps
@@ -496,6 +505,8 @@ def main():
                    "configs[3] (8192 scenarios sharded over the ranks)" if (world > 1 and S * world == 8192 and shape == (64, 90, 512)) else
                    "configs[2]" + (" per GPU" if world > 1 else "") if (S,) + shape == (2048, 64, 90, 512) else
                    "configs[1]" if (S,) + shape == (256, 32, 90, 200) else "custom shape")
+        if args.context_slots or args.context_polylines:      # reported separately, flagged non-reference
+            cfg_tag = f"NON-REFERENCE secondary (wide context: A={d.A} slots, P={d.P} polylines per context; the reference's cfg has 24 / 200) on " + cfg_tag
         out = {
             "metric": "agent-steps/sec (closed-loop rollout), 64 agents x 90 steps",
             "dtype_short": f"f32 ({'f16x3' if f16 else 'bf16x6'} split-operand MFMA, fp32 accumulate)",
@@ -508,7 +519,7 @@ def main():
                                        f"CtRL-Sim base model (random init)" + (", tilt sweep" if args.tilt_sweep else ""),
                        "workload": f"{S} synthetic Waymo-shaped scenarios resident per GPU x {N} agents x {R} steps, "
                                    f"{args.polylines} road polylines x 100 points, CtRL-Sim base model (8.29M params, "
-                                   f"random init), context A=24/T=32/P=200"
+                                   f"random init), context A={d.A}/T={d.T}/P={d.P}"
                                    + (" = BASELINE.json configs[4] (reward-tilt sweep: 8 tilt values x 1024 scenarios)"
                                       if (args.tilt_sweep and S * world == 8192 and (N, R, args.polylines) == (64, 90, 512)) else
                                       " = BASELINE.json configs[3] (8192 scenarios sharded over the ranks)"

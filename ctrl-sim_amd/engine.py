@@ -263,8 +263,9 @@ class RolloutEngine:
         # hold (CTRLSIM_MAX_CLASSES) 1.014x the rows and 1.033x the attention pairs of exact per-context sizes — the eight classes
         # of round 2 (6, 8, 10, 12, 14, 16, 20, 24) cost 1.080x / 1.142x.  Row-wise kernels run once over all classes and the
         # attention grid is a concatenation, so a class costs nothing but a few index launches.
+        # Other slot counts (tests, the non-reference wide context A = 64): every size up to 17 slots, else 16 sizes spread evenly up to A.
         tuned = (4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 24) if A == 24 else \
-            tuple(sorted({a for a in range(max(2, A - 15), A)} | {A}))[-16:]
+            tuple(range(2, A + 1))[-16:] if A <= 17 else tuple(sorted({max(2, (A * k + 15) // 16) for k in range(1, 17)}))
         if sizes is not None:                       # explicit class set (A/B measurements, tests): ascending slot counts, A last
             tuned = tuple(int(a) for a in sizes)
             assert tuned == tuple(sorted(set(tuned))) and tuned[-1] == A and tuned[0] >= 2 and len(tuned) <= 16

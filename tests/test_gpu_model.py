@@ -39,8 +39,9 @@ def _run_both_passes(model, d, inp, Tq, new_bins):
     return rtg.cpu().numpy(), act.cpu().numpy(), seg.cpu().numpy()
 
 
-@pytest.mark.parametrize("kind,B", [("tiny", 3), ("loop", 2), ("full", 2)])
+@pytest.mark.parametrize("kind,B", [("tiny", 3), ("loop", 2), ("full", 2), ("wide", 1)])
 def test_forward_matches_oracle(kind, B):
+    """(wide: A = 64 slots, P = 512 polylines in ONE context, L = 6144 token rows — the non-reference "wide context" of SURVEY.md section 8(d))"""
     cfg = cfg_of(kind)
     d = spec.Dims(cfg)
     w = weights.generate(d, 0)
