@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("CTRLSIM_LIB") or os.path.join(HERE, "csrc", "libctrls
 
 
 class Dims(C.Structure):
-    _fields_ = [(k, C.c_int) for k in ("A", "T", "P", "NP", "D", "H", "F", "V", "R", "C", "NE", "ND", "MAXT", "variant")]
+    _fields_ = [(k, C.c_int) for k in ("A", "T", "P", "NP", "D", "H", "F", "V", "R", "C", "NE", "ND", "MAXT", "variant", "flags")]
 
 
 class DtRewardCfg(C.Structure):

@@ -34,6 +34,10 @@ struct EmbedTables {
   const float* ln_b;
   int rtg_linear;          // Decision Transformer: the RTGs are continuous (float bits in rtg_bin) and rtg_g/v/r are single
                            // rows: embed_rtg(cat_c Linear_c(r_c)) = r_0 g + r_1 v + r_2 r + rtg_bias (pack.py fold)
+  int flags;               // ctrlsim_dims.flags (include/ctrlsim.h): bit 0 = cfg.model.no_actions — the action embeddings (with their timestep
+                           // and agent-id parts) are multiplied by zero before embed_ln (modules/encoder.py:129-130): an action row is
+                           // LayerNorm(0) = the norm's bias; bit 2 = encode_initial_state False — the vehicles' initial-state rows are no
+                           // keys of the scene encoder / the decoder's memory (modules/encoder.py:159-166): their padding byte is always 1
 };
 
 // Compact contexts (forward.hip): the context tensors hold A slots per step, of which the first Areg are "regular" and — when
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(256) void assemble_tokens_classes_kernel(
   if (tt == 0) {
     const size_t s0 = ac.srow[k] + (size_t)b * M;
     *reinterpret_cast<f32x4*>(src + (s0 + P + a) * DM + c4) = v;
-    if (lane == 0) src_pad[s0 + P + a] = ex != 0.f ? 0 : 1;
+    if (lane == 0) src_pad[s0 + P + a] = (ex != 0.f && !(tb.flags & 4)) ? 0 : 1;
     if (a == A - 1) {
       for (int e = P + A; e < M; ++e) {
         *reinterpret_cast<f32x4*>(src + (s0 + e) * DM + c4) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(256) void assemble_tokens_classes_kernel(
          *reinterpret_cast<const f32x4*>(tb.rtg_bias + c4) + pos) * ex;
   }
   *reinterpret_cast<f32x4*>(xo + DM) = ln256(v, g, be);
-  v = (*reinterpret_cast<const f32x4*>(tb.act + (size_t)act_tok[grow_] * DM + c4) + pos) * ex;
+  v = (*reinterpret_cast<const f32x4*>(tb.act + (size_t)act_tok[grow_] * DM + c4) + pos) * ((tb.flags & 1) ? 0.f : ex);
   *reinterpret_cast<f32x4*>(xo + 2 * DM) = ln256(v, g, be);
 }
 
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256) void assemble_tokens_kernel(
              *reinterpret_cast<const f32x4*>(Gp + ((size_t)b * A + a) * DM + c4) + pos) * ex;
   if (tt == 0) {
     *reinterpret_cast<f32x4*>(src + ((size_t)b * M + P + a) * DM + c4) = v;
-    if (lane == 0) src_pad[(size_t)b * M + P + a] = ex != 0.f ? 0 : 1;
+    if (lane == 0) src_pad[(size_t)b * M + P + a] = (ex != 0.f && !(tb.flags & 4)) ? 0 : 1;
     if (a == A - 1) {                              // filler rows up to M (forward.hip: M is rounded up to a multiple of 4): zero, key-padded
       for (int e = P + A; e < M; ++e) {
         *reinterpret_cast<f32x4*>(src + ((size_t)b * M + e) * DM + c4) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256) void assemble_tokens_kernel(
   }
   *reinterpret_cast<f32x4*>(xo + DM) = ln256(v, g, be);
   // action
-  v = (*reinterpret_cast<const f32x4*>(tb.act + (size_t)act_tok[row] * DM + c4) + pos) * ex;
+  v = (*reinterpret_cast<const f32x4*>(tb.act + (size_t)act_tok[row] * DM + c4) + pos) * ((tb.flags & 1) ? 0.f : ex);
   *reinterpret_cast<f32x4*>(xo + 2 * DM) = ln256(v, g, be);
 }
 
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(256) void assemble_rows_kernel(int rows, int Rn, in
   } else {
     v = *reinterpret_cast<const f32x4*>(tb.act + (size_t)act_tok[cr] * DM + c4);
   }
-  v = (v + posemb) * ex;
+  v = (v + posemb) * ((k == 2 && (tb.flags & 1)) ? 0.f : ex);
   *reinterpret_cast<f32x4*>(Xn + (size_t)row * DM + c4) = ln256(v, g, be);
 }
 

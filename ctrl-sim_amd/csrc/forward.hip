@@ -56,14 +56,14 @@ int launch_row_copy(const float*, int, float*, int, const int*, int, int, int, h
 int launch_gemm256_rows(const float*, int, const void*, int, int, const float*, float*, int, const int*, int, hipStream_t);
 int launch_attention(int, const float*, int, long, const float*, const float*, int, long, float*, int, long, const int*,
                      const unsigned char*, int, int, int, int, hipStream_t);
-struct EmbedTables { const float *act, *rtg_g, *rtg_v, *rtg_r, *rtg_bias, *tstep, *agent, *ln_g, *ln_b; int rtg_linear; };
+struct EmbedTables { const float *act, *rtg_g, *rtg_v, *rtg_r, *rtg_bias, *tstep, *agent, *ln_g, *ln_b; int rtg_linear, flags; };
 int launch_assemble_tokens(int, int, int, int, const float*, const float*, const float*, const int*, const int*, const int*,
                            EmbedTables, float*, float*, int, int, unsigned char*, hipStream_t);
 int launch_assemble_rows(int, int, int, int, int, const int*, const float*, const float*, const float*, const int*, const int*,
                          const int*, EmbedTables, float*, hipStream_t);
 int launch_assemble_rtg_rows(int, int, int, int, int, int, int, int, const int*, const int*, const int*, const float*,
                              const int*, EmbedTables, const int*, float*, hipStream_t);
-struct MapPoolWeights { const float *Wc2, *Wc, *G, *ln_b, *U, *cb, *Mt, *mb; };
+struct MapPoolWeights { const float *Wc2, *Wc, *G, *ln_b, *U, *cb, *Mt, *mb; int force_pad; };
 int launch_map_pool(int, int, int, int, const float*, MapPoolWeights, float*, unsigned char*, hipStream_t);
 int launch_map_pool_classes(int, const int*, const int*, const long*, int, int, const float*, MapPoolWeights, float*, unsigned char*,
                             hipStream_t);
@@ -126,6 +126,9 @@ extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_w
   if (!dims || !dev_weights || !names || !offsets || !out) return CTRLSIM_EINVAL;
   if (dims->D != DM || dims->H != NHEAD || dims->A < 1 || dims->A > 64 || dims->variant < 0 || dims->variant > 4)
     return CTRLSIM_EINVAL;
+  // flags (include/ctrlsim.h): 1 no_actions, 2 use_map = False, 4 encode_initial_state = False — CtRL-Sim token layout only; without a map AND
+  // without the initial states the reference has no scene memory to build (modules/encoder.py:155-170 reads an undefined tensor)
+  if ((dims->flags & ~7) || (dims->flags && tok_variant(dims->variant) != 0) || (dims->flags & 6) == 6) return CTRLSIM_EINVAL;
   std::unordered_map<std::string, const float*> tab;
   for (int i = 0; i < n; ++i) tab[names[i]] = dev_weights + offsets[i];
   bool ok = true;
@@ -165,10 +168,10 @@ extern "C" int ctrlsim_model_create(const ctrlsim_dims* dims, const float* dev_w
   m->tb = EmbedTables{P("encoder.embed_action.weight"), P("fold.rtg_table_goal"), P("fold.rtg_table_veh"),
                       P("fold.rtg_table_road"), P("fold.rtg_bias"), P("encoder.embed_timestep.weight"),
                       P("encoder.embed_agent_id.weight"), P("encoder.embed_ln.weight"), P("encoder.embed_ln.bias"),
-                      dims->variant == 3 ? 1 : 0};
+                      dims->variant == 3 ? 1 : 0, dims->flags & 5};
   const std::string me = "encoder.map_encoder.";
   m->mp = MapPoolWeights{P("fold.map.Wc2"), P("fold.map.Wc"), P("fold.map.G"), P(me + "road_pts_encoder.mlp.1.bias"),
-                         P("fold.map.U"), P("fold.map.cb"), P("fold.map.Mt"), P("fold.map.mb")};
+                         P("fold.map.U"), P("fold.map.cb"), P("fold.map.Mt"), P("fold.map.mb"), (dims->flags & 2) ? 1 : 0};
   m->map_out = lin(me + "road_pts_attn_layer.out_proj");
   m->map_n1 = lnp(me + "norm1");
   m->map_n2 = lnp(me + "norm2");

@@ -34,6 +34,8 @@ struct MapPoolWeights {
   const float* cb;      // [8]
   const float* Mt;      // [256(c),256(j)]
   const float* mb;      // [256]
+  int force_pad;        // 1: cfg.model.use_map = False (ctrlsim_dims.flags bit 1) — every polyline row is key-padded: the scene encoder and the
+                        // decoder's memory then hold the vehicles' initial-state rows only, as modules/encoder.py:168-170 builds them
 };
 
 // G polylines per workgroup (2 when a polyline has <= 128 points).  Only VISIBLE points are evaluated: a padded point has softmax
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(256) void map_pool_kernel(int NP, int P, MapClasses
     int k = 0;
     while (k + 1 < mc.n && bp >= mc.bp0[k + 1]) ++k;
     const int rel = bp - mc.bp0[k], b = rel / P, p = rel - b * P;
-    src_pad[mc.pad0[k] + (size_t)b * mc.M[k] + p] = any_exist[tid] ? 0 : 1;
+    src_pad[mc.pad0[k] + (size_t)b * mc.M[k] + p] = (any_exist[tid] && !w.force_pad) ? 0 : 1;
   }
 }
 
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(256) void map_pool_pk_kernel(int NP, int P, MapClas
     int k = 0;
     while (k + 1 < mc.n && bp >= mc.bp0[k + 1]) ++k;
     const int rel = bp - mc.bp0[k], b = rel / P, p = rel - b * P;
-    src_pad[mc.pad0[k] + (size_t)b * mc.M[k] + p] = any_exist[tid] ? 0 : 1;
+    src_pad[mc.pad0[k] + (size_t)b * mc.M[k] + p] = (any_exist[tid] && !w.force_pad) ? 0 : 1;
   }
 }
 

@@ -39,7 +39,8 @@ from .spec import Dims, ZERO_ACTION_TOKEN, ZERO_RTG_BINS, check_supported
 
 def _dims_struct(d: Dims):
     return _lib.Dims(A=d.A, T=d.T, P=d.P, NP=d.NP, D=d.D, H=d.H, F=d.F, V=d.V, R=d.R, C=d.C, NE=d.NE, ND=d.ND,
-                     MAXT=d.MAXT, variant=4 if getattr(d, "MASK_OWN", False) else d.VARIANT)   # 4: CtRL-Sim tokens, own-return mask
+                     MAXT=d.MAXT, variant=4 if getattr(d, "MASK_OWN", False) else d.VARIANT,    # 4: CtRL-Sim tokens, own-return mask
+                     flags=int(getattr(d, "FLAGS", 0)))
 
 
 class HipModel:
@@ -51,6 +52,14 @@ class HipModel:
         self.dims = Dims(cfg)
         self.device = torch.device(device)
         self.lib = _lib.lib()
+        if self.dims.FLAGS & 2:
+            # cfg.model.use_map = False: the checkpoint has no encoder.map_encoder.* (modules/encoder.py:18).  The kernels still run the map
+            # side — its polyline rows are key-padded everywhere (ctrlsim_dims.flags bit 1) — on zeros of the shapes the module would have
+            from . import weights as _w
+            weights = dict(weights)
+            for k, v in _w.generate(self.dims, 0).items():
+                if "map_encoder." in k and k not in weights:
+                    weights[k] = np.zeros_like(v)
         flat, names, offsets = _pack.pack(self.dims, weights)
         self.flat = torch.from_numpy(flat).to(self.device)
         self._names = (C.c_char_p * len(names))(*[n.encode() for n in names])

@@ -124,9 +124,8 @@ def make_cfg(**overrides):
 # and return logits of the wrong model, so the model layer refuses it by name instead.
 _FROZEN_MODEL_FLAGS = (
     # (key, required value, what the other value changes in the reference)
-    ("use_map", True, "no MapEncoder, no polyline tokens in the scene encoder (modules/encoder.py:18,155)"),
-    ("encode_initial_state", True, "no scene encoder memory at all (modules/encoder.py:84,111,135,159)"),
-    ("no_actions", False, "action embeddings are dropped from the token rows (modules/encoder.py:129)"),
+    # (use_map = False, encode_initial_state = False and no_actions = True are BUILT since round 6 — ctrlsim_dims.flags, Dims.FLAGS below — for
+    #  the CtRL-Sim token layout; check_supported refuses them with a baseline layout and the two scene switches together)
     # (local_frame_predictions is NOT here: it selects the TRAINING target of the predict_future_states head — world or agent frame,
     #  models/ctrl_sim.py:114,151 — and nothing in the forward pass reads it: a checkpoint trained either way is the same network)
     ("ctg_plus_plus", False, "the diffusion baseline is another model (models/ctg_plus_plus.py)"),
@@ -134,6 +133,14 @@ _FROZEN_MODEL_FLAGS = (
     ("num_heads", 8, "the kernels are built for 8 heads of 32 (csrc/common.h: NHEAD, HD)"),
     ("num_reward_components", 3, "three return components per token (csrc/sample.hip)"),
 )
+
+
+def model_flags(cfg):
+    """ctrlsim_dims.flags (include/ctrlsim.h) of a cfg: 1 = no_actions, 2 = use_map False, 4 = encode_initial_state False
+    (cfgs/model/base.yaml:4,10; ctrl_sim.yaml:9; modules/encoder.py:18,84,129-130,155-170)."""
+    m = cfg.model
+    return (1 if bool(m.get("no_actions", False)) else 0) | (0 if bool(m.get("use_map", True)) else 2) | \
+        (0 if bool(m.get("encode_initial_state", True)) else 4)
 
 
 def check_supported(cfg):
@@ -149,6 +156,12 @@ def check_supported(cfg):
     if variants and bool(m.get("attend_own_return_action", False)):
         bad.append("model.attend_own_return_action with a baseline token layout (utils/train_utils.py:114-129 assumes the three CtRL-Sim token "
                    "types: `type_idx_j = index_j % 3`)")
+    flags = model_flags(cfg)
+    if flags and variants:
+        bad.append(f"model.{variants[0]} with use_map = False / encode_initial_state = False / no_actions = True (built for the CtRL-Sim token layout only)")
+    if (flags & 6) == 6:
+        bad.append("model.use_map = False together with model.encode_initial_state = False (the reference has no scene memory to build then: "
+                   "modules/encoder.py:155-170 reads an undefined tensor)")
     if not variants and not bool(m.get("predict_rtg", True)):
         bad.append("model.predict_rtg = False with the CtRL-Sim token layout (the rollout's first pass reads the return head: "
                    "policies/autoregressive_policy.py:201-221)")
@@ -173,6 +186,7 @@ class Dims:
         # action tokens of EARLIER timesteps are hidden.  Built in round 6 as mask mode 5 of the in-kernel-mask attention path (plain
         # 24-slot contexts, full recompute every step: engine.py)
         self.MASK_OWN = bool(m.get("attend_own_return_action", False)) and self.VARIANT == 0
+        self.FLAGS = model_flags(cfg) if self.VARIANT == 0 else 0
         self.L = self.A * self.T * self.K         # decoder tokens
         self.P = int(w.max_num_road_polylines)
         self.NP = int(w.max_num_road_pts_per_polyline)

@@ -42,6 +42,12 @@ typedef struct ctrlsim_dims {
                   decoder.py:29-64; 4 (round 6) = the CtRL-Sim tokens and heads of 0 under cfg.model.attend_own_return_action
                   (cfgs/model/base.yaml:15, utils/train_utils.py:114-129: other agents' return / action tokens of EARLIER
                   timesteps are hidden; attention mask mode 5; plain 24-slot contexts, no K/V-cached entry point) */
+  int flags;   /* model switches of cfgs/model/base.yaml beyond the shipped values (round 6; 0 = shipped; CtRL-Sim token layout only):
+                  1 = no_actions (modules/encoder.py:129-130: action embeddings x 0 in front of embed_ln),
+                  2 = use_map False (encoder.py:18,155-170: no MapEncoder — the polyline rows of the scene memory are key-padded, the weights
+                      named encoder.map_encoder.* may be zeros),
+                  4 = encode_initial_state False (encoder.py:84,111,135,159-166: the initial-state rows are key-padded).  2 and 4 together are
+                      refused (the reference has no scene memory to build then). */
 } ctrlsim_dims;
 
 /* Agent-local context tensors of B contexts (outputs of ctrlsim_build_context, inputs of the forward). */

@@ -1191,7 +1191,10 @@ def gen_ingest():
 
 # --------------------------------------------------------------------------------------------- IL / Trajeglish variants
 def variant_weights(cfg, w):
-    """The reference IL / Trajeglish modules have no predict_rtg / predict_future_states heads (cfgs/model/{il,trajeglish}.yaml)."""
+    """The reference IL / Trajeglish modules have no predict_rtg / predict_future_states heads (cfgs/model/{il,trajeglish}.yaml); with
+    use_map = False the Encoder has no MapEncoder (modules/encoder.py:18)."""
+    if not cfg.model.get("use_map", True):
+        w = {k: v for k, v in w.items() if "map_encoder." not in k}
     if not (cfg.model.get("il", False) or cfg.model.get("trajeglish", False)):
         return w
     return {k: v for k, v in w.items() if not k.startswith(("decoder.predict_rtg", "decoder.predict_future_states"))}
@@ -1289,6 +1292,52 @@ def gen_own_return():
     out["loop_tokens_default_mask"] = r0["tokens"]
     print("tokens that differ from the default mask's rollout:", int((r0["tokens"] != r["tokens"]).sum()), "of", r["tokens"].size)
     save("own_return", **out)
+
+
+MODEL_FLAG_CASES = {"no_actions": {"model__no_actions": True}, "no_map": {"model__use_map": False},
+                    "no_init": {"model__encode_initial_state": False},
+                    "no_actions_no_map": {"model__no_actions": True, "model__use_map": False}}
+
+
+def gen_model_flags():
+    """cfg.model.no_actions = True, use_map = False, encode_initial_state = False (cfgs/model/base.yaml:4,10; ctrl_sim.yaml:9;
+    modules/encoder.py:18,84,129-130,155-170) through the UNMODIFIED reference: logits of the reference Encoder / Decoder built with each cfg
+    (tiny dims: every token of both heads; loop dims: the slice the policy reads at the last filled step) and, for the three single switches,
+    a closed loop of the unmodified reference policy + real FreeCar / Box2D (14 steps at the loop dims, through the window slide)."""
+    ref_shims.install()
+    out = {}
+    for name, over in MODEL_FLAG_CASES.items():
+        for tag, dims_over in (("tiny", TINY), ("loop", LOOP)):
+            cfg = spec.make_cfg(**dims_over, **over)
+            d = spec.Dims(cfg)
+            assert d.FLAGS
+            w = weights.generate(d, 0)
+            ref = ref_shims.build_reference_model(cfg, variant_weights(cfg, w))
+            for seed, t_fill in ((1, d.T), (2, max(1, d.T // 2))):
+                inp = synth_inputs.random_context(d, seed, B=1, t_fill=t_fill, n_agents=d.A - 1, n_polys=d.P - 1)
+                r = ref(synth_inputs.to_motion_data(inp), eval=True)
+                for head in ("action_preds", "rtg_preds"):
+                    v = r[head].detach().numpy()
+                    out[f"{name}_{tag}_s{seed}_{head}"] = v if tag == "tiny" else v[0, :, t_fill - 1]
+                out[f"{name}_{tag}_s{seed}_recipe"] = np.array([seed, t_fill, d.A - 1, d.P - 1])
+        if "_no_" in name[3:]:
+            continue
+        cfg = spec.make_cfg(**LOOP, **over)
+        d = spec.Dims(cfg)
+        w = weights.generate(d, 0)
+        for idx in range(60):
+            scn = scenarios.make_scenario(23, idx, n_agents=9, n_polylines=15, n_points=d.NP, extent=40.0)
+            r = ref_closed_loop(cfg, w, scn, 14, seed=6, tilt=(0.0, 5.0, -5.0))
+            if r["margins"].min() > 2e-4:
+                break
+        r0 = ref_closed_loop(spec.make_cfg(**LOOP), w, scn, 14, seed=6, tilt=(0.0, 5.0, -5.0))
+        print(name, "scene", idx, "groups/step", r["n_groups"], "min race margin", r["margins"].min(), "veh-veh flags", r["coll"][..., 0].sum(),
+              "tokens that differ from the shipped cfg's rollout:", int((r0["tokens"] != r["tokens"]).sum()), "of", r["tokens"].size)
+        for k in ("tokens", "rtg_cont", "states", "coll", "actions", "n_groups", "margins"):
+            out[f"{name}_loop_{k}"] = r[k]
+        out[f"{name}_loop_recipe"] = np.array([23, idx, 9, 15, 40.0, 6, 0.0, 5.0, -5.0])
+        out[f"{name}_loop_tokens_shipped_cfg"] = r0["tokens"]
+    save("model_flags", **out)
 
 
 # --------------------------------------------------------------------------------------------- real-time (dense) rewards
@@ -1438,7 +1487,7 @@ def gen_dt_loop():
 ALL = dict(model=gen_model, model_trained=gen_model_trained, closed_loop_trained=gen_closed_loop_trained, closed_loop_wide_trained=gen_closed_loop_wide_trained, features=gen_features, sampling=gen_sampling, physics=gen_physics,
            collision=gen_collision, closed_loop=gen_closed_loop, closed_loop_full=gen_closed_loop_full, closed_loop_wide=gen_closed_loop_wide, metrics=gen_metrics, interesting=gen_interesting, preprocessed=gen_preprocessed, ingest_gt=gen_ingest_gt, state_dict=gen_state_dict, bicycle=gen_bicycle, contacts=gen_contacts,
            planner_adversary=gen_planner_adversary, ingest=gen_ingest,
-           variants=gen_variants, dense_reward=gen_dense_reward, dt_loop=gen_dt_loop, own_return=gen_own_return)
+           variants=gen_variants, dense_reward=gen_dense_reward, dt_loop=gen_dt_loop, own_return=gen_own_return, model_flags=gen_model_flags)
 
 if __name__ == "__main__":
     assert ref_shims.available(), "the reference tree is required to (re)generate golden vectors"

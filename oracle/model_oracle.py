@@ -159,7 +159,8 @@ def embed_tokens(w, data, dims):
             F.embedding(rtgs[..., 2], w["encoder.embed_rtg_road.weight"])], -1)
     r_emb = _linear(r_emb, w, "encoder.embed_rtg") + ts_emb + id_emb
     ex = exist.float()
-    s_emb, a_emb, r_emb = s_emb * ex, a_emb * ex, r_emb * ex
+    # cfg.model.no_actions (encoder.py:129-130): the action embeddings are multiplied by zeros instead of the existence mask
+    s_emb, a_emb, r_emb = s_emb * ex, a_emb * (torch.zeros_like(ex) if (getattr(dims, "FLAGS", 0) & 1) else ex), r_emb * ex
     init_emb = s_emb[:, 0]                                            # [B,A,D]
     init_exist = exist[:, 0, :, 0].bool()
     variant = getattr(dims, "VARIANT", 0)
@@ -197,9 +198,17 @@ def forward(w, data, dims, return_hidden=False):
           timesteps [B,A,T,1], road_points [B,P,NP,3], road_types [B,P,8]."""
     H = dims.H
     stacked, init_emb, init_exist = embed_tokens(w, data, dims)
-    seg, valid = map_encoder(w, data["road_points"], data["road_types"], H)
-    src = torch.cat([seg, init_emb], 1)
-    pad = ~torch.cat([valid, init_exist], 1)
+    flags = getattr(dims, "FLAGS", 0)
+    seg = None
+    if flags & 2:                                                     # use_map False (encoder.py:168-170): the initial states alone
+        src, pad = init_emb, ~init_exist
+    else:
+        seg, valid = map_encoder(w, data["road_points"], data["road_types"], H)
+        if flags & 4:                                                 # encode_initial_state False (encoder.py:163-166): the polylines alone
+            src, pad = seg, ~valid
+        else:
+            src = torch.cat([seg, init_emb], 1)
+            pad = ~torch.cat([valid, init_exist], 1)
     mem = src
     for i in range(dims.NE):
         mem = _enc_layer(mem, w, f"encoder.transformer_encoder.layers.{i}", H, pad)

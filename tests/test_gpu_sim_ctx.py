@@ -772,6 +772,60 @@ def test_attend_own_return_action_matches_reference_fixture():
     assert (g["loop_tokens"] != g["loop_tokens_default_mask"]).sum() > 0
 
 
+MODEL_FLAG_CASES = {"no_actions": {"model__no_actions": True}, "no_map": {"model__use_map": False},
+                    "no_init": {"model__encode_initial_state": False}, "no_actions_no_map": {"model__no_actions": True, "model__use_map": False}}
+
+
+@pytest.mark.parametrize("name", list(MODEL_FLAG_CASES))
+def test_model_flags_match_reference_fixture(name):
+    """cfg.model.no_actions = True / use_map = False / encode_initial_state = False (cfgs/model/base.yaml:4,10; ctrl_sim.yaml:9; modules/encoder.py:
+    18,84,129-130,155-170) on the HIP path (ctrlsim_dims.flags, round 6: action rows = LayerNorm(0); polyline / initial-state rows of the scene
+    memory key-padded — the same attention over the same keys as the reference's shorter concatenation): logits of both heads against the
+    reference Encoder / Decoder built with each cfg (tiny dims every token, loop dims the policy's slice), then — the three single switches —
+    the closed loop against the unmodified reference policy + real FreeCar / Box2D through compact contexts, the K/V-cached phase and the
+    window slide (tests/golden/model_flags.npz): tokens and flags identical, states within 1e-4.  A use_map = False checkpoint has no
+    encoder.map_encoder.* entries: the model is built from a state dict without them."""
+    from ctrlsim_amd.models.ctrl_sim import CtRLSim
+    from helpers import LOOP, TINY
+    g = golden("model_flags")
+    over = MODEL_FLAG_CASES[name]
+
+    def state_dict(cfg, d):
+        w = weights.generate(d, 0)
+        return {k: v for k, v in w.items() if "map_encoder." not in k} if not cfg.model.use_map else w
+
+    for tag, dims_over in (("tiny", TINY), ("loop", LOOP)):
+        cfg = spec.make_cfg(**dims_over, **over)
+        d = spec.Dims(cfg)
+        net = CtRLSim(cfg, state_dict(cfg, d), device=DEV)
+        for seed in (1, 2):
+            _, t_fill, n_ag, n_pl = [int(v) for v in g[f"{name}_{tag}_s{seed}_recipe"]]
+            inp = synth_inputs.random_context(d, seed, B=1, t_fill=t_fill, n_agents=n_ag, n_polys=n_pl)
+            if tag == "tiny":
+                out = net(synth_inputs.to_motion_data(inp), eval=True)
+                for head in ("action_preds", "rtg_preds"):
+                    np.testing.assert_allclose(out[head].cpu().numpy(), g[f"{name}_tiny_s{seed}_{head}"], atol=1e-4, rtol=0, err_msg=head)
+            else:
+                out = net(synth_inputs.to_motion_data(inp), eval=True, token_index=t_fill - 1)
+                for head in ("action_preds", "rtg_preds"):
+                    np.testing.assert_allclose(out[head][0].cpu().numpy(), g[f"{name}_loop_s{seed}_{head}"], atol=1e-4, rtol=0, err_msg=head)
+    if f"{name}_loop_recipe" not in g.files:
+        return
+    rc = g[f"{name}_loop_recipe"]
+    scn = scenarios.make_scenario(int(rc[0]), int(rc[1]), n_agents=int(rc[2]), n_polylines=int(rc[3]), n_points=d.NP, extent=float(rc[4]))
+    for lanes in (1, 2):
+        eng = RolloutEngine(cfg, state_dict(cfg, d), DEV, max_ctx=32, seed=int(rc[5]), tilt=tuple(float(v) for v in rc[6:9]), model=net.hip, lanes=lanes)
+        assert len(eng.sizes) > 1 and eng.use_cache                 # compact contexts and the K/V-cached phase stay on
+        eng.load_scenarios([scn, scn], steps=14)
+        r = eng.run(14).results()
+        for s_ in range(2):
+            assert np.array_equal(r["n_groups"][:, s_], g[f"{name}_loop_n_groups"])
+            assert np.array_equal(r["tokens"][s_][:, :14], g[f"{name}_loop_tokens"])
+            np.testing.assert_allclose(r["states"][s_], g[f"{name}_loop_states"], atol=1e-4, rtol=0)
+            assert np.array_equal(r["coll"][s_], g[f"{name}_loop_coll"])
+    assert (g[f"{name}_loop_tokens"] != g[f"{name}_loop_tokens_shipped_cfg"]).sum() > 0
+
+
 def test_kinematic_integrator_mode_matches_oracle():
     """mode 1 of ctrlsim_sim_step = Object::KinematicBicycleStep (object.cc:126-137; not what eval_sim.py runs — optional,
     SURVEY 8a S6): scripted actions vs the oracle's restatement, which holds the reference's own known answers

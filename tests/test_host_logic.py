@@ -211,8 +211,7 @@ def test_real_time_reward_policy_starts_from_the_preprocessed_rtgs():
                                               for i in range(2)}, goal, {0: 5.0, 1: 4.0}, gt, None)
 
 
-@pytest.mark.parametrize("key,value", [("use_map", False), ("encode_initial_state", False), ("no_actions", True),
-                                       ("ctg_plus_plus", True), ("hidden_dim", 128), ("num_heads", 4),
+@pytest.mark.parametrize("key,value", [("ctg_plus_plus", True), ("hidden_dim", 128), ("num_heads", 4),
                                        ("num_reward_components", 2), ("predict_rtg", False)])
 def test_model_layer_refuses_configurations_it_does_not_implement(key, value):
     """Round-5 review: the model layer accepted any cfg silently.  Every option of cfgs/model/base.yaml that changes the NETWORK and that the
@@ -242,6 +241,17 @@ def test_model_layer_accepts_the_shipped_configurations():
         spec.check_supported(spec.make_cfg(model__il=True, model__trajeglish=True))
     # cfg.model.attend_own_return_action (cfgs/model/base.yaml:15): built in round 6 for the CtRL-Sim tokens (mask mode 5, dims.variant 4);
     # with a baseline's token layout the reference's own mask code does not describe a network (utils/train_utils.py:114-129), so: refused
+    # no_actions / use_map / encode_initial_state (cfgs/model/base.yaml:4,10; ctrl_sim.yaml:9): built in round 6 as ctrlsim_dims.flags for the CtRL-Sim
+    # token layout; refused with a baseline layout, and the two scene switches together (the reference itself cannot build that model)
+    for over, flags in (({"no_actions": True}, 1), ({"use_map": False}, 2), ({"encode_initial_state": False}, 4), ({"no_actions": True, "use_map": False}, 3)):
+        c = spec.make_cfg(**{"model__" + k: v for k, v in over.items()})
+        spec.check_supported(c)
+        assert spec.Dims(c).FLAGS == flags and spec.model_flags(c) == flags
+    assert spec.Dims(spec.make_cfg()).FLAGS == 0
+    with pytest.raises(NotImplementedError, match="no scene memory"):
+        spec.check_supported(spec.make_cfg(model__use_map=False, model__encode_initial_state=False))
+    with pytest.raises(NotImplementedError, match="CtRL-Sim token layout only"):
+        spec.check_supported(spec.make_cfg(model__il=True, model__predict_rtg=False, model__predict_future_states=False, model__no_actions=True))
     spec.check_supported(spec.make_cfg(model__local_frame_predictions=True))      # a training-target switch: the same network (models/ctrl_sim.py:114,151)
     own = spec.make_cfg(model__attend_own_return_action=True)
     spec.check_supported(own)

@@ -453,6 +453,44 @@ def test_own_return_mask_oracles_match_reference():
     assert (g["loop_tokens"] != g["loop_tokens_default_mask"]).sum() > 0
 
 
+FLAG_CASES = {"no_actions": {"model__no_actions": True}, "no_map": {"model__use_map": False},
+              "no_init": {"model__encode_initial_state": False}, "no_actions_no_map": {"model__no_actions": True, "model__use_map": False}}
+
+
+@pytest.mark.parametrize("name", list(FLAG_CASES))
+def test_model_flag_oracles_match_reference(name):
+    """cfg.model.no_actions = True / use_map = False / encode_initial_state = False (cfgs/model/base.yaml:4,10; ctrl_sim.yaml:9; built in round 6):
+    the model oracle — which follows the reference's branches (modules/encoder.py:129-130,155-170), not the device's key-padding form — against
+    the reference Encoder / Decoder built with each cfg, and the rollout oracle against the unmodified reference policy + real FreeCar / Box2D
+    (tests/golden/model_flags.npz; the same scene under the shipped cfg gives other tokens)."""
+    g = golden("model_flags")
+    from helpers import TINY, LOOP
+    over = FLAG_CASES[name]
+    for tag, dims_over in (("tiny", TINY), ("loop", LOOP)):
+        cfg = spec.make_cfg(**dims_over, **over)
+        d = spec.Dims(cfg)
+        assert d.FLAGS
+        tw = mo.as_torch_weights(weights.generate(d, 0))
+        for seed in (1, 2):
+            _, t_fill, n_ag, n_pl = [int(v) for v in g[f"{name}_{tag}_s{seed}_recipe"]]
+            inp = synth_inputs.random_context(d, seed, B=1, t_fill=t_fill, n_agents=n_ag, n_polys=n_pl)
+            with torch.no_grad():
+                out = mo.forward(tw, synth_inputs.to_torch(inp), d)
+            for head in ("action_preds", "rtg_preds"):
+                got = out[head].numpy() if tag == "tiny" else out[head][0, :, t_fill - 1].numpy()
+                np.testing.assert_allclose(got, g[f"{name}_{tag}_s{seed}_{head}"], atol=2e-5, rtol=0)
+    if f"{name}_loop_recipe" not in g.files:
+        return
+    rc = g[f"{name}_loop_recipe"]
+    cfg = spec.make_cfg(**LOOP, **over)
+    d = spec.Dims(cfg)
+    scn = scenarios.make_scenario(int(rc[0]), int(rc[1]), n_agents=int(rc[2]), n_polylines=int(rc[3]), n_points=d.NP, extent=float(rc[4]))
+    r = rollout_oracle.RolloutOracle(cfg, weights.generate(d, 0), seed=int(rc[5]), tilt=tuple(float(v) for v in rc[6:9])).run(scn, 14, sim_libs.OracleSim)
+    assert np.array_equal(r["tokens"], g[f"{name}_loop_tokens"]) and np.array_equal(r["n_groups"], g[f"{name}_loop_n_groups"])
+    assert np.array_equal(r["states"], g[f"{name}_loop_states"]) and np.array_equal(r["coll"], g[f"{name}_loop_coll"])
+    assert (g[f"{name}_loop_tokens"] != g[f"{name}_loop_tokens_shipped_cfg"]).sum() > 0
+
+
 def test_inverse_bicycle_matches_reference():
     """G10: nocturne/bicycle_model.py:51-109 (log-replay actions)."""
     from ctrlsim_amd.kinematics import bicycle_backward
