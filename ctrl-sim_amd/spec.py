@@ -132,6 +132,9 @@ _FROZEN_MODEL_FLAGS = (
     ("hidden_dim", 256, "the kernels are built for 256-wide rows (csrc/common.h: DM)"),
     ("num_heads", 8, "the kernels are built for 8 heads of 32 (csrc/common.h: NHEAD, HD)"),
     ("num_reward_components", 3, "three return components per token (csrc/sample.hip)"),
+    ("map_attr", 3, "road points are (x, y, exist) rows (modules/map_encoder.py:18,41; csrc/map_encoder.hip)"),
+    ("num_road_types", 8, "one-hot road types of width 8 (modules/map_encoder.py:23; csrc/forward.hip: in_mlp<8>)"),
+    ("state_dim", 12, "state rows of 7 kinematic values + 5 type flags (modules/encoder.py:21; csrc/context.hip)"),
 )
 
 

@@ -212,7 +212,7 @@ def test_real_time_reward_policy_starts_from_the_preprocessed_rtgs():
 
 
 @pytest.mark.parametrize("key,value", [("ctg_plus_plus", True), ("hidden_dim", 128), ("num_heads", 4),
-                                       ("num_reward_components", 2), ("predict_rtg", False)])
+                                       ("num_reward_components", 2), ("predict_rtg", False), ("map_attr", 2), ("num_road_types", 6), ("state_dim", 10)])
 def test_model_layer_refuses_configurations_it_does_not_implement(key, value):
     """Round-5 review: the model layer accepted any cfg silently.  Every option of cfgs/model/base.yaml that changes the NETWORK and that the
     HIP path freezes is refused by name — by spec.check_supported, which HipModel and CtRLSim (constructor and
