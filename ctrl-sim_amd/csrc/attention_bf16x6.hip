@@ -28,6 +28,9 @@ namespace SPLIT_NS {
 #define ATT_PMAX 32768.0f     // row-sum bound of the speculative softmax path: every probability then fits the fp16 plane
 
 
+#ifndef ATT_PRIO
+#define ATT_PRIO 0           // 1: s_setprio 1 for waves 4-7 of the 8-wave kernels before the tile loop; 2: the softmax section at priority 1 (experiments)
+#endif
 #ifndef ATT_ALIGN_END
 #define ATT_ALIGN_END 0      // 1: the mask-table kernel's 256-query blocks end at the last row (the partial block is the FIRST one): see the kernel
 #endif
@@ -506,6 +509,11 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (RES ? 4 : (NW == 8 ?
   };
   if (DIR && n_it > 0) dir_fetch(0, 0);
   int cur = 0;
+#if ATT_PRIO == 1
+  // round-6 experiment (MI355X_MICROARCH.md, "static priority for the younger half"): the second-dispatched half of an 8-wave workgroup loses
+  // the VALU arbitration on every segment; one s_setprio before the loop, no per-segment flips
+  if (NW == 8 && !DIR && wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   for (int it = 0; it < n_it; ++it, cur = (cur + 1 == NBUF ? 0 : cur + 1)) {
     const bool more = it + 1 < n_it;
     const int nxt = cur + 1 == NBUF ? 0 : cur + 1;                       // buffer of tile it + 1
@@ -740,6 +748,9 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (RES ? 4 : (NW == 8 ?
       // on the base, the accumulators simply keep their scale.  The general path below (exact maximum, rescale) runs while
       // a query has no base yet and in the sub-tiles that fail the test — rare: moving the base at every new maximum sent
       // ~60 % of the sub-tiles of a 32-query wave through it (one of 32 queries sees a new maximum almost every time).
+#if ATT_PRIO == 2
+      if (!DIR) __builtin_amdgcn_s_setprio(1);       // experiment: the softmax (the VALU chain between the two MFMA chains) at raised priority
+#endif
       float psum = 0.f;
       bool general = __any(m_run[g] == NEG_INF);
       if (!general) {
@@ -790,6 +801,9 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (RES ? 4 : (NW == 8 ?
 #define PV(PA, PB)                                \
   oa[g] = MFMA_OP(v0f[PA], pf[0][PB], oa[g]);     \
   oa[g] = MFMA_OP(v1f[PA], pf[1][PB], oa[g]);
+#if ATT_PRIO == 2
+      if (!DIR) __builtin_amdgcn_s_setprio(0);
+#endif
       PROD_LIST(PV)
 #undef PV
       }
