@@ -28,6 +28,10 @@ namespace SPLIT_NS {
 #define ATT_PMAX 32768.0f     // row-sum bound of the speculative softmax path: every probability then fits the fp16 plane
 
 
+#ifndef ATT_DIRECT_STORE
+#define ATT_DIRECT_STORE 1   // 1 (round 6, default): every staged kernel stores its output rows straight from the accumulators (four 16-byte stores per
+#endif                       //    lane; a lane pair completes 32 contiguous bytes, the four stores a 128-byte line) instead of transposing them through
+                             //    LDS into sixteen 4-byte stores per lane: causal kernel -1.5 % (every class), rollout +0.25 % (four pairs)
 #ifndef ATT_PRIO
 #define ATT_PRIO 0           // 1: s_setprio 1 for waves 4-7 of the 8-wave kernels before the tile loop; 2: the softmax section at priority 1 (experiments)
 #endif
@@ -819,7 +823,7 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (RES ? 4 : (NW == 8 ?
     if (!DIR || MODE == MODE6_KEYPAD) __syncthreads();       // DIR: only the key-padding bias block goes through LDS
   }
 
-  // ---- normalise, transpose through LDS, store rows
+  // ---- normalise, store rows (ATT_DIRECT_STORE: from the accumulators; else, and for the one-wave streaming form, transposed through LDS)
 #pragma unroll
   for (int g = 0; g < QG; ++g) {
     float lr = l_run[g];
@@ -828,11 +832,11 @@ __global__ __launch_bounds__(DIR ? 64 : 64 * NW, DIR ? 3 : (RES ? 4 : (NW == 8 ?
       lr = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
     const float inv = lr > 0.f ? 1.0f / lr : 0.f;
-    if (RES) {
+    if (RES || (ATT_DIRECT_STORE && !DIR && !(ldo & 3))) {
       // straight from the accumulators: lane (query l31, half) holds d = 8 q + 4 half + (0..3) in registers 4 q .. 4 q + 3 — four 16-byte
       // stores into its query's row (a lane pair completes 32 contiguous bytes); the resident tiles leave no LDS for a transpose
-      const int gq = qb + wave * 32 + l31;
-      if (gq < Lq) {
+      const int gq = qb + (wave * QG + g) * 32 + l31;
+      if (gq >= 0 && gq < Lq) {
         float* orow = O + (size_t)b * o_batch_stride + (size_t)gq * ldo + h * HD + 4 * half;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
