@@ -47,8 +47,8 @@ def test_forward_matches_oracle(kind, B):
     w = weights.generate(d, 0)
     model = HipModel(cfg, w, DEV)
     tw = mo.as_torch_weights(w)
-    for seed, Tq in ((11, d.T), (12, max(1, d.T // 3)), (13, 1)):
-        inp = synth_inputs.random_context(d, seed, B=B, t_fill=Tq, n_agents=d.A - 1, n_polys=d.P - 1)
+    for seed, Tq in ((11, d.T), (12, max(1, d.T // 3)), (13, 1))[:1 if kind == "wide" else 3]:     # (wide: the full window only — the oracle's two
+        inp = synth_inputs.random_context(d, seed, B=B, t_fill=Tq, n_agents=d.A - 1, n_polys=d.P - 1)  #  6144-row forwards take ~10 s of CPU each)
         ti = Tq - 1
         rs = np.random.RandomState(seed)
         new_bins = rs.randint(0, d.R, (B, d.A, 3))

@@ -1004,23 +1004,23 @@ def test_rollout_of_a_scenario_does_not_depend_on_the_world_size():
 
 
 def test_wide_context_closed_loop_matches_oracle():
-    """SURVEY.md section 8(d), secondary (non-reference) interpretation: WIDE contexts — max_num_agents = 64 slots, so that all 20 vehicles of
+    """SURVEY.md section 8(d), secondary (non-reference) interpretation: WIDE contexts — max_num_agents = 40 slots here, so that all 16 vehicles of
     the scene sit in every context (the reference's greedy grouping still opens about log2(N) groups per step: its list-mutation quirk removes
-    every other in-context vehicle from the to-do list, autoregressive_policy.py:124-127) — through the whole engine (size classes up to 64
-    slots, mask tables at 192 tokens per step, K/V-cached phase, window slide at T = 8) against the oracle's closed loop under the same cfg:
-    tokens identical, states within 1e-4.
-    (The logits of the full-size wide context, L = 6144 rows and 512 polylines: test_gpu_model.py::test_forward_matches_oracle[wide].)"""
-    cfg = spec.make_cfg(dataset__waymo__max_num_agents=64, dataset__waymo__train_context_length=8, dataset__waymo__max_num_road_polylines=48,
+    every other in-context vehicle from the to-do list, autoregressive_policy.py:124-127) — through the whole engine (the 16 size classes spread
+    over 3..40 slots, mask tables at 120 tokens per step, K/V-cached phase, window slide at T = 8) against the oracle's closed loop under the same
+    cfg: tokens identical, states within 1e-4.
+    (The logits of the full-size wide context — 64 slots, L = 6144 rows, 512 polylines: test_gpu_model.py::test_forward_matches_oracle[wide].)"""
+    cfg = spec.make_cfg(dataset__waymo__max_num_agents=40, dataset__waymo__train_context_length=8, dataset__waymo__max_num_road_polylines=32,
                         dataset__waymo__max_num_road_pts_per_polyline=20, nocturne__steps=20)
     d = spec.Dims(cfg)
     w = weights.generate(d, 0)
-    scn = scenarios.make_scenario(83, 1, n_agents=20, n_polylines=30, n_points=d.NP, extent=30.0)
+    scn = scenarios.make_scenario(83, 1, n_agents=16, n_polylines=24, n_points=d.NP, extent=30.0)
     steps = 9
     o = rollout_oracle.RolloutOracle(cfg, w, seed=9, tilt=(5.0, 0.0, -5.0)).run(scn, steps, sim_libs.OracleSim)
-    assert (o["n_groups"] >= 3).all() and (o["n_groups"] <= 8).all()          # ~log2(20): every context holds all 20 vehicles
+    assert (o["n_groups"] >= 3).all() and (o["n_groups"] <= 8).all()          # ~log2(16): every context holds all 16 vehicles
     for lanes in (1, 2):
         eng = RolloutEngine(cfg, w, DEV, max_ctx=8, seed=9, tilt=(5.0, 0.0, -5.0), lanes=lanes)
-        assert eng.sizes[-1] == 64 and len(eng.sizes) > 1
+        assert eng.sizes[-1] == 40 and len(eng.sizes) == 16
         eng.load_scenarios([scn, scn, scn], steps=steps)
         r = eng.run(steps).results()
         for s_ in range(3):
