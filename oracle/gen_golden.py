@@ -1296,7 +1296,8 @@ def gen_own_return():
 
 MODEL_FLAG_CASES = {"no_actions": {"model__no_actions": True}, "no_map": {"model__use_map": False},
                     "no_init": {"model__encode_initial_state": False},
-                    "no_actions_no_map": {"model__no_actions": True, "model__use_map": False}}
+                    "no_actions_no_map": {"model__no_actions": True, "model__use_map": False},
+                    "own_return_no_init": {"model__attend_own_return_action": True, "model__encode_initial_state": False}}
 
 
 def gen_model_flags():
@@ -1320,7 +1321,7 @@ def gen_model_flags():
                     v = r[head].detach().numpy()
                     out[f"{name}_{tag}_s{seed}_{head}"] = v if tag == "tiny" else v[0, :, t_fill - 1]
                 out[f"{name}_{tag}_s{seed}_recipe"] = np.array([seed, t_fill, d.A - 1, d.P - 1])
-        if "_no_" in name[3:]:
+        if name in ("no_actions_no_map", "own_return_no_init"):      # combinations: logits only
             continue
         cfg = spec.make_cfg(**LOOP, **over)
         d = spec.Dims(cfg)

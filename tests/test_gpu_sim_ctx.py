@@ -773,7 +773,8 @@ def test_attend_own_return_action_matches_reference_fixture():
 
 
 MODEL_FLAG_CASES = {"no_actions": {"model__no_actions": True}, "no_map": {"model__use_map": False},
-                    "no_init": {"model__encode_initial_state": False}, "no_actions_no_map": {"model__no_actions": True, "model__use_map": False}}
+                    "no_init": {"model__encode_initial_state": False}, "no_actions_no_map": {"model__no_actions": True, "model__use_map": False},
+                    "own_return_no_init": {"model__attend_own_return_action": True, "model__encode_initial_state": False}}
 
 
 @pytest.mark.parametrize("name", list(MODEL_FLAG_CASES))
